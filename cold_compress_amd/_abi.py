@@ -1,0 +1,118 @@
+"""ctypes binding of the C ABI declared in include/coldcompress.h.
+
+The product path has NO CPU fallback: `lib()` raises if `libcoldcompress_hip.so` has not been built
+(`python -c "import __graft_entry__ as g; g.build()"`), and every wrapper raises `ColdCompressError` on a
+non-zero return code.  The same signature table binds the CPU oracle (`oracle/oracle_lib.py`, `_cpu`
+suffix) for tests — the oracle is never imported from here.
+"""
+import ctypes as C
+import os
+
+CC_OK = 0
+CC_DT_F32, CC_DT_BF16, CC_DT_F16 = 0, 1, 2
+CC_PRIO_F32, CC_PRIO_BF16, CC_PRIO_F16, CC_PRIO_I64 = 0, 1, 2, 3
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libcoldcompress_hip.so")
+
+
+class ColdCompressError(RuntimeError):
+    pass
+
+
+class KVView(C.Structure):
+    """struct cc_kv_view (include/coldcompress.h)."""
+
+    _fields_ = [
+        ("k_cache", C.c_void_p),
+        ("v_cache", C.c_void_p),
+        ("pos", C.c_void_p),
+        ("mask", C.c_void_p),
+        ("cache_cts", C.c_void_p),
+        ("H", C.c_int32),
+        ("Hp", C.c_int32),
+        ("Hc", C.c_int32),
+        ("S", C.c_int32),
+        ("D", C.c_int32),
+        ("dtype", C.c_int32),
+    ]
+
+
+_vp, _i32, _f32, _sz = C.c_void_p, C.c_int32, C.c_float, C.c_size_t
+_view = C.POINTER(KVView)
+
+# name -> (restype, argtypes); one row per declaration in include/coldcompress.h
+SIGNATURES = {
+    "cc_abi_version": (C.c_int, []),
+    "cc_error_string": (C.c_char_p, [C.c_int]),
+    "cc_device_info": (C.c_int, [_vp, _vp, _vp, C.c_char_p, C.c_int]),
+    "cc_decode_update_full": (C.c_int, [_view, _vp, _vp, _vp, _vp, _vp]),
+    "cc_decode_update_recent_global": (C.c_int, [_view, _vp, _vp, _vp, _i32, _vp, _vp]),
+    "cc_decode_update_scores": (C.c_int, [_view, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp]),
+    "cc_decode_update_random": (C.c_int, [_view, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp]),
+    "cc_decode_update_l2_workspace_bytes": (_sz, [_i32, _i32]),
+    "cc_decode_update_l2": (C.c_int, [_view, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _sz, _vp]),
+    "cc_decode_update_heavy_hitter": (C.c_int, [_view, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp]),
+    "cc_hh_update": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "cc_decode_attn_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32, _i32]),
+    "cc_decode_attn_gqa": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp,
+                                     _vp, _vp, _vp, _vp, _sz, _vp]),
+    "cc_prefill_fill": (C.c_int, [_view, _vp, _vp, _vp, _i32, _i32, _vp]),
+    "cc_row_l2_norm": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "cc_topk_keep_workspace_bytes": (_sz, [_i32, _i32, _i32]),
+    "cc_topk_keep": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _sz, _vp]),
+    "cc_gather_rows": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "cc_gather_vec": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "cc_snapkv_priority": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "cc_prefill_attn_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32, _i32]),
+    "cc_prefill_attn": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _i32, _vp,
+                                  _sz, _vp]),
+    "cc_attn_colsum": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "cc_colsum_to_mean": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
+}
+
+# entry points that only the device library has (no `_cpu` twin)
+DEVICE_ONLY = {"cc_error_string", "cc_device_info"}
+
+
+def bind(cdll, suffix=""):
+    """Attach restype/argtypes for every ABI symbol; raises AttributeError if one is missing."""
+    fns = {}
+    for name, (res, args) in SIGNATURES.items():
+        if suffix and name in DEVICE_ONLY:
+            continue
+        fn = getattr(cdll, name + suffix)
+        fn.restype = res
+        fn.argtypes = args
+        fns[name] = fn
+    return fns
+
+
+_LIB = None
+_FNS = None
+
+
+def lib():
+    """The device library's bound functions; raises loudly when it has not been built."""
+    global _LIB, _FNS
+    if _FNS is None:
+        if not os.path.exists(LIB_PATH):
+            raise ColdCompressError(
+                f"{LIB_PATH} not found: build the HIP extension first "
+                "(python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
+        _LIB = C.CDLL(LIB_PATH)
+        _FNS = bind(_LIB)
+        v = _FNS["cc_abi_version"]()
+        if v != 1:
+            raise ColdCompressError(f"ABI version mismatch: library {v}, python 1")
+    return _FNS
+
+
+def check(code, what):
+    if code != CC_OK:
+        msg = lib()["cc_error_string"](code)
+        raise ColdCompressError(f"{what} failed: {code} ({msg.decode() if msg else '?'})")
+
+
+def call(name, *args):
+    check(lib()[name](*args), name)

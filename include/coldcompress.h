@@ -1,0 +1,231 @@
+/*
+ * coldcompress.h — C ABI of the MI355X-native KV-cache eviction + pruned-cache attention path.
+ *
+ * This is the drop-in boundary.  The reference (AnswerDotAI/cold-compress) has no
+ * FFI of its own: its boundary is the Python class surface in cache.py / attention_utils.py /
+ * prompt_compression.py.  The Python mirror of that surface lives in cold_compress_amd/ and reaches the
+ * device ONLY through the entry points declared here (ctypes, see cold_compress_amd/_abi.py and
+ * INTEGRATION.md).  Each entry point cites the reference code it replaces as
+ * "ref: <file>:<lines>" (paths relative to the reference checkout).
+ *
+ * Conventions
+ *  - Every pointer is a DEVICE pointer (HBM) unless stated otherwise.  Batch is 1 (ref: model.py:188-189).
+ *  - `stream` is a hipStream_t passed as void*.  No entry point synchronises the stream, allocates or
+ *    frees memory; scratch is supplied by the caller (torch's caching allocator) and sized by the
+ *    matching *_workspace_bytes() query.  All entry points are hipGraph-capturable.
+ *  - Return value: CC_OK (0) or a negative CC_ERR_* code.  Nothing throws.
+ *  - `input_pos` for decode is a device int32[1] (the reference's decode `input_pos` tensor,
+ *    generation_utils.py:482) so that captured graphs replay with an advancing position.
+ *  - Arg-min rule everywhere: lowest slot index wins ties, NaN counts as the minimum (torch.argmin).
+ *  - dtype codes: element type of K/V/q/probabilities ("model dtype" in the reference).
+ *
+ * The CPU oracle (oracle/cc_oracle.c) exports the same functions with a `_cpu` suffix and identical
+ * signatures taking HOST pointers; it is test infrastructure only.
+ */
+#ifndef COLDCOMPRESS_H
+#define COLDCOMPRESS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CC_ABI_VERSION 1
+
+#define CC_OK 0
+#define CC_ERR_BAD_ARG (-1)      /* null pointer / non-positive size / inconsistent shape           */
+#define CC_ERR_UNSUPPORTED (-2)  /* dtype / head_dim / window size the kernels are not built for     */
+#define CC_ERR_HIP (-3)          /* hipGetLastError() != hipSuccess after a launch                   */
+#define CC_ERR_WORKSPACE (-4)    /* workspace too small                                              */
+
+#define CC_DT_F32 0
+#define CC_DT_BF16 1
+#define CC_DT_F16 2
+
+/* priority dtypes for cc_topk_keep (prompt compaction) */
+#define CC_PRIO_F32 0
+#define CC_PRIO_BF16 1
+#define CC_PRIO_F16 2
+#define CC_PRIO_I64 3
+
+typedef void* cc_stream_t;
+
+/* View of one layer's cache buffers; mirrors the nn.Module buffers of ref: cache.py:178-227.
+ *   k_cache, v_cache : [H, S, D] model dtype           (cache.py:185-201)
+ *   pos              : [Hp, S] int32, -1 = empty slot; Hp = H if head_specific else 1 (cache.py:207-218)
+ *   mask             : [H, S] bool (1 byte)            (cache.py:226-227)
+ *   cache_cts        : [Hc] int32; Hc = H if variable_length else 1 (cache.py:219-222)
+ */
+typedef struct cc_kv_view {
+  void* k_cache;
+  void* v_cache;
+  int32_t* pos;
+  uint8_t* mask;
+  int32_t* cache_cts;
+  int32_t H;
+  int32_t Hp;
+  int32_t Hc;
+  int32_t S;
+  int32_t D;
+  int32_t dtype;
+} cc_kv_view;
+
+int cc_abi_version(void);
+const char* cc_error_string(int code);
+/* Device properties of the current HIP device (host ints out); used by bench.py / DESIGN numbers. */
+int cc_device_info(int* n_cu, int* wave_size, int* lds_bytes_per_cu, char* name, int name_len);
+
+/* ------------------------------------------------------------------------------------------------
+ * Decode-time update_kv: choose the slot to overwrite, then insert the new token in place.
+ * ref: KVCache.update_kv cache.py:314-340 -> _decoding_update :348-364 -> _eviction_idx + _fill.
+ *
+ * Common behaviour (Appendix A of SURVEY.md):
+ *   idx[h] chosen per policy; num_ins[h] = (pos[h or 0][idx]== -1); then
+ *   pos[.,idx] <- *input_pos; K[h,idx,:] <- k_new[h,:]; V likewise; mask[h,idx] <- 1;
+ *   cache_cts[j] += num_ins[j] for j < Hc                     (cache.py:330, 356-362, 390-401, 460-490)
+ * k_new/v_new: [H, D] model dtype.  idx_out: int64 [Hp] (what _eviction_idx returns).
+ * If k_new == NULL the call is "select only": idx_out is produced (plus the policy's own side effects,
+ * e.g. heavy-hitter history zeroing, which the reference performs inside _eviction_idx) and nothing is
+ * inserted.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* ref: KVCacheFull._eviction_idx cache.py:500-502 — argmin over pos (first empty slot). Hp must be 1. */
+int cc_decode_update_full(const cc_kv_view* c, const void* k_new, const void* v_new,
+                          const int32_t* input_pos, int64_t* idx_out, cc_stream_t stream);
+
+/* ref: KVCacheRecentGlobal._eviction_idx cache.py:552-556 — g + argmin(pos[g:]). Hp must be 1. */
+int cc_decode_update_recent_global(const cc_kv_view* c, const void* k_new, const void* v_new,
+                                   const int32_t* input_pos, int32_t global_tokens, int64_t* idx_out,
+                                   cc_stream_t stream);
+
+/* Generic base path for caller-supplied importances.
+ * ref: KVCache._eviction_idx cache.py:366-379 — scores[:, :g]=+inf; pos==-1 -> -inf; argmin.
+ * scores: [Hs, S] of score_dtype (CC_DT_*), Hs = Hp or 1 (a 1-D score vector is broadcast like
+ * scores.unsqueeze(0), cache.py:369-370, and then Hp must be 1).  Scores are NOT modified. */
+int cc_decode_update_scores(const cc_kv_view* c, const void* k_new, const void* v_new,
+                            const int32_t* input_pos, const void* scores, int32_t score_dtype,
+                            int32_t global_tokens, int64_t* idx_out, cc_stream_t stream);
+
+/* ref: KVCacheRandom._token_importances cache.py:519-524 + base _eviction_idx :366-379.
+ * rand_u: [S] f32 uniform [0,1) drawn by the caller (the RNG stream is backend-specific; parity is
+ * defined given this vector).  pos[s] >= *input_pos - recent_window -> +inf. Hp must be 1. */
+int cc_decode_update_random(const cc_kv_view* c, const void* k_new, const void* v_new,
+                            const int32_t* input_pos, const float* rand_u, int32_t global_tokens,
+                            int32_t recent_window, int64_t* idx_out, cc_stream_t stream);
+
+/* ref: KVCacheL2 cache.py:580-605 — score = dtype(max(key_norm) - key_norm) with the max taken over
+ * ALL heads and slots, recent window -> +inf, then base rules; on insert key_norm[h,idx] <- ||k_new[h]||2
+ * (fp32 accumulate, rounded to model dtype).  key_norm: [H, S] model dtype.  Hp must be H.
+ * workspace: cc_decode_update_l2_workspace_bytes(H,S) bytes. */
+size_t cc_decode_update_l2_workspace_bytes(int32_t H, int32_t S);
+int cc_decode_update_l2(const cc_kv_view* c, const void* k_new, const void* v_new,
+                        const int32_t* input_pos, void* key_norm, int32_t global_tokens,
+                        int32_t recent_window, int64_t* idx_out, void* workspace, size_t workspace_bytes,
+                        cc_stream_t stream);
+
+/* ref: KVCacheHeavyHitter._eviction_idx cache.py:725-765 (history_window_size W == 1, float64 history).
+ *   avg = f32(num) / f32(max(denom,1));  (pos<g)|(pos>=p-w) -> 1.0;  pos==-1 -> 0.0;  argmin;
+ *   num[h,idx] <- 0; denom[h,idx] <- 0; then the common insert.
+ * num: [H, S] float64; denom: [H, S] int32.  Hp must be H. */
+int cc_decode_update_heavy_hitter(const cc_kv_view* c, const void* k_new, const void* v_new,
+                                  const int32_t* input_pos, double* num, int32_t* denom,
+                                  int32_t global_tokens, int32_t recent_window, int64_t* idx_out,
+                                  cc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Heavy-hitter history update.  ref: KVCacheHeavyHitter.update_state cache.py:690-723 (W == 1).
+ *   num[h,s] += (double)attn[h,s] for s < T (zero padding to S beyond T); denom[h,s] += 1 for ALL s;
+ *   *counter += 1.  attn: [H, T] model dtype, already averaged over the query group.
+ * ---------------------------------------------------------------------------------------------- */
+int cc_hh_update(double* num, int32_t* denom, int64_t* counter, const void* attn, int32_t H, int32_t S,
+                 int32_t T, int32_t dtype, cc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Decode attention over the pruned cache, GQA-aware (K/V read once, no repeat_interleave).
+ * ref: model.py:395-418 + attention_utils.py:27-54.
+ *   q: [HQ, D]; k,v: [H, S, D]; mask: [H, S] bool or NULL; R = HQ/H; query head j uses kv head j/R.
+ *   score = dtype(dtype(q.k) * scale) (+ -inf where mask==0); P = dtype(softmax_fp32(score));
+ *   y[HQ, D] = dtype(sum_s P*v);  probs_out[HQ, S] = P (optional, may be NULL);
+ *   attn_out[H, S] = dtype(mean over the R heads of the group of P) (optional, may be NULL).
+ * For CC_DT_F32 the "dtype()" roundings are identities.
+ * If hh_num != NULL the heavy-hitter history update (cc_hh_update with T = S) is fused into the
+ * combine pass: hh_num += attn_out, hh_denom += 1, *hh_counter += 1.
+ * ---------------------------------------------------------------------------------------------- */
+size_t cc_decode_attn_workspace_bytes(int32_t HQ, int32_t H, int32_t S, int32_t D, int32_t dtype);
+int cc_decode_attn_gqa(const void* q, const void* k, const void* v, const uint8_t* mask, int32_t HQ,
+                       int32_t H, int32_t S, int32_t D, int32_t dtype, float scale, void* y,
+                       void* attn_out, void* probs_out, double* hh_num, int32_t* hh_denom,
+                       int64_t* hh_counter, void* workspace, size_t workspace_bytes,
+                       cc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Prefill-time cache fill.  ref: KVCache._prefill_update / _fill_contiguous cache.py:381-401.
+ *   slots 0..T-1 of every head <- k_val/v_val rows; pos[hp, t] <- pos_val[min(hp,PH-1), t] (int32 cast);
+ *   mask[h, t] <- 1; cache_cts[j] += T.
+ * k_val, v_val: [H, T, D] contiguous; pos_val: int64 [PH, T] with PH == 1 or PH == Hp.
+ * ---------------------------------------------------------------------------------------------- */
+int cc_prefill_fill(const cc_kv_view* c, const void* k_val, const void* v_val, const int64_t* pos_val,
+                    int32_t PH, int32_t T, cc_stream_t stream);
+
+/* Row L2 norms.  ref: KVCacheL2.update_state cache.py:607-612; PromptCompressorL2 prompt_compression.py:201-203.
+ * x: [H, N, D] dtype -> out[H, N] dtype = dtype(sqrt(sum_d x^2)) (fp32 accumulate); negate != 0 -> -norm. */
+int cc_row_l2_norm(const void* x, int32_t H, int32_t N, int32_t D, int32_t dtype, int32_t negate,
+                   void* out, cc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Prompt compaction.  ref: PromptCompressor._keep_idxs prompt_compression.py:21-26 and
+ * _filter_kv :69-72 / :82-88.
+ * cc_topk_keep: keep[hs, 0..K) = ascending-sorted indices of the K largest priorities of row hs.
+ *   Ties at the K-th value are broken lowest-index-first (torch's CPU order there is
+ *   implementation-defined; see DESIGN.md "top-k tie contract").  NaN ranks above +inf (torch.topk).
+ *   priority: [Hs, L] of prio_dtype (CC_PRIO_*).  keep_out: int64 [Hs, K].
+ * cc_gather_rows: dst[h, j, :] = src[h, keep[min(h,Hk-1), j], :]; src [H, L, D], dst [H, K, D].
+ * ---------------------------------------------------------------------------------------------- */
+size_t cc_topk_keep_workspace_bytes(int32_t Hs, int32_t L, int32_t K);
+int cc_topk_keep(const void* priority, int32_t prio_dtype, int32_t Hs, int32_t L, int32_t K,
+                 int64_t* keep_out, void* workspace, size_t workspace_bytes, cc_stream_t stream);
+int cc_gather_rows(const void* src, const int64_t* keep, int32_t Hk, int32_t H, int32_t L, int32_t K,
+                   int32_t D, int32_t dtype, void* dst, cc_stream_t stream);
+/* dst[hs, j] = src[hs, keep[hs, j]] for a [Hs, L] vector of `dtype` (cumulative-attention gather,
+ * ref: PromptCompressorHeavyHitter._update_state prompt_compression.py:189-194). */
+int cc_gather_vec(const void* src, const int64_t* keep, int32_t Hs, int32_t L, int32_t K, int32_t dtype,
+                  void* dst, cc_stream_t stream);
+
+/* SnapKV priority.  ref: PromptCompressorHeavyHitter._token_importances prompt_compression.py:170-187.
+ *   obs_mean: [H, L] dtype = mean over the last min(16,L) query rows of the group-averaged probabilities.
+ *   out[h,t] = dtype(avgpool5(obs_mean)[h,t]) (pad 2, count_include_pad=False);
+ *   t >= L-obs_len -> 1.0; t < global_tokens -> 1.0. */
+int cc_snapkv_priority(const void* obs_mean, int32_t H, int32_t L, int32_t dtype, int32_t obs_len,
+                       int32_t global_tokens, void* out, cc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Prefill attention with the side outputs the eviction policies need, without materialising [HQ,L,L].
+ * ref: attention_utils.py:36-54 (naive path, causal mask) + model.py:413-418 (group mean) +
+ *      cache.py:704 / prompt_compression.py:170-173,189-192 (column mean, observation-window mean).
+ *   q: [HQ, L, D]; k, v: [H, L, D]; causal.  y: [HQ, L, D] dtype.
+ *   colsum_out [H, L] f32 (optional): sum over queries of the group-averaged dtype-rounded probabilities.
+ *   obs_out    [H, L] f32 (optional): mean over the last obs_len queries of the same.
+ * ---------------------------------------------------------------------------------------------- */
+size_t cc_prefill_attn_workspace_bytes(int32_t HQ, int32_t H, int32_t L, int32_t D, int32_t dtype);
+int cc_prefill_attn(const void* q, const void* k, const void* v, int32_t HQ, int32_t H, int32_t L,
+                    int32_t D, int32_t dtype, float scale, void* y, float* colsum_out, float* obs_out,
+                    int32_t obs_len, void* workspace, size_t workspace_bytes, cc_stream_t stream);
+
+/* Column sums of a materialised attention tensor (API-compat path when a caller hands the reference's
+ * own [H, L, L] probabilities).  ref: cache.py:704.  out[h,k] = sum_q attn[h,q,k] (fp32 accumulate). */
+int cc_attn_colsum(const void* attn, int32_t H, int32_t Lq, int32_t Lk, int32_t dtype, float* out,
+                   cc_stream_t stream);
+
+/* Column mean used by the heavy-hitter prefill state and the SnapKV state.
+ * ref: cache.py:704 and prompt_compression.py:191: `attn.sum(dim=2) / (seq_len - input_pos)` on a
+ * model-dtype tensor: out[h,t] = dtype( dtype(colsum[h,t]) / (float)(L - input_pos[t]) ).
+ * input_pos: int64 [L] or NULL (= arange(L), what prefill always passes, generation_utils.py:462). */
+int cc_colsum_to_mean(const float* colsum, const int64_t* input_pos, int32_t H, int32_t L, int32_t dtype,
+                      void* out, cc_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COLDCOMPRESS_H */

@@ -1,0 +1,662 @@
+/*
+ * cc_oracle.c — CPU ORACLE for the cold-compress hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * A plain-C restatement of the reference's algorithms (AnswerDotAI/cold-compress @ 2024-10-22), one
+ * function per entry point of include/coldcompress.h, exported with a `_cpu` suffix and taking HOST
+ * pointers.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library,
+ * and only as the checker / the timed CPU baseline — never as a fallback for the product path.
+ *
+ * Parity pinning: every function here is checked against golden vectors captured by importing the
+ * reference itself (oracle/gen_golden.py -> tests/golden/ *.npz; tests/test_oracle_golden.py).
+ * The reference has no tests or vectors of its own.
+ *
+ * Each function cites the reference lines it restates ("ref:" = path under the reference checkout).
+ * Arithmetic notes that matter for bit-exactness are called out inline.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/coldcompress.h"
+
+/* ---------------------------------------------------------------- element types ------------------ */
+
+static inline float bf16_to_f32(uint16_t h) {
+  uint32_t u = (uint32_t)h << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+/* round-to-nearest-even, NaN preserved as quiet NaN (matches c10::BFloat16 round_to_nearest_even) */
+static inline uint16_t f32_to_bf16(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return 0x7fc0;
+  uint32_t lsb = (u >> 16) & 1u;
+  u += 0x7fffu + lsb;
+  return (uint16_t)(u >> 16);
+}
+
+static inline float f16_to_f32(uint16_t h) {
+  uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+  uint32_t exp = (h >> 10) & 0x1fu;
+  uint32_t man = h & 0x3ffu;
+  uint32_t u;
+  if (exp == 0) {
+    if (man == 0) {
+      u = sign;
+    } else { /* subnormal */
+      int e = -1;
+      do {
+        man <<= 1;
+        e++;
+      } while (!(man & 0x400u));
+      man &= 0x3ffu;
+      u = sign | ((uint32_t)(127 - 15 - e) << 23) | (man << 13);
+    }
+  } else if (exp == 31) {
+    u = sign | 0x7f800000u | (man << 13);
+  } else {
+    u = sign | ((exp + 112u) << 23) | (man << 13);
+  }
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+static inline uint16_t f32_to_f16(float f) {
+  uint32_t x;
+  memcpy(&x, &f, 4);
+  uint32_t sign = (x >> 16) & 0x8000u;
+  x &= 0x7fffffffu;
+  if (x > 0x7f800000u) return (uint16_t)(sign | 0x7e00u);
+  if (x >= 0x47800000u) return (uint16_t)(sign | 0x7c00u); /* overflow -> inf (>= 65520 rounds to inf) */
+  if (x >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);
+  if (x < 0x33000001u) return (uint16_t)sign; /* underflow to zero (<= 2^-25) */
+  uint32_t e = x >> 23;
+  uint32_t m = (x & 0x7fffffu) | 0x800000u;
+  uint32_t r;
+  if (e < 113) { /* subnormal half */
+    uint32_t shift = 126 - e; /* 14..24 */
+    uint32_t halfm = m >> shift;
+    uint32_t rem = m & ((1u << shift) - 1u);
+    uint32_t half = 1u << (shift - 1);
+    if (rem > half || (rem == half && (halfm & 1u))) halfm++;
+    r = halfm;
+  } else {
+    uint32_t halfm = ((e - 112) << 10) | ((m & 0x7fffffu) >> 13);
+    uint32_t rem = m & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (halfm & 1u))) halfm++;
+    r = halfm;
+  }
+  return (uint16_t)(sign | r);
+}
+
+static inline size_t dt_size(int dt) { return dt == CC_DT_F32 ? 4 : 2; }
+
+static inline float ld(const void* p, int dt, size_t i) {
+  switch (dt) {
+    case CC_DT_F32: return ((const float*)p)[i];
+    case CC_DT_BF16: return bf16_to_f32(((const uint16_t*)p)[i]);
+    default: return f16_to_f32(((const uint16_t*)p)[i]);
+  }
+}
+
+/* round a float to the model dtype and back ("dtype(x)" in the header comments) */
+static inline float rnd(float x, int dt) {
+  switch (dt) {
+    case CC_DT_F32: return x;
+    case CC_DT_BF16: return bf16_to_f32(f32_to_bf16(x));
+    default: return f16_to_f32(f32_to_f16(x));
+  }
+}
+
+static inline void st(void* p, int dt, size_t i, float x) {
+  switch (dt) {
+    case CC_DT_F32: ((float*)p)[i] = x; break;
+    case CC_DT_BF16: ((uint16_t*)p)[i] = f32_to_bf16(x); break;
+    default: ((uint16_t*)p)[i] = f32_to_f16(x); break;
+  }
+}
+
+static int dt_ok(int dt) { return dt == CC_DT_F32 || dt == CC_DT_BF16 || dt == CC_DT_F16; }
+
+/* ---------------------------------------------------------------- arg-min ------------------------ */
+
+/* torch.argmin over a float row: first index of the minimum, NaN counts as the minimum (first NaN
+ * wins) — ref: ATen reduce min with index; probed in SURVEY.md §7. */
+static int64_t argmin_f32(const float* x, int n) {
+  int64_t best = 0;
+  float bv = x[0];
+  if (bv != bv) return 0;
+  for (int i = 1; i < n; i++) {
+    float v = x[i];
+    if (v != v) return i;
+    if (v < bv) {
+      bv = v;
+      best = i;
+    }
+  }
+  return best;
+}
+
+static int64_t argmin_i32(const int32_t* x, int n) {
+  int64_t best = 0;
+  for (int i = 1; i < n; i++)
+    if (x[i] < x[best]) best = i;
+  return best;
+}
+
+static int view_ok(const cc_kv_view* c) {
+  return c && c->k_cache && c->v_cache && c->pos && c->mask && c->cache_cts && c->H > 0 && c->S > 0 &&
+         c->D > 0 && (c->Hp == 1 || c->Hp == c->H) && (c->Hc == 1 || c->Hc == c->H) && dt_ok(c->dtype);
+}
+
+/* ref: _decoding_update cache.py:356-362 (num_insertions from the OLD pos), KVCacheHeadConstant._fill
+ * :436-437 -> _fill_contiguous :390-401, KVCacheHeadSpecific._fill :460-490, update_kv :330. */
+static void insert_token(const cc_kv_view* c, const void* k_new, const void* v_new, int32_t p,
+                         const int64_t* idx) {
+  const size_t es = dt_size(c->dtype);
+  int32_t num_ins[4096];
+  for (int hp = 0; hp < c->Hp; hp++) num_ins[hp] = (c->pos[(size_t)hp * c->S + idx[hp]] == -1);
+  for (int hp = 0; hp < c->Hp; hp++) c->pos[(size_t)hp * c->S + idx[hp]] = p;
+  for (int h = 0; h < c->H; h++) {
+    int64_t i = idx[c->Hp == 1 ? 0 : h];
+    memcpy((char*)c->k_cache + ((size_t)h * c->S + i) * c->D * es, (const char*)k_new + (size_t)h * c->D * es,
+           c->D * es);
+    memcpy((char*)c->v_cache + ((size_t)h * c->S + i) * c->D * es, (const char*)v_new + (size_t)h * c->D * es,
+           c->D * es);
+    c->mask[(size_t)h * c->S + i] = 1;
+  }
+  /* cache_cts += num_insertions[:len(cache_cts)] with broadcasting when num_insertions has 1 element */
+  for (int j = 0; j < c->Hc; j++) c->cache_cts[j] += num_ins[c->Hp == 1 ? 0 : j];
+}
+
+int cc_abi_version_cpu(void) { return CC_ABI_VERSION; }
+
+/* ref: KVCacheFull._eviction_idx cache.py:500-502 */
+int cc_decode_update_full_cpu(const cc_kv_view* c, const void* k_new, const void* v_new,
+                              const int32_t* input_pos, int64_t* idx_out, cc_stream_t stream) {
+  (void)stream;
+  if (!view_ok(c) || !input_pos || !idx_out || c->Hp != 1 || c->H > 4096) return CC_ERR_BAD_ARG;
+  idx_out[0] = argmin_i32(c->pos, c->S);
+  if (k_new) insert_token(c, k_new, v_new, *input_pos, idx_out);
+  return CC_OK;
+}
+
+/* ref: KVCacheRecentGlobal._eviction_idx cache.py:552-556 */
+int cc_decode_update_recent_global_cpu(const cc_kv_view* c, const void* k_new, const void* v_new,
+                                       const int32_t* input_pos, int32_t g, int64_t* idx_out,
+                                       cc_stream_t stream) {
+  (void)stream;
+  if (!view_ok(c) || !input_pos || !idx_out || c->Hp != 1 || g < 0 || g >= c->S || c->H > 4096)
+    return CC_ERR_BAD_ARG;
+  idx_out[0] = argmin_i32(c->pos + g, c->S - g) + g;
+  if (k_new) insert_token(c, k_new, v_new, *input_pos, idx_out);
+  return CC_OK;
+}
+
+/* ref: KVCache._eviction_idx cache.py:366-379 applied to one row of scores */
+static int64_t base_evict_row(float* sc, const int32_t* pos, int S, int g) {
+  for (int s = 0; s < g && s < S; s++) sc[s] = INFINITY; /* :373 protects the first g SLOTS */
+  for (int s = 0; s < S; s++)
+    if (pos[s] == -1) sc[s] = -INFINITY; /* :376 */
+  return argmin_f32(sc, S);               /* :379 */
+}
+
+int cc_decode_update_scores_cpu(const cc_kv_view* c, const void* k_new, const void* v_new,
+                                const int32_t* input_pos, const void* scores, int32_t score_dtype,
+                                int32_t g, int64_t* idx_out, cc_stream_t stream) {
+  (void)stream;
+  if (!view_ok(c) || !input_pos || !idx_out || !scores || !dt_ok(score_dtype) || g < 0 || c->H > 4096)
+    return CC_ERR_BAD_ARG;
+  float* sc = (float*)malloc(sizeof(float) * (size_t)c->S);
+  for (int hp = 0; hp < c->Hp; hp++) {
+    for (int s = 0; s < c->S; s++) sc[s] = ld(scores, score_dtype, (size_t)hp * c->S + s);
+    idx_out[hp] = base_evict_row(sc, c->pos + (size_t)hp * c->S, c->S, g);
+  }
+  free(sc);
+  if (k_new) insert_token(c, k_new, v_new, *input_pos, idx_out);
+  return CC_OK;
+}
+
+/* ref: KVCacheRandom._token_importances cache.py:519-524, then base rules :366-379 */
+int cc_decode_update_random_cpu(const cc_kv_view* c, const void* k_new, const void* v_new,
+                                const int32_t* input_pos, const float* rand_u, int32_t g, int32_t w,
+                                int64_t* idx_out, cc_stream_t stream) {
+  (void)stream;
+  if (!view_ok(c) || !input_pos || !idx_out || !rand_u || c->Hp != 1 || g < 0 || c->H > 4096)
+    return CC_ERR_BAD_ARG;
+  const int32_t p = *input_pos;
+  float* sc = (float*)malloc(sizeof(float) * (size_t)c->S);
+  for (int s = 0; s < c->S; s++) sc[s] = (c->pos[s] >= p - w) ? INFINITY : rand_u[s]; /* :523 */
+  idx_out[0] = base_evict_row(sc, c->pos, c->S, g);
+  free(sc);
+  if (k_new) insert_token(c, k_new, v_new, p, idx_out);
+  return CC_OK;
+}
+
+size_t cc_decode_update_l2_workspace_bytes_cpu(int32_t H, int32_t S) {
+  (void)H;
+  (void)S;
+  return 0;
+}
+
+/* ref: KVCacheL2._token_importances cache.py:597-605, _decoding_update :580-595.
+ * The score is a model-dtype tensor: (max - norm) is evaluated in fp32 and rounded to the dtype, which
+ * manufactures ties; the max is over ALL heads and slots (:602). */
+int cc_decode_update_l2_cpu(const cc_kv_view* c, const void* k_new, const void* v_new,
+                            const int32_t* input_pos, void* key_norm, int32_t g, int32_t w,
+                            int64_t* idx_out, void* workspace, size_t workspace_bytes,
+                            cc_stream_t stream) {
+  (void)stream;
+  (void)workspace;
+  (void)workspace_bytes;
+  if (!view_ok(c) || !input_pos || !idx_out || !key_norm || c->Hp != c->H || g < 0 || c->H > 4096)
+    return CC_ERR_BAD_ARG;
+  const int32_t p = *input_pos;
+  const int dt = c->dtype;
+  float mx = -INFINITY;
+  int has_nan = 0;
+  for (size_t i = 0; i < (size_t)c->H * c->S; i++) {
+    float v = ld(key_norm, dt, i);
+    if (v != v) has_nan = 1;
+    if (v > mx) mx = v;
+  }
+  if (has_nan) mx = NAN; /* torch.max propagates NaN */
+  float* sc = (float*)malloc(sizeof(float) * (size_t)c->S);
+  for (int h = 0; h < c->H; h++) {
+    const int32_t* pos = c->pos + (size_t)h * c->S;
+    for (int s = 0; s < c->S; s++) {
+      float v = rnd(mx - ld(key_norm, dt, (size_t)h * c->S + s), dt);
+      sc[s] = (pos[s] >= p - w) ? INFINITY : v; /* :603 */
+    }
+    idx_out[h] = base_evict_row(sc, pos, c->S, g);
+  }
+  free(sc);
+  if (k_new) {
+    insert_token(c, k_new, v_new, p, idx_out);
+    for (int h = 0; h < c->H; h++) { /* :592-593 vector_norm in fp32 opmath, stored in model dtype */
+      float acc = 0.f;
+      for (int d = 0; d < c->D; d++) {
+        float x = ld(k_new, dt, (size_t)h * c->D + d);
+        acc += x * x;
+      }
+      st(key_norm, dt, (size_t)h * c->S + idx_out[h], sqrtf(acc));
+    }
+  }
+  return CC_OK;
+}
+
+/* ref: KVCacheHeavyHitter._eviction_idx cache.py:725-765 with history_window_size == 1.
+ *  :727 numerator = num.sum(-1).float()  -> (float)double, round-to-nearest-even
+ *  :732 denominator = denom.clamp_min(1) (int32); :738 float32 / int32 -> IEEE fp32 divide
+ *  :741-747 (pos < g) | (pos >= p - w) -> 1.0 ; :749 pos == -1 -> 0.0 (applied last, so it wins)
+ *  :751 argmin ; :754-763 zero num/denom at idx. */
+int cc_decode_update_heavy_hitter_cpu(const cc_kv_view* c, const void* k_new, const void* v_new,
+                                      const int32_t* input_pos, double* num, int32_t* denom, int32_t g,
+                                      int32_t w, int64_t* idx_out, cc_stream_t stream) {
+  (void)stream;
+  if (!view_ok(c) || !input_pos || !idx_out || !num || !denom || c->Hp != c->H || c->H > 4096)
+    return CC_ERR_BAD_ARG;
+  const int32_t p = *input_pos;
+  float* sc = (float*)malloc(sizeof(float) * (size_t)c->S);
+  for (int h = 0; h < c->H; h++) {
+    const int32_t* pos = c->pos + (size_t)h * c->S;
+    for (int s = 0; s < c->S; s++) {
+      size_t i = (size_t)h * c->S + s;
+      int32_t dn = denom[i] < 1 ? 1 : denom[i];
+      float v = (float)num[i] / (float)dn;
+      if (pos[s] < g || pos[s] >= p - w) v = 1.0f;
+      if (pos[s] == -1) v = 0.0f;
+      sc[s] = v;
+    }
+    idx_out[h] = argmin_f32(sc, c->S);
+  }
+  free(sc);
+  for (int h = 0; h < c->H; h++) {
+    num[(size_t)h * c->S + idx_out[h]] = 0.0;
+    denom[(size_t)h * c->S + idx_out[h]] = 0;
+  }
+  if (k_new) insert_token(c, k_new, v_new, p, idx_out);
+  return CC_OK;
+}
+
+/* ref: KVCacheHeavyHitter.update_state cache.py:706-723 (W == 1): zero-pad attn to S, num += attn
+ * (float64 += widened model dtype: exact), denom += 1 everywhere, counter += 1. */
+int cc_hh_update_cpu(double* num, int32_t* denom, int64_t* counter, const void* attn, int32_t H, int32_t S,
+                     int32_t T, int32_t dtype, cc_stream_t stream) {
+  (void)stream;
+  if (!num || !denom || !attn || H <= 0 || S <= 0 || T < 0 || T > S || !dt_ok(dtype)) return CC_ERR_BAD_ARG;
+  for (int h = 0; h < H; h++) {
+    for (int s = 0; s < T; s++) num[(size_t)h * S + s] += (double)ld(attn, dtype, (size_t)h * T + s);
+    for (int s = 0; s < S; s++) denom[(size_t)h * S + s] += 1;
+  }
+  if (counter) *counter += 1;
+  return CC_OK;
+}
+
+/* ---------------------------------------------------------------- decode attention ---------------- */
+
+size_t cc_decode_attn_workspace_bytes_cpu(int32_t HQ, int32_t H, int32_t S, int32_t D, int32_t dtype) {
+  (void)HQ;
+  (void)H;
+  (void)S;
+  (void)D;
+  (void)dtype;
+  return 0;
+}
+
+/* ref: model.py:395-418 + attention_utils.py:36-54 (naive path; the fused F.sdpa path :27-35 is the
+ * same math without returning P).  Rounding points of the reference in a 16-bit model dtype:
+ *   :37 (q @ k^T) -> dtype ; * scale_factor -> dtype ; :42-43 + (-inf) bias ; :52 softmax (fp32 inside,
+ *   result -> dtype) ; :54 P @ v -> dtype ; model.py:416-418 mean over the R query heads -> dtype.
+ * Contractions are accumulated in double here (the exactly-rounded value every fp32 summation order
+ * approximates); comparisons against the device kernel and the reference are tolerance-based (1e-3). */
+int cc_decode_attn_gqa_cpu(const void* q, const void* k, const void* v, const uint8_t* mask, int32_t HQ,
+                           int32_t H, int32_t S, int32_t D, int32_t dtype, float scale, void* y,
+                           void* attn_out, void* probs_out, double* hh_num, int32_t* hh_denom,
+                           int64_t* hh_counter, void* workspace, size_t workspace_bytes,
+                           cc_stream_t stream) {
+  (void)stream;
+  (void)workspace;
+  (void)workspace_bytes;
+  if (!q || !k || !v || !y || HQ <= 0 || H <= 0 || HQ % H || S <= 0 || D <= 0 || !dt_ok(dtype))
+    return CC_ERR_BAD_ARG;
+  const int R = HQ / H;
+  float* P = (float*)malloc(sizeof(float) * (size_t)R * S);
+  float* sc = (float*)malloc(sizeof(float) * (size_t)S);
+  for (int h = 0; h < H; h++) {
+    for (int r = 0; r < R; r++) {
+      const int j = h * R + r;
+      float m = -INFINITY;
+      for (int s = 0; s < S; s++) {
+        double acc = 0.0;
+        for (int d = 0; d < D; d++)
+          acc += (double)ld(q, dtype, (size_t)j * D + d) * (double)ld(k, dtype, ((size_t)h * S + s) * D + d);
+        float x = rnd(rnd((float)acc, dtype) * scale, dtype);
+        if (mask && !mask[(size_t)h * S + s]) x = -INFINITY;
+        sc[s] = x;
+        if (x > m) m = x;
+      }
+      double sum = 0.0;
+      for (int s = 0; s < S; s++) {
+        sc[s] = expf(sc[s] - m);
+        sum += sc[s];
+      }
+      const float fsum = (float)sum;
+      for (int s = 0; s < S; s++) {
+        float pr = rnd(sc[s] / fsum, dtype);
+        P[(size_t)r * S + s] = pr;
+        if (probs_out) st(probs_out, dtype, (size_t)j * S + s, pr);
+      }
+      for (int d = 0; d < D; d++) {
+        double acc = 0.0;
+        for (int s = 0; s < S; s++) acc += (double)P[(size_t)r * S + s] * (double)ld(v, dtype, ((size_t)h * S + s) * D + d);
+        st(y, dtype, (size_t)j * D + d, (float)acc);
+      }
+    }
+    if (attn_out || hh_num) {
+      for (int s = 0; s < S; s++) {
+        float acc = 0.f;
+        for (int r = 0; r < R; r++) acc += P[(size_t)r * S + s];
+        float a = rnd(acc / (float)R, dtype);
+        if (attn_out) st(attn_out, dtype, (size_t)h * S + s, a);
+        if (hh_num) {
+          hh_num[(size_t)h * S + s] += (double)a;
+          hh_denom[(size_t)h * S + s] += 1;
+        }
+      }
+    }
+  }
+  if (hh_num && hh_counter) *hh_counter += 1;
+  free(P);
+  free(sc);
+  return CC_OK;
+}
+
+/* ---------------------------------------------------------------- prefill fill / norms ------------ */
+
+/* ref: _prefill_update cache.py:381-388, _fill_contiguous :390-401, update_kv :330 */
+int cc_prefill_fill_cpu(const cc_kv_view* c, const void* k_val, const void* v_val, const int64_t* pos_val,
+                        int32_t PH, int32_t T, cc_stream_t stream) {
+  (void)stream;
+  if (!view_ok(c) || !k_val || !v_val || !pos_val || T <= 0 || T > c->S || (PH != 1 && PH != c->Hp))
+    return CC_ERR_BAD_ARG;
+  const size_t es = dt_size(c->dtype);
+  for (int hp = 0; hp < c->Hp; hp++)
+    for (int t = 0; t < T; t++) c->pos[(size_t)hp * c->S + t] = (int32_t)pos_val[(size_t)(PH == 1 ? 0 : hp) * T + t];
+  for (int h = 0; h < c->H; h++) {
+    memcpy((char*)c->k_cache + (size_t)h * c->S * c->D * es, (const char*)k_val + (size_t)h * T * c->D * es,
+           (size_t)T * c->D * es);
+    memcpy((char*)c->v_cache + (size_t)h * c->S * c->D * es, (const char*)v_val + (size_t)h * T * c->D * es,
+           (size_t)T * c->D * es);
+    memset(c->mask + (size_t)h * c->S, 1, (size_t)T);
+  }
+  for (int j = 0; j < c->Hc; j++) c->cache_cts[j] += T;
+  return CC_OK;
+}
+
+/* ref: torch.linalg.vector_norm(x, ord=2, dim=-1) at cache.py:612 and prompt_compression.py:203 */
+int cc_row_l2_norm_cpu(const void* x, int32_t H, int32_t N, int32_t D, int32_t dtype, int32_t negate,
+                       void* out, cc_stream_t stream) {
+  (void)stream;
+  if (!x || !out || H <= 0 || N <= 0 || D <= 0 || !dt_ok(dtype)) return CC_ERR_BAD_ARG;
+  for (size_t r = 0; r < (size_t)H * N; r++) {
+    float acc = 0.f;
+    for (int d = 0; d < D; d++) {
+      float e = ld(x, dtype, r * D + d);
+      acc += e * e;
+    }
+    float n = sqrtf(acc);
+    st(out, dtype, r, negate ? -n : n);
+  }
+  return CC_OK;
+}
+
+/* ---------------------------------------------------------------- prompt compaction --------------- */
+
+typedef struct {
+  double v; /* every priority dtype (f32/bf16/f16/int64 < 2^53 in practice) is exact in a double */
+  int isnan;
+  int64_t i;
+} prio_t;
+
+static int prio_cmp(const void* a, const void* b) {
+  const prio_t* x = (const prio_t*)a;
+  const prio_t* y = (const prio_t*)b;
+  if (x->isnan != y->isnan) return y->isnan - x->isnan; /* NaN ranks as the largest (torch.topk) */
+  if (!x->isnan) {
+    if (x->v > y->v) return -1;
+    if (x->v < y->v) return 1;
+  }
+  return (x->i > y->i) - (x->i < y->i); /* tie: lowest index first (see DESIGN.md tie contract) */
+}
+
+static int i64_cmp(const void* a, const void* b) {
+  int64_t x = *(const int64_t*)a, y = *(const int64_t*)b;
+  return (x > y) - (x < y);
+}
+
+size_t cc_topk_keep_workspace_bytes_cpu(int32_t Hs, int32_t L, int32_t K) {
+  (void)Hs;
+  (void)L;
+  (void)K;
+  return 0;
+}
+
+/* ref: PromptCompressor._keep_idxs prompt_compression.py:21-26: topk(K).indices.sort().values */
+int cc_topk_keep_cpu(const void* priority, int32_t prio_dtype, int32_t Hs, int32_t L, int32_t K,
+                     int64_t* keep_out, void* workspace, size_t workspace_bytes, cc_stream_t stream) {
+  (void)stream;
+  (void)workspace;
+  (void)workspace_bytes;
+  if (!priority || !keep_out || Hs <= 0 || L <= 0 || K <= 0 || K > L || prio_dtype < 0 || prio_dtype > 3)
+    return CC_ERR_BAD_ARG;
+  prio_t* a = (prio_t*)malloc(sizeof(prio_t) * (size_t)L);
+  for (int h = 0; h < Hs; h++) {
+    for (int t = 0; t < L; t++) {
+      size_t i = (size_t)h * L + t;
+      double v;
+      if (prio_dtype == CC_PRIO_I64) v = (double)((const int64_t*)priority)[i];
+      else v = (double)ld(priority, prio_dtype, i);
+      a[t].v = v;
+      a[t].isnan = (v != v);
+      a[t].i = t;
+    }
+    qsort(a, (size_t)L, sizeof(prio_t), prio_cmp);
+    for (int j = 0; j < K; j++) keep_out[(size_t)h * K + j] = a[j].i;
+    qsort(keep_out + (size_t)h * K, (size_t)K, sizeof(int64_t), i64_cmp);
+  }
+  free(a);
+  return CC_OK;
+}
+
+/* ref: _filter_kv prompt_compression.py:69-72 (head-constant index) / :82-88 (head-specific gather) */
+int cc_gather_rows_cpu(const void* src, const int64_t* keep, int32_t Hk, int32_t H, int32_t L, int32_t K,
+                       int32_t D, int32_t dtype, void* dst, cc_stream_t stream) {
+  (void)stream;
+  if (!src || !keep || !dst || H <= 0 || L <= 0 || K <= 0 || D <= 0 || (Hk != 1 && Hk != H) || !dt_ok(dtype))
+    return CC_ERR_BAD_ARG;
+  const size_t rb = (size_t)D * dt_size(dtype);
+  for (int h = 0; h < H; h++)
+    for (int j = 0; j < K; j++) {
+      int64_t t = keep[(size_t)(Hk == 1 ? 0 : h) * K + j];
+      if (t < 0 || t >= L) return CC_ERR_BAD_ARG;
+      memcpy((char*)dst + ((size_t)h * K + j) * rb, (const char*)src + ((size_t)h * L + t) * rb, rb);
+    }
+  return CC_OK;
+}
+
+/* ref: cum_attn.gather(2, keep_idxs) prompt_compression.py:193 */
+int cc_gather_vec_cpu(const void* src, const int64_t* keep, int32_t Hs, int32_t L, int32_t K, int32_t dtype,
+                      void* dst, cc_stream_t stream) {
+  (void)stream;
+  if (!src || !keep || !dst || Hs <= 0 || L <= 0 || K <= 0 || !dt_ok(dtype)) return CC_ERR_BAD_ARG;
+  const size_t es = dt_size(dtype);
+  for (int h = 0; h < Hs; h++)
+    for (int j = 0; j < K; j++) {
+      int64_t t = keep[(size_t)h * K + j];
+      if (t < 0 || t >= L) return CC_ERR_BAD_ARG;
+      memcpy((char*)dst + ((size_t)h * K + j) * es, (const char*)src + ((size_t)h * L + t) * es, es);
+    }
+  return CC_OK;
+}
+
+/* ref: PromptCompressorHeavyHitter._token_importances prompt_compression.py:170-187.
+ * AvgPool1d(kernel 5, stride 1, padding 2, count_include_pad=False): mean of the in-range neighbours,
+ * fp32 accumulate, rounded to the model dtype; then the observation window and the global tokens are
+ * forced to 1.0 (:182-186). */
+int cc_snapkv_priority_cpu(const void* obs_mean, int32_t H, int32_t L, int32_t dtype, int32_t obs_len,
+                           int32_t g, void* out, cc_stream_t stream) {
+  (void)stream;
+  if (!obs_mean || !out || H <= 0 || L <= 0 || !dt_ok(dtype) || obs_len < 0) return CC_ERR_BAD_ARG;
+  for (int h = 0; h < H; h++)
+    for (int t = 0; t < L; t++) {
+      int lo = t - 2 < 0 ? 0 : t - 2, hi = t + 2 >= L ? L - 1 : t + 2;
+      float acc = 0.f;
+      for (int u = lo; u <= hi; u++) acc += ld(obs_mean, dtype, (size_t)h * L + u);
+      float v = acc / (float)(hi - lo + 1);
+      if (t >= L - obs_len || t < g) v = 1.0f;
+      st(out, dtype, (size_t)h * L + t, v);
+    }
+  return CC_OK;
+}
+
+/* ---------------------------------------------------------------- prefill attention --------------- */
+
+size_t cc_prefill_attn_workspace_bytes_cpu(int32_t HQ, int32_t H, int32_t L, int32_t D, int32_t dtype) {
+  (void)HQ;
+  (void)H;
+  (void)L;
+  (void)D;
+  (void)dtype;
+  return 0;
+}
+
+/* ref: attention_utils.py:36-54 with the causal mask of generation_utils.py:153-158, model.py:413-418
+ * (group mean), cache.py:704 / prompt_compression.py:191 (column sums) and prompt_compression.py:173
+ * (mean of the last obs_len query rows).  O(L^2 D) — small L only. */
+int cc_prefill_attn_cpu(const void* q, const void* k, const void* v, int32_t HQ, int32_t H, int32_t L,
+                        int32_t D, int32_t dtype, float scale, void* y, float* colsum_out, float* obs_out,
+                        int32_t obs_len, void* workspace, size_t workspace_bytes, cc_stream_t stream) {
+  (void)stream;
+  (void)workspace;
+  (void)workspace_bytes;
+  if (!q || !k || !v || !y || HQ <= 0 || H <= 0 || HQ % H || L <= 0 || D <= 0 || !dt_ok(dtype))
+    return CC_ERR_BAD_ARG;
+  const int R = HQ / H;
+  if (obs_len > L) obs_len = L;
+  float* P = (float*)malloc(sizeof(float) * (size_t)R * L);
+  float* sc = (float*)malloc(sizeof(float) * (size_t)L);
+  if (colsum_out) memset(colsum_out, 0, sizeof(float) * (size_t)H * L);
+  if (obs_out) memset(obs_out, 0, sizeof(float) * (size_t)H * L);
+  for (int h = 0; h < H; h++)
+    for (int i = 0; i < L; i++) {
+      for (int r = 0; r < R; r++) {
+        const int j = h * R + r;
+        float m = -INFINITY;
+        for (int s = 0; s <= i; s++) {
+          double acc = 0.0;
+          for (int d = 0; d < D; d++)
+            acc += (double)ld(q, dtype, ((size_t)j * L + i) * D + d) * (double)ld(k, dtype, ((size_t)h * L + s) * D + d);
+          float x = rnd(rnd((float)acc, dtype) * scale, dtype);
+          sc[s] = x;
+          if (x > m) m = x;
+        }
+        double sum = 0.0;
+        for (int s = 0; s <= i; s++) {
+          sc[s] = expf(sc[s] - m);
+          sum += sc[s];
+        }
+        const float fsum = (float)sum;
+        for (int s = 0; s < L; s++) P[(size_t)r * L + s] = s <= i ? rnd(sc[s] / fsum, dtype) : 0.f;
+        for (int d = 0; d < D; d++) {
+          double acc = 0.0;
+          for (int s = 0; s <= i; s++) acc += (double)P[(size_t)r * L + s] * (double)ld(v, dtype, ((size_t)h * L + s) * D + d);
+          st(y, dtype, ((size_t)j * L + i) * D + d, (float)acc);
+        }
+      }
+      for (int s = 0; s <= i; s++) {
+        float acc = 0.f;
+        for (int r = 0; r < R; r++) acc += P[(size_t)r * L + s];
+        float a = rnd(acc / (float)R, dtype);
+        if (colsum_out) colsum_out[(size_t)h * L + s] += a;
+        if (obs_out && i >= L - obs_len) obs_out[(size_t)h * L + s] += a;
+      }
+    }
+  if (obs_out && obs_len > 0)
+    for (size_t i = 0; i < (size_t)H * L; i++) obs_out[i] /= (float)obs_len;
+  free(P);
+  free(sc);
+  return CC_OK;
+}
+
+/* ref: attn.squeeze(0).sum(dim=1) cache.py:704 */
+int cc_attn_colsum_cpu(const void* attn, int32_t H, int32_t Lq, int32_t Lk, int32_t dtype, float* out,
+                       cc_stream_t stream) {
+  (void)stream;
+  if (!attn || !out || H <= 0 || Lq <= 0 || Lk <= 0 || !dt_ok(dtype)) return CC_ERR_BAD_ARG;
+  for (int h = 0; h < H; h++)
+    for (int s = 0; s < Lk; s++) {
+      float acc = 0.f;
+      for (int i = 0; i < Lq; i++) acc += ld(attn, dtype, ((size_t)h * Lq + i) * Lk + s);
+      out[(size_t)h * Lk + s] = acc;
+    }
+  return CC_OK;
+}
+
+/* ref: cache.py:704, prompt_compression.py:191 */
+int cc_colsum_to_mean_cpu(const float* colsum, const int64_t* input_pos, int32_t H, int32_t L, int32_t dtype,
+                          void* out, cc_stream_t stream) {
+  (void)stream;
+  if (!colsum || !out || H <= 0 || L <= 0 || !dt_ok(dtype)) return CC_ERR_BAD_ARG;
+  for (int h = 0; h < H; h++)
+    for (int t = 0; t < L; t++) {
+      int64_t p = input_pos ? input_pos[t] : t;
+      st(out, dtype, (size_t)h * L + t, rnd(colsum[(size_t)h * L + t], dtype) / (float)(L - p));
+    }
+  return CC_OK;
+}

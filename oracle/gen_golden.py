@@ -1,0 +1,425 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by IMPORTING THE REFERENCE (AnswerDotAI/cold-compress) on CPU.
+
+Runs only in the build container where /root/reference exists; nothing from the reference is copied —
+only inputs and the outputs the reference computed for them are written, as small .npz/.json fixtures
+under tests/golden/.  The GPU box never sees the reference.
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py [--out tests/golden]
+
+Fixtures:
+  f1_e2e_<strategy>.npz   tiny-Llama end-to-end runs through generation_utils.generate
+  f2_hh_<dtype>.npz       KVCacheHeavyHitter replay trace (update_kv / update_state, as model.py:389-427)
+  f3_l2_<case>.npz        KVCacheL2 replay traces (bf16 rounding ties, unfilled slots, H == 1)
+  f4_random.npz           KVCacheRandom with captured torch.rand vectors
+  f4_headconst.npz        KVCacheFull / KVCacheRecentGlobal / KVCacheKeepItOdd decode traces
+  f5_compress.npz         prompt_compression.* priorities -> keep_idxs (+ boundary-tie flags)
+  f7_attn_<dtype>.npz     attention_utils.scaled_dot_product_attention decode + small prefill
+  f8_budgets.json         generation_utils budget arithmetic
+Low-precision tensors are stored as their uint16 bit patterns with a "<name>__dtype" tag.
+"""
+import argparse
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+
+
+def _import_reference():
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, REF)
+    tk = types.ModuleType("tiktoken")
+    tk.Encoding = object
+    tl = types.ModuleType("tiktoken.load")
+    tl.load_tiktoken_bpe = lambda p: {}
+    tk.load = tl
+    sys.modules["tiktoken"] = tk
+    sys.modules["tiktoken.load"] = tl
+    import attention_utils as A  # noqa
+    import cache as C  # noqa
+    import generation_utils as G  # noqa
+    import model as M  # noqa
+    import prompt_compression as P  # noqa
+
+    return A, C, G, M, P
+
+
+def pack(d):
+    """torch tensors -> numpy; bf16/f16 as uint16 bit patterns + dtype tag."""
+    out = {}
+    for k, v in d.items():
+        if torch.is_tensor(v):
+            if v.dtype in (torch.bfloat16, torch.float16):
+                out[k] = v.contiguous().view(torch.int16).numpy().view(np.uint16)
+                out[k + "__dtype"] = np.array("bf16" if v.dtype == torch.bfloat16 else "f16")
+            else:
+                out[k] = v.contiguous().numpy()
+        else:
+            out[k] = np.asarray(v)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ F1
+
+
+class FakeTok:
+    def special_ids(self):
+        return [[1], [2, 3]]
+
+    def punctuation_ids(self):
+        return [5, 6, 7]
+
+
+TINY = dict(block_size=256, vocab_size=128, n_layer=2, n_head=4, n_local_heads=2, dim=64, intermediate_size=128)
+
+
+def run_e2e(C, G, M, name, cache_args, prompt_len=40, new_tokens=12, seed=0, n_layer=2):
+    torch.manual_seed(seed)
+    cfg = dict(TINY)
+    cfg["n_layer"] = n_layer
+    model = M.Transformer(M.ModelArgs(**cfg)).to(torch.float32).eval()
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    parser = argparse.ArgumentParser()
+    C.add_cache_arguments(parser)
+    G.add_generation_arguments(parser)
+    args = parser.parse_args([])
+    kw = vars(args)
+    kw.update(cache_args)
+    cache_kwargs = G.setup_caches(model, FakeTok(), "cpu", prompt_len + new_tokens, dict(kw))
+
+    evict_log = []  # (layer, idx tensor)
+    for li, layer in enumerate(model.layers):
+        kv = layer.attention.kv_cache
+        orig = kv._eviction_idx
+
+        def wrapped(input_pos, _orig=orig, _li=li):
+            r = _orig(input_pos)
+            evict_log.append((_li, r.clone().view(-1)))
+            return r
+
+        kv._eviction_idx = wrapped
+    logits_log = []
+    orig_fwd = model.forward
+
+    def fwd(*a, **k):
+        out = orig_fwd(*a, **k)
+        logits_log.append(out[0, -1].detach().clone().float())
+        return out
+
+    model.forward = fwd
+    prompt = (torch.arange(prompt_len) * 7 % 128).to(torch.int32) if name != "recent_global" else (
+        torch.arange(prompt_len) % 128).to(torch.int32)
+    seq, probs, stats = G.generate(model, prompt, G.prefill, G.decode_one_token, max_new_tokens=new_tokens)
+    d = {"prompt": prompt, "seq": seq, "logits": torch.stack(logits_log),
+         "n_layer": n_layer, "prompt_len": prompt_len, "new_tokens": new_tokens,
+         "max_cache_length": np.array(cache_kwargs["max_cache_length"]),
+         "recent_window": np.array(cache_kwargs["recent_window"]),
+         "cache_args_json": json.dumps({k: v for k, v in cache_args.items()}),
+         "torch_version": torch.__version__}
+    for k, v in state.items():
+        d["sd." + k] = v
+    H = TINY["n_local_heads"]
+    for li in range(n_layer):
+        rows = [r for (l, r) in evict_log if l == li]
+        width = max(r.numel() for r in rows) if rows else 1
+        d[f"evict_idx_L{li}"] = torch.stack([r.expand(width) if r.numel() == 1 else r for r in rows]) if rows else torch.zeros(0, 1)
+        kv = model.layers[li].attention.kv_cache
+        d[f"final_pos_L{li}"] = kv.pos.clone()
+        d[f"final_mask_L{li}"] = kv.mask.clone()
+        d[f"final_cts_L{li}"] = kv.cache_cts.clone()
+        d[f"final_k_L{li}"] = kv.k_cache.clone()
+        if hasattr(kv, "attn_history_num"):
+            d[f"final_num_L{li}"] = kv.attn_history_num.clone()
+            d[f"final_denom_L{li}"] = kv.attn_history_denom.clone()
+        if hasattr(kv, "key_norm"):
+            d[f"final_keynorm_L{li}"] = kv.key_norm.clone()
+    cs = model.get_cache_stats(prompt_len, new_tokens)
+    d["compression_ratio_avg"] = cs["compression_ratio_avg"]
+    return pack(d)
+
+
+# ------------------------------------------------------------------------------------------------ F2/F3/F4
+
+
+def softmax_rows(shape, dtype, gen, mask=None):
+    x = torch.randn(shape, generator=gen) * 2.0
+    if mask is not None:
+        x = x.masked_fill(~mask, float("-inf"))
+    return torch.softmax(x, dim=-1).to(dtype)
+
+
+def replay_cache(C, strategy, dtype, H, S, D, T_prefill, steps, g, w, seed, extra=None, rand_capture=None):
+    """Drive a reference cache exactly as model.py:389-427 does and record inputs/outputs."""
+    gen = torch.Generator().manual_seed(seed)
+    cls, rk = C.get_cache_constructor(strategy)
+    kw = dict(max_cache_length=S, global_tokens=g, max_seq_length=4 * S, cache_bits=None, recent_window=w,
+              history_window_size=1, attn_thresholding=False)
+    if extra:
+        kw.update(extra)
+    kv = cls(1, H, D, dtype, **{k: kw[k] for k in rk})
+    rec = {"H": H, "S": S, "D": D, "T_prefill": T_prefill, "steps": steps, "g": g, "w": w,
+           "strategy": np.array(strategy), "dtype": np.array(str(dtype).split(".")[-1])}
+    # ---- prefill (no compression: T <= S)
+    T = T_prefill
+    k0 = (torch.randn(1, H, T, D, generator=gen)).to(dtype)
+    v0 = (torch.randn(1, H, T, D, generator=gen)).to(dtype)
+    pos0 = torch.arange(T)
+    kv.update_kv(pos0, k0, v0, True)
+    attn0 = None
+    if kv.return_attn():
+        causal = torch.tril(torch.ones(T, T, dtype=torch.bool)).view(1, 1, T, T)
+        attn0 = softmax_rows((1, H, T, T), dtype, gen, causal.expand(1, H, T, T))
+    kv.update_state(pos0, k0, v0, True, attn0)
+    rec.update({"k0": k0, "v0": v0})
+    if attn0 is not None:
+        rec["attn0"] = attn0
+        rec["num_after_prefill"] = kv.attn_history_num.clone()
+        rec["denom_after_prefill"] = kv.attn_history_denom.clone()
+    if hasattr(kv, "key_norm"):
+        rec["keynorm_after_prefill"] = kv.key_norm.clone()
+    # ---- decode
+    ks, vs, attns, idxs, rands, cts = [], [], [], [], [], []
+    for t in range(steps):
+        p = torch.tensor([T + t], dtype=torch.int32)
+        k1 = torch.randn(1, H, 1, D, generator=gen).to(dtype)
+        v1 = torch.randn(1, H, 1, D, generator=gen).to(dtype)
+        pos_before = kv.pos.clone()
+        if rand_capture is not None:
+            r = torch.rand(S, generator=gen)
+            rands.append(r)
+            rand_capture["next"] = r
+        kv.update_kv(p, k1, v1, False, input_ids=torch.tensor([[1]]))
+        changed = (kv.pos != pos_before)
+        # idx per pos-head = the slot whose pos changed (pos always changes: p is new)
+        idx = changed.squeeze(0).int().argmax(dim=-1)
+        assert bool(changed.squeeze(0).sum(dim=-1).eq(1).all())
+        idxs.append(idx.clone().long())
+        cts.append(kv.cache_cts.clone())
+        a = None
+        if kv.return_attn():
+            a = softmax_rows((1, H, 1, S), dtype, gen, kv.mask.clone())
+            attns.append(a)
+        kv.update_state(p, k1, v1, False, a)
+        ks.append(k1)
+        vs.append(v1)
+    rec.update({"k_new": torch.stack(ks), "v_new": torch.stack(vs), "idx": torch.stack(idxs),
+                "cache_cts_steps": torch.stack(cts)})
+    if attns:
+        rec["attn"] = torch.stack(attns)
+        rec["final_num"] = kv.attn_history_num.clone()
+        rec["final_denom"] = kv.attn_history_denom.clone()
+        rec["final_counter"] = kv.attn_counter.clone()
+    if rands:
+        rec["rand_u"] = torch.stack(rands)
+    if hasattr(kv, "key_norm"):
+        rec["final_keynorm"] = kv.key_norm.clone()
+    rec.update({"final_pos": kv.pos.clone(), "final_mask": kv.mask.clone(), "final_cts": kv.cache_cts.clone(),
+                "final_k": kv.k_cache.clone(), "final_v": kv.v_cache.clone()})
+    return pack(rec)
+
+
+# ------------------------------------------------------------------------------------------------ F5
+
+
+def compress_cases(P):
+    gen = torch.Generator().manual_seed(11)
+    out = {}
+    cases = []
+
+    def boundary_tie(prio, K):
+        # True if the K-th largest value equals the (K+1)-th largest in any row
+        s = prio.float().sort(dim=-1, descending=True).values
+        return bool((s[..., K - 1] == s[..., K]).any()) if prio.shape[-1] > K else False
+
+    def add(name, comp, input_pos, k, v, **kw):
+        torch.manual_seed(5)  # the random compressor draws randperm per call: same draw for both calls
+        prio = comp._token_importances(input_pos, k, v, **kw)
+        # NB: the heavy-hitter compressor mutates nothing we re-use; call the full path too
+        torch.manual_seed(5)
+        keep, k2, v2, st = comp(input_pos, k, v, **kw)
+        out[name + ".priority"] = prio.clone()
+        out[name + ".keep"] = keep.clone()
+        out[name + ".k_in"] = k
+        out[name + ".v_in"] = v
+        out[name + ".k_out"] = k2
+        out[name + ".v_out"] = v2
+        out[name + ".tie"] = np.array(boundary_tie(prio, comp.max_cache_length))
+        if st is not None:
+            out[name + ".state"] = st
+        cases.append(name)
+
+    H, L, D, S = 4, 96, 16, 40
+    pos = torch.arange(L)
+    for dt, tag in ((torch.float32, "f32"), (torch.bfloat16, "bf16")):
+        k = torch.randn(1, H, L, D, generator=gen).to(dt)
+        v = torch.randn(1, H, L, D, generator=gen).to(dt)
+        kw = dict(max_cache_length=S, global_tokens=4, recent_window=10)
+        add(f"recent_global_{tag}", P.PromptCompressorRecentGlobal(head_specific=False, **kw), pos, k, v)
+        add(f"l2_{tag}", P.PromptCompressorL2(head_specific=True, **kw), pos, k, v)
+        causal = torch.tril(torch.ones(L, L, dtype=torch.bool)).view(1, 1, L, L).expand(1, H, L, L)
+        attn = softmax_rows((1, H, L, L), dt, gen, causal)
+        out[f"heavy_hitter_{tag}.attn"] = attn
+        add(f"heavy_hitter_{tag}", P.PromptCompressorHeavyHitter(head_specific=True, **kw), pos, k, v, attn=attn)
+        # random: capture the permutation through the priority itself (priority is an input of the check)
+        torch.manual_seed(5)
+        add(f"random_{tag}", P.PromptCompressorRandom(head_specific=False, **kw), pos, k, v)
+        add(f"keep_it_odd_{tag}", P.PromptCompressorKeepItOdd(head_specific=False, **kw), pos, k, v)
+    # a larger bf16 L2 case where boundary ties are near-certain
+    H, L, D, S = 2, 2048, 32, 640
+    k = torch.randn(1, H, L, D, generator=gen).to(torch.bfloat16)
+    v = torch.randn(1, H, L, D, generator=gen).to(torch.bfloat16)
+    add("l2_big_bf16", P.PromptCompressorL2(head_specific=True, max_cache_length=S, global_tokens=4, recent_window=10),
+        torch.arange(L), k, v)
+    out["cases"] = np.array(cases)
+    return pack(out)
+
+
+# ------------------------------------------------------------------------------------------------ F7
+
+
+def attn_cases(A, dtype):
+    gen = torch.Generator().manual_seed(3)
+    out = {}
+    # decode: HQ=8, H=2 (R=4), S=96, D=32, with mask; driven as model.py:395-418
+    HQ, H, S, D = 8, 2, 96, 32
+    R = HQ // H
+    q = torch.randn(1, HQ, 1, D, generator=gen).to(dtype)
+    k = torch.randn(1, H, S, D, generator=gen).to(dtype)
+    v = torch.randn(1, H, S, D, generator=gen).to(dtype)
+    mask = torch.rand(1, H, 1, S, generator=gen) > 0.2
+    mask[..., 0] = True
+    y, p = A.scaled_dot_product_attention(q, k.repeat_interleave(R, 1), v.repeat_interleave(R, 1),
+                                          attn_mask=mask.repeat_interleave(R, 1), return_attn=True)
+    y2, _ = A.scaled_dot_product_attention(q, k.repeat_interleave(R, 1), v.repeat_interleave(R, 1),
+                                           attn_mask=mask.repeat_interleave(R, 1), return_attn=False)
+    out.update({"dec.q": q, "dec.k": k, "dec.v": v, "dec.mask": mask, "dec.y": y, "dec.probs": p, "dec.y_fused": y2,
+                "dec.attn_gm": p.view(1, H, R, 1, -1).mean(dim=2)})
+    # decode, Llama-3-8B head geometry but short cache: HQ=32,H=8,D=128,S=256
+    HQ, H, S, D = 32, 8, 256, 128
+    R = HQ // H
+    q = torch.randn(1, HQ, 1, D, generator=gen).to(dtype)
+    k = torch.randn(1, H, S, D, generator=gen).to(dtype)
+    v = torch.randn(1, H, S, D, generator=gen).to(dtype)
+    mask = torch.ones(1, H, 1, S, dtype=torch.bool)
+    mask[..., 200:] = False
+    y, p = A.scaled_dot_product_attention(q, k.repeat_interleave(R, 1), v.repeat_interleave(R, 1),
+                                          attn_mask=mask.repeat_interleave(R, 1), return_attn=True)
+    out.update({"dec8b.q": q, "dec8b.k": k, "dec8b.v": v, "dec8b.mask": mask, "dec8b.y": y, "dec8b.probs": p,
+                "dec8b.attn_gm": p.view(1, H, R, 1, -1).mean(dim=2)})
+    # prefill: HQ=4,H=2,L=48,D=16, causal
+    HQ, H, L, D = 4, 2, 48, 16
+    R = HQ // H
+    q = torch.randn(1, HQ, L, D, generator=gen).to(dtype)
+    k = torch.randn(1, H, L, D, generator=gen).to(dtype)
+    v = torch.randn(1, H, L, D, generator=gen).to(dtype)
+    causal = torch.tril(torch.ones(L, L, dtype=torch.bool)).view(1, 1, L, L)
+    y, p = A.scaled_dot_product_attention(q, k.repeat_interleave(R, 1), v.repeat_interleave(R, 1),
+                                          attn_mask=causal, return_attn=True)
+    gm = p.view(1, H, R, L, -1).mean(dim=2)
+    out.update({"pre.q": q, "pre.k": k, "pre.v": v, "pre.y": y, "pre.attn_gm": gm,
+                "pre.colsum": gm.sum(dim=2), "pre.obs_mean": gm[:, :, -16:, :].mean(dim=2)})
+    return pack(out)
+
+
+# ------------------------------------------------------------------------------------------------ F8
+
+
+def budgets(G, M):
+    rows = {"normalize": [], "pattern": [], "pyramid": [], "find_multiple": []}
+    for frac, mx in [(0.25, 10240), (0.1, 34816), (1.0, 18432), (0.5, 52), (4096, 10240), (16, 52), (0.33, 1000),
+                     (20000, 10240), (0.05, 8192), (1, 77)]:
+        rows["normalize"].append([frac, mx, G.normalize_cache_length(frac, mx)])
+    for pat, n, strat in [([1, 2], 4, "tile"), ([1, 2], 4, "repeat"), (["a"], 3, "tile"), ([5, 6, 7, 8], 8, "repeat"),
+                          ([5, 6, 7, 8], 8, "tile")]:
+        rows["pattern"].append([pat, n, strat, G.apply_pattern(pat, n, strat)])
+    for length, mx, n, dec in [(1024, 18432, 32, True), (1024, 18432, 32, False), (2560, 10240, 32, True),
+                               (512, 4096, 16, True), (300, 4096, 8, True), (3488, 34816, 80, True)]:
+        rows["pyramid"].append([length, mx, n, dec, G.apply_pyramid_pattern(length, mx, n, decreasing=dec)])
+    for n, k in [(5, 8), (8, 8), (2557, 8), (0, 8), (13, 256)]:
+        rows["find_multiple"].append([n, k, M.find_multiple(n, k)])
+    return rows
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
+    a = ap.parse_args()
+    os.makedirs(a.out, exist_ok=True)
+    A, C, G, M, P = _import_reference()
+    torch.set_num_threads(1)
+
+    def save(name, d):
+        np.savez_compressed(os.path.join(a.out, name), **d)
+        print("wrote", name, sum(v.nbytes for v in d.values()) // 1024, "KiB")
+
+    # F1: config C1 (README.md:103 of the reference) + companions on the same tiny model
+    save("f1_e2e_recent_global.npz", run_e2e(C, G, M, "recent_global", dict(
+        cache_strategy=["recent_global"], prompt_compression_strategy=["recent_global"], max_cache_length=[16],
+        global_tokens=4)))
+    save("f1_e2e_heavy_hitter.npz", run_e2e(C, G, M, "heavy_hitter", dict(
+        cache_strategy=["heavy_hitter"], prompt_compression_strategy=["heavy_hitter"], max_cache_length=[32],
+        global_tokens=4, recent_window=4), prompt_len=56, new_tokens=24))
+    save("f1_e2e_heavy_hitter_short.npz", run_e2e(C, G, M, "heavy_hitter", dict(
+        cache_strategy=["heavy_hitter"], prompt_compression_strategy=["heavy_hitter"], max_cache_length=[32],
+        global_tokens=2, recent_window=3), prompt_len=20, new_tokens=30))
+    save("f1_e2e_l2.npz", run_e2e(C, G, M, "l2", dict(
+        cache_strategy=["l2"], prompt_compression_strategy=["l2"], max_cache_length=[24], global_tokens=4,
+        recent_window=5), prompt_len=48, new_tokens=16))
+    save("f1_e2e_full.npz", run_e2e(C, G, M, "full", dict(
+        cache_strategy=["full"], prompt_compression_strategy=["full"], max_cache_length=[1.0]),
+        prompt_len=24, new_tokens=10))
+    save("f1_e2e_hh_pyramid.npz", run_e2e(C, G, M, "heavy_hitter", dict(
+        cache_strategy=["heavy_hitter"], prompt_compression_strategy=["heavy_hitter"], max_cache_length=[64],
+        cache_length_pattern="pyramid", global_tokens=2, recent_window=3), prompt_len=120, new_tokens=16, n_layer=4))
+
+    # F2: heavy-hitter replay
+    for dt, tag in ((torch.float32, "f32"), (torch.bfloat16, "bf16")):
+        save(f"f2_hh_{tag}.npz", replay_cache(C, "heavy_hitter", dt, H=4, S=48, D=16, T_prefill=30, steps=80, g=2, w=3,
+                                              seed=21))
+    save("f2_hh_h1_bf16.npz", replay_cache(C, "heavy_hitter", torch.bfloat16, H=2, S=130, D=128, T_prefill=100, steps=70,
+                                           g=4, w=10, seed=22))
+    # F3: L2
+    save("f3_l2_bf16.npz", replay_cache(C, "l2", torch.bfloat16, H=4, S=48, D=16, T_prefill=30, steps=80, g=2, w=3, seed=31))
+    save("f3_l2_f32.npz", replay_cache(C, "l2", torch.float32, H=4, S=48, D=16, T_prefill=30, steps=60, g=2, w=3, seed=32))
+    save("f3_l2_h1_bf16.npz", replay_cache(C, "l2", torch.bfloat16, H=1, S=200, D=128, T_prefill=150, steps=120, g=4, w=10,
+                                           seed=33))
+    # F4: random with captured rand vectors
+    cap = {}
+    orig_rand = torch.rand
+
+    def patched_rand(*args, **kw):
+        if "generator" in kw or "next" not in cap:
+            return orig_rand(*args, **kw)
+        return cap["next"].clone()
+
+    torch.rand = patched_rand
+    try:
+        save("f4_random.npz", replay_cache(C, "random", torch.bfloat16, H=3, S=40, D=16, T_prefill=25, steps=60, g=2, w=4,
+                                           seed=41, rand_capture=cap))
+    finally:
+        torch.rand = orig_rand
+    d = {}
+    for strat in ("full", "recent_global", "keep_it_odd"):
+        S = 64 if strat == "full" else 24
+        r = replay_cache(C, strat, torch.bfloat16, H=3, S=S, D=16, T_prefill=12, steps=40, g=3, w=4, seed=42)
+        for k, v in r.items():
+            d[f"{strat}.{k}"] = v
+    save("f4_headconst.npz", d)
+    # F5
+    save("f5_compress.npz", compress_cases(P))
+    # F7
+    save("f7_attn_f32.npz", attn_cases(A, torch.float32))
+    save("f7_attn_bf16.npz", attn_cases(A, torch.bfloat16))
+    # F8
+    with open(os.path.join(a.out, "f8_budgets.json"), "w") as f:
+        json.dump(budgets(G, M), f)
+    print("wrote f8_budgets.json")
+
+
+if __name__ == "__main__":
+    main()

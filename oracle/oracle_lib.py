@@ -1,0 +1,50 @@
+"""Loader + numpy-level wrappers for the CPU oracle (oracle/cc_oracle.c).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.  It binds
+`liboracle.so` with the same signature table as the device library (cold_compress_amd/_abi.py), symbol
+suffix `_cpu`, and takes numpy arrays (host memory).  16-bit floats travel as uint16 bit patterns.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from cold_compress_amd import _abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(_HERE, "liboracle.so")
+_FNS = None
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "cc_oracle.c")
+    if force or not os.path.exists(SO) or os.path.getmtime(SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
+    return SO
+
+
+def fns():
+    global _FNS
+    if _FNS is None:
+        if not os.path.exists(SO):
+            build()
+        _FNS = _abi.bind(C.CDLL(SO), suffix="_cpu")
+    return _FNS
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def view(k, v, pos, mask, cts, dtype):
+    """k,v: [H,S,D] arrays (uint16 for bf16/f16), pos [Hp,S] int32, mask [H,S] uint8/bool, cts [Hc] int32."""
+    H, S, D = k.shape
+    kv = _abi.KVView(ptr(k), ptr(v), ptr(pos), ptr(mask), ptr(cts), H, pos.shape[0], cts.shape[0], S, D, dtype)
+    return kv
+
+
+def call(name, *args):
+    rc = fns()[name](*args)
+    if rc != 0:
+        raise RuntimeError(f"oracle {name} -> {rc}")
