@@ -1,0 +1,319 @@
+#!/usr/bin/env python3
+"""bench.py — decode tokens/s of Llama-3-8B (bf16, random weights) with the heavy_hitter KV-cache policy at
+cache_len = 4096 after an 8k-token prompt (BASELINE.json metric; SURVEY §8(d) config C3/C2 family), plus the
+HBM roofline of the dominant hot-path kernel and a CPU baseline of the same hot path.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one full decode token: 32 x (norm, wqkv GEMV, RoPE, evict-select + insert, GQA attention over
+the pruned cache, history update, wo, FFN) + LM head + greedy sampling, replayed from a hipGraph.
+N > 1 = tensor parallel over KV heads (cold_compress_amd/tp.py: RCCL all-reduce over xGMI), same model and
+token stream -> "strong" scaling.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--prompt_len", type=int, default=8192)
+    ap.add_argument("--cache_len", type=int, default=4096)
+    ap.add_argument("--n_layer", type=int, default=32, help="debug only; anything but 32 is not the named config")
+    ap.add_argument("--no_graph", action="store_true")
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--cpu_tokens", type=int, default=2)
+    ap.add_argument("--roofline_iters", type=int, default=20)
+    return ap.parse_args()
+
+
+def build_model(args, world, dev):
+    from cold_compress_amd import tp
+    from cold_compress_amd.harness import CONFIGS, ModelArgs, Transformer
+
+    cfg = dict(CONFIGS["Meta-Llama-3.1-8B-Instruct"])
+    cfg["n_layer"] = args.n_layer
+    cfg["block_size"] = max(16384, args.prompt_len + args.steps + args.warmup + 64)
+    torch.manual_seed(1234)  # the seed generate.py:108 uses
+    with torch.device("meta"):
+        model = Transformer(ModelArgs(**cfg))
+    if world > 1:
+        # shard shapes first (on meta), then materialise only this rank's slice
+        tp.apply_tp(model)
+    model = model.to_empty(device=dev).to(torch.bfloat16)
+    g = torch.Generator(device=dev).manual_seed(1234 + (dist.get_rank() if world > 1 else 0))
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if "norm" in name:
+                p.fill_(1.0)
+            else:
+                p.normal_(0.0, 0.02, generator=g)
+        if world > 1:  # replicated tensors must be identical on every rank (tp.py: embeddings / LM head / norms)
+            for name, p in model.named_parameters():
+                if name.startswith(("tok_embeddings", "output", "norm")) or "norm" in name:
+                    dist.broadcast(p.data, src=0)
+    return model.eval()
+
+
+def cache_kwargs(args):
+    # cache_configs/heavy_hitter.yaml of the reference: g=4, w=10, W=1, no thresholding
+    return dict(max_cache_length=[float(args.cache_len)], cache_bits=None, cache_length_pattern="tile",
+                cache_strategy=["heavy_hitter"], cache_strategy_pattern="tile", feed_long_prompts=False,
+                prompt_compression_strategy=["heavy_hitter"], global_tokens=4, recent_window=10, history_window_size=1,
+                attn_thresholding=False, min_recovery_frac=0.9)
+
+
+def roofline(model, args, dev):
+    """HBM roofline of the dominant kernel (decode_attn_split_kernel: streams K and V of one layer once).
+    achieved = algorithmic bytes per launch / mean launch duration, HIP events on the launch stream."""
+    from cold_compress_amd import _abi
+
+    layers = [l.attention for l in model.layers]
+    kv0 = layers[0].kv_cache
+    H, S, D = kv0.n_heads, kv0.max_cache_length, kv0.head_dim
+    HQ = layers[0].n_head
+    fns = _abi.lib()
+    nbytes = fns["cc_decode_attn_workspace_bytes"](HQ, H, S, D, 1)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    q = torch.randn(HQ, D, device=dev).to(torch.bfloat16)
+    y = torch.empty(HQ, D, device=dev, dtype=torch.bfloat16)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+
+    def launch(att, phases):
+        kv = att.kv_cache
+        rc = fns["cc_decode_attn_gqa_phases"](p(q), p(kv.k_cache), p(kv.v_cache), p(kv.mask), HQ, H, S, D, 1,
+                                               1.0 / math.sqrt(D), p(y), None, None, None, None, None, p(ws), nbytes, st, phases)
+        assert rc == 0, rc
+
+    for att in layers:  # warm
+        launch(att, 3)
+    torch.cuda.synchronize()
+    times = []
+    for _ in range(args.roofline_iters):
+        for att in layers:  # rotate over all layers' distinct K/V (32 x 16 MiB >> 256 MB Infinity Cache)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            launch(att, 1)
+            e1.record()
+            times.append((e0, e1))
+            launch(att, 2)
+    torch.cuda.synchronize()
+    us = sorted(a.elapsed_time(b) * 1e3 for a, b in times)
+    mean_us = sum(us) / len(us)
+    # algorithmic bytes of this launch: K and V once (2*H*S*D*2) + mask (H*S) + q; outputs (scores, partials) excluded
+    alg = 2 * H * S * D * 2 + H * S + HQ * D * 2
+    # whole layer-step bytes: K,V + 29 B/slot of heavy-hitter state
+    step_bytes = 2 * H * S * D * 2 + H * S * 29
+    ach = alg / (mean_us * 1e-6) / 1e9
+    return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "decode_attn_split_kernel<bf16,128,4,8,4>",
+            "bytes_per_launch": alg, "mean_us": round(mean_us, 3), "median_us": round(us[len(us) // 2], 3),
+            "min_us": round(us[0], 3), "launches": len(us), "layer_step_bytes": step_bytes}
+
+
+def layer_step_time(model, args, dev):
+    """Mean device time of one layer's full hot-path step (evict+insert, attention split+combine with the fused
+    history update) measured with one event pair around the three launches, rotating over layers."""
+    from cold_compress_amd.attention_utils import scaled_dot_product_attention as sdpa
+
+    layers = [l.attention for l in model.layers]
+    kv0 = layers[0].kv_cache
+    H, D, HQ = kv0.n_heads, kv0.head_dim, layers[0].n_head
+    q = torch.randn(1, HQ, 1, D, device=dev).to(torch.bfloat16)
+    k1 = torch.randn(1, H, 1, D, device=dev).to(torch.bfloat16)
+    pos = torch.tensor([args.prompt_len + 10_000], dtype=torch.int32, device=dev)
+    snap = [{k: v.clone() for k, v in a.kv_cache._buffers.items()} for a in layers]
+
+    def step(att):
+        kv = att.kv_cache
+        kc, vc, m = kv.update_kv(pos, k1, k1, False)
+        sdpa(q, kc, vc, attn_mask=m, group_mean=True, history=kv.fused_history())
+
+    for att in layers:
+        step(att)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        step(layers[0])
+    torch.cuda.current_stream().wait_stream(s)
+    with torch.cuda.graph(g):
+        for att in layers:
+            step(att)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = 10
+    e0.record()
+    for _ in range(n):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / (n * len(layers))
+    for a, sn in zip(layers, snap):
+        for k, v in sn.items():
+            a.kv_cache._buffers[k].copy_(v)
+    return us
+
+
+def cpu_baseline(args, H_total=8, HQ=32, D=128):
+    """The oracle (a scalar C port of the reference's algorithm) timed on ONE host core over a bounded sample:
+    `cpu_tokens` tokens x 32 layers of the heavy-hitter hot path (evict-select + insert + attention + history)
+    at the same cache length; excludes the dense GEMVs, so it flatters the CPU."""
+    import numpy as np
+
+    from oracle import oracle_lib as o
+
+    o.build()
+    S = args.cache_len
+    rng = np.random.default_rng(0)
+
+    def bf16(a):
+        return (a.astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
+
+    k = bf16(rng.standard_normal((H_total, S, D)))
+    v = bf16(rng.standard_normal((H_total, S, D)))
+    pos = np.stack([rng.permutation(S + 100)[:S] for _ in range(H_total)]).astype(np.int32)
+    mask = np.ones((H_total, S), np.uint8)
+    cts = np.array([S], np.int32)
+    num = rng.random((H_total, S))
+    denom = rng.integers(1, 100, (H_total, S)).astype(np.int32)
+    ctr = np.zeros(1, np.int64)
+    q = bf16(rng.standard_normal((HQ, D)))
+    k1 = bf16(rng.standard_normal((H_total, D)))
+    y = np.zeros((HQ, D), np.uint16)
+    idx = np.zeros(H_total, np.int64)
+    view = o.view(k, v, pos, mask, cts, 1)
+    n_layer_steps = args.cpu_tokens * 32
+    t0 = time.perf_counter()
+    for i in range(n_layer_steps):
+        p = np.array([S + 200 + i], np.int32)
+        o.call("cc_decode_update_heavy_hitter", C.byref(view), o.ptr(k1), o.ptr(k1), o.ptr(p), o.ptr(num), o.ptr(denom), 4, 10,
+               o.ptr(idx), None)
+        o.call("cc_decode_attn_gqa", o.ptr(q), o.ptr(k), o.ptr(v), o.ptr(mask), HQ, H_total, S, D, 1, 1.0 / math.sqrt(D),
+               o.ptr(y), None, None, o.ptr(num), o.ptr(denom), o.ptr(ctr), None, 0, None)
+    dt = time.perf_counter() - t0
+    return {"value": round(args.cpu_tokens / dt, 4), "unit": "tokens/s", "cores": 1, "kind": "port",
+            "sample": f"{args.cpu_tokens} tokens x 32 layers of the heavy-hitter hot path only (evict+insert+attention+"
+                      f"history, cache_len={S}, H=8, HQ=32, D=128, bf16) on 1 of {os.cpu_count()} host cores; dense "
+                      f"GEMVs excluded; {dt:.1f} s of CPU work"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from cold_compress_amd import _abi
+    from cold_compress_amd.harness import GraphedDecoder, decode_one_token, prefill, setup_caches
+
+    _abi.lib()  # fail loudly before anything else if the HIP extension is missing
+    model = build_model(args, world, dev)
+    max_seq = args.prompt_len + 2048  # BASELINE: 8k prompt -> 2k decode
+    setup_caches(model, None, dev, max_seq, cache_kwargs(args))
+
+    g = torch.Generator().manual_seed(1234)
+    prompt = torch.randint(0, model.config.vocab_size, (args.prompt_len,), generator=g, dtype=torch.int32).to(dev)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        tok, _ = prefill(model, prompt.view(1, -1), torch.arange(args.prompt_len, device=dev))
+        torch.cuda.synchronize()
+        prefill_s = time.perf_counter() - t0
+        pos = torch.tensor([args.prompt_len], dtype=torch.int32, device=dev)
+        cur = tok.view(1, 1).to(torch.int32)
+        mode = "hipgraph"
+        dec = decode_one_token
+        if not args.no_graph:
+            try:
+                dec = GraphedDecoder(model)
+                dec(model, cur, pos)  # captures (on a state snapshot) and runs the first step
+                pos += 1
+            except Exception as e:  # pragma: no cover - only if capture is refused (e.g. RCCL under capture)
+                print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); falling back to eager launches",
+                      file=sys.stderr)
+                dec, mode = decode_one_token, "eager"
+        else:
+            mode = "eager"
+
+        def run(n):
+            nonlocal cur
+            for _ in range(n):
+                nt, _ = dec(model, cur, pos)
+                cur = nt.view(1, 1)
+                pos.add_(1)
+
+        run(args.warmup)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(args.steps)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+
+        roof = step_us = None
+        cpu = None
+        if rank == 0:
+            roof = roofline(model, args, dev)
+            try:
+                step_us = layer_step_time(model, args, dev)
+            except Exception as e:  # pragma: no cover
+                print(f"[bench] layer-step timing skipped: {e}", file=sys.stderr)
+            if world == 1 and not args.no_cpu_baseline:
+                cpu = cpu_baseline(args)
+    if rank == 0:
+        kv0 = model.layers[0].attention.kv_cache
+        out = {
+            "metric": "decode tokens/sec, Llama-3-8B heavy_hitter cache=4096 (+ evict/attention kernel HBM GB/s in roofline)",
+            "value": round(args.steps / dt, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"Llama-3-8B shape (32 layers, HQ=32, H=8, D=128, bf16, random N(0,0.02) weights), "
+                                   f"cache_strategy=heavy_hitter, max_cache_length={kv0.max_cache_length}, "
+                                   f"{args.prompt_len}-token random prompt -> decode, batch 1, greedy",
+                       "parallelism": f"tp{world}", "decode_mode": mode, "n_layer": args.n_layer,
+                       "prefill_seconds": round(prefill_s, 2)},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        if step_us is not None and roof is not None:
+            out["layer_step"] = {"us": round(step_us, 3), "bytes": roof["layer_step_bytes"],
+                                 "frac_of_hbm_peak": round(roof["layer_step_bytes"] / (step_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                 "note": "evict+insert, attention split+combine with fused history; device time incl. launch gaps"}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,131 @@
+"""`scaled_dot_product_attention` behind the reference's signature (ref: attention_utils.py:8-54), executed
+by the HIP kernels in csrc/cc_attn_decode.hip (decode over the pruned cache) and csrc/cc_attn_prefill.hip
+(causal prefill).
+
+Differences from the reference that a caller can rely on:
+  * GQA-aware: `key`/`value` may carry H kv heads with H | HQ; nothing needs `repeat_interleave`
+    (model.py:399-400 materialises 4x K/V per step).  Pre-repeated inputs (H == HQ) work too.
+  * `group_mean=True` returns the probabilities already averaged over each query group, [1, H, 1, S]
+    (what model.py:413-418 computes next), instead of [1, HQ, 1, S].
+  * Prefill with `return_attn=True` returns an `AttnSummary` (column sums + observation-window mean) instead
+    of the [1, HQ, L, L] tensor; every policy in cache.py / prompt_compression.py consumes exactly that.
+  * `history=(num, denom, counter)` folds the heavy-hitter history update into the decode combine pass.
+Unsupported (raised loudly): dropout_p != 0, attn_top_k < 1, non-causal prefill masks.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _abi
+from ._abi import ColdCompressError
+from .prompt_compression import AttnSummary
+
+_DT = {torch.float32: _abi.CC_DT_F32, torch.bfloat16: _abi.CC_DT_BF16, torch.float16: _abi.CC_DT_F16}
+_WS = {}
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _workspace(nbytes, device):
+    """One grow-only scratch buffer per device (never freed mid-graph; sized by the ABI's query)."""
+    key = str(device)
+    ws = _WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
+        _WS[key] = ws
+    return ws
+
+
+def decode_attention(query, key, value, attn_mask=None, scale=None, return_attn=False, group_mean=False,
+                     history=None):
+    """query [1, HQ, 1, D]; key/value [1, H, S, D]; attn_mask bool [1, H or HQ, 1, S] or None."""
+    if not query.is_cuda:
+        raise ColdCompressError("decode attention needs ROCm device tensors (no CPU fallback)")
+    _, HQ, _, D = query.shape
+    _, H, S, _ = key.shape
+    if HQ % H:
+        raise ColdCompressError(f"query heads {HQ} not a multiple of kv heads {H}")
+    dt = query.dtype
+    if key.dtype != dt or value.dtype != dt:
+        raise ColdCompressError("q/k/v dtypes differ")
+    R = HQ // H
+    q = query.reshape(HQ, D).contiguous()
+    k = key if key.is_contiguous() else key.contiguous()
+    v = value if value.is_contiguous() else value.contiguous()
+    m = None
+    if attn_mask is not None:
+        m = attn_mask
+        if m.shape[1] == HQ and R > 1:
+            m = m[:, ::R]  # a caller that repeat_interleave'd the mask: every R-th row is the kv head's mask
+        m = m.reshape(H, S).contiguous()
+        if m.dtype != torch.bool:
+            raise ColdCompressError("attn_mask must be bool")
+    y = torch.empty((1, HQ, 1, D), dtype=dt, device=query.device)
+    attn = probs = None
+    if return_attn or history is not None:
+        if group_mean:
+            attn = torch.empty((1, H, 1, S), dtype=dt, device=query.device)
+        else:
+            probs = torch.empty((1, HQ, 1, S), dtype=dt, device=query.device)
+    nbytes = _abi.lib()["cc_decode_attn_workspace_bytes"](HQ, H, S, D, _DT[dt])
+    ws = _workspace(nbytes, query.device)
+    sc = 1.0 / math.sqrt(D) if scale is None else scale
+    hn = hd = hc = None
+    if history is not None:
+        hn, hd, hc = history
+    _abi.call("cc_decode_attn_gqa", _ptr(q), _ptr(k), _ptr(v), _ptr(m), HQ, H, S, D, _DT[dt], sc, _ptr(y), _ptr(attn),
+              _ptr(probs), _ptr(hn), _ptr(hd), _ptr(hc), _ptr(ws), ws.numel(), _stream())
+    return y, (attn if group_mean else probs) if return_attn else None
+
+
+def prefill_attention(query, key, value, scale=None, return_attn=False, obs_len=16):
+    """Causal attention, query [1, HQ, L, D], key/value [1, H, L, D]; side outputs as an AttnSummary."""
+    if not query.is_cuda:
+        raise ColdCompressError("prefill attention needs ROCm device tensors (no CPU fallback)")
+    _, HQ, L, D = query.shape
+    H = key.shape[1]
+    dt = query.dtype
+    q, k, v = query.contiguous(), key.contiguous(), value.contiguous()
+    y = torch.empty((1, HQ, L, D), dtype=dt, device=query.device)
+    colsum = obs = None
+    ol = min(obs_len, L)
+    if return_attn:
+        colsum = torch.empty((H, L), dtype=torch.float32, device=query.device)
+        obs = torch.empty((H, L), dtype=torch.float32, device=query.device)
+    nbytes = _abi.lib()["cc_prefill_attn_workspace_bytes"](HQ, H, L, D, _DT[dt])
+    ws = _workspace(nbytes, query.device)
+    sc = 1.0 / math.sqrt(D) if scale is None else scale
+    _abi.call("cc_prefill_attn", _ptr(q), _ptr(k), _ptr(v), HQ, H, L, D, _DT[dt], sc, _ptr(y), _ptr(colsum), _ptr(obs),
+              ol, _ptr(ws), ws.numel(), _stream())
+    return y, (AttnSummary(colsum, obs, ol, dt) if return_attn else None)
+
+
+def _is_causal_mask(attn_mask, L):
+    if attn_mask is None or attn_mask.shape[-2:] != (L, L) or attn_mask.dtype != torch.bool:
+        return False
+    tril = torch.ones(L, L, dtype=torch.bool, device=attn_mask.device).tril_()
+    return bool((attn_mask.reshape(-1, L, L) == tril).all())
+
+
+def scaled_dot_product_attention(query, key, value, attn_mask=None, dropout_p=0.0, scale=None, return_attn=False,
+                                 attn_top_k=1.0, group_mean=False, history=None, is_causal=None):
+    """ref: attention_utils.py:8-54 (same positional/keyword surface; extra keywords documented above)."""
+    if dropout_p != 0.0:
+        raise ColdCompressError("dropout is not part of the inference path")
+    L, S = query.size(-2), key.size(-2)
+    if L == 1:
+        if int(attn_top_k * S) != S:
+            raise NotImplementedError("attn_top_k < 1 is a SURVEY §8(f) follow-up and not built yet")
+        return decode_attention(query, key, value, attn_mask, scale, return_attn, group_mean, history)
+    if is_causal is None:
+        is_causal = _is_causal_mask(attn_mask, L)
+    if not is_causal or L != S:
+        raise ColdCompressError("prefill attention supports the causal [L, L] mask of generation_utils.py:153-158 only")
+    return prefill_attention(query, key, value, scale, return_attn)

@@ -1,0 +1,387 @@
+// cc_attn_decode.hip — decode attention over the pruned cache for gfx950, GQA-aware, split along the cache
+// axis ("flash-decode"): K and V are read from HBM exactly once, with no repeat_interleave.
+//
+// ref: model.py:395-418 (GQA glue, group mean of the probabilities) + attention_utils.py:27-54.
+//
+// Kernel 1 (split): grid (n_split, H, R/RT) workgroups of NW waves.  A K/V row of D elements is 16-byte
+//   chunks over LPR = D*sizeof(T)/16 lanes, so one wave-wide 16-byte load covers 64/LPR whole rows, fully
+//   coalesced along [H, S, D].  Every lane issues all of its K and V loads for the iteration (2*U x 16 B)
+//   before the first use, so the whole 2*H*S*D*sizeof(T) bytes of the layer are in flight at once.  The
+//   q.k dot products are reduced across the LPR lanes with __shfl_xor; softmax statistics are kept online
+//   per wave, combined across waves through LDS, and one (m, l, O[RT][D]) partial per workgroup goes to the
+//   workspace together with the dtype-rounded scores.
+// Kernel 2 (combine): merges the partials into y, turns scores into probabilities with the final (M, L),
+//   averages them over the R query heads of the group, and optionally applies the heavy-hitter history
+//   update (cache.py:690-723) in the same pass.
+// HBM-bound: ~1 flop/byte, no MFMA.
+#include "cc_common.h"
+
+namespace {
+
+struct SplitArgs {
+  const void* q;
+  const void* k;
+  const void* v;
+  const uint8_t* mask;
+  void* scores;    // [HQ, S] T
+  float* part_ml;  // [HQ, n_split, 2]
+  float* part_o;   // [HQ, n_split, D]
+  int S, R, n_split, rows_per_split;
+  float scale;
+};
+
+template <typename T, int D, int RT, int NW, int U>
+__global__ __launch_bounds__(NW * 64) void decode_attn_split_kernel(SplitArgs a) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  constexpr int LPR = D / VEC;
+  static_assert(LPR >= 1 && LPR <= 64 && (LPR & (LPR - 1)) == 0, "head_dim must map to a power-of-two lane count");
+  constexpr int RPW = 64 / LPR;
+  __shared__ float sm_m[NW][RT];
+  __shared__ float sm_l[NW][RT];
+  __shared__ __attribute__((aligned(16))) float sm_acc[NW][RT][D];
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lr = lane / LPR, lc = lane % LPR;
+  const int split = blockIdx.x, h = blockIdx.y, q0 = h * a.R + blockIdx.z * RT;
+  const int S = a.S;
+  const int row_begin = split * a.rows_per_split;
+  const int row_end = min(S, row_begin + a.rows_per_split);
+  const T* kh = reinterpret_cast<const T*>(a.k) + (size_t)h * S * D + lc * VEC;
+  const T* vh = reinterpret_cast<const T*>(a.v) + (size_t)h * S * D + lc * VEC;
+  const uint8_t* mh = a.mask ? a.mask + (size_t)h * S : nullptr;
+  T* sc_out = reinterpret_cast<T*>(a.scores);
+
+  float qf[RT][VEC];
+#pragma unroll
+  for (int r = 0; r < RT; r++) {
+    Vec16<T> t;
+    t.load(reinterpret_cast<const T*>(a.q) + (size_t)(q0 + r) * D + lc * VEC);
+    t.unpack(qf[r]);
+  }
+  float m[RT], l[RT], acc[RT][VEC];
+#pragma unroll
+  for (int r = 0; r < RT; r++) {
+    m[r] = -INFINITY;
+    l[r] = 0.f;
+#pragma unroll
+    for (int e = 0; e < VEC; e++) acc[r][e] = 0.f;
+  }
+
+  for (int base = row_begin + wave * (RPW * U); base < row_end; base += NW * RPW * U) {
+    Vec16<T> kk[U], vv[U];
+    bool valid[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int row = base + u * RPW + lr;
+      const int rc = row < row_end ? row : row_end - 1;
+      kk[u].load(kh + (size_t)rc * D);
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int row = base + u * RPW + lr;
+      const int rc = row < row_end ? row : row_end - 1;
+      vv[u].load(vh + (size_t)rc * D);
+      valid[u] = (row < row_end) && (mh ? mh[rc] != 0 : true);
+    }
+    float s[RT][U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      float kf[VEC];
+      kk[u].unpack(kf);
+      const int row = base + u * RPW + lr;
+#pragma unroll
+      for (int r = 0; r < RT; r++) {
+        float d = 0.f;
+#pragma unroll
+        for (int e = 0; e < VEC; e++) d = fmaf(qf[r][e], kf[e], d);
+#pragma unroll
+        for (int off = LPR / 2; off > 0; off >>= 1) d += __shfl_xor(d, off, CC_WAVE);
+        // ref: attention_utils.py:37 (q@k^T -> dtype, * scale -> dtype), :42-43 (-inf bias where masked)
+        float x = ElemTraits<T>::rnd(ElemTraits<T>::rnd(d) * a.scale);
+        if (!valid[u]) x = -INFINITY;
+        s[r][u] = x;
+        if (lc == 0 && row < row_end) ElemTraits<T>::store(sc_out, (size_t)(q0 + r) * S + row, x);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < RT; r++) {
+      float mx = s[r][0];
+#pragma unroll
+      for (int u = 1; u < U; u++) mx = fmaxf(mx, s[r][u]);
+#pragma unroll
+      for (int off = LPR; off < 64; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off, CC_WAVE));
+      const float m_new = fmaxf(m[r], mx);
+      const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+      const float alpha = expf(m[r] - m_use);
+      l[r] *= alpha;
+#pragma unroll
+      for (int e = 0; e < VEC; e++) acc[r][e] *= alpha;
+      m[r] = m_new;
+#pragma unroll
+      for (int u = 0; u < U; u++) s[r][u] = expf(s[r][u] - m_use);
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      float vf[VEC];
+      vv[u].unpack(vf);
+#pragma unroll
+      for (int r = 0; r < RT; r++) {
+        const float p = s[r][u];
+        l[r] += p;
+#pragma unroll
+        for (int e = 0; e < VEC; e++) acc[r][e] = fmaf(p, vf[e], acc[r][e]);
+      }
+    }
+  }
+
+  // wave totals: sum the 64/LPR row groups
+#pragma unroll
+  for (int r = 0; r < RT; r++) {
+#pragma unroll
+    for (int off = LPR; off < 64; off <<= 1) {
+      l[r] += __shfl_xor(l[r], off, CC_WAVE);
+#pragma unroll
+      for (int e = 0; e < VEC; e++) acc[r][e] += __shfl_xor(acc[r][e], off, CC_WAVE);
+    }
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int r = 0; r < RT; r++) {
+      sm_m[wave][r] = m[r];
+      sm_l[wave][r] = l[r];
+    }
+  }
+  if (lr == 0) {
+#pragma unroll
+    for (int r = 0; r < RT; r++)
+#pragma unroll
+      for (int e = 0; e < VEC; e++) sm_acc[wave][r][lc * VEC + e] = acc[r][e];
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < RT * D; t += NW * 64) {
+    const int r = t / D, d = t - r * D;
+    float M = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < NW; w++) M = fmaxf(M, sm_m[w][r]);
+    const float Mu = (M == -INFINITY) ? 0.f : M;
+    float L = 0.f, O = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+      const float f = expf(sm_m[w][r] - Mu);
+      L = fmaf(sm_l[w][r], f, L);
+      O = fmaf(sm_acc[w][r][d], f, O);
+    }
+    const size_t pj = (size_t)(q0 + r) * a.n_split + split;
+    a.part_o[pj * D + d] = O;
+    if (d == 0) {
+      a.part_ml[pj * 2 + 0] = M;
+      a.part_ml[pj * 2 + 1] = L;
+    }
+  }
+}
+
+struct CombineArgs {
+  const void* scores;
+  const float* part_ml;
+  const float* part_o;
+  void* y;
+  void* attn_out;
+  void* probs_out;
+  double* hh_num;
+  int32_t* hh_denom;
+  int64_t* hh_counter;
+  int S, R, D, n_split, chunk;
+};
+
+constexpr int kMaxR = 64;
+
+template <typename T>
+__global__ __launch_bounds__(256) void decode_attn_combine_kernel(CombineArgs a) {
+  __shared__ float sm_M[kMaxR], sm_L[kMaxR];
+  const int h = blockIdx.y, c = blockIdx.x, nchunks = gridDim.x;
+  const int R = a.R, S = a.S, D = a.D, ns = a.n_split;
+  if (threadIdx.x < R) {
+    const int j = h * R + threadIdx.x;
+    float M = -INFINITY;
+    for (int i = 0; i < ns; i++) M = fmaxf(M, a.part_ml[((size_t)j * ns + i) * 2]);
+    const float Mu = (M == -INFINITY) ? 0.f : M;
+    float L = 0.f;
+    for (int i = 0; i < ns; i++) {
+      const float* ml = a.part_ml + ((size_t)j * ns + i) * 2;
+      L = fmaf(ml[1], expf(ml[0] - Mu), L);
+    }
+    sm_M[threadIdx.x] = Mu;
+    sm_L[threadIdx.x] = L;
+  }
+  __syncthreads();
+
+  // y: the R*D outputs of this kv head are spread over the chunk blocks
+  {
+    const int total = R * D;
+    const int per = (total + nchunks - 1) / nchunks;
+    const int lo = c * per, hi = min(total, lo + per);
+    for (int t = lo + threadIdx.x; t < hi; t += blockDim.x) {
+      const int r = t / D, d = t - r * D, j = h * R + r;
+      float O = 0.f;
+      for (int i = 0; i < ns; i++) {
+        const size_t pj = (size_t)j * ns + i;
+        O = fmaf(a.part_o[pj * D + d], expf(a.part_ml[pj * 2] - sm_M[r]), O);
+      }
+      ElemTraits<T>::store(reinterpret_cast<T*>(a.y), (size_t)j * D + d, O / sm_L[r]);
+    }
+  }
+
+  // probabilities for this chunk of slots
+  const T* sc = reinterpret_cast<const T*>(a.scores);
+  const int s_lo = c * a.chunk, s_hi = min(S, s_lo + a.chunk);
+  const float invR = 1.0f / (float)R;
+  (void)invR;
+  for (int s = s_lo + threadIdx.x; s < s_hi; s += blockDim.x) {
+    float sum = 0.f;
+    for (int r = 0; r < R; r++) {
+      const size_t j = (size_t)h * R + r;
+      const float x = ElemTraits<T>::load(sc, j * S + s);
+      // ref: attention_utils.py:52 softmax (fp32 inside, result rounded to the model dtype)
+      const float p = ElemTraits<T>::rnd(__fdiv_rn(expf(x - sm_M[r]), sm_L[r]));
+      if (a.probs_out) ElemTraits<T>::store(reinterpret_cast<T*>(a.probs_out), j * S + s, p);
+      sum += p;
+    }
+    // ref: model.py:416-418 mean over the R query heads of the group -> model dtype
+    const float av = ElemTraits<T>::rnd(__fdiv_rn(sum, (float)R));
+    const size_t i = (size_t)h * S + s;
+    if (a.attn_out) ElemTraits<T>::store(reinterpret_cast<T*>(a.attn_out), i, av);
+    if (a.hh_num) {  // fused cache.py:716-722 (W == 1, attention already padded to S)
+      a.hh_num[i] += (double)av;
+      a.hh_denom[i] += 1;
+    }
+  }
+  if (a.hh_num && a.hh_counter && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *a.hh_counter += 1;
+}
+
+// ---------------------------------------------------------------- launch plan
+constexpr int kNW = 8;  // waves per split workgroup
+constexpr int kU = 4;   // 16-byte K loads (and V loads) in flight per lane
+
+struct Plan {
+  int n_split, rows_per_split, rt, chunk, n_chunks;
+};
+
+static int rows_per_iter(int D, int dtype) {
+  const int vec = 16 / (int)cc_dt_size(dtype);
+  const int lpr = D / vec;
+  return (64 / lpr) * kU * kNW;
+}
+
+static Plan make_plan(int HQ, int H, int S, int D, int dtype) {
+  Plan p;
+  const int R = HQ / H;
+  p.rt = (R % 4 == 0) ? 4 : (R % 2 == 0) ? 2 : 1;
+  const int rpi = rows_per_iter(D, dtype);
+  // one iteration per workgroup when that keeps the grid at >= ~256 workgroups; otherwise grow the chunk
+  int ns = (S + rpi - 1) / rpi;
+  const int max_split = 64;
+  if (ns > max_split) ns = max_split;
+  if (ns < 1) ns = 1;
+  int rps = (S + ns - 1) / ns;
+  rps = ((rps + rpi - 1) / rpi) * rpi;
+  ns = (S + rps - 1) / rps;
+  p.n_split = ns;
+  p.rows_per_split = rps;
+  p.chunk = 256;
+  p.n_chunks = (S + p.chunk - 1) / p.chunk;
+  return p;
+}
+
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+template <typename T, int D>
+static int launch_split_rt(const SplitArgs& a, const Plan& p, int H, int R, hipStream_t st) {
+  dim3 grid(p.n_split, H, R / p.rt), block(kNW * 64);
+  switch (p.rt) {
+    case 4: hipLaunchKernelGGL((decode_attn_split_kernel<T, D, 4, kNW, kU>), grid, block, 0, st, a); break;
+    case 2: hipLaunchKernelGGL((decode_attn_split_kernel<T, D, 2, kNW, kU>), grid, block, 0, st, a); break;
+    default: hipLaunchKernelGGL((decode_attn_split_kernel<T, D, 1, kNW, kU>), grid, block, 0, st, a); break;
+  }
+  CC_LAUNCH_CHECK();
+  return CC_OK;
+}
+
+template <typename T>
+static int launch_split(const SplitArgs& a, const Plan& p, int H, int R, int D, hipStream_t st) {
+  switch (D) {
+    case 16: return launch_split_rt<T, 16>(a, p, H, R, st);
+    case 32: return launch_split_rt<T, 32>(a, p, H, R, st);
+    case 64: return launch_split_rt<T, 64>(a, p, H, R, st);
+    case 128: return launch_split_rt<T, 128>(a, p, H, R, st);
+    default: break;
+  }
+  return CC_ERR_UNSUPPORTED;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t cc_decode_attn_workspace_bytes(int32_t HQ, int32_t H, int32_t S, int32_t D, int32_t dtype) {
+  if (HQ <= 0 || H <= 0 || HQ % H || S <= 0 || D <= 0 || !cc_dt_ok(dtype)) return 0;
+  const Plan p = make_plan(HQ, H, S, D, dtype);
+  return align256((size_t)HQ * S * cc_dt_size(dtype)) + align256((size_t)HQ * p.n_split * 2 * sizeof(float)) +
+         align256((size_t)HQ * p.n_split * D * sizeof(float));
+}
+
+int cc_decode_attn_gqa_phases(const void* q, const void* k, const void* v, const uint8_t* mask, int32_t HQ, int32_t H,
+                              int32_t S, int32_t D, int32_t dtype, float scale, void* y, void* attn_out,
+                              void* probs_out, double* hh_num, int32_t* hh_denom, int64_t* hh_counter,
+                              void* workspace, size_t workspace_bytes, cc_stream_t stream, int32_t phases) {
+  if (!q || !k || !v || !y || HQ <= 0 || H <= 0 || HQ % H || S <= 0 || D <= 0 || !cc_dt_ok(dtype) || !workspace)
+    return CC_ERR_BAD_ARG;
+  if (hh_num && !hh_denom) return CC_ERR_BAD_ARG;
+  const int R = HQ / H;
+  if (R > kMaxR) return CC_ERR_UNSUPPORTED;
+  if (D != 16 && D != 32 && D != 64 && D != 128) return CC_ERR_UNSUPPORTED;
+  if (workspace_bytes < cc_decode_attn_workspace_bytes(HQ, H, S, D, dtype)) return CC_ERR_WORKSPACE;
+  const Plan p = make_plan(HQ, H, S, D, dtype);
+  char* ws = reinterpret_cast<char*>(workspace);
+  SplitArgs sa{};
+  sa.q = q; sa.k = k; sa.v = v; sa.mask = mask;
+  sa.scores = ws;
+  ws += align256((size_t)HQ * S * cc_dt_size(dtype));
+  sa.part_ml = reinterpret_cast<float*>(ws);
+  ws += align256((size_t)HQ * p.n_split * 2 * sizeof(float));
+  sa.part_o = reinterpret_cast<float*>(ws);
+  sa.S = S; sa.R = R; sa.n_split = p.n_split; sa.rows_per_split = p.rows_per_split; sa.scale = scale;
+  hipStream_t st = (hipStream_t)stream;
+  int rc = CC_OK;
+  if (phases & 1) {
+    switch (dtype) {
+      case CC_DT_F32: rc = launch_split<float>(sa, p, H, R, D, st); break;
+      case CC_DT_BF16: rc = launch_split<bf16_t>(sa, p, H, R, D, st); break;
+      default: rc = launch_split<f16_t>(sa, p, H, R, D, st); break;
+    }
+  }
+  if (rc != CC_OK) return rc;
+  if (!(phases & 2)) return CC_OK;
+  CombineArgs ca{};
+  ca.scores = sa.scores; ca.part_ml = sa.part_ml; ca.part_o = sa.part_o;
+  ca.y = y; ca.attn_out = attn_out; ca.probs_out = probs_out;
+  ca.hh_num = hh_num; ca.hh_denom = hh_denom; ca.hh_counter = hh_counter;
+  ca.S = S; ca.R = R; ca.D = D; ca.n_split = p.n_split; ca.chunk = p.chunk;
+  dim3 grid(p.n_chunks, H), block(256);
+  switch (dtype) {
+    case CC_DT_F32: hipLaunchKernelGGL(decode_attn_combine_kernel<float>, grid, block, 0, st, ca); break;
+    case CC_DT_BF16: hipLaunchKernelGGL(decode_attn_combine_kernel<bf16_t>, grid, block, 0, st, ca); break;
+    default: hipLaunchKernelGGL(decode_attn_combine_kernel<f16_t>, grid, block, 0, st, ca); break;
+  }
+  CC_LAUNCH_CHECK();
+  return CC_OK;
+}
+
+int cc_decode_attn_gqa(const void* q, const void* k, const void* v, const uint8_t* mask, int32_t HQ, int32_t H,
+                       int32_t S, int32_t D, int32_t dtype, float scale, void* y, void* attn_out, void* probs_out,
+                       double* hh_num, int32_t* hh_denom, int64_t* hh_counter, void* workspace,
+                       size_t workspace_bytes, cc_stream_t stream) {
+  return cc_decode_attn_gqa_phases(q, k, v, mask, HQ, H, S, D, dtype, scale, y, attn_out, probs_out, hh_num, hh_denom,
+                                   hh_counter, workspace, workspace_bytes, stream, 3);
+}
+
+}  // extern "C"

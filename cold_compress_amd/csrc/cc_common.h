@@ -1,0 +1,172 @@
+// cc_common.h — device helpers shared by the gfx950 kernels (wave64, CDNA4 only; no CUDA paths).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/coldcompress.h"
+
+#define CC_WAVE 64
+
+// ------------------------------------------------------------------ element types
+struct bf16_t {
+  uint16_t x;
+};
+struct f16_t {
+  uint16_t x;
+};
+
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t h) { return __uint_as_float(h << 16); }
+
+// round-to-nearest-even with quiet-NaN preservation; bit-identical to oracle/cc_oracle.c f32_to_bf16
+__device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return 0x7fc0;
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+__device__ __forceinline__ float f16_bits_to_f32(uint16_t h) {
+  _Float16 v;
+  __builtin_memcpy(&v, &h, 2);
+  return (float)v;
+}
+__device__ __forceinline__ uint16_t f32_to_f16_bits(float f) {
+  _Float16 v = (_Float16)f;  // v_cvt_f16_f32: round-to-nearest-even
+  uint16_t h;
+  __builtin_memcpy(&h, &v, 2);
+  return h;
+}
+
+template <typename T>
+struct ElemTraits;
+template <>
+struct ElemTraits<float> {
+  static constexpr int code = CC_DT_F32;
+  __device__ static __forceinline__ float load(const float* p, size_t i) { return p[i]; }
+  __device__ static __forceinline__ void store(float* p, size_t i, float v) { p[i] = v; }
+  __device__ static __forceinline__ float rnd(float v) { return v; }
+};
+template <>
+struct ElemTraits<bf16_t> {
+  static constexpr int code = CC_DT_BF16;
+  __device__ static __forceinline__ float load(const bf16_t* p, size_t i) { return bf16_bits_to_f32(p[i].x); }
+  __device__ static __forceinline__ void store(bf16_t* p, size_t i, float v) { p[i].x = f32_to_bf16_bits(v); }
+  __device__ static __forceinline__ float rnd(float v) { return bf16_bits_to_f32(f32_to_bf16_bits(v)); }
+};
+template <>
+struct ElemTraits<f16_t> {
+  static constexpr int code = CC_DT_F16;
+  __device__ static __forceinline__ float load(const f16_t* p, size_t i) { return f16_bits_to_f32(p[i].x); }
+  __device__ static __forceinline__ void store(f16_t* p, size_t i, float v) { p[i].x = f32_to_f16_bits(v); }
+  __device__ static __forceinline__ float rnd(float v) { return f16_bits_to_f32(f32_to_f16_bits(v)); }
+};
+
+// 16-byte vector of T, unpacked to floats
+template <typename T>
+struct Vec16 {
+  static constexpr int N = 16 / sizeof(T);
+  uint4 raw;
+  __device__ __forceinline__ void load(const T* p) { raw = *reinterpret_cast<const uint4*>(p); }
+  __device__ __forceinline__ void unpack(float* out) const;
+};
+template <>
+__device__ __forceinline__ void Vec16<float>::unpack(float* o) const {
+  o[0] = __uint_as_float(raw.x);
+  o[1] = __uint_as_float(raw.y);
+  o[2] = __uint_as_float(raw.z);
+  o[3] = __uint_as_float(raw.w);
+}
+template <>
+__device__ __forceinline__ void Vec16<bf16_t>::unpack(float* o) const {
+  const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    o[2 * i] = __uint_as_float(w[i] << 16);
+    o[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+  }
+}
+template <>
+__device__ __forceinline__ void Vec16<f16_t>::unpack(float* o) const {
+  const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    o[2 * i] = f16_bits_to_f32((uint16_t)(w[i] & 0xffffu));
+    o[2 * i + 1] = f16_bits_to_f32((uint16_t)(w[i] >> 16));
+  }
+}
+
+// ------------------------------------------------------------------ torch.argmin ordering as a 64-bit key
+// key = (orderable(value) << 32) | slot ; min over keys == first index of the minimum.
+// NaN maps to 0 (torch.argmin returns the first NaN); -0.0 is canonicalised to +0.0 (they compare equal).
+__device__ __forceinline__ uint32_t orderable_f32(float f) {
+  if (f != f) return 0u;
+  if (f == 0.0f) f = 0.0f;
+  uint32_t u = __float_as_uint(f);
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  return u == 0u ? 1u : u;  // keep 0 reserved for NaN (only ~0x ffffffff = -NaN pattern could hit it)
+}
+__device__ __forceinline__ uint32_t orderable_i32(int32_t v) { return (uint32_t)v ^ 0x80000000u; }
+
+__device__ __forceinline__ unsigned long long make_key(uint32_t ord, uint32_t slot) {
+  return ((unsigned long long)ord << 32) | slot;
+}
+
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    unsigned long long o = __shfl_xor(v, off, CC_WAVE);
+    v = o < v ? o : v;
+  }
+  return v;
+}
+
+__device__ __forceinline__ float wave_max_f32(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, CC_WAVE));
+  return v;
+}
+
+// Block-wide min of 64-bit keys; result valid in every thread.  `sm` needs blockDim.x/64 + 1 slots.
+__device__ __forceinline__ unsigned long long block_min_u64(unsigned long long v, unsigned long long* sm) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  v = wave_min_u64(v);
+  if (lane == 0) sm[wave] = v;
+  __syncthreads();
+  if (wave == 0) {
+    unsigned long long x = lane < nw ? sm[lane] : ~0ull;
+    x = wave_min_u64(x);
+    if (lane == 0) sm[nw] = x;
+  }
+  __syncthreads();
+  return sm[nw];
+}
+
+// Canonical sum of squares of a D-vector, evaluated by 16 cooperating lanes (lane16 = 0..15 of an aligned
+// 16-lane group): a_j = sum_i x[j+16i]^2 (sequential in i; separate multiply and add, no fma), then the
+// butterfly a_j += a_{j^8}, ^4, ^2, ^1.  oracle/cc_oracle.c sumsq_canonical() evaluates the same order,
+// so row norms are bit-identical between device and oracle (the reference's own order is unspecified).
+template <typename T>
+__device__ __forceinline__ float sumsq_canonical_16(const T* x, int D, int lane16) {
+  float a = 0.f;
+  for (int d = lane16; d < D; d += 16) {
+    float e = ElemTraits<T>::load(x, d);
+    float sq = __fmul_rn(e, e);
+    a = __fadd_rn(a, sq);
+  }
+#pragma unroll
+  for (int off = 8; off > 0; off >>= 1) a = __fadd_rn(a, __shfl_xor(a, off, 16));
+  return a;
+}
+
+#define CC_LAUNCH_CHECK()                               \
+  do {                                                  \
+    if (hipGetLastError() != hipSuccess) return CC_ERR_HIP; \
+  } while (0)
+
+static inline int cc_dt_ok(int dt) { return dt == CC_DT_F32 || dt == CC_DT_BF16 || dt == CC_DT_F16; }
+static inline size_t cc_dt_size(int dt) { return dt == CC_DT_F32 ? 4 : 2; }
+static inline int cc_view_ok(const cc_kv_view* c) {
+  return c && c->k_cache && c->v_cache && c->pos && c->mask && c->cache_cts && c->H > 0 && c->S > 0 && c->D > 0 &&
+         (c->Hp == 1 || c->Hp == c->H) && (c->Hc == 1 || c->Hc == c->H) && cc_dt_ok(c->dtype) &&
+         ((size_t)c->D * cc_dt_size(c->dtype)) % 4 == 0;
+}

@@ -1,0 +1,375 @@
+// cc_evict.hip — decode-time update_kv for every eviction policy: per-head importance scan, arg-min with
+// torch's tie rules, in-place KV insert; plus the heavy-hitter history update, the prefill fill and row
+// L2 norms.  gfx950 (wave64).  HBM-bound integer/byte work: coalesced scans, wave shuffles + one LDS hop
+// for the cross-wave arg-min; no MFMA.
+//
+// One workgroup of 1024 threads (16 waves) per "pos head" (Hp = H for head-specific policies, 1 otherwise):
+// each thread scans S/1024 slots with all of its loads issued before the first use, reduces a 64-bit
+// (orderable score, slot) key with __shfl_xor, one LDS hop across waves, then the same workgroup inserts
+// the new token so that select+insert is a single launch (cache.py does it in ~10).
+#include "cc_common.h"
+
+namespace {
+
+enum Policy { P_FULL = 0, P_RECENT_GLOBAL = 1, P_SCORES = 2, P_RANDOM = 3, P_L2 = 4, P_HH = 5 };
+
+struct UpdArgs {
+  void* k_cache;
+  void* v_cache;
+  int32_t* pos;
+  uint8_t* mask;
+  int32_t* cache_cts;
+  int H, Hp, Hc, S, D;
+  const void* k_new;
+  const void* v_new;
+  const int32_t* input_pos;
+  int64_t* idx_out;
+  int g, w;
+  const void* scores;    // P_SCORES: [Hs,S] score dtype ; P_RANDOM: [S] f32
+  int score_heads;       // rows in `scores`
+  void* key_norm;        // P_L2: [H,S] T
+  double* num;           // P_HH
+  int32_t* denom;        // P_HH
+};
+
+constexpr int kUpdThreads = 1024;
+
+// Insert the new token for kv-head h at slot idx (all threads of the block participate).
+template <typename T>
+__device__ __forceinline__ void insert_row(const UpdArgs& a, int h, int idx) {
+  const int words = a.D * (int)sizeof(T) / 4;
+  const uint32_t* ks = reinterpret_cast<const uint32_t*>(a.k_new) + (size_t)h * words;
+  const uint32_t* vs = reinterpret_cast<const uint32_t*>(a.v_new) + (size_t)h * words;
+  uint32_t* kd = reinterpret_cast<uint32_t*>(a.k_cache) + ((size_t)h * a.S + idx) * words;
+  uint32_t* vd = reinterpret_cast<uint32_t*>(a.v_cache) + ((size_t)h * a.S + idx) * words;
+  for (int i = threadIdx.x; i < 2 * words; i += blockDim.x) {
+    if (i < words) kd[i] = ks[i];
+    else vd[i - words] = vs[i - words];
+  }
+  if (threadIdx.x == 0) a.mask[(size_t)h * a.S + idx] = 1;
+}
+
+template <int POLICY, typename T, typename ST>
+__global__ __launch_bounds__(kUpdThreads) void decode_update_kernel(UpdArgs a) {
+  __shared__ unsigned long long sm_key[kUpdThreads / 64 + 2];
+  __shared__ float sm_f[kUpdThreads / 64 + 2];
+  const int hp = blockIdx.x;
+  const int S = a.S;
+  const int32_t* pos = a.pos + (size_t)hp * S;
+  const int32_t p = *a.input_pos;
+
+  float gmax = 0.f;
+  if (POLICY == P_L2) {
+    // ref: cache.py:602 `self.key_norm.max()` over ALL heads and slots (each workgroup recomputes it from
+    // L2: H*S*2 bytes); NaN propagates like torch.max.
+    const T* kn = reinterpret_cast<const T*>(a.key_norm);
+    float m = -INFINITY;
+    int nan = 0;
+    const int n = a.H * S;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      float v = ElemTraits<T>::load(kn, i);
+      nan |= (v != v);
+      m = fmaxf(m, v);
+    }
+    m = wave_max_f32(m);
+    nan = __any(nan);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) sm_f[wave] = nan ? NAN : m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float mm = -INFINITY;
+      int nn = 0;
+      for (int i = 0; i < kUpdThreads / 64; i++) {
+        float v = sm_f[i];
+        nn |= (v != v);
+        mm = fmaxf(mm, v);
+      }
+      sm_f[kUpdThreads / 64] = nn ? NAN : mm;
+    }
+    __syncthreads();
+    gmax = sm_f[kUpdThreads / 64];
+  }
+
+  unsigned long long best = ~0ull;
+  for (int s = threadIdx.x; s < S; s += blockDim.x) {
+    const int32_t ps = pos[s];
+    uint32_t ord;
+    if (POLICY == P_FULL) {
+      ord = orderable_i32(ps);  // ref: cache.py:502 pos.argmin()
+    } else if (POLICY == P_RECENT_GLOBAL) {
+      if (s < a.g) continue;  // ref: cache.py:554 argmin(pos[:, :, g:]) + g
+      ord = orderable_i32(ps);
+    } else {
+      float sc;
+      if (POLICY == P_SCORES) {
+        sc = ElemTraits<ST>::load(reinterpret_cast<const ST*>(a.scores), (size_t)(a.score_heads == 1 ? 0 : hp) * S + s);
+      } else if (POLICY == P_RANDOM) {
+        sc = reinterpret_cast<const float*>(a.scores)[s];
+        if (ps >= p - a.w) sc = INFINITY;  // ref: cache.py:523
+      } else if (POLICY == P_L2) {
+        // ref: cache.py:601-605 — model-dtype subtraction (fp32 op, rounded to T), recent window -> +inf
+        sc = ElemTraits<T>::rnd(gmax - ElemTraits<T>::load(reinterpret_cast<const T*>(a.key_norm), (size_t)hp * S + s));
+        if (ps >= p - a.w) sc = INFINITY;
+      } else {  // P_HH, ref: cache.py:727-749
+        const double nm = a.num[(size_t)hp * S + s];
+        int32_t dn = a.denom[(size_t)hp * S + s];
+        dn = dn < 1 ? 1 : dn;
+        sc = __fdiv_rn((float)nm, (float)dn);  // f64->f32 RNE, int32->f32, IEEE divide
+        if (ps < a.g || ps >= p - a.w) sc = 1.0f;
+        if (ps == -1) sc = 0.0f;
+      }
+      if (POLICY != P_HH) {
+        // ref: cache.py:373-376 base rules: first g SLOTS -> +inf, then empty slots -> -inf
+        if (s < a.g) sc = INFINITY;
+        if (ps == -1) sc = -INFINITY;
+      }
+      ord = orderable_f32(sc);
+    }
+    const unsigned long long key = make_key(ord, (uint32_t)s);
+    best = key < best ? key : best;
+  }
+  best = block_min_u64(best, sm_key);
+  const int idx = (int)(best & 0xffffffffull);
+  if (threadIdx.x == 0) a.idx_out[hp] = idx;
+
+  if (POLICY == P_HH && threadIdx.x == 0) {  // ref: cache.py:754-763 (part of _eviction_idx itself)
+    a.num[(size_t)hp * S + idx] = 0.0;
+    a.denom[(size_t)hp * S + idx] = 0;
+  }
+  if (a.k_new == nullptr) return;  // select only
+
+  // ---- insert (ref: cache.py:356-362, 390-401, 460-490, 330)
+  if (threadIdx.x == 0) {
+    const int32_t old = pos[idx];
+    a.pos[(size_t)hp * S + idx] = p;
+    const int ins = (old == -1);
+    if (a.Hp == 1) {
+      for (int j = 0; j < a.Hc; j++) a.cache_cts[j] += ins;
+    } else if (a.Hc == a.Hp) {
+      a.cache_cts[hp] += ins;
+    } else if (hp == 0) {
+      a.cache_cts[0] += ins;  // num_insertions[:1]
+    }
+  }
+  if (a.Hp == 1) {
+    for (int h = 0; h < a.H; h++) insert_row<T>(a, h, idx);
+  } else {
+    insert_row<T>(a, hp, idx);
+  }
+  if (POLICY == P_L2 && threadIdx.x < 16) {  // ref: cache.py:592-593
+    const float ss = sumsq_canonical_16<T>(reinterpret_cast<const T*>(a.k_new) + (size_t)hp * a.D, a.D, threadIdx.x);
+    if (threadIdx.x == 0) ElemTraits<T>::store(reinterpret_cast<T*>(a.key_norm), (size_t)hp * S + idx, __fsqrt_rn(ss));
+  }
+}
+
+template <int POLICY, typename ST = float>
+int launch_update(const cc_kv_view* c, UpdArgs& a, hipStream_t st) {
+  a.k_cache = c->k_cache;
+  a.v_cache = c->v_cache;
+  a.pos = c->pos;
+  a.mask = c->mask;
+  a.cache_cts = c->cache_cts;
+  a.H = c->H;
+  a.Hp = c->Hp;
+  a.Hc = c->Hc;
+  a.S = c->S;
+  a.D = c->D;
+  dim3 grid(c->Hp), block(kUpdThreads);
+  switch (c->dtype) {
+    case CC_DT_F32: hipLaunchKernelGGL((decode_update_kernel<POLICY, float, ST>), grid, block, 0, st, a); break;
+    case CC_DT_BF16: hipLaunchKernelGGL((decode_update_kernel<POLICY, bf16_t, ST>), grid, block, 0, st, a); break;
+    default: hipLaunchKernelGGL((decode_update_kernel<POLICY, f16_t, ST>), grid, block, 0, st, a); break;
+  }
+  CC_LAUNCH_CHECK();
+  return CC_OK;
+}
+
+// ---------------------------------------------------------------- heavy-hitter history update
+template <typename T>
+__global__ __launch_bounds__(256) void hh_update_kernel(double* num, int32_t* denom, int64_t* counter, const T* attn,
+                                                        int H, int S, int Tn) {
+  const int n = H * S;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int h = i / S, s = i - h * S;
+    if (s < Tn) num[i] += (double)ElemTraits<T>::load(attn, (size_t)h * Tn + s);  // exact widening add
+    denom[i] += 1;
+  }
+  if (counter && blockIdx.x == 0 && threadIdx.x == 0) *counter += 1;
+}
+
+// ---------------------------------------------------------------- prefill fill
+template <typename T>
+__global__ __launch_bounds__(256) void prefill_fill_kernel(UpdArgs a, const int64_t* pos_val, int PH, int Tn) {
+  // grid.x over 16-byte chunks of [H, Tn, D]; rows keep their layout, only the slot stride changes (Tn -> S)
+  const int row_words = a.D * (int)sizeof(T) / 4;
+  const size_t total = (size_t)a.H * Tn * row_words;
+  const uint32_t* ks = reinterpret_cast<const uint32_t*>(a.k_new);
+  const uint32_t* vs = reinterpret_cast<const uint32_t*>(a.v_new);
+  uint32_t* kd = reinterpret_cast<uint32_t*>(a.k_cache);
+  uint32_t* vd = reinterpret_cast<uint32_t*>(a.v_cache);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t row = i / row_words;
+    const int wd = (int)(i - row * row_words);
+    const int h = (int)(row / Tn), t = (int)(row - (size_t)h * Tn);
+    const size_t dst = ((size_t)h * a.S + t) * row_words + wd;
+    kd[dst] = ks[i];
+    vd[dst] = vs[i];
+  }
+  const int np = a.Hp * Tn;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < np; i += gridDim.x * blockDim.x) {
+    const int hp = i / Tn, t = i - hp * Tn;
+    a.pos[(size_t)hp * a.S + t] = (int32_t)pos_val[(size_t)(PH == 1 ? 0 : hp) * Tn + t];
+  }
+  const int nm = a.H * Tn;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nm; i += gridDim.x * blockDim.x) {
+    const int h = i / Tn, t = i - h * Tn;
+    a.mask[(size_t)h * a.S + t] = 1;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < a.Hc) a.cache_cts[threadIdx.x] += Tn;
+}
+
+// ---------------------------------------------------------------- row L2 norms
+template <typename T>
+__global__ __launch_bounds__(256) void row_l2_norm_kernel(const T* x, int rows, int D, int negate, T* out) {
+  const int lane16 = threadIdx.x & 15;
+  const int group = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  const int ngroups = (gridDim.x * blockDim.x) >> 4;
+  for (int r = group; r < rows; r += ngroups) {
+    const float ss = sumsq_canonical_16<T>(x + (size_t)r * D, D, lane16);
+    if (lane16 == 0) {
+      const float n = __fsqrt_rn(ss);
+      ElemTraits<T>::store(out, r, negate ? -n : n);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int cc_decode_update_full(const cc_kv_view* c, const void* k_new, const void* v_new, const int32_t* input_pos,
+                          int64_t* idx_out, cc_stream_t stream) {
+  if (!cc_view_ok(c) || !input_pos || !idx_out || c->Hp != 1 || (k_new && !v_new)) return CC_ERR_BAD_ARG;
+  UpdArgs a{};
+  a.k_new = k_new; a.v_new = v_new; a.input_pos = input_pos; a.idx_out = idx_out;
+  return launch_update<P_FULL>(c, a, (hipStream_t)stream);
+}
+
+int cc_decode_update_recent_global(const cc_kv_view* c, const void* k_new, const void* v_new,
+                                   const int32_t* input_pos, int32_t g, int64_t* idx_out, cc_stream_t stream) {
+  if (!cc_view_ok(c) || !input_pos || !idx_out || c->Hp != 1 || g < 0 || g >= c->S || (k_new && !v_new))
+    return CC_ERR_BAD_ARG;
+  UpdArgs a{};
+  a.k_new = k_new; a.v_new = v_new; a.input_pos = input_pos; a.idx_out = idx_out; a.g = g;
+  return launch_update<P_RECENT_GLOBAL>(c, a, (hipStream_t)stream);
+}
+
+int cc_decode_update_scores(const cc_kv_view* c, const void* k_new, const void* v_new, const int32_t* input_pos,
+                            const void* scores, int32_t score_dtype, int32_t g, int64_t* idx_out,
+                            cc_stream_t stream) {
+  if (!cc_view_ok(c) || !input_pos || !idx_out || !scores || !cc_dt_ok(score_dtype) || g < 0 || (k_new && !v_new))
+    return CC_ERR_BAD_ARG;
+  UpdArgs a{};
+  a.k_new = k_new; a.v_new = v_new; a.input_pos = input_pos; a.idx_out = idx_out; a.g = g;
+  a.scores = scores; a.score_heads = c->Hp;
+  switch (score_dtype) {
+    case CC_DT_F32: return launch_update<P_SCORES, float>(c, a, (hipStream_t)stream);
+    case CC_DT_BF16: return launch_update<P_SCORES, bf16_t>(c, a, (hipStream_t)stream);
+    default: return launch_update<P_SCORES, f16_t>(c, a, (hipStream_t)stream);
+  }
+}
+
+int cc_decode_update_random(const cc_kv_view* c, const void* k_new, const void* v_new, const int32_t* input_pos,
+                            const float* rand_u, int32_t g, int32_t w, int64_t* idx_out, cc_stream_t stream) {
+  if (!cc_view_ok(c) || !input_pos || !idx_out || !rand_u || c->Hp != 1 || g < 0 || (k_new && !v_new))
+    return CC_ERR_BAD_ARG;
+  UpdArgs a{};
+  a.k_new = k_new; a.v_new = v_new; a.input_pos = input_pos; a.idx_out = idx_out; a.g = g; a.w = w;
+  a.scores = rand_u; a.score_heads = 1;
+  return launch_update<P_RANDOM>(c, a, (hipStream_t)stream);
+}
+
+size_t cc_decode_update_l2_workspace_bytes(int32_t H, int32_t S) {
+  (void)H; (void)S;
+  return 0;  // the global max is recomputed per workgroup from L2; no scratch needed
+}
+
+int cc_decode_update_l2(const cc_kv_view* c, const void* k_new, const void* v_new, const int32_t* input_pos,
+                        void* key_norm, int32_t g, int32_t w, int64_t* idx_out, void* workspace,
+                        size_t workspace_bytes, cc_stream_t stream) {
+  (void)workspace; (void)workspace_bytes;
+  if (!cc_view_ok(c) || !input_pos || !idx_out || !key_norm || c->Hp != c->H || g < 0 || (k_new && !v_new))
+    return CC_ERR_BAD_ARG;
+  UpdArgs a{};
+  a.k_new = k_new; a.v_new = v_new; a.input_pos = input_pos; a.idx_out = idx_out; a.g = g; a.w = w;
+  a.key_norm = key_norm;
+  return launch_update<P_L2>(c, a, (hipStream_t)stream);
+}
+
+int cc_decode_update_heavy_hitter(const cc_kv_view* c, const void* k_new, const void* v_new,
+                                  const int32_t* input_pos, double* num, int32_t* denom, int32_t g, int32_t w,
+                                  int64_t* idx_out, cc_stream_t stream) {
+  if (!cc_view_ok(c) || !input_pos || !idx_out || !num || !denom || c->Hp != c->H || (k_new && !v_new))
+    return CC_ERR_BAD_ARG;
+  UpdArgs a{};
+  a.k_new = k_new; a.v_new = v_new; a.input_pos = input_pos; a.idx_out = idx_out; a.g = g; a.w = w;
+  a.num = num; a.denom = denom;
+  return launch_update<P_HH>(c, a, (hipStream_t)stream);
+}
+
+int cc_hh_update(double* num, int32_t* denom, int64_t* counter, const void* attn, int32_t H, int32_t S, int32_t T,
+                 int32_t dtype, cc_stream_t stream) {
+  if (!num || !denom || !attn || H <= 0 || S <= 0 || T < 0 || T > S || !cc_dt_ok(dtype)) return CC_ERR_BAD_ARG;
+  const int n = H * S;
+  dim3 grid((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  switch (dtype) {
+    case CC_DT_F32: hipLaunchKernelGGL(hh_update_kernel<float>, grid, block, 0, st, num, denom, counter, (const float*)attn, H, S, T); break;
+    case CC_DT_BF16: hipLaunchKernelGGL(hh_update_kernel<bf16_t>, grid, block, 0, st, num, denom, counter, (const bf16_t*)attn, H, S, T); break;
+    default: hipLaunchKernelGGL(hh_update_kernel<f16_t>, grid, block, 0, st, num, denom, counter, (const f16_t*)attn, H, S, T); break;
+  }
+  CC_LAUNCH_CHECK();
+  return CC_OK;
+}
+
+int cc_prefill_fill(const cc_kv_view* c, const void* k_val, const void* v_val, const int64_t* pos_val, int32_t PH,
+                    int32_t T, cc_stream_t stream) {
+  if (!cc_view_ok(c) || !k_val || !v_val || !pos_val || T <= 0 || T > c->S || (PH != 1 && PH != c->Hp) || c->Hc > 256)
+    return CC_ERR_BAD_ARG;
+  UpdArgs a{};
+  a.k_cache = c->k_cache; a.v_cache = c->v_cache; a.pos = c->pos; a.mask = c->mask; a.cache_cts = c->cache_cts;
+  a.H = c->H; a.Hp = c->Hp; a.Hc = c->Hc; a.S = c->S; a.D = c->D;
+  a.k_new = k_val; a.v_new = v_val;
+  const size_t words = (size_t)c->H * T * c->D * cc_dt_size(c->dtype) / 4;
+  size_t nb = (words + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  if (nb < 1) nb = 1;
+  dim3 grid((unsigned)nb), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  switch (c->dtype) {
+    case CC_DT_F32: hipLaunchKernelGGL(prefill_fill_kernel<float>, grid, block, 0, st, a, pos_val, PH, T); break;
+    case CC_DT_BF16: hipLaunchKernelGGL(prefill_fill_kernel<bf16_t>, grid, block, 0, st, a, pos_val, PH, T); break;
+    default: hipLaunchKernelGGL(prefill_fill_kernel<f16_t>, grid, block, 0, st, a, pos_val, PH, T); break;
+  }
+  CC_LAUNCH_CHECK();
+  return CC_OK;
+}
+
+int cc_row_l2_norm(const void* x, int32_t H, int32_t N, int32_t D, int32_t dtype, int32_t negate, void* out,
+                   cc_stream_t stream) {
+  if (!x || !out || H <= 0 || N <= 0 || D <= 0 || !cc_dt_ok(dtype)) return CC_ERR_BAD_ARG;
+  const int rows = H * N;
+  int nb = (rows + 15) / 16;
+  if (nb > 2048) nb = 2048;
+  dim3 grid(nb), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  switch (dtype) {
+    case CC_DT_F32: hipLaunchKernelGGL(row_l2_norm_kernel<float>, grid, block, 0, st, (const float*)x, rows, D, negate, (float*)out); break;
+    case CC_DT_BF16: hipLaunchKernelGGL(row_l2_norm_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, rows, D, negate, (bf16_t*)out); break;
+    default: hipLaunchKernelGGL(row_l2_norm_kernel<f16_t>, grid, block, 0, st, (const f16_t*)x, rows, D, negate, (f16_t*)out); break;
+  }
+  CC_LAUNCH_CHECK();
+  return CC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,246 @@
+"""Llama/Qwen2-style decoder used as the CALLER of the hot path (the build's counterpart of the reference's
+model.py, which never ships).  Dense projections, norms and RoPE are ordinary PyTorch-ROCm ops (hipBLASLt
+GEMMs — out of scope for hand kernels); every cache / attention step goes through the HIP path.
+
+Conventions that fixture F1's logits depend on (ref: model.py):
+  parameter names/layout (:179-184, :335-338, :438-440), pre-norm blocks (:317-327), RMSNorm in fp32
+  (:452-457), interleaved-pair RoPE with the table stored in the model dtype (:460-519), decode inserts
+  into the cache BEFORE attending (:391-411), probabilities averaged per query group (:413-418).
+"""
+import math
+from collections import defaultdict
+from dataclasses import dataclass
+from typing import Any, Dict, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch import Tensor
+
+from ..attention_utils import scaled_dot_product_attention
+from ..cache import KVCacheHeavyHitter, get_cache_constructor
+from ..prompt_compression import get_prompt_compressor_constructor
+
+
+def find_multiple(n: int, k: int) -> int:
+    return n if n % k == 0 else n + k - (n % k)
+
+
+@dataclass
+class ModelArgs:
+    block_size: int = 2048
+    vocab_size: int = 32000
+    n_layer: int = 32
+    n_head: int = 32
+    dim: int = 4096
+    intermediate_size: Optional[int] = None
+    n_local_heads: int = -1
+    head_dim: int = 64
+    rope_base: float = 10000
+    norm_eps: float = 1e-5
+    attention_bias: bool = False
+    max_length: int = 4096
+    rope_scaling: Optional[Dict[str, Any]] = None
+
+    def __post_init__(self):
+        if self.n_local_heads == -1:
+            self.n_local_heads = self.n_head
+        if self.intermediate_size is None:
+            self.intermediate_size = find_multiple(int(2 * (4 * self.dim) / 3), 256)
+        self.head_dim = self.dim // self.n_head
+
+
+_LLAMA31_SCALING = {"factor": 8.0, "low_freq_factor": 1.0, "high_freq_factor": 4.0,
+                    "original_max_position_embeddings": 8192, "rope_type": "llama3"}
+
+# Shapes the BASELINE configs name (ref: model.py:103-131, :90-92; the 70B/128k-vocab shape is SURVEY C5's).
+CONFIGS = {
+    "tiny": dict(block_size=256, vocab_size=128, n_layer=2, n_head=4, n_local_heads=2, dim=64, intermediate_size=128),
+    "Meta-Llama-3-8B-Instruct": dict(block_size=8192, n_layer=32, n_head=32, n_local_heads=8, dim=4096,
+                                     intermediate_size=14336, vocab_size=128256, rope_base=500000, max_length=8192),
+    "Meta-Llama-3.1-8B-Instruct": dict(block_size=131072, n_layer=32, n_head=32, n_local_heads=8, dim=4096,
+                                       intermediate_size=14336, vocab_size=128256, rope_base=500000, max_length=131072,
+                                       rope_scaling=_LLAMA31_SCALING),
+    "Llama-3-70B-shape": dict(block_size=131072, n_layer=80, n_head=64, n_local_heads=8, dim=8192,
+                              intermediate_size=28672, vocab_size=128256, rope_base=500000, max_length=131072,
+                              rope_scaling=_LLAMA31_SCALING),
+    "Qwen2-7B-Instruct": dict(block_size=32768, n_layer=28, n_head=28, n_local_heads=4, dim=3584, intermediate_size=18944,
+                              vocab_size=152064, rope_base=1000000, attention_bias=True, norm_eps=1e-6, max_length=32768),
+}
+
+
+def precompute_freqs_cis(seq_len, n_elem, base=10000, dtype=torch.bfloat16, rope_scaling=None) -> Tensor:
+    """ref: model.py:460-504 — [seq_len, n_elem/2, 2] (cos, sin), built in fp32, STORED in the model dtype."""
+    freqs = 1.0 / (base ** (torch.arange(0, n_elem, 2)[: n_elem // 2].float() / n_elem))
+    if rope_scaling is not None:
+        assert rope_scaling["rope_type"] == "llama3", "Only Llama 3.1 scaling is supported"
+        orig = rope_scaling["original_max_position_embeddings"]
+        lo_wl, hi_wl = orig / rope_scaling["low_freq_factor"], orig / rope_scaling["high_freq_factor"]
+        out = []
+        for f in freqs:
+            wl = 2 * math.pi / f
+            if wl < hi_wl:
+                out.append(f)
+            elif wl > lo_wl:
+                out.append(f / rope_scaling["factor"])
+            else:
+                smooth = (orig / wl - rope_scaling["low_freq_factor"]) / (
+                    rope_scaling["high_freq_factor"] - rope_scaling["low_freq_factor"])
+                out.append((1 - smooth) * f / rope_scaling["factor"] + smooth * f)
+        freqs = torch.tensor(out)
+    ang = torch.outer(torch.arange(seq_len), freqs)
+    cis = torch.polar(torch.ones_like(ang), ang)
+    return torch.stack([cis.real, cis.imag], dim=-1).to(dtype=dtype)
+
+
+def apply_rotary_emb(x: Tensor, freqs_cis: Tensor) -> Tensor:
+    """ref: model.py:507-519 — adjacent pairs rotated in fp32, cast back to x's dtype."""
+    xs = x.float().reshape(*x.shape[:-1], -1, 2)
+    fc = freqs_cis.view(1, xs.size(1), 1, xs.size(3), 2)
+    out = torch.stack([xs[..., 0] * fc[..., 0] - xs[..., 1] * fc[..., 1],
+                       xs[..., 1] * fc[..., 0] + xs[..., 0] * fc[..., 1]], -1)
+    return out.flatten(3).type_as(x)
+
+
+class RMSNorm(nn.Module):
+    def __init__(self, dim: int, eps: float = 1e-5):
+        super().__init__()
+        self.eps = eps
+        self.weight = nn.Parameter(torch.ones(dim))
+
+    def forward(self, x: Tensor) -> Tensor:
+        xf = x.float()
+        return (xf * torch.rsqrt(torch.mean(xf * xf, dim=-1, keepdim=True) + self.eps)).type_as(x) * self.weight
+
+
+class FeedForward(nn.Module):
+    def __init__(self, config: ModelArgs) -> None:
+        super().__init__()
+        self.w1 = nn.Linear(config.dim, config.intermediate_size, bias=False)
+        self.w3 = nn.Linear(config.dim, config.intermediate_size, bias=False)
+        self.w2 = nn.Linear(config.intermediate_size, config.dim, bias=False)
+
+    def forward(self, x: Tensor) -> Tensor:
+        return self.w2(F.silu(self.w1(x)) * self.w3(x))
+
+
+class Attention(nn.Module):
+    def __init__(self, config: ModelArgs):
+        super().__init__()
+        assert config.dim % config.n_head == 0
+        total = (config.n_head + 2 * config.n_local_heads) * config.head_dim
+        self.wqkv = nn.Linear(config.dim, total, bias=config.attention_bias)
+        self.wo = nn.Linear(config.dim, config.dim, bias=False)
+        self.kv_cache = None
+        self.prompt_compressor = None
+        self.n_head, self.head_dim = config.n_head, config.head_dim
+        self.n_local_heads, self.dim = config.n_local_heads, config.dim
+        self.fuse_state_update = True  # fold cache.py:690-723 into the decode attention combine pass
+
+    def compress_prompt(self, input_pos, k_val, v_val, attn):
+        if self.kv_cache.max_cache_length < input_pos.shape[0]:
+            return self.prompt_compressor(input_pos, k_val, v_val, attn=attn)
+        return input_pos, k_val, v_val, attn
+
+    def forward(self, x, input_ids, freqs_cis, mask, is_prefill, input_pos=None, attn_top_k=1.0):
+        """The glue of ref: model.py:363-432, GQA-aware (no repeat_interleave)."""
+        bsz, seqlen, _ = x.shape
+        kv_size = self.n_local_heads * self.head_dim
+        q, k, v = self.wqkv(x).split([self.dim, kv_size, kv_size], dim=-1)
+        q = apply_rotary_emb(q.view(bsz, seqlen, self.n_head, self.head_dim), freqs_cis).transpose(1, 2)
+        k = apply_rotary_emb(k.view(bsz, seqlen, self.n_local_heads, self.head_dim), freqs_cis).transpose(1, 2)
+        v = v.view(bsz, seqlen, self.n_local_heads, self.head_dim).transpose(1, 2)
+        cache = self.kv_cache
+        ck = {"input_ids": input_ids}
+        if not is_prefill:
+            kc, vc, kv_mask = cache.update_kv(input_pos, k, v, False, **ck)  # insert first, then attend
+            fuse = self.fuse_state_update and isinstance(cache, KVCacheHeavyHitter) and type(cache) is KVCacheHeavyHitter
+            y, attn = scaled_dot_product_attention(
+                q, kc, vc, attn_mask=kv_mask, attn_top_k=attn_top_k, return_attn=cache.return_attn() and not fuse,
+                group_mean=True, history=cache.fused_history() if fuse else None)
+            if fuse:
+                cache._state_fused = True
+            cache.update_state(input_pos, k, v, False, attn, **ck)
+        else:
+            y, attn = scaled_dot_product_attention(q, k, v, attn_mask=mask, return_attn=cache.return_attn(),
+                                                   is_causal=True)
+            input_pos, k, v, attn = self.compress_prompt(input_pos, k, v, attn)
+            cache.update_kv(input_pos, k, v, True, **ck)
+            cache.update_state(input_pos, k, v, True, attn, **ck)
+        y = y.transpose(1, 2).contiguous().view(bsz, seqlen, self.dim)
+        return self.wo(y)
+
+
+class TransformerBlock(nn.Module):
+    def __init__(self, config: ModelArgs) -> None:
+        super().__init__()
+        self.attention = Attention(config)
+        self.feed_forward = FeedForward(config)
+        self.ffn_norm = RMSNorm(config.dim, config.norm_eps)
+        self.attention_norm = RMSNorm(config.dim, config.norm_eps)
+
+    def forward(self, x, input_ids, input_pos, is_prefill, freqs_cis, mask, attn_top_k=1.0):
+        h = x + self.attention(self.attention_norm(x), input_ids, freqs_cis, mask, is_prefill, input_pos, attn_top_k=attn_top_k)
+        return h + self.feed_forward(self.ffn_norm(h))
+
+
+class Transformer(nn.Module):
+    def __init__(self, config: ModelArgs) -> None:
+        super().__init__()
+        self.config = config
+        self.tok_embeddings = nn.Embedding(config.vocab_size, config.dim)
+        self.layers = nn.ModuleList(TransformerBlock(config) for _ in range(config.n_layer))
+        self.norm = RMSNorm(config.dim, eps=config.norm_eps)
+        self.output = nn.Linear(config.dim, config.vocab_size, bias=False)
+        self.freqs_cis: Optional[Tensor] = None
+        self.max_batch_size = 1
+
+    @classmethod
+    def from_name(cls, name: str):
+        return cls(ModelArgs(**CONFIGS[name]))
+
+    def setup_caches(self, **kwargs):
+        """ref: model.py:191-233 — one cache + one prompt compressor per layer, each given only its relevant kwargs."""
+        cache_strategy = kwargs.pop("cache_strategy")
+        head_dim = self.config.dim // self.config.n_head
+        dtype = self.output.weight.dtype
+        layerwise = {"max_cache_length", "recent_window", "prompt_compression_strategy"}
+        for i, b in enumerate(self.layers):
+            ctor, relevant = get_cache_constructor(cache_strategy=cache_strategy[i])
+            lk = {k: kwargs[k][i] if k in layerwise else kwargs[k] for k in relevant}
+            b.attention.kv_cache = ctor(self.max_batch_size, self.config.n_local_heads, head_dim, dtype, **lk)
+            b.attention.prompt_compressor = get_prompt_compressor_constructor(
+                kwargs["prompt_compression_strategy"][i])(head_specific=b.attention.kv_cache.head_specific, **lk)
+        self.freqs_cis = precompute_freqs_cis(self.config.block_size, head_dim, self.config.rope_base, dtype,
+                                              self.config.rope_scaling)
+        dev = self.output.weight.device
+        self.freqs_cis = self.freqs_cis.to(dev)
+
+    def reset_caches(self):
+        for layer in self.layers:
+            layer.attention.kv_cache.reset()
+
+    def min_cache_length(self):
+        return min(layer.attention.kv_cache.max_cache_length for layer in self.layers)
+
+    def get_cache_stats(self, prompt_len, gen_len):
+        """ref: model.py:245-263."""
+        stats, avgs, mem = {}, defaultdict(list), 0
+        for i, layer in enumerate(self.layers):
+            st = layer.attention.kv_cache.compute_statistics(seq_len=torch.tensor(prompt_len + gen_len))
+            mem += st.pop("cache_memory_gb")
+            for k, v in st.items():
+                stats[f"{k}_{i}"] = v
+                avgs[k].append(v)
+        for k, v in avgs.items():
+            stats[f"{k}_avg"] = sum(v) / len(v)
+        stats["cache_memory_gb"] = mem
+        return stats
+
+    def forward(self, idx, input_pos, is_prefill, mask=None, attn_top_k=1.0) -> Tensor:
+        assert self.freqs_cis is not None, "Caches must be initialized first"
+        freqs_cis = self.freqs_cis[input_pos]
+        x = self.tok_embeddings(idx)
+        for layer in self.layers:
+            x = layer(x, idx, input_pos, is_prefill, freqs_cis, mask, attn_top_k=attn_top_k)
+        return self.output(self.norm(x))

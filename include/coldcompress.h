@@ -160,6 +160,15 @@ int cc_decode_attn_gqa(const void* q, const void* k, const void* v, const uint8_
                        int64_t* hh_counter, void* workspace, size_t workspace_bytes,
                        cc_stream_t stream);
 
+/* Measurement hook: the same operation with its two launches selectable, so that bench.py can bracket the
+ * dominant kernel alone with HIP events.  phases: 1 = split kernel only (K/V streaming pass),
+ * 2 = combine kernel only (needs a prior phase-1 call on the same workspace), 3 = both (== cc_decode_attn_gqa). */
+int cc_decode_attn_gqa_phases(const void* q, const void* k, const void* v, const uint8_t* mask, int32_t HQ,
+                              int32_t H, int32_t S, int32_t D, int32_t dtype, float scale, void* y,
+                              void* attn_out, void* probs_out, double* hh_num, int32_t* hh_denom,
+                              int64_t* hh_counter, void* workspace, size_t workspace_bytes,
+                              cc_stream_t stream, int32_t phases);
+
 /* ------------------------------------------------------------------------------------------------
  * Prefill-time cache fill.  ref: KVCache._prefill_update / _fill_contiguous cache.py:381-401.
  *   slots 0..T-1 of every head <- k_val/v_val rows; pos[hp, t] <- pos_val[min(hp,PH-1), t] (int32 cast);

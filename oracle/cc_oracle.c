@@ -123,6 +123,28 @@ static inline void st(void* p, int dt, size_t i, float x) {
 
 static int dt_ok(int dt) { return dt == CC_DT_F32 || dt == CC_DT_BF16 || dt == CC_DT_F16; }
 
+/* Canonical sum of squares (shared with the device kernels, cc_common.h sumsq_canonical_16): 16 strided
+ * partials a_j = sum_i x[j+16i]^2 (sequential in i, separate multiply and add), then the butterfly
+ * a_j += a_{j^8}, ^4, ^2, ^1.  torch.linalg.vector_norm's own fp32 order is unspecified (vectorised);
+ * the golden tests bound the difference to 1 ulp of the model dtype. */
+static float sumsq_canonical(const void* x, int dt, size_t off, int D) {
+  float a[16], b[16];
+  for (int j = 0; j < 16; j++) {
+    float acc = 0.f;
+    for (int d = j; d < D; d += 16) {
+      float e = ld(x, dt, off + d);
+      float sq = e * e;
+      acc = acc + sq;
+    }
+    a[j] = acc;
+  }
+  for (int k = 8; k > 0; k >>= 1) {
+    for (int j = 0; j < 16; j++) b[j] = a[j] + a[j ^ k];
+    memcpy(a, b, sizeof(a));
+  }
+  return a[0];
+}
+
 /* ---------------------------------------------------------------- arg-min ------------------------ */
 
 /* torch.argmin over a float row: first index of the minimum, NaN counts as the minimum (first NaN
@@ -279,11 +301,7 @@ int cc_decode_update_l2_cpu(const cc_kv_view* c, const void* k_new, const void* 
   if (k_new) {
     insert_token(c, k_new, v_new, p, idx_out);
     for (int h = 0; h < c->H; h++) { /* :592-593 vector_norm in fp32 opmath, stored in model dtype */
-      float acc = 0.f;
-      for (int d = 0; d < c->D; d++) {
-        float x = ld(k_new, dt, (size_t)h * c->D + d);
-        acc += x * x;
-      }
+      float acc = sumsq_canonical(k_new, dt, (size_t)h * c->D, c->D);
       st(key_norm, dt, (size_t)h * c->S + idx_out[h], sqrtf(acc));
     }
   }
@@ -445,12 +463,7 @@ int cc_row_l2_norm_cpu(const void* x, int32_t H, int32_t N, int32_t D, int32_t d
   (void)stream;
   if (!x || !out || H <= 0 || N <= 0 || D <= 0 || !dt_ok(dtype)) return CC_ERR_BAD_ARG;
   for (size_t r = 0; r < (size_t)H * N; r++) {
-    float acc = 0.f;
-    for (int d = 0; d < D; d++) {
-      float e = ld(x, dtype, r * D + d);
-      acc += e * e;
-    }
-    float n = sqrtf(acc);
+    float n = sqrtf(sumsq_canonical(x, dtype, r * D, D));
     st(out, dtype, r, negate ? -n : n);
   }
   return CC_OK;
@@ -659,4 +672,15 @@ int cc_colsum_to_mean_cpu(const float* colsum, const int64_t* input_pos, int32_t
       st(out, dtype, (size_t)h * L + t, rnd(colsum[(size_t)h * L + t], dtype) / (float)(L - p));
     }
   return CC_OK;
+}
+
+/* measurement hook twin: the oracle has no phases; phase 2 (or 3) computes everything, phase 1 alone nothing */
+int cc_decode_attn_gqa_phases_cpu(const void* q, const void* k, const void* v, const uint8_t* mask, int32_t HQ,
+                                  int32_t H, int32_t S, int32_t D, int32_t dtype, float scale, void* y,
+                                  void* attn_out, void* probs_out, double* hh_num, int32_t* hh_denom,
+                                  int64_t* hh_counter, void* workspace, size_t workspace_bytes,
+                                  cc_stream_t stream, int32_t phases) {
+  if (!(phases & 2)) return CC_OK;
+  return cc_decode_attn_gqa_cpu(q, k, v, mask, HQ, H, S, D, dtype, scale, y, attn_out, probs_out, hh_num, hh_denom,
+                                hh_counter, workspace, workspace_bytes, stream);
 }

@@ -329,8 +329,22 @@ def attn_cases(A, dtype):
 # ------------------------------------------------------------------------------------------------ F8
 
 
-def budgets(G, M):
+def budgets(G, M, C=None):
     rows = {"normalize": [], "pattern": [], "pyramid": [], "find_multiple": []}
+    if C is not None:  # registry surface: relevant_kwargs per strategy + argparse defaults (cache.py:13-118, 1444-1478)
+        rows["relevant_kwargs"] = {s: C.get_cache_constructor(s)[1] for s in
+                                   ["full", "random", "recent_global", "heavy_hitter", "l2", "hybrid", "keep_it_odd",
+                                    "debug_heavy_hitter"]}
+        ap = argparse.ArgumentParser()
+        C.add_cache_arguments(ap)
+        rows["arg_defaults"] = {k: v for k, v in vars(ap.parse_args([])).items()}
+        rw = []
+        for rwin, lens in [(10, [2560] * 4), (0.5, [100, 7, 1]), (1, [8, 16]), (4000, [2036, 256])]:
+            if rwin <= 1:
+                rw.append([rwin, lens, [max(1, int(rwin * l)) for l in lens]])
+            else:
+                rw.append([rwin, lens, [max(1, min(rwin, l)) for l in lens]])
+        rows["recent_window"] = rw
     for frac, mx in [(0.25, 10240), (0.1, 34816), (1.0, 18432), (0.5, 52), (4096, 10240), (16, 52), (0.33, 1000),
                      (20000, 10240), (0.05, 8192), (1, 77)]:
         rows["normalize"].append([frac, mx, G.normalize_cache_length(frac, mx)])
@@ -417,7 +431,7 @@ def main():
     save("f7_attn_bf16.npz", attn_cases(A, torch.bfloat16))
     # F8
     with open(os.path.join(a.out, "f8_budgets.json"), "w") as f:
-        json.dump(budgets(G, M), f)
+        json.dump(budgets(G, M, C), f)
     print("wrote f8_budgets.json")
 
 

@@ -1,0 +1,112 @@
+"""End-to-end GPU tests: the build's tiny-Llama harness + HIP cache/attention path against fixture F1
+(captured from the reference's generation_utils.generate on CPU, fp32): generated tokens identical, per-step
+per-layer eviction indices bit-exact, fp32 logits within 1e-3 (the north-star tolerance), final cache state.
+Also: the hipGraph-captured decode step must reproduce the eager decode exactly.
+"""
+import argparse
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _build(f, n_layer):
+    import cold_compress_amd.cache as cache
+    from cold_compress_amd.harness import ModelArgs, Transformer, setup_caches
+
+    cfg = dict(block_size=256, vocab_size=128, n_layer=n_layer, n_head=4, n_local_heads=2, dim=64, intermediate_size=128)
+    model = Transformer(ModelArgs(**cfg)).to(torch.float32).eval()
+    sd = {k[3:]: v for k, v in f.items() if k.startswith("sd.")}
+    model.load_state_dict(sd, strict=True)
+    model = model.to(DEV)
+    ap = argparse.ArgumentParser()
+    cache.add_cache_arguments(ap)
+    kw = vars(ap.parse_args([]))
+    kw.update(json.loads(f["cache_args_json"]))
+    ck = setup_caches(model, None, DEV, f["prompt_len"] + f["new_tokens"], dict(kw))
+    return model, ck
+
+
+def _log_evictions(model):
+    log = {i: [] for i in range(len(model.layers))}
+    for i, layer in enumerate(model.layers):
+        kv = layer.attention.kv_cache
+        orig = kv._run_select
+
+        def wrapped(input_pos, k, v, _orig=orig, _kv=kv, _i=i):
+            _orig(input_pos, k, v)
+            log[_i].append(_kv._idx_buf().clone())
+
+        kv._run_select = wrapped
+    return log
+
+
+def _run(name, graphed=False):
+    from cold_compress_amd.harness import GraphedDecoder, decode_one_token, generate, prefill
+
+    f = load_golden(name)
+    model, ck = _build(f, f["n_layer"])
+    assert list(ck["max_cache_length"]) == f["max_cache_length"].tolist()
+    assert list(ck["recent_window"]) == f["recent_window"].tolist()
+    log = None if graphed else _log_evictions(model)
+    logits = []
+    if not graphed:
+        orig = model.forward
+
+        def fwd(*a, **k):
+            out = orig(*a, **k)
+            logits.append(out[0, -1].detach().float().clone())
+            return out
+
+        model.forward = fwd
+    dec = GraphedDecoder(model) if graphed else decode_one_token
+    seq, probs, stats = generate(model, f["prompt"].to(DEV), prefill, dec, max_new_tokens=f["new_tokens"])
+    torch.cuda.synchronize()
+    return f, model, seq.cpu(), log, logits
+
+
+@pytest.mark.parametrize("name", ["f1_e2e_recent_global.npz", "f1_e2e_full.npz", "f1_e2e_heavy_hitter.npz",
+                                  "f1_e2e_heavy_hitter_short.npz", "f1_e2e_l2.npz", "f1_e2e_hh_pyramid.npz"])
+def test_e2e_matches_reference(name):
+    f, model, seq, log, logits = _run(name)
+    assert torch.equal(seq, f["seq"]), "generated tokens differ from the reference"
+    got = torch.stack(logits).cpu()
+    assert got.shape == f["logits"].shape
+    assert (got - f["logits"]).abs().max() < 1e-3, "fp32 logits differ by more than the north-star 1e-3"
+    for li, layer in enumerate(model.layers):
+        kv = layer.attention.kv_cache
+        ref_idx = f[f"evict_idx_L{li}"]
+        mine = torch.stack(log[li]).cpu() if log[li] else torch.zeros(0, 1)
+        assert mine.shape[0] == ref_idx.shape[0]
+        assert torch.equal(mine.view(ref_idx.shape[0], -1), ref_idx.view(ref_idx.shape[0], -1).long()), f"layer {li} eviction indices"
+        assert torch.equal(kv.pos.cpu(), f[f"final_pos_L{li}"])
+        assert torch.equal(kv.mask.cpu(), f[f"final_mask_L{li}"])
+        assert torch.equal(kv.cache_cts.cpu(), f[f"final_cts_L{li}"])
+        assert (kv.k_cache.cpu() - f[f"final_k_L{li}"]).abs().max() < 1e-4
+        if f"final_denom_L{li}" in f:
+            assert torch.equal(kv.attn_history_denom.cpu(), f[f"final_denom_L{li}"])
+            assert torch.allclose(kv.attn_history_num.cpu(), f[f"final_num_L{li}"], rtol=1e-4, atol=1e-6)
+    stats = model.get_cache_stats(f["prompt_len"], f["new_tokens"])
+    assert abs(stats["compression_ratio_avg"] - f["compression_ratio_avg"]) < 1e-6
+
+
+def test_c1_ring_known_answer():
+    """BASELINE config C1: recent_global, S=16, g=4 -> slot at decode step t is 4 + (t mod 12)."""
+    f, model, seq, log, _ = _run("f1_e2e_recent_global.npz")
+    for li in range(2):
+        idx = [int(x) for x in torch.stack(log[li]).cpu().view(-1)]
+        assert idx == [4 + (t % 12) for t in range(len(idx))]
+
+
+@pytest.mark.parametrize("name", ["f1_e2e_heavy_hitter.npz", "f1_e2e_l2.npz", "f1_e2e_recent_global.npz"])
+def test_hipgraph_decode_matches_reference(name):
+    f, model, seq, _, _ = _run(name, graphed=True)
+    assert torch.equal(seq, f["seq"])
+    for li, layer in enumerate(model.layers):
+        assert torch.equal(layer.attention.kv_cache.pos.cpu(), f[f"final_pos_L{li}"])

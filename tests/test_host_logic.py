@@ -1,0 +1,150 @@
+"""CPU tests: host logic (budgets, registry, kwargs plumbing, statistics), the C-ABI surface of the built
+library (every symbol include/coldcompress.h declares is exported; no compute calls without a GPU), and the
+no-fallback rule (CPU tensors are refused loudly)."""
+import argparse
+import ctypes as C
+import json
+import os
+import re
+
+import pytest
+import torch
+
+from helpers import GOLDEN
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def f8():
+    with open(os.path.join(GOLDEN, "f8_budgets.json")) as fh:
+        return json.load(fh)
+
+
+def test_budget_arithmetic_matches_reference(f8):
+    from cold_compress_amd.harness import apply_pattern, apply_pyramid_pattern, find_multiple, normalize_cache_length
+
+    for frac, mx, want in f8["normalize"]:
+        assert normalize_cache_length(frac, mx) == want
+    for pat, n, strat, want in f8["pattern"]:
+        assert apply_pattern(pat, n, strat) == want
+    for length, mx, n, dec, want in f8["pyramid"]:
+        assert apply_pyramid_pattern(length, mx, n, decreasing=dec) == want
+        assert apply_pattern([length], n, "pyramid" if dec else "funnel", max_seq_length=mx) == want
+    for n, k, want in f8["find_multiple"]:
+        assert find_multiple(n, k) == want
+
+
+def test_baseline_config_lengths():
+    """C2 -> 2560, C5 -> 3488, C4(ii) pyramid starts 2036, 1916 and ends in 256s."""
+    from cold_compress_amd.harness import apply_pyramid_pattern, normalize_cache_length
+
+    assert normalize_cache_length(0.25, 8192 + 2048) == 2560
+    assert normalize_cache_length(0.1, 32768 + 2048) == 3488
+    lens = apply_pyramid_pattern(1024, 18432, 32)
+    assert lens[:2] == [2036, 1916] and lens[-4:] == [256] * 4 and len(lens) == 32
+
+
+def test_registry_and_relevant_kwargs(f8):
+    import cold_compress_amd.cache as cache
+
+    for strat in ["full", "random", "recent_global", "heavy_hitter", "l2", "keep_it_odd"]:
+        cls, rk = cache.get_cache_constructor(strat)
+        assert rk == f8["relevant_kwargs"][strat], strat
+        assert callable(cls)
+    with pytest.raises(ValueError):
+        cache.get_cache_constructor("nope")
+    ap = argparse.ArgumentParser()
+    cache.add_cache_arguments(ap)
+    assert vars(ap.parse_args([])) == f8["arg_defaults"]
+    ns = ap.parse_args(["--cache_strategy", "heavy_hitter", "--prompt_compression_strategy", "heavy_hitter",
+                        "--max_cache_length", "0.25"])
+    cache.cache_compatibility(ns)
+    ns.prompt_compression_strategy = ["recent_global"]
+    with pytest.raises(AssertionError):
+        cache.cache_compatibility(ns)
+
+
+def test_recent_window_lists(f8):
+    from cold_compress_amd.harness import ModelArgs, Transformer, setup_caches
+
+    for rw, lens, want in f8["recent_window"]:
+        model = Transformer(ModelArgs(block_size=64, vocab_size=16, n_layer=len(lens), n_head=2, dim=16, intermediate_size=32))
+        ck = dict(max_cache_length=[float(x) for x in lens], cache_length_pattern="tile", cache_strategy=["l2"],
+                  prompt_compression_strategy=["l2"], cache_strategy_pattern="tile", recent_window=rw, global_tokens=1,
+                  cache_bits=None)
+        out = setup_caches(model, None, "cpu", 1 << 20, ck)
+        # lengths are rounded up to multiples of 8 first (generation_utils.py:276); windows follow those
+        exp = [max(1, int(rw * n)) if rw <= 1 else max(1, min(rw, n)) for n in out["max_cache_length"]]
+        assert out["recent_window"] == exp
+        for layer, n in zip(model.layers, out["max_cache_length"]):
+            kv = layer.attention.kv_cache
+            assert kv.max_cache_length == n and kv.pos.shape == (1, 2, n) and kv.pos.dtype == torch.int32
+            assert kv.key_norm.shape == (1, 2, n) and kv.mask.dtype == torch.bool and kv.cache_cts.dtype == torch.int32
+
+
+def test_buffers_and_statistics_on_cpu():
+    import cold_compress_amd.cache as cache
+
+    kw = dict(max_cache_length=16, global_tokens=2, max_seq_length=64, cache_bits=None, history_window_size=1,
+              recent_window=3, attn_thresholding=False)
+    kv = cache.KVCacheHeavyHitter(1, 2, 8, torch.bfloat16, **kw)
+    assert kv.attn_history_num.dtype == torch.float64 and kv.attn_history_num.shape == (1, 2, 16, 1)
+    assert kv.attn_history_denom.dtype == torch.int32 and kv.attn_counter.dtype == torch.int64
+    assert kv.return_attn() and kv.head_specific and bool((kv.pos == -1).all())
+    kv.cache_cts.fill_(10)
+    st = kv.compute_statistics(torch.tensor(41))
+    assert abs(st["compression_ratio"] - (40 - 10) / 40) < 1e-6
+    nbytes = sum(b.numel() * b.element_size() for b in kv.buffers())
+    assert abs(st["cache_memory_gb"] - nbytes / 2 ** 30) < 1e-12
+    kv.reset()
+    assert int(kv.cache_cts[0]) == 0
+    for bad in (dict(cache_bits=4), dict(history_window_size=4), dict(attn_thresholding=True)):
+        with pytest.raises(NotImplementedError):
+            cache.KVCacheHeavyHitter(1, 2, 8, torch.bfloat16, **{**kw, **bad})
+
+
+def test_cpu_tensors_refused_no_fallback():
+    import cold_compress_amd.cache as cache
+    from cold_compress_amd._abi import ColdCompressError
+    from cold_compress_amd.attention_utils import scaled_dot_product_attention
+
+    kv = cache.KVCacheRecentGlobal(1, 2, 8, torch.float32, max_cache_length=16, global_tokens=2, max_seq_length=64, cache_bits=None)
+    with pytest.raises(ColdCompressError):
+        kv.update_kv(torch.arange(4), torch.zeros(1, 2, 4, 8), torch.zeros(1, 2, 4, 8), True)
+    with pytest.raises(ColdCompressError):
+        scaled_dot_product_attention(torch.zeros(1, 4, 1, 8), torch.zeros(1, 2, 16, 8), torch.zeros(1, 2, 16, 8))
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under cold_compress_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "cold_compress_amd")
+    for dp, _, fns in os.walk(pkg):
+        for fn in fns:
+            if fn.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dp, fn)).read()
+                assert not re.search(r"^\s*(from|import)\s+[\w.]*oracle|CDLL\([^)]*oracle|import_module\([^)]*oracle|liboracle", src, re.M), fn
+
+
+def test_abi_exports_every_declared_symbol():
+    from cold_compress_amd import _abi, _build
+
+    so = _build.build()
+    header = open(os.path.join(ROOT, "include", "coldcompress.h")).read()
+    declared = set(re.findall(r"\b(cc_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_abi.SIGNATURES), declared ^ set(_abi.SIGNATURES)
+    lib = C.CDLL(so)
+    fns = _abi.bind(lib)  # raises AttributeError if a symbol is missing
+    assert fns["cc_abi_version"]() == 1
+    assert fns["cc_error_string"](-4) == b"workspace too small"
+    # argument validation happens before any launch, so it is checkable without a GPU
+    assert fns["cc_hh_update"](None, None, None, None, 1, 1, 1, 0, None) == -1
+    assert fns["cc_decode_attn_workspace_bytes"](32, 8, 4096, 128, 1) > 32 * 4096 * 2
+    assert fns["cc_topk_keep"](None, 0, 1, 1, 1, None, None, 0, None) == -1
+
+
+def test_oracle_exports_cpu_twins(oracle):
+    from cold_compress_amd import _abi
+
+    fns = oracle.fns()
+    assert set(fns) == set(_abi.SIGNATURES) - _abi.DEVICE_ONLY
