@@ -8,6 +8,8 @@ suffix) for tests — the oracle is never imported from here.
 import ctypes as C
 import os
 
+import torch  # noqa: F401  (must load ITS bundled HIP runtime before our library resolves libamdhip64)
+
 CC_OK = 0
 CC_DT_F32, CC_DT_BF16, CC_DT_F16 = 0, 1, 2
 CC_PRIO_F32, CC_PRIO_BF16, CC_PRIO_F16, CC_PRIO_I64 = 0, 1, 2, 3

@@ -5,7 +5,8 @@
 
 extern "C" {
 
-int cc_abi_version(void) { return CC_ABI_VERSION; }
+int cc_abi_version(void) {
+  CC_ENTRY(); return CC_ABI_VERSION; }
 
 const char* cc_error_string(int code) {
   switch (code) {
@@ -19,6 +20,7 @@ const char* cc_error_string(int code) {
 }
 
 int cc_device_info(int* n_cu, int* wave_size, int* lds_bytes_per_cu, char* name, int name_len) {
+  CC_ENTRY();
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return CC_ERR_HIP;
   hipDeviceProp_t p;

@@ -5,11 +5,14 @@
 //
 // Kernel 1 (split): grid (n_split, H, R/RT) workgroups of NW waves.  A K/V row of D elements is 16-byte
 //   chunks over LPR = D*sizeof(T)/16 lanes, so one wave-wide 16-byte load covers 64/LPR whole rows, fully
-//   coalesced along [H, S, D].  Every lane issues all of its K and V loads for the iteration (2*U x 16 B)
-//   before the first use, so the whole 2*H*S*D*sizeof(T) bytes of the layer are in flight at once.  The
-//   q.k dot products are reduced across the LPR lanes with __shfl_xor; softmax statistics are kept online
-//   per wave, combined across waves through LDS, and one (m, l, O[RT][D]) partial per workgroup goes to the
-//   workspace together with the dtype-rounded scores.
+//   coalesced along [H, S, D].  Every lane issues its mask bytes, then ALL of its K and V loads for the
+//   iteration (2*U x 16 B) before the first use, so the whole 2*H*S*D*sizeof(T) bytes of the layer are in
+//   flight at once (the first version waited vmcnt(0) after every mask byte: 13.8 us -> see profiles/).
+//   q.k partial dots are all-reduced across the LPR lanes with DPP moves (quad_perm / row_half_mirror /
+//   row_mirror); scores leave through ONE coalesced store per iteration; softmax statistics are kept
+//   online per wave; per-row-group partial outputs go through LDS (no cross-lane shuffles for the 32
+//   accumulators), are merged across the workgroup, and one (m, l, O[RT][D]) partial per workgroup goes to
+//   the workspace.
 // Kernel 2 (combine): merges the partials into y, turns scores into probabilities with the final (M, L),
 //   averages them over the R query heads of the group, and optionally applies the heavy-hitter history
 //   update (cache.py:690-723) in the same pass.
@@ -17,6 +20,39 @@
 #include "cc_common.h"
 
 namespace {
+
+// ---------------------------------------------------------------- cross-lane all-reduce helpers
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+
+// sum over an aligned group of W lanes (W power of two <= 64); every lane of the group gets the total
+template <int W>
+__device__ __forceinline__ float group_sum(float v) {
+  if (W >= 2) v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]  : lane ^ 1
+  if (W >= 4) v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]  : lane ^ 2
+  if (W >= 8) v += dpp_mov<0x141>(v);   // row_half_mirror      : pairs the two quads of each 8
+  if (W >= 16) v += dpp_mov<0x140>(v);  // row_mirror           : pairs the two halves of each 16
+  if (W >= 32) v += __shfl_xor(v, 16, CC_WAVE);
+  if (W >= 64) v += __shfl_xor(v, 32, CC_WAVE);
+  return v;
+}
+// max over the 64/W groups of a wave (lanes with equal lane % W); every lane gets the result
+template <int W>
+__device__ __forceinline__ float across_groups_max(float v) {
+  if (W <= 1) v = fmaxf(v, dpp_mov<0xB1>(v));
+  if (W <= 2) v = fmaxf(v, dpp_mov<0x4E>(v));
+  if (W <= 4) v = fmaxf(v, dpp_mov<0x141>(v));
+  if (W <= 8) v = fmaxf(v, dpp_mov<0x140>(v));
+  if (W <= 16) v = fmaxf(v, __shfl_xor(v, 16, CC_WAVE));
+  if (W <= 32) v = fmaxf(v, __shfl_xor(v, 32, CC_WAVE));
+  return v;
+}
+
+__device__ __forceinline__ float fast_exp(float x) {  // e^x via v_exp_f32 (2^x); exp(-inf) = 0
+  return __builtin_amdgcn_exp2f(x * 1.4426950408889634f);
+}
 
 struct SplitArgs {
   const void* q;
@@ -35,10 +71,11 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_split_kernel(SplitArgs a)
   constexpr int VEC = 16 / (int)sizeof(T);
   constexpr int LPR = D / VEC;
   static_assert(LPR >= 1 && LPR <= 64 && (LPR & (LPR - 1)) == 0, "head_dim must map to a power-of-two lane count");
-  constexpr int RPW = 64 / LPR;
+  constexpr int RPW = 64 / LPR;  // rows per wave-wide load
+  constexpr int NG = NW * RPW;   // row groups per workgroup
   __shared__ float sm_m[NW][RT];
-  __shared__ float sm_l[NW][RT];
-  __shared__ __attribute__((aligned(16))) float sm_acc[NW][RT][D];
+  __shared__ float sm_l[NG][RT];
+  __shared__ __attribute__((aligned(16))) float sm_acc[NG][RT][D];
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lr = lane / LPR, lc = lane % LPR;
@@ -48,16 +85,10 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_split_kernel(SplitArgs a)
   const int row_end = min(S, row_begin + a.rows_per_split);
   const T* kh = reinterpret_cast<const T*>(a.k) + (size_t)h * S * D + lc * VEC;
   const T* vh = reinterpret_cast<const T*>(a.v) + (size_t)h * S * D + lc * VEC;
-  const uint8_t* mh = a.mask ? a.mask + (size_t)h * S : nullptr;
+  const bool has_mask = a.mask != nullptr;
+  const uint8_t* mh = has_mask ? a.mask + (size_t)h * S : reinterpret_cast<const uint8_t*>(a.k);
   T* sc_out = reinterpret_cast<T*>(a.scores);
 
-  float qf[RT][VEC];
-#pragma unroll
-  for (int r = 0; r < RT; r++) {
-    Vec16<T> t;
-    t.load(reinterpret_cast<const T*>(a.q) + (size_t)(q0 + r) * D + lc * VEC);
-    t.unpack(qf[r]);
-  }
   float m[RT], l[RT], acc[RT][VEC];
 #pragma unroll
   for (int r = 0; r < RT; r++) {
@@ -68,57 +99,76 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_split_kernel(SplitArgs a)
   }
 
   for (int base = row_begin + wave * (RPW * U); base < row_end; base += NW * RPW * U) {
+    // ---- issue every load of this iteration before the first use: mask bytes, K rows, V rows
+    uint8_t mk[U];
     Vec16<T> kk[U], vv[U];
-    bool valid[U];
+    int rcl[U];
 #pragma unroll
     for (int u = 0; u < U; u++) {
       const int row = base + u * RPW + lr;
-      const int rc = row < row_end ? row : row_end - 1;
-      kk[u].load(kh + (size_t)rc * D);
+      rcl[u] = row < row_end ? row : row_end - 1;
+      mk[u] = mh[rcl[u]];
     }
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-      const int row = base + u * RPW + lr;
-      const int rc = row < row_end ? row : row_end - 1;
-      vv[u].load(vh + (size_t)rc * D);
-      valid[u] = (row < row_end) && (mh ? mh[rc] != 0 : true);
+    for (int u = 0; u < U; u++) kk[u].load(kh + (size_t)rcl[u] * D);
+#pragma unroll
+    for (int u = 0; u < U; u++) vv[u].load(vh + (size_t)rcl[u] * D);
+
+    float qf[RT][VEC];
+#pragma unroll
+    for (int r = 0; r < RT; r++) {
+      Vec16<T> t;
+      t.load(reinterpret_cast<const T*>(a.q) + (size_t)(q0 + r) * D + lc * VEC);
+      t.unpack(qf[r]);
     }
+
     float s[RT][U];
 #pragma unroll
     for (int u = 0; u < U; u++) {
       float kf[VEC];
       kk[u].unpack(kf);
-      const int row = base + u * RPW + lr;
+      const bool valid = (base + u * RPW + lr < row_end) && (!has_mask || mk[u] != 0);
 #pragma unroll
       for (int r = 0; r < RT; r++) {
         float d = 0.f;
 #pragma unroll
         for (int e = 0; e < VEC; e++) d = fmaf(qf[r][e], kf[e], d);
-#pragma unroll
-        for (int off = LPR / 2; off > 0; off >>= 1) d += __shfl_xor(d, off, CC_WAVE);
+        d = group_sum<LPR>(d);
         // ref: attention_utils.py:37 (q@k^T -> dtype, * scale -> dtype), :42-43 (-inf bias where masked)
-        float x = ElemTraits<T>::rnd(ElemTraits<T>::rnd(d) * a.scale);
-        if (!valid[u]) x = -INFINITY;
-        s[r][u] = x;
-        if (lc == 0 && row < row_end) ElemTraits<T>::store(sc_out, (size_t)(q0 + r) * S + row, x);
+        const float x = ElemTraits<T>::rnd(ElemTraits<T>::rnd(d) * a.scale);
+        s[r][u] = valid ? x : -INFINITY;
       }
     }
+    // ---- scores out: lane lc of each row group stores pair t = pass*LPR + lc  (t = r*U + u): one store
+    //      instruction per pass with every lane active, 2*RPW*U contiguous bytes per query head
+#pragma unroll
+    for (int pass = 0; pass * LPR < RT * U; pass++) {
+      const int t = pass * LPR + lc;
+      float val = 0.f;
+#pragma unroll
+      for (int r = 0; r < RT; r++)
+#pragma unroll
+        for (int u = 0; u < U; u++) val = (t == r * U + u) ? s[r][u] : val;
+      const int r = t / U, u = t - r * U;
+      const int row = base + u * RPW + lr;
+      if (t < RT * U && row < row_end) ElemTraits<T>::store(sc_out, (size_t)(q0 + r) * S + row, val);
+    }
+    // ---- online softmax (wave-uniform running max per query head)
 #pragma unroll
     for (int r = 0; r < RT; r++) {
       float mx = s[r][0];
 #pragma unroll
       for (int u = 1; u < U; u++) mx = fmaxf(mx, s[r][u]);
-#pragma unroll
-      for (int off = LPR; off < 64; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off, CC_WAVE));
+      mx = across_groups_max<LPR>(mx);
       const float m_new = fmaxf(m[r], mx);
       const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-      const float alpha = expf(m[r] - m_use);
+      const float alpha = fast_exp(m[r] - m_use);
       l[r] *= alpha;
 #pragma unroll
       for (int e = 0; e < VEC; e++) acc[r][e] *= alpha;
       m[r] = m_new;
 #pragma unroll
-      for (int u = 0; u < U; u++) s[r][u] = expf(s[r][u] - m_use);
+      for (int u = 0; u < U; u++) s[r][u] = fast_exp(s[r][u] - m_use);
     }
 #pragma unroll
     for (int u = 0; u < U; u++) {
@@ -134,29 +184,22 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_split_kernel(SplitArgs a)
     }
   }
 
-  // wave totals: sum the 64/LPR row groups
-#pragma unroll
-  for (int r = 0; r < RT; r++) {
-#pragma unroll
-    for (int off = LPR; off < 64; off <<= 1) {
-      l[r] += __shfl_xor(l[r], off, CC_WAVE);
-#pragma unroll
-      for (int e = 0; e < VEC; e++) acc[r][e] += __shfl_xor(acc[r][e], off, CC_WAVE);
-    }
-  }
+  // ---- row-group partials -> LDS (every lane writes its own VEC-wide slice; no cross-lane shuffles)
+  const int grp = wave * RPW + lr;
   if (lane == 0) {
 #pragma unroll
-    for (int r = 0; r < RT; r++) {
-      sm_m[wave][r] = m[r];
-      sm_l[wave][r] = l[r];
-    }
+    for (int r = 0; r < RT; r++) sm_m[wave][r] = m[r];
   }
-  if (lr == 0) {
+  if (lc == 0) {
 #pragma unroll
-    for (int r = 0; r < RT; r++)
-#pragma unroll
-      for (int e = 0; e < VEC; e++) sm_acc[wave][r][lc * VEC + e] = acc[r][e];
+    for (int r = 0; r < RT; r++) sm_l[grp][r] = l[r];
   }
+#pragma unroll
+  for (int r = 0; r < RT; r++)
+#pragma unroll
+    for (int e = 0; e < VEC; e += 4)
+      *reinterpret_cast<float4*>(&sm_acc[grp][r][lc * VEC + e]) =
+          make_float4(acc[r][e], acc[r][e + 1], acc[r][e + 2], acc[r][e + 3]);
   __syncthreads();
   for (int t = threadIdx.x; t < RT * D; t += NW * 64) {
     const int r = t / D, d = t - r * D;
@@ -167,9 +210,15 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_split_kernel(SplitArgs a)
     float L = 0.f, O = 0.f;
 #pragma unroll
     for (int w = 0; w < NW; w++) {
-      const float f = expf(sm_m[w][r] - Mu);
-      L = fmaf(sm_l[w][r], f, L);
-      O = fmaf(sm_acc[w][r][d], f, O);
+      const float f = fast_exp(sm_m[w][r] - Mu);
+      float lw = 0.f, ow = 0.f;
+#pragma unroll
+      for (int g = 0; g < RPW; g++) {
+        lw += sm_l[w * RPW + g][r];
+        ow += sm_acc[w * RPW + g][r][d];
+      }
+      L = fmaf(lw, f, L);
+      O = fmaf(ow, f, O);
     }
     const size_t pj = (size_t)(q0 + r) * a.n_split + split;
     a.part_o[pj * D + d] = O;
@@ -193,25 +242,36 @@ struct CombineArgs {
   int S, R, D, n_split, chunk;
 };
 
-constexpr int kMaxR = 64;
+constexpr int kMaxR = 32;
+constexpr int kMaxSplit = 512;
 
 template <typename T>
 __global__ __launch_bounds__(256) void decode_attn_combine_kernel(CombineArgs a) {
   __shared__ float sm_M[kMaxR], sm_L[kMaxR];
+  extern __shared__ __attribute__((aligned(16))) float sm_wdyn[];  // [R][n_split]: exp(m_i - M)
   const int h = blockIdx.y, c = blockIdx.x, nchunks = gridDim.x;
   const int R = a.R, S = a.S, D = a.D, ns = a.n_split;
-  if (threadIdx.x < R) {
-    const int j = h * R + threadIdx.x;
-    float M = -INFINITY;
-    for (int i = 0; i < ns; i++) M = fmaxf(M, a.part_ml[((size_t)j * ns + i) * 2]);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // final (M, L) per query head: one wave per head, lanes stride over the splits (fixed order: deterministic)
+  for (int r = wave; r < R; r += 4) {
+    const float2* ml = reinterpret_cast<const float2*>(a.part_ml) + (size_t)(h * R + r) * ns;
+    float mi = -INFINITY;
+    for (int i = lane; i < ns; i += 64) mi = fmaxf(mi, ml[i].x);
+    const float M = wave_max_f32(mi);
     const float Mu = (M == -INFINITY) ? 0.f : M;
     float L = 0.f;
-    for (int i = 0; i < ns; i++) {
-      const float* ml = a.part_ml + ((size_t)j * ns + i) * 2;
-      L = fmaf(ml[1], expf(ml[0] - Mu), L);
+    for (int i = lane; i < ns; i += 64) {
+      const float2 v = ml[i];
+      const float w = expf(v.x - Mu);
+      sm_wdyn[r * ns + i] = w;
+      L = fmaf(v.y, w, L);
     }
-    sm_M[threadIdx.x] = Mu;
-    sm_L[threadIdx.x] = L;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) L += __shfl_xor(L, off, CC_WAVE);
+    if (lane == 0) {
+      sm_M[r] = Mu;
+      sm_L[r] = L;
+    }
   }
   __syncthreads();
 
@@ -222,11 +282,17 @@ __global__ __launch_bounds__(256) void decode_attn_combine_kernel(CombineArgs a)
     const int lo = c * per, hi = min(total, lo + per);
     for (int t = lo + threadIdx.x; t < hi; t += blockDim.x) {
       const int r = t / D, d = t - r * D, j = h * R + r;
+      const float* po = a.part_o + (size_t)j * ns * D + d;
       float O = 0.f;
-      for (int i = 0; i < ns; i++) {
-        const size_t pj = (size_t)j * ns + i;
-        O = fmaf(a.part_o[pj * D + d], expf(a.part_ml[pj * 2] - sm_M[r]), O);
+      int i = 0;
+      for (; i + 8 <= ns; i += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = po[(size_t)(i + u) * D];
+#pragma unroll
+        for (int u = 0; u < 8; u++) O = fmaf(v[u], sm_wdyn[r * ns + i + u], O);
       }
+      for (; i < ns; i++) O = fmaf(po[(size_t)i * D], sm_wdyn[r * ns + i], O);
       ElemTraits<T>::store(reinterpret_cast<T*>(a.y), (size_t)j * D + d, O / sm_L[r]);
     }
   }
@@ -234,8 +300,6 @@ __global__ __launch_bounds__(256) void decode_attn_combine_kernel(CombineArgs a)
   // probabilities for this chunk of slots
   const T* sc = reinterpret_cast<const T*>(a.scores);
   const int s_lo = c * a.chunk, s_hi = min(S, s_lo + a.chunk);
-  const float invR = 1.0f / (float)R;
-  (void)invR;
   for (int s = s_lo + threadIdx.x; s < s_hi; s += blockDim.x) {
     float sum = 0.f;
     for (int r = 0; r < R; r++) {
@@ -279,15 +343,14 @@ static Plan make_plan(int HQ, int H, int S, int D, int dtype) {
   const int rpi = rows_per_iter(D, dtype);
   // one iteration per workgroup when that keeps the grid at >= ~256 workgroups; otherwise grow the chunk
   int ns = (S + rpi - 1) / rpi;
-  const int max_split = 64;
-  if (ns > max_split) ns = max_split;
+  if (ns > kMaxSplit) ns = kMaxSplit;
   if (ns < 1) ns = 1;
   int rps = (S + ns - 1) / ns;
   rps = ((rps + rpi - 1) / rpi) * rpi;
   ns = (S + rps - 1) / rps;
   p.n_split = ns;
   p.rows_per_split = rps;
-  p.chunk = 256;
+  p.chunk = 128;
   p.n_chunks = (S + p.chunk - 1) / p.chunk;
   return p;
 }
@@ -333,6 +396,7 @@ int cc_decode_attn_gqa_phases(const void* q, const void* k, const void* v, const
                               int32_t S, int32_t D, int32_t dtype, float scale, void* y, void* attn_out,
                               void* probs_out, double* hh_num, int32_t* hh_denom, int64_t* hh_counter,
                               void* workspace, size_t workspace_bytes, cc_stream_t stream, int32_t phases) {
+  CC_ENTRY();
   if (!q || !k || !v || !y || HQ <= 0 || H <= 0 || HQ % H || S <= 0 || D <= 0 || !cc_dt_ok(dtype) || !workspace)
     return CC_ERR_BAD_ARG;
   if (hh_num && !hh_denom) return CC_ERR_BAD_ARG;
@@ -341,6 +405,7 @@ int cc_decode_attn_gqa_phases(const void* q, const void* k, const void* v, const
   if (D != 16 && D != 32 && D != 64 && D != 128) return CC_ERR_UNSUPPORTED;
   if (workspace_bytes < cc_decode_attn_workspace_bytes(HQ, H, S, D, dtype)) return CC_ERR_WORKSPACE;
   const Plan p = make_plan(HQ, H, S, D, dtype);
+  if ((size_t)R * p.n_split * sizeof(float) > 64 * 1024) return CC_ERR_UNSUPPORTED;  // combine-kernel LDS budget
   char* ws = reinterpret_cast<char*>(workspace);
   SplitArgs sa{};
   sa.q = q; sa.k = k; sa.v = v; sa.mask = mask;
@@ -367,10 +432,11 @@ int cc_decode_attn_gqa_phases(const void* q, const void* k, const void* v, const
   ca.hh_num = hh_num; ca.hh_denom = hh_denom; ca.hh_counter = hh_counter;
   ca.S = S; ca.R = R; ca.D = D; ca.n_split = p.n_split; ca.chunk = p.chunk;
   dim3 grid(p.n_chunks, H), block(256);
+  const size_t lds = (size_t)R * p.n_split * sizeof(float);  // <= 32 * 512 * 4 = 64 KiB
   switch (dtype) {
-    case CC_DT_F32: hipLaunchKernelGGL(decode_attn_combine_kernel<float>, grid, block, 0, st, ca); break;
-    case CC_DT_BF16: hipLaunchKernelGGL(decode_attn_combine_kernel<bf16_t>, grid, block, 0, st, ca); break;
-    default: hipLaunchKernelGGL(decode_attn_combine_kernel<f16_t>, grid, block, 0, st, ca); break;
+    case CC_DT_F32: hipLaunchKernelGGL(decode_attn_combine_kernel<float>, grid, block, lds, st, ca); break;
+    case CC_DT_BF16: hipLaunchKernelGGL(decode_attn_combine_kernel<bf16_t>, grid, block, lds, st, ca); break;
+    default: hipLaunchKernelGGL(decode_attn_combine_kernel<f16_t>, grid, block, lds, st, ca); break;
   }
   CC_LAUNCH_CHECK();
   return CC_OK;

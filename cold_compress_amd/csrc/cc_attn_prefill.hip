@@ -272,6 +272,7 @@ size_t cc_prefill_attn_workspace_bytes(int32_t HQ, int32_t H, int32_t L, int32_t
 int cc_prefill_attn(const void* q, const void* k, const void* v, int32_t HQ, int32_t H, int32_t L, int32_t D,
                     int32_t dtype, float scale, void* y, float* colsum_out, float* obs_out, int32_t obs_len,
                     void* workspace, size_t workspace_bytes, cc_stream_t stream) {
+  CC_ENTRY();
   if (!q || !k || !v || !y || HQ <= 0 || H <= 0 || HQ % H || L <= 0 || D <= 0 || !cc_dt_ok(dtype) || !workspace)
     return CC_ERR_BAD_ARG;
   const int R = HQ / H;

@@ -252,6 +252,7 @@ size_t cc_topk_keep_workspace_bytes(int32_t Hs, int32_t L, int32_t K) {
 
 int cc_topk_keep(const void* priority, int32_t prio_dtype, int32_t Hs, int32_t L, int32_t K, int64_t* keep_out,
                  void* workspace, size_t workspace_bytes, cc_stream_t stream) {
+  CC_ENTRY();
   (void)workspace; (void)workspace_bytes;
   if (!priority || !keep_out || Hs <= 0 || L <= 0 || K <= 0 || K > L) return CC_ERR_BAD_ARG;
   dim3 grid(Hs), block(kSelThreads);
@@ -269,6 +270,7 @@ int cc_topk_keep(const void* priority, int32_t prio_dtype, int32_t Hs, int32_t L
 
 int cc_gather_rows(const void* src, const int64_t* keep, int32_t Hk, int32_t H, int32_t L, int32_t K, int32_t D,
                    int32_t dtype, void* dst, cc_stream_t stream) {
+  CC_ENTRY();
   if (!src || !keep || !dst || H <= 0 || L <= 0 || K <= 0 || D <= 0 || (Hk != 1 && Hk != H) || !cc_dt_ok(dtype))
     return CC_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
@@ -294,6 +296,7 @@ int cc_gather_rows(const void* src, const int64_t* keep, int32_t Hk, int32_t H, 
 
 int cc_gather_vec(const void* src, const int64_t* keep, int32_t Hs, int32_t L, int32_t K, int32_t dtype, void* dst,
                   cc_stream_t stream) {
+  CC_ENTRY();
   if (!src || !keep || !dst || Hs <= 0 || L <= 0 || K <= 0 || !cc_dt_ok(dtype)) return CC_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid = grid_for((size_t)Hs * K), block(256);
@@ -308,6 +311,7 @@ int cc_gather_vec(const void* src, const int64_t* keep, int32_t Hs, int32_t L, i
 
 int cc_snapkv_priority(const void* obs_mean, int32_t H, int32_t L, int32_t dtype, int32_t obs_len, int32_t g, void* out,
                        cc_stream_t stream) {
+  CC_ENTRY();
   if (!obs_mean || !out || H <= 0 || L <= 0 || !cc_dt_ok(dtype) || obs_len < 0) return CC_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid = grid_for((size_t)H * L), block(256);
@@ -321,6 +325,7 @@ int cc_snapkv_priority(const void* obs_mean, int32_t H, int32_t L, int32_t dtype
 }
 
 int cc_attn_colsum(const void* attn, int32_t H, int32_t Lq, int32_t Lk, int32_t dtype, float* out, cc_stream_t stream) {
+  CC_ENTRY();
   if (!attn || !out || H <= 0 || Lq <= 0 || Lk <= 0 || !cc_dt_ok(dtype)) return CC_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid = grid_for((size_t)H * Lk), block(256);
@@ -335,6 +340,7 @@ int cc_attn_colsum(const void* attn, int32_t H, int32_t Lq, int32_t Lk, int32_t 
 
 int cc_colsum_to_mean(const float* colsum, const int64_t* input_pos, int32_t H, int32_t L, int32_t dtype, void* out,
                       cc_stream_t stream) {
+  CC_ENTRY();
   if (!colsum || !out || H <= 0 || L <= 0 || !cc_dt_ok(dtype)) return CC_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid = grid_for((size_t)H * L), block(256);

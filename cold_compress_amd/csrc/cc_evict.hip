@@ -66,7 +66,27 @@ __global__ __launch_bounds__(kUpdThreads) void decode_update_kernel(UpdArgs a) {
     float m = -INFINITY;
     int nan = 0;
     const int n = a.H * S;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    constexpr int VEC = 16 / (int)sizeof(T);
+    const int nvec = ((reinterpret_cast<uintptr_t>(kn) & 15) == 0) ? n / VEC : 0;
+    for (int i0 = threadIdx.x; i0 < nvec; i0 += kUpdThreads * 4) {  // 4 x 16-byte loads in flight per thread
+      Vec16<T> vv[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int i = i0 + u * kUpdThreads;
+        vv[u].load(kn + (size_t)(i < nvec ? i : nvec - 1) * VEC);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        float f[VEC];
+        vv[u].unpack(f);
+#pragma unroll
+        for (int e = 0; e < VEC; e++) {
+          nan |= (f[e] != f[e]);
+          m = fmaxf(m, f[e]);
+        }
+      }
+    }
+    for (int i = nvec * VEC + threadIdx.x; i < n; i += blockDim.x) {
       float v = ElemTraits<T>::load(kn, i);
       nan |= (v != v);
       m = fmaxf(m, v);
@@ -91,42 +111,66 @@ __global__ __launch_bounds__(kUpdThreads) void decode_update_kernel(UpdArgs a) {
   }
 
   unsigned long long best = ~0ull;
-  for (int s = threadIdx.x; s < S; s += blockDim.x) {
-    const int32_t ps = pos[s];
-    uint32_t ord;
-    if (POLICY == P_FULL) {
-      ord = orderable_i32(ps);  // ref: cache.py:502 pos.argmin()
-    } else if (POLICY == P_RECENT_GLOBAL) {
-      if (s < a.g) continue;  // ref: cache.py:554 argmin(pos[:, :, g:]) + g
-      ord = orderable_i32(ps);
-    } else {
-      float sc;
-      if (POLICY == P_SCORES) {
-        sc = ElemTraits<ST>::load(reinterpret_cast<const ST*>(a.scores), (size_t)(a.score_heads == 1 ? 0 : hp) * S + s);
-      } else if (POLICY == P_RANDOM) {
-        sc = reinterpret_cast<const float*>(a.scores)[s];
-        if (ps >= p - a.w) sc = INFINITY;  // ref: cache.py:523
-      } else if (POLICY == P_L2) {
-        // ref: cache.py:601-605 — model-dtype subtraction (fp32 op, rounded to T), recent window -> +inf
-        sc = ElemTraits<T>::rnd(gmax - ElemTraits<T>::load(reinterpret_cast<const T*>(a.key_norm), (size_t)hp * S + s));
-        if (ps >= p - a.w) sc = INFINITY;
-      } else {  // P_HH, ref: cache.py:727-749
-        const double nm = a.num[(size_t)hp * S + s];
-        int32_t dn = a.denom[(size_t)hp * S + s];
-        dn = dn < 1 ? 1 : dn;
-        sc = __fdiv_rn((float)nm, (float)dn);  // f64->f32 RNE, int32->f32, IEEE divide
-        if (ps < a.g || ps >= p - a.w) sc = 1.0f;
-        if (ps == -1) sc = 0.0f;
+  constexpr int UN = 4;  // slots per thread per pass: all per-slot loads are issued before the first use
+  const size_t hoff = (size_t)hp * S;
+  for (int s0 = threadIdx.x; s0 < S; s0 += kUpdThreads * UN) {
+    int32_t psv[UN];
+    float fv[UN];
+    double dv[UN];
+    int32_t iv[UN];
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+      const int s = s0 + u * kUpdThreads;
+      const int sc = s < S ? s : S - 1;  // clamped: loads stay unconditional (no exec-masked waits)
+      psv[u] = pos[sc];
+      fv[u] = 0.f;
+      dv[u] = 0.0;
+      iv[u] = 0;
+      if (POLICY == P_SCORES) fv[u] = ElemTraits<ST>::load(reinterpret_cast<const ST*>(a.scores), (a.score_heads == 1 ? 0 : hoff) + sc);
+      if (POLICY == P_RANDOM) fv[u] = reinterpret_cast<const float*>(a.scores)[sc];
+      if (POLICY == P_L2) fv[u] = ElemTraits<T>::load(reinterpret_cast<const T*>(a.key_norm), hoff + sc);
+      if (POLICY == P_HH) {
+        dv[u] = a.num[hoff + sc];
+        iv[u] = a.denom[hoff + sc];
       }
-      if (POLICY != P_HH) {
-        // ref: cache.py:373-376 base rules: first g SLOTS -> +inf, then empty slots -> -inf
-        if (s < a.g) sc = INFINITY;
-        if (ps == -1) sc = -INFINITY;
-      }
-      ord = orderable_f32(sc);
     }
-    const unsigned long long key = make_key(ord, (uint32_t)s);
-    best = key < best ? key : best;
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+      const int s = s0 + u * kUpdThreads;
+      const int32_t ps = psv[u];
+      uint32_t ord;
+      bool skip = s >= S;
+      if (POLICY == P_FULL) {
+        ord = orderable_i32(ps);  // ref: cache.py:502 pos.argmin()
+      } else if (POLICY == P_RECENT_GLOBAL) {
+        skip |= s < a.g;  // ref: cache.py:554 argmin(pos[:, :, g:]) + g
+        ord = orderable_i32(ps);
+      } else {
+        float sc;
+        if (POLICY == P_SCORES) {
+          sc = fv[u];
+        } else if (POLICY == P_RANDOM) {
+          sc = (ps >= p - a.w) ? INFINITY : fv[u];  // ref: cache.py:523
+        } else if (POLICY == P_L2) {
+          // ref: cache.py:601-605 — model-dtype subtraction (fp32 op, rounded to T), recent window -> +inf
+          sc = ElemTraits<T>::rnd(gmax - fv[u]);
+          if (ps >= p - a.w) sc = INFINITY;
+        } else {  // P_HH, ref: cache.py:727-749
+          const int32_t dn = iv[u] < 1 ? 1 : iv[u];
+          sc = __fdiv_rn((float)dv[u], (float)dn);  // f64->f32 RNE, int32->f32, IEEE divide
+          if (ps < a.g || ps >= p - a.w) sc = 1.0f;
+          if (ps == -1) sc = 0.0f;
+        }
+        if (POLICY != P_HH) {
+          // ref: cache.py:373-376 base rules: first g SLOTS -> +inf, then empty slots -> -inf
+          if (s < a.g) sc = INFINITY;
+          if (ps == -1) sc = -INFINITY;
+        }
+        ord = orderable_f32(sc);
+      }
+      const unsigned long long key = skip ? ~0ull : make_key(ord, (uint32_t)s);
+      best = key < best ? key : best;
+    }
   }
   best = block_min_u64(best, sm_key);
   const int idx = (int)(best & 0xffffffffull);
@@ -249,6 +293,7 @@ extern "C" {
 
 int cc_decode_update_full(const cc_kv_view* c, const void* k_new, const void* v_new, const int32_t* input_pos,
                           int64_t* idx_out, cc_stream_t stream) {
+  CC_ENTRY();
   if (!cc_view_ok(c) || !input_pos || !idx_out || c->Hp != 1 || (k_new && !v_new)) return CC_ERR_BAD_ARG;
   UpdArgs a{};
   a.k_new = k_new; a.v_new = v_new; a.input_pos = input_pos; a.idx_out = idx_out;
@@ -257,6 +302,7 @@ int cc_decode_update_full(const cc_kv_view* c, const void* k_new, const void* v_
 
 int cc_decode_update_recent_global(const cc_kv_view* c, const void* k_new, const void* v_new,
                                    const int32_t* input_pos, int32_t g, int64_t* idx_out, cc_stream_t stream) {
+  CC_ENTRY();
   if (!cc_view_ok(c) || !input_pos || !idx_out || c->Hp != 1 || g < 0 || g >= c->S || (k_new && !v_new))
     return CC_ERR_BAD_ARG;
   UpdArgs a{};
@@ -267,6 +313,7 @@ int cc_decode_update_recent_global(const cc_kv_view* c, const void* k_new, const
 int cc_decode_update_scores(const cc_kv_view* c, const void* k_new, const void* v_new, const int32_t* input_pos,
                             const void* scores, int32_t score_dtype, int32_t g, int64_t* idx_out,
                             cc_stream_t stream) {
+  CC_ENTRY();
   if (!cc_view_ok(c) || !input_pos || !idx_out || !scores || !cc_dt_ok(score_dtype) || g < 0 || (k_new && !v_new))
     return CC_ERR_BAD_ARG;
   UpdArgs a{};
@@ -281,6 +328,7 @@ int cc_decode_update_scores(const cc_kv_view* c, const void* k_new, const void* 
 
 int cc_decode_update_random(const cc_kv_view* c, const void* k_new, const void* v_new, const int32_t* input_pos,
                             const float* rand_u, int32_t g, int32_t w, int64_t* idx_out, cc_stream_t stream) {
+  CC_ENTRY();
   if (!cc_view_ok(c) || !input_pos || !idx_out || !rand_u || c->Hp != 1 || g < 0 || (k_new && !v_new))
     return CC_ERR_BAD_ARG;
   UpdArgs a{};
@@ -297,6 +345,7 @@ size_t cc_decode_update_l2_workspace_bytes(int32_t H, int32_t S) {
 int cc_decode_update_l2(const cc_kv_view* c, const void* k_new, const void* v_new, const int32_t* input_pos,
                         void* key_norm, int32_t g, int32_t w, int64_t* idx_out, void* workspace,
                         size_t workspace_bytes, cc_stream_t stream) {
+  CC_ENTRY();
   (void)workspace; (void)workspace_bytes;
   if (!cc_view_ok(c) || !input_pos || !idx_out || !key_norm || c->Hp != c->H || g < 0 || (k_new && !v_new))
     return CC_ERR_BAD_ARG;
@@ -309,6 +358,7 @@ int cc_decode_update_l2(const cc_kv_view* c, const void* k_new, const void* v_ne
 int cc_decode_update_heavy_hitter(const cc_kv_view* c, const void* k_new, const void* v_new,
                                   const int32_t* input_pos, double* num, int32_t* denom, int32_t g, int32_t w,
                                   int64_t* idx_out, cc_stream_t stream) {
+  CC_ENTRY();
   if (!cc_view_ok(c) || !input_pos || !idx_out || !num || !denom || c->Hp != c->H || (k_new && !v_new))
     return CC_ERR_BAD_ARG;
   UpdArgs a{};
@@ -319,6 +369,7 @@ int cc_decode_update_heavy_hitter(const cc_kv_view* c, const void* k_new, const 
 
 int cc_hh_update(double* num, int32_t* denom, int64_t* counter, const void* attn, int32_t H, int32_t S, int32_t T,
                  int32_t dtype, cc_stream_t stream) {
+  CC_ENTRY();
   if (!num || !denom || !attn || H <= 0 || S <= 0 || T < 0 || T > S || !cc_dt_ok(dtype)) return CC_ERR_BAD_ARG;
   const int n = H * S;
   dim3 grid((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024), block(256);
@@ -334,6 +385,7 @@ int cc_hh_update(double* num, int32_t* denom, int64_t* counter, const void* attn
 
 int cc_prefill_fill(const cc_kv_view* c, const void* k_val, const void* v_val, const int64_t* pos_val, int32_t PH,
                     int32_t T, cc_stream_t stream) {
+  CC_ENTRY();
   if (!cc_view_ok(c) || !k_val || !v_val || !pos_val || T <= 0 || T > c->S || (PH != 1 && PH != c->Hp) || c->Hc > 256)
     return CC_ERR_BAD_ARG;
   UpdArgs a{};
@@ -357,6 +409,7 @@ int cc_prefill_fill(const cc_kv_view* c, const void* k_val, const void* v_val, c
 
 int cc_row_l2_norm(const void* x, int32_t H, int32_t N, int32_t D, int32_t dtype, int32_t negate, void* out,
                    cc_stream_t stream) {
+  CC_ENTRY();
   if (!x || !out || H <= 0 || N <= 0 || D <= 0 || !cc_dt_ok(dtype)) return CC_ERR_BAD_ARG;
   const int rows = H * N;
   int nb = (rows + 15) / 16;

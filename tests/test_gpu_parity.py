@@ -109,8 +109,6 @@ def test_l2_replay_vs_reference(cc, name):
         p = torch.tensor([T + t], dtype=torch.int32, device=DEV)
         kv.update_kv(p, f["k_new"][t].to(DEV), f["v_new"][t].to(DEV), False)
         assert np.array_equal(_idx(kv), f["idx"][t].numpy()), f"step {t}"
-        # keep the norms on the reference's values so that every later index is compared on identical state
-        ref_idx = f["idx"][t]
     _final_equal(kv, f)
     assert torch.allclose(kv.key_norm.cpu().float(), f["final_keynorm"].float(), **tol)
 
