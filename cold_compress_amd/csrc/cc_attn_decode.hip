@@ -38,15 +38,45 @@ __device__ __forceinline__ float group_sum(float v) {
   if (W >= 64) v += __shfl_xor(v, 32, CC_WAVE);
   return v;
 }
-// max over the 64/W groups of a wave (lanes with equal lane % W); every lane gets the result
+// value held by lane ^ OFF for OFF in {16, 32}: one v_permlane{16,32}_swap (VALU; no LDS crossbar traffic).
+// swap(x, x) returns {rows a|a, rows b|b}: whichever differs from ours is the partner's value — but we only ever
+// need sum or max with the partner, both symmetric, so combine the two returned halves directly.
+template <int OFF, bool IS_MAX>
+__device__ __forceinline__ float xor_combine(float v) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  float a, b;
+  if (OFF == 16) {
+    auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    a = __builtin_bit_cast(float, (unsigned)r[0]);
+    b = __builtin_bit_cast(float, (unsigned)r[1]);
+  } else {
+    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    a = __builtin_bit_cast(float, (unsigned)r[0]);
+    b = __builtin_bit_cast(float, (unsigned)r[1]);
+  }
+  return IS_MAX ? fmaxf(a, b) : a + b;
+}
+// sum / max over the 64/W row groups of a wave (lanes with equal lane % W); every lane gets the result
+// (partners must keep lane % W: quad_perm for bits 0/1, row rotations by 4 and 8 for bits 2/3 — a mirror would
+// pair different columns — then the permlane swaps for bits 4/5)
+template <int W>
+__device__ __forceinline__ float across_groups_sum(float v) {
+  if (W <= 1) v += dpp_mov<0xB1>(v);   // lane ^ 1
+  if (W <= 2) v += dpp_mov<0x4E>(v);   // lane ^ 2
+  if (W <= 4) v += dpp_mov<0x124>(v);  // row_ror:4
+  if (W <= 8) v += dpp_mov<0x128>(v);  // row_ror:8 (== lane ^ 8)
+  if (W <= 16) v = xor_combine<16, false>(v);
+  if (W <= 32) v = xor_combine<32, false>(v);
+  return v;
+}
 template <int W>
 __device__ __forceinline__ float across_groups_max(float v) {
   if (W <= 1) v = fmaxf(v, dpp_mov<0xB1>(v));
   if (W <= 2) v = fmaxf(v, dpp_mov<0x4E>(v));
-  if (W <= 4) v = fmaxf(v, dpp_mov<0x141>(v));
-  if (W <= 8) v = fmaxf(v, dpp_mov<0x140>(v));
-  if (W <= 16) v = fmaxf(v, __shfl_xor(v, 16, CC_WAVE));
-  if (W <= 32) v = fmaxf(v, __shfl_xor(v, 32, CC_WAVE));
+  if (W <= 4) v = fmaxf(v, dpp_mov<0x124>(v));
+  if (W <= 8) v = fmaxf(v, dpp_mov<0x128>(v));
+  if (W <= 16) v = xor_combine<16, true>(v);
+  if (W <= 32) v = xor_combine<32, true>(v);
   return v;
 }
 
@@ -64,6 +94,7 @@ struct SplitArgs {
   float* part_o;   // [HQ, n_split, D]
   int S, R, n_split, rows_per_split;
   float scale;
+  int abl;  // measurement-only ablation bits (phases >> 8): 1 = no score store, 2 = no epilogue, 4 = no mask
 };
 
 template <typename T, int D, int RT, int NW, int U>
@@ -72,8 +103,8 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_split_kernel(SplitArgs a)
   constexpr int LPR = D / VEC;
   static_assert(LPR >= 1 && LPR <= 64 && (LPR & (LPR - 1)) == 0, "head_dim must map to a power-of-two lane count");
   constexpr int RPW = 64 / LPR;  // rows per wave-wide load
-  constexpr int NG = NW * RPW;   // row groups per workgroup
-  __shared__ float sm_m[NW][RT];
+  constexpr int NG = NW * RPW;  // row groups per workgroup
+  __shared__ float sm_m[NG][RT];
   __shared__ float sm_l[NG][RT];
   __shared__ __attribute__((aligned(16))) float sm_acc[NG][RT][D];
 
@@ -85,7 +116,7 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_split_kernel(SplitArgs a)
   const int row_end = min(S, row_begin + a.rows_per_split);
   const T* kh = reinterpret_cast<const T*>(a.k) + (size_t)h * S * D + lc * VEC;
   const T* vh = reinterpret_cast<const T*>(a.v) + (size_t)h * S * D + lc * VEC;
-  const bool has_mask = a.mask != nullptr;
+  const bool has_mask = a.mask != nullptr && !(a.abl & 4);
   const uint8_t* mh = has_mask ? a.mask + (size_t)h * S : reinterpret_cast<const uint8_t*>(a.k);
   T* sc_out = reinterpret_cast<T*>(a.scores);
 
@@ -98,36 +129,45 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_split_kernel(SplitArgs a)
     for (int e = 0; e < VEC; e++) acc[r][e] = 0.f;
   }
 
-  for (int base = row_begin + wave * (RPW * U); base < row_end; base += NW * RPW * U) {
-    // ---- issue every load of this iteration before the first use: mask bytes, K rows, V rows
-    uint8_t mk[U];
-    Vec16<T> kk[U], vv[U];
-    int rcl[U];
+  // q: [RT][D] of this query group, this lane's VEC-wide column slice (L2-resident after the first workgroups)
+  float qf[RT][VEC];
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-      const int row = base + u * RPW + lr;
-      rcl[u] = row < row_end ? row : row_end - 1;
-      mk[u] = mh[rcl[u]];
-    }
-#pragma unroll
-    for (int u = 0; u < U; u++) kk[u].load(kh + (size_t)rcl[u] * D);
-#pragma unroll
-    for (int u = 0; u < U; u++) vv[u].load(vh + (size_t)rcl[u] * D);
+  for (int r = 0; r < RT; r++) {
+    Vec16<T> t;
+    t.load(reinterpret_cast<const T*>(a.q) + (size_t)(q0 + r) * D + lc * VEC);
+    t.unpack(qf[r]);
+  }
 
-    float qf[RT][VEC];
+  // Row group lr of wave `wave` owns the U CONSECUTIVE rows base + lr*U + [0, U): its mask bytes are one
+  // aligned 32-bit word, its scores one contiguous run, and its softmax state (m, l, acc) is private to the
+  // 16-lane group — no cross-group shuffles anywhere in the loop.
+  for (int base = row_begin + wave * (RPW * U); base < row_end; base += NW * RPW * U) {
+    // ---- issue every load of this iteration before the first use: mask word, K rows, V rows
+    const int row0 = base + lr * U;
+    static_assert(U <= 4, "mask bytes of a row group are packed into one 32-bit word");
+    uint32_t mword = 0x01010101u;
+    if (has_mask) {
+      if (U == 4 && row0 + 3 < S && ((reinterpret_cast<uintptr_t>(mh) + (size_t)row0) & 3) == 0) {
+        mword = *reinterpret_cast<const uint32_t*>(mh + row0);  // the common case: one aligned word
+      } else {  // ragged tail / unaligned head offset: assemble from bytes
+        mword = 0;
 #pragma unroll
-    for (int r = 0; r < RT; r++) {
-      Vec16<T> t;
-      t.load(reinterpret_cast<const T*>(a.q) + (size_t)(q0 + r) * D + lc * VEC);
-      t.unpack(qf[r]);
+        for (int u = 0; u < U; u++)
+          if (row0 + u < S) mword |= (uint32_t)mh[row0 + u] << (8 * u);
+      }
     }
+    Vec16<T> kk[U], vv[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) kk[u].load(kh + (size_t)(row0 + u < row_end ? row0 + u : row_end - 1) * D);
+#pragma unroll
+    for (int u = 0; u < U; u++) vv[u].load(vh + (size_t)(row0 + u < row_end ? row0 + u : row_end - 1) * D);
 
     float s[RT][U];
 #pragma unroll
     for (int u = 0; u < U; u++) {
       float kf[VEC];
       kk[u].unpack(kf);
-      const bool valid = (base + u * RPW + lr < row_end) && (!has_mask || mk[u] != 0);
+      const bool valid = (row0 + u < row_end) && (((mword >> (8 * u)) & 0xffu) != 0);
 #pragma unroll
       for (int r = 0; r < RT; r++) {
         float d = 0.f;
@@ -140,7 +180,7 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_split_kernel(SplitArgs a)
       }
     }
     // ---- scores out: lane lc of each row group stores pair t = pass*LPR + lc  (t = r*U + u): one store
-    //      instruction per pass with every lane active, 2*RPW*U contiguous bytes per query head
+    //      instruction per pass with every lane active, RPW*U contiguous elements per query head
 #pragma unroll
     for (int pass = 0; pass * LPR < RT * U; pass++) {
       const int t = pass * LPR + lc;
@@ -150,16 +190,15 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_split_kernel(SplitArgs a)
 #pragma unroll
         for (int u = 0; u < U; u++) val = (t == r * U + u) ? s[r][u] : val;
       const int r = t / U, u = t - r * U;
-      const int row = base + u * RPW + lr;
-      if (t < RT * U && row < row_end) ElemTraits<T>::store(sc_out, (size_t)(q0 + r) * S + row, val);
+      const int row = row0 + u;
+      if (t < RT * U && row < row_end && !(a.abl & 1)) ElemTraits<T>::store(sc_out, (size_t)(q0 + r) * S + row, val);
     }
-    // ---- online softmax (wave-uniform running max per query head)
+    // ---- online softmax, state private to the row group
 #pragma unroll
     for (int r = 0; r < RT; r++) {
       float mx = s[r][0];
 #pragma unroll
       for (int u = 1; u < U; u++) mx = fmaxf(mx, s[r][u]);
-      mx = across_groups_max<LPR>(mx);
       const float m_new = fmaxf(m[r], mx);
       const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
       const float alpha = fast_exp(m[r] - m_use);
@@ -184,41 +223,51 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_split_kernel(SplitArgs a)
     }
   }
 
-  // ---- row-group partials -> LDS (every lane writes its own VEC-wide slice; no cross-lane shuffles)
-  const int grp = wave * RPW + lr;
-  if (lane == 0) {
+  if (a.abl & 2) {  // measurement only: keep the accumulators live, skip the merge
+    float x = 0.f;
 #pragma unroll
-    for (int r = 0; r < RT; r++) sm_m[wave][r] = m[r];
+    for (int r = 0; r < RT; r++) {
+      x += l[r] + m[r];
+#pragma unroll
+      for (int e = 0; e < VEC; e++) x += acc[r][e];
+    }
+    if (x == 1.2345f) a.part_ml[0] = x;
+    return;
   }
+  // ---- row-group partials -> LDS.  Every lane writes its own VEC-wide slice as 16-byte pieces; piece e4 of
+  //      lane lc lands at column (e4/4)*(D/ (VEC/4)) ... i.e. [piece][lc][4]: consecutive lanes are 16 B apart,
+  //      so the ds_write_b128 lane groups are bank-conflict free.  (Measured: merging the row groups in
+  //      registers with v_permlane16/32_swap butterflies instead is SLOWER: 8.9 vs 7.75 us at S = 4096.)
+  constexpr int NP = VEC / 4 > 0 ? VEC / 4 : 1;  // 16-byte pieces per lane
+  const int grp = wave * RPW + lr;
   if (lc == 0) {
 #pragma unroll
-    for (int r = 0; r < RT; r++) sm_l[grp][r] = l[r];
+    for (int r = 0; r < RT; r++) {
+      sm_m[grp][r] = m[r];
+      sm_l[grp][r] = l[r];
+    }
   }
 #pragma unroll
   for (int r = 0; r < RT; r++)
 #pragma unroll
-    for (int e = 0; e < VEC; e += 4)
-      *reinterpret_cast<float4*>(&sm_acc[grp][r][lc * VEC + e]) =
-          make_float4(acc[r][e], acc[r][e + 1], acc[r][e + 2], acc[r][e + 3]);
+    for (int pc = 0; pc < NP; pc++)
+      *reinterpret_cast<float4*>(&sm_acc[grp][r][(pc * LPR + lc) * 4]) =
+          make_float4(acc[r][pc * 4], acc[r][pc * 4 + 1], acc[r][pc * 4 + 2], acc[r][pc * 4 + 3]);
   __syncthreads();
   for (int t = threadIdx.x; t < RT * D; t += NW * 64) {
     const int r = t / D, d = t - r * D;
+    // column d lives in lane d / VEC, piece (d % VEC) / 4, element d % 4
+    const int dl = (((d % VEC) / 4) * LPR + d / VEC) * 4 + (d & 3);
     float M = -INFINITY;
 #pragma unroll
-    for (int w = 0; w < NW; w++) M = fmaxf(M, sm_m[w][r]);
+    for (int g = 0; g < NG; g++) M = fmaxf(M, sm_m[g][r]);
     const float Mu = (M == -INFINITY) ? 0.f : M;
     float L = 0.f, O = 0.f;
 #pragma unroll
-    for (int w = 0; w < NW; w++) {
-      const float f = fast_exp(sm_m[w][r] - Mu);
-      float lw = 0.f, ow = 0.f;
-#pragma unroll
-      for (int g = 0; g < RPW; g++) {
-        lw += sm_l[w * RPW + g][r];
-        ow += sm_acc[w * RPW + g][r][d];
-      }
-      L = fmaf(lw, f, L);
-      O = fmaf(ow, f, O);
+    for (int g = 0; g < NG; g++) {  // fixed order: deterministic
+      const float f = fast_exp(sm_m[g][r] - Mu);
+      L = fmaf(sm_l[g][r], f, L);
+      O = fmaf(sm_acc[g][r][dl], f, O);
     }
     const size_t pj = (size_t)(q0 + r) * a.n_split + split;
     a.part_o[pj * D + d] = O;
@@ -245,15 +294,32 @@ struct CombineArgs {
 constexpr int kMaxR = 32;
 constexpr int kMaxSplit = 512;
 
+constexpr int kCombThreads = 128;  // == slots per block: every thread owns one cache slot of its kv head
+constexpr int kPre = 8;            // query heads whose scores are prefetched into registers (R <= 8 typical)
+
 template <typename T>
-__global__ __launch_bounds__(256) void decode_attn_combine_kernel(CombineArgs a) {
+__global__ __launch_bounds__(kCombThreads) void decode_attn_combine_kernel(CombineArgs a) {
   __shared__ float sm_M[kMaxR], sm_L[kMaxR];
   extern __shared__ __attribute__((aligned(16))) float sm_wdyn[];  // [R][n_split]: exp(m_i - M)
   const int h = blockIdx.y, c = blockIdx.x, nchunks = gridDim.x;
   const int R = a.R, S = a.S, D = a.D, ns = a.n_split;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // ---- issue this thread's per-slot loads first: their latency overlaps the (M, L) reduction below
+  const T* sc = reinterpret_cast<const T*>(a.scores);
+  const int s_mine = c * a.chunk + threadIdx.x;
+  const bool have = threadIdx.x < a.chunk && s_mine < S;
+  const int s_ld = have ? s_mine : 0;
+  float xs[kPre];
+#pragma unroll
+  for (int r = 0; r < kPre; r++) xs[r] = ElemTraits<T>::load(sc, (size_t)(h * R + (r < R ? r : 0)) * S + s_ld);
+  double num_old = 0.0;
+  int32_t den_old = 0;
+  if (a.hh_num) {
+    num_old = a.hh_num[(size_t)h * S + s_ld];
+    den_old = a.hh_denom[(size_t)h * S + s_ld];
+  }
   // final (M, L) per query head: one wave per head, lanes stride over the splits (fixed order: deterministic)
-  for (int r = wave; r < R; r += 4) {
+  for (int r = wave; r < R; r += kCombThreads / 64) {
     const float2* ml = reinterpret_cast<const float2*>(a.part_ml) + (size_t)(h * R + r) * ns;
     float mi = -INFINITY;
     for (int i = lane; i < ns; i += 64) mi = fmaxf(mi, ml[i].x);
@@ -275,36 +341,56 @@ __global__ __launch_bounds__(256) void decode_attn_combine_kernel(CombineArgs a)
   }
   __syncthreads();
 
-  // y: the R*D outputs of this kv head are spread over the chunk blocks
+  // y: the R*D outputs of this kv head are spread over the chunk blocks; inside a block the (output, split)
+  // products are spread over ALL threads (G split-groups per output) so every partial-O load is in flight at
+  // once, then reduced through LDS in a fixed order (deterministic).
   {
+    __shared__ float sm_y[kCombThreads];
     const int total = R * D;
     const int per = (total + nchunks - 1) / nchunks;
     const int lo = c * per, hi = min(total, lo + per);
-    for (int t = lo + threadIdx.x; t < hi; t += blockDim.x) {
-      const int r = t / D, d = t - r * D, j = h * R + r;
-      const float* po = a.part_o + (size_t)j * ns * D + d;
-      float O = 0.f;
-      int i = 0;
-      for (; i + 8 <= ns; i += 8) {
-        float v[8];
+    for (int o0 = lo; o0 < hi; o0 += kCombThreads) {
+      const int nout = min(hi - o0, kCombThreads);
+      const int G = max(1, min(kCombThreads / nout, ns));
+      const int oi = threadIdx.x % nout, g = threadIdx.x / nout;
+      const int t = o0 + oi, r = t / D, d = t - r * D, j = h * R + r;
+      float part = 0.f;
+      if (g < G) {
+        const float* po = a.part_o + (size_t)j * ns * D + d;
+        int i = g;
+        for (; i + 7 * G < ns; i += 8 * G) {
+          float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) v[u] = po[(size_t)(i + u) * D];
+          for (int u = 0; u < 8; u++) v[u] = po[(size_t)(i + u * G) * D];
 #pragma unroll
-        for (int u = 0; u < 8; u++) O = fmaf(v[u], sm_wdyn[r * ns + i + u], O);
+          for (int u = 0; u < 8; u++) part = fmaf(v[u], sm_wdyn[r * ns + i + u * G], part);
+        }
+        for (; i < ns; i += G) part = fmaf(po[(size_t)i * D], sm_wdyn[r * ns + i], part);
       }
-      for (; i < ns; i++) O = fmaf(po[(size_t)i * D], sm_wdyn[r * ns + i], O);
-      ElemTraits<T>::store(reinterpret_cast<T*>(a.y), (size_t)j * D + d, O / sm_L[r]);
+      __syncthreads();
+      sm_y[threadIdx.x] = part;
+      __syncthreads();
+      if (g == 0) {
+        float O = 0.f;
+        for (int gg = 0; gg < G; gg++) O += sm_y[gg * nout + oi];
+        ElemTraits<T>::store(reinterpret_cast<T*>(a.y), (size_t)j * D + d, O / sm_L[r]);
+      }
     }
   }
 
-  // probabilities for this chunk of slots
-  const T* sc = reinterpret_cast<const T*>(a.scores);
-  const int s_lo = c * a.chunk, s_hi = min(S, s_lo + a.chunk);
-  for (int s = s_lo + threadIdx.x; s < s_hi; s += blockDim.x) {
+  // probabilities for this thread's slot
+  if (have) {
+    const int s = s_mine;
     float sum = 0.f;
     for (int r = 0; r < R; r++) {
       const size_t j = (size_t)h * R + r;
-      const float x = ElemTraits<T>::load(sc, j * S + s);
+      float x = 0.f;
+      if (r < kPre) {
+#pragma unroll
+        for (int t = 0; t < kPre; t++) x = (t == r) ? xs[t] : x;
+      } else {
+        x = ElemTraits<T>::load(sc, j * S + s);
+      }
       // ref: attention_utils.py:52 softmax (fp32 inside, result rounded to the model dtype)
       const float p = ElemTraits<T>::rnd(__fdiv_rn(expf(x - sm_M[r]), sm_L[r]));
       if (a.probs_out) ElemTraits<T>::store(reinterpret_cast<T*>(a.probs_out), j * S + s, p);
@@ -315,15 +401,18 @@ __global__ __launch_bounds__(256) void decode_attn_combine_kernel(CombineArgs a)
     const size_t i = (size_t)h * S + s;
     if (a.attn_out) ElemTraits<T>::store(reinterpret_cast<T*>(a.attn_out), i, av);
     if (a.hh_num) {  // fused cache.py:716-722 (W == 1, attention already padded to S)
-      a.hh_num[i] += (double)av;
-      a.hh_denom[i] += 1;
+      a.hh_num[i] = num_old + (double)av;
+      a.hh_denom[i] = den_old + 1;
     }
   }
   if (a.hh_num && a.hh_counter && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *a.hh_counter += 1;
 }
 
 // ---------------------------------------------------------------- launch plan
-constexpr int kNW = 8;  // waves per split workgroup
+// 4-wave workgroups: ~150 VGPRs -> 3 waves/SIMD -> 3 workgroups resident per CU (33 KiB LDS each), so one
+// workgroup's load phase overlaps another's math/epilogue.  (8-wave workgroups at 66 KiB LDS left ONE resident
+// workgroup per CU and plateaued at ~3 TB/s even at S = 65536: profiles/r01_sweep_before.txt.)
+constexpr int kNW = 4;  // waves per split workgroup
 constexpr int kU = 4;   // 16-byte K loads (and V loads) in flight per lane
 
 struct Plan {
@@ -415,6 +504,7 @@ int cc_decode_attn_gqa_phases(const void* q, const void* k, const void* v, const
   ws += align256((size_t)HQ * p.n_split * 2 * sizeof(float));
   sa.part_o = reinterpret_cast<float*>(ws);
   sa.S = S; sa.R = R; sa.n_split = p.n_split; sa.rows_per_split = p.rows_per_split; sa.scale = scale;
+  sa.abl = (phases >> 8) & 0xff;
   hipStream_t st = (hipStream_t)stream;
   int rc = CC_OK;
   if (phases & 1) {
@@ -431,7 +521,7 @@ int cc_decode_attn_gqa_phases(const void* q, const void* k, const void* v, const
   ca.y = y; ca.attn_out = attn_out; ca.probs_out = probs_out;
   ca.hh_num = hh_num; ca.hh_denom = hh_denom; ca.hh_counter = hh_counter;
   ca.S = S; ca.R = R; ca.D = D; ca.n_split = p.n_split; ca.chunk = p.chunk;
-  dim3 grid(p.n_chunks, H), block(256);
+  dim3 grid(p.n_chunks, H), block(kCombThreads);
   const size_t lds = (size_t)R * p.n_split * sizeof(float);  // <= 32 * 512 * 4 = 64 KiB
   switch (dtype) {
     case CC_DT_F32: hipLaunchKernelGGL(decode_attn_combine_kernel<float>, grid, block, lds, st, ca); break;

@@ -34,19 +34,28 @@ struct UpdArgs {
 
 constexpr int kUpdThreads = 1024;
 
-// Insert the new token for kv-head h at slot idx (all threads of the block participate).
+// The new token's K/V words this workgroup will write: word i of [n_heads_here][2][words] (K row then V row).
+// `pre` = word threadIdx.x, loaded BEFORE the scan so its latency hides behind it.
 template <typename T>
-__device__ __forceinline__ void insert_row(const UpdArgs& a, int h, int idx) {
+__device__ __forceinline__ uint32_t new_word(const UpdArgs& a, int h0, int i) {
   const int words = a.D * (int)sizeof(T) / 4;
-  const uint32_t* ks = reinterpret_cast<const uint32_t*>(a.k_new) + (size_t)h * words;
-  const uint32_t* vs = reinterpret_cast<const uint32_t*>(a.v_new) + (size_t)h * words;
-  uint32_t* kd = reinterpret_cast<uint32_t*>(a.k_cache) + ((size_t)h * a.S + idx) * words;
-  uint32_t* vd = reinterpret_cast<uint32_t*>(a.v_cache) + ((size_t)h * a.S + idx) * words;
-  for (int i = threadIdx.x; i < 2 * words; i += blockDim.x) {
-    if (i < words) kd[i] = ks[i];
-    else vd[i - words] = vs[i - words];
+  const int h = h0 + i / (2 * words), j = i % (2 * words);
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(j < words ? a.k_new : a.v_new) + (size_t)h * words;
+  return src[j < words ? j : j - words];
+}
+
+// Insert the new token for kv heads [h0, h0+nh) at slot idx (all threads of the block participate).
+template <typename T>
+__device__ __forceinline__ void insert_rows(const UpdArgs& a, int h0, int nh, int idx, uint32_t pre) {
+  const int words = a.D * (int)sizeof(T) / 4;
+  const int total = nh * 2 * words;
+  for (int i = threadIdx.x; i < total; i += blockDim.x) {
+    const uint32_t val = (i == (int)threadIdx.x) ? pre : new_word<T>(a, h0, i);
+    const int h = h0 + i / (2 * words), j = i % (2 * words);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(j < words ? a.k_cache : a.v_cache) + ((size_t)h * a.S + idx) * words;
+    dst[j < words ? j : j - words] = val;
   }
-  if (threadIdx.x == 0) a.mask[(size_t)h * a.S + idx] = 1;
+  if ((int)threadIdx.x < nh) a.mask[(size_t)(h0 + threadIdx.x) * a.S + idx] = 1;
 }
 
 template <int POLICY, typename T, typename ST>
@@ -57,6 +66,10 @@ __global__ __launch_bounds__(kUpdThreads) void decode_update_kernel(UpdArgs a) {
   const int S = a.S;
   const int32_t* pos = a.pos + (size_t)hp * S;
   const int32_t p = *a.input_pos;
+  // heads this workgroup inserts for: all of them when pos is shared (head-constant policies), else its own
+  const int h0 = a.Hp == 1 ? 0 : hp, nh = a.Hp == 1 ? a.H : 1;
+  uint32_t pre = 0;
+  if (a.k_new != nullptr && (int)threadIdx.x < nh * 2 * (a.D * (int)sizeof(T) / 4)) pre = new_word<T>(a, h0, threadIdx.x);
 
   float gmax = 0.f;
   if (POLICY == P_L2) {
@@ -168,12 +181,15 @@ __global__ __launch_bounds__(kUpdThreads) void decode_update_kernel(UpdArgs a) {
         }
         ord = orderable_f32(sc);
       }
-      const unsigned long long key = skip ? ~0ull : make_key(ord, (uint32_t)s);
+      // low word = slot << 1 | (slot was empty): ordering by slot is preserved, and the winner's "was empty"
+      // bit travels with the key so no dependent re-read of pos[idx] is needed after the reduction
+      const unsigned long long key = skip ? ~0ull : make_key(ord, ((uint32_t)s << 1) | (uint32_t)(ps == -1));
       best = key < best ? key : best;
     }
   }
   best = block_min_u64(best, sm_key);
-  const int idx = (int)(best & 0xffffffffull);
+  const int idx = (int)((best & 0xffffffffull) >> 1);
+  const int ins = (int)(best & 1ull);  // ref: cache.py:356-360 num_insertions = (old pos == -1)
   if (threadIdx.x == 0) a.idx_out[hp] = idx;
 
   if (POLICY == P_HH && threadIdx.x == 0) {  // ref: cache.py:754-763 (part of _eviction_idx itself)
@@ -184,9 +200,7 @@ __global__ __launch_bounds__(kUpdThreads) void decode_update_kernel(UpdArgs a) {
 
   // ---- insert (ref: cache.py:356-362, 390-401, 460-490, 330)
   if (threadIdx.x == 0) {
-    const int32_t old = pos[idx];
     a.pos[(size_t)hp * S + idx] = p;
-    const int ins = (old == -1);
     if (a.Hp == 1) {
       for (int j = 0; j < a.Hc; j++) a.cache_cts[j] += ins;
     } else if (a.Hc == a.Hp) {
@@ -195,11 +209,7 @@ __global__ __launch_bounds__(kUpdThreads) void decode_update_kernel(UpdArgs a) {
       a.cache_cts[0] += ins;  // num_insertions[:1]
     }
   }
-  if (a.Hp == 1) {
-    for (int h = 0; h < a.H; h++) insert_row<T>(a, h, idx);
-  } else {
-    insert_row<T>(a, hp, idx);
-  }
+  insert_rows<T>(a, h0, nh, idx, pre);
   if (POLICY == P_L2 && threadIdx.x < 16) {  // ref: cache.py:592-593
     const float ss = sumsq_canonical_16<T>(reinterpret_cast<const T*>(a.k_new) + (size_t)hp * a.D, a.D, threadIdx.x);
     if (threadIdx.x == 0) ElemTraits<T>::store(reinterpret_cast<T*>(a.key_norm), (size_t)hp * S + idx, __fsqrt_rn(ss));

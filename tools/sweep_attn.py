@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--H", type=int, default=8)
     ap.add_argument("--HQ", type=int, default=32)
     ap.add_argument("--D", type=int, default=128)
+    ap.add_argument("--ablate", action="store_true", help="time the split kernel with parts switched off")
     a = ap.parse_args()
     dev = "cuda"
     fns = _abi.lib()
@@ -101,6 +102,18 @@ def main():
             attn(i, 3, True)
 
         n = n_buf
+        if a.ablate:
+            res = {"S": S}
+            for name, bits in (("full", 0), ("no_store", 1), ("no_epilogue", 2), ("no_mask", 4), ("no_store_epi", 3),
+                               ("none", 7)):
+                t, _ = timed_graph(lambda i, b=bits: attn(i, 1 | (b << 8), False), n)
+                res[name + "_us"] = round(t, 2)
+            t, _ = timed_graph(lambda i: attn(i, 2, True), n)
+            res["combine_only_fused_us"] = round(t, 2)
+            t, _ = timed_graph(lambda i: attn(i, 2, False), n)
+            res["combine_only_plain_us"] = round(t, 2)
+            print(json.dumps(res), flush=True)
+            continue
         t_split, t_split_min = timed_graph(lambda i: attn(i, 1, False), n)
         t_both, _ = timed_graph(lambda i: attn(i, 3, True), n)
         t_ev, _ = timed_graph(evict, n)
