@@ -141,7 +141,7 @@ def roofline(model, args, dev):
     step_bytes = 2 * H * S * D * 2 + H * S * 29
     ach = alg / (mean_us * 1e-6) / 1e9
     return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "decode_attn_split_kernel<bf16,128,4,8,4>",
+            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "decode_attn_split_kernel<bf16_t,128,4,4,4>",
             "bytes_per_launch": alg, "mean_us": round(mean_us, 3), "median_us": round(us[len(us) // 2], 3),
             "min_us": round(us[0], 3), "launches": len(us) * len(layers), "layer_step_bytes": step_bytes,
             "timing": "HIP events around hipGraph replays of 32 launches (one per layer); per-launch = total/32, "
