@@ -73,6 +73,9 @@ SIGNATURES = {
                                   _sz, _vp]),
     "cc_attn_colsum": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "cc_colsum_to_mean": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
+    "cc_add_rmsnorm": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _f32, _i32, _vp, _vp, _vp]),
+    "cc_qkv_rope": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "cc_silu_mul": (C.c_int, [_vp, _vp, C.c_int64, _i32, _vp, _vp]),
 }
 
 # entry points that only the device library has (no `_cpu` twin)

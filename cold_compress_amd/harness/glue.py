@@ -1,0 +1,81 @@
+"""Caller glue (residual + RMSNorm, QKV split + RoPE + head layout, SwiGLU gate) as three fused HIP launches.
+
+These are NOT part of the cache/attention hot path — they are the model-side code around it
+(ref: model.py:317-327, 375-387, 442-443, 452-457, 507-519), which the reference leaves to ~45 eager elementwise
+launches per layer or to torch.compile.  On device tensors they call the C ABI (`cc_add_rmsnorm`, `cc_qkv_rope`,
+`cc_silu_mul`); on CPU tensors (host-only unit tests of the model wiring, e.g. the gloo TP test) the same
+formulas run as plain eager PyTorch, exactly as the reference writes them.  The cache / attention classes have no
+such host path.
+"""
+import ctypes as C
+
+import torch
+import torch.nn.functional as F
+
+from .. import _abi
+
+_DT = {torch.float32: _abi.CC_DT_F32, torch.bfloat16: _abi.CC_DT_BF16, torch.float16: _abi.CC_DT_F16}
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def add_rmsnorm(x, weight, eps, delta=None):
+    """-> (h, normed) with h = x + delta (or x itself when delta is None)."""
+    if not x.is_cuda:
+        h = x if delta is None else x + delta
+        hf = h.float()
+        return h, (hf * torch.rsqrt(torch.mean(hf * hf, dim=-1, keepdim=True) + eps)).type_as(h) * weight
+    dim = x.shape[-1]
+    xc = x.contiguous()
+    T = xc.numel() // dim
+    out = torch.empty_like(xc)
+    h = xc
+    dc = None
+    if delta is not None:
+        dc = delta.contiguous()
+        h = torch.empty_like(xc)
+    _abi.call("cc_add_rmsnorm", _p(xc), _p(dc), _p(weight), T, dim, float(eps), _DT[x.dtype], _p(h) if delta is not None else None,
+              _p(out), _stream())
+    return h, out
+
+
+def apply_rotary_emb(x, freqs_cis):
+    """ref: model.py:507-519 — adjacent pairs rotated in fp32, cast back to x's dtype (eager form)."""
+    xs = x.float().reshape(*x.shape[:-1], -1, 2)
+    fc = freqs_cis.view(1, xs.size(1), 1, xs.size(3), 2)
+    out = torch.stack([xs[..., 0] * fc[..., 0] - xs[..., 1] * fc[..., 1],
+                       xs[..., 1] * fc[..., 0] + xs[..., 0] * fc[..., 1]], -1)
+    return out.flatten(3).type_as(x)
+
+
+def qkv_rope(qkv, freqs_cis, n_head, n_local_heads, head_dim):
+    """qkv [1, T, (HQ+2H)*D], freqs_cis [T, D/2, 2] -> q [1,HQ,T,D], k [1,H,T,D], v [1,H,T,D] (rotated, head-major)."""
+    bsz, T, _ = qkv.shape
+    HQ, H, D = n_head, n_local_heads, head_dim
+    if not qkv.is_cuda:
+        q, k, v = qkv.split([HQ * D, H * D, H * D], dim=-1)
+        q = apply_rotary_emb(q.view(bsz, T, HQ, D), freqs_cis).transpose(1, 2)
+        k = apply_rotary_emb(k.view(bsz, T, H, D), freqs_cis).transpose(1, 2)
+        return q, k, v.view(bsz, T, H, D).transpose(1, 2)
+    qc = qkv.contiguous()
+    fc = freqs_cis.contiguous()
+    q = torch.empty((1, HQ, T, D), dtype=qkv.dtype, device=qkv.device)
+    k = torch.empty((1, H, T, D), dtype=qkv.dtype, device=qkv.device)
+    v = torch.empty((1, H, T, D), dtype=qkv.dtype, device=qkv.device)
+    _abi.call("cc_qkv_rope", _p(qc), _p(fc), T, HQ, H, D, _DT[qkv.dtype], _p(q), _p(k), _p(v), _stream())
+    return q, k, v
+
+
+def silu_mul(a, b):
+    if not a.is_cuda:
+        return F.silu(a) * b
+    ac, bc = a.contiguous(), b.contiguous()
+    out = torch.empty_like(ac)
+    _abi.call("cc_silu_mul", _p(ac), _p(bc), ac.numel(), _DT[a.dtype], _p(out), _stream())
+    return out

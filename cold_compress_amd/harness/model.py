@@ -14,9 +14,9 @@ from typing import Any, Dict, Optional
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 from torch import Tensor
 
+from . import glue
 from ..attention_utils import scaled_dot_product_attention
 from ..cache import KVCacheHeavyHitter, get_cache_constructor
 from ..prompt_compression import get_prompt_compressor_constructor
@@ -93,13 +93,7 @@ def precompute_freqs_cis(seq_len, n_elem, base=10000, dtype=torch.bfloat16, rope
     return torch.stack([cis.real, cis.imag], dim=-1).to(dtype=dtype)
 
 
-def apply_rotary_emb(x: Tensor, freqs_cis: Tensor) -> Tensor:
-    """ref: model.py:507-519 — adjacent pairs rotated in fp32, cast back to x's dtype."""
-    xs = x.float().reshape(*x.shape[:-1], -1, 2)
-    fc = freqs_cis.view(1, xs.size(1), 1, xs.size(3), 2)
-    out = torch.stack([xs[..., 0] * fc[..., 0] - xs[..., 1] * fc[..., 1],
-                       xs[..., 1] * fc[..., 0] + xs[..., 0] * fc[..., 1]], -1)
-    return out.flatten(3).type_as(x)
+apply_rotary_emb = glue.apply_rotary_emb  # eager form of ref: model.py:507-519 (the device path is cc_qkv_rope)
 
 
 class RMSNorm(nn.Module):
@@ -108,9 +102,9 @@ class RMSNorm(nn.Module):
         self.eps = eps
         self.weight = nn.Parameter(torch.ones(dim))
 
-    def forward(self, x: Tensor) -> Tensor:
-        xf = x.float()
-        return (xf * torch.rsqrt(torch.mean(xf * xf, dim=-1, keepdim=True) + self.eps)).type_as(x) * self.weight
+    def forward(self, x: Tensor, delta: Optional[Tensor] = None):
+        """-> (h, norm(h)) with h = x + delta (the pending residual of the previous sub-block), one fused launch."""
+        return glue.add_rmsnorm(x, self.weight, self.eps, delta)
 
 
 class FeedForward(nn.Module):
@@ -121,7 +115,7 @@ class FeedForward(nn.Module):
         self.w2 = nn.Linear(config.intermediate_size, config.dim, bias=False)
 
     def forward(self, x: Tensor) -> Tensor:
-        return self.w2(F.silu(self.w1(x)) * self.w3(x))
+        return self.w2(glue.silu_mul(self.w1(x), self.w3(x)))
 
 
 class Attention(nn.Module):
@@ -145,11 +139,8 @@ class Attention(nn.Module):
     def forward(self, x, input_ids, freqs_cis, mask, is_prefill, input_pos=None, attn_top_k=1.0):
         """The glue of ref: model.py:363-432, GQA-aware (no repeat_interleave)."""
         bsz, seqlen, _ = x.shape
-        kv_size = self.n_local_heads * self.head_dim
-        q, k, v = self.wqkv(x).split([self.dim, kv_size, kv_size], dim=-1)
-        q = apply_rotary_emb(q.view(bsz, seqlen, self.n_head, self.head_dim), freqs_cis).transpose(1, 2)
-        k = apply_rotary_emb(k.view(bsz, seqlen, self.n_local_heads, self.head_dim), freqs_cis).transpose(1, 2)
-        v = v.view(bsz, seqlen, self.n_local_heads, self.head_dim).transpose(1, 2)
+        # split + RoPE(q, k) + head-major layout in one launch (ref: model.py:375-387)
+        q, k, v = glue.qkv_rope(self.wqkv(x), freqs_cis, self.n_head, self.n_local_heads, self.head_dim)
         cache = self.kv_cache
         ck = {"input_ids": input_ids}
         if not is_prefill:
@@ -179,9 +170,13 @@ class TransformerBlock(nn.Module):
         self.ffn_norm = RMSNorm(config.dim, config.norm_eps)
         self.attention_norm = RMSNorm(config.dim, config.norm_eps)
 
-    def forward(self, x, input_ids, input_pos, is_prefill, freqs_cis, mask, attn_top_k=1.0):
-        h = x + self.attention(self.attention_norm(x), input_ids, freqs_cis, mask, is_prefill, input_pos, attn_top_k=attn_top_k)
-        return h + self.feed_forward(self.ffn_norm(h))
+    def forward(self, x, delta, input_ids, input_pos, is_prefill, freqs_cis, mask, attn_top_k=1.0):
+        """Pre-norm block (ref: model.py:317-327) with the residual adds folded into the norms:
+        takes (x, pending residual delta) and returns (h, f) with the block output being h + f."""
+        x, n1 = self.attention_norm(x, delta)  # x <- x + delta
+        a = self.attention(n1, input_ids, freqs_cis, mask, is_prefill, input_pos, attn_top_k=attn_top_k)
+        h, n2 = self.ffn_norm(x, a)  # h = x + attn
+        return h, self.feed_forward(n2)
 
 
 class Transformer(nn.Module):
@@ -240,7 +235,7 @@ class Transformer(nn.Module):
     def forward(self, idx, input_pos, is_prefill, mask=None, attn_top_k=1.0) -> Tensor:
         assert self.freqs_cis is not None, "Caches must be initialized first"
         freqs_cis = self.freqs_cis[input_pos]
-        x = self.tok_embeddings(idx)
+        x, delta = self.tok_embeddings(idx), None
         for layer in self.layers:
-            x = layer(x, idx, input_pos, is_prefill, freqs_cis, mask, attn_top_k=attn_top_k)
-        return self.output(self.norm(x))
+            x, delta = layer(x, delta, idx, input_pos, is_prefill, freqs_cis, mask, attn_top_k=attn_top_k)
+        return self.output(self.norm(x, delta)[1])

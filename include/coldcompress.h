@@ -234,6 +234,30 @@ int cc_attn_colsum(const void* attn, int32_t H, int32_t Lq, int32_t Lk, int32_t 
 int cc_colsum_to_mean(const float* colsum, const int64_t* input_pos, int32_t H, int32_t L, int32_t dtype,
                       void* out, cc_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Caller glue around the hot path (ref: model.py Attention.forward / TransformerBlock / RMSNorm /
+ * apply_rotary_emb / FeedForward).  The reference leaves these to ~45 eager elementwise launches per layer
+ * (or to torch.compile); here they are three fused launches so the decode step is GEMV-bound.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* (optional residual add) + RMSNorm.  ref: model.py:452-457 and :325-326.
+ *   h = delta ? x + delta : x   (model dtype add, written to h_out if non-NULL; h_out may alias x)
+ *   out = dtype( dtype( float(h) * rsqrt(mean(float(h)^2) + eps) ) * weight )
+ * x, delta, h_out, out: [T, dim] dtype; weight: [dim] dtype. */
+int cc_add_rmsnorm(const void* x, const void* delta, const void* weight, int32_t T, int32_t dim, float eps,
+                   int32_t dtype, void* h_out, void* out, cc_stream_t stream);
+
+/* Split the fused QKV projection, apply rotary embedding to q and k, and lay the heads out for attention.
+ * ref: model.py:375-387 + apply_rotary_emb :507-519 (adjacent pairs, fp32 math, table stored in model dtype).
+ *   qkv: [T, (HQ + 2H) * D] dtype (q block, k block, v block); freqs: [T, D/2, 2] dtype = rows of the
+ *   (cos, sin) table already gathered at the token positions.
+ *   q_out: [HQ, T, D]; k_out, v_out: [H, T, D]  (== the transposes model.py:385-387 produces). */
+int cc_qkv_rope(const void* qkv, const void* freqs, int32_t T, int32_t HQ, int32_t H, int32_t D, int32_t dtype,
+                void* q_out, void* k_out, void* v_out, cc_stream_t stream);
+
+/* SwiGLU gate: out = dtype( dtype(silu(a)) * b ).  ref: model.py:442-443 F.silu(w1 x) * w3 x.  a, b, out: [n]. */
+int cc_silu_mul(const void* a, const void* b, int64_t n, int32_t dtype, void* out, cc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

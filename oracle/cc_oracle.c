@@ -684,3 +684,67 @@ int cc_decode_attn_gqa_phases_cpu(const void* q, const void* k, const void* v, c
   return cc_decode_attn_gqa_cpu(q, k, v, mask, HQ, H, S, D, dtype, scale, y, attn_out, probs_out, hh_num, hh_denom,
                                 hh_counter, workspace, workspace_bytes, stream);
 }
+
+/* ---------------------------------------------------------------- caller glue ---------------------- */
+
+/* ref: model.py:452-457 RMSNorm (fp32 inside, cast, * weight) and the residual add of :325-326 */
+int cc_add_rmsnorm_cpu(const void* x, const void* delta, const void* weight, int32_t T, int32_t dim, float eps,
+                       int32_t dtype, void* h_out, void* out, cc_stream_t stream) {
+  (void)stream;
+  if (!x || !weight || !out || T <= 0 || dim <= 0 || !dt_ok(dtype)) return CC_ERR_BAD_ARG;
+  float* h = (float*)malloc(sizeof(float) * (size_t)dim);
+  for (int t = 0; t < T; t++) {
+    double ss = 0.0;
+    for (int i = 0; i < dim; i++) {
+      float v = ld(x, dtype, (size_t)t * dim + i);
+      if (delta) v = rnd(v + ld(delta, dtype, (size_t)t * dim + i), dtype);
+      h[i] = v;
+      ss += (double)v * (double)v;
+    }
+    if (delta && h_out)
+      for (int i = 0; i < dim; i++) st(h_out, dtype, (size_t)t * dim + i, h[i]);
+    const float rs = 1.0f / sqrtf((float)(ss / dim) + eps);
+    for (int i = 0; i < dim; i++) st(out, dtype, (size_t)t * dim + i, rnd(h[i] * rs, dtype) * ld(weight, dtype, i));
+  }
+  free(h);
+  return CC_OK;
+}
+
+/* ref: model.py:375-387 (split, view, transpose) + apply_rotary_emb :507-519 */
+int cc_qkv_rope_cpu(const void* qkv, const void* freqs, int32_t T, int32_t HQ, int32_t H, int32_t D, int32_t dtype,
+                    void* q_out, void* k_out, void* v_out, cc_stream_t stream) {
+  (void)stream;
+  if (!qkv || !freqs || !q_out || !k_out || !v_out || T <= 0 || HQ <= 0 || H <= 0 || D <= 0 || (D & 1) || !dt_ok(dtype))
+    return CC_ERR_BAD_ARG;
+  const int heads = HQ + 2 * H, half = D / 2;
+  for (int t = 0; t < T; t++)
+    for (int hd = 0; hd < heads; hd++) {
+      void* dst = hd < HQ ? q_out : (hd < HQ + H ? k_out : v_out);
+      const int hh = hd < HQ ? hd : (hd < HQ + H ? hd - HQ : hd - HQ - H);
+      for (int p = 0; p < half; p++) {
+        const size_t src = ((size_t)t * heads + hd) * D + 2 * p, o = ((size_t)hh * T + t) * D + 2 * p;
+        const float x0 = ld(qkv, dtype, src), x1 = ld(qkv, dtype, src + 1);
+        if (hd < HQ + H) {
+          const float c = ld(freqs, dtype, ((size_t)t * half + p) * 2), s = ld(freqs, dtype, ((size_t)t * half + p) * 2 + 1);
+          const float a0 = x0 * c, a1 = x1 * s, b0 = x1 * c, b1 = x0 * s;
+          st(dst, dtype, o, a0 - a1);
+          st(dst, dtype, o + 1, b0 + b1);
+        } else {
+          st(dst, dtype, o, x0);
+          st(dst, dtype, o + 1, x1);
+        }
+      }
+    }
+  return CC_OK;
+}
+
+/* ref: model.py:442-443 F.silu(w1 x) * w3 x */
+int cc_silu_mul_cpu(const void* a, const void* b, int64_t n, int32_t dtype, void* out, cc_stream_t stream) {
+  (void)stream;
+  if (!a || !b || !out || n <= 0 || !dt_ok(dtype)) return CC_ERR_BAD_ARG;
+  for (int64_t i = 0; i < n; i++) {
+    const float x = ld(a, dtype, (size_t)i);
+    st(out, dtype, (size_t)i, rnd(x / (1.0f + expf(-x)), dtype) * ld(b, dtype, (size_t)i));
+  }
+  return CC_OK;
+}
