@@ -71,8 +71,14 @@ SIGNATURES = {
     "cc_prefill_attn_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32, _i32]),
     "cc_prefill_attn": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _i32, _vp,
                                   _sz, _vp]),
+    "cc_prefill_attn_bands": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _i32, _vp, _i32,
+                                        _vp, _vp, _sz, _vp]),
     "cc_attn_colsum": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "cc_colsum_to_mean": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
+    "cc_hybrid_decode_update": (C.c_int, [_view, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp,
+                                          _i32, _i32, _vp, _vp]),
+    "cc_hh_ring_update": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "cc_attn_bandsum": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "cc_add_rmsnorm": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _f32, _i32, _vp, _vp, _vp]),
     "cc_qkv_rope": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "cc_silu_mul": (C.c_int, [_vp, _vp, C.c_int64, _i32, _vp, _vp]),

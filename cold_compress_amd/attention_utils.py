@@ -85,8 +85,9 @@ def decode_attention(query, key, value, attn_mask=None, scale=None, return_attn=
     return y, (attn if group_mean else probs) if return_attn else None
 
 
-def prefill_attention(query, key, value, scale=None, return_attn=False, obs_len=16):
-    """Causal attention, query [1, HQ, L, D], key/value [1, H, L, D]; side outputs as an AttnSummary."""
+def prefill_attention(query, key, value, scale=None, return_attn=False, obs_len=16, bands=()):
+    """Causal attention, query [1, HQ, L, D], key/value [1, H, L, D]; side outputs as an AttnSummary.
+    `bands`: window widths (<= 4) whose band sums the hybrid cache's profiling score needs."""
     if not query.is_cuda:
         raise ColdCompressError("prefill attention needs ROCm device tensors (no CPU fallback)")
     _, HQ, L, D = query.shape
@@ -102,9 +103,16 @@ def prefill_attention(query, key, value, scale=None, return_attn=False, obs_len=
     nbytes = _abi.lib()["cc_prefill_attn_workspace_bytes"](HQ, H, L, D, _DT[dt])
     ws = _workspace(nbytes, query.device)
     sc = 1.0 / math.sqrt(D) if scale is None else scale
-    _abi.call("cc_prefill_attn", _ptr(q), _ptr(k), _ptr(v), HQ, H, L, D, _DT[dt], sc, _ptr(y), _ptr(colsum), _ptr(obs),
-              ol, _ptr(ws), ws.numel(), _stream())
-    return y, (AttnSummary(colsum, obs, ol, dt) if return_attn else None)
+    bands = [int(b) for b in bands] if return_attn else []
+    if len(bands) > 4:
+        raise ColdCompressError("at most 4 distinct window widths are supported per prefill")
+    band_out = torch.empty((len(bands), H, L), dtype=torch.float32, device=query.device) if bands else None
+    barr = (C.c_int32 * len(bands))(*bands) if bands else None
+    _abi.call("cc_prefill_attn_bands", _ptr(q), _ptr(k), _ptr(v), HQ, H, L, D, _DT[dt], sc, _ptr(y), _ptr(colsum), _ptr(obs),
+              ol, barr, len(bands), _ptr(band_out), _ptr(ws), ws.numel(), _stream())
+    if not return_attn:
+        return y, None
+    return y, AttnSummary(colsum, obs, ol, dt, {b: band_out[i] for i, b in enumerate(bands)})
 
 
 def _is_causal_mask(attn_mask, L):
@@ -115,7 +123,7 @@ def _is_causal_mask(attn_mask, L):
 
 
 def scaled_dot_product_attention(query, key, value, attn_mask=None, dropout_p=0.0, scale=None, return_attn=False,
-                                 attn_top_k=1.0, group_mean=False, history=None, is_causal=None):
+                                 attn_top_k=1.0, group_mean=False, history=None, is_causal=None, bands=()):
     """ref: attention_utils.py:8-54 (same positional/keyword surface; extra keywords documented above)."""
     if dropout_p != 0.0:
         raise ColdCompressError("dropout is not part of the inference path")
@@ -128,4 +136,4 @@ def scaled_dot_product_attention(query, key, value, attn_mask=None, dropout_p=0.
         is_causal = _is_causal_mask(attn_mask, L)
     if not is_causal or L != S:
         raise ColdCompressError("prefill attention supports the causal [L, L] mask of generation_utils.py:153-158 only")
-    return prefill_attention(query, key, value, scale, return_attn)
+    return prefill_attention(query, key, value, scale, return_attn, bands=bands)

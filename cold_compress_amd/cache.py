@@ -357,6 +357,276 @@ class KVCacheHeavyHitter(KVCacheHeadSpecific):
         self._apply(a, T)
 
 
+_HF = {"heavy_hitter": 1, "window": 2, "punc": 4, "special": 8}
+
+
+class KVCacheHybrid(KVCacheHeadSpecific):
+    """FastGen-style per-head policies (ref: cache.py:768-1288): at prefill every head is profiled against the
+    ordered list `hybrid_strategies` and takes the FIRST policy that recovers `min_recovery_frac` of its attention
+    mass; at decode each head appends or evicts according to its own policy (one launch for all heads; the
+    reference loops over heads in Python with a device sync each).
+
+    Differences a caller can rely on:
+      * the prefill partition (kept tokens first) is STABLE; the reference's non-stable argsort leaves the slot
+        order within each class implementation-defined on CPU.  `_partition_order` is the hook.
+      * the profiling score is evaluated per key from column sums and window band sums in fp32 instead of from
+        [n_policies, H, L, L] boolean masks (8.6 GB at L = 16k); heads whose score sits within rounding of
+        `min_recovery_frac` may therefore pick a neighbouring policy.
+      * `reset_history_on_evict = False` reproduces the reference's EFFECTIVE behaviour: its reset of the evicted
+        slot's history (cache.py:992-996) indexes with a tensor, so `.fill_(0)` lands on an advanced-indexing copy
+        and the ring / denominator of the reused slot are never cleared (verified against the reference: the
+        denominator of a re-used slot keeps counting).  Set it to True for the behaviour the code intends.
+    """
+    reset_history_on_evict = False
+    relevant_kwargs = ["max_cache_length", "max_seq_length", "cache_bits", "global_tokens", "token_ids",
+                       "min_recovery_frac", "hybrid_strategies"]
+
+    def __init__(self, max_batch_size, n_heads, head_dim, dtype=torch.bfloat16, **kwargs):
+        self.attn_thresholding = False
+        self.history_window_size = 400  # ScissorHands default, fixed by the reference (cache.py:789-790)
+        self.recent_window = None
+        super().__init__(max_batch_size, n_heads, head_dim, dtype, variable_length=True, **kwargs)
+        S, W = self.max_cache_length, self.history_window_size
+        self.register_buffer("attn_history_num", torch.zeros((1, n_heads, S, W), dtype=dtype))
+        self.register_buffer("attn_history_denom", torch.zeros((1, n_heads, S), dtype=torch.int32))
+        self.register_buffer("attn_counter", torch.zeros((1,), dtype=torch.int64))
+        names = [s["strategy"] for s in self.hybrid_strategies]
+        self.requires_special = any("special" in n for n in names)
+        self.requires_punc = any("punc" in n for n in names)
+        if self.requires_special:
+            self.special_ids = [list(ids) for ids in kwargs["token_ids"]["special"]]
+            self.register_buffer("special_mask", torch.zeros((1, n_heads, S), dtype=torch.bool))
+            self.register_buffer("num_special", torch.zeros((1,), dtype=torch.int32))
+        if self.requires_punc:
+            self.register_buffer("punc_ids", torch.tensor(kwargs["token_ids"]["punctuation"], dtype=torch.int64))
+            self.register_buffer("punc_mask", torch.zeros((1, n_heads, S), dtype=torch.bool))
+            self.register_buffer("num_punc", torch.zeros((1,), dtype=torch.int32))
+        self.requires_heavy_hitter = self._init_requires_heavy_hitter()
+        self.cache_strategies = None
+        self._table = None
+
+    # ------------------------------------------------------------------ small helpers
+    def _init_requires_heavy_hitter(self):
+        return any("heavy_hitter" in s["strategy"] for s in self.hybrid_strategies)
+
+    def return_attn(self):
+        return self.requires_heavy_hitter
+
+    def attn_bands(self, seq_len):
+        """Window widths (in queries) whose band sums the profiling score needs (ref: cache.py:1093)."""
+        return sorted({max(1, int(s["recent_window"] * seq_len)) for s in self.hybrid_strategies if "window" in s["strategy"]})
+
+    def _policy_table(self):
+        if self._table is None or self._table.device != self.k_cache.device:
+            S = self.max_cache_length
+            rows = []
+            for s in self.hybrid_strategies:
+                name = s["strategy"]
+                flags = 16 if name == "full" else sum(v for k, v in _HF.items() if k in name)
+                rows.append([flags, round(s.get("recent_window", 0) * S), round(s.get("heavy_hitter_frac", 0) * S)])
+            self._table = torch.tensor(rows, dtype=torch.int32, device=self.k_cache.device)
+        return self._table
+
+    def reset(self):
+        super().reset()
+        self.attn_history_num.zero_()
+        self.attn_history_denom.zero_()
+        self.attn_counter.zero_()
+        self.cache_strategies = None
+        self.requires_heavy_hitter = self._init_requires_heavy_hitter()
+        if hasattr(self, "special_mask"):
+            self.special_mask.zero_()
+            self.num_special.zero_()
+        if hasattr(self, "punc_mask"):
+            self.punc_mask.zero_()
+            self.num_punc.zero_()
+
+    def build_special_ids_mask(self, input_ids):
+        """ref: cache.py:1021-1034 (exact sub-sequence match for multi-token special ids)."""
+        ids = input_ids.tolist()
+        m = [False] * len(ids)
+        for sp in self.special_ids:
+            n = len(sp)
+            for i in range(len(ids) - n + 1):
+                if ids[i:i + n] == sp:
+                    for j in range(i, i + n):
+                        m[j] = True
+        return torch.tensor(m, dtype=torch.bool, device=input_ids.device)
+
+    def _partition_order(self, mask_optimal):
+        """Kept tokens first, original order preserved inside each class (stable)."""
+        return torch.argsort((~mask_optimal).to(torch.int8), dim=1, stable=True)
+
+    # ------------------------------------------------------------------ decode (ref: cache.py:965-1019)
+    def _decoding_update(self, input_pos, k_val, v_val, **kwargs):
+        if self.cache_strategies is None:
+            raise ColdCompressError("hybrid cache used before prefill profiling (update_state with is_prefill=True)")
+        k, v = self._new_rows(k_val, v_val)
+        is_punc = None
+        if hasattr(self, "punc_ids"):
+            ids = kwargs.get("input_ids")
+            is_punc = torch.isin(ids.to(self.punc_ids.device), self.punc_ids).reshape(-1)[:1].to(torch.uint8).contiguous()
+        self._is_punc = is_punc
+        tab = self._policy_table()
+        _abi.call("cc_hybrid_decode_update", self._view(), _ptr(k), _ptr(v), _ptr(self._pos32(input_pos)),
+                  _ptr(self.cache_strategies), _ptr(tab), tab.shape[0], _ptr(self.attn_history_num),
+                  _ptr(self.attn_history_denom), self.history_window_size, _ptr(getattr(self, "special_mask", None)),
+                  _ptr(getattr(self, "punc_mask", None)), _ptr(is_punc), _ptr(getattr(self, "num_special", None)),
+                  _ptr(getattr(self, "num_punc", None)), int(self.global_tokens),
+                  int(bool(self.requires_heavy_hitter and self.reset_history_on_evict)),
+                  _ptr(self._idx_buf()), _stream())
+
+    def _ring_update(self, attn_ht, T):
+        _abi.call("cc_hh_ring_update", _ptr(self.attn_history_num), _ptr(self.attn_history_denom), _ptr(self.attn_counter),
+                  _ptr(attn_ht), self.n_heads, self.max_cache_length, T, self.history_window_size,
+                  _DT[self.k_cache.dtype], _stream())
+
+    def update_state(self, input_pos, k_val, v_val, is_prefill, attn, **kwargs):
+        """ref: cache.py:1274-1288."""
+        if is_prefill:
+            self.profile_and_update(input_pos, k_val, v_val, attn, **kwargs)
+        elif self.requires_heavy_hitter:
+            _need_device(attn, "attn")
+            a = attn.reshape(self.n_heads, -1).contiguous()
+            self._ring_update(a, a.shape[1])
+        else:
+            assert attn is None, "Attn should be None if no attention is required."
+
+    # ------------------------------------------------------------------ prefill (ref: cache.py:1066-1272)
+    def _column_stats(self, attn, input_pos, bands):
+        """-> colsum f32 [H,L], column mean dtype [H,L], {band: band sums f32 [H,L]}."""
+        H, dt = self.n_heads, self.k_cache.dtype
+        if isinstance(attn, AttnSummary):
+            missing = [b for b in bands if b not in attn.bands]
+            if missing:
+                raise ColdCompressError(f"prefill attention was run without band sums for window widths {missing}")
+            return attn.colsum, attn.column_mean(input_pos)[0], {b: attn.bands[b] for b in bands}
+        _need_device(attn, "attn")
+        a = attn.contiguous()
+        Lq, L = a.shape[-2], a.shape[-1]
+        colsum = torch.empty((H, L), dtype=torch.float32, device=a.device)
+        _abi.call("cc_attn_colsum", _ptr(a), H, Lq, L, _DT[a.dtype], _ptr(colsum), _stream())
+        mean = torch.empty((H, L), dtype=dt, device=a.device)
+        _abi.call("cc_colsum_to_mean", _ptr(colsum), _ptr(input_pos.to(torch.int64).contiguous()), H, L, _DT[dt], _ptr(mean), _stream())
+        out = {}
+        for b in bands:
+            t = torch.empty((H, L), dtype=torch.float32, device=a.device)
+            _abi.call("cc_attn_bandsum", _ptr(a), H, Lq, L, _DT[a.dtype], int(b), _ptr(t), _stream())
+            out[b] = t
+        return colsum, mean, out
+
+    def _column_sets(self, cum_attn, special_mask, punc_mask, total_len, L):
+        """Per policy: (static column set incl. heavy hitters [H,L] bool, window width or 0).  ref: build_masks
+        cache.py:1066-1136 — only the last query row of each [L,L] mask is a column set; the window part of the
+        other rows is accounted for by band sums."""
+        from .prompt_compression import topk_keep
+
+        H, dev = self.n_heads, cum_attn.device
+        t = torch.arange(L, device=dev)
+        out = []
+        for s in self.hybrid_strategies:
+            name = s["strategy"]
+            col = (t < self.global_tokens)
+            if "special" in name:
+                col = col | special_mask
+            if "punc" in name:
+                col = col | punc_mask
+            win = 0
+            last_row = col
+            if "window" in name:
+                assert "recent_window" in s and s["recent_window"] <= 1, \
+                    "Window strategy should have recent_window expressed as a fraction <= 1."
+                win = max(1, int(s["recent_window"] * total_len))
+                last_row = col | (t >= L - win)
+            cols = col.unsqueeze(0).expand(H, L).clone()
+            if "heavy_hitter" in name:
+                avail = ~last_row
+                n_avail = int(avail.sum())
+                import math
+                num_hh = math.ceil(min(s["heavy_hitter_frac"] * total_len, n_avail))
+                if num_hh > 0:
+                    prio = cum_attn.float().masked_fill(~avail.unsqueeze(0), float("-inf")).contiguous()
+                    keep = topk_keep(prio, num_hh)  # [H, num_hh], ties lowest-index-first
+                    cols.scatter_(1, keep, True)
+            if name == "full":
+                cols.fill_(True)
+            out.append((cols, win))
+        return out
+
+    def profile_and_update(self, input_pos, k_val, v_val, attn, **kwargs):
+        input_ids = kwargs["input_ids"].reshape(-1)
+        dev = self.k_cache.device
+        input_ids = input_ids.to(dev)
+        L, H, S, D = input_ids.shape[-1], self.n_heads, self.max_cache_length, self.head_dim
+        assert S >= L
+        special_mask = punc_mask = None
+        if self.requires_special:
+            special_mask = self.build_special_ids_mask(input_ids)
+            self.num_special.copy_(special_mask.sum().to(torch.int32).view(1))
+        if self.requires_punc:
+            punc_mask = torch.isin(input_ids, self.punc_ids)
+            self.num_punc.copy_(punc_mask.sum().to(torch.int32).view(1))
+        zeros = torch.zeros(L, dtype=torch.bool, device=dev)
+        sm = special_mask if special_mask is not None else zeros
+        pm = punc_mask if punc_mask is not None else zeros
+        needs_attn = any("heavy_hitter" in s["strategy"] or "window" in s["strategy"] for s in self.hybrid_strategies)
+        bands = self.attn_bands(L)
+        if attn is None:
+            raise ColdCompressError("hybrid profiling needs the prefill attention (return_attn() was True)")
+        colsum, cum_attn, band = self._column_stats(attn, input_pos, bands)
+        # ---- score every policy per head (ref: profile_attn_heads cache.py:1160-1173)
+        scoring = self._column_sets(cum_attn, sm, pm, L, L)
+        scores = []
+        for cols, win in scoring:
+            outside = band[win] if win else torch.zeros_like(colsum)
+            scores.append(torch.where(cols, colsum, outside).sum(dim=1) / L)
+        scores = torch.stack(scores)  # [n_policies, H]
+        self.compressed_scores = scores
+        self.cache_strategies = (scores >= self.min_recovery_frac).int().argmax(dim=0).to(torch.int64).contiguous()
+        # ---- fill mask from the chosen policy, built for the FULL cache length (cache.py:1177-1185)
+        filling = self._column_sets(cum_attn, sm, pm, S, L)
+        t = torch.arange(L, device=dev)
+        mask_all = torch.stack([cols | (t >= L - win if win else zeros).unsqueeze(0) for cols, win in filling])  # [n,H,L]
+        mask_optimal = mask_all.gather(0, self.cache_strategies.view(1, H, 1).expand(1, H, L)).squeeze(0)
+        chosen = [self.hybrid_strategies[i]["strategy"] for i in self.cache_strategies.tolist()]
+        self.requires_heavy_hitter = any("heavy_hitter" in n for n in chosen)
+        self.requires_punc = any("punc" in n for n in chosen)
+        self.requires_special = any("special" in n for n in chosen)
+        # ---- kept tokens first (cache.py:1228-1246)
+        order = self._partition_order(mask_optimal).contiguous()
+        from .prompt_compression import gather_rows
+
+        k_ord, v_ord = gather_rows(k_val, order), gather_rows(v_val, order)
+        pos_ord = input_pos.to(dev).to(torch.int64).unsqueeze(0).expand(H, -1).gather(1, order).contiguous()
+        self.cache_cts.zero_()
+        self.mask.zero_()
+        _abi.call("cc_prefill_fill", self._view(), _ptr(k_ord), _ptr(v_ord), _ptr(pos_ord), H, L, _stream())
+        cts = mask_optimal.sum(dim=1).to(torch.int32)
+        self.cache_cts.copy_(cts)
+        live = torch.arange(S, device=dev).view(1, S) < cts.view(H, 1)  # [H,S]
+        self.pos[0].masked_fill_(~live, -1)
+        self.k_cache[0].masked_fill_(~live.unsqueeze(-1), 0)
+        self.v_cache[0].masked_fill_(~live.unsqueeze(-1), 0)
+        self.mask[0, :, 0, :] = live & (torch.arange(S, device=dev).view(1, S) < L)
+        if hasattr(self, "special_mask"):
+            self.special_mask[0, :, :L] = sm.unsqueeze(0).expand(H, -1).gather(1, order)
+        if hasattr(self, "punc_mask"):
+            self.punc_mask[0, :, :L] = pm.unsqueeze(0).expand(H, -1).gather(1, order)
+        if self.requires_heavy_hitter:  # cache.py:1267-1272 seeds the ring with the gathered column means
+            a = cum_attn.gather(1, order).contiguous()
+            self._ring_update(a, L)
+
+    def compute_statistics(self, seq_len):
+        """ref: cache.py:1043-1064."""
+        stats = super().compute_statistics(seq_len)
+        idxs = self.cache_strategies.tolist()
+        names = [self.hybrid_strategies[i]["strategy"] for i in idxs]
+        stats["avg_strategy_idx"] = sum(idxs) / len(idxs)
+        for n in sorted({s["strategy"] for s in self.hybrid_strategies}):
+            stats[n] = names.count(n) / len(names)
+        return stats
+
+
 class KVCacheKeepItOdd(KVCacheHeadConstant):
     """ref: cache.py:1423-1441 (toy policy; exercises the generic caller-supplied-importances path)."""
     relevant_kwargs = ["max_cache_length", "max_seq_length", "cache_bits", "global_tokens", "recent_window"]
@@ -377,13 +647,14 @@ def get_cache_constructor(cache_strategy):
         "random": KVCacheRandom,
         "recent_global": KVCacheRecentGlobal,
         "heavy_hitter": KVCacheHeavyHitter,
+        "hybrid": KVCacheHybrid,
         "keep_it_odd": KVCacheKeepItOdd,
     }
     if cache_strategy in table:
         cls = table[cache_strategy]
         return cls, cls.relevant_kwargs
-    if cache_strategy == "hybrid" or cache_strategy.startswith("debug"):
+    if cache_strategy.startswith("debug"):
         name = re.sub(r"debug_+", "", cache_strategy).strip()
-        if name in table or name == "hybrid":
+        if name in table:
             raise NotImplementedError(f"cache strategy '{cache_strategy}' is a SURVEY §8 follow-up and not built yet")
     raise ValueError(f"Invalid cache strategy: {cache_strategy}")

@@ -23,12 +23,16 @@ struct PfArgs {
   const void* v;
   void* y;
   float* stats;   // [HQ, L, 2] (m, l)
-  float* cpart;   // [kNWG, H, L]
+  float* cpart;   // [1 + nb, kNWG, H, L]: plane 0 = column sums, plane 1+b = band b
   float* colsum;  // [H, L] or null
   float* obs;     // [H, L] or null
   int HQ, H, R, L, D, QB, TK, obs_len;
   float scale;
+  int nb;           // number of band-sum side outputs (<= kMaxBands)
+  int band[4];      // window widths in queries: band b sums a[h,q,k] over q in [k, k + band[b])
+  float* band_out;  // [nb, H, L] or null
 };
+constexpr int kMaxBands = 4;
 
 // LDS carve (floats): Qs[kRows][D+1] | Ks[TK][D+1] | Vs[TK][D] | Ps[kRows][TK+1]
 __device__ __forceinline__ int lds_floats(int D, int TK) { return kRows * (D + 1) + TK * (D + 1) + TK * D + kRows * (TK + 1); }
@@ -128,7 +132,9 @@ __global__ __launch_bounds__(kThreads) void prefill_pv_kernel(PfArgs a) {
   __shared__ float sm_m[kRows], sm_l[kRows];
   const int h = blockIdx.y, w = blockIdx.x;
   float* cp = a.cpart + ((size_t)w * a.H + h) * L;
-  for (int s = threadIdx.x; s < L; s += kThreads) cp[s] = 0.f;
+  const size_t plane = (size_t)gridDim.x * a.H * L;  // one plane per side output
+  for (int pl = 0; pl <= a.nb; pl++)
+    for (int s = threadIdx.x; s < L; s += kThreads) cp[pl * plane + s] = 0.f;
   const int nqb = (L + a.QB - 1) / a.QB;
   const int n_out = kRows * D;  // y accumulators of this block, kThreads-strided
   for (int qb = w; qb < nqb; qb += gridDim.x) {
@@ -166,13 +172,21 @@ __global__ __launch_bounds__(kThreads) void prefill_pv_kernel(PfArgs a) {
       // column sums of the group mean (ref: model.py:416-418, cache.py:704), one key per thread
       if (threadIdx.x < TK && k0 + threadIdx.x < L) {
         const int kk = threadIdx.x;
-        float cs = 0.f;
+        float cs = 0.f, bs[kMaxBands] = {0.f, 0.f, 0.f, 0.f};
         for (int il = 0; il < a.QB; il++) {
           float sum = 0.f;
           for (int r = 0; r < a.R; r++) sum += Ps[(r * a.QB + il) * (TK + 1) + kk];
-          cs += ElemTraits<T>::rnd(__fdiv_rn(sum, (float)a.R));
+          const float av = ElemTraits<T>::rnd(__fdiv_rn(sum, (float)a.R));
+          cs += av;
+          const int dist = (qb0 + il) - (k0 + kk);  // query index - key index (av == 0 when negative)
+#pragma unroll
+          for (int b = 0; b < kMaxBands; b++)
+            if (b < a.nb && dist < a.band[b]) bs[b] += av;
         }
         cp[k0 + kk] += cs;
+#pragma unroll
+        for (int b = 0; b < kMaxBands; b++)
+          if (b < a.nb) cp[(size_t)(1 + b) * plane + k0 + kk] += bs[b];
       }
       // y += P . V
 #pragma unroll
@@ -209,6 +223,14 @@ __global__ __launch_bounds__(kThreads) void prefill_side_kernel(PfArgs a, int nw
       float cs = 0.f;
       for (int w = 0; w < nwg; w++) cs += a.cpart[((size_t)w * a.H + h) * L + s];
       a.colsum[idx] = cs;
+    }
+    if (a.band_out) {
+      const size_t plane = (size_t)nwg * a.H * L;
+      for (int b = 0; b < a.nb; b++) {
+        float bs = 0.f;
+        for (int w = 0; w < nwg; w++) bs += a.cpart[(size_t)(1 + b) * plane + ((size_t)w * a.H + h) * L + s];
+        a.band_out[(size_t)b * a.H * L + idx] = bs;
+      }
     }
     if (a.obs) {
       // ref: prompt_compression.py:173 attn[:, :, -obs_len:, :].mean(dim=2)
@@ -250,7 +272,7 @@ static int run_prefill(PfArgs a, hipStream_t st) {
   const int nwg = nqb < kNWG ? nqb : kNWG;
   hipLaunchKernelGGL(prefill_pv_kernel<T>, dim3(nwg, a.H), dim3(kThreads), lds, st, a);
   CC_LAUNCH_CHECK();
-  if (a.colsum || a.obs) {
+  if (a.colsum || a.obs || a.band_out) {
     int nb = (a.H * a.L + kThreads - 1) / kThreads;
     if (nb > 2048) nb = 2048;
     hipLaunchKernelGGL(prefill_side_kernel<T>, dim3(nb), dim3(kThreads), 0, st, a, nwg);
@@ -266,13 +288,27 @@ extern "C" {
 size_t cc_prefill_attn_workspace_bytes(int32_t HQ, int32_t H, int32_t L, int32_t D, int32_t dtype) {
   (void)D; (void)dtype;
   if (HQ <= 0 || H <= 0 || L <= 0) return 0;
-  return align256((size_t)HQ * L * 2 * sizeof(float)) + align256((size_t)kNWG * H * L * sizeof(float));
+  return align256((size_t)HQ * L * 2 * sizeof(float)) + align256((size_t)(1 + kMaxBands) * kNWG * H * L * sizeof(float));
 }
+
+int cc_prefill_attn_bands(const void* q, const void* k, const void* v, int32_t HQ, int32_t H, int32_t L, int32_t D,
+                          int32_t dtype, float scale, void* y, float* colsum_out, float* obs_out, int32_t obs_len,
+                          const int32_t* bands, int32_t n_bands, float* band_out, void* workspace,
+                          size_t workspace_bytes, cc_stream_t stream);
 
 int cc_prefill_attn(const void* q, const void* k, const void* v, int32_t HQ, int32_t H, int32_t L, int32_t D,
                     int32_t dtype, float scale, void* y, float* colsum_out, float* obs_out, int32_t obs_len,
                     void* workspace, size_t workspace_bytes, cc_stream_t stream) {
+  return cc_prefill_attn_bands(q, k, v, HQ, H, L, D, dtype, scale, y, colsum_out, obs_out, obs_len, nullptr, 0, nullptr,
+                               workspace, workspace_bytes, stream);
+}
+
+int cc_prefill_attn_bands(const void* q, const void* k, const void* v, int32_t HQ, int32_t H, int32_t L, int32_t D,
+                          int32_t dtype, float scale, void* y, float* colsum_out, float* obs_out, int32_t obs_len,
+                          const int32_t* bands, int32_t n_bands, float* band_out, void* workspace,
+                          size_t workspace_bytes, cc_stream_t stream) {
   CC_ENTRY();
+  if (n_bands < 0 || n_bands > kMaxBands || (n_bands > 0 && (!bands || !band_out))) return CC_ERR_BAD_ARG;
   if (!q || !k || !v || !y || HQ <= 0 || H <= 0 || HQ % H || L <= 0 || D <= 0 || !cc_dt_ok(dtype) || !workspace)
     return CC_ERR_BAD_ARG;
   const int R = HQ / H;
@@ -283,6 +319,8 @@ int cc_prefill_attn(const void* q, const void* k, const void* v, int32_t HQ, int
   a.stats = reinterpret_cast<float*>(workspace);
   a.cpart = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + align256((size_t)HQ * L * 2 * sizeof(float)));
   a.colsum = colsum_out; a.obs = obs_out;
+  a.nb = n_bands; a.band_out = n_bands > 0 ? band_out : nullptr;
+  for (int b = 0; b < n_bands; b++) a.band[b] = bands[b];  // HOST array: values travel as kernel arguments
   a.HQ = HQ; a.H = H; a.R = R; a.L = L; a.D = D;
   a.QB = kRows / R;
   a.TK = D <= 128 ? 32 : 16;

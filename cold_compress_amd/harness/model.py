@@ -153,8 +153,9 @@ class Attention(nn.Module):
                 cache._state_fused = True
             cache.update_state(input_pos, k, v, False, attn, **ck)
         else:
+            bands = cache.attn_bands(seqlen) if hasattr(cache, "attn_bands") else ()  # hybrid profiling side outputs
             y, attn = scaled_dot_product_attention(q, k, v, attn_mask=mask, return_attn=cache.return_attn(),
-                                                   is_causal=True)
+                                                   is_causal=True, bands=bands)
             input_pos, k, v, attn = self.compress_prompt(input_pos, k, v, attn)
             cache.update_kv(input_pos, k, v, True, **ck)
             cache.update_state(input_pos, k, v, True, attn, **ck)

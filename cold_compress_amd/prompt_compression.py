@@ -39,8 +39,9 @@ class AttnSummary:
     [1, H, L, L] probability tensor (attention_utils.py:36-54): per kv-head column sums of the group-averaged
     probabilities and their mean over the last `obs_len` query rows, both float32 [H, L]."""
 
-    def __init__(self, colsum, obs_mean, obs_len, dtype):
+    def __init__(self, colsum, obs_mean, obs_len, dtype, bands=None):
         self.colsum, self.obs_mean, self.obs_len, self.dtype = colsum, obs_mean, obs_len, dtype
+        self.bands = bands or {}  # {window width in queries: band sums float32 [H, L]} (hybrid profiling)
         self.ndim = 4  # quacks like the reference's 4-D attention for `attn.ndim == 4` checks
         self.shape = (1, colsum.shape[0], colsum.shape[1], colsum.shape[1])
 

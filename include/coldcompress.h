@@ -222,6 +222,14 @@ int cc_prefill_attn(const void* q, const void* k, const void* v, int32_t HQ, int
                     int32_t D, int32_t dtype, float scale, void* y, float* colsum_out, float* obs_out,
                     int32_t obs_len, void* workspace, size_t workspace_bytes, cc_stream_t stream);
 
+/* The same with band-sum side outputs for the hybrid profiling score: band_out[b, h, k] = sum over queries
+ * q in [k, k + bands[b]) of the group-averaged dtype-rounded probabilities (cf. cc_attn_bandsum).
+ * bands: HOST int32[n_bands], n_bands <= 4; band_out: device f32 [n_bands, H, L]. */
+int cc_prefill_attn_bands(const void* q, const void* k, const void* v, int32_t HQ, int32_t H, int32_t L, int32_t D,
+                          int32_t dtype, float scale, void* y, float* colsum_out, float* obs_out, int32_t obs_len,
+                          const int32_t* bands, int32_t n_bands, float* band_out, void* workspace,
+                          size_t workspace_bytes, cc_stream_t stream);
+
 /* Column sums of a materialised attention tensor (API-compat path when a caller hands the reference's
  * own [H, L, L] probabilities).  ref: cache.py:704.  out[h,k] = sum_q attn[h,q,k] (fp32 accumulate). */
 int cc_attn_colsum(const void* attn, int32_t H, int32_t Lq, int32_t Lk, int32_t dtype, float* out,
@@ -233,6 +241,41 @@ int cc_attn_colsum(const void* attn, int32_t H, int32_t Lq, int32_t Lk, int32_t 
  * input_pos: int64 [L] or NULL (= arange(L), what prefill always passes, generation_utils.py:462). */
 int cc_colsum_to_mean(const float* colsum, const int64_t* input_pos, int32_t H, int32_t L, int32_t dtype,
                       void* out, cc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Hybrid (FastGen) cache and the W-slot attention-history ring.  ref: KVCacheHybrid cache.py:768-1288.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Decode-time update for a cache whose heads follow different policies.
+ * ref: _decoding_update cache.py:965-1019, _select_fill_idx :896-950, _eviction_idx_for_head :844-894.
+ *   strategies: int64 [H], policy index of each head (cache_strategies).
+ *   policy_table: int32 [n_policies, 3] on the device = {flags, window slots = round(recent_window*S),
+ *     heavy-hitter slots = round(heavy_hitter_frac*S)}; flags: 1 heavy_hitter, 2 window, 4 punc, 8 special, 16 full.
+ *   num: [H, S, W] model dtype history ring; denom: [H, S] int32.  The heavy-hitter score of a slot is
+ *     dtype(sum_W num) / min(denom, W) over the first cache_cts[h] slots; protected slots (first g slots,
+ *     special/punctuation slots, pos > p - window) -> +inf; arg-min.
+ *   is_punc: device bool[1] (torch.isin(input_ids, punc_ids)) or NULL; num_special / num_punc: device int32[1] or NULL.
+ *   c must be head-specific and variable-length (Hp == Hc == H).  fill_out: int64 [H] (dropped tokens report S-1).
+ * Effects: pos/K/V written at fill_out for every head; mask and cache_cts only on appends; history zeroed on
+ * evictions when requires_heavy_hitter; punc_mask set and num_punc += 1 when is_punc. */
+int cc_hybrid_decode_update(const cc_kv_view* c, const void* k_new, const void* v_new, const int32_t* input_pos,
+                            const int64_t* strategies, const int32_t* policy_table, int32_t n_policies, void* num,
+                            int32_t* denom, int32_t W, const uint8_t* special_mask, uint8_t* punc_mask,
+                            const uint8_t* is_punc, const int32_t* num_special, int32_t* num_punc,
+                            int32_t global_tokens, int32_t requires_heavy_hitter, int64_t* fill_out,
+                            cc_stream_t stream);
+
+/* History ring update, history_window_size W > 1.  ref: cache.py:716-723:
+ *   num[h, s, *counter % W] = attn[h, s] (0 beyond T); denom += 1 everywhere; *counter += 1.
+ * num: [H, S, W] dtype; attn: [H, T] dtype. */
+int cc_hh_ring_update(void* num, int32_t* denom, int64_t* counter, const void* attn, int32_t H, int32_t S, int32_t T,
+                      int32_t W, int32_t dtype, cc_stream_t stream);
+
+/* Band sums of a materialised attention tensor: out[h,k] = sum_{q=k}^{k+band-1} attn[h,q,k] (fp32, sequential).
+ * Used by the hybrid profiling score for window policies (ref: create_window_attention_mask cache.py:142-149 +
+ * profile_attn_heads :1165-1168 rewritten per key instead of per [L, L] mask). */
+int cc_attn_bandsum(const void* attn, int32_t H, int32_t Lq, int32_t Lk, int32_t dtype, int32_t band, float* out,
+                    cc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Caller glue around the hot path (ref: model.py Attention.forward / TransformerBlock / RMSNorm /

@@ -748,3 +748,160 @@ int cc_silu_mul_cpu(const void* a, const void* b, int64_t n, int32_t dtype, void
   }
   return CC_OK;
 }
+
+/* ---------------------------------------------------------------- hybrid (FastGen) ----------------- */
+
+enum { HF_HH = 1, HF_WIN = 2, HF_PUNC = 4, HF_SPECIAL = 8, HF_FULL = 16 };
+
+/* dtype(sum_W row): fp32 accumulation in index order, rounded to the model dtype (cache.py:855-859) */
+static float window_sum_row(const void* num, int dt, size_t off, int W) {
+  float acc = 0.f;
+  for (int j = 0; j < W; j++) acc = acc + ld(num, dt, off + j);
+  return rnd(acc, dt);
+}
+
+/* ref: KVCacheHybrid._decoding_update cache.py:965-1019, _select_fill_idx :896-950, _eviction_idx_for_head :844-894 */
+int cc_hybrid_decode_update_cpu(const cc_kv_view* c, const void* k_new, const void* v_new, const int32_t* input_pos,
+                                const int64_t* strategies, const int32_t* policy_table, int32_t n_policies, void* num,
+                                int32_t* denom, int32_t W, const uint8_t* special_mask, uint8_t* punc_mask,
+                                const uint8_t* is_punc_p, const int32_t* num_special, int32_t* num_punc, int32_t g,
+                                int32_t requires_hh, int64_t* fill_out, cc_stream_t stream) {
+  (void)stream;
+  if (!view_ok(c) || !k_new || !v_new || !input_pos || !strategies || !policy_table || n_policies <= 0 || !num || !denom ||
+      W <= 0 || !fill_out || c->Hp != c->H || c->Hc != c->H)
+    return CC_ERR_BAD_ARG;
+  const int S = c->S, dt = c->dtype;
+  const int32_t p = *input_pos;
+  const int is_punc = is_punc_p ? (*is_punc_p != 0) : 0;
+  const size_t es = dt_size(dt);
+  float* sc = (float*)malloc(sizeof(float) * (size_t)S);
+  for (int h = 0; h < c->H; h++) {
+    const int pol = (int)strategies[h];
+    const int flags = policy_table[pol * 3], win = policy_table[pol * 3 + 1], hhs = policy_table[pol * 3 + 2];
+    const int cts = c->cache_cts[h];
+    const int end_idx = cts < S - 1 ? cts : S - 1;
+    const size_t hoff = (size_t)h * S;
+    int fill = -1, evict = 0;
+    if ((flags & HF_PUNC) && is_punc) fill = end_idx;
+    else if (flags & HF_FULL) fill = end_idx;
+    else {
+      int budget = g;
+      if (flags & HF_SPECIAL) budget += num_special ? *num_special : 0;
+      if (flags & HF_PUNC) budget += num_punc ? *num_punc : 0;
+      if (flags & HF_WIN) budget += win;
+      if (flags & HF_HH) budget += hhs;
+      if (cts < budget) fill = end_idx;
+      else if (flags & (HF_HH | HF_WIN)) {
+        evict = 1;
+        const int n = cts < S ? cts : S;
+        for (int s = 0; s < n; s++) {
+          const int32_t ps = c->pos[hoff + s];
+          float v;
+          if (flags & HF_HH) {
+            int32_t dn = denom[hoff + s];
+            dn = dn > W ? W : dn;
+            v = window_sum_row(num, dt, (hoff + s) * (size_t)W, W) / (float)dn;
+          } else v = (float)ps;
+          int save = s < g;
+          if ((flags & HF_SPECIAL) && special_mask) save |= special_mask[hoff + s] != 0;
+          if ((flags & HF_PUNC) && punc_mask) save |= punc_mask[hoff + s] != 0;
+          if (flags & HF_WIN) save |= ps > p - win;
+          sc[s] = save ? INFINITY : v;
+        }
+        fill = (int)argmin_f32(sc, n);
+      }
+    }
+    const int slot = fill < 0 ? S - 1 : fill;
+    fill_out[h] = slot;
+    if (evict && requires_hh) {
+      for (int j = 0; j < W; j++) st(num, dt, (hoff + slot) * (size_t)W + j, 0.f);
+      denom[hoff + slot] = 0;
+    }
+    if (!evict && fill >= 0) {
+      c->cache_cts[h] = cts + 1;
+      c->mask[hoff + slot] = 1;
+    }
+    c->pos[hoff + slot] = p;
+    memcpy((char*)c->k_cache + (hoff + slot) * c->D * es, (const char*)k_new + (size_t)h * c->D * es, c->D * es);
+    memcpy((char*)c->v_cache + (hoff + slot) * c->D * es, (const char*)v_new + (size_t)h * c->D * es, c->D * es);
+    if (is_punc && punc_mask) punc_mask[hoff + slot] = 1;
+  }
+  if (is_punc && num_punc) *num_punc += 1;
+  free(sc);
+  return CC_OK;
+}
+
+/* ref: cache.py:716-723 with history_window_size > 1 */
+int cc_hh_ring_update_cpu(void* num, int32_t* denom, int64_t* counter, const void* attn, int32_t H, int32_t S, int32_t T,
+                          int32_t W, int32_t dtype, cc_stream_t stream) {
+  (void)stream;
+  if (!num || !denom || !counter || !attn || H <= 0 || S <= 0 || T < 0 || T > S || W <= 0 || !dt_ok(dtype)) return CC_ERR_BAD_ARG;
+  const int slot = (int)(*counter % W);
+  for (int h = 0; h < H; h++)
+    for (int s = 0; s < S; s++) {
+      st(num, dtype, ((size_t)h * S + s) * W + slot, s < T ? ld(attn, dtype, (size_t)h * T + s) : 0.f);
+      denom[(size_t)h * S + s] += 1;
+    }
+  *counter += 1;
+  return CC_OK;
+}
+
+int cc_attn_bandsum_cpu(const void* attn, int32_t H, int32_t Lq, int32_t Lk, int32_t dtype, int32_t band, float* out,
+                        cc_stream_t stream) {
+  (void)stream;
+  if (!attn || !out || H <= 0 || Lq <= 0 || Lk <= 0 || band <= 0 || !dt_ok(dtype)) return CC_ERR_BAD_ARG;
+  for (int h = 0; h < H; h++)
+    for (int s = 0; s < Lk; s++) {
+      float acc = 0.f;
+      const int hi = s + band < Lq ? s + band : Lq;
+      for (int i = s; i < hi; i++) acc = acc + ld(attn, dtype, ((size_t)h * Lq + i) * Lk + s);
+      out[(size_t)h * Lk + s] = acc;
+    }
+  return CC_OK;
+}
+
+/* prefill attention with band sums (hybrid profiling): band_out[b,h,k] = sum_{q in [k, k+bands[b])} a[h,q,k] */
+int cc_prefill_attn_bands_cpu(const void* q, const void* k, const void* v, int32_t HQ, int32_t H, int32_t L, int32_t D,
+                              int32_t dtype, float scale, void* y, float* colsum_out, float* obs_out, int32_t obs_len,
+                              const int32_t* bands, int32_t n_bands, float* band_out, void* workspace,
+                              size_t workspace_bytes, cc_stream_t stream) {
+  int rc = cc_prefill_attn_cpu(q, k, v, HQ, H, L, D, dtype, scale, y, colsum_out, obs_out, obs_len, workspace,
+                               workspace_bytes, stream);
+  if (rc != CC_OK || n_bands <= 0) return rc;
+  if (!bands || !band_out || n_bands > 4) return CC_ERR_BAD_ARG;
+  const int R = HQ / H;
+  float* P = (float*)malloc(sizeof(float) * (size_t)R * L);
+  float* sc = (float*)malloc(sizeof(float) * (size_t)L);
+  memset(band_out, 0, sizeof(float) * (size_t)n_bands * H * L);
+  for (int h = 0; h < H; h++)
+    for (int i = 0; i < L; i++) {
+      for (int r = 0; r < R; r++) {
+        const int j = h * R + r;
+        float m = -INFINITY;
+        for (int s = 0; s <= i; s++) {
+          double acc = 0.0;
+          for (int d = 0; d < D; d++)
+            acc += (double)ld(q, dtype, ((size_t)j * L + i) * D + d) * (double)ld(k, dtype, ((size_t)h * L + s) * D + d);
+          float x = rnd(rnd((float)acc, dtype) * scale, dtype);
+          sc[s] = x;
+          if (x > m) m = x;
+        }
+        double sum = 0.0;
+        for (int s = 0; s <= i; s++) {
+          sc[s] = expf(sc[s] - m);
+          sum += sc[s];
+        }
+        for (int s = 0; s <= i; s++) P[(size_t)r * L + s] = rnd(sc[s] / (float)sum, dtype);
+      }
+      for (int s = 0; s <= i; s++) {
+        float acc = 0.f;
+        for (int r = 0; r < R; r++) acc += P[(size_t)r * L + s];
+        const float a = rnd(acc / (float)R, dtype);
+        for (int b = 0; b < n_bands; b++)
+          if (i - s < bands[b]) band_out[((size_t)b * H + h) * L + s] += a;
+      }
+    }
+  free(P);
+  free(sc);
+  return CC_OK;
+}

@@ -359,9 +359,117 @@ def budgets(G, M, C=None):
     return rows
 
 
+# ------------------------------------------------------------------------------------------------ F6
+
+
+HYBRID_YAML = [  # cache_configs/hybrid.yaml of the reference
+    {"strategy": "window", "recent_window": 0.1},
+    {"strategy": "window_heavy_hitter", "heavy_hitter_frac": 0.25, "recent_window": 0.1},
+    {"strategy": "window_heavy_hitter", "heavy_hitter_frac": 0.5, "recent_window": 0.1},
+    {"strategy": "full"},
+]
+FASTGEN_YAML = [  # cache_configs/fastgen.yaml of the reference
+    {"strategy": "special"},
+    {"strategy": "special_punc"},
+    {"strategy": "special_punc_heavy_hitter", "heavy_hitter_frac": 0.3},
+    {"strategy": "special_punc_heavy_hitter_window", "recent_window": 0.3, "heavy_hitter_frac": 0.3},
+    {"strategy": "full"},
+]
+
+
+def hybrid_case(C, dtype, strategies, min_recovery, seed, H=4, L=48, S=96, D=16, steps=40, peaky=1.5):
+    """KVCacheHybrid driven as model.py:389-427 does: prefill (update_kv, then update_state with the [1,H,L,L]
+    attention -> profile_and_update) and `steps` decode steps."""
+    gen = torch.Generator().manual_seed(seed)
+    token_ids = {"special": [[1], [2, 3]], "punctuation": [5, 6, 7]}
+    kv = C.KVCacheHybrid(1, H, D, dtype, max_cache_length=S, max_seq_length=S, cache_bits=None, global_tokens=4,
+                         token_ids=token_ids, min_recovery_frac=min_recovery, hybrid_strategies=strategies)
+    ids = torch.randint(8, 64, (1, L), generator=gen)
+    ids[0, 0] = 1
+    ids[0, 10], ids[0, 11] = 2, 3
+    ids[0, 20] = 5
+    ids[0, 33] = 6
+    ids[0, 40] = 7
+    k0 = torch.randn(1, H, L, D, generator=gen).to(dtype)
+    v0 = torch.randn(1, H, L, D, generator=gen).to(dtype)
+    causal = torch.tril(torch.ones(L, L, dtype=torch.bool)).view(1, 1, L, L).expand(1, H, L, L)
+    # heads of different "peakiness" so that different policies get selected
+    x = torch.randn(1, H, L, L, generator=gen) * torch.tensor([0.3, peaky, 3.0, 6.0][:H]).view(1, H, 1, 1)
+    x[:, :, :, :4] += 2.0
+    attn0 = torch.softmax(x.masked_fill(~causal, float("-inf")), -1).to(dtype)
+    pos0 = torch.arange(L)
+    kv.update_kv(pos0, k0, v0, True, input_ids=ids)
+    # capture the partition order the reference's (non-stable) argsort produced
+    cap = {}
+    orig_argsort = torch.Tensor.argsort
+
+    def spy(self, *a, **k):
+        r = orig_argsort(self, *a, **k)
+        if self.dtype == torch.int32 and self.ndim == 2 and self.shape == (H, L):
+            cap["order"] = r.clone()
+        return r
+
+    torch.Tensor.argsort = spy
+    try:
+        kv.update_state(pos0, k0, v0, True, attn0, input_ids=ids)
+    finally:
+        torch.Tensor.argsort = orig_argsort
+    rec = {"H": H, "L": L, "S": S, "D": D, "steps": steps, "min_recovery_frac": min_recovery,
+           "strategies_json": json.dumps(strategies), "dtype": np.array(str(dtype).split(".")[-1]),
+           "ids": ids, "k0": k0, "v0": v0, "attn0": attn0, "order": cap["order"],
+           "cache_strategies": kv.cache_strategies.clone(), "cts_after_prefill": kv.cache_cts.clone(),
+           "pos_after_prefill": kv.pos.clone(), "mask_after_prefill": kv.mask.clone(),
+           "num_after_prefill": kv.attn_history_num.clone(), "denom_after_prefill": kv.attn_history_denom.clone(),
+           "k_after_prefill": kv.k_cache.clone(), "requires_hh": int(kv.requires_heavy_hitter),
+           "num_special": kv.num_special.clone().view(-1) if hasattr(kv, "num_special") else torch.zeros(1),
+           "num_punc": kv.num_punc.clone().view(-1) if hasattr(kv, "num_punc") else torch.zeros(1)}
+    if hasattr(kv, "special_mask"):
+        rec["special_mask_after_prefill"] = kv.special_mask.clone()
+    if hasattr(kv, "punc_mask"):
+        rec["punc_mask_after_prefill"] = kv.punc_mask.clone()
+    ks, vs, attns, toks, fills, cts = [], [], [], [], [], []
+    orig_fill = kv._fill
+
+    def fill_spy(input_pos, k_val, v_val, fill_idxs, **kw):
+        fills.append(fill_idxs.clone())
+        return orig_fill(input_pos, k_val, v_val, fill_idxs, **kw)
+
+    kv._fill = fill_spy
+    for t in range(steps):
+        p = torch.tensor([L + t], dtype=torch.int32)
+        tok = torch.randint(8, 64, (1, 1), generator=gen)
+        if t in (5, 17, 18):
+            tok[0, 0] = 6  # punctuation tokens arriving at decode time
+        k1 = torch.randn(1, H, 1, D, generator=gen).to(dtype)
+        v1 = torch.randn(1, H, 1, D, generator=gen).to(dtype)
+        kv.update_kv(p, k1, v1, False, input_ids=tok)
+        a = None
+        if kv.return_attn():
+            a = softmax_rows((1, H, 1, S), dtype, gen, kv.mask.clone())
+            attns.append(a)
+        kv.update_state(p, k1, v1, False, a, input_ids=tok)
+        ks.append(k1)
+        vs.append(v1)
+        toks.append(tok.view(-1))
+        cts.append(kv.cache_cts.clone())
+    rec.update({"k_new": torch.stack(ks), "v_new": torch.stack(vs), "tok": torch.stack(toks),
+                "fill": torch.stack(fills), "cts_steps": torch.stack(cts), "final_pos": kv.pos.clone(),
+                "final_mask": kv.mask.clone(), "final_cts": kv.cache_cts.clone(), "final_num": kv.attn_history_num.clone(),
+                "final_denom": kv.attn_history_denom.clone(), "final_k": kv.k_cache.clone()})
+    if attns:
+        rec["attn"] = torch.stack(attns)
+    if hasattr(kv, "punc_mask"):
+        rec["final_punc_mask"] = kv.punc_mask.clone()
+        rec["final_num_punc"] = kv.num_punc.clone().view(-1)
+    st = kv.compute_statistics(torch.tensor(L + steps))
+    rec["stats_json"] = json.dumps({k: float(v) for k, v in st.items()})
+    return pack(rec)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
+    ap.add_argument("--only", default=None, help="generate only one fixture family (e.g. f6)")
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     A, C, G, M, P = _import_reference()
@@ -370,6 +478,15 @@ def main():
     def save(name, d):
         np.savez_compressed(os.path.join(a.out, name), **d)
         print("wrote", name, sum(v.nbytes for v in d.values()) // 1024, "KiB")
+
+    # F6: hybrid (FastGen) prefill profiling + decode traces
+    if a.only in (None, "f6"):
+        save("f6_hybrid_f32.npz", hybrid_case(C, torch.float32, HYBRID_YAML, 0.9, seed=61))
+        save("f6_hybrid_bf16.npz", hybrid_case(C, torch.bfloat16, HYBRID_YAML, 0.55, seed=62, steps=60))
+        save("f6_hybrid_mixed_f32.npz", hybrid_case(C, torch.float32, HYBRID_YAML, 0.45, seed=64, steps=60, peaky=0.8))
+        save("f6_fastgen_f32.npz", hybrid_case(C, torch.float32, FASTGEN_YAML, 0.7, seed=63))
+        if a.only == "f6":
+            return
 
     # F1: config C1 (README.md:103 of the reference) + companions on the same tiny model
     save("f1_e2e_recent_global.npz", run_e2e(C, G, M, "recent_global", dict(

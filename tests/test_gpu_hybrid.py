@@ -1,0 +1,238 @@
+"""GPU tests of KVCacheHybrid (FastGen per-head policies): prefill profiling + decode, through the Python class
+-> C ABI -> HIP kernels, against traces captured from the reference's KVCacheHybrid (tests/golden/f6_*.npz) and
+against the oracle at larger sizes.
+
+With the reference's (implementation-defined) partition order injected, everything is compared bit-exactly:
+chosen policy per head, per-head counts, pos/mask/special/punc masks, and every decode fill index.  With our own
+stable partition, the per-head SETS of kept positions and the counts must match (SURVEY §8(c) contract (5))."""
+import ctypes as C
+import json
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import DT_CODE, DT_FROM_NAME, from_np, load_golden, to_np
+from test_oracle_hybrid import FIXTURES, policy_table
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+TOKEN_IDS = {"special": [[1], [2, 3]], "punctuation": [5, 6, 7]}
+
+
+def _make(f, dtype):
+    import cold_compress_amd.cache as cache
+
+    cls, rk = cache.get_cache_constructor("hybrid")
+    kw = dict(max_cache_length=f["S"], max_seq_length=f["S"], cache_bits=None, global_tokens=4, token_ids=TOKEN_IDS,
+              min_recovery_frac=f["min_recovery_frac"], hybrid_strategies=json.loads(f["strategies_json"]))
+    with torch.device(DEV):
+        kv = cls(1, f["H"], f["D"], dtype, **{k: kw[k] for k in rk})
+    return kv
+
+
+def _prefill(kv, f, inject_order):
+    L = f["L"]
+    pos0 = torch.arange(L, device=DEV)
+    k0, v0 = f["k0"].to(DEV), f["v0"].to(DEV)
+    ids = f["ids"].to(DEV)
+    kv.update_kv(pos0, k0, v0, True, input_ids=ids)
+    if inject_order:
+        kv._partition_order = lambda m: f["order"].to(DEV)
+    kv.update_state(pos0, k0, v0, True, f["attn0"].to(DEV), input_ids=ids)
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_hybrid_prefill_and_decode_vs_reference(name):
+    f = load_golden(name)
+    dtype = DT_FROM_NAME[f["dtype"]]
+    kv = _make(f, dtype)
+    _prefill(kv, f, inject_order=True)
+    assert kv.cache_strategies.cpu().tolist() == f["cache_strategies"].tolist()
+    assert torch.equal(kv.cache_cts.cpu(), f["cts_after_prefill"].to(torch.int32))
+    assert torch.equal(kv.pos.cpu(), f["pos_after_prefill"])
+    assert torch.equal(kv.mask.cpu(), f["mask_after_prefill"])
+    assert (kv.k_cache.cpu().float() - f["k_after_prefill"].float()).abs().max() == 0
+    assert bool(kv.requires_heavy_hitter) == bool(f["requires_hh"])
+    if "special_mask_after_prefill" in f:
+        assert torch.equal(kv.special_mask.cpu(), f["special_mask_after_prefill"])
+        assert int(kv.num_special) == int(f["num_special"][0])
+    if "punc_mask_after_prefill" in f:
+        assert torch.equal(kv.punc_mask.cpu(), f["punc_mask_after_prefill"])
+        assert int(kv.num_punc) == int(f["num_punc"][0])
+    assert torch.equal(kv.attn_history_denom.cpu(), f["denom_after_prefill"])
+    tol = dict(rtol=2 ** -7 if dtype != torch.float32 else 1e-5, atol=1e-7)
+    assert torch.allclose(kv.attn_history_num.cpu().float(), f["num_after_prefill"].float(), **tol)
+    kv.attn_history_num.copy_(f["num_after_prefill"].to(DEV))  # column-sum order is unspecified: continue on equal state
+    L = f["L"]
+    ai = 0
+    for t in range(f["steps"]):
+        p = torch.tensor([L + t], dtype=torch.int32, device=DEV)
+        tok = f["tok"][t].view(1, 1).to(DEV)
+        k1, v1 = f["k_new"][t].to(DEV), f["v_new"][t].to(DEV)
+        kv.update_kv(p, k1, v1, False, input_ids=tok)
+        torch.cuda.synchronize()
+        assert kv._idx_buf().cpu().tolist() == f["fill"][t].tolist(), f"step {t}"
+        assert torch.equal(kv.cache_cts.cpu(), f["cts_steps"][t].to(torch.int32)), f"step {t}"
+        a = None
+        if kv.return_attn():
+            a = f["attn"][ai].to(DEV)
+            ai += 1
+        kv.update_state(p, k1, v1, False, a, input_ids=tok)
+    torch.cuda.synchronize()
+    assert torch.equal(kv.pos.cpu(), f["final_pos"]) and torch.equal(kv.mask.cpu(), f["final_mask"])
+    assert torch.equal(kv.attn_history_denom.cpu(), f["final_denom"])
+    assert torch.equal(kv.attn_history_num.cpu().float(), f["final_num"].float())
+    assert (kv.k_cache.cpu().float() - f["final_k"].float()).abs().max() == 0
+    st = kv.compute_statistics(torch.tensor(L + f["steps"]))
+    ref = json.loads(f["stats_json"])
+    for key in ref:
+        if key != "cache_memory_gb":
+            assert abs(st[key] - ref[key]) < 1e-6, key
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_hybrid_stable_partition_keeps_the_same_sets(name):
+    f = load_golden(name)
+    dtype = DT_FROM_NAME[f["dtype"]]
+    kv = _make(f, dtype)
+    _prefill(kv, f, inject_order=False)
+    assert kv.cache_strategies.cpu().tolist() == f["cache_strategies"].tolist()
+    cts = kv.cache_cts.cpu()
+    assert torch.equal(cts, f["cts_after_prefill"].to(torch.int32))
+    for h in range(f["H"]):
+        mine = kv.pos.cpu()[0, h, : int(cts[h])]
+        ref = f["pos_after_prefill"][0, h, : int(cts[h])]
+        assert sorted(mine.tolist()) == sorted(ref.tolist())
+        assert bool((mine[1:] > mine[:-1]).all()), "stable partition keeps the original order inside the kept class"
+        assert bool((kv.pos.cpu()[0, h, int(cts[h]):] == -1).all())
+
+
+def test_hybrid_decode_vs_oracle_at_scale(oracle):
+    """H=8, S=2048, W=400, bf16: seeded state, 10 decode steps on both sides, bit-exact."""
+    import cold_compress_amd.cache as cache
+
+    H, S, D, W, g = 8, 2048, 128, 400, 4
+    strategies = [{"strategy": "window", "recent_window": 0.1},
+                  {"strategy": "window_heavy_hitter", "heavy_hitter_frac": 0.25, "recent_window": 0.1},
+                  {"strategy": "special_punc_heavy_hitter", "heavy_hitter_frac": 0.3}, {"strategy": "full"}]
+    gen = torch.Generator().manual_seed(99)
+    kw = dict(max_cache_length=S, max_seq_length=S, cache_bits=None, global_tokens=g, token_ids=TOKEN_IDS, min_recovery_frac=0.9,
+              hybrid_strategies=strategies)
+    with torch.device(DEV):
+        kv = cache.KVCacheHybrid(1, H, D, torch.bfloat16, **kw)
+    strat = torch.tensor([0, 1, 2, 3, 1, 2, 0, 1], dtype=torch.int64)
+    cts = torch.tensor([300, 900, 800, 1500, 716, 1200, 208, 720], dtype=torch.int32)
+    kv.cache_strategies = strat.to(DEV)
+    kv.cache_cts.copy_(cts)
+    pos = torch.full((H, S), -1, dtype=torch.int32)
+    for h in range(H):
+        pos[h, : cts[h]] = torch.sort(torch.randperm(1700, generator=gen)[: cts[h]]).values.int()
+    kv.pos[0] = pos.to(DEV)
+    kv.mask[0, :, 0] = (torch.arange(S).view(1, S) < cts.view(H, 1)).to(DEV)
+    kv.k_cache.copy_(torch.randn(1, H, S, D, generator=gen).to(torch.bfloat16))
+    kv.v_cache.copy_(torch.randn(1, H, S, D, generator=gen).to(torch.bfloat16))
+    kv.attn_history_num.copy_((torch.rand(1, H, S, W, generator=gen) * 0.01).to(torch.bfloat16))
+    kv.attn_history_denom.copy_(torch.randint(0, 600, (1, H, S), generator=gen, dtype=torch.int32))
+    kv.special_mask[0] = (torch.rand(H, S, generator=gen) < 0.01).to(DEV)
+    kv.punc_mask[0] = (torch.rand(H, S, generator=gen) < 0.02).to(DEV)
+    kv.num_special.fill_(20)
+    kv.num_punc.fill_(40)
+    kv.attn_counter.fill_(777)
+    st = dict(k=to_np(kv.k_cache.cpu()[0]), v=to_np(kv.v_cache.cpu()[0]), pos=kv.pos.cpu()[0].numpy().copy(),
+              mask=kv.mask.cpu()[0, :, 0].numpy().astype(np.uint8), cts=kv.cache_cts.cpu().numpy().copy(),
+              num=to_np(kv.attn_history_num.cpu()[0]), denom=kv.attn_history_denom.cpu()[0].numpy().copy(),
+              special=kv.special_mask.cpu()[0].numpy().astype(np.uint8), punc=kv.punc_mask.cpu()[0].numpy().astype(np.uint8),
+              nsp=np.array([20], np.int32), npc=np.array([40], np.int32), ctr=np.array([777], np.int64))
+    tab = policy_table(strategies, S)
+    o = oracle
+    for t in range(10):
+        p = torch.tensor([1800 + t], dtype=torch.int32)
+        tok = torch.tensor([[6 if t in (3, 4) else 30]])
+        k1 = torch.randn(1, H, 1, D, generator=gen).to(torch.bfloat16)
+        v1 = torch.randn(1, H, 1, D, generator=gen).to(torch.bfloat16)
+        a = torch.softmax(torch.randn(H, S, generator=gen), -1).to(torch.bfloat16)
+        kv.update_kv(p.to(DEV), k1.to(DEV), v1.to(DEV), False, input_ids=tok.to(DEV))
+        kv.update_state(p.to(DEV), k1.to(DEV), v1.to(DEV), False, a.view(1, H, 1, S).to(DEV), input_ids=tok.to(DEV))
+        torch.cuda.synchronize()
+        view = o.view(st["k"], st["v"], st["pos"], st["mask"], st["cts"], 1)
+        fill = np.zeros(H, np.int64)
+        isp = np.array([int(int(tok) in (5, 6, 7))], np.uint8)
+        stn = strat.numpy().copy()
+        o.call("cc_hybrid_decode_update", C.byref(view), o.ptr(to_np(k1.reshape(H, D))), o.ptr(to_np(v1.reshape(H, D))),
+               o.ptr(p.numpy().copy()), o.ptr(stn), o.ptr(tab), len(tab), o.ptr(st["num"]), o.ptr(st["denom"]), W, o.ptr(st["special"]),
+               o.ptr(st["punc"]), o.ptr(isp), o.ptr(st["nsp"]), o.ptr(st["npc"]), g, 0, o.ptr(fill), None)
+        o.call("cc_hh_ring_update", o.ptr(st["num"]), o.ptr(st["denom"]), o.ptr(st["ctr"]), o.ptr(to_np(a)), H, S, S, W, 1, None)
+        assert kv._idx_buf().cpu().tolist() == fill.tolist(), f"step {t}"
+    assert np.array_equal(kv.pos.cpu()[0].numpy(), st["pos"]) and np.array_equal(kv.cache_cts.cpu().numpy(), st["cts"])
+    assert np.array_equal(to_np(kv.attn_history_num.cpu()[0]), st["num"])
+    assert np.array_equal(kv.attn_history_denom.cpu()[0].numpy(), st["denom"])
+    assert np.array_equal(kv.punc_mask.cpu()[0].numpy().astype(np.uint8), st["punc"]) and int(kv.num_punc) == int(st["npc"][0])
+    assert np.array_equal(to_np(kv.k_cache.cpu()[0]), st["k"]) and int(kv.attn_counter) == int(st["ctr"][0])
+
+
+@pytest.mark.parametrize("dtype,HQ,H,L,D", [(torch.float32, 4, 2, 70, 16), (torch.bfloat16, 8, 2, 130, 64)])
+def test_prefill_band_sums_vs_oracle(oracle, dtype, HQ, H, L, D):
+    from cold_compress_amd.attention_utils import prefill_attention
+
+    gen = torch.Generator().manual_seed(3 + L)
+    q = torch.randn(1, HQ, L, D, generator=gen).to(dtype)
+    k = torch.randn(1, H, L, D, generator=gen).to(dtype)
+    v = torch.randn(1, H, L, D, generator=gen).to(dtype)
+    bands = [1, 7, 13, L]
+    y, summ = prefill_attention(q.to(DEV), k.to(DEV), v.to(DEV), return_attn=True, bands=bands)
+    code = DT_CODE[dtype]
+    es = np.float32 if code == 0 else np.uint16
+    yo, cs, ob = np.zeros((HQ, L, D), es), np.zeros((H, L), np.float32), np.zeros((H, L), np.float32)
+    bo = np.zeros((len(bands), H, L), np.float32)
+    barr = np.array(bands, np.int32)
+    oracle.call("cc_prefill_attn_bands", oracle.ptr(to_np(q[0])), oracle.ptr(to_np(k[0])), oracle.ptr(to_np(v[0])), HQ, H, L, D, code,
+                1.0 / math.sqrt(D), oracle.ptr(yo), oracle.ptr(cs), oracle.ptr(ob), 16, oracle.ptr(barr), len(bands), oracle.ptr(bo), None, 0, None)
+    tol = 5e-2 if code else 1e-3
+    for i, b in enumerate(bands):
+        assert (summ.bands[b].cpu() - torch.from_numpy(bo[i])).abs().max() < tol
+    assert (summ.bands[L].cpu() - summ.colsum.cpu()).abs().max() < 1e-5  # a band as wide as the prompt is the column sum
+
+
+def test_hybrid_end_to_end_through_the_harness():
+    """hybrid.yaml on the tiny model: prefill profiling + decode run through generate(); invariants hold."""
+    import argparse
+
+    import cold_compress_amd.cache as cache
+    from cold_compress_amd.harness import ModelArgs, Transformer, decode_one_token, generate, prefill, setup_caches
+    HYBRID_YAML = [{"strategy": "window", "recent_window": 0.1},  # the policy list of cache_configs/hybrid.yaml
+                   {"strategy": "window_heavy_hitter", "heavy_hitter_frac": 0.25, "recent_window": 0.1},
+                   {"strategy": "window_heavy_hitter", "heavy_hitter_frac": 0.5, "recent_window": 0.1}, {"strategy": "full"}]
+
+    class Tok:
+        def special_ids(self):
+            return [[1], [2, 3]]
+
+        def punctuation_ids(self):
+            return [5, 6, 7]
+
+    torch.manual_seed(0)
+    model = Transformer(ModelArgs(block_size=256, vocab_size=128, n_layer=2, n_head=4, n_local_heads=2, dim=64,
+                                  intermediate_size=128)).to(torch.float32).eval().to(DEV)
+    ap = argparse.ArgumentParser()
+    cache.add_cache_arguments(ap)
+    kw = vars(ap.parse_args([]))
+    kw.update(cache_strategy=["hybrid"], prompt_compression_strategy=["full"], max_cache_length=[1.0], global_tokens=4,
+              hybrid_strategies=HYBRID_YAML, min_recovery_frac=0.6)
+    setup_caches(model, Tok(), DEV, 40 + 24, dict(kw))
+    prompt = (torch.arange(40) * 7 % 128).to(torch.int32).to(DEV)
+    seq, _, stats = generate(model, prompt, prefill, decode_one_token, max_new_tokens=24)
+    assert seq.numel() == 64
+    for layer in model.layers:
+        kv = layer.attention.kv_cache
+        cts = kv.cache_cts.cpu()
+        assert bool((cts <= kv.max_cache_length).all()) and bool((cts >= 4).all())
+        pos = kv.pos.cpu()[0]
+        for h in range(2):
+            live = pos[h, : int(cts[h])]
+            assert bool((live >= 0).all()) and len(set(live.tolist())) == live.numel()
+            assert bool(kv.mask.cpu()[0, h, 0, : int(cts[h])].all()) and not bool(kv.mask.cpu()[0, h, 0, int(cts[h]):].any())
+        st = kv.compute_statistics(torch.tensor(64))
+        assert 0 <= st["compression_ratio"] <= 1 and "avg_strategy_idx" in st
