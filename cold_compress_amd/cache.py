@@ -298,11 +298,13 @@ class KVCacheHeavyHitter(KVCacheHeadSpecific):
 
     def __init__(self, max_batch_size, n_heads, head_dim, dtype=torch.bfloat16, variable_length=False, **kwargs):
         super().__init__(max_batch_size, n_heads, head_dim, dtype, variable_length, **kwargs)
-        if self.attn_thresholding or self.history_window_size != 1:
+        if self.attn_thresholding:
             raise NotImplementedError(
-                "attn_thresholding / history_window_size > 1 are SURVEY §8(f) follow-ups and not built yet")
-        S = self.max_cache_length
-        self.register_buffer("attn_history_num", torch.zeros((1, n_heads, S, 1), dtype=torch.float64))
+                "attn_thresholding: the reference itself fails on this path (cache.py:721 index_put of an Int source "
+                "into its Bool history buffer raises), so there is no behaviour to reproduce or pin")
+        S, W = self.max_cache_length, int(self.history_window_size)
+        # ref: cache.py:661-667 — one float64 accumulator for the full history (W == 1), else a model-dtype ring
+        self.register_buffer("attn_history_num", torch.zeros((1, n_heads, S, W), dtype=torch.float64 if W == 1 else dtype))
         self.register_buffer("attn_history_denom", torch.zeros((1, n_heads, S), dtype=torch.int32))
         self.register_buffer("attn_counter", torch.zeros((1,), dtype=torch.int64))
         # set by the attention op when it already applied this step's history update in its combine pass
@@ -318,17 +320,29 @@ class KVCacheHeavyHitter(KVCacheHeadSpecific):
         return True
 
     def _run_select(self, input_pos, k, v):
-        _abi.call("cc_decode_update_heavy_hitter", self._view(), _ptr(k), _ptr(v), _ptr(self._pos32(input_pos)),
-                  _ptr(self.attn_history_num), _ptr(self.attn_history_denom), int(self.global_tokens),
-                  int(self.recent_window), _ptr(self._idx_buf()), _stream())
+        if self.history_window_size == 1:
+            _abi.call("cc_decode_update_heavy_hitter", self._view(), _ptr(k), _ptr(v), _ptr(self._pos32(input_pos)),
+                      _ptr(self.attn_history_num), _ptr(self.attn_history_denom), int(self.global_tokens),
+                      int(self.recent_window), _ptr(self._idx_buf()), _stream())
+        else:
+            _abi.call("cc_decode_update_heavy_hitter_ring", self._view(), _ptr(k), _ptr(v), _ptr(self._pos32(input_pos)),
+                      _ptr(self.attn_history_num), _ptr(self.attn_history_denom), int(self.history_window_size),
+                      int(self.global_tokens), int(self.recent_window), _ptr(self._idx_buf()), _stream())
 
     def fused_history(self):
-        """Pointers the decode attention kernel needs to fold cache.py:690-723 into its combine pass."""
+        """Pointers the decode attention kernel needs to fold cache.py:690-723 into its combine pass (W == 1 only)."""
+        if self.history_window_size != 1:
+            return None
         return self.attn_history_num, self.attn_history_denom, self.attn_counter
 
     def _apply(self, attn_hs, T):
-        _abi.call("cc_hh_update", _ptr(self.attn_history_num), _ptr(self.attn_history_denom), _ptr(self.attn_counter),
-                  _ptr(attn_hs), self.n_heads, self.max_cache_length, T, _DT[self.k_cache.dtype], _stream())
+        if self.history_window_size == 1:
+            _abi.call("cc_hh_update", _ptr(self.attn_history_num), _ptr(self.attn_history_denom), _ptr(self.attn_counter),
+                      _ptr(attn_hs), self.n_heads, self.max_cache_length, T, _DT[self.k_cache.dtype], _stream())
+        else:
+            _abi.call("cc_hh_ring_update", _ptr(self.attn_history_num), _ptr(self.attn_history_denom), _ptr(self.attn_counter),
+                      _ptr(attn_hs), self.n_heads, self.max_cache_length, T, int(self.history_window_size),
+                      _DT[self.k_cache.dtype], _stream())
 
     def update_state(self, input_pos, k_val, v_val, is_prefill, attn, **kwargs):
         """ref: cache.py:690-723."""

@@ -136,6 +136,67 @@ __global__ __launch_bounds__(kHybThreads) void hybrid_decode_kernel(HybArgs a) {
   }
 }
 
+// Plain heavy hitter with a finite history window (history_window_size W > 1, model-dtype ring).
+// ref: KVCacheHeavyHitter._eviction_idx cache.py:725-765: avg = float(dtype(sum_W num)) / clamp(denom, 1, W);
+// (pos < g) | (pos >= p - w) -> 1.0; pos == -1 -> 0.0; arg-min; ring row and denom of the slot zeroed; insert.
+struct RingArgs {
+  void* k_cache;
+  void* v_cache;
+  int32_t* pos;
+  uint8_t* mask;
+  int32_t* cache_cts;
+  int H, Hc, S, D, W, g, w;
+  const void* k_new;
+  const void* v_new;
+  const int32_t* input_pos;
+  void* num;
+  int32_t* denom;
+  int64_t* idx_out;
+};
+
+template <typename T>
+__global__ __launch_bounds__(kHybThreads) void hh_ring_decode_kernel(RingArgs a) {
+  __shared__ unsigned long long sm_key[kHybThreads / 64 + 2];
+  const int h = blockIdx.x, S = a.S, W = a.W;
+  const int32_t p = *a.input_pos;
+  const size_t hoff = (size_t)h * S;
+  T* num = reinterpret_cast<T*>(a.num);
+  unsigned long long best = ~0ull;
+  for (int s = threadIdx.x; s < S; s += blockDim.x) {
+    const int32_t ps = a.pos[hoff + s];
+    int32_t dn = a.denom[hoff + s];
+    dn = dn < 1 ? 1 : (dn > W ? W : dn);
+    float sc = __fdiv_rn(window_sum<T>(num + (hoff + s) * (size_t)W, W), (float)dn);
+    if (ps < a.g || ps >= p - a.w) sc = 1.0f;
+    if (ps == -1) sc = 0.0f;
+    const unsigned long long key = make_key(orderable_f32(sc), ((uint32_t)s << 1) | (uint32_t)(ps == -1));
+    best = key < best ? key : best;
+  }
+  best = block_min_u64(best, sm_key);
+  const int idx = (int)((best & 0xffffffffull) >> 1), ins = (int)(best & 1ull);
+  for (int j = threadIdx.x; j < W; j += blockDim.x) ElemTraits<T>::store(num + (hoff + idx) * (size_t)W, j, 0.f);
+  if (threadIdx.x == 0) {
+    a.idx_out[h] = idx;
+    a.denom[hoff + idx] = 0;
+  }
+  if (a.k_new == nullptr) return;
+  if (threadIdx.x == 0) {
+    a.pos[hoff + idx] = p;
+    a.mask[hoff + idx] = 1;
+    if (a.Hc == a.H) a.cache_cts[h] += ins;
+    else if (h == 0) a.cache_cts[0] += ins;
+  }
+  const int words = a.D * (int)sizeof(T) / 4;
+  const uint32_t* ks = reinterpret_cast<const uint32_t*>(a.k_new) + (size_t)h * words;
+  const uint32_t* vs = reinterpret_cast<const uint32_t*>(a.v_new) + (size_t)h * words;
+  uint32_t* kd = reinterpret_cast<uint32_t*>(a.k_cache) + (hoff + idx) * words;
+  uint32_t* vd = reinterpret_cast<uint32_t*>(a.v_cache) + (hoff + idx) * words;
+  for (int i = threadIdx.x; i < 2 * words; i += blockDim.x) {
+    if (i < words) kd[i] = ks[i];
+    else vd[i - words] = vs[i - words];
+  }
+}
+
 // num_punc += 1 once per step (ref: :1017), after every head has read the old value
 __global__ void hybrid_bump_punc_kernel(const uint8_t* is_punc, int32_t* num_punc) {
   if (threadIdx.x == 0 && blockIdx.x == 0 && *is_punc) *num_punc += 1;
@@ -202,6 +263,27 @@ int cc_hybrid_decode_update(const cc_kv_view* c, const void* k_new, const void* 
     hipLaunchKernelGGL(hybrid_bump_punc_kernel, dim3(1), dim3(64), 0, st, is_punc, num_punc);
     CC_LAUNCH_CHECK();
   }
+  return CC_OK;
+}
+
+int cc_decode_update_heavy_hitter_ring(const cc_kv_view* c, const void* k_new, const void* v_new,
+                                       const int32_t* input_pos, void* num, int32_t* denom, int32_t W, int32_t g,
+                                       int32_t w, int64_t* idx_out, cc_stream_t stream) {
+  CC_ENTRY();
+  if (!cc_view_ok(c) || !input_pos || !idx_out || !num || !denom || W <= 0 || c->Hp != c->H || (k_new && !v_new))
+    return CC_ERR_BAD_ARG;
+  RingArgs a{};
+  a.k_cache = c->k_cache; a.v_cache = c->v_cache; a.pos = c->pos; a.mask = c->mask; a.cache_cts = c->cache_cts;
+  a.H = c->H; a.Hc = c->Hc; a.S = c->S; a.D = c->D; a.W = W; a.g = g; a.w = w;
+  a.k_new = k_new; a.v_new = v_new; a.input_pos = input_pos; a.num = num; a.denom = denom; a.idx_out = idx_out;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(c->H), block(kHybThreads);
+  switch (c->dtype) {
+    case CC_DT_F32: hipLaunchKernelGGL(hh_ring_decode_kernel<float>, grid, block, 0, st, a); break;
+    case CC_DT_BF16: hipLaunchKernelGGL(hh_ring_decode_kernel<bf16_t>, grid, block, 0, st, a); break;
+    default: hipLaunchKernelGGL(hh_ring_decode_kernel<f16_t>, grid, block, 0, st, a); break;
+  }
+  CC_LAUNCH_CHECK();
   return CC_OK;
 }
 

@@ -145,7 +145,7 @@ class Attention(nn.Module):
         ck = {"input_ids": input_ids}
         if not is_prefill:
             kc, vc, kv_mask = cache.update_kv(input_pos, k, v, False, **ck)  # insert first, then attend
-            fuse = self.fuse_state_update and isinstance(cache, KVCacheHeavyHitter) and type(cache) is KVCacheHeavyHitter
+            fuse = (self.fuse_state_update and type(cache) is KVCacheHeavyHitter and cache.fused_history() is not None)
             y, attn = scaled_dot_product_attention(
                 q, kc, vc, attn_mask=kv_mask, attn_top_k=attn_top_k, return_attn=cache.return_attn() and not fuse,
                 group_mean=True, history=cache.fused_history() if fuse else None)

@@ -905,3 +905,34 @@ int cc_prefill_attn_bands_cpu(const void* q, const void* k, const void* v, int32
   free(sc);
   return CC_OK;
 }
+
+/* ref: KVCacheHeavyHitter._eviction_idx cache.py:725-765 with history_window_size W > 1 */
+int cc_decode_update_heavy_hitter_ring_cpu(const cc_kv_view* c, const void* k_new, const void* v_new,
+                                           const int32_t* input_pos, void* num, int32_t* denom, int32_t W, int32_t g,
+                                           int32_t w, int64_t* idx_out, cc_stream_t stream) {
+  (void)stream;
+  if (!view_ok(c) || !input_pos || !idx_out || !num || !denom || W <= 0 || c->Hp != c->H || c->H > 4096) return CC_ERR_BAD_ARG;
+  const int32_t p = *input_pos;
+  const int dt = c->dtype;
+  float* sc = (float*)malloc(sizeof(float) * (size_t)c->S);
+  for (int h = 0; h < c->H; h++) {
+    const int32_t* pos = c->pos + (size_t)h * c->S;
+    for (int s = 0; s < c->S; s++) {
+      const size_t i = (size_t)h * c->S + s;
+      int32_t dn = denom[i] < 1 ? 1 : (denom[i] > W ? W : denom[i]);
+      float v = window_sum_row(num, dt, i * (size_t)W, W) / (float)dn;
+      if (pos[s] < g || pos[s] >= p - w) v = 1.0f;
+      if (pos[s] == -1) v = 0.0f;
+      sc[s] = v;
+    }
+    idx_out[h] = argmin_f32(sc, c->S);
+  }
+  free(sc);
+  for (int h = 0; h < c->H; h++) {
+    const size_t i = (size_t)h * c->S + idx_out[h];
+    for (int j = 0; j < W; j++) st(num, dt, i * (size_t)W + j, 0.f);
+    denom[i] = 0;
+  }
+  if (k_new) insert_token(c, k_new, v_new, p, idx_out);
+  return CC_OK;
+}

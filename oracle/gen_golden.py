@@ -488,6 +488,17 @@ def main():
         if a.only == "f6":
             return
 
+    # F2w: heavy hitter with a finite history window (ScissorHands m) and with binary thresholded history
+    if a.only in (None, "f2w"):
+        save("f2_hh_w8_f32.npz", replay_cache(C, "heavy_hitter", torch.float32, H=4, S=48, D=16, T_prefill=30, steps=80, g=2,
+                                              w=3, seed=23, extra={"history_window_size": 8}))
+        save("f2_hh_w8_bf16.npz", replay_cache(C, "heavy_hitter", torch.bfloat16, H=4, S=48, D=16, T_prefill=30, steps=80, g=2,
+                                               w=3, seed=24, extra={"history_window_size": 8}))
+        # attn_thresholding=True cannot be captured: the reference itself raises at cache.py:721
+        # ("Index put requires the source and destination dtypes match, got Bool ... and Int") on torch 2.10.
+        if a.only == "f2w":
+            return
+
     # F1: config C1 (README.md:103 of the reference) + companions on the same tiny model
     save("f1_e2e_recent_global.npz", run_e2e(C, G, M, "recent_global", dict(
         cache_strategy=["recent_global"], prompt_compression_strategy=["recent_global"], max_cache_length=[16],

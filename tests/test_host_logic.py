@@ -99,9 +99,12 @@ def test_buffers_and_statistics_on_cpu():
     assert abs(st["cache_memory_gb"] - nbytes / 2 ** 30) < 1e-12
     kv.reset()
     assert int(kv.cache_cts[0]) == 0
-    for bad in (dict(cache_bits=4), dict(history_window_size=4), dict(attn_thresholding=True)):
+    for bad in (dict(cache_bits=4), dict(attn_thresholding=True)):
         with pytest.raises(NotImplementedError):
             cache.KVCacheHeavyHitter(1, 2, 8, torch.bfloat16, **{**kw, **bad})
+    ring = cache.KVCacheHeavyHitter(1, 2, 8, torch.bfloat16, **{**kw, "history_window_size": 4})
+    assert ring.attn_history_num.shape == (1, 2, 16, 4) and ring.attn_history_num.dtype == torch.bfloat16  # cache.py:661-667
+    assert ring.fused_history() is None
 
 
 def test_cpu_tensors_refused_no_fallback():
