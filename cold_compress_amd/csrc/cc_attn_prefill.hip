@@ -281,14 +281,35 @@ static int run_prefill(PfArgs a, hipStream_t st) {
   return CC_OK;
 }
 
+constexpr int kNWGMfma = 64;  // persistent workgroups per kv head on the MFMA path
+
+// MFMA path (cc_attn_prefill_mfma.hip): 16-bit dtype, D == 128, HQ == 4*H.
+static bool mfma_eligible(int HQ, int H, int D, int dtype) {
+  return D == 128 && HQ == 4 * H && (dtype == CC_DT_BF16 || dtype == CC_DT_F16);
+}
+
+template <typename T>
+static int run_side(PfArgs a, int nwg, hipStream_t st) {
+  int nb = (a.H * a.L + kThreads - 1) / kThreads;
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(prefill_side_kernel<T>, dim3(nb), dim3(kThreads), 0, st, a, nwg);
+  CC_LAUNCH_CHECK();
+  return CC_OK;
+}
+
 }  // namespace
+
+extern "C" int cc_prefill_attn_mfma_impl(const void* q, const void* k, const void* v, int HQ, int H, int L, int D, int dtype,
+                                         float scale, void* y, float* stats, float* cpart, int nwg, void* vt, const int* bands,
+                                         int nb, hipStream_t st);
 
 extern "C" {
 
 size_t cc_prefill_attn_workspace_bytes(int32_t HQ, int32_t H, int32_t L, int32_t D, int32_t dtype) {
-  (void)D; (void)dtype;
   if (HQ <= 0 || H <= 0 || L <= 0) return 0;
-  return align256((size_t)HQ * L * 2 * sizeof(float)) + align256((size_t)(1 + kMaxBands) * kNWG * H * L * sizeof(float));
+  const size_t Lp = ((size_t)L + 31) & ~(size_t)31;
+  return align256((size_t)HQ * L * 2 * sizeof(float)) + align256((size_t)(1 + kMaxBands) * kNWGMfma * H * L * sizeof(float)) +
+         (mfma_eligible(HQ, H, D, dtype) ? align256((size_t)H * D * Lp * 2) : 0);
 }
 
 int cc_prefill_attn_bands(const void* q, const void* k, const void* v, int32_t HQ, int32_t H, int32_t L, int32_t D,
@@ -327,6 +348,15 @@ int cc_prefill_attn_bands(const void* q, const void* k, const void* v, int32_t H
   a.obs_len = obs_len < 0 ? 0 : (obs_len > L ? L : obs_len);
   a.scale = scale;
   hipStream_t st = (hipStream_t)stream;
+  if (mfma_eligible(HQ, H, D, dtype) && L >= 64) {
+    const int nqt = (L + 31) / 32;
+    const int nwg = nqt < kNWGMfma ? nqt : kNWGMfma;
+    char* vt = reinterpret_cast<char*>(a.cpart) + align256((size_t)(1 + kMaxBands) * kNWGMfma * H * L * sizeof(float));
+    const int rc = cc_prefill_attn_mfma_impl(q, k, v, HQ, H, L, D, dtype, scale, y, a.stats, a.cpart, nwg, vt, a.band, a.nb, st);
+    if (rc != CC_OK) return rc;
+    if (a.colsum || a.obs || a.band_out) return dtype == CC_DT_BF16 ? run_side<bf16_t>(a, nwg, st) : run_side<f16_t>(a, nwg, st);
+    return CC_OK;
+  }
   switch (dtype) {
     case CC_DT_F32: return run_prefill<float>(a, st);
     case CC_DT_BF16: return run_prefill<bf16_t>(a, st);

@@ -1,0 +1,257 @@
+// cc_attn_prefill_mfma.hip — causal prefill attention on the gfx950 matrix cores (v_mfma_f32_32x32x16_{bf16,f16}),
+// with the side outputs the eviction policies need, for the Llama-3 geometry (16-bit dtype, D = 128, R = HQ/H = 4).
+// Everything else falls back to the LDS-tiled VALU kernels in cc_attn_prefill.hip.
+//
+// ref: attention_utils.py:36-54 (scores -> dtype, *scale -> dtype, softmax -> dtype, P@V), model.py:413-418
+// (group mean), cache.py:704 / prompt_compression.py:170-194 (column sums, observation window).
+//
+// Structure (two passes, like the VALU path, because the reference's probabilities are rounded to the model dtype
+// AFTER normalisation with the final row statistics):
+//   workgroup = 4 waves = the 4 query heads of one kv head x one tile of 32 queries; persistent over query tiles
+//   (w, w + NWG, ...) so the per-workgroup column-sum partials accumulate in a fixed order (no atomics).
+//   S^T = K . Q^T  ("swapped" product): the MFMA C tile has col = query (lane & 31) and 16 keys per lane, so every
+//   softmax row statistic is lane-local + one half-wave exchange.
+//   P (C layout) is converted to 16-bit and used DIRECTLY as the A operand of the PV MFMA; the B operand comes
+//   from V^T stored with the matching key permutation inside each 32-key block (vt_perm), one 16-byte load per
+//   operand — no LDS transpose, no cross-lane shuffles on the MFMA path.
+// MFMA-bound contraction; HBM traffic is negligible (K/V tiles are re-read from L2 by the 4 waves).
+#include "cc_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+template <typename T>
+struct MfmaOps;
+template <>
+struct MfmaOps<bf16_t> {
+  __device__ static __forceinline__ f32x16 mma(uint4 a, uint4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+  __device__ static __forceinline__ uint32_t pack2(float lo, float hi) {
+    return (uint32_t)f32_to_bf16_bits(lo) | ((uint32_t)f32_to_bf16_bits(hi) << 16);
+  }
+};
+template <>
+struct MfmaOps<f16_t> {
+  __device__ static __forceinline__ f32x16 mma(uint4 a, uint4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+  __device__ static __forceinline__ uint32_t pack2(float lo, float hi) {
+    return (uint32_t)f32_to_f16_bits(lo) | ((uint32_t)f32_to_f16_bits(hi) << 16);
+  }
+};
+
+constexpr int kD = 128;
+constexpr int kTQ = 32;   // queries per tile
+constexpr int kTK = 32;   // keys per tile
+constexpr int kMaxBandsM = 4;
+
+struct MArgs {
+  const void* q;   // [HQ, L, D]
+  const void* k;   // [H, L, D]
+  const void* vt;  // [H, D, Lp] transposed + permuted V (Lp = L rounded up to 32)
+  void* y;         // [HQ, L, D]
+  float* stats;    // [HQ, L, 2]
+  float* cpart;    // [1 + nb, NWG, H, L]
+  int H, L, Lp, nb;
+  int band[kMaxBandsM];
+  float scale;
+};
+
+// key offset inside a 32-key tile held by accumulator register `reg` of a lane in half `hi`
+__device__ __forceinline__ int c_row(int reg, int hi) { return (reg & 3) + 8 * (reg >> 2) + 4 * hi; }
+
+// V [H, L, D] -> vt_perm [H, D, Lp]: position pp = kb*16 + 8*hi + i of each 32-key block holds key c_row(kb*8 + i, hi)
+template <typename T>
+__global__ __launch_bounds__(256) void vt_perm_kernel(const T* v, T* vt, int H, int L, int Lp) {
+  const size_t total = (size_t)H * kD * Lp;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int pp_abs = (int)(idx % Lp);
+    const int d = (int)((idx / Lp) % kD);
+    const int h = (int)(idx / ((size_t)Lp * kD));
+    const int blk = pp_abs >> 5, pp = pp_abs & 31;
+    const int kb = pp >> 4, hi = (pp >> 3) & 1, i = pp & 7;
+    const int key = blk * 32 + c_row(kb * 8 + i, hi);
+    T val;
+    val.x = 0;
+    if (key < L) val = v[((size_t)h * L + key) * kD + d];
+    vt[idx] = val;
+  }
+}
+
+template <typename T, int PASS>
+__global__ __launch_bounds__(256) void prefill_mfma_kernel(MArgs a) {
+  __shared__ float sm_p[4][kTK][kTQ + 1];   // per-wave probability tiles (pass 2): [r][key][query]
+  __shared__ float sm_red[1 + kMaxBandsM][8][kTK];
+  const int lane = threadIdx.x & 63, r = threadIdx.x >> 6;  // wave = query head of the group
+  const int hi = lane >> 5, lq = lane & 31;
+  const int h = blockIdx.y, L = a.L;
+  const int j = h * 4 + r;
+  const T* qh = reinterpret_cast<const T*>(a.q) + (size_t)j * L * kD;
+  const T* kh = reinterpret_cast<const T*>(a.k) + (size_t)h * L * kD;
+  const T* vth = reinterpret_cast<const T*>(a.vt) + (size_t)h * kD * a.Lp;
+  const int nqt = (L + kTQ - 1) / kTQ;
+  const size_t plane = (size_t)gridDim.x * a.H * L;
+  float* cp = a.cpart + ((size_t)blockIdx.x * a.H + h) * L;
+  if (PASS == 2) {
+    for (int pl = 0; pl <= a.nb; pl++)
+      for (int s = threadIdx.x; s < L; s += 256) cp[pl * plane + s] = 0.f;
+  }
+
+  for (int qt = blockIdx.x; qt < nqt; qt += gridDim.x) {
+    const int q0 = qt * kTQ;
+    const int query = q0 + lq;
+    const int qc = query < L ? query : L - 1;
+    uint4 qb[8];  // B operand of the QK MFMA for the 8 d-steps: Q[query][16*ds + 8*hi .. +7]
+#pragma unroll
+    for (int ds = 0; ds < 8; ds++) qb[ds] = *reinterpret_cast<const uint4*>(qh + (size_t)qc * kD + ds * 16 + 8 * hi);
+    float m_run = -INFINITY, l_run = 0.f;  // pass 1: partial over this lane's keys
+    float m_fin = 0.f, l_fin = 1.f;        // pass 2
+    if (PASS == 2) {
+      m_fin = a.stats[((size_t)j * L + qc) * 2];
+      l_fin = a.stats[((size_t)j * L + qc) * 2 + 1];
+    }
+    f32x16 o[4];
+#pragma unroll
+    for (int b = 0; b < 4; b++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) o[b][e] = 0.f;
+
+    const int last_q = min(L, q0 + kTQ) - 1;
+    for (int k0 = 0; k0 <= last_q; k0 += kTK) {
+      // ---- S^T tile = K . Q^T  (rows = keys, cols = queries)
+      const int krow = k0 + lq < L ? k0 + lq : L - 1;
+      f32x16 s;
+#pragma unroll
+      for (int e = 0; e < 16; e++) s[e] = 0.f;
+#pragma unroll
+      for (int ds = 0; ds < 8; ds++) {
+        const uint4 ka = *reinterpret_cast<const uint4*>(kh + (size_t)krow * kD + ds * 16 + 8 * hi);
+        s = MfmaOps<T>::mma(ka, qb[ds], s);
+      }
+      float x[16];
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        const int key = k0 + c_row(e, hi);
+        const float v = ElemTraits<T>::rnd(ElemTraits<T>::rnd(s[e]) * a.scale);
+        x[e] = (key > query || key >= L || query >= L) ? -INFINITY : v;
+      }
+      if (PASS == 1) {
+        float mx = m_run;
+#pragma unroll
+        for (int e = 0; e < 16; e++) mx = fmaxf(mx, x[e]);
+        const float mu = (mx == -INFINITY) ? 0.f : mx;
+        float sum = l_run * expf(m_run - mu);
+#pragma unroll
+        for (int e = 0; e < 16; e++) sum += expf(x[e] - mu);
+        m_run = mx;
+        l_run = sum;
+      } else {
+        float p[16];
+#pragma unroll
+        for (int e = 0; e < 16; e++) p[e] = ElemTraits<T>::rnd(__fdiv_rn(expf(x[e] - m_fin), l_fin));  // exp(-inf) = 0
+        // ---- column sums of the group mean: P tiles of the 4 query heads meet in LDS
+        __syncthreads();  // previous tile's readers are done
+#pragma unroll
+        for (int e = 0; e < 16; e++) sm_p[r][c_row(e, hi)][lq] = p[e];
+        __syncthreads();
+        {
+          const int key = threadIdx.x & 31, qs = threadIdx.x >> 5;  // 8 slices of 4 queries
+          float cs = 0.f, bs[kMaxBandsM] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int qq = 0; qq < 4; qq++) {
+            const int ql = qs * 4 + qq;
+            const float sum = ((sm_p[0][key][ql] + sm_p[1][key][ql]) + sm_p[2][key][ql]) + sm_p[3][key][ql];
+            const float av = ElemTraits<T>::rnd(__fdiv_rn(sum, 4.0f));
+            cs += av;
+            const int dist = (q0 + ql) - (k0 + key);
+#pragma unroll
+            for (int b = 0; b < kMaxBandsM; b++)
+              if (b < a.nb && dist < a.band[b]) bs[b] += av;
+          }
+          sm_red[0][qs][key] = cs;
+#pragma unroll
+          for (int b = 0; b < kMaxBandsM; b++)
+            if (b < a.nb) sm_red[1 + b][qs][key] = bs[b];
+        }
+        __syncthreads();
+        if (threadIdx.x < kTK && k0 + threadIdx.x < L) {
+          const int key = threadIdx.x;
+          for (int pl = 0; pl <= a.nb; pl++) {
+            float tot = 0.f;
+#pragma unroll
+            for (int qs = 0; qs < 8; qs++) tot += sm_red[pl][qs][key];
+            cp[pl * plane + k0 + key] += tot;
+          }
+        }
+        // ---- O += P . V : A = P (C layout -> 16-bit, no data movement), B = vt_perm (one 16-byte load each)
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++) {
+          uint4 pa;
+          pa.x = MfmaOps<T>::pack2(p[kb * 8 + 0], p[kb * 8 + 1]);
+          pa.y = MfmaOps<T>::pack2(p[kb * 8 + 2], p[kb * 8 + 3]);
+          pa.z = MfmaOps<T>::pack2(p[kb * 8 + 4], p[kb * 8 + 5]);
+          pa.w = MfmaOps<T>::pack2(p[kb * 8 + 6], p[kb * 8 + 7]);
+#pragma unroll
+          for (int db = 0; db < 4; db++) {
+            const uint4 vb = *reinterpret_cast<const uint4*>(vth + (size_t)(db * 32 + lq) * a.Lp + k0 + kb * 16 + 8 * hi);
+            o[db] = MfmaOps<T>::mma(pa, vb, o[db]);
+          }
+        }
+      }
+    }
+    if (PASS == 1) {
+      // merge the two half-waves (each saw 16 of every 32 keys)
+      const float m_o = __shfl_xor(m_run, 32, CC_WAVE), l_o = __shfl_xor(l_run, 32, CC_WAVE);
+      const float mx = fmaxf(m_run, m_o);
+      const float mu = (mx == -INFINITY) ? 0.f : mx;
+      const float lt = l_run * expf(m_run - mu) + l_o * expf(m_o - mu);
+      if (hi == 0 && query < L) {
+        a.stats[((size_t)j * L + query) * 2] = mx;
+        a.stats[((size_t)j * L + query) * 2 + 1] = lt;
+      }
+    } else {
+      T* yh = reinterpret_cast<T*>(a.y) + (size_t)j * L * kD;
+#pragma unroll
+      for (int db = 0; db < 4; db++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+          const int qrow = q0 + c_row(e, hi);
+          if (qrow < L) ElemTraits<T>::store(yh, (size_t)qrow * kD + db * 32 + lq, o[db][e]);
+        }
+    }
+  }
+}
+
+}  // namespace
+
+// Entry used by cc_attn_prefill.hip's dispatcher.  Returns CC_ERR_UNSUPPORTED when the geometry is not the MFMA one.
+// workspace layout is owned by the caller: stats | cpart planes | vt_perm.
+extern "C" int cc_prefill_attn_mfma_impl(const void* q, const void* k, const void* v, int HQ, int H, int L, int D, int dtype,
+                                         float scale, void* y, float* stats, float* cpart, int nwg, void* vt, const int* bands,
+                                         int nb, hipStream_t st) {
+  if (D != kD || HQ != 4 * H || (dtype != CC_DT_BF16 && dtype != CC_DT_F16) || nb > kMaxBandsM) return CC_ERR_UNSUPPORTED;
+  const int Lp = (L + 31) & ~31;
+  MArgs a{};
+  a.q = q; a.k = k; a.vt = vt; a.y = y; a.stats = stats; a.cpart = cpart;
+  a.H = H; a.L = L; a.Lp = Lp; a.nb = nb; a.scale = scale;
+  for (int b = 0; b < nb; b++) a.band[b] = bands[b];
+  const size_t tot = (size_t)H * kD * Lp;
+  size_t nbk = (tot + 255) / 256;
+  if (nbk > 8192) nbk = 8192;
+  dim3 grid(nwg, H), block(256);
+  if (dtype == CC_DT_BF16) {
+    hipLaunchKernelGGL(vt_perm_kernel<bf16_t>, dim3((unsigned)nbk), dim3(256), 0, st, (const bf16_t*)v, (bf16_t*)vt, H, L, Lp);
+    hipLaunchKernelGGL((prefill_mfma_kernel<bf16_t, 1>), grid, block, 0, st, a);
+    hipLaunchKernelGGL((prefill_mfma_kernel<bf16_t, 2>), grid, block, 0, st, a);
+  } else {
+    hipLaunchKernelGGL(vt_perm_kernel<f16_t>, dim3((unsigned)nbk), dim3(256), 0, st, (const f16_t*)v, (f16_t*)vt, H, L, Lp);
+    hipLaunchKernelGGL((prefill_mfma_kernel<f16_t, 1>), grid, block, 0, st, a);
+    hipLaunchKernelGGL((prefill_mfma_kernel<f16_t, 2>), grid, block, 0, st, a);
+  }
+  if (hipGetLastError() != hipSuccess) return CC_ERR_HIP;
+  return CC_OK;
+}

@@ -173,7 +173,8 @@ def test_hybrid_decode_vs_oracle_at_scale(oracle):
     assert np.array_equal(to_np(kv.k_cache.cpu()[0]), st["k"]) and int(kv.attn_counter) == int(st["ctr"][0])
 
 
-@pytest.mark.parametrize("dtype,HQ,H,L,D", [(torch.float32, 4, 2, 70, 16), (torch.bfloat16, 8, 2, 130, 64)])
+@pytest.mark.parametrize("dtype,HQ,H,L,D", [(torch.float32, 4, 2, 70, 16), (torch.bfloat16, 8, 2, 130, 64),
+                                            (torch.bfloat16, 8, 2, 203, 128), (torch.float16, 16, 4, 96, 128)])  # last two: MFMA path
 def test_prefill_band_sums_vs_oracle(oracle, dtype, HQ, H, L, D):
     from cold_compress_amd.attention_utils import prefill_attention
 
@@ -190,6 +191,11 @@ def test_prefill_band_sums_vs_oracle(oracle, dtype, HQ, H, L, D):
     barr = np.array(bands, np.int32)
     oracle.call("cc_prefill_attn_bands", oracle.ptr(to_np(q[0])), oracle.ptr(to_np(k[0])), oracle.ptr(to_np(v[0])), HQ, H, L, D, code,
                 1.0 / math.sqrt(D), oracle.ptr(yo), oracle.ptr(cs), oracle.ptr(ob), 16, oracle.ptr(barr), len(bands), oracle.ptr(bo), None, 0, None)
+    yref = from_np(yo, dtype).float()
+    ulp = {torch.float32: 1e-5, torch.bfloat16: 2 ** -8, torch.float16: 2 ** -11}[dtype]
+    assert (y.cpu().float()[0] - yref).abs().max() <= 1e-3 + 2 * ulp * yref.abs().max()
+    assert (summ.colsum.cpu() - torch.from_numpy(cs)).abs().max() < (5e-2 if code else 1e-3)
+    assert (summ.obs_mean.cpu() - torch.from_numpy(ob)).abs().max() < (4e-3 if code else 1e-3)
     tol = 5e-2 if code else 1e-3
     for i, b in enumerate(bands):
         assert (summ.bands[b].cpu() - torch.from_numpy(bo[i])).abs().max() < tol
