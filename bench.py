@@ -151,8 +151,6 @@ def roofline(model, args, dev):
 def layer_step_time(model, args, dev):
     """Mean device time of one layer's full hot-path step (evict+insert, attention split+combine with the fused
     history update) measured with one event pair around the three launches, rotating over layers."""
-    from cold_compress_amd.attention_utils import scaled_dot_product_attention as sdpa
-
     layers = [l.attention for l in model.layers]
     kv0 = layers[0].kv_cache
     H, D, HQ = kv0.n_heads, kv0.head_dim, layers[0].n_head
@@ -162,22 +160,24 @@ def layer_step_time(model, args, dev):
     snap = [{k: v.clone() for k, v in a.kv_cache._buffers.items()} for a in layers]
 
     def step(att):
-        kv = att.kv_cache
-        kc, vc, m = kv.update_kv(pos, k1, k1, False)
-        sdpa(q, kc, vc, attn_mask=m, group_mean=True, history=kv.fused_history())
+        att.kv_cache.decode_step(q, k1, k1, pos)  # the fused two-launch step the harness uses
 
     for att in layers:
         step(att)
+    pos.add_(1)
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(s):
-        step(layers[0])
+        for att in layers:
+            step(att)
+        pos.add_(1)
     torch.cuda.current_stream().wait_stream(s)
     with torch.cuda.graph(g):
         for att in layers:
             step(att)
+        pos.add_(1)  # positions advance by one per token, as the pipeline assumes
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     n = 10
@@ -190,6 +190,7 @@ def layer_step_time(model, args, dev):
     for a, sn in zip(layers, snap):
         for k, v in sn.items():
             a.kv_cache._buffers[k].copy_(v)
+        a.kv_cache._next_valid = False  # the measurement advanced positions on its own: re-seed on next use
     return us
 
 
@@ -328,7 +329,7 @@ def main():
         if step_us is not None and roof is not None:
             out["layer_step"] = {"us": round(step_us, 3), "bytes": roof["layer_step_bytes"],
                                  "frac_of_hbm_peak": round(roof["layer_step_bytes"] / (step_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                                 "note": "evict+insert, attention split+combine with fused history; device time incl. launch gaps"}
+                                 "note": "fused two-launch step (K/V streaming pass with the insert folded in; combine with history update + next-eviction scoring); device time incl. launch gaps"}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -309,15 +309,56 @@ class KVCacheHeavyHitter(KVCacheHeadSpecific):
         self.register_buffer("attn_counter", torch.zeros((1,), dtype=torch.int64))
         # set by the attention op when it already applied this step's history update in its combine pass
         self._state_fused = False
+        # fused decode-step pipeline (decode_step): arg-min keys for the NEXT position, double-buffered by parity
+        self.register_buffer("next_key", torch.full((2, n_heads), -1, dtype=torch.int64), persistent=False)
+        self._next_valid = False
 
     def reset(self):
         super().reset()
         self.attn_history_num.zero_()
         self.attn_history_denom.zero_()
         self.attn_counter.zero_()
+        self._next_valid = False
 
     def return_attn(self) -> bool:
         return True
+
+    def update_kv(self, input_pos, k_val, v_val, is_prefill, **kwargs):
+        self._next_valid = False  # the three-call path mutates pos / history outside the pipeline
+        return super().update_kv(input_pos, k_val, v_val, is_prefill, **kwargs)
+
+    # ------------------------------------------------------------------ fused decode step (2 launches per layer)
+    def prepare_decode(self, input_pos):
+        """Seed the pipeline: arg-min keys for `input_pos` from the current state (one select-only launch)."""
+        if self.history_window_size != 1:
+            raise ColdCompressError("the fused decode step needs history_window_size == 1")
+        _abi.call("cc_hh_next_key_init", self._view(), _ptr(self._pos32(input_pos)), _ptr(self.attn_history_num),
+                  _ptr(self.attn_history_denom), int(self.global_tokens), int(self.recent_window), _ptr(self.next_key),
+                  _stream())
+        self._next_valid = True
+
+    def decode_step(self, query, k_val, v_val, input_pos, scale=None):
+        """update_kv + attention over the pruned cache + update_state for one decode token in two launches
+        (cc_decode_step_heavy_hitter).  Bit-identical to the three-call sequence; positions must advance by one
+        between calls (any update_kv / update_state / reset in between re-seeds automatically)."""
+        from .attention_utils import _workspace
+        import math
+
+        k, v = self._new_rows(k_val, v_val)
+        p32 = self._pos32(input_pos)
+        if not self._next_valid:
+            self.prepare_decode(p32)
+        _, HQ, _, D = query.shape
+        q = query.reshape(HQ, D).contiguous()
+        y = torch.empty((1, HQ, 1, D), dtype=query.dtype, device=query.device)
+        code = _DT[self.k_cache.dtype]
+        nbytes = _abi.lib()["cc_decode_attn_workspace_bytes"](HQ, self.n_heads, self.max_cache_length, D, code)
+        ws = _workspace(nbytes, query.device)
+        _abi.call("cc_decode_step_heavy_hitter", self._view(), _ptr(q), _ptr(k), _ptr(v), _ptr(p32), _ptr(self.attn_history_num),
+                  _ptr(self.attn_history_denom), _ptr(self.attn_counter), _ptr(self.next_key), int(self.global_tokens),
+                  int(self.recent_window), HQ, 1.0 / math.sqrt(D) if scale is None else scale, _ptr(y), None, _ptr(ws),
+                  ws.numel(), _stream())
+        return y
 
     def _run_select(self, input_pos, k, v):
         if self.history_window_size == 1:
@@ -346,6 +387,7 @@ class KVCacheHeavyHitter(KVCacheHeadSpecific):
 
     def update_state(self, input_pos, k_val, v_val, is_prefill, attn, **kwargs):
         """ref: cache.py:690-723."""
+        self._next_valid = False
         if self._state_fused:
             self._state_fused = False
             return

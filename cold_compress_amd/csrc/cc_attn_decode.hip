@@ -95,6 +95,18 @@ struct SplitArgs {
   int S, R, n_split, rows_per_split;
   float scale;
   int abl;  // measurement-only ablation bits (phases >> 8): 1 = no score store, 2 = no epilogue, 4 = no mask
+  // ---- fused decode step (next_key != null): this step's insert is folded into the prologue.  The slot comes
+  //      from the arg-min key the PREVIOUS step's combine pass (or cc_hh_next_key_init) left in next_key[p & 1].
+  const unsigned long long* next_key;  // [2][H]
+  const int32_t* input_pos;
+  const void* k_new;  // [H, D]
+  const void* v_new;
+  int32_t* pos;        // [H, S]
+  uint8_t* mask_w;     // [H, S]
+  int32_t* cache_cts;  // [Hc]
+  double* num;         // [H, S]
+  int32_t* denom;      // [H, S]
+  int H, Hc;
 };
 
 template <typename T, int D, int RT, int NW, int U>
@@ -127,6 +139,20 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_split_kernel(SplitArgs a)
     l[r] = 0.f;
 #pragma unroll
     for (int e = 0; e < VEC; e++) acc[r][e] = 0.f;
+  }
+
+  // fused insert: slot chosen for this step's token (or -1), and this lane's slice of the new K/V rows
+  int ins_idx = -1;
+  int32_t p_now = 0;
+  Vec16<T> kn, vn;
+  kn.raw = make_uint4(0, 0, 0, 0);
+  vn.raw = kn.raw;
+  if (a.next_key != nullptr) {
+    p_now = *a.input_pos;
+    const unsigned long long key = a.next_key[(size_t)(p_now & 1) * a.H + h];
+    ins_idx = (key == ~0ull) ? -1 : (int)((key & 0xffffffffull) >> 1);
+    kn.load(reinterpret_cast<const T*>(a.k_new) + (size_t)h * D + lc * VEC);
+    vn.load(reinterpret_cast<const T*>(a.v_new) + (size_t)h * D + lc * VEC);
   }
 
   // q: [RT][D] of this query group, this lane's VEC-wide column slice (L2-resident after the first workgroups)
@@ -162,12 +188,42 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_split_kernel(SplitArgs a)
 #pragma unroll
     for (int u = 0; u < U; u++) vv[u].load(vh + (size_t)(row0 + u < row_end ? row0 + u : row_end - 1) * D);
 
+    // fused insert (cache.py:356-362, 460-490, 754-763): the row group that owns the chosen slot uses the new
+    // token's K/V instead of the stale cache row, writes them back, and one lane does the bookkeeping
+    bool isnew[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      isnew[u] = (row0 + u == ins_idx);
+      kk[u].raw.x = isnew[u] ? kn.raw.x : kk[u].raw.x;
+      kk[u].raw.y = isnew[u] ? kn.raw.y : kk[u].raw.y;
+      kk[u].raw.z = isnew[u] ? kn.raw.z : kk[u].raw.z;
+      kk[u].raw.w = isnew[u] ? kn.raw.w : kk[u].raw.w;
+      vv[u].raw.x = isnew[u] ? vn.raw.x : vv[u].raw.x;
+      vv[u].raw.y = isnew[u] ? vn.raw.y : vv[u].raw.y;
+      vv[u].raw.z = isnew[u] ? vn.raw.z : vv[u].raw.z;
+      vv[u].raw.w = isnew[u] ? vn.raw.w : vv[u].raw.w;
+      if (isnew[u] && blockIdx.z == 0) {
+        const size_t slot = (size_t)h * S + ins_idx;
+        *reinterpret_cast<uint4*>(const_cast<T*>(kh) + (size_t)ins_idx * D) = kn.raw;
+        *reinterpret_cast<uint4*>(const_cast<T*>(vh) + (size_t)ins_idx * D) = vn.raw;
+        if (lc == 0) {
+          const int ins = (a.pos[slot] == -1);
+          a.pos[slot] = p_now;
+          a.mask_w[slot] = 1;
+          a.num[slot] = 0.0;
+          a.denom[slot] = 0;
+          if (a.Hc == a.H) a.cache_cts[h] += ins;
+          else if (h == 0) a.cache_cts[0] += ins;
+        }
+      }
+    }
+
     float s[RT][U];
 #pragma unroll
     for (int u = 0; u < U; u++) {
       float kf[VEC];
       kk[u].unpack(kf);
-      const bool valid = (row0 + u < row_end) && (((mword >> (8 * u)) & 0xffu) != 0);
+      const bool valid = (row0 + u < row_end) && ((((mword >> (8 * u)) & 0xffu) != 0) || isnew[u]);
 #pragma unroll
       for (int r = 0; r < RT; r++) {
         float d = 0.f;
@@ -289,6 +345,11 @@ struct CombineArgs {
   int32_t* hh_denom;
   int64_t* hh_counter;
   int S, R, D, n_split, chunk;
+  // ---- fused decode step: score the NEXT step's eviction (cache.py:725-749 at position p + 1) in the same pass
+  unsigned long long* next_key;  // [2][H] or null
+  const int32_t* input_pos;
+  const int32_t* pos;  // [H, S]
+  int H, g, w;
 };
 
 constexpr int kMaxR = 32;
@@ -318,6 +379,12 @@ __global__ __launch_bounds__(kCombThreads) void decode_attn_combine_kernel(Combi
     num_old = a.hh_num[(size_t)h * S + s_ld];
     den_old = a.hh_denom[(size_t)h * S + s_ld];
   }
+  int32_t ps_mine = 0, p_next = 0;
+  if (a.next_key) {
+    ps_mine = a.pos[(size_t)h * S + s_ld];
+    p_next = *a.input_pos + 1;
+  }
+  unsigned long long my_key = ~0ull;
   // final (M, L) per query head: one wave per head, lanes stride over the splits (fixed order: deterministic)
   for (int r = wave; r < R; r += kCombThreads / 64) {
     const float2* ml = reinterpret_cast<const float2*>(a.part_ml) + (size_t)(h * R + r) * ns;
@@ -401,8 +468,30 @@ __global__ __launch_bounds__(kCombThreads) void decode_attn_combine_kernel(Combi
     const size_t i = (size_t)h * S + s;
     if (a.attn_out) ElemTraits<T>::store(reinterpret_cast<T*>(a.attn_out), i, av);
     if (a.hh_num) {  // fused cache.py:716-722 (W == 1, attention already padded to S)
-      a.hh_num[i] = num_old + (double)av;
-      a.hh_denom[i] = den_old + 1;
+      const double num_new = num_old + (double)av;
+      const int32_t den_new = den_old + 1;
+      a.hh_num[i] = num_new;
+      a.hh_denom[i] = den_new;
+      if (a.next_key) {  // next step's eviction score from the freshly updated history (cache.py:727-749)
+        float scn = __fdiv_rn((float)num_new, (float)(den_new < 1 ? 1 : den_new));
+        if (ps_mine < a.g || ps_mine >= p_next - a.w) scn = 1.0f;
+        if (ps_mine == -1) scn = 0.0f;
+        my_key = make_key(orderable_f32(scn), ((uint32_t)s << 1) | (uint32_t)(ps_mine == -1));
+      }
+    }
+  }
+  if (a.next_key) {
+    __shared__ unsigned long long sm_k[kCombThreads / 64];
+    const unsigned long long wk = wave_min_u64(my_key);
+    if (lane == 0) sm_k[wave] = wk;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned long long bk = sm_k[0];
+#pragma unroll
+      for (int w2 = 1; w2 < kCombThreads / 64; w2++) bk = sm_k[w2] < bk ? sm_k[w2] : bk;
+      // the minimum over all blocks of this head IS torch's arg-min (order-independent -> deterministic)
+      atomicMin(&a.next_key[(size_t)(p_next & 1) * a.H + h], bk);
+      if (c == 0) a.next_key[(size_t)((p_next + 1) & 1) * a.H + h] = ~0ull;  // this step's key has been consumed
     }
   }
   if (a.hh_num && a.hh_counter && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *a.hh_counter += 1;
@@ -481,10 +570,24 @@ size_t cc_decode_attn_workspace_bytes(int32_t HQ, int32_t H, int32_t S, int32_t 
          align256((size_t)HQ * p.n_split * D * sizeof(float));
 }
 
-int cc_decode_attn_gqa_phases(const void* q, const void* k, const void* v, const uint8_t* mask, int32_t HQ, int32_t H,
-                              int32_t S, int32_t D, int32_t dtype, float scale, void* y, void* attn_out,
-                              void* probs_out, double* hh_num, int32_t* hh_denom, int64_t* hh_counter,
-                              void* workspace, size_t workspace_bytes, cc_stream_t stream, int32_t phases) {
+}  // extern "C"
+
+namespace {
+// Everything the fused decode step adds to the two launches (null = plain attention).
+struct FusedStep {
+  const cc_kv_view* c;
+  const void* k_new;
+  const void* v_new;
+  const int32_t* input_pos;
+  unsigned long long* next_key;
+  int g, w;
+};
+}  // namespace
+
+static int attn_impl(const void* q, const void* k, const void* v, const uint8_t* mask, int32_t HQ, int32_t H,
+                     int32_t S, int32_t D, int32_t dtype, float scale, void* y, void* attn_out,
+                     void* probs_out, double* hh_num, int32_t* hh_denom, int64_t* hh_counter,
+                     void* workspace, size_t workspace_bytes, cc_stream_t stream, int32_t phases, const FusedStep* fs) {
   CC_ENTRY();
   if (!q || !k || !v || !y || HQ <= 0 || H <= 0 || HQ % H || S <= 0 || D <= 0 || !cc_dt_ok(dtype) || !workspace)
     return CC_ERR_BAD_ARG;
@@ -505,6 +608,11 @@ int cc_decode_attn_gqa_phases(const void* q, const void* k, const void* v, const
   sa.part_o = reinterpret_cast<float*>(ws);
   sa.S = S; sa.R = R; sa.n_split = p.n_split; sa.rows_per_split = p.rows_per_split; sa.scale = scale;
   sa.abl = (phases >> 8) & 0xff;
+  if (fs) {
+    sa.next_key = fs->next_key; sa.input_pos = fs->input_pos; sa.k_new = fs->k_new; sa.v_new = fs->v_new;
+    sa.pos = fs->c->pos; sa.mask_w = fs->c->mask; sa.cache_cts = fs->c->cache_cts; sa.num = hh_num; sa.denom = hh_denom;
+    sa.H = H; sa.Hc = fs->c->Hc;
+  }
   hipStream_t st = (hipStream_t)stream;
   int rc = CC_OK;
   if (phases & 1) {
@@ -521,6 +629,9 @@ int cc_decode_attn_gqa_phases(const void* q, const void* k, const void* v, const
   ca.y = y; ca.attn_out = attn_out; ca.probs_out = probs_out;
   ca.hh_num = hh_num; ca.hh_denom = hh_denom; ca.hh_counter = hh_counter;
   ca.S = S; ca.R = R; ca.D = D; ca.n_split = p.n_split; ca.chunk = p.chunk;
+  if (fs) {
+    ca.next_key = fs->next_key; ca.input_pos = fs->input_pos; ca.pos = fs->c->pos; ca.H = H; ca.g = fs->g; ca.w = fs->w;
+  }
   dim3 grid(p.n_chunks, H), block(kCombThreads);
   const size_t lds = (size_t)R * p.n_split * sizeof(float);  // <= 32 * 512 * 4 = 64 KiB
   switch (dtype) {
@@ -530,6 +641,28 @@ int cc_decode_attn_gqa_phases(const void* q, const void* k, const void* v, const
   }
   CC_LAUNCH_CHECK();
   return CC_OK;
+}
+
+extern "C" {
+
+int cc_decode_attn_gqa_phases(const void* q, const void* k, const void* v, const uint8_t* mask, int32_t HQ, int32_t H,
+                              int32_t S, int32_t D, int32_t dtype, float scale, void* y, void* attn_out,
+                              void* probs_out, double* hh_num, int32_t* hh_denom, int64_t* hh_counter,
+                              void* workspace, size_t workspace_bytes, cc_stream_t stream, int32_t phases) {
+  return attn_impl(q, k, v, mask, HQ, H, S, D, dtype, scale, y, attn_out, probs_out, hh_num, hh_denom, hh_counter, workspace,
+                   workspace_bytes, stream, phases, nullptr);
+}
+
+int cc_decode_step_heavy_hitter(const cc_kv_view* c, const void* q, const void* k_new, const void* v_new,
+                                const int32_t* input_pos, double* num, int32_t* denom, int64_t* counter,
+                                uint64_t* next_key, int32_t global_tokens, int32_t recent_window, int32_t HQ, float scale,
+                                void* y, void* attn_out, void* workspace, size_t workspace_bytes, cc_stream_t stream) {
+  if (!cc_view_ok(c) || !q || !k_new || !v_new || !input_pos || !num || !denom || !next_key || !y || c->Hp != c->H ||
+      HQ <= 0 || HQ % c->H)
+    return CC_ERR_BAD_ARG;
+  FusedStep fs{c, k_new, v_new, input_pos, reinterpret_cast<unsigned long long*>(next_key), global_tokens, recent_window};
+  return attn_impl(q, c->k_cache, c->v_cache, c->mask, HQ, c->H, c->S, c->D, c->dtype, scale, y, attn_out, nullptr, num, denom,
+                   counter, workspace, workspace_bytes, stream, 3, &fs);
 }
 
 int cc_decode_attn_gqa(const void* q, const void* k, const void* v, const uint8_t* mask, int32_t HQ, int32_t H,

@@ -30,6 +30,7 @@ struct UpdArgs {
   void* key_norm;        // P_L2: [H,S] T
   double* num;           // P_HH
   int32_t* denom;        // P_HH
+  unsigned long long* key_out;  // P_HH pipeline seed: [2][H] arg-min keys indexed by (*input_pos & 1); no side effects
 };
 
 constexpr int kUpdThreads = 1024;
@@ -190,6 +191,13 @@ __global__ __launch_bounds__(kUpdThreads) void decode_update_kernel(UpdArgs a) {
   best = block_min_u64(best, sm_key);
   const int idx = (int)((best & 0xffffffffull) >> 1);
   const int ins = (int)(best & 1ull);  // ref: cache.py:356-360 num_insertions = (old pos == -1)
+  if (a.key_out != nullptr) {  // seed of the fused decode-step pipeline: publish the key, touch nothing else
+    if (threadIdx.x == 0) {
+      a.key_out[(size_t)(p & 1) * a.Hp + hp] = best;
+      a.key_out[(size_t)((p + 1) & 1) * a.Hp + hp] = ~0ull;
+    }
+    return;
+  }
   if (threadIdx.x == 0) a.idx_out[hp] = idx;
 
   if (POLICY == P_HH && threadIdx.x == 0) {  // ref: cache.py:754-763 (part of _eviction_idx itself)
@@ -374,6 +382,17 @@ int cc_decode_update_heavy_hitter(const cc_kv_view* c, const void* k_new, const 
   UpdArgs a{};
   a.k_new = k_new; a.v_new = v_new; a.input_pos = input_pos; a.idx_out = idx_out; a.g = g; a.w = w;
   a.num = num; a.denom = denom;
+  return launch_update<P_HH>(c, a, (hipStream_t)stream);
+}
+
+int cc_hh_next_key_init(const cc_kv_view* c, const int32_t* input_pos, const double* num, const int32_t* denom,
+                        int32_t g, int32_t w, uint64_t* next_key, cc_stream_t stream) {
+  CC_ENTRY();
+  if (!cc_view_ok(c) || !input_pos || !num || !denom || !next_key || c->Hp != c->H) return CC_ERR_BAD_ARG;
+  UpdArgs a{};
+  a.input_pos = input_pos; a.g = g; a.w = w;
+  a.num = const_cast<double*>(num); a.denom = const_cast<int32_t*>(denom);
+  a.key_out = reinterpret_cast<unsigned long long*>(next_key);
   return launch_update<P_HH>(c, a, (hipStream_t)stream);
 }
 

@@ -127,19 +127,29 @@ class GraphedDecoder:
 
     def capture(self):
         """Capture must start from a state where one extra (discarded) step is harmless: run it on a snapshot."""
-        snap = [{k: v.clone() for k, v in l.attention.kv_cache._buffers.items()} for l in self.model.layers]
+        caches = [l.attention.kv_cache for l in self.model.layers]
+        for c in caches:  # seed the fused decode-step pipelines BEFORE the snapshot so the restored state is runnable
+            if hasattr(c, "prepare_decode") and getattr(c, "history_window_size", 1) == 1 and not c._next_valid:
+                c.prepare_decode(self.pos)
+        snap = [{k: v.clone() for k, v in c._buffers.items()} for c in caches]
+        flags = [getattr(c, "_next_valid", None) for c in caches]
+        pos0 = self.pos.clone()
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
-            for _ in range(self.warmup):
+            for _ in range(self.warmup):  # positions advance like a real decode (the pipeline assumes +1 steps)
                 decode_one_token(self.model, self.tok, self.pos)
+                self.pos += 1
         torch.cuda.current_stream().wait_stream(s)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.out_tok, self.out_probs = decode_one_token(self.model, self.tok, self.pos)
-        for l, sn in zip(self.model.layers, snap):
+        self.pos.copy_(pos0)
+        for c, sn, fl in zip(caches, snap, flags):
             for k, v in sn.items():
-                l.attention.kv_cache._buffers[k].copy_(v)
+                c._buffers[k].copy_(v)
+            if fl is not None:
+                c._next_valid = fl
 
     def __call__(self, model, x, input_pos, next_token=None, **_):
         if self.graph is None:

@@ -130,6 +130,7 @@ class Attention(nn.Module):
         self.n_head, self.head_dim = config.n_head, config.head_dim
         self.n_local_heads, self.dim = config.n_local_heads, config.dim
         self.fuse_state_update = True  # fold cache.py:690-723 into the decode attention combine pass
+        self.fuse_decode_step = True   # heavy hitter: whole update_kv + attention + update_state in two launches
 
     def compress_prompt(self, input_pos, k_val, v_val, attn):
         if self.kv_cache.max_cache_length < input_pos.shape[0]:
@@ -143,7 +144,12 @@ class Attention(nn.Module):
         q, k, v = glue.qkv_rope(self.wqkv(x), freqs_cis, self.n_head, self.n_local_heads, self.head_dim)
         cache = self.kv_cache
         ck = {"input_ids": input_ids}
-        if not is_prefill:
+        if (not is_prefill and self.fuse_decode_step and type(cache) is KVCacheHeavyHitter
+                and cache.history_window_size == 1 and attn_top_k == 1.0):
+            # two launches per layer: insert folded into the K/V streaming pass, history update + next eviction
+            # scoring folded into the combine pass (bit-identical to the three-call sequence below)
+            y = cache.decode_step(q, k, v, input_pos)
+        elif not is_prefill:
             kc, vc, kv_mask = cache.update_kv(input_pos, k, v, False, **ck)  # insert first, then attend
             fuse = (self.fuse_state_update and type(cache) is KVCacheHeavyHitter and cache.fused_history() is not None)
             y, attn = scaled_dot_product_attention(

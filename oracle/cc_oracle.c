@@ -936,3 +936,70 @@ int cc_decode_update_heavy_hitter_ring_cpu(const cc_kv_view* c, const void* k_ne
   if (k_new) insert_token(c, k_new, v_new, p, idx_out);
   return CC_OK;
 }
+
+/* ---------------------------------------------------------------- fused decode step (pipeline form) ----- */
+
+/* arg-min key of the heavy-hitter eviction at position p: (orderable(score) << 32) | slot << 1 | was_empty */
+static uint32_t orderable_f32_host(float f) {
+  uint32_t u;
+  if (f != f) return 0u;
+  if (f == 0.0f) f = 0.0f;
+  memcpy(&u, &f, 4);
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  return u == 0u ? 1u : u;
+}
+static uint64_t hh_key_for_head(const cc_kv_view* c, int h, int32_t p, const double* num, const int32_t* denom, int g, int w) {
+  uint64_t best = ~(uint64_t)0;
+  for (int s = 0; s < c->S; s++) {
+    const size_t i = (size_t)h * c->S + s;
+    const int32_t ps = c->pos[i];
+    int32_t dn = denom[i] < 1 ? 1 : denom[i];
+    float v = (float)num[i] / (float)dn;
+    if (ps < g || ps >= p - w) v = 1.0f;
+    if (ps == -1) v = 0.0f;
+    const uint64_t key = ((uint64_t)orderable_f32_host(v) << 32) | ((uint64_t)(uint32_t)s << 1) | (uint64_t)(ps == -1);
+    if (key < best) best = key;
+  }
+  return best;
+}
+
+int cc_hh_next_key_init_cpu(const cc_kv_view* c, const int32_t* input_pos, const double* num, const int32_t* denom, int32_t g,
+                            int32_t w, uint64_t* next_key, cc_stream_t stream) {
+  (void)stream;
+  if (!view_ok(c) || !input_pos || !num || !denom || !next_key || c->Hp != c->H) return CC_ERR_BAD_ARG;
+  const int32_t p = *input_pos;
+  for (int h = 0; h < c->H; h++) {
+    next_key[(size_t)(p & 1) * c->H + h] = hh_key_for_head(c, h, p, num, denom, g, w);
+    next_key[(size_t)((p + 1) & 1) * c->H + h] = ~(uint64_t)0;
+  }
+  return CC_OK;
+}
+
+/* One whole heavy-hitter decode step in pipeline form: consume the slot chosen for this position, insert, attend
+ * with the fused history update, and leave the NEXT position's arg-min key (ref: the same lines as
+ * cc_decode_update_heavy_hitter + cc_decode_attn_gqa; the only difference is WHEN the arg-min is evaluated). */
+int cc_decode_step_heavy_hitter_cpu(const cc_kv_view* c, const void* q, const void* k_new, const void* v_new,
+                                    const int32_t* input_pos, double* num, int32_t* denom, int64_t* counter,
+                                    uint64_t* next_key, int32_t g, int32_t w, int32_t HQ, float scale, void* y,
+                                    void* attn_out, void* workspace, size_t workspace_bytes, cc_stream_t stream) {
+  if (!view_ok(c) || !q || !k_new || !v_new || !input_pos || !num || !denom || !next_key || !y || c->Hp != c->H || c->H > 4096)
+    return CC_ERR_BAD_ARG;
+  const int32_t p = *input_pos;
+  int64_t idx[4096];
+  for (int h = 0; h < c->H; h++) {
+    const uint64_t key = next_key[(size_t)(p & 1) * c->H + h];
+    if (key == ~(uint64_t)0) return CC_ERR_BAD_ARG;
+    idx[h] = (int64_t)((key & 0xffffffffu) >> 1);
+    num[(size_t)h * c->S + idx[h]] = 0.0;
+    denom[(size_t)h * c->S + idx[h]] = 0;
+  }
+  insert_token(c, k_new, v_new, p, idx);
+  int rc = cc_decode_attn_gqa_cpu(q, c->k_cache, c->v_cache, c->mask, HQ, c->H, c->S, c->D, c->dtype, scale, y, attn_out, NULL,
+                                  num, denom, counter, workspace, workspace_bytes, stream);
+  if (rc != CC_OK) return rc;
+  for (int h = 0; h < c->H; h++) {
+    next_key[(size_t)((p + 1) & 1) * c->H + h] = hh_key_for_head(c, h, p + 1, num, denom, g, w);
+    next_key[(size_t)(p & 1) * c->H + h] = ~(uint64_t)0;
+  }
+  return CC_OK;
+}

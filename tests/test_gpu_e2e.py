@@ -47,6 +47,17 @@ def _log_evictions(model):
             log[_i].append(_kv._idx_buf().clone())
 
         kv._run_select = wrapped
+        if hasattr(kv, "decode_step"):  # fused two-launch step: the slot is the arg-min key left for this position
+            orig_step = kv.decode_step
+
+            def step(query, k_val, v_val, input_pos, scale=None, _orig=orig_step, _kv=kv, _i=i):
+                if not _kv._next_valid:
+                    _kv.prepare_decode(input_pos)
+                par = int(input_pos.item()) & 1
+                log[_i].append(((_kv.next_key[par] & 0xffffffff) >> 1).clone())
+                return _orig(query, k_val, v_val, input_pos, scale)
+
+            kv.decode_step = step
     return log
 
 

@@ -1,0 +1,94 @@
+"""The fused heavy-hitter decode step (cc_decode_step_heavy_hitter: insert folded into the K/V streaming pass,
+history update + next-position arg-min folded into the combine pass) must be bit-identical to the three-call
+sequence update_kv -> attention -> update_state, step after step, at the BASELINE shape — and to the oracle's
+pipeline twin on a small shape."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import to_np
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _mk(H, S, D, dtype, g=4, w=10):
+    import cold_compress_amd.cache as cache
+
+    with torch.device(DEV):
+        return cache.KVCacheHeavyHitter(1, H, D, dtype, max_cache_length=S, max_seq_length=4 * S, cache_bits=None, global_tokens=g,
+                                        history_window_size=1, recent_window=w, attn_thresholding=False)
+
+
+def _seed(kv, gen, T):
+    H, S, D = kv.n_heads, kv.max_cache_length, kv.head_dim
+    dt = kv.k_cache.dtype
+    kv.update_kv(torch.arange(T, device=DEV), torch.randn(1, H, T, D, generator=gen).to(dt).to(DEV),
+                 torch.randn(1, H, T, D, generator=gen).to(dt).to(DEV), True)
+    kv.attn_history_num[0, :, :T, 0] = torch.rand(H, T, generator=gen, dtype=torch.float64).to(DEV)
+    kv.attn_history_denom[0, :, :T] = torch.randint(1, 5, (H, T), generator=gen, dtype=torch.int32).to(DEV)
+    kv.attn_history_num[0, :, 50:60, 0] = 0.0  # engineered ties
+
+
+@pytest.mark.parametrize("dtype,H,HQ,S,D,T", [(torch.bfloat16, 8, 32, 4096, 128, 4090), (torch.float32, 2, 4, 333, 16, 300),
+                                              (torch.bfloat16, 1, 8, 3488, 128, 3488), (torch.float16, 4, 8, 1000, 64, 1000)])
+def test_fused_step_equals_three_calls(dtype, H, HQ, S, D, T):
+    from cold_compress_amd.attention_utils import scaled_dot_product_attention as sdpa
+
+    a, b = _mk(H, S, D, dtype), _mk(H, S, D, dtype)
+    for kv in (a, b):
+        _seed(kv, torch.Generator().manual_seed(17), T)
+    gen = torch.Generator().manual_seed(5)
+    for t in range(14):
+        p = torch.tensor([T + 7 + t], dtype=torch.int32, device=DEV)
+        k1 = torch.randn(1, H, 1, D, generator=gen).to(dtype).to(DEV)
+        v1 = torch.randn(1, H, 1, D, generator=gen).to(dtype).to(DEV)
+        q = torch.randn(1, HQ, 1, D, generator=gen).to(dtype).to(DEV)
+        ka, va, ma = a.update_kv(p, k1, v1, False)
+        ya, attn = sdpa(q, ka, va, attn_mask=ma, return_attn=True, group_mean=True)
+        a.update_state(p, k1, v1, False, attn)
+        yb = b.decode_step(q, k1, v1, p)
+        torch.cuda.synchronize()
+        assert torch.equal(ya, yb), f"step {t}: attention output"
+        for (na, ta), (nb, tb) in zip(a.named_buffers(), b.named_buffers()):
+            if na != "next_key":
+                assert torch.equal(ta, tb), f"step {t}: {na}"
+    assert b._next_valid and not a._next_valid
+
+
+def test_fused_step_vs_oracle_pipeline(oracle):
+    H, HQ, S, D, g, w = 4, 16, 512, 128, 4, 10
+    kv = _mk(H, S, D, torch.bfloat16, g, w)
+    _seed(kv, torch.Generator().manual_seed(3), S - 3)
+    st = dict(k=to_np(kv.k_cache.cpu()[0]), v=to_np(kv.v_cache.cpu()[0]), pos=kv.pos.cpu()[0].numpy().copy(),
+              mask=kv.mask.cpu()[0, :, 0].numpy().astype(np.uint8), cts=kv.cache_cts.cpu().numpy().copy(),
+              num=kv.attn_history_num.cpu()[0, :, :, 0].numpy().copy(), denom=kv.attn_history_denom.cpu()[0].numpy().copy(),
+              ctr=np.zeros(1, np.int64), key=np.zeros((2, H), np.uint64))
+    gen = torch.Generator().manual_seed(8)
+    o = oracle
+    p0 = S + 20
+    view = o.view(st["k"], st["v"], st["pos"], st["mask"], st["cts"], 1)
+    o.call("cc_hh_next_key_init", C.byref(view), o.ptr(np.array([p0], np.int32)), o.ptr(st["num"]), o.ptr(st["denom"]), g, w,
+           o.ptr(st["key"]), None)
+    for t in range(6):
+        p = torch.tensor([p0 + t], dtype=torch.int32)
+        k1 = torch.randn(1, H, 1, D, generator=gen).to(torch.bfloat16)
+        v1 = torch.randn(1, H, 1, D, generator=gen).to(torch.bfloat16)
+        q = torch.randn(1, HQ, 1, D, generator=gen).to(torch.bfloat16)
+        y = kv.decode_step(q.to(DEV), k1.to(DEV), v1.to(DEV), p.to(DEV))
+        torch.cuda.synchronize()
+        view = o.view(st["k"], st["v"], st["pos"], st["mask"], st["cts"], 1)
+        yo = np.zeros((HQ, D), np.uint16)
+        o.call("cc_decode_step_heavy_hitter", C.byref(view), o.ptr(to_np(q.reshape(HQ, D))), o.ptr(to_np(k1.reshape(H, D))),
+               o.ptr(to_np(v1.reshape(H, D))), o.ptr(p.numpy().copy()), o.ptr(st["num"]), o.ptr(st["denom"]), o.ptr(st["ctr"]),
+               o.ptr(st["key"]), g, w, HQ, 1.0 / math.sqrt(D), o.ptr(yo), None, None, 0, None)
+        # slots chosen so far are identical (pos is written by the insert); outputs within bf16 tolerance
+        assert np.array_equal(kv.pos.cpu()[0].numpy(), st["pos"]), f"step {t}"
+        assert np.array_equal(kv.cache_cts.cpu().numpy(), st["cts"])
+        yr = torch.from_numpy(yo.view(np.int16).copy()).view(torch.bfloat16).float()
+        assert (y.cpu().float()[0, :, 0] - yr).abs().max() < 1e-2
+    assert np.array_equal(kv.attn_history_denom.cpu()[0].numpy(), st["denom"])
+    assert np.array_equal(to_np(kv.k_cache.cpu()[0]), st["k"])
