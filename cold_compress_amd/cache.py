@@ -309,8 +309,9 @@ class KVCacheHeavyHitter(KVCacheHeadSpecific):
         self.register_buffer("attn_counter", torch.zeros((1,), dtype=torch.int64))
         # set by the attention op when it already applied this step's history update in its combine pass
         self._state_fused = False
-        # fused decode-step pipeline (decode_step): arg-min keys for the NEXT position, double-buffered by parity
-        self.register_buffer("next_key", torch.full((2, n_heads), -1, dtype=torch.int64), persistent=False)
+        # fused decode-step pipeline (decode_step): partial arg-min keys for the NEXT position, [H, NK]
+        nk = int(_abi.lib()["cc_hh_next_key_slots"](S))
+        self.register_buffer("next_key", torch.full((n_heads, nk), -1, dtype=torch.int64), persistent=False)
         self._next_valid = False
 
     def reset(self):

@@ -38,6 +38,55 @@ __device__ __forceinline__ float group_sum(float v) {
   if (W >= 64) v += __shfl_xor(v, 32, CC_WAVE);
   return v;
 }
+// Whole-wave reductions with a wave-UNIFORM (scalar) result: four DPP steps fold each row of 16 lanes, four
+// v_readlane pick up the row results.  No LDS crossbar (ds_bpermute) round trips: ~12 VALU ops instead of 6
+// dependent ~100-cycle shuffles.  Fixed combination order -> deterministic.
+__device__ __forceinline__ float wave_max_uniform(float v) {
+  v = fmaxf(v, dpp_mov<0xB1>(v));
+  v = fmaxf(v, dpp_mov<0x4E>(v));
+  v = fmaxf(v, dpp_mov<0x141>(v));
+  v = fmaxf(v, dpp_mov<0x140>(v));
+  const int u = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(u, 0));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(u, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(u, 32));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(u, 48));
+  return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+__device__ __forceinline__ float wave_sum_uniform(float v) {
+  v += dpp_mov<0xB1>(v);
+  v += dpp_mov<0x4E>(v);
+  v += dpp_mov<0x141>(v);
+  v += dpp_mov<0x140>(v);
+  const int u = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(u, 0));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(u, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(u, 32));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(u, 48));
+  return (r0 + r1) + (r2 + r3);
+}
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp_min_u64(unsigned long long v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(v & 0xffffffffull), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), CTRL, 0xf, 0xf, true);
+  const unsigned long long o = ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+  return o < v ? o : v;
+}
+__device__ __forceinline__ unsigned long long wave_min_u64_uniform(unsigned long long v) {
+  v = dpp_min_u64<0xB1>(v);
+  v = dpp_min_u64<0x4E>(v);
+  v = dpp_min_u64<0x141>(v);
+  v = dpp_min_u64<0x140>(v);
+  const int lo = (int)(unsigned)(v & 0xffffffffull), hi = (int)(unsigned)(v >> 32);
+  unsigned long long best = ~0ull;
+#pragma unroll
+  for (int row = 0; row < 4; row++) {
+    const unsigned long long x = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(hi, row * 16) << 32) |
+                                 (unsigned)__builtin_amdgcn_readlane(lo, row * 16);
+    best = x < best ? x : best;
+  }
+  return best;
+}
 // value held by lane ^ OFF for OFF in {16, 32}: one v_permlane{16,32}_swap (VALU; no LDS crossbar traffic).
 // swap(x, x) returns {rows a|a, rows b|b}: whichever differs from ours is the partner's value — but we only ever
 // need sum or max with the partner, both symmetric, so combine the two returned halves directly.
@@ -96,8 +145,10 @@ struct SplitArgs {
   float scale;
   int abl;  // measurement-only ablation bits (phases >> 8): 1 = no score store, 2 = no epilogue, 4 = no mask
   // ---- fused decode step (next_key != null): this step's insert is folded into the prologue.  The slot comes
-  //      from the arg-min key the PREVIOUS step's combine pass (or cc_hh_next_key_init) left in next_key[p & 1].
-  const unsigned long long* next_key;  // [2][H]
+  //      from the partial arg-min keys the PREVIOUS step's combine pass (or cc_hh_next_key_init) left in
+  //      next_key[h][0..nk): their minimum is torch's arg-min.
+  const unsigned long long* next_key;  // [H][nk]
+  int nk;
   const int32_t* input_pos;
   const void* k_new;  // [H, D]
   const void* v_new;
@@ -141,37 +192,29 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_split_kernel(SplitArgs a)
     for (int e = 0; e < VEC; e++) acc[r][e] = 0.f;
   }
 
-  // fused insert: slot chosen for this step's token (or -1), and this lane's slice of the new K/V rows
-  int ins_idx = -1;
-  int32_t p_now = 0;
-  Vec16<T> kn, vn;
-  kn.raw = make_uint4(0, 0, 0, 0);
-  vn.raw = kn.raw;
-  if (a.next_key != nullptr) {
-    p_now = *a.input_pos;
-    const unsigned long long key = a.next_key[(size_t)(p_now & 1) * a.H + h];
-    ins_idx = (key == ~0ull) ? -1 : (int)((key & 0xffffffffull) >> 1);
-    kn.load(reinterpret_cast<const T*>(a.k_new) + (size_t)h * D + lc * VEC);
-    vn.load(reinterpret_cast<const T*>(a.v_new) + (size_t)h * D + lc * VEC);
-  }
-
+  // ---- Issue EVERY load of the first tile before anything waits: the dependent chain of this kernel is
+  //      kernel args -> {partial keys, q, mask, K, V all in flight} -> math, not args -> q -> K/V.  (An earlier
+  //      version converted q to fp32 first, which put a full L2 round trip in front of the K/V loads: -1 us.)
+  //      vmcnt retires in issue order, so the loads are issued in the order their results are consumed.
+  // fused insert: every wave reduces the head's partial arg-min keys itself (no LDS, no barrier)
+  int ins_idx = -1, ins_was_empty = 0;
+  bool key_pending = a.next_key != nullptr && !(a.abl & 128);
+  unsigned long long key_part = ~0ull;
+  if (key_pending && lane < a.nk) key_part = a.next_key[(size_t)h * a.nk + lane];
   // q: [RT][D] of this query group, this lane's VEC-wide column slice (L2-resident after the first workgroups)
-  float qf[RT][VEC];
+  Vec16<T> qraw[RT];
 #pragma unroll
-  for (int r = 0; r < RT; r++) {
-    Vec16<T> t;
-    t.load(reinterpret_cast<const T*>(a.q) + (size_t)(q0 + r) * D + lc * VEC);
-    t.unpack(qf[r]);
-  }
+  for (int r = 0; r < RT; r++) qraw[r].load(reinterpret_cast<const T*>(a.q) + (size_t)(q0 + r) * D + lc * VEC);
 
   // Row group lr of wave `wave` owns the U CONSECUTIVE rows base + lr*U + [0, U): its mask bytes are one
   // aligned 32-bit word, its scores one contiguous run, and its softmax state (m, l, acc) is private to the
   // 16-lane group — no cross-group shuffles anywhere in the loop.
-  for (int base = row_begin + wave * (RPW * U); base < row_end; base += NW * RPW * U) {
-    // ---- issue every load of this iteration before the first use: mask word, K rows, V rows
+  static_assert(U <= 4, "mask bytes of a row group are packed into one 32-bit word");
+  uint32_t mword = 0x01010101u;
+  Vec16<T> kk[U], vv[U];
+  auto issue_tile = [&](int base) {
     const int row0 = base + lr * U;
-    static_assert(U <= 4, "mask bytes of a row group are packed into one 32-bit word");
-    uint32_t mword = 0x01010101u;
+    mword = 0x01010101u;
     if (has_mask) {
       if (U == 4 && row0 + 3 < S && ((reinterpret_cast<uintptr_t>(mh) + (size_t)row0) & 3) == 0) {
         mword = *reinterpret_cast<const uint32_t*>(mh + row0);  // the common case: one aligned word
@@ -182,38 +225,58 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_split_kernel(SplitArgs a)
           if (row0 + u < S) mword |= (uint32_t)mh[row0 + u] << (8 * u);
       }
     }
-    Vec16<T> kk[U], vv[U];
 #pragma unroll
     for (int u = 0; u < U; u++) kk[u].load(kh + (size_t)(row0 + u < row_end ? row0 + u : row_end - 1) * D);
 #pragma unroll
     for (int u = 0; u < U; u++) vv[u].load(vh + (size_t)(row0 + u < row_end ? row0 + u : row_end - 1) * D);
+  };
+  int base = row_begin + wave * (RPW * U);
+  bool more = base < row_end;
+  if (more) issue_tile(base);
 
-    // fused insert (cache.py:356-362, 460-490, 754-763): the row group that owns the chosen slot uses the new
-    // token's K/V instead of the stale cache row, writes them back, and one lane does the bookkeeping
-    bool isnew[U];
+  float qf[RT][VEC];
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-      isnew[u] = (row0 + u == ins_idx);
-      kk[u].raw.x = isnew[u] ? kn.raw.x : kk[u].raw.x;
-      kk[u].raw.y = isnew[u] ? kn.raw.y : kk[u].raw.y;
-      kk[u].raw.z = isnew[u] ? kn.raw.z : kk[u].raw.z;
-      kk[u].raw.w = isnew[u] ? kn.raw.w : kk[u].raw.w;
-      vv[u].raw.x = isnew[u] ? vn.raw.x : vv[u].raw.x;
-      vv[u].raw.y = isnew[u] ? vn.raw.y : vv[u].raw.y;
-      vv[u].raw.z = isnew[u] ? vn.raw.z : vv[u].raw.z;
-      vv[u].raw.w = isnew[u] ? vn.raw.w : vv[u].raw.w;
-      if (isnew[u] && blockIdx.z == 0) {
+  for (int r = 0; r < RT; r++) qraw[r].unpack(qf[r]);
+
+  while (more) {
+    const int row0 = base + lr * U;
+    // fused insert (cache.py:356-362, 460-490, 754-763): the row group that owns the chosen slot uses the new
+    // token's K/V instead of the stale cache row, writes them back, and one lane does the bookkeeping.  The new
+    // rows (and the position) are fetched inside this rare branch — one row group per kv head takes it — so
+    // they cost nothing on the streaming path; their latency hides behind the K/V loads already in flight.
+    if (key_pending) {  // wave-uniform; first iteration only
+      for (int i = lane + 64; i < a.nk; i += 64) {  // caches beyond 64 chunks (S > 8192)
+        const unsigned long long x = a.next_key[(size_t)h * a.nk + i];
+        key_part = x < key_part ? x : key_part;
+      }
+      const unsigned long long key = wave_min_u64_uniform(key_part);
+      ins_idx = (key == ~0ull) ? -1 : (int)((key & 0xffffffffull) >> 1);
+      if (a.abl & 64) ins_idx = -1;
+      ins_was_empty = (int)(key & 1ull);  // the winner's "slot was empty" bit travels with the key (cache.py:356-360)
+      key_pending = false;
+    }
+    if ((unsigned)(ins_idx - row0) < (unsigned)U) {
+      Vec16<T> kn, vn;
+      kn.load(reinterpret_cast<const T*>(a.k_new) + (size_t)h * D + lc * VEC);
+      vn.load(reinterpret_cast<const T*>(a.v_new) + (size_t)h * D + lc * VEC);
+      const int32_t p_now = *a.input_pos;
+#pragma unroll
+      for (int u = 0; u < U; u++)
+        if (row0 + u == ins_idx) {
+          kk[u].raw = kn.raw;
+          vv[u].raw = vn.raw;
+          mword |= 1u << (8 * u);
+        }
+      if (blockIdx.z == 0) {
         const size_t slot = (size_t)h * S + ins_idx;
         *reinterpret_cast<uint4*>(const_cast<T*>(kh) + (size_t)ins_idx * D) = kn.raw;
         *reinterpret_cast<uint4*>(const_cast<T*>(vh) + (size_t)ins_idx * D) = vn.raw;
-        if (lc == 0) {
-          const int ins = (a.pos[slot] == -1);
+        if (lc == 0) {  // stores only: nothing here waits on memory
           a.pos[slot] = p_now;
           a.mask_w[slot] = 1;
           a.num[slot] = 0.0;
           a.denom[slot] = 0;
-          if (a.Hc == a.H) a.cache_cts[h] += ins;
-          else if (h == 0) a.cache_cts[0] += ins;
+          if (ins_was_empty && (a.Hc == a.H || h == 0)) atomicAdd(&a.cache_cts[a.Hc == a.H ? h : 0], 1);
         }
       }
     }
@@ -223,7 +286,7 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_split_kernel(SplitArgs a)
     for (int u = 0; u < U; u++) {
       float kf[VEC];
       kk[u].unpack(kf);
-      const bool valid = (row0 + u < row_end) && ((((mword >> (8 * u)) & 0xffu) != 0) || isnew[u]);
+      const bool valid = (row0 + u < row_end) && (((mword >> (8 * u)) & 0xffu) != 0);
 #pragma unroll
       for (int r = 0; r < RT; r++) {
         float d = 0.f;
@@ -277,6 +340,9 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_split_kernel(SplitArgs a)
         for (int e = 0; e < VEC; e++) acc[r][e] = fmaf(p, vf[e], acc[r][e]);
       }
     }
+    base += NW * RPW * U;
+    more = base < row_end;
+    if (more) issue_tile(base);
   }
 
   if (a.abl & 2) {  // measurement only: keep the accumulators live, skip the merge
@@ -346,10 +412,11 @@ struct CombineArgs {
   int64_t* hh_counter;
   int S, R, D, n_split, chunk;
   // ---- fused decode step: score the NEXT step's eviction (cache.py:725-749 at position p + 1) in the same pass
-  unsigned long long* next_key;  // [2][H] or null
+  unsigned long long* next_key;  // [H][gridDim.x] or null: block c publishes the minimum over its slots
   const int32_t* input_pos;
   const int32_t* pos;  // [H, S]
   int H, g, w;
+  int abl;  // measurement-only ablation bits (phases >> 8): 8 = no next-key epilogue, 16 = no y merge, 32 = no per-slot pass
 };
 
 constexpr int kMaxR = 32;
@@ -385,22 +452,63 @@ __global__ __launch_bounds__(kCombThreads) void decode_attn_combine_kernel(Combi
     p_next = *a.input_pos + 1;
   }
   unsigned long long my_key = ~0ull;
-  // final (M, L) per query head: one wave per head, lanes stride over the splits (fixed order: deterministic)
-  for (int r = wave; r < R; r += kCombThreads / 64) {
+  // y: the R*D outputs of this kv head are spread over the chunk blocks; inside a block the (output, split)
+  // products are spread over ALL threads (G split-groups per output).  The first 8 partial-O values of every
+  // thread are fetched NOW, so that their latency overlaps the (M, L) reduction instead of following it.
+  const int y_total = R * D;
+  const int y_per = (y_total + nchunks - 1) / nchunks;
+  const int y_lo = c * y_per, y_hi = min(y_total, y_lo + y_per);
+  float pv[8];
+  {
+    const int nout = min(y_hi - y_lo, kCombThreads);
+    if (nout > 0) {
+      const int G = max(1, min(kCombThreads / nout, ns));
+      const int oi = threadIdx.x % nout, g = threadIdx.x / nout;
+      const int t = y_lo + oi, r = t / D, d = t - r * D;
+      const float* po = a.part_o + (size_t)(h * R + r) * ns * D + d;
+#pragma unroll
+      for (int u = 0; u < 8; u++) pv[u] = (g < G && g + u * G < ns) ? po[(size_t)(g + u * G) * D] : 0.f;
+    }
+  }
+  // final (M, L) per query head: one wave per head, lanes stride over the splits (fixed order: deterministic).
+  // The first 64 splits of up to kMLPre heads per wave are fetched before any reduction starts.
+  constexpr int kWaves = kCombThreads / 64, kMLPre = 4;
+  float2 mlv[kMLPre];
+#pragma unroll
+  for (int j = 0; j < kMLPre; j++) {
+    const int r = wave + j * kWaves;
+    mlv[j] = (r < R && lane < ns) ? reinterpret_cast<const float2*>(a.part_ml)[(size_t)(h * R + r) * ns + lane]
+                                  : make_float2(-INFINITY, 0.f);
+  }
+#pragma unroll
+  for (int j = 0; j < (kMaxR + kWaves - 1) / kWaves; j++) {
+    const int r = wave + j * kWaves;
+    if (r >= R) break;
     const float2* ml = reinterpret_cast<const float2*>(a.part_ml) + (size_t)(h * R + r) * ns;
-    float mi = -INFINITY;
-    for (int i = lane; i < ns; i += 64) mi = fmaxf(mi, ml[i].x);
-    const float M = wave_max_f32(mi);
+    float2 first = make_float2(-INFINITY, 0.f);
+    if (j < kMLPre) {
+#pragma unroll
+      for (int t = 0; t < kMLPre; t++) first = (t == j) ? mlv[t] : first;
+    } else if (lane < ns) {
+      first = ml[lane];
+    }
+    float mi = first.x;
+    for (int i = lane + 64; i < ns; i += 64) mi = fmaxf(mi, ml[i].x);
+    const float M = wave_max_uniform(mi);
     const float Mu = (M == -INFINITY) ? 0.f : M;
     float L = 0.f;
-    for (int i = lane; i < ns; i += 64) {
+    if (lane < ns) {
+      const float w = expf(first.x - Mu);
+      sm_wdyn[r * ns + lane] = w;
+      L = first.y * w;
+    }
+    for (int i = lane + 64; i < ns; i += 64) {
       const float2 v = ml[i];
       const float w = expf(v.x - Mu);
       sm_wdyn[r * ns + i] = w;
       L = fmaf(v.y, w, L);
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) L += __shfl_xor(L, off, CC_WAVE);
+    L = wave_sum_uniform(L);
     if (lane == 0) {
       sm_M[r] = Mu;
       sm_L[r] = L;
@@ -408,45 +516,53 @@ __global__ __launch_bounds__(kCombThreads) void decode_attn_combine_kernel(Combi
   }
   __syncthreads();
 
-  // y: the R*D outputs of this kv head are spread over the chunk blocks; inside a block the (output, split)
-  // products are spread over ALL threads (G split-groups per output) so every partial-O load is in flight at
-  // once, then reduced through LDS in a fixed order (deterministic).
-  {
-    __shared__ float sm_y[kCombThreads];
-    const int total = R * D;
-    const int per = (total + nchunks - 1) / nchunks;
-    const int lo = c * per, hi = min(total, lo + per);
-    for (int o0 = lo; o0 < hi; o0 += kCombThreads) {
-      const int nout = min(hi - o0, kCombThreads);
-      const int G = max(1, min(kCombThreads / nout, ns));
-      const int oi = threadIdx.x % nout, g = threadIdx.x / nout;
-      const int t = o0 + oi, r = t / D, d = t - r * D, j = h * R + r;
-      float part = 0.f;
-      if (g < G) {
-        const float* po = a.part_o + (size_t)j * ns * D + d;
-        int i = g;
-        for (; i + 7 * G < ns; i += 8 * G) {
-          float v[8];
+  // y (continued): weights are in LDS now.  The partial products of the first output group go to LDS, then the
+  // per-slot pass and the next-key reduction run, and ONE barrier later the fixed-order final sums are taken
+  // (deterministic) — the LDS round trip overlaps the per-slot work instead of adding three barriers.
+  __shared__ float sm_y[kCombThreads];
+  __shared__ unsigned long long sm_k[kWaves];
+  auto y_partial = [&](int o0, bool prefetched, int& nout, int& G, int& oi, int& g, int& r, int& d) -> float {
+    nout = min(y_hi - o0, kCombThreads);
+    G = max(1, min(kCombThreads / nout, ns));
+    oi = threadIdx.x % nout;
+    g = threadIdx.x / nout;
+    const int t = o0 + oi;
+    r = t / D;
+    d = t - r * D;
+    float part = 0.f;
+    if (g < G) {
+      const float* po = a.part_o + (size_t)(h * R + r) * ns * D + d;
+      int i = g;
+      if (prefetched) {
 #pragma unroll
-          for (int u = 0; u < 8; u++) v[u] = po[(size_t)(i + u * G) * D];
+        for (int u = 0; u < 8; u++)
+          if (i + u * G < ns) part = fmaf(pv[u], sm_wdyn[r * ns + i + u * G], part);
+        i += 8 * G;
+      }
+      for (; i + 7 * G < ns; i += 8 * G) {
+        float v[8];
 #pragma unroll
-          for (int u = 0; u < 8; u++) part = fmaf(v[u], sm_wdyn[r * ns + i + u * G], part);
-        }
-        for (; i < ns; i += G) part = fmaf(po[(size_t)i * D], sm_wdyn[r * ns + i], part);
+        for (int u = 0; u < 8; u++) v[u] = po[(size_t)(i + u * G) * D];
+#pragma unroll
+        for (int u = 0; u < 8; u++) part = fmaf(v[u], sm_wdyn[r * ns + i + u * G], part);
       }
-      __syncthreads();
-      sm_y[threadIdx.x] = part;
-      __syncthreads();
-      if (g == 0) {
-        float O = 0.f;
-        for (int gg = 0; gg < G; gg++) O += sm_y[gg * nout + oi];
-        ElemTraits<T>::store(reinterpret_cast<T*>(a.y), (size_t)j * D + d, O / sm_L[r]);
-      }
+      for (; i < ns; i += G) part = fmaf(po[(size_t)i * D], sm_wdyn[r * ns + i], part);
     }
-  }
+    return part;
+  };
+  auto y_final = [&](int nout, int G, int oi, int g, int r, int d) {
+    if (g == 0) {
+      float O = 0.f;
+      for (int gg = 0; gg < G; gg++) O += sm_y[gg * nout + oi];
+      ElemTraits<T>::store(reinterpret_cast<T*>(a.y), (size_t)(h * R + r) * D + d, O / sm_L[r]);
+    }
+  };
+  const bool do_y = !(a.abl & 16) && y_lo < y_hi;
+  int y_nout = 1, y_G = 1, y_oi = 0, y_g = 1, y_r = 0, y_d = 0;
+  if (do_y) sm_y[threadIdx.x] = y_partial(y_lo, true, y_nout, y_G, y_oi, y_g, y_r, y_d);
 
   // probabilities for this thread's slot
-  if (have) {
+  if (have && !(a.abl & 32)) {
     const int s = s_mine;
     float sum = 0.f;
     for (int r = 0; r < R; r++) {
@@ -480,20 +596,27 @@ __global__ __launch_bounds__(kCombThreads) void decode_attn_combine_kernel(Combi
       }
     }
   }
-  if (a.next_key) {
-    __shared__ unsigned long long sm_k[kCombThreads / 64];
-    const unsigned long long wk = wave_min_u64(my_key);
+  if (a.next_key && !(a.abl & 8)) {
+    const unsigned long long wk = wave_min_u64_uniform(my_key);
     if (lane == 0) sm_k[wave] = wk;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      unsigned long long bk = sm_k[0];
-#pragma unroll
-      for (int w2 = 1; w2 < kCombThreads / 64; w2++) bk = sm_k[w2] < bk ? sm_k[w2] : bk;
-      // the minimum over all blocks of this head IS torch's arg-min (order-independent -> deterministic)
-      atomicMin(&a.next_key[(size_t)(p_next & 1) * a.H + h], bk);
-      if (c == 0) a.next_key[(size_t)((p_next + 1) & 1) * a.H + h] = ~0ull;  // this step's key has been consumed
-    }
   }
+  __syncthreads();
+  if (do_y) y_final(y_nout, y_G, y_oi, y_g, y_r, y_d);
+  if (a.next_key && !(a.abl & 8) && threadIdx.x == 0) {
+    unsigned long long bk = sm_k[0];
+#pragma unroll
+    for (int w2 = 1; w2 < kWaves; w2++) bk = sm_k[w2] < bk ? sm_k[w2] : bk;
+    // the minimum over all blocks of this head IS torch's arg-min; the next step's streaming pass takes it
+    // (plain store: same-address atomics from 8 XCDs measured +4.5 us on this 5 us kernel)
+    a.next_key[(size_t)h * nchunks + c] = bk;
+  }
+  if (do_y)  // further output groups (only when R*D / n_chunks > 128, i.e. very short caches)
+    for (int o0 = y_lo + kCombThreads; o0 < y_hi; o0 += kCombThreads) {
+      __syncthreads();
+      sm_y[threadIdx.x] = y_partial(o0, false, y_nout, y_G, y_oi, y_g, y_r, y_d);
+      __syncthreads();
+      y_final(y_nout, y_G, y_oi, y_g, y_r, y_d);
+    }
   if (a.hh_num && a.hh_counter && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *a.hh_counter += 1;
 }
 
@@ -528,7 +651,7 @@ static Plan make_plan(int HQ, int H, int S, int D, int dtype) {
   ns = (S + rps - 1) / rps;
   p.n_split = ns;
   p.rows_per_split = rps;
-  p.chunk = 128;
+  p.chunk = kNextKeyChunk;  // cc_hh_next_key_slots(S) == n_chunks: one partial arg-min key per combine block
   p.n_chunks = (S + p.chunk - 1) / p.chunk;
   return p;
 }
@@ -609,7 +732,7 @@ static int attn_impl(const void* q, const void* k, const void* v, const uint8_t*
   sa.S = S; sa.R = R; sa.n_split = p.n_split; sa.rows_per_split = p.rows_per_split; sa.scale = scale;
   sa.abl = (phases >> 8) & 0xff;
   if (fs) {
-    sa.next_key = fs->next_key; sa.input_pos = fs->input_pos; sa.k_new = fs->k_new; sa.v_new = fs->v_new;
+    sa.next_key = fs->next_key; sa.nk = p.n_chunks; sa.input_pos = fs->input_pos; sa.k_new = fs->k_new; sa.v_new = fs->v_new;
     sa.pos = fs->c->pos; sa.mask_w = fs->c->mask; sa.cache_cts = fs->c->cache_cts; sa.num = hh_num; sa.denom = hh_denom;
     sa.H = H; sa.Hc = fs->c->Hc;
   }
@@ -632,6 +755,7 @@ static int attn_impl(const void* q, const void* k, const void* v, const uint8_t*
   if (fs) {
     ca.next_key = fs->next_key; ca.input_pos = fs->input_pos; ca.pos = fs->c->pos; ca.H = H; ca.g = fs->g; ca.w = fs->w;
   }
+  ca.abl = (phases >> 8) & 0xff;
   dim3 grid(p.n_chunks, H), block(kCombThreads);
   const size_t lds = (size_t)R * p.n_split * sizeof(float);  // <= 32 * 512 * 4 = 64 KiB
   switch (dtype) {
@@ -657,12 +781,21 @@ int cc_decode_step_heavy_hitter(const cc_kv_view* c, const void* q, const void* 
                                 const int32_t* input_pos, double* num, int32_t* denom, int64_t* counter,
                                 uint64_t* next_key, int32_t global_tokens, int32_t recent_window, int32_t HQ, float scale,
                                 void* y, void* attn_out, void* workspace, size_t workspace_bytes, cc_stream_t stream) {
+  return cc_decode_step_heavy_hitter_phases(c, q, k_new, v_new, input_pos, num, denom, counter, next_key, global_tokens,
+                                            recent_window, HQ, scale, y, attn_out, workspace, workspace_bytes, stream, 3);
+}
+
+int cc_decode_step_heavy_hitter_phases(const cc_kv_view* c, const void* q, const void* k_new, const void* v_new,
+                                       const int32_t* input_pos, double* num, int32_t* denom, int64_t* counter,
+                                       uint64_t* next_key, int32_t global_tokens, int32_t recent_window, int32_t HQ,
+                                       float scale, void* y, void* attn_out, void* workspace, size_t workspace_bytes,
+                                       cc_stream_t stream, int32_t phases) {
   if (!cc_view_ok(c) || !q || !k_new || !v_new || !input_pos || !num || !denom || !next_key || !y || c->Hp != c->H ||
       HQ <= 0 || HQ % c->H)
     return CC_ERR_BAD_ARG;
   FusedStep fs{c, k_new, v_new, input_pos, reinterpret_cast<unsigned long long*>(next_key), global_tokens, recent_window};
   return attn_impl(q, c->k_cache, c->v_cache, c->mask, HQ, c->H, c->S, c->D, c->dtype, scale, y, attn_out, nullptr, num, denom,
-                   counter, workspace, workspace_bytes, stream, 3, &fs);
+                   counter, workspace, workspace_bytes, stream, phases, &fs);
 }
 
 int cc_decode_attn_gqa(const void* q, const void* k, const void* v, const uint8_t* mask, int32_t HQ, int32_t H,

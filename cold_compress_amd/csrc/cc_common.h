@@ -112,6 +112,12 @@ __device__ __forceinline__ unsigned long long make_key(uint32_t ord, uint32_t sl
   return ((unsigned long long)ord << 32) | slot;
 }
 
+// Fused heavy-hitter decode step: the arg-min key of the next eviction is published as one partial minimum
+// per 128-slot chunk of the cache (no atomics: same-address atomics from 8 XCDs serialise in the fabric and
+// cost more than the whole pass); consumers take the minimum over a head's cc_next_key_slots(S) entries.
+constexpr int kNextKeyChunk = 128;
+static inline int cc_next_key_slots(int S) { return (S + kNextKeyChunk - 1) / kNextKeyChunk; }
+
 __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {

@@ -30,7 +30,8 @@ struct UpdArgs {
   void* key_norm;        // P_L2: [H,S] T
   double* num;           // P_HH
   int32_t* denom;        // P_HH
-  unsigned long long* key_out;  // P_HH pipeline seed: [2][H] arg-min keys indexed by (*input_pos & 1); no side effects
+  unsigned long long* key_out;  // P_HH pipeline seed: [H][nk] partial arg-min keys (entry 0 = the key, rest = ~0); no side effects
+  int nk;
 };
 
 constexpr int kUpdThreads = 1024;
@@ -192,10 +193,7 @@ __global__ __launch_bounds__(kUpdThreads) void decode_update_kernel(UpdArgs a) {
   const int idx = (int)((best & 0xffffffffull) >> 1);
   const int ins = (int)(best & 1ull);  // ref: cache.py:356-360 num_insertions = (old pos == -1)
   if (a.key_out != nullptr) {  // seed of the fused decode-step pipeline: publish the key, touch nothing else
-    if (threadIdx.x == 0) {
-      a.key_out[(size_t)(p & 1) * a.Hp + hp] = best;
-      a.key_out[(size_t)((p + 1) & 1) * a.Hp + hp] = ~0ull;
-    }
+    for (int i = threadIdx.x; i < a.nk; i += blockDim.x) a.key_out[(size_t)hp * a.nk + i] = (i == 0) ? best : ~0ull;
     return;
   }
   if (threadIdx.x == 0) a.idx_out[hp] = idx;
@@ -385,6 +383,8 @@ int cc_decode_update_heavy_hitter(const cc_kv_view* c, const void* k_new, const 
   return launch_update<P_HH>(c, a, (hipStream_t)stream);
 }
 
+int32_t cc_hh_next_key_slots(int32_t S) { return S > 0 ? cc_next_key_slots(S) : 0; }
+
 int cc_hh_next_key_init(const cc_kv_view* c, const int32_t* input_pos, const double* num, const int32_t* denom,
                         int32_t g, int32_t w, uint64_t* next_key, cc_stream_t stream) {
   CC_ENTRY();
@@ -393,6 +393,7 @@ int cc_hh_next_key_init(const cc_kv_view* c, const int32_t* input_pos, const dou
   a.input_pos = input_pos; a.g = g; a.w = w;
   a.num = const_cast<double*>(num); a.denom = const_cast<int32_t*>(denom);
   a.key_out = reinterpret_cast<unsigned long long*>(next_key);
+  a.nk = cc_next_key_slots(c->S);
   return launch_update<P_HH>(c, a, (hipStream_t)stream);
 }
 

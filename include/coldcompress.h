@@ -165,13 +165,17 @@ int cc_decode_attn_gqa(const void* q, const void* k, const void* v, const uint8_
  * in TWO launches instead of three.  Same reference lines as cc_decode_update_heavy_hitter, cc_decode_attn_gqa
  * and cc_hh_update; the only difference is WHEN the arg-min runs:
  *   launch 1 (K/V streaming pass): the insert of this step's token is folded into its prologue — the slot is the
- *     arg-min key left in next_key[*input_pos & 1] by the previous step (or by cc_hh_next_key_init);
+ *     minimum over the partial arg-min keys next_key[h][0 .. NK) left by the previous step (or by
+ *     cc_hh_next_key_init);
  *   launch 2 (combine): y, group-averaged probabilities, history update, and the arg-min for position
- *     *input_pos + 1 evaluated on the freshly updated history -> next_key[(*input_pos + 1) & 1].
- * next_key: uint64 [2, H] = (orderable(score) << 32) | slot << 1 | was_empty.  Valid as long as positions advance
- * by one and nothing else mutates pos / history in between; re-seed with cc_hh_next_key_init otherwise.
+ *     *input_pos + 1 evaluated on the freshly updated history: one partial minimum per 128-slot chunk
+ *     -> next_key[h][chunk] (plain stores; no atomics, no reset pass).
+ * next_key: uint64 [H, NK], NK = cc_hh_next_key_slots(S); entry = (orderable(score) << 32) | slot << 1 | was_empty,
+ * ~0 = "no candidate".  Valid as long as positions advance by one and nothing else mutates pos / history in
+ * between; re-seed with cc_hh_next_key_init otherwise.
  * Results are bit-identical to the three-call sequence (tests/test_gpu_fused_step.py).
  * ---------------------------------------------------------------------------------------------- */
+int32_t cc_hh_next_key_slots(int32_t S);
 int cc_hh_next_key_init(const cc_kv_view* c, const int32_t* input_pos, const double* num, const int32_t* denom,
                         int32_t global_tokens, int32_t recent_window, uint64_t* next_key, cc_stream_t stream);
 int cc_decode_step_heavy_hitter(const cc_kv_view* c, const void* q, const void* k_new, const void* v_new,
@@ -179,6 +183,12 @@ int cc_decode_step_heavy_hitter(const cc_kv_view* c, const void* q, const void* 
                                 uint64_t* next_key, int32_t global_tokens, int32_t recent_window, int32_t HQ,
                                 float scale, void* y, void* attn_out, void* workspace, size_t workspace_bytes,
                                 cc_stream_t stream);
+/* Measurement hook (cf. cc_decode_attn_gqa_phases): the same step with its two launches selectable. */
+int cc_decode_step_heavy_hitter_phases(const cc_kv_view* c, const void* q, const void* k_new, const void* v_new,
+                                const int32_t* input_pos, double* num, int32_t* denom, int64_t* counter,
+                                uint64_t* next_key, int32_t global_tokens, int32_t recent_window, int32_t HQ,
+                                float scale, void* y, void* attn_out, void* workspace, size_t workspace_bytes,
+                                cc_stream_t stream, int32_t phases);
 
 /* Measurement hook: the same operation with its two launches selectable, so that bench.py can bracket the
  * dominant kernel alone with HIP events.  phases: 1 = split kernel only (K/V streaming pass),

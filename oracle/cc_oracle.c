@@ -963,14 +963,19 @@ static uint64_t hh_key_for_head(const cc_kv_view* c, int h, int32_t p, const dou
   return best;
 }
 
+/* next_key is [H][NK] partial minima (the device publishes one per 128-slot chunk); only their minimum is
+ * contractual, so the oracle keeps the whole key in entry 0. */
+int32_t cc_hh_next_key_slots_cpu(int32_t S) { return S > 0 ? (S + 127) / 128 : 0; }
+
 int cc_hh_next_key_init_cpu(const cc_kv_view* c, const int32_t* input_pos, const double* num, const int32_t* denom, int32_t g,
                             int32_t w, uint64_t* next_key, cc_stream_t stream) {
   (void)stream;
   if (!view_ok(c) || !input_pos || !num || !denom || !next_key || c->Hp != c->H) return CC_ERR_BAD_ARG;
   const int32_t p = *input_pos;
+  const int nk = cc_hh_next_key_slots_cpu(c->S);
   for (int h = 0; h < c->H; h++) {
-    next_key[(size_t)(p & 1) * c->H + h] = hh_key_for_head(c, h, p, num, denom, g, w);
-    next_key[(size_t)((p + 1) & 1) * c->H + h] = ~(uint64_t)0;
+    for (int i = 1; i < nk; i++) next_key[(size_t)h * nk + i] = ~(uint64_t)0;
+    next_key[(size_t)h * nk] = hh_key_for_head(c, h, p, num, denom, g, w);
   }
   return CC_OK;
 }
@@ -985,9 +990,12 @@ int cc_decode_step_heavy_hitter_cpu(const cc_kv_view* c, const void* q, const vo
   if (!view_ok(c) || !q || !k_new || !v_new || !input_pos || !num || !denom || !next_key || !y || c->Hp != c->H || c->H > 4096)
     return CC_ERR_BAD_ARG;
   const int32_t p = *input_pos;
+  const int nk = cc_hh_next_key_slots_cpu(c->S);
   int64_t idx[4096];
   for (int h = 0; h < c->H; h++) {
-    const uint64_t key = next_key[(size_t)(p & 1) * c->H + h];
+    uint64_t key = ~(uint64_t)0;
+    for (int i = 0; i < nk; i++)
+      if (next_key[(size_t)h * nk + i] < key) key = next_key[(size_t)h * nk + i];
     if (key == ~(uint64_t)0) return CC_ERR_BAD_ARG;
     idx[h] = (int64_t)((key & 0xffffffffu) >> 1);
     num[(size_t)h * c->S + idx[h]] = 0.0;
@@ -998,8 +1006,19 @@ int cc_decode_step_heavy_hitter_cpu(const cc_kv_view* c, const void* q, const vo
                                   num, denom, counter, workspace, workspace_bytes, stream);
   if (rc != CC_OK) return rc;
   for (int h = 0; h < c->H; h++) {
-    next_key[(size_t)((p + 1) & 1) * c->H + h] = hh_key_for_head(c, h, p + 1, num, denom, g, w);
-    next_key[(size_t)(p & 1) * c->H + h] = ~(uint64_t)0;
+    for (int i = 1; i < nk; i++) next_key[(size_t)h * nk + i] = ~(uint64_t)0;
+    next_key[(size_t)h * nk] = hh_key_for_head(c, h, p + 1, num, denom, g, w);
   }
   return CC_OK;
+}
+
+/* Measurement hook twin: the oracle has no launches to select; only phases == 3 (the whole step) is meaningful. */
+int cc_decode_step_heavy_hitter_phases_cpu(const cc_kv_view* c, const void* q, const void* k_new, const void* v_new,
+                                           const int32_t* input_pos, double* num, int32_t* denom, int64_t* counter,
+                                           uint64_t* next_key, int32_t g, int32_t w, int32_t HQ, float scale, void* y,
+                                           void* attn_out, void* workspace, size_t workspace_bytes, cc_stream_t stream,
+                                           int32_t phases) {
+  if ((phases & 3) != 3) return CC_ERR_UNSUPPORTED;
+  return cc_decode_step_heavy_hitter_cpu(c, q, k_new, v_new, input_pos, num, denom, counter, next_key, g, w, HQ, scale, y,
+                                         attn_out, workspace, workspace_bytes, stream);
 }

@@ -53,8 +53,8 @@ def _log_evictions(model):
             def step(query, k_val, v_val, input_pos, scale=None, _orig=orig_step, _kv=kv, _i=i):
                 if not _kv._next_valid:
                     _kv.prepare_decode(input_pos)
-                par = int(input_pos.item()) & 1
-                log[_i].append(((_kv.next_key[par] & 0xffffffff) >> 1).clone())
+                keys = _kv.next_key.cpu().numpy().view("uint64").min(axis=1)  # partial minima per chunk -> arg-min key
+                log[_i].append(torch.from_numpy(((keys & 0xffffffff) >> 1).astype("int64")))
                 return _orig(query, k_val, v_val, input_pos, scale)
 
             kv.decode_step = step

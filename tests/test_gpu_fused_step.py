@@ -66,7 +66,7 @@ def test_fused_step_vs_oracle_pipeline(oracle):
     st = dict(k=to_np(kv.k_cache.cpu()[0]), v=to_np(kv.v_cache.cpu()[0]), pos=kv.pos.cpu()[0].numpy().copy(),
               mask=kv.mask.cpu()[0, :, 0].numpy().astype(np.uint8), cts=kv.cache_cts.cpu().numpy().copy(),
               num=kv.attn_history_num.cpu()[0, :, :, 0].numpy().copy(), denom=kv.attn_history_denom.cpu()[0].numpy().copy(),
-              ctr=np.zeros(1, np.int64), key=np.zeros((2, H), np.uint64))
+              ctr=np.zeros(1, np.int64), key=np.zeros((H, (S + 127) // 128), np.uint64))
     gen = torch.Generator().manual_seed(8)
     o = oracle
     p0 = S + 20

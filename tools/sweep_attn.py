@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--HQ", type=int, default=32)
     ap.add_argument("--D", type=int, default=128)
     ap.add_argument("--ablate", action="store_true", help="time the split kernel with parts switched off")
+    ap.add_argument("--fused", action="store_true", help="time the fused two-launch heavy-hitter step and its parts")
     a = ap.parse_args()
     dev = "cuda"
     fns = _abi.lib()
@@ -102,6 +103,28 @@ def main():
             attn(i, 3, True)
 
         n = n_buf
+        if a.fused:
+            for kv in caches:
+                kv.prepare_decode(pos)
+
+            def fstep(i, phases):
+                kv = caches[i % n_buf]
+                st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+                rc = fns["cc_decode_step_heavy_hitter_phases"](
+                    kv._view(), p(q), p(k1), p(k1), p(pos), p(kv.attn_history_num), p(kv.attn_history_denom),
+                    p(kv.attn_counter), p(kv.next_key), 4, 10, HQ, 1.0 / math.sqrt(D), p(y), None, p(ws), nbytes, st, phases)
+                assert rc == 0, rc
+
+            res = {"S": S}
+            for name, ph in (("step", 3), ("split", 1), ("split_nobranch", 1 | (64 << 8)), ("split_nokey", 1 | (128 << 8)), ("combine", 2), ("combine_nokey", 2 | (8 << 8)),
+                             ("combine_noy", 2 | (16 << 8)), ("combine_noslot", 2 | (32 << 8)),
+                             ("combine_empty", 2 | (56 << 8))):
+                t, tmin = timed_graph(lambda i, ph=ph: fstep(i, ph), n)
+                res[name + "_us"] = round(t, 2)
+            t, _ = timed_graph(lambda i: attn(i, 2, True), n)
+            res["combine_unfused_hist_us"] = round(t, 2)
+            print(json.dumps(res), flush=True)
+            continue
         if a.ablate:
             res = {"S": S}
             for name, bits in (("full", 0), ("no_store", 1), ("no_epilogue", 2), ("no_mask", 4), ("no_store_epi", 3),
