@@ -81,7 +81,8 @@ def cache_kwargs(args):
 
 
 def roofline(model, args, dev):
-    """HBM roofline of the dominant kernel (decode_attn_split_kernel: streams K and V of one layer once).
+    """HBM roofline of the dominant kernel: the K/V streaming pass of the fused heavy-hitter decode step
+    (decode_attn_split_mfma_kernel — streams K and V of one layer once, with this step's insert folded in).
     achieved = algorithmic bytes per launch / mean launch duration, HIP events on the launch stream."""
     from cold_compress_amd import _abi
 
@@ -93,20 +94,28 @@ def roofline(model, args, dev):
     nbytes = fns["cc_decode_attn_workspace_bytes"](HQ, H, S, D, 1)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     q = torch.randn(HQ, D, device=dev).to(torch.bfloat16)
+    k1 = torch.randn(H, D, device=dev).to(torch.bfloat16)
     y = torch.empty(HQ, D, device=dev, dtype=torch.bfloat16)
-    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    pos = torch.tensor([args.prompt_len + 20_000], dtype=torch.int32, device=dev)
     p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    # the measurement inserts a synthetic token into every layer's cache: work on the live buffers, restore afterwards
+    snap = [{k: v.clone() for k, v in a.kv_cache._buffers.items()} for a in layers]
+    for att in layers:
+        att.kv_cache.prepare_decode(pos)
 
     def launch(att, phases):
         kv = att.kv_cache
-        rc = fns["cc_decode_attn_gqa_phases"](p(q), p(kv.k_cache), p(kv.v_cache), p(kv.mask), HQ, H, S, D, 1,
-                                               1.0 / math.sqrt(D), p(y), None, None, None, None, None, p(ws), nbytes, st, phases)
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        rc = fns["cc_decode_step_heavy_hitter_phases"](
+            kv._view(), p(q), p(k1), p(k1), p(pos), p(kv.attn_history_num), p(kv.attn_history_denom), p(kv.attn_counter),
+            p(kv.next_key), int(kv.global_tokens), int(kv.recent_window), HQ, 1.0 / math.sqrt(D), p(y), None, p(ws), nbytes,
+            st, phases)
         assert rc == 0, rc
 
     for att in layers:  # warm
         launch(att, 3)
     torch.cuda.synchronize()
-    # One hipGraph = the split kernel launched once per layer, rotating over all layers' distinct K/V
+    # One hipGraph = the streaming pass launched once per layer, rotating over all layers' distinct K/V
     # (32 x 16 MiB >> 256 MB Infinity Cache).  HIP events bracket whole replays on the launch stream, so the
     # per-launch figure INCLUDES the dependent-launch boundary (~1.2-1.5 us) and is therefore conservative
     # with respect to the rocprofv3 kernel duration committed under profiles/ (an event pair around a single
@@ -114,15 +123,12 @@ def roofline(model, args, dev):
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
-        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         launch(layers[0], 1)
     torch.cuda.current_stream().wait_stream(side)
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
-        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         for att in layers:
             launch(att, 1)
-    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     graph.replay()
     torch.cuda.synchronize()
     us = []
@@ -133,6 +139,10 @@ def roofline(model, args, dev):
         e1.record()
         torch.cuda.synchronize()
         us.append(e0.elapsed_time(e1) * 1e3 / len(layers))
+    for a, sn in zip(layers, snap):
+        for k, v in sn.items():
+            a.kv_cache._buffers[k].copy_(v)
+        a.kv_cache._next_valid = False
     us.sort()
     mean_us = sum(us) / len(us)
     # algorithmic bytes of this launch: K and V once (2*H*S*D*2) + mask (H*S) + q; outputs (scores, partials) excluded
@@ -141,7 +151,7 @@ def roofline(model, args, dev):
     step_bytes = 2 * H * S * D * 2 + H * S * 29
     ach = alg / (mean_us * 1e-6) / 1e9
     return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "decode_attn_split_kernel<bf16_t,128,4,4,4>",
+            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "decode_attn_split_mfma_kernel<bf16_t,4,4>",
             "bytes_per_launch": alg, "mean_us": round(mean_us, 3), "median_us": round(us[len(us) // 2], 3),
             "min_us": round(us[0], 3), "launches": len(us) * len(layers), "layer_step_bytes": step_bytes,
             "timing": "HIP events around hipGraph replays of 32 launches (one per layer); per-launch = total/32, "

@@ -400,6 +400,337 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_split_kernel(SplitArgs a)
   }
 }
 
+// ================================================================================================================
+// Matrix-core variant of the streaming pass for 16-bit caches with head_dim 128 (Llama-3 / Qwen-2 class models).
+//
+// The VALU kernel above spends ~560 vector instructions per 16-row tile, ~40% of them on q.k (fma + bf16 unpack +
+// 16-lane DPP reductions) — with two waves per SIMD that is ~1.9 us of issue time at S = 4096, the same order as
+// the 3.3 us it takes HBM to deliver the tile.  Here q.k runs as FOUR v_mfma_f32_16x16x32 per tile:
+//   * global loads stay exactly as coalesced as before (16 lanes x 16 B = one whole 256-byte K row), but lane c of
+//     the row with tile-local index i fetches 16-byte chunk (c ^ i) of that row instead of chunk c;
+//   * every lane drops its chunk into its own wave's 4 KiB LDS slab at [i][c] (ds_write_b128, conflict free);
+//   * the A operand of step j is read back as [i = lane % 16][(4j + lane / 16) ^ i] — the XOR applied at LOAD time
+//     makes the 16 rows read by a quarter-wave land in 16 different bank groups (conflict free, no padding);
+//   * B = q^T (query head n of the group in column n, zero for n >= RT) lives in 16 VGPRs for the whole kernel;
+//   * C[i][n]: lane (g = lane / 16, n = lane % 16) gets the scores of ITS OWN row group's four rows against head n,
+//     so the mask word, the online-softmax state (one m, l per lane instead of RT) and the 8-byte score store all
+//     stay in the lane that already owns them; p and alpha reach the 16 lanes of the group through DPP
+//     row_newbcast (one v_mov_dpp each), and P.V stays on the packed-fp32 VALU path over the coalesced V rows.
+// ~190 vector instructions per tile instead of ~560.  No workgroup barrier in the loop: the LDS slab is wave-private.
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+template <typename T>
+struct Mfma16x16x32;
+template <>
+struct Mfma16x16x32<bf16_t> {
+  __device__ static __forceinline__ f32x4_t mma(uint4 a, uint4 b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  }
+};
+template <>
+struct Mfma16x16x32<f16_t> {
+  __device__ static __forceinline__ f32x4_t mma(uint4 a, uint4 b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+  }
+};
+// value held by lane N of the caller's 16-lane row (DPP row_newbcast, gfx90a+)
+template <int N>
+__device__ __forceinline__ float row_bcast(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + N, 0xf, 0xf, true));
+}
+template <int RT>
+__device__ __forceinline__ void row_bcast_heads(float v, float (&out)[RT]) {
+  out[0] = row_bcast<0>(v);
+  if constexpr (RT > 1) out[1] = row_bcast<1>(v);
+  if constexpr (RT > 2) {
+    out[2] = row_bcast<2>(v);
+    out[3] = row_bcast<3>(v);
+  }
+}
+
+template <typename T, int RT, int NW>
+__global__ __launch_bounds__(NW * 64) void decode_attn_split_mfma_kernel(SplitArgs a) {
+  static_assert(sizeof(T) == 2 && (RT == 1 || RT == 2 || RT == 4), "16-bit caches, up to 4 query heads per pass");
+  constexpr int D = 128, VEC = 8, LPR = 16, RPW = 4, U = 4;
+  constexpr int NG = NW * RPW;
+  static_assert(NG == 16, "the merge below reads the 16 row-group states of a query head as four float4");
+  __shared__ __attribute__((aligned(16))) float sm_m[RT][NG];
+  __shared__ __attribute__((aligned(16))) float sm_l[RT][NG];
+  __shared__ __attribute__((aligned(16))) float sm_acc[NG][RT][D];
+  __shared__ __attribute__((aligned(16))) uint4 sm_k[NW][16][16];  // [wave][tile row i][slot]: 4 KiB per wave
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, c = lane & 15;  // row group of the wave / 16-byte column chunk (and MFMA column n)
+  const int split = blockIdx.x, h = blockIdx.y, q0 = h * a.R + blockIdx.z * RT;
+  const int S = a.S;
+  const int row_begin = split * a.rows_per_split;
+  const int row_end = min(S, row_begin + a.rows_per_split);
+  const T* kb = reinterpret_cast<const T*>(a.k) + (size_t)h * S * D;
+  const T* vh = reinterpret_cast<const T*>(a.v) + (size_t)h * S * D + c * VEC;
+  const bool has_mask = a.mask != nullptr && !(a.abl & 4);
+  const uint8_t* mh = has_mask ? a.mask + (size_t)h * S : reinterpret_cast<const uint8_t*>(a.k);
+  T* sc_out = reinterpret_cast<T*>(a.scores);
+
+  float m = -INFINITY, l = 0.f;  // softmax state of (row group g, query head c); meaningful for c < RT
+  float acc[RT][VEC];
+#pragma unroll
+  for (int r = 0; r < RT; r++)
+#pragma unroll
+    for (int e = 0; e < VEC; e++) acc[r][e] = 0.f;
+
+  // ---- every load of the first tile is issued before anything waits (partial keys, q, mask, K, V: use order)
+  int ins_idx = -1, ins_was_empty = 0;
+  bool key_pending = a.next_key != nullptr && !(a.abl & 128);
+  unsigned long long key_part = ~0ull;
+  if (key_pending) {
+    if (lane < a.nk) key_part = a.next_key[(size_t)h * a.nk + lane];
+    // caches beyond 64 chunks (S > 8192) — kept OUT of the streaming loop so that the waits there stay exact
+    for (int i = lane + 64; i < a.nk; i += 64) {
+      const unsigned long long x = a.next_key[(size_t)h * a.nk + i];
+      key_part = x < key_part ? x : key_part;
+    }
+  }
+  // B operand: lane (n = c, kb = g) of step j holds q[head n][8 * (4j + g) .. + 8]; columns n >= RT are zero
+  Vec16<T> qB[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    qB[j].raw = make_uint4(0, 0, 0, 0);
+    if (c < RT) qB[j].load(reinterpret_cast<const T*>(a.q) + (size_t)(q0 + c) * D + (4 * j + g) * VEC);
+  }
+  uint32_t mword = 0x01010101u;
+  Vec16<T> kk[U], vv[U];
+  auto issue_k = [&](int base) {  // mask word + the four K rows of this lane's row group (tile row i = 4g + u takes chunk c ^ i)
+    const int row0 = base + g * U;
+    mword = 0x01010101u;
+    if (has_mask) {
+      if (row0 + 3 < S && ((reinterpret_cast<uintptr_t>(mh) + (size_t)row0) & 3) == 0) {
+        mword = *reinterpret_cast<const uint32_t*>(mh + row0);
+      } else {
+        mword = 0;
+#pragma unroll
+        for (int u = 0; u < U; u++)
+          if (row0 + u < S) mword |= (uint32_t)mh[row0 + u] << (8 * u);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int rr = row0 + u < row_end ? row0 + u : row_end - 1;
+      kk[u].load(kb + (size_t)rr * D + ((c ^ (4 * g + u)) & 15) * VEC);
+    }
+  };
+  auto issue_v = [&](int base) {
+    const int row0 = base + g * U;
+#pragma unroll
+    for (int u = 0; u < U; u++) vv[u].load(vh + (size_t)(row0 + u < row_end ? row0 + u : row_end - 1) * D);
+  };
+  int base = row_begin + wave * (RPW * U);
+  bool more = base < row_end;
+  if (more) {
+    issue_k(base);
+    issue_v(base);
+  }
+
+  while (more) {
+    const int row0 = base + g * U;
+    const int base_next = base + NW * RPW * U;
+    const bool more_next = base_next < row_end;
+    if (key_pending) {  // wave-uniform; first iteration only
+      const unsigned long long key = wave_min_u64_uniform(key_part);
+      ins_idx = (key == ~0ull) ? -1 : (int)((key & 0xffffffffull) >> 1);
+      if (a.abl & 64) ins_idx = -1;
+      ins_was_empty = (int)(key & 1ull);
+      key_pending = false;
+    }
+    // fused insert (cache.py:356-362, 460-490, 754-763) — see the VALU kernel; the K chunk follows the swizzle
+    if ((unsigned)(ins_idx - row0) < (unsigned)U) {
+      const int um = ins_idx - row0;
+      const int kcol = ((c ^ (4 * g + um)) & 15) * VEC;
+      Vec16<T> kn, vn;
+      kn.load(reinterpret_cast<const T*>(a.k_new) + (size_t)h * D + kcol);
+      vn.load(reinterpret_cast<const T*>(a.v_new) + (size_t)h * D + c * VEC);
+      const int32_t p_now = *a.input_pos;
+#pragma unroll
+      for (int u = 0; u < U; u++)
+        if (u == um) {
+          kk[u].raw = kn.raw;
+          vv[u].raw = vn.raw;
+          mword |= 1u << (8 * u);
+        }
+      if (blockIdx.z == 0) {
+        const size_t slot = (size_t)h * S + ins_idx;
+        *reinterpret_cast<uint4*>(const_cast<T*>(kb) + (size_t)ins_idx * D + kcol) = kn.raw;
+        *reinterpret_cast<uint4*>(const_cast<T*>(vh) + (size_t)ins_idx * D) = vn.raw;
+        if (c == 0) {
+          a.pos[slot] = p_now;
+          a.mask_w[slot] = 1;
+          a.num[slot] = 0.0;
+          a.denom[slot] = 0;
+          if (ins_was_empty && (a.Hc == a.H || h == 0)) atomicAdd(&a.cache_cts[a.Hc == a.H ? h : 0], 1);
+        }
+      }
+    }
+
+    // ---- K tile -> wave-private LDS slab -> A operand; S^T = K q^T on the matrix core
+#pragma unroll
+    for (int u = 0; u < U; u++) sm_k[wave][4 * g + u][c] = kk[u].raw;
+    const uint32_t mcur = mword;
+    if (more_next) issue_k(base_next);  // K registers are free again: the next tile streams in behind this tile's math
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    f32x4_t cs = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; j++) cs = Mfma16x16x32<T>::mma(sm_k[wave][c][((4 * j + g) ^ c) & 15], qB[j].raw, cs);
+    __builtin_amdgcn_wave_barrier();  // the next tile's stores must stay behind these reads
+
+    // ---- lane (g, n = c): scores of rows row0 + 0..3 against query head c
+    // ref: attention_utils.py:37 (q@k^T -> dtype, * scale -> dtype), :42-43 (-inf bias where masked)
+    float s[U];
+#pragma unroll
+    for (int t = 0; t < U; t++) {
+      const bool valid = (row0 + t < row_end) && (((mcur >> (8 * t)) & 0xffu) != 0);
+      const float x = ElemTraits<T>::rnd(ElemTraits<T>::rnd(cs[t]) * a.scale);
+      s[t] = valid ? x : -INFINITY;
+    }
+    if (c < RT && !(a.abl & 1)) {
+      const size_t o = (size_t)(q0 + c) * S + row0;
+      if (row0 + 3 < row_end && (o & 3) == 0) {  // four consecutive 16-bit scores: one 8-byte store
+        T e0, e1, e2, e3;  // s[] already holds values rounded to T: the stores below are exact
+        ElemTraits<T>::store(&e0, 0, s[0]);
+        ElemTraits<T>::store(&e1, 0, s[1]);
+        ElemTraits<T>::store(&e2, 0, s[2]);
+        ElemTraits<T>::store(&e3, 0, s[3]);
+        *reinterpret_cast<uint2*>(sc_out + o) =
+            make_uint2((uint32_t)e0.x | ((uint32_t)e1.x << 16), (uint32_t)e2.x | ((uint32_t)e3.x << 16));
+      } else {
+#pragma unroll
+        for (int t = 0; t < U; t++)
+          if (row0 + t < row_end) ElemTraits<T>::store(sc_out, o + t, s[t]);
+      }
+    }
+    // ---- online softmax: ONE (m, l) per lane
+    float p[U];
+    {
+      const float mx = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+      const float m_new = fmaxf(m, mx);
+      const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+      const float alpha = fast_exp(m - m_use);
+      m = m_new;
+      l *= alpha;
+#pragma unroll
+      for (int t = 0; t < U; t++) {
+        p[t] = fast_exp(s[t] - m_use);
+        l += p[t];
+      }
+      float al[RT];
+      row_bcast_heads<RT>(alpha, al);
+#pragma unroll
+      for (int r = 0; r < RT; r++)
+#pragma unroll
+        for (int e = 0; e < VEC; e++) acc[r][e] *= al[r];
+    }
+    // ---- P.V on the VALU over the coalesced V rows; p of head r comes from lane r of the row group
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      float vf[VEC];
+      vv[u].unpack(vf);
+      float pu[RT];
+      row_bcast_heads<RT>(p[u], pu);
+#pragma unroll
+      for (int r = 0; r < RT; r++)
+#pragma unroll
+        for (int e = 0; e < VEC; e++) acc[r][e] = fmaf(pu[r], vf[e], acc[r][e]);
+    }
+    if (more_next) issue_v(base_next);
+    base = base_next;
+    more = more_next;
+  }
+
+  if (a.abl & 2) {  // measurement only
+    float x = l + m;
+#pragma unroll
+    for (int r = 0; r < RT; r++)
+#pragma unroll
+      for (int e = 0; e < VEC; e++) x += acc[r][e];
+    if (x == 1.2345f) a.part_ml[0] = x;
+    return;
+  }
+  // ---- row-group partials -> LDS -> one partial per (query head, split).
+  // Merge item = (query head r, 4 output columns k, half of the 16 row groups): 12 LDS instructions per thread
+  // (4 x b128 for the 16 maxima, 8 x b128 accumulator slices) and 8 exps, the two halves meet through one DPP
+  // add per component; fixed order -> deterministic.  (The per-column merge of the VALU kernel issues ~100
+  // ds_read_b32 and 32 exps per thread — 1.6 us of the 7.2 us kernel at S = 4096.)
+  constexpr int NP = VEC / 4;
+  const int grp = wave * RPW + g;
+  if (c < RT) {
+    sm_m[c][grp] = m;
+    sm_l[c][grp] = l;
+  }
+#pragma unroll
+  for (int r = 0; r < RT; r++)
+#pragma unroll
+    for (int pc = 0; pc < NP; pc++)
+      *reinterpret_cast<float4*>(&sm_acc[grp][r][(pc * LPR + c) * 4]) =
+          make_float4(acc[r][pc * 4], acc[r][pc * 4 + 1], acc[r][pc * 4 + 2], acc[r][pc * 4 + 3]);
+  __syncthreads();
+  const int item = threadIdx.x;
+  if (item < RT * 64) {
+    const int half = item & 1, k4 = (item >> 1) & 31, r = item >> 6;
+    const float4 m0 = *reinterpret_cast<const float4*>(&sm_m[r][0]);
+    const float4 m1 = *reinterpret_cast<const float4*>(&sm_m[r][4]);
+    const float4 m2 = *reinterpret_cast<const float4*>(&sm_m[r][8]);
+    const float4 m3 = *reinterpret_cast<const float4*>(&sm_m[r][12]);
+    const float M = fmaxf(fmaxf(fmaxf(fmaxf(m0.x, m0.y), fmaxf(m0.z, m0.w)), fmaxf(fmaxf(m1.x, m1.y), fmaxf(m1.z, m1.w))),
+                          fmaxf(fmaxf(fmaxf(m2.x, m2.y), fmaxf(m2.z, m2.w)), fmaxf(fmaxf(m3.x, m3.y), fmaxf(m3.z, m3.w))));
+    const float Mu = (M == -INFINITY) ? 0.f : M;
+    // columns 4*k4 .. +3 live in piece (k4 & 1) of lane k4 >> 1 (see the store above)
+    const int dl = ((k4 & 1) * LPR + (k4 >> 1)) * 4;
+    float f[NG / 2];  // registers only: every index below is a compile-time constant
+    f[0] = fast_exp((half ? m2.x : m0.x) - Mu);
+    f[1] = fast_exp((half ? m2.y : m0.y) - Mu);
+    f[2] = fast_exp((half ? m2.z : m0.z) - Mu);
+    f[3] = fast_exp((half ? m2.w : m0.w) - Mu);
+    f[4] = fast_exp((half ? m3.x : m1.x) - Mu);
+    f[5] = fast_exp((half ? m3.y : m1.y) - Mu);
+    f[6] = fast_exp((half ? m3.z : m1.z) - Mu);
+    f[7] = fast_exp((half ? m3.w : m1.w) - Mu);
+    float4 O = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* accp = &sm_acc[half * (NG / 2)][r][dl];
+#pragma unroll
+    for (int i = 0; i < NG / 2; i++) {
+      const float4 a4 = *reinterpret_cast<const float4*>(accp + (size_t)i * RT * D);
+      O.x = fmaf(a4.x, f[i], O.x);
+      O.y = fmaf(a4.y, f[i], O.y);
+      O.z = fmaf(a4.z, f[i], O.z);
+      O.w = fmaf(a4.w, f[i], O.w);
+    }
+    float L = 0.f;
+    if (k4 == 0) {
+      const float4 la = *reinterpret_cast<const float4*>(&sm_l[r][half * (NG / 2)]);
+      const float4 lb = *reinterpret_cast<const float4*>(&sm_l[r][half * (NG / 2) + 4]);
+      L = fmaf(la.x, f[0], L);
+      L = fmaf(la.y, f[1], L);
+      L = fmaf(la.z, f[2], L);
+      L = fmaf(la.w, f[3], L);
+      L = fmaf(lb.x, f[4], L);
+      L = fmaf(lb.y, f[5], L);
+      L = fmaf(lb.z, f[6], L);
+      L = fmaf(lb.w, f[7], L);
+    }
+    O.x += dpp_mov<0xB1>(O.x);  // lane ^ 1: the other half of the row groups
+    O.y += dpp_mov<0xB1>(O.y);
+    O.z += dpp_mov<0xB1>(O.z);
+    O.w += dpp_mov<0xB1>(O.w);
+    L += dpp_mov<0xB1>(L);
+    if (half == 0) {
+      const size_t pj = (size_t)(q0 + r) * a.n_split + split;
+      *reinterpret_cast<float4*>(a.part_o + pj * D + 4 * k4) = O;
+      if (k4 == 0) *reinterpret_cast<float2*>(a.part_ml + pj * 2) = make_float2(M, L);
+    }
+  }
+}
+
 struct CombineArgs {
   const void* scores;
   const float* part_ml;
@@ -642,9 +973,16 @@ static Plan make_plan(int HQ, int H, int S, int D, int dtype) {
   const int R = HQ / H;
   p.rt = (R % 4 == 0) ? 4 : (R % 2 == 0) ? 2 : 1;
   const int rpi = rows_per_iter(D, dtype);
-  // one iteration per workgroup when that keeps the grid at >= ~256 workgroups; otherwise grow the chunk
+  // ~512 workgroups (two per CU, all resident at once): one tile per workgroup up to S = 64 * 64 rows per kv
+  // head at 8 kv heads, MORE TILES PER WORKGROUP beyond that — the loop prefetches the next tile behind the
+  // current one, the per-workgroup merge and the number of partials the combine pass has to fold stay constant.
+  // (512 splits at S = 65536 made every combine block re-reduce 2048 (m, l) pairs: 27 us of a 33 us launch.)
+  const int zb = R / p.rt;
+  int ns_cap = (512 + H * zb - 1) / (H * zb);
+  if (ns_cap < 16) ns_cap = 16;
+  if (ns_cap > kMaxSplit) ns_cap = kMaxSplit;
   int ns = (S + rpi - 1) / rpi;
-  if (ns > kMaxSplit) ns = kMaxSplit;
+  if (ns > ns_cap) ns = ns_cap;
   if (ns < 1) ns = 1;
   int rps = (S + ns - 1) / ns;
   rps = ((rps + rpi - 1) / rpi) * rpi;
@@ -672,6 +1010,19 @@ static int launch_split_rt(const SplitArgs& a, const Plan& p, int H, int R, hipS
 
 template <typename T>
 static int launch_split(const SplitArgs& a, const Plan& p, int H, int R, int D, hipStream_t st) {
+  if constexpr (sizeof(T) == 2) {
+    if (D == 128 && !(a.abl & 32)) {  // matrix-core streaming pass (abl bit 32 = measurement: force the VALU kernel)
+      static_assert(kU == 4, "the MFMA tile is 4 row groups x 4 rows per wave");
+      dim3 grid(p.n_split, H, R / p.rt), block(kNW * 64);
+      switch (p.rt) {
+        case 4: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 4, kNW>), grid, block, 0, st, a); break;
+        case 2: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 2, kNW>), grid, block, 0, st, a); break;
+        default: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 1, kNW>), grid, block, 0, st, a); break;
+      }
+      CC_LAUNCH_CHECK();
+      return CC_OK;
+    }
+  }
   switch (D) {
     case 16: return launch_split_rt<T, 16>(a, p, H, R, st);
     case 32: return launch_split_rt<T, 32>(a, p, H, R, st);
