@@ -150,8 +150,22 @@ def roofline(model, args, dev):
     # whole layer-step bytes: K,V + 29 B/slot of heavy-hitter state
     step_bytes = 2 * H * S * D * 2 + H * S * 29
     ach = alg / (mean_us * 1e-6) / 1e9
+    # HBM bytes per launch from the PMC counters: they need rocprofv3 around the process (two separate --pmc passes),
+    # so they come from the committed summary of that run (tools/pmc_traffic.py), not from inside this process
+    traffic, traffic_src = None, None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            k = json.load(f)["kernels"].get("decode_attn_split_mfma_kernel<bf16_t, 4, 4>")
+        if k and (H, S, D, HQ) == (8, 4096, 128, 32):
+            traffic = k["traffic_bytes"]
+            traffic_src = ("profiles/r01_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950 wide-read correction) "
+                           "+ --pmc WRITE_SIZE, separate passes, median per launch; fetch %d + write %d B"
+                           % (k["fetch_bytes"], k["write_bytes"]))
+    except (OSError, KeyError, ValueError):
+        pass
     return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "decode_attn_split_mfma_kernel<bf16_t,4,4>",
+            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+            "kernel": "decode_attn_split_mfma_kernel<bf16_t,4,4>",
             "bytes_per_launch": alg, "mean_us": round(mean_us, 3), "median_us": round(us[len(us) // 2], 3),
             "min_us": round(us[0], 3), "launches": len(us) * len(layers), "layer_step_bytes": step_bytes,
             "timing": "HIP events around hipGraph replays of 32 launches (one per layer); per-launch = total/32, "
