@@ -98,12 +98,15 @@ class KVCache(nn.Module):
             setattr(self, key, value)
         if max_batch_size != 1:
             raise ColdCompressError("batch size is fixed at 1 (ref: model.py:188-189)")
-        if getattr(self, "cache_bits", None) is not None:
-            raise NotImplementedError("cache_bits (quantised KV) is a SURVEY §8(f) follow-up and not built yet")
         if dtype not in _DT:
             raise ColdCompressError(f"unsupported cache dtype {dtype}")
-        self.cache_bits = None
-        self.n_bit = None
+        # ref: cache.py:180-183 — quantised KV: 8 / 4 / 2 bits, one (scale, zero point) per cache slot (axis 2)
+        self.cache_bits = getattr(self, "cache_bits", None)
+        if self.cache_bits not in (None, 8, 4, 2):
+            raise ColdCompressError("Only 2-bit, 4-bit, and 8-bit quantization are supported (ref: quantization_utils.py:5)")
+        self.quantize = self.cache_bits is not None
+        self.n_bit = self.cache_bits
+        self.quantization_axis = 2
         self.n_heads = n_heads
         self.head_dim = head_dim
         self.head_specific = head_specific
@@ -115,6 +118,19 @@ class KVCache(nn.Module):
         self.register_buffer("pos", torch.full((1, n_heads if head_specific else 1, S), -1, dtype=torch.int32))
         self.register_buffer("cache_cts", torch.zeros((n_heads if variable_length else 1,), dtype=torch.int32))
         self.register_buffer("mask", torch.zeros((1, n_heads, 1, S), dtype=torch.bool))
+        if self.quantize:
+            # k_cache / v_cache stay the model-dtype WORKING cache every kernel reads (what the reference's
+            # dequantize_cache() would produce); the image the reference holds between updates lives beside it.
+            if head_dim % (8 // self.n_bit):
+                raise ColdCompressError("head_dim must be a multiple of the values packed per byte")
+            qshape = self.cache_shape if self.n_bit == 8 else (n_heads * S * head_dim * self.n_bit // 8,)
+            qdt = torch.int8 if self.n_bit == 8 else torch.uint8
+            for name in ("k", "v"):
+                self.register_buffer(f"{name}_cache_q", torch.zeros(qshape, dtype=qdt))
+                self.register_buffer(f"{name}_scales", torch.zeros((S,), dtype=dtype))
+                self.register_buffer(f"{name}_zero_points", torch.zeros((S,), dtype=dtype))
+        # the constructor quantises the zero cache (cache.py:188-197): done by the first flush
+        self._quant_pending = self.quantize
         self._scratch = _Scratch()
         self._view_cache = None
 
@@ -125,6 +141,24 @@ class KVCache(nn.Module):
         self.mask.zero_()
         self.cache_cts.zero_()
         self.pos.fill_(-1)
+        self._quant_pending = self.quantize
+
+    # ------------------------------------------------------------------ quantised KV (ref: cache.py:283-309, 323-338)
+    def quantize_cache(self):
+        """The reference quantises the whole cache at the end of every update and dequantises it at the start of the
+        next; attention in between reads the UNQUANTISED tensors update_kv returned.  Here the working cache is
+        replaced by its quantise -> dequantise round trip (one pass, cc_kv_requant) lazily — at the start of the
+        next update, or when this method is called — and the quantised image / scales / zero points are emitted."""
+        if self.quantize and self._quant_pending:
+            H, S, D = self.n_heads, self.max_cache_length, self.head_dim
+            for w, q, sc, zp in ((self.k_cache, self.k_cache_q, self.k_scales, self.k_zero_points),
+                                 (self.v_cache, self.v_cache_q, self.v_scales, self.v_zero_points)):
+                _need_device(w, "k/v cache")
+                _abi.call("cc_kv_requant", _ptr(w), _ptr(q), _ptr(sc), _ptr(zp), H, S, D, _DT[w.dtype], int(self.n_bit), _stream())
+            self._quant_pending = False
+
+    def dequantize_cache(self):
+        """No-op: k_cache / v_cache always hold the dequantised values (see quantize_cache)."""
 
     def return_attn(self):
         return False
@@ -178,10 +212,12 @@ class KVCache(nn.Module):
 
     # ------------------------------------------------------------------ update_kv (ref: cache.py:314-340)
     def update_kv(self, input_pos, k_val, v_val, is_prefill, **kwargs):
+        self.quantize_cache()  # the previous update's quantise + this update's dequantise (no-op without cache_bits)
         if is_prefill:
             self._prefill_update(input_pos, k_val, v_val, **kwargs)
         else:
             self._decoding_update(input_pos, k_val, v_val, **kwargs)
+        self._quant_pending = self.quantize
         return self.return_kv_cache()
 
     def update_state(self, *args, **kwargs):
@@ -274,6 +310,11 @@ class KVCacheL2(KVCacheHeadSpecific):
 
     def __init__(self, max_batch_size, n_heads, head_dim, dtype=torch.bfloat16, **kwargs):
         super().__init__(max_batch_size, n_heads, head_dim, dtype, **kwargs)
+        if self.quantize:
+            raise NotImplementedError(
+                "l2 with cache_bits: the reference itself fails on this path (cache.py:611 takes the norm of the "
+                "quantised int8 cache: 'linalg.vector_norm: Expected a floating point ... Got Char'), so there is "
+                "no behaviour to reproduce or pin")
         self.register_buffer("key_norm", torch.zeros((1, n_heads, self.max_cache_length), dtype=dtype))
 
     def reset(self):
@@ -345,6 +386,7 @@ class KVCacheHeavyHitter(KVCacheHeadSpecific):
         from .attention_utils import _workspace
         import math
 
+        self.quantize_cache()
         k, v = self._new_rows(k_val, v_val)
         p32 = self._pos32(input_pos)
         if not self._next_valid:
@@ -359,6 +401,7 @@ class KVCacheHeavyHitter(KVCacheHeadSpecific):
                   _ptr(self.attn_history_denom), _ptr(self.attn_counter), _ptr(self.next_key), int(self.global_tokens),
                   int(self.recent_window), HQ, 1.0 / math.sqrt(D) if scale is None else scale, _ptr(y), None, _ptr(ws),
                   ws.numel(), _stream())
+        self._quant_pending = self.quantize
         return y
 
     def _run_select(self, input_pos, k, v):
@@ -443,6 +486,11 @@ class KVCacheHybrid(KVCacheHeadSpecific):
         self.history_window_size = 400  # ScissorHands default, fixed by the reference (cache.py:789-790)
         self.recent_window = None
         super().__init__(max_batch_size, n_heads, head_dim, dtype, variable_length=True, **kwargs)
+        if self.quantize:
+            raise NotImplementedError(
+                "hybrid with cache_bits: the reference itself fails on this path (profile_and_update writes float rows "
+                "into the quantised int8 cache, cache.py:1228-1260: 'Index put requires the source and destination "
+                "dtypes match'), so there is no behaviour to reproduce or pin")
         S, W = self.max_cache_length, self.history_window_size
         self.register_buffer("attn_history_num", torch.zeros((1, n_heads, S, W), dtype=dtype))
         self.register_buffer("attn_history_denom", torch.zeros((1, n_heads, S), dtype=torch.int32))
@@ -713,5 +761,8 @@ def get_cache_constructor(cache_strategy):
     if cache_strategy.startswith("debug"):
         name = re.sub(r"debug_+", "", cache_strategy).strip()
         if name in table:
-            raise NotImplementedError(f"cache strategy '{cache_strategy}' is a SURVEY §8 follow-up and not built yet")
+            raise NotImplementedError(
+                f"cache strategy '{cache_strategy}': the reference's KVCacheAnalysis cannot be constructed at this commit "
+                "(cache.py:1319-1324 passes the full cache no cache_bits -> AttributeError in KVCache.__init__, cache.py:181), "
+                "so there is no behaviour to reproduce or pin")
     raise ValueError(f"Invalid cache strategy: {cache_strategy}")

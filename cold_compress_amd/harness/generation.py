@@ -132,7 +132,7 @@ class GraphedDecoder:
             if hasattr(c, "prepare_decode") and getattr(c, "history_window_size", 1) == 1 and not c._next_valid:
                 c.prepare_decode(self.pos)
         snap = [{k: v.clone() for k, v in c._buffers.items()} for c in caches]
-        flags = [getattr(c, "_next_valid", None) for c in caches]
+        flags = [(getattr(c, "_next_valid", None), getattr(c, "_quant_pending", False)) for c in caches]
         pos0 = self.pos.clone()
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
@@ -148,8 +148,9 @@ class GraphedDecoder:
         for c, sn, fl in zip(caches, snap, flags):
             for k, v in sn.items():
                 c._buffers[k].copy_(v)
-            if fl is not None:
-                c._next_valid = fl
+            if fl[0] is not None:
+                c._next_valid = fl[0]
+            c._quant_pending = fl[1]
 
     def __call__(self, model, x, input_pos, next_token=None, **_):
         if self.graph is None:

@@ -200,6 +200,24 @@ int cc_decode_attn_gqa_phases(const void* q, const void* k, const void* v, const
                               cc_stream_t stream, int32_t phases);
 
 /* ------------------------------------------------------------------------------------------------
+ * Quantised KV cache, --cache_bits {8, 4, 2}.  ref: quantization_utils.py:4-98 (quantize_tensor /
+ * dequantize_tensor with axis = 2), KVCache.quantize_cache / dequantize_cache cache.py:283-309, called around
+ * every update (cache.py:323-338).  One (scale, zero point) per cache slot, shared by all heads and channels;
+ * every elementwise op rounds to the cache dtype as torch does:
+ *   scale[s] = dtype(max(dtype(max_s - min_s), dtype(1e-6)) / (2^n - 1));  zero[s] = dtype(min_s + dtype(scale * 2^(n-1)));
+ *   q = clamp(roundeven(dtype(dtype(x - min_s) / scale)), 0, 2^n - 1);  dequant = dtype(dtype((q - 2^(n-1)) * scale) + zero).
+ * q image: n = 8 -> int8 [H, S, D] holding (uint8)q;  n = 4 / 2 -> uint8 [H*S*D*n/8], 8/n consecutive values of the
+ * flattened [H, S, D] tensor per byte, value j shifted left by j*n bits (D % (8/n) == 0).
+ * cc_kv_requant: work <- dequant(quant(work)) in place and the q image / scales / zeros are emitted — the
+ *   reference's quantize_cache() at the end of one update followed by dequantize_cache() at the start of the next.
+ * cc_kv_dequant: work_out <- dequant(q image) (loading a quantised state).
+ * ---------------------------------------------------------------------------------------------- */
+int cc_kv_requant(void* work, void* q_out, void* scales, void* zeros, int32_t H, int32_t S, int32_t D,
+                  int32_t dtype, int32_t n_bit, cc_stream_t stream);
+int cc_kv_dequant(const void* q, const void* scales, const void* zeros, void* work_out, int32_t H, int32_t S,
+                  int32_t D, int32_t dtype, int32_t n_bit, cc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Prefill-time cache fill.  ref: KVCache._prefill_update / _fill_contiguous cache.py:381-401.
  *   slots 0..T-1 of every head <- k_val/v_val rows; pos[hp, t] <- pos_val[min(hp,PH-1), t] (int32 cast);
  *   mask[h, t] <- 1; cache_cts[j] += T.

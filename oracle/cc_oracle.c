@@ -1022,3 +1022,84 @@ int cc_decode_step_heavy_hitter_phases_cpu(const cc_kv_view* c, const void* q, c
   return cc_decode_step_heavy_hitter_cpu(c, q, k_new, v_new, input_pos, num, denom, counter, next_key, g, w, HQ, scale, y,
                                          attn_out, workspace, workspace_bytes, stream);
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Quantised KV cache (--cache_bits {8,4,2}).  ref: quantization_utils.py:4-98 with axis = 2 (cache.py:183):
+ * ONE (scale, zero point) per cache slot s, shared by all heads and channels; every op is a torch elementwise op
+ * on tensors of the cache dtype, i.e. computed in fp32 and rounded to the dtype after EACH op (rnd()):
+ *   min, max over x[:, s, :];  scale = rnd(max(rnd(max - min), T(1e-6)) / max_int);
+ *   zero = rnd(min + rnd(scale * 2^(n-1)));  q = clamp(roundeven(rnd(rnd(x - min) / scale)), 0, max_int);
+ *   dequant = rnd(rnd((q - 2^(n-1)) * scale) + zero).
+ * Storage: n = 8 -> int8 [H, S, D] holding (uint8)q (the reference's .to(int8) wraps);  n = 4 / 2 -> 8/n consecutive
+ * values of the flattened [H, S, D] tensor per byte, value j of the group shifted left by j*n bits.
+ * cc_kv_requant = quantize_cache() followed by dequantize_cache() (cache.py:283-309): `work` is replaced by its
+ * quantise -> dequantise round trip and the quantised image is emitted.
+ * ---------------------------------------------------------------------------------------------- */
+static int quant_args_ok(int32_t H, int32_t S, int32_t D, int32_t dt, int32_t n_bit) {
+  return H > 0 && S > 0 && D > 0 && dt_ok(dt) && (n_bit == 8 || n_bit == 4 || n_bit == 2) && (D % (8 / n_bit)) == 0;
+}
+
+static void q_store(uint8_t* q, size_t i, int n_bit, int v) {
+  if (n_bit == 8) { q[i] = (uint8_t)v; return; }
+  const int per = 8 / n_bit;
+  const size_t byte = i / per;
+  const int sh = (int)(i % per) * n_bit;
+  q[byte] = (uint8_t)((q[byte] & ~(((1u << n_bit) - 1u) << sh)) | ((unsigned)v << sh));
+}
+
+static int q_load(const uint8_t* q, size_t i, int n_bit) {
+  if (n_bit == 8) return q[i];
+  const int per = 8 / n_bit;
+  return (q[i / per] >> ((int)(i % per) * n_bit)) & ((1 << n_bit) - 1);
+}
+
+int cc_kv_requant_cpu(void* work, void* q_out, void* scales, void* zeros, int32_t H, int32_t S, int32_t D, int32_t dt,
+                      int32_t n_bit, cc_stream_t stream) {
+  (void)stream;
+  if (!work || !q_out || !scales || !zeros || !quant_args_ok(H, S, D, dt, n_bit)) return CC_ERR_BAD_ARG;
+  const int max_int = (1 << n_bit) - 1, half = 1 << (n_bit - 1);
+  for (int s = 0; s < S; s++) {
+    float mn = INFINITY, mx = -INFINITY;
+    for (int h = 0; h < H; h++)
+      for (int d = 0; d < D; d++) {
+        const float x = ld(work, dt, ((size_t)h * S + s) * D + d);
+        if (x < mn) mn = x;
+        if (x > mx) mx = x;
+      }
+    float range = rnd(mx - mn, dt);
+    const float floor_t = rnd(1e-6f, dt);
+    if (range < floor_t) range = floor_t;
+    const float scale = rnd(range / (float)max_int, dt);
+    const float zero = rnd(mn + rnd(scale * (float)half, dt), dt);
+    st(scales, dt, (size_t)s, scale);
+    st(zeros, dt, (size_t)s, zero);
+    for (int h = 0; h < H; h++)
+      for (int d = 0; d < D; d++) {
+        const size_t i = ((size_t)h * S + s) * D + d;
+        float t = rnd(rnd(ld(work, dt, i) - mn, dt) / scale, dt);
+        t = nearbyintf(t);  /* round half to even (default rounding mode), as torch.round */
+        if (t < 0.f) t = 0.f;
+        if (t > (float)max_int) t = (float)max_int;
+        const int q = (int)t;
+        q_store((uint8_t*)q_out, i, n_bit, q);
+        st(work, dt, i, rnd(rnd((float)(q - half) * scale, dt) + zero, dt));
+      }
+  }
+  return CC_OK;
+}
+
+int cc_kv_dequant_cpu(const void* q, const void* scales, const void* zeros, void* work_out, int32_t H, int32_t S, int32_t D,
+                      int32_t dt, int32_t n_bit, cc_stream_t stream) {
+  (void)stream;
+  if (!q || !scales || !zeros || !work_out || !quant_args_ok(H, S, D, dt, n_bit)) return CC_ERR_BAD_ARG;
+  const int half = 1 << (n_bit - 1);
+  for (int h = 0; h < H; h++)
+    for (int s = 0; s < S; s++) {
+      const float scale = ld(scales, dt, (size_t)s), zero = ld(zeros, dt, (size_t)s);
+      for (int d = 0; d < D; d++) {
+        const size_t i = ((size_t)h * S + s) * D + d;
+        st(work_out, dt, i, rnd(rnd((float)(q_load((const uint8_t*)q, i, n_bit) - half) * scale, dt) + zero, dt));
+      }
+    }
+  return CC_OK;
+}

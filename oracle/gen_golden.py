@@ -16,6 +16,8 @@ Fixtures:
   f5_compress.npz         prompt_compression.* priorities -> keep_idxs (+ boundary-tie flags)
   f7_attn_<dtype>.npz     attention_utils.scaled_dot_product_attention decode + small prefill
   f8_budgets.json         generation_utils budget arithmetic
+  f9_quant_*.npz          --cache_bits: quantize/dequantize known answers, quantised heavy-hitter / recent-global replays
+                          (the K/V attention sees at every step + the final int8 / packed images), one end-to-end run
 Low-precision tensors are stored as their uint16 bit patterns with a "<name>__dtype" tag.
 """
 import argparse
@@ -138,6 +140,12 @@ def run_e2e(C, G, M, name, cache_args, prompt_len=40, new_tokens=12, seed=0, n_l
             d[f"final_denom_L{li}"] = kv.attn_history_denom.clone()
         if hasattr(kv, "key_norm"):
             d[f"final_keynorm_L{li}"] = kv.key_norm.clone()
+        if getattr(kv, "quantize", False):
+            d[f"final_v_L{li}"] = kv.v_cache.clone()
+            d[f"final_k_scales_L{li}"] = kv.k_scales.clone()
+            d[f"final_k_zero_points_L{li}"] = kv.k_zero_points.clone()
+            d[f"final_v_scales_L{li}"] = kv.v_scales.clone()
+            d[f"final_v_zero_points_L{li}"] = kv.v_zero_points.clone()
     cs = model.get_cache_stats(prompt_len, new_tokens)
     d["compression_ratio_avg"] = cs["compression_ratio_avg"]
     return pack(d)
@@ -153,7 +161,7 @@ def softmax_rows(shape, dtype, gen, mask=None):
     return torch.softmax(x, dim=-1).to(dtype)
 
 
-def replay_cache(C, strategy, dtype, H, S, D, T_prefill, steps, g, w, seed, extra=None, rand_capture=None):
+def replay_cache(C, strategy, dtype, H, S, D, T_prefill, steps, g, w, seed, extra=None, rand_capture=None, capture_kv=False):
     """Drive a reference cache exactly as model.py:389-427 does and record inputs/outputs."""
     gen = torch.Generator().manual_seed(seed)
     cls, rk = C.get_cache_constructor(strategy)
@@ -193,7 +201,10 @@ def replay_cache(C, strategy, dtype, H, S, D, T_prefill, steps, g, w, seed, extr
             r = torch.rand(S, generator=gen)
             rands.append(r)
             rand_capture["next"] = r
-        kv.update_kv(p, k1, v1, False, input_ids=torch.tensor([[1]]))
+        ret = kv.update_kv(p, k1, v1, False, input_ids=torch.tensor([[1]]))
+        if capture_kv:  # what attention sees this step (quantised caches: the dequantised tensors, cache.py:333-338)
+            rec.setdefault("_k_ret", []).append(ret[0].clone())
+            rec.setdefault("_v_ret", []).append(ret[1].clone())
         changed = (kv.pos != pos_before)
         # idx per pos-head = the slot whose pos changed (pos always changes: p is new)
         idx = changed.squeeze(0).int().argmax(dim=-1)
@@ -220,7 +231,40 @@ def replay_cache(C, strategy, dtype, H, S, D, T_prefill, steps, g, w, seed, extr
         rec["final_keynorm"] = kv.key_norm.clone()
     rec.update({"final_pos": kv.pos.clone(), "final_mask": kv.mask.clone(), "final_cts": kv.cache_cts.clone(),
                 "final_k": kv.k_cache.clone(), "final_v": kv.v_cache.clone()})
+    if capture_kv:
+        rec["k_ret"] = torch.stack(rec.pop("_k_ret"))
+        rec["v_ret"] = torch.stack(rec.pop("_v_ret"))
+    if getattr(kv, "quantize", False):
+        rec.update({"k_scales": kv.k_scales.clone(), "v_scales": kv.v_scales.clone(), "k_zero_points": kv.k_zero_points.clone(),
+                    "v_zero_points": kv.v_zero_points.clone(), "cache_bits": kv.n_bit})
     return pack(rec)
+
+
+# ------------------------------------------------------------------------------------------------ F9 (quantised KV)
+
+
+def quant_cases():
+    """quantization_utils.quantize_tensor / dequantize_tensor with axis = 2 on [1, H, S, D] tensors: known answers."""
+    import quantization_utils as Q
+
+    gen = torch.Generator().manual_seed(23)
+    out = {}
+    H, S, D = 3, 40, 16
+    for dt, tag in ((torch.float32, "f32"), (torch.bfloat16, "bf16"), (torch.float16, "f16")):
+        x = (torch.randn(1, H, S, D, generator=gen) * 1.7).to(dt)
+        x[:, :, 5] = 0  # an empty slot (range 0 -> the 1e-6 floor)
+        x[:, :, 6] = 0.75  # a constant slot
+        x[:, :, 7] *= 1e-4  # tiny range
+        x[:, :, 8] *= 300.0  # large range
+        out[f"x_{tag}"] = x
+        for nb in (8, 4, 2):
+            q, sc, zp = Q.quantize_tensor(x, n_bit=nb, axis=2)
+            y = Q.dequantize_tensor(q, sc, zp, x.shape, n_bit=nb, axis=2)
+            out[f"q_{tag}_{nb}"] = q.contiguous().view(torch.uint8) if q.dtype == torch.int8 else q
+            out[f"scales_{tag}_{nb}"] = sc
+            out[f"zeros_{tag}_{nb}"] = zp
+            out[f"y_{tag}_{nb}"] = y.contiguous()
+    return pack(out)
 
 
 # ------------------------------------------------------------------------------------------------ F5
@@ -497,6 +541,20 @@ def main():
         # attn_thresholding=True cannot be captured: the reference itself raises at cache.py:721
         # ("Index put requires the source and destination dtypes match, got Bool ... and Int") on torch 2.10.
         if a.only == "f2w":
+            return
+
+    if a.only in (None, "f9"):
+        save("f9_quant_known_answers.npz", quant_cases())
+        for dt, tag in ((torch.float32, "f32"), (torch.bfloat16, "bf16")):
+            for nb in (8, 4, 2):
+                save(f"f9_quant_hh_{tag}_{nb}.npz", replay_cache(C, "heavy_hitter", dt, H=3, S=24, D=16, T_prefill=17, steps=20, g=2,
+                                                                w=3, seed=31 + nb, extra=dict(cache_bits=nb), capture_kv=True))
+        save("f9_quant_recent_global_f32_8.npz", replay_cache(C, "recent_global", torch.float32, H=2, S=16, D=8, T_prefill=16, steps=12,
+                                                              g=4, w=3, seed=5, extra=dict(cache_bits=8), capture_kv=True))
+        save("f9_e2e_heavy_hitter_q8.npz", run_e2e(C, G, M, "heavy_hitter", dict(
+            cache_strategy=["heavy_hitter"], prompt_compression_strategy=["heavy_hitter"], max_cache_length=[32],
+            global_tokens=4, recent_window=4, cache_bits=8), prompt_len=56, new_tokens=24))
+        if a.only == "f9":
             return
 
     # F1: config C1 (README.md:103 of the reference) + companions on the same tiny model

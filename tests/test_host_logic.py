@@ -99,9 +99,20 @@ def test_buffers_and_statistics_on_cpu():
     assert abs(st["cache_memory_gb"] - nbytes / 2 ** 30) < 1e-12
     kv.reset()
     assert int(kv.cache_cts[0]) == 0
-    for bad in (dict(cache_bits=4), dict(attn_thresholding=True)):
-        with pytest.raises(NotImplementedError):
-            cache.KVCacheHeavyHitter(1, 2, 8, torch.bfloat16, **{**kw, **bad})
+    with pytest.raises(NotImplementedError):  # the reference itself crashes on this path
+        cache.KVCacheHeavyHitter(1, 2, 8, torch.bfloat16, **{**kw, "attn_thresholding": True})
+    # quantised KV (cache.py:180-198): the image the reference holds + one (scale, zero point) per slot
+    q4 = cache.KVCacheHeavyHitter(1, 2, 8, torch.bfloat16, **{**kw, "cache_bits": 4})
+    assert q4.k_cache_q.dtype == torch.uint8 and q4.k_cache_q.shape == (2 * 16 * 8 // 2,) and q4.k_scales.shape == (16,)
+    q8 = cache.KVCacheRecentGlobal(1, 2, 8, torch.float32, max_cache_length=16, global_tokens=2, max_seq_length=64, cache_bits=8)
+    assert q8.k_cache_q.dtype == torch.int8 and q8.k_cache_q.shape == (1, 2, 16, 8) and q8.v_zero_points.dtype == torch.float32
+    q8.cache_cts.fill_(10)
+    assert abs(q8.compute_statistics(torch.tensor(41))["compression_ratio"] - (40 - 10 * 8 / 16) / 40) < 1e-6  # cache.py:279-281
+    for cls, extra in ((cache.KVCacheL2, dict(recent_window=3)), ):
+        with pytest.raises(NotImplementedError):  # reference crashes: norm of the int8 image
+            cls(1, 2, 8, torch.bfloat16, max_cache_length=16, global_tokens=2, max_seq_length=64, cache_bits=8, **extra)
+    with pytest.raises(NotImplementedError):  # KVCacheAnalysis cannot be constructed in the reference either
+        cache.get_cache_constructor("debug_heavy_hitter")
     ring = cache.KVCacheHeavyHitter(1, 2, 8, torch.bfloat16, **{**kw, "history_window_size": 4})
     assert ring.attn_history_num.shape == (1, 2, 16, 4) and ring.attn_history_num.dtype == torch.bfloat16  # cache.py:661-667
     assert ring.fused_history() is None
