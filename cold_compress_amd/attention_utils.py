@@ -10,7 +10,7 @@ Differences from the reference that a caller can rely on:
   * Prefill with `return_attn=True` returns an `AttnSummary` (column sums + observation-window mean) instead
     of the [1, HQ, L, L] tensor; every policy in cache.py / prompt_compression.py consumes exactly that.
   * `history=(num, denom, counter)` folds the heavy-hitter history update into the decode combine pass.
-Unsupported (raised loudly): dropout_p != 0, attn_top_k < 1, non-causal prefill masks.
+Unsupported (raised loudly): dropout_p != 0, non-causal prefill masks; attn_top_k < 1 asserts with a mask, like the reference.
 """
 import ctypes as C
 import math
@@ -122,6 +122,30 @@ def _is_causal_mask(attn_mask, L):
     return bool((attn_mask.reshape(-1, L, L) == tril).all())
 
 
+def _topk_decode_attention(query, key, value, attn_mask, scale, top_k):
+    """ref: attention_utils.py:24-26, 40-50 — decode attention over the top-k logits only.  The reference asserts when
+    a mask is present ("Top-k attention not supported with masks."), and its model always passes the cache mask at
+    decode time (model.py:389-396), so this is reachable only by a direct, mask-less call with keys already
+    expanded to the query heads — reproduced with the same behaviour: same assertion; otherwise softmax over the
+    k largest logits (a membership mask fed to the decode kernel), probabilities returned in top-k order."""
+    assert attn_mask is None, "Top-k attention not supported with masks."
+    from .prompt_compression import topk_keep
+
+    _, HQ, _, D = query.shape
+    H, S = key.shape[1], key.shape[2]
+    if H != HQ:
+        raise ColdCompressError("top-k decode attention selects per query head: expand K/V to the query heads (reference call shape)")
+    _, probs = decode_attention(query, key, value, None, scale, True, False, None)  # softmax is monotone: same top-k set
+    p2 = probs.reshape(HQ, S)
+    keep = topk_keep(p2, top_k)  # ascending indices, ties lowest-index-first
+    member = torch.zeros((1, HQ, 1, S), dtype=torch.bool, device=query.device)
+    member.view(HQ, S).scatter_(1, keep, True)
+    y, p_sel = decode_attention(query, key, value, member, scale, True, False, None)
+    vals = p_sel.reshape(HQ, S).gather(1, keep)
+    order = torch.sort(vals.float(), dim=1, descending=True, stable=True).indices  # torch.topk returns descending values
+    return y, vals.gather(1, order).view(1, HQ, 1, top_k)
+
+
 def scaled_dot_product_attention(query, key, value, attn_mask=None, dropout_p=0.0, scale=None, return_attn=False,
                                  attn_top_k=1.0, group_mean=False, history=None, is_causal=None, bands=()):
     """ref: attention_utils.py:8-54 (same positional/keyword surface; extra keywords documented above)."""
@@ -129,8 +153,9 @@ def scaled_dot_product_attention(query, key, value, attn_mask=None, dropout_p=0.
         raise ColdCompressError("dropout is not part of the inference path")
     L, S = query.size(-2), key.size(-2)
     if L == 1:
-        if int(attn_top_k * S) != S:
-            raise NotImplementedError("attn_top_k < 1 is a SURVEY §8(f) follow-up and not built yet")
+        top_k = int(attn_top_k * S)
+        if top_k != S:
+            return _topk_decode_attention(query, key, value, attn_mask, scale, top_k)
         return decode_attention(query, key, value, attn_mask, scale, return_attn, group_mean, history)
     if is_causal is None:
         is_causal = _is_causal_mask(attn_mask, L)

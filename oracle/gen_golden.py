@@ -370,6 +370,26 @@ def attn_cases(A, dtype):
     return pack(out)
 
 
+def attn_topk_case(A):
+    """attention_utils.py:24-26, 45-50: top-k decode attention (L == 1, NO mask — with a mask the reference asserts)."""
+    gen = torch.Generator().manual_seed(9)
+    H, S, D = 4, 64, 16
+    q = torch.randn(1, H, 1, D, generator=gen)
+    k = torch.randn(1, H, S, D, generator=gen)
+    v = torch.randn(1, H, S, D, generator=gen)
+    out = {"q": q, "k": k, "v": v}
+    for frac in (0.25, 0.5):
+        y, p = A.scaled_dot_product_attention(q, k, v, attn_mask=None, return_attn=True, attn_top_k=frac)
+        out[f"y_{int(frac * 100)}"] = y
+        out[f"p_{int(frac * 100)}"] = p
+    try:
+        A.scaled_dot_product_attention(q, k, v, attn_mask=torch.ones(1, H, 1, S, dtype=torch.bool), return_attn=True, attn_top_k=0.5)
+        out["mask_asserts"] = np.array(False)
+    except AssertionError:
+        out["mask_asserts"] = np.array(True)
+    return pack(out)
+
+
 # ------------------------------------------------------------------------------------------------ F8
 
 
@@ -541,6 +561,11 @@ def main():
         # attn_thresholding=True cannot be captured: the reference itself raises at cache.py:721
         # ("Index put requires the source and destination dtypes match, got Bool ... and Int") on torch 2.10.
         if a.only == "f2w":
+            return
+
+    if a.only in (None, "f7k"):
+        save("f7_attn_topk_f32.npz", attn_topk_case(A))
+        if a.only == "f7k":
             return
 
     if a.only in (None, "f9"):

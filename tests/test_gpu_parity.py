@@ -399,3 +399,21 @@ def test_cpu_tensors_are_refused(cc):
     kv = cls(1, 2, 16, torch.float32, **{k: kw[k] for k in rk})  # buffers on CPU
     with pytest.raises(ColdCompressError):
         kv.update_kv(torch.arange(4), torch.zeros(1, 2, 4, 16), torch.zeros(1, 2, 4, 16), True)
+
+
+def test_topk_decode_attention_matches_reference():
+    """attention_utils.py:24-26, 45-50 (attn_top_k < 1, L == 1, no mask): output and the top-k probabilities (descending
+    order, as torch.topk returns them) within 1e-5 in fp32; with a mask the reference asserts, and so do we."""
+    from cold_compress_amd.attention_utils import scaled_dot_product_attention as sdpa
+
+    f = load_golden("f7_attn_topk_f32.npz")
+    assert f["mask_asserts"] == 1
+    q, k, v = f["q"].to(DEV), f["k"].to(DEV), f["v"].to(DEV)
+    for pct in (25, 50):
+        y, p = sdpa(q, k, v, attn_mask=None, return_attn=True, attn_top_k=pct / 100.0)
+        torch.cuda.synchronize()
+        assert p.shape == f[f"p_{pct}"].shape
+        assert (y.cpu() - f[f"y_{pct}"]).abs().max() < 1e-5
+        assert (p.cpu() - f[f"p_{pct}"]).abs().max() < 1e-5
+    with pytest.raises(AssertionError, match="Top-k attention not supported with masks"):
+        sdpa(q, k, v, attn_mask=torch.ones(1, 4, 1, 64, dtype=torch.bool, device=DEV), return_attn=True, attn_top_k=0.5)
