@@ -1,0 +1,329 @@
+// cc_gemv.hip — the five dense matrix-vector products of a decode layer, with the caller glue fused in:
+//   wqkv : RMSNorm(x + delta) prologue (the pending residual add included) + RoPE epilogue on the q / k rows
+//   wo   : plain
+//   w1/w3: RMSNorm prologue + SwiGLU epilogue  silu(w1·n) * (w3·n)  (one pass over both matrices)
+//   w2   : plain
+// ref (caller side): model.py:317-327 (pre-norm block), :375-387 (split + apply_rotary_emb), :442-443 (FFN),
+// :452-457 (RMSNorm), :507-519 (RoPE).  Eleven launches per layer become six; every rounding point of the eager
+// bf16 chain is kept (each tensor op rounds to the model dtype).
+//
+// HBM-bound streaming of W (batch 1: 2 flops per 2-byte weight).  One WAVE owns a row at a time: its 64 lanes
+// stride over K with 16-byte loads (one fully coalesced 1 KiB segment per load instruction), RB rows and CU
+// column steps are in flight together (RB*CU 16-byte loads per lane), products go through v_dot2c_f32_bf16 /
+// v_dot2_f32_f16 (fp32 accumulate), the row total through 4 DPP steps + 4 v_readlane.  The input vector is
+// normalised ONCE per workgroup into LDS as packed 16-bit (every workgroup recomputes the 8 KiB norm rather than
+// paying a launch for it) and read back with ds_read_b128 shared by the RB rows.  No atomics, fixed orders.
+#include <cstdio>
+#include <cstdlib>
+
+#include "cc_common.h"
+
+namespace {
+
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+
+template <typename T>
+struct Dot16;  // acc += <16 bytes of W, 16 bytes of x>
+template <>
+struct Dot16<bf16_t> {
+  __device__ static __forceinline__ float run(uint4 w, uint4 x, float acc) {
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w.x), __builtin_bit_cast(bf16x2_t, x.x), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w.y), __builtin_bit_cast(bf16x2_t, x.y), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w.z), __builtin_bit_cast(bf16x2_t, x.z), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w.w), __builtin_bit_cast(bf16x2_t, x.w), acc, false);
+    return acc;
+  }
+};
+template <>
+struct Dot16<f16_t> {
+  __device__ static __forceinline__ float run(uint4 w, uint4 x, float acc) {
+    acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2_t, w.x), __builtin_bit_cast(f16x2_t, x.x), acc, false);
+    acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2_t, w.y), __builtin_bit_cast(f16x2_t, x.y), acc, false);
+    acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2_t, w.z), __builtin_bit_cast(f16x2_t, x.z), acc, false);
+    acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2_t, w.w), __builtin_bit_cast(f16x2_t, x.w), acc, false);
+    return acc;
+  }
+};
+template <>
+struct Dot16<float> {
+  __device__ static __forceinline__ float run(uint4 w, uint4 x, float acc) {
+    acc = fmaf(__uint_as_float(w.x), __uint_as_float(x.x), acc);
+    acc = fmaf(__uint_as_float(w.y), __uint_as_float(x.y), acc);
+    acc = fmaf(__uint_as_float(w.z), __uint_as_float(x.z), acc);
+    acc = fmaf(__uint_as_float(w.w), __uint_as_float(x.w), acc);
+    return acc;
+  }
+};
+
+template <int CTRL>
+__device__ __forceinline__ float gv_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+// whole-wave sum with a wave-uniform result (4 DPP steps per 16-lane row, 4 v_readlane); fixed order
+__device__ __forceinline__ float gv_wave_sum(float v) {
+  v += gv_dpp<0xB1>(v);
+  v += gv_dpp<0x4E>(v);
+  v += gv_dpp<0x141>(v);
+  v += gv_dpp<0x140>(v);
+  const int u = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(u, 0));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(u, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(u, 32));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(u, 48));
+  return (r0 + r1) + (r2 + r3);
+}
+
+struct GemvArgs {
+  const void* W;
+  const void* W3;      // second matrix of the SwiGLU pair, or null
+  const void* x;       // [K]
+  const void* delta;   // [K] pending residual, or null
+  const void* norm_w;  // [K] RMSNorm weight, or null (no norm prologue)
+  const void* bias;    // [N] or null
+  const void* freqs;   // [head_dim/2, 2] (cos, sin) of this position, or null
+  void* h_out;         // [K] x + delta, or null
+  void* y;             // [N]
+  float eps;
+  int N, K, rope_rows, head_dim;
+};
+
+constexpr int kGvThreads = 256;
+constexpr int kGvWaves = kGvThreads / 64;
+
+template <typename T>
+__device__ __forceinline__ uint4 pack16(const float* f) {
+  if constexpr (sizeof(T) == 4) {
+    return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+  } else {
+    T e[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) ElemTraits<T>::store(&e[i], 0, f[i]);
+    return make_uint4((uint32_t)e[0].x | ((uint32_t)e[1].x << 16), (uint32_t)e[2].x | ((uint32_t)e[3].x << 16),
+                      (uint32_t)e[4].x | ((uint32_t)e[5].x << 16), (uint32_t)e[6].x | ((uint32_t)e[7].x << 16));
+  }
+}
+
+template <typename T, bool SWIGLU, int RB, int CU>
+__global__ __launch_bounds__(kGvThreads) void gemv_kernel(GemvArgs a) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  extern __shared__ __attribute__((aligned(16))) uint4 sm_x[];  // [K / VEC] the (normalised) input, packed T
+  __shared__ float sm_red[kGvWaves];
+  __shared__ float sm_part[kGvWaves][2][RB];
+  const int K = a.K, N = a.N;
+  const int nch = K / VEC;
+  const T* xg = reinterpret_cast<const T*>(a.x);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+  // ---- Work decomposition: a WORKGROUP owns RB consecutive rows at a time; its four waves split K (wave w takes
+  //      the 1 KiB segments w, w+4, w+8, ... of every row), CU segments per row in flight per wave, and the four
+  //      partial sums meet in LDS.  For the decode shapes this puts a whole matrix in flight in one phase
+  //      (wo: 4 rows x 2 segments per wave; w2: 2-4 rows x 7 segments) instead of looping inside a wave.
+  //      The FIRST tile's weight loads are issued before the input vector is staged: W does not depend on x, and
+  //      the norm prologue (two passes over x plus a barrier) would otherwise sit in front of the first HBM request.
+  const int nseg = (nch + 63) / 64;                      // 1 KiB segments per row
+  const int nstep = (nseg + kGvWaves - 1) / kGvWaves;    // segments per wave
+  const uint4* Wv = reinterpret_cast<const uint4*>(a.W);
+  const uint4* W3v = reinterpret_cast<const uint4*>(a.W3);
+  uint4 w[RB][CU], w3[RB][CU];
+  auto issue = [&](int r0, int s0) {
+#pragma unroll
+    for (int u = 0; u < CU; u++) {
+      const int c = ((s0 + u) * kGvWaves + wave) * 64 + lane;
+      const bool cin = (s0 + u < nstep) && c < nch;
+#pragma unroll
+      for (int r = 0; r < RB; r++) {
+        const bool in = cin && (r0 + r < N);
+        const size_t off = (size_t)(r0 + r) * nch + c;
+        w[r][u] = in ? Wv[off] : make_uint4(0, 0, 0, 0);
+        if (SWIGLU) w3[r][u] = in ? W3v[off] : make_uint4(0, 0, 0, 0);
+      }
+    }
+  };
+  const int row_first = blockIdx.x * RB;
+  if (row_first < N) issue(row_first, 0);
+
+  // ---- prologue: stage the input vector (normalised if asked) into LDS
+  if (a.norm_w != nullptr) {
+    const T* dg = reinterpret_cast<const T*>(a.delta);
+    const T* wg = reinterpret_cast<const T*>(a.norm_w);
+    float ss = 0.f;
+    for (int c = threadIdx.x; c < nch; c += kGvThreads) {
+      Vec16<T> xv;
+      float h[VEC];
+      xv.load(xg + (size_t)c * VEC);
+      xv.unpack(h);
+      if (dg != nullptr) {
+        Vec16<T> dv;
+        float d[VEC];
+        dv.load(dg + (size_t)c * VEC);
+        dv.unpack(d);
+#pragma unroll
+        for (int e = 0; e < VEC; e++) h[e] = ElemTraits<T>::rnd(__fadd_rn(h[e], d[e]));  // model-dtype residual add
+      }
+#pragma unroll
+      for (int e = 0; e < VEC; e++) ss = fmaf(h[e], h[e], ss);
+      const uint4 hp = pack16<T>(h);
+      sm_x[c] = hp;
+      if (a.h_out != nullptr && blockIdx.x == 0) reinterpret_cast<uint4*>(a.h_out)[c] = hp;
+    }
+    ss = gv_wave_sum(ss);
+    if (lane == 0) sm_red[wave] = ss;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int wv = 0; wv < kGvWaves; wv++) tot += sm_red[wv];
+    const float rs = rsqrtf(tot / (float)K + a.eps);  // ref: model.py:452-457 (fp32 inside)
+    for (int c = threadIdx.x; c < nch; c += kGvThreads) {
+      Vec16<T> hv, wv;
+      float h[VEC], wf[VEC], o[VEC];
+      hv.raw = sm_x[c];
+      hv.unpack(h);
+      wv.load(wg + (size_t)c * VEC);
+      wv.unpack(wf);
+#pragma unroll
+      for (int e = 0; e < VEC; e++) o[e] = ElemTraits<T>::rnd(__fmul_rn(ElemTraits<T>::rnd(__fmul_rn(h[e], rs)), wf[e]));
+      sm_x[c] = pack16<T>(o);
+    }
+  } else {
+    for (int c = threadIdx.x; c < nch; c += kGvThreads) sm_x[c] = reinterpret_cast<const uint4*>(xg)[c];
+  }
+  __syncthreads();
+
+  T* yo = reinterpret_cast<T*>(a.y);
+  bool first = true;
+  for (int r0 = row_first; r0 < N; r0 += gridDim.x * RB) {
+    float acc[RB], acc3[RB];
+#pragma unroll
+    for (int r = 0; r < RB; r++) acc[r] = acc3[r] = 0.f;
+    for (int s0 = 0; s0 < nstep; s0 += CU) {
+      if (!first) issue(r0, s0);
+      first = false;
+#pragma unroll
+      for (int u = 0; u < CU; u++) {
+        const int c = ((s0 + u) * kGvWaves + wave) * 64 + lane;
+        const uint4 xv = ((s0 + u < nstep) && c < nch) ? sm_x[c] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < RB; r++) {
+          acc[r] = Dot16<T>::run(w[r][u], xv, acc[r]);
+          if (SWIGLU) acc3[r] = Dot16<T>::run(w3[r][u], xv, acc3[r]);
+        }
+      }
+    }
+    // ---- the four K-quarters of every row meet in LDS (fixed order: deterministic)
+#pragma unroll
+    for (int r = 0; r < RB; r++) {
+      const float s = gv_wave_sum(acc[r]);
+      float s3 = 0.f;
+      if (SWIGLU) s3 = gv_wave_sum(acc3[r]);
+      if (lane == 0) {
+        sm_part[wave][0][r] = s;
+        if (SWIGLU) sm_part[wave][1][r] = s3;
+      }
+    }
+    __syncthreads();
+    if (wave == 0) {
+      float out = 0.f;  // lane r finishes row r0 + r
+      const int r = lane < RB ? lane : 0;
+      float s = (sm_part[0][0][r] + sm_part[1][0][r]) + (sm_part[2][0][r] + sm_part[3][0][r]);
+      const int row = r0 + r;
+      if (a.bias != nullptr && row < N) s += ElemTraits<T>::load(reinterpret_cast<const T*>(a.bias), (size_t)row);
+      s = ElemTraits<T>::rnd(s);  // the Linear's output in the model dtype
+      if (SWIGLU) {
+        const float s3 = ElemTraits<T>::rnd((sm_part[0][1][r] + sm_part[1][1][r]) + (sm_part[2][1][r] + sm_part[3][1][r]));
+        const float sl = ElemTraits<T>::rnd(__fdiv_rn(s, 1.0f + expf(-s)));  // F.silu -> dtype (model.py:443)
+        s = __fmul_rn(sl, s3);
+      }
+      out = s;
+      if (a.freqs != nullptr) {  // RoPE on the (even, odd) row pairs of the q / k heads (model.py:507-519)
+        const float other = gv_dpp<0xB1>(out);  // the pair partner lives in lane ^ 1 (r0 is even)
+        if (row < a.rope_rows) {
+          const int pr = (row % a.head_dim) >> 1;
+          const float c = ElemTraits<T>::load(reinterpret_cast<const T*>(a.freqs), (size_t)pr * 2);
+          const float sn = ElemTraits<T>::load(reinterpret_cast<const T*>(a.freqs), (size_t)pr * 2 + 1);
+          out = (row & 1) ? __fadd_rn(__fmul_rn(out, c), __fmul_rn(other, sn)) : __fsub_rn(__fmul_rn(out, c), __fmul_rn(other, sn));
+        }
+      }
+      if (lane < RB && row < N) ElemTraits<T>::store(yo, (size_t)row, out);
+    }
+    __syncthreads();  // sm_part is reused by the next row group
+  }
+}
+
+struct GvCfg {
+  int rb, cu, cap;
+};
+
+static GvCfg pick_cfg(const GemvArgs& a, int vec) {
+  static int env_rb = -1, env_cu = -1, env_cap = 2048;
+  if (env_rb < 0) {  // tuning hook: CC_GEMV_CFG="RB,CU[,max workgroups]"
+    env_rb = env_cu = 0;
+    if (const char* e = getenv("CC_GEMV_CFG")) sscanf(e, "%d,%d,%d", &env_rb, &env_cu, &env_cap);
+  }
+  if (env_rb > 0 && env_cu > 0) return {env_rb, env_cu, env_cap};
+  const int nseg = (a.K / vec + 63) / 64, nstep = (nseg + kGvWaves - 1) / kGvWaves;
+  // measured on MI355X (tools/bench_gemv.py): many small workgroups beat few large ones — 2 rows x 2 segments per
+  // wave for K = 4096 (wo 8.3 us, wqkv 10.5 us, w1 21.9 us = 5.35 TB/s), 4 x 4 for K = 14336 (w2 24.4 us)
+  GvCfg c;
+  c.cap = 2048;
+  if (nstep <= 2) {
+    c.rb = 2; c.cu = 2;
+  } else if (a.W3 != nullptr) {
+    c.rb = 2; c.cu = nstep <= 4 ? 4 : 8;
+  } else {
+    c.rb = 4; c.cu = 4;
+  }
+  return c;
+}
+
+template <typename T, bool SWIGLU, int RB, int CU>
+static void launch_cfg(const GemvArgs& a, hipStream_t st, int cap) {
+  const size_t lds = (size_t)a.K * sizeof(T);
+  int blocks = (a.N + RB - 1) / RB;
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL((gemv_kernel<T, SWIGLU, RB, CU>), dim3(blocks), dim3(kGvThreads), lds, st, a);
+}
+
+template <typename T>
+static int launch_gemv(const GemvArgs& a, hipStream_t st) {
+  const GvCfg c = pick_cfg(a, 16 / (int)sizeof(T));
+  const int key = (a.W3 ? 1000 : 0) + c.rb * 10 + c.cu;
+  switch (key) {
+    case 22: launch_cfg<T, false, 2, 2>(a, st, c.cap); break;
+    case 42: launch_cfg<T, false, 4, 2>(a, st, c.cap); break;
+    case 82: launch_cfg<T, false, 8, 2>(a, st, c.cap); break;
+    case 24: launch_cfg<T, false, 2, 4>(a, st, c.cap); break;
+    case 44: launch_cfg<T, false, 4, 4>(a, st, c.cap); break;
+    case 28: launch_cfg<T, false, 2, 8>(a, st, c.cap); break;
+    case 48: launch_cfg<T, false, 4, 8>(a, st, c.cap); break;
+    case 1022: launch_cfg<T, true, 2, 2>(a, st, c.cap); break;
+    case 1042: launch_cfg<T, true, 4, 2>(a, st, c.cap); break;
+    case 1024: launch_cfg<T, true, 2, 4>(a, st, c.cap); break;
+    case 1028: launch_cfg<T, true, 2, 8>(a, st, c.cap); break;
+    default: return CC_ERR_UNSUPPORTED;
+  }
+  CC_LAUNCH_CHECK();
+  return CC_OK;
+}
+
+}  // namespace
+
+extern "C" int cc_gemv_fused(const void* W, const void* W3, const void* x, const void* delta, const void* norm_w, float eps,
+                             void* h_out, const void* bias, const void* freqs, int32_t rope_rows, int32_t head_dim, void* y,
+                             int32_t N, int32_t K, int32_t dtype, cc_stream_t stream) {
+  CC_ENTRY();
+  if (!W || !x || !y || N <= 0 || K <= 0 || !cc_dt_ok(dtype)) return CC_ERR_BAD_ARG;
+  if ((delta || h_out) && !norm_w) return CC_ERR_BAD_ARG;
+  if (freqs && (W3 || rope_rows < 0 || rope_rows > N || head_dim <= 0 || (head_dim & 1) || (rope_rows % head_dim))) return CC_ERR_BAD_ARG;
+  if (W3 && bias) return CC_ERR_BAD_ARG;
+  const int vec = 16 / (int)cc_dt_size(dtype);
+  if (K % vec) return CC_ERR_UNSUPPORTED;
+  if ((size_t)K * cc_dt_size(dtype) > 64 * 1024) return CC_ERR_UNSUPPORTED;  // the input vector lives in LDS
+  GemvArgs a{W, W3, x, delta, norm_w, bias, freqs, h_out, y, eps, N, K, freqs ? rope_rows : 0, freqs ? head_dim : 2};
+  hipStream_t st = (hipStream_t)stream;
+  switch (dtype) {
+    case CC_DT_F32: return launch_gemv<float>(a, st);
+    case CC_DT_BF16: return launch_gemv<bf16_t>(a, st);
+    default: return launch_gemv<f16_t>(a, st);
+  }
+}

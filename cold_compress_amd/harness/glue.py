@@ -79,3 +79,23 @@ def silu_mul(a, b):
     out = torch.empty_like(ac)
     _abi.call("cc_silu_mul", _p(ac), _p(bc), ac.numel(), _DT[a.dtype], _p(out), _stream())
     return out
+
+
+def gemv_supported(*weights):
+    """Single-token dense layers on the device path: the input vector must fit the kernel's LDS staging buffer."""
+    return all(w.is_cuda and w.is_contiguous() and w.dtype in _DT and w.shape[1] * w.element_size() <= 64 * 1024
+               and w.shape[1] % (16 // w.element_size()) == 0 for w in weights)
+
+
+def gemv_fused(weight, x, w3=None, delta=None, norm_weight=None, eps=1e-5, h_out=None, bias=None, freqs=None, rope_rows=0,
+               head_dim=0):
+    """One decode-time dense layer with its glue fused (cc_gemv_fused): optional RMSNorm(x + delta) prologue (h_out
+    receives x + delta), optional SwiGLU pairing with `w3`, optional RoPE epilogue on the first `rope_rows` rows.
+    x: [K] (any shape with K elements); returns [N] in the model dtype."""
+    N, K = weight.shape
+    xc = x.contiguous()
+    y = torch.empty((N,), dtype=weight.dtype, device=weight.device)
+    _abi.call("cc_gemv_fused", _p(weight), _p(w3), _p(xc), _p(delta.contiguous() if delta is not None else None), _p(norm_weight),
+              float(eps), _p(h_out), _p(bias), _p(freqs.contiguous() if freqs is not None else None), int(rope_rows), int(head_dim),
+              _p(y), N, K, _DT[weight.dtype], _stream())
+    return y

@@ -114,7 +114,13 @@ class FeedForward(nn.Module):
         self.w3 = nn.Linear(config.dim, config.intermediate_size, bias=False)
         self.w2 = nn.Linear(config.intermediate_size, config.dim, bias=False)
 
-    def forward(self, x: Tensor) -> Tensor:
+    def forward(self, x: Tensor, fused=None) -> Tensor:
+        """`fused = (delta, norm, h_out)`: single-token decode on the device — RMSNorm(x + delta) is the prologue of
+        the w1/w3 pass (h_out <- x + delta), SwiGLU its epilogue; w2 follows as a plain streamed GEMV."""
+        if fused is not None:
+            delta, norm, h_out = fused
+            g = glue.gemv_fused(self.w1.weight, x, w3=self.w3.weight, delta=delta, norm_weight=norm.weight, eps=norm.eps, h_out=h_out)
+            return glue.gemv_fused(self.w2.weight, g).view(1, 1, -1)
         return self.w2(glue.silu_mul(self.w1(x), self.w3(x)))
 
 
@@ -137,11 +143,22 @@ class Attention(nn.Module):
             return self.prompt_compressor(input_pos, k_val, v_val, attn=attn)
         return input_pos, k_val, v_val, attn
 
-    def forward(self, x, input_ids, freqs_cis, mask, is_prefill, input_pos=None, attn_top_k=1.0):
-        """The glue of ref: model.py:363-432, GQA-aware (no repeat_interleave)."""
+    def forward(self, x, input_ids, freqs_cis, mask, is_prefill, input_pos=None, attn_top_k=1.0, fused=None):
+        """The glue of ref: model.py:363-432, GQA-aware (no repeat_interleave).
+        `fused = (delta, norm, h_out)`: single-token decode on the device — x is the un-normalised residual stream,
+        RMSNorm(x + delta) is the prologue of the wqkv pass (h_out <- x + delta), RoPE its epilogue."""
         bsz, seqlen, _ = x.shape
-        # split + RoPE(q, k) + head-major layout in one launch (ref: model.py:375-387)
-        q, k, v = glue.qkv_rope(self.wqkv(x), freqs_cis, self.n_head, self.n_local_heads, self.head_dim)
+        if fused is not None:
+            delta, norm, h_out = fused
+            HQ, H, D = self.n_head, self.n_local_heads, self.head_dim
+            qkv = glue.gemv_fused(self.wqkv.weight, x, delta=delta, norm_weight=norm.weight, eps=norm.eps, h_out=h_out,
+                                  bias=self.wqkv.bias, freqs=freqs_cis, rope_rows=(HQ + H) * D, head_dim=D)
+            q = qkv[: HQ * D].view(1, HQ, 1, D)
+            k = qkv[HQ * D: (HQ + H) * D].view(1, H, 1, D)
+            v = qkv[(HQ + H) * D:].view(1, H, 1, D)
+        else:
+            # split + RoPE(q, k) + head-major layout in one launch (ref: model.py:375-387)
+            q, k, v = glue.qkv_rope(self.wqkv(x), freqs_cis, self.n_head, self.n_local_heads, self.head_dim)
         cache = self.kv_cache
         ck = {"input_ids": input_ids}
         if (not is_prefill and self.fuse_decode_step and type(cache) is KVCacheHeavyHitter
@@ -165,6 +182,8 @@ class Attention(nn.Module):
             input_pos, k, v, attn = self.compress_prompt(input_pos, k, v, attn)
             cache.update_kv(input_pos, k, v, True, **ck)
             cache.update_state(input_pos, k, v, True, attn, **ck)
+        if fused is not None:
+            return glue.gemv_fused(self.wo.weight, y).view(1, 1, -1)
         y = y.transpose(1, 2).contiguous().view(bsz, seqlen, self.dim)
         return self.wo(y)
 
@@ -176,14 +195,24 @@ class TransformerBlock(nn.Module):
         self.feed_forward = FeedForward(config)
         self.ffn_norm = RMSNorm(config.dim, config.norm_eps)
         self.attention_norm = RMSNorm(config.dim, config.norm_eps)
+        self.fuse_gemv = True  # single-token decode: hand-written streamed GEMVs with the glue fused (cc_gemv_fused)
 
     def forward(self, x, delta, input_ids, input_pos, is_prefill, freqs_cis, mask, attn_top_k=1.0):
         """Pre-norm block (ref: model.py:317-327) with the residual adds folded into the norms:
         takes (x, pending residual delta) and returns (h, f) with the block output being h + f."""
+        att, ffn = self.attention, self.feed_forward
+        if (not is_prefill and self.fuse_gemv and x.shape[1] == 1 and x.is_cuda
+                and glue.gemv_supported(att.wqkv.weight, att.wo.weight, ffn.w1.weight, ffn.w3.weight, ffn.w2.weight)):
+            # decode on the device: six launches per layer — norm + wqkv + RoPE | K/V streaming pass | combine | wo |
+            # norm + w1/w3 + SwiGLU | w2 — the residual adds ride in the norm prologues (h1, h2 are their outputs)
+            h1 = torch.empty_like(x)
+            a = att(x, input_ids, freqs_cis, mask, False, input_pos, attn_top_k=attn_top_k, fused=(delta, self.attention_norm, h1))
+            h2 = torch.empty_like(x)
+            return h2, ffn(h1, fused=(a, self.ffn_norm, h2))
         x, n1 = self.attention_norm(x, delta)  # x <- x + delta
-        a = self.attention(n1, input_ids, freqs_cis, mask, is_prefill, input_pos, attn_top_k=attn_top_k)
+        a = att(n1, input_ids, freqs_cis, mask, is_prefill, input_pos, attn_top_k=attn_top_k)
         h, n2 = self.ffn_norm(x, a)  # h = x + attn
-        return h, self.feed_forward(n2)
+        return h, ffn(n2)
 
 
 class Transformer(nn.Module):

@@ -359,6 +359,23 @@ int cc_qkv_rope(const void* qkv, const void* freqs, int32_t T, int32_t HQ, int32
 /* SwiGLU gate: out = dtype( dtype(silu(a)) * b ).  ref: model.py:442-443 F.silu(w1 x) * w3 x.  a, b, out: [n]. */
 int cc_silu_mul(const void* a, const void* b, int64_t n, int32_t dtype, void* out, cc_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Decode-time dense layer (one token) with the caller glue fused in.  ref (caller side): model.py:317-327 (pre-norm
+ * block + residual adds), :375-387 (qkv split + apply_rotary_emb), :442-443 (FFN), :452-457 (RMSNorm), :507-519 (RoPE).
+ *   prologue  (norm_w != NULL): h = dtype(x + delta) (delta may be NULL), h_out <- h (optional, the updated residual
+ *             stream), in = dtype(dtype(h * rsqrt(mean(h^2) + eps)) * norm_w);  else in = x.
+ *   product   t[n] = dtype(sum_k W[n,k] * in[k] (+ bias[n])), fp32 accumulation; W: [N, K] row-major (nn.Linear.weight).
+ *   W3 != NULL: y[n] = dtype(dtype(silu(t[n])) * dtype(sum_k W3[n,k] * in[k]))           (SwiGLU: w1, w3 in one pass)
+ *   freqs != NULL: rows [0, rope_rows) are rotated in (even, odd) pairs with freqs[(row % head_dim)/2] = (cos, sin)
+ *             of the current position, fp32 math on the dtype-rounded t (q and k heads of a fused wqkv); rows beyond
+ *             rope_rows (v) are copied.
+ * K * sizeof(dtype) <= 64 KiB (the input vector is staged in LDS).  Summation order inside a dot product is the
+ * kernel's own (tolerance class, like any GEMM library).
+ * ---------------------------------------------------------------------------------------------- */
+int cc_gemv_fused(const void* W, const void* W3, const void* x, const void* delta, const void* norm_w, float eps,
+                  void* h_out, const void* bias, const void* freqs, int32_t rope_rows, int32_t head_dim, void* y,
+                  int32_t N, int32_t K, int32_t dtype, cc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

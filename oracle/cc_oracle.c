@@ -1103,3 +1103,63 @@ int cc_kv_dequant_cpu(const void* q, const void* scales, const void* zeros, void
     }
   return CC_OK;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Decode-time dense layers with the caller glue fused (see include/coldcompress.h: cc_gemv_fused).
+ * Plain restatement of the eager chain (model.py:317-327, 375-387, 442-443, 452-457, 507-519): every tensor op
+ * rounds to the model dtype; dot products accumulate in fp32 (summation order is unspecified -> tolerance class).
+ * ---------------------------------------------------------------------------------------------- */
+int cc_gemv_fused_cpu(const void* W, const void* W3, const void* x, const void* delta, const void* norm_w, float eps,
+                      void* h_out, const void* bias, const void* freqs, int32_t rope_rows, int32_t head_dim, void* y, int32_t N,
+                      int32_t K, int32_t dt, cc_stream_t stream) {
+  (void)stream;
+  if (!W || !x || !y || N <= 0 || K <= 0 || !dt_ok(dt)) return CC_ERR_BAD_ARG;
+  if ((delta || h_out) && !norm_w) return CC_ERR_BAD_ARG;
+  if (freqs && (W3 || rope_rows < 0 || rope_rows > N || head_dim <= 0 || (head_dim & 1) || (rope_rows % head_dim))) return CC_ERR_BAD_ARG;
+  if (W3 && bias) return CC_ERR_BAD_ARG;
+  float* in = (float*)malloc(sizeof(float) * (size_t)K);
+  float* out = (float*)malloc(sizeof(float) * (size_t)N);
+  if (!in || !out) { free(in); free(out); return CC_ERR_BAD_ARG; }
+  if (norm_w) {
+    double ss = 0.0;
+    for (int k = 0; k < K; k++) {
+      float h = ld(x, dt, (size_t)k);
+      if (delta) h = rnd(h + ld(delta, dt, (size_t)k), dt);
+      if (h_out) st(h_out, dt, (size_t)k, h);
+      in[k] = h;
+      ss += (double)h * (double)h;
+    }
+    const float rs = 1.0f / sqrtf((float)(ss / (double)K) + eps);
+    for (int k = 0; k < K; k++) in[k] = rnd(rnd(in[k] * rs, dt) * ld(norm_w, dt, (size_t)k), dt);
+  } else {
+    for (int k = 0; k < K; k++) in[k] = ld(x, dt, (size_t)k);
+  }
+  for (int n = 0; n < N; n++) {
+    double a = 0.0, a3 = 0.0;
+    for (int k = 0; k < K; k++) {
+      a += (double)ld(W, dt, (size_t)n * K + k) * (double)in[k];
+      if (W3) a3 += (double)ld(W3, dt, (size_t)n * K + k) * (double)in[k];
+    }
+    float s = (float)a;
+    if (bias) s += ld(bias, dt, (size_t)n);
+    s = rnd(s, dt);
+    if (W3) {
+      const float s3 = rnd((float)a3, dt);
+      const float sl = rnd(s / (1.0f + expf(-s)), dt);
+      s = sl * s3;
+    }
+    out[n] = s;
+  }
+  if (freqs)
+    for (int n = 0; n + 1 < rope_rows; n += 2) {
+      const int pr = (n % head_dim) >> 1;
+      const float c = ld(freqs, dt, (size_t)pr * 2), sn = ld(freqs, dt, (size_t)pr * 2 + 1);
+      const float x0 = out[n], x1 = out[n + 1];
+      out[n] = x0 * c - x1 * sn;
+      out[n + 1] = x1 * c + x0 * sn;
+    }
+  for (int n = 0; n < N; n++) st(y, dt, (size_t)n, out[n]);
+  free(in);
+  free(out);
+  return CC_OK;
+}
