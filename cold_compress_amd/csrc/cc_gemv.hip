@@ -145,25 +145,55 @@ __global__ __launch_bounds__(kGvThreads) void gemv_kernel(GemvArgs a) {
 
   // ---- prologue: stage the input vector (normalised if asked) into LDS
   if (a.norm_w != nullptr) {
+    // one memory round trip: x, delta and the norm weight of every chunk this thread owns are requested together,
+    // h = x + delta stays in registers across the barrier that produces rstd
+    constexpr int kPre = 2;  // chunks per thread held in registers (K <= 4096 at 16 bits); longer rows re-read LDS
     const T* dg = reinterpret_cast<const T*>(a.delta);
     const T* wg = reinterpret_cast<const T*>(a.norm_w);
-    float ss = 0.f;
-    for (int c = threadIdx.x; c < nch; c += kGvThreads) {
-      Vec16<T> xv;
-      float h[VEC];
-      xv.load(xg + (size_t)c * VEC);
-      xv.unpack(h);
-      if (dg != nullptr) {
-        Vec16<T> dv;
-        float d[VEC];
-        dv.load(dg + (size_t)c * VEC);
-        dv.unpack(d);
+    Vec16<T> xv[kPre], dv[kPre], nv[kPre];
 #pragma unroll
-        for (int e = 0; e < VEC; e++) h[e] = ElemTraits<T>::rnd(__fadd_rn(h[e], d[e]));  // model-dtype residual add
+    for (int j = 0; j < kPre; j++) {
+      const int c = threadIdx.x + j * kGvThreads;
+      if (c < nch) {
+        xv[j].load(xg + (size_t)c * VEC);
+        if (dg != nullptr) dv[j].load(dg + (size_t)c * VEC);
+        nv[j].load(wg + (size_t)c * VEC);
+      }
+    }
+    float h[kPre][VEC];
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < kPre; j++) {
+      const int c = threadIdx.x + j * kGvThreads;
+      if (c < nch) {
+        xv[j].unpack(h[j]);
+        if (dg != nullptr) {
+          float d[VEC];
+          dv[j].unpack(d);
+#pragma unroll
+          for (int e = 0; e < VEC; e++) h[j][e] = ElemTraits<T>::rnd(__fadd_rn(h[j][e], d[e]));  // model-dtype residual add
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; e++) ss = fmaf(h[j][e], h[j][e], ss);
+        if (a.h_out != nullptr && blockIdx.x == 0) reinterpret_cast<uint4*>(a.h_out)[c] = pack16<T>(h[j]);
+      }
+    }
+    for (int c = threadIdx.x + kPre * kGvThreads; c < nch; c += kGvThreads) {  // very long rows: stage h in LDS
+      Vec16<T> xl;
+      float hl[VEC];
+      xl.load(xg + (size_t)c * VEC);
+      xl.unpack(hl);
+      if (dg != nullptr) {
+        Vec16<T> dl;
+        float d[VEC];
+        dl.load(dg + (size_t)c * VEC);
+        dl.unpack(d);
+#pragma unroll
+        for (int e = 0; e < VEC; e++) hl[e] = ElemTraits<T>::rnd(__fadd_rn(hl[e], d[e]));
       }
 #pragma unroll
-      for (int e = 0; e < VEC; e++) ss = fmaf(h[e], h[e], ss);
-      const uint4 hp = pack16<T>(h);
+      for (int e = 0; e < VEC; e++) ss = fmaf(hl[e], hl[e], ss);
+      const uint4 hp = pack16<T>(hl);
       sm_x[c] = hp;
       if (a.h_out != nullptr && blockIdx.x == 0) reinterpret_cast<uint4*>(a.h_out)[c] = hp;
     }
@@ -174,15 +204,26 @@ __global__ __launch_bounds__(kGvThreads) void gemv_kernel(GemvArgs a) {
 #pragma unroll
     for (int wv = 0; wv < kGvWaves; wv++) tot += sm_red[wv];
     const float rs = rsqrtf(tot / (float)K + a.eps);  // ref: model.py:452-457 (fp32 inside)
-    for (int c = threadIdx.x; c < nch; c += kGvThreads) {
+#pragma unroll
+    for (int j = 0; j < kPre; j++) {
+      const int c = threadIdx.x + j * kGvThreads;
+      if (c < nch) {
+        float wf[VEC], o[VEC];
+        nv[j].unpack(wf);
+#pragma unroll
+        for (int e = 0; e < VEC; e++) o[e] = ElemTraits<T>::rnd(__fmul_rn(ElemTraits<T>::rnd(__fmul_rn(h[j][e], rs)), wf[e]));
+        sm_x[c] = pack16<T>(o);
+      }
+    }
+    for (int c = threadIdx.x + kPre * kGvThreads; c < nch; c += kGvThreads) {
       Vec16<T> hv, wv;
-      float h[VEC], wf[VEC], o[VEC];
+      float hl[VEC], wf[VEC], o[VEC];
       hv.raw = sm_x[c];
-      hv.unpack(h);
+      hv.unpack(hl);
       wv.load(wg + (size_t)c * VEC);
       wv.unpack(wf);
 #pragma unroll
-      for (int e = 0; e < VEC; e++) o[e] = ElemTraits<T>::rnd(__fmul_rn(ElemTraits<T>::rnd(__fmul_rn(h[e], rs)), wf[e]));
+      for (int e = 0; e < VEC; e++) o[e] = ElemTraits<T>::rnd(__fmul_rn(ElemTraits<T>::rnd(__fmul_rn(hl[e], rs)), wf[e]));
       sm_x[c] = pack16<T>(o);
     }
   } else {
