@@ -12,7 +12,7 @@
 // column steps are in flight together (RB*CU 16-byte loads per lane), products go through v_dot2c_f32_bf16 /
 // v_dot2_f32_f16 (fp32 accumulate), the row total through 4 DPP steps + 4 v_readlane.  The input vector is
 // normalised ONCE per workgroup into LDS as packed 16-bit (every workgroup recomputes the 8 KiB norm rather than
-// paying a launch for it) and read back with ds_read_b128 shared by the RB rows.  No atomics, fixed orders.
+// paying a launch for it) and kept in the registers of the lanes that multiply it.  No atomics, fixed orders.
 #include <cstdio>
 #include <cstdlib>
 
@@ -104,10 +104,9 @@ __device__ __forceinline__ uint4 pack16(const float* f) {
   }
 }
 
-template <typename T, bool SWIGLU, int RB, int CU>
+template <typename T, bool SWIGLU, int RB, int CU, int XS>
 __global__ __launch_bounds__(kGvThreads) void gemv_kernel(GemvArgs a) {
   constexpr int VEC = 16 / (int)sizeof(T);
-  extern __shared__ __attribute__((aligned(16))) uint4 sm_x[];  // [K / VEC] the (normalised) input, packed T
   __shared__ float sm_red[kGvWaves];
   __shared__ float sm_part[kGvWaves][2][RB];
   const int K = a.K, N = a.N;
@@ -118,11 +117,10 @@ __global__ __launch_bounds__(kGvThreads) void gemv_kernel(GemvArgs a) {
   // ---- Work decomposition: a WORKGROUP owns RB consecutive rows at a time; its four waves split K (wave w takes
   //      the 1 KiB segments w, w+4, w+8, ... of every row), CU segments per row in flight per wave, and the four
   //      partial sums meet in LDS.  For the decode shapes this puts a whole matrix in flight in one phase
-  //      (wo: 4 rows x 2 segments per wave; w2: 2-4 rows x 7 segments) instead of looping inside a wave.
-  //      The FIRST tile's weight loads are issued before the input vector is staged: W does not depend on x, and
-  //      the norm prologue (two passes over x plus a barrier) would otherwise sit in front of the first HBM request.
+  //      (wo: 2 rows x 2 segments per wave; w2: 4 rows x 4 of 7 segments) instead of looping inside a wave.
+  //      The FIRST tile's weight loads are issued before the input vector is touched: W does not depend on x.
   const int nseg = (nch + 63) / 64;                      // 1 KiB segments per row
-  const int nstep = (nseg + kGvWaves - 1) / kGvWaves;    // segments per wave
+  const int nstep = (nseg + kGvWaves - 1) / kGvWaves;    // segments per wave (<= XS, checked by the launcher)
   const uint4* Wv = reinterpret_cast<const uint4*>(a.W);
   const uint4* W3v = reinterpret_cast<const uint4*>(a.W3);
   uint4 w[RB][CU], w3[RB][CU];
@@ -143,93 +141,70 @@ __global__ __launch_bounds__(kGvThreads) void gemv_kernel(GemvArgs a) {
   const int row_first = blockIdx.x * RB;
   if (row_first < N) issue(row_first, 0);
 
-  // ---- prologue: stage the input vector (normalised if asked) into LDS
+  // ---- the input vector: every lane keeps exactly the 16-byte chunks it will multiply (no LDS staging).  With a
+  //      norm prologue, x / delta / norm weight of those chunks are requested together (one memory round trip), the
+  //      four waves exchange their partial sums of squares through LDS (one barrier), and the normalised chunks
+  //      replace h in the same registers.
+  uint4 xr[XS];
   if (a.norm_w != nullptr) {
-    // one memory round trip: x, delta and the norm weight of every chunk this thread owns are requested together,
-    // h = x + delta stays in registers across the barrier that produces rstd
-    constexpr int kPre = 2;  // chunks per thread held in registers (K <= 4096 at 16 bits); longer rows re-read LDS
     const T* dg = reinterpret_cast<const T*>(a.delta);
     const T* wg = reinterpret_cast<const T*>(a.norm_w);
-    Vec16<T> xv[kPre], dv[kPre], nv[kPre];
+    Vec16<T> xv[XS], dv[XS], nv[XS];
 #pragma unroll
-    for (int j = 0; j < kPre; j++) {
-      const int c = threadIdx.x + j * kGvThreads;
-      if (c < nch) {
+    for (int j = 0; j < XS; j++) {
+      const int c = (j * kGvWaves + wave) * 64 + lane;
+      if (j < nstep && c < nch) {
         xv[j].load(xg + (size_t)c * VEC);
         if (dg != nullptr) dv[j].load(dg + (size_t)c * VEC);
         nv[j].load(wg + (size_t)c * VEC);
       }
     }
-    float h[kPre][VEC];
     float ss = 0.f;
 #pragma unroll
-    for (int j = 0; j < kPre; j++) {
-      const int c = threadIdx.x + j * kGvThreads;
-      if (c < nch) {
-        xv[j].unpack(h[j]);
+    for (int j = 0; j < XS; j++) {
+      const int c = (j * kGvWaves + wave) * 64 + lane;
+      xr[j] = make_uint4(0, 0, 0, 0);
+      if (j < nstep && c < nch) {
+        float h[VEC];
+        xv[j].unpack(h);
         if (dg != nullptr) {
           float d[VEC];
           dv[j].unpack(d);
 #pragma unroll
-          for (int e = 0; e < VEC; e++) h[j][e] = ElemTraits<T>::rnd(__fadd_rn(h[j][e], d[e]));  // model-dtype residual add
+          for (int e = 0; e < VEC; e++) h[e] = ElemTraits<T>::rnd(__fadd_rn(h[e], d[e]));  // model-dtype residual add
         }
 #pragma unroll
-        for (int e = 0; e < VEC; e++) ss = fmaf(h[j][e], h[j][e], ss);
-        if (a.h_out != nullptr && blockIdx.x == 0) reinterpret_cast<uint4*>(a.h_out)[c] = pack16<T>(h[j]);
+        for (int e = 0; e < VEC; e++) ss = fmaf(h[e], h[e], ss);
+        xr[j] = pack16<T>(h);  // h is already rounded to T: packing is exact
+        if (a.h_out != nullptr && blockIdx.x == 0) reinterpret_cast<uint4*>(a.h_out)[c] = xr[j];
       }
-    }
-    for (int c = threadIdx.x + kPre * kGvThreads; c < nch; c += kGvThreads) {  // very long rows: stage h in LDS
-      Vec16<T> xl;
-      float hl[VEC];
-      xl.load(xg + (size_t)c * VEC);
-      xl.unpack(hl);
-      if (dg != nullptr) {
-        Vec16<T> dl;
-        float d[VEC];
-        dl.load(dg + (size_t)c * VEC);
-        dl.unpack(d);
-#pragma unroll
-        for (int e = 0; e < VEC; e++) hl[e] = ElemTraits<T>::rnd(__fadd_rn(hl[e], d[e]));
-      }
-#pragma unroll
-      for (int e = 0; e < VEC; e++) ss = fmaf(hl[e], hl[e], ss);
-      const uint4 hp = pack16<T>(hl);
-      sm_x[c] = hp;
-      if (a.h_out != nullptr && blockIdx.x == 0) reinterpret_cast<uint4*>(a.h_out)[c] = hp;
     }
     ss = gv_wave_sum(ss);
     if (lane == 0) sm_red[wave] = ss;
     __syncthreads();
-    float tot = 0.f;
-#pragma unroll
-    for (int wv = 0; wv < kGvWaves; wv++) tot += sm_red[wv];
+    const float tot = (sm_red[0] + sm_red[1]) + (sm_red[2] + sm_red[3]);
     const float rs = rsqrtf(tot / (float)K + a.eps);  // ref: model.py:452-457 (fp32 inside)
 #pragma unroll
-    for (int j = 0; j < kPre; j++) {
-      const int c = threadIdx.x + j * kGvThreads;
-      if (c < nch) {
-        float wf[VEC], o[VEC];
+    for (int j = 0; j < XS; j++) {
+      const int c = (j * kGvWaves + wave) * 64 + lane;
+      if (j < nstep && c < nch) {
+        Vec16<T> hv;
+        float h[VEC], wf[VEC], o[VEC];
+        hv.raw = xr[j];
+        hv.unpack(h);
         nv[j].unpack(wf);
 #pragma unroll
-        for (int e = 0; e < VEC; e++) o[e] = ElemTraits<T>::rnd(__fmul_rn(ElemTraits<T>::rnd(__fmul_rn(h[j][e], rs)), wf[e]));
-        sm_x[c] = pack16<T>(o);
+        for (int e = 0; e < VEC; e++) o[e] = ElemTraits<T>::rnd(__fmul_rn(ElemTraits<T>::rnd(__fmul_rn(h[e], rs)), wf[e]));
+        xr[j] = pack16<T>(o);
       }
     }
-    for (int c = threadIdx.x + kPre * kGvThreads; c < nch; c += kGvThreads) {
-      Vec16<T> hv, wv;
-      float hl[VEC], wf[VEC], o[VEC];
-      hv.raw = sm_x[c];
-      hv.unpack(hl);
-      wv.load(wg + (size_t)c * VEC);
-      wv.unpack(wf);
-#pragma unroll
-      for (int e = 0; e < VEC; e++) o[e] = ElemTraits<T>::rnd(__fmul_rn(ElemTraits<T>::rnd(__fmul_rn(hl[e], rs)), wf[e]));
-      sm_x[c] = pack16<T>(o);
-    }
   } else {
-    for (int c = threadIdx.x; c < nch; c += kGvThreads) sm_x[c] = reinterpret_cast<const uint4*>(xg)[c];
+#pragma unroll
+    for (int j = 0; j < XS; j++) {
+      const int c = (j * kGvWaves + wave) * 64 + lane;
+      xr[j] = (j < nstep && c < nch) ? reinterpret_cast<const uint4*>(xg)[c] : make_uint4(0, 0, 0, 0);
+    }
   }
-  __syncthreads();
 
   T* yo = reinterpret_cast<T*>(a.y);
   bool first = true;
@@ -237,17 +212,19 @@ __global__ __launch_bounds__(kGvThreads) void gemv_kernel(GemvArgs a) {
     float acc[RB], acc3[RB];
 #pragma unroll
     for (int r = 0; r < RB; r++) acc[r] = acc3[r] = 0.f;
-    for (int s0 = 0; s0 < nstep; s0 += CU) {
-      if (!first) issue(r0, s0);
-      first = false;
 #pragma unroll
-      for (int u = 0; u < CU; u++) {
-        const int c = ((s0 + u) * kGvWaves + wave) * 64 + lane;
-        const uint4 xv = ((s0 + u < nstep) && c < nch) ? sm_x[c] : make_uint4(0, 0, 0, 0);
+    for (int s0 = 0; s0 < XS; s0 += CU) {
+      if (s0 < nstep) {
+        if (!first) issue(r0, s0);
+        first = false;
 #pragma unroll
-        for (int r = 0; r < RB; r++) {
-          acc[r] = Dot16<T>::run(w[r][u], xv, acc[r]);
-          if (SWIGLU) acc3[r] = Dot16<T>::run(w3[r][u], xv, acc3[r]);
+        for (int u = 0; u < CU; u++) {
+          const uint4 xv = xr[s0 + u < XS ? s0 + u : XS - 1];  // beyond nstep the weights are zero-filled
+#pragma unroll
+          for (int r = 0; r < RB; r++) {
+            acc[r] = Dot16<T>::run(w[r][u], xv, acc[r]);
+            if (SWIGLU) acc3[r] = Dot16<T>::run(w3[r][u], xv, acc3[r]);
+          }
         }
       }
     }
@@ -310,37 +287,45 @@ static GvCfg pick_cfg(const GemvArgs& a, int vec) {
   if (nstep <= 2) {
     c.rb = 2; c.cu = 2;
   } else if (a.W3 != nullptr) {
-    c.rb = 2; c.cu = nstep <= 4 ? 4 : 8;
+    c.rb = 2; c.cu = (nstep <= 4 || nstep > 8) ? 4 : 8;
   } else {
     c.rb = 4; c.cu = 4;
   }
   return c;
 }
 
-template <typename T, bool SWIGLU, int RB, int CU>
+template <typename T, bool SWIGLU, int RB, int CU, int XS>
 static void launch_cfg(const GemvArgs& a, hipStream_t st, int cap) {
-  const size_t lds = (size_t)a.K * sizeof(T);
   int blocks = (a.N + RB - 1) / RB;
   if (blocks > cap) blocks = cap;
-  hipLaunchKernelGGL((gemv_kernel<T, SWIGLU, RB, CU>), dim3(blocks), dim3(kGvThreads), lds, st, a);
+  hipLaunchKernelGGL((gemv_kernel<T, SWIGLU, RB, CU, XS>), dim3(blocks), dim3(kGvThreads), 0, st, a);
 }
 
 template <typename T>
 static int launch_gemv(const GemvArgs& a, hipStream_t st) {
-  const GvCfg c = pick_cfg(a, 16 / (int)sizeof(T));
-  const int key = (a.W3 ? 1000 : 0) + c.rb * 10 + c.cu;
+  const int vec = 16 / (int)sizeof(T);
+  const GvCfg c = pick_cfg(a, vec);
+  const int nseg = (a.K / vec + 63) / 64, nstep = (nseg + kGvWaves - 1) / kGvWaves;
+  const int xs = nstep <= 2 ? 2 : nstep <= 8 ? 8 : 16;  // input chunks kept per lane
+  if (nstep > 16 || c.cu > xs) return CC_ERR_UNSUPPORTED;
+  const int key = (a.W3 ? 100000 : 0) + xs * 1000 + c.rb * 10 + c.cu;
   switch (key) {
-    case 22: launch_cfg<T, false, 2, 2>(a, st, c.cap); break;
-    case 42: launch_cfg<T, false, 4, 2>(a, st, c.cap); break;
-    case 82: launch_cfg<T, false, 8, 2>(a, st, c.cap); break;
-    case 24: launch_cfg<T, false, 2, 4>(a, st, c.cap); break;
-    case 44: launch_cfg<T, false, 4, 4>(a, st, c.cap); break;
-    case 28: launch_cfg<T, false, 2, 8>(a, st, c.cap); break;
-    case 48: launch_cfg<T, false, 4, 8>(a, st, c.cap); break;
-    case 1022: launch_cfg<T, true, 2, 2>(a, st, c.cap); break;
-    case 1042: launch_cfg<T, true, 4, 2>(a, st, c.cap); break;
-    case 1024: launch_cfg<T, true, 2, 4>(a, st, c.cap); break;
-    case 1028: launch_cfg<T, true, 2, 8>(a, st, c.cap); break;
+    case 2022: launch_cfg<T, false, 2, 2, 2>(a, st, c.cap); break;
+    case 2042: launch_cfg<T, false, 4, 2, 2>(a, st, c.cap); break;
+    case 2082: launch_cfg<T, false, 8, 2, 2>(a, st, c.cap); break;
+    case 8022: launch_cfg<T, false, 2, 2, 8>(a, st, c.cap); break;
+    case 8024: launch_cfg<T, false, 2, 4, 8>(a, st, c.cap); break;
+    case 8044: launch_cfg<T, false, 4, 4, 8>(a, st, c.cap); break;
+    case 8028: launch_cfg<T, false, 2, 8, 8>(a, st, c.cap); break;
+    case 8048: launch_cfg<T, false, 4, 8, 8>(a, st, c.cap); break;
+    case 16044: launch_cfg<T, false, 4, 4, 16>(a, st, c.cap); break;
+    case 16028: launch_cfg<T, false, 2, 8, 16>(a, st, c.cap); break;
+    case 102022: launch_cfg<T, true, 2, 2, 2>(a, st, c.cap); break;
+    case 102042: launch_cfg<T, true, 4, 2, 2>(a, st, c.cap); break;
+    case 108022: launch_cfg<T, true, 2, 2, 8>(a, st, c.cap); break;
+    case 108024: launch_cfg<T, true, 2, 4, 8>(a, st, c.cap); break;
+    case 108028: launch_cfg<T, true, 2, 8, 8>(a, st, c.cap); break;
+    case 116024: launch_cfg<T, true, 2, 4, 16>(a, st, c.cap); break;
     default: return CC_ERR_UNSUPPORTED;
   }
   CC_LAUNCH_CHECK();
@@ -359,7 +344,7 @@ extern "C" int cc_gemv_fused(const void* W, const void* W3, const void* x, const
   if (W3 && bias) return CC_ERR_BAD_ARG;
   const int vec = 16 / (int)cc_dt_size(dtype);
   if (K % vec) return CC_ERR_UNSUPPORTED;
-  if ((size_t)K * cc_dt_size(dtype) > 64 * 1024) return CC_ERR_UNSUPPORTED;  // the input vector lives in LDS
+  if ((size_t)K * cc_dt_size(dtype) > 64 * 1024) return CC_ERR_UNSUPPORTED;  // 16 input chunks per lane at most
   GemvArgs a{W, W3, x, delta, norm_w, bias, freqs, h_out, y, eps, N, K, freqs ? rope_rows : 0, freqs ? head_dim : 2};
   hipStream_t st = (hipStream_t)stream;
   switch (dtype) {

@@ -369,7 +369,7 @@ int cc_silu_mul(const void* a, const void* b, int64_t n, int32_t dtype, void* ou
  *   freqs != NULL: rows [0, rope_rows) are rotated in (even, odd) pairs with freqs[(row % head_dim)/2] = (cos, sin)
  *             of the current position, fp32 math on the dtype-rounded t (q and k heads of a fused wqkv); rows beyond
  *             rope_rows (v) are copied.
- * K * sizeof(dtype) <= 64 KiB (the input vector is staged in LDS).  Summation order inside a dot product is the
+ * K * sizeof(dtype) <= 64 KiB (16 input chunks per lane).  Summation order inside a dot product is the
  * kernel's own (tolerance class, like any GEMM library).
  * ---------------------------------------------------------------------------------------------- */
 int cc_gemv_fused(const void* W, const void* W3, const void* x, const void* delta, const void* norm_w, float eps,

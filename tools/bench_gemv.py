@@ -65,6 +65,15 @@ def main():
         res = {"shape": name, "N": N, "K": K, "MB": round(nbytes / 1e6, 1), "hipblaslt_us": round(t_lib, 2),
                "cc_gemv_us": round(t_own, 2), "hipblaslt_GBps": round(nbytes / t_lib / 1e3), "cc_gemv_GBps": round(nbytes / t_own / 1e3),
                "rel_err_vs_fp32": err}
+        if name == "wqkv":  # as the decode loop launches it: norm(x + delta) prologue, RoPE epilogue on q and k
+            delta = torch.randn(K, device=dev).to(torch.bfloat16)
+            nw = torch.ones(K, device=dev, dtype=torch.bfloat16)
+            h = torch.empty(K, device=dev, dtype=torch.bfloat16)
+            fr = torch.rand(64, 2, device=dev).to(torch.bfloat16)
+            res["norm_only_us"] = round(timed(lambda i: gemv(Ws[i % ncopy], x, y, delta=delta, nw=nw, h_out=h), ncopy), 2)
+            res["rope_only_us"] = round(timed(lambda i: gemv(Ws[i % ncopy], x, y, freqs=fr, rope_rows=5120, hd=128), ncopy), 2)
+            res["norm_rope_us"] = round(timed(lambda i: gemv(Ws[i % ncopy], x, y, delta=delta, nw=nw, h_out=h, freqs=fr, rope_rows=5120,
+                                                             hd=128), ncopy), 2)
         if name == "w1":  # SwiGLU pair in one pass
             W3s = [torch.randn(N, K, device=dev).mul_(0.02).to(torch.bfloat16) for _ in range(ncopy)]
             try:
