@@ -207,3 +207,145 @@ int cc_silu_mul(const void* a, const void* b, int64_t n, int32_t dtype, void* ou
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------
+// Greedy sampling tail (ref: generation_utils.py:136-142): probs = softmax(logits) in the model dtype, next token =
+// first index of the largest ROUNDED probability (torch.argmax returns the first maximal element).
+// Two small launches over kSmBlocks workgroups instead of torch's softmax + reduce kernels (35 + 41 us at vocab
+// 128256; a single-workgroup version is VALU-bound on one CU at 39 us):
+//   pass 1: per-slice (max, sum of exp) partials;
+//   pass 2: every workgroup folds the partials itself (fixed order), writes its slice of probabilities and
+//           min-reduces a 64-bit key (~orderable(p) << 32 | index); the last workgroup to arrive (ticket counter,
+//           no spinning) publishes the token.  The arg-min over keys is order independent -> deterministic.
+namespace {
+constexpr int kSmThreads = 256;
+constexpr int kSmBlocks = 128;
+
+struct SmWs {  // caller-provided scratch (cc_softmax_argmax_workspace_bytes)
+  float2 part[kSmBlocks];
+  unsigned long long key;
+  unsigned int ticket;
+};
+
+template <typename T>
+__device__ __forceinline__ float sm_exp(float x) {
+  // 16-bit outputs: v_exp_f32 (relative error ~1e-6, far below the 2^-9 rounding of the result); fp32: accurate expf
+  if constexpr (sizeof(T) == 4) return expf(x);
+  return __builtin_amdgcn_exp2f(x * 1.4426950408889634f);
+}
+
+__device__ __forceinline__ void sm_slice(int V, int& lo, int& hi) {
+  const int per = ((V + kSmBlocks - 1) / kSmBlocks + 7) & ~7;  // multiples of 8 elements: slices stay 16-byte aligned
+  lo = min(V, (int)blockIdx.x * per);
+  hi = min(V, lo + per);
+}
+
+template <typename T>
+__global__ __launch_bounds__(kSmThreads) void softmax_partial_kernel(const T* logits, int V, SmWs* ws) {
+  __shared__ float sm_f[kSmThreads / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int lo, hi;
+  sm_slice(V, lo, hi);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    ws->key = ~0ull;
+    ws->ticket = 0u;
+  }
+  float x[4];
+  int n = 0;
+  float mx = -INFINITY;
+  for (int i = lo + threadIdx.x; i < hi; i += kSmThreads) {
+    const float v = ElemTraits<T>::load(logits, (size_t)i);
+    if (n < 4) x[n] = v;
+    n++;
+    mx = fmaxf(mx, v);
+  }
+  mx = wave_max_f32(mx);
+  if (lane == 0) sm_f[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(sm_f[0], sm_f[1]), fmaxf(sm_f[2], sm_f[3]));
+  __syncthreads();
+  float sum = 0.f;
+  int k = 0;
+  for (int i = lo + threadIdx.x; i < hi; i += kSmThreads, k++)
+    sum += sm_exp<T>((k < 4 ? x[k] : ElemTraits<T>::load(logits, (size_t)i)) - mx);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, CC_WAVE);
+  if (lane == 0) sm_f[wave] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) ws->part[blockIdx.x] = make_float2(mx, (sm_f[0] + sm_f[1]) + (sm_f[2] + sm_f[3]));
+}
+
+template <typename T>
+__global__ __launch_bounds__(kSmThreads) void softmax_write_kernel(const T* logits, int V, T* probs, int32_t* idx_out, SmWs* ws) {
+  __shared__ float sm_ml[2];
+  __shared__ unsigned long long sm_k[kSmThreads / 64 + 1];
+  int lo, hi;
+  sm_slice(V, lo, hi);
+  if (threadIdx.x < 64) {  // one wave folds the partials: M = max m_g, S = sum s_g * exp(m_g - M), fixed order
+    float m = -INFINITY;
+    for (int g = threadIdx.x; g < kSmBlocks; g += 64) m = fmaxf(m, ws->part[g].x);
+    m = wave_max_f32(m);
+    float sacc = 0.f;
+    for (int g = threadIdx.x; g < kSmBlocks; g += 64) {
+      const float2 p = ws->part[g];
+      if (p.y > 0.f) sacc += p.y * sm_exp<T>(p.x - m);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sacc += __shfl_xor(sacc, off, CC_WAVE);
+    if (threadIdx.x == 0) {
+      sm_ml[0] = m;
+      sm_ml[1] = sacc;
+    }
+  }
+  __syncthreads();
+  const float mx = sm_ml[0], sum = sm_ml[1];
+  float bp = -1.f;
+  int bi = 0x7fffffff;
+  for (int i = lo + threadIdx.x; i < hi; i += kSmThreads) {  // indices increase: the first maximal element wins
+    const float p = ElemTraits<T>::rnd(__fdiv_rn(sm_exp<T>(ElemTraits<T>::load(logits, (size_t)i) - mx), sum));
+    ElemTraits<T>::store(probs, (size_t)i, p);
+    if (p > bp) {
+      bp = p;
+      bi = i;
+    }
+  }
+  unsigned long long best = bi == 0x7fffffff ? ~0ull : (((unsigned long long)(~orderable_f32(bp)) << 32) | (unsigned)bi);
+  best = block_min_u64(best, sm_k);
+  if (threadIdx.x == 0) {
+    atomicMin(&ws->key, best);
+    __threadfence();
+    if (atomicAdd(&ws->ticket, 1u) == (unsigned)gridDim.x - 1) {  // last workgroup: every key is in
+      __threadfence();
+      *idx_out = (int32_t)(atomicMin(&ws->key, ~0ull) & 0xffffffffull);
+    }
+  }
+}
+}  // namespace
+
+extern "C" size_t cc_softmax_argmax_workspace_bytes(void) { return sizeof(SmWs); }
+
+extern "C" int cc_softmax_argmax(const void* logits, int32_t V, int32_t dtype, void* probs, int32_t* idx_out, void* workspace,
+                                 size_t workspace_bytes, cc_stream_t stream) {
+  CC_ENTRY();
+  if (!logits || !probs || !idx_out || !workspace || V <= 0 || !cc_dt_ok(dtype)) return CC_ERR_BAD_ARG;
+  if (workspace_bytes < sizeof(SmWs)) return CC_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  SmWs* ws = reinterpret_cast<SmWs*>(workspace);
+  dim3 grid(kSmBlocks), block(kSmThreads);
+  switch (dtype) {
+    case CC_DT_F32:
+      hipLaunchKernelGGL(softmax_partial_kernel<float>, grid, block, 0, st, (const float*)logits, V, ws);
+      hipLaunchKernelGGL(softmax_write_kernel<float>, grid, block, 0, st, (const float*)logits, V, (float*)probs, idx_out, ws);
+      break;
+    case CC_DT_BF16:
+      hipLaunchKernelGGL(softmax_partial_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)logits, V, ws);
+      hipLaunchKernelGGL(softmax_write_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)logits, V, (bf16_t*)probs, idx_out, ws);
+      break;
+    default:
+      hipLaunchKernelGGL(softmax_partial_kernel<f16_t>, grid, block, 0, st, (const f16_t*)logits, V, ws);
+      hipLaunchKernelGGL(softmax_write_kernel<f16_t>, grid, block, 0, st, (const f16_t*)logits, V, (f16_t*)probs, idx_out, ws);
+      break;
+  }
+  CC_LAUNCH_CHECK();
+  return CC_OK;
+}

@@ -94,7 +94,13 @@ def setup_caches(model: Transformer, tokenizer, device, max_seq_length: int, cac
 # ------------------------------------------------------------------------------ sampling / steps
 def greedy(logits, next_token):
     """ref: generation_utils.py:136-142."""
-    probs = torch.nn.functional.softmax(logits[0, -1], dim=-1)
+    row = logits[0, -1]
+    if row.is_cuda and next_token is None:
+        from . import glue
+
+        probs, idx_next = glue.softmax_argmax(row)  # one launch instead of softmax + arg-max reduce
+        return idx_next, probs
+    probs = torch.nn.functional.softmax(row, dim=-1)
     idx_next = torch.argmax(probs, keepdim=True).to(dtype=torch.int) if next_token is None else next_token
     return idx_next, probs
 

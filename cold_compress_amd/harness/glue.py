@@ -99,3 +99,19 @@ def gemv_fused(weight, x, w3=None, delta=None, norm_weight=None, eps=1e-5, h_out
               float(eps), _p(h_out), _p(bias), _p(freqs.contiguous() if freqs is not None else None), int(rope_rows), int(head_dim),
               _p(y), N, K, _DT[weight.dtype], _stream())
     return y
+
+
+def softmax_argmax(logits):
+    """probs = softmax(logits) in the model dtype and the greedy token (first index of the largest rounded probability),
+    one launch (cc_softmax_argmax).  logits: [V]."""
+    lc = logits.contiguous()
+    probs = torch.empty_like(lc)
+    idx = torch.empty((1,), dtype=torch.int32, device=lc.device)
+    ws = _SM_WS.get(lc.device)
+    if ws is None:
+        ws = _SM_WS[lc.device] = torch.empty(int(_abi.lib()["cc_softmax_argmax_workspace_bytes"]()), dtype=torch.uint8, device=lc.device)
+    _abi.call("cc_softmax_argmax", _p(lc), lc.numel(), _DT[lc.dtype], _p(probs), _p(idx), _p(ws), ws.numel(), _stream())
+    return probs, idx
+
+
+_SM_WS = {}

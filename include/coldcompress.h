@@ -376,6 +376,13 @@ int cc_gemv_fused(const void* W, const void* W3, const void* x, const void* delt
                   void* h_out, const void* bias, const void* freqs, int32_t rope_rows, int32_t head_dim, void* y,
                   int32_t N, int32_t K, int32_t dtype, cc_stream_t stream);
 
+/* Greedy sampling tail, ref: generation_utils.py:136-142: probs[V] = dtype(softmax_fp32(logits[V])),
+ * *idx_out = first index of the largest rounded probability (torch.argmax semantics).  Two small launches; `workspace`
+ * (cc_softmax_argmax_workspace_bytes) needs no initialisation. */
+size_t cc_softmax_argmax_workspace_bytes(void);
+int cc_softmax_argmax(const void* logits, int32_t V, int32_t dtype, void* probs, int32_t* idx_out, void* workspace,
+                      size_t workspace_bytes, cc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1163,3 +1163,27 @@ int cc_gemv_fused_cpu(const void* W, const void* W3, const void* x, const void* 
   free(out);
   return CC_OK;
 }
+
+/* Greedy sampling tail, ref: generation_utils.py:136-142: probs = dtype(softmax_fp32(logits)); idx = first index of
+ * the largest rounded probability (torch.argmax).  The fp32 sum order is unspecified -> probabilities are a
+ * tolerance class; the arg-max is exact given the probabilities. */
+size_t cc_softmax_argmax_workspace_bytes_cpu(void) { return 0; }
+
+int cc_softmax_argmax_cpu(const void* logits, int32_t V, int32_t dt, void* probs, int32_t* idx_out, void* workspace,
+                          size_t workspace_bytes, cc_stream_t stream) {
+  (void)stream; (void)workspace; (void)workspace_bytes;
+  if (!logits || !probs || !idx_out || V <= 0 || !dt_ok(dt)) return CC_ERR_BAD_ARG;
+  float mx = -INFINITY;
+  for (int i = 0; i < V; i++) { const float x = ld(logits, dt, (size_t)i); if (x > mx) mx = x; }
+  double sum = 0.0;
+  for (int i = 0; i < V; i++) sum += (double)expf(ld(logits, dt, (size_t)i) - mx);
+  float best = -INFINITY;
+  int bi = 0;
+  for (int i = 0; i < V; i++) {
+    const float p = rnd(expf(ld(logits, dt, (size_t)i) - mx) / (float)sum, dt);
+    st(probs, dt, (size_t)i, p);
+    if (p > best) { best = p; bi = i; }
+  }
+  *idx_out = bi;
+  return CC_OK;
+}

@@ -84,3 +84,24 @@ def test_silu_mul(oracle, dtype, n):
     o = np.zeros(n, np.float32 if code == 0 else np.uint16)
     oracle.call("cc_silu_mul", oracle.ptr(to_np(a.cpu())), oracle.ptr(to_np(b.cpu())), n, code, oracle.ptr(o), None)
     assert torch.allclose(from_np(o, dtype).float(), out.cpu().float(), rtol=2 * ULP[dtype], atol=1e-6)
+
+
+@pytest.mark.parametrize("dt,V", [(torch.bfloat16, 128256), (torch.float32, 128), (torch.float16, 32000), (torch.float32, 50257)])
+def test_softmax_argmax_matches_torch(dt, V):
+    """cc_softmax_argmax vs torch.softmax / torch.argmax on the device (generation_utils.py:136-142): probabilities
+    within one ulp of the dtype at the largest value, token = first index of the largest ROUNDED probability."""
+    from cold_compress_amd.harness import glue
+
+    g = torch.Generator().manual_seed(V)
+    logits = (torch.randn(V, generator=g) * 3).to(dt).to(DEV)
+    probs, idx = glue.softmax_argmax(logits)
+    ref = torch.softmax(logits, dim=-1)
+    torch.cuda.synchronize()
+    ulp = {torch.float32: 1.2e-7, torch.bfloat16: 2 ** -8, torch.float16: 2 ** -11}[dt]
+    assert (probs.float() - ref.float()).abs().max() <= 2 * ulp * float(ref.max()) + 1e-12
+    assert int(idx) == int(torch.argmax(probs))  # exact given OUR probabilities: first maximal element
+    assert float(ref[int(idx)]) >= float(ref.max()) * (1 - 4 * ulp)
+    # engineered tie: two equal maxima -> the first index wins
+    logits[7] = logits[V - 3] = logits.max() + 1
+    probs, idx = glue.softmax_argmax(logits)
+    assert int(idx) == 7
