@@ -412,7 +412,11 @@ class KVCacheHeavyHitter(KVCacheHeadSpecific):
         else:
             _abi.call("cc_decode_update_heavy_hitter_ring", self._view(), _ptr(k), _ptr(v), _ptr(self._pos32(input_pos)),
                       _ptr(self.attn_history_num), _ptr(self.attn_history_denom), int(self.history_window_size),
-                      int(self.global_tokens), int(self.recent_window), _ptr(self._idx_buf()), _stream())
+                      int(self.global_tokens), int(self.recent_window), _ptr(self._idx_buf()), _ptr(self._wsum_buf()), _stream())
+
+    def _wsum_buf(self):
+        """fp32 [H, S] scratch for the ring window sums (chip-wide pre-pass of the W > 1 policies)."""
+        return self._scratch.get("wsum", (self.n_heads, self.max_cache_length), torch.float32, self.k_cache.device)
 
     def fused_history(self):
         """Pointers the decode attention kernel needs to fold cache.py:690-723 into its combine pass (W == 1 only)."""
@@ -570,7 +574,9 @@ class KVCacheHybrid(KVCacheHeadSpecific):
         is_punc = None
         if hasattr(self, "punc_ids"):
             ids = kwargs.get("input_ids")
-            is_punc = torch.isin(ids.to(self.punc_ids.device), self.punc_ids).reshape(-1)[:1].to(torch.uint8).contiguous()
+            # one token against a handful of ids: a compare + any, not torch.isin (which sorts: ~6 launches per step)
+            is_punc = (ids.to(self.punc_ids.device).reshape(-1)[:1].unsqueeze(1) == self.punc_ids.reshape(1, -1)).any(dim=1) \
+                .to(torch.uint8).contiguous()
         self._is_punc = is_punc
         tab = self._policy_table()
         _abi.call("cc_hybrid_decode_update", self._view(), _ptr(k), _ptr(v), _ptr(self._pos32(input_pos)),
@@ -579,7 +585,9 @@ class KVCacheHybrid(KVCacheHeadSpecific):
                   _ptr(getattr(self, "punc_mask", None)), _ptr(is_punc), _ptr(getattr(self, "num_special", None)),
                   _ptr(getattr(self, "num_punc", None)), int(self.global_tokens),
                   int(bool(self.requires_heavy_hitter and self.reset_history_on_evict)),
-                  _ptr(self._idx_buf()), _stream())
+                  _ptr(self._idx_buf()),
+                  _ptr(self._scratch.get("wsum", (self.n_heads, self.max_cache_length), torch.float32, self.k_cache.device)),
+                  _stream())
 
     def _ring_update(self, attn_ht, T):
         _abi.call("cc_hh_ring_update", _ptr(self.attn_history_num), _ptr(self.attn_history_denom), _ptr(self.attn_counter),

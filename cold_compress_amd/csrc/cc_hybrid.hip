@@ -31,28 +31,51 @@ struct HybArgs {
   int32_t* num_punc;            // device int[1] or null
   int requires_hh;
   int64_t* fill_out;  // [H]
+  const float* wsum;  // [H,S] window sums from the pre-pass
 };
 
-// sum of the W history slots of one cache slot in the model dtype: fp32 accumulation in index order, result
-// rounded to T (ref: cache.py:855-859 `.sum(dim=-1)` on a model-dtype tensor; torch's own fp32 order is
-// unspecified — the oracle uses this same order)
+// dtype(sum of the W history entries of one cache slot) (cache.py:855-859 `.sum(dim=-1)` on a model-dtype tensor;
+// torch's own fp32 order is unspecified).  Canonical order, shared with the oracle: ONE WAVE per cache slot — the
+// row is cut into 16-byte chunks, lane l accumulates chunks l, l+64, ... element by element in index order, the 64
+// partials meet in an xor butterfly (32 .. 1), the total is rounded to the model dtype.  A 400-entry bf16 ring row
+// is 800 contiguous bytes: one fully coalesced load instruction per slot.
 template <typename T>
-__device__ __forceinline__ float window_sum(const T* row, int W) {
+__device__ __forceinline__ float wave_window_sum(const T* row, int W, int lane) {
   constexpr int VEC = 16 / (int)sizeof(T);
   float acc = 0.f;
-  int j = 0;
-  if ((reinterpret_cast<uintptr_t>(row) & 15) == 0) {
-    for (; j + VEC <= W; j += VEC) {
+  const bool aligned = (reinterpret_cast<uintptr_t>(row) & 15) == 0;
+  for (int c = lane; c * VEC < W; c += 64) {
+    if (aligned && c * VEC + VEC <= W) {
       Vec16<T> v;
       float f[VEC];
-      v.load(row + j);
+      v.load(row + (size_t)c * VEC);
       v.unpack(f);
 #pragma unroll
       for (int e = 0; e < VEC; e++) acc = __fadd_rn(acc, f[e]);
+    } else {
+      for (int e = 0; e < VEC && c * VEC + e < W; e++) acc = __fadd_rn(acc, ElemTraits<T>::load(row, (size_t)c * VEC + e));
     }
   }
-  for (; j < W; j++) acc = __fadd_rn(acc, ElemTraits<T>::load(row, j));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc = __fadd_rn(acc, __shfl_xor(acc, off, CC_WAVE));
   return ElemTraits<T>::rnd(acc);
+}
+
+// Pre-pass of the ring policies: wsum[h, s] for every slot of every head that scores by accumulated attention.
+// The [H, S, W] ring is the only large operand of these policies (118 MB at S = 18432, W = 400): it is streamed
+// once, coalesced, by the whole chip — the decision kernels below (one workgroup per head) then read 4 bytes per
+// slot.  (The first version summed rows inside the one-workgroup-per-head kernel: 8 CUs, 800-byte strides, 1.4 ms.)
+template <typename T>
+__global__ __launch_bounds__(256) void ring_window_sum_kernel(const T* num, const int64_t* strategies, const int32_t* table, int H,
+                                                              int S, int W, float* out) {
+  const int lane = threadIdx.x & 63;
+  const size_t total = (size_t)H * S;
+  const size_t nw = (size_t)gridDim.x * (blockDim.x >> 6);
+  for (size_t i = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); i < total; i += nw) {
+    if (strategies != nullptr && !(table[strategies[i / S] * 3] & 1 /* F_HH */)) continue;
+    const float v = wave_window_sum<T>(num + i * (size_t)W, W, lane);
+    if (lane == 0) out[i] = v;
+  }
 }
 
 constexpr int kHybThreads = 1024;
@@ -86,25 +109,44 @@ __global__ __launch_bounds__(kHybThreads) void hybrid_decode_kernel(HybArgs a) {
     } else if (flags & (F_HH | F_WIN)) {  // :932-946 -> _eviction_idx_for_head :844-894
       evict = true;
       unsigned long long best = ~0ull;
-      const T* num = reinterpret_cast<const T*>(a.num);
-      for (int s = threadIdx.x; s < cts && s < S; s += blockDim.x) {
-        float sc;
-        const int32_t ps = a.pos[hoff + s];
-        if (flags & F_HH) {
-          const float nm = window_sum<T>(num + (hoff + s) * (size_t)W, W);
-          int32_t dn = a.denom[hoff + s];
-          dn = dn > W ? W : dn;  // clamp_max only (:868-870): a zero count divides by zero like the reference
-          sc = __fdiv_rn(nm, (float)dn);
-        } else {
-          sc = (float)ps;  // :873
+      // UN slots per thread per iteration, every per-slot load issued before the first use (one workgroup scans a
+      // whole head: the loop is latency-bound unless the loads of several slots are in flight together)
+      constexpr int UN = 4;
+      const int lim = cts < S ? cts : S;
+      for (int s0 = threadIdx.x; s0 < lim; s0 += blockDim.x * UN) {
+        int32_t ps[UN], dn[UN];
+        float ws[UN];
+        uint8_t sp[UN], pm[UN];
+#pragma unroll
+        for (int u = 0; u < UN; u++) {
+          const int s = s0 + u * blockDim.x;
+          const bool in = s < lim;
+          const size_t i = hoff + (in ? s : 0);
+          ps[u] = a.pos[i];
+          ws[u] = (flags & F_HH) ? a.wsum[i] : 0.f;
+          dn[u] = (flags & F_HH) ? a.denom[i] : 1;
+          sp[u] = ((flags & F_SPECIAL) && a.special_mask) ? a.special_mask[i] : 0;
+          pm[u] = ((flags & F_PUNC) && a.punc_mask) ? a.punc_mask[i] : 0;
         }
-        bool save = s < a.g;  // :876 first g SLOTS
-        if ((flags & F_SPECIAL) && a.special_mask) save |= a.special_mask[hoff + s] != 0;
-        if ((flags & F_PUNC) && a.punc_mask) save |= a.punc_mask[hoff + s] != 0;
-        if (flags & F_WIN) save |= ps > p - win;  // :885-889 strict
-        if (save) sc = INFINITY;
-        const unsigned long long key = make_key(orderable_f32(sc), (uint32_t)s);
-        best = key < best ? key : best;
+#pragma unroll
+        for (int u = 0; u < UN; u++) {
+          const int s = s0 + u * blockDim.x;
+          if (s >= lim) continue;
+          float sc;
+          if (flags & F_HH) {
+            const int32_t d = dn[u] > W ? W : dn[u];  // clamp_max only (:868-870): a zero count divides by zero like the reference
+            sc = __fdiv_rn(ws[u], (float)d);
+          } else {
+            sc = (float)ps[u];  // :873
+          }
+          bool save = s < a.g;  // :876 first g SLOTS
+          save |= sp[u] != 0;
+          save |= pm[u] != 0;
+          if (flags & F_WIN) save |= ps[u] > p - win;  // :885-889 strict
+          if (save) sc = INFINITY;
+          const unsigned long long key = make_key(orderable_f32(sc), (uint32_t)s);
+          best = key < best ? key : best;
+        }
       }
       best = block_min_u64(best, sm_key);
       fill = (int)(best & 0xffffffffull);
@@ -152,6 +194,7 @@ struct RingArgs {
   void* num;
   int32_t* denom;
   int64_t* idx_out;
+  const float* wsum;  // [H,S] window sums from the pre-pass
 };
 
 template <typename T>
@@ -166,7 +209,7 @@ __global__ __launch_bounds__(kHybThreads) void hh_ring_decode_kernel(RingArgs a)
     const int32_t ps = a.pos[hoff + s];
     int32_t dn = a.denom[hoff + s];
     dn = dn < 1 ? 1 : (dn > W ? W : dn);
-    float sc = __fdiv_rn(window_sum<T>(num + (hoff + s) * (size_t)W, W), (float)dn);
+    float sc = __fdiv_rn(a.wsum[hoff + s], (float)dn);
     if (ps < a.g || ps >= p - a.w) sc = 1.0f;
     if (ps == -1) sc = 0.0f;
     const unsigned long long key = make_key(orderable_f32(sc), ((uint32_t)s << 1) | (uint32_t)(ps == -1));
@@ -232,6 +275,19 @@ __global__ __launch_bounds__(256) void attn_bandsum_kernel(const T* attn, int H,
   }
 }
 
+static void launch_window_sums(const void* num, const int64_t* strategies, const int32_t* table, int H, int S, int W, int dtype,
+                               float* out, hipStream_t st) {
+  const size_t slots = (size_t)H * S;
+  size_t nb = (slots + 3) / 4;  // 4 waves per workgroup, one slot per wave per iteration
+  if (nb > 4096) nb = 4096;
+  dim3 grid((unsigned)nb), block(256);
+  switch (dtype) {
+    case CC_DT_F32: hipLaunchKernelGGL(ring_window_sum_kernel<float>, grid, block, 0, st, (const float*)num, strategies, table, H, S, W, out); break;
+    case CC_DT_BF16: hipLaunchKernelGGL(ring_window_sum_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)num, strategies, table, H, S, W, out); break;
+    default: hipLaunchKernelGGL(ring_window_sum_kernel<f16_t>, grid, block, 0, st, (const f16_t*)num, strategies, table, H, S, W, out); break;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -240,18 +296,21 @@ int cc_hybrid_decode_update(const cc_kv_view* c, const void* k_new, const void* 
                             const int64_t* strategies, const int32_t* policy_table, int32_t n_policies, void* num,
                             int32_t* denom, int32_t W, const uint8_t* special_mask, uint8_t* punc_mask,
                             const uint8_t* is_punc, const int32_t* num_special, int32_t* num_punc, int32_t global_tokens,
-                            int32_t requires_heavy_hitter, int64_t* fill_out, cc_stream_t stream) {
+                            int32_t requires_heavy_hitter, int64_t* fill_out, float* wsum_workspace, cc_stream_t stream) {
   CC_ENTRY();
   if (!cc_view_ok(c) || !k_new || !v_new || !input_pos || !strategies || !policy_table || n_policies <= 0 || !num ||
       !denom || W <= 0 || !fill_out || c->Hp != c->H || c->Hc != c->H)
     return CC_ERR_BAD_ARG;
+  if (!wsum_workspace) return CC_ERR_WORKSPACE;
   HybArgs a{};
   a.k_cache = c->k_cache; a.v_cache = c->v_cache; a.pos = c->pos; a.mask = c->mask; a.cache_cts = c->cache_cts;
   a.H = c->H; a.S = c->S; a.D = c->D; a.W = W; a.g = global_tokens;
   a.k_new = k_new; a.v_new = v_new; a.input_pos = input_pos; a.strategies = strategies; a.table = policy_table;
   a.num = num; a.denom = denom; a.special_mask = special_mask; a.punc_mask = punc_mask; a.is_punc = is_punc;
   a.num_special = num_special; a.num_punc = num_punc; a.requires_hh = requires_heavy_hitter; a.fill_out = fill_out;
+  a.wsum = wsum_workspace;
   hipStream_t st = (hipStream_t)stream;
+  launch_window_sums(num, strategies, policy_table, c->H, c->S, W, c->dtype, wsum_workspace, st);
   dim3 grid(c->H), block(kHybThreads);
   switch (c->dtype) {
     case CC_DT_F32: hipLaunchKernelGGL(hybrid_decode_kernel<float>, grid, block, 0, st, a); break;
@@ -268,15 +327,18 @@ int cc_hybrid_decode_update(const cc_kv_view* c, const void* k_new, const void* 
 
 int cc_decode_update_heavy_hitter_ring(const cc_kv_view* c, const void* k_new, const void* v_new,
                                        const int32_t* input_pos, void* num, int32_t* denom, int32_t W, int32_t g,
-                                       int32_t w, int64_t* idx_out, cc_stream_t stream) {
+                                       int32_t w, int64_t* idx_out, float* wsum_workspace, cc_stream_t stream) {
   CC_ENTRY();
   if (!cc_view_ok(c) || !input_pos || !idx_out || !num || !denom || W <= 0 || c->Hp != c->H || (k_new && !v_new))
     return CC_ERR_BAD_ARG;
+  if (!wsum_workspace) return CC_ERR_WORKSPACE;
   RingArgs a{};
   a.k_cache = c->k_cache; a.v_cache = c->v_cache; a.pos = c->pos; a.mask = c->mask; a.cache_cts = c->cache_cts;
   a.H = c->H; a.Hc = c->Hc; a.S = c->S; a.D = c->D; a.W = W; a.g = g; a.w = w;
   a.k_new = k_new; a.v_new = v_new; a.input_pos = input_pos; a.num = num; a.denom = denom; a.idx_out = idx_out;
+  a.wsum = wsum_workspace;
   hipStream_t st = (hipStream_t)stream;
+  launch_window_sums(num, nullptr, nullptr, c->H, c->S, W, c->dtype, wsum_workspace, st);
   dim3 grid(c->H), block(kHybThreads);
   switch (c->dtype) {
     case CC_DT_F32: hipLaunchKernelGGL(hh_ring_decode_kernel<float>, grid, block, 0, st, a); break;

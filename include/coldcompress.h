@@ -311,17 +311,19 @@ int cc_hybrid_decode_update(const cc_kv_view* c, const void* k_new, const void* 
                             int32_t* denom, int32_t W, const uint8_t* special_mask, uint8_t* punc_mask,
                             const uint8_t* is_punc, const int32_t* num_special, int32_t* num_punc,
                             int32_t global_tokens, int32_t requires_heavy_hitter, int64_t* fill_out,
-                            cc_stream_t stream);
+                            float* wsum_workspace, cc_stream_t stream);
 
 /* Heavy-hitter decode update with a finite history window (history_window_size W > 1; model-dtype ring).
  * ref: KVCacheHeavyHitter._eviction_idx cache.py:725-765:
  *   avg = float(dtype(sum_W num)) / clamp(denom, 1, W); (pos<g)|(pos>=p-w) -> 1.0; pos==-1 -> 0.0; arg-min;
  *   ring row and denom of the chosen slot zeroed; then the common insert (k_new == NULL: select only).
- * num: [H, S, W] model dtype; denom: [H, S] int32; Hp must be H. */
+ * num: [H, S, W] model dtype; denom: [H, S] int32; Hp must be H.
+ * wsum_workspace: float [H*S] caller scratch (both ring entry points): the window sums are produced by a chip-wide
+ * pre-pass (one wave per slot, coalesced) and only read by the one-workgroup-per-head decision kernel. */
 int cc_decode_update_heavy_hitter_ring(const cc_kv_view* c, const void* k_new, const void* v_new,
                                        const int32_t* input_pos, void* num, int32_t* denom, int32_t W,
                                        int32_t global_tokens, int32_t recent_window, int64_t* idx_out,
-                                       cc_stream_t stream);
+                                       float* wsum_workspace, cc_stream_t stream);
 
 /* History ring update, history_window_size W > 1.  ref: cache.py:716-723:
  *   num[h, s, *counter % W] = attn[h, s] (0 beyond T); denom += 1 everywhere; *counter += 1.

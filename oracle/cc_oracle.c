@@ -753,11 +753,24 @@ int cc_silu_mul_cpu(const void* a, const void* b, int64_t n, int32_t dtype, void
 
 enum { HF_HH = 1, HF_WIN = 2, HF_PUNC = 4, HF_SPECIAL = 8, HF_FULL = 16 };
 
-/* dtype(sum_W row): fp32 accumulation in index order, rounded to the model dtype (cache.py:855-859) */
+/* dtype(sum_W row) (cache.py:855-859 `.sum(dim=-1)` on a model-dtype tensor; torch's fp32 order is unspecified).
+ * Canonical order shared with the device (one wave per cache slot, cc_hybrid.hip ring_window_sum_kernel): the row
+ * is cut into 16-byte chunks; lane l of 64 accumulates chunks l, l+64, ... element by element in index order; the 64
+ * partials meet in an xor butterfly (32, 16, 8, 4, 2, 1); the total is rounded to the model dtype. */
 static float window_sum_row(const void* num, int dt, size_t off, int W) {
-  float acc = 0.f;
-  for (int j = 0; j < W; j++) acc = acc + ld(num, dt, off + j);
-  return rnd(acc, dt);
+  const int vec = 16 / (int)dt_size(dt);
+  float p[64], q[64];
+  for (int l = 0; l < 64; l++) {
+    float acc = 0.f;
+    for (int c = l; c * vec < W; c += 64)
+      for (int e = 0; e < vec && c * vec + e < W; e++) acc = acc + ld(num, dt, off + (size_t)c * vec + e);
+    p[l] = acc;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    for (int l = 0; l < 64; l++) q[l] = p[l] + p[l ^ o];
+    for (int l = 0; l < 64; l++) p[l] = q[l];
+  }
+  return rnd(p[0], dt);
 }
 
 /* ref: KVCacheHybrid._decoding_update cache.py:965-1019, _select_fill_idx :896-950, _eviction_idx_for_head :844-894 */
@@ -765,7 +778,8 @@ int cc_hybrid_decode_update_cpu(const cc_kv_view* c, const void* k_new, const vo
                                 const int64_t* strategies, const int32_t* policy_table, int32_t n_policies, void* num,
                                 int32_t* denom, int32_t W, const uint8_t* special_mask, uint8_t* punc_mask,
                                 const uint8_t* is_punc_p, const int32_t* num_special, int32_t* num_punc, int32_t g,
-                                int32_t requires_hh, int64_t* fill_out, cc_stream_t stream) {
+                                int32_t requires_hh, int64_t* fill_out, float* wsum_workspace, cc_stream_t stream) {
+  (void)wsum_workspace;
   (void)stream;
   if (!view_ok(c) || !k_new || !v_new || !input_pos || !strategies || !policy_table || n_policies <= 0 || !num || !denom ||
       W <= 0 || !fill_out || c->Hp != c->H || c->Hc != c->H)
@@ -909,7 +923,8 @@ int cc_prefill_attn_bands_cpu(const void* q, const void* k, const void* v, int32
 /* ref: KVCacheHeavyHitter._eviction_idx cache.py:725-765 with history_window_size W > 1 */
 int cc_decode_update_heavy_hitter_ring_cpu(const cc_kv_view* c, const void* k_new, const void* v_new,
                                            const int32_t* input_pos, void* num, int32_t* denom, int32_t W, int32_t g,
-                                           int32_t w, int64_t* idx_out, cc_stream_t stream) {
+                                           int32_t w, int64_t* idx_out, float* wsum_workspace, cc_stream_t stream) {
+  (void)wsum_workspace;
   (void)stream;
   if (!view_ok(c) || !input_pos || !idx_out || !num || !denom || W <= 0 || c->Hp != c->H || c->H > 4096) return CC_ERR_BAD_ARG;
   const int32_t p = *input_pos;

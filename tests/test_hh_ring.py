@@ -45,7 +45,7 @@ def test_ring_replay_oracle(oracle, name):
         idx = np.zeros(H, np.int64)
         pp = np.array([T + t], np.int32)
         o.call("cc_decode_update_heavy_hitter_ring", C.byref(view), o.ptr(to_np(f["k_new"][t].reshape(H, D))),
-               o.ptr(to_np(f["v_new"][t].reshape(H, D))), o.ptr(pp), o.ptr(num), o.ptr(denom), W, g, w, o.ptr(idx), None)
+               o.ptr(to_np(f["v_new"][t].reshape(H, D))), o.ptr(pp), o.ptr(num), o.ptr(denom), W, g, w, o.ptr(idx), None, None)
         assert np.array_equal(idx, f["idx"][t].numpy()), f"step {t}"
         assert np.array_equal(cts, f["cache_cts_steps"][t].numpy())
         o.call("cc_hh_ring_update", o.ptr(num), o.ptr(denom), o.ptr(counter), o.ptr(to_np(f["attn"][t][0, :, 0])), H, S, S, W, code, None)

@@ -57,7 +57,7 @@ def test_hybrid_decode_replay_bit_exact(oracle, name):
         fill = np.zeros(H, np.int64)
         o.call("cc_hybrid_decode_update", C.byref(view), o.ptr(kn), o.ptr(vn), o.ptr(p), o.ptr(strat), o.ptr(tab), len(tab),
                o.ptr(num), o.ptr(denom), W, o.ptr(special), o.ptr(punc), o.ptr(is_punc), o.ptr(n_special), o.ptr(n_punc), 4,
-               0, o.ptr(fill), None)  # 0: the reference's history reset on eviction is an effective no-op
+               0, o.ptr(fill), None, None)  # 0: the reference's history reset on eviction is an effective no-op
         assert np.array_equal(fill, f["fill"][t].numpy()), f"step {t}: {fill} vs {f['fill'][t].tolist()}"
         assert np.array_equal(cts, f["cts_steps"][t].numpy()), f"step {t}"
         if f["requires_hh"]:

@@ -1,0 +1,112 @@
+#!/usr/bin/env python3
+"""Layer-step time (update_kv + attention + update_state, hipGraph-replayed, rotating over > 512 MB of distinct K/V)
+of every cache policy at the SURVEY §8(d) configurations: C2 (S = 2560), C3 (S = 4096), C4 (hybrid S = 18432),
+C5 (Llama-3-70B at TP = 8: one kv head, 8 query heads per rank, S = 3488).  Llama-3 head geometry, bf16."""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch  # noqa: E402
+
+from cold_compress_amd.attention_utils import scaled_dot_product_attention as sdpa  # noqa: E402
+from cold_compress_amd.cache import get_cache_constructor  # noqa: E402
+
+dev = "cuda"
+HYBRID = [{"strategy": "special"}, {"strategy": "special_punc"}, {"strategy": "special_punc_heavy_hitter", "heavy_hitter_frac": 0.3},
+          {"strategy": "special_punc_window", "recent_window": 0.3}, {"strategy": "full"}]
+
+
+def timed(fn, n, iters=8):
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        fn(0)
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for i in range(n):
+            fn(i)
+    g.replay()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(iters):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3 / n)
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+def make(strategy, H, S, D, extra=None):
+    cls, rk = get_cache_constructor(strategy)
+    kw = dict(max_cache_length=S, global_tokens=4, max_seq_length=4 * S, cache_bits=None, recent_window=10, history_window_size=1,
+              attn_thresholding=False, token_ids={"special": [[1], [2, 3]], "punctuation": [5, 6, 7]}, min_recovery_frac=0.9,
+              hybrid_strategies=HYBRID)
+    kw.update(extra or {})
+    with torch.device(dev):
+        kv = cls(1, H, D, torch.bfloat16, **{k: kw[k] for k in rk})
+    T = S
+    kv.k_cache.normal_()
+    kv.v_cache.normal_()
+    kv.pos[0] = torch.stack([torch.randperm(S + 64, device=dev)[:S] for _ in range(kv.pos.shape[1])]).int()
+    kv.mask.fill_(True)
+    kv.cache_cts.fill_(S)
+    if hasattr(kv, "attn_history_num"):
+        kv.attn_history_num.uniform_()
+        kv.attn_history_denom.fill_(3)
+    if hasattr(kv, "key_norm"):
+        kv.key_norm.uniform_(8, 12)
+    if strategy == "hybrid":  # a decode-ready state: head h runs policy h % 5
+        kv.cache_strategies = (torch.arange(H, device=dev) % len(HYBRID)).to(torch.int64).contiguous()
+        kv.requires_heavy_hitter = kv.requires_punc = kv.requires_special = True
+    return kv
+
+
+def main():
+    cfgs = [("C2", 8, 32, 2560), ("C3", 8, 32, 4096), ("C4", 8, 32, 18432), ("C5", 1, 8, 3488)]
+    D = 128
+    for tag, H, HQ, S in cfgs:
+        n_buf = max(4, min(32, (600 << 20) // (2 * H * S * D * 2) + 1))
+        for strategy in (["hybrid"] if tag == "C4" else ["heavy_hitter", "l2", "random", "recent_global", "full"]) + (["heavy_hitter"] if tag == "C4" else []):
+            try:
+                caches = [make(strategy, H, S, D) for _ in range(n_buf)]
+            except Exception as e:
+                print(json.dumps({"cfg": tag, "strategy": strategy, "error": f"{type(e).__name__}: {e}"[:160]}), flush=True)
+                continue
+            q = torch.randn(1, HQ, 1, D, device=dev).to(torch.bfloat16)
+            k1 = torch.randn(1, H, 1, D, device=dev).to(torch.bfloat16)
+            pos = torch.tensor([S + 100], dtype=torch.int32, device=dev)
+            ids = torch.tensor([[11]], device=dev)
+
+            def three_call(i):
+                kv = caches[i % n_buf]
+                k, v, m = kv.update_kv(pos, k1, k1, False, input_ids=ids)
+                fuse = strategy == "heavy_hitter"
+                y, a = sdpa(q, k, v, attn_mask=m, return_attn=kv.return_attn() and not fuse, group_mean=True,
+                            history=kv.fused_history() if fuse else None)
+                if fuse:
+                    kv._state_fused = True
+                kv.update_state(pos, k1, k1, False, a, input_ids=ids)
+
+            for i in range(n_buf):  # lazily built per-cache tables / scratch must exist before graph capture
+                three_call(i)
+            res = {"cfg": tag, "strategy": strategy, "H": H, "HQ": HQ, "S": S, "three_call_us": round(timed(three_call, n_buf), 2)}
+            if strategy == "heavy_hitter":
+                for kv in caches:
+                    kv.prepare_decode(pos)
+                res["fused_step_us"] = round(timed(lambda i: caches[i % n_buf].decode_step(q, k1, k1, pos), n_buf), 2)
+            b = 2 * H * S * D * 2
+            res["kv_MB"] = round(b / 1e6, 1)
+            best = res.get("fused_step_us", res["three_call_us"])
+            res["kv_GBps"] = round(b / best / 1e3)
+            print(json.dumps(res), flush=True)
+            del caches
+            torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()
