@@ -162,3 +162,37 @@ def test_oracle_exports_cpu_twins(oracle):
 
     fns = oracle.fns()
     assert set(fns) == set(_abi.SIGNATURES) - _abi.DEVICE_ONLY
+
+
+def test_oracle_glue_twins_match_torch_cpu(oracle):
+    """The oracle's twins of the caller-glue entry points (cc_gemv_fused, cc_softmax_argmax) against plain PyTorch on
+    CPU in fp32 — they are the checkers of the GPU tests, so they get pinned here (tolerance: fp32 summation order)."""
+    import numpy as np
+
+    g = torch.Generator().manual_seed(3)
+    N, K, hd = 96, 64, 16
+    W, W3 = torch.randn(N, K, generator=g) * 0.1, torch.randn(N, K, generator=g) * 0.1
+    x, delta, nw = torch.randn(K, generator=g), torch.randn(K, generator=g) * 0.3, 1 + 0.1 * torch.randn(K, generator=g)
+    ang = torch.rand(hd // 2, generator=g) * 6.28
+    freqs = torch.stack([torch.cos(ang), torch.sin(ang)], -1).contiguous()
+    h = x + delta
+    n = h * torch.rsqrt((h * h).mean() + 1e-5) * nw
+    o = oracle
+    f = lambda t: o.ptr(t.numpy().copy()) if t is not None else None  # noqa: E731
+    # norm prologue + RoPE epilogue on the first 64 rows
+    y, hout = np.zeros(N, np.float32), np.zeros(K, np.float32)
+    o.call("cc_gemv_fused", f(W), None, f(x), f(delta), f(nw), 1e-5, o.ptr(hout), None, f(freqs), 64, hd, o.ptr(y), N, K, 0, None)
+    t = W @ n
+    rr = t[:64].view(-1, hd // 2, 2)
+    c, s = freqs[:, 0].view(1, -1), freqs[:, 1].view(1, -1)
+    ref = torch.cat([torch.stack([rr[..., 0] * c - rr[..., 1] * s, rr[..., 1] * c + rr[..., 0] * s], -1).reshape(-1), t[64:]])
+    assert np.allclose(y, ref.numpy(), rtol=1e-5, atol=1e-5) and np.allclose(hout, h.numpy(), rtol=0, atol=0)
+    # SwiGLU pair
+    o.call("cc_gemv_fused", f(W), f(W3), f(x), None, None, 1e-5, None, None, None, 0, 0, o.ptr(y), N, K, 0, None)
+    assert np.allclose(y, (torch.nn.functional.silu(W @ x) * (W3 @ x)).numpy(), rtol=1e-5, atol=1e-5)
+    # greedy tail: first maximal element on ties
+    logits = torch.randn(1000, generator=g)
+    logits[17] = logits[900] = 9.0
+    probs, idx = np.zeros(1000, np.float32), np.zeros(1, np.int32)
+    o.call("cc_softmax_argmax", f(logits), 1000, 0, o.ptr(probs), o.ptr(idx), None, 0, None)
+    assert np.allclose(probs, torch.softmax(logits, -1).numpy(), rtol=1e-5, atol=1e-8) and int(idx[0]) == 17
