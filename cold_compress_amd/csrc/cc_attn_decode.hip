@@ -516,13 +516,13 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_split_mfma_kernel(SplitAr
 #pragma unroll
     for (int u = 0; u < U; u++) {
       const int rr = row0 + u < row_end ? row0 + u : row_end - 1;
-      kk[u].load(kb + (size_t)rr * D + ((c ^ (4 * g + u)) & 15) * VEC);
+      kk[u].load_nt(kb + (size_t)rr * D + ((c ^ (4 * g + u)) & 15) * VEC);
     }
   };
   auto issue_v = [&](int base) {
     const int row0 = base + g * U;
 #pragma unroll
-    for (int u = 0; u < U; u++) vv[u].load(vh + (size_t)(row0 + u < row_end ? row0 + u : row_end - 1) * D);
+    for (int u = 0; u < U; u++) vv[u].load_nt(vh + (size_t)(row0 + u < row_end ? row0 + u : row_end - 1) * D);
   };
   int base = row_begin + wave * (RPW * U);
   bool more = base < row_end;
@@ -723,7 +723,9 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_split_mfma_kernel(SplitAr
     O.z += dpp_mov<0xB1>(O.z);
     O.w += dpp_mov<0xB1>(O.w);
     L += dpp_mov<0xB1>(L);
-    if (half == 0) {
+    if (a.abl & 16) {  // measurement only: merge but do not store the partials
+      if (O.x + O.y + O.z + O.w + L == 1.2345f) a.part_ml[0] = L;
+    } else if (half == 0) {
       const size_t pj = (size_t)(q0 + r) * a.n_split + split;
       *reinterpret_cast<float4*>(a.part_o + pj * D + 4 * k4) = O;
       if (k4 == 0) *reinterpret_cast<float2*>(a.part_ml + pj * 2) = make_float2(M, L);

@@ -68,6 +68,12 @@ struct Vec16 {
   static constexpr int N = 16 / sizeof(T);
   uint4 raw;
   __device__ __forceinline__ void load(const T* p) { raw = *reinterpret_cast<const uint4*>(p); }
+  // streamed-once data (K/V rows of a decode step, weights): non-temporal, do not displace what L2 / MALL hold
+  __device__ __forceinline__ void load_nt(const T* p) {
+    typedef unsigned int u32x4_nt __attribute__((ext_vector_type(4)));
+    const u32x4_nt v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_nt*>(p));
+    raw = make_uint4(v.x, v.y, v.z, v.w);
+  }
   __device__ __forceinline__ void unpack(float* out) const;
 };
 template <>

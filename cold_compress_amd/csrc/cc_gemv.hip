@@ -74,6 +74,12 @@ __device__ __forceinline__ float gv_wave_sum(float v) {
   return (r0 + r1) + (r2 + r3);
 }
 
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 nt_load(const uint4* p) {  // streamed once per token: do not keep it in L2 / MALL
+  const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 struct GemvArgs {
   const void* W;
   const void* W3;      // second matrix of the SwiGLU pair, or null
@@ -133,8 +139,10 @@ __global__ __launch_bounds__(kGvThreads) void gemv_kernel(GemvArgs a) {
       for (int r = 0; r < RB; r++) {
         const bool in = cin && (r0 + r < N);
         const size_t off = (size_t)(r0 + r) * nch + c;
-        w[r][u] = in ? Wv[off] : make_uint4(0, 0, 0, 0);
-        if (SWIGLU) w3[r][u] = in ? W3v[off] : make_uint4(0, 0, 0, 0);
+        // non-temporal: 15 GB of weights pass once per token, nothing is gained by keeping them in L2 / the 256 MB
+        // Infinity Cache (measured: w1+w3 43.1 -> 40.1 us, w2 24.8 -> 22.5 us)
+        w[r][u] = in ? nt_load(Wv + off) : make_uint4(0, 0, 0, 0);
+        if (SWIGLU) w3[r][u] = in ? nt_load(W3v + off) : make_uint4(0, 0, 0, 0);
       }
     }
   };

@@ -127,7 +127,7 @@ def main():
             continue
         if a.ablate:
             res = {"S": S}
-            for name, bits in (("full", 0), ("no_store", 1), ("no_epilogue", 2), ("no_mask", 4), ("no_store_epi", 3),
+            for name, bits in (("full", 0), ("no_store", 1), ("no_epilogue", 2), ("no_mask", 4), ("no_store_epi", 3), ("no_partial_store", 16), ("no_stores_at_all", 17),
                                ("none", 7)):
                 t, _ = timed_graph(lambda i, b=bits: attn(i, 1 | (b << 8), False), n)
                 res[name + "_us"] = round(t, 2)
