@@ -274,4 +274,8 @@ class Transformer(nn.Module):
         x, delta = self.tok_embeddings(idx), None
         for layer in self.layers:
             x, delta = layer(x, delta, idx, input_pos, is_prefill, freqs_cis, mask, attn_top_k=attn_top_k)
+        if (not is_prefill and x.shape[1] == 1 and x.is_cuda and self.layers[0].fuse_gemv and self.output.bias is None
+                and glue.gemv_supported(self.output.weight)):
+            # final RMSNorm (with the last pending residual) fused into the streamed LM head
+            return glue.gemv_fused(self.output.weight, x, delta=delta, norm_weight=self.norm.weight, eps=self.norm.eps).view(1, 1, -1)
         return self.output(self.norm(x, delta)[1])
