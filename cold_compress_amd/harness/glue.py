@@ -3,9 +3,9 @@
 These are NOT part of the cache/attention hot path — they are the model-side code around it
 (ref: model.py:317-327, 375-387, 442-443, 452-457, 507-519), which the reference leaves to ~45 eager elementwise
 launches per layer or to torch.compile.  On device tensors they call the C ABI (`cc_add_rmsnorm`, `cc_qkv_rope`,
-`cc_silu_mul`); on CPU tensors (host-only unit tests of the model wiring, e.g. the gloo TP test) the same
-formulas run as plain eager PyTorch, exactly as the reference writes them.  The cache / attention classes have no
-such host path.
+`cc_silu_mul`, `cc_gemv_fused`, `cc_softmax_argmax`); CPU tensors raise.  Only when a unit test of the model wiring
+sets `HOST_EAGER_FOR_TESTS` (the gloo TP test) do the three elementwise formulas run as plain eager PyTorch,
+exactly as the reference writes them.  The cache / attention classes have no host path at all.
 """
 import ctypes as C
 
@@ -15,6 +15,16 @@ import torch.nn.functional as F
 from .. import _abi
 
 _DT = {torch.float32: _abi.CC_DT_F32, torch.bfloat16: _abi.CC_DT_BF16, torch.float16: _abi.CC_DT_F16}
+
+# Host-side eager restatement of the three glue formulas, for unit tests of the MODEL WIRING only (the gloo tensor-
+# parallel test runs the harness on CPU tensors with a test-local attention double).  Off by default: on the product
+# path a CPU tensor reaching the glue raises, like it does in the cache / attention classes.
+HOST_EAGER_FOR_TESTS = False
+
+
+def _host(t, what):
+    if not HOST_EAGER_FOR_TESTS:
+        raise _abi.ColdCompressError(f"{what} is on {t.device}: the HIP path needs ROCm device tensors (no CPU fallback).")
 
 
 def _stream():
@@ -28,6 +38,7 @@ def _p(t):
 def add_rmsnorm(x, weight, eps, delta=None):
     """-> (h, normed) with h = x + delta (or x itself when delta is None)."""
     if not x.is_cuda:
+        _host(x, "add_rmsnorm input")
         h = x if delta is None else x + delta
         hf = h.float()
         return h, (hf * torch.rsqrt(torch.mean(hf * hf, dim=-1, keepdim=True) + eps)).type_as(h) * weight
@@ -59,6 +70,7 @@ def qkv_rope(qkv, freqs_cis, n_head, n_local_heads, head_dim):
     bsz, T, _ = qkv.shape
     HQ, H, D = n_head, n_local_heads, head_dim
     if not qkv.is_cuda:
+        _host(qkv, "qkv_rope input")
         q, k, v = qkv.split([HQ * D, H * D, H * D], dim=-1)
         q = apply_rotary_emb(q.view(bsz, T, HQ, D), freqs_cis).transpose(1, 2)
         k = apply_rotary_emb(k.view(bsz, T, H, D), freqs_cis).transpose(1, 2)
@@ -74,6 +86,7 @@ def qkv_rope(qkv, freqs_cis, n_head, n_local_heads, head_dim):
 
 def silu_mul(a, b):
     if not a.is_cuda:
+        _host(a, "silu_mul input")
         return F.silu(a) * b
     ac, bc = a.contiguous(), b.contiguous()
     out = torch.empty_like(ac)

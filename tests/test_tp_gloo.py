@@ -60,6 +60,7 @@ def _worker(rank, world, port, q):
 
         assert tp.maybe_init_dist() == rank and dist.get_backend() == "gloo"
         hm.scaled_dot_product_attention = _attention_double
+        hm.glue.HOST_EAGER_FOR_TESTS = True  # CPU tensors: model wiring only, with the test-local attention double
         torch.manual_seed(0)
         cfg = dict(block_size=64, vocab_size=64, n_layer=2, n_head=8, n_local_heads=4, dim=64, intermediate_size=96)
         full = Transformer(ModelArgs(**cfg)).eval()
