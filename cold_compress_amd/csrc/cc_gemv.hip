@@ -298,6 +298,7 @@ static GvCfg pick_cfg(const GemvArgs& a, int vec) {
     c.rb = 2; c.cu = (nstep <= 4 || nstep > 8) ? 4 : 8;
   } else {
     c.rb = 4; c.cu = 4;
+    c.cap = 512;  // long rows: two workgroups per CU looping over row groups (w2: 21.1 vs 21.8 us at 1024+)
   }
   return c;
 }

@@ -50,7 +50,10 @@ def gemv(W, x, y, W3=None, delta=None, nw=None, h_out=None, freqs=None, rope_row
 def main():
     torch.manual_seed(0)
     shapes = {"wqkv": (6144, 4096), "wo": (4096, 4096), "w1": (14336, 4096), "w2": (4096, 14336), "lm_head": (128256, 4096)}
+    only = sys.argv[1:]
     for name, (N, K) in shapes.items():
+        if only and name not in only:
+            continue
         nbytes = N * K * 2
         ncopy = max(2, (600 << 20) // nbytes + 1) if nbytes < (600 << 20) else 1
         Ws = [torch.randn(N, K, device=dev).mul_(0.02).to(torch.bfloat16) for _ in range(ncopy)]
