@@ -37,7 +37,8 @@ def parse():
     ap.add_argument("--prompt_len", type=int, default=8192)
     ap.add_argument("--cache_len", type=int, default=4096)
     ap.add_argument("--n_layer", type=int, default=32, help="debug only; anything but 32 is not the named config")
-    ap.add_argument("--no_graph", action="store_true")
+    ap.add_argument("--no_graph", action="store_true", help="force eager launches")
+    ap.add_argument("--graph", action="store_true", help="force hipGraph replay (default: time both on a few untimed tokens, keep the faster)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--cpu_tokens", type=int, default=20)
     ap.add_argument("--roofline_iters", type=int, default=20)
@@ -50,7 +51,7 @@ def build_model(args, world, dev):
 
     cfg = dict(CONFIGS["Meta-Llama-3.1-8B-Instruct"])
     cfg["n_layer"] = args.n_layer
-    cfg["block_size"] = max(16384, args.prompt_len + args.steps + args.warmup + 64)
+    cfg["block_size"] = max(16384, args.prompt_len + args.steps + args.warmup + 128)
     torch.manual_seed(1234)  # the seed generate.py:108 uses
     with torch.device("meta"):
         model = Transformer(ModelArgs(**cfg))
@@ -290,26 +291,52 @@ def main():
         prefill_s = time.perf_counter() - t0
         pos = torch.tensor([args.prompt_len], dtype=torch.int32, device=dev)
         cur = tok.view(1, 1).to(torch.int32)
-        mode = "hipgraph"
-        dec = decode_one_token
+        # Decode launch mode: hipGraph replay or plain eager launches — same kernels, same results.  With six launches
+        # per layer the GPU side of a token (~3 ms) hides the ~200 Python launches, and graph replay measured 2.4 %
+        # SLOWER than eager on one GPU; under tensor parallelism the per-rank work shrinks and the graph wins.  Default:
+        # time both on a few untimed tokens and keep the faster (ranks agree through a MAX all-reduce).
+        def run_with(dec_fn, n):
+            nonlocal cur
+            for _ in range(n):
+                nt, _ = dec_fn(model, cur, pos)
+                cur = nt.view(1, 1)
+                pos.add_(1)
+
+        def timed_tokens(dec_fn, n):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            run_with(dec_fn, n)
+            torch.cuda.synchronize()
+            t = time.perf_counter() - t
+            if world > 1:
+                tt = torch.tensor([t], device=dev, dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                t = float(tt.item())
+            return t
+
+        gdec = None
         if not args.no_graph:
             try:
-                dec = GraphedDecoder(model)
-                dec(model, cur, pos)  # captures (on a state snapshot) and runs the first step
-                pos += 1
+                gdec = GraphedDecoder(model)
+                run_with(gdec, 1)  # captures (on a state snapshot) and runs the first step
             except Exception as e:  # pragma: no cover - only if capture is refused (e.g. RCCL under capture)
                 print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); falling back to eager launches",
                       file=sys.stderr)
-                dec, mode = decode_one_token, "eager"
+                gdec = None
+        if gdec is None:
+            dec, mode = decode_one_token, "eager"
+        elif args.graph:
+            dec, mode = gdec, "hipgraph"
         else:
-            mode = "eager"
+            run_with(decode_one_token, 6)
+            t_e = timed_tokens(decode_one_token, 24)
+            run_with(gdec, 6)
+            t_g = timed_tokens(gdec, 24)
+            dec, mode = (gdec, "hipgraph") if t_g < t_e else (decode_one_token, "eager")
+            print(f"[bench] decode mode: {mode} (24 tokens: eager {t_e * 1e3:.2f} ms, hipgraph {t_g * 1e3:.2f} ms)", file=sys.stderr)
 
         def run(n):
-            nonlocal cur
-            for _ in range(n):
-                nt, _ = dec(model, cur, pos)
-                cur = nt.view(1, 1)
-                pos.add_(1)
+            run_with(dec, n)
 
         run(args.warmup)
         if world > 1:
