@@ -151,10 +151,10 @@ class KVCache(nn.Module):
         next update, or when this method is called — and the quantised image / scales / zero points are emitted."""
         if self.quantize and self._quant_pending:
             H, S, D = self.n_heads, self.max_cache_length, self.head_dim
-            for w, q, sc, zp in ((self.k_cache, self.k_cache_q, self.k_scales, self.k_zero_points),
-                                 (self.v_cache, self.v_cache_q, self.v_scales, self.v_zero_points)):
-                _need_device(w, "k/v cache")
-                _abi.call("cc_kv_requant", _ptr(w), _ptr(q), _ptr(sc), _ptr(zp), H, S, D, _DT[w.dtype], int(self.n_bit), _stream())
+            _need_device(self.k_cache, "k/v cache")
+            _abi.call("cc_kv_requant_pair", _ptr(self.k_cache), _ptr(self.k_cache_q), _ptr(self.k_scales), _ptr(self.k_zero_points),
+                      _ptr(self.v_cache), _ptr(self.v_cache_q), _ptr(self.v_scales), _ptr(self.v_zero_points), H, S, D,
+                      _DT[self.k_cache.dtype], int(self.n_bit), _stream())
             self._quant_pending = False
 
     def dequantize_cache(self):

@@ -21,9 +21,19 @@ __device__ __forceinline__ float q_dequant(int q, int half, float scale, float z
   return ElemTraits<T>::rnd(__fadd_rn(ElemTraits<T>::rnd(__fmul_rn((float)(q - half), scale)), zero));
 }
 
+struct RequantSet {
+  void* work[2];
+  uint8_t* q[2];
+  void* scales[2];
+  void* zeros[2];
+};
+
 template <typename T>
-__global__ __launch_bounds__(kQThreads) void kv_requant_kernel(T* work, uint8_t* q_out, T* scales, T* zeros, int H, int S,
-                                                              int D, int n_bit) {
+__global__ __launch_bounds__(kQThreads) void kv_requant_kernel(RequantSet rs, int H, int S, int D, int n_bit) {
+  T* work = reinterpret_cast<T*>(rs.work[blockIdx.y]);  // blockIdx.y: 0 = K, 1 = V (one launch for both)
+  uint8_t* q_out = rs.q[blockIdx.y];
+  T* scales = reinterpret_cast<T*>(rs.scales[blockIdx.y]);
+  T* zeros = reinterpret_cast<T*>(rs.zeros[blockIdx.y]);
   __shared__ float sm_mn[kQThreads / 64], sm_mx[kQThreads / 64];
   const int s = blockIdx.x;
   const int n = H * D;
@@ -135,6 +145,116 @@ static bool quant_args_ok(int H, int S, int D, int dtype, int n_bit) {
   return H > 0 && S > 0 && D > 0 && cc_dt_ok(dtype) && (n_bit == 8 || n_bit == 4 || n_bit == 2) && D % (8 / n_bit) == 0;
 }
 
+// Vectorised round trip: one thread = one 16-byte vector of the slot (H * D / VEC threads per slot, up to 1024), so a
+// slot costs one 16-byte load, one 16-byte store of the round trip and one packed store of the image per thread
+// (the element-wise kernel above issues 2-byte loads: ~1 TB/s).  Same arithmetic, element for element.
+template <typename T>
+__global__ __launch_bounds__(1024) void kv_requant_vec_kernel(RequantSet rs, int H, int S, int D, int n_bit) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  __shared__ float sm_mn[16], sm_mx[16];
+  T* work = reinterpret_cast<T*>(rs.work[blockIdx.y]);
+  uint8_t* q_out = rs.q[blockIdx.y];
+  T* scales = reinterpret_cast<T*>(rs.scales[blockIdx.y]);
+  T* zeros = reinterpret_cast<T*>(rs.zeros[blockIdx.y]);
+  const int s = blockIdx.x;
+  const int vpr = D / VEC;           // vectors per row
+  const int nvec = H * vpr;          // == blockDim.x rounded up to a wave
+  const int v = threadIdx.x;
+  const bool in = v < nvec;
+  const int h = in ? v / vpr : 0, dv = in ? v - (v / vpr) * vpr : 0;
+  const size_t base = ((size_t)h * S + s) * D + (size_t)dv * VEC;
+  const int max_int = (1 << n_bit) - 1, half = 1 << (n_bit - 1);
+  float x[VEC];
+  float mn = INFINITY, mx = -INFINITY;
+  if (in) {
+    Vec16<T> xv;
+    xv.load(work + base);
+    xv.unpack(x);
+#pragma unroll
+    for (int e = 0; e < VEC; e++) {
+      mn = fminf(mn, x[e]);
+      mx = fmaxf(mx, x[e]);
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    mn = fminf(mn, __shfl_xor(mn, off, CC_WAVE));
+    mx = fmaxf(mx, __shfl_xor(mx, off, CC_WAVE));
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  if (lane == 0) {
+    sm_mn[wave] = mn;
+    sm_mx[wave] = mx;
+  }
+  __syncthreads();
+  mn = sm_mn[0];
+  mx = sm_mx[0];
+  for (int w = 1; w < nw; w++) {
+    mn = fminf(mn, sm_mn[w]);
+    mx = fmaxf(mx, sm_mx[w]);
+  }
+  float range = ElemTraits<T>::rnd(__fsub_rn(mx, mn));
+  const float floor_t = ElemTraits<T>::rnd(1e-6f);
+  range = range < floor_t ? floor_t : range;
+  const float scale = ElemTraits<T>::rnd(__fdiv_rn(range, (float)max_int));
+  const float zero = ElemTraits<T>::rnd(__fadd_rn(mn, ElemTraits<T>::rnd(__fmul_rn(scale, (float)half))));
+  if (threadIdx.x == 0) {
+    ElemTraits<T>::store(scales, (size_t)s, scale);
+    ElemTraits<T>::store(zeros, (size_t)s, zero);
+  }
+  if (!in) return;
+  float o[VEC];
+  unsigned long long packed = 0ull;  // VEC values of n_bit bits, value j shifted left by j * n_bit
+#pragma unroll
+  for (int e = 0; e < VEC; e++) {
+    float t = ElemTraits<T>::rnd(__fdiv_rn(ElemTraits<T>::rnd(__fsub_rn(x[e], mn)), scale));
+    t = fminf(fmaxf(rintf(t), 0.f), (float)max_int);
+    const int q = (int)t;
+    o[e] = q_dequant<T>(q, half, scale, zero);
+    packed |= (unsigned long long)q << (e * n_bit);
+  }
+  if constexpr (sizeof(T) == 4) {
+    *reinterpret_cast<float4*>(work + base) = make_float4(o[0], o[1], o[2], o[3]);
+  } else {
+    T e16[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; e++) ElemTraits<T>::store(&e16[e], 0, o[e]);
+    uint32_t w32[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) w32[i] = (uint32_t)e16[2 * i].x | ((uint32_t)e16[2 * i + 1].x << 16);
+    *reinterpret_cast<uint4*>(work + base) = make_uint4(w32[0], w32[1], w32[2], w32[3]);
+  }
+  const size_t qbyte = base * n_bit / 8;  // VEC * n_bit is a whole number of bytes (VEC >= 4)
+  const int nbytes = VEC * n_bit / 8;
+  if (nbytes == 8) *reinterpret_cast<uint2*>(q_out + qbyte) = make_uint2((uint32_t)packed, (uint32_t)(packed >> 32));
+  else if (nbytes == 4) *reinterpret_cast<uint32_t*>(q_out + qbyte) = (uint32_t)packed;
+  else if (nbytes == 2) *reinterpret_cast<uint16_t*>(q_out + qbyte) = (uint16_t)packed;
+  else q_out[qbyte] = (uint8_t)packed;
+}
+
+static int requant_launch(const RequantSet& rs, int n, int32_t H, int32_t S, int32_t D, int32_t dtype, int32_t n_bit, hipStream_t st) {
+  const int vec = 16 / (int)cc_dt_size(dtype);
+  if (D % vec == 0 && H * (D / vec) <= 1024) {  // the common case: one thread per 16-byte vector of the slot
+    const int threads = ((H * (D / vec) + 63) / 64) * 64;
+    dim3 grid(S, n), block(threads);
+    switch (dtype) {
+      case CC_DT_F32: hipLaunchKernelGGL(kv_requant_vec_kernel<float>, grid, block, 0, st, rs, H, S, D, n_bit); break;
+      case CC_DT_BF16: hipLaunchKernelGGL(kv_requant_vec_kernel<bf16_t>, grid, block, 0, st, rs, H, S, D, n_bit); break;
+      default: hipLaunchKernelGGL(kv_requant_vec_kernel<f16_t>, grid, block, 0, st, rs, H, S, D, n_bit); break;
+    }
+    CC_LAUNCH_CHECK();
+    return CC_OK;
+  }
+  dim3 grid(S, n), block(kQThreads);
+  switch (dtype) {
+    case CC_DT_F32: hipLaunchKernelGGL(kv_requant_kernel<float>, grid, block, 0, st, rs, H, S, D, n_bit); break;
+    case CC_DT_BF16: hipLaunchKernelGGL(kv_requant_kernel<bf16_t>, grid, block, 0, st, rs, H, S, D, n_bit); break;
+    default: hipLaunchKernelGGL(kv_requant_kernel<f16_t>, grid, block, 0, st, rs, H, S, D, n_bit); break;
+  }
+  CC_LAUNCH_CHECK();
+  return CC_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -143,24 +263,18 @@ int cc_kv_requant(void* work, void* q_out, void* scales, void* zeros, int32_t H,
                   int32_t n_bit, cc_stream_t stream) {
   CC_ENTRY();
   if (!work || !q_out || !scales || !zeros || !quant_args_ok(H, S, D, dtype, n_bit)) return CC_ERR_BAD_ARG;
-  hipStream_t st = (hipStream_t)stream;
-  uint8_t* q = reinterpret_cast<uint8_t*>(q_out);
-  switch (dtype) {
-    case CC_DT_F32:
-      hipLaunchKernelGGL(kv_requant_kernel<float>, dim3(S), dim3(kQThreads), 0, st, (float*)work, q, (float*)scales,
-                         (float*)zeros, H, S, D, n_bit);
-      break;
-    case CC_DT_BF16:
-      hipLaunchKernelGGL(kv_requant_kernel<bf16_t>, dim3(S), dim3(kQThreads), 0, st, (bf16_t*)work, q, (bf16_t*)scales,
-                         (bf16_t*)zeros, H, S, D, n_bit);
-      break;
-    default:
-      hipLaunchKernelGGL(kv_requant_kernel<f16_t>, dim3(S), dim3(kQThreads), 0, st, (f16_t*)work, q, (f16_t*)scales,
-                         (f16_t*)zeros, H, S, D, n_bit);
-      break;
-  }
-  CC_LAUNCH_CHECK();
-  return CC_OK;
+  RequantSet rs{{work, nullptr}, {reinterpret_cast<uint8_t*>(q_out), nullptr}, {scales, nullptr}, {zeros, nullptr}};
+  return requant_launch(rs, 1, H, S, D, dtype, n_bit, (hipStream_t)stream);
+}
+
+int cc_kv_requant_pair(void* k_work, void* k_q, void* k_scales, void* k_zeros, void* v_work, void* v_q, void* v_scales,
+                       void* v_zeros, int32_t H, int32_t S, int32_t D, int32_t dtype, int32_t n_bit, cc_stream_t stream) {
+  CC_ENTRY();
+  if (!k_work || !k_q || !k_scales || !k_zeros || !v_work || !v_q || !v_scales || !v_zeros || !quant_args_ok(H, S, D, dtype, n_bit))
+    return CC_ERR_BAD_ARG;
+  RequantSet rs{{k_work, v_work}, {reinterpret_cast<uint8_t*>(k_q), reinterpret_cast<uint8_t*>(v_q)}, {k_scales, v_scales},
+                {k_zeros, v_zeros}};
+  return requant_launch(rs, 2, H, S, D, dtype, n_bit, (hipStream_t)stream);
 }
 
 int cc_kv_dequant(const void* q, const void* scales, const void* zeros, void* work_out, int32_t H, int32_t S, int32_t D,

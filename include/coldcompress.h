@@ -214,6 +214,9 @@ int cc_decode_attn_gqa_phases(const void* q, const void* k, const void* v, const
  * ---------------------------------------------------------------------------------------------- */
 int cc_kv_requant(void* work, void* q_out, void* scales, void* zeros, int32_t H, int32_t S, int32_t D,
                   int32_t dtype, int32_t n_bit, cc_stream_t stream);
+/* K and V in one launch (what KVCache.quantize_cache does every step). */
+int cc_kv_requant_pair(void* k_work, void* k_q, void* k_scales, void* k_zeros, void* v_work, void* v_q, void* v_scales,
+                       void* v_zeros, int32_t H, int32_t S, int32_t D, int32_t dtype, int32_t n_bit, cc_stream_t stream);
 int cc_kv_dequant(const void* q, const void* scales, const void* zeros, void* work_out, int32_t H, int32_t S,
                   int32_t D, int32_t dtype, int32_t n_bit, cc_stream_t stream);
 

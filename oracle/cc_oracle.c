@@ -1103,6 +1103,13 @@ int cc_kv_requant_cpu(void* work, void* q_out, void* scales, void* zeros, int32_
   return CC_OK;
 }
 
+int cc_kv_requant_pair_cpu(void* k_work, void* k_q, void* k_scales, void* k_zeros, void* v_work, void* v_q, void* v_scales,
+                           void* v_zeros, int32_t H, int32_t S, int32_t D, int32_t dt, int32_t n_bit, cc_stream_t stream) {
+  int rc = cc_kv_requant_cpu(k_work, k_q, k_scales, k_zeros, H, S, D, dt, n_bit, stream);
+  if (rc != CC_OK) return rc;
+  return cc_kv_requant_cpu(v_work, v_q, v_scales, v_zeros, H, S, D, dt, n_bit, stream);
+}
+
 int cc_kv_dequant_cpu(const void* q, const void* scales, const void* zeros, void* work_out, int32_t H, int32_t S, int32_t D,
                       int32_t dt, int32_t n_bit, cc_stream_t stream) {
   (void)stream;
