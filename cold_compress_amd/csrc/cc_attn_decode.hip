@@ -415,7 +415,10 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_split_kernel(SplitArgs a)
 //   * C[i][n]: lane (g = lane / 16, n = lane % 16) gets the scores of ITS OWN row group's four rows against head n,
 //     so the mask word, the online-softmax state (one m, l per lane instead of RT) and the 8-byte score store all
 //     stay in the lane that already owns them; p and alpha reach the 16 lanes of the group through DPP
-//     row_newbcast (one v_mov_dpp each), and P.V stays on the packed-fp32 VALU path over the coalesced V rows.
+//     row_newbcast (one v_mov_dpp each), and P.V stays on the packed-fp32 VALU path over the coalesced V rows;
+//   * the four row groups of a wave share ONE running maximum per head (two v_permlane swaps per tile), so the
+//     epilogue merges them by plain addition in registers (permlane32/16 swaps) and only 2 KiB per wave go
+//     through LDS for the 4-wave merge.
 // ~190 vector instructions per tile instead of ~560.  No workgroup barrier in the loop: the LDS slab is wave-private.
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
@@ -452,12 +455,7 @@ __device__ __forceinline__ void row_bcast_heads(float v, float (&out)[RT]) {
 template <typename T, int RT, int NW>
 __global__ __launch_bounds__(NW * 64) void decode_attn_split_mfma_kernel(SplitArgs a) {
   static_assert(sizeof(T) == 2 && (RT == 1 || RT == 2 || RT == 4), "16-bit caches, up to 4 query heads per pass");
-  constexpr int D = 128, VEC = 8, LPR = 16, RPW = 4, U = 4;
-  constexpr int NG = NW * RPW;
-  static_assert(NG == 16, "the merge below reads the 16 row-group states of a query head as four float4");
-  __shared__ __attribute__((aligned(16))) float sm_m[RT][NG];
-  __shared__ __attribute__((aligned(16))) float sm_l[RT][NG];
-  __shared__ __attribute__((aligned(16))) float sm_acc[NG][RT][D];
+  constexpr int D = 128, VEC = 8, RPW = 4, U = 4;
   __shared__ __attribute__((aligned(16))) uint4 sm_k[NW][16][16];  // [wave][tile row i][slot]: 4 KiB per wave
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -612,7 +610,10 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_split_mfma_kernel(SplitAr
     // ---- online softmax: ONE (m, l) per lane
     float p[U];
     {
-      const float mx = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+      float mx = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+      // ONE running maximum per (wave, head): the four row groups share it (two v_permlane swaps), so their
+      // accumulators carry the same scale and merge by plain addition in the epilogue — no exponentials there
+      mx = xor_combine<32, true>(xor_combine<16, true>(mx));
       const float m_new = fmaxf(m, mx);
       const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
       const float alpha = fast_exp(m - m_use);
@@ -656,80 +657,61 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_split_mfma_kernel(SplitAr
     if (x == 1.2345f) a.part_ml[0] = x;
     return;
   }
-  // ---- row-group partials -> LDS -> one partial per (query head, split).
-  // Merge item = (query head r, 4 output columns k, half of the 16 row groups): 12 LDS instructions per thread
-  // (4 x b128 for the 16 maxima, 8 x b128 accumulator slices) and 8 exps, the two halves meet through one DPP
-  // add per component; fixed order -> deterministic.  (The per-column merge of the VALU kernel issues ~100
-  // ds_read_b32 and 32 exps per thread — 1.6 us of the 7.2 us kernel at S = 4096.)
-  constexpr int NP = VEC / 4;
-  const int grp = wave * RPW + g;
-  if (c < RT) {
-    sm_m[c][grp] = m;
-    sm_l[c][grp] = l;
+  // ---- Epilogue.  The four row groups of a wave are merged IN REGISTERS (they share the running maximum, so it is
+  //      plain addition): for every quad of accumulator registers (X, Y, P, Q)
+  //        v_permlane32_swap(X, Y) -> [X0 X1 Y0 Y1] + [X2 X3 Y2 Y3]     (rows of 16 lanes; one add)
+  //        v_permlane32_swap(P, Q) -> likewise
+  //        v_permlane16_swap(Z, Z2) -> [sum X | sum P | sum Y | sum Q]   (row r of the result = one register's total)
+  //      3 swaps + 3 adds per quad: 32 accumulators -> 8 registers holding the wave's [RT][128] partial, one float per
+  //      (lane, register).  Only 2 KiB per wave then go through LDS for the 4-wave merge (the all-LDS version moved
+  //      64 KiB per workgroup through LDS and was LDS-bandwidth bound: 0.8 us of a 7 us kernel).
+  __shared__ float sm_wm[NW][RT], sm_wl[NW][RT];
+  __shared__ float sm_wacc[NW][RT][D];
+  {
+    l = xor_combine<32, false>(xor_combine<16, false>(l));  // the wave's l of head c, in every row
+    if (lane < RT) {                                          // row 0, column c = head
+      sm_wm[wave][lane] = m;
+      sm_wl[wave][lane] = l;
+    }
+    auto swap32_add = [](float a, float b) -> float {
+      auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
+      return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+    };
+    auto swap16_add = [](float a, float b) -> float {
+      auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
+      return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+    };
+    const int jm = (g == 0) ? 0 : (g == 1) ? 2 : (g == 2) ? 1 : 3;  // which register of the quad this row ends up holding
+#pragma unroll
+    for (int r = 0; r < RT; r++)
+#pragma unroll
+      for (int hb = 0; hb < VEC; hb += 4) {
+        const float z = swap32_add(acc[r][hb + 0], acc[r][hb + 1]);
+        const float z2 = swap32_add(acc[r][hb + 2], acc[r][hb + 3]);
+        sm_wacc[wave][r][c * VEC + hb + jm] = swap16_add(z, z2);
+      }
   }
-#pragma unroll
-  for (int r = 0; r < RT; r++)
-#pragma unroll
-    for (int pc = 0; pc < NP; pc++)
-      *reinterpret_cast<float4*>(&sm_acc[grp][r][(pc * LPR + c) * 4]) =
-          make_float4(acc[r][pc * 4], acc[r][pc * 4 + 1], acc[r][pc * 4 + 2], acc[r][pc * 4 + 3]);
   __syncthreads();
-  const int item = threadIdx.x;
-  if (item < RT * 64) {
-    const int half = item & 1, k4 = (item >> 1) & 31, r = item >> 6;
-    const float4 m0 = *reinterpret_cast<const float4*>(&sm_m[r][0]);
-    const float4 m1 = *reinterpret_cast<const float4*>(&sm_m[r][4]);
-    const float4 m2 = *reinterpret_cast<const float4*>(&sm_m[r][8]);
-    const float4 m3 = *reinterpret_cast<const float4*>(&sm_m[r][12]);
-    const float M = fmaxf(fmaxf(fmaxf(fmaxf(m0.x, m0.y), fmaxf(m0.z, m0.w)), fmaxf(fmaxf(m1.x, m1.y), fmaxf(m1.z, m1.w))),
-                          fmaxf(fmaxf(fmaxf(m2.x, m2.y), fmaxf(m2.z, m2.w)), fmaxf(fmaxf(m3.x, m3.y), fmaxf(m3.z, m3.w))));
-    const float Mu = (M == -INFINITY) ? 0.f : M;
-    // columns 4*k4 .. +3 live in piece (k4 & 1) of lane k4 >> 1 (see the store above)
-    const int dl = ((k4 & 1) * LPR + (k4 >> 1)) * 4;
-    float f[NG / 2];  // registers only: every index below is a compile-time constant
-    f[0] = fast_exp((half ? m2.x : m0.x) - Mu);
-    f[1] = fast_exp((half ? m2.y : m0.y) - Mu);
-    f[2] = fast_exp((half ? m2.z : m0.z) - Mu);
-    f[3] = fast_exp((half ? m2.w : m0.w) - Mu);
-    f[4] = fast_exp((half ? m3.x : m1.x) - Mu);
-    f[5] = fast_exp((half ? m3.y : m1.y) - Mu);
-    f[6] = fast_exp((half ? m3.z : m1.z) - Mu);
-    f[7] = fast_exp((half ? m3.w : m1.w) - Mu);
-    float4 O = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float* accp = &sm_acc[half * (NG / 2)][r][dl];
+  for (int t = threadIdx.x; t < RT * D; t += NW * 64) {
+    const int r = t / D, d = t - r * D;
+    float M = sm_wm[0][r];
 #pragma unroll
-    for (int i = 0; i < NG / 2; i++) {
-      const float4 a4 = *reinterpret_cast<const float4*>(accp + (size_t)i * RT * D);
-      O.x = fmaf(a4.x, f[i], O.x);
-      O.y = fmaf(a4.y, f[i], O.y);
-      O.z = fmaf(a4.z, f[i], O.z);
-      O.w = fmaf(a4.w, f[i], O.w);
+    for (int w = 1; w < NW; w++) M = fmaxf(M, sm_wm[w][r]);
+    const float Mu = (M == -INFINITY) ? 0.f : M;
+    float L = 0.f, O = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; w++) {  // fixed order: deterministic
+      const float f = fast_exp(sm_wm[w][r] - Mu);
+      L = fmaf(sm_wl[w][r], f, L);
+      O = fmaf(sm_wacc[w][r][d], f, O);
     }
-    float L = 0.f;
-    if (k4 == 0) {
-      const float4 la = *reinterpret_cast<const float4*>(&sm_l[r][half * (NG / 2)]);
-      const float4 lb = *reinterpret_cast<const float4*>(&sm_l[r][half * (NG / 2) + 4]);
-      L = fmaf(la.x, f[0], L);
-      L = fmaf(la.y, f[1], L);
-      L = fmaf(la.z, f[2], L);
-      L = fmaf(la.w, f[3], L);
-      L = fmaf(lb.x, f[4], L);
-      L = fmaf(lb.y, f[5], L);
-      L = fmaf(lb.z, f[6], L);
-      L = fmaf(lb.w, f[7], L);
-    }
-    O.x += dpp_mov<0xB1>(O.x);  // lane ^ 1: the other half of the row groups
-    O.y += dpp_mov<0xB1>(O.y);
-    O.z += dpp_mov<0xB1>(O.z);
-    O.w += dpp_mov<0xB1>(O.w);
-    L += dpp_mov<0xB1>(L);
     if (a.abl & 16) {  // measurement only: merge but do not store the partials
-      if (O.x + O.y + O.z + O.w + L == 1.2345f) a.part_ml[0] = L;
-    } else if (half == 0) {
-      const size_t pj = (size_t)(q0 + r) * a.n_split + split;
-      *reinterpret_cast<float4*>(a.part_o + pj * D + 4 * k4) = O;
-      if (k4 == 0) *reinterpret_cast<float2*>(a.part_ml + pj * 2) = make_float2(M, L);
+      if (O + L == 1.2345f) a.part_ml[0] = L;
+      continue;
     }
+    const size_t pj = (size_t)(q0 + r) * a.n_split + split;
+    a.part_o[pj * D + d] = O;
+    if (d == 0) *reinterpret_cast<float2*>(a.part_ml + pj * 2) = make_float2(M, L);
   }
 }
 
