@@ -44,6 +44,11 @@ struct MfmaOps<f16_t> {
   }
 };
 
+// e^x through v_exp_f32 (2^x): relative error ~1e-6, far below the 2^-9 rounding the probabilities get next.  The
+// accurate expf (~20 VALU ops) and an IEEE divide per probability cost 0.7 ms of the 3.1 ms second pass at L = 8192.
+// (Double-buffering the K / V fragments across key tiles was tried and is SLOWER: 195 VGPRs, one wave per SIMD.)
+__device__ __forceinline__ float pf_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+
 constexpr int kD = 128;
 constexpr int kTQ = 32;   // queries per tile
 constexpr int kTK = 32;   // keys per tile
@@ -114,6 +119,7 @@ __global__ __launch_bounds__(256) void prefill_mfma_kernel(MArgs a) {
       m_fin = a.stats[((size_t)j * L + qc) * 2];
       l_fin = a.stats[((size_t)j * L + qc) * 2 + 1];
     }
+    const float inv_l = __frcp_rn(l_fin);  // one reciprocal per query row instead of one IEEE divide per probability
     f32x16 o[4];
 #pragma unroll
     for (int b = 0; b < 4; b++)
@@ -144,15 +150,15 @@ __global__ __launch_bounds__(256) void prefill_mfma_kernel(MArgs a) {
 #pragma unroll
         for (int e = 0; e < 16; e++) mx = fmaxf(mx, x[e]);
         const float mu = (mx == -INFINITY) ? 0.f : mx;
-        float sum = l_run * expf(m_run - mu);
+        float sum = l_run * pf_exp(m_run - mu);
 #pragma unroll
-        for (int e = 0; e < 16; e++) sum += expf(x[e] - mu);
+        for (int e = 0; e < 16; e++) sum += pf_exp(x[e] - mu);
         m_run = mx;
         l_run = sum;
       } else {
         float p[16];
 #pragma unroll
-        for (int e = 0; e < 16; e++) p[e] = ElemTraits<T>::rnd(__fdiv_rn(expf(x[e] - m_fin), l_fin));  // exp(-inf) = 0
+        for (int e = 0; e < 16; e++) p[e] = ElemTraits<T>::rnd(pf_exp(x[e] - m_fin) * inv_l);  // exp(-inf) = 0
         // ---- column sums of the group mean: P tiles of the 4 query heads meet in LDS
         __syncthreads();  // previous tile's readers are done
 #pragma unroll
@@ -208,7 +214,7 @@ __global__ __launch_bounds__(256) void prefill_mfma_kernel(MArgs a) {
       const float m_o = __shfl_xor(m_run, 32, CC_WAVE), l_o = __shfl_xor(l_run, 32, CC_WAVE);
       const float mx = fmaxf(m_run, m_o);
       const float mu = (mx == -INFINITY) ? 0.f : mx;
-      const float lt = l_run * expf(m_run - mu) + l_o * expf(m_o - mu);
+      const float lt = l_run * pf_exp(m_run - mu) + l_o * pf_exp(m_o - mu);
       if (hi == 0 && query < L) {
         a.stats[((size_t)j * L + query) * 2] = mx;
         a.stats[((size_t)j * L + query) * 2 + 1] = lt;
