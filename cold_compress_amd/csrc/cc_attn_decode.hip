@@ -414,12 +414,17 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_split_kernel(SplitArgs a)
 //   * B = q^T (query head n of the group in column n, zero for n >= RT) lives in 16 VGPRs for the whole kernel;
 //   * C[i][n]: lane (g = lane / 16, n = lane % 16) gets the scores of ITS OWN row group's four rows against head n,
 //     so the mask word, the online-softmax state (one m, l per lane instead of RT) and the 8-byte score store all
-//     stay in the lane that already owns them; p and alpha reach the 16 lanes of the group through DPP
-//     row_newbcast (one v_mov_dpp each), and P.V stays on the packed-fp32 VALU path over the coalesced V rows;
-//   * the four row groups of a wave share ONE running maximum per head (two v_permlane swaps per tile), so the
-//     epilogue merges them by plain addition in registers (permlane32/16 swaps) and only 2 KiB per wave go
-//     through LDS for the 4-wave merge.
-// ~190 vector instructions per tile instead of ~560.  No workgroup barrier in the loop: the LDS slab is wave-private.
+//     stay in the lane that already owns them; the four row groups of a wave share ONE running maximum per head
+//     (two v_permlane swaps per tile);
+//   * P.V runs on the matrix cores too, as O^T = V^T . P^T with v_mfma_f32_16x16x16: the QK output layout IS the
+//     B operand (four probabilities per lane, converted to 16 bit), and the A operand comes from the V tile staged
+//     row-major in a second wave-private LDS slab (coalesced ds_write_b128, chunks XOR-swizzled by 2*(row & 7)) and
+//     read back with the gfx950 LDS transpose read ds_read_b64_tr_b16 — lane i of a 16-lane group supplies the
+//     address of 4 columns of row i/4 and receives the 4 rows of column i (layout verified on the device with
+//     tools/probes/tr_read_probe.hip).  The accumulators then cover all 16 rows of the tile: one partial per WAVE,
+//     nothing to merge inside a wave, every accumulator of a lane belongs to one head (lane-local rescale).
+// ~120 vector instructions + 12 MFMAs per tile instead of ~560 vector instructions.  No workgroup barrier in the
+// loop: both LDS slabs are wave-private.
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
@@ -437,6 +442,37 @@ struct Mfma16x16x32<f16_t> {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
   }
 };
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+// P.V step: v_mfma_f32_16x16x16 (K = 16 cache rows); A = V^T fragment from the LDS transpose read, B = P^T (the QK
+// MFMA's own output layout, converted to 16 bit)
+template <typename T>
+struct Mfma16x16x16;
+template <>
+struct Mfma16x16x16<bf16_t> {
+  __device__ static __forceinline__ f32x4_t mma(s16x4_t a, s16x4_t b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+  }
+  __device__ static __forceinline__ s16x4_t pack(const float* p) {
+    s16x4_t r;
+#pragma unroll
+    for (int i = 0; i < 4; i++) r[i] = (short)f32_to_bf16_bits(p[i]);
+    return r;
+  }
+};
+template <>
+struct Mfma16x16x16<f16_t> {
+  __device__ static __forceinline__ f32x4_t mma(s16x4_t a, s16x4_t b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4_t, a), __builtin_bit_cast(f16x4_t, b), c, 0, 0, 0);
+  }
+  __device__ static __forceinline__ s16x4_t pack(const float* p) {
+    s16x4_t r;
+#pragma unroll
+    for (int i = 0; i < 4; i++) r[i] = (short)f32_to_f16_bits(p[i]);
+    return r;
+  }
+};
+
 // value held by lane N of the caller's 16-lane row (DPP row_newbcast, gfx90a+)
 template <int N>
 __device__ __forceinline__ float row_bcast(float v) {
@@ -457,6 +493,7 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_split_mfma_kernel(SplitAr
   static_assert(sizeof(T) == 2 && (RT == 1 || RT == 2 || RT == 4), "16-bit caches, up to 4 query heads per pass");
   constexpr int D = 128, VEC = 8, RPW = 4, U = 4;
   __shared__ __attribute__((aligned(16))) uint4 sm_k[NW][16][16];  // [wave][tile row i][slot]: 4 KiB per wave
+  __shared__ __attribute__((aligned(16))) uint4 sm_v[NW][16][16];  // [wave][tile row][chunk ^ 2*(row & 7)]: V tile, row major
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, c = lane & 15;  // row group of the wave / 16-byte column chunk (and MFMA column n)
@@ -470,12 +507,18 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_split_mfma_kernel(SplitAr
   const uint8_t* mh = has_mask ? a.mask + (size_t)h * S : reinterpret_cast<const uint8_t*>(a.k);
   T* sc_out = reinterpret_cast<T*>(a.scores);
 
-  float m = -INFINITY, l = 0.f;  // softmax state of (row group g, query head c); meaningful for c < RT
-  float acc[RT][VEC];
+  float m = -INFINITY, l = 0.f;  // softmax state of (wave, query head c) / (row group g, head c); meaningful for c < RT
+  // O^T accumulators of the P.V MFMAs: block b covers output columns 16b .. 16b+15; lane (g, n = c) holds
+  // O[head n][16b + 4g + t] in acc[b][t] — one partial per WAVE (all 16 rows of the tile), not per row group
+  f32x4_t acc[D / 16];
 #pragma unroll
-  for (int r = 0; r < RT; r++)
-#pragma unroll
-    for (int e = 0; e < VEC; e++) acc[r][e] = 0.f;
+  for (int b = 0; b < D / 16; b++) acc[b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  // LDS transpose read (ds_read_b64_tr_b16): lane i of a 16-lane group supplies the address of 4 contiguous columns
+  // of row (i / 4); the group receives, lane n, the 4 ROWS of column n — the A fragment of v_mfma_16x16x16 without
+  // any register shuffles.  Row r of the V tile is stored with its 16-byte chunks XOR-swizzled by 2*(r & 7), which
+  // makes both the row-major ds_write_b128 and the transpose reads bank-conflict free.
+  const int tr_row = 4 * g + (c >> 2);
+  const int tr_sw = 2 * (tr_row & 7), tr_qh = (c >> 1) & 1, tr_half = c & 1;
 
   // ---- every load of the first tile is issued before anything waits (partial keys, q, mask, K, V: use order)
   int ins_idx = -1, ins_was_empty = 0;
@@ -624,25 +667,28 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_split_mfma_kernel(SplitAr
         p[t] = fast_exp(s[t] - m_use);
         l += p[t];
       }
-      float al[RT];
-      row_bcast_heads<RT>(alpha, al);
 #pragma unroll
-      for (int r = 0; r < RT; r++)
-#pragma unroll
-        for (int e = 0; e < VEC; e++) acc[r][e] *= al[r];
+      for (int b = 0; b < D / 16; b++) acc[b] *= alpha;  // every accumulator of this lane belongs to head c
     }
-    // ---- P.V on the VALU over the coalesced V rows; p of head r comes from lane r of the row group
+    // ---- O^T += V^T . P^T on the matrix cores: V tile -> wave-private LDS slab (row major, coalesced), A fragments
+    //      back through the transpose read, B = this lane's four probabilities in 16 bit
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-      float vf[VEC];
-      vv[u].unpack(vf);
-      float pu[RT];
-      row_bcast_heads<RT>(p[u], pu);
+    for (int u = 0; u < U; u++) sm_v[wave][4 * g + u][(c ^ (2 * ((4 * g + u) & 7))) & 15] = vv[u].raw;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    {
+      const s16x4_t pb = Mfma16x16x16<T>::pack(p);
+      const char* vrow = reinterpret_cast<const char*>(&sm_v[wave][tr_row][0]) + tr_half * 8;
 #pragma unroll
-      for (int r = 0; r < RT; r++)
-#pragma unroll
-        for (int e = 0; e < VEC; e++) acc[r][e] = fmaf(pu[r], vf[e], acc[r][e]);
+      for (int b = 0; b < D / 16; b++) {
+        const int pos = ((2 * b) ^ tr_sw) | tr_qh;  // chunk 2b + q/2 of the row, swizzled
+        const s16x4_t va = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (s16x4_t __attribute__((address_space(3)))*)(vrow + pos * 16));
+        acc[b] = Mfma16x16x16<T>::mma(va, pb, acc[b]);
+      }
     }
+    __builtin_amdgcn_wave_barrier();  // the next tile's V stores must stay behind these reads
     if (more_next) issue_v(base_next);
     base = base_next;
     more = more_next;
@@ -651,45 +697,26 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_split_mfma_kernel(SplitAr
   if (a.abl & 2) {  // measurement only
     float x = l + m;
 #pragma unroll
-    for (int r = 0; r < RT; r++)
-#pragma unroll
-      for (int e = 0; e < VEC; e++) x += acc[r][e];
+    for (int b = 0; b < D / 16; b++) x += acc[b][0] + acc[b][1] + acc[b][2] + acc[b][3];
     if (x == 1.2345f) a.part_ml[0] = x;
     return;
   }
-  // ---- Epilogue.  The four row groups of a wave are merged IN REGISTERS (they share the running maximum, so it is
-  //      plain addition): for every quad of accumulator registers (X, Y, P, Q)
-  //        v_permlane32_swap(X, Y) -> [X0 X1 Y0 Y1] + [X2 X3 Y2 Y3]     (rows of 16 lanes; one add)
-  //        v_permlane32_swap(P, Q) -> likewise
-  //        v_permlane16_swap(Z, Z2) -> [sum X | sum P | sum Y | sum Q]   (row r of the result = one register's total)
-  //      3 swaps + 3 adds per quad: 32 accumulators -> 8 registers holding the wave's [RT][128] partial, one float per
-  //      (lane, register).  Only 2 KiB per wave then go through LDS for the 4-wave merge (the all-LDS version moved
-  //      64 KiB per workgroup through LDS and was LDS-bandwidth bound: 0.8 us of a 7 us kernel).
+  // ---- Epilogue.  The P.V accumulators already cover all 16 rows of the wave's tiles (one running maximum per
+  //      (wave, head)), so there is nothing to merge inside a wave: lanes n < RT drop their [128] partial into LDS
+  //      (8 x ds_write_b128) and the four waves of the workgroup meet there.
   __shared__ float sm_wm[NW][RT], sm_wl[NW][RT];
-  __shared__ float sm_wacc[NW][RT][D];
+  __shared__ __attribute__((aligned(16))) float sm_wacc[NW][RT][D];
   {
-    l = xor_combine<32, false>(xor_combine<16, false>(l));  // the wave's l of head c, in every row
-    if (lane < RT) {                                          // row 0, column c = head
+    l = xor_combine<32, false>(xor_combine<16, false>(l));  // the wave's l of head c, in every row group
+    if (lane < RT) {                                          // row group 0, column c = head
       sm_wm[wave][lane] = m;
       sm_wl[wave][lane] = l;
     }
-    auto swap32_add = [](float a, float b) -> float {
-      auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
-      return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
-    };
-    auto swap16_add = [](float a, float b) -> float {
-      auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
-      return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
-    };
-    const int jm = (g == 0) ? 0 : (g == 1) ? 2 : (g == 2) ? 1 : 3;  // which register of the quad this row ends up holding
+    if (c < RT) {
 #pragma unroll
-    for (int r = 0; r < RT; r++)
-#pragma unroll
-      for (int hb = 0; hb < VEC; hb += 4) {
-        const float z = swap32_add(acc[r][hb + 0], acc[r][hb + 1]);
-        const float z2 = swap32_add(acc[r][hb + 2], acc[r][hb + 3]);
-        sm_wacc[wave][r][c * VEC + hb + jm] = swap16_add(z, z2);
-      }
+      for (int b = 0; b < D / 16; b++)
+        *reinterpret_cast<float4*>(&sm_wacc[wave][c][16 * b + 4 * g]) = make_float4(acc[b][0], acc[b][1], acc[b][2], acc[b][3]);
+    }
   }
   __syncthreads();
   for (int t = threadIdx.x; t < RT * D; t += NW * 64) {
