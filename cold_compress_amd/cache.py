@@ -269,12 +269,59 @@ class KVCacheHeadSpecific(KVCache):
                          **kwargs)
 
 
-class KVCacheFull(KVCacheHeadConstant):
+class _RingFusedStep:
+    """Two-launch decode step for the head-constant ring policies (recent_global, full): the slot for position p + 1 is
+    the arg-min of `pos` behind the sinks, scored in the combine pass of step p and consumed by the K/V streaming pass
+    of step p + 1 (cc_decode_step_recent_global).  Same contract as KVCacheHeavyHitter.decode_step."""
+
+    def _init_ring_pipeline(self):
+        nk = int(_abi.lib()["cc_hh_next_key_slots"](self.max_cache_length))
+        self.register_buffer("next_key", torch.full((1, nk), -1, dtype=torch.int64), persistent=False)
+        self._next_valid = False
+
+    def supports_fused_step(self):
+        return True
+
+    def reset(self):
+        super().reset()
+        self._next_valid = False
+
+    def update_kv(self, input_pos, k_val, v_val, is_prefill, **kwargs):
+        self._next_valid = False  # the three-call path mutates pos outside the pipeline
+        return super().update_kv(input_pos, k_val, v_val, is_prefill, **kwargs)
+
+    def prepare_decode(self, input_pos):
+        _abi.call("cc_rg_next_key_init", self._view(), _ptr(self._pos32(input_pos)), int(self.global_tokens), _ptr(self.next_key),
+                  _stream())
+        self._next_valid = True
+
+    def decode_step(self, query, k_val, v_val, input_pos, scale=None):
+        from .attention_utils import _workspace
+        import math
+
+        self.quantize_cache()
+        k, v = self._new_rows(k_val, v_val)
+        p32 = self._pos32(input_pos)
+        if not self._next_valid:
+            self.prepare_decode(p32)
+        _, HQ, _, D = query.shape
+        q = query.reshape(HQ, D).contiguous()
+        y = torch.empty((1, HQ, 1, D), dtype=query.dtype, device=query.device)
+        nbytes = _abi.lib()["cc_decode_attn_workspace_bytes"](HQ, self.n_heads, self.max_cache_length, D, _DT[self.k_cache.dtype])
+        ws = _workspace(nbytes, query.device)
+        _abi.call("cc_decode_step_recent_global", self._view(), _ptr(q), _ptr(k), _ptr(v), _ptr(p32), _ptr(self.next_key),
+                  int(self.global_tokens), HQ, 1.0 / math.sqrt(D) if scale is None else scale, _ptr(y), _ptr(ws), ws.numel(), _stream())
+        self._quant_pending = self.quantize
+        return y
+
+
+class KVCacheFull(_RingFusedStep, KVCacheHeadConstant):
     """ref: cache.py:493-502."""
 
     def __init__(self, max_batch_size, n_heads, head_dim, dtype=torch.bfloat16, **kwargs):
         self.global_tokens = 0
         super().__init__(max_batch_size, n_heads, head_dim, dtype, **kwargs)
+        self._init_ring_pipeline()
 
     def _run_select(self, input_pos, k, v):
         _abi.call("cc_decode_update_full", self._view(), _ptr(k), _ptr(v), _ptr(self._pos32(input_pos)),
@@ -295,9 +342,13 @@ class KVCacheRandom(KVCacheHeadConstant):
                   int(self.global_tokens), int(self.recent_window), _ptr(self._idx_buf()), _stream())
 
 
-class KVCacheRecentGlobal(KVCacheHeadConstant):
+class KVCacheRecentGlobal(_RingFusedStep, KVCacheHeadConstant):
     """ref: cache.py:527-556 (ring buffer behind the global sink tokens)."""
     relevant_kwargs = ["max_cache_length", "max_seq_length", "cache_bits", "global_tokens"]
+
+    def __init__(self, max_batch_size, n_heads, head_dim, dtype=torch.bfloat16, **kwargs):
+        super().__init__(max_batch_size, n_heads, head_dim, dtype, **kwargs)
+        self._init_ring_pipeline()
 
     def _run_select(self, input_pos, k, v):
         _abi.call("cc_decode_update_recent_global", self._view(), _ptr(k), _ptr(v), _ptr(self._pos32(input_pos)),
@@ -364,6 +415,9 @@ class KVCacheHeavyHitter(KVCacheHeadSpecific):
 
     def return_attn(self) -> bool:
         return True
+
+    def supports_fused_step(self):
+        return self.history_window_size == 1
 
     def update_kv(self, input_pos, k_val, v_val, is_prefill, **kwargs):
         self._next_valid = False  # the three-call path mutates pos / history outside the pipeline

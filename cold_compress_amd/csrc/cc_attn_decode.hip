@@ -157,7 +157,7 @@ struct SplitArgs {
   int32_t* cache_cts;  // [Hc]
   double* num;         // [H, S]
   int32_t* denom;      // [H, S]
-  int H, Hc;
+  int H, Hc, Hp;  // Hp == 1: head-constant policy (one pos row, one key row shared by every kv head)
 };
 
 template <typename T, int D, int RT, int NW, int U>
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_split_kernel(SplitArgs a)
   int ins_idx = -1, ins_was_empty = 0;
   bool key_pending = a.next_key != nullptr && !(a.abl & 128);
   unsigned long long key_part = ~0ull;
-  if (key_pending && lane < a.nk) key_part = a.next_key[(size_t)h * a.nk + lane];
+  if (key_pending && lane < a.nk) key_part = a.next_key[(size_t)(a.Hp == 1 ? 0 : h) * a.nk + lane];
   // q: [RT][D] of this query group, this lane's VEC-wide column slice (L2-resident after the first workgroups)
   Vec16<T> qraw[RT];
 #pragma unroll
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_split_kernel(SplitArgs a)
     // they cost nothing on the streaming path; their latency hides behind the K/V loads already in flight.
     if (key_pending) {  // wave-uniform; first iteration only
       for (int i = lane + 64; i < a.nk; i += 64) {  // caches beyond 64 chunks (S > 8192)
-        const unsigned long long x = a.next_key[(size_t)h * a.nk + i];
+        const unsigned long long x = a.next_key[(size_t)(a.Hp == 1 ? 0 : h) * a.nk + i];
         key_part = x < key_part ? x : key_part;
       }
       const unsigned long long key = wave_min_u64_uniform(key_part);
@@ -272,10 +272,12 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_split_kernel(SplitArgs a)
         *reinterpret_cast<uint4*>(const_cast<T*>(kh) + (size_t)ins_idx * D) = kn.raw;
         *reinterpret_cast<uint4*>(const_cast<T*>(vh) + (size_t)ins_idx * D) = vn.raw;
         if (lc == 0) {  // stores only: nothing here waits on memory
-          a.pos[slot] = p_now;
+          if (a.Hp != 1 || h == 0) a.pos[(a.Hp == 1 ? 0 : (size_t)h * S) + ins_idx] = p_now;
           a.mask_w[slot] = 1;
-          a.num[slot] = 0.0;
-          a.denom[slot] = 0;
+          if (a.num != nullptr) {  // heavy hitter: cache.py:754-763
+            a.num[slot] = 0.0;
+            a.denom[slot] = 0;
+          }
           if (ins_was_empty && (a.Hc == a.H || h == 0)) atomicAdd(&a.cache_cts[a.Hc == a.H ? h : 0], 1);
         }
       }
@@ -525,10 +527,10 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_split_mfma_kernel(SplitAr
   bool key_pending = a.next_key != nullptr && !(a.abl & 128);
   unsigned long long key_part = ~0ull;
   if (key_pending) {
-    if (lane < a.nk) key_part = a.next_key[(size_t)h * a.nk + lane];
+    if (lane < a.nk) key_part = a.next_key[(size_t)(a.Hp == 1 ? 0 : h) * a.nk + lane];
     // caches beyond 64 chunks (S > 8192) — kept OUT of the streaming loop so that the waits there stay exact
     for (int i = lane + 64; i < a.nk; i += 64) {
-      const unsigned long long x = a.next_key[(size_t)h * a.nk + i];
+      const unsigned long long x = a.next_key[(size_t)(a.Hp == 1 ? 0 : h) * a.nk + i];
       key_part = x < key_part ? x : key_part;
     }
   }
@@ -603,10 +605,12 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_split_mfma_kernel(SplitAr
         *reinterpret_cast<uint4*>(const_cast<T*>(kb) + (size_t)ins_idx * D + kcol) = kn.raw;
         *reinterpret_cast<uint4*>(const_cast<T*>(vh) + (size_t)ins_idx * D) = vn.raw;
         if (c == 0) {
-          a.pos[slot] = p_now;
+          if (a.Hp != 1 || h == 0) a.pos[(a.Hp == 1 ? 0 : (size_t)h * S) + ins_idx] = p_now;
           a.mask_w[slot] = 1;
-          a.num[slot] = 0.0;
-          a.denom[slot] = 0;
+          if (a.num != nullptr) {  // heavy hitter: cache.py:754-763
+            a.num[slot] = 0.0;
+            a.denom[slot] = 0;
+          }
           if (ins_was_empty && (a.Hc == a.H || h == 0)) atomicAdd(&a.cache_cts[a.Hc == a.H ? h : 0], 1);
         }
       }
@@ -756,8 +760,10 @@ struct CombineArgs {
   // ---- fused decode step: score the NEXT step's eviction (cache.py:725-749 at position p + 1) in the same pass
   unsigned long long* next_key;  // [H][gridDim.x] or null: block c publishes the minimum over its slots
   const int32_t* input_pos;
-  const int32_t* pos;  // [H, S]
+  const int32_t* pos;  // [Hp, S]
   int H, g, w;
+  int policy;  // next-eviction scoring: 1 = heavy hitter (cache.py:727-749), 2 = recent_global / full (cache.py:500-502, 552-556)
+  int Hp;
   int abl;  // measurement-only ablation bits (phases >> 8): 8 = no next-key epilogue, 16 = no y merge, 32 = no per-slot pass
 };
 
@@ -790,7 +796,7 @@ __global__ __launch_bounds__(kCombThreads) void decode_attn_combine_kernel(Combi
   }
   int32_t ps_mine = 0, p_next = 0;
   if (a.next_key) {
-    ps_mine = a.pos[(size_t)h * S + s_ld];
+    ps_mine = a.pos[(a.Hp == 1 ? 0 : (size_t)h * S) + s_ld];
     p_next = *a.input_pos + 1;
   }
   unsigned long long my_key = ~0ull;
@@ -930,7 +936,7 @@ __global__ __launch_bounds__(kCombThreads) void decode_attn_combine_kernel(Combi
       const int32_t den_new = den_old + 1;
       a.hh_num[i] = num_new;
       a.hh_denom[i] = den_new;
-      if (a.next_key) {  // next step's eviction score from the freshly updated history (cache.py:727-749)
+      if (a.next_key && a.policy == 1) {  // next step's eviction score from the freshly updated history (cache.py:727-749)
         float scn = __fdiv_rn((float)num_new, (float)(den_new < 1 ? 1 : den_new));
         if (ps_mine < a.g || ps_mine >= p_next - a.w) scn = 1.0f;
         if (ps_mine == -1) scn = 0.0f;
@@ -938,6 +944,8 @@ __global__ __launch_bounds__(kCombThreads) void decode_attn_combine_kernel(Combi
       }
     }
   }
+  if (a.next_key && a.policy == 2 && have && h == 0 && s_mine >= a.g)  // arg-min of pos over the slots behind the sinks; -1 = empty first
+    my_key = make_key(orderable_i32(ps_mine), ((uint32_t)s_mine << 1) | (uint32_t)(ps_mine == -1));
   if (a.next_key && !(a.abl & 8)) {
     const unsigned long long wk = wave_min_u64_uniform(my_key);
     if (lane == 0) sm_k[wave] = wk;
@@ -950,7 +958,7 @@ __global__ __launch_bounds__(kCombThreads) void decode_attn_combine_kernel(Combi
     for (int w2 = 1; w2 < kWaves; w2++) bk = sm_k[w2] < bk ? sm_k[w2] : bk;
     // the minimum over all blocks of this head IS torch's arg-min; the next step's streaming pass takes it
     // (plain store: same-address atomics from 8 XCDs measured +4.5 us on this 5 us kernel)
-    a.next_key[(size_t)h * nchunks + c] = bk;
+    if (a.Hp != 1 || h == 0) a.next_key[(size_t)(a.Hp == 1 ? 0 : h) * nchunks + c] = bk;
   }
   if (do_y)  // further output groups (only when R*D / n_chunks > 128, i.e. very short caches)
     for (int o0 = y_lo + kCombThreads; o0 < y_hi; o0 += kCombThreads) {
@@ -1066,6 +1074,7 @@ struct FusedStep {
   const int32_t* input_pos;
   unsigned long long* next_key;
   int g, w;
+  int policy;  // 1 = heavy hitter, 2 = recent_global / full
 };
 }  // namespace
 
@@ -1096,7 +1105,7 @@ static int attn_impl(const void* q, const void* k, const void* v, const uint8_t*
   if (fs) {
     sa.next_key = fs->next_key; sa.nk = p.n_chunks; sa.input_pos = fs->input_pos; sa.k_new = fs->k_new; sa.v_new = fs->v_new;
     sa.pos = fs->c->pos; sa.mask_w = fs->c->mask; sa.cache_cts = fs->c->cache_cts; sa.num = hh_num; sa.denom = hh_denom;
-    sa.H = H; sa.Hc = fs->c->Hc;
+    sa.H = H; sa.Hc = fs->c->Hc; sa.Hp = fs->c->Hp;
   }
   hipStream_t st = (hipStream_t)stream;
   int rc = CC_OK;
@@ -1116,6 +1125,7 @@ static int attn_impl(const void* q, const void* k, const void* v, const uint8_t*
   ca.S = S; ca.R = R; ca.D = D; ca.n_split = p.n_split; ca.chunk = p.chunk;
   if (fs) {
     ca.next_key = fs->next_key; ca.input_pos = fs->input_pos; ca.pos = fs->c->pos; ca.H = H; ca.g = fs->g; ca.w = fs->w;
+    ca.policy = fs->policy; ca.Hp = fs->c->Hp;
   }
   ca.abl = (phases >> 8) & 0xff;
   dim3 grid(p.n_chunks, H), block(kCombThreads);
@@ -1155,9 +1165,20 @@ int cc_decode_step_heavy_hitter_phases(const cc_kv_view* c, const void* q, const
   if (!cc_view_ok(c) || !q || !k_new || !v_new || !input_pos || !num || !denom || !next_key || !y || c->Hp != c->H ||
       HQ <= 0 || HQ % c->H)
     return CC_ERR_BAD_ARG;
-  FusedStep fs{c, k_new, v_new, input_pos, reinterpret_cast<unsigned long long*>(next_key), global_tokens, recent_window};
+  FusedStep fs{c, k_new, v_new, input_pos, reinterpret_cast<unsigned long long*>(next_key), global_tokens, recent_window, 1};
   return attn_impl(q, c->k_cache, c->v_cache, c->mask, HQ, c->H, c->S, c->D, c->dtype, scale, y, attn_out, nullptr, num, denom,
                    counter, workspace, workspace_bytes, stream, phases, &fs);
+}
+
+int cc_decode_step_recent_global(const cc_kv_view* c, const void* q, const void* k_new, const void* v_new,
+                                 const int32_t* input_pos, uint64_t* next_key, int32_t global_tokens, int32_t HQ, float scale,
+                                 void* y, void* workspace, size_t workspace_bytes, cc_stream_t stream) {
+  if (!cc_view_ok(c) || !q || !k_new || !v_new || !input_pos || !next_key || !y || c->Hp != 1 || HQ <= 0 || HQ % c->H ||
+      global_tokens < 0 || global_tokens >= c->S)
+    return CC_ERR_BAD_ARG;
+  FusedStep fs{c, k_new, v_new, input_pos, reinterpret_cast<unsigned long long*>(next_key), global_tokens, 0, 2};
+  return attn_impl(q, c->k_cache, c->v_cache, c->mask, HQ, c->H, c->S, c->D, c->dtype, scale, y, nullptr, nullptr, nullptr, nullptr,
+                   nullptr, workspace, workspace_bytes, stream, 3, &fs);
 }
 
 int cc_decode_attn_gqa(const void* q, const void* k, const void* v, const uint8_t* mask, int32_t HQ, int32_t H,

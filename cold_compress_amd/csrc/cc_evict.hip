@@ -397,6 +397,16 @@ int cc_hh_next_key_init(const cc_kv_view* c, const int32_t* input_pos, const dou
   return launch_update<P_HH>(c, a, (hipStream_t)stream);
 }
 
+int cc_rg_next_key_init(const cc_kv_view* c, const int32_t* input_pos, int32_t g, uint64_t* next_key, cc_stream_t stream) {
+  CC_ENTRY();
+  if (!cc_view_ok(c) || !input_pos || !next_key || c->Hp != 1 || g < 0 || g >= c->S) return CC_ERR_BAD_ARG;
+  UpdArgs a{};
+  a.input_pos = input_pos; a.g = g;
+  a.key_out = reinterpret_cast<unsigned long long*>(next_key);
+  a.nk = cc_next_key_slots(c->S);
+  return launch_update<P_RECENT_GLOBAL>(c, a, (hipStream_t)stream);
+}
+
 int cc_hh_update(double* num, int32_t* denom, int64_t* counter, const void* attn, int32_t H, int32_t S, int32_t T,
                  int32_t dtype, cc_stream_t stream) {
   CC_ENTRY();

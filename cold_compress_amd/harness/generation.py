@@ -135,7 +135,7 @@ class GraphedDecoder:
         """Capture must start from a state where one extra (discarded) step is harmless: run it on a snapshot."""
         caches = [l.attention.kv_cache for l in self.model.layers]
         for c in caches:  # seed the fused decode-step pipelines BEFORE the snapshot so the restored state is runnable
-            if hasattr(c, "prepare_decode") and getattr(c, "history_window_size", 1) == 1 and not c._next_valid:
+            if hasattr(c, "prepare_decode") and c.supports_fused_step() and not c._next_valid:
                 c.prepare_decode(self.pos)
         snap = [{k: v.clone() for k, v in c._buffers.items()} for c in caches]
         flags = [(getattr(c, "_next_valid", None), getattr(c, "_quant_pending", False)) for c in caches]

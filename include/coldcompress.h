@@ -183,6 +183,14 @@ int cc_decode_step_heavy_hitter(const cc_kv_view* c, const void* q, const void* 
                                 uint64_t* next_key, int32_t global_tokens, int32_t recent_window, int32_t HQ,
                                 float scale, void* y, void* attn_out, void* workspace, size_t workspace_bytes,
                                 cc_stream_t stream);
+/* The same two-launch step for the head-constant ring policies: KVCacheRecentGlobal (cache.py:527-556: arg-min of
+ * pos over the slots behind the first `global_tokens` sinks; empty slots, pos == -1, first) and KVCacheFull
+ * (cache.py:493-502: global_tokens = 0).  c->Hp must be 1; next_key: uint64 [1, NK].  No history, no group-mean output. */
+int cc_rg_next_key_init(const cc_kv_view* c, const int32_t* input_pos, int32_t global_tokens, uint64_t* next_key,
+                        cc_stream_t stream);
+int cc_decode_step_recent_global(const cc_kv_view* c, const void* q, const void* k_new, const void* v_new,
+                                 const int32_t* input_pos, uint64_t* next_key, int32_t global_tokens, int32_t HQ,
+                                 float scale, void* y, void* workspace, size_t workspace_bytes, cc_stream_t stream);
 /* Measurement hook (cf. cc_decode_attn_gqa_phases): the same step with its two launches selectable. */
 int cc_decode_step_heavy_hitter_phases(const cc_kv_view* c, const void* q, const void* k_new, const void* v_new,
                                 const int32_t* input_pos, double* num, int32_t* denom, int64_t* counter,

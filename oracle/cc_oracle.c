@@ -1209,3 +1209,40 @@ int cc_softmax_argmax_cpu(const void* logits, int32_t V, int32_t dt, void* probs
   *idx_out = bi;
   return CC_OK;
 }
+
+/* Two-launch decode step of the head-constant ring policies (recent_global / full), pipeline form: the slot for this
+ * position was chosen at the end of the previous step (or by cc_rg_next_key_init); insert, attend, choose the next.
+ * ref: cache.py:493-502, 527-556 + model.py:389-418; only WHEN the arg-min runs differs from the three-call sequence. */
+static uint64_t rg_key(const cc_kv_view* c, int32_t g) {
+  const int64_t s = argmin_i32(c->pos + g, c->S - g) + g;
+  const int32_t ps = c->pos[s];
+  return ((uint64_t)((uint32_t)ps ^ 0x80000000u) << 32) | ((uint64_t)(uint32_t)s << 1) | (uint64_t)(ps == -1);
+}
+
+int cc_rg_next_key_init_cpu(const cc_kv_view* c, const int32_t* input_pos, int32_t g, uint64_t* next_key, cc_stream_t stream) {
+  (void)stream;
+  if (!view_ok(c) || !input_pos || !next_key || c->Hp != 1 || g < 0 || g >= c->S) return CC_ERR_BAD_ARG;
+  const int nk = cc_hh_next_key_slots_cpu(c->S);
+  for (int i = 1; i < nk; i++) next_key[i] = ~(uint64_t)0;
+  next_key[0] = rg_key(c, g);
+  return CC_OK;
+}
+
+int cc_decode_step_recent_global_cpu(const cc_kv_view* c, const void* q, const void* k_new, const void* v_new,
+                                     const int32_t* input_pos, uint64_t* next_key, int32_t g, int32_t HQ, float scale, void* y,
+                                     void* workspace, size_t workspace_bytes, cc_stream_t stream) {
+  if (!view_ok(c) || !q || !k_new || !v_new || !input_pos || !next_key || !y || c->Hp != 1 || g < 0 || g >= c->S) return CC_ERR_BAD_ARG;
+  const int nk = cc_hh_next_key_slots_cpu(c->S);
+  uint64_t key = ~(uint64_t)0;
+  for (int i = 0; i < nk; i++)
+    if (next_key[i] < key) key = next_key[i];
+  if (key == ~(uint64_t)0) return CC_ERR_BAD_ARG;
+  int64_t idx = (int64_t)((key & 0xffffffffu) >> 1);
+  insert_token(c, k_new, v_new, *input_pos, &idx);
+  int rc = cc_decode_attn_gqa_cpu(q, c->k_cache, c->v_cache, c->mask, HQ, c->H, c->S, c->D, c->dtype, scale, y, NULL, NULL, NULL,
+                                  NULL, NULL, workspace, workspace_bytes, stream);
+  if (rc != CC_OK) return rc;
+  for (int i = 1; i < nk; i++) next_key[i] = ~(uint64_t)0;
+  next_key[0] = rg_key(c, g);
+  return CC_OK;
+}

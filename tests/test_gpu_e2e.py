@@ -54,7 +54,7 @@ def _log_evictions(model):
                 if not _kv._next_valid:
                     _kv.prepare_decode(input_pos)
                 keys = _kv.next_key.cpu().numpy().view("uint64").min(axis=1)  # partial minima per chunk -> arg-min key
-                log[_i].append(torch.from_numpy(((keys & 0xffffffff) >> 1).astype("int64")))
+                log[_i].append(torch.from_numpy(((keys & 0xffffffff) >> 1).astype("int64")).to(DEV))
                 return _orig(query, k_val, v_val, input_pos, scale)
 
             kv.decode_step = step

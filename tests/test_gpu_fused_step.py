@@ -92,3 +92,39 @@ def test_fused_step_vs_oracle_pipeline(oracle):
         assert (y.cpu().float()[0, :, 0] - yr).abs().max() < 1e-2
     assert np.array_equal(kv.attn_history_denom.cpu()[0].numpy(), st["denom"])
     assert np.array_equal(to_np(kv.k_cache.cpu()[0]), st["k"])
+
+
+@pytest.mark.parametrize("strategy,dtype,H,HQ,S,D,T", [("recent_global", torch.bfloat16, 8, 32, 4096, 128, 4090), ("recent_global", torch.float32, 2, 4, 77, 16, 77),
+                                                       ("full", torch.bfloat16, 4, 16, 600, 128, 500), ("recent_global", torch.float16, 1, 8, 3488, 128, 3488)])
+def test_ring_fused_step_equals_three_calls(strategy, dtype, H, HQ, S, D, T):
+    """Head-constant ring policies (recent_global, full): the two-launch step (cc_decode_step_recent_global) against
+    update_kv -> attention, every buffer bit for bit, appends (empty slots) and evictions (ring) both covered."""
+    import cold_compress_amd.cache as cache
+    from cold_compress_amd.attention_utils import scaled_dot_product_attention as sdpa
+
+    cls, rk = cache.get_cache_constructor(strategy)
+    kw = dict(max_cache_length=S, global_tokens=4, max_seq_length=4 * S, cache_bits=None)
+
+    def mk():
+        with torch.device(DEV):
+            return cls(1, H, D, dtype, **{k: kw[k] for k in rk})
+
+    a, b = mk(), mk()
+    gen = torch.Generator().manual_seed(11)
+    k0 = torch.randn(1, H, T, D, generator=gen).to(dtype).to(DEV)
+    v0 = torch.randn(1, H, T, D, generator=gen).to(dtype).to(DEV)
+    for kv in (a, b):
+        kv.update_kv(torch.arange(T, device=DEV), k0, v0, True)
+    for t in range(12):
+        p = torch.tensor([T + t], dtype=torch.int32, device=DEV)
+        k1 = torch.randn(1, H, 1, D, generator=gen).to(dtype).to(DEV)
+        v1 = torch.randn(1, H, 1, D, generator=gen).to(dtype).to(DEV)
+        q = torch.randn(1, HQ, 1, D, generator=gen).to(dtype).to(DEV)
+        ka, va, ma = a.update_kv(p, k1, v1, False)
+        ya, _ = sdpa(q, ka, va, attn_mask=ma)
+        yb = b.decode_step(q, k1, v1, p)
+        torch.cuda.synchronize()
+        assert torch.equal(ya, yb), f"step {t}: attention output"
+        for (na, ta), (nb, tb) in zip(a.named_buffers(), b.named_buffers()):
+            if na != "next_key":
+                assert torch.equal(ta, tb), f"step {t}: {na}"
