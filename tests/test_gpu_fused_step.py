@@ -34,7 +34,9 @@ def _seed(kv, gen, T):
 
 
 @pytest.mark.parametrize("dtype,H,HQ,S,D,T", [(torch.bfloat16, 8, 32, 4096, 128, 4090), (torch.float32, 2, 4, 333, 16, 300),
-                                              (torch.bfloat16, 1, 8, 3488, 128, 3488), (torch.float16, 4, 8, 1000, 64, 1000)])
+                                              (torch.bfloat16, 1, 8, 3488, 128, 3488), (torch.float16, 4, 8, 1000, 64, 1000),
+                                              (torch.bfloat16, 3, 12, 1001, 128, 990), (torch.float16, 2, 2, 67, 128, 60),
+                                              (torch.bfloat16, 5, 10, 8200, 128, 8200)])
 def test_fused_step_equals_three_calls(dtype, H, HQ, S, D, T):
     from cold_compress_amd.attention_utils import scaled_dot_product_attention as sdpa
 

@@ -315,7 +315,8 @@ def test_decode_update_bit_exact_vs_oracle(cc, oracle, strategy, dtype, H, S, D)
                                             (torch.float32, 4, 2, 77, 16), (torch.float16, 8, 8, 300, 64),
                                             (torch.bfloat16, 8, 1, 3488, 128), (torch.bfloat16, 28, 4, 513, 128),
                                             (torch.bfloat16, 16, 8, 200, 128), (torch.float16, 32, 8, 1000, 128),
-                                            (torch.bfloat16, 4, 4, 40, 128), (torch.float16, 6, 3, 8200, 128)])
+                                            (torch.bfloat16, 4, 4, 40, 128), (torch.float16, 6, 3, 8200, 128),
+                                            (torch.bfloat16, 12, 3, 1001, 128), (torch.bfloat16, 2, 1, 13, 128)])
 def test_decode_attention_vs_oracle(cc, oracle, dtype, HQ, H, S, D):
     from cold_compress_amd.attention_utils import scaled_dot_product_attention as sdpa
 
