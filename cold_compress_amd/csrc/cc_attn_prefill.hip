@@ -31,6 +31,7 @@ struct PfArgs {
   int nb;           // number of band-sum side outputs (<= kMaxBands)
   int band[4];      // window widths in queries: band b sums a[h,q,k] over q in [k, k + band[b])
   float* band_out;  // [nb, H, L] or null
+  int obs_plane;    // >= 0: the observation-window sums are plane obs_plane of cpart (MFMA path); -1: recompute here
 };
 constexpr int kMaxBands = 4;
 
@@ -232,7 +233,12 @@ __global__ __launch_bounds__(kThreads) void prefill_side_kernel(PfArgs a, int nw
         a.band_out[(size_t)b * a.H * L + idx] = bs;
       }
     }
-    if (a.obs) {
+    if (a.obs && a.obs_plane >= 0) {
+      const size_t plane = (size_t)nwg * a.H * L;
+      float os = 0.f;
+      for (int w = 0; w < nwg; w++) os += a.cpart[(size_t)a.obs_plane * plane + ((size_t)w * a.H + h) * L + s];
+      a.obs[idx] = a.obs_len > 0 ? __fdiv_rn(os, (float)a.obs_len) : 0.f;
+    } else if (a.obs) {
       // ref: prompt_compression.py:173 attn[:, :, -obs_len:, :].mean(dim=2)
       float os = 0.f;
       const T* kr = reinterpret_cast<const T*>(a.k) + ((size_t)h * L + s) * D;
@@ -301,14 +307,14 @@ static int run_side(PfArgs a, int nwg, hipStream_t st) {
 
 extern "C" int cc_prefill_attn_mfma_impl(const void* q, const void* k, const void* v, int HQ, int H, int L, int D, int dtype,
                                          float scale, void* y, float* stats, float* cpart, int nwg, void* vt, const int* bands,
-                                         int nb, hipStream_t st);
+                                         int nb, int obs_len, hipStream_t st);
 
 extern "C" {
 
 size_t cc_prefill_attn_workspace_bytes(int32_t HQ, int32_t H, int32_t L, int32_t D, int32_t dtype) {
   if (HQ <= 0 || H <= 0 || L <= 0) return 0;
   const size_t Lp = ((size_t)L + 31) & ~(size_t)31;
-  return align256((size_t)HQ * L * 2 * sizeof(float)) + align256((size_t)(1 + kMaxBands) * kNWGMfma * H * L * sizeof(float)) +
+  return align256((size_t)HQ * L * 2 * sizeof(float)) + align256((size_t)(2 + kMaxBands) * kNWGMfma * H * L * sizeof(float)) +
          (mfma_eligible(HQ, H, D, dtype) ? align256((size_t)H * D * Lp * 2) : 0);
 }
 
@@ -347,13 +353,16 @@ int cc_prefill_attn_bands(const void* q, const void* k, const void* v, int32_t H
   a.TK = D <= 128 ? 32 : 16;
   a.obs_len = obs_len < 0 ? 0 : (obs_len > L ? L : obs_len);
   a.scale = scale;
+  a.obs_plane = -1;
   hipStream_t st = (hipStream_t)stream;
   if (mfma_eligible(HQ, H, D, dtype) && L >= 64) {
     const int nqt = (L + 31) / 32;
     const int nwg = nqt < kNWGMfma ? nqt : kNWGMfma;
-    char* vt = reinterpret_cast<char*>(a.cpart) + align256((size_t)(1 + kMaxBands) * kNWGMfma * H * L * sizeof(float));
-    const int rc = cc_prefill_attn_mfma_impl(q, k, v, HQ, H, L, D, dtype, scale, y, a.stats, a.cpart, nwg, vt, a.band, a.nb, st);
+    char* vt = reinterpret_cast<char*>(a.cpart) + align256((size_t)(2 + kMaxBands) * kNWGMfma * H * L * sizeof(float));
+    const int obs_len = a.obs ? a.obs_len : 0;
+    const int rc = cc_prefill_attn_mfma_impl(q, k, v, HQ, H, L, D, dtype, scale, y, a.stats, a.cpart, nwg, vt, a.band, a.nb, obs_len, st);
     if (rc != CC_OK) return rc;
+    a.obs_plane = obs_len > 0 ? 1 + a.nb : -1;
     if (a.colsum || a.obs || a.band_out) return dtype == CC_DT_BF16 ? run_side<bf16_t>(a, nwg, st) : run_side<f16_t>(a, nwg, st);
     return CC_OK;
   }

@@ -60,8 +60,9 @@ struct MArgs {
   const void* vt;  // [H, D, Lp] transposed + permuted V (Lp = L rounded up to 32)
   void* y;         // [HQ, L, D]
   float* stats;    // [HQ, L, 2]
-  float* cpart;    // [1 + nb, NWG, H, L]
+  float* cpart;    // [1 + nb (+1), NWG, H, L]: column sums, band sums, observation-window sums
   int H, L, Lp, nb;
+  int obs_len;     // > 0: plane 1 + nb accumulates the group-mean probabilities of the last obs_len query rows
   int band[kMaxBandsM];
   float scale;
 };
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(256) void vt_perm_kernel(const T* v, T* vt, int H, 
 template <typename T, int PASS>
 __global__ __launch_bounds__(256) void prefill_mfma_kernel(MArgs a) {
   __shared__ float sm_p[4][kTK][kTQ + 1];   // per-wave probability tiles (pass 2): [r][key][query]
-  __shared__ float sm_red[1 + kMaxBandsM][8][kTK];
+  __shared__ float sm_red[2 + kMaxBandsM][8][kTK];
   const int lane = threadIdx.x & 63, r = threadIdx.x >> 6;  // wave = query head of the group
   const int hi = lane >> 5, lq = lane & 31;
   const int h = blockIdx.y, L = a.L;
@@ -101,13 +102,15 @@ __global__ __launch_bounds__(256) void prefill_mfma_kernel(MArgs a) {
   const int nqt = (L + kTQ - 1) / kTQ;
   const size_t plane = (size_t)gridDim.x * a.H * L;
   float* cp = a.cpart + ((size_t)blockIdx.x * a.H + h) * L;
+  const int npl = 1 + a.nb + (a.obs_len > 0 ? 1 : 0);
   if (PASS == 2) {
-    for (int pl = 0; pl <= a.nb; pl++)
+    for (int pl = 0; pl < npl; pl++)
       for (int s = threadIdx.x; s < L; s += 256) cp[pl * plane + s] = 0.f;
   }
 
   for (int qt = blockIdx.x; qt < nqt; qt += gridDim.x) {
     const int q0 = qt * kTQ;
+    const bool obs_tile = a.obs_len > 0 && q0 + kTQ > L - a.obs_len;  // workgroup-uniform: only the last tiles pay
     const int query = q0 + lq;
     const int qc = query < L ? query : L - 1;
     uint4 qb[8];  // B operand of the QK MFMA for the 8 d-steps: Q[query][16*ds + 8*hi .. +7]
@@ -166,13 +169,17 @@ __global__ __launch_bounds__(256) void prefill_mfma_kernel(MArgs a) {
         __syncthreads();
         {
           const int key = threadIdx.x & 31, qs = threadIdx.x >> 5;  // 8 slices of 4 queries
-          float cs = 0.f, bs[kMaxBandsM] = {0.f, 0.f, 0.f, 0.f};
+          float cs = 0.f, os = 0.f, bs[kMaxBandsM] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int qq = 0; qq < 4; qq++) {
             const int ql = qs * 4 + qq;
             const float sum = ((sm_p[0][key][ql] + sm_p[1][key][ql]) + sm_p[2][key][ql]) + sm_p[3][key][ql];
             const float av = ElemTraits<T>::rnd(__fdiv_rn(sum, 4.0f));
             cs += av;
+            // ref: prompt_compression.py:173 attn[:, :, -obs_len:, :] — the SnapKV observation window is just
+            // another side sum of the probabilities this pass already has (the VALU path recomputes 16 x R dot
+            // products per key for it: 1.15 ms per layer at L = 8192)
+            if (obs_tile && q0 + ql >= L - a.obs_len && q0 + ql < L) os += av;
             const int dist = (q0 + ql) - (k0 + key);
 #pragma unroll
             for (int b = 0; b < kMaxBandsM; b++)
@@ -182,11 +189,13 @@ __global__ __launch_bounds__(256) void prefill_mfma_kernel(MArgs a) {
 #pragma unroll
           for (int b = 0; b < kMaxBandsM; b++)
             if (b < a.nb) sm_red[1 + b][qs][key] = bs[b];
+          if (obs_tile) sm_red[1 + a.nb][qs][key] = os;
         }
         __syncthreads();
         if (threadIdx.x < kTK && k0 + threadIdx.x < L) {
           const int key = threadIdx.x;
-          for (int pl = 0; pl <= a.nb; pl++) {
+          for (int pl = 0; pl < npl; pl++) {
+            if (pl == 1 + a.nb && !obs_tile) continue;  // the observation plane only exists for the last query tiles
             float tot = 0.f;
 #pragma unroll
             for (int qs = 0; qs < 8; qs++) tot += sm_red[pl][qs][key];
@@ -238,12 +247,12 @@ __global__ __launch_bounds__(256) void prefill_mfma_kernel(MArgs a) {
 // workspace layout is owned by the caller: stats | cpart planes | vt_perm.
 extern "C" int cc_prefill_attn_mfma_impl(const void* q, const void* k, const void* v, int HQ, int H, int L, int D, int dtype,
                                          float scale, void* y, float* stats, float* cpart, int nwg, void* vt, const int* bands,
-                                         int nb, hipStream_t st) {
+                                         int nb, int obs_len, hipStream_t st) {
   if (D != kD || HQ != 4 * H || (dtype != CC_DT_BF16 && dtype != CC_DT_F16) || nb > kMaxBandsM) return CC_ERR_UNSUPPORTED;
   const int Lp = (L + 31) & ~31;
   MArgs a{};
   a.q = q; a.k = k; a.vt = vt; a.y = y; a.stats = stats; a.cpart = cpart;
-  a.H = H; a.L = L; a.Lp = Lp; a.nb = nb; a.scale = scale;
+  a.H = H; a.L = L; a.Lp = Lp; a.nb = nb; a.scale = scale; a.obs_len = obs_len;
   for (int b = 0; b < nb; b++) a.band[b] = bands[b];
   const size_t tot = (size_t)H * kD * Lp;
   size_t nbk = (tot + 255) / 256;
