@@ -105,30 +105,6 @@ __device__ __forceinline__ float xor_combine(float v) {
   }
   return IS_MAX ? fmaxf(a, b) : a + b;
 }
-// sum / max over the 64/W row groups of a wave (lanes with equal lane % W); every lane gets the result
-// (partners must keep lane % W: quad_perm for bits 0/1, row rotations by 4 and 8 for bits 2/3 — a mirror would
-// pair different columns — then the permlane swaps for bits 4/5)
-template <int W>
-__device__ __forceinline__ float across_groups_sum(float v) {
-  if (W <= 1) v += dpp_mov<0xB1>(v);   // lane ^ 1
-  if (W <= 2) v += dpp_mov<0x4E>(v);   // lane ^ 2
-  if (W <= 4) v += dpp_mov<0x124>(v);  // row_ror:4
-  if (W <= 8) v += dpp_mov<0x128>(v);  // row_ror:8 (== lane ^ 8)
-  if (W <= 16) v = xor_combine<16, false>(v);
-  if (W <= 32) v = xor_combine<32, false>(v);
-  return v;
-}
-template <int W>
-__device__ __forceinline__ float across_groups_max(float v) {
-  if (W <= 1) v = fmaxf(v, dpp_mov<0xB1>(v));
-  if (W <= 2) v = fmaxf(v, dpp_mov<0x4E>(v));
-  if (W <= 4) v = fmaxf(v, dpp_mov<0x124>(v));
-  if (W <= 8) v = fmaxf(v, dpp_mov<0x128>(v));
-  if (W <= 16) v = xor_combine<16, true>(v);
-  if (W <= 32) v = xor_combine<32, true>(v);
-  return v;
-}
-
 __device__ __forceinline__ float fast_exp(float x) {  // e^x via v_exp_f32 (2^x); exp(-inf) = 0
   return __builtin_amdgcn_exp2f(x * 1.4426950408889634f);
 }
@@ -474,21 +450,6 @@ struct Mfma16x16x16<f16_t> {
     return r;
   }
 };
-
-// value held by lane N of the caller's 16-lane row (DPP row_newbcast, gfx90a+)
-template <int N>
-__device__ __forceinline__ float row_bcast(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + N, 0xf, 0xf, true));
-}
-template <int RT>
-__device__ __forceinline__ void row_bcast_heads(float v, float (&out)[RT]) {
-  out[0] = row_bcast<0>(v);
-  if constexpr (RT > 1) out[1] = row_bcast<1>(v);
-  if constexpr (RT > 2) {
-    out[2] = row_bcast<2>(v);
-    out[3] = row_bcast<3>(v);
-  }
-}
 
 template <typename T, int RT, int NW>
 __global__ __launch_bounds__(NW * 64) void decode_attn_split_mfma_kernel(SplitArgs a) {
