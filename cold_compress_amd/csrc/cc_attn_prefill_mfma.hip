@@ -241,6 +241,89 @@ __global__ __launch_bounds__(256) void prefill_mfma_kernel(MArgs a) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Pass 1 (row maxima and sums), LDS-shared K tiles.  PMC counters of the per-wave-loading version above: 65 % of the
+// wave cycles parked in s_waitcnt — every wave fetched its own K fragments per 32-key tile (the four query heads of
+// a group fetched the SAME tile four times) and waited out an L2 round trip per tile.  Here the workgroup fetches a
+// K tile ONCE (two 16-byte loads per thread, coalesced rows), one tile ahead of the math, into a double-buffered LDS
+// image whose 16-byte chunks are XOR-swizzled by (key & 15) so that the MFMA A-fragment reads (ds_read_b128, four
+// non-contiguous 16-lane groups) are bank-conflict free; one barrier per tile.
+template <typename T>
+__global__ __launch_bounds__(256) void prefill_stats_lds_kernel(MArgs a) {
+  __shared__ __attribute__((aligned(16))) uint4 sm_kt[2][kTK][16];
+  const int lane = threadIdx.x & 63, r = threadIdx.x >> 6;
+  const int hi = lane >> 5, lq = lane & 31;
+  const int h = blockIdx.y, L = a.L;
+  const int j = h * 4 + r;
+  const T* qh = reinterpret_cast<const T*>(a.q) + (size_t)j * L * kD;
+  const T* kh = reinterpret_cast<const T*>(a.k) + (size_t)h * L * kD;
+  const int nqt = (L + kTQ - 1) / kTQ;
+  // cooperative tile load: thread t -> key row t / 8, chunks 2 * (t % 8) and + 1 (32 contiguous bytes)
+  const int ld_row = threadIdx.x >> 3, ld_c0 = (threadIdx.x & 7) * 2;
+
+  for (int qt = blockIdx.x; qt < nqt; qt += gridDim.x) {
+    const int q0 = qt * kTQ;
+    const int query = q0 + lq;
+    const int qc = query < L ? query : L - 1;
+    uint4 qb[8];
+#pragma unroll
+    for (int ds = 0; ds < 8; ds++) qb[ds] = *reinterpret_cast<const uint4*>(qh + (size_t)qc * kD + ds * 16 + 8 * hi);
+    float m_run = -INFINITY, l_run = 0.f;
+    const int last_q = min(L, q0 + kTQ) - 1;
+    const int ntile = last_q / kTK + 1;
+    uint4 st0, st1;
+    auto fetch = [&](int t) {
+      const int krow = min(t * kTK + ld_row, L - 1);
+      const uint4* src = reinterpret_cast<const uint4*>(kh + (size_t)krow * kD) + ld_c0;
+      st0 = src[0];
+      st1 = src[1];
+    };
+    auto stash = [&](int buf) {
+      sm_kt[buf][ld_row][(ld_c0 ^ (ld_row & 15)) & 15] = st0;
+      sm_kt[buf][ld_row][((ld_c0 + 1) ^ (ld_row & 15)) & 15] = st1;
+    };
+    __syncthreads();  // the previous query tile's last readers are done with both buffers
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int t = 0; t < ntile; t++) {
+      const int k0 = t * kTK;
+      if (t + 1 < ntile) fetch(t + 1);  // in flight during this tile's MFMAs and softmax
+      f32x16 s;
+#pragma unroll
+      for (int e = 0; e < 16; e++) s[e] = 0.f;
+#pragma unroll
+      for (int ds = 0; ds < 8; ds++) s = MfmaOps<T>::mma(sm_kt[t & 1][lq][((2 * ds + hi) ^ (lq & 15)) & 15], qb[ds], s);
+      float mx = m_run;
+      float x[16];
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        const int key = k0 + c_row(e, hi);
+        const float v = ElemTraits<T>::rnd(ElemTraits<T>::rnd(s[e]) * a.scale);
+        x[e] = (key > query || key >= L || query >= L) ? -INFINITY : v;
+        mx = fmaxf(mx, x[e]);
+      }
+      const float mu = (mx == -INFINITY) ? 0.f : mx;
+      float sum = l_run * pf_exp(m_run - mu);
+#pragma unroll
+      for (int e = 0; e < 16; e++) sum += pf_exp(x[e] - mu);
+      m_run = mx;
+      l_run = sum;
+      if (t + 1 < ntile) stash((t + 1) & 1);
+      __syncthreads();
+    }
+    const float m_o = __shfl_xor(m_run, 32, CC_WAVE), l_o = __shfl_xor(l_run, 32, CC_WAVE);
+    const float mx = fmaxf(m_run, m_o);
+    const float mu = (mx == -INFINITY) ? 0.f : mx;
+    const float lt = l_run * pf_exp(m_run - mu) + l_o * pf_exp(m_o - mu);
+    if (hi == 0 && query < L) {
+      a.stats[((size_t)j * L + query) * 2] = mx;
+      a.stats[((size_t)j * L + query) * 2 + 1] = lt;
+    }
+  }
+}
+
 }  // namespace
 
 // Entry used by cc_attn_prefill.hip's dispatcher.  Returns CC_ERR_UNSUPPORTED when the geometry is not the MFMA one.
@@ -258,13 +341,16 @@ extern "C" int cc_prefill_attn_mfma_impl(const void* q, const void* k, const voi
   size_t nbk = (tot + 255) / 256;
   if (nbk > 8192) nbk = 8192;
   dim3 grid(nwg, H), block(256);
+  // pass 1 keeps no per-workgroup partial planes: it can use as many workgroups as fit (5 per CU at ~100 VGPRs)
+  const int nqt = (L + kTQ - 1) / kTQ;
+  dim3 grid1(nqt < 256 ? nqt : 256, H);
   if (dtype == CC_DT_BF16) {
     hipLaunchKernelGGL(vt_perm_kernel<bf16_t>, dim3((unsigned)nbk), dim3(256), 0, st, (const bf16_t*)v, (bf16_t*)vt, H, L, Lp);
-    hipLaunchKernelGGL((prefill_mfma_kernel<bf16_t, 1>), grid, block, 0, st, a);
+    hipLaunchKernelGGL(prefill_stats_lds_kernel<bf16_t>, grid1, block, 0, st, a);
     hipLaunchKernelGGL((prefill_mfma_kernel<bf16_t, 2>), grid, block, 0, st, a);
   } else {
     hipLaunchKernelGGL(vt_perm_kernel<f16_t>, dim3((unsigned)nbk), dim3(256), 0, st, (const f16_t*)v, (f16_t*)vt, H, L, Lp);
-    hipLaunchKernelGGL((prefill_mfma_kernel<f16_t, 1>), grid, block, 0, st, a);
+    hipLaunchKernelGGL(prefill_stats_lds_kernel<f16_t>, grid1, block, 0, st, a);
     hipLaunchKernelGGL((prefill_mfma_kernel<f16_t, 2>), grid, block, 0, st, a);
   }
   if (hipGetLastError() != hipSuccess) return CC_ERR_HIP;
