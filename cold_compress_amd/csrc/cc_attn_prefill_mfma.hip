@@ -9,6 +9,8 @@
 // AFTER normalisation with the final row statistics):
 //   workgroup = 4 waves = the 4 query heads of one kv head x one tile of 32 queries; persistent over query tiles
 //   (w, w + NWG, ...) so the per-workgroup column-sum partials accumulate in a fixed order (no atomics).
+//   K (and V^T) tiles of 32 keys are fetched ONCE per workgroup — the four heads share them — one tile ahead of the
+//   math, into double-buffered XOR-swizzled LDS images (conflict-free ds_read_b128 fragment reads).
 //   S^T = K . Q^T  ("swapped" product): the MFMA C tile has col = query (lane & 31) and 16 keys per lane, so every
 //   softmax row statistic is lane-local + one half-wave exchange.
 //   P (C layout) is converted to 16-bit and used DIRECTLY as the A operand of the PV MFMA; the B operand comes
@@ -88,162 +90,8 @@ __global__ __launch_bounds__(256) void vt_perm_kernel(const T* v, T* vt, int H, 
   }
 }
 
-template <typename T, int PASS>
-__global__ __launch_bounds__(256) void prefill_mfma_kernel(MArgs a) {
-  __shared__ float sm_p[4][kTK][kTQ + 1];   // per-wave probability tiles (pass 2): [r][key][query]
-  __shared__ float sm_red[2 + kMaxBandsM][8][kTK];
-  const int lane = threadIdx.x & 63, r = threadIdx.x >> 6;  // wave = query head of the group
-  const int hi = lane >> 5, lq = lane & 31;
-  const int h = blockIdx.y, L = a.L;
-  const int j = h * 4 + r;
-  const T* qh = reinterpret_cast<const T*>(a.q) + (size_t)j * L * kD;
-  const T* kh = reinterpret_cast<const T*>(a.k) + (size_t)h * L * kD;
-  const T* vth = reinterpret_cast<const T*>(a.vt) + (size_t)h * kD * a.Lp;
-  const int nqt = (L + kTQ - 1) / kTQ;
-  const size_t plane = (size_t)gridDim.x * a.H * L;
-  float* cp = a.cpart + ((size_t)blockIdx.x * a.H + h) * L;
-  const int npl = 1 + a.nb + (a.obs_len > 0 ? 1 : 0);
-  if (PASS == 2) {
-    for (int pl = 0; pl < npl; pl++)
-      for (int s = threadIdx.x; s < L; s += 256) cp[pl * plane + s] = 0.f;
-  }
-
-  for (int qt = blockIdx.x; qt < nqt; qt += gridDim.x) {
-    const int q0 = qt * kTQ;
-    const bool obs_tile = a.obs_len > 0 && q0 + kTQ > L - a.obs_len;  // workgroup-uniform: only the last tiles pay
-    const int query = q0 + lq;
-    const int qc = query < L ? query : L - 1;
-    uint4 qb[8];  // B operand of the QK MFMA for the 8 d-steps: Q[query][16*ds + 8*hi .. +7]
-#pragma unroll
-    for (int ds = 0; ds < 8; ds++) qb[ds] = *reinterpret_cast<const uint4*>(qh + (size_t)qc * kD + ds * 16 + 8 * hi);
-    float m_run = -INFINITY, l_run = 0.f;  // pass 1: partial over this lane's keys
-    float m_fin = 0.f, l_fin = 1.f;        // pass 2
-    if (PASS == 2) {
-      m_fin = a.stats[((size_t)j * L + qc) * 2];
-      l_fin = a.stats[((size_t)j * L + qc) * 2 + 1];
-    }
-    const float inv_l = __frcp_rn(l_fin);  // one reciprocal per query row instead of one IEEE divide per probability
-    f32x16 o[4];
-#pragma unroll
-    for (int b = 0; b < 4; b++)
-#pragma unroll
-      for (int e = 0; e < 16; e++) o[b][e] = 0.f;
-
-    const int last_q = min(L, q0 + kTQ) - 1;
-    for (int k0 = 0; k0 <= last_q; k0 += kTK) {
-      // ---- S^T tile = K . Q^T  (rows = keys, cols = queries)
-      const int krow = k0 + lq < L ? k0 + lq : L - 1;
-      f32x16 s;
-#pragma unroll
-      for (int e = 0; e < 16; e++) s[e] = 0.f;
-#pragma unroll
-      for (int ds = 0; ds < 8; ds++) {
-        const uint4 ka = *reinterpret_cast<const uint4*>(kh + (size_t)krow * kD + ds * 16 + 8 * hi);
-        s = MfmaOps<T>::mma(ka, qb[ds], s);
-      }
-      float x[16];
-#pragma unroll
-      for (int e = 0; e < 16; e++) {
-        const int key = k0 + c_row(e, hi);
-        const float v = ElemTraits<T>::rnd(ElemTraits<T>::rnd(s[e]) * a.scale);
-        x[e] = (key > query || key >= L || query >= L) ? -INFINITY : v;
-      }
-      if (PASS == 1) {
-        float mx = m_run;
-#pragma unroll
-        for (int e = 0; e < 16; e++) mx = fmaxf(mx, x[e]);
-        const float mu = (mx == -INFINITY) ? 0.f : mx;
-        float sum = l_run * pf_exp(m_run - mu);
-#pragma unroll
-        for (int e = 0; e < 16; e++) sum += pf_exp(x[e] - mu);
-        m_run = mx;
-        l_run = sum;
-      } else {
-        float p[16];
-#pragma unroll
-        for (int e = 0; e < 16; e++) p[e] = ElemTraits<T>::rnd(pf_exp(x[e] - m_fin) * inv_l);  // exp(-inf) = 0
-        // ---- column sums of the group mean: P tiles of the 4 query heads meet in LDS
-        __syncthreads();  // previous tile's readers are done
-#pragma unroll
-        for (int e = 0; e < 16; e++) sm_p[r][c_row(e, hi)][lq] = p[e];
-        __syncthreads();
-        {
-          const int key = threadIdx.x & 31, qs = threadIdx.x >> 5;  // 8 slices of 4 queries
-          float cs = 0.f, os = 0.f, bs[kMaxBandsM] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int qq = 0; qq < 4; qq++) {
-            const int ql = qs * 4 + qq;
-            const float sum = ((sm_p[0][key][ql] + sm_p[1][key][ql]) + sm_p[2][key][ql]) + sm_p[3][key][ql];
-            const float av = ElemTraits<T>::rnd(__fdiv_rn(sum, 4.0f));
-            cs += av;
-            // ref: prompt_compression.py:173 attn[:, :, -obs_len:, :] — the SnapKV observation window is just
-            // another side sum of the probabilities this pass already has (the VALU path recomputes 16 x R dot
-            // products per key for it: 1.15 ms per layer at L = 8192)
-            if (obs_tile && q0 + ql >= L - a.obs_len && q0 + ql < L) os += av;
-            const int dist = (q0 + ql) - (k0 + key);
-#pragma unroll
-            for (int b = 0; b < kMaxBandsM; b++)
-              if (b < a.nb && dist < a.band[b]) bs[b] += av;
-          }
-          sm_red[0][qs][key] = cs;
-#pragma unroll
-          for (int b = 0; b < kMaxBandsM; b++)
-            if (b < a.nb) sm_red[1 + b][qs][key] = bs[b];
-          if (obs_tile) sm_red[1 + a.nb][qs][key] = os;
-        }
-        __syncthreads();
-        if (threadIdx.x < kTK && k0 + threadIdx.x < L) {
-          const int key = threadIdx.x;
-          for (int pl = 0; pl < npl; pl++) {
-            if (pl == 1 + a.nb && !obs_tile) continue;  // the observation plane only exists for the last query tiles
-            float tot = 0.f;
-#pragma unroll
-            for (int qs = 0; qs < 8; qs++) tot += sm_red[pl][qs][key];
-            cp[pl * plane + k0 + key] += tot;
-          }
-        }
-        // ---- O += P . V : A = P (C layout -> 16-bit, no data movement), B = vt_perm (one 16-byte load each)
-#pragma unroll
-        for (int kb = 0; kb < 2; kb++) {
-          uint4 pa;
-          pa.x = MfmaOps<T>::pack2(p[kb * 8 + 0], p[kb * 8 + 1]);
-          pa.y = MfmaOps<T>::pack2(p[kb * 8 + 2], p[kb * 8 + 3]);
-          pa.z = MfmaOps<T>::pack2(p[kb * 8 + 4], p[kb * 8 + 5]);
-          pa.w = MfmaOps<T>::pack2(p[kb * 8 + 6], p[kb * 8 + 7]);
-#pragma unroll
-          for (int db = 0; db < 4; db++) {
-            const uint4 vb = *reinterpret_cast<const uint4*>(vth + (size_t)(db * 32 + lq) * a.Lp + k0 + kb * 16 + 8 * hi);
-            o[db] = MfmaOps<T>::mma(pa, vb, o[db]);
-          }
-        }
-      }
-    }
-    if (PASS == 1) {
-      // merge the two half-waves (each saw 16 of every 32 keys)
-      const float m_o = __shfl_xor(m_run, 32, CC_WAVE), l_o = __shfl_xor(l_run, 32, CC_WAVE);
-      const float mx = fmaxf(m_run, m_o);
-      const float mu = (mx == -INFINITY) ? 0.f : mx;
-      const float lt = l_run * pf_exp(m_run - mu) + l_o * pf_exp(m_o - mu);
-      if (hi == 0 && query < L) {
-        a.stats[((size_t)j * L + query) * 2] = mx;
-        a.stats[((size_t)j * L + query) * 2 + 1] = lt;
-      }
-    } else {
-      T* yh = reinterpret_cast<T*>(a.y) + (size_t)j * L * kD;
-#pragma unroll
-      for (int db = 0; db < 4; db++)
-#pragma unroll
-        for (int e = 0; e < 16; e++) {
-          const int qrow = q0 + c_row(e, hi);
-          if (qrow < L) ElemTraits<T>::store(yh, (size_t)qrow * kD + db * 32 + lq, o[db][e]);
-        }
-    }
-  }
-}
-
-
 // ---------------------------------------------------------------------------------------------------------------
-// Pass 1 (row maxima and sums), LDS-shared K tiles.  PMC counters of the per-wave-loading version above: 65 % of the
+// Pass 1 (row maxima and sums), LDS-shared K tiles.  PMC counters of the first, per-wave-loading version: 65 % of the
 // wave cycles parked in s_waitcnt — every wave fetched its own K fragments per 32-key tile (the four query heads of
 // a group fetched the SAME tile four times) and waited out an L2 round trip per tile.  Here the workgroup fetches a
 // K tile ONCE (two 16-byte loads per thread, coalesced rows), one tile ahead of the math, into a double-buffered LDS
@@ -324,6 +172,154 @@ __global__ __launch_bounds__(256) void prefill_stats_lds_kernel(MArgs a) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Pass 2 (probabilities -> P.V, group-mean column / band / observation-window sums) with the same LDS pipeline as
+// pass 1: K and V^T tiles are fetched once per workgroup, one tile ahead, into double-buffered swizzled LDS images;
+// the partial side sums of tile t are folded into the workgroup's planes during tile t + 1 (double-buffered
+// sm_red), so a tile costs TWO barriers instead of three and no wave waits on its own global loads.
+template <typename T>
+__global__ __launch_bounds__(256) void prefill_pv_lds_kernel(MArgs a) {
+  __shared__ __attribute__((aligned(16))) uint4 sm_kt[2][kTK][16];   // [buf][key][chunk ^ (key & 15)]
+  __shared__ __attribute__((aligned(16))) uint4 sm_vt[2][kD][4];     // [buf][d][chunk ^ ((d >> 2) & 3)]  (V^T, permuted keys)
+  __shared__ float sm_p[4][kTK][kTQ + 1];                            // per-wave probability tiles: [r][key][query]
+  __shared__ float sm_red[2][2 + kMaxBandsM][8][kTK];
+  const int lane = threadIdx.x & 63, r = threadIdx.x >> 6;
+  const int hi = lane >> 5, lq = lane & 31;
+  const int h = blockIdx.y, L = a.L;
+  const int j = h * 4 + r;
+  const T* qh = reinterpret_cast<const T*>(a.q) + (size_t)j * L * kD;
+  const T* kh = reinterpret_cast<const T*>(a.k) + (size_t)h * L * kD;
+  const T* vth = reinterpret_cast<const T*>(a.vt) + (size_t)h * kD * a.Lp;
+  const int nqt = (L + kTQ - 1) / kTQ;
+  const size_t plane = (size_t)gridDim.x * a.H * L;
+  float* cp = a.cpart + ((size_t)blockIdx.x * a.H + h) * L;
+  const int npl = 1 + a.nb + (a.obs_len > 0 ? 1 : 0);
+  for (int pl = 0; pl < npl; pl++)
+    for (int s = threadIdx.x; s < L; s += 256) cp[pl * plane + s] = 0.f;
+  const int kl_row = threadIdx.x >> 3, kl_c0 = (threadIdx.x & 7) * 2;   // K tile: row t/8, chunks 2(t%8), +1
+  const int vl_row = threadIdx.x >> 1, vl_c0 = (threadIdx.x & 1) * 2;   // V^T tile: d row t/2, chunks 2(t%2), +1
+
+  for (int qt = blockIdx.x; qt < nqt; qt += gridDim.x) {
+    const int q0 = qt * kTQ;
+    const bool obs_tile = a.obs_len > 0 && q0 + kTQ > L - a.obs_len;
+    const int query = q0 + lq;
+    const int qc = query < L ? query : L - 1;
+    uint4 qb[8];
+#pragma unroll
+    for (int ds = 0; ds < 8; ds++) qb[ds] = *reinterpret_cast<const uint4*>(qh + (size_t)qc * kD + ds * 16 + 8 * hi);
+    const float m_fin = a.stats[((size_t)j * L + qc) * 2];
+    const float inv_l = __frcp_rn(a.stats[((size_t)j * L + qc) * 2 + 1]);
+    f32x16 o[4];
+#pragma unroll
+    for (int b = 0; b < 4; b++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) o[b][e] = 0.f;
+    const int last_q = min(L, q0 + kTQ) - 1;
+    const int ntile = last_q / kTK + 1;
+    uint4 sk0, sk1, sv0, sv1;
+    auto fetch = [&](int t) {
+      const int krow = min(t * kTK + kl_row, L - 1);
+      const uint4* ks = reinterpret_cast<const uint4*>(kh + (size_t)krow * kD) + kl_c0;
+      sk0 = ks[0];
+      sk1 = ks[1];
+      const uint4* vs = reinterpret_cast<const uint4*>(vth + (size_t)vl_row * a.Lp + t * kTK) + vl_c0;
+      sv0 = vs[0];
+      sv1 = vs[1];
+    };
+    auto stash = [&](int buf) {
+      sm_kt[buf][kl_row][(kl_c0 ^ (kl_row & 15)) & 15] = sk0;
+      sm_kt[buf][kl_row][((kl_c0 + 1) ^ (kl_row & 15)) & 15] = sk1;
+      sm_vt[buf][vl_row][(vl_c0 ^ ((vl_row >> 2) & 3)) & 3] = sv0;
+      sm_vt[buf][vl_row][((vl_c0 + 1) ^ ((vl_row >> 2) & 3)) & 3] = sv1;
+    };
+    // fold the side sums tile t left in sm_red[t & 1] into this workgroup's planes (fixed order: deterministic)
+    auto fold = [&](int t, bool obs_t) {
+      if (threadIdx.x < kTK && t * kTK + (int)threadIdx.x < L) {
+        const int key = threadIdx.x;
+        for (int pl = 0; pl < npl; pl++) {
+          if (pl == 1 + a.nb && !obs_t) continue;
+          float tot = 0.f;
+#pragma unroll
+          for (int qs = 0; qs < 8; qs++) tot += sm_red[t & 1][pl][qs][key];
+          cp[pl * plane + t * kTK + key] += tot;
+        }
+      }
+    };
+    __syncthreads();
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int t = 0; t < ntile; t++) {
+      const int k0 = t * kTK, buf = t & 1;
+      if (t + 1 < ntile) fetch(t + 1);
+      // ---- S^T tile = K . Q^T from the LDS image
+      f32x16 s;
+#pragma unroll
+      for (int e = 0; e < 16; e++) s[e] = 0.f;
+#pragma unroll
+      for (int ds = 0; ds < 8; ds++) s = MfmaOps<T>::mma(sm_kt[buf][lq][((2 * ds + hi) ^ (lq & 15)) & 15], qb[ds], s);
+      float p[16];
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        const int key = k0 + c_row(e, hi);
+        const float v = ElemTraits<T>::rnd(ElemTraits<T>::rnd(s[e]) * a.scale);
+        const float x = (key > query || key >= L || query >= L) ? -INFINITY : v;
+        p[e] = ElemTraits<T>::rnd(pf_exp(x - m_fin) * inv_l);  // exp(-inf) = 0
+        sm_p[r][c_row(e, hi)][lq] = p[e];
+      }
+      __syncthreads();  // B1: the four heads' probability tiles are in LDS
+      {
+        const int key = threadIdx.x & 31, qs = threadIdx.x >> 5;  // 8 slices of 4 queries
+        float cs = 0.f, os = 0.f, bs[kMaxBandsM] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int qq = 0; qq < 4; qq++) {
+          const int ql = qs * 4 + qq;
+          const float sum = ((sm_p[0][key][ql] + sm_p[1][key][ql]) + sm_p[2][key][ql]) + sm_p[3][key][ql];
+          const float av = ElemTraits<T>::rnd(__fdiv_rn(sum, 4.0f));
+          cs += av;
+          if (obs_tile && q0 + ql >= L - a.obs_len && q0 + ql < L) os += av;
+          const int dist = (q0 + ql) - (k0 + key);
+#pragma unroll
+          for (int b = 0; b < kMaxBandsM; b++)
+            if (b < a.nb && dist < a.band[b]) bs[b] += av;
+        }
+        sm_red[buf][0][qs][key] = cs;
+#pragma unroll
+        for (int b = 0; b < kMaxBandsM; b++)
+          if (b < a.nb) sm_red[buf][1 + b][qs][key] = bs[b];
+        if (obs_tile) sm_red[buf][1 + a.nb][qs][key] = os;
+      }
+      if (t > 0) fold(t - 1, obs_tile);  // the previous tile's sums became visible at the last barrier
+      // ---- O += P . V : A = P (C layout -> 16-bit), B = V^T fragments from the LDS image
+#pragma unroll
+      for (int kb = 0; kb < 2; kb++) {
+        uint4 pa;
+        pa.x = MfmaOps<T>::pack2(p[kb * 8 + 0], p[kb * 8 + 1]);
+        pa.y = MfmaOps<T>::pack2(p[kb * 8 + 2], p[kb * 8 + 3]);
+        pa.z = MfmaOps<T>::pack2(p[kb * 8 + 4], p[kb * 8 + 5]);
+        pa.w = MfmaOps<T>::pack2(p[kb * 8 + 6], p[kb * 8 + 7]);
+#pragma unroll
+        for (int db = 0; db < 4; db++) {
+          const int d = db * 32 + lq;
+          o[db] = MfmaOps<T>::mma(pa, sm_vt[buf][d][((kb * 2 + hi) ^ ((d >> 2) & 3)) & 3], o[db]);
+        }
+      }
+      if (t + 1 < ntile) stash((t + 1) & 1);
+      __syncthreads();  // B2: tile t + 1 is in LDS, tile t's side sums are in sm_red[buf], sm_p may be rewritten
+    }
+    fold(ntile - 1, obs_tile);
+    T* yh = reinterpret_cast<T*>(a.y) + (size_t)j * L * kD;
+#pragma unroll
+    for (int db = 0; db < 4; db++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        const int qrow = q0 + c_row(e, hi);
+        if (qrow < L) ElemTraits<T>::store(yh, (size_t)qrow * kD + db * 32 + lq, o[db][e]);
+      }
+  }
+}
+
 }  // namespace
 
 // Entry used by cc_attn_prefill.hip's dispatcher.  Returns CC_ERR_UNSUPPORTED when the geometry is not the MFMA one.
@@ -347,11 +343,11 @@ extern "C" int cc_prefill_attn_mfma_impl(const void* q, const void* k, const voi
   if (dtype == CC_DT_BF16) {
     hipLaunchKernelGGL(vt_perm_kernel<bf16_t>, dim3((unsigned)nbk), dim3(256), 0, st, (const bf16_t*)v, (bf16_t*)vt, H, L, Lp);
     hipLaunchKernelGGL(prefill_stats_lds_kernel<bf16_t>, grid1, block, 0, st, a);
-    hipLaunchKernelGGL((prefill_mfma_kernel<bf16_t, 2>), grid, block, 0, st, a);
+    hipLaunchKernelGGL(prefill_pv_lds_kernel<bf16_t>, grid, block, 0, st, a);
   } else {
     hipLaunchKernelGGL(vt_perm_kernel<f16_t>, dim3((unsigned)nbk), dim3(256), 0, st, (const f16_t*)v, (f16_t*)vt, H, L, Lp);
     hipLaunchKernelGGL(prefill_stats_lds_kernel<f16_t>, grid1, block, 0, st, a);
-    hipLaunchKernelGGL((prefill_mfma_kernel<f16_t, 2>), grid, block, 0, st, a);
+    hipLaunchKernelGGL(prefill_pv_lds_kernel<f16_t>, grid, block, 0, st, a);
   }
   if (hipGetLastError() != hipSuccess) return CC_ERR_HIP;
   return CC_OK;
