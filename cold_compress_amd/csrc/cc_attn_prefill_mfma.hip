@@ -145,12 +145,23 @@ __global__ __launch_bounds__(256) void prefill_stats_lds_kernel(MArgs a) {
       for (int ds = 0; ds < 8; ds++) s = MfmaOps<T>::mma(sm_kt[t & 1][lq][((2 * ds + hi) ^ (lq & 15)) & 15], qb[ds], s);
       float mx = m_run;
       float x[16];
+      // every tile strictly below the diagonal of a complete query tile needs no causal / bounds masking: the 16
+      // compares + selects per lane are only paid on the diagonal tile (and on the ragged last query tile)
+      const bool full_tile = (k0 + kTK - 1 <= q0) && (q0 + kTQ <= L);
+      if (full_tile) {
 #pragma unroll
-      for (int e = 0; e < 16; e++) {
-        const int key = k0 + c_row(e, hi);
-        const float v = ElemTraits<T>::rnd(ElemTraits<T>::rnd(s[e]) * a.scale);
-        x[e] = (key > query || key >= L || query >= L) ? -INFINITY : v;
-        mx = fmaxf(mx, x[e]);
+        for (int e = 0; e < 16; e++) {
+          x[e] = ElemTraits<T>::rnd(ElemTraits<T>::rnd(s[e]) * a.scale);
+          mx = fmaxf(mx, x[e]);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+          const int key = k0 + c_row(e, hi);
+          const float v = ElemTraits<T>::rnd(ElemTraits<T>::rnd(s[e]) * a.scale);
+          x[e] = (key > query || key >= L || query >= L) ? -INFINITY : v;
+          mx = fmaxf(mx, x[e]);
+        }
       }
       const float mu = (mx == -INFINITY) ? 0.f : mx;
       float sum = l_run * pf_exp(m_run - mu);
@@ -260,13 +271,23 @@ __global__ __launch_bounds__(256) void prefill_pv_lds_kernel(MArgs a) {
 #pragma unroll
       for (int ds = 0; ds < 8; ds++) s = MfmaOps<T>::mma(sm_kt[buf][lq][((2 * ds + hi) ^ (lq & 15)) & 15], qb[ds], s);
       float p[16];
+      const bool full_tile = (k0 + kTK - 1 <= q0) && (q0 + kTQ <= L);  // no causal / bounds masking below the diagonal
+      if (full_tile) {
 #pragma unroll
-      for (int e = 0; e < 16; e++) {
-        const int key = k0 + c_row(e, hi);
-        const float v = ElemTraits<T>::rnd(ElemTraits<T>::rnd(s[e]) * a.scale);
-        const float x = (key > query || key >= L || query >= L) ? -INFINITY : v;
-        p[e] = ElemTraits<T>::rnd(pf_exp(x - m_fin) * inv_l);  // exp(-inf) = 0
-        sm_p[r][c_row(e, hi)][lq] = p[e];
+        for (int e = 0; e < 16; e++) {
+          const float v = ElemTraits<T>::rnd(ElemTraits<T>::rnd(s[e]) * a.scale);
+          p[e] = ElemTraits<T>::rnd(pf_exp(v - m_fin) * inv_l);
+          sm_p[r][c_row(e, hi)][lq] = p[e];
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+          const int key = k0 + c_row(e, hi);
+          const float v = ElemTraits<T>::rnd(ElemTraits<T>::rnd(s[e]) * a.scale);
+          const float x = (key > query || key >= L || query >= L) ? -INFINITY : v;
+          p[e] = ElemTraits<T>::rnd(pf_exp(x - m_fin) * inv_l);  // exp(-inf) = 0
+          sm_p[r][c_row(e, hi)][lq] = p[e];
+        }
       }
       __syncthreads();  // B1: the four heads' probability tiles are in LDS
       {
@@ -276,13 +297,15 @@ __global__ __launch_bounds__(256) void prefill_pv_lds_kernel(MArgs a) {
         for (int qq = 0; qq < 4; qq++) {
           const int ql = qs * 4 + qq;
           const float sum = ((sm_p[0][key][ql] + sm_p[1][key][ql]) + sm_p[2][key][ql]) + sm_p[3][key][ql];
-          const float av = ElemTraits<T>::rnd(__fdiv_rn(sum, 4.0f));
+          const float av = ElemTraits<T>::rnd(sum * 0.25f);  // == sum / 4 exactly (power of two); model.py:416-418
           cs += av;
           if (obs_tile && q0 + ql >= L - a.obs_len && q0 + ql < L) os += av;
-          const int dist = (q0 + ql) - (k0 + key);
+          if (a.nb > 0) {
+            const int dist = (q0 + ql) - (k0 + key);
 #pragma unroll
-          for (int b = 0; b < kMaxBandsM; b++)
-            if (b < a.nb && dist < a.band[b]) bs[b] += av;
+            for (int b = 0; b < kMaxBandsM; b++)
+              if (b < a.nb && dist < a.band[b]) bs[b] += av;
+          }
         }
         sm_red[buf][0][qs][key] = cs;
 #pragma unroll
