@@ -270,9 +270,10 @@ class KVCacheHeadSpecific(KVCache):
 
 
 class _RingFusedStep:
-    """Two-launch decode step for the head-constant ring policies (recent_global, full): the slot for position p + 1 is
-    the arg-min of `pos` behind the sinks, scored in the combine pass of step p and consumed by the K/V streaming pass
-    of step p + 1 (cc_decode_step_recent_global).  Same contract as KVCacheHeavyHitter.decode_step."""
+    """Two-launch decode step for the head-constant policies (recent_global, full, random): the slot for position
+    p + 1 is scored in the combine pass of step p (arg-min of `pos` behind the sinks; for random, of the next uniform
+    draw) and consumed by the K/V streaming pass of step p + 1 (cc_decode_step_recent_global / cc_decode_step_random).
+    Same contract as KVCacheHeavyHitter.decode_step."""
 
     def _init_ring_pipeline(self):
         nk = int(_abi.lib()["cc_hh_next_key_slots"](self.max_cache_length))
@@ -290,9 +291,15 @@ class _RingFusedStep:
         self._next_valid = False  # the three-call path mutates pos outside the pipeline
         return super().update_kv(input_pos, k_val, v_val, is_prefill, **kwargs)
 
+    def _pipeline_init(self, p32):
+        _abi.call("cc_rg_next_key_init", self._view(), _ptr(p32), int(self.global_tokens), _ptr(self.next_key), _stream())
+
+    def _pipeline_step(self, q, k, v, p32, HQ, scale, y, ws):
+        _abi.call("cc_decode_step_recent_global", self._view(), _ptr(q), _ptr(k), _ptr(v), _ptr(p32), _ptr(self.next_key),
+                  int(self.global_tokens), HQ, scale, _ptr(y), _ptr(ws), ws.numel(), _stream())
+
     def prepare_decode(self, input_pos):
-        _abi.call("cc_rg_next_key_init", self._view(), _ptr(self._pos32(input_pos)), int(self.global_tokens), _ptr(self.next_key),
-                  _stream())
+        self._pipeline_init(self._pos32(input_pos))
         self._next_valid = True
 
     def decode_step(self, query, k_val, v_val, input_pos, scale=None):
@@ -309,8 +316,7 @@ class _RingFusedStep:
         y = torch.empty((1, HQ, 1, D), dtype=query.dtype, device=query.device)
         nbytes = _abi.lib()["cc_decode_attn_workspace_bytes"](HQ, self.n_heads, self.max_cache_length, D, _DT[self.k_cache.dtype])
         ws = _workspace(nbytes, query.device)
-        _abi.call("cc_decode_step_recent_global", self._view(), _ptr(q), _ptr(k), _ptr(v), _ptr(p32), _ptr(self.next_key),
-                  int(self.global_tokens), HQ, 1.0 / math.sqrt(D) if scale is None else scale, _ptr(y), _ptr(ws), ws.numel(), _stream())
+        self._pipeline_step(q, k, v, p32, HQ, 1.0 / math.sqrt(D) if scale is None else scale, y, ws)
         self._quant_pending = self.quantize
         return y
 
@@ -328,13 +334,28 @@ class KVCacheFull(_RingFusedStep, KVCacheHeadConstant):
                   _ptr(self._idx_buf()), _stream())
 
 
-class KVCacheRandom(KVCacheHeadConstant):
+class KVCacheRandom(_RingFusedStep, KVCacheHeadConstant):
     """ref: cache.py:505-524.  The uniform vector is drawn by torch on the device (RNG streams are
-    backend-specific); `_rand` is the injection point tests use to replay the reference's draws."""
+    backend-specific); `_rand` is the injection point tests use to replay the reference's draws.  In the two-launch
+    pipeline the draw for position p + 1 is made during step p (one draw per step, same order as the reference)."""
     relevant_kwargs = ["max_cache_length", "max_seq_length", "cache_bits", "global_tokens", "recent_window"]
+
+    def __init__(self, max_batch_size, n_heads, head_dim, dtype=torch.bfloat16, **kwargs):
+        super().__init__(max_batch_size, n_heads, head_dim, dtype, **kwargs)
+        self._init_ring_pipeline()
 
     def _rand(self):
         return torch.rand(self.max_cache_length, device=self.k_cache.device)
+
+    def _pipeline_init(self, p32):
+        r = self._rand().to(torch.float32).contiguous()
+        _abi.call("cc_random_next_key_init", self._view(), _ptr(p32), _ptr(r), int(self.global_tokens), int(self.recent_window),
+                  _ptr(self.next_key), _stream())
+
+    def _pipeline_step(self, q, k, v, p32, HQ, scale, y, ws):
+        r = self._rand().to(torch.float32).contiguous()
+        _abi.call("cc_decode_step_random", self._view(), _ptr(q), _ptr(k), _ptr(v), _ptr(p32), _ptr(r), _ptr(self.next_key),
+                  int(self.global_tokens), int(self.recent_window), HQ, scale, _ptr(y), _ptr(ws), ws.numel(), _stream())
 
     def _run_select(self, input_pos, k, v):
         r = self._rand().to(torch.float32).contiguous()

@@ -723,7 +723,9 @@ struct CombineArgs {
   const int32_t* input_pos;
   const int32_t* pos;  // [Hp, S]
   int H, g, w;
-  int policy;  // next-eviction scoring: 1 = heavy hitter (cache.py:727-749), 2 = recent_global / full (cache.py:500-502, 552-556)
+  int policy;  // next-eviction scoring: 1 = heavy hitter (cache.py:727-749), 2 = recent_global / full (cache.py:500-502, 552-556),
+               // 3 = random (cache.py:519-524 over rand_next)
+  const float* rand_next;  // policy 3: [S] uniform draws for position p + 1
   int Hp;
   int abl;  // measurement-only ablation bits (phases >> 8): 8 = no next-key epilogue, 16 = no y merge, 32 = no per-slot pass
 };
@@ -760,6 +762,8 @@ __global__ __launch_bounds__(kCombThreads) void decode_attn_combine_kernel(Combi
     ps_mine = a.pos[(a.Hp == 1 ? 0 : (size_t)h * S) + s_ld];
     p_next = *a.input_pos + 1;
   }
+  float rnd_mine = 0.f;
+  if (a.next_key && a.policy == 3) rnd_mine = a.rand_next[s_ld];
   unsigned long long my_key = ~0ull;
   // y: the R*D outputs of this kv head are spread over the chunk blocks; inside a block the (output, split)
   // products are spread over ALL threads (G split-groups per output).  The first 8 partial-O values of every
@@ -907,6 +911,13 @@ __global__ __launch_bounds__(kCombThreads) void decode_attn_combine_kernel(Combi
   }
   if (a.next_key && a.policy == 2 && have && h == 0 && s_mine >= a.g)  // arg-min of pos over the slots behind the sinks; -1 = empty first
     my_key = make_key(orderable_i32(ps_mine), ((uint32_t)s_mine << 1) | (uint32_t)(ps_mine == -1));
+  if (a.next_key && a.policy == 3 && have && h == 0) {  // ref: cache.py:523 recent window -> +inf, then the base rules :373-376
+    float scn = rnd_mine;
+    if (ps_mine >= p_next - a.w) scn = INFINITY;
+    if (s_mine < a.g) scn = INFINITY;
+    if (ps_mine == -1) scn = -INFINITY;
+    my_key = make_key(orderable_f32(scn), ((uint32_t)s_mine << 1) | (uint32_t)(ps_mine == -1));
+  }
   if (a.next_key && !(a.abl & 8)) {
     const unsigned long long wk = wave_min_u64_uniform(my_key);
     if (lane == 0) sm_k[wave] = wk;
@@ -1035,7 +1046,8 @@ struct FusedStep {
   const int32_t* input_pos;
   unsigned long long* next_key;
   int g, w;
-  int policy;  // 1 = heavy hitter, 2 = recent_global / full
+  int policy;  // 1 = heavy hitter, 2 = recent_global / full, 3 = random
+  const float* rand_next;
 };
 }  // namespace
 
@@ -1086,7 +1098,7 @@ static int attn_impl(const void* q, const void* k, const void* v, const uint8_t*
   ca.S = S; ca.R = R; ca.D = D; ca.n_split = p.n_split; ca.chunk = p.chunk;
   if (fs) {
     ca.next_key = fs->next_key; ca.input_pos = fs->input_pos; ca.pos = fs->c->pos; ca.H = H; ca.g = fs->g; ca.w = fs->w;
-    ca.policy = fs->policy; ca.Hp = fs->c->Hp;
+    ca.policy = fs->policy; ca.Hp = fs->c->Hp; ca.rand_next = fs->rand_next;
   }
   ca.abl = (phases >> 8) & 0xff;
   dim3 grid(p.n_chunks, H), block(kCombThreads);
@@ -1126,7 +1138,7 @@ int cc_decode_step_heavy_hitter_phases(const cc_kv_view* c, const void* q, const
   if (!cc_view_ok(c) || !q || !k_new || !v_new || !input_pos || !num || !denom || !next_key || !y || c->Hp != c->H ||
       HQ <= 0 || HQ % c->H)
     return CC_ERR_BAD_ARG;
-  FusedStep fs{c, k_new, v_new, input_pos, reinterpret_cast<unsigned long long*>(next_key), global_tokens, recent_window, 1};
+  FusedStep fs{c, k_new, v_new, input_pos, reinterpret_cast<unsigned long long*>(next_key), global_tokens, recent_window, 1, nullptr};
   return attn_impl(q, c->k_cache, c->v_cache, c->mask, HQ, c->H, c->S, c->D, c->dtype, scale, y, attn_out, nullptr, num, denom,
                    counter, workspace, workspace_bytes, stream, phases, &fs);
 }
@@ -1137,7 +1149,18 @@ int cc_decode_step_recent_global(const cc_kv_view* c, const void* q, const void*
   if (!cc_view_ok(c) || !q || !k_new || !v_new || !input_pos || !next_key || !y || c->Hp != 1 || HQ <= 0 || HQ % c->H ||
       global_tokens < 0 || global_tokens >= c->S)
     return CC_ERR_BAD_ARG;
-  FusedStep fs{c, k_new, v_new, input_pos, reinterpret_cast<unsigned long long*>(next_key), global_tokens, 0, 2};
+  FusedStep fs{c, k_new, v_new, input_pos, reinterpret_cast<unsigned long long*>(next_key), global_tokens, 0, 2, nullptr};
+  return attn_impl(q, c->k_cache, c->v_cache, c->mask, HQ, c->H, c->S, c->D, c->dtype, scale, y, nullptr, nullptr, nullptr, nullptr,
+                   nullptr, workspace, workspace_bytes, stream, 3, &fs);
+}
+
+int cc_decode_step_random(const cc_kv_view* c, const void* q, const void* k_new, const void* v_new, const int32_t* input_pos,
+                          const float* rand_next, uint64_t* next_key, int32_t global_tokens, int32_t recent_window, int32_t HQ,
+                          float scale, void* y, void* workspace, size_t workspace_bytes, cc_stream_t stream) {
+  if (!cc_view_ok(c) || !q || !k_new || !v_new || !input_pos || !rand_next || !next_key || !y || c->Hp != 1 || HQ <= 0 ||
+      HQ % c->H || global_tokens < 0)
+    return CC_ERR_BAD_ARG;
+  FusedStep fs{c, k_new, v_new, input_pos, reinterpret_cast<unsigned long long*>(next_key), global_tokens, recent_window, 3, rand_next};
   return attn_impl(q, c->k_cache, c->v_cache, c->mask, HQ, c->H, c->S, c->D, c->dtype, scale, y, nullptr, nullptr, nullptr, nullptr,
                    nullptr, workspace, workspace_bytes, stream, 3, &fs);
 }

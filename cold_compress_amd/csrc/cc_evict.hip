@@ -407,6 +407,18 @@ int cc_rg_next_key_init(const cc_kv_view* c, const int32_t* input_pos, int32_t g
   return launch_update<P_RECENT_GLOBAL>(c, a, (hipStream_t)stream);
 }
 
+int cc_random_next_key_init(const cc_kv_view* c, const int32_t* input_pos, const float* rand_u, int32_t g, int32_t w,
+                            uint64_t* next_key, cc_stream_t stream) {
+  CC_ENTRY();
+  if (!cc_view_ok(c) || !input_pos || !rand_u || !next_key || c->Hp != 1 || g < 0) return CC_ERR_BAD_ARG;
+  UpdArgs a{};
+  a.input_pos = input_pos; a.g = g; a.w = w;
+  a.scores = rand_u; a.score_heads = 1;
+  a.key_out = reinterpret_cast<unsigned long long*>(next_key);
+  a.nk = cc_next_key_slots(c->S);
+  return launch_update<P_RANDOM>(c, a, (hipStream_t)stream);
+}
+
 int cc_hh_update(double* num, int32_t* denom, int64_t* counter, const void* attn, int32_t H, int32_t S, int32_t T,
                  int32_t dtype, cc_stream_t stream) {
   CC_ENTRY();

@@ -191,6 +191,16 @@ int cc_rg_next_key_init(const cc_kv_view* c, const int32_t* input_pos, int32_t g
 int cc_decode_step_recent_global(const cc_kv_view* c, const void* q, const void* k_new, const void* v_new,
                                  const int32_t* input_pos, uint64_t* next_key, int32_t global_tokens, int32_t HQ,
                                  float scale, void* y, void* workspace, size_t workspace_bytes, cc_stream_t stream);
+/* The same two-launch step for KVCacheRandom (cache.py:505-524: uniform scores, the `recent_window` newest positions
+ * -> +inf, then the base rules cache.py:373-376).  `rand_u` / `rand_next`: float32 [S] uniform draws — the init call takes
+ * the draw for position *input_pos, every step the draw for position *input_pos + 1 (the reference draws one vector
+ * per step, cache.py:521; the order of draws is unchanged).  c->Hp must be 1; next_key: uint64 [1, NK]. */
+int cc_random_next_key_init(const cc_kv_view* c, const int32_t* input_pos, const float* rand_u, int32_t global_tokens,
+                            int32_t recent_window, uint64_t* next_key, cc_stream_t stream);
+int cc_decode_step_random(const cc_kv_view* c, const void* q, const void* k_new, const void* v_new,
+                          const int32_t* input_pos, const float* rand_next, uint64_t* next_key, int32_t global_tokens,
+                          int32_t recent_window, int32_t HQ, float scale, void* y, void* workspace,
+                          size_t workspace_bytes, cc_stream_t stream);
 /* Measurement hook (cf. cc_decode_attn_gqa_phases): the same step with its two launches selectable. */
 int cc_decode_step_heavy_hitter_phases(const cc_kv_view* c, const void* q, const void* k_new, const void* v_new,
                                 const int32_t* input_pos, double* num, int32_t* denom, int64_t* counter,

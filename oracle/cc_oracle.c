@@ -1027,6 +1027,51 @@ int cc_decode_step_heavy_hitter_cpu(const cc_kv_view* c, const void* q, const vo
   return CC_OK;
 }
 
+/* KVCacheRandom in the same pipeline (ref: cache.py:505-524 + :373-376): the key of the slot the reference's arg-min picks
+ * for position p, from the uniform draw for that position. */
+static uint64_t random_key(const cc_kv_view* c, const float* rand_u, int32_t p, int32_t g, int32_t w) {
+  uint64_t best = ~(uint64_t)0;
+  for (int s = 0; s < c->S; s++) {
+    const int32_t ps = c->pos[s];
+    float v = (ps >= p - w) ? INFINITY : rand_u[s]; /* :523 */
+    if (s < g) v = INFINITY;                        /* :374 */
+    if (ps == -1) v = -INFINITY;                    /* :376 */
+    const uint64_t key = ((uint64_t)orderable_f32_host(v) << 32) | ((uint64_t)(uint32_t)s << 1) | (uint64_t)(ps == -1);
+    if (key < best) best = key;
+  }
+  return best;
+}
+
+int cc_random_next_key_init_cpu(const cc_kv_view* c, const int32_t* input_pos, const float* rand_u, int32_t g, int32_t w,
+                                uint64_t* next_key, cc_stream_t stream) {
+  (void)stream;
+  if (!view_ok(c) || !input_pos || !rand_u || !next_key || c->Hp != 1 || g < 0) return CC_ERR_BAD_ARG;
+  const int nk = cc_hh_next_key_slots_cpu(c->S);
+  for (int i = 1; i < nk; i++) next_key[i] = ~(uint64_t)0;
+  next_key[0] = random_key(c, rand_u, *input_pos, g, w);
+  return CC_OK;
+}
+
+int cc_decode_step_random_cpu(const cc_kv_view* c, const void* q, const void* k_new, const void* v_new, const int32_t* input_pos,
+                              const float* rand_next, uint64_t* next_key, int32_t g, int32_t w, int32_t HQ, float scale, void* y,
+                              void* workspace, size_t workspace_bytes, cc_stream_t stream) {
+  if (!view_ok(c) || !q || !k_new || !v_new || !input_pos || !rand_next || !next_key || !y || c->Hp != 1 || g < 0)
+    return CC_ERR_BAD_ARG;
+  const int nk = cc_hh_next_key_slots_cpu(c->S);
+  uint64_t key = ~(uint64_t)0;
+  for (int i = 0; i < nk; i++)
+    if (next_key[i] < key) key = next_key[i];
+  if (key == ~(uint64_t)0) return CC_ERR_BAD_ARG;
+  int64_t idx = (int64_t)((key & 0xffffffffu) >> 1);
+  insert_token(c, k_new, v_new, *input_pos, &idx);
+  int rc = cc_decode_attn_gqa_cpu(q, c->k_cache, c->v_cache, c->mask, HQ, c->H, c->S, c->D, c->dtype, scale, y, NULL, NULL, NULL,
+                                  NULL, NULL, workspace, workspace_bytes, stream);
+  if (rc != CC_OK) return rc;
+  for (int i = 1; i < nk; i++) next_key[i] = ~(uint64_t)0;
+  next_key[0] = random_key(c, rand_next, *input_pos + 1, g, w);
+  return CC_OK;
+}
+
 /* Measurement hook twin: the oracle has no launches to select; only phases == 3 (the whole step) is meaningful. */
 int cc_decode_step_heavy_hitter_phases_cpu(const cc_kv_view* c, const void* q, const void* k_new, const void* v_new,
                                            const int32_t* input_pos, double* num, int32_t* denom, int64_t* counter,

@@ -130,3 +130,76 @@ def test_ring_fused_step_equals_three_calls(strategy, dtype, H, HQ, S, D, T):
         for (na, ta), (nb, tb) in zip(a.named_buffers(), b.named_buffers()):
             if na != "next_key":
                 assert torch.equal(ta, tb), f"step {t}: {na}"
+
+
+@pytest.mark.parametrize("dtype,H,HQ,S,D,T,g,w", [(torch.bfloat16, 8, 32, 4096, 128, 4090, 4, 10), (torch.float32, 2, 4, 77, 16, 70, 2, 3),
+                                                  (torch.float16, 4, 16, 600, 128, 600, 0, 1)])
+def test_random_fused_step_equals_three_calls(dtype, H, HQ, S, D, T, g, w):
+    """KVCacheRandom: the two-launch step (cc_decode_step_random, the draw for p + 1 scored in step p) against
+    update_kv -> attention on the same sequence of uniform draws; every buffer bit for bit."""
+    import cold_compress_amd.cache as cache
+    from cold_compress_amd.attention_utils import scaled_dot_product_attention as sdpa
+
+    cls, rk = cache.get_cache_constructor("random")
+    kw = dict(max_cache_length=S, global_tokens=g, recent_window=w, max_seq_length=4 * S, cache_bits=None)
+
+    def mk():
+        with torch.device(DEV):
+            return cls(1, H, D, dtype, **{k: kw[k] for k in rk})
+
+    a, b = mk(), mk()
+    gen = torch.Generator().manual_seed(12)
+    steps = 12
+    draws = [torch.rand(S, generator=gen).to(DEV) for _ in range(steps + 1)]
+    ia, ib = iter(draws), iter(draws)
+    a._rand = lambda: next(ia)
+    b._rand = lambda: next(ib)
+    k0 = torch.randn(1, H, T, D, generator=gen).to(dtype).to(DEV)
+    v0 = torch.randn(1, H, T, D, generator=gen).to(dtype).to(DEV)
+    for kv in (a, b):
+        kv.update_kv(torch.arange(T, device=DEV), k0, v0, True)
+    for t in range(steps):
+        p = torch.tensor([T + t], dtype=torch.int32, device=DEV)
+        k1 = torch.randn(1, H, 1, D, generator=gen).to(dtype).to(DEV)
+        v1 = torch.randn(1, H, 1, D, generator=gen).to(dtype).to(DEV)
+        q = torch.randn(1, HQ, 1, D, generator=gen).to(dtype).to(DEV)
+        ka, va, ma = a.update_kv(p, k1, v1, False)
+        ya, _ = sdpa(q, ka, va, attn_mask=ma)
+        yb = b.decode_step(q, k1, v1, p)
+        torch.cuda.synchronize()
+        assert torch.equal(ya, yb), f"step {t}: attention output"
+        for (na, ta), (nb, tb) in zip(a.named_buffers(), b.named_buffers()):
+            if na != "next_key":
+                assert torch.equal(ta, tb), f"step {t}: {na}"
+
+
+def test_random_fused_replay_vs_reference():
+    """The reference's own random-policy trace (tests/golden/f4_random.npz: its draws, its evicted slots, its final
+    buffers) replayed through the two-launch step."""
+    import cold_compress_amd.cache as cache
+    from helpers import DT_FROM_NAME, load_golden
+
+    f = load_golden("f4_random.npz")
+    dtype = DT_FROM_NAME[f["dtype"]]
+    H, S, D, T, g, w = f["H"], f["S"], f["D"], f["T_prefill"], f["g"], f["w"]
+    cls, rk = cache.get_cache_constructor("random")
+    kw = dict(max_cache_length=S, global_tokens=g, recent_window=w, max_seq_length=4 * S, cache_bits=None)
+    with torch.device(DEV):
+        kv = cls(1, H, D, dtype, **{k: kw[k] for k in rk})
+    steps = f["steps"]
+    draws = iter([f["rand_u"][t].to(DEV) for t in range(steps)] + [torch.zeros(S, device=DEV)])
+    kv._rand = lambda: next(draws)
+    kv.update_kv(torch.arange(T, device=DEV), f["k0"].to(DEV), f["v0"].to(DEV), True)
+    gen = torch.Generator().manual_seed(3)
+    for t in range(steps):
+        before = kv.pos.clone()
+        q = torch.randn(1, H, 1, D, generator=gen).to(dtype).to(DEV)
+        kv.decode_step(q, f["k_new"][t].to(DEV), f["v_new"][t].to(DEV), torch.tensor([T + t], dtype=torch.int32, device=DEV))
+        changed = (kv.pos != before).reshape(-1).nonzero().reshape(-1).cpu().numpy()
+        assert np.array_equal(changed, f["idx"][t].numpy().reshape(-1)), f"step {t}: evicted slot"
+    torch.cuda.synchronize()
+    assert torch.equal(kv.pos.cpu(), f["final_pos"])
+    assert torch.equal(kv.mask.cpu(), f["final_mask"])
+    assert torch.equal(kv.cache_cts.cpu(), f["final_cts"])
+    assert torch.equal(kv.k_cache.cpu().view(torch.int16), f["final_k"].view(torch.int16))
+    assert torch.equal(kv.v_cache.cpu().view(torch.int16), f["final_v"].view(torch.int16))
