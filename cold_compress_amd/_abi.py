@@ -91,10 +91,12 @@ SIGNATURES = {
                                         _vp, _vp, _sz, _vp]),
     "cc_attn_colsum": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "cc_colsum_to_mean": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
-    "cc_hybrid_decode_update": (C.c_int, [_view, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp,
-                                          _i32, _i32, _vp, _vp, _vp]),
-    "cc_decode_update_heavy_hitter_ring": (C.c_int, [_view, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
-    "cc_hh_ring_update": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "cc_hybrid_decode_update": (C.c_int, [_view, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32,
+                                          _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "cc_decode_update_heavy_hitter_ring": (C.c_int, [_view, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "cc_hh_ring_update": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "cc_hh_ring_acc_words": (_sz, [_i32, _i32, _i32, _i32]),
+    "cc_hh_ring_window_sums": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "cc_attn_bandsum": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "cc_add_rmsnorm": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _f32, _i32, _vp, _vp, _vp]),
     "cc_qkv_rope": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),

@@ -404,7 +404,39 @@ class KVCacheL2(KVCacheHeadSpecific):
                       _DT[self.k_cache.dtype], 0, _ptr(self.key_norm), _stream())
 
 
-class KVCacheHeavyHitter(KVCacheHeadSpecific):
+class _TrackedWindowSums:
+    """Exact window sums of the [H, S, W] attention-history ring, kept incrementally on the device (cc_hh_ring_update
+    with tracked state; see include/coldcompress.h) instead of re-reading the whole ring on every decode step.  The
+    kernels write through raw pointers, so torch's tensor version counter moves only when torch-side code touches the
+    ring (reset, load_state_dict, a test poking values): that is the signal to rebuild the state from the ring."""
+
+    def _init_window_state(self):
+        H, S = self.n_heads, self.max_cache_length
+        words = int(_abi.lib()["cc_hh_ring_acc_words"](H, S, int(self.history_window_size), _DT[self.attn_history_num.dtype]))
+        self.register_buffer("attn_window_acc", torch.zeros(words, dtype=torch.int64), persistent=False)
+        self.register_buffer("attn_window_sum", torch.zeros((H, S), dtype=torch.float32), persistent=False)
+        self._ring_version = None
+
+    def _ring_tag(self):
+        r = self.attn_history_num
+        return (r._version, r.data_ptr(), self.attn_window_acc.data_ptr())
+
+    def _zero_window_state(self):
+        self.attn_window_acc.zero_()
+        self.attn_window_sum.zero_()
+        self._ring_version = self._ring_tag()
+
+    def _window_state(self):
+        """-> (wsum, acc), current for the ring."""
+        if self._ring_tag() != self._ring_version:
+            _abi.call("cc_hh_ring_window_sums", _ptr(self.attn_history_num), self.n_heads, self.max_cache_length,
+                      int(self.history_window_size), _DT[self.attn_history_num.dtype], _ptr(self.attn_window_sum),
+                      _ptr(self.attn_window_acc), _stream())
+            self._ring_version = self._ring_tag()
+        return self.attn_window_sum, self.attn_window_acc
+
+
+class KVCacheHeavyHitter(_TrackedWindowSums, KVCacheHeadSpecific):
     """ref: cache.py:615-765 (ScissorHands / H2O style accumulated attention), history_window_size == 1."""
     relevant_kwargs = ["max_cache_length", "max_seq_length", "cache_bits", "global_tokens", "history_window_size",
                        "recent_window", "attn_thresholding"]
@@ -426,6 +458,8 @@ class KVCacheHeavyHitter(KVCacheHeadSpecific):
         nk = int(_abi.lib()["cc_hh_next_key_slots"](S))
         self.register_buffer("next_key", torch.full((n_heads, nk), -1, dtype=torch.int64), persistent=False)
         self._next_valid = False
+        if W > 1:
+            self._init_window_state()
 
     def reset(self):
         super().reset()
@@ -433,6 +467,8 @@ class KVCacheHeavyHitter(KVCacheHeadSpecific):
         self.attn_history_denom.zero_()
         self.attn_counter.zero_()
         self._next_valid = False
+        if self.history_window_size > 1:
+            self._zero_window_state()
 
     def return_attn(self) -> bool:
         return True
@@ -485,13 +521,10 @@ class KVCacheHeavyHitter(KVCacheHeadSpecific):
                       _ptr(self.attn_history_num), _ptr(self.attn_history_denom), int(self.global_tokens),
                       int(self.recent_window), _ptr(self._idx_buf()), _stream())
         else:
+            wsum, acc = self._window_state()
             _abi.call("cc_decode_update_heavy_hitter_ring", self._view(), _ptr(k), _ptr(v), _ptr(self._pos32(input_pos)),
                       _ptr(self.attn_history_num), _ptr(self.attn_history_denom), int(self.history_window_size),
-                      int(self.global_tokens), int(self.recent_window), _ptr(self._idx_buf()), _ptr(self._wsum_buf()), _stream())
-
-    def _wsum_buf(self):
-        """fp32 [H, S] scratch for the ring window sums (chip-wide pre-pass of the W > 1 policies)."""
-        return self._scratch.get("wsum", (self.n_heads, self.max_cache_length), torch.float32, self.k_cache.device)
+                      int(self.global_tokens), int(self.recent_window), _ptr(self._idx_buf()), _ptr(wsum), _ptr(acc), _stream())
 
     def fused_history(self):
         """Pointers the decode attention kernel needs to fold cache.py:690-723 into its combine pass (W == 1 only)."""
@@ -504,9 +537,10 @@ class KVCacheHeavyHitter(KVCacheHeadSpecific):
             _abi.call("cc_hh_update", _ptr(self.attn_history_num), _ptr(self.attn_history_denom), _ptr(self.attn_counter),
                       _ptr(attn_hs), self.n_heads, self.max_cache_length, T, _DT[self.k_cache.dtype], _stream())
         else:
+            wsum, acc = self._window_state()
             _abi.call("cc_hh_ring_update", _ptr(self.attn_history_num), _ptr(self.attn_history_denom), _ptr(self.attn_counter),
                       _ptr(attn_hs), self.n_heads, self.max_cache_length, T, int(self.history_window_size),
-                      _DT[self.k_cache.dtype], _stream())
+                      _DT[self.k_cache.dtype], _ptr(acc), _ptr(wsum), _stream())
 
     def update_state(self, input_pos, k_val, v_val, is_prefill, attn, **kwargs):
         """ref: cache.py:690-723."""
@@ -539,7 +573,7 @@ class KVCacheHeavyHitter(KVCacheHeadSpecific):
 _HF = {"heavy_hitter": 1, "window": 2, "punc": 4, "special": 8}
 
 
-class KVCacheHybrid(KVCacheHeadSpecific):
+class KVCacheHybrid(_TrackedWindowSums, KVCacheHeadSpecific):
     """FastGen-style per-head policies (ref: cache.py:768-1288): at prefill every head is profiled against the
     ordered list `hybrid_strategies` and takes the FIRST policy that recovers `min_recovery_frac` of its attention
     mass; at decode each head appends or evicts according to its own policy (one launch for all heads; the
@@ -588,6 +622,7 @@ class KVCacheHybrid(KVCacheHeadSpecific):
         self.requires_heavy_hitter = self._init_requires_heavy_hitter()
         self.cache_strategies = None
         self._table = None
+        self._init_window_state()
 
     # ------------------------------------------------------------------ small helpers
     def _init_requires_heavy_hitter(self):
@@ -616,6 +651,7 @@ class KVCacheHybrid(KVCacheHeadSpecific):
         self.attn_history_num.zero_()
         self.attn_history_denom.zero_()
         self.attn_counter.zero_()
+        self._zero_window_state()
         self.cache_strategies = None
         self.requires_heavy_hitter = self._init_requires_heavy_hitter()
         if hasattr(self, "special_mask"):
@@ -646,28 +682,27 @@ class KVCacheHybrid(KVCacheHeadSpecific):
         if self.cache_strategies is None:
             raise ColdCompressError("hybrid cache used before prefill profiling (update_state with is_prefill=True)")
         k, v = self._new_rows(k_val, v_val)
-        is_punc = None
-        if hasattr(self, "punc_ids"):
+        tok = pids = None
+        if hasattr(self, "punc_ids"):  # ref: cache.py:975 torch.isin(input_ids, punc_ids) — evaluated inside the launch
             ids = kwargs.get("input_ids")
-            # one token against a handful of ids: a compare + any, not torch.isin (which sorts: ~6 launches per step)
-            is_punc = (ids.to(self.punc_ids.device).reshape(-1)[:1].unsqueeze(1) == self.punc_ids.reshape(1, -1)).any(dim=1) \
-                .to(torch.uint8).contiguous()
-        self._is_punc = is_punc
+            tok = ids.to(device=self.punc_ids.device, dtype=torch.int64).reshape(-1)[:1].contiguous()
+            pids = self.punc_ids
         tab = self._policy_table()
+        wsum, acc = self._window_state()
         _abi.call("cc_hybrid_decode_update", self._view(), _ptr(k), _ptr(v), _ptr(self._pos32(input_pos)),
                   _ptr(self.cache_strategies), _ptr(tab), tab.shape[0], _ptr(self.attn_history_num),
                   _ptr(self.attn_history_denom), self.history_window_size, _ptr(getattr(self, "special_mask", None)),
-                  _ptr(getattr(self, "punc_mask", None)), _ptr(is_punc), _ptr(getattr(self, "num_special", None)),
+                  _ptr(getattr(self, "punc_mask", None)), None, _ptr(tok), _ptr(pids), 0 if pids is None else pids.numel(),
+                  _ptr(getattr(self, "num_special", None)),
                   _ptr(getattr(self, "num_punc", None)), int(self.global_tokens),
                   int(bool(self.requires_heavy_hitter and self.reset_history_on_evict)),
-                  _ptr(self._idx_buf()),
-                  _ptr(self._scratch.get("wsum", (self.n_heads, self.max_cache_length), torch.float32, self.k_cache.device)),
-                  _stream())
+                  _ptr(self._idx_buf()), _ptr(wsum), _ptr(acc), _stream())
 
     def _ring_update(self, attn_ht, T):
+        wsum, acc = self._window_state()
         _abi.call("cc_hh_ring_update", _ptr(self.attn_history_num), _ptr(self.attn_history_denom), _ptr(self.attn_counter),
                   _ptr(attn_ht), self.n_heads, self.max_cache_length, T, self.history_window_size,
-                  _DT[self.k_cache.dtype], _stream())
+                  _DT[self.k_cache.dtype], _ptr(acc), _ptr(wsum), _stream())
 
     def update_state(self, input_pos, k_val, v_val, is_prefill, attn, **kwargs):
         """ref: cache.py:1274-1288."""

@@ -9,6 +9,7 @@
 namespace {
 
 enum { F_HH = 1, F_WIN = 2, F_PUNC = 4, F_SPECIAL = 8, F_FULL = 16 };
+typedef unsigned long long u64;
 
 struct HybArgs {
   void* k_cache;
@@ -27,22 +28,126 @@ struct HybArgs {
   const uint8_t* special_mask;  // [H,S] or null
   uint8_t* punc_mask;           // [H,S] or null
   const uint8_t* is_punc;       // device bool[1] or null
+  const int64_t* token_id;      // device int64[1] + punc_ids[n_punc_ids]: the same test evaluated here (is_punc == null)
+  const int64_t* punc_ids;
+  int n_punc_ids;
+  unsigned int* punc_ticket;    // tracked state: num_punc is bumped by the last head to have read it (null: separate launch)
   const int32_t* num_special;   // device int[1] or null
   int32_t* num_punc;            // device int[1] or null
   int requires_hh;
   int64_t* fill_out;  // [H]
-  const float* wsum;  // [H,S] window sums from the pre-pass
+  float* wsum;        // [H,S] window sums: from the pre-pass, or the tracked state kept by cc_hh_ring_update
+  u64* wacc;          // [H,S,4] tracked exact accumulators or null (stateless: pre-pass every call)
 };
 
 // dtype(sum of the W history entries of one cache slot) (cache.py:855-859 `.sum(dim=-1)` on a model-dtype tensor;
-// torch's own fp32 order is unspecified).  Canonical order, shared with the oracle: ONE WAVE per cache slot — the
-// row is cut into 16-byte chunks, lane l accumulates chunks l, l+64, ... element by element in index order, the 64
-// partials meet in an xor butterfly (32 .. 1), the total is rounded to the model dtype.  A 400-entry bf16 ring row
-// is 800 contiguous bytes: one fully coalesced load instruction per slot.
+// torch's own fp32 summation order is unspecified and backend-specific).  Definition used here and in the oracle:
+// the EXACT sum of the W entries, rounded once (nearest-even) to the model dtype.  Exactness makes the value
+// independent of summation order, which is what lets the ring policies keep it INCREMENTALLY (sum += new - old when
+// one ring column is overwritten) instead of re-reading the [H, S, W] ring — 118 MB per layer per step at S = 18432,
+// W = 400 — on every decode step.
+//
+// WAcc: 192-bit two's-complement fixed point in units of 2^-149 (the fp32 subnormal quantum; every bf16 / f16 / fp32
+// value is an integer multiple of it) + a count of entries that do not fit: |v| >= 4 or non-finite (attention
+// probabilities are <= 1; the window sum of a row holding such an entry is NaN).  192 bits hold 2^40 entries < 4.
+struct WAcc {
+  u64 w0, w1, w2, special;
+};
+
+__device__ __forceinline__ void wacc_add_words(WAcc& a, u64 b0, u64 b1, u64 b2) {
+  const u64 r0 = a.w0 + b0;
+  const u64 c0 = r0 < b0;
+  const u64 t = a.w1 + b1;
+  u64 c1 = t < b1;
+  const u64 r1 = t + c0;
+  c1 |= (u64)(r1 < t);
+  a.w0 = r0;
+  a.w1 = r1;
+  a.w2 = a.w2 + b2 + c1;
+}
+__device__ __forceinline__ void wacc_merge(WAcc& a, const WAcc& b) {
+  wacc_add_words(a, b.w0, b.w1, b.w2);
+  a.special += b.special;
+}
+// a += v (remove == false) or a -= v (remove == true), exactly
+__device__ __forceinline__ void wacc_add_value(WAcc& a, float v, bool remove) {
+  const uint32_t u = __float_as_uint(v);
+  const uint32_t E = (u >> 23) & 0xffu, M = u & 0x7fffffu;
+  if ((u << 1) == 0) return;
+  if (E >= 129) {  // |v| >= 4, inf, nan
+    a.special += remove ? ~0ull : 1ull;
+    return;
+  }
+  const u64 m = E ? (u64)(M | 0x800000u) : (u64)M;  // v = m * 2^(sh - 149)
+  const int sh = E ? (int)E - 1 : 0;
+  const int word = sh >> 6, bit = sh & 63;
+  const u64 lo = m << bit;
+  const u64 hi = bit > 40 ? m >> (64 - bit) : 0ull;
+  u64 b0 = word == 0 ? lo : 0ull, b1 = word == 0 ? hi : lo, b2 = word == 0 ? 0ull : hi;
+  if (((u >> 31) != 0) != remove) {  // subtract: two's complement of the 192-bit magnitude
+    b0 = ~b0 + 1ull;
+    const u64 k0 = b0 == 0;
+    b1 = ~b1 + k0;
+    const u64 k1 = k0 && b1 == 0;
+    b2 = ~b2 + k1;
+  }
+  wacc_add_words(a, b0, b1, b2);
+}
+// the exact value of the accumulator, rounded once to T (nearest-even), returned as a float
 template <typename T>
-__device__ __forceinline__ float wave_window_sum(const T* row, int W, int lane) {
+__device__ __forceinline__ float wacc_round(const WAcc& a) {
+  if (a.special != 0) return NAN;
+  u64 m0 = a.w0, m1 = a.w1, m2 = a.w2;
+  const bool neg = (long long)m2 < 0;
+  if (neg) {
+    m0 = ~m0 + 1ull;
+    const u64 k0 = m0 == 0;
+    m1 = ~m1 + k0;
+    const u64 k1 = k0 && m1 == 0;
+    m2 = ~m2 + k1;
+  }
+  if ((m0 | m1 | m2) == 0) return 0.f;
+  const int P = m2 ? 191 - __clzll((long long)m2) : (m1 ? 127 - __clzll((long long)m1) : 63 - __clzll((long long)m0));
+  uint32_t bits;
+  if (P < 24) {
+    bits = (uint32_t)m0;  // below 2^-125: the accumulator IS the fp32 encoding (subnormal or first binade), nothing to round
+  } else {
+    // 64-bit window whose top bit is bit P; sticky = any set bit below the window
+    u64 hi, sticky;
+    if (P < 63) {
+      hi = m0 << (63 - P);
+      sticky = 0;
+    } else {
+      const int lb = P - 63, wi = lb >> 6, b = lb & 63;
+      const u64 x0 = wi == 0 ? m0 : (wi == 1 ? m1 : m2);
+      const u64 x1 = wi == 0 ? m1 : (wi == 1 ? m2 : 0ull);
+      hi = b ? (x0 >> b) | (x1 << (64 - b)) : x0;
+      sticky = (b ? (x0 & ((1ull << b) - 1ull)) : 0ull) | (wi >= 1 ? m0 : 0ull) | (wi >= 2 ? m1 : 0ull);
+    }
+    u64 mant = hi >> 40;  // 24 bits, leading one included
+    const u64 rem = hi & ((1ull << 40) - 1ull);
+    int Pe = P;
+    if (sizeof(T) == 4) {  // the target IS fp32: nearest-even here
+      const u64 half = 1ull << 39;
+      if (rem > half || (rem == half && (sticky != 0 || (mant & 1ull)))) mant += 1;
+      if (mant == (1ull << 24)) {
+        mant >>= 1;
+        Pe += 1;
+      }
+    } else {  // 16-bit target: round to odd at 24 bits, then the dtype's own nearest-even is exact (>= 13 spare bits)
+      mant |= (u64)((rem | sticky) != 0);
+    }
+    bits = ((uint32_t)(Pe - 22) << 23) | ((uint32_t)mant & 0x7fffffu);
+  }
+  const float f = __uint_as_float(bits | (neg ? 0x80000000u : 0u));
+  return ElemTraits<T>::rnd(f);
+}
+
+// exact sum of one ring row, one wave per row: 16-byte chunks strided over the lanes, integer butterfly
+template <typename T>
+__device__ __forceinline__ WAcc wave_window_acc(const T* row, int W, int lane) {
   constexpr int VEC = 16 / (int)sizeof(T);
-  float acc = 0.f;
+  WAcc acc{0, 0, 0, 0};
   const bool aligned = (reinterpret_cast<uintptr_t>(row) & 15) == 0;
   for (int c = lane; c * VEC < W; c += 64) {
     if (aligned && c * VEC + VEC <= W) {
@@ -51,14 +156,21 @@ __device__ __forceinline__ float wave_window_sum(const T* row, int W, int lane) 
       v.load(row + (size_t)c * VEC);
       v.unpack(f);
 #pragma unroll
-      for (int e = 0; e < VEC; e++) acc = __fadd_rn(acc, f[e]);
+      for (int e = 0; e < VEC; e++) wacc_add_value(acc, f[e], false);
     } else {
-      for (int e = 0; e < VEC && c * VEC + e < W; e++) acc = __fadd_rn(acc, ElemTraits<T>::load(row, (size_t)c * VEC + e));
+      for (int e = 0; e < VEC && c * VEC + e < W; e++) wacc_add_value(acc, ElemTraits<T>::load(row, (size_t)c * VEC + e), false);
     }
   }
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) acc = __fadd_rn(acc, __shfl_xor(acc, off, CC_WAVE));
-  return ElemTraits<T>::rnd(acc);
+  for (int off = 32; off > 0; off >>= 1) {
+    WAcc o;
+    o.w0 = __shfl_xor(acc.w0, off, CC_WAVE);
+    o.w1 = __shfl_xor(acc.w1, off, CC_WAVE);
+    o.w2 = __shfl_xor(acc.w2, off, CC_WAVE);
+    o.special = __shfl_xor(acc.special, off, CC_WAVE);
+    wacc_merge(acc, o);
+  }
+  return acc;
 }
 
 // Pre-pass of the ring policies: wsum[h, s] for every slot of every head that scores by accumulated attention.
@@ -67,14 +179,24 @@ __device__ __forceinline__ float wave_window_sum(const T* row, int W, int lane) 
 // slot.  (The first version summed rows inside the one-workgroup-per-head kernel: 8 CUs, 800-byte strides, 1.4 ms.)
 template <typename T>
 __global__ __launch_bounds__(256) void ring_window_sum_kernel(const T* num, const int64_t* strategies, const int32_t* table, int H,
-                                                              int S, int W, float* out) {
+                                                              int S, int W, float* out, u64* acc_out) {
   const int lane = threadIdx.x & 63;
   const size_t total = (size_t)H * S;
   const size_t nw = (size_t)gridDim.x * (blockDim.x >> 6);
+  if (acc_out && blockIdx.x == 0 && threadIdx.x < 2) acc_out[total * 4 + threadIdx.x] = 0;  // launch ticket of the tracked update (+ pad)
   for (size_t i = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); i < total; i += nw) {
     if (strategies != nullptr && !(table[strategies[i / S] * 3] & 1 /* F_HH */)) continue;
-    const float v = wave_window_sum<T>(num + i * (size_t)W, W, lane);
-    if (lane == 0) out[i] = v;
+    const WAcc a = wave_window_acc<T>(num + i * (size_t)W, W, lane);
+    if (acc_out) {  // column-major shadow of the ring, behind the accumulators and the ticket word
+      T* shadow = reinterpret_cast<T*>(acc_out + total * 4 + 2);
+      for (int j = lane; j < W; j += 64) shadow[(size_t)j * total + i] = num[i * (size_t)W + j];
+    }
+    if (lane == 0) {
+      out[i] = wacc_round<T>(a);
+      if (acc_out) {
+        acc_out[i * 4 + 0] = a.w0; acc_out[i * 4 + 1] = a.w1; acc_out[i * 4 + 2] = a.w2; acc_out[i * 4 + 3] = a.special;
+      }
+    }
   }
 }
 
@@ -88,7 +210,26 @@ __global__ __launch_bounds__(kHybThreads) void hybrid_decode_kernel(HybArgs a) {
   const int pol = (int)a.strategies[h];
   const int flags = a.table[pol * 3], win = a.table[pol * 3 + 1], hhs = a.table[pol * 3 + 2];
   const int cts = a.cache_cts[h];
-  const bool is_punc = a.is_punc ? (*a.is_punc != 0) : false;
+  // ref: cache.py:975 torch.isin(input_ids, punc_ids): given by the caller or evaluated here; num_punc is read once
+  // per head BEFORE the head takes its ticket, so the last ticket holder may bump it (ref :1017) in this launch
+  __shared__ int sm_punc[2];
+  unsigned int ptk = 0;
+  if (threadIdx.x == 0) {
+    bool f = false;
+    if (a.is_punc) {
+      f = *a.is_punc != 0;
+    } else if (a.token_id && a.punc_ids) {
+      const int64_t id = *a.token_id;
+      for (int k = 0; k < a.n_punc_ids; k++) f |= a.punc_ids[k] == id;
+    }
+    sm_punc[0] = f;
+    sm_punc[1] = a.num_punc ? *a.num_punc : 0;
+  }
+  __syncthreads();
+  const bool is_punc = sm_punc[0] != 0;
+  const int num_punc_old = sm_punc[1];
+  if (threadIdx.x == 0 && a.punc_ticket && a.num_punc)
+    ptk = __hip_atomic_fetch_add(a.punc_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const int end_idx = cts < S - 1 ? cts : S - 1;  // ref: _end_idx() :897-899
   const size_t hoff = (size_t)h * S;
 
@@ -101,7 +242,7 @@ __global__ __launch_bounds__(kHybThreads) void hybrid_decode_kernel(HybArgs a) {
   } else {
     int budget = a.g;  // :912-925
     if (flags & F_SPECIAL) budget += a.num_special ? *a.num_special : 0;
-    if (flags & F_PUNC) budget += a.num_punc ? *a.num_punc : 0;
+    if (flags & F_PUNC) budget += num_punc_old;
     if (flags & F_WIN) budget += win;
     if (flags & F_HH) budget += hhs;
     if (cts < budget) {  // :927-930
@@ -158,6 +299,13 @@ __global__ __launch_bounds__(kHybThreads) void hybrid_decode_kernel(HybArgs a) {
     T* num = reinterpret_cast<T*>(a.num) + (hoff + slot) * (size_t)W;
     for (int j = threadIdx.x; j < W; j += blockDim.x) ElemTraits<T>::store(num, j, 0.f);
     if (threadIdx.x == 0) a.denom[hoff + slot] = 0;
+    if (a.wacc) {  // tracked state of a zeroed row: sum, accumulator and the shadow column entries
+      const size_t hs = (size_t)a.H * S;
+      T* shadow = reinterpret_cast<T*>(a.wacc + hs * 4 + 2);
+      for (int j = threadIdx.x; j < W; j += blockDim.x) ElemTraits<T>::store(shadow, (size_t)j * hs + hoff + slot, 0.f);
+      if (threadIdx.x < 4) a.wacc[(hoff + slot) * 4 + threadIdx.x] = 0;
+      if (threadIdx.x == 4) a.wsum[hoff + slot] = 0.f;
+    }
   }
   if (threadIdx.x == 0) {
     if (!evict && fill >= 0) {  // :997-1001
@@ -166,6 +314,10 @@ __global__ __launch_bounds__(kHybThreads) void hybrid_decode_kernel(HybArgs a) {
     }
     a.pos[hoff + slot] = p;  // :1006-1007 _fill(update_mask=False) — every head, dropped tokens land in slot S-1
     if (is_punc && a.punc_mask) a.punc_mask[hoff + slot] = 1;  // :1011-1016
+    if (a.punc_ticket && a.num_punc && ptk == gridDim.x - 1) {
+      if (is_punc) *a.num_punc = num_punc_old + 1;  // :1017
+      __hip_atomic_store(a.punc_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
   const int words = a.D * (int)sizeof(T) / 4;
   const uint32_t* ks = reinterpret_cast<const uint32_t*>(a.k_new) + (size_t)h * words;
@@ -194,7 +346,8 @@ struct RingArgs {
   void* num;
   int32_t* denom;
   int64_t* idx_out;
-  const float* wsum;  // [H,S] window sums from the pre-pass
+  float* wsum;  // [H,S] window sums: from the pre-pass, or the tracked state kept by cc_hh_ring_update
+  u64* wacc;    // [H,S,4] tracked exact accumulators or null
 };
 
 template <typename T>
@@ -222,6 +375,13 @@ __global__ __launch_bounds__(kHybThreads) void hh_ring_decode_kernel(RingArgs a)
     a.idx_out[h] = idx;
     a.denom[hoff + idx] = 0;
   }
+  if (a.wacc) {  // tracked state of a zeroed row: sum, accumulator and the shadow column entries
+    const size_t hs = (size_t)a.H * S;
+    T* shadow = reinterpret_cast<T*>(a.wacc + hs * 4 + 2);
+    for (int j = threadIdx.x; j < W; j += blockDim.x) ElemTraits<T>::store(shadow, (size_t)j * hs + hoff + idx, 0.f);
+    if (threadIdx.x < 4) a.wacc[(hoff + idx) * 4 + threadIdx.x] = 0;
+    if (threadIdx.x == 4) a.wsum[hoff + idx] = 0.f;
+  }
   if (a.k_new == nullptr) return;
   if (threadIdx.x == 0) {
     a.pos[hoff + idx] = p;
@@ -241,8 +401,17 @@ __global__ __launch_bounds__(kHybThreads) void hh_ring_decode_kernel(RingArgs a)
 }
 
 // num_punc += 1 once per step (ref: :1017), after every head has read the old value
-__global__ void hybrid_bump_punc_kernel(const uint8_t* is_punc, int32_t* num_punc) {
-  if (threadIdx.x == 0 && blockIdx.x == 0 && *is_punc) *num_punc += 1;
+__global__ void hybrid_bump_punc_kernel(const uint8_t* is_punc, const int64_t* token_id, const int64_t* punc_ids, int n,
+                                        int32_t* num_punc) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  bool f = false;
+  if (is_punc) {
+    f = *is_punc != 0;
+  } else {
+    const int64_t id = *token_id;
+    for (int k = 0; k < n; k++) f |= punc_ids[k] == id;
+  }
+  if (f) *num_punc += 1;
 }
 
 // ref: cache.py:716-723 with W > 1: num[h,s,counter % W] = attn (zero beyond T), denom += 1, counter += 1
@@ -256,6 +425,51 @@ __global__ __launch_bounds__(256) void hh_ring_update_kernel(T* num, int32_t* de
     const float v = s < Tn ? ElemTraits<T>::load(attn, (size_t)h * Tn + s) : 0.f;
     ElemTraits<T>::store(num, (size_t)i * W + slot, v);
     denom[i] += 1;
+  }
+}
+// The same update keeping the exact window sums current: the overwritten ring entry leaves the accumulator, the new
+// one enters, the rounded sum is republished.  The entry being overwritten is read from the column-major SHADOW of the
+// ring kept inside the tracked state ([W][H*S]: the column is contiguous; the same read from the [H, S, W] ring is an
+// 800-byte-stride gather, measured +7.8 us at H*S = 147k).  Per slot: 2 B attn + 2 B shadow + 32 B accumulator in,
+// 2 B ring (strided, fire-and-forget) + 2 B shadow + 32 B + 4 B out — instead of re-reading W entries next step.
+// Counter: thread 0 of every workgroup reads it, THEN takes a ticket; the workgroup holding the last ticket knows
+// that every workgroup has read the old value and bumps it at once (the atomic's latency hides behind the slot loop).
+template <typename T>
+__global__ __launch_bounds__(1024) void hh_ring_update_tracked_kernel(T* num, int32_t* denom, int64_t* counter, const T* attn,
+                                                                      int H, int S, int Tn, int W, u64* wacc, float* wsum) {
+  __shared__ int sm_slot;
+  const int n = H * S;
+  int64_t c0 = 0;
+  if (threadIdx.x == 0) {
+    c0 = *counter;
+    sm_slot = (int)(c0 % W);
+  }
+  __syncthreads();
+  unsigned int tk = 0;
+  unsigned int* ticket = reinterpret_cast<unsigned int*>(wacc + (size_t)n * 4);
+  // the load above has returned (its value was used), so a relaxed atomic is ordered after it; nobody waits for the ticket
+  if (threadIdx.x == 0) tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int slot = sm_slot;
+  T* shadow = reinterpret_cast<T*>(wacc + (size_t)n * 4 + 2) + (size_t)slot * n;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int h = i / S, s = i - h * S;
+    const float v = s < Tn ? ElemTraits<T>::load(attn, (size_t)h * Tn + s) : 0.f;
+    const float old = ElemTraits<T>::load(shadow, i);
+    const ulonglong2 a01 = *reinterpret_cast<const ulonglong2*>(wacc + (size_t)i * 4);
+    const ulonglong2 a23 = *reinterpret_cast<const ulonglong2*>(wacc + (size_t)i * 4 + 2);
+    WAcc a{a01.x, a01.y, a23.x, a23.y};
+    ElemTraits<T>::store(num, (size_t)i * W + slot, v);
+    ElemTraits<T>::store(shadow, i, v);
+    denom[i] += 1;
+    wacc_add_value(a, ElemTraits<T>::rnd(v), false);
+    wacc_add_value(a, old, true);
+    *reinterpret_cast<ulonglong2*>(wacc + (size_t)i * 4) = make_ulonglong2(a.w0, a.w1);
+    *reinterpret_cast<ulonglong2*>(wacc + (size_t)i * 4 + 2) = make_ulonglong2(a.w2, a.special);
+    wsum[i] = wacc_round<T>(a);
+  }
+  if (threadIdx.x == 0 && tk == gridDim.x - 1) {  // every workgroup has read the old counter: bump it, re-arm the ticket
+    *counter = c0 + 1;
+    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 __global__ void bump_counter_kernel(int64_t* counter) {
@@ -276,15 +490,15 @@ __global__ __launch_bounds__(256) void attn_bandsum_kernel(const T* attn, int H,
 }
 
 static void launch_window_sums(const void* num, const int64_t* strategies, const int32_t* table, int H, int S, int W, int dtype,
-                               float* out, hipStream_t st) {
+                               float* out, u64* acc_out, hipStream_t st) {
   const size_t slots = (size_t)H * S;
   size_t nb = (slots + 3) / 4;  // 4 waves per workgroup, one slot per wave per iteration
   if (nb > 4096) nb = 4096;
   dim3 grid((unsigned)nb), block(256);
   switch (dtype) {
-    case CC_DT_F32: hipLaunchKernelGGL(ring_window_sum_kernel<float>, grid, block, 0, st, (const float*)num, strategies, table, H, S, W, out); break;
-    case CC_DT_BF16: hipLaunchKernelGGL(ring_window_sum_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)num, strategies, table, H, S, W, out); break;
-    default: hipLaunchKernelGGL(ring_window_sum_kernel<f16_t>, grid, block, 0, st, (const f16_t*)num, strategies, table, H, S, W, out); break;
+    case CC_DT_F32: hipLaunchKernelGGL(ring_window_sum_kernel<float>, grid, block, 0, st, (const float*)num, strategies, table, H, S, W, out, acc_out); break;
+    case CC_DT_BF16: hipLaunchKernelGGL(ring_window_sum_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)num, strategies, table, H, S, W, out, acc_out); break;
+    default: hipLaunchKernelGGL(ring_window_sum_kernel<f16_t>, grid, block, 0, st, (const f16_t*)num, strategies, table, H, S, W, out, acc_out); break;
   }
 }
 
@@ -295,22 +509,29 @@ extern "C" {
 int cc_hybrid_decode_update(const cc_kv_view* c, const void* k_new, const void* v_new, const int32_t* input_pos,
                             const int64_t* strategies, const int32_t* policy_table, int32_t n_policies, void* num,
                             int32_t* denom, int32_t W, const uint8_t* special_mask, uint8_t* punc_mask,
-                            const uint8_t* is_punc, const int32_t* num_special, int32_t* num_punc, int32_t global_tokens,
-                            int32_t requires_heavy_hitter, int64_t* fill_out, float* wsum_workspace, cc_stream_t stream) {
+                            const uint8_t* is_punc, const int64_t* token_id, const int64_t* punc_ids, int32_t n_punc_ids,
+                            const int32_t* num_special, int32_t* num_punc, int32_t global_tokens,
+                            int32_t requires_heavy_hitter, int64_t* fill_out, float* wsum_workspace, uint64_t* wsum_acc,
+                            cc_stream_t stream) {
   CC_ENTRY();
   if (!cc_view_ok(c) || !k_new || !v_new || !input_pos || !strategies || !policy_table || n_policies <= 0 || !num ||
-      !denom || W <= 0 || !fill_out || c->Hp != c->H || c->Hc != c->H)
+      !denom || W <= 0 || !fill_out || c->Hp != c->H || c->Hc != c->H || (punc_ids && n_punc_ids < 0))
     return CC_ERR_BAD_ARG;
   if (!wsum_workspace) return CC_ERR_WORKSPACE;
   HybArgs a{};
+  const bool punc_here = !is_punc && token_id && punc_ids;
+  a.token_id = token_id; a.punc_ids = punc_ids; a.n_punc_ids = n_punc_ids;
+  // second ticket word of the tracked state (the pad behind the ring-update ticket)
+  a.punc_ticket = wsum_acc ? reinterpret_cast<unsigned int*>(wsum_acc + (size_t)c->H * c->S * 4 + 1) : nullptr;
   a.k_cache = c->k_cache; a.v_cache = c->v_cache; a.pos = c->pos; a.mask = c->mask; a.cache_cts = c->cache_cts;
   a.H = c->H; a.S = c->S; a.D = c->D; a.W = W; a.g = global_tokens;
   a.k_new = k_new; a.v_new = v_new; a.input_pos = input_pos; a.strategies = strategies; a.table = policy_table;
   a.num = num; a.denom = denom; a.special_mask = special_mask; a.punc_mask = punc_mask; a.is_punc = is_punc;
   a.num_special = num_special; a.num_punc = num_punc; a.requires_hh = requires_heavy_hitter; a.fill_out = fill_out;
   a.wsum = wsum_workspace;
+  a.wacc = reinterpret_cast<u64*>(wsum_acc);
   hipStream_t st = (hipStream_t)stream;
-  launch_window_sums(num, strategies, policy_table, c->H, c->S, W, c->dtype, wsum_workspace, st);
+  if (!wsum_acc) launch_window_sums(num, strategies, policy_table, c->H, c->S, W, c->dtype, wsum_workspace, nullptr, st);
   dim3 grid(c->H), block(kHybThreads);
   switch (c->dtype) {
     case CC_DT_F32: hipLaunchKernelGGL(hybrid_decode_kernel<float>, grid, block, 0, st, a); break;
@@ -318,8 +539,8 @@ int cc_hybrid_decode_update(const cc_kv_view* c, const void* k_new, const void* 
     default: hipLaunchKernelGGL(hybrid_decode_kernel<f16_t>, grid, block, 0, st, a); break;
   }
   CC_LAUNCH_CHECK();
-  if (is_punc && num_punc) {
-    hipLaunchKernelGGL(hybrid_bump_punc_kernel, dim3(1), dim3(64), 0, st, is_punc, num_punc);
+  if ((is_punc || punc_here) && num_punc && !a.punc_ticket) {
+    hipLaunchKernelGGL(hybrid_bump_punc_kernel, dim3(1), dim3(64), 0, st, is_punc, token_id, punc_ids, n_punc_ids, num_punc);
     CC_LAUNCH_CHECK();
   }
   return CC_OK;
@@ -327,7 +548,8 @@ int cc_hybrid_decode_update(const cc_kv_view* c, const void* k_new, const void* 
 
 int cc_decode_update_heavy_hitter_ring(const cc_kv_view* c, const void* k_new, const void* v_new,
                                        const int32_t* input_pos, void* num, int32_t* denom, int32_t W, int32_t g,
-                                       int32_t w, int64_t* idx_out, float* wsum_workspace, cc_stream_t stream) {
+                                       int32_t w, int64_t* idx_out, float* wsum_workspace, uint64_t* wsum_acc,
+                                       cc_stream_t stream) {
   CC_ENTRY();
   if (!cc_view_ok(c) || !input_pos || !idx_out || !num || !denom || W <= 0 || c->Hp != c->H || (k_new && !v_new))
     return CC_ERR_BAD_ARG;
@@ -337,8 +559,9 @@ int cc_decode_update_heavy_hitter_ring(const cc_kv_view* c, const void* k_new, c
   a.H = c->H; a.Hc = c->Hc; a.S = c->S; a.D = c->D; a.W = W; a.g = g; a.w = w;
   a.k_new = k_new; a.v_new = v_new; a.input_pos = input_pos; a.num = num; a.denom = denom; a.idx_out = idx_out;
   a.wsum = wsum_workspace;
+  a.wacc = reinterpret_cast<u64*>(wsum_acc);
   hipStream_t st = (hipStream_t)stream;
-  launch_window_sums(num, nullptr, nullptr, c->H, c->S, W, c->dtype, wsum_workspace, st);
+  if (!wsum_acc) launch_window_sums(num, nullptr, nullptr, c->H, c->S, W, c->dtype, wsum_workspace, nullptr, st);
   dim3 grid(c->H), block(kHybThreads);
   switch (c->dtype) {
     case CC_DT_F32: hipLaunchKernelGGL(hh_ring_decode_kernel<float>, grid, block, 0, st, a); break;
@@ -349,16 +572,45 @@ int cc_decode_update_heavy_hitter_ring(const cc_kv_view* c, const void* k_new, c
   return CC_OK;
 }
 
-int cc_hh_ring_update(void* num, int32_t* denom, int64_t* counter, const void* attn, int32_t H, int32_t S, int32_t T,
-                      int32_t W, int32_t dtype, cc_stream_t stream) {
+size_t cc_hh_ring_acc_words(int32_t H, int32_t S, int32_t W, int32_t dtype) {
+  const size_t hs = (size_t)H * (size_t)S, es = dtype == CC_DT_F32 ? 4 : 2;
+  return hs * 4 + 2 + (hs * (size_t)W * es + 7) / 8;  // accumulators, ticket (+ pad), column-major shadow of the ring
+}
+
+int cc_hh_ring_window_sums(const void* num, int32_t H, int32_t S, int32_t W, int32_t dtype, float* wsum, uint64_t* wsum_acc,
+                           cc_stream_t stream) {
   CC_ENTRY();
-  if (!num || !denom || !counter || !attn || H <= 0 || S <= 0 || T < 0 || T > S || W <= 0 || !cc_dt_ok(dtype))
+  if (!num || !wsum || H <= 0 || S <= 0 || W <= 0 || !cc_dt_ok(dtype)) return CC_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  launch_window_sums(num, nullptr, nullptr, H, S, W, dtype, wsum, reinterpret_cast<u64*>(wsum_acc), st);
+  CC_LAUNCH_CHECK();
+  return CC_OK;
+}
+
+int cc_hh_ring_update(void* num, int32_t* denom, int64_t* counter, const void* attn, int32_t H, int32_t S, int32_t T,
+                      int32_t W, int32_t dtype, uint64_t* wsum_acc, float* wsum, cc_stream_t stream) {
+  CC_ENTRY();
+  if (!num || !denom || !counter || !attn || H <= 0 || S <= 0 || T < 0 || T > S || W <= 0 || !cc_dt_ok(dtype) ||
+      ((wsum_acc == nullptr) != (wsum == nullptr)))
     return CC_ERR_BAD_ARG;
   const int n = H * S;
   int nb = (n + 255) / 256;
   if (nb > 2048) nb = 2048;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(nb), block(256);
+  if (wsum_acc) {
+    // few, large workgroups: one same-address ticket atomic per workgroup (2048 of them serialise to 26 us)
+    u64* wa = reinterpret_cast<u64*>(wsum_acc);
+    block = dim3(1024);
+    grid = dim3((unsigned)((n + 1023) / 1024 < 192 ? (n + 1023) / 1024 : 192));
+    switch (dtype) {
+      case CC_DT_F32: hipLaunchKernelGGL(hh_ring_update_tracked_kernel<float>, grid, block, 0, st, (float*)num, denom, counter, (const float*)attn, H, S, T, W, wa, wsum); break;
+      case CC_DT_BF16: hipLaunchKernelGGL(hh_ring_update_tracked_kernel<bf16_t>, grid, block, 0, st, (bf16_t*)num, denom, counter, (const bf16_t*)attn, H, S, T, W, wa, wsum); break;
+      default: hipLaunchKernelGGL(hh_ring_update_tracked_kernel<f16_t>, grid, block, 0, st, (f16_t*)num, denom, counter, (const f16_t*)attn, H, S, T, W, wa, wsum); break;
+    }
+    CC_LAUNCH_CHECK();
+    return CC_OK;
+  }
   switch (dtype) {
     case CC_DT_F32: hipLaunchKernelGGL(hh_ring_update_kernel<float>, grid, block, 0, st, (float*)num, denom, counter, (const float*)attn, H, S, T, W); break;
     case CC_DT_BF16: hipLaunchKernelGGL(hh_ring_update_kernel<bf16_t>, grid, block, 0, st, (bf16_t*)num, denom, counter, (const bf16_t*)attn, H, S, T, W); break;

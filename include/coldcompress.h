@@ -323,34 +323,52 @@ int cc_colsum_to_mean(const float* colsum, const int64_t* input_pos, int32_t H, 
  *   num: [H, S, W] model dtype history ring; denom: [H, S] int32.  The heavy-hitter score of a slot is
  *     dtype(sum_W num) / min(denom, W) over the first cache_cts[h] slots; protected slots (first g slots,
  *     special/punctuation slots, pos > p - window) -> +inf; arg-min.
- *   is_punc: device bool[1] (torch.isin(input_ids, punc_ids)) or NULL; num_special / num_punc: device int32[1] or NULL.
+ *   is_punc: device bool[1] (torch.isin(input_ids, punc_ids), cache.py:975) or NULL; with is_punc == NULL and
+ *     token_id (device int64[1]) + punc_ids (device int64[n_punc_ids]) given, the same membership test is evaluated
+ *     inside the launch.  num_special / num_punc: device int32[1] or NULL.
  *   c must be head-specific and variable-length (Hp == Hc == H).  fill_out: int64 [H] (dropped tokens report S-1).
  * Effects: pos/K/V written at fill_out for every head; mask and cache_cts only on appends; history zeroed on
  * evictions when requires_heavy_hitter; punc_mask set and num_punc += 1 when is_punc. */
 int cc_hybrid_decode_update(const cc_kv_view* c, const void* k_new, const void* v_new, const int32_t* input_pos,
                             const int64_t* strategies, const int32_t* policy_table, int32_t n_policies, void* num,
                             int32_t* denom, int32_t W, const uint8_t* special_mask, uint8_t* punc_mask,
-                            const uint8_t* is_punc, const int32_t* num_special, int32_t* num_punc,
+                            const uint8_t* is_punc, const int64_t* token_id, const int64_t* punc_ids,
+                            int32_t n_punc_ids, const int32_t* num_special, int32_t* num_punc,
                             int32_t global_tokens, int32_t requires_heavy_hitter, int64_t* fill_out,
-                            float* wsum_workspace, cc_stream_t stream);
+                            float* wsum_workspace, uint64_t* wsum_acc, cc_stream_t stream);
 
 /* Heavy-hitter decode update with a finite history window (history_window_size W > 1; model-dtype ring).
  * ref: KVCacheHeavyHitter._eviction_idx cache.py:725-765:
  *   avg = float(dtype(sum_W num)) / clamp(denom, 1, W); (pos<g)|(pos>=p-w) -> 1.0; pos==-1 -> 0.0; arg-min;
  *   ring row and denom of the chosen slot zeroed; then the common insert (k_new == NULL: select only).
  * num: [H, S, W] model dtype; denom: [H, S] int32; Hp must be H.
- * wsum_workspace: float [H*S] caller scratch (both ring entry points): the window sums are produced by a chip-wide
- * pre-pass (one wave per slot, coalesced) and only read by the one-workgroup-per-head decision kernel. */
+ *
+ * Window sums (both ring entry points).  dtype(sum_W num) is DEFINED as the exact sum of the W ring entries rounded
+ * once, nearest-even, to the model dtype (torch's own fp32 summation order is unspecified); being exact it does not
+ * depend on summation order, so it can be produced two ways with identical results:
+ *   wsum_acc == NULL (stateless): wsum_workspace, float [H*S], is caller scratch; a chip-wide pre-pass (one wave per
+ *     slot, coalesced) re-reads the whole [H, S, W] ring on every call — 118 MB at H = 8, S = 18432, W = 400.
+ *   wsum_acc != NULL (tracked): wsum_workspace / wsum_acc are PERSISTENT state kept current by cc_hh_ring_update
+ *     (the overwritten ring entry leaves the sum, the new one enters) and by the evictions here (row zeroed -> sum
+ *     zeroed); no pre-pass.  wsum_acc: uint64 [cc_hh_ring_acc_words(H, S, W, dtype)] = per slot a 192-bit
+ *     two's-complement fixed-point accumulator in units of 2^-149 plus a count of entries with |v| >= 4 or non-finite
+ *     (their window sum is NaN; attention probabilities are <= 1); then a launch-ticket word; then a column-major
+ *     [W][H*S] shadow of the ring (the entry a step overwrites is read from there, coalesced).  Zero-initialise it
+ *     together with the ring, or (re)build it from an existing ring with cc_hh_ring_window_sums. */
 int cc_decode_update_heavy_hitter_ring(const cc_kv_view* c, const void* k_new, const void* v_new,
                                        const int32_t* input_pos, void* num, int32_t* denom, int32_t W,
                                        int32_t global_tokens, int32_t recent_window, int64_t* idx_out,
-                                       float* wsum_workspace, cc_stream_t stream);
+                                       float* wsum_workspace, uint64_t* wsum_acc, cc_stream_t stream);
 
 /* History ring update, history_window_size W > 1.  ref: cache.py:716-723:
  *   num[h, s, *counter % W] = attn[h, s] (0 beyond T); denom += 1 everywhere; *counter += 1.
- * num: [H, S, W] dtype; attn: [H, T] dtype. */
+ * num: [H, S, W] dtype; attn: [H, T] dtype.  wsum_acc / wsum: both NULL, or the tracked window-sum state (above). */
 int cc_hh_ring_update(void* num, int32_t* denom, int64_t* counter, const void* attn, int32_t H, int32_t S, int32_t T,
-                      int32_t W, int32_t dtype, cc_stream_t stream);
+                      int32_t W, int32_t dtype, uint64_t* wsum_acc, float* wsum, cc_stream_t stream);
+size_t cc_hh_ring_acc_words(int32_t H, int32_t S, int32_t W, int32_t dtype);
+/* Exact window sums of a whole ring: wsum float [H*S]; wsum_acc (optional) the tracked state rebuilt from the ring. */
+int cc_hh_ring_window_sums(const void* num, int32_t H, int32_t S, int32_t W, int32_t dtype, float* wsum,
+                           uint64_t* wsum_acc, cc_stream_t stream);
 
 /* Band sums of a materialised attention tensor: out[h,k] = sum_{q=k}^{k+band-1} attn[h,q,k] (fp32, sequential).
  * Used by the hybrid profiling score for window policies (ref: create_window_attention_mask cache.py:142-149 +

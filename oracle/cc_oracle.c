@@ -753,40 +753,137 @@ int cc_silu_mul_cpu(const void* a, const void* b, int64_t n, int32_t dtype, void
 
 enum { HF_HH = 1, HF_WIN = 2, HF_PUNC = 4, HF_SPECIAL = 8, HF_FULL = 16 };
 
-/* dtype(sum_W row) (cache.py:855-859 `.sum(dim=-1)` on a model-dtype tensor; torch's fp32 order is unspecified).
- * Canonical order shared with the device (one wave per cache slot, cc_hybrid.hip ring_window_sum_kernel): the row
- * is cut into 16-byte chunks; lane l of 64 accumulates chunks l, l+64, ... element by element in index order; the 64
- * partials meet in an xor butterfly (32, 16, 8, 4, 2, 1); the total is rounded to the model dtype. */
+/* dtype(sum_W row) (cache.py:855-859 `.sum(dim=-1)` on a model-dtype tensor; torch's fp32 summation order is
+ * unspecified and backend-specific).  Definition shared with the device (cc_hybrid.hip): the EXACT sum of the W ring
+ * entries, rounded once, nearest-even, to the model dtype — independent of summation order, which is what allows the
+ * device to keep it incrementally.  Restated here with a different mechanism than the device's 192-bit adds: signed
+ * base-2^32 bins with deferred carries, then a bit-serial rounding.
+ * acc[0..2]: the sum as a 192-bit two's-complement integer in units of 2^-149; acc[3]: number of entries with
+ * |v| >= 4 or non-finite (such a row sums to NaN). */
+static void window_acc_row(const void* num, int dt, size_t off, int W, uint64_t acc[4]) {
+  int64_t bin[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint64_t special = 0;
+  for (int j = 0; j < W; j++) {
+    const float v = ld(num, dt, off + (size_t)j);
+    uint32_t u;
+    memcpy(&u, &v, 4);
+    if ((u << 1) == 0) continue;
+    const uint32_t E = (u >> 23) & 0xffu, M = u & 0x7fffffu;
+    if (E >= 129) {
+      special++;
+      continue;
+    }
+    const uint64_t m = E ? (uint64_t)(M | 0x800000u) : (uint64_t)M; /* v = m * 2^(sh - 149) */
+    const int sh = E ? (int)E - 1 : 0;
+    const uint64_t t = m << (sh & 31); /* < 2^55 */
+    const int64_t lo = (int64_t)(t & 0xffffffffu), hi = (int64_t)(t >> 32);
+    if (u >> 31) {
+      bin[sh >> 5] -= lo;
+      bin[(sh >> 5) + 1] -= hi;
+    } else {
+      bin[sh >> 5] += lo;
+      bin[(sh >> 5) + 1] += hi;
+    }
+  }
+  uint32_t dig[6];
+  int64_t carry = 0;
+  for (int k = 0; k < 6; k++) {
+    const int64_t t = bin[k] + carry;
+    dig[k] = (uint32_t)((uint64_t)t & 0xffffffffu);
+    carry = (t - (int64_t)dig[k]) / 4294967296LL; /* floor division: t - dig is an exact multiple of 2^32 */
+  }
+  acc[0] = (uint64_t)dig[0] | ((uint64_t)dig[1] << 32);
+  acc[1] = (uint64_t)dig[2] | ((uint64_t)dig[3] << 32);
+  acc[2] = (uint64_t)dig[4] | ((uint64_t)dig[5] << 32);
+  acc[3] = special;
+}
+static int acc_bit(const uint64_t m[3], int i) { return i < 0 ? 0 : (int)((m[i >> 6] >> (i & 63)) & 1u); }
+static float window_acc_round(const uint64_t acc[4], int dt) {
+  if (acc[3] != 0) return NAN;
+  uint64_t m[3] = {acc[0], acc[1], acc[2]};
+  const int neg = (int)(m[2] >> 63);
+  if (neg) { /* magnitude */
+    m[0] = ~m[0]; m[1] = ~m[1]; m[2] = ~m[2];
+    if (++m[0] == 0 && ++m[1] == 0) ++m[2];
+  }
+  int P = -1;
+  for (int i = 191; i >= 0; i--)
+    if (acc_bit(m, i)) { P = i; break; }
+  if (P < 0) return 0.f;
+  uint32_t bits;
+  if (P < 24) {
+    bits = (uint32_t)m[0]; /* the integer IS the fp32 encoding below 2^-125 */
+  } else {
+    uint32_t mant = 0;
+    for (int i = P; i > P - 24; i--) mant = (mant << 1) | (uint32_t)acc_bit(m, i);
+    const int guard = acc_bit(m, P - 24);
+    int rest = 0;
+    for (int i = P - 25; i >= 0 && !rest; i--) rest = acc_bit(m, i);
+    int Pe = P;
+    if (dt == CC_DT_F32) { /* nearest-even straight to fp32 */
+      if (guard && (rest || (mant & 1u))) mant++;
+      if (mant == (1u << 24)) { mant >>= 1; Pe++; }
+    } else { /* round to odd at 24 bits; the 16-bit nearest-even that follows is then exact */
+      mant |= (uint32_t)(guard || rest);
+    }
+    bits = ((uint32_t)(Pe - 22) << 23) | (mant & 0x7fffffu);
+  }
+  if (neg) bits |= 0x80000000u;
+  float f;
+  memcpy(&f, &bits, 4);
+  return rnd(f, dt);
+}
 static float window_sum_row(const void* num, int dt, size_t off, int W) {
-  const int vec = 16 / (int)dt_size(dt);
-  float p[64], q[64];
-  for (int l = 0; l < 64; l++) {
-    float acc = 0.f;
-    for (int c = l; c * vec < W; c += 64)
-      for (int e = 0; e < vec && c * vec + e < W; e++) acc = acc + ld(num, dt, off + (size_t)c * vec + e);
-    p[l] = acc;
+  uint64_t acc[4];
+  window_acc_row(num, dt, off, W, acc);
+  return window_acc_round(acc, dt);
+}
+/* the tracked state the device keeps (wsum float [H*S], acc uint64 [H*S*4 + 1]) recomputed from the ring */
+static void window_state_from_ring(const void* num, int dt, int H, int S, int W, float* wsum, uint64_t* acc) {
+  for (size_t i = 0; i < (size_t)H * S; i++) {
+    uint64_t a[4];
+    window_acc_row(num, dt, i * (size_t)W, W, a);
+    if (wsum) wsum[i] = window_acc_round(a, dt);
+    if (acc) memcpy(acc + i * 4, a, sizeof(a));
   }
-  for (int o = 32; o > 0; o >>= 1) {
-    for (int l = 0; l < 64; l++) q[l] = p[l] + p[l ^ o];
-    for (int l = 0; l < 64; l++) p[l] = q[l];
+  if (acc) { /* ticket + pad, then the column-major shadow of the ring */
+    const size_t hs = (size_t)H * S, es = dt_size(dt);
+    acc[hs * 4] = acc[hs * 4 + 1] = 0;
+    char* shadow = (char*)(acc + hs * 4 + 2);
+    for (size_t i = 0; i < hs; i++)
+      for (int j = 0; j < W; j++) memcpy(shadow + ((size_t)j * hs + i) * es, (const char*)num + (i * (size_t)W + j) * es, es);
   }
-  return rnd(p[0], dt);
+}
+
+size_t cc_hh_ring_acc_words_cpu(int32_t H, int32_t S, int32_t W, int32_t dtype) {
+  const size_t hs = (size_t)H * (size_t)S, es = dtype == CC_DT_F32 ? 4 : 2;
+  return hs * 4 + 2 + (hs * (size_t)W * es + 7) / 8;
+}
+
+int cc_hh_ring_window_sums_cpu(const void* num, int32_t H, int32_t S, int32_t W, int32_t dtype, float* wsum, uint64_t* wsum_acc,
+                               cc_stream_t stream) {
+  (void)stream;
+  if (!num || !wsum || H <= 0 || S <= 0 || W <= 0 || !dt_ok(dtype)) return CC_ERR_BAD_ARG;
+  window_state_from_ring(num, dtype, H, S, W, wsum, wsum_acc);
+  return CC_OK;
 }
 
 /* ref: KVCacheHybrid._decoding_update cache.py:965-1019, _select_fill_idx :896-950, _eviction_idx_for_head :844-894 */
 int cc_hybrid_decode_update_cpu(const cc_kv_view* c, const void* k_new, const void* v_new, const int32_t* input_pos,
                                 const int64_t* strategies, const int32_t* policy_table, int32_t n_policies, void* num,
                                 int32_t* denom, int32_t W, const uint8_t* special_mask, uint8_t* punc_mask,
-                                const uint8_t* is_punc_p, const int32_t* num_special, int32_t* num_punc, int32_t g,
-                                int32_t requires_hh, int64_t* fill_out, float* wsum_workspace, cc_stream_t stream) {
-  (void)wsum_workspace;
+                                const uint8_t* is_punc_p, const int64_t* token_id, const int64_t* punc_ids, int32_t n_punc_ids,
+                                const int32_t* num_special, int32_t* num_punc, int32_t g, int32_t requires_hh,
+                                int64_t* fill_out, float* wsum_workspace, uint64_t* wsum_acc, cc_stream_t stream) {
   (void)stream;
   if (!view_ok(c) || !k_new || !v_new || !input_pos || !strategies || !policy_table || n_policies <= 0 || !num || !denom ||
       W <= 0 || !fill_out || c->Hp != c->H || c->Hc != c->H)
     return CC_ERR_BAD_ARG;
   const int S = c->S, dt = c->dtype;
   const int32_t p = *input_pos;
-  const int is_punc = is_punc_p ? (*is_punc_p != 0) : 0;
+  int is_punc = is_punc_p ? (*is_punc_p != 0) : 0;
+  if (!is_punc_p && token_id && punc_ids) /* ref: cache.py:975 torch.isin(input_ids, punc_ids) */
+    for (int k = 0; k < n_punc_ids; k++) is_punc |= punc_ids[k] == *token_id;
   const size_t es = dt_size(dt);
   float* sc = (float*)malloc(sizeof(float) * (size_t)S);
   for (int h = 0; h < c->H; h++) {
@@ -830,6 +927,12 @@ int cc_hybrid_decode_update_cpu(const cc_kv_view* c, const void* k_new, const vo
     if (evict && requires_hh) {
       for (int j = 0; j < W; j++) st(num, dt, (hoff + slot) * (size_t)W + j, 0.f);
       denom[hoff + slot] = 0;
+      if (wsum_acc) { /* tracked state: the sum of a zeroed row (+ its shadow entries) */
+        const size_t hs = (size_t)c->H * S;
+        memset(wsum_acc + (hoff + slot) * 4, 0, 4 * sizeof(uint64_t));
+        wsum_workspace[hoff + slot] = 0.f;
+        for (int j = 0; j < W; j++) memset((char*)(wsum_acc + hs * 4 + 2) + ((size_t)j * hs + hoff + slot) * es, 0, es);
+      }
     }
     if (!evict && fill >= 0) {
       c->cache_cts[h] = cts + 1;
@@ -847,9 +950,11 @@ int cc_hybrid_decode_update_cpu(const cc_kv_view* c, const void* k_new, const vo
 
 /* ref: cache.py:716-723 with history_window_size > 1 */
 int cc_hh_ring_update_cpu(void* num, int32_t* denom, int64_t* counter, const void* attn, int32_t H, int32_t S, int32_t T,
-                          int32_t W, int32_t dtype, cc_stream_t stream) {
+                          int32_t W, int32_t dtype, uint64_t* wsum_acc, float* wsum, cc_stream_t stream) {
   (void)stream;
-  if (!num || !denom || !counter || !attn || H <= 0 || S <= 0 || T < 0 || T > S || W <= 0 || !dt_ok(dtype)) return CC_ERR_BAD_ARG;
+  if (!num || !denom || !counter || !attn || H <= 0 || S <= 0 || T < 0 || T > S || W <= 0 || !dt_ok(dtype) ||
+      ((wsum_acc == NULL) != (wsum == NULL)))
+    return CC_ERR_BAD_ARG;
   const int slot = (int)(*counter % W);
   for (int h = 0; h < H; h++)
     for (int s = 0; s < S; s++) {
@@ -857,6 +962,7 @@ int cc_hh_ring_update_cpu(void* num, int32_t* denom, int64_t* counter, const voi
       denom[(size_t)h * S + s] += 1;
     }
   *counter += 1;
+  if (wsum_acc) window_state_from_ring(num, dtype, H, S, W, wsum, wsum_acc); /* the oracle recomputes; the device tracks */
   return CC_OK;
 }
 
@@ -923,8 +1029,8 @@ int cc_prefill_attn_bands_cpu(const void* q, const void* k, const void* v, int32
 /* ref: KVCacheHeavyHitter._eviction_idx cache.py:725-765 with history_window_size W > 1 */
 int cc_decode_update_heavy_hitter_ring_cpu(const cc_kv_view* c, const void* k_new, const void* v_new,
                                            const int32_t* input_pos, void* num, int32_t* denom, int32_t W, int32_t g,
-                                           int32_t w, int64_t* idx_out, float* wsum_workspace, cc_stream_t stream) {
-  (void)wsum_workspace;
+                                           int32_t w, int64_t* idx_out, float* wsum_workspace, uint64_t* wsum_acc,
+                                           cc_stream_t stream) {
   (void)stream;
   if (!view_ok(c) || !input_pos || !idx_out || !num || !denom || W <= 0 || c->Hp != c->H || c->H > 4096) return CC_ERR_BAD_ARG;
   const int32_t p = *input_pos;
@@ -947,6 +1053,12 @@ int cc_decode_update_heavy_hitter_ring_cpu(const cc_kv_view* c, const void* k_ne
     const size_t i = (size_t)h * c->S + idx_out[h];
     for (int j = 0; j < W; j++) st(num, dt, i * (size_t)W + j, 0.f);
     denom[i] = 0;
+    if (wsum_acc) { /* tracked state: the sum of a zeroed row (+ its shadow entries) */
+      const size_t hs = (size_t)c->H * c->S, es = dt_size(dt);
+      memset(wsum_acc + i * 4, 0, 4 * sizeof(uint64_t));
+      wsum_workspace[i] = 0.f;
+      for (int j = 0; j < W; j++) memset((char*)(wsum_acc + hs * 4 + 2) + ((size_t)j * hs + i) * es, 0, es);
+    }
   }
   if (k_new) insert_token(c, k_new, v_new, p, idx_out);
   return CC_OK;

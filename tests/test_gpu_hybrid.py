@@ -163,8 +163,8 @@ def test_hybrid_decode_vs_oracle_at_scale(oracle):
         stn = strat.numpy().copy()
         o.call("cc_hybrid_decode_update", C.byref(view), o.ptr(to_np(k1.reshape(H, D))), o.ptr(to_np(v1.reshape(H, D))),
                o.ptr(p.numpy().copy()), o.ptr(stn), o.ptr(tab), len(tab), o.ptr(st["num"]), o.ptr(st["denom"]), W, o.ptr(st["special"]),
-               o.ptr(st["punc"]), o.ptr(isp), o.ptr(st["nsp"]), o.ptr(st["npc"]), g, 0, o.ptr(fill), None, None)
-        o.call("cc_hh_ring_update", o.ptr(st["num"]), o.ptr(st["denom"]), o.ptr(st["ctr"]), o.ptr(to_np(a)), H, S, S, W, 1, None)
+               o.ptr(st["punc"]), o.ptr(isp), None, None, 0, o.ptr(st["nsp"]), o.ptr(st["npc"]), g, 0, o.ptr(fill), None, None, None)
+        o.call("cc_hh_ring_update", o.ptr(st["num"]), o.ptr(st["denom"]), o.ptr(st["ctr"]), o.ptr(to_np(a)), H, S, S, W, 1, None, None, None)
         assert kv._idx_buf().cpu().tolist() == fill.tolist(), f"step {t}"
     assert np.array_equal(kv.pos.cpu()[0].numpy(), st["pos"]) and np.array_equal(kv.cache_cts.cpu().numpy(), st["cts"])
     assert np.array_equal(to_np(kv.attn_history_num.cpu()[0]), st["num"])

@@ -36,7 +36,7 @@ def test_ring_replay_oracle(oracle, name):
     mean = np.zeros((H, T), es)
     o.call("cc_colsum_to_mean", o.ptr(colsum), None, H, T, code, o.ptr(mean), None)
     num2, den2, ctr2 = np.zeros((H, S, W), es), np.zeros((H, S), np.int32), np.zeros(1, np.int64)
-    o.call("cc_hh_ring_update", o.ptr(num2), o.ptr(den2), o.ptr(ctr2), o.ptr(mean), H, S, T, W, code, None)
+    o.call("cc_hh_ring_update", o.ptr(num2), o.ptr(den2), o.ptr(ctr2), o.ptr(mean), H, S, T, W, code, None, None, None)
     from helpers import from_np
     assert torch.allclose(from_np(num2, dtype).float(), from_np(num, dtype).float(), rtol=2 ** -7 if code else 1e-6, atol=0)
     assert np.array_equal(den2, denom) and ctr2[0] == 1
@@ -45,10 +45,10 @@ def test_ring_replay_oracle(oracle, name):
         idx = np.zeros(H, np.int64)
         pp = np.array([T + t], np.int32)
         o.call("cc_decode_update_heavy_hitter_ring", C.byref(view), o.ptr(to_np(f["k_new"][t].reshape(H, D))),
-               o.ptr(to_np(f["v_new"][t].reshape(H, D))), o.ptr(pp), o.ptr(num), o.ptr(denom), W, g, w, o.ptr(idx), None, None)
+               o.ptr(to_np(f["v_new"][t].reshape(H, D))), o.ptr(pp), o.ptr(num), o.ptr(denom), W, g, w, o.ptr(idx), None, None, None)
         assert np.array_equal(idx, f["idx"][t].numpy()), f"step {t}"
         assert np.array_equal(cts, f["cache_cts_steps"][t].numpy())
-        o.call("cc_hh_ring_update", o.ptr(num), o.ptr(denom), o.ptr(counter), o.ptr(to_np(f["attn"][t][0, :, 0])), H, S, S, W, code, None)
+        o.call("cc_hh_ring_update", o.ptr(num), o.ptr(denom), o.ptr(counter), o.ptr(to_np(f["attn"][t][0, :, 0])), H, S, S, W, code, None, None, None)
     assert np.array_equal(num, to_np(f["final_num"][0])) and np.array_equal(denom, f["final_denom"][0].numpy())
     assert np.array_equal(pos, f["final_pos"][0].numpy()) and np.array_equal(k, to_np(f["final_k"][0]))
 

@@ -56,14 +56,14 @@ def test_hybrid_decode_replay_bit_exact(oracle, name):
         is_punc = np.array([int(int(f["tok"][t][0]) in punc_ids)], np.uint8) if punc is not None else None
         fill = np.zeros(H, np.int64)
         o.call("cc_hybrid_decode_update", C.byref(view), o.ptr(kn), o.ptr(vn), o.ptr(p), o.ptr(strat), o.ptr(tab), len(tab),
-               o.ptr(num), o.ptr(denom), W, o.ptr(special), o.ptr(punc), o.ptr(is_punc), o.ptr(n_special), o.ptr(n_punc), 4,
-               0, o.ptr(fill), None, None)  # 0: the reference's history reset on eviction is an effective no-op
+               o.ptr(num), o.ptr(denom), W, o.ptr(special), o.ptr(punc), o.ptr(is_punc), None, None, 0, o.ptr(n_special), o.ptr(n_punc), 4,
+               0, o.ptr(fill), None, None, None)  # 0: the reference's history reset on eviction is an effective no-op
         assert np.array_equal(fill, f["fill"][t].numpy()), f"step {t}: {fill} vs {f['fill'][t].tolist()}"
         assert np.array_equal(cts, f["cts_steps"][t].numpy()), f"step {t}"
         if f["requires_hh"]:
             a = to_np(f["attn"][ai][0, :, 0])
             ai += 1
-            o.call("cc_hh_ring_update", o.ptr(num), o.ptr(denom), o.ptr(counter), o.ptr(a), H, S, S, W, code, None)
+            o.call("cc_hh_ring_update", o.ptr(num), o.ptr(denom), o.ptr(counter), o.ptr(a), H, S, S, W, code, None, None, None)
     assert np.array_equal(pos, f["final_pos"][0].numpy())
     assert np.array_equal(mask.astype(bool), f["final_mask"][0, :, 0].numpy())
     assert np.array_equal(k, to_np(f["final_k"][0]))

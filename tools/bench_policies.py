@@ -69,9 +69,12 @@ def make(strategy, H, S, D, extra=None):
 def main():
     cfgs = [("C2", 8, 32, 2560), ("C3", 8, 32, 4096), ("C4", 8, 32, 18432), ("C5", 1, 8, 3488)]
     D = 128
+    only = os.environ.get("CC_POLICIES_ONLY")  # e.g. "C4:hybrid" — one configuration, for profiling
     for tag, H, HQ, S in cfgs:
         n_buf = max(4, min(32, (600 << 20) // (2 * H * S * D * 2) + 1))
         for strategy in (["hybrid"] if tag == "C4" else ["heavy_hitter", "l2", "random", "recent_global", "full"]) + (["heavy_hitter"] if tag == "C4" else []):
+            if only and only != f"{tag}:{strategy}":
+                continue
             try:
                 caches = [make(strategy, H, S, D) for _ in range(n_buf)]
             except Exception as e:
