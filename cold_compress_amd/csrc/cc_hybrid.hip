@@ -32,6 +32,7 @@ struct HybArgs {
   const int64_t* punc_ids;
   int n_punc_ids;
   unsigned int* punc_ticket;    // tracked state: num_punc is bumped by the last head to have read it (null: separate launch)
+  u64* head_scratch;            // tracked state, gridDim.y > 1: [H] inverted arg-min keys + [H] tickets, zero between launches
   const int32_t* num_special;   // device int[1] or null
   int32_t* num_punc;            // device int[1] or null
   int requires_hh;
@@ -179,11 +180,13 @@ __device__ __forceinline__ WAcc wave_window_acc(const T* row, int W, int lane) {
 // slot.  (The first version summed rows inside the one-workgroup-per-head kernel: 8 CUs, 800-byte strides, 1.4 ms.)
 template <typename T>
 __global__ __launch_bounds__(256) void ring_window_sum_kernel(const T* num, const int64_t* strategies, const int32_t* table, int H,
-                                                              int S, int W, float* out, u64* acc_out) {
+                                                              int S, int W, float* out, u64* acc_out, size_t scratch_off) {
   const int lane = threadIdx.x & 63;
   const size_t total = (size_t)H * S;
   const size_t nw = (size_t)gridDim.x * (blockDim.x >> 6);
-  if (acc_out && blockIdx.x == 0 && threadIdx.x < 2) acc_out[total * 4 + threadIdx.x] = 0;  // launch ticket of the tracked update (+ pad)
+  if (acc_out && blockIdx.x == 0 && threadIdx.x < 2) acc_out[total * 4 + threadIdx.x] = 0;  // the two launch tickets
+  if (acc_out && blockIdx.x == 0)
+    for (int i = threadIdx.x; i < 2 * H; i += blockDim.x) acc_out[scratch_off + i] = 0;  // meeting words of the split decision kernel
   for (size_t i = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); i < total; i += nw) {
     if (strategies != nullptr && !(table[strategies[i / S] * 3] & 1 /* F_HH */)) continue;
     const WAcc a = wave_window_acc<T>(num + i * (size_t)W, W, lane);
@@ -205,7 +208,30 @@ constexpr int kHybThreads = 1024;
 template <typename T>
 __global__ __launch_bounds__(kHybThreads) void hybrid_decode_kernel(HybArgs a) {
   __shared__ unsigned long long sm_key[kHybThreads / 64 + 2];
-  const int h = blockIdx.x, S = a.S, W = a.W;
+  // gridDim.y workgroups share the slots of one head (tracked state only: they meet through head_scratch).  Every
+  // workgroup reads all its inputs first; only the LAST one to arrive writes anything, so no read sees a write.
+  const int h = blockIdx.x, S = a.S, W = a.W, nb = gridDim.y, bi = blockIdx.y;
+  // the first batch of per-slot operands is requested before the policy chain (strategy -> table -> counts) resolves
+  constexpr int UN = 4;
+  const size_t hoff = (size_t)h * S;
+  const int per = (S + nb - 1) / nb;
+  const int lo = bi * per, hi = lo + per < S ? lo + per : S;
+  int32_t ps[UN], dn[UN];
+  float ws[UN];
+  uint8_t sp[UN], pm[UN];
+  auto load_batch = [&](int s0) {
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+      const int s = s0 + u * (int)blockDim.x;
+      const size_t i = hoff + (s < hi ? s : lo);
+      ps[u] = a.pos[i];
+      ws[u] = a.wsum[i];
+      dn[u] = a.denom[i];
+      sp[u] = a.special_mask ? a.special_mask[i] : 0;
+      pm[u] = a.punc_mask ? a.punc_mask[i] : 0;
+    }
+  };
+  load_batch(lo + threadIdx.x);
   const int32_t p = *a.input_pos;
   const int pol = (int)a.strategies[h];
   const int flags = a.table[pol * 3], win = a.table[pol * 3 + 1], hhs = a.table[pol * 3 + 2];
@@ -231,10 +257,10 @@ __global__ __launch_bounds__(kHybThreads) void hybrid_decode_kernel(HybArgs a) {
   if (threadIdx.x == 0 && a.punc_ticket && a.num_punc)
     ptk = __hip_atomic_fetch_add(a.punc_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const int end_idx = cts < S - 1 ? cts : S - 1;  // ref: _end_idx() :897-899
-  const size_t hoff = (size_t)h * S;
 
   int fill = -1;       // -1 = token not kept by this head (ref: :948-950 -> dummy slot S-1)
   bool evict = false;
+  unsigned long long best = ~0ull;
   if ((flags & F_PUNC) && is_punc) {  // :905-906
     fill = end_idx;
   } else if (flags & F_FULL) {  // :908-909
@@ -249,31 +275,17 @@ __global__ __launch_bounds__(kHybThreads) void hybrid_decode_kernel(HybArgs a) {
       fill = end_idx;
     } else if (flags & (F_HH | F_WIN)) {  // :932-946 -> _eviction_idx_for_head :844-894
       evict = true;
-      unsigned long long best = ~0ull;
-      // UN slots per thread per iteration, every per-slot load issued before the first use (one workgroup scans a
-      // whole head: the loop is latency-bound unless the loads of several slots are in flight together)
-      constexpr int UN = 4;
-      const int lim = cts < S ? cts : S;
-      for (int s0 = threadIdx.x; s0 < lim; s0 += blockDim.x * UN) {
-        int32_t ps[UN], dn[UN];
-        float ws[UN];
-        uint8_t sp[UN], pm[UN];
-#pragma unroll
-        for (int u = 0; u < UN; u++) {
-          const int s = s0 + u * blockDim.x;
-          const bool in = s < lim;
-          const size_t i = hoff + (in ? s : 0);
-          ps[u] = a.pos[i];
-          ws[u] = (flags & F_HH) ? a.wsum[i] : 0.f;
-          dn[u] = (flags & F_HH) ? a.denom[i] : 1;
-          sp[u] = ((flags & F_SPECIAL) && a.special_mask) ? a.special_mask[i] : 0;
-          pm[u] = ((flags & F_PUNC) && a.punc_mask) ? a.punc_mask[i] : 0;
-        }
+      const int lim_all = cts < S ? cts : S;
+      const int lim = hi < lim_all ? hi : lim_all;
+      for (int s0 = lo + threadIdx.x; s0 < lim; s0 += blockDim.x * UN) {
+        if (s0 != lo + (int)threadIdx.x) load_batch(s0);
 #pragma unroll
         for (int u = 0; u < UN; u++) {
           const int s = s0 + u * blockDim.x;
           if (s >= lim) continue;
           float sc;
+          if (!(flags & F_SPECIAL)) sp[u] = 0;
+          if (!(flags & F_PUNC)) pm[u] = 0;
           if (flags & F_HH) {
             const int32_t d = dn[u] > W ? W : dn[u];  // clamp_max only (:868-870): a zero count divides by zero like the reference
             sc = __fdiv_rn(ws[u], (float)d);
@@ -290,9 +302,33 @@ __global__ __launch_bounds__(kHybThreads) void hybrid_decode_kernel(HybArgs a) {
         }
       }
       best = block_min_u64(best, sm_key);
-      fill = (int)(best & 0xffffffffull);
     }
   }
+  if (threadIdx.x == 0 && a.punc_ticket && a.num_punc && ptk == gridDim.x * gridDim.y - 1) {
+    if (is_punc) *a.num_punc = num_punc_old + 1;  // :1017 — every workgroup has read the old value
+    __hip_atomic_store(a.punc_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (nb > 1) {  // meet the other workgroups of this head; the last to arrive carries on alone
+    __shared__ unsigned long long sm_meet[2];
+    if (threadIdx.x == 0) {
+      u64* inv_key = a.head_scratch + h;
+      unsigned int* ticket = reinterpret_cast<unsigned int*>(a.head_scratch + a.H + h);
+      if (evict) atomicMax(inv_key, ~best);
+      __threadfence();
+      const bool last = atomicAdd(ticket, 1u) == (unsigned)nb - 1;
+      if (last) {
+        __threadfence();
+        best = ~atomicExch(inv_key, 0ull);
+        atomicExch(ticket, 0u);
+      }
+      sm_meet[0] = last;
+      sm_meet[1] = best;
+    }
+    __syncthreads();
+    if (!sm_meet[0]) return;
+    best = sm_meet[1];
+  }
+  if (evict) fill = (int)(best & 0xffffffffull);
   const int slot = fill < 0 ? S - 1 : fill;
   if (threadIdx.x == 0) a.fill_out[h] = slot;
   if (evict && a.requires_hh) {  // :992-996
@@ -314,10 +350,6 @@ __global__ __launch_bounds__(kHybThreads) void hybrid_decode_kernel(HybArgs a) {
     }
     a.pos[hoff + slot] = p;  // :1006-1007 _fill(update_mask=False) — every head, dropped tokens land in slot S-1
     if (is_punc && a.punc_mask) a.punc_mask[hoff + slot] = 1;  // :1011-1016
-    if (a.punc_ticket && a.num_punc && ptk == gridDim.x - 1) {
-      if (is_punc) *a.num_punc = num_punc_old + 1;  // :1017
-      __hip_atomic_store(a.punc_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
   }
   const int words = a.D * (int)sizeof(T) / 4;
   const uint32_t* ks = reinterpret_cast<const uint32_t*>(a.k_new) + (size_t)h * words;
@@ -492,13 +524,14 @@ __global__ __launch_bounds__(256) void attn_bandsum_kernel(const T* attn, int H,
 static void launch_window_sums(const void* num, const int64_t* strategies, const int32_t* table, int H, int S, int W, int dtype,
                                float* out, u64* acc_out, hipStream_t st) {
   const size_t slots = (size_t)H * S;
+  const size_t scratch_off = cc_hh_ring_acc_words(H, S, W, dtype) - 2 * (size_t)H;
   size_t nb = (slots + 3) / 4;  // 4 waves per workgroup, one slot per wave per iteration
   if (nb > 4096) nb = 4096;
   dim3 grid((unsigned)nb), block(256);
   switch (dtype) {
-    case CC_DT_F32: hipLaunchKernelGGL(ring_window_sum_kernel<float>, grid, block, 0, st, (const float*)num, strategies, table, H, S, W, out, acc_out); break;
-    case CC_DT_BF16: hipLaunchKernelGGL(ring_window_sum_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)num, strategies, table, H, S, W, out, acc_out); break;
-    default: hipLaunchKernelGGL(ring_window_sum_kernel<f16_t>, grid, block, 0, st, (const f16_t*)num, strategies, table, H, S, W, out, acc_out); break;
+    case CC_DT_F32: hipLaunchKernelGGL(ring_window_sum_kernel<float>, grid, block, 0, st, (const float*)num, strategies, table, H, S, W, out, acc_out, scratch_off); break;
+    case CC_DT_BF16: hipLaunchKernelGGL(ring_window_sum_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)num, strategies, table, H, S, W, out, acc_out, scratch_off); break;
+    default: hipLaunchKernelGGL(ring_window_sum_kernel<f16_t>, grid, block, 0, st, (const f16_t*)num, strategies, table, H, S, W, out, acc_out, scratch_off); break;
   }
 }
 
@@ -523,6 +556,12 @@ int cc_hybrid_decode_update(const cc_kv_view* c, const void* k_new, const void* 
   a.token_id = token_id; a.punc_ids = punc_ids; a.n_punc_ids = n_punc_ids;
   // second ticket word of the tracked state (the pad behind the ring-update ticket)
   a.punc_ticket = wsum_acc ? reinterpret_cast<unsigned int*>(wsum_acc + (size_t)c->H * c->S * 4 + 1) : nullptr;
+  int nsplit = 1;
+  if (wsum_acc) {  // meeting place of the workgroups that share a head: the last 2H words of the tracked state
+    a.head_scratch = reinterpret_cast<u64*>(wsum_acc) + cc_hh_ring_acc_words(c->H, c->S, W, c->dtype) - 2 * (size_t)c->H;
+    nsplit = (c->S + 1023) / 1024;
+    if (nsplit > 32) nsplit = 32;
+  }
   a.k_cache = c->k_cache; a.v_cache = c->v_cache; a.pos = c->pos; a.mask = c->mask; a.cache_cts = c->cache_cts;
   a.H = c->H; a.S = c->S; a.D = c->D; a.W = W; a.g = global_tokens;
   a.k_new = k_new; a.v_new = v_new; a.input_pos = input_pos; a.strategies = strategies; a.table = policy_table;
@@ -532,7 +571,7 @@ int cc_hybrid_decode_update(const cc_kv_view* c, const void* k_new, const void* 
   a.wacc = reinterpret_cast<u64*>(wsum_acc);
   hipStream_t st = (hipStream_t)stream;
   if (!wsum_acc) launch_window_sums(num, strategies, policy_table, c->H, c->S, W, c->dtype, wsum_workspace, nullptr, st);
-  dim3 grid(c->H), block(kHybThreads);
+  dim3 grid(c->H, nsplit), block(nsplit > 1 ? 256 : kHybThreads);
   switch (c->dtype) {
     case CC_DT_F32: hipLaunchKernelGGL(hybrid_decode_kernel<float>, grid, block, 0, st, a); break;
     case CC_DT_BF16: hipLaunchKernelGGL(hybrid_decode_kernel<bf16_t>, grid, block, 0, st, a); break;
@@ -574,7 +613,8 @@ int cc_decode_update_heavy_hitter_ring(const cc_kv_view* c, const void* k_new, c
 
 size_t cc_hh_ring_acc_words(int32_t H, int32_t S, int32_t W, int32_t dtype) {
   const size_t hs = (size_t)H * (size_t)S, es = dtype == CC_DT_F32 ? 4 : 2;
-  return hs * 4 + 2 + (hs * (size_t)W * es + 7) / 8;  // accumulators, ticket (+ pad), column-major shadow of the ring
+  // accumulators, two ticket words, column-major shadow of the ring, [H] keys + [H] tickets of the split decision kernel
+  return hs * 4 + 2 + (hs * (size_t)W * es + 7) / 8 + 2 * (size_t)H;
 }
 
 int cc_hh_ring_window_sums(const void* num, int32_t H, int32_t S, int32_t W, int32_t dtype, float* wsum, uint64_t* wsum_acc,

@@ -352,8 +352,9 @@ int cc_hybrid_decode_update(const cc_kv_view* c, const void* k_new, const void* 
  *     (the overwritten ring entry leaves the sum, the new one enters) and by the evictions here (row zeroed -> sum
  *     zeroed); no pre-pass.  wsum_acc: uint64 [cc_hh_ring_acc_words(H, S, W, dtype)] = per slot a 192-bit
  *     two's-complement fixed-point accumulator in units of 2^-149 plus a count of entries with |v| >= 4 or non-finite
- *     (their window sum is NaN; attention probabilities are <= 1); then a launch-ticket word; then a column-major
- *     [W][H*S] shadow of the ring (the entry a step overwrites is read from there, coalesced).  Zero-initialise it
+ *     (their window sum is NaN; attention probabilities are <= 1); then two launch-ticket words; then a column-major
+ *     [W][H*S] shadow of the ring (the entry a step overwrites is read from there, coalesced); then 2H words where the
+ *     workgroups sharing a head meet (zero between launches).  Zero-initialise it
  *     together with the ring, or (re)build it from an existing ring with cc_hh_ring_window_sums. */
 int cc_decode_update_heavy_hitter_ring(const cc_kv_view* c, const void* k_new, const void* v_new,
                                        const int32_t* input_pos, void* num, int32_t* denom, int32_t W,

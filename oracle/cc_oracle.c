@@ -857,7 +857,7 @@ static void window_state_from_ring(const void* num, int dt, int H, int S, int W,
 
 size_t cc_hh_ring_acc_words_cpu(int32_t H, int32_t S, int32_t W, int32_t dtype) {
   const size_t hs = (size_t)H * (size_t)S, es = dtype == CC_DT_F32 ? 4 : 2;
-  return hs * 4 + 2 + (hs * (size_t)W * es + 7) / 8;
+  return hs * 4 + 2 + (hs * (size_t)W * es + 7) / 8 + 2 * (size_t)H; /* the device's layout: the last 2H words are scratch (zero) */
 }
 
 int cc_hh_ring_window_sums_cpu(const void* num, int32_t H, int32_t S, int32_t W, int32_t dtype, float* wsum, uint64_t* wsum_acc,
