@@ -59,6 +59,8 @@ SIGNATURES = {
     "cc_decode_attn_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32, _i32]),
     "cc_decode_attn_gqa": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp,
                                      _vp, _vp, _vp, _vp, _sz, _vp]),
+    "cc_decode_attn_gqa_ring": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _i32,
+                                          _vp, _vp, _vp, _sz, _vp]),
     "cc_softmax_argmax_workspace_bytes": (_sz, []),
     "cc_softmax_argmax": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
     "cc_gemv_fused": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _vp]),

@@ -30,7 +30,7 @@ def _stale(obj, src):
     if not os.path.exists(obj):
         return True
     t = os.path.getmtime(obj)
-    deps = [src, os.path.join(CSRC, "cc_common.h"), os.path.join(HERE, "..", "include", "coldcompress.h"), __file__]
+    deps = [src, os.path.join(CSRC, "cc_common.h"), os.path.join(CSRC, "cc_wacc.h"), os.path.join(HERE, "..", "include", "coldcompress.h"), __file__]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

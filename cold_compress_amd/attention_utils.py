@@ -9,7 +9,8 @@ Differences from the reference that a caller can rely on:
     (what model.py:413-418 computes next), instead of [1, HQ, 1, S].
   * Prefill with `return_attn=True` returns an `AttnSummary` (column sums + observation-window mean) instead
     of the [1, HQ, L, L] tensor; every policy in cache.py / prompt_compression.py consumes exactly that.
-  * `history=(num, denom, counter)` folds the heavy-hitter history update into the decode combine pass.
+  * `history=(num, denom, counter)` folds the heavy-hitter history update into the decode combine pass;
+    `history=(ring, denom, counter, W, acc, wsum)` does the same for the `history_window_size > 1` ring.
 Unsupported (raised loudly): dropout_p != 0, non-causal prefill masks; attn_top_k < 1 asserts with a mask, like the reference.
 """
 import ctypes as C
@@ -78,6 +79,11 @@ def decode_attention(query, key, value, attn_mask=None, scale=None, return_attn=
     ws = _workspace(nbytes, query.device)
     sc = 1.0 / math.sqrt(D) if scale is None else scale
     hn = hd = hc = None
+    if history is not None and len(history) == 6:  # W > 1 ring + tracked window sums folded into the combine pass
+        ring, hd, hc, W, acc, wsum = history
+        _abi.call("cc_decode_attn_gqa_ring", _ptr(q), _ptr(k), _ptr(v), _ptr(m), HQ, H, S, D, _DT[dt], sc, _ptr(y),
+                  _ptr(attn) if return_attn else None, _ptr(ring), _ptr(hd), _ptr(hc), W, _ptr(acc), _ptr(wsum), _ptr(ws), ws.numel(), _stream())
+        return y, attn if return_attn else None
     if history is not None:
         hn, hd, hc = history
     _abi.call("cc_decode_attn_gqa", _ptr(q), _ptr(k), _ptr(v), _ptr(m), HQ, H, S, D, _DT[dt], sc, _ptr(y), _ptr(attn),

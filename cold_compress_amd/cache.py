@@ -415,7 +415,7 @@ class _TrackedWindowSums:
         words = int(_abi.lib()["cc_hh_ring_acc_words"](H, S, int(self.history_window_size), _DT[self.attn_history_num.dtype]))
         self.register_buffer("attn_window_acc", torch.zeros(words, dtype=torch.int64), persistent=False)
         self.register_buffer("attn_window_sum", torch.zeros((H, S), dtype=torch.float32), persistent=False)
-        self._ring_version = None
+        self._ring_version = self._ring_tag()  # all-zero state of an all-zero ring
 
     def _ring_tag(self):
         r = self.attn_history_num
@@ -527,9 +527,11 @@ class KVCacheHeavyHitter(_TrackedWindowSums, KVCacheHeadSpecific):
                       int(self.global_tokens), int(self.recent_window), _ptr(self._idx_buf()), _ptr(wsum), _ptr(acc), _stream())
 
     def fused_history(self):
-        """Pointers the decode attention kernel needs to fold cache.py:690-723 into its combine pass (W == 1 only)."""
+        """What the decode attention kernel needs to fold cache.py:690-723 into its combine pass: (num, denom, counter)
+        for the W == 1 accumulator, (ring, denom, counter, W, acc, wsum) for the W > 1 ring with tracked window sums."""
         if self.history_window_size != 1:
-            return None
+            wsum, acc = self._window_state()
+            return self.attn_history_num, self.attn_history_denom, self.attn_counter, int(self.history_window_size), acc, wsum
         return self.attn_history_num, self.attn_history_denom, self.attn_counter
 
     def _apply(self, attn_hs, T):
@@ -622,6 +624,7 @@ class KVCacheHybrid(_TrackedWindowSums, KVCacheHeadSpecific):
         self.requires_heavy_hitter = self._init_requires_heavy_hitter()
         self.cache_strategies = None
         self._table = None
+        self._state_fused = False  # set by the attention op when its combine pass already recorded this step's attention
         self._init_window_state()
 
     # ------------------------------------------------------------------ small helpers
@@ -704,8 +707,19 @@ class KVCacheHybrid(_TrackedWindowSums, KVCacheHeadSpecific):
                   _ptr(attn_ht), self.n_heads, self.max_cache_length, T, self.history_window_size,
                   _DT[self.k_cache.dtype], _ptr(acc), _ptr(wsum), _stream())
 
+    def fused_history(self):
+        """The ring update of cache.py:1283-1286 folded into the decode attention's combine pass (None: no head scores by
+        accumulated attention, nothing to record)."""
+        if not self.requires_heavy_hitter:
+            return None
+        wsum, acc = self._window_state()
+        return self.attn_history_num, self.attn_history_denom, self.attn_counter, int(self.history_window_size), acc, wsum
+
     def update_state(self, input_pos, k_val, v_val, is_prefill, attn, **kwargs):
         """ref: cache.py:1274-1288."""
+        if not is_prefill and self._state_fused:
+            self._state_fused = False
+            return
         if is_prefill:
             self.profile_and_update(input_pos, k_val, v_val, attn, **kwargs)
         elif self.requires_heavy_hitter:

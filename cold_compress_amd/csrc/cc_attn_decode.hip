@@ -18,6 +18,7 @@
 //   update (cache.py:690-723) in the same pass.
 // HBM-bound: ~1 flop/byte, no MFMA.
 #include "cc_common.h"
+#include "cc_wacc.h"
 
 namespace {
 
@@ -134,10 +135,17 @@ struct SplitArgs {
   double* num;         // [H, S]
   int32_t* denom;      // [H, S]
   int H, Hc, Hp;  // Hp == 1: head-constant policy (one pos row, one key row shared by every kv head)
+  // ---- ring history folded into the combine pass (history_window_size W > 1): this launch publishes the ring column
+  //      of the step, *ring_counter % W, so that the combine launch may bump the counter without a reader racing it
+  const int64_t* ring_counter;
+  int* ring_col;
+  int ring_W;
 };
 
 template <typename T, int D, int RT, int NW, int U>
 __global__ __launch_bounds__(NW * 64) void decode_attn_split_kernel(SplitArgs a) {
+  if (a.ring_col && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0)
+    *a.ring_col = (int)(*a.ring_counter % a.ring_W);
   constexpr int VEC = 16 / (int)sizeof(T);
   constexpr int LPR = D / VEC;
   static_assert(LPR >= 1 && LPR <= 64 && (LPR & (LPR - 1)) == 0, "head_dim must map to a power-of-two lane count");
@@ -455,6 +463,8 @@ template <typename T, int RT, int NW>
 __global__ __launch_bounds__(NW * 64) void decode_attn_split_mfma_kernel(SplitArgs a) {
   static_assert(sizeof(T) == 2 && (RT == 1 || RT == 2 || RT == 4), "16-bit caches, up to 4 query heads per pass");
   constexpr int D = 128, VEC = 8, RPW = 4, U = 4;
+  if (a.ring_col && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0)
+    *a.ring_col = (int)(*a.ring_counter % a.ring_W);
   __shared__ __attribute__((aligned(16))) uint4 sm_k[NW][16][16];  // [wave][tile row i][slot]: 4 KiB per wave
   __shared__ __attribute__((aligned(16))) uint4 sm_v[NW][16][16];  // [wave][tile row][chunk ^ 2*(row & 7)]: V tile, row major
 
@@ -726,6 +736,12 @@ struct CombineArgs {
   int policy;  // next-eviction scoring: 1 = heavy hitter (cache.py:727-749), 2 = recent_global / full (cache.py:500-502, 552-556),
                // 3 = random (cache.py:519-524 over rand_next)
   const float* rand_next;  // policy 3: [S] uniform draws for position p + 1
+  // ---- ring history (history_window_size W > 1, cache.py:716-723) folded into this pass, tracked window sums included
+  void* ring_num;        // [H, S, W] T or null
+  const int* ring_col;   // the step's ring column, published by the streaming pass of the same call
+  int ring_W;
+  u64* ring_acc;         // tracked state (include/coldcompress.h): accumulators, tickets, column-major shadow
+  float* ring_wsum;      // [H, S]
   int Hp;
   int abl;  // measurement-only ablation bits (phases >> 8): 8 = no next-key epilogue, 16 = no y merge, 32 = no per-slot pass
 };
@@ -764,6 +780,21 @@ __global__ __launch_bounds__(kCombThreads) void decode_attn_combine_kernel(Combi
   }
   float rnd_mine = 0.f;
   if (a.next_key && a.policy == 3) rnd_mine = a.rand_next[s_ld];
+  // ring history (W > 1): the entry this step overwrites (from the column-major shadow) and the slot's exact accumulator
+  int ring_col = 0;
+  float ring_old = 0.f;
+  WAcc racc{0, 0, 0, 0};
+  T* ring_shadow = nullptr;
+  if (a.ring_num) {
+    const size_t hs = (size_t)gridDim.y * S, i = (size_t)h * S + s_ld;
+    ring_col = *a.ring_col;
+    ring_shadow = reinterpret_cast<T*>(a.ring_acc + hs * 4 + 2) + (size_t)ring_col * hs;
+    ring_old = ElemTraits<T>::load(ring_shadow, i);
+    const ulonglong2 a01 = *reinterpret_cast<const ulonglong2*>(a.ring_acc + i * 4);
+    const ulonglong2 a23 = *reinterpret_cast<const ulonglong2*>(a.ring_acc + i * 4 + 2);
+    racc = WAcc{a01.x, a01.y, a23.x, a23.y};
+    den_old = a.hh_denom[i];
+  }
   unsigned long long my_key = ~0ull;
   // y: the R*D outputs of this kv head are spread over the chunk blocks; inside a block the (output, split)
   // products are spread over ALL threads (G split-groups per output).  The first 8 partial-O values of every
@@ -896,6 +927,16 @@ __global__ __launch_bounds__(kCombThreads) void decode_attn_combine_kernel(Combi
     const float av = ElemTraits<T>::rnd(__fdiv_rn(sum, (float)R));
     const size_t i = (size_t)h * S + s;
     if (a.attn_out) ElemTraits<T>::store(reinterpret_cast<T*>(a.attn_out), i, av);
+    if (a.ring_num) {  // fused cache.py:716-723, W > 1: ring[h, s, counter % W] = attn; denom += 1; window sum kept exact
+      ElemTraits<T>::store(reinterpret_cast<T*>(a.ring_num), i * (size_t)a.ring_W + ring_col, av);
+      ElemTraits<T>::store(ring_shadow, i, av);
+      a.hh_denom[i] = den_old + 1;
+      wacc_add_value(racc, av, false);
+      wacc_add_value(racc, ring_old, true);
+      *reinterpret_cast<ulonglong2*>(a.ring_acc + i * 4) = make_ulonglong2(racc.w0, racc.w1);
+      *reinterpret_cast<ulonglong2*>(a.ring_acc + i * 4 + 2) = make_ulonglong2(racc.w2, racc.special);
+      a.ring_wsum[i] = wacc_round<T>(racc);
+    }
     if (a.hh_num) {  // fused cache.py:716-722 (W == 1, attention already padded to S)
       const double num_new = num_old + (double)av;
       const int32_t den_new = den_old + 1;
@@ -939,7 +980,7 @@ __global__ __launch_bounds__(kCombThreads) void decode_attn_combine_kernel(Combi
       __syncthreads();
       y_final(y_nout, y_G, y_oi, y_g, y_r, y_d);
     }
-  if (a.hh_num && a.hh_counter && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *a.hh_counter += 1;
+  if ((a.hh_num || a.ring_num) && a.hh_counter && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *a.hh_counter += 1;
 }
 
 // ---------------------------------------------------------------- launch plan
@@ -1032,7 +1073,7 @@ size_t cc_decode_attn_workspace_bytes(int32_t HQ, int32_t H, int32_t S, int32_t 
   if (HQ <= 0 || H <= 0 || HQ % H || S <= 0 || D <= 0 || !cc_dt_ok(dtype)) return 0;
   const Plan p = make_plan(HQ, H, S, D, dtype);
   return align256((size_t)HQ * S * cc_dt_size(dtype)) + align256((size_t)HQ * p.n_split * 2 * sizeof(float)) +
-         align256((size_t)HQ * p.n_split * D * sizeof(float));
+         align256((size_t)HQ * p.n_split * D * sizeof(float)) + 256;  // + the ring column word of the fused W > 1 history
 }
 
 }  // extern "C"
@@ -1049,12 +1090,20 @@ struct FusedStep {
   int policy;  // 1 = heavy hitter, 2 = recent_global / full, 3 = random
   const float* rand_next;
 };
+// The W > 1 history ring folded into the combine pass (denom / counter travel as hh_denom / hh_counter).
+struct RingHistory {
+  void* num;
+  int W;
+  uint64_t* acc;
+  float* wsum;
+};
 }  // namespace
 
 static int attn_impl(const void* q, const void* k, const void* v, const uint8_t* mask, int32_t HQ, int32_t H,
                      int32_t S, int32_t D, int32_t dtype, float scale, void* y, void* attn_out,
                      void* probs_out, double* hh_num, int32_t* hh_denom, int64_t* hh_counter,
-                     void* workspace, size_t workspace_bytes, cc_stream_t stream, int32_t phases, const FusedStep* fs) {
+                     void* workspace, size_t workspace_bytes, cc_stream_t stream, int32_t phases, const FusedStep* fs,
+                     const RingHistory* rh = nullptr) {
   CC_ENTRY();
   if (!q || !k || !v || !y || HQ <= 0 || H <= 0 || HQ % H || S <= 0 || D <= 0 || !cc_dt_ok(dtype) || !workspace)
     return CC_ERR_BAD_ARG;
@@ -1073,6 +1122,11 @@ static int attn_impl(const void* q, const void* k, const void* v, const uint8_t*
   sa.part_ml = reinterpret_cast<float*>(ws);
   ws += align256((size_t)HQ * p.n_split * 2 * sizeof(float));
   sa.part_o = reinterpret_cast<float*>(ws);
+  ws += align256((size_t)HQ * p.n_split * D * sizeof(float));
+  if (rh) {
+    if (!rh->num || rh->W <= 1 || !rh->acc || !rh->wsum || !hh_denom || !hh_counter || hh_num) return CC_ERR_BAD_ARG;
+    sa.ring_counter = hh_counter; sa.ring_col = reinterpret_cast<int*>(ws); sa.ring_W = rh->W;
+  }
   sa.S = S; sa.R = R; sa.n_split = p.n_split; sa.rows_per_split = p.rows_per_split; sa.scale = scale;
   sa.abl = (phases >> 8) & 0xff;
   if (fs) {
@@ -1095,6 +1149,10 @@ static int attn_impl(const void* q, const void* k, const void* v, const uint8_t*
   ca.scores = sa.scores; ca.part_ml = sa.part_ml; ca.part_o = sa.part_o;
   ca.y = y; ca.attn_out = attn_out; ca.probs_out = probs_out;
   ca.hh_num = hh_num; ca.hh_denom = hh_denom; ca.hh_counter = hh_counter;
+  if (rh) {
+    ca.ring_num = rh->num; ca.ring_col = sa.ring_col; ca.ring_W = rh->W;
+    ca.ring_acc = reinterpret_cast<u64*>(rh->acc); ca.ring_wsum = rh->wsum;
+  }
   ca.S = S; ca.R = R; ca.D = D; ca.n_split = p.n_split; ca.chunk = p.chunk;
   if (fs) {
     ca.next_key = fs->next_key; ca.input_pos = fs->input_pos; ca.pos = fs->c->pos; ca.H = H; ca.g = fs->g; ca.w = fs->w;
@@ -1163,6 +1221,15 @@ int cc_decode_step_random(const cc_kv_view* c, const void* q, const void* k_new,
   FusedStep fs{c, k_new, v_new, input_pos, reinterpret_cast<unsigned long long*>(next_key), global_tokens, recent_window, 3, rand_next};
   return attn_impl(q, c->k_cache, c->v_cache, c->mask, HQ, c->H, c->S, c->D, c->dtype, scale, y, nullptr, nullptr, nullptr, nullptr,
                    nullptr, workspace, workspace_bytes, stream, 3, &fs);
+}
+
+int cc_decode_attn_gqa_ring(const void* q, const void* k, const void* v, const uint8_t* mask, int32_t HQ, int32_t H, int32_t S,
+                            int32_t D, int32_t dtype, float scale, void* y, void* attn_out, void* ring_num, int32_t* denom,
+                            int64_t* counter, int32_t W, uint64_t* wsum_acc, float* wsum, void* workspace,
+                            size_t workspace_bytes, cc_stream_t stream) {
+  RingHistory rh{ring_num, W, wsum_acc, wsum};
+  return attn_impl(q, k, v, mask, HQ, H, S, D, dtype, scale, y, attn_out, nullptr, nullptr, denom, counter, workspace,
+                   workspace_bytes, stream, 3, nullptr, &rh);
 }
 
 int cc_decode_attn_gqa(const void* q, const void* k, const void* v, const uint8_t* mask, int32_t HQ, int32_t H,

@@ -18,7 +18,7 @@ from torch import Tensor
 
 from . import glue
 from ..attention_utils import scaled_dot_product_attention
-from ..cache import KVCacheFull, KVCacheHeavyHitter, KVCacheRandom, KVCacheRecentGlobal, get_cache_constructor
+from ..cache import KVCacheFull, KVCacheHeavyHitter, KVCacheHybrid, KVCacheRandom, KVCacheRecentGlobal, get_cache_constructor
 from ..prompt_compression import get_prompt_compressor_constructor
 
 
@@ -168,10 +168,12 @@ class Attention(nn.Module):
             y = cache.decode_step(q, k, v, input_pos)
         elif not is_prefill:
             kc, vc, kv_mask = cache.update_kv(input_pos, k, v, False, **ck)  # insert first, then attend
-            fuse = (self.fuse_state_update and type(cache) is KVCacheHeavyHitter and cache.fused_history() is not None)
+            hist = cache.fused_history() if (self.fuse_state_update and type(cache) in (KVCacheHeavyHitter, KVCacheHybrid)
+                                             and attn_top_k == 1.0) else None
+            fuse = hist is not None
             y, attn = scaled_dot_product_attention(
                 q, kc, vc, attn_mask=kv_mask, attn_top_k=attn_top_k, return_attn=cache.return_attn() and not fuse,
-                group_mean=True, history=cache.fused_history() if fuse else None)
+                group_mean=True, history=hist)
             if fuse:
                 cache._state_fused = True
             cache.update_state(input_pos, k, v, False, attn, **ck)

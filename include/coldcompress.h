@@ -160,6 +160,15 @@ int cc_decode_attn_gqa(const void* q, const void* k, const void* v, const uint8_
                        int64_t* hh_counter, void* workspace, size_t workspace_bytes,
                        cc_stream_t stream);
 
+/* The same attention with the W > 1 history ring folded into the combine pass (cf. hh_num/hh_denom/hh_counter above,
+ * which fold the W == 1 history): ring[h, s, *counter % W] = group-mean attention; denom += 1; *counter += 1
+ * (ref: cache.py:716-723), and the tracked window-sum state (wsum_acc / wsum, see cc_hh_ring_update) kept current.
+ * Equivalent to cc_decode_attn_gqa(attn_out) followed by cc_hh_ring_update(attn = attn_out, T = S, tracked). */
+int cc_decode_attn_gqa_ring(const void* q, const void* k, const void* v, const uint8_t* mask, int32_t HQ, int32_t H,
+                            int32_t S, int32_t D, int32_t dtype, float scale, void* y, void* attn_out, void* ring_num,
+                            int32_t* denom, int64_t* counter, int32_t W, uint64_t* wsum_acc, float* wsum,
+                            void* workspace, size_t workspace_bytes, cc_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Fused heavy-hitter decode step (history_window_size == 1): update_kv + attention + update_state of one layer
  * in TWO launches instead of three.  Same reference lines as cc_decode_update_heavy_hitter, cc_decode_attn_gqa

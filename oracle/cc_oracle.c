@@ -966,6 +966,20 @@ int cc_hh_ring_update_cpu(void* num, int32_t* denom, int64_t* counter, const voi
   return CC_OK;
 }
 
+/* ref: model.py:399-418 + cache.py:716-723 — attention, then the W > 1 history update from its group-mean output */
+int cc_decode_attn_gqa_ring_cpu(const void* q, const void* k, const void* v, const uint8_t* mask, int32_t HQ, int32_t H, int32_t S,
+                                int32_t D, int32_t dtype, float scale, void* y, void* attn_out, void* ring_num, int32_t* denom,
+                                int64_t* counter, int32_t W, uint64_t* wsum_acc, float* wsum, void* workspace,
+                                size_t workspace_bytes, cc_stream_t stream) {
+  if (!ring_num || !denom || !counter || W <= 1 || !wsum_acc || !wsum) return CC_ERR_BAD_ARG;
+  void* attn = attn_out ? attn_out : malloc((size_t)H * S * dt_size(dtype));
+  int rc = cc_decode_attn_gqa_cpu(q, k, v, mask, HQ, H, S, D, dtype, scale, y, attn, NULL, NULL, NULL, NULL, workspace, workspace_bytes,
+                                  stream);
+  if (rc == CC_OK) rc = cc_hh_ring_update_cpu(ring_num, denom, counter, attn, H, S, S, W, dtype, wsum_acc, wsum, stream);
+  if (!attn_out) free(attn);
+  return rc;
+}
+
 int cc_attn_bandsum_cpu(const void* attn, int32_t H, int32_t Lq, int32_t Lk, int32_t dtype, int32_t band, float* out,
                         cc_stream_t stream) {
   (void)stream;

@@ -203,3 +203,58 @@ def test_random_fused_replay_vs_reference():
     assert torch.equal(kv.cache_cts.cpu(), f["final_cts"])
     assert torch.equal(kv.k_cache.cpu().view(torch.int16), f["final_k"].view(torch.int16))
     assert torch.equal(kv.v_cache.cpu().view(torch.int16), f["final_v"].view(torch.int16))
+
+
+@pytest.mark.parametrize("strategy,dtype,H,HQ,S,D,T,W", [("heavy_hitter", torch.bfloat16, 8, 32, 1024, 128, 1000, 8),
+                                                         ("heavy_hitter", torch.float32, 2, 4, 77, 16, 70, 3),
+                                                         ("hybrid", torch.bfloat16, 5, 20, 640, 128, 600, 400)])
+def test_ring_history_folded_into_combine(strategy, dtype, H, HQ, S, D, T, W):
+    """history_window_size > 1 (and the hybrid cache's W = 400 ring): attention with the ring update folded into its
+    combine pass (cc_decode_attn_gqa_ring) against attention -> update_state; every buffer, the tracked window sums
+    included, bit for bit over appends and evictions."""
+    import cold_compress_amd.cache as cache
+    from cold_compress_amd.attention_utils import scaled_dot_product_attention as sdpa
+
+    cls, rk = cache.get_cache_constructor(strategy)
+    hyb = [{"strategy": "special"}, {"strategy": "special_punc"}, {"strategy": "special_punc_heavy_hitter", "heavy_hitter_frac": 0.3},
+           {"strategy": "special_punc_window", "recent_window": 0.3}, {"strategy": "full"}]
+    kw = dict(max_cache_length=S, global_tokens=4, recent_window=10, history_window_size=W, attn_thresholding=False,
+              max_seq_length=4 * S, cache_bits=None, token_ids={"special": [[1], [2, 3]], "punctuation": [5, 6, 7]},
+              min_recovery_frac=0.9, hybrid_strategies=hyb)
+
+    def mk():
+        with torch.device(DEV):
+            kv = cls(1, H, D, dtype, **{k: kw[k] for k in rk})
+        return kv
+
+    a, b = mk(), mk()
+    gen = torch.Generator().manual_seed(21)
+    k0 = torch.randn(1, H, T, D, generator=gen).to(dtype).to(DEV)
+    v0 = torch.randn(1, H, T, D, generator=gen).to(dtype).to(DEV)
+    for kv in (a, b):
+        kv.update_kv(torch.arange(T, device=DEV), k0, v0, True, input_ids=torch.zeros(T, dtype=torch.int64, device=DEV))
+        if strategy == "hybrid":  # a decode-ready state without the profiling pass: head h runs policy h % 5
+            kv.cache_strategies = (torch.arange(H, device=DEV) % len(hyb)).to(torch.int64).contiguous()
+            kv.requires_heavy_hitter = True
+            kv.cache_cts.fill_(T)
+            kv.mask[..., :T] = True
+            kv.pos[0, :, :T] = torch.arange(T, device=DEV, dtype=kv.pos.dtype)
+    for t in range(2 * min(W, 12) + 3):
+        p = torch.tensor([T + t], dtype=torch.int32, device=DEV)
+        ids = torch.tensor([5 if t % 4 == 1 else 9], dtype=torch.int64, device=DEV)
+        k1 = torch.randn(1, H, 1, D, generator=gen).to(dtype).to(DEV)
+        v1 = torch.randn(1, H, 1, D, generator=gen).to(dtype).to(DEV)
+        q = torch.randn(1, HQ, 1, D, generator=gen).to(dtype).to(DEV)
+        ka, va, ma = a.update_kv(p, k1, v1, False, input_ids=ids)
+        ya, attn = sdpa(q, ka, va, attn_mask=ma, return_attn=True, group_mean=True)
+        a.update_state(p, k1, v1, False, attn, input_ids=ids)
+        kb, vb, mb = b.update_kv(p, k1, v1, False, input_ids=ids)
+        hist = b.fused_history()
+        assert hist is not None and len(hist) == 6
+        yb, _ = sdpa(q, kb, vb, attn_mask=mb, group_mean=True, history=hist)
+        b._state_fused = True
+        b.update_state(p, k1, v1, False, None, input_ids=ids)
+        torch.cuda.synchronize()
+        assert torch.equal(ya, yb), f"step {t}: attention output"
+        for (na, ta), (nb, tb) in zip(a.named_buffers(), b.named_buffers()):
+            assert torch.equal(ta, tb), f"step {t}: {na}"

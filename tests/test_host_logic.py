@@ -115,7 +115,8 @@ def test_buffers_and_statistics_on_cpu():
         cache.get_cache_constructor("debug_heavy_hitter")
     ring = cache.KVCacheHeavyHitter(1, 2, 8, torch.bfloat16, **{**kw, "history_window_size": 4})
     assert ring.attn_history_num.shape == (1, 2, 16, 4) and ring.attn_history_num.dtype == torch.bfloat16  # cache.py:661-667
-    assert ring.fused_history() is None
+    hist = ring.fused_history()  # W > 1: ring, denom, counter, W, tracked accumulators, window sums (no launch: state is current)
+    assert len(hist) == 6 and hist[3] == 4 and hist[5].shape == (2, 16) and hist[4].dtype == torch.int64
 
 
 def test_cpu_tensors_refused_no_fallback():

@@ -88,7 +88,7 @@ def main():
             def three_call(i):
                 kv = caches[i % n_buf]
                 k, v, m = kv.update_kv(pos, k1, k1, False, input_ids=ids)
-                fuse = strategy == "heavy_hitter"
+                fuse = strategy in ("heavy_hitter", "hybrid")
                 y, a = sdpa(q, k, v, attn_mask=m, return_attn=kv.return_attn() and not fuse, group_mean=True,
                             history=kv.fused_history() if fuse else None)
                 if fuse:
