@@ -156,7 +156,8 @@ def roofline(model, args, dev):
     traffic, traffic_src = None, None
     try:
         with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            k = json.load(f)["kernels"].get("decode_attn_split_mfma_kernel<bf16_t, 4, 4>")
+            ks = json.load(f)["kernels"]
+            k = next((v for n, v in ks.items() if n.startswith("decode_attn_split_mfma_kernel<bf16_t, 4, 4")), None)
         if k and (H, S, D, HQ) == (8, 4096, 128, 32):
             traffic = k["traffic_bytes"]
             traffic_src = ("profiles/r01_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950 wide-read correction) "
@@ -166,7 +167,7 @@ def roofline(model, args, dev):
         pass
     return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-            "kernel": "decode_attn_split_mfma_kernel<bf16_t,4,4>",
+            "kernel": "decode_attn_split_mfma_kernel<bf16_t,4,4,false>",
             "bytes_per_launch": alg, "mean_us": round(mean_us, 3), "median_us": round(us[len(us) // 2], 3),
             "min_us": round(us[0], 3), "launches": len(us) * len(layers), "layer_step_bytes": step_bytes,
             "timing": "HIP events around hipGraph replays of 32 launches (one per layer); per-launch = total/32, "

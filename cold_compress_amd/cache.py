@@ -275,9 +275,9 @@ class _RingFusedStep:
     draw) and consumed by the K/V streaming pass of step p + 1 (cc_decode_step_recent_global / cc_decode_step_random).
     Same contract as KVCacheHeavyHitter.decode_step."""
 
-    def _init_ring_pipeline(self):
+    def _init_ring_pipeline(self, rows=1):
         nk = int(_abi.lib()["cc_hh_next_key_slots"](self.max_cache_length))
-        self.register_buffer("next_key", torch.full((1, nk), -1, dtype=torch.int64), persistent=False)
+        self.register_buffer("next_key", torch.full((rows, nk), -1, dtype=torch.int64), persistent=False)
         self._next_valid = False
 
     def supports_fused_step(self):
@@ -376,8 +376,10 @@ class KVCacheRecentGlobal(_RingFusedStep, KVCacheHeadConstant):
                   int(self.global_tokens), _ptr(self._idx_buf()), _stream())
 
 
-class KVCacheL2(KVCacheHeadSpecific):
-    """ref: cache.py:559-612."""
+class KVCacheL2(_RingFusedStep, KVCacheHeadSpecific):
+    """ref: cache.py:559-612.  Two-launch decode step (cc_decode_step_l2) for 16-bit caches with head_dim 128: the
+    global norm maximum of cache.py:602 is folded across the step boundary (per-wave maxima from the streaming pass +
+    the freshly inserted norms, combined in the combine pass)."""
     relevant_kwargs = ["max_cache_length", "max_seq_length", "cache_bits", "global_tokens", "recent_window"]
 
     def __init__(self, max_batch_size, n_heads, head_dim, dtype=torch.bfloat16, **kwargs):
@@ -388,6 +390,18 @@ class KVCacheL2(KVCacheHeadSpecific):
                 "quantised int8 cache: 'linalg.vector_norm: Expected a floating point ... Got Char'), so there is "
                 "no behaviour to reproduce or pin")
         self.register_buffer("key_norm", torch.zeros((1, n_heads, self.max_cache_length), dtype=dtype))
+        self._init_ring_pipeline(rows=n_heads)
+
+    def supports_fused_step(self):
+        return self.k_cache.dtype in (torch.bfloat16, torch.float16) and self.head_dim == 128
+
+    def _pipeline_init(self, p32):
+        _abi.call("cc_l2_next_key_init", self._view(), _ptr(p32), _ptr(self.key_norm), int(self.global_tokens),
+                  int(self.recent_window), _ptr(self.next_key), _stream())
+
+    def _pipeline_step(self, q, k, v, p32, HQ, scale, y, ws):
+        _abi.call("cc_decode_step_l2", self._view(), _ptr(q), _ptr(k), _ptr(v), _ptr(p32), _ptr(self.key_norm), _ptr(self.next_key),
+                  int(self.global_tokens), int(self.recent_window), HQ, scale, _ptr(y), _ptr(ws), ws.numel(), _stream())
 
     def reset(self):
         super().reset()

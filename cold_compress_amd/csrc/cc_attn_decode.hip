@@ -140,6 +140,12 @@ struct SplitArgs {
   const int64_t* ring_counter;
   int* ring_col;
   int ring_W;
+  // ---- l2 policy in the fused step (matrix-core kernel only): the inserted key's norm is recorded here, and every
+  //      wave publishes the maximum of key_norm over its slots (the evicted slot's old norm excluded), so that the
+  //      combine launch can form the global maximum of cache.py:602 without re-reading [H, S] norms per workgroup
+  void* key_norm;   // [H, S] T
+  float* l2_pmax;   // [H, n_split, NW]
+  float* l2_new;    // [H]
 };
 
 template <typename T, int D, int RT, int NW, int U>
@@ -459,7 +465,7 @@ struct Mfma16x16x16<f16_t> {
   }
 };
 
-template <typename T, int RT, int NW>
+template <typename T, int RT, int NW, bool L2>  // L2: the l2 policy's norm bookkeeping (its own instantiation: the others pay nothing)
 __global__ __launch_bounds__(NW * 64) void decode_attn_split_mfma_kernel(SplitArgs a) {
   static_assert(sizeof(T) == 2 && (RT == 1 || RT == 2 || RT == 4), "16-bit caches, up to 4 query heads per pass");
   constexpr int D = 128, VEC = 8, RPW = 4, U = 4;
@@ -493,6 +499,11 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_split_mfma_kernel(SplitAr
   const int tr_row = 4 * g + (c >> 2);
   const int tr_sw = 2 * (tr_row & 7), tr_qh = (c >> 1) & 1, tr_half = c & 1;
 
+  // l2: this thread's first norm of the block is requested here and examined only after the streaming loop
+  const bool l2_here = L2 && blockIdx.z == 0;
+  const int kn_row0 = row_begin + (int)threadIdx.x;
+  float kn_first = -INFINITY;
+  if (L2 && l2_here && kn_row0 < row_end) kn_first = ElemTraits<T>::load(reinterpret_cast<const T*>(a.key_norm) + (size_t)h * S, kn_row0);
   // ---- every load of the first tile is issued before anything waits (partial keys, q, mask, K, V: use order)
   int ins_idx = -1, ins_was_empty = 0;
   bool key_pending = a.next_key != nullptr && !(a.abl & 128);
@@ -563,6 +574,11 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_split_mfma_kernel(SplitAr
       Vec16<T> kn, vn;
       kn.load(reinterpret_cast<const T*>(a.k_new) + (size_t)h * D + kcol);
       vn.load(reinterpret_cast<const T*>(a.v_new) + (size_t)h * D + c * VEC);
+      float xq[D / 16];  // l2: the new key again, in the canonical norm's element order (same latency window as kn / vn)
+      if (L2) {
+#pragma unroll
+        for (int i = 0; i < D / 16; i++) xq[i] = ElemTraits<T>::load(reinterpret_cast<const T*>(a.k_new) + (size_t)h * D, c + 16 * i);
+      }
       const int32_t p_now = *a.input_pos;
 #pragma unroll
       for (int u = 0; u < U; u++)
@@ -583,6 +599,18 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_split_mfma_kernel(SplitAr
             a.denom[slot] = 0;
           }
           if (ins_was_empty && (a.Hc == a.H || h == 0)) atomicAdd(&a.cache_cts[a.Hc == a.H ? h : 0], 1);
+        }
+        if (L2) {  // l2: cache.py:592-593 — the new key's norm (sumsq_canonical_16's order), model dtype
+          float ss = 0.f;
+#pragma unroll
+          for (int i = 0; i < D / 16; i++) ss = __fadd_rn(ss, __fmul_rn(xq[i], xq[i]));
+#pragma unroll
+          for (int off = 8; off > 0; off >>= 1) ss = __fadd_rn(ss, __shfl_xor(ss, off, 16));
+          if (c == 0) {
+            const float nv = ElemTraits<T>::rnd(__fsqrt_rn(ss));
+            ElemTraits<T>::store(reinterpret_cast<T*>(a.key_norm), slot, nv);
+            a.l2_new[h] = nv;
+          }
         }
       }
     }
@@ -668,6 +696,24 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_split_mfma_kernel(SplitAr
     base = base_next;
     more = more_next;
   }
+  if (L2 && l2_here) {  // publish this wave's maximum over the norms that survive this step
+    if (key_pending) {  // a wave without rows never entered the loop
+      const unsigned long long key = wave_min_u64_uniform(key_part);
+      ins_idx = (key == ~0ull) ? -1 : (int)((key & 0xffffffffull) >> 1);
+    }
+    float v = (kn_row0 == ins_idx) ? -INFINITY : kn_first;  // the evicted slot's old norm is gone
+    bool kn_nan = v != v;
+    for (int r = kn_row0 + NW * 64; r < row_end; r += NW * 64) {  // only beyond 256 slots per workgroup
+      const float x = ElemTraits<T>::load(reinterpret_cast<const T*>(a.key_norm) + (size_t)h * S, r);
+      if (r != ins_idx) {
+        kn_nan |= (x != x);
+        v = fmaxf(v, x);
+      }
+    }
+    v = wave_max_f32(v);
+    const bool nn = __any(kn_nan) != 0;
+    if (lane == 0) a.l2_pmax[((size_t)h * a.n_split + split) * NW + wave] = nn ? NAN : v;
+  }
 
   if (a.abl & 2) {  // measurement only
     float x = l + m;
@@ -736,6 +782,12 @@ struct CombineArgs {
   int policy;  // next-eviction scoring: 1 = heavy hitter (cache.py:727-749), 2 = recent_global / full (cache.py:500-502, 552-556),
                // 3 = random (cache.py:519-524 over rand_next)
   const float* rand_next;  // policy 3: [S] uniform draws for position p + 1
+  // ---- l2 (policy 4, cache.py:597-605): score = dtype(max over all norms - norm); the maximum is folded from the
+  //      per-wave partials of the streaming pass and the H freshly inserted norms
+  const void* key_norm;   // [H, S] T
+  const float* l2_pmax;   // [l2_np]
+  const float* l2_new;    // [H]
+  int l2_np;
   // ---- ring history (history_window_size W > 1, cache.py:716-723) folded into this pass, tracked window sums included
   void* ring_num;        // [H, S, W] T or null
   const int* ring_col;   // the step's ring column, published by the streaming pass of the same call
@@ -780,6 +832,33 @@ __global__ __launch_bounds__(kCombThreads) void decode_attn_combine_kernel(Combi
   }
   float rnd_mine = 0.f;
   if (a.next_key && a.policy == 3) rnd_mine = a.rand_next[s_ld];
+  float kn_mine = 0.f, l2_part = -INFINITY;
+  bool l2_nan = false;
+  if (a.next_key && a.policy == 4) {
+    kn_mine = ElemTraits<T>::load(reinterpret_cast<const T*>(a.key_norm), (size_t)h * S + s_ld);
+    // [H, n_split, 4 waves] partial maxima: one float4 per streaming workgroup, the first four per thread in flight at once
+    const float4* pm4 = reinterpret_cast<const float4*>(a.l2_pmax);
+    const int n4 = a.l2_np >> 2;
+    float4 pq[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int i = threadIdx.x + u * kCombThreads;
+      pq[u] = i < n4 ? pm4[i] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    }
+    const float nw = threadIdx.x < a.H ? a.l2_new[threadIdx.x] : -INFINITY;
+    auto fold = [&](float v) {
+      l2_nan |= (v != v);
+      l2_part = fmaxf(l2_part, v);
+    };
+#pragma unroll
+    for (int u = 0; u < 4; u++) { fold(pq[u].x); fold(pq[u].y); fold(pq[u].z); fold(pq[u].w); }
+    fold(nw);
+    for (int i = threadIdx.x + 4 * kCombThreads; i < n4; i += kCombThreads) {
+      const float4 q4 = pm4[i];
+      fold(q4.x); fold(q4.y); fold(q4.z); fold(q4.w);
+    }
+    for (int i = kCombThreads + threadIdx.x; i < a.H; i += kCombThreads) fold(a.l2_new[i]);
+  }
   // ring history (W > 1): the entry this step overwrites (from the column-major shadow) and the slot's exact accumulator
   int ring_col = 0;
   float ring_old = 0.f;
@@ -857,6 +936,12 @@ __global__ __launch_bounds__(kCombThreads) void decode_attn_combine_kernel(Combi
       sm_M[r] = Mu;
       sm_L[r] = L;
     }
+  }
+  __shared__ float sm_l2[kCombThreads / 64];
+  if (a.next_key && a.policy == 4) {  // l2: global maximum of the norms (torch.max propagates NaN)
+    const float wm = wave_max_f32(l2_part);
+    const bool nn = __any(l2_nan) != 0;
+    if (lane == 0) sm_l2[wave] = nn ? NAN : wm;
   }
   __syncthreads();
 
@@ -952,6 +1037,21 @@ __global__ __launch_bounds__(kCombThreads) void decode_attn_combine_kernel(Combi
   }
   if (a.next_key && a.policy == 2 && have && h == 0 && s_mine >= a.g)  // arg-min of pos over the slots behind the sinks; -1 = empty first
     my_key = make_key(orderable_i32(ps_mine), ((uint32_t)s_mine << 1) | (uint32_t)(ps_mine == -1));
+  if (a.next_key && a.policy == 4 && have) {  // ref: cache.py:597-605: dtype(max - norm), recent window -> +inf, base rules
+    float gm = -INFINITY;
+    bool gn = false;
+#pragma unroll
+    for (int w2 = 0; w2 < kCombThreads / 64; w2++) {
+      const float v = sm_l2[w2];
+      gn |= (v != v);
+      gm = fmaxf(gm, v);
+    }
+    float scn = ElemTraits<T>::rnd((gn ? NAN : gm) - kn_mine);
+    if (ps_mine >= p_next - a.w) scn = INFINITY;
+    if (s_mine < a.g) scn = INFINITY;
+    if (ps_mine == -1) scn = -INFINITY;
+    my_key = make_key(orderable_f32(scn), ((uint32_t)s_mine << 1) | (uint32_t)(ps_mine == -1));
+  }
   if (a.next_key && a.policy == 3 && have && h == 0) {  // ref: cache.py:523 recent window -> +inf, then the base rules :373-376
     float scn = rnd_mine;
     if (ps_mine >= p_next - a.w) scn = INFINITY;
@@ -1046,10 +1146,18 @@ static int launch_split(const SplitArgs& a, const Plan& p, int H, int R, int D, 
     if (D == 128 && !(a.abl & 32)) {  // matrix-core streaming pass (abl bit 32 = measurement: force the VALU kernel)
       static_assert(kU == 4, "the MFMA tile is 4 row groups x 4 rows per wave");
       dim3 grid(p.n_split, H, R / p.rt), block(kNW * 64);
-      switch (p.rt) {
-        case 4: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 4, kNW>), grid, block, 0, st, a); break;
-        case 2: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 2, kNW>), grid, block, 0, st, a); break;
-        default: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 1, kNW>), grid, block, 0, st, a); break;
+      if (a.key_norm != nullptr) {
+        switch (p.rt) {
+          case 4: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 4, kNW, true>), grid, block, 0, st, a); break;
+          case 2: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 2, kNW, true>), grid, block, 0, st, a); break;
+          default: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 1, kNW, true>), grid, block, 0, st, a); break;
+        }
+      } else {
+        switch (p.rt) {
+          case 4: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 4, kNW, false>), grid, block, 0, st, a); break;
+          case 2: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 2, kNW, false>), grid, block, 0, st, a); break;
+          default: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 1, kNW, false>), grid, block, 0, st, a); break;
+        }
       }
       CC_LAUNCH_CHECK();
       return CC_OK;
@@ -1073,7 +1181,8 @@ size_t cc_decode_attn_workspace_bytes(int32_t HQ, int32_t H, int32_t S, int32_t 
   if (HQ <= 0 || H <= 0 || HQ % H || S <= 0 || D <= 0 || !cc_dt_ok(dtype)) return 0;
   const Plan p = make_plan(HQ, H, S, D, dtype);
   return align256((size_t)HQ * S * cc_dt_size(dtype)) + align256((size_t)HQ * p.n_split * 2 * sizeof(float)) +
-         align256((size_t)HQ * p.n_split * D * sizeof(float)) + 256;  // + the ring column word of the fused W > 1 history
+         align256((size_t)HQ * p.n_split * D * sizeof(float)) + 256 +  // + the ring column word of the fused W > 1 history
+         align256(((size_t)H * p.n_split * kNW + H) * sizeof(float));   // + the l2 policy's partial maxima and new norms
 }
 
 }  // extern "C"
@@ -1087,8 +1196,9 @@ struct FusedStep {
   const int32_t* input_pos;
   unsigned long long* next_key;
   int g, w;
-  int policy;  // 1 = heavy hitter, 2 = recent_global / full, 3 = random
+  int policy;  // 1 = heavy hitter, 2 = recent_global / full, 3 = random, 4 = l2
   const float* rand_next;
+  void* key_norm;  // policy 4
 };
 // The W > 1 history ring folded into the combine pass (denom / counter travel as hh_denom / hh_counter).
 struct RingHistory {
@@ -1129,6 +1239,12 @@ static int attn_impl(const void* q, const void* k, const void* v, const uint8_t*
   }
   sa.S = S; sa.R = R; sa.n_split = p.n_split; sa.rows_per_split = p.rows_per_split; sa.scale = scale;
   sa.abl = (phases >> 8) & 0xff;
+  if (fs && fs->policy == 4) {
+    if (!fs->key_norm || cc_dt_size(dtype) != 2 || D != 128 || ((phases >> 8) & 32)) return CC_ERR_UNSUPPORTED;
+    sa.key_norm = fs->key_norm;
+    sa.l2_pmax = reinterpret_cast<float*>(ws + 256);
+    sa.l2_new = sa.l2_pmax + (size_t)H * p.n_split * kNW;
+  }
   if (fs) {
     sa.next_key = fs->next_key; sa.nk = p.n_chunks; sa.input_pos = fs->input_pos; sa.k_new = fs->k_new; sa.v_new = fs->v_new;
     sa.pos = fs->c->pos; sa.mask_w = fs->c->mask; sa.cache_cts = fs->c->cache_cts; sa.num = hh_num; sa.denom = hh_denom;
@@ -1157,6 +1273,7 @@ static int attn_impl(const void* q, const void* k, const void* v, const uint8_t*
   if (fs) {
     ca.next_key = fs->next_key; ca.input_pos = fs->input_pos; ca.pos = fs->c->pos; ca.H = H; ca.g = fs->g; ca.w = fs->w;
     ca.policy = fs->policy; ca.Hp = fs->c->Hp; ca.rand_next = fs->rand_next;
+    ca.key_norm = sa.key_norm; ca.l2_pmax = sa.l2_pmax; ca.l2_new = sa.l2_new; ca.l2_np = H * p.n_split * kNW;
   }
   ca.abl = (phases >> 8) & 0xff;
   dim3 grid(p.n_chunks, H), block(kCombThreads);
@@ -1196,7 +1313,7 @@ int cc_decode_step_heavy_hitter_phases(const cc_kv_view* c, const void* q, const
   if (!cc_view_ok(c) || !q || !k_new || !v_new || !input_pos || !num || !denom || !next_key || !y || c->Hp != c->H ||
       HQ <= 0 || HQ % c->H)
     return CC_ERR_BAD_ARG;
-  FusedStep fs{c, k_new, v_new, input_pos, reinterpret_cast<unsigned long long*>(next_key), global_tokens, recent_window, 1, nullptr};
+  FusedStep fs{c, k_new, v_new, input_pos, reinterpret_cast<unsigned long long*>(next_key), global_tokens, recent_window, 1, nullptr, nullptr};
   return attn_impl(q, c->k_cache, c->v_cache, c->mask, HQ, c->H, c->S, c->D, c->dtype, scale, y, attn_out, nullptr, num, denom,
                    counter, workspace, workspace_bytes, stream, phases, &fs);
 }
@@ -1207,7 +1324,7 @@ int cc_decode_step_recent_global(const cc_kv_view* c, const void* q, const void*
   if (!cc_view_ok(c) || !q || !k_new || !v_new || !input_pos || !next_key || !y || c->Hp != 1 || HQ <= 0 || HQ % c->H ||
       global_tokens < 0 || global_tokens >= c->S)
     return CC_ERR_BAD_ARG;
-  FusedStep fs{c, k_new, v_new, input_pos, reinterpret_cast<unsigned long long*>(next_key), global_tokens, 0, 2, nullptr};
+  FusedStep fs{c, k_new, v_new, input_pos, reinterpret_cast<unsigned long long*>(next_key), global_tokens, 0, 2, nullptr, nullptr};
   return attn_impl(q, c->k_cache, c->v_cache, c->mask, HQ, c->H, c->S, c->D, c->dtype, scale, y, nullptr, nullptr, nullptr, nullptr,
                    nullptr, workspace, workspace_bytes, stream, 3, &fs);
 }
@@ -1218,7 +1335,19 @@ int cc_decode_step_random(const cc_kv_view* c, const void* q, const void* k_new,
   if (!cc_view_ok(c) || !q || !k_new || !v_new || !input_pos || !rand_next || !next_key || !y || c->Hp != 1 || HQ <= 0 ||
       HQ % c->H || global_tokens < 0)
     return CC_ERR_BAD_ARG;
-  FusedStep fs{c, k_new, v_new, input_pos, reinterpret_cast<unsigned long long*>(next_key), global_tokens, recent_window, 3, rand_next};
+  FusedStep fs{c, k_new, v_new, input_pos, reinterpret_cast<unsigned long long*>(next_key), global_tokens, recent_window, 3, rand_next, nullptr};
+  return attn_impl(q, c->k_cache, c->v_cache, c->mask, HQ, c->H, c->S, c->D, c->dtype, scale, y, nullptr, nullptr, nullptr, nullptr,
+                   nullptr, workspace, workspace_bytes, stream, 3, &fs);
+}
+
+int cc_decode_step_l2(const cc_kv_view* c, const void* q, const void* k_new, const void* v_new, const int32_t* input_pos,
+                      void* key_norm, uint64_t* next_key, int32_t global_tokens, int32_t recent_window, int32_t HQ, float scale,
+                      void* y, void* workspace, size_t workspace_bytes, cc_stream_t stream) {
+  if (!cc_view_ok(c) || !q || !k_new || !v_new || !input_pos || !key_norm || !next_key || !y || c->Hp != c->H || HQ <= 0 ||
+      HQ % c->H || global_tokens < 0)
+    return CC_ERR_BAD_ARG;
+  FusedStep fs{c, k_new, v_new, input_pos, reinterpret_cast<unsigned long long*>(next_key), global_tokens, recent_window, 4, nullptr,
+               key_norm};
   return attn_impl(q, c->k_cache, c->v_cache, c->mask, HQ, c->H, c->S, c->D, c->dtype, scale, y, nullptr, nullptr, nullptr, nullptr,
                    nullptr, workspace, workspace_bytes, stream, 3, &fs);
 }

@@ -371,6 +371,18 @@ int cc_decode_update_l2(const cc_kv_view* c, const void* k_new, const void* v_ne
   return launch_update<P_L2>(c, a, (hipStream_t)stream);
 }
 
+int cc_l2_next_key_init(const cc_kv_view* c, const int32_t* input_pos, void* key_norm, int32_t g, int32_t w, uint64_t* next_key,
+                        cc_stream_t stream) {
+  CC_ENTRY();
+  if (!cc_view_ok(c) || !input_pos || !key_norm || !next_key || c->Hp != c->H || g < 0) return CC_ERR_BAD_ARG;
+  UpdArgs a{};
+  a.input_pos = input_pos; a.g = g; a.w = w;
+  a.key_norm = key_norm;
+  a.key_out = reinterpret_cast<unsigned long long*>(next_key);
+  a.nk = cc_next_key_slots(c->S);
+  return launch_update<P_L2>(c, a, (hipStream_t)stream);
+}
+
 int cc_decode_update_heavy_hitter(const cc_kv_view* c, const void* k_new, const void* v_new,
                                   const int32_t* input_pos, double* num, int32_t* denom, int32_t g, int32_t w,
                                   int64_t* idx_out, cc_stream_t stream) {

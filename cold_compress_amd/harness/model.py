@@ -18,7 +18,7 @@ from torch import Tensor
 
 from . import glue
 from ..attention_utils import scaled_dot_product_attention
-from ..cache import KVCacheFull, KVCacheHeavyHitter, KVCacheHybrid, KVCacheRandom, KVCacheRecentGlobal, get_cache_constructor
+from ..cache import KVCacheFull, KVCacheHeavyHitter, KVCacheHybrid, KVCacheL2, KVCacheRandom, KVCacheRecentGlobal, get_cache_constructor
 from ..prompt_compression import get_prompt_compressor_constructor
 
 
@@ -161,7 +161,7 @@ class Attention(nn.Module):
             q, k, v = glue.qkv_rope(self.wqkv(x), freqs_cis, self.n_head, self.n_local_heads, self.head_dim)
         cache = self.kv_cache
         ck = {"input_ids": input_ids}
-        if (not is_prefill and self.fuse_decode_step and type(cache) in (KVCacheHeavyHitter, KVCacheRecentGlobal, KVCacheFull, KVCacheRandom)
+        if (not is_prefill and self.fuse_decode_step and type(cache) in (KVCacheHeavyHitter, KVCacheRecentGlobal, KVCacheFull, KVCacheRandom, KVCacheL2)
                 and cache.supports_fused_step() and attn_top_k == 1.0):
             # two launches per layer: insert folded into the K/V streaming pass, history update + next eviction
             # scoring folded into the combine pass (bit-identical to the three-call sequence below)

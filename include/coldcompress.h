@@ -210,6 +210,17 @@ int cc_decode_step_random(const cc_kv_view* c, const void* q, const void* k_new,
                           const int32_t* input_pos, const float* rand_next, uint64_t* next_key, int32_t global_tokens,
                           int32_t recent_window, int32_t HQ, float scale, void* y, void* workspace,
                           size_t workspace_bytes, cc_stream_t stream);
+/* The same two-launch step for KVCacheL2 (cache.py:559-612: score = dtype(max over ALL heads' and slots' key norms -
+ * norm), recent window -> +inf, base rules; the inserted key's norm recorded, cache.py:592-593).  The global maximum
+ * is folded across the step boundary: the streaming pass publishes per-wave maxima of the surviving norms, the
+ * combine pass folds them with the freshly inserted ones.  16-bit caches with head_dim 128 only (CC_ERR_UNSUPPORTED
+ * otherwise: use cc_decode_update_l2 + cc_decode_attn_gqa).  c->Hp must be H; key_norm: [H, S] model dtype;
+ * next_key: uint64 [H, NK]. */
+int cc_l2_next_key_init(const cc_kv_view* c, const int32_t* input_pos, void* key_norm, int32_t global_tokens,
+                        int32_t recent_window, uint64_t* next_key, cc_stream_t stream);
+int cc_decode_step_l2(const cc_kv_view* c, const void* q, const void* k_new, const void* v_new, const int32_t* input_pos,
+                      void* key_norm, uint64_t* next_key, int32_t global_tokens, int32_t recent_window, int32_t HQ,
+                      float scale, void* y, void* workspace, size_t workspace_bytes, cc_stream_t stream);
 /* Measurement hook (cf. cc_decode_attn_gqa_phases): the same step with its two launches selectable. */
 int cc_decode_step_heavy_hitter_phases(const cc_kv_view* c, const void* q, const void* k_new, const void* v_new,
                                 const int32_t* input_pos, double* num, int32_t* denom, int64_t* counter,

@@ -1153,6 +1153,73 @@ int cc_decode_step_heavy_hitter_cpu(const cc_kv_view* c, const void* q, const vo
   return CC_OK;
 }
 
+/* KVCacheL2 in the same pipeline (ref: cache.py:597-605 + :373-376): the key of the slot head h evicts at position p */
+static float l2_global_max(const cc_kv_view* c, const void* key_norm) {
+  float mx = -INFINITY;
+  int has_nan = 0;
+  for (size_t i = 0; i < (size_t)c->H * c->S; i++) {
+    const float v = ld(key_norm, c->dtype, i);
+    if (v != v) has_nan = 1;
+    if (v > mx) mx = v;
+  }
+  return has_nan ? NAN : mx; /* torch.max propagates NaN */
+}
+static uint64_t l2_key_for_head(const cc_kv_view* c, int h, const void* key_norm, float mx, int32_t p, int32_t g, int32_t w) {
+  uint64_t best = ~(uint64_t)0;
+  for (int s = 0; s < c->S; s++) {
+    const int32_t ps = c->pos[(size_t)h * c->S + s];
+    float v = rnd(mx - ld(key_norm, c->dtype, (size_t)h * c->S + s), c->dtype);
+    if (ps >= p - w) v = INFINITY;
+    if (s < g) v = INFINITY;
+    if (ps == -1) v = -INFINITY;
+    const uint64_t key = ((uint64_t)orderable_f32_host(v) << 32) | ((uint64_t)(uint32_t)s << 1) | (uint64_t)(ps == -1);
+    if (key < best) best = key;
+  }
+  return best;
+}
+
+int cc_l2_next_key_init_cpu(const cc_kv_view* c, const int32_t* input_pos, void* key_norm, int32_t g, int32_t w, uint64_t* next_key,
+                            cc_stream_t stream) {
+  (void)stream;
+  if (!view_ok(c) || !input_pos || !key_norm || !next_key || c->Hp != c->H || g < 0) return CC_ERR_BAD_ARG;
+  const int nk = cc_hh_next_key_slots_cpu(c->S);
+  const float mx = l2_global_max(c, key_norm);
+  for (int h = 0; h < c->H; h++) {
+    for (int i = 1; i < nk; i++) next_key[(size_t)h * nk + i] = ~(uint64_t)0;
+    next_key[(size_t)h * nk] = l2_key_for_head(c, h, key_norm, mx, *input_pos, g, w);
+  }
+  return CC_OK;
+}
+
+int cc_decode_step_l2_cpu(const cc_kv_view* c, const void* q, const void* k_new, const void* v_new, const int32_t* input_pos,
+                          void* key_norm, uint64_t* next_key, int32_t g, int32_t w, int32_t HQ, float scale, void* y, void* workspace,
+                          size_t workspace_bytes, cc_stream_t stream) {
+  if (!view_ok(c) || !q || !k_new || !v_new || !input_pos || !key_norm || !next_key || !y || c->Hp != c->H || g < 0 || c->H > 4096)
+    return CC_ERR_BAD_ARG;
+  if (dt_size(c->dtype) != 2 || c->D != 128) return CC_ERR_UNSUPPORTED;
+  const int nk = cc_hh_next_key_slots_cpu(c->S);
+  int64_t idx[4096];
+  for (int h = 0; h < c->H; h++) {
+    uint64_t key = ~(uint64_t)0;
+    for (int i = 0; i < nk; i++)
+      if (next_key[(size_t)h * nk + i] < key) key = next_key[(size_t)h * nk + i];
+    if (key == ~(uint64_t)0) return CC_ERR_BAD_ARG;
+    idx[h] = (int64_t)((key & 0xffffffffu) >> 1);
+  }
+  insert_token(c, k_new, v_new, *input_pos, idx);
+  for (int h = 0; h < c->H; h++) /* :592-593 */
+    st(key_norm, c->dtype, (size_t)h * c->S + idx[h], sqrtf(sumsq_canonical(k_new, c->dtype, (size_t)h * c->D, c->D)));
+  int rc = cc_decode_attn_gqa_cpu(q, c->k_cache, c->v_cache, c->mask, HQ, c->H, c->S, c->D, c->dtype, scale, y, NULL, NULL, NULL,
+                                  NULL, NULL, workspace, workspace_bytes, stream);
+  if (rc != CC_OK) return rc;
+  const float mx = l2_global_max(c, key_norm);
+  for (int h = 0; h < c->H; h++) {
+    for (int i = 1; i < nk; i++) next_key[(size_t)h * nk + i] = ~(uint64_t)0;
+    next_key[(size_t)h * nk] = l2_key_for_head(c, h, key_norm, mx, *input_pos + 1, g, w);
+  }
+  return CC_OK;
+}
+
 /* KVCacheRandom in the same pipeline (ref: cache.py:505-524 + :373-376): the key of the slot the reference's arg-min picks
  * for position p, from the uniform draw for that position. */
 static uint64_t random_key(const cc_kv_view* c, const float* rand_u, int32_t p, int32_t g, int32_t w) {

@@ -258,3 +258,92 @@ def test_ring_history_folded_into_combine(strategy, dtype, H, HQ, S, D, T, W):
         assert torch.equal(ya, yb), f"step {t}: attention output"
         for (na, ta), (nb, tb) in zip(a.named_buffers(), b.named_buffers()):
             assert torch.equal(ta, tb), f"step {t}: {na}"
+
+
+@pytest.mark.parametrize("dtype,H,HQ,S,D,T,g,w", [(torch.bfloat16, 8, 32, 4096, 128, 4090, 4, 10), (torch.float16, 1, 8, 600, 128, 600, 2, 3),
+                                                  (torch.bfloat16, 4, 16, 333, 128, 300, 0, 1), (torch.bfloat16, 8, 32, 18432, 128, 18432, 4, 10)])
+def test_l2_fused_step_equals_three_calls(dtype, H, HQ, S, D, T, g, w):
+    """KVCacheL2: the two-launch step (cc_decode_step_l2: global norm maximum folded across the step boundary) against
+    update_kv -> attention; every buffer (key_norm included) bit for bit.  The evicted slot is usually the one holding
+    the global maximum, so the exclusion of its old norm from the running maximum is exercised on every step."""
+    import cold_compress_amd.cache as cache
+    from cold_compress_amd.attention_utils import scaled_dot_product_attention as sdpa
+
+    cls, rk = cache.get_cache_constructor("l2")
+    kw = dict(max_cache_length=S, global_tokens=g, recent_window=w, max_seq_length=4 * S, cache_bits=None)
+
+    def mk():
+        with torch.device(DEV):
+            return cls(1, H, D, dtype, **{k: kw[k] for k in rk})
+
+    a, b = mk(), mk()
+    assert b.supports_fused_step()
+    gen = torch.Generator().manual_seed(13)
+    k0 = (torch.randn(1, H, T, D, generator=gen) * torch.rand(1, H, T, 1, generator=gen)).to(dtype).to(DEV)
+    v0 = torch.randn(1, H, T, D, generator=gen).to(dtype).to(DEV)
+    for kv in (a, b):
+        kv.update_kv(torch.arange(T, device=DEV), k0, v0, True)
+        kv.update_state(torch.arange(T, device=DEV), k0, v0, True, None)
+    for t in range(12):
+        p = torch.tensor([T + t], dtype=torch.int32, device=DEV)
+        scale_k = 3.0 if t == 5 else 1.0  # one very large key: it becomes the global maximum inside the recent window
+        k1 = (torch.randn(1, H, 1, D, generator=gen) * scale_k).to(dtype).to(DEV)
+        v1 = torch.randn(1, H, 1, D, generator=gen).to(dtype).to(DEV)
+        q = torch.randn(1, HQ, 1, D, generator=gen).to(dtype).to(DEV)
+        ka, va, ma = a.update_kv(p, k1, v1, False)
+        ya, _ = sdpa(q, ka, va, attn_mask=ma)
+        yb = b.decode_step(q, k1, v1, p)
+        torch.cuda.synchronize()
+        assert torch.equal(ya, yb), f"step {t}: attention output"
+        for (na, ta), (nb, tb) in zip(a.named_buffers(), b.named_buffers()):
+            if na != "next_key":
+                assert torch.equal(ta, tb), f"step {t}: {na}"
+
+
+def test_l2_fused_step_vs_oracle():
+    """The same step through the C ABI against the oracle's twin: slots, norms, K/V and the attention output."""
+    import ctypes as C
+    from cold_compress_amd import _abi
+    from oracle import oracle_lib as o
+
+    o.build(); o.fns()
+    H, HQ, S, D, T, g, w = 2, 8, 200, 128, 190, 2, 4
+    dtype, code = torch.bfloat16, 1
+    gen = torch.Generator().manual_seed(14)
+    import cold_compress_amd.cache as cache
+    cls, rk = cache.get_cache_constructor("l2")
+    kw = dict(max_cache_length=S, global_tokens=g, recent_window=w, max_seq_length=4 * S, cache_bits=None)
+    with torch.device(DEV):
+        kv = cls(1, H, D, dtype, **{k: kw[k] for k in rk})
+    k0 = torch.randn(1, H, T, D, generator=gen).to(dtype).to(DEV)
+    v0 = torch.randn(1, H, T, D, generator=gen).to(dtype).to(DEV)
+    kv.update_kv(torch.arange(T, device=DEV), k0, v0, True)
+    kv.update_state(torch.arange(T, device=DEV), k0, v0, True, None)
+    torch.cuda.synchronize()
+    st = dict(k=to_np(kv.k_cache.cpu()[0]), v=to_np(kv.v_cache.cpu()[0]), pos=kv.pos.cpu()[0].numpy().astype(np.int32).copy(),
+              mask=kv.mask.cpu().reshape(H, S).numpy().astype(np.uint8).copy(), cts=kv.cache_cts.cpu().numpy().astype(np.int32).copy(),
+              kn=to_np(kv.key_norm.cpu()[0]))
+    nk = int(_abi.lib()["cc_hh_next_key_slots"](S))
+    nkey = np.zeros((H, nk), np.uint64)
+    view = o.view(st["k"], st["v"], st["pos"], st["mask"], st["cts"], code)
+    p0 = np.array([T], np.int32)
+    o.call("cc_l2_next_key_init", C.byref(view), o.ptr(p0), o.ptr(st["kn"]), g, w, o.ptr(nkey), None)
+    nbytes = _abi.lib()["cc_decode_attn_workspace_bytes"](HQ, H, S, D, code)
+    ws = np.zeros(nbytes, np.uint8)
+    for t in range(16):
+        p = torch.tensor([T + t], dtype=torch.int32, device=DEV)
+        k1 = torch.randn(1, H, 1, D, generator=gen).to(dtype)
+        v1 = torch.randn(1, H, 1, D, generator=gen).to(dtype)
+        q = torch.randn(1, HQ, 1, D, generator=gen).to(dtype)
+        y = kv.decode_step(q.to(DEV), k1.to(DEV), v1.to(DEV), p)
+        yo = np.zeros((HQ, D), np.uint16)
+        view = o.view(st["k"], st["v"], st["pos"], st["mask"], st["cts"], code)
+        o.call("cc_decode_step_l2", C.byref(view), o.ptr(to_np(q.reshape(HQ, D))), o.ptr(to_np(k1.reshape(H, D))),
+               o.ptr(to_np(v1.reshape(H, D))), o.ptr(np.array([T + t], np.int32)), o.ptr(st["kn"]), o.ptr(nkey), g, w, HQ,
+               1.0 / math.sqrt(D), o.ptr(yo), o.ptr(ws), ws.size, None)
+        torch.cuda.synchronize()
+        assert np.array_equal(kv.pos.cpu()[0].numpy(), st["pos"]), f"step {t}: slots"
+        assert np.array_equal(to_np(kv.key_norm.cpu()[0]), st["kn"]), f"step {t}: norms"
+        from helpers import from_np
+        assert torch.allclose(y.cpu().float().reshape(HQ, D), from_np(yo, dtype).float(), atol=2e-2, rtol=2e-2), f"step {t}: y"
+    assert np.array_equal(to_np(kv.k_cache.cpu()[0]), st["k"]) and np.array_equal(kv.cache_cts.cpu().numpy(), st["cts"])

@@ -98,7 +98,7 @@ def main():
             for i in range(n_buf):  # lazily built per-cache tables / scratch must exist before graph capture
                 three_call(i)
             res = {"cfg": tag, "strategy": strategy, "H": H, "HQ": HQ, "S": S, "three_call_us": round(timed(three_call, n_buf), 2)}
-            if strategy in ("heavy_hitter", "recent_global", "full", "random"):
+            if strategy in ("heavy_hitter", "recent_global", "full", "random", "l2"):
                 for kv in caches:
                     kv.prepare_decode(pos)
                 res["fused_step_us"] = round(timed(lambda i: caches[i % n_buf].decode_step(q, k1, k1, pos), n_buf), 2)
