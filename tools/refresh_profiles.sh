@@ -1,0 +1,13 @@
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/ref
+python bench.py > gpurun_out/ref/bench.json 2> gpurun_out/ref/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ref/prof -- python bench.py --steps 32 --warmup 4 --no_cpu_baseline --graph > gpurun_out/ref/prof_bench.json 2>/dev/null
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/ref/fetch -- python bench.py --steps 4 --warmup 2 --no_cpu_baseline > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/ref/write -- python bench.py --steps 4 --warmup 2 --no_cpu_baseline > /dev/null 2>&1
+T=$(ls gpurun_out/ref/prof/*/*kernel_trace.csv | head -1)
+python tools/summarize_prof.py $T > gpurun_out/ref/summary.txt
+cp $(ls gpurun_out/ref/prof/*/*kernel_stats.csv | head -1) gpurun_out/ref/kernel_stats.csv
+F=$(ls gpurun_out/ref/fetch/*/*counter_collection.csv | head -1); W=$(ls gpurun_out/ref/write/*/*counter_collection.csv | head -1)
+python tools/pmc_traffic.py $F $W > gpurun_out/ref/pmc_traffic.json
+rm -rf gpurun_out/ref/prof gpurun_out/ref/fetch gpurun_out/ref/write
+cat gpurun_out/ref/bench.json
