@@ -679,16 +679,21 @@ class KVCacheHybrid(_TrackedWindowSums, KVCacheHeadSpecific):
             self.num_punc.zero_()
 
     def build_special_ids_mask(self, input_ids):
-        """ref: cache.py:1021-1034 (exact sub-sequence match for multi-token special ids)."""
-        ids = input_ids.tolist()
-        m = [False] * len(ids)
+        """ref: cache.py:1021-1034 (exact sub-sequence match for multi-token special ids) — as shifted compares on the
+        device: no `.tolist()` round trip per layer (it cost ~10 ms x 32 layers on a 16k prompt)."""
+        ids = input_ids.reshape(-1)
+        L = ids.numel()
+        m = torch.zeros(L, dtype=torch.bool, device=ids.device)
         for sp in self.special_ids:
             n = len(sp)
-            for i in range(len(ids) - n + 1):
-                if ids[i:i + n] == sp:
-                    for j in range(i, i + n):
-                        m[j] = True
-        return torch.tensor(m, dtype=torch.bool, device=input_ids.device)
+            if n == 0 or n > L:
+                continue
+            hit = torch.ones(L - n + 1, dtype=torch.bool, device=ids.device)  # hit[i]: ids[i : i + n] == sp
+            for j, tok in enumerate(sp):
+                hit &= ids[j:L - n + 1 + j] == tok
+            for j in range(n):
+                m[j:L - n + 1 + j] |= hit
+        return m
 
     def _partition_order(self, mask_optimal):
         """Kept tokens first, original order preserved inside each class (stable)."""
