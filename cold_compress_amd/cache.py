@@ -291,12 +291,16 @@ class _RingFusedStep:
         self._next_valid = False  # the three-call path mutates pos outside the pipeline
         return super().update_kv(input_pos, k_val, v_val, is_prefill, **kwargs)
 
+    def _ring_sinks(self):
+        """Slots the ring's arg-min skips (cache.py:554 `pos[:, :, g:]`)."""
+        return int(self.global_tokens)
+
     def _pipeline_init(self, p32):
-        _abi.call("cc_rg_next_key_init", self._view(), _ptr(p32), int(self.global_tokens), _ptr(self.next_key), _stream())
+        _abi.call("cc_rg_next_key_init", self._view(), _ptr(p32), self._ring_sinks(), _ptr(self.next_key), _stream())
 
     def _pipeline_step(self, q, k, v, p32, HQ, scale, y, ws):
         _abi.call("cc_decode_step_recent_global", self._view(), _ptr(q), _ptr(k), _ptr(v), _ptr(p32), _ptr(self.next_key),
-                  int(self.global_tokens), HQ, scale, _ptr(y), _ptr(ws), ws.numel(), _stream())
+                  self._ring_sinks(), HQ, scale, _ptr(y), _ptr(ws), ws.numel(), _stream())
 
     def prepare_decode(self, input_pos):
         self._pipeline_init(self._pos32(input_pos))
@@ -328,6 +332,9 @@ class KVCacheFull(_RingFusedStep, KVCacheHeadConstant):
         self.global_tokens = 0
         super().__init__(max_batch_size, n_heads, head_dim, dtype, **kwargs)
         self._init_ring_pipeline()
+
+    def _ring_sinks(self):
+        return 0  # cache.py:502 is a plain pos.argmin(): a `global_tokens` kwarg (it overrides the 0 above, as in the reference) is ignored
 
     def _run_select(self, input_pos, k, v):
         _abi.call("cc_decode_update_full", self._view(), _ptr(k), _ptr(v), _ptr(self._pos32(input_pos)),
