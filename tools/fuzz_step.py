@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""Differential fuzz: random (policy, dtype, heads, cache length, head_dim, fill level, sinks, window, cache_bits) —
+the two-launch decode step against update_kv -> attention -> update_state, every buffer bit for bit.
+    python tools/fuzz_step.py [--n 300] [--seed 0]"""
+import argparse
+import os
+import random
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch  # noqa: E402
+
+import cold_compress_amd.cache as cache  # noqa: E402
+from cold_compress_amd.attention_utils import scaled_dot_product_attention as sdpa  # noqa: E402
+
+DEV = "cuda"
+
+
+def one(rng, idx):
+    strategy = rng.choice(["heavy_hitter", "recent_global", "full", "random", "l2"])
+    dtype = rng.choice([torch.bfloat16, torch.float16, torch.float32])
+    D = rng.choice([16, 32, 64, 128, 128, 128])
+    H = rng.choice([1, 2, 3, 8])
+    R = rng.choice([1, 2, 4, 8])
+    S = rng.choice([rng.randint(6, 40), rng.randint(41, 300), rng.randint(301, 3000), rng.choice([4096, 5000, 9000])])
+    T = rng.choice([0, S, S, rng.randint(0, S)])
+    g = rng.randint(0, min(4, S // 3))
+    w = rng.randint(1, max(1, min(10, S // 3)))
+    bits = rng.choice([None, None, None, 8, 4]) if strategy not in ("l2",) else None
+    W = 1
+    cfg = dict(strategy=strategy, dtype=str(dtype), H=H, R=R, S=S, D=D, T=T, g=g, w=w, bits=bits)
+    cls, rk = cache.get_cache_constructor(strategy)
+    kw = dict(max_cache_length=S, global_tokens=g, recent_window=w, history_window_size=W, attn_thresholding=False,
+              max_seq_length=4 * S + 64, cache_bits=bits)
+
+    def mk():
+        with torch.device(DEV):
+            return cls(1, H, D, dtype, **{k: kw[k] for k in rk})
+
+    try:
+        a, b = mk(), mk()
+    except NotImplementedError:
+        return None
+    if not b.supports_fused_step():
+        return None
+    gen = torch.Generator().manual_seed(idx)
+    steps = 6
+    if strategy == "random":
+        draws = [torch.rand(S, generator=gen).to(DEV) for _ in range(steps + 1)]
+        ia, ib = iter(draws), iter(draws)
+        a._rand = lambda: next(ia)
+        b._rand = lambda: next(ib)
+    if T > 0:
+        k0 = torch.randn(1, H, T, D, generator=gen).to(dtype).to(DEV)
+        v0 = torch.randn(1, H, T, D, generator=gen).to(dtype).to(DEV)
+        for kv in (a, b):
+            kv.update_kv(torch.arange(T, device=DEV), k0, v0, True)
+            if strategy == "l2":
+                kv.update_state(torch.arange(T, device=DEV), k0, v0, True, None)
+    for t in range(steps):
+        p = torch.tensor([T + t], dtype=torch.int32, device=DEV)
+        k1 = torch.randn(1, H, 1, D, generator=gen).to(dtype).to(DEV)
+        v1 = torch.randn(1, H, 1, D, generator=gen).to(dtype).to(DEV)
+        q = torch.randn(1, H * R, 1, D, generator=gen).to(dtype).to(DEV)
+        ka, va, ma = a.update_kv(p, k1, v1, False)
+        fuse = strategy == "heavy_hitter"
+        ya, at = sdpa(q, ka, va, attn_mask=ma, return_attn=a.return_attn() and not fuse, group_mean=True,
+                      history=a.fused_history() if fuse else None)
+        if fuse:
+            a._state_fused = True
+        a.update_state(p, k1, v1, False, at)
+        yb = b.decode_step(q, k1, v1, p)
+        torch.cuda.synchronize()
+        if not torch.equal(ya, yb):
+            return f"{cfg} step {t}: y differs (max {float((ya.float() - yb.float()).abs().max())})"
+        a.dequantize_cache(), b.dequantize_cache()
+        for (na, ta), (nb, tb) in zip(a.named_buffers(), b.named_buffers()):
+            if na != "next_key" and not torch.equal(ta, tb):
+                return f"{cfg} step {t}: buffer {na} differs"
+    return ""
+
+
+HYB = [{"strategy": "special"}, {"strategy": "special_punc"}, {"strategy": "special_punc_heavy_hitter", "heavy_hitter_frac": 0.3},
+       {"strategy": "special_punc_window", "recent_window": 0.3}, {"strategy": "full"}]
+
+
+def one_ring(rng, idx):
+    """history ring (heavy_hitter with W > 1, hybrid with W = 400): the update folded into the combine pass against
+    attention -> update_state, tracked window sums included."""
+    strategy = rng.choice(["heavy_hitter", "hybrid"])
+    dtype = rng.choice([torch.bfloat16, torch.float16, torch.float32])
+    D = rng.choice([16, 64, 128, 128])
+    H = rng.choice([1, 2, 5, 8])
+    R = rng.choice([1, 4, 8])
+    S = rng.choice([rng.randint(8, 60), rng.randint(61, 700), rng.randint(701, 2500)])
+    T = rng.choice([S, S, rng.randint(1, S)])
+    W = rng.choice([2, 3, 8, 33]) if strategy == "heavy_hitter" else 400
+    g = rng.randint(0, min(4, S // 3))
+    w = rng.randint(1, max(1, min(10, S // 3)))
+    cfg = dict(strategy=strategy, dtype=str(dtype), H=H, R=R, S=S, D=D, T=T, g=g, w=w, W=W)
+    cls, rk = cache.get_cache_constructor(strategy)
+    kw = dict(max_cache_length=S, global_tokens=g, recent_window=w, history_window_size=W, attn_thresholding=False,
+              max_seq_length=4 * S + 64, cache_bits=None, token_ids={"special": [[1], [2, 3]], "punctuation": [5, 6, 7]},
+              min_recovery_frac=0.9, hybrid_strategies=HYB)
+
+    def mk():
+        with torch.device(DEV):
+            return cls(1, H, D, dtype, **{k: kw[k] for k in rk})
+
+    a, b = mk(), mk()
+    gen = torch.Generator().manual_seed(10_000 + idx)
+    k0 = torch.randn(1, H, T, D, generator=gen).to(dtype).to(DEV)
+    v0 = torch.randn(1, H, T, D, generator=gen).to(dtype).to(DEV)
+    for kv in (a, b):
+        kv.update_kv(torch.arange(T, device=DEV), k0, v0, True, input_ids=torch.zeros(T, dtype=torch.int64, device=DEV))
+        if strategy == "hybrid":
+            kv.cache_strategies = (torch.arange(H, device=DEV) % len(HYB)).to(torch.int64).contiguous()
+            kv.requires_heavy_hitter = True
+            kv.cache_cts.fill_(T)
+            kv.mask[..., :T] = True
+            kv.pos[0, :, :T] = torch.arange(T, device=DEV, dtype=kv.pos.dtype)
+    for t in range(2 * min(W, 6) + 2):
+        p = torch.tensor([T + t], dtype=torch.int32, device=DEV)
+        ids = torch.tensor([5 if t % 3 == 1 else 9], dtype=torch.int64, device=DEV)
+        k1 = torch.randn(1, H, 1, D, generator=gen).to(dtype).to(DEV)
+        v1 = torch.randn(1, H, 1, D, generator=gen).to(dtype).to(DEV)
+        q = torch.randn(1, H * R, 1, D, generator=gen).to(dtype).to(DEV)
+        ka, va, ma = a.update_kv(p, k1, v1, False, input_ids=ids)
+        ya, attn = sdpa(q, ka, va, attn_mask=ma, return_attn=True, group_mean=True)
+        a.update_state(p, k1, v1, False, attn, input_ids=ids)
+        kb, vb, mb = b.update_kv(p, k1, v1, False, input_ids=ids)
+        yb, _ = sdpa(q, kb, vb, attn_mask=mb, group_mean=True, history=b.fused_history())
+        b._state_fused = True
+        b.update_state(p, k1, v1, False, None, input_ids=ids)
+        torch.cuda.synchronize()
+        if not torch.equal(ya, yb):
+            return f"{cfg} step {t}: y differs"
+        for (na, ta), (nb, tb) in zip(a.named_buffers(), b.named_buffers()):
+            if not torch.equal(ta, tb):
+                return f"{cfg} step {t}: buffer {na} differs"
+    return ""
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=300)
+    ap.add_argument("--seed", type=int, default=0)
+    a = ap.parse_args()
+    rng = random.Random(a.seed)
+    ran = bad = 0
+    for i in range(a.n):
+        try:
+            r = one(rng, i) if i % 4 else one_ring(rng, i)
+        except Exception as e:  # a crash is a finding too
+            r = f"case {i}: {type(e).__name__}: {e}"
+        if r is None:
+            continue
+        ran += 1
+        if r:
+            bad += 1
+            print("MISMATCH", r, flush=True)
+    print(f"fuzz: {ran} cases ran, {bad} mismatches")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
