@@ -607,7 +607,7 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_split_mfma_kernel(SplitAr
 #pragma unroll
           for (int off = 8; off > 0; off >>= 1) ss = __fadd_rn(ss, __shfl_xor(ss, off, 16));
           if (c == 0) {
-            const float nv = ElemTraits<T>::rnd(__fsqrt_rn(ss));
+            const float nv = ElemTraits<T>::rnd(cc_sqrt_rn(ss));
             ElemTraits<T>::store(reinterpret_cast<T*>(a.key_norm), slot, nv);
             a.l2_new[h] = nv;
           }

@@ -154,6 +154,11 @@ __device__ __forceinline__ unsigned long long block_min_u64(unsigned long long v
   return sm[nw];
 }
 
+// Correctly rounded fp32 square root (what torch.linalg.vector_norm's sqrt is on any IEEE backend): through fp64 —
+// 53 >= 2 * 24 + 2 bits make the double rounding exact.  (__fsqrt_rn compiled to a 1-ulp v_sqrt_f32 here: fp32 key
+// norms differed from the oracle in the last bit.)
+__device__ __forceinline__ float cc_sqrt_rn(float x) { return (float)__dsqrt_rn((double)x); }
+
 // Canonical sum of squares of a D-vector, evaluated by 16 cooperating lanes (lane16 = 0..15 of an aligned
 // 16-lane group): a_j = sum_i x[j+16i]^2 (sequential in i; separate multiply and add, no fma), then the
 // butterfly a_j += a_{j^8}, ^4, ^2, ^1.  oracle/cc_oracle.c sumsq_canonical() evaluates the same order,

@@ -218,7 +218,7 @@ __global__ __launch_bounds__(kUpdThreads) void decode_update_kernel(UpdArgs a) {
   insert_rows<T>(a, h0, nh, idx, pre);
   if (POLICY == P_L2 && threadIdx.x < 16) {  // ref: cache.py:592-593
     const float ss = sumsq_canonical_16<T>(reinterpret_cast<const T*>(a.k_new) + (size_t)hp * a.D, a.D, threadIdx.x);
-    if (threadIdx.x == 0) ElemTraits<T>::store(reinterpret_cast<T*>(a.key_norm), (size_t)hp * S + idx, __fsqrt_rn(ss));
+    if (threadIdx.x == 0) ElemTraits<T>::store(reinterpret_cast<T*>(a.key_norm), (size_t)hp * S + idx, cc_sqrt_rn(ss));
   }
 }
 
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256) void row_l2_norm_kernel(const T* x, int rows, 
   for (int r = group; r < rows; r += ngroups) {
     const float ss = sumsq_canonical_16<T>(x + (size_t)r * D, D, lane16);
     if (lane16 == 0) {
-      const float n = __fsqrt_rn(ss);
+      const float n = cc_sqrt_rn(ss);
       ElemTraits<T>::store(out, r, negate ? -n : n);
     }
   }

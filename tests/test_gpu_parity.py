@@ -256,10 +256,28 @@ def _oracle_state(oracle, kv, strategy):
     ("heavy_hitter", torch.bfloat16, 1, 3488, 128)])
 def test_decode_update_bit_exact_vs_oracle(cc, oracle, strategy, dtype, H, S, D):
     """Seeded state at BASELINE sizes; 12 decode steps on both sides; every index and all state bit-exact."""
-    g, w = 4, 10
-    gen = torch.Generator().manual_seed(1234 + S)
+    _replay_vs_oracle(cc, oracle, strategy, dtype, H, S, D, S - 5, 4, 10)  # a few empty slots: the -1 path runs first
+
+
+def test_decode_update_fuzz_vs_oracle(cc, oracle):
+    """The same replay over 60 seeded random configurations: policy, dtype, head count, cache length 6 .. 3000,
+    head_dim 16 .. 128, fill level 0 .. full, sinks and recent window."""
+    import random
+
+    rng = random.Random(2024)
+    for i in range(60):
+        strategy = rng.choice(["heavy_hitter", "l2", "random", "recent_global", "full"])
+        dtype = rng.choice([torch.bfloat16, torch.float16, torch.float32])
+        H, D = rng.choice([1, 2, 3, 8]), rng.choice([16, 32, 64, 128])
+        S = rng.choice([rng.randint(6, 40), rng.randint(41, 300), rng.randint(301, 3000)])
+        T = rng.choice([0, S, rng.randint(0, S)])
+        g, w = rng.randint(0, min(4, S // 3)), rng.randint(1, max(1, min(10, S // 3)))
+        _replay_vs_oracle(cc, oracle, strategy, dtype, H, S, D, T, g, w, steps=8, seed=i, tag=f"case {i}")
+
+
+def _replay_vs_oracle(cc, oracle, strategy, dtype, H, S, D, T, g, w, steps=12, seed=None, tag=""):
+    gen = torch.Generator().manual_seed(1234 + S if seed is None else 99_000 + seed)
     kv = _make(cc, strategy, dtype, H, S, D, g, w)
-    T = S - 5  # leave a few empty slots so the -1 path is exercised first
     hp = H if kv.head_specific else 1
     pos = torch.stack([torch.randperm(T + 50, generator=gen)[:T] for _ in range(hp)]).to(torch.int32)
     kv.pos[0, :, :T] = pos.to(DEV)
@@ -267,7 +285,7 @@ def test_decode_update_bit_exact_vs_oracle(cc, oracle, strategy, dtype, H, S, D)
     kv.cache_cts.fill_(T)
     kv.k_cache.copy_(torch.randn(1, H, S, D, generator=gen).to(dtype))
     kv.v_cache.copy_(torch.randn(1, H, S, D, generator=gen).to(dtype))
-    if strategy == "heavy_hitter":
+    if strategy == "heavy_hitter" and T > 0:
         kv.attn_history_num[0, :, :T, 0] = torch.rand(H, T, generator=gen, dtype=torch.float64).to(DEV) * 3
         kv.attn_history_denom[0, :, :T] = torch.randint(1, 9, (H, T), generator=gen, dtype=torch.int32).to(DEV)
         # engineered ties: identical averages in several slots -> lowest index must win
@@ -277,7 +295,7 @@ def test_decode_update_bit_exact_vs_oracle(cc, oracle, strategy, dtype, H, S, D)
     st = _oracle_state(oracle, kv, strategy)
     code = DT_CODE[dtype]
     p0 = T + 60
-    for t in range(12):
+    for t in range(steps):
         k1 = torch.randn(1, H, 1, D, generator=gen).to(dtype)
         v1 = torch.randn(1, H, 1, D, generator=gen).to(dtype)
         p = torch.tensor([p0 + t], dtype=torch.int32)
@@ -300,7 +318,7 @@ def test_decode_update_bit_exact_vs_oracle(cc, oracle, strategy, dtype, H, S, D)
             o.call("cc_decode_update_recent_global", C.byref(view), o.ptr(kn), o.ptr(vn), o.ptr(pn), g, o.ptr(idx), None)
         else:
             o.call("cc_decode_update_full", C.byref(view), o.ptr(kn), o.ptr(vn), o.ptr(pn), o.ptr(idx), None)
-        assert np.array_equal(_idx(kv), idx), f"step {t}"
+        assert np.array_equal(_idx(kv), idx), f"{tag} step {t}: {strategy} {dtype} H={H} S={S} D={D} T={T} g={g} w={w}"
         if strategy == "heavy_hitter":  # evolve the history identically on both sides
             a = torch.softmax(torch.randn(H, S, generator=gen) * 3, -1).to(dtype)
             kv.update_state(p.to(DEV), k1.to(DEV), v1.to(DEV), False, a.view(1, H, 1, S).to(DEV))
@@ -308,7 +326,10 @@ def test_decode_update_bit_exact_vs_oracle(cc, oracle, strategy, dtype, H, S, D)
             o.call("cc_hh_update", o.ptr(st["num"]), o.ptr(st["denom"]), None, o.ptr(an), H, S, S, code, None)
     got = _oracle_state(oracle, kv, strategy)
     for key in st:
-        assert np.array_equal(got[key], st[key]), key
+        if not np.array_equal(got[key], st[key]):
+            where = np.argwhere(np.asarray(got[key]) != np.asarray(st[key]))[:4].tolist()
+            vals = [(np.asarray(got[key])[tuple(ix)].item(), np.asarray(st[key])[tuple(ix)].item()) for ix in where]
+            raise AssertionError(f"{tag} {key}: {strategy} {dtype} H={H} S={S} D={D} T={T} g={g} w={w}: first differences at {where}: {vals}")
 
 
 @pytest.mark.parametrize("dtype,HQ,H,S,D", [(torch.bfloat16, 32, 8, 4096, 128), (torch.bfloat16, 32, 8, 2560, 128),
