@@ -112,29 +112,52 @@ def test_hybrid_stable_partition_keeps_the_same_sets(name):
 
 def test_hybrid_decode_vs_oracle_at_scale(oracle):
     """H=8, S=2048, W=400, bf16: seeded state, 10 decode steps on both sides, bit-exact."""
+    _hybrid_decode_vs_oracle(oracle, 8, 2048, 128, torch.bfloat16, 99, [0, 1, 2, 3, 1, 2, 0, 1], [300, 900, 800, 1500, 716, 1200, 208, 720], 1700)
+
+
+def test_hybrid_decode_fuzz_vs_oracle(oracle):
+    """16 seeded random configurations: 1 .. 8 heads, 24 .. 700 slots, head_dim 16 .. 128, three dtypes, random policy per
+    head and random fill levels (empty-ish to full)."""
+    import random
+
+    rng = random.Random(31)
+    for i in range(16):
+        H, D = rng.choice([1, 2, 5, 8]), rng.choice([16, 64, 128])
+        S = rng.choice([rng.randint(24, 100), rng.randint(101, 700)])
+        dtype = rng.choice([torch.bfloat16, torch.float16, torch.float32])
+        strat = [rng.randrange(4) for _ in range(H)]
+        cts = [rng.choice([rng.randint(1, S), S, max(1, S // 3)]) for _ in range(H)]
+        _hybrid_decode_vs_oracle(oracle, H, S, D, dtype, 300 + i, strat, cts, 3 * S, steps=6, tag=f"case {i}")
+    # the decision kernel split over 5 workgroups per head (S > 1024), full and nearly empty heads side by side
+    _hybrid_decode_vs_oracle(oracle, 4, 4700, 128, torch.bfloat16, 399, [1, 2, 0, 3], [4700, 4699, 30, 2500], 9000, steps=5, tag="split")
+
+
+def _hybrid_decode_vs_oracle(oracle, H, S, D, dtype, seed, strat_list, cts_list, pos_hi, steps=10, tag=""):
     import cold_compress_amd.cache as cache
 
-    H, S, D, W, g = 8, 2048, 128, 400, 4
+    W, g = 400, min(4, S // 8)
+    code = DT_CODE[dtype]
+    what = f"{tag} {dtype} H={H} S={S} D={D} strat={strat_list} cts={cts_list}"
     strategies = [{"strategy": "window", "recent_window": 0.1},
                   {"strategy": "window_heavy_hitter", "heavy_hitter_frac": 0.25, "recent_window": 0.1},
                   {"strategy": "special_punc_heavy_hitter", "heavy_hitter_frac": 0.3}, {"strategy": "full"}]
-    gen = torch.Generator().manual_seed(99)
+    gen = torch.Generator().manual_seed(seed)
     kw = dict(max_cache_length=S, max_seq_length=S, cache_bits=None, global_tokens=g, token_ids=TOKEN_IDS, min_recovery_frac=0.9,
               hybrid_strategies=strategies)
     with torch.device(DEV):
-        kv = cache.KVCacheHybrid(1, H, D, torch.bfloat16, **kw)
-    strat = torch.tensor([0, 1, 2, 3, 1, 2, 0, 1], dtype=torch.int64)
-    cts = torch.tensor([300, 900, 800, 1500, 716, 1200, 208, 720], dtype=torch.int32)
+        kv = cache.KVCacheHybrid(1, H, D, dtype, **kw)
+    strat = torch.tensor(strat_list, dtype=torch.int64)
+    cts = torch.tensor(cts_list, dtype=torch.int32)
     kv.cache_strategies = strat.to(DEV)
     kv.cache_cts.copy_(cts)
     pos = torch.full((H, S), -1, dtype=torch.int32)
     for h in range(H):
-        pos[h, : cts[h]] = torch.sort(torch.randperm(1700, generator=gen)[: cts[h]]).values.int()
+        pos[h, : cts[h]] = torch.sort(torch.randperm(pos_hi, generator=gen)[: cts[h]]).values.int()
     kv.pos[0] = pos.to(DEV)
     kv.mask[0, :, 0] = (torch.arange(S).view(1, S) < cts.view(H, 1)).to(DEV)
-    kv.k_cache.copy_(torch.randn(1, H, S, D, generator=gen).to(torch.bfloat16))
-    kv.v_cache.copy_(torch.randn(1, H, S, D, generator=gen).to(torch.bfloat16))
-    kv.attn_history_num.copy_((torch.rand(1, H, S, W, generator=gen) * 0.01).to(torch.bfloat16))
+    kv.k_cache.copy_(torch.randn(1, H, S, D, generator=gen).to(dtype))
+    kv.v_cache.copy_(torch.randn(1, H, S, D, generator=gen).to(dtype))
+    kv.attn_history_num.copy_((torch.rand(1, H, S, W, generator=gen) * 0.01).to(dtype))
     kv.attn_history_denom.copy_(torch.randint(0, 600, (1, H, S), generator=gen, dtype=torch.int32))
     kv.special_mask[0] = (torch.rand(H, S, generator=gen) < 0.01).to(DEV)
     kv.punc_mask[0] = (torch.rand(H, S, generator=gen) < 0.02).to(DEV)
@@ -148,25 +171,25 @@ def test_hybrid_decode_vs_oracle_at_scale(oracle):
               nsp=np.array([20], np.int32), npc=np.array([40], np.int32), ctr=np.array([777], np.int64))
     tab = policy_table(strategies, S)
     o = oracle
-    for t in range(10):
-        p = torch.tensor([1800 + t], dtype=torch.int32)
+    for t in range(steps):
+        p = torch.tensor([pos_hi + 100 + t], dtype=torch.int32)
         tok = torch.tensor([[6 if t in (3, 4) else 30]])
-        k1 = torch.randn(1, H, 1, D, generator=gen).to(torch.bfloat16)
-        v1 = torch.randn(1, H, 1, D, generator=gen).to(torch.bfloat16)
-        a = torch.softmax(torch.randn(H, S, generator=gen), -1).to(torch.bfloat16)
+        k1 = torch.randn(1, H, 1, D, generator=gen).to(dtype)
+        v1 = torch.randn(1, H, 1, D, generator=gen).to(dtype)
+        a = torch.softmax(torch.randn(H, S, generator=gen), -1).to(dtype)
         kv.update_kv(p.to(DEV), k1.to(DEV), v1.to(DEV), False, input_ids=tok.to(DEV))
         kv.update_state(p.to(DEV), k1.to(DEV), v1.to(DEV), False, a.view(1, H, 1, S).to(DEV), input_ids=tok.to(DEV))
         torch.cuda.synchronize()
-        view = o.view(st["k"], st["v"], st["pos"], st["mask"], st["cts"], 1)
+        view = o.view(st["k"], st["v"], st["pos"], st["mask"], st["cts"], code)
         fill = np.zeros(H, np.int64)
         isp = np.array([int(int(tok) in (5, 6, 7))], np.uint8)
         stn = strat.numpy().copy()
         o.call("cc_hybrid_decode_update", C.byref(view), o.ptr(to_np(k1.reshape(H, D))), o.ptr(to_np(v1.reshape(H, D))),
                o.ptr(p.numpy().copy()), o.ptr(stn), o.ptr(tab), len(tab), o.ptr(st["num"]), o.ptr(st["denom"]), W, o.ptr(st["special"]),
                o.ptr(st["punc"]), o.ptr(isp), None, None, 0, o.ptr(st["nsp"]), o.ptr(st["npc"]), g, 0, o.ptr(fill), None, None, None)
-        o.call("cc_hh_ring_update", o.ptr(st["num"]), o.ptr(st["denom"]), o.ptr(st["ctr"]), o.ptr(to_np(a)), H, S, S, W, 1, None, None, None)
-        assert kv._idx_buf().cpu().tolist() == fill.tolist(), f"step {t}"
-    assert np.array_equal(kv.pos.cpu()[0].numpy(), st["pos"]) and np.array_equal(kv.cache_cts.cpu().numpy(), st["cts"])
+        o.call("cc_hh_ring_update", o.ptr(st["num"]), o.ptr(st["denom"]), o.ptr(st["ctr"]), o.ptr(to_np(a)), H, S, S, W, code, None, None, None)
+        assert kv._idx_buf().cpu().tolist() == fill.tolist(), f"{what} step {t}"
+    assert np.array_equal(kv.pos.cpu()[0].numpy(), st["pos"]) and np.array_equal(kv.cache_cts.cpu().numpy(), st["cts"]), what
     assert np.array_equal(to_np(kv.attn_history_num.cpu()[0]), st["num"])
     assert np.array_equal(kv.attn_history_denom.cpu()[0].numpy(), st["denom"])
     assert np.array_equal(kv.punc_mask.cpu()[0].numpy().astype(np.uint8), st["punc"]) and int(kv.num_punc) == int(st["npc"][0])
