@@ -2,8 +2,10 @@
 //
 // ref: KVCacheHybrid cache.py:768-1288 (decode: _decoding_update :965-1019, _select_fill_idx :896-950,
 // _eviction_idx_for_head :844-894); KVCacheHeavyHitter with history_window_size > 1 (:707-736).
-// The reference walks the heads in a Python loop with a device sync per head; here one workgroup per head does
-// budget check, protected-slot masking, windowed-history scoring, arg-min and the insert in one launch.
+// The reference walks the heads in a Python loop with a device sync per head; here one launch does budget check,
+// protected-slot masking, windowed-history scoring, arg-min and the insert for every head (up to 32 workgroups per
+// head when the caller keeps the tracked window-sum state, one otherwise).  The window sums of the ring are exact and
+// kept incrementally (cc_wacc.h); the full-ring pre-pass below remains as the stateless / rebuild path.
 #include "cc_common.h"
 #include "cc_wacc.h"
 
@@ -71,10 +73,11 @@ __device__ __forceinline__ WAcc wave_window_acc(const T* row, int W, int lane) {
   return acc;
 }
 
-// Pre-pass of the ring policies: wsum[h, s] for every slot of every head that scores by accumulated attention.
-// The [H, S, W] ring is the only large operand of these policies (118 MB at S = 18432, W = 400): it is streamed
-// once, coalesced, by the whole chip — the decision kernels below (one workgroup per head) then read 4 bytes per
-// slot.  (The first version summed rows inside the one-workgroup-per-head kernel: 8 CUs, 800-byte strides, 1.4 ms.)
+// Stateless / rebuild path of the ring policies: wsum[h, s] (and, on request, the tracked state: accumulators + the
+// column-major shadow) for every slot of every head that scores by accumulated attention.  The [H, S, W] ring is the
+// only large operand of these policies (118 MB at S = 18432, W = 400): it is streamed once, coalesced, by the whole
+// chip, one wave per slot.  Callers that keep the tracked state never run this on the decode path.
+// (The first version summed rows inside the one-workgroup-per-head kernel: 8 CUs, 800-byte strides, 1.4 ms.)
 template <typename T>
 __global__ __launch_bounds__(256) void ring_window_sum_kernel(const T* num, const int64_t* strategies, const int32_t* table, int H,
                                                               int S, int W, float* out, u64* acc_out, size_t scratch_off) {
