@@ -157,6 +157,8 @@ class GraphedDecoder:
             if fl[0] is not None:
                 c._next_valid = fl[0]
             c._quant_pending = fl[1]
+            if hasattr(c, "_ring_version"):  # ring and tracked window sums were restored together: still in step
+                c._ring_version = c._ring_tag()
 
     def __call__(self, model, x, input_pos, next_token=None, **_):
         if self.graph is None:
