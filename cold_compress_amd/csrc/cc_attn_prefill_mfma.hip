@@ -50,6 +50,19 @@ struct MfmaOps<f16_t> {
 // accurate expf (~20 VALU ops) and an IEEE divide per probability cost 0.7 ms of the 3.1 ms second pass at L = 8192.
 // (Double-buffering the K / V fragments across key tiles was tried and is SLOWER: 195 VGPRs, one wave per SIMD.)
 __device__ __forceinline__ float pf_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+constexpr float kLog2e = 1.4426950408889634f;
+
+// dtype rounding of two values at once; returns the packed 16-bit pair (lo | hi << 16)
+template <typename T>
+__device__ __forceinline__ uint32_t pf_rnd2(float a, float b, float& ra, float& rb) {
+  if constexpr (sizeof(T) == 2 && ElemTraits<T>::code == CC_DT_BF16) {
+    return bf16_round_pair(a, b, ra, rb);
+  } else {
+    ra = ElemTraits<T>::rnd(a);
+    rb = ElemTraits<T>::rnd(b);
+    return MfmaOps<T>::pack2(ra, rb);
+  }
+}
 
 constexpr int kD = 128;
 constexpr int kTQ = 32;   // queries per tile
@@ -148,21 +161,21 @@ __global__ __launch_bounds__(256) void prefill_stats_lds_kernel(MArgs a) {
       // every tile strictly below the diagonal of a complete query tile needs no causal / bounds masking: the 16
       // compares + selects per lane are only paid on the diagonal tile (and on the ragged last query tile)
       const bool full_tile = (k0 + kTK - 1 <= q0) && (q0 + kTQ <= L);
-      if (full_tile) {
 #pragma unroll
-        for (int e = 0; e < 16; e++) {
-          x[e] = ElemTraits<T>::rnd(ElemTraits<T>::rnd(s[e]) * a.scale);
-          mx = fmaxf(mx, x[e]);
-        }
-      } else {
+      for (int e = 0; e < 16; e += 2) {  // dtype(dtype(q.k) * scale), two elements per conversion
+        float r0, r1;
+        pf_rnd2<T>(s[e], s[e + 1], r0, r1);
+        pf_rnd2<T>(r0 * a.scale, r1 * a.scale, x[e], x[e + 1]);
+      }
+      if (!full_tile) {
 #pragma unroll
         for (int e = 0; e < 16; e++) {
           const int key = k0 + c_row(e, hi);
-          const float v = ElemTraits<T>::rnd(ElemTraits<T>::rnd(s[e]) * a.scale);
-          x[e] = (key > query || key >= L || query >= L) ? -INFINITY : v;
-          mx = fmaxf(mx, x[e]);
+          if (key > query || key >= L || query >= L) x[e] = -INFINITY;
         }
       }
+#pragma unroll
+      for (int e = 0; e < 16; e++) mx = fmaxf(mx, x[e]);
       const float mu = (mx == -INFINITY) ? 0.f : mx;
       float sum = l_run * pf_exp(m_run - mu);
 #pragma unroll
@@ -219,7 +232,7 @@ __global__ __launch_bounds__(256) void prefill_pv_lds_kernel(MArgs a) {
     uint4 qb[8];
 #pragma unroll
     for (int ds = 0; ds < 8; ds++) qb[ds] = *reinterpret_cast<const uint4*>(qh + (size_t)qc * kD + ds * 16 + 8 * hi);
-    const float m_fin = a.stats[((size_t)j * L + qc) * 2];
+    const float m_fin_l2 = -a.stats[((size_t)j * L + qc) * 2] * kLog2e;
     const float inv_l = __frcp_rn(a.stats[((size_t)j * L + qc) * 2 + 1]);
     f32x16 o[4];
 #pragma unroll
@@ -271,23 +284,24 @@ __global__ __launch_bounds__(256) void prefill_pv_lds_kernel(MArgs a) {
 #pragma unroll
       for (int ds = 0; ds < 8; ds++) s = MfmaOps<T>::mma(sm_kt[buf][lq][((2 * ds + hi) ^ (lq & 15)) & 15], qb[ds], s);
       float p[16];
+      uint32_t pp[8];  // the same probabilities as packed 16-bit pairs: the A operand of the P.V products
       const bool full_tile = (k0 + kTK - 1 <= q0) && (q0 + kTQ <= L);  // no causal / bounds masking below the diagonal
-      if (full_tile) {
 #pragma unroll
-        for (int e = 0; e < 16; e++) {
-          const float v = ElemTraits<T>::rnd(ElemTraits<T>::rnd(s[e]) * a.scale);
-          p[e] = ElemTraits<T>::rnd(pf_exp(v - m_fin) * inv_l);
-          sm_p[r][c_row(e, hi)][lq] = p[e];
+      for (int e = 0; e < 16; e += 2) {  // two elements per dtype conversion (v_cvt_pk_bf16_f32)
+        float r0, r1, v0, v1;
+        pf_rnd2<T>(s[e], s[e + 1], r0, r1);
+        pf_rnd2<T>(r0 * a.scale, r1 * a.scale, v0, v1);
+        if (!full_tile) {
+          const int key0 = k0 + c_row(e, hi), key1 = k0 + c_row(e + 1, hi);
+          if (key0 > query || key0 >= L || query >= L) v0 = -INFINITY;
+          if (key1 > query || key1 >= L || query >= L) v1 = -INFINITY;
         }
-      } else {
-#pragma unroll
-        for (int e = 0; e < 16; e++) {
-          const int key = k0 + c_row(e, hi);
-          const float v = ElemTraits<T>::rnd(ElemTraits<T>::rnd(s[e]) * a.scale);
-          const float x = (key > query || key >= L || query >= L) ? -INFINITY : v;
-          p[e] = ElemTraits<T>::rnd(pf_exp(x - m_fin) * inv_l);  // exp(-inf) = 0
-          sm_p[r][c_row(e, hi)][lq] = p[e];
-        }
+        // exp(v - m) = 2^(v log2e - m log2e), exp(-inf) = 0
+        const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(v0, kLog2e, m_fin_l2)) * inv_l;
+        const float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(v1, kLog2e, m_fin_l2)) * inv_l;
+        pp[e >> 1] = pf_rnd2<T>(e0, e1, p[e], p[e + 1]);
+        sm_p[r][c_row(e, hi)][lq] = p[e];
+        sm_p[r][c_row(e + 1, hi)][lq] = p[e + 1];
       }
       __syncthreads();  // B1: the four heads' probability tiles are in LDS
       {
@@ -317,11 +331,7 @@ __global__ __launch_bounds__(256) void prefill_pv_lds_kernel(MArgs a) {
       // ---- O += P . V : A = P (C layout -> 16-bit), B = V^T fragments from the LDS image
 #pragma unroll
       for (int kb = 0; kb < 2; kb++) {
-        uint4 pa;
-        pa.x = MfmaOps<T>::pack2(p[kb * 8 + 0], p[kb * 8 + 1]);
-        pa.y = MfmaOps<T>::pack2(p[kb * 8 + 2], p[kb * 8 + 3]);
-        pa.z = MfmaOps<T>::pack2(p[kb * 8 + 4], p[kb * 8 + 5]);
-        pa.w = MfmaOps<T>::pack2(p[kb * 8 + 6], p[kb * 8 + 7]);
+        const uint4 pa = make_uint4(pp[kb * 4 + 0], pp[kb * 4 + 1], pp[kb * 4 + 2], pp[kb * 4 + 3]);
 #pragma unroll
         for (int db = 0; db < 4; db++) {
           const int d = db * 32 + lq;

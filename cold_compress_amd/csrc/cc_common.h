@@ -54,6 +54,19 @@ struct ElemTraits<bf16_t> {
   __device__ static __forceinline__ void store(bf16_t* p, size_t i, float v) { p[i].x = f32_to_bf16_bits(v); }
   __device__ static __forceinline__ float rnd(float v) { return bf16_bits_to_f32(f32_to_bf16_bits(v)); }
 };
+// two roundings in one v_cvt_pk_bf16_f32 (the conversion is a packed instruction: rounding values one at a time wastes
+// half of it); `packed` = lo | hi << 16 is what a 16-bit MFMA operand wants, the floats are its two halves
+__device__ __forceinline__ uint32_t bf16_round_pair(float a, float b, float& ra, float& rb) {
+  typedef float cc_f32x2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 cc_bf16x2 __attribute__((ext_vector_type(2)));
+  const cc_f32x2 v = {a, b};
+  const cc_bf16x2 r = __builtin_convertvector(v, cc_bf16x2);
+  const uint32_t packed = __builtin_bit_cast(uint32_t, r);
+  ra = __uint_as_float(packed << 16);
+  rb = __uint_as_float(packed & 0xffff0000u);
+  return packed;
+}
+
 template <>
 struct ElemTraits<f16_t> {
   static constexpr int code = CC_DT_F16;
