@@ -65,7 +65,7 @@ SIGNATURES = {
     "cc_softmax_argmax": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
     "cc_gemv_fused": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _vp]),
     "cc_kv_requant": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
-    "cc_kv_requant_pair": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "cc_kv_requant_pair": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp]),
     "cc_kv_dequant": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "cc_hh_next_key_slots": (_i32, [_i32]),
     "cc_rg_next_key_init": (C.c_int, [_view, _vp, _i32, _vp, _vp]),

@@ -129,6 +129,11 @@ class KVCache(nn.Module):
                 self.register_buffer(f"{name}_cache_q", torch.zeros(qshape, dtype=qdt))
                 self.register_buffer(f"{name}_scales", torch.zeros((S,), dtype=dtype))
                 self.register_buffer(f"{name}_zero_points", torch.zeros((S,), dtype=dtype))
+            # which slots the round trip no longer changes, and the positions they held when that was established
+            self.register_buffer("_quant_stable", torch.zeros((2, S), dtype=torch.uint8), persistent=False)
+            self.register_buffer("_quant_pos_seen", torch.zeros((2, n_heads if head_specific else 1, S), dtype=torch.int32),
+                                 persistent=False)
+            self._quant_tag = None
         # the constructor quantises the zero cache (cache.py:188-197): done by the first flush
         self._quant_pending = self.quantize
         self._scratch = _Scratch()
@@ -152,9 +157,17 @@ class KVCache(nn.Module):
         if self.quantize and self._quant_pending:
             H, S, D = self.n_heads, self.max_cache_length, self.head_dim
             _need_device(self.k_cache, "k/v cache")
+            # slots the round trip no longer changes are skipped exactly (include/coldcompress.h); torch-side writes to
+            # the working caches (prefill gathers, reset, a test poking values) move the tensors' version counters
+            tag = (self.k_cache._version, self.v_cache._version, self.k_cache.data_ptr(), self.v_cache.data_ptr())
+            if tag != self._quant_tag:
+                self._quant_stable.zero_()
+                self._quant_pos_seen.zero_()
+                self._quant_tag = tag
             _abi.call("cc_kv_requant_pair", _ptr(self.k_cache), _ptr(self.k_cache_q), _ptr(self.k_scales), _ptr(self.k_zero_points),
                       _ptr(self.v_cache), _ptr(self.v_cache_q), _ptr(self.v_scales), _ptr(self.v_zero_points), H, S, D,
-                      _DT[self.k_cache.dtype], int(self.n_bit), _stream())
+                      _DT[self.k_cache.dtype], int(self.n_bit), _ptr(self.pos), int(self.pos.shape[1]), _ptr(self._quant_stable),
+                      _ptr(self._quant_pos_seen), _stream())
             self._quant_pending = False
 
     def dequantize_cache(self):

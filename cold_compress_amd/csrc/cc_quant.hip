@@ -21,11 +21,21 @@ __device__ __forceinline__ float q_dequant(int q, int half, float scale, float z
   return ElemTraits<T>::rnd(__fadd_rn(ElemTraits<T>::rnd(__fmul_rn((float)(q - half), scale)), zero));
 }
 
+constexpr int kQSlots = 4;   // slots per workgroup of the vectorised round trip
+
 struct RequantSet {
   void* work[2];
   uint8_t* q[2];
   void* scales[2];
   void* zeros[2];
+  // Exact skipping of slots the round trip no longer changes (vectorised kernel only; null = requantise everything).
+  // The round trip of a slot is a pure function of that slot's rows: once a pass left a slot's rows bit-identical
+  // (stable = 1) and nothing has been inserted there since (pos of every head still equals pos_seen), running it
+  // again would reproduce the same rows, image, scale and zero point — so it is not run.
+  const int32_t* pos;   // [Hp, S]
+  int Hp;
+  uint8_t* stable;      // [2, S]   (K, V)
+  int32_t* pos_seen;    // [2, Hp, S]
 };
 
 template <typename T>
@@ -156,7 +166,29 @@ __global__ __launch_bounds__(1024) void kv_requant_vec_kernel(RequantSet rs, int
   uint8_t* q_out = rs.q[blockIdx.y];
   T* scales = reinterpret_cast<T*>(rs.scales[blockIdx.y]);
   T* zeros = reinterpret_cast<T*>(rs.zeros[blockIdx.y]);
-  const int s = blockIdx.x;
+  // kQSlots consecutive slots per workgroup: lane t of the first wave decides whether slot s0 + t needs the round trip
+  // (in steady state ~0.3 % do: the freshly inserted slot and the few whose image oscillates), then the whole
+  // workgroup walks the ones that do
+  __shared__ unsigned long long sm_need;
+  __shared__ int sm_changed;
+  const int s0 = blockIdx.x * kQSlots;
+  if (threadIdx.x < 64) {
+    const int sc = s0 + (int)threadIdx.x;
+    bool need = threadIdx.x < kQSlots && sc < S;
+    if (need && rs.stable != nullptr) {
+      bool same = rs.stable[(size_t)blockIdx.y * S + sc] != 0;
+      for (int hp = 0; hp < rs.Hp; hp++)
+        same &= rs.pos[(size_t)hp * S + sc] == rs.pos_seen[((size_t)blockIdx.y * rs.Hp + hp) * S + sc];
+      need = !same;
+    }
+    const unsigned long long m = __ballot(need);
+    if (threadIdx.x == 0) sm_need = m;
+  }
+  __syncthreads();
+  unsigned long long todo = sm_need;
+  while (todo) {
+  const int s = s0 + __builtin_ctzll(todo);
+  todo &= todo - 1;
   const int vpr = D / VEC;           // vectors per row
   const int nvec = H * vpr;          // == blockDim.x rounded up to a wave
   const int v = threadIdx.x;
@@ -202,7 +234,8 @@ __global__ __launch_bounds__(1024) void kv_requant_vec_kernel(RequantSet rs, int
     ElemTraits<T>::store(scales, (size_t)s, scale);
     ElemTraits<T>::store(zeros, (size_t)s, zero);
   }
-  if (!in) return;
+  bool changed = false;
+  if (in) {
   float o[VEC];
   unsigned long long packed = 0ull;  // VEC values of n_bit bits, value j shifted left by j * n_bit
 #pragma unroll
@@ -214,6 +247,8 @@ __global__ __launch_bounds__(1024) void kv_requant_vec_kernel(RequantSet rs, int
     packed |= (unsigned long long)q << (e * n_bit);
   }
   if constexpr (sizeof(T) == 4) {
+#pragma unroll
+    for (int e = 0; e < VEC; e++) changed |= __float_as_uint(o[e]) != __float_as_uint(x[e]);
     *reinterpret_cast<float4*>(work + base) = make_float4(o[0], o[1], o[2], o[3]);
   } else {
     T e16[VEC];
@@ -222,6 +257,11 @@ __global__ __launch_bounds__(1024) void kv_requant_vec_kernel(RequantSet rs, int
     uint32_t w32[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) w32[i] = (uint32_t)e16[2 * i].x | ((uint32_t)e16[2 * i + 1].x << 16);
+    T x16[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; e++) ElemTraits<T>::store(&x16[e], 0, x[e]);  // exact: x came from T
+#pragma unroll
+    for (int i = 0; i < 4; i++) changed |= w32[i] != ((uint32_t)x16[2 * i].x | ((uint32_t)x16[2 * i + 1].x << 16));
     *reinterpret_cast<uint4*>(work + base) = make_uint4(w32[0], w32[1], w32[2], w32[3]);
   }
   const size_t qbyte = base * n_bit / 8;  // VEC * n_bit is a whole number of bytes (VEC >= 4)
@@ -230,13 +270,25 @@ __global__ __launch_bounds__(1024) void kv_requant_vec_kernel(RequantSet rs, int
   else if (nbytes == 4) *reinterpret_cast<uint32_t*>(q_out + qbyte) = (uint32_t)packed;
   else if (nbytes == 2) *reinterpret_cast<uint16_t*>(q_out + qbyte) = (uint16_t)packed;
   else q_out[qbyte] = (uint8_t)packed;
+  }
+  if (rs.stable != nullptr) {  // did this pass leave the slot's rows bit-identical?
+    if (threadIdx.x == 0) sm_changed = 0;
+    __syncthreads();
+    if (changed) sm_changed = 1;
+    __syncthreads();
+    if (threadIdx.x == 0) rs.stable[(size_t)blockIdx.y * S + s] = sm_changed ? 0 : 1;
+    if ((int)threadIdx.x < rs.Hp)
+      rs.pos_seen[((size_t)blockIdx.y * rs.Hp + threadIdx.x) * S + s] = rs.pos[(size_t)threadIdx.x * S + s];
+  }
+  __syncthreads();  // sm_mn / sm_mx / sm_changed are reused by the next slot
+  }
 }
 
 static int requant_launch(const RequantSet& rs, int n, int32_t H, int32_t S, int32_t D, int32_t dtype, int32_t n_bit, hipStream_t st) {
   const int vec = 16 / (int)cc_dt_size(dtype);
   if (D % vec == 0 && H * (D / vec) <= 1024) {  // the common case: one thread per 16-byte vector of the slot
     const int threads = ((H * (D / vec) + 63) / 64) * 64;
-    dim3 grid(S, n), block(threads);
+    dim3 grid((S + kQSlots - 1) / kQSlots, n), block(threads);
     switch (dtype) {
       case CC_DT_F32: hipLaunchKernelGGL(kv_requant_vec_kernel<float>, grid, block, 0, st, rs, H, S, D, n_bit); break;
       case CC_DT_BF16: hipLaunchKernelGGL(kv_requant_vec_kernel<bf16_t>, grid, block, 0, st, rs, H, S, D, n_bit); break;
@@ -268,12 +320,14 @@ int cc_kv_requant(void* work, void* q_out, void* scales, void* zeros, int32_t H,
 }
 
 int cc_kv_requant_pair(void* k_work, void* k_q, void* k_scales, void* k_zeros, void* v_work, void* v_q, void* v_scales,
-                       void* v_zeros, int32_t H, int32_t S, int32_t D, int32_t dtype, int32_t n_bit, cc_stream_t stream) {
+                       void* v_zeros, int32_t H, int32_t S, int32_t D, int32_t dtype, int32_t n_bit, const int32_t* pos,
+                       int32_t Hp, uint8_t* stable, int32_t* pos_seen, cc_stream_t stream) {
   CC_ENTRY();
   if (!k_work || !k_q || !k_scales || !k_zeros || !v_work || !v_q || !v_scales || !v_zeros || !quant_args_ok(H, S, D, dtype, n_bit))
     return CC_ERR_BAD_ARG;
+  if (stable && (!pos || !pos_seen || Hp <= 0 || Hp > 64)) return CC_ERR_BAD_ARG;
   RequantSet rs{{k_work, v_work}, {reinterpret_cast<uint8_t*>(k_q), reinterpret_cast<uint8_t*>(v_q)}, {k_scales, v_scales},
-                {k_zeros, v_zeros}};
+                {k_zeros, v_zeros}, pos, Hp, stable, pos_seen};
   return requant_launch(rs, 2, H, S, D, dtype, n_bit, (hipStream_t)stream);
 }
 

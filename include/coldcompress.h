@@ -252,9 +252,15 @@ int cc_decode_attn_gqa_phases(const void* q, const void* k, const void* v, const
  * ---------------------------------------------------------------------------------------------- */
 int cc_kv_requant(void* work, void* q_out, void* scales, void* zeros, int32_t H, int32_t S, int32_t D,
                   int32_t dtype, int32_t n_bit, cc_stream_t stream);
-/* K and V in one launch (what KVCache.quantize_cache does every step). */
+/* K and V in one launch (what KVCache.quantize_cache does every step).
+ * Optional exact skipping (stable != NULL): the round trip of a slot is a pure function of that slot's rows, so once a
+ * pass left them bit-identical (stable[kv, s] = 1) and no insert touched the slot since (pos[:, s] still equals
+ * pos_seen[kv, :, s]; an insert always writes a new position), repeating it would reproduce the same rows, image,
+ * scale and zero point — the slot is skipped.  stable: uint8 [2, S], pos_seen: int32 [2, Hp, S], both zero-initialised
+ * (and zeroed again whenever the working caches are written by anything but the cache's own inserts); pos: [Hp, S]. */
 int cc_kv_requant_pair(void* k_work, void* k_q, void* k_scales, void* k_zeros, void* v_work, void* v_q, void* v_scales,
-                       void* v_zeros, int32_t H, int32_t S, int32_t D, int32_t dtype, int32_t n_bit, cc_stream_t stream);
+                       void* v_zeros, int32_t H, int32_t S, int32_t D, int32_t dtype, int32_t n_bit, const int32_t* pos,
+                       int32_t Hp, uint8_t* stable, int32_t* pos_seen, cc_stream_t stream);
 int cc_kv_dequant(const void* q, const void* scales, const void* zeros, void* work_out, int32_t H, int32_t S,
                   int32_t D, int32_t dtype, int32_t n_bit, cc_stream_t stream);
 

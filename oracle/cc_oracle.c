@@ -1342,7 +1342,10 @@ int cc_kv_requant_cpu(void* work, void* q_out, void* scales, void* zeros, int32_
 }
 
 int cc_kv_requant_pair_cpu(void* k_work, void* k_q, void* k_scales, void* k_zeros, void* v_work, void* v_q, void* v_scales,
-                           void* v_zeros, int32_t H, int32_t S, int32_t D, int32_t dt, int32_t n_bit, cc_stream_t stream) {
+                           void* v_zeros, int32_t H, int32_t S, int32_t D, int32_t dt, int32_t n_bit, const int32_t* pos, int32_t Hp,
+                           uint8_t* stable, int32_t* pos_seen, cc_stream_t stream) {
+  /* the oracle always runs the whole round trip: the device's skipping of stable slots must be invisible */
+  (void)pos; (void)Hp; (void)stable; (void)pos_seen;
   int rc = cc_kv_requant_cpu(k_work, k_q, k_scales, k_zeros, H, S, D, dt, n_bit, stream);
   if (rc != CC_OK) return rc;
   return cc_kv_requant_cpu(v_work, v_q, v_scales, v_zeros, H, S, D, dt, n_bit, stream);
