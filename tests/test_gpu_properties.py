@@ -7,6 +7,7 @@ S = 4096, bf16) — checked with plain torch on the device, independently of the
   * attention is invariant under a permutation of the cache slots (K, V, mask permuted together);
   * masked-out padding does not matter: the same cache embedded in a longer, masked buffer gives the same output;
   * prompt compaction keeps indices sorted, keeps every global / recent token, and gathers rows bit for bit."""
+import numpy as np
 import pytest
 import torch
 
@@ -124,3 +125,40 @@ def test_prompt_compaction_properties():
         worst_kept = norms[h][kept[h] & ~prot].max()
         best_dropped = norms[h][~kept[h]].min()
         assert best_dropped >= worst_kept * (1 - 2 ** -7), "a dropped key is clearly smaller than a kept one"
+
+
+def test_topk_keep_fuzz_vs_oracle(oracle):
+    """Prompt compaction's keep set (cc_topk_keep) over 60 seeded random cases — priority dtype (f32 / bf16 / f16 / int64),
+    1 .. 9 rows, 1 .. 5000 keys, K from 1 to L, heavy ties (few distinct values), +-inf and NaN entries — device ==
+    oracle exactly: the tie rule (lowest index first) and NaN-above-+inf are part of the contract."""
+    import random
+
+    from cold_compress_amd.prompt_compression import topk_keep
+    from helpers import to_np
+
+    rng = random.Random(17)
+    codes = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2, torch.int64: 3}
+    for i in range(60):
+        dt = rng.choice(list(codes))
+        Hs = rng.choice([1, 2, 8, 9])
+        L = rng.choice([rng.randint(1, 70), rng.randint(71, 1100), rng.randint(1101, 5000)])
+        K = rng.choice([1, L, rng.randint(1, L), max(1, L // 2)])
+        gen = torch.Generator().manual_seed(4000 + i)
+        if dt == torch.int64:
+            pr = torch.randint(-5, rng.choice([3, 1000, 2 ** 40]), (Hs, L), generator=gen, dtype=torch.int64)
+        else:
+            pr = torch.randn(Hs, L, generator=gen)
+            kind = rng.randrange(4)
+            if kind == 1:
+                pr = (pr * 2).round() / 2  # few distinct values: long tie classes at the K-th priority
+            elif kind == 2:
+                pr[:, :: max(1, L // 7)] = float("inf")
+                pr[:, 1:: max(2, L // 5)] = float("-inf")
+            elif kind == 3:
+                pr[:, :: max(1, L // 4)] = float("nan")
+            pr = pr.to(dt)
+        keep = topk_keep(pr.to(DEV), K).cpu().numpy()
+        ko = np.zeros((Hs, K), np.int64)
+        arr = pr.numpy().copy() if dt == torch.int64 else to_np(pr)
+        oracle.call("cc_topk_keep", oracle.ptr(arr), codes[dt], Hs, L, K, oracle.ptr(ko), None, 0, None)
+        assert np.array_equal(keep, ko), f"case {i}: {dt} Hs={Hs} L={L} K={K}"

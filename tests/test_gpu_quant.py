@@ -114,3 +114,49 @@ def test_e2e_cache_bits_8(graphed):
         assert torch.equal(kv.attn_history_denom.cpu(), f[f"final_denom_L{li}"])
     stats = model.get_cache_stats(f["prompt_len"], f["new_tokens"])
     assert abs(stats["compression_ratio_avg"] - f["compression_ratio_avg"]) < 1e-6
+
+
+def test_requant_fuzz_vs_oracle(oracle):
+    """40 seeded random shapes (heads, slots, head_dim, dtype, bits) and value patterns (normal, constant rows, zeros,
+    huge spread, a slot of subnormals): device round trip == oracle, bit for bit — working cache, image, scales, zeros.
+    Both device kernels are hit: one thread per 16-byte vector (H * D / vec <= 1024) and the element-wise fallback."""
+    import ctypes as C
+    import random
+
+    from cold_compress_amd import _abi
+    from helpers import DT_CODE, to_np
+
+    rng = random.Random(5)
+    p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    for i in range(40):
+        dt = rng.choice([torch.bfloat16, torch.float16, torch.float32])
+        nb = rng.choice([8, 4, 2])
+        H, S = rng.choice([1, 2, 3, 8, 32]), rng.randint(1, 200)
+        D = rng.choice([8, 16, 64, 128, 256])
+        gen = torch.Generator().manual_seed(900 + i)
+        x = torch.randn(H, S, D, generator=gen)
+        kind = rng.randrange(5)
+        if kind == 1:
+            x[:, ::3] = 0.75  # constant slots: zero range -> the 1e-6 floor
+        elif kind == 2:
+            x[:, 1::2] = 0.0
+        elif kind == 3:
+            x = x * torch.logspace(-6, 4, S).view(1, S, 1)
+        elif kind == 4 and dt != torch.float16:
+            x[:, 0] = 1e-39
+        x = x.to(dt)
+        code = DT_CODE[dt]
+        work_o = to_np(x).copy()
+        q_o = np.zeros(H * S * D * nb // 8, np.uint8)
+        es = np.float32 if code == 0 else np.uint16
+        sc_o, zp_o = np.zeros(S, es), np.zeros(S, es)
+        oracle.call("cc_kv_requant", oracle.ptr(work_o), oracle.ptr(q_o), oracle.ptr(sc_o), oracle.ptr(zp_o), H, S, D, code, nb, None)
+        work = x.to(DEV).contiguous()
+        q = torch.zeros(H * S * D * nb // 8, dtype=torch.uint8, device=DEV)
+        sc, zp = torch.zeros(S, dtype=dt, device=DEV), torch.zeros(S, dtype=dt, device=DEV)
+        _abi.call("cc_kv_requant", p(work), p(q), p(sc), p(zp), H, S, D, code, nb, None)
+        torch.cuda.synchronize()
+        what = f"case {i}: {dt} H={H} S={S} D={D} bits={nb} kind={kind}"
+        assert np.array_equal(to_np(work.cpu()), work_o), what + " (working cache)"
+        assert np.array_equal(q.cpu().numpy(), q_o), what + " (image)"
+        assert np.array_equal(to_np(sc.cpu()), sc_o) and np.array_equal(to_np(zp.cpu()), zp_o), what + " (scale / zero point)"
