@@ -56,11 +56,46 @@ CASES = [
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16, torch.float32])
 @pytest.mark.parametrize("name,N,K,opt", CASES)
 def test_gemv_fused_matches_fp32_reference(oracle, dt, name, N, K, opt):
-    from cold_compress_amd.harness import glue
-
     if dt == torch.float32 and K * 4 > 64 * 1024:
         pytest.skip("input vector beyond the LDS staging buffer for fp32 (the harness falls back to the library GEMV)")
-    g = torch.Generator().manual_seed(N * 7 + K)
+    _gemv_case(oracle, dt, name, N, K, opt, N * 7 + K)
+
+
+def test_gemv_fused_fuzz(oracle):
+    """40 seeded random shapes and option sets: 1 .. 3000 rows (odd counts included), K a multiple of the 16-byte vector
+    up to the 64 KiB input limit, any valid combination of norm / delta / SwiGLU pair / RoPE rows / bias."""
+    import random
+
+    rng = random.Random(23)
+    for i in range(40):
+        dt = rng.choice([torch.bfloat16, torch.float16, torch.float32])
+        vec = 4 if dt == torch.float32 else 8
+        K = vec * rng.choice([1, 2, 7, 33, 64, 129, 512, rng.randint(1, 1000)])
+        if K * (4 if dt == torch.float32 else 2) > 64 * 1024:
+            K = vec * 512
+        N = rng.choice([1, 2, 3, rng.randint(4, 300), rng.randint(301, 3000)])
+        opt = {}
+        if rng.random() < 0.6:
+            opt["norm"] = True
+            opt["delta"] = rng.random() < 0.6
+        mode = rng.randrange(3)
+        if mode == 1:
+            opt["swiglu"] = True
+        elif mode == 2 and N >= 2:
+            hd = rng.choice([2, 4, 16, 64])
+            rows = (N // hd) * hd if rng.random() < 0.5 else ((N // hd) // 2) * hd
+            if rows > 0:
+                opt["rope"] = (rows, hd)
+            opt["bias"] = rng.random() < 0.5
+        elif mode == 0:
+            opt["bias"] = rng.random() < 0.3
+        _gemv_case(oracle, dt, f"case {i}: {dt} N={N} K={K} {opt}", N, K, opt, 8000 + i)
+
+
+def _gemv_case(oracle, dt, name, N, K, opt, seed):
+    from cold_compress_amd.harness import glue
+
+    g = torch.Generator().manual_seed(seed)
     W = (torch.randn(N, K, generator=g) * 0.05).to(dt)
     W3 = (torch.randn(N, K, generator=g) * 0.05).to(dt) if opt.get("swiglu") else None
     x = torch.randn(K, generator=g).to(dt)
@@ -91,4 +126,4 @@ def test_gemv_fused_matches_fp32_reference(oracle, dt, name, N, K, opt):
     o.call("cc_gemv_fused", pp(W), pp(W3), pp(x), pp(delta), pp(nw), 1e-5, o.ptr(ho) if ho is not None else None, pp(bias), pp(freqs),
            rope_rows, hd, o.ptr(yo), N, K, DT_CODE[dt], None)
     yo_t = torch.from_numpy(yo.view(np.int16).copy()).view(dt).float() if dt != torch.float32 else torch.from_numpy(yo)
-    assert (y.cpu().float() - yo_t).abs().max() <= tol
+    assert (y.cpu().float() - yo_t).abs().max() <= tol, name
