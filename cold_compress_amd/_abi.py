@@ -70,6 +70,9 @@ SIGNATURES = {
     "cc_hh_next_key_slots": (_i32, [_i32]),
     "cc_rg_next_key_init": (C.c_int, [_view, _vp, _i32, _vp, _vp]),
     "cc_decode_step_recent_global": (C.c_int, [_view, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _sz, _vp]),
+    "cc_hh_ring_next_key_init": (C.c_int, [_view, _vp, _vp, _i32, _vp, _i32, _i32, _vp, _vp]),
+    "cc_decode_step_heavy_hitter_ring": (C.c_int, [_view, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32,
+                                                   _f32, _vp, _vp, _vp, _sz, _vp]),
     "cc_l2_next_key_init": (C.c_int, [_view, _vp, _vp, _i32, _i32, _vp, _vp]),
     "cc_decode_step_l2": (C.c_int, [_view, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _sz, _vp]),
     "cc_random_next_key_init": (C.c_int, [_view, _vp, _vp, _i32, _i32, _vp, _vp]),

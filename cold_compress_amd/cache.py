@@ -508,7 +508,7 @@ class KVCacheHeavyHitter(_TrackedWindowSums, KVCacheHeadSpecific):
         return True
 
     def supports_fused_step(self):
-        return self.history_window_size == 1
+        return True
 
     def update_kv(self, input_pos, k_val, v_val, is_prefill, **kwargs):
         self._next_valid = False  # the three-call path mutates pos / history outside the pipeline
@@ -517,11 +517,15 @@ class KVCacheHeavyHitter(_TrackedWindowSums, KVCacheHeadSpecific):
     # ------------------------------------------------------------------ fused decode step (2 launches per layer)
     def prepare_decode(self, input_pos):
         """Seed the pipeline: arg-min keys for `input_pos` from the current state (one select-only launch)."""
-        if self.history_window_size != 1:
-            raise ColdCompressError("the fused decode step needs history_window_size == 1")
-        _abi.call("cc_hh_next_key_init", self._view(), _ptr(self._pos32(input_pos)), _ptr(self.attn_history_num),
-                  _ptr(self.attn_history_denom), int(self.global_tokens), int(self.recent_window), _ptr(self.next_key),
-                  _stream())
+        if self.history_window_size != 1:  # finite history window: scored from the tracked window sums
+            wsum, _ = self._window_state()
+            _abi.call("cc_hh_ring_next_key_init", self._view(), _ptr(self._pos32(input_pos)), _ptr(self.attn_history_denom),
+                      int(self.history_window_size), _ptr(wsum), int(self.global_tokens), int(self.recent_window),
+                      _ptr(self.next_key), _stream())
+        else:
+            _abi.call("cc_hh_next_key_init", self._view(), _ptr(self._pos32(input_pos)), _ptr(self.attn_history_num),
+                      _ptr(self.attn_history_denom), int(self.global_tokens), int(self.recent_window), _ptr(self.next_key),
+                      _stream())
         self._next_valid = True
 
     def decode_step(self, query, k_val, v_val, input_pos, scale=None):
@@ -542,6 +546,14 @@ class KVCacheHeavyHitter(_TrackedWindowSums, KVCacheHeadSpecific):
         code = _DT[self.k_cache.dtype]
         nbytes = _abi.lib()["cc_decode_attn_workspace_bytes"](HQ, self.n_heads, self.max_cache_length, D, code)
         ws = _workspace(nbytes, query.device)
+        if self.history_window_size != 1:
+            wsum, acc = self._window_state()
+            _abi.call("cc_decode_step_heavy_hitter_ring", self._view(), _ptr(q), _ptr(k), _ptr(v), _ptr(p32), _ptr(self.attn_history_num),
+                      _ptr(self.attn_history_denom), _ptr(self.attn_counter), int(self.history_window_size), _ptr(acc), _ptr(wsum),
+                      _ptr(self.next_key), int(self.global_tokens), int(self.recent_window), HQ,
+                      1.0 / math.sqrt(D) if scale is None else scale, _ptr(y), None, _ptr(ws), ws.numel(), _stream())
+            self._quant_pending = self.quantize
+            return y
         _abi.call("cc_decode_step_heavy_hitter", self._view(), _ptr(q), _ptr(k), _ptr(v), _ptr(p32), _ptr(self.attn_history_num),
                   _ptr(self.attn_history_denom), _ptr(self.attn_counter), _ptr(self.next_key), int(self.global_tokens),
                   int(self.recent_window), HQ, 1.0 / math.sqrt(D) if scale is None else scale, _ptr(y), None, _ptr(ws),

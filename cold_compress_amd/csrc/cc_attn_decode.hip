@@ -780,7 +780,7 @@ struct CombineArgs {
   const int32_t* pos;  // [Hp, S]
   int H, g, w;
   int policy;  // next-eviction scoring: 1 = heavy hitter (cache.py:727-749), 2 = recent_global / full (cache.py:500-502, 552-556),
-               // 3 = random (cache.py:519-524 over rand_next)
+               // 3 = random (cache.py:519-524 over rand_next), 4 = l2, 5 = heavy hitter over the W > 1 history ring
   const float* rand_next;  // policy 3: [S] uniform draws for position p + 1
   // ---- l2 (policy 4, cache.py:597-605): score = dtype(max over all norms - norm); the maximum is folded from the
   //      per-wave partials of the streaming pass and the H freshly inserted norms
@@ -990,6 +990,7 @@ __global__ __launch_bounds__(kCombThreads) void decode_attn_combine_kernel(Combi
   int y_nout = 1, y_G = 1, y_oi = 0, y_g = 1, y_r = 0, y_d = 0;
   if (do_y) sm_y[threadIdx.x] = y_partial(y_lo, true, y_nout, y_G, y_oi, y_g, y_r, y_d);
 
+  bool fresh = false;
   // probabilities for this thread's slot
   if (have && !(a.abl & 32)) {
     const int s = s_mine;
@@ -1013,6 +1014,12 @@ __global__ __launch_bounds__(kCombThreads) void decode_attn_combine_kernel(Combi
     const size_t i = (size_t)h * S + s;
     if (a.attn_out) ElemTraits<T>::store(reinterpret_cast<T*>(a.attn_out), i, av);
     if (a.ring_num) {  // fused cache.py:716-723, W > 1: ring[h, s, counter % W] = attn; denom += 1; window sum kept exact
+      if (a.next_key && ps_mine == p_next - 1) {  // two-launch step: this slot was evicted and refilled by the streaming
+        racc = WAcc{0, 0, 0, 0};                  // pass — its history starts from zero (cache.py:754-763); the rest of
+        ring_old = 0.f;                           // the ring row and shadow column is cleared below, by the whole wave
+        den_old = 0;
+        fresh = true;
+      }
       ElemTraits<T>::store(reinterpret_cast<T*>(a.ring_num), i * (size_t)a.ring_W + ring_col, av);
       ElemTraits<T>::store(ring_shadow, i, av);
       a.hh_denom[i] = den_old + 1;
@@ -1020,7 +1027,15 @@ __global__ __launch_bounds__(kCombThreads) void decode_attn_combine_kernel(Combi
       wacc_add_value(racc, ring_old, true);
       *reinterpret_cast<ulonglong2*>(a.ring_acc + i * 4) = make_ulonglong2(racc.w0, racc.w1);
       *reinterpret_cast<ulonglong2*>(a.ring_acc + i * 4 + 2) = make_ulonglong2(racc.w2, racc.special);
-      a.ring_wsum[i] = wacc_round<T>(racc);
+      const float ws_new = wacc_round<T>(racc);
+      a.ring_wsum[i] = ws_new;
+      if (a.next_key && a.policy == 5) {  // next eviction score of the windowed history (cache.py:727-749, W > 1)
+        const int32_t dn = den_old + 1;
+        float scn = __fdiv_rn(ws_new, (float)(dn < 1 ? 1 : (dn > a.ring_W ? a.ring_W : dn)));
+        if (ps_mine < a.g || ps_mine >= p_next - a.w) scn = 1.0f;
+        if (ps_mine == -1) scn = 0.0f;
+        my_key = make_key(orderable_f32(scn), ((uint32_t)s << 1) | (uint32_t)(ps_mine == -1));
+      }
     }
     if (a.hh_num) {  // fused cache.py:716-722 (W == 1, attention already padded to S)
       const double num_new = num_old + (double)av;
@@ -1033,6 +1048,22 @@ __global__ __launch_bounds__(kCombThreads) void decode_attn_combine_kernel(Combi
         if (ps_mine == -1) scn = 0.0f;
         my_key = make_key(orderable_f32(scn), ((uint32_t)s << 1) | (uint32_t)(ps_mine == -1));
       }
+    }
+  }
+  if (a.ring_num && a.next_key) {  // clear the rest of a refilled slot's ring row and shadow column (one slot per head and step)
+    unsigned long long fm = __ballot(fresh);
+    while (fm) {
+      const int src = __builtin_ctzll(fm);
+      fm &= fm - 1;
+      const int sl = __shfl(s_mine, src, CC_WAVE);
+      const size_t hs = (size_t)gridDim.y * S, i = (size_t)h * S + sl;
+      T* ring = reinterpret_cast<T*>(a.ring_num) + i * (size_t)a.ring_W;
+      T* shadow0 = reinterpret_cast<T*>(a.ring_acc + hs * 4 + 2);
+      for (int j = lane; j < a.ring_W; j += 64)
+        if (j != ring_col) {
+          ElemTraits<T>::store(ring, j, 0.f);
+          ElemTraits<T>::store(shadow0, (size_t)j * hs + i, 0.f);
+        }
     }
   }
   if (a.next_key && a.policy == 2 && have && h == 0 && s_mine >= a.g)  // arg-min of pos over the slots behind the sinks; -1 = empty first
@@ -1350,6 +1381,19 @@ int cc_decode_step_l2(const cc_kv_view* c, const void* q, const void* k_new, con
                key_norm};
   return attn_impl(q, c->k_cache, c->v_cache, c->mask, HQ, c->H, c->S, c->D, c->dtype, scale, y, nullptr, nullptr, nullptr, nullptr,
                    nullptr, workspace, workspace_bytes, stream, 3, &fs);
+}
+
+int cc_decode_step_heavy_hitter_ring(const cc_kv_view* c, const void* q, const void* k_new, const void* v_new, const int32_t* input_pos,
+                                     void* ring_num, int32_t* denom, int64_t* counter, int32_t W, uint64_t* wsum_acc, float* wsum,
+                                     uint64_t* next_key, int32_t global_tokens, int32_t recent_window, int32_t HQ, float scale, void* y,
+                                     void* attn_out, void* workspace, size_t workspace_bytes, cc_stream_t stream) {
+  if (!cc_view_ok(c) || !q || !k_new || !v_new || !input_pos || !next_key || !y || c->Hp != c->H || HQ <= 0 || HQ % c->H)
+    return CC_ERR_BAD_ARG;
+  FusedStep fs{c, k_new, v_new, input_pos, reinterpret_cast<unsigned long long*>(next_key), global_tokens, recent_window, 5, nullptr,
+               nullptr};
+  RingHistory rh{ring_num, W, wsum_acc, wsum};
+  return attn_impl(q, c->k_cache, c->v_cache, c->mask, HQ, c->H, c->S, c->D, c->dtype, scale, y, attn_out, nullptr, nullptr, denom, counter,
+                   workspace, workspace_bytes, stream, 3, &fs, &rh);
 }
 
 int cc_decode_attn_gqa_ring(const void* q, const void* k, const void* v, const uint8_t* mask, int32_t HQ, int32_t H, int32_t S,

@@ -280,6 +280,8 @@ struct RingArgs {
   int64_t* idx_out;
   float* wsum;  // [H,S] window sums: from the pre-pass, or the tracked state kept by cc_hh_ring_update
   u64* wacc;    // [H,S,4] tracked exact accumulators or null
+  unsigned long long* key_out;  // seed of the two-launch pipeline: [H][nk] arg-min keys, nothing else is touched
+  int nk;
 };
 
 template <typename T>
@@ -301,6 +303,10 @@ __global__ __launch_bounds__(kHybThreads) void hh_ring_decode_kernel(RingArgs a)
     best = key < best ? key : best;
   }
   best = block_min_u64(best, sm_key);
+  if (a.key_out != nullptr) {
+    for (int i = threadIdx.x; i < a.nk; i += blockDim.x) a.key_out[(size_t)h * a.nk + i] = (i == 0) ? best : ~0ull;
+    return;
+  }
   const int idx = (int)((best & 0xffffffffull) >> 1), ins = (int)(best & 1ull);
   for (int j = threadIdx.x; j < W; j += blockDim.x) ElemTraits<T>::store(num + (hoff + idx) * (size_t)W, j, 0.f);
   if (threadIdx.x == 0) {
@@ -502,6 +508,26 @@ int cc_decode_update_heavy_hitter_ring(const cc_kv_view* c, const void* k_new, c
   hipStream_t st = (hipStream_t)stream;
   if (!wsum_acc) launch_window_sums(num, nullptr, nullptr, c->H, c->S, W, c->dtype, wsum_workspace, nullptr, st);
   dim3 grid(c->H), block(kHybThreads);
+  switch (c->dtype) {
+    case CC_DT_F32: hipLaunchKernelGGL(hh_ring_decode_kernel<float>, grid, block, 0, st, a); break;
+    case CC_DT_BF16: hipLaunchKernelGGL(hh_ring_decode_kernel<bf16_t>, grid, block, 0, st, a); break;
+    default: hipLaunchKernelGGL(hh_ring_decode_kernel<f16_t>, grid, block, 0, st, a); break;
+  }
+  CC_LAUNCH_CHECK();
+  return CC_OK;
+}
+
+int cc_hh_ring_next_key_init(const cc_kv_view* c, const int32_t* input_pos, const int32_t* denom, int32_t W, const float* wsum,
+                             int32_t g, int32_t w, uint64_t* next_key, cc_stream_t stream) {
+  CC_ENTRY();
+  if (!cc_view_ok(c) || !input_pos || !denom || W <= 1 || !wsum || !next_key || c->Hp != c->H) return CC_ERR_BAD_ARG;
+  RingArgs a{};
+  a.pos = c->pos; a.H = c->H; a.Hc = c->Hc; a.S = c->S; a.D = c->D; a.W = W; a.g = g; a.w = w;
+  a.input_pos = input_pos; a.denom = const_cast<int32_t*>(denom); a.wsum = const_cast<float*>(wsum);
+  a.key_out = reinterpret_cast<unsigned long long*>(next_key);
+  a.nk = cc_next_key_slots(c->S);
+  dim3 grid(c->H), block(kHybThreads);
+  hipStream_t st = (hipStream_t)stream;
   switch (c->dtype) {
     case CC_DT_F32: hipLaunchKernelGGL(hh_ring_decode_kernel<float>, grid, block, 0, st, a); break;
     case CC_DT_BF16: hipLaunchKernelGGL(hh_ring_decode_kernel<bf16_t>, grid, block, 0, st, a); break;

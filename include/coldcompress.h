@@ -221,6 +221,18 @@ int cc_l2_next_key_init(const cc_kv_view* c, const int32_t* input_pos, void* key
 int cc_decode_step_l2(const cc_kv_view* c, const void* q, const void* k_new, const void* v_new, const int32_t* input_pos,
                       void* key_norm, uint64_t* next_key, int32_t global_tokens, int32_t recent_window, int32_t HQ,
                       float scale, void* y, void* workspace, size_t workspace_bytes, cc_stream_t stream);
+/* The same two-launch step for KVCacheHeavyHitter with a finite history window (history_window_size W > 1): the score is
+ * dtype(sum_W ring) / clamp(denom, 1, W) over the TRACKED window sums (see cc_hh_ring_update); the evicted slot's ring
+ * row, shadow column, accumulator and denom restart from zero inside the combine pass (cache.py:754-763), which also
+ * records this step's attention (cache.py:716-723).  ring_num / denom / counter / wsum_acc / wsum as for
+ * cc_decode_attn_gqa_ring; next_key: uint64 [H, NK]; attn_out optional. */
+int cc_hh_ring_next_key_init(const cc_kv_view* c, const int32_t* input_pos, const int32_t* denom, int32_t W, const float* wsum,
+                             int32_t global_tokens, int32_t recent_window, uint64_t* next_key, cc_stream_t stream);
+int cc_decode_step_heavy_hitter_ring(const cc_kv_view* c, const void* q, const void* k_new, const void* v_new,
+                                     const int32_t* input_pos, void* ring_num, int32_t* denom, int64_t* counter, int32_t W,
+                                     uint64_t* wsum_acc, float* wsum, uint64_t* next_key, int32_t global_tokens,
+                                     int32_t recent_window, int32_t HQ, float scale, void* y, void* attn_out,
+                                     void* workspace, size_t workspace_bytes, cc_stream_t stream);
 /* Measurement hook (cf. cc_decode_attn_gqa_phases): the same step with its two launches selectable. */
 int cc_decode_step_heavy_hitter_phases(const cc_kv_view* c, const void* q, const void* k_new, const void* v_new,
                                 const int32_t* input_pos, double* num, int32_t* denom, int64_t* counter,

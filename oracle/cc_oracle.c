@@ -1153,6 +1153,81 @@ int cc_decode_step_heavy_hitter_cpu(const cc_kv_view* c, const void* q, const vo
   return CC_OK;
 }
 
+/* KVCacheHeavyHitter with history_window_size W > 1 in the same pipeline (ref: cache.py:725-765, 716-723): the key of
+ * the slot head h evicts at position p, from the ring itself (exact window sums). */
+static uint64_t hh_ring_key_for_head(const cc_kv_view* c, int h, const void* num, const int32_t* denom, int W, int32_t p, int g, int w) {
+  uint64_t best = ~(uint64_t)0;
+  for (int s = 0; s < c->S; s++) {
+    const size_t i = (size_t)h * c->S + s;
+    const int32_t ps = c->pos[i];
+    int32_t dn = denom[i] < 1 ? 1 : (denom[i] > W ? W : denom[i]);
+    float v = window_sum_row(num, c->dtype, i * (size_t)W, W) / (float)dn;
+    if (ps < g || ps >= p - w) v = 1.0f;
+    if (ps == -1) v = 0.0f;
+    const uint64_t key = ((uint64_t)orderable_f32_host(v) << 32) | ((uint64_t)(uint32_t)s << 1) | (uint64_t)(ps == -1);
+    if (key < best) best = key;
+  }
+  return best;
+}
+
+int cc_decode_step_heavy_hitter_ring_cpu(const cc_kv_view* c, const void* q, const void* k_new, const void* v_new,
+                                         const int32_t* input_pos, void* ring_num, int32_t* denom, int64_t* counter, int32_t W,
+                                         uint64_t* wsum_acc, float* wsum, uint64_t* next_key, int32_t g, int32_t w, int32_t HQ,
+                                         float scale, void* y, void* attn_out, void* workspace, size_t workspace_bytes,
+                                         cc_stream_t stream) {
+  if (!view_ok(c) || !q || !k_new || !v_new || !input_pos || !ring_num || !denom || !counter || W <= 1 || !wsum_acc || !wsum ||
+      !next_key || !y || c->Hp != c->H || c->H > 4096)
+    return CC_ERR_BAD_ARG;
+  const int nk = cc_hh_next_key_slots_cpu(c->S);
+  const size_t hs = (size_t)c->H * c->S, es = dt_size(c->dtype);
+  int64_t idx[4096];
+  for (int h = 0; h < c->H; h++) {
+    uint64_t key = ~(uint64_t)0;
+    for (int i = 0; i < nk; i++)
+      if (next_key[(size_t)h * nk + i] < key) key = next_key[(size_t)h * nk + i];
+    if (key == ~(uint64_t)0) return CC_ERR_BAD_ARG;
+    idx[h] = (int64_t)((key & 0xffffffffu) >> 1);
+    const size_t i = (size_t)h * c->S + idx[h]; /* :754-763 the evicted slot's history restarts from zero */
+    for (int j = 0; j < W; j++) st(ring_num, c->dtype, i * (size_t)W + j, 0.f);
+    denom[i] = 0;
+    memset(wsum_acc + i * 4, 0, 4 * sizeof(uint64_t));
+    wsum[i] = 0.f;
+    for (int j = 0; j < W; j++) memset((char*)(wsum_acc + hs * 4 + 2) + ((size_t)j * hs + i) * es, 0, es);
+  }
+  insert_token(c, k_new, v_new, *input_pos, idx);
+  int rc = cc_decode_attn_gqa_ring_cpu(q, c->k_cache, c->v_cache, c->mask, HQ, c->H, c->S, c->D, c->dtype, scale, y, attn_out, ring_num,
+                                       denom, counter, W, wsum_acc, wsum, workspace, workspace_bytes, stream);
+  if (rc != CC_OK) return rc;
+  for (int h = 0; h < c->H; h++) {
+    for (int i = 1; i < nk; i++) next_key[(size_t)h * nk + i] = ~(uint64_t)0;
+    next_key[(size_t)h * nk] = hh_ring_key_for_head(c, h, ring_num, denom, W, *input_pos + 1, g, w);
+  }
+  return CC_OK;
+}
+
+int cc_hh_ring_next_key_init_cpu(const cc_kv_view* c, const int32_t* input_pos, const int32_t* denom, int32_t W, const float* wsum,
+                                 int32_t g, int32_t w, uint64_t* next_key, cc_stream_t stream) {
+  (void)stream;
+  if (!view_ok(c) || !input_pos || !denom || W <= 1 || !wsum || !next_key || c->Hp != c->H) return CC_ERR_BAD_ARG;
+  const int nk = cc_hh_next_key_slots_cpu(c->S);
+  for (int h = 0; h < c->H; h++) {
+    uint64_t best = ~(uint64_t)0;
+    for (int s = 0; s < c->S; s++) { /* from the window sums handed in (the caller's tracked state) */
+      const size_t i = (size_t)h * c->S + s;
+      const int32_t ps = c->pos[i];
+      int32_t dn = denom[i] < 1 ? 1 : (denom[i] > W ? W : denom[i]);
+      float v = wsum[i] / (float)dn;
+      if (ps < g || ps >= *input_pos - w) v = 1.0f;
+      if (ps == -1) v = 0.0f;
+      const uint64_t key = ((uint64_t)orderable_f32_host(v) << 32) | ((uint64_t)(uint32_t)s << 1) | (uint64_t)(ps == -1);
+      if (key < best) best = key;
+    }
+    for (int i = 1; i < nk; i++) next_key[(size_t)h * nk + i] = ~(uint64_t)0;
+    next_key[(size_t)h * nk] = best;
+  }
+  return CC_OK;
+}
+
 /* KVCacheL2 in the same pipeline (ref: cache.py:597-605 + :373-376): the key of the slot head h evicts at position p */
 static float l2_global_max(const cc_kv_view* c, const void* key_norm) {
   float mx = -INFINITY;

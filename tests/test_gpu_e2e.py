@@ -158,3 +158,71 @@ def test_hipgraph_decode_equals_eager(name):
         a, b = lg.attention.kv_cache, le.attention.kv_cache
         for (na, ta), (nb, tb) in zip(a.named_buffers(), b.named_buffers()):
             assert na == nb and torch.equal(ta, tb), na
+
+
+@pytest.mark.parametrize("strategy,extra", [("heavy_hitter", {"history_window_size": 8}), ("l2", {}), ("hybrid", {})])
+def test_harness_two_launch_step_equals_three_call_path(strategy, extra):
+    """Through the caller model (bf16, head_dim 128, hipGraph decode): the fused decode step / fused history of every
+    policy added after the goldens were captured — finite history window, l2, hybrid — generates the same tokens and
+    leaves the same cache state as the plain update_kv -> attention -> update_state sequence.  (random is covered with
+    injected draws in test_gpu_fused_step.py: its RNG stream differs between eager launches and a captured graph.)"""
+    import cold_compress_amd.cache as cache
+    from cold_compress_amd.harness import GraphedDecoder, ModelArgs, Transformer, decode_one_token, prefill, setup_caches
+
+    hyb = [{"strategy": "special"}, {"strategy": "special_punc"}, {"strategy": "special_punc_heavy_hitter", "heavy_hitter_frac": 0.3},
+           {"strategy": "special_punc_window", "recent_window": 0.3}, {"strategy": "full"}]
+
+    class Tok:
+        def special_ids(self):
+            return [[1], [2, 3]]
+
+        def punctuation_ids(self):
+            return [5, 6, 7]
+
+    def build(fused):
+        torch.manual_seed(5)
+        cfg = dict(block_size=512, vocab_size=256, n_layer=2, n_head=8, n_local_heads=2, dim=1024, intermediate_size=512)
+        model = Transformer(ModelArgs(**cfg)).to(torch.bfloat16).eval().to(DEV)
+        ap = argparse.ArgumentParser()
+        cache.add_cache_arguments(ap)
+        kw = vars(ap.parse_args([]))
+        kw.update(dict(cache_strategy=[strategy], prompt_compression_strategy=["full" if strategy == "hybrid" else strategy],
+                       max_cache_length=[1.0 if strategy == "hybrid" else 96.0], global_tokens=4, recent_window=10,
+                       hybrid_strategies=hyb, min_recovery_frac=0.9), **extra)
+        setup_caches(model, Tok(), DEV, 300, dict(kw))
+        for layer in model.layers:
+            layer.attention.fuse_decode_step = fused
+            layer.attention.fuse_state_update = fused
+        return model
+
+    outs = []
+    for fused in (False, True):
+        model = build(fused)
+        gen = torch.Generator().manual_seed(9)
+        prompt = torch.randint(8, 256, (200,), generator=gen, dtype=torch.int32).to(DEV)
+        prompt[::17] = 6  # some punctuation for the hybrid policies
+        with torch.no_grad():
+            tok, _ = prefill(model, prompt.view(1, -1), torch.arange(200, device=DEV))
+            if strategy == "hybrid":  # random weights profile every head as "full": force the reference's policy mix
+                for layer in model.layers:
+                    kv = layer.attention.kv_cache
+                    kv.cache_strategies = (torch.arange(kv.n_heads, device=DEV) % len(hyb)).to(torch.int64).contiguous()
+                    kv.requires_heavy_hitter = kv.requires_punc = kv.requires_special = True
+            dec = GraphedDecoder(model) if fused else decode_one_token
+            pos = torch.tensor([200], dtype=torch.int32, device=DEV)
+            cur = tok.view(1, 1).to(torch.int32)
+            toks = []
+            for _ in range(24):
+                cur = dec(model, cur, pos)[0].view(1, 1)
+                toks.append(int(cur))
+                pos += 1
+        state = {}
+        for li, layer in enumerate(model.layers):
+            kv = layer.attention.kv_cache
+            for n, b in kv.named_buffers():
+                if n != "next_key":
+                    state[f"{li}.{n}"] = b.clone()
+        outs.append((toks, state))
+    assert outs[0][0] == outs[1][0], "generated tokens"
+    for n in outs[0][1]:
+        assert torch.equal(outs[0][1][n], outs[1][1][n]), n

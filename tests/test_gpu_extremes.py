@@ -8,12 +8,12 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-def run(strategy, dtype, H, HQ, S, D, T, steps=6):
+def run(strategy, dtype, H, HQ, S, D, T, steps=6, W=1):
     import cold_compress_amd.cache as cache
     from cold_compress_amd.attention_utils import scaled_dot_product_attention as sdpa
 
     cls, rk = cache.get_cache_constructor(strategy)
-    kw = dict(max_cache_length=S, global_tokens=min(2, S // 2), recent_window=min(3, max(S // 4, 1)), history_window_size=1,
+    kw = dict(max_cache_length=S, global_tokens=min(2, S // 2), recent_window=min(3, max(S // 4, 1)), history_window_size=W,
               attn_thresholding=False, max_seq_length=4 * S + 64, cache_bits=None)
 
     def mk():
@@ -40,7 +40,7 @@ def run(strategy, dtype, H, HQ, S, D, T, steps=6):
         v1 = torch.randn(1, H, 1, D, generator=gen).to(dtype).to(DEV)
         q = torch.randn(1, HQ, 1, D, generator=gen).to(dtype).to(DEV)
         ka, va, ma = a.update_kv(p, k1, v1, False)
-        fuse = strategy == "heavy_hitter"
+        fuse = strategy == "heavy_hitter" and W == 1
         ya, at = sdpa(q, ka, va, attn_mask=ma, return_attn=a.return_attn() and not fuse, group_mean=True,
                       history=a.fused_history() if fuse else None)
         if fuse:
@@ -73,3 +73,13 @@ def test_32_query_heads_per_kv_head():
 
 def test_fp32_small_head_dim_single_query_head():
     run("heavy_hitter", torch.float32, 3, 3, 50, 32, 45)
+
+
+@pytest.mark.parametrize("dtype,H,HQ,S,D,T,W,steps", [(torch.bfloat16, 8, 32, 1024, 128, 1024, 8, 20), (torch.float32, 2, 4, 77, 16, 60, 3, 30),
+                                                      (torch.float16, 3, 12, 300, 128, 300, 33, 12), (torch.bfloat16, 1, 8, 40, 128, 0, 2, 50)])
+def test_finite_history_window_two_launch_step(dtype, H, HQ, S, D, T, W, steps):
+    """KVCacheHeavyHitter with history_window_size W > 1: cc_decode_step_heavy_hitter_ring (eviction scored from the
+    tracked window sums in the combine pass; the refilled slot's ring row / shadow / accumulator restart from zero
+    there) against update_kv -> attention -> update_state; ring, window sums, accumulators, everything bit for bit,
+    across ring wrap-arounds."""
+    run("heavy_hitter", dtype, H, HQ, S, D, T, steps=steps, W=W)

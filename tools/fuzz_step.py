@@ -27,7 +27,7 @@ def one(rng, idx):
     g = rng.randint(0, min(4, S // 3))
     w = rng.randint(1, max(1, min(10, S // 3)))
     bits = rng.choice([None, None, None, 8, 4]) if strategy not in ("l2",) else None
-    W = 1
+    W = rng.choice([1, 1, 2, 5, 33]) if strategy == "heavy_hitter" else 1
     cfg = dict(strategy=strategy, dtype=str(dtype), H=H, R=R, S=S, D=D, T=T, g=g, w=w, bits=bits)
     cls, rk = cache.get_cache_constructor(strategy)
     kw = dict(max_cache_length=S, global_tokens=g, recent_window=w, history_window_size=W, attn_thresholding=False,
@@ -63,7 +63,7 @@ def one(rng, idx):
         v1 = torch.randn(1, H, 1, D, generator=gen).to(dtype).to(DEV)
         q = torch.randn(1, H * R, 1, D, generator=gen).to(dtype).to(DEV)
         ka, va, ma = a.update_kv(p, k1, v1, False)
-        fuse = strategy == "heavy_hitter"
+        fuse = strategy == "heavy_hitter" and W == 1
         ya, at = sdpa(q, ka, va, attn_mask=ma, return_attn=a.return_attn() and not fuse, group_mean=True,
                       history=a.fused_history() if fuse else None)
         if fuse:
