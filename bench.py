@@ -263,17 +263,49 @@ def cpu_baseline(args, H_total=8, HQ=32, D=128):
                       f"GEMVs excluded; {dt:.1f} s of CPU work"}
 
 
+def _stage_collectives_through_host():
+    """gloo has no device path here: move device tensors through the host for the dry run."""
+    ar, bc = dist.all_reduce, dist.broadcast
+
+    def all_reduce(t, op=dist.ReduceOp.SUM, **kw):
+        if t.is_cuda:
+            c = t.float().cpu() if t.is_floating_point() else t.cpu()
+            ar(c, op=op)
+            t.copy_(c.to(t.dtype))
+            return None
+        return ar(t, op=op, **kw)
+
+    def broadcast(t, src=0, **kw):
+        if t.is_cuda:
+            c = t.cpu()
+            bc(c, src=src)
+            t.copy_(c)
+            return None
+        return bc(t, src=src, **kw)
+
+    dist.all_reduce, dist.broadcast = all_reduce, broadcast
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # Dry run of the N > 1 control flow on a box with ONE GPU (not a measurement): CC_BENCH_DRYRUN_ONE_GPU=1 puts every
+    # rank on cuda:0 and stages the collectives through gloo / the host.  The driver never sets it.
+    dry = world > 1 and os.environ.get("CC_BENCH_DRYRUN_ONE_GPU") == "1"
+    if dry:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if dry:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            _stage_collectives_through_host()
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from cold_compress_amd import _abi
     from cold_compress_amd.harness import GraphedDecoder, decode_one_token, prefill, setup_caches

@@ -140,25 +140,28 @@ class GraphedDecoder:
         snap = [{k: v.clone() for k, v in c._buffers.items()} for c in caches]
         flags = [(getattr(c, "_next_valid", None), getattr(c, "_quant_pending", False)) for c in caches]
         pos0 = self.pos.clone()
-        s = torch.cuda.Stream()
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            for _ in range(self.warmup):  # positions advance like a real decode (the pipeline assumes +1 steps)
-                decode_one_token(self.model, self.tok, self.pos)
-                self.pos += 1
-        torch.cuda.current_stream().wait_stream(s)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.out_tok, self.out_probs = decode_one_token(self.model, self.tok, self.pos)
-        self.pos.copy_(pos0)
-        for c, sn, fl in zip(caches, snap, flags):
-            for k, v in sn.items():
-                c._buffers[k].copy_(v)
-            if fl[0] is not None:
-                c._next_valid = fl[0]
-            c._quant_pending = fl[1]
-            if hasattr(c, "_ring_version"):  # ring and tracked window sums were restored together: still in step
-                c._ring_version = c._ring_tag()
+        try:
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                for _ in range(self.warmup):  # positions advance like a real decode (the pipeline assumes +1 steps)
+                    decode_one_token(self.model, self.tok, self.pos)
+                    self.pos += 1
+            torch.cuda.current_stream().wait_stream(s)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self.out_tok, self.out_probs = decode_one_token(self.model, self.tok, self.pos)
+            self.graph = graph
+        finally:  # also when capture is refused (e.g. a collective that cannot be captured): the caller falls back to
+            self.pos.copy_(pos0)  # eager launches and must find the state it handed in
+            for c, sn, fl in zip(caches, snap, flags):
+                for k, v in sn.items():
+                    c._buffers[k].copy_(v)
+                if fl[0] is not None:
+                    c._next_valid = fl[0]
+                c._quant_pending = fl[1]
+                if hasattr(c, "_ring_version"):  # ring and tracked window sums were restored together: still in step
+                    c._ring_version = c._ring_tag()
 
     def __call__(self, model, x, input_pos, next_token=None, **_):
         if self.graph is None:
