@@ -5,7 +5,6 @@ by torch.compile (generation_utils.py:578-594).
 Budget helpers are exact-integer restatements checked against tests/golden/f8_budgets.json.
 """
 import time
-from typing import Optional
 
 import torch
 

@@ -8,7 +8,6 @@ import ctypes as C
 import os
 import subprocess
 
-import numpy as np
 
 from cold_compress_amd import _abi
 

@@ -6,7 +6,6 @@ Also: the hipGraph-captured decode step must reproduce the eager decode exactly.
 import argparse
 import json
 
-import numpy as np
 import pytest
 import torch
 

@@ -2,7 +2,6 @@
 op chain and against the oracle's twin: plain, RMSNorm(x + delta) prologue, SwiGLU pair, RoPE epilogue, bias; bf16 /
 fp16 / fp32; the Llama-3-8B decode shapes and ragged ones.  Tolerance: 2 ulp of the output dtype relative to the
 largest output (the summation order of a dot product is the kernel's own), stated per case."""
-import ctypes as C
 
 import numpy as np
 import pytest

@@ -10,7 +10,6 @@ state needs no exchange (every buffer is indexed by kv head), which the GPU pari
 import os
 import socket
 
-import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
