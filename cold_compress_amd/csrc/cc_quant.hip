@@ -315,7 +315,7 @@ int cc_kv_requant(void* work, void* q_out, void* scales, void* zeros, int32_t H,
                   int32_t n_bit, cc_stream_t stream) {
   CC_ENTRY();
   if (!work || !q_out || !scales || !zeros || !quant_args_ok(H, S, D, dtype, n_bit)) return CC_ERR_BAD_ARG;
-  RequantSet rs{{work, nullptr}, {reinterpret_cast<uint8_t*>(q_out), nullptr}, {scales, nullptr}, {zeros, nullptr}};
+  RequantSet rs{{work, nullptr}, {reinterpret_cast<uint8_t*>(q_out), nullptr}, {scales, nullptr}, {zeros, nullptr}, nullptr, 0, nullptr, nullptr};
   return requant_launch(rs, 1, H, S, D, dtype, n_bit, (hipStream_t)stream);
 }
 
