@@ -558,6 +558,10 @@ def main():
                                               w=3, seed=23, extra={"history_window_size": 8}))
         save("f2_hh_w8_bf16.npz", replay_cache(C, "heavy_hitter", torch.bfloat16, H=4, S=48, D=16, T_prefill=30, steps=80, g=2,
                                                w=3, seed=24, extra={"history_window_size": 8}))
+        # a long trace (400 decode steps, the 33-entry ring wraps 12 times, full cache from the start): pins the "exact sum
+        # rounded once" definition of the window sums against torch's own bf16 `.sum(dim=-1)` over many evictions
+        save("f2_hh_w33_long_bf16.npz", replay_cache(C, "heavy_hitter", torch.bfloat16, H=3, S=64, D=16, T_prefill=64, steps=400,
+                                                     g=3, w=5, seed=102, extra={"history_window_size": 33}))
         # attn_thresholding=True cannot be captured: the reference itself raises at cache.py:721
         # ("Index put requires the source and destination dtypes match, got Bool ... and Int") on torch 2.10.
         if a.only == "f2w":

@@ -1,4 +1,4 @@
-"""KVCacheHeavyHitter with a finite history window (history_window_size = 8; ScissorHands' m), pinned against traces
+"""KVCacheHeavyHitter with a finite history window (history_window_size = 8 and 33; ScissorHands' m), pinned against traces
 captured from the reference (tests/golden/f2_hh_w8_*.npz): oracle on CPU, HIP path on the GPU.  The prefill column
 mean is tolerance-class (unspecified fp32 summation order), after which the replay continues on the reference's
 state and every eviction index, count and the ring contents are compared bit-exactly."""
@@ -10,12 +10,13 @@ import torch
 
 from helpers import DT_CODE, DT_FROM_NAME, load_golden, to_np
 
-NAMES = ["f2_hh_w8_f32.npz", "f2_hh_w8_bf16.npz"]
-W = 8
+NAMES = ["f2_hh_w8_f32.npz", "f2_hh_w8_bf16.npz", "f2_hh_w33_long_bf16.npz"]
+WINDOW = {"f2_hh_w33_long_bf16.npz": 33}  # history_window_size of each fixture (default 8)
 
 
 @pytest.mark.parametrize("name", NAMES)
 def test_ring_replay_oracle(oracle, name):
+    W = WINDOW.get(name, 8)
     f = load_golden(name)
     dtype = DT_FROM_NAME[f["dtype"]]
     code = DT_CODE[dtype]
@@ -58,6 +59,7 @@ def test_ring_replay_oracle(oracle, name):
 def test_ring_replay_gpu(name):
     import cold_compress_amd.cache as cache
 
+    W = WINDOW.get(name, 8)
     f = load_golden(name)
     dtype = DT_FROM_NAME[f["dtype"]]
     H, S, D, T, g, w = f["H"], f["S"], f["D"], f["T_prefill"], f["g"], f["w"]
