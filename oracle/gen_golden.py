@@ -549,6 +549,8 @@ def main():
         save("f6_hybrid_bf16.npz", hybrid_case(C, torch.bfloat16, HYBRID_YAML, 0.55, seed=62, steps=60))
         save("f6_hybrid_mixed_f32.npz", hybrid_case(C, torch.float32, HYBRID_YAML, 0.45, seed=64, steps=60, peaky=0.8))
         save("f6_fastgen_f32.npz", hybrid_case(C, torch.float32, FASTGEN_YAML, 0.7, seed=63))
+        # 450 decode steps: the hybrid cache's fixed 400-entry history ring wraps around (bf16 window sums)
+        save("f6_hybrid_long_bf16.npz", hybrid_case(C, torch.bfloat16, HYBRID_YAML, 0.55, seed=65, steps=450))
         if a.only == "f6":
             return
 

@@ -12,7 +12,7 @@ import torch
 from helpers import DT_CODE, DT_FROM_NAME, load_golden, to_np
 
 _HF = {"heavy_hitter": 1, "window": 2, "punc": 4, "special": 8}
-FIXTURES = ["f6_hybrid_f32.npz", "f6_hybrid_bf16.npz", "f6_hybrid_mixed_f32.npz", "f6_fastgen_f32.npz"]
+FIXTURES = ["f6_hybrid_f32.npz", "f6_hybrid_bf16.npz", "f6_hybrid_mixed_f32.npz", "f6_fastgen_f32.npz", "f6_hybrid_long_bf16.npz"]
 
 
 def policy_table(strategies, S):
