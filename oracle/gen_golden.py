@@ -615,6 +615,11 @@ def main():
     save("f2_hh_h1_bf16.npz", replay_cache(C, "heavy_hitter", torch.bfloat16, H=2, S=130, D=128, T_prefill=100, steps=70,
                                            g=4, w=10, seed=22))
     # F3: L2
+    # long traces at the model's head_dim (300 decode steps from a full cache): rare rounding cases get their chance
+    save("f2_hh_long_bf16.npz", replay_cache(C, "heavy_hitter", torch.bfloat16, H=2, S=256, D=128, T_prefill=256, steps=300, g=4,
+                                             w=10, seed=201))
+    save("f3_l2_long_bf16.npz", replay_cache(C, "l2", torch.bfloat16, H=2, S=300, D=128, T_prefill=300, steps=300, g=4, w=10,
+                                             seed=202))
     save("f3_l2_bf16.npz", replay_cache(C, "l2", torch.bfloat16, H=4, S=48, D=16, T_prefill=30, steps=80, g=2, w=3, seed=31))
     save("f3_l2_f32.npz", replay_cache(C, "l2", torch.float32, H=4, S=48, D=16, T_prefill=30, steps=60, g=2, w=3, seed=32))
     save("f3_l2_h1_bf16.npz", replay_cache(C, "l2", torch.bfloat16, H=1, S=200, D=128, T_prefill=150, steps=120, g=4, w=10,

@@ -67,7 +67,7 @@ def _final_equal(kv, f):
     assert torch.equal(kv.v_cache.cpu().float(), f["final_v"].float())
 
 
-@pytest.mark.parametrize("name", ["f2_hh_f32.npz", "f2_hh_bf16.npz", "f2_hh_h1_bf16.npz"])
+@pytest.mark.parametrize("name", ["f2_hh_f32.npz", "f2_hh_bf16.npz", "f2_hh_h1_bf16.npz", "f2_hh_long_bf16.npz"])
 def test_heavy_hitter_replay_vs_reference(cc, name):
     f = load_golden(name)
     dtype = DT_FROM_NAME[f["dtype"]]
@@ -93,7 +93,7 @@ def test_heavy_hitter_replay_vs_reference(cc, name):
     _final_equal(kv, f)
 
 
-@pytest.mark.parametrize("name", ["f3_l2_bf16.npz", "f3_l2_f32.npz", "f3_l2_h1_bf16.npz"])
+@pytest.mark.parametrize("name", ["f3_l2_bf16.npz", "f3_l2_f32.npz", "f3_l2_h1_bf16.npz", "f3_l2_long_bf16.npz"])
 def test_l2_replay_vs_reference(cc, name):
     f = load_golden(name)
     dtype = DT_FROM_NAME[f["dtype"]]

@@ -92,7 +92,7 @@ def _hh_prefill_state(oracle, c, attn0, T):
                 c.code, None)
 
 
-@pytest.mark.parametrize("name", ["f2_hh_f32.npz", "f2_hh_bf16.npz", "f2_hh_h1_bf16.npz"])
+@pytest.mark.parametrize("name", ["f2_hh_f32.npz", "f2_hh_bf16.npz", "f2_hh_h1_bf16.npz", "f2_hh_long_bf16.npz"])
 def test_heavy_hitter_replay_bit_exact(oracle, name):
     f = load_golden(name)
     dtype = DT_FROM_NAME[f["dtype"]]
@@ -120,7 +120,7 @@ def test_heavy_hitter_replay_bit_exact(oracle, name):
     _check_final(c, f, dtype)
 
 
-@pytest.mark.parametrize("name", ["f3_l2_bf16.npz", "f3_l2_f32.npz", "f3_l2_h1_bf16.npz"])
+@pytest.mark.parametrize("name", ["f3_l2_bf16.npz", "f3_l2_f32.npz", "f3_l2_h1_bf16.npz", "f3_l2_long_bf16.npz"])
 def test_l2_replay_bit_exact(oracle, name):
     f = load_golden(name)
     dtype = DT_FROM_NAME[f["dtype"]]
