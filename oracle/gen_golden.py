@@ -580,6 +580,11 @@ def main():
             for nb in (8, 4, 2):
                 save(f"f9_quant_hh_{tag}_{nb}.npz", replay_cache(C, "heavy_hitter", dt, H=3, S=24, D=16, T_prefill=17, steps=20, g=2,
                                                                 w=3, seed=31 + nb, extra=dict(cache_bits=nb), capture_kv=True))
+        # 120 steps from a full cache: every slot is round-tripped 120 times by the reference — the device's exact skipping
+        # of slots the round trip no longer changes has to stay invisible at every step
+        for nb, seed in ((8, 301), (4, 302)):
+            save(f"f9_quant_hh_long_bf16_{nb}.npz", replay_cache(C, "heavy_hitter", torch.bfloat16, H=3, S=40, D=16, T_prefill=40, steps=120,
+                                                                 g=2, w=3, seed=seed, extra=dict(cache_bits=nb), capture_kv=True))
         save("f9_quant_recent_global_f32_8.npz", replay_cache(C, "recent_global", torch.float32, H=2, S=16, D=8, T_prefill=16, steps=12,
                                                               g=4, w=3, seed=5, extra=dict(cache_bits=8), capture_kv=True))
         save("f9_e2e_heavy_hitter_q8.npz", run_e2e(C, G, M, "heavy_hitter", dict(

@@ -47,7 +47,7 @@ def test_requant_known_answers(tag, nb):
 
 
 @pytest.mark.parametrize("name", [f"f9_quant_hh_{t}_{nb}.npz" for t in ("f32", "bf16") for nb in (8, 4, 2)]
-                         + ["f9_quant_recent_global_f32_8.npz"])
+                         + ["f9_quant_recent_global_f32_8.npz", "f9_quant_hh_long_bf16_8.npz", "f9_quant_hh_long_bf16_4.npz"])
 def test_quantised_cache_replay_bit_exact(name):
     import cold_compress_amd.cache as cache
 
