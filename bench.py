@@ -93,7 +93,7 @@ def roofline(model, args, dev):
     HQ = layers[0].n_head
     fns = _abi.lib()
     nbytes = fns["cc_decode_attn_workspace_bytes"](HQ, H, S, D, 1)
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    ws = torch.zeros(nbytes, dtype=torch.uint8, device=dev)  # zero: the single-launch step's epoch words live here
     q = torch.randn(HQ, D, device=dev).to(torch.bfloat16)
     k1 = torch.randn(H, D, device=dev).to(torch.bfloat16)
     y = torch.empty(HQ, D, device=dev, dtype=torch.bfloat16)
@@ -286,17 +286,37 @@ def _stage_collectives_through_host():
     dist.all_reduce, dist.broadcast = all_reduce, broadcast
 
 
+def _self_launch(args):
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run with N ranks (one per GPU,
+    RCCL over xGMI), exactly the command the driver would have used.  Never silently runs TP=1 for --gpus N."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] --gpus {args.gpus} without WORLD_SIZE: launching {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr)
+    os.execv(sys.executable, cmd)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        _self_launch(args)  # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a {world}-rank run as {args.gpus} GPUs")
     # Dry run of the N > 1 control flow on a box with ONE GPU (not a measurement): CC_BENCH_DRYRUN_ONE_GPU=1 puts every
     # rank on cuda:0 and stages the collectives through gloo / the host.  The driver never sets it.
     dry = world > 1 and os.environ.get("CC_BENCH_DRYRUN_ONE_GPU") == "1"
     if dry:
         local = 0
+    elif torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py: --gpus {world} needs {world} visible GPUs, found {torch.cuda.device_count()} "
+                         "(one process per GPU; ranks never share a device)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
@@ -306,6 +326,7 @@ def main():
             _stage_collectives_through_host()
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
 
     from cold_compress_amd import _abi
     from cold_compress_amd.harness import GraphedDecoder, decode_one_token, prefill, setup_caches
@@ -410,7 +431,8 @@ def main():
             "config": {"workload": f"Llama-3-8B shape (32 layers, HQ=32, H=8, D=128, bf16, random N(0,0.02) weights), "
                                    f"cache_strategy=heavy_hitter, max_cache_length={kv0.max_cache_length}, "
                                    f"{args.prompt_len}-token random prompt -> decode, batch 1, greedy",
-                       "parallelism": f"tp{world}", "decode_mode": mode, "n_layer": args.n_layer,
+                       "parallelism": f"tp{world}", "rccl_ranks": (dist.get_world_size() if world > 1 else 1),
+                       "collective_backend": ("none" if world == 1 else dist.get_backend()), "decode_mode": mode, "n_layer": args.n_layer,
                        "prefill_seconds": round(prefill_s, 2)},
             "roofline": roof, "cpu_baseline": cpu,
         }

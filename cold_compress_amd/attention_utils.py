@@ -34,12 +34,23 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
-def _workspace(nbytes, device):
-    """One grow-only scratch buffer per device (never freed mid-graph; sized by the ABI's query)."""
-    key = str(device)
+_RETIRED = []  # superseded scratch buffers stay alive: a captured hipGraph may still hold their addresses
+
+
+def _workspace(nbytes, device, kind="decode"):
+    """Scratch for the attention kernels, sized by the ABI's query: one zero-initialised buffer per (device, kind).
+    Decode and prefill never share one: the decode buffer carries state across launches (the single-launch step's epoch
+    words, include/coldcompress.h) and its address is baked into captured hipGraphs, so it is only ever replaced by a
+    larger one — and the old one is kept alive, never handed back to the allocator."""
+    key = (str(device), kind)
     ws = _WS.get(key)
     if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
+        if torch.cuda.is_current_stream_capturing():
+            raise ColdCompressError("attention scratch must be allocated before hipGraph capture (run one eager step first): "
+                                    "a captured allocation would re-zero the single-launch step's epoch words on every replay")
+        if ws is not None:
+            _RETIRED.append(ws)
+        ws = torch.zeros(max(nbytes, 1), dtype=torch.uint8, device=device)
         _WS[key] = ws
     return ws
 
@@ -107,7 +118,7 @@ def prefill_attention(query, key, value, scale=None, return_attn=False, obs_len=
         colsum = torch.empty((H, L), dtype=torch.float32, device=query.device)
         obs = torch.empty((H, L), dtype=torch.float32, device=query.device)
     nbytes = _abi.lib()["cc_prefill_attn_workspace_bytes"](HQ, H, L, D, _DT[dt])
-    ws = _workspace(nbytes, query.device)
+    ws = _workspace(nbytes, query.device, "prefill")
     sc = 1.0 / math.sqrt(D) if scale is None else scale
     bands = [int(b) for b in bands] if return_attn else []
     if len(bands) > 4:

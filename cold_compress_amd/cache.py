@@ -6,8 +6,9 @@ compute_statistics` plus the buffers `k_cache, v_cache, pos, mask, cache_cts` (s
 as ref: cache.py:178-227).  All device work goes through the C ABI in include/coldcompress.h via
 `_abi.call`; there is no CPU or eager-PyTorch fallback — tensors must live on the ROCm device.
 
-Not yet covered (raised loudly): `cache_bits`, `history_window_size > 1`,
-`attn_thresholding`, `hybrid`, `debug_*`.
+Raised loudly because the reference itself fails there (nothing to pin): `attn_thresholding`, `l2` or `hybrid` with
+`cache_bits`.  Everything else of SURVEY §8 (a)/(f) is implemented, including `cache_bits`, the `history_window_size > 1`
+ring, `hybrid` and the `debug_*` analysis wrapper.
 """
 import argparse
 import ctypes as C
@@ -474,6 +475,7 @@ class KVCacheHeavyHitter(_TrackedWindowSums, KVCacheHeadSpecific):
     """ref: cache.py:615-765 (ScissorHands / H2O style accumulated attention), history_window_size == 1."""
     relevant_kwargs = ["max_cache_length", "max_seq_length", "cache_bits", "global_tokens", "history_window_size",
                        "recent_window", "attn_thresholding"]
+    single_launch = True  # decode_step: one launch per layer step where possible (False: always the two-launch step)
 
     def __init__(self, max_batch_size, n_heads, head_dim, dtype=torch.bfloat16, variable_length=False, **kwargs):
         super().__init__(max_batch_size, n_heads, head_dim, dtype, variable_length, **kwargs)
@@ -554,12 +556,29 @@ class KVCacheHeavyHitter(_TrackedWindowSums, KVCacheHeadSpecific):
                       1.0 / math.sqrt(D) if scale is None else scale, _ptr(y), None, _ptr(ws), ws.numel(), _stream())
             self._quant_pending = self.quantize
             return y
-        _abi.call("cc_decode_step_heavy_hitter", self._view(), _ptr(q), _ptr(k), _ptr(v), _ptr(p32), _ptr(self.attn_history_num),
+        # one launch per layer step where the shape and the device allow it (include/coldcompress.h), else two
+        phases = 3 if self.single_launch else 3 | _abi.CC_PHASE_TWO_LAUNCH
+        _abi.call("cc_decode_step_heavy_hitter_phases", self._view(), _ptr(q), _ptr(k), _ptr(v), _ptr(p32), _ptr(self.attn_history_num),
                   _ptr(self.attn_history_denom), _ptr(self.attn_counter), _ptr(self.next_key), int(self.global_tokens),
                   int(self.recent_window), HQ, 1.0 / math.sqrt(D) if scale is None else scale, _ptr(y), None, _ptr(ws),
-                  ws.numel(), _stream())
+                  ws.numel(), _stream(), phases)
         self._quant_pending = self.quantize
         return y
+
+    def single_launch_active(self, HQ):
+        """True when decode_step runs as ONE launch for `HQ` query heads on this device."""
+        return bool(self.single_launch and self.history_window_size == 1 and _abi.lib()["cc_decode_step_single_launch"](
+            HQ, self.n_heads, self.max_cache_length, self.head_dim, _DT[self.k_cache.dtype]))
+
+    def step_status(self, HQ):
+        """0, or 1 if a single-launch step ever failed to complete its in-launch hand-off on this device (synchronises)."""
+        from .attention_utils import _WS
+
+        off = _abi.lib()["cc_decode_step_status_offset"]()
+        ws = _WS.get((str(self.k_cache.device), "decode"))
+        if ws is None or off + 4 > ws.numel():
+            return 0
+        return int(ws[off:off + 4].view(torch.int32).item())
 
     def _run_select(self, input_pos, k, v):
         if self.history_window_size == 1:

@@ -109,6 +109,18 @@ __device__ __forceinline__ float xor_combine(float v) {
 __device__ __forceinline__ float fast_exp(float x) {  // e^x via v_exp_f32 (2^x); exp(-inf) = 0
   return __builtin_amdgcn_exp2f(x * 1.4426950408889634f);
 }
+// e^x for x <= 0 to about one ulp in seven instructions (the library expf is ~40 with a branch, and it sat on the
+// latency-critical tail of the step): x * log2(e) = t + r with t = fl(x * C_hi) and the residual r recovered by two fmas
+// (log2(e) = C_hi + C_lo), then 2^(t + r) = 2^t * (1 + r ln 2 + O(r^2)), |r| < 2^-18.  Used for the probabilities that
+// feed the float64 history — by the combine pass and the single-launch tail alike, so the two stay bit-identical.
+__device__ __forceinline__ float exp_nonpos(float x) {
+  x = fmaxf(x, -200.f);  // e^-200 = 0 in fp32; keeps -inf away from the residual (inf - inf)
+  const float t = x * 1.44269502162933349609f;
+  float r = fmaf(x, 1.44269502162933349609f, -t);
+  r = fmaf(x, 1.92596299112661746e-08f, r);
+  const float e = __builtin_amdgcn_exp2f(t);
+  return fmaf(e, r * 0.6931471805599453f, e);
+}
 
 struct SplitArgs {
   const void* q;
@@ -146,6 +158,20 @@ struct SplitArgs {
   void* key_norm;   // [H, S] T
   float* l2_pmax;   // [H, n_split, NW]
   float* l2_new;    // [H]
+  // ---- single-launch layer step (ONE): the combine pass folded into this launch.  Every workgroup publishes its
+  //      partial as self-validating 16-byte granules {tag, x, tag, y} (write-through stores), waits until the
+  //      n_split workgroups of its kv head have published, and then finishes ITS OWN 64 slots (probabilities, group
+  //      mean, history, next-eviction key) from the scores still in its registers, plus its share of y.
+  unsigned* one_hdr;  // [H] epoch words (tag = epoch + 1, bumped once per launch and head), then the spin-timeout word
+  void* one_ml;       // [H][n_split][RT] granules {tag, m, tag, l}
+  void* one_o;        // [H * RT][n_split][64] granules {tag, O[2p], tag, O[2p + 1]}
+  unsigned one_ml_bytes, one_o_bytes;
+  void* y;            // [HQ, D] T
+  void* attn_out;     // [H, S] T or null
+  int64_t* hh_counter;
+  int g, w;           // global_tokens, recent_window of the next-eviction score
+  int yc_chunks;      // grid.x of the two-launch combine pass (unused)
+  unsigned long long* trace;  // measurement only (cc_decode_step_trace): [workgroup][16] time stamps and hardware ids
 };
 
 template <typename T, int D, int RT, int NW, int U>
@@ -465,9 +491,17 @@ struct Mfma16x16x16<f16_t> {
   }
 };
 
-template <typename T, int RT, int NW, bool L2>  // L2: the l2 policy's norm bookkeeping (its own instantiation: the others pay nothing)
-__global__ __launch_bounds__(NW * 64) void decode_attn_split_mfma_kernel(SplitArgs a) {
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+constexpr unsigned kOneSpinMax = 1u << 18;  // bounded spin: a launch that is not fully resident gives up instead of hanging
+constexpr int kOneStatusWordDev = 1023;     // hdr[0 .. H): per-head epochs; hdr[1023]: timeout word (== kOneStatusWord)
+constexpr int kOneAuxCoherent = 17;         // sc0 sc1: write-through stores / loads that bypass the non-coherent L1 (and stale L2 lines)
+
+// L2: the l2 policy's norm bookkeeping (its own instantiation: the others pay nothing).  ONE: the single-launch layer
+// step of the heavy-hitter policy (needs R == RT, one tile per wave, every workgroup of the grid co-resident).
+template <typename T, int RT, int NW, bool L2, bool ONE = false>
+__global__ __launch_bounds__(NW * 64, ONE ? 2 : 1) void decode_attn_split_mfma_kernel(SplitArgs a) {
   static_assert(sizeof(T) == 2 && (RT == 1 || RT == 2 || RT == 4), "16-bit caches, up to 4 query heads per pass");
+  static_assert(!(ONE && L2) && (!ONE || NW == 4), "the single-launch step is the heavy-hitter policy on 4-wave workgroups");
   constexpr int D = 128, VEC = 8, RPW = 4, U = 4;
   if (a.ring_col && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0)
     *a.ring_col = (int)(*a.ring_counter % a.ring_W);
@@ -516,6 +550,25 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_split_mfma_kernel(SplitAr
       key_part = x < key_part ? x : key_part;
     }
   }
+  // ONE: this lane's slot of the per-slot pass (lane c = t * RT of row group g finishes row 4g + t of the wave's tile): its
+  // history and position are requested here, with everything else, and consumed after the hand-off
+  unsigned long long tr0 = 0, tr1 = 0, tr2 = 0, tr3 = 0, tr4 = 0, rt0 = 0, rt1 = 0;
+  if constexpr (ONE) {
+    if (a.trace) {
+      tr0 = __builtin_amdgcn_s_memtime();
+      rt0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz, one clock for the whole device (s_memtime is per XCD)
+    }
+  }
+  unsigned one_tag = 0;
+  double one_num = 0.0;
+  int32_t one_den = 0, one_ps = 0, one_pin = 0;
+  const int one_slot = row_begin + wave * (RPW * U) + g * U + c / RT;
+  const bool one_have = ONE && c < U * RT && (c % RT) == 0 && one_slot < row_end;
+  if constexpr (ONE) {
+    one_tag = a.one_hdr[h] + 1u;
+    one_pin = *a.input_pos;
+  }
+  float s_keep[U] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};  // ONE: the wave's (single) tile of scores, kept for the per-slot pass
   // B operand: lane (n = c, kb = g) of step j holds q[head n][8 * (4j + g) .. + 8]; columns n >= RT are zero
   Vec16<T> qB[4];
 #pragma unroll
@@ -554,6 +607,13 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_split_mfma_kernel(SplitAr
   if (more) {
     issue_k(base);
     issue_v(base);
+  }
+  if constexpr (ONE) {  // behind the K/V requests: nothing on the streaming path waits for these
+    if (one_have) {
+      one_num = a.num[(size_t)h * S + one_slot];
+      one_den = a.denom[(size_t)h * S + one_slot];
+      one_ps = a.pos[(size_t)h * S + one_slot];
+    }
   }
 
   while (more) {
@@ -594,7 +654,7 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_split_mfma_kernel(SplitAr
         if (c == 0) {
           if (a.Hp != 1 || h == 0) a.pos[(a.Hp == 1 ? 0 : (size_t)h * S) + ins_idx] = p_now;
           a.mask_w[slot] = 1;
-          if (a.num != nullptr) {  // heavy hitter: cache.py:754-763
+          if (!ONE && a.num != nullptr) {  // heavy hitter: cache.py:754-763 (ONE: the per-slot pass restarts the history)
             a.num[slot] = 0.0;
             a.denom[slot] = 0;
           }
@@ -637,7 +697,11 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_split_mfma_kernel(SplitAr
       const float x = ElemTraits<T>::rnd(ElemTraits<T>::rnd(cs[t]) * a.scale);
       s[t] = valid ? x : -INFINITY;
     }
-    if (c < RT && !(a.abl & 1)) {
+    if constexpr (ONE) {
+#pragma unroll
+      for (int t = 0; t < U; t++) s_keep[t] = s[t];
+    }
+    if (!ONE && c < RT && !(a.abl & 1)) {
       const size_t o = (size_t)(q0 + c) * S + row0;
       if (row0 + 3 < row_end && (o & 3) == 0) {  // four consecutive 16-bit scores: one 8-byte store
         T e0, e1, e2, e3;  // s[] already holds values rounded to T: the stores below are exact
@@ -740,6 +804,229 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_split_mfma_kernel(SplitAr
     }
   }
   __syncthreads();
+  if constexpr (ONE) {
+    // ============================================================================================================
+    // Single-launch layer step: what the combine launch did, done here behind an in-launch hand-off.
+    //   publish   the workgroup's (m, l, O[RT][128]) partial as 16-byte granules {tag, x, tag, y}: write-through
+    //             (sc0 sc1) stores; each 8-byte half validates itself, so no flag, no fence and no store ordering;
+    //   gather    wave r collects the n_split (m, l) pairs of query head r (lane = split) and every thread its share
+    //             of the O granules of the output columns this workgroup finishes — coherent loads, re-read until every
+    //             tag is this launch's.  Tags only ever grow (the epoch words live in the workspace and are bumped once
+    //             per launch and head), so a granule left by any earlier launch, layer or shape can never match;
+    //   finish    the final (M, L) per head in the combine kernel's exact order; then this workgroup's 64 slots —
+    //             probabilities from the scores still in registers, group mean, history update, next-eviction key —
+    //             and its columns of y.
+    // Probabilities, history and keys repeat decode_attn_combine_kernel's operations in its order: bit-identical to the
+    // two-launch step (y sums its partials in a different fixed order: equal up to fp32 rounding).  Needs all
+    // n_split * H workgroups co-resident (the launcher checks); every wait is bounded and reports through the
+    // timeout word should that ever not hold.
+    const int ns = a.n_split;
+    const unsigned tag = one_tag;
+    if (a.trace) {
+      tr1 = __builtin_amdgcn_s_memtime();
+      rt1 = __builtin_amdgcn_s_memrealtime();
+    }
+    __shared__ float sm_w1[RT][64];  // exp(m_i - M_r)
+    __shared__ float sm_M1[RT], sm_L1[RT];
+    __shared__ __attribute__((aligned(16))) float sm_o1[2 * (RT * 64 + 64)];  // [split][pair of this workgroup][2]: raw partial O
+    __shared__ float sm_yp[2 * (RT * 64 + 64)];                                // [output][chain]: partial sums of y
+    __shared__ unsigned long long sm_key1[NW];
+    const auto ml_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.one_ml, 0, (int)a.one_ml_bytes, 0x00020000);
+    const auto o_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.one_o, 0, (int)a.one_o_bytes, 0x00020000);
+    // ---- publish: thread t merges output columns 2t, 2t + 1 of the workgroup's partial (the arithmetic of the
+    //      two-launch epilogue below) and stores them as one granule
+    {
+      const int o2 = (int)threadIdx.x * 2;
+      if (o2 < RT * D) {
+        const int r = o2 / D, d = o2 - r * D;
+        float M = sm_wm[0][r];
+#pragma unroll
+        for (int w = 1; w < NW; w++) M = fmaxf(M, sm_wm[w][r]);
+        const float Mu = (M == -INFINITY) ? 0.f : M;
+        float L = 0.f, O0 = 0.f, O1 = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; w++) {  // fixed order: deterministic
+          const float f = fast_exp(sm_wm[w][r] - Mu);
+          L = fmaf(sm_wl[w][r], f, L);
+          O0 = fmaf(sm_wacc[w][r][d], f, O0);
+          O1 = fmaf(sm_wacc[w][r][d + 1], f, O1);
+        }
+        const u32x4_t og = {tag, __float_as_uint(O0), tag, __float_as_uint(O1)};
+        __builtin_amdgcn_raw_buffer_store_b128(og, o_rsrc, (((h * RT + r) * ns + split) * 64 + (d >> 1)) * 16, 0, kOneAuxCoherent);
+        if (d == 0) {
+          const u32x4_t mg = {tag, __float_as_uint(M), tag, __float_as_uint(L)};
+          __builtin_amdgcn_raw_buffer_store_b128(mg, ml_rsrc, ((h * ns + split) * RT + r) * 16, 0, kOneAuxCoherent);
+        }
+      }
+    }
+    if (a.trace) tr2 = __builtin_amdgcn_s_memtime();
+    // ---- what this thread gathers: the (m, l) granule of (head = wave, split = lane) and up to two O granules
+    const int ppw = (RT * 64 + ns - 1) / ns;  // output pairs finished per workgroup (pair P = r * 64 + d / 2)
+    const int n_items = ns * ppw;             // (split, pair) granules this workgroup reads
+    const int pair0 = split * ppw;
+    int n_pairs = RT * 64 - pair0;
+    n_pairs = n_pairs < 0 ? 0 : (n_pairs > ppw ? ppw : n_pairs);
+    const int ml_off = ((h * ns + (lane < ns ? lane : 0)) * RT + (wave < RT ? wave : 0)) * 16;
+    int o_off[2], o_lds[2];
+    bool o_use[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      const int item = (int)threadIdx.x + k * NW * 64;
+      const int i = item / ppw, qq = item - i * ppw;
+      o_use[k] = item < n_items && qq < n_pairs;
+      const int P = o_use[k] ? pair0 + qq : 0;
+      o_off[k] = (((h * RT + (P >> 6)) * ns + (o_use[k] ? i : 0)) * 64 + (P & 63)) * 16;
+      o_lds[k] = (i * ppw + qq) * 2;
+    }
+    bool timed_out = false;
+    if (!(a.abl & 1)) {  // one wave watches query head 0's (m, l) granules; the others sleep at the barrier instead of polling
+      if (wave == 0) {
+        const int off0 = ((h * ns + (lane < ns ? lane : 0)) * RT) * 16;
+        for (unsigned spins = 0;; spins++) {
+          const u32x4_t x = __builtin_amdgcn_raw_buffer_load_b128(ml_rsrc, off0, 0, kOneAuxCoherent);
+          if (__all(x[0] == tag && x[2] == tag)) break;
+          if (spins > kOneSpinMax) {
+            timed_out = true;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      __syncthreads();
+    }
+    if (a.trace) tr3 = __builtin_amdgcn_s_memtime();
+    u32x4_t mlq, oq[2];
+    for (unsigned spins = 0;; spins++) {
+      mlq = __builtin_amdgcn_raw_buffer_load_b128(ml_rsrc, ml_off, 0, kOneAuxCoherent);
+#pragma unroll
+      for (int k = 0; k < 2; k++) oq[k] = __builtin_amdgcn_raw_buffer_load_b128(o_rsrc, o_off[k], 0, kOneAuxCoherent);
+      bool ok = mlq[0] == tag && mlq[2] == tag;
+#pragma unroll
+      for (int k = 0; k < 2; k++) ok = ok && (!o_use[k] || (oq[k][0] == tag && oq[k][2] == tag));
+      if (__all(ok)) break;
+      if (spins > kOneSpinMax) {
+        timed_out = true;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    if (a.trace) tr4 = __builtin_amdgcn_s_memtime();
+    if (timed_out && lane == 0) a.one_hdr[kOneStatusWordDev] = 1u;  // this launch's results are invalid; the host reads the word
+    // ---- final (M, L) of query head r = wave: decode_attn_combine_kernel's order (lane = split, n_split <= 64)
+    if (wave < RT) {
+      const float mi = lane < ns ? __uint_as_float(mlq[1]) : -INFINITY;
+      const float M = wave_max_uniform(mi);
+      const float Mu = (M == -INFINITY) ? 0.f : M;
+      float L = 0.f;
+      if (lane < ns) {
+        const float wgt = exp_nonpos(mi - Mu);
+        sm_w1[wave][lane] = wgt;
+        L = __uint_as_float(mlq[3]) * wgt;
+      }
+      L = wave_sum_uniform(L);
+      if (lane == 0) {
+        sm_M1[wave] = Mu;
+        sm_L1[wave] = L;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 2; k++)
+      if (o_use[k]) *reinterpret_cast<float2*>(&sm_o1[o_lds[k]]) = make_float2(__uint_as_float(oq[k][1]), __uint_as_float(oq[k][3]));
+    __syncthreads();
+    // ---- y: per output column, G1 strided chains over the splits ...
+    const int n_out = 2 * n_pairs;
+    const int sh = ns >= 8 ? 3 : (ns >= 4 ? 2 : (ns >= 2 ? 1 : 0)), G1 = 1 << sh;
+    for (int task = (int)threadIdx.x; task < (n_out << sh); task += NW * 64) {
+      const int ol = task >> sh, gg = task & (G1 - 1);
+      const int r = (2 * pair0 + ol) / D;
+      float part = 0.f;
+      for (int i = gg; i < ns; i += G1) part = fmaf(sm_o1[i * ppw * 2 + ol], sm_w1[r][i], part);
+      sm_yp[task] = part;
+    }
+    // ---- this workgroup's slots.  ref: attention_utils.py:52 softmax -> model dtype; model.py:416-418 group mean -> model
+    //      dtype; cache.py:716-722 history; cache.py:727-749 the next position's eviction score
+    unsigned long long my_key = ~0ull;
+    {
+      // lane c of a row group computes ONE probability, of (row t = c / RT, head r = c % RT) — 16 lanes x 1 exp + 1
+      // IEEE divide instead of 4 lanes x 4; the score of (row t, head r) sits in lane r of the group as s_keep[t]
+      const int t_me = c / RT, r_me = c % RT;
+      const int src = (lane & ~15) | r_me;
+      float x = -INFINITY;
+#pragma unroll
+      for (int t = 0; t < U; t++) {
+        const float v = __shfl(s_keep[t], src, CC_WAVE);
+        x = (t == t_me) ? v : x;
+      }
+      const float pr = ElemTraits<T>::rnd(__fdiv_rn(exp_nonpos(x - sm_M1[r_me]), sm_L1[r_me]));
+      float sum = 0.f;  // over the heads of the group in order, like the combine pass: lanes t * RT + (0 .. RT)
+      if constexpr (RT == 4) {
+        sum += dpp_mov<0x00>(pr);
+        sum += dpp_mov<0x55>(pr);
+        sum += dpp_mov<0xAA>(pr);
+        sum += dpp_mov<0xFF>(pr);
+      } else if constexpr (RT == 2) {
+        sum += dpp_mov<0xA0>(pr);  // quad_perm [0, 0, 2, 2]
+        sum += dpp_mov<0xF5>(pr);  // quad_perm [1, 1, 3, 3]
+      } else {
+        sum += pr;
+      }
+      const float av = ElemTraits<T>::rnd(__fdiv_rn(sum, (float)RT));
+      if (one_have) {
+        const size_t i = (size_t)h * S + one_slot;
+        int32_t ps = one_ps;
+        double num_old = one_num;
+        int32_t den_old = one_den;
+        if (one_slot == ins_idx) {  // refilled by this launch's insert: position p, history from zero (cache.py:754-763)
+          ps = one_pin;
+          num_old = 0.0;
+          den_old = 0;
+        }
+        if (a.attn_out) ElemTraits<T>::store(reinterpret_cast<T*>(a.attn_out), i, av);
+        const double num_new = num_old + (double)av;
+        const int32_t den_new = den_old + 1;
+        a.num[i] = num_new;
+        a.denom[i] = den_new;
+        const int32_t p_next = one_pin + 1;
+        float scn = __fdiv_rn((float)num_new, (float)(den_new < 1 ? 1 : den_new));
+        if (ps < a.g || ps >= p_next - a.w) scn = 1.0f;
+        if (ps == -1) scn = 0.0f;
+        my_key = make_key(orderable_f32(scn), ((uint32_t)one_slot << 1) | (uint32_t)(ps == -1));
+      }
+    }
+    {
+      const unsigned long long wk = wave_min_u64_uniform(my_key);
+      if (lane == 0) sm_key1[wave] = wk;
+    }
+    __syncthreads();
+    for (int ol = (int)threadIdx.x; ol < n_out; ol += NW * 64) {
+      const int to = 2 * pair0 + ol, r = to / D, d = to - r * D;
+      float O = 0.f;
+      for (int gg = 0; gg < G1; gg++) O += sm_yp[(ol << sh) + gg];
+      ElemTraits<T>::store(reinterpret_cast<T*>(a.y), (size_t)(h * RT + r) * D + d, O / sm_L1[r]);
+    }
+    if (threadIdx.x == 0) {
+      unsigned long long bk = sm_key1[0];
+#pragma unroll
+      for (int w2 = 1; w2 < NW; w2++) bk = sm_key1[w2] < bk ? sm_key1[w2] : bk;
+      unsigned long long* nk_row = const_cast<unsigned long long*>(a.next_key) + (size_t)h * a.nk;
+      nk_row[split] = bk;  // every key of this head was consumed before its owner published: no reader is left
+      for (int s2 = split + ns; s2 < a.nk; s2 += ns) nk_row[s2] = ~0ull;
+      if (split == 0) {
+        a.one_hdr[h] = tag;  // all n_split workgroups of this head have published, hence read the old epoch
+        if (h == 0 && a.hh_counter) *a.hh_counter += 1;
+      }
+      if (a.trace) {
+        unsigned long long* tr = a.trace + (size_t)(h * ns + split) * 16;
+        tr[0] = tr0; tr[1] = tr1; tr[2] = tr2; tr[3] = tr3; tr[4] = tr4; tr[5] = __builtin_amdgcn_s_memtime();
+        tr[6] = rt0;
+        tr[7] = rt1;
+        tr[8] = __builtin_amdgcn_s_memrealtime();
+        tr[9] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID
+        tr[10] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));  // HW_REG_XCC_ID[3:0]
+      }
+    }
+    return;
+  }
   for (int t = threadIdx.x; t < RT * D; t += NW * 64) {
     const int r = t / D, d = t - r * D;
     float M = sm_wm[0][r];
@@ -921,13 +1208,13 @@ __global__ __launch_bounds__(kCombThreads) void decode_attn_combine_kernel(Combi
     const float Mu = (M == -INFINITY) ? 0.f : M;
     float L = 0.f;
     if (lane < ns) {
-      const float w = expf(first.x - Mu);
+      const float w = exp_nonpos(first.x - Mu);
       sm_wdyn[r * ns + lane] = w;
       L = first.y * w;
     }
     for (int i = lane + 64; i < ns; i += 64) {
       const float2 v = ml[i];
-      const float w = expf(v.x - Mu);
+      const float w = exp_nonpos(v.x - Mu);
       sm_wdyn[r * ns + i] = w;
       L = fmaf(v.y, w, L);
     }
@@ -1005,7 +1292,7 @@ __global__ __launch_bounds__(kCombThreads) void decode_attn_combine_kernel(Combi
         x = ElemTraits<T>::load(sc, j * S + s);
       }
       // ref: attention_utils.py:52 softmax (fp32 inside, result rounded to the model dtype)
-      const float p = ElemTraits<T>::rnd(__fdiv_rn(expf(x - sm_M[r]), sm_L[r]));
+      const float p = ElemTraits<T>::rnd(__fdiv_rn(exp_nonpos(x - sm_M[r]), sm_L[r]));
       if (a.probs_out) ElemTraits<T>::store(reinterpret_cast<T*>(a.probs_out), j * S + s, p);
       sum += p;
     }
@@ -1102,7 +1389,13 @@ __global__ __launch_bounds__(kCombThreads) void decode_attn_combine_kernel(Combi
     for (int w2 = 1; w2 < kWaves; w2++) bk = sm_k[w2] < bk ? sm_k[w2] : bk;
     // the minimum over all blocks of this head IS torch's arg-min; the next step's streaming pass takes it
     // (plain store: same-address atomics from 8 XCDs measured +4.5 us on this 5 us kernel)
-    if (a.Hp != 1 || h == 0) a.next_key[(size_t)(a.Hp == 1 ? 0 : h) * nchunks + c] = bk;
+    // (a head's key row has 2 * nchunks entries — one per 64 slots, the single-launch step's granularity — the upper half
+    //  stays ~0 here)
+    if (a.Hp != 1 || h == 0) {
+      unsigned long long* row = a.next_key + (size_t)(a.Hp == 1 ? 0 : h) * (2 * nchunks);
+      row[c] = bk;
+      row[nchunks + c] = ~0ull;
+    }
   }
   if (do_y)  // further output groups (only when R*D / n_chunks > 128, i.e. very short caches)
     for (int o0 = y_lo + kCombThreads; o0 < y_hi; o0 += kCombThreads) {
@@ -1152,7 +1445,7 @@ static Plan make_plan(int HQ, int H, int S, int D, int dtype) {
   ns = (S + rps - 1) / rps;
   p.n_split = ns;
   p.rows_per_split = rps;
-  p.chunk = kNextKeyChunk;  // cc_hh_next_key_slots(S) == n_chunks: one partial arg-min key per combine block
+  p.chunk = kNextKeyChunk;  // one partial arg-min key per combine block (the lower half of a head's key row)
   p.n_chunks = (S + p.chunk - 1) / p.chunk;
   return p;
 }
@@ -1208,13 +1501,83 @@ static int launch_split(const SplitArgs& a, const Plan& p, int H, int R, int D, 
 
 extern "C" {
 
-size_t cc_decode_attn_workspace_bytes(int32_t HQ, int32_t H, int32_t S, int32_t D, int32_t dtype) {
-  if (HQ <= 0 || H <= 0 || HQ % H || S <= 0 || D <= 0 || !cc_dt_ok(dtype)) return 0;
-  const Plan p = make_plan(HQ, H, S, D, dtype);
+}  // extern "C"
+
+namespace {
+// ---- single-launch layer step: shape eligibility, workspace regions, residency
+// Workspace layout: [epoch words + timeout word: 4 KiB][(m, l) granules: 128 KiB][O granules: 8 MiB][two-launch scratch].
+// The single-launch regions sit at FIXED offsets and fixed capacities, whatever the shape: caches of different lengths
+// (pyramid budgets) share one workspace and one set of epoch words, tags grow monotonically across all of them, and
+// nothing but the single-launch kernel ever writes a word that could be mistaken for a tag.
+constexpr size_t kOneHdrBytes = 4096, kOneMlCap = 128 << 10, kOneOCap = 8 << 20;
+constexpr size_t kOneBytes = kOneHdrBytes + kOneMlCap + kOneOCap;
+constexpr int kOneStatusWord = 1023;  // hdr[0 .. H): epochs; hdr[1023]: timeout word
+static bool one_shape_ok(const Plan& p, int HQ, int H, int D, int dtype) {
+  const int R = HQ / H;
+  return cc_dt_size(dtype) == 2 && D == 128 && R == p.rt && p.rows_per_split == rows_per_iter(D, dtype) && p.n_split <= 64 &&
+         H < kOneStatusWord && (size_t)HQ * p.n_split * 16 <= kOneMlCap && (size_t)HQ * p.n_split * 64 * 16 <= kOneOCap;
+}
+static size_t base_workspace_bytes(const Plan& p, int HQ, int H, int S, int D, int dtype) {
   return align256((size_t)HQ * S * cc_dt_size(dtype)) + align256((size_t)HQ * p.n_split * 2 * sizeof(float)) +
          align256((size_t)HQ * p.n_split * D * sizeof(float)) + 256 +  // + the ring column word of the fused W > 1 history
          align256(((size_t)H * p.n_split * kNW + H) * sizeof(float));   // + the l2 policy's partial maxima and new norms
 }
+// workgroups of the single-launch kernel the device keeps resident at once (0: unknown -> never use it)
+template <typename KernelT>
+static int one_capacity(KernelT kernel) {
+  static int cap = -1;  // per instantiation
+  if (cap < 0) {
+    int dev = 0, cus = 0, nb = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, kNW * 64, 0) != hipSuccess) {
+      (void)hipGetLastError();
+      return 0;
+    }
+    cap = cus * (nb > 8 ? 8 : nb);
+  }
+  return cap;
+}
+template <typename T>
+static int one_capacity_rt(int rt) {
+  switch (rt) {
+    case 4: return one_capacity(decode_attn_split_mfma_kernel<T, 4, kNW, false, true>);
+    case 2: return one_capacity(decode_attn_split_mfma_kernel<T, 2, kNW, false, true>);
+    default: return one_capacity(decode_attn_split_mfma_kernel<T, 1, kNW, false, true>);
+  }
+}
+template <typename T>
+static int launch_one(const SplitArgs& a, const Plan& p, int H, hipStream_t st) {
+  dim3 grid(p.n_split, H, 1), block(kNW * 64);
+  switch (p.rt) {
+    case 4: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 4, kNW, false, true>), grid, block, 0, st, a); break;
+    case 2: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 2, kNW, false, true>), grid, block, 0, st, a); break;
+    default: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 1, kNW, false, true>), grid, block, 0, st, a); break;
+  }
+  CC_LAUNCH_CHECK();
+  return CC_OK;
+}
+}  // namespace
+
+extern "C" {
+
+size_t cc_decode_attn_workspace_bytes(int32_t HQ, int32_t H, int32_t S, int32_t D, int32_t dtype) {
+  if (HQ <= 0 || H <= 0 || HQ % H || S <= 0 || D <= 0 || !cc_dt_ok(dtype)) return 0;
+  const Plan p = make_plan(HQ, H, S, D, dtype);
+  return kOneBytes + base_workspace_bytes(p, HQ, H, S, D, dtype);
+}
+
+int32_t cc_decode_step_single_launch(int32_t HQ, int32_t H, int32_t S, int32_t D, int32_t dtype) {
+  if (HQ <= 0 || H <= 0 || HQ % H || S <= 0 || D <= 0 || !cc_dt_ok(dtype)) return 0;
+  const Plan p = make_plan(HQ, H, S, D, dtype);
+  if (!one_shape_ok(p, HQ, H, D, dtype)) return 0;
+  const int cap = dtype == CC_DT_BF16 ? one_capacity_rt<bf16_t>(p.rt) : one_capacity_rt<f16_t>(p.rt);
+  return p.n_split * H <= cap ? 1 : 0;
+}
+
+int32_t cc_decode_step_status_offset(void) { return kOneStatusWord * (int32_t)sizeof(unsigned); }
+
+static void* g_one_trace = nullptr;
+void cc_decode_step_trace(void* buf) { g_one_trace = buf; }
 
 }  // extern "C"
 
@@ -1255,7 +1618,7 @@ static int attn_impl(const void* q, const void* k, const void* v, const uint8_t*
   if (workspace_bytes < cc_decode_attn_workspace_bytes(HQ, H, S, D, dtype)) return CC_ERR_WORKSPACE;
   const Plan p = make_plan(HQ, H, S, D, dtype);
   if ((size_t)R * p.n_split * sizeof(float) > 64 * 1024) return CC_ERR_UNSUPPORTED;  // combine-kernel LDS budget
-  char* ws = reinterpret_cast<char*>(workspace);
+  char* ws = reinterpret_cast<char*>(workspace) + kOneBytes;  // the single-launch regions come first, at fixed offsets
   SplitArgs sa{};
   sa.q = q; sa.k = k; sa.v = v; sa.mask = mask;
   sa.scores = ws;
@@ -1277,12 +1640,31 @@ static int attn_impl(const void* q, const void* k, const void* v, const uint8_t*
     sa.l2_new = sa.l2_pmax + (size_t)H * p.n_split * kNW;
   }
   if (fs) {
-    sa.next_key = fs->next_key; sa.nk = p.n_chunks; sa.input_pos = fs->input_pos; sa.k_new = fs->k_new; sa.v_new = fs->v_new;
+    sa.next_key = fs->next_key; sa.nk = cc_next_key_slots(S); sa.input_pos = fs->input_pos; sa.k_new = fs->k_new; sa.v_new = fs->v_new;
     sa.pos = fs->c->pos; sa.mask_w = fs->c->mask; sa.cache_cts = fs->c->cache_cts; sa.num = hh_num; sa.denom = hh_denom;
     sa.H = H; sa.Hc = fs->c->Hc; sa.Hp = fs->c->Hp;
   }
   hipStream_t st = (hipStream_t)stream;
   int rc = CC_OK;
+  // ---- single-launch layer step (heavy hitter, W == 1): phases bit CC_PHASE_ONE_LAUNCH forces it (error if the shape or
+  //      the device's residency does not allow it), CC_PHASE_TWO_LAUNCH forbids it; otherwise it is used whenever it can be
+  const bool one_asked = (phases & CC_PHASE_ONE_LAUNCH) != 0;
+  if (one_asked || ((phases & 3) == 3 && !(phases & CC_PHASE_TWO_LAUNCH))) {
+    const bool one_ok = fs && fs->policy == 1 && !rh && !probs_out && hh_num && hh_denom && fs->c->Hp == H &&
+                        cc_decode_step_single_launch(HQ, H, S, D, dtype) == 1;
+    if (one_asked && !one_ok) return CC_ERR_UNSUPPORTED;
+    if (one_ok) {
+      char* ob = reinterpret_cast<char*>(workspace);
+      sa.one_hdr = reinterpret_cast<unsigned*>(ob);
+      sa.one_ml = ob + kOneHdrBytes;
+      sa.one_o = ob + kOneHdrBytes + kOneMlCap;
+      sa.one_ml_bytes = (unsigned)kOneMlCap;
+      sa.one_o_bytes = (unsigned)kOneOCap;
+      sa.trace = reinterpret_cast<unsigned long long*>(g_one_trace);
+      sa.y = y; sa.attn_out = attn_out; sa.hh_counter = hh_counter; sa.g = fs->g; sa.w = fs->w; sa.yc_chunks = p.n_chunks;
+      return dtype == CC_DT_BF16 ? launch_one<bf16_t>(sa, p, H, st) : launch_one<f16_t>(sa, p, H, st);
+    }
+  }
   if (phases & 1) {
     switch (dtype) {
       case CC_DT_F32: rc = launch_split<float>(sa, p, H, R, D, st); break;

@@ -179,8 +179,9 @@ int cc_decode_attn_gqa_ring(const void* q, const void* k, const void* v, const u
  *   launch 2 (combine): y, group-averaged probabilities, history update, and the arg-min for position
  *     *input_pos + 1 evaluated on the freshly updated history: one partial minimum per 128-slot chunk
  *     -> next_key[h][chunk] (plain stores; no atomics, no reset pass).
- * next_key: uint64 [H, NK], NK = cc_hh_next_key_slots(S); entry = (orderable(score) << 32) | slot << 1 | was_empty,
- * ~0 = "no candidate".  Valid as long as positions advance by one and nothing else mutates pos / history in
+ * next_key: uint64 [H, NK], NK = cc_hh_next_key_slots(S) (two entries per 128-slot chunk: the combine pass fills the
+ * lower half of a row and keeps the upper half at ~0; the single-launch step below publishes one key per 64 slots);
+ * entry = (orderable(score) << 32) | slot << 1 | was_empty, ~0 = "no candidate".  Valid as long as positions advance by one and nothing else mutates pos / history in
  * between; re-seed with cc_hh_next_key_init otherwise.
  * Results are bit-identical to the three-call sequence (tests/test_gpu_fused_step.py).
  * ---------------------------------------------------------------------------------------------- */
@@ -233,7 +234,33 @@ int cc_decode_step_heavy_hitter_ring(const cc_kv_view* c, const void* q, const v
                                      uint64_t* wsum_acc, float* wsum, uint64_t* next_key, int32_t global_tokens,
                                      int32_t recent_window, int32_t HQ, float scale, void* y, void* attn_out,
                                      void* workspace, size_t workspace_bytes, cc_stream_t stream);
-/* Measurement hook (cf. cc_decode_attn_gqa_phases): the same step with its two launches selectable. */
+/* ------------------------------------------------------------------------------------------------
+ * Single-launch layer step.  cc_decode_step_heavy_hitter runs the whole step — insert, K/V streaming pass, softmax
+ * normalisation, group mean, history update (cache.py:716-722), the arg-min for position *input_pos + 1 (cache.py:725-749)
+ * and y — in ONE launch whenever cc_decode_step_single_launch(...) returns 1: 16-bit caches, head_dim 128, HQ / H in
+ * {1, 2, 4}, at most 64 slots per workgroup tile and 64 tiles per kv head (S <= 4096), and the n_split * H workgroups all
+ * resident on the device at once.  Every workgroup publishes its partial (m, l, O) through the workspace as
+ * self-validating tagged granules (write-through stores), waits — bounded — for the other workgroups of its kv head,
+ * and finishes its own 64 slots from the scores still in its registers.  pos, mask, cache_cts, K/V, num, denom, counter,
+ * attn_out and the next keys are bit-identical to the two-launch step; y agrees up to fp32 summation order.
+ * Workspace contract for this mode: the first 4 KiB + 128 KiB + 8 MiB of every decode workspace (sized in by
+ * cc_decode_attn_workspace_bytes, at fixed offsets whatever the shape, so that caches of different lengths may share one
+ * workspace) hold per-head epoch words and the granules; they must be ZERO before first use and written by nobody
+ * else; a launch that could not complete its hand-off (a device that did not keep the grid resident) sets the 32-bit
+ * word at byte offset cc_decode_step_status_offset() to 1 — its results are then invalid.
+ * phases for cc_decode_step_heavy_hitter_phases: 1 / 2 / 3 select the launches of the two-launch step as before
+ * (3 = both = let the library choose single or two launches); | CC_PHASE_TWO_LAUNCH never uses the single launch;
+ * CC_PHASE_ONE_LAUNCH demands it (CC_ERR_UNSUPPORTED when not possible).
+ * ---------------------------------------------------------------------------------------------- */
+#define CC_PHASE_TWO_LAUNCH 0x10000
+#define CC_PHASE_ONE_LAUNCH 0x20000
+int32_t cc_decode_step_single_launch(int32_t HQ, int32_t H, int32_t S, int32_t D, int32_t dtype);
+int32_t cc_decode_step_status_offset(void);
+/* Measurement hook: buf = device buffer of [workgroups][16] uint64, or NULL (default).  While set, thread 0 of every
+ * workgroup of a single-launch step records [0..5] s_memtime stamps (start, streaming done, published, sentinel seen,
+ * gathered, end), [6..8] s_memrealtime at start / streaming done / end, [9] HW_ID, [10] XCC_ID. */
+void cc_decode_step_trace(void* buf);
+/* Measurement hook (cf. cc_decode_attn_gqa_phases): the same step with its launches selectable. */
 int cc_decode_step_heavy_hitter_phases(const cc_kv_view* c, const void* q, const void* k_new, const void* v_new,
                                 const int32_t* input_pos, double* num, int32_t* denom, int64_t* counter,
                                 uint64_t* next_key, int32_t global_tokens, int32_t recent_window, int32_t HQ,

@@ -77,7 +77,7 @@ def main():
             kv.attn_history_denom.fill_(3)
             caches.append(kv)
         nbytes = fns["cc_decode_attn_workspace_bytes"](HQ, H, S, D, 1)
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        ws = torch.zeros(nbytes, dtype=torch.uint8, device=dev)  # zero: the single-launch step's epoch words live here
         q = torch.randn(HQ, D, device=dev).to(torch.bfloat16)
         y = torch.empty(HQ, D, device=dev, dtype=torch.bfloat16)
         k1 = torch.randn(H, D, device=dev).to(torch.bfloat16)
@@ -116,7 +116,14 @@ def main():
                 assert rc == 0, rc
 
             res = {"S": S}
-            for name, ph in (("step", 3), ("split", 1), ("split_nobranch", 1 | (64 << 8)), ("split_nokey", 1 | (128 << 8)), ("combine", 2), ("combine_nokey", 2 | (8 << 8)),
+            one = fns["cc_decode_step_single_launch"](HQ, H, S, D, 1) == 1
+            res["single_launch_supported"] = bool(one)
+            if one:  # the single-launch step (0x20000 demands it; abl bit 1 << 8: every thread polls, no sentinel wave)
+                for name, ph in (("step_one", 3 | 0x20000), ("step_one_pollall", 3 | 0x20000 | (1 << 8)), ("step_one_noepi", 3 | 0x20000 | (2 << 8))):
+                    t, tmin = timed_graph(lambda i, ph=ph: fstep(i, ph), n)
+                    res[name + "_us"] = round(t, 2)
+                    res[name + "_min_us"] = round(tmin, 2)
+            for name, ph in (("step", 3 | 0x10000), ("split", 1), ("split_nobranch", 1 | (64 << 8)), ("split_nokey", 1 | (128 << 8)), ("combine", 2), ("combine_nokey", 2 | (8 << 8)),
                              ("combine_noy", 2 | (16 << 8)), ("combine_noslot", 2 | (32 << 8)),
                              ("combine_empty", 2 | (56 << 8))):
                 t, tmin = timed_graph(lambda i, ph=ph: fstep(i, ph), n)
