@@ -178,7 +178,14 @@ class KVCache(nn.Module):
         return False
 
     def memory_usage(self):
-        tensors = [b for b in self._buffers.values() if torch.is_tensor(b)]
+        """ref: cache.py:247-257 — bytes of the cache's state tensors.  Our non-persistent pipeline state (partial arg-min
+        keys, tracked window sums, quantisation marks) is not cache content and is left out; for a quantised cache the
+        figure is the reference's (int8 / packed image + scales + zero points), not the model-dtype working copy the
+        kernels read, which is reported separately as `working_cache_gb` by compute_statistics."""
+        skip = set(self._non_persistent_buffers_set)
+        if self.quantize:
+            skip |= {"k_cache", "v_cache"}
+        tensors = [b for n, b in self._buffers.items() if torch.is_tensor(b) and n not in skip]
         for obj in vars(self).values():
             if torch.is_tensor(obj):
                 tensors.append(obj)
@@ -193,7 +200,10 @@ class KVCache(nn.Module):
         return ((n - size) / n).mean()
 
     def compute_statistics(self, seq_len):
-        return {"compression_ratio": self.compression_ratio(seq_len).item(), "cache_memory_gb": self.memory_usage()}
+        stats = {"compression_ratio": self.compression_ratio(seq_len).item(), "cache_memory_gb": self.memory_usage()}
+        if self.quantize:
+            stats["working_cache_gb"] = (self.k_cache.numel() + self.v_cache.numel()) * self.k_cache.element_size() / (1024 ** 3)
+        return stats
 
     def return_kv_cache(self):
         return self.k_cache, self.v_cache, self.mask
@@ -249,6 +259,8 @@ class KVCache(nn.Module):
         v = v_val.reshape(H, T, D).contiguous() if v_val.is_contiguous() else v_val.contiguous().view(H, T, D)
         p = input_pos.to(torch.int64).reshape(-1, T).contiguous()
         _abi.call("cc_prefill_fill", self._view(), _ptr(k), _ptr(v), _ptr(p), p.shape[0], T, _stream())
+        if self.quantize:  # a raw-pointer bulk write: the tensors' version counters did not move, the stable marks are void
+            self._quant_tag = None
 
     def _decoding_update(self, input_pos, k_val, v_val, **kwargs):
         """ref: cache.py:348-364: generic path = `_token_importances` -> base rules -> arg-min -> insert."""
@@ -429,8 +441,9 @@ class KVCacheL2(_RingFusedStep, KVCacheHeadSpecific):
         self.key_norm.zero_()
 
     def _run_select(self, input_pos, k, v):
+        ws = self._scratch.get("l2_max", (256,), torch.uint8, self.k_cache.device)  # the norm maximum, taken before any insert
         _abi.call("cc_decode_update_l2", self._view(), _ptr(k), _ptr(v), _ptr(self._pos32(input_pos)),
-                  _ptr(self.key_norm), int(self.global_tokens), int(self.recent_window), _ptr(self._idx_buf()), None, 0,
+                  _ptr(self.key_norm), int(self.global_tokens), int(self.recent_window), _ptr(self._idx_buf()), _ptr(ws), ws.numel(),
                   _stream())
 
     def update_state(self, input_pos, k_val, v_val, is_prefill, attn, **kwargs):
@@ -887,9 +900,13 @@ class KVCacheHybrid(_TrackedWindowSums, KVCacheHeadSpecific):
         for cols, win in scoring:
             outside = band[win] if win else torch.zeros_like(colsum)
             scores.append(torch.where(cols, colsum, outside).sum(dim=1) / L)
-        scores = torch.stack(scores)  # [n_policies, H]
+        # the reference's scores are model-dtype tensors (cache.py:1165-1167: .sum(-1).mean(-1) of the probabilities) and a
+        # Python scalar does not promote a tensor, so the comparison of cache.py:1171 happens in the model dtype:
+        # bf16(0.9) = 0.8984 is the effective threshold of a bf16 model
+        scores = torch.stack(scores).to(self.k_cache.dtype)  # [n_policies, H]
         self.compressed_scores = scores
-        self.cache_strategies = (scores >= self.min_recovery_frac).int().argmax(dim=0).to(torch.int64).contiguous()
+        thr = torch.tensor(self.min_recovery_frac, dtype=scores.dtype, device=scores.device)
+        self.cache_strategies = (scores >= thr).int().argmax(dim=0).to(torch.int64).contiguous()
         # ---- fill mask from the chosen policy, built for the FULL cache length (cache.py:1177-1185)
         filling = self._column_sets(cum_attn, sm, pm, S, L)
         t = torch.arange(L, device=dev)

@@ -936,7 +936,8 @@ __global__ __launch_bounds__(NW * 64, ONE ? 2 : 1) void decode_attn_split_mfma_k
     // ---- y: per output column, G1 strided chains over the splits ...
     const int n_out = 2 * n_pairs;
     const int sh = ns >= 8 ? 3 : (ns >= 4 ? 2 : (ns >= 2 ? 1 : 0)), G1 = 1 << sh;
-    for (int task = (int)threadIdx.x; task < (n_out << sh); task += NW * 64) {
+    // (tasks go to the LAST threads first: wave 0 keeps the workgroup's serial duties after the next barrier)
+    for (int task = NW * 64 - 1 - (int)threadIdx.x; task < (n_out << sh); task += NW * 64) {
       const int ol = task >> sh, gg = task & (G1 - 1);
       const int r = (2 * pair0 + ol) / D;
       float part = 0.f;

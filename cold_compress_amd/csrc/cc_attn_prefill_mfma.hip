@@ -17,6 +17,8 @@
 //   from V^T stored with the matching key permutation inside each 32-key block (vt_perm), one 16-byte load per
 //   operand — no LDS transpose, no cross-lane shuffles on the MFMA path.
 // MFMA-bound contraction; HBM traffic is negligible (K/V tiles are re-read from L2 by the 4 waves).
+#include <stdlib.h>
+
 #include "cc_common.h"
 
 namespace {
@@ -77,10 +79,28 @@ struct MArgs {
   float* stats;    // [HQ, L, 2]
   float* cpart;    // [1 + nb (+1), NWG, H, L]: column sums, band sums, observation-window sums
   int H, L, Lp, nb;
+  int nwg;         // persistent workgroups per kv head (the grid is 1-D: nwg * H)
+  int xcd_remap;   // H % 8 == 0: all workgroups of kv head h sit on XCD h % 8 (workgroup b is dispatched to XCD b % 8 —
+                   // observed, used for speed only), so that one head's K / V^T prefix (2 * L * 256 B) is served by ONE 4 MiB L2
+                   // instead of every head's by all eight
   int obs_len;     // > 0: plane 1 + nb accumulates the group-mean probabilities of the last obs_len query rows
   int band[kMaxBandsM];
   float scale;
 };
+
+
+// 1-D grid -> (persistent workgroup index within the head, kv head)
+__device__ __forceinline__ void wg_coords(const MArgs& a, int& bx, int& h) {
+  const int b = blockIdx.x;
+  if (a.xcd_remap) {
+    const int idx = b >> 3;
+    h = (b & 7) + 8 * (idx / a.nwg);
+    bx = idx % a.nwg;
+  } else {
+    h = b / a.nwg;
+    bx = b % a.nwg;
+  }
+}
 
 // key offset inside a 32-key tile held by accumulator register `reg` of a lane in half `hi`
 __device__ __forceinline__ int c_row(int reg, int hi) { return (reg & 3) + 8 * (reg >> 2) + 4 * hi; }
@@ -115,7 +135,9 @@ __global__ __launch_bounds__(256) void prefill_stats_lds_kernel(MArgs a) {
   __shared__ __attribute__((aligned(16))) uint4 sm_kt[2][kTK][16];
   const int lane = threadIdx.x & 63, r = threadIdx.x >> 6;
   const int hi = lane >> 5, lq = lane & 31;
-  const int h = blockIdx.y, L = a.L;
+  int bx, h;
+  wg_coords(a, bx, h);
+  const int L = a.L;
   const int j = h * 4 + r;
   const T* qh = reinterpret_cast<const T*>(a.q) + (size_t)j * L * kD;
   const T* kh = reinterpret_cast<const T*>(a.k) + (size_t)h * L * kD;
@@ -123,7 +145,7 @@ __global__ __launch_bounds__(256) void prefill_stats_lds_kernel(MArgs a) {
   // cooperative tile load: thread t -> key row t / 8, chunks 2 * (t % 8) and + 1 (32 contiguous bytes)
   const int ld_row = threadIdx.x >> 3, ld_c0 = (threadIdx.x & 7) * 2;
 
-  for (int qt = blockIdx.x; qt < nqt; qt += gridDim.x) {
+  for (int qt = bx; qt < nqt; qt += a.nwg) {
     const int q0 = qt * kTQ;
     const int query = q0 + lq;
     const int qc = query < L ? query : L - 1;
@@ -202,29 +224,45 @@ __global__ __launch_bounds__(256) void prefill_stats_lds_kernel(MArgs a) {
 // pass 1: K and V^T tiles are fetched once per workgroup, one tile ahead, into double-buffered swizzled LDS images;
 // the partial side sums of tile t are folded into the workgroup's planes during tile t + 1 (double-buffered
 // sm_red), so a tile costs TWO barriers instead of three and no wave waits on its own global loads.
-template <typename T>
-__global__ __launch_bounds__(256) void prefill_pv_lds_kernel(MArgs a) {
+//
+// The tile body is compiled four times — {below the diagonal, on it} x {observation-window rows, none} — and the number
+// of band planes is a template parameter (NB = -1: run-time a.nb): the loop was ISSUE-bound on the predicate / select /
+// branch instructions of the causal mask, the band tests and the plane loops (~220 of ~690 instructions per 32 x 32
+// tile, against 16 MFMAs), all of which are constants for every tile but the diagonal one.
+template <bool B>
+struct BoolC {
+  static constexpr bool value = B;
+};
+
+template <typename T, int NB>
+__global__ __launch_bounds__(256, 2) void prefill_pv_lds_kernel(MArgs a) {
   __shared__ __attribute__((aligned(16))) uint4 sm_kt[2][kTK][16];   // [buf][key][chunk ^ (key & 15)]
   __shared__ __attribute__((aligned(16))) uint4 sm_vt[2][kD][4];     // [buf][d][chunk ^ ((d >> 2) & 3)]  (V^T, permuted keys)
   __shared__ float sm_p[4][kTK][kTQ + 1];                            // per-wave probability tiles: [r][key][query]
   __shared__ float sm_red[2][2 + kMaxBandsM][8][kTK];
+  constexpr int NBC = NB >= 0 ? NB : kMaxBandsM;  // band planes the compiled code iterates over
+  const int nb = NB >= 0 ? NB : a.nb;
   const int lane = threadIdx.x & 63, r = threadIdx.x >> 6;
   const int hi = lane >> 5, lq = lane & 31;
-  const int h = blockIdx.y, L = a.L;
+  int bx, h;
+  wg_coords(a, bx, h);
+  const int L = a.L;
   const int j = h * 4 + r;
   const T* qh = reinterpret_cast<const T*>(a.q) + (size_t)j * L * kD;
   const T* kh = reinterpret_cast<const T*>(a.k) + (size_t)h * L * kD;
   const T* vth = reinterpret_cast<const T*>(a.vt) + (size_t)h * kD * a.Lp;
   const int nqt = (L + kTQ - 1) / kTQ;
-  const size_t plane = (size_t)gridDim.x * a.H * L;
-  float* cp = a.cpart + ((size_t)blockIdx.x * a.H + h) * L;
-  const int npl = 1 + a.nb + (a.obs_len > 0 ? 1 : 0);
+  const size_t plane = (size_t)a.nwg * a.H * L;
+  float* cp = a.cpart + ((size_t)bx * a.H + h) * L;
+  const int obs_pl = 1 + nb;
+  const int npl = 1 + nb + (a.obs_len > 0 ? 1 : 0);
   for (int pl = 0; pl < npl; pl++)
     for (int s = threadIdx.x; s < L; s += 256) cp[pl * plane + s] = 0.f;
   const int kl_row = threadIdx.x >> 3, kl_c0 = (threadIdx.x & 7) * 2;   // K tile: row t/8, chunks 2(t%8), +1
   const int vl_row = threadIdx.x >> 1, vl_c0 = (threadIdx.x & 1) * 2;   // V^T tile: d row t/2, chunks 2(t%2), +1
+  const int rd_key = threadIdx.x & 31, rd_qs = threadIdx.x >> 5;        // side sums: key, slice of 4 queries
 
-  for (int qt = blockIdx.x; qt < nqt; qt += gridDim.x) {
+  for (int qt = bx; qt < nqt; qt += a.nwg) {
     const int q0 = qt * kTQ;
     const bool obs_tile = a.obs_len > 0 && q0 + kTQ > L - a.obs_len;
     const int query = q0 + lq;
@@ -257,41 +295,61 @@ __global__ __launch_bounds__(256) void prefill_pv_lds_kernel(MArgs a) {
       sm_vt[buf][vl_row][(vl_c0 ^ ((vl_row >> 2) & 3)) & 3] = sv0;
       sm_vt[buf][vl_row][((vl_c0 + 1) ^ ((vl_row >> 2) & 3)) & 3] = sv1;
     };
-    // fold the side sums tile t left in sm_red[t & 1] into this workgroup's planes (fixed order: deterministic)
-    auto fold = [&](int t, bool obs_t) {
+    // Fold the side sums tile t left in sm_red[t & 1] into this workgroup's planes (fixed order: deterministic).  The plane
+    // values are REQUESTED at the top of the iteration that folds them (fold_fetch) and consumed a QK^T product and a
+    // softmax later: a read-modify-write that waited out its own L2 round trip stalled wave 0 — and, at the next barrier,
+    // the whole workgroup — once per tile.
+    float cpv[2 + kMaxBandsM];
+    auto fold_fetch = [&](int t, auto obs_c) {
+      constexpr bool OBS = decltype(obs_c)::value;
       if (threadIdx.x < kTK && t * kTK + (int)threadIdx.x < L) {
-        const int key = threadIdx.x;
-        for (int pl = 0; pl < npl; pl++) {
-          if (pl == 1 + a.nb && !obs_t) continue;
-          float tot = 0.f;
+        float* row = cp + t * kTK + threadIdx.x;
+        cpv[0] = row[0];
 #pragma unroll
-          for (int qs = 0; qs < 8; qs++) tot += sm_red[t & 1][pl][qs][key];
-          cp[pl * plane + t * kTK + key] += tot;
-        }
+        for (int b = 0; b < NBC; b++)
+          if (NB >= 0 || b < nb) cpv[1 + b] = row[(size_t)(1 + b) * plane];
+        if (OBS) cpv[1 + kMaxBandsM] = row[(size_t)obs_pl * plane];
       }
     };
-    __syncthreads();
-    fetch(0);
-    stash(0);
-    __syncthreads();
-    for (int t = 0; t < ntile; t++) {
+    auto fold = [&](int t, auto obs_c) {
+      constexpr bool OBS = decltype(obs_c)::value;
+      if (threadIdx.x < kTK && t * kTK + (int)threadIdx.x < L) {
+        const int key = threadIdx.x, pbuf = t & 1;
+        float* row = cp + t * kTK + key;
+        auto total = [&](int pl) {
+          float tot = 0.f;
+#pragma unroll
+          for (int qs = 0; qs < 8; qs++) tot += sm_red[pbuf][pl][qs][key];
+          return tot;
+        };
+        row[0] = cpv[0] + total(0);
+#pragma unroll
+        for (int b = 0; b < NBC; b++)
+          if (NB >= 0 || b < nb) row[(size_t)(1 + b) * plane] = cpv[1 + b] + total(1 + b);
+        if (OBS) row[(size_t)obs_pl * plane] = cpv[1 + kMaxBandsM] + total(obs_pl);
+      }
+    };
+    // ---- one 32-key tile.  FULL: strictly below the diagonal of a complete query tile (no causal / bounds masking);
+    //      OBS: this query tile holds observation-window rows
+    auto tile = [&](int t, auto full_c, auto obs_c) {
+      constexpr bool FULL = decltype(full_c)::value;
+      constexpr bool OBS = decltype(obs_c)::value;
       const int k0 = t * kTK, buf = t & 1;
       if (t + 1 < ntile) fetch(t + 1);
-      // ---- S^T tile = K . Q^T from the LDS image
+      if (t > 0) fold_fetch(t - 1, obs_c);
+      // S^T tile = K . Q^T from the LDS image
       f32x16 s;
 #pragma unroll
       for (int e = 0; e < 16; e++) s[e] = 0.f;
 #pragma unroll
       for (int ds = 0; ds < 8; ds++) s = MfmaOps<T>::mma(sm_kt[buf][lq][((2 * ds + hi) ^ (lq & 15)) & 15], qb[ds], s);
-      float p[16];
-      uint32_t pp[8];  // the same probabilities as packed 16-bit pairs: the A operand of the P.V products
-      const bool full_tile = (k0 + kTK - 1 <= q0) && (q0 + kTQ <= L);  // no causal / bounds masking below the diagonal
+      uint32_t pp[8];  // the probabilities as packed 16-bit pairs: the A operand of the P.V products
 #pragma unroll
       for (int e = 0; e < 16; e += 2) {  // two elements per dtype conversion (v_cvt_pk_bf16_f32)
-        float r0, r1, v0, v1;
+        float r0, r1, v0, v1, p0, p1;
         pf_rnd2<T>(s[e], s[e + 1], r0, r1);
         pf_rnd2<T>(r0 * a.scale, r1 * a.scale, v0, v1);
-        if (!full_tile) {
+        if (!FULL) {
           const int key0 = k0 + c_row(e, hi), key1 = k0 + c_row(e + 1, hi);
           if (key0 > query || key0 >= L || query >= L) v0 = -INFINITY;
           if (key1 > query || key1 >= L || query >= L) v1 = -INFINITY;
@@ -299,36 +357,35 @@ __global__ __launch_bounds__(256) void prefill_pv_lds_kernel(MArgs a) {
         // exp(v - m) = 2^(v log2e - m log2e), exp(-inf) = 0
         const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(v0, kLog2e, m_fin_l2)) * inv_l;
         const float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(v1, kLog2e, m_fin_l2)) * inv_l;
-        pp[e >> 1] = pf_rnd2<T>(e0, e1, p[e], p[e + 1]);
-        sm_p[r][c_row(e, hi)][lq] = p[e];
-        sm_p[r][c_row(e + 1, hi)][lq] = p[e + 1];
+        pp[e >> 1] = pf_rnd2<T>(e0, e1, p0, p1);
+        sm_p[r][c_row(e, hi)][lq] = p0;
+        sm_p[r][c_row(e + 1, hi)][lq] = p1;
       }
       __syncthreads();  // B1: the four heads' probability tiles are in LDS
       {
-        const int key = threadIdx.x & 31, qs = threadIdx.x >> 5;  // 8 slices of 4 queries
         float cs = 0.f, os = 0.f, bs[kMaxBandsM] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int qq = 0; qq < 4; qq++) {
-          const int ql = qs * 4 + qq;
-          const float sum = ((sm_p[0][key][ql] + sm_p[1][key][ql]) + sm_p[2][key][ql]) + sm_p[3][key][ql];
+          const int ql = rd_qs * 4 + qq;
+          const float sum = ((sm_p[0][rd_key][ql] + sm_p[1][rd_key][ql]) + sm_p[2][rd_key][ql]) + sm_p[3][rd_key][ql];
           const float av = ElemTraits<T>::rnd(sum * 0.25f);  // == sum / 4 exactly (power of two); model.py:416-418
           cs += av;
-          if (obs_tile && q0 + ql >= L - a.obs_len && q0 + ql < L) os += av;
-          if (a.nb > 0) {
-            const int dist = (q0 + ql) - (k0 + key);
+          if (OBS && q0 + ql >= L - a.obs_len && q0 + ql < L) os += av;
+          if (NBC > 0) {
+            const int dist = (q0 + ql) - (k0 + rd_key);
 #pragma unroll
-            for (int b = 0; b < kMaxBandsM; b++)
-              if (b < a.nb && dist < a.band[b]) bs[b] += av;
+            for (int b = 0; b < NBC; b++)
+              if ((NB >= 0 || b < nb) && dist < a.band[b]) bs[b] += av;
           }
         }
-        sm_red[buf][0][qs][key] = cs;
+        sm_red[buf][0][rd_qs][rd_key] = cs;
 #pragma unroll
-        for (int b = 0; b < kMaxBandsM; b++)
-          if (b < a.nb) sm_red[buf][1 + b][qs][key] = bs[b];
-        if (obs_tile) sm_red[buf][1 + a.nb][qs][key] = os;
+        for (int b = 0; b < NBC; b++)
+          if (NB >= 0 || b < nb) sm_red[buf][1 + b][rd_qs][rd_key] = bs[b];
+        if (OBS) sm_red[buf][obs_pl][rd_qs][rd_key] = os;
       }
-      if (t > 0) fold(t - 1, obs_tile);  // the previous tile's sums became visible at the last barrier
-      // ---- O += P . V : A = P (C layout -> 16-bit), B = V^T fragments from the LDS image
+      if (t > 0) fold(t - 1, obs_c);  // the previous tile's sums became visible at the last barrier
+      // O += P . V : A = P (C layout -> 16-bit), B = V^T fragments from the LDS image
 #pragma unroll
       for (int kb = 0; kb < 2; kb++) {
         const uint4 pa = make_uint4(pp[kb * 4 + 0], pp[kb * 4 + 1], pp[kb * 4 + 2], pp[kb * 4 + 3]);
@@ -340,8 +397,24 @@ __global__ __launch_bounds__(256) void prefill_pv_lds_kernel(MArgs a) {
       }
       if (t + 1 < ntile) stash((t + 1) & 1);
       __syncthreads();  // B2: tile t + 1 is in LDS, tile t's side sums are in sm_red[buf], sm_p may be rewritten
+    };
+    __syncthreads();
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    // tiles [0, n_full) lie strictly below the diagonal of a complete query tile
+    const int n_full = (q0 + kTQ <= L) ? min(ntile, (q0 + 1) / kTK) : 0;
+    if (obs_tile) {
+      for (int t = 0; t < n_full; t++) tile(t, BoolC<true>{}, BoolC<true>{});
+      for (int t = n_full; t < ntile; t++) tile(t, BoolC<false>{}, BoolC<true>{});
+      fold_fetch(ntile - 1, BoolC<true>{});
+      fold(ntile - 1, BoolC<true>{});
+    } else {
+      for (int t = 0; t < n_full; t++) tile(t, BoolC<true>{}, BoolC<false>{});
+      for (int t = n_full; t < ntile; t++) tile(t, BoolC<false>{}, BoolC<false>{});
+      fold_fetch(ntile - 1, BoolC<false>{});
+      fold(ntile - 1, BoolC<false>{});
     }
-    fold(ntile - 1, obs_tile);
     T* yh = reinterpret_cast<T*>(a.y) + (size_t)j * L * kD;
 #pragma unroll
     for (int db = 0; db < 4; db++)
@@ -350,6 +423,15 @@ __global__ __launch_bounds__(256) void prefill_pv_lds_kernel(MArgs a) {
         const int qrow = q0 + c_row(e, hi);
         if (qrow < L) ElemTraits<T>::store(yh, (size_t)qrow * kD + db * 32 + lq, o[db][e]);
       }
+  }
+}
+
+template <typename T>
+static void launch_pv(const MArgs& a, dim3 grid, hipStream_t st) {
+  switch (a.nb) {
+    case 0: hipLaunchKernelGGL((prefill_pv_lds_kernel<T, 0>), grid, dim3(256), 0, st, a); break;
+    case 1: hipLaunchKernelGGL((prefill_pv_lds_kernel<T, 1>), grid, dim3(256), 0, st, a); break;
+    default: hipLaunchKernelGGL((prefill_pv_lds_kernel<T, -1>), grid, dim3(256), 0, st, a); break;
   }
 }
 
@@ -369,18 +451,23 @@ extern "C" int cc_prefill_attn_mfma_impl(const void* q, const void* k, const voi
   const size_t tot = (size_t)H * kD * Lp;
   size_t nbk = (tot + 255) / 256;
   if (nbk > 8192) nbk = 8192;
-  dim3 grid(nwg, H), block(256);
+  dim3 block(256);
+  static const bool no_remap = getenv("CC_PREFILL_NO_XCD_REMAP") != nullptr;  // measurement only
+  a.xcd_remap = (H % 8 == 0 && !no_remap) ? 1 : 0;
   // pass 1 keeps no per-workgroup partial planes: it can use as many workgroups as fit (5 per CU at ~100 VGPRs)
   const int nqt = (L + kTQ - 1) / kTQ;
-  dim3 grid1(nqt < 256 ? nqt : 256, H);
+  MArgs a1 = a;
+  a1.nwg = nqt < 256 ? nqt : 256;
+  a.nwg = nwg;
+  dim3 grid1((unsigned)(a1.nwg * H)), grid((unsigned)(nwg * H));
   if (dtype == CC_DT_BF16) {
     hipLaunchKernelGGL(vt_perm_kernel<bf16_t>, dim3((unsigned)nbk), dim3(256), 0, st, (const bf16_t*)v, (bf16_t*)vt, H, L, Lp);
-    hipLaunchKernelGGL(prefill_stats_lds_kernel<bf16_t>, grid1, block, 0, st, a);
-    hipLaunchKernelGGL(prefill_pv_lds_kernel<bf16_t>, grid, block, 0, st, a);
+    hipLaunchKernelGGL(prefill_stats_lds_kernel<bf16_t>, grid1, block, 0, st, a1);
+    launch_pv<bf16_t>(a, grid, st);
   } else {
     hipLaunchKernelGGL(vt_perm_kernel<f16_t>, dim3((unsigned)nbk), dim3(256), 0, st, (const f16_t*)v, (f16_t*)vt, H, L, Lp);
-    hipLaunchKernelGGL(prefill_stats_lds_kernel<f16_t>, grid1, block, 0, st, a);
-    hipLaunchKernelGGL(prefill_pv_lds_kernel<f16_t>, grid, block, 0, st, a);
+    hipLaunchKernelGGL(prefill_stats_lds_kernel<f16_t>, grid1, block, 0, st, a1);
+    launch_pv<f16_t>(a, grid, st);
   }
   if (hipGetLastError() != hipSuccess) return CC_ERR_HIP;
   return CC_OK;

@@ -28,6 +28,7 @@ struct UpdArgs {
   const void* scores;    // P_SCORES: [Hs,S] score dtype ; P_RANDOM: [S] f32
   int score_heads;       // rows in `scores`
   void* key_norm;        // P_L2: [H,S] T
+  const float* gmax_in;  // P_L2: the norm maximum from l2_norm_max_kernel, or null = recompute per workgroup (select-only calls)
   double* num;           // P_HH
   int32_t* denom;        // P_HH
   unsigned long long* key_out;  // P_HH pipeline seed: [H][nk] partial arg-min keys (entry 0 = the key, rest = ~0); no side effects
@@ -60,6 +61,67 @@ __device__ __forceinline__ void insert_rows(const UpdArgs& a, int h0, int nh, in
   if ((int)threadIdx.x < nh) a.mask[(size_t)(h0 + threadIdx.x) * a.S + idx] = 1;
 }
 
+// ref: cache.py:602 `self.key_norm.max()` over ALL heads and slots, by one whole workgroup of kUpdThreads threads (the
+// norms are H*S*2 bytes: L2-resident); NaN propagates like torch.max.  `sm_f` needs kUpdThreads / 64 + 1 floats.
+template <typename T>
+__device__ __forceinline__ float block_norm_max(const void* key_norm, int n, float* sm_f) {
+  const T* kn = reinterpret_cast<const T*>(key_norm);
+  float m = -INFINITY;
+  int nan = 0;
+  constexpr int VEC = 16 / (int)sizeof(T);
+  const int nvec = ((reinterpret_cast<uintptr_t>(kn) & 15) == 0) ? n / VEC : 0;
+  for (int i0 = threadIdx.x; i0 < nvec; i0 += kUpdThreads * 4) {  // 4 x 16-byte loads in flight per thread
+    Vec16<T> vv[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int i = i0 + u * kUpdThreads;
+      vv[u].load(kn + (size_t)(i < nvec ? i : nvec - 1) * VEC);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      float f[VEC];
+      vv[u].unpack(f);
+#pragma unroll
+      for (int e = 0; e < VEC; e++) {
+        nan |= (f[e] != f[e]);
+        m = fmaxf(m, f[e]);
+      }
+    }
+  }
+  for (int i = nvec * VEC + threadIdx.x; i < n; i += blockDim.x) {
+    float v = ElemTraits<T>::load(kn, i);
+    nan |= (v != v);
+    m = fmaxf(m, v);
+  }
+  m = wave_max_f32(m);
+  nan = __any(nan);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) sm_f[wave] = nan ? NAN : m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float mm = -INFINITY;
+    int nn = 0;
+    for (int i = 0; i < kUpdThreads / 64; i++) {
+      float v = sm_f[i];
+      nn |= (v != v);
+      mm = fmaxf(mm, v);
+    }
+    sm_f[kUpdThreads / 64] = nn ? NAN : mm;
+  }
+  __syncthreads();
+  return sm_f[kUpdThreads / 64];
+}
+
+// The maximum taken BEFORE any head inserts (cache.py:602 precedes the scatter of :592-593): with more than one head,
+// a workgroup of the update launch that started late could otherwise see another head's freshly inserted norm in
+// place of the evicted maximum.
+template <typename T>
+__global__ __launch_bounds__(kUpdThreads) void l2_norm_max_kernel(const void* key_norm, int n, float* out) {
+  __shared__ float sm_f[kUpdThreads / 64 + 2];
+  const float m = block_norm_max<T>(key_norm, n, sm_f);
+  if (threadIdx.x == 0) *out = m;
+}
+
 template <int POLICY, typename T, typename ST>
 __global__ __launch_bounds__(kUpdThreads) void decode_update_kernel(UpdArgs a) {
   __shared__ unsigned long long sm_key[kUpdThreads / 64 + 2];
@@ -74,56 +136,7 @@ __global__ __launch_bounds__(kUpdThreads) void decode_update_kernel(UpdArgs a) {
   if (a.k_new != nullptr && (int)threadIdx.x < nh * 2 * (a.D * (int)sizeof(T) / 4)) pre = new_word<T>(a, h0, threadIdx.x);
 
   float gmax = 0.f;
-  if (POLICY == P_L2) {
-    // ref: cache.py:602 `self.key_norm.max()` over ALL heads and slots (each workgroup recomputes it from
-    // L2: H*S*2 bytes); NaN propagates like torch.max.
-    const T* kn = reinterpret_cast<const T*>(a.key_norm);
-    float m = -INFINITY;
-    int nan = 0;
-    const int n = a.H * S;
-    constexpr int VEC = 16 / (int)sizeof(T);
-    const int nvec = ((reinterpret_cast<uintptr_t>(kn) & 15) == 0) ? n / VEC : 0;
-    for (int i0 = threadIdx.x; i0 < nvec; i0 += kUpdThreads * 4) {  // 4 x 16-byte loads in flight per thread
-      Vec16<T> vv[4];
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const int i = i0 + u * kUpdThreads;
-        vv[u].load(kn + (size_t)(i < nvec ? i : nvec - 1) * VEC);
-      }
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        float f[VEC];
-        vv[u].unpack(f);
-#pragma unroll
-        for (int e = 0; e < VEC; e++) {
-          nan |= (f[e] != f[e]);
-          m = fmaxf(m, f[e]);
-        }
-      }
-    }
-    for (int i = nvec * VEC + threadIdx.x; i < n; i += blockDim.x) {
-      float v = ElemTraits<T>::load(kn, i);
-      nan |= (v != v);
-      m = fmaxf(m, v);
-    }
-    m = wave_max_f32(m);
-    nan = __any(nan);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) sm_f[wave] = nan ? NAN : m;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      float mm = -INFINITY;
-      int nn = 0;
-      for (int i = 0; i < kUpdThreads / 64; i++) {
-        float v = sm_f[i];
-        nn |= (v != v);
-        mm = fmaxf(mm, v);
-      }
-      sm_f[kUpdThreads / 64] = nn ? NAN : mm;
-    }
-    __syncthreads();
-    gmax = sm_f[kUpdThreads / 64];
-  }
+  if (POLICY == P_L2) gmax = a.gmax_in ? *a.gmax_in : block_norm_max<T>(a.key_norm, a.H * S, sm_f);
 
   unsigned long long best = ~0ull;
   constexpr int UN = 4;  // slots per thread per pass: all per-slot loads are issued before the first use
@@ -354,20 +367,32 @@ int cc_decode_update_random(const cc_kv_view* c, const void* k_new, const void* 
 }
 
 size_t cc_decode_update_l2_workspace_bytes(int32_t H, int32_t S) {
-  (void)H; (void)S;
-  return 0;  // the global max is recomputed per workgroup from L2; no scratch needed
+  (void)S;
+  return H > 1 ? 256 : 0;  // the norm maximum, taken by a pre-launch before any head inserts
 }
 
 int cc_decode_update_l2(const cc_kv_view* c, const void* k_new, const void* v_new, const int32_t* input_pos,
                         void* key_norm, int32_t g, int32_t w, int64_t* idx_out, void* workspace,
                         size_t workspace_bytes, cc_stream_t stream) {
   CC_ENTRY();
-  (void)workspace; (void)workspace_bytes;
   if (!cc_view_ok(c) || !input_pos || !idx_out || !key_norm || c->Hp != c->H || g < 0 || (k_new && !v_new))
     return CC_ERR_BAD_ARG;
   UpdArgs a{};
   a.k_new = k_new; a.v_new = v_new; a.input_pos = input_pos; a.idx_out = idx_out; a.g = g; a.w = w;
   a.key_norm = key_norm;
+  if (k_new && c->H > 1) {  // inserts of other heads must not reach this head's maximum: take it in a launch of its own
+    if (!workspace || workspace_bytes < cc_decode_update_l2_workspace_bytes(c->H, c->S)) return CC_ERR_WORKSPACE;
+    float* gm = reinterpret_cast<float*>(workspace);
+    const int n = c->H * c->S;
+    hipStream_t st = (hipStream_t)stream;
+    switch (c->dtype) {
+      case CC_DT_F32: hipLaunchKernelGGL(l2_norm_max_kernel<float>, dim3(1), dim3(kUpdThreads), 0, st, key_norm, n, gm); break;
+      case CC_DT_BF16: hipLaunchKernelGGL(l2_norm_max_kernel<bf16_t>, dim3(1), dim3(kUpdThreads), 0, st, key_norm, n, gm); break;
+      default: hipLaunchKernelGGL(l2_norm_max_kernel<f16_t>, dim3(1), dim3(kUpdThreads), 0, st, key_norm, n, gm); break;
+    }
+    CC_LAUNCH_CHECK();
+    a.gmax_in = gm;
+  }
   return launch_update<P_L2>(c, a, (hipStream_t)stream);
 }
 

@@ -325,7 +325,8 @@ int cc_kv_requant_pair(void* k_work, void* k_q, void* k_scales, void* k_zeros, v
   CC_ENTRY();
   if (!k_work || !k_q || !k_scales || !k_zeros || !v_work || !v_q || !v_scales || !v_zeros || !quant_args_ok(H, S, D, dtype, n_bit))
     return CC_ERR_BAD_ARG;
-  if (stable && (!pos || !pos_seen || Hp <= 0 || Hp > 64)) return CC_ERR_BAD_ARG;
+  if (stable && (!pos || !pos_seen || Hp <= 0)) return CC_ERR_BAD_ARG;
+  if (Hp > 64) stable = nullptr;  // the stable-slot bookkeeping covers up to 64 position rows: beyond that every slot is redone
   RequantSet rs{{k_work, v_work}, {reinterpret_cast<uint8_t*>(k_q), reinterpret_cast<uint8_t*>(v_q)}, {k_scales, v_scales},
                 {k_zeros, v_zeros}, pos, Hp, stable, pos_seen};
   return requant_launch(rs, 2, H, S, D, dtype, n_bit, (hipStream_t)stream);

@@ -93,7 +93,6 @@ def precompute_freqs_cis(seq_len, n_elem, base=10000, dtype=torch.bfloat16, rope
     return torch.stack([cis.real, cis.imag], dim=-1).to(dtype=dtype)
 
 
-apply_rotary_emb = glue.apply_rotary_emb  # eager form of ref: model.py:507-519 (the device path is cc_qkv_rope)
 
 
 class RMSNorm(nn.Module):

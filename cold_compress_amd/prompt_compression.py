@@ -57,6 +57,45 @@ class AttnSummary:
         """ref: prompt_compression.py:173 attn[:, :, -obs_len:, :].mean(dim=2) -> [1, H, L] dtype."""
         return self.obs_mean.to(self.dtype).unsqueeze(0)
 
+    def view(self, *shape):
+        """The reference's model.py:413-418 runs UNCHANGED on a summary: `attn.view(bsz, n_local_heads, R, seqlen, -1)
+        .mean(dim=2)`.  When the kernel was handed GQA-shaped K/V the summary is already per kv head (R groups averaged
+        inside the prefill pass) and the call returns it as is; when the caller repeat_interleave'd K/V first
+        (model.py:399-400), the summary has one row per QUERY head and `.mean(dim=2)` averages each group of R rows —
+        on the fp32 column sums rather than per bf16 probability (same value up to the rounding of the reference's
+        per-element mean)."""
+        if len(shape) == 1 and isinstance(shape[0], (tuple, list, torch.Size)):
+            shape = tuple(shape[0])
+        rows, L = self.colsum.shape
+        if len(shape) != 5 or shape[0] != 1 or shape[3] != L or shape[4] not in (-1, L) or shape[1] <= 0 or shape[2] <= 0:
+            raise ColdCompressError(f"AttnSummary.view{tuple(shape)}: only the group view (1, H, R, L, -1) of model.py:413-418 exists")
+        H, R = shape[1], shape[2]
+        if H * R == rows:
+            return _GroupView(self, H, R)
+        if H == rows:  # already averaged over the group inside the kernel
+            return _GroupView(self, H, 1)
+        raise ColdCompressError(f"AttnSummary.view: {rows} summary rows cannot be seen as {H} kv heads x {R} query heads")
+
+
+class _GroupView:
+    """`AttnSummary.view(1, H, R, L, -1)`: the only thing the reference does with it is `.mean(dim=2)`."""
+
+    def __init__(self, summary, H, R):
+        self.summary, self.H, self.R = summary, H, R
+
+    def mean(self, dim):
+        if dim != 2:
+            raise ColdCompressError("the group view of an AttnSummary supports .mean(dim=2) only (model.py:416-418)")
+        s, H, R = self.summary, self.H, self.R
+        if R == 1:
+            return s
+        L = s.colsum.shape[1]
+
+        def grp(t):
+            return t.view(H, R, L).mean(dim=1)
+
+        return AttnSummary(grp(s.colsum), grp(s.obs_mean), s.obs_len, s.dtype, {b: grp(t) for b, t in s.bands.items()})
+
 
 def topk_keep(priority, K):
     """Ascending indices of the K largest entries per row (ref: prompt_compression.py:21-26)."""

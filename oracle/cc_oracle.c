@@ -198,6 +198,22 @@ static void insert_token(const cc_kv_view* c, const void* k_new, const void* v_n
 
 int cc_abi_version_cpu(void) { return CC_ABI_VERSION; }
 
+/* Thread count of the OpenMP loops (oracle_lib sets 1 at load: tests stay single-threaded; bench.py's CPU baseline
+ * raises it to the host's core count).  Returns the previous maximum. */
+#ifdef _OPENMP
+#include <omp.h>
+int cc_oracle_set_threads(int n) {
+  const int old = omp_get_max_threads();
+  if (n > 0) omp_set_num_threads(n);
+  return old;
+}
+#else
+int cc_oracle_set_threads(int n) {
+  (void)n;
+  return 1;
+}
+#endif
+
 /* ref: KVCacheFull._eviction_idx cache.py:500-502 */
 int cc_decode_update_full_cpu(const cc_kv_view* c, const void* k_new, const void* v_new,
                               const int32_t* input_pos, int64_t* idx_out, cc_stream_t stream) {
@@ -320,8 +336,11 @@ int cc_decode_update_heavy_hitter_cpu(const cc_kv_view* c, const void* k_new, co
   if (!view_ok(c) || !input_pos || !idx_out || !num || !denom || c->Hp != c->H || c->H > 4096)
     return CC_ERR_BAD_ARG;
   const int32_t p = *input_pos;
-  float* sc = (float*)malloc(sizeof(float) * (size_t)c->S);
+  /* heads are independent (cache.py:725-765): one OpenMP thread per head when built with -fopenmp (bench.py's CPU
+   * baseline); the result does not depend on the thread count */
+#pragma omp parallel for schedule(static)
   for (int h = 0; h < c->H; h++) {
+    float* sc = (float*)malloc(sizeof(float) * (size_t)c->S);
     const int32_t* pos = c->pos + (size_t)h * c->S;
     for (int s = 0; s < c->S; s++) {
       size_t i = (size_t)h * c->S + s;
@@ -332,8 +351,8 @@ int cc_decode_update_heavy_hitter_cpu(const cc_kv_view* c, const void* k_new, co
       sc[s] = v;
     }
     idx_out[h] = argmin_f32(sc, c->S);
+    free(sc);
   }
-  free(sc);
   for (int h = 0; h < c->H; h++) {
     num[(size_t)h * c->S + idx_out[h]] = 0.0;
     denom[(size_t)h * c->S + idx_out[h]] = 0;
@@ -384,11 +403,18 @@ int cc_decode_attn_gqa_cpu(const void* q, const void* k, const void* v, const ui
   if (!q || !k || !v || !y || HQ <= 0 || H <= 0 || HQ % H || S <= 0 || D <= 0 || !dt_ok(dtype))
     return CC_ERR_BAD_ARG;
   const int R = HQ / H;
-  float* P = (float*)malloc(sizeof(float) * (size_t)R * S);
-  float* sc = (float*)malloc(sizeof(float) * (size_t)S);
-  for (int h = 0; h < H; h++) {
-    for (int r = 0; r < R; r++) {
-      const int j = h * R + r;
+  /* Every (kv head, query head) pair is independent up to the group mean: OpenMP over the HQ query heads first (bench.py's
+   * CPU baseline runs this with OMP_NUM_THREADS = nproc), then over the kv heads for the group mean / history.  Each
+   * value is computed by exactly one thread with the same arithmetic: results do not depend on the thread count. */
+  float* Pall = (float*)malloc(sizeof(float) * (size_t)HQ * S);
+#pragma omp parallel for schedule(static)
+  for (int j = 0; j < HQ; j++) {
+    const int h = j / R;
+    float* P = Pall + (size_t)(j - h * R) * S + (size_t)h * R * S;
+    float* sc = (float*)malloc(sizeof(float) * (size_t)S);
+    {
+      const int r = j - h * R;
+      (void)r;
       float m = -INFINITY;
       for (int s = 0; s < S; s++) {
         double acc = 0.0;
@@ -407,15 +433,20 @@ int cc_decode_attn_gqa_cpu(const void* q, const void* k, const void* v, const ui
       const float fsum = (float)sum;
       for (int s = 0; s < S; s++) {
         float pr = rnd(sc[s] / fsum, dtype);
-        P[(size_t)r * S + s] = pr;
+        P[s] = pr;
         if (probs_out) st(probs_out, dtype, (size_t)j * S + s, pr);
       }
       for (int d = 0; d < D; d++) {
         double acc = 0.0;
-        for (int s = 0; s < S; s++) acc += (double)P[(size_t)r * S + s] * (double)ld(v, dtype, ((size_t)h * S + s) * D + d);
+        for (int s = 0; s < S; s++) acc += (double)P[s] * (double)ld(v, dtype, ((size_t)h * S + s) * D + d);
         st(y, dtype, (size_t)j * D + d, (float)acc);
       }
     }
+    free(sc);
+  }
+#pragma omp parallel for schedule(static)
+  for (int h = 0; h < H; h++) {
+    const float* P = Pall + (size_t)h * R * S;
     if (attn_out || hh_num) {
       for (int s = 0; s < S; s++) {
         float acc = 0.f;
@@ -430,8 +461,7 @@ int cc_decode_attn_gqa_cpu(const void* q, const void* k, const void* v, const ui
     }
   }
   if (hh_num && hh_counter) *hh_counter += 1;
-  free(P);
-  free(sc);
+  free(Pall);
   return CC_OK;
 }
 
@@ -592,6 +622,108 @@ size_t cc_prefill_attn_workspace_bytes_cpu(int32_t HQ, int32_t H, int32_t L, int
 /* ref: attention_utils.py:36-54 with the causal mask of generation_utils.py:153-158, model.py:413-418
  * (group mean), cache.py:704 / prompt_compression.py:191 (column sums) and prompt_compression.py:173
  * (mean of the last obs_len query rows).  O(L^2 D) — small L only. */
+/* Core shared by cc_prefill_attn_cpu and cc_prefill_attn_bands_cpu.  Query rows are processed in blocks of kPfBlock: the
+ * rows of a block are independent (one OpenMP thread each: scores, softmax, probabilities, y, group mean -> A[row][s]),
+ * then every COLUMN s accumulates its block of rows sequentially in query order — the canonical order of the column,
+ * observation-window and band sums (one thread per column; the result does not depend on the thread count). */
+enum { kPfBlock = 128 };
+static int prefill_core(const void* q, const void* k, const void* v, int HQ, int H, int L, int D, int dtype, float scale, void* y,
+                        float* colsum_out, float* obs_out, int obs_len, const int32_t* bands, int n_bands, float* band_out,
+                        float* attn_full) {
+  const int R = HQ / H;
+  if (obs_len > L) obs_len = L;
+  if (colsum_out) memset(colsum_out, 0, sizeof(float) * (size_t)H * L);
+  if (obs_out) memset(obs_out, 0, sizeof(float) * (size_t)H * L);
+  if (band_out) memset(band_out, 0, sizeof(float) * (size_t)n_bands * H * L);
+  float* kf = (float*)malloc(sizeof(float) * (size_t)L * D);
+  float* vf = (float*)malloc(sizeof(float) * (size_t)L * D);
+  float* A = (float*)malloc(sizeof(float) * (size_t)kPfBlock * L);
+  const int need_a = colsum_out || obs_out || band_out || attn_full;
+  for (int h = 0; h < H; h++) {
+    for (size_t e = 0; e < (size_t)L * D; e++) {
+      kf[e] = ld(k, dtype, (size_t)h * L * D + e);
+      vf[e] = ld(v, dtype, (size_t)h * L * D + e);
+    }
+    for (int i0 = 0; i0 < L; i0 += kPfBlock) {
+      const int nb = L - i0 < kPfBlock ? L - i0 : kPfBlock;
+#pragma omp parallel
+      {
+      /* per-thread scratch, allocated once per block (per-row allocations of this size go through mmap and serialise
+       * hundreds of threads in the kernel) */
+      float* P = (float*)malloc(sizeof(float) * (size_t)R * (i0 + nb));
+      float* sc = (float*)malloc(sizeof(float) * (size_t)(i0 + nb));
+      float* qf = (float*)malloc(sizeof(float) * (size_t)D);
+#pragma omp for schedule(dynamic, 1)
+      for (int bi = 0; bi < nb; bi++) {
+        const int i = i0 + bi;
+        for (int r = 0; r < R; r++) {
+          const int j = h * R + r;
+          for (int d = 0; d < D; d++) qf[d] = ld(q, dtype, ((size_t)j * L + i) * D + d);
+          float m = -INFINITY;
+          for (int s = 0; s <= i; s++) {
+            double acc = 0.0;
+            const float* kr = kf + (size_t)s * D;
+            for (int d = 0; d < D; d++) acc += (double)qf[d] * (double)kr[d];
+            float x = rnd(rnd((float)acc, dtype) * scale, dtype);
+            sc[s] = x;
+            if (x > m) m = x;
+          }
+          double sum = 0.0;
+          for (int s = 0; s <= i; s++) {
+            sc[s] = expf(sc[s] - m);
+            sum += sc[s];
+          }
+          const float fsum = (float)sum;
+          float* Pr = P + (size_t)r * (i + 1);
+          for (int s = 0; s <= i; s++) Pr[s] = rnd(sc[s] / fsum, dtype);
+          for (int d = 0; d < D; d++) {
+            double acc = 0.0;
+            for (int s = 0; s <= i; s++) acc += (double)Pr[s] * (double)vf[(size_t)s * D + d];
+            st(y, dtype, ((size_t)j * L + i) * D + d, (float)acc);
+          }
+        }
+        if (need_a) {
+          float* Ar = A + (size_t)bi * L;
+          for (int s = 0; s <= i; s++) {
+            float acc = 0.f;
+            for (int r = 0; r < R; r++) acc += P[(size_t)r * (i + 1) + s];
+            Ar[s] = rnd(acc / (float)R, dtype);
+          }
+        }
+      }
+      free(P);
+      free(sc);
+      free(qf);
+      }
+      if (attn_full)  /* the group-averaged probabilities themselves, [H, L, L], zero above the diagonal */
+        for (int bi = 0; bi < nb; bi++) {
+          float* dst = attn_full + ((size_t)h * L + i0 + bi) * L;
+          memcpy(dst, A + (size_t)bi * L, sizeof(float) * (size_t)(i0 + bi + 1));
+          memset(dst + i0 + bi + 1, 0, sizeof(float) * (size_t)(L - i0 - bi - 1));
+        }
+      if (need_a) {
+#pragma omp parallel for schedule(static)
+        for (int s = 0; s < i0 + nb; s++) {
+          for (int bi = (s > i0 ? s - i0 : 0); bi < nb; bi++) {  // rows i >= s only (causal)
+            const int i = i0 + bi;
+            const float a = A[(size_t)bi * L + s];
+            if (colsum_out) colsum_out[(size_t)h * L + s] += a;
+            if (obs_out && i >= L - obs_len) obs_out[(size_t)h * L + s] += a;
+            for (int b = 0; b < n_bands; b++)
+              if (i - s < bands[b]) band_out[((size_t)b * H + h) * L + s] += a;
+          }
+        }
+      }
+    }
+  }
+  if (obs_out && obs_len > 0)
+    for (size_t i = 0; i < (size_t)H * L; i++) obs_out[i] /= (float)obs_len;
+  free(kf);
+  free(vf);
+  free(A);
+  return CC_OK;
+}
+
 int cc_prefill_attn_cpu(const void* q, const void* k, const void* v, int32_t HQ, int32_t H, int32_t L,
                         int32_t D, int32_t dtype, float scale, void* y, float* colsum_out, float* obs_out,
                         int32_t obs_len, void* workspace, size_t workspace_bytes, cc_stream_t stream) {
@@ -600,51 +732,7 @@ int cc_prefill_attn_cpu(const void* q, const void* k, const void* v, int32_t HQ,
   (void)workspace_bytes;
   if (!q || !k || !v || !y || HQ <= 0 || H <= 0 || HQ % H || L <= 0 || D <= 0 || !dt_ok(dtype))
     return CC_ERR_BAD_ARG;
-  const int R = HQ / H;
-  if (obs_len > L) obs_len = L;
-  float* P = (float*)malloc(sizeof(float) * (size_t)R * L);
-  float* sc = (float*)malloc(sizeof(float) * (size_t)L);
-  if (colsum_out) memset(colsum_out, 0, sizeof(float) * (size_t)H * L);
-  if (obs_out) memset(obs_out, 0, sizeof(float) * (size_t)H * L);
-  for (int h = 0; h < H; h++)
-    for (int i = 0; i < L; i++) {
-      for (int r = 0; r < R; r++) {
-        const int j = h * R + r;
-        float m = -INFINITY;
-        for (int s = 0; s <= i; s++) {
-          double acc = 0.0;
-          for (int d = 0; d < D; d++)
-            acc += (double)ld(q, dtype, ((size_t)j * L + i) * D + d) * (double)ld(k, dtype, ((size_t)h * L + s) * D + d);
-          float x = rnd(rnd((float)acc, dtype) * scale, dtype);
-          sc[s] = x;
-          if (x > m) m = x;
-        }
-        double sum = 0.0;
-        for (int s = 0; s <= i; s++) {
-          sc[s] = expf(sc[s] - m);
-          sum += sc[s];
-        }
-        const float fsum = (float)sum;
-        for (int s = 0; s < L; s++) P[(size_t)r * L + s] = s <= i ? rnd(sc[s] / fsum, dtype) : 0.f;
-        for (int d = 0; d < D; d++) {
-          double acc = 0.0;
-          for (int s = 0; s <= i; s++) acc += (double)P[(size_t)r * L + s] * (double)ld(v, dtype, ((size_t)h * L + s) * D + d);
-          st(y, dtype, ((size_t)j * L + i) * D + d, (float)acc);
-        }
-      }
-      for (int s = 0; s <= i; s++) {
-        float acc = 0.f;
-        for (int r = 0; r < R; r++) acc += P[(size_t)r * L + s];
-        float a = rnd(acc / (float)R, dtype);
-        if (colsum_out) colsum_out[(size_t)h * L + s] += a;
-        if (obs_out && i >= L - obs_len) obs_out[(size_t)h * L + s] += a;
-      }
-    }
-  if (obs_out && obs_len > 0)
-    for (size_t i = 0; i < (size_t)H * L; i++) obs_out[i] /= (float)obs_len;
-  free(P);
-  free(sc);
-  return CC_OK;
+  return prefill_core(q, k, v, HQ, H, L, D, dtype, scale, y, colsum_out, obs_out, obs_len, NULL, 0, NULL, NULL);
 }
 
 /* ref: attn.squeeze(0).sum(dim=1) cache.py:704 */
@@ -999,45 +1087,23 @@ int cc_prefill_attn_bands_cpu(const void* q, const void* k, const void* v, int32
                               int32_t dtype, float scale, void* y, float* colsum_out, float* obs_out, int32_t obs_len,
                               const int32_t* bands, int32_t n_bands, float* band_out, void* workspace,
                               size_t workspace_bytes, cc_stream_t stream) {
-  int rc = cc_prefill_attn_cpu(q, k, v, HQ, H, L, D, dtype, scale, y, colsum_out, obs_out, obs_len, workspace,
-                               workspace_bytes, stream);
-  if (rc != CC_OK || n_bands <= 0) return rc;
-  if (!bands || !band_out || n_bands > 4) return CC_ERR_BAD_ARG;
-  const int R = HQ / H;
-  float* P = (float*)malloc(sizeof(float) * (size_t)R * L);
-  float* sc = (float*)malloc(sizeof(float) * (size_t)L);
-  memset(band_out, 0, sizeof(float) * (size_t)n_bands * H * L);
-  for (int h = 0; h < H; h++)
-    for (int i = 0; i < L; i++) {
-      for (int r = 0; r < R; r++) {
-        const int j = h * R + r;
-        float m = -INFINITY;
-        for (int s = 0; s <= i; s++) {
-          double acc = 0.0;
-          for (int d = 0; d < D; d++)
-            acc += (double)ld(q, dtype, ((size_t)j * L + i) * D + d) * (double)ld(k, dtype, ((size_t)h * L + s) * D + d);
-          float x = rnd(rnd((float)acc, dtype) * scale, dtype);
-          sc[s] = x;
-          if (x > m) m = x;
-        }
-        double sum = 0.0;
-        for (int s = 0; s <= i; s++) {
-          sc[s] = expf(sc[s] - m);
-          sum += sc[s];
-        }
-        for (int s = 0; s <= i; s++) P[(size_t)r * L + s] = rnd(sc[s] / (float)sum, dtype);
-      }
-      for (int s = 0; s <= i; s++) {
-        float acc = 0.f;
-        for (int r = 0; r < R; r++) acc += P[(size_t)r * L + s];
-        const float a = rnd(acc / (float)R, dtype);
-        for (int b = 0; b < n_bands; b++)
-          if (i - s < bands[b]) band_out[((size_t)b * H + h) * L + s] += a;
-      }
-    }
-  free(P);
-  free(sc);
-  return CC_OK;
+  (void)stream;
+  (void)workspace;
+  (void)workspace_bytes;
+  if (!q || !k || !v || !y || HQ <= 0 || H <= 0 || HQ % H || L <= 0 || D <= 0 || !dt_ok(dtype))
+    return CC_ERR_BAD_ARG;
+  if (n_bands > 0 && (!bands || !band_out || n_bands > 4)) return CC_ERR_BAD_ARG;
+  return prefill_core(q, k, v, HQ, H, L, D, dtype, scale, y, colsum_out, obs_out, obs_len, bands, n_bands > 0 ? n_bands : 0,
+                      n_bands > 0 ? band_out : NULL, NULL);
+}
+
+/* Oracle-only (no device twin): the materialised [H, L, L] group-averaged attention the reference's policies consume
+ * (attention_utils.py:36-54 + model.py:413-418), as float32 values already rounded to the model dtype — what the
+ * full-size hybrid profiling test feeds to its restatement of cache.py:1066-1187. */
+int cc_prefill_attn_matrix_cpu(const void* q, const void* k, const void* v, int32_t HQ, int32_t H, int32_t L, int32_t D,
+                               int32_t dtype, float scale, void* y, float* attn_full) {
+  if (!q || !k || !v || !y || !attn_full || HQ <= 0 || H <= 0 || HQ % H || L <= 0 || D <= 0 || !dt_ok(dtype)) return CC_ERR_BAD_ARG;
+  return prefill_core(q, k, v, HQ, H, L, D, dtype, scale, y, NULL, NULL, 0, NULL, 0, NULL, attn_full);
 }
 
 /* ref: KVCacheHeavyHitter._eviction_idx cache.py:725-765 with history_window_size W > 1 */

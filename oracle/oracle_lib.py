@@ -14,6 +14,8 @@ from cold_compress_amd import _abi
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO = os.path.join(_HERE, "liboracle.so")
 _FNS = None
+_SET_THREADS = None
+_ATTN_MATRIX = None
 
 
 def build(force=False):
@@ -28,8 +30,24 @@ def fns():
     if _FNS is None:
         if not os.path.exists(SO):
             build()
-        _FNS = _abi.bind(C.CDLL(SO), suffix="_cpu")
+        lib = C.CDLL(SO)
+        _FNS = _abi.bind(lib, suffix="_cpu")
+        lib.cc_oracle_set_threads.restype = C.c_int
+        lib.cc_oracle_set_threads.argtypes = [C.c_int]
+        global _SET_THREADS
+        _SET_THREADS = lib.cc_oracle_set_threads
+        lib.cc_oracle_set_threads(1)  # the checker runs single-threaded; bench.py's CPU baseline raises it explicitly
+        global _ATTN_MATRIX
+        lib.cc_prefill_attn_matrix_cpu.restype = C.c_int
+        lib.cc_prefill_attn_matrix_cpu.argtypes = [C.c_void_p] * 3 + [C.c_int32] * 5 + [C.c_float, C.c_void_p, C.c_void_p]
+        _ATTN_MATRIX = lib.cc_prefill_attn_matrix_cpu
     return _FNS
+
+
+def set_threads(n):
+    """Thread count of the oracle's OpenMP loops (per-head loops of the decode hot path); returns the previous one."""
+    fns()
+    return _SET_THREADS(int(n))
 
 
 def ptr(a):
@@ -47,3 +65,11 @@ def call(name, *args):
     rc = fns()[name](*args)
     if rc != 0:
         raise RuntimeError(f"oracle {name} -> {rc}")
+
+
+def prefill_attn_matrix(q, k, v, HQ, H, L, D, dtype, scale, y, attn_full):
+    """Oracle-only: causal prefill attention with the materialised [H, L, L] group-averaged probabilities (float32)."""
+    fns()
+    rc = _ATTN_MATRIX(ptr(q), ptr(k), ptr(v), HQ, H, L, D, dtype, scale, ptr(y), ptr(attn_full))
+    if rc != 0:
+        raise RuntimeError(f"oracle cc_prefill_attn_matrix -> {rc}")

@@ -1,0 +1,250 @@
+"""Parity at the prompt lengths the BASELINE configurations actually use (8192 and 16384 tokens), on a subset of heads so the
+C oracle — OpenMP over the host's cores, still the same arithmetic — finishes in seconds:
+
+  * the matrix-core prefill attention with its side planes (column sums, SnapKV observation window, FastGen band sums at the
+    config's window width 0.1 * L) against the oracle (attention_utils.py:36-54, cache.py:1093, 1155);
+  * KVCacheHybrid's prefill profiling at L = 16384 / S = 18432 against a row-by-row restatement of the reference's
+    definition over the materialised [H, L, L] attention (cache.py:1066-1187; tests/hybrid_profile_ref.py);
+  * a heavy-hitter prefill -> SnapKV compaction -> decode replay that NEVER overwrites the device's numeric state with the
+    oracle's: every eviction is either identical or justified as a rounding-level near-tie in the oracle's own scores, and
+    the drift of the float64 history is bounded.
+"""
+import ctypes as C
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import from_np, to_np
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+BF16_ULP = 2.0 ** -8
+
+
+@pytest.fixture()
+def oracle_mt(oracle):
+    """The oracle on all host cores for the full-size cases (identical results, see oracle/cc_oracle.c)."""
+    oracle.set_threads(os.cpu_count() or 1)
+    yield oracle
+    oracle.set_threads(1)
+
+
+@pytest.mark.parametrize("L", [8192, 16384])
+def test_prefill_bands_full_size(oracle_mt, L):
+    from cold_compress_amd.attention_utils import prefill_attention
+
+    o = oracle_mt
+    HQ, H, D, dtype = 4, 1, 128, torch.bfloat16
+    band = max(1, int(0.1 * L))  # hybrid.yaml: recent_window 0.1 (cache.py:1093)
+    gen = torch.Generator().manual_seed(L)
+    q = (1.5 * torch.randn(1, HQ, L, D, generator=gen)).to(dtype)
+    k = (1.5 * torch.randn(1, H, L, D, generator=gen)).to(dtype)
+    v = torch.randn(1, H, L, D, generator=gen).to(dtype)
+    y, summ = prefill_attention(q.to(DEV), k.to(DEV), v.to(DEV), return_attn=True, bands=[band])
+    torch.cuda.synchronize()
+    yo, cs, ob = np.zeros((HQ, L, D), np.uint16), np.zeros((H, L), np.float32), np.zeros((H, L), np.float32)
+    bo = np.zeros((1, H, L), np.float32)
+    barr = (C.c_int32 * 1)(band)
+    o.call("cc_prefill_attn_bands", o.ptr(to_np(q[0])), o.ptr(to_np(k[0])), o.ptr(to_np(v[0])), HQ, H, L, D, 1, 1.0 / math.sqrt(D),
+           o.ptr(yo), o.ptr(cs), o.ptr(ob), 16, barr, 1, o.ptr(bo), None, 0, None)
+    yref = from_np(yo, dtype).float()
+    # y: 1e-3 (north star) + two roundings of the output dtype
+    assert (y.cpu().float()[0] - yref).abs().max() <= 1e-3 + 2 * BF16_ULP * yref.abs().max()
+    # sums of up to L probabilities, each rounded to bf16 on both sides (the device's exp / reciprocal may land on the
+    # neighbouring bf16 value): one bf16 ulp of the sum, plus the 5e-2 the small-shape tests allow
+    for name, mine, ref in (("colsum", summ.colsum.cpu(), torch.from_numpy(cs)), ("band", summ.bands[band].cpu(), torch.from_numpy(bo[0]))):
+        err = (mine - ref).abs()
+        assert bool((err <= 5e-2 + BF16_ULP * ref.abs()).all()), f"{name}: max err {float(err.max())}"
+    assert (summ.obs_mean.cpu() - torch.from_numpy(ob)).abs().max() < 4e-3
+    # size-independent properties: every query row's probabilities sum to ~1, so the column sums add up to ~L, and the
+    # band sums are the part of them within `band` queries of each key
+    assert abs(float(summ.colsum.sum()) / L - 1.0) < 2e-2
+    assert bool((summ.bands[band] <= summ.colsum + 1e-3).all())
+
+
+HYBRID = [{"strategy": "window", "recent_window": 0.1},
+          {"strategy": "window_heavy_hitter", "heavy_hitter_frac": 0.25, "recent_window": 0.1},
+          {"strategy": "window_heavy_hitter", "heavy_hitter_frac": 0.5, "recent_window": 0.1},
+          {"strategy": "full"}]
+
+
+def test_hybrid_profiling_full_size(oracle_mt):
+    """C4: 16384-token prompt, cache 18432, hybrid.yaml's four policies; three kinds of heads (tests/hybrid_inputs.py)."""
+    import cold_compress_amd.cache as cache
+    import hybrid_profile_ref as hp
+    from cold_compress_amd.attention_utils import prefill_attention
+    from hybrid_inputs import make_inputs
+
+    o = oracle_mt
+    L, S, H, R, D, g, frac, dtype = 16384, 18432, 3, 2, 128, 4, 0.97, torch.bfloat16
+    HQ = H * R
+    q, k, v = make_inputs(L, H, R, D, 0, dtype)
+    cls, rk = cache.get_cache_constructor("hybrid")
+    kw = dict(max_cache_length=S, max_seq_length=S, cache_bits=None, global_tokens=g, token_ids={"special": [], "punctuation": []},
+              min_recovery_frac=frac, hybrid_strategies=HYBRID)
+    with torch.device(DEV):
+        kv = cls(1, H, D, dtype, **{x: kw[x] for x in rk})
+    pos0 = torch.arange(L, device=DEV)
+    ids = torch.zeros(1, L, dtype=torch.int64, device=DEV)
+    kd, vd = k.unsqueeze(0).to(DEV), v.unsqueeze(0).to(DEV)
+    y, summ = prefill_attention(q.unsqueeze(0).to(DEV), kd, vd, return_attn=True, bands=kv.attn_bands(L))
+    kv.update_kv(pos0, kd, vd, True, input_ids=ids)
+    kv.update_state(pos0, kd, vd, True, summ, input_ids=ids)
+    torch.cuda.synchronize()
+    # ---- the reference's definition, row by row over the materialised attention
+    A = np.zeros((H, L, L), np.float32)
+    yo = np.zeros((HQ, L, D), np.uint16)
+    o.prefill_attn_matrix(to_np(q), to_np(k), to_np(v), HQ, H, L, D, 1, 1.0 / math.sqrt(D), yo, A)
+    ref = hp.profile(A, HYBRID, g, frac, S, "bfloat16")
+    del A
+    mine = kv.cache_strategies.cpu().tolist()
+    cts = kv.cache_cts.cpu().tolist()
+    pos = kv.pos.cpu()[0]
+    assert len(set(ref["strategies"].tolist())) >= 2, "the synthetic heads were meant to pick different policies"
+    checked = 0
+    for h in range(H):
+        near = [p for p in range(len(HYBRID)) if abs(float(ref["scores"][p, h]) - ref["threshold"]) <= 2 * BF16_ULP]
+        if mine[h] != int(ref["strategies"][h]):
+            # only a score within rounding of the threshold may tip a head to the neighbouring policy (cache.py:633-635 of ours)
+            assert near, f"head {h}: policy {mine[h]} vs {int(ref['strategies'][h])}, scores {ref['scores'][:, h]}"
+            continue
+        checked += 1
+        keep_ref = ref["mask_optimal"][h]
+        assert cts[h] == int(keep_ref.sum()), f"head {h}: {cts[h]} kept vs {int(keep_ref.sum())}"
+        kept = pos[h, :cts[h]]
+        assert bool((kept[1:] > kept[:-1]).all()) and bool((pos[h, cts[h]:] == -1).all())
+        mine_set = np.zeros(L, bool)
+        mine_set[kept.numpy()] = True
+        diff = mine_set ^ keep_ref
+        if diff.any():
+            # only heavy-hitter members at the k-th column mean may differ: ties (and values one bf16 step apart — the two
+            # sides round their fp32 column sums independently) are interchangeable
+            cols, win = ref["filling"][int(ref["strategies"][h])]
+            assert "heavy_hitter" in HYBRID[int(ref["strategies"][h])]["strategy"], f"head {h}: kept sets differ without a top-k"
+            cum = ref["cum_attn"][h]
+            static = hp.static_columns(HYBRID[int(ref["strategies"][h])]["strategy"], L, g, np.zeros(L, bool), np.zeros(L, bool))
+            hh_ref = keep_ref & ~static
+            hh_ref[max(0, L - win):] = False
+            vk = cum[hh_ref].min()  # the k-th largest column mean
+            lo, hi = vk * (1 - 2 * BF16_ULP), vk * (1 + 2 * BF16_ULP)
+            assert bool(((cum[diff] >= lo) & (cum[diff] <= hi)).all()), f"head {h}: a non-tie member differs"
+            assert diff.sum() <= 0.02 * keep_ref.sum() + 8, f"head {h}: {int(diff.sum())} members differ"
+    assert checked >= 2
+    # the attention output of the same pass, loosely: these heads have logits of magnitude ~40, where one bf16 step of a
+    # score (the reference rounds q.k to the model dtype, attention_utils.py:37) is 0.25 — a last-bit difference of the
+    # fp32 dot product moves a probability by a quarter.  The tight bound on y is test_prefill_bands_full_size's.
+    yr = from_np(yo, dtype).float()
+    assert (y.cpu().float()[0] - yr).abs().max() <= 0.05 * yr.abs().max()
+
+
+def test_heavy_hitter_prefill_to_decode_without_state_sync(oracle_mt):
+    """8192-token prompt -> SnapKV compaction to 4096 -> history from the column means -> 48 decode steps of the fused
+    step, device and oracle each continuing from THEIR OWN numeric state (nothing is copied across after the prompt's
+    keep set has been checked)."""
+    import cold_compress_amd.cache as cache
+    from cold_compress_amd.attention_utils import prefill_attention
+    from cold_compress_amd.prompt_compression import get_prompt_compressor_constructor
+
+    o = oracle_mt
+    L, S, H, R, D, g, w, dtype, steps = 8192, 4096, 2, 4, 128, 4, 10, torch.bfloat16, 48
+    HQ, code = H * R, 1
+    gen = torch.Generator().manual_seed(77)
+    q = (1.5 * torch.randn(1, HQ, L, D, generator=gen)).to(dtype)
+    k = (1.5 * torch.randn(1, H, L, D, generator=gen)).to(dtype)
+    v = torch.randn(1, H, L, D, generator=gen).to(dtype)
+    cls, rk = cache.get_cache_constructor("heavy_hitter")
+    kw = dict(max_cache_length=S, global_tokens=g, max_seq_length=L + 2048, cache_bits=None, recent_window=w, history_window_size=1,
+              attn_thresholding=False)
+    with torch.device(DEV):
+        kv = cls(1, H, D, dtype, **{x: kw[x] for x in rk})
+    comp = get_prompt_compressor_constructor("heavy_hitter")(head_specific=True, **{x: kw[x] for x in rk})
+    pos0 = torch.arange(L, device=DEV)
+    kd, vd = k.to(DEV), v.to(DEV)
+    y, summ = prefill_attention(q.to(DEV), kd, vd, return_attn=True)
+    keep, kc, vc, state = comp(pos0, kd, vd, attn=summ)
+    kv.update_kv(keep, kc, vc, True)
+    kv.update_state(keep, kc, vc, True, state)
+    torch.cuda.synchronize()
+    # ---- oracle: the same pipeline from the same inputs
+    yo, cs, ob = np.zeros((HQ, L, D), np.uint16), np.zeros((H, L), np.float32), np.zeros((H, L), np.float32)
+    o.call("cc_prefill_attn", o.ptr(to_np(q[0])), o.ptr(to_np(k[0])), o.ptr(to_np(v[0])), HQ, H, L, D, code, 1.0 / math.sqrt(D),
+           o.ptr(yo), o.ptr(cs), o.ptr(ob), 16, None, 0, None)
+    obs_dt = to_np(torch.from_numpy(ob).to(dtype))
+    prio = np.zeros((H, L), np.uint16)
+    o.call("cc_snapkv_priority", o.ptr(obs_dt), H, L, code, 16, g, o.ptr(prio), None)
+    keep_o = np.zeros((H, S), np.int64)
+    o.call("cc_topk_keep", o.ptr(prio), 1, H, L, S, o.ptr(keep_o), None, 0, None)
+    keep_d = keep.cpu().numpy().reshape(H, S)
+    pf = from_np(prio, dtype).float().numpy()
+    for h in range(H):  # tie contract of the keep set: members one bf16 step around the S-th priority may differ
+        a, b = set(keep_d[h].tolist()), set(keep_o[h].tolist())
+        if a != b:
+            kth = np.sort(pf[h])[-S]
+            d = np.array(sorted(a ^ b))
+            assert bool((np.abs(pf[h][d] - kth) <= 2 * BF16_ULP * abs(kth) + 1e-30).all()), f"head {h}: non-tie keep members differ"
+            assert len(d) <= 0.02 * S
+    # the oracle continues with the DEVICE's keep set (same cache contents) but its OWN column means
+    keep_use = np.ascontiguousarray(keep_d)
+    ko, vo = np.zeros((H, S, D), np.uint16), np.zeros((H, S, D), np.uint16)
+    o.call("cc_gather_rows", o.ptr(to_np(k[0])), o.ptr(keep_use), H, H, L, S, D, code, o.ptr(ko), None)
+    o.call("cc_gather_rows", o.ptr(to_np(v[0])), o.ptr(keep_use), H, H, L, S, D, code, o.ptr(vo), None)
+    assert np.array_equal(ko, to_np(kv.k_cache.cpu()[0]))
+    mean = np.zeros((H, L), np.uint16)
+    o.call("cc_colsum_to_mean", o.ptr(cs), None, H, L, code, o.ptr(mean), None)
+    st0 = np.zeros((H, S), np.uint16)
+    o.call("cc_gather_vec", o.ptr(mean), o.ptr(keep_use), H, L, S, code, o.ptr(st0), None)
+    st = dict(k=ko, v=vo, pos=keep_use.astype(np.int32).copy(), mask=np.ones((H, S), np.uint8), cts=np.array([S], np.int32),
+              num=np.zeros((H, S), np.float64), denom=np.zeros((H, S), np.int32), ctr=np.zeros(1, np.int64))
+    o.call("cc_hh_update", o.ptr(st["num"]), o.ptr(st["denom"]), o.ptr(st["ctr"]), o.ptr(st0), H, S, S, code, None)
+    num_d = kv.attn_history_num.cpu()[0, :, :, 0].numpy()
+    assert np.allclose(num_d, st["num"], rtol=2 * BF16_ULP, atol=1e-6), "prefill history beyond one rounding of the column means"
+    assert np.array_equal(kv.attn_history_denom.cpu()[0].numpy(), st["denom"])
+    # ---- decode: both sides on their own state; a differing eviction must be a near-tie in the ORACLE's scores, and is then
+    #      followed (the oracle is made to evict the device's slot) so that the caches stay comparable
+    justified = total = 0
+    for t in range(steps):
+        p = L + t
+        pt = torch.tensor([p], dtype=torch.int32)
+        k1 = (1.5 * torch.randn(1, H, 1, D, generator=gen)).to(dtype)
+        v1 = torch.randn(1, H, 1, D, generator=gen).to(dtype)
+        q1 = (1.5 * torch.randn(1, HQ, 1, D, generator=gen)).to(dtype)
+        pos_before = kv.pos.cpu()[0].numpy().copy()
+        yd = kv.decode_step(q1.to(DEV), k1.to(DEV), v1.to(DEV), pt.to(DEV))
+        torch.cuda.synchronize()
+        pos_after = kv.pos.cpu()[0].numpy()
+        idx_d = np.array([int(np.nonzero(pos_after[h] != pos_before[h])[0][0]) for h in range(H)])
+        # the oracle's scores for this position (cache.py:727-749)
+        dn = np.maximum(st["denom"], 1).astype(np.float32)
+        sc = (st["num"].astype(np.float32) / dn).astype(np.float32)
+        sc[(st["pos"] < g) | (st["pos"] >= p - w)] = 1.0
+        sc[st["pos"] == -1] = 0.0
+        idx_o = sc.argmin(axis=1)
+        for h in range(H):
+            total += 1
+            if idx_d[h] != idx_o[h]:
+                gap = float(sc[h, idx_d[h]] - sc[h, idx_o[h]])
+                assert 0 <= gap <= 2 * BF16_ULP * float(sc[h, idx_o[h]]) + 1e-12, f"step {t} head {h}: evicted {idx_d[h]} (score gap {gap})"
+                justified += 1
+                st["num"][h, idx_d[h]] = -1.0  # make the oracle follow the device's (equally good) choice
+        view = o.view(st["k"], st["v"], st["pos"], st["mask"], st["cts"], code)
+        idx = np.zeros(H, np.int64)
+        o.call("cc_decode_update_heavy_hitter", C.byref(view), o.ptr(to_np(k1.reshape(H, D))), o.ptr(to_np(v1.reshape(H, D))),
+               o.ptr(pt.numpy().copy()), o.ptr(st["num"]), o.ptr(st["denom"]), g, w, o.ptr(idx), None)
+        assert np.array_equal(idx, idx_d)
+        yo1 = np.zeros((HQ, D), np.uint16)
+        o.call("cc_decode_attn_gqa", o.ptr(to_np(q1.reshape(HQ, D))), o.ptr(st["k"]), o.ptr(st["v"]), o.ptr(st["mask"]), HQ, H, S, D, code,
+               1.0 / math.sqrt(D), o.ptr(yo1), None, None, o.ptr(st["num"]), o.ptr(st["denom"]), o.ptr(st["ctr"]), None, 0, None)
+        yr = from_np(yo1, dtype).float()
+        assert (yd.cpu().float()[0, :, 0] - yr).abs().max() <= 1e-3 + 2 * BF16_ULP * yr.abs().max(), f"step {t}: y"
+        assert np.array_equal(pos_after, st["pos"]), f"step {t}: positions"
+    assert justified <= 0.05 * total, f"{justified} of {total} evictions were near-tie divergences"
+    num_d = kv.attn_history_num.cpu()[0, :, :, 0].numpy()
+    assert np.array_equal(kv.attn_history_denom.cpu()[0].numpy(), st["denom"])
+    # drift of the float64 history after `steps` unsynchronised steps: each step adds one bf16-rounded probability per slot
+    assert np.allclose(num_d, st["num"], rtol=2 * BF16_ULP, atol=steps * 2.0 ** -16), float(np.abs(num_d - st["num"]).max())
+    assert np.array_equal(to_np(kv.k_cache.cpu()[0]), st["k"])
+    assert kv.step_status(HQ) == 0

@@ -95,8 +95,12 @@ def test_buffers_and_statistics_on_cpu():
     kv.cache_cts.fill_(10)
     st = kv.compute_statistics(torch.tensor(41))
     assert abs(st["compression_ratio"] - (40 - 10) / 40) < 1e-6
-    nbytes = sum(b.numel() * b.element_size() for b in kv.buffers())
+    # the reference's figure (cache.py:247-257): the cache's own state tensors; our non-persistent pipeline state
+    # (partial arg-min keys of the fused decode step) is not cache content
+    nbytes = sum(b.numel() * b.element_size() for n, b in kv.named_buffers() if n not in kv._non_persistent_buffers_set)
     assert abs(st["cache_memory_gb"] - nbytes / 2 ** 30) < 1e-12
+    ref_names = {"k_cache", "v_cache", "pos", "cache_cts", "mask", "attn_history_num", "attn_history_denom", "attn_counter"}
+    assert {n for n, _ in kv.named_buffers() if n not in kv._non_persistent_buffers_set} == ref_names
     kv.reset()
     assert int(kv.cache_cts[0]) == 0
     with pytest.raises(NotImplementedError):  # the reference itself crashes on this path
@@ -197,3 +201,30 @@ def test_oracle_glue_twins_match_torch_cpu(oracle):
     probs, idx = np.zeros(1000, np.float32), np.zeros(1, np.int32)
     o.call("cc_softmax_argmax", f(logits), 1000, 0, o.ptr(probs), o.ptr(idx), None, 0, None)
     assert np.allclose(probs, torch.softmax(logits, -1).numpy(), rtol=1e-5, atol=1e-8) and int(idx[0]) == 17
+
+
+def test_attn_summary_runs_reference_group_mean_unchanged():
+    """model.py:413-418 of the reference, verbatim call sequence, on the prefill kernel's AttnSummary: both for a
+    GQA-shaped kernel call (summary already per kv head) and for pre-repeated K/V (one row per query head)."""
+    from cold_compress_amd._abi import ColdCompressError
+    from cold_compress_amd.prompt_compression import AttnSummary
+
+    bsz, n_local_heads, n_head, seqlen = 1, 2, 8, 12
+    g = torch.Generator().manual_seed(0)
+    for rows in (n_local_heads, n_head):
+        colsum, obs = torch.rand(rows, seqlen, generator=g), torch.rand(rows, seqlen, generator=g)
+        attn = AttnSummary(colsum, obs, 4, torch.bfloat16, {3: torch.rand(rows, seqlen, generator=g)})
+        assert attn is not None and attn.ndim == 4
+        attn2 = attn.view(bsz, n_local_heads, n_head // n_local_heads, seqlen, -1).mean(dim=2)  # the reference's two lines
+        assert isinstance(attn2, AttnSummary) and attn2.colsum.shape == (n_local_heads, seqlen)
+        if rows == n_local_heads:
+            assert attn2 is attn
+        else:
+            R = n_head // n_local_heads
+            assert torch.allclose(attn2.colsum, colsum.view(n_local_heads, R, seqlen).mean(1))
+            assert torch.allclose(attn2.obs_mean, obs.view(n_local_heads, R, seqlen).mean(1))
+            assert set(attn2.bands) == {3} and attn2.bands[3].shape == (n_local_heads, seqlen)
+    with pytest.raises(ColdCompressError):
+        attn.view(bsz, 3, 2, seqlen, -1)
+    with pytest.raises(ColdCompressError):
+        attn.view(bsz, n_local_heads, 4, seqlen, -1).mean(dim=1)

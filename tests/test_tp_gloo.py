@@ -9,6 +9,9 @@ state needs no exchange (every buffer is indexed by kv head), which the GPU pari
 """
 import os
 import socket
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))  # spawned workers import tests/host_glue.py
 
 import torch
 import torch.distributed as dist
@@ -59,7 +62,9 @@ def _worker(rank, world, port, q):
 
         assert tp.maybe_init_dist() == rank and dist.get_backend() == "gloo"
         hm.scaled_dot_product_attention = _attention_double
-        hm.glue.HOST_EAGER_FOR_TESTS = True  # CPU tensors: model wiring only, with the test-local attention double
+        import host_glue
+
+        host_glue.install(hm.glue)  # CPU tensors: model wiring only, with test-local glue and attention doubles
         torch.manual_seed(0)
         cfg = dict(block_size=64, vocab_size=64, n_layer=2, n_head=8, n_local_heads=4, dim=64, intermediate_size=96)
         full = Transformer(ModelArgs(**cfg)).eval()

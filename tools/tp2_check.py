@@ -1,8 +1,14 @@
 #!/usr/bin/env python3
-"""TP = 2 on ONE GPU: both ranks drive cuda:0, collectives go through gloo (staged over the host) — no RCCL, but every
-kernel of the sharded decode path (4 kv heads per rank, row / column sliced GEMVs, the two all-reduces per layer) runs
-for real and is compared against the unsharded model on the same weights.
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29541 tools/tp2_check.py"""
+"""The tensor-parallel PRODUCT path (cache + attention kernels under cold_compress_amd.tp) at TP = N against the unsharded
+model on the same weights: tokens equal, layer-0 evictions identical.
+
+  --backend nccl  : one GPU per rank, RCCL all-reduces over xGMI (what tp.py:41-56, 124-176 does with NCCL); with --graph
+                    the sharded decode step, collectives included, is replayed from a hipGraph
+  --backend gloo  : every rank drives cuda:0 and the collectives are staged over the host — no RCCL, but every kernel of
+                    the sharded decode path runs for real (what a 1-GPU box can check)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29541 \
+        tools/tp2_check.py [--backend nccl --graph]"""
+import argparse
 import copy
 import os
 import sys
@@ -16,21 +22,33 @@ from cold_compress_amd.harness import CONFIGS, ModelArgs, Transformer, decode_on
 
 
 def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--backend", choices=["gloo", "nccl"], default="gloo")
+    ap.add_argument("--graph", action="store_true", help="replay the sharded decode step from a hipGraph (collectives captured)")
+    args = ap.parse_args()
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    torch.cuda.set_device(0)
-    dev = torch.device("cuda", 0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    orig = dist.all_reduce
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if args.backend == "nccl":
+        assert torch.cuda.device_count() >= world, f"{world} ranks need {world} GPUs (found {torch.cuda.device_count()})"
+        torch.cuda.set_device(rank)
+        dev = torch.device("cuda", rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        assert dist.get_backend() == "nccl" and dist.get_world_size() == world
+    else:
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        orig = dist.all_reduce
 
-    def staged(t, op=dist.ReduceOp.SUM, **kw):  # gloo without device support: sum on the host in fp32, round once
-        if t.is_cuda:
-            c = t.float().cpu()
-            orig(c, op=op)
-            t.copy_(c.to(t.dtype))
-            return None
-        return orig(t, op=op, **kw)
+        def staged(t, op=dist.ReduceOp.SUM, **kw):  # gloo without device support: sum on the host in fp32, round once
+            if t.is_cuda:
+                c = t.float().cpu()
+                orig(c, op=op)
+                t.copy_(c.to(t.dtype))
+                return None
+            return orig(t, op=op, **kw)
 
-    dist.all_reduce = staged
+        dist.all_reduce = staged
     cfg = dict(CONFIGS["Meta-Llama-3.1-8B-Instruct"])
     cfg["n_layer"] = 2
     cfg["block_size"] = 1024
@@ -56,9 +74,14 @@ def main():
             pos = torch.tensor([300], dtype=torch.int32, device=dev)
             toks, plist = [int(tok)], [probs.float().clone()]
             cur = tok.view(1, 1).to(torch.int32)
+            step = decode_one_token
+            if args.graph and name == "tp2":
+                from cold_compress_amd.harness import GraphedDecoder
+
+                step = GraphedDecoder(model)  # capture fails loudly if a collective cannot be captured
             for _ in range(12):
                 # teacher-force the unsharded model's tokens so that both runs see the same inputs
-                nt, pr = decode_one_token(model, cur, pos)
+                nt, pr = step(model, cur, pos)
                 plist.append(pr.float().clone())
                 toks.append(int(nt))
                 cur = (nt if name == "tp1" else torch.tensor(outs[0][0][len(toks) - 1], device=dev)).view(1, 1).to(torch.int32)
@@ -83,7 +106,8 @@ def main():
     # rounded differently by the all-reduce, and heavy-hitter scores of random data sit in near-ties
     ok = ok and agree[0] == 1.0 and same_tokens >= len(outs[0][0]) - 1
     if rank == 0:
-        print(f"tokens equal: {same_tokens}/{len(outs[0][0])}; TP2 CHECK {'OK' if ok else 'FAIL'}", flush=True)
+        print(f"backend {dist.get_backend()} world {world} graph {bool(args.graph)}: tokens equal: {same_tokens}/{len(outs[0][0])}; "
+              f"TP{world} CHECK {'OK' if ok else 'FAIL'}", flush=True)
     dist.destroy_process_group()
     sys.exit(0 if ok else 1)
 
