@@ -71,6 +71,7 @@ SIGNATURES = {
     "cc_decode_step_single_launch": (_i32, [_i32, _i32, _i32, _i32, _i32]),
     "cc_decode_step_status_offset": (_i32, []),
     "cc_decode_step_trace": (None, [_vp]),
+    "cc_decode_step_set_single_launch": (None, [_i32]),
     "cc_rg_next_key_init": (C.c_int, [_view, _vp, _i32, _vp, _vp]),
     "cc_decode_step_recent_global": (C.c_int, [_view, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _sz, _vp]),
     "cc_hh_ring_next_key_init": (C.c_int, [_view, _vp, _vp, _i32, _vp, _i32, _i32, _vp, _vp]),
@@ -115,7 +116,7 @@ SIGNATURES = {
 
 # entry points that only the device library has (no `_cpu` twin)
 DEVICE_ONLY = {"cc_error_string", "cc_device_info", "cc_decode_step_single_launch", "cc_decode_step_status_offset",
-               "cc_decode_step_trace"}
+               "cc_decode_step_trace", "cc_decode_step_set_single_launch"}
 CC_PHASE_TWO_LAUNCH, CC_PHASE_ONE_LAUNCH = 0x10000, 0x20000
 
 

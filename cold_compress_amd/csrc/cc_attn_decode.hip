@@ -170,6 +170,8 @@ struct SplitArgs {
   void* attn_out;     // [H, S] T or null
   int64_t* hh_counter;
   int g, w;           // global_tokens, recent_window of the next-eviction score
+  int policy;         // 1 = heavy hitter (history in num / denom), 2 = recent_global / full, 3 = random (head-constant: no history)
+  const float* rand_next;  // policy 3: [S] uniform draws for position p + 1
   int yc_chunks;      // grid.x of the two-launch combine pass (unused)
   unsigned long long* trace;  // measurement only (cc_decode_step_trace): [workgroup][16] time stamps and hardware ids
 };
@@ -500,8 +502,8 @@ constexpr int kOneAuxCoherent = 17;         // sc0 sc1: write-through stores / l
 // step of the heavy-hitter policy (needs R == RT, one tile per wave, every workgroup of the grid co-resident).
 template <typename T, int RT, int NW, bool L2, bool ONE = false>
 __global__ __launch_bounds__(NW * 64, ONE ? 2 : 1) void decode_attn_split_mfma_kernel(SplitArgs a) {
-  static_assert(sizeof(T) == 2 && (RT == 1 || RT == 2 || RT == 4), "16-bit caches, up to 4 query heads per pass");
-  static_assert(!(ONE && L2) && (!ONE || NW == 4), "the single-launch step is the heavy-hitter policy on 4-wave workgroups");
+  static_assert(sizeof(T) == 2 && (RT == 1 || RT == 2 || RT == 4 || RT == 8), "16-bit caches, up to 8 query heads per pass (the MFMA has 16 columns)");
+  static_assert(!(ONE && L2) && (!ONE || NW == 4), "the single-launch step runs on 4-wave workgroups; l2 needs a cross-head maximum");
   constexpr int D = 128, VEC = 8, RPW = 4, U = 4;
   if (a.ring_col && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0)
     *a.ring_col = (int)(*a.ring_counter % a.ring_W);
@@ -550,8 +552,8 @@ __global__ __launch_bounds__(NW * 64, ONE ? 2 : 1) void decode_attn_split_mfma_k
       key_part = x < key_part ? x : key_part;
     }
   }
-  // ONE: this lane's slot of the per-slot pass (lane c = t * RT of row group g finishes row 4g + t of the wave's tile): its
-  // history and position are requested here, with everything else, and consumed after the hand-off
+  // ONE: this lane's slot of the per-slot pass (lane c = t * LPR of row group g finishes row 4g + t of the wave's tile): its
+  // history and position are requested behind the first K/V tile and consumed after the hand-off
   unsigned long long tr0 = 0, tr1 = 0, tr2 = 0, tr3 = 0, tr4 = 0, rt0 = 0, rt1 = 0;
   if constexpr (ONE) {
     if (a.trace) {
@@ -562,8 +564,10 @@ __global__ __launch_bounds__(NW * 64, ONE ? 2 : 1) void decode_attn_split_mfma_k
   unsigned one_tag = 0;
   double one_num = 0.0;
   int32_t one_den = 0, one_ps = 0, one_pin = 0;
-  const int one_slot = row_begin + wave * (RPW * U) + g * U + c / RT;
-  const bool one_have = ONE && c < U * RT && (c % RT) == 0 && one_slot < row_end;
+  constexpr int LPR = RT < 4 ? RT : 4;  // lanes per tile row in the per-slot pass; each computes KH = RT / LPR probabilities
+  constexpr int KH = RT / LPR;
+  const int one_slot = row_begin + wave * (RPW * U) + g * U + c / LPR;
+  const bool one_have = ONE && c < U * LPR && (c % LPR) == 0 && one_slot < row_end;
   if constexpr (ONE) {
     one_tag = a.one_hdr[h] + 1u;
     one_pin = *a.input_pos;
@@ -608,11 +612,15 @@ __global__ __launch_bounds__(NW * 64, ONE ? 2 : 1) void decode_attn_split_mfma_k
     issue_k(base);
     issue_v(base);
   }
+  float one_rnd = 0.f;
   if constexpr (ONE) {  // behind the K/V requests: nothing on the streaming path waits for these
     if (one_have) {
-      one_num = a.num[(size_t)h * S + one_slot];
-      one_den = a.denom[(size_t)h * S + one_slot];
-      one_ps = a.pos[(size_t)h * S + one_slot];
+      if (a.num) {
+        one_num = a.num[(size_t)h * S + one_slot];
+        one_den = a.denom[(size_t)h * S + one_slot];
+      }
+      one_ps = a.pos[(a.Hp == 1 ? 0 : (size_t)h * S) + one_slot];
+      if (a.policy == 3) one_rnd = a.rand_next[one_slot];
     }
   }
 
@@ -835,9 +843,8 @@ __global__ __launch_bounds__(NW * 64, ONE ? 2 : 1) void decode_attn_split_mfma_k
     const auto o_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.one_o, 0, (int)a.one_o_bytes, 0x00020000);
     // ---- publish: thread t merges output columns 2t, 2t + 1 of the workgroup's partial (the arithmetic of the
     //      two-launch epilogue below) and stores them as one granule
-    {
-      const int o2 = (int)threadIdx.x * 2;
-      if (o2 < RT * D) {
+    for (int o2 = (int)threadIdx.x * 2; o2 < RT * D; o2 += 2 * NW * 64) {
+      {
         const int r = o2 / D, d = o2 - r * D;
         float M = sm_wm[0][r];
 #pragma unroll
@@ -866,11 +873,15 @@ __global__ __launch_bounds__(NW * 64, ONE ? 2 : 1) void decode_attn_split_mfma_k
     const int pair0 = split * ppw;
     int n_pairs = RT * 64 - pair0;
     n_pairs = n_pairs < 0 ? 0 : (n_pairs > ppw ? ppw : n_pairs);
-    const int ml_off = ((h * ns + (lane < ns ? lane : 0)) * RT + (wave < RT ? wave : 0)) * 16;
-    int o_off[2], o_lds[2];
-    bool o_use[2];
+    constexpr int MLN = (RT + NW - 1) / NW;            // (m, l) granules per thread: wave w collects heads w, w + NW, ...
+    constexpr int NOG = (RT * 64 + 64 + NW * 64 - 1) / (NW * 64);  // O granules per thread
+    int ml_off[MLN];
 #pragma unroll
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < MLN; k++) ml_off[k] = ((h * ns + (lane < ns ? lane : 0)) * RT + (wave + k * NW < RT ? wave + k * NW : 0)) * 16;
+    int o_off[NOG], o_lds[NOG];
+    bool o_use[NOG];
+#pragma unroll
+    for (int k = 0; k < NOG; k++) {
       const int item = (int)threadIdx.x + k * NW * 64;
       const int i = item / ppw, qq = item - i * ppw;
       o_use[k] = item < n_items && qq < n_pairs;
@@ -895,14 +906,17 @@ __global__ __launch_bounds__(NW * 64, ONE ? 2 : 1) void decode_attn_split_mfma_k
       __syncthreads();
     }
     if (a.trace) tr3 = __builtin_amdgcn_s_memtime();
-    u32x4_t mlq, oq[2];
+    u32x4_t mlq[MLN], oq[NOG];
     for (unsigned spins = 0;; spins++) {
-      mlq = __builtin_amdgcn_raw_buffer_load_b128(ml_rsrc, ml_off, 0, kOneAuxCoherent);
 #pragma unroll
-      for (int k = 0; k < 2; k++) oq[k] = __builtin_amdgcn_raw_buffer_load_b128(o_rsrc, o_off[k], 0, kOneAuxCoherent);
-      bool ok = mlq[0] == tag && mlq[2] == tag;
+      for (int k = 0; k < MLN; k++) mlq[k] = __builtin_amdgcn_raw_buffer_load_b128(ml_rsrc, ml_off[k], 0, kOneAuxCoherent);
 #pragma unroll
-      for (int k = 0; k < 2; k++) ok = ok && (!o_use[k] || (oq[k][0] == tag && oq[k][2] == tag));
+      for (int k = 0; k < NOG; k++) oq[k] = __builtin_amdgcn_raw_buffer_load_b128(o_rsrc, o_off[k], 0, kOneAuxCoherent);
+      bool ok = true;
+#pragma unroll
+      for (int k = 0; k < MLN; k++) ok = ok && mlq[k][0] == tag && mlq[k][2] == tag;
+#pragma unroll
+      for (int k = 0; k < NOG; k++) ok = ok && (!o_use[k] || (oq[k][0] == tag && oq[k][2] == tag));
       if (__all(ok)) break;
       if (spins > kOneSpinMax) {
         timed_out = true;
@@ -912,25 +926,29 @@ __global__ __launch_bounds__(NW * 64, ONE ? 2 : 1) void decode_attn_split_mfma_k
     }
     if (a.trace) tr4 = __builtin_amdgcn_s_memtime();
     if (timed_out && lane == 0) a.one_hdr[kOneStatusWordDev] = 1u;  // this launch's results are invalid; the host reads the word
-    // ---- final (M, L) of query head r = wave: decode_attn_combine_kernel's order (lane = split, n_split <= 64)
-    if (wave < RT) {
-      const float mi = lane < ns ? __uint_as_float(mlq[1]) : -INFINITY;
-      const float M = wave_max_uniform(mi);
-      const float Mu = (M == -INFINITY) ? 0.f : M;
-      float L = 0.f;
-      if (lane < ns) {
-        const float wgt = exp_nonpos(mi - Mu);
-        sm_w1[wave][lane] = wgt;
-        L = __uint_as_float(mlq[3]) * wgt;
-      }
-      L = wave_sum_uniform(L);
-      if (lane == 0) {
-        sm_M1[wave] = Mu;
-        sm_L1[wave] = L;
+    // ---- final (M, L) of query heads r = wave, wave + NW, ...: decode_attn_combine_kernel's order (lane = split, n_split <= 64)
+#pragma unroll
+    for (int k = 0; k < MLN; k++) {
+      const int rr = wave + k * NW;
+      if (rr < RT) {
+        const float mi = lane < ns ? __uint_as_float(mlq[k][1]) : -INFINITY;
+        const float M = wave_max_uniform(mi);
+        const float Mu = (M == -INFINITY) ? 0.f : M;
+        float L = 0.f;
+        if (lane < ns) {
+          const float wgt = exp_nonpos(mi - Mu);
+          sm_w1[rr][lane] = wgt;
+          L = __uint_as_float(mlq[k][3]) * wgt;
+        }
+        L = wave_sum_uniform(L);
+        if (lane == 0) {
+          sm_M1[rr] = Mu;
+          sm_L1[rr] = L;
+        }
       }
     }
 #pragma unroll
-    for (int k = 0; k < 2; k++)
+    for (int k = 0; k < NOG; k++)
       if (o_use[k]) *reinterpret_cast<float2*>(&sm_o1[o_lds[k]]) = make_float2(__uint_as_float(oq[k][1]), __uint_as_float(oq[k][3]));
     __syncthreads();
     // ---- y: per output column, G1 strided chains over the splits ...
@@ -948,30 +966,43 @@ __global__ __launch_bounds__(NW * 64, ONE ? 2 : 1) void decode_attn_split_mfma_k
     //      dtype; cache.py:716-722 history; cache.py:727-749 the next position's eviction score
     unsigned long long my_key = ~0ull;
     {
-      // lane c of a row group computes ONE probability, of (row t = c / RT, head r = c % RT) — 16 lanes x 1 exp + 1
-      // IEEE divide instead of 4 lanes x 4; the score of (row t, head r) sits in lane r of the group as s_keep[t]
-      const int t_me = c / RT, r_me = c % RT;
-      const int src = (lane & ~15) | r_me;
-      float x = -INFINITY;
+      float av = 0.f;
+      if (a.num) {  // heavy hitter: the group-mean probability of this lane's row (the head-constant policies keep no history)
+        // lane c of a row group computes the probabilities of row t = c / LPR for heads (c % LPR) * KH + [0, KH) — one exp and one
+        // IEEE divide per (row, head), spread over the 16 lanes; the score of (row t, head r) sits in lane r of the group as
+        // s_keep[t].  The group mean adds the heads in order r = 0 .. RT - 1, like the combine pass.
+        const int t_me = c / LPR, j_me = c % LPR;
+        float pr[KH];
 #pragma unroll
-      for (int t = 0; t < U; t++) {
-        const float v = __shfl(s_keep[t], src, CC_WAVE);
-        x = (t == t_me) ? v : x;
+        for (int kk = 0; kk < KH; kk++) {
+          const int r_me = j_me * KH + kk;
+          const int src = (lane & ~15) | r_me;
+          float x = -INFINITY;
+#pragma unroll
+          for (int t = 0; t < U; t++) {
+            const float v = __shfl(s_keep[t], src, CC_WAVE);
+            x = (t == t_me) ? v : x;
+          }
+          pr[kk] = ElemTraits<T>::rnd(__fdiv_rn(exp_nonpos(x - sm_M1[r_me]), sm_L1[r_me]));
+        }
+        float sum = 0.f;
+        if constexpr (LPR == 4) {
+#pragma unroll
+          for (int kk = 0; kk < KH; kk++) sum += dpp_mov<0x00>(pr[kk]);
+#pragma unroll
+          for (int kk = 0; kk < KH; kk++) sum += dpp_mov<0x55>(pr[kk]);
+#pragma unroll
+          for (int kk = 0; kk < KH; kk++) sum += dpp_mov<0xAA>(pr[kk]);
+#pragma unroll
+          for (int kk = 0; kk < KH; kk++) sum += dpp_mov<0xFF>(pr[kk]);
+        } else if constexpr (LPR == 2) {
+          sum += dpp_mov<0xA0>(pr[0]);  // quad_perm [0, 0, 2, 2]
+          sum += dpp_mov<0xF5>(pr[0]);  // quad_perm [1, 1, 3, 3]
+        } else {
+          sum += pr[0];
+        }
+        av = ElemTraits<T>::rnd(__fdiv_rn(sum, (float)RT));
       }
-      const float pr = ElemTraits<T>::rnd(__fdiv_rn(exp_nonpos(x - sm_M1[r_me]), sm_L1[r_me]));
-      float sum = 0.f;  // over the heads of the group in order, like the combine pass: lanes t * RT + (0 .. RT)
-      if constexpr (RT == 4) {
-        sum += dpp_mov<0x00>(pr);
-        sum += dpp_mov<0x55>(pr);
-        sum += dpp_mov<0xAA>(pr);
-        sum += dpp_mov<0xFF>(pr);
-      } else if constexpr (RT == 2) {
-        sum += dpp_mov<0xA0>(pr);  // quad_perm [0, 0, 2, 2]
-        sum += dpp_mov<0xF5>(pr);  // quad_perm [1, 1, 3, 3]
-      } else {
-        sum += pr;
-      }
-      const float av = ElemTraits<T>::rnd(__fdiv_rn(sum, (float)RT));
       if (one_have) {
         const size_t i = (size_t)h * S + one_slot;
         int32_t ps = one_ps;
@@ -982,16 +1013,29 @@ __global__ __launch_bounds__(NW * 64, ONE ? 2 : 1) void decode_attn_split_mfma_k
           num_old = 0.0;
           den_old = 0;
         }
-        if (a.attn_out) ElemTraits<T>::store(reinterpret_cast<T*>(a.attn_out), i, av);
-        const double num_new = num_old + (double)av;
-        const int32_t den_new = den_old + 1;
-        a.num[i] = num_new;
-        a.denom[i] = den_new;
         const int32_t p_next = one_pin + 1;
-        float scn = __fdiv_rn((float)num_new, (float)(den_new < 1 ? 1 : den_new));
-        if (ps < a.g || ps >= p_next - a.w) scn = 1.0f;
-        if (ps == -1) scn = 0.0f;
-        my_key = make_key(orderable_f32(scn), ((uint32_t)one_slot << 1) | (uint32_t)(ps == -1));
+        const uint32_t low = ((uint32_t)one_slot << 1) | (uint32_t)(ps == -1);
+        if (a.num) {
+          if (a.attn_out) ElemTraits<T>::store(reinterpret_cast<T*>(a.attn_out), i, av);
+          const double num_new = num_old + (double)av;
+          const int32_t den_new = den_old + 1;
+          a.num[i] = num_new;
+          a.denom[i] = den_new;
+          float scn = __fdiv_rn((float)num_new, (float)(den_new < 1 ? 1 : den_new));
+          if (ps < a.g || ps >= p_next - a.w) scn = 1.0f;
+          if (ps == -1) scn = 0.0f;
+          my_key = make_key(orderable_f32(scn), low);
+        } else if (h == 0) {  // head-constant policies: one key row, scored by the workgroups of kv head 0
+          if (a.policy == 2) {  // ref: cache.py:500-502, 552-556 — arg-min of pos behind the sinks; -1 = empty first
+            if (one_slot >= a.g) my_key = make_key(orderable_i32(ps), low);
+          } else {  // random, ref: cache.py:523 recent window -> +inf, then the base rules :373-376
+            float scn = one_rnd;
+            if (ps >= p_next - a.w) scn = INFINITY;
+            if (one_slot < a.g) scn = INFINITY;
+            if (ps == -1) scn = -INFINITY;
+            my_key = make_key(orderable_f32(scn), low);
+          }
+        }
       }
     }
     {
@@ -1009,9 +1053,11 @@ __global__ __launch_bounds__(NW * 64, ONE ? 2 : 1) void decode_attn_split_mfma_k
       unsigned long long bk = sm_key1[0];
 #pragma unroll
       for (int w2 = 1; w2 < NW; w2++) bk = sm_key1[w2] < bk ? sm_key1[w2] : bk;
-      unsigned long long* nk_row = const_cast<unsigned long long*>(a.next_key) + (size_t)h * a.nk;
-      nk_row[split] = bk;  // every key of this head was consumed before its owner published: no reader is left
-      for (int s2 = split + ns; s2 < a.nk; s2 += ns) nk_row[s2] = ~0ull;
+      if (a.Hp != 1 || h == 0) {
+        unsigned long long* nk_row = const_cast<unsigned long long*>(a.next_key) + (a.Hp == 1 ? 0 : (size_t)h * a.nk);
+        nk_row[split] = bk;  // every key of this row was consumed before its readers published: no reader is left
+        for (int s2 = split + ns; s2 < a.nk; s2 += ns) nk_row[s2] = ~0ull;
+      }
       if (split == 0) {
         a.one_hdr[h] = tag;  // all n_split workgroups of this head have published, hence read the old epoch
         if (h == 0 && a.hh_counter) *a.hh_counter += 1;
@@ -1429,6 +1475,9 @@ static Plan make_plan(int HQ, int H, int S, int D, int dtype) {
   Plan p;
   const int R = HQ / H;
   p.rt = (R % 4 == 0) ? 4 : (R % 2 == 0) ? 2 : 1;
+  // the matrix-core streaming pass has 16 score columns: 8 query heads per pass read K and V ONCE for a group of 8 (Llama-3
+  // 70B: HQ / H = 8; with 4 per pass every K / V row was streamed twice)
+  if (R % 8 == 0 && cc_dt_size(dtype) == 2 && D == 128) p.rt = 8;
   const int rpi = rows_per_iter(D, dtype);
   // ~512 workgroups (two per CU, all resident at once): one tile per workgroup up to S = 64 * 64 rows per kv
   // head at 8 kv heads, MORE TILES PER WORKGROUP beyond that — the loop prefetches the next tile behind the
@@ -1473,12 +1522,14 @@ static int launch_split(const SplitArgs& a, const Plan& p, int H, int R, int D, 
       dim3 grid(p.n_split, H, R / p.rt), block(kNW * 64);
       if (a.key_norm != nullptr) {
         switch (p.rt) {
+          case 8: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 8, kNW, true>), grid, block, 0, st, a); break;
           case 4: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 4, kNW, true>), grid, block, 0, st, a); break;
           case 2: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 2, kNW, true>), grid, block, 0, st, a); break;
           default: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 1, kNW, true>), grid, block, 0, st, a); break;
         }
       } else {
         switch (p.rt) {
+          case 8: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 8, kNW, false>), grid, block, 0, st, a); break;
           case 4: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 4, kNW, false>), grid, block, 0, st, a); break;
           case 2: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 2, kNW, false>), grid, block, 0, st, a); break;
           default: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 1, kNW, false>), grid, block, 0, st, a); break;
@@ -1488,6 +1539,7 @@ static int launch_split(const SplitArgs& a, const Plan& p, int H, int R, int D, 
       return CC_OK;
     }
   }
+  if (p.rt > 4) return CC_ERR_UNSUPPORTED;  // 8 heads per pass exist on the matrix-core path only (reached here only by the measurement switch)
   switch (D) {
     case 16: return launch_split_rt<T, 16>(a, p, H, R, st);
     case 32: return launch_split_rt<T, 32>(a, p, H, R, st);
@@ -1541,6 +1593,7 @@ static int one_capacity(KernelT kernel) {
 template <typename T>
 static int one_capacity_rt(int rt) {
   switch (rt) {
+    case 8: return one_capacity(decode_attn_split_mfma_kernel<T, 8, kNW, false, true>);
     case 4: return one_capacity(decode_attn_split_mfma_kernel<T, 4, kNW, false, true>);
     case 2: return one_capacity(decode_attn_split_mfma_kernel<T, 2, kNW, false, true>);
     default: return one_capacity(decode_attn_split_mfma_kernel<T, 1, kNW, false, true>);
@@ -1550,6 +1603,7 @@ template <typename T>
 static int launch_one(const SplitArgs& a, const Plan& p, int H, hipStream_t st) {
   dim3 grid(p.n_split, H, 1), block(kNW * 64);
   switch (p.rt) {
+    case 8: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 8, kNW, false, true>), grid, block, 0, st, a); break;
     case 4: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 4, kNW, false, true>), grid, block, 0, st, a); break;
     case 2: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 2, kNW, false, true>), grid, block, 0, st, a); break;
     default: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 1, kNW, false, true>), grid, block, 0, st, a); break;
@@ -1580,6 +1634,9 @@ int32_t cc_decode_step_status_offset(void) { return kOneStatusWord * (int32_t)si
 static void* g_one_trace = nullptr;
 void cc_decode_step_trace(void* buf) { g_one_trace = buf; }
 
+static int g_one_enabled = 1;
+void cc_decode_step_set_single_launch(int32_t enabled) { g_one_enabled = enabled ? 1 : 0; }
+
 }  // extern "C"
 
 namespace {
@@ -1603,6 +1660,10 @@ struct RingHistory {
   float* wsum;
 };
 }  // namespace
+
+// the single-launch tail computes probabilities only where a history consumes them: a group-mean output without one
+// needs the two-launch step
+static bool attn_out_needs_probs(const FusedStep* fs, const void* attn_out) { return attn_out != nullptr && fs && fs->policy != 1; }
 
 static int attn_impl(const void* q, const void* k, const void* v, const uint8_t* mask, int32_t HQ, int32_t H,
                      int32_t S, int32_t D, int32_t dtype, float scale, void* y, void* attn_out,
@@ -1650,8 +1711,10 @@ static int attn_impl(const void* q, const void* k, const void* v, const uint8_t*
   // ---- single-launch layer step (heavy hitter, W == 1): phases bit CC_PHASE_ONE_LAUNCH forces it (error if the shape or
   //      the device's residency does not allow it), CC_PHASE_TWO_LAUNCH forbids it; otherwise it is used whenever it can be
   const bool one_asked = (phases & CC_PHASE_ONE_LAUNCH) != 0;
-  if (one_asked || ((phases & 3) == 3 && !(phases & CC_PHASE_TWO_LAUNCH))) {
-    const bool one_ok = fs && fs->policy == 1 && !rh && !probs_out && hh_num && hh_denom && fs->c->Hp == H &&
+  if (one_asked || (g_one_enabled && (phases & 3) == 3 && !(phases & CC_PHASE_TWO_LAUNCH))) {
+    const bool policy_ok = fs && ((fs->policy == 1 && hh_num && hh_denom && fs->c->Hp == H) ||
+                                  ((fs->policy == 2 || (fs->policy == 3 && fs->rand_next)) && !hh_num && fs->c->Hp == 1));
+    const bool one_ok = policy_ok && !rh && !probs_out && !attn_out_needs_probs(fs, attn_out) &&
                         cc_decode_step_single_launch(HQ, H, S, D, dtype) == 1;
     if (one_asked && !one_ok) return CC_ERR_UNSUPPORTED;
     if (one_ok) {
@@ -1663,6 +1726,7 @@ static int attn_impl(const void* q, const void* k, const void* v, const uint8_t*
       sa.one_o_bytes = (unsigned)kOneOCap;
       sa.trace = reinterpret_cast<unsigned long long*>(g_one_trace);
       sa.y = y; sa.attn_out = attn_out; sa.hh_counter = hh_counter; sa.g = fs->g; sa.w = fs->w; sa.yc_chunks = p.n_chunks;
+      sa.policy = fs->policy; sa.rand_next = fs->rand_next;
       return dtype == CC_DT_BF16 ? launch_one<bf16_t>(sa, p, H, st) : launch_one<f16_t>(sa, p, H, st);
     }
   }

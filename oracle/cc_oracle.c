@@ -202,12 +202,22 @@ int cc_abi_version_cpu(void) { return CC_ABI_VERSION; }
  * raises it to the host's core count).  Returns the previous maximum. */
 #ifdef _OPENMP
 #include <omp.h>
+/* team size for a loop of n independent iterations: never more threads than iterations (an over-sized team spends its time
+ * in the barrier: 256 threads on an 8- or 32-iteration loop measured 18x SLOWER than one thread) */
+static int team(int n) {
+  const int m = omp_get_max_threads();
+  return n < m ? (n > 0 ? n : 1) : m;
+}
 int cc_oracle_set_threads(int n) {
   const int old = omp_get_max_threads();
   if (n > 0) omp_set_num_threads(n);
   return old;
 }
 #else
+static int team(int n) {
+  (void)n;
+  return 1;
+}
 int cc_oracle_set_threads(int n) {
   (void)n;
   return 1;
@@ -338,7 +348,7 @@ int cc_decode_update_heavy_hitter_cpu(const cc_kv_view* c, const void* k_new, co
   const int32_t p = *input_pos;
   /* heads are independent (cache.py:725-765): one OpenMP thread per head when built with -fopenmp (bench.py's CPU
    * baseline); the result does not depend on the thread count */
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(team(c->H))
   for (int h = 0; h < c->H; h++) {
     float* sc = (float*)malloc(sizeof(float) * (size_t)c->S);
     const int32_t* pos = c->pos + (size_t)h * c->S;
@@ -407,7 +417,7 @@ int cc_decode_attn_gqa_cpu(const void* q, const void* k, const void* v, const ui
    * CPU baseline runs this with OMP_NUM_THREADS = nproc), then over the kv heads for the group mean / history.  Each
    * value is computed by exactly one thread with the same arithmetic: results do not depend on the thread count. */
   float* Pall = (float*)malloc(sizeof(float) * (size_t)HQ * S);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(team(HQ))
   for (int j = 0; j < HQ; j++) {
     const int h = j / R;
     float* P = Pall + (size_t)(j - h * R) * S + (size_t)h * R * S;
@@ -444,7 +454,7 @@ int cc_decode_attn_gqa_cpu(const void* q, const void* k, const void* v, const ui
     }
     free(sc);
   }
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(team(H))
   for (int h = 0; h < H; h++) {
     const float* P = Pall + (size_t)h * R * S;
     if (attn_out || hh_num) {
@@ -626,7 +636,14 @@ size_t cc_prefill_attn_workspace_bytes_cpu(int32_t HQ, int32_t H, int32_t L, int
  * rows of a block are independent (one OpenMP thread each: scores, softmax, probabilities, y, group mean -> A[row][s]),
  * then every COLUMN s accumulates its block of rows sequentially in query order — the canonical order of the column,
  * observation-window and band sums (one thread per column; the result does not depend on the thread count). */
-enum { kPfBlock = 128 };
+enum { kPfBlock = 256 };
+#ifdef _OPENMP
+static int pf_thread(void) { return omp_get_thread_num(); }
+static int pf_max_threads(void) { return omp_get_max_threads(); }
+#else
+static int pf_thread(void) { return 0; }
+static int pf_max_threads(void) { return 1; }
+#endif
 static int prefill_core(const void* q, const void* k, const void* v, int HQ, int H, int L, int D, int dtype, float scale, void* y,
                         float* colsum_out, float* obs_out, int obs_len, const int32_t* bands, int n_bands, float* band_out,
                         float* attn_full) {
@@ -638,6 +655,8 @@ static int prefill_core(const void* q, const void* k, const void* v, int HQ, int
   float* kf = (float*)malloc(sizeof(float) * (size_t)L * D);
   float* vf = (float*)malloc(sizeof(float) * (size_t)L * D);
   float* A = (float*)malloc(sizeof(float) * (size_t)kPfBlock * L);
+  const size_t per_thread = (size_t)R * L + L + D;
+  float* scratch = (float*)malloc(sizeof(float) * per_thread * (size_t)pf_max_threads());
   const int need_a = colsum_out || obs_out || band_out || attn_full;
   for (int h = 0; h < H; h++) {
     for (size_t e = 0; e < (size_t)L * D; e++) {
@@ -646,16 +665,14 @@ static int prefill_core(const void* q, const void* k, const void* v, int HQ, int
     }
     for (int i0 = 0; i0 < L; i0 += kPfBlock) {
       const int nb = L - i0 < kPfBlock ? L - i0 : kPfBlock;
-#pragma omp parallel
-      {
-      /* per-thread scratch, allocated once per block (per-row allocations of this size go through mmap and serialise
-       * hundreds of threads in the kernel) */
-      float* P = (float*)malloc(sizeof(float) * (size_t)R * (i0 + nb));
-      float* sc = (float*)malloc(sizeof(float) * (size_t)(i0 + nb));
-      float* qf = (float*)malloc(sizeof(float) * (size_t)D);
-#pragma omp for schedule(dynamic, 1)
+#pragma omp parallel for schedule(dynamic, 1)
       for (int bi = 0; bi < nb; bi++) {
         const int i = i0 + bi;
+        /* per-thread scratch from one allocation per call (per-row allocations of this size go through mmap and
+         * serialise hundreds of threads in the kernel) */
+        float* P = scratch + (size_t)pf_thread() * per_thread;
+        float* sc = P + (size_t)R * L;
+        float* qf = sc + L;
         for (int r = 0; r < R; r++) {
           const int j = h * R + r;
           for (int d = 0; d < D; d++) qf[d] = ld(q, dtype, ((size_t)j * L + i) * D + d);
@@ -691,10 +708,6 @@ static int prefill_core(const void* q, const void* k, const void* v, int HQ, int
           }
         }
       }
-      free(P);
-      free(sc);
-      free(qf);
-      }
       if (attn_full)  /* the group-averaged probabilities themselves, [H, L, L], zero above the diagonal */
         for (int bi = 0; bi < nb; bi++) {
           float* dst = attn_full + ((size_t)h * L + i0 + bi) * L;
@@ -721,6 +734,7 @@ static int prefill_core(const void* q, const void* k, const void* v, int HQ, int
   free(kf);
   free(vf);
   free(A);
+  free(scratch);
   return CC_OK;
 }
 

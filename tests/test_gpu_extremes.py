@@ -21,6 +21,11 @@ def run(strategy, dtype, H, HQ, S, D, T, steps=6, W=1):
             return cls(1, H, D, dtype, **{k: kw[k] for k in rk})
 
     a, b = mk(), mk()
+    from cold_compress_amd import _abi
+
+    code = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}[dtype]
+    one = (strategy in ("recent_global", "full", "random") or (strategy == "heavy_hitter" and W == 1)) and \
+        _abi.lib()["cc_decode_step_single_launch"](HQ, H, S, D, code) == 1
     gen = torch.Generator().manual_seed(3)
     if strategy == "random":  # the same uniform draws for both caches (the two-launch step draws one step ahead)
         draws = [torch.rand(S, generator=gen).to(DEV) for _ in range(steps + 1)]
@@ -48,7 +53,10 @@ def run(strategy, dtype, H, HQ, S, D, T, steps=6, W=1):
         a.update_state(p, k1, v1, False, at)
         yb = b.decode_step(q, k1, v1, p)
         torch.cuda.synchronize()
-        assert torch.equal(ya, yb), (strategy, S, t)
+        if one:  # the single-launch step folds y's partial sums in its own fixed order: one rounding apart at most
+            assert torch.allclose(ya.float(), yb.float(), rtol=2.0 ** -7, atol=1e-6), (strategy, S, t)
+        else:
+            assert torch.equal(ya, yb), (strategy, S, t)
         for (na, ta), (nb, tb) in zip(a.named_buffers(), b.named_buffers()):
             if na != "next_key":
                 assert torch.equal(ta, tb), (strategy, S, t, na)

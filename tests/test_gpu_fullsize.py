@@ -27,8 +27,10 @@ BF16_ULP = 2.0 ** -8
 
 @pytest.fixture()
 def oracle_mt(oracle):
-    """The oracle on all host cores for the full-size cases (identical results, see oracle/cc_oracle.c)."""
-    oracle.set_threads(os.cpu_count() or 1)
+    """The oracle on 16 host threads for the full-size cases (identical results, see oracle/cc_oracle.c; measured on the
+    256-thread GPU box, tools/oracle_scale.py: 16 threads 1.4 s, 64 threads 2.2 s, 256 threads 11.4 s at L = 8192 — the
+    row loop is bound by the shared K / V image, not by cores)."""
+    oracle.set_threads(min(16, os.cpu_count() or 1))
     yield oracle
     oracle.set_threads(1)
 
