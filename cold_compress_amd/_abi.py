@@ -77,6 +77,9 @@ SIGNATURES = {
     "cc_hh_ring_next_key_init": (C.c_int, [_view, _vp, _vp, _i32, _vp, _i32, _i32, _vp, _vp]),
     "cc_decode_step_heavy_hitter_ring": (C.c_int, [_view, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32,
                                                    _f32, _vp, _vp, _vp, _sz, _vp]),
+    "cc_hybrid_next_key_init": (C.c_int, [_view, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp]),
+    "cc_decode_step_hybrid": (C.c_int, [_view, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
+                                        _i32, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _sz, _vp]),
     "cc_l2_next_key_init": (C.c_int, [_view, _vp, _vp, _i32, _i32, _vp, _vp]),
     "cc_decode_step_l2": (C.c_int, [_view, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _sz, _vp]),
     "cc_random_next_key_init": (C.c_int, [_view, _vp, _vp, _i32, _i32, _vp, _vp]),
@@ -135,6 +138,11 @@ def bind(cdll, suffix=""):
 
 _LIB = None
 _FNS = None
+
+
+def built():
+    """True when the HIP extension exists (host-side constructors size their pipeline buffers through it)."""
+    return os.path.exists(LIB_PATH)
 
 
 def lib():

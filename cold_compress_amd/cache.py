@@ -704,6 +704,10 @@ class KVCacheHybrid(_TrackedWindowSums, KVCacheHeadSpecific):
         self._table = None
         self._state_fused = False  # set by the attention op when its combine pass already recorded this step's attention
         self._init_window_state()
+        # fused two-launch decode step (decode_step): every head's eviction candidate for the NEXT position, [H, NK]
+        nk = int(_abi.lib()["cc_hh_next_key_slots"](S)) if _abi.built() else 0
+        self.register_buffer("next_key", torch.full((n_heads, max(nk, 1)), -1, dtype=torch.int64), persistent=False)
+        self._next_valid = False
 
     # ------------------------------------------------------------------ small helpers
     def _init_requires_heavy_hitter(self):
@@ -734,6 +738,7 @@ class KVCacheHybrid(_TrackedWindowSums, KVCacheHeadSpecific):
         self.attn_counter.zero_()
         self._zero_window_state()
         self.cache_strategies = None
+        self._next_valid = False
         self.requires_heavy_hitter = self._init_requires_heavy_hitter()
         if hasattr(self, "special_mask"):
             self.special_mask.zero_()
@@ -763,10 +768,64 @@ class KVCacheHybrid(_TrackedWindowSums, KVCacheHeadSpecific):
         """Kept tokens first, original order preserved inside each class (stable)."""
         return torch.argsort((~mask_optimal).to(torch.int8), dim=1, stable=True)
 
+    # ------------------------------------------------------------------ fused decode step (2 launches per layer)
+    def supports_fused_step(self):
+        """cc_decode_step_hybrid: 16-bit caches with head_dim 128, profiled heads, and the reference's effective
+        no-reset-on-evict behaviour (see the class docstring)."""
+        return (self.cache_strategies is not None and self.k_cache.dtype in (torch.bfloat16, torch.float16) and self.head_dim == 128
+                and not self.reset_history_on_evict and self.n_heads <= 48)
+
+    def _punc_operands(self, input_ids):
+        if not hasattr(self, "punc_ids"):
+            return None, None
+        tok = input_ids.to(device=self.punc_ids.device, dtype=torch.int64).reshape(-1)[:1].contiguous()
+        return tok, self.punc_ids
+
+    def prepare_decode(self, input_pos):
+        """Seed the pipeline: every head's eviction candidate for `input_pos` from the current state (one launch)."""
+        tab = self._policy_table()
+        wsum, _ = self._window_state()
+        _abi.call("cc_hybrid_next_key_init", self._view(), _ptr(self._pos32(input_pos)), _ptr(self.cache_strategies), _ptr(tab),
+                  tab.shape[0], _ptr(self.attn_history_denom), self.history_window_size, _ptr(wsum),
+                  _ptr(getattr(self, "special_mask", None)), _ptr(getattr(self, "punc_mask", None)), int(self.global_tokens),
+                  _ptr(self.next_key), _stream())
+        self._next_valid = True
+
+    def decode_step(self, query, k_val, v_val, input_pos, scale=None, input_ids=None):
+        """update_kv + attention + update_state of one decode token in two launches (cc_decode_step_hybrid): the per-head
+        decision and the insert ride the K/V streaming pass, the ring update, the next candidates, the counts and num_punc
+        the combine pass.  Bit-identical to the three-launch sequence; positions must advance by one between calls."""
+        from .attention_utils import _workspace
+        import math
+
+        k, v = self._new_rows(k_val, v_val)
+        p32 = self._pos32(input_pos)
+        if not self._next_valid:
+            self.prepare_decode(p32)
+        _, HQ, _, D = query.shape
+        q = query.reshape(HQ, D).contiguous()
+        y = torch.empty((1, HQ, 1, D), dtype=query.dtype, device=query.device)
+        nbytes = _abi.lib()["cc_decode_attn_workspace_bytes"](HQ, self.n_heads, self.max_cache_length, D, _DT[self.k_cache.dtype])
+        ws = _workspace(nbytes, query.device)
+        tab = self._policy_table()
+        tok, pids = self._punc_operands(input_ids) if input_ids is not None else (None, None)
+        ring = denom = counter = acc = wsum = None
+        if self.requires_heavy_hitter:
+            wsum, acc = self._window_state()
+            ring, denom, counter = self.attn_history_num, self.attn_history_denom, self.attn_counter
+        _abi.call("cc_decode_step_hybrid", self._view(), _ptr(q), _ptr(k), _ptr(v), _ptr(p32), _ptr(self.cache_strategies), _ptr(tab),
+                  tab.shape[0], _ptr(ring), _ptr(denom), _ptr(counter), self.history_window_size, _ptr(acc), _ptr(wsum),
+                  _ptr(getattr(self, "special_mask", None)), _ptr(getattr(self, "punc_mask", None)), _ptr(tok), _ptr(pids),
+                  0 if pids is None else pids.numel(), _ptr(getattr(self, "num_special", None)), _ptr(getattr(self, "num_punc", None)),
+                  _ptr(self.next_key), int(self.global_tokens), HQ, 1.0 / math.sqrt(D) if scale is None else scale, _ptr(y), None,
+                  _ptr(ws), ws.numel(), _stream())
+        return y
+
     # ------------------------------------------------------------------ decode (ref: cache.py:965-1019)
     def _decoding_update(self, input_pos, k_val, v_val, **kwargs):
         if self.cache_strategies is None:
             raise ColdCompressError("hybrid cache used before prefill profiling (update_state with is_prefill=True)")
+        self._next_valid = False  # the three-call path mutates pos / counts / history outside the pipeline
         k, v = self._new_rows(k_val, v_val)
         tok = pids = None
         if hasattr(self, "punc_ids"):  # ref: cache.py:975 torch.isin(input_ids, punc_ids) — evaluated inside the launch
@@ -803,6 +862,7 @@ class KVCacheHybrid(_TrackedWindowSums, KVCacheHeadSpecific):
         if not is_prefill and self._state_fused:
             self._state_fused = False
             return
+        self._next_valid = False
         if is_prefill:
             self.profile_and_update(input_pos, k_val, v_val, attn, **kwargs)
         elif self.requires_heavy_hitter:

@@ -122,6 +122,25 @@ __device__ __forceinline__ float exp_nonpos(float x) {
   return fmaf(e, r * 0.6931471805599453f, e);
 }
 
+// KVCacheHybrid (FastGen) in the fused two-launch step: what the per-head decision of cache.py:896-950 needs.  The
+// eviction CANDIDATE of a head (arg-min over its live slots, protections applied) is scored by the combine pass of the
+// previous step; whether the head appends, evicts that candidate or drops the token is decided here, at the top of the
+// streaming pass, from the head's policy, its count, the budget terms and the incoming token's punctuation flag.
+enum { HF_HH = 1, HF_WIN = 2, HF_PUNC = 4, HF_SPECIAL = 8, HF_FULL = 16 };
+struct HybridStep {
+  const int64_t* strategies;    // [H] policy index per head
+  const int32_t* table;         // [n_pol, 3]: flags, window slots, heavy-hitter slots
+  const uint8_t* special_mask;  // [H, S] or null
+  uint8_t* punc_mask;           // [H, S] or null
+  const int64_t* token_id;      // device int64[1] or null
+  const int64_t* punc_ids;      // [n_punc_ids] or null
+  int n_punc_ids;
+  const int32_t* num_special;   // device int[1] or null
+  int32_t* num_punc;            // device int[1] or null
+  int32_t* cts_next;            // [H] workspace: the head's count after this step's insert (committed by the combine pass)
+  int W;                        // history window of the ring (clamp of the denominator)
+};
+
 struct SplitArgs {
   const void* q;
   const void* k;
@@ -174,6 +193,7 @@ struct SplitArgs {
   const float* rand_next;  // policy 3: [S] uniform draws for position p + 1
   int yc_chunks;      // grid.x of the two-launch combine pass (unused)
   unsigned long long* trace;  // measurement only (cc_decode_step_trace): [workgroup][16] time stamps and hardware ids
+  HybridStep hyb;     // HYB instantiation only
 };
 
 template <typename T, int D, int RT, int NW, int U>
@@ -500,8 +520,9 @@ constexpr int kOneAuxCoherent = 17;         // sc0 sc1: write-through stores / l
 
 // L2: the l2 policy's norm bookkeeping (its own instantiation: the others pay nothing).  ONE: the single-launch layer
 // step of the heavy-hitter policy (needs R == RT, one tile per wave, every workgroup of the grid co-resident).
-template <typename T, int RT, int NW, bool L2, bool ONE = false>
+template <typename T, int RT, int NW, bool L2, bool ONE = false, bool HYB = false>
 __global__ __launch_bounds__(NW * 64, ONE ? 2 : 1) void decode_attn_split_mfma_kernel(SplitArgs a) {
+  static_assert(!(HYB && (L2 || ONE)), "the hybrid decision rides the plain two-launch streaming pass");
   static_assert(sizeof(T) == 2 && (RT == 1 || RT == 2 || RT == 4 || RT == 8), "16-bit caches, up to 8 query heads per pass (the MFMA has 16 columns)");
   static_assert(!(ONE && L2) && (!ONE || NW == 4), "the single-launch step runs on 4-wave workgroups; l2 needs a cross-head maximum");
   constexpr int D = 128, VEC = 8, RPW = 4, U = 4;
@@ -542,6 +563,8 @@ __global__ __launch_bounds__(NW * 64, ONE ? 2 : 1) void decode_attn_split_mfma_k
   if (L2 && l2_here && kn_row0 < row_end) kn_first = ElemTraits<T>::load(reinterpret_cast<const T*>(a.key_norm) + (size_t)h * S, kn_row0);
   // ---- every load of the first tile is issued before anything waits (partial keys, q, mask, K, V: use order)
   int ins_idx = -1, ins_was_empty = 0;
+  int hyb_kind = 0, hyb_cts = 0;  // HYB: 0 = append at the end, 1 = evict the candidate, 2 = drop (slot S - 1, mask untouched)
+  bool hyb_punc = false;
   bool key_pending = a.next_key != nullptr && !(a.abl & 128);
   unsigned long long key_part = ~0ull;
   if (key_pending) {
@@ -634,6 +657,37 @@ __global__ __launch_bounds__(NW * 64, ONE ? 2 : 1) void decode_attn_split_mfma_k
       if (a.abl & 64) ins_idx = -1;
       ins_was_empty = (int)(key & 1ull);
       key_pending = false;
+      if constexpr (HYB) {  // ref: cache.py:896-950 _select_fill_idx, per head
+        const int pol = (int)a.hyb.strategies[h];
+        const int flags = a.hyb.table[pol * 3], win = a.hyb.table[pol * 3 + 1], hhs = a.hyb.table[pol * 3 + 2];
+        const int cts = a.cache_cts[h];
+        if (a.hyb.token_id && a.hyb.punc_ids) {  // ref: cache.py:975 torch.isin(input_ids, punc_ids)
+          const long long id = *a.hyb.token_id;
+          for (int k2 = 0; k2 < a.hyb.n_punc_ids; k2++) hyb_punc |= a.hyb.punc_ids[k2] == id;
+        }
+        const int end_idx = cts < S - 1 ? cts : S - 1;  // :897-899
+        hyb_cts = cts;
+        if (((flags & HF_PUNC) && hyb_punc) || (flags & HF_FULL)) {  // :905-909
+          ins_idx = end_idx;
+          hyb_kind = 0;
+        } else {
+          int budget = a.g;  // :912-925
+          if (flags & HF_SPECIAL) budget += a.hyb.num_special ? *a.hyb.num_special : 0;
+          if (flags & HF_PUNC) budget += a.hyb.num_punc ? *a.hyb.num_punc : 0;
+          if (flags & HF_WIN) budget += win;
+          if (flags & HF_HH) budget += hhs;
+          if (cts < budget) {  // :927-930 append
+            ins_idx = end_idx;
+            hyb_kind = 0;
+          } else if (flags & (HF_HH | HF_WIN)) {  // :932-946 evict the candidate the previous step scored
+            hyb_kind = 1;
+            if (ins_idx < 0) ins_idx = 0;  // unreachable with a positive budget (a head over budget has live slots)
+          } else {  // :948-950 the token is not kept: it lands in slot S - 1 with the mask untouched
+            ins_idx = S - 1;
+            hyb_kind = 2;
+          }
+        }
+      }
     }
     // fused insert (cache.py:356-362, 460-490, 754-763) — see the VALU kernel; the K chunk follows the swizzle
     if ((unsigned)(ins_idx - row0) < (unsigned)U) {
@@ -653,9 +707,19 @@ __global__ __launch_bounds__(NW * 64, ONE ? 2 : 1) void decode_attn_split_mfma_k
         if (u == um) {
           kk[u].raw = kn.raw;
           vv[u].raw = vn.raw;
-          mword |= 1u << (8 * u);
+          if (!HYB || hyb_kind != 2) mword |= 1u << (8 * u);
         }
-      if (blockIdx.z == 0) {
+      if (HYB && blockIdx.z == 0) {  // ref: cache.py:997-1016 — bookkeeping of the hybrid decision
+        const size_t slot = (size_t)h * S + ins_idx;
+        *reinterpret_cast<uint4*>(const_cast<T*>(kb) + (size_t)ins_idx * D + kcol) = kn.raw;
+        *reinterpret_cast<uint4*>(const_cast<T*>(vh) + (size_t)ins_idx * D) = vn.raw;
+        if (c == 0) {
+          a.pos[slot] = p_now;  // :1006-1007 every head, dropped tokens included
+          if (hyb_kind == 0) a.mask_w[slot] = 1;  // :997-1001 appends only (an evicted slot is live already)
+          a.hyb.cts_next[h] = hyb_cts + (hyb_kind == 0 ? 1 : 0);  // committed to cache_cts by the combine pass
+          if (hyb_punc && a.hyb.punc_mask) a.hyb.punc_mask[slot] = 1;  // :1011-1016
+        }
+      } else if (blockIdx.z == 0) {
         const size_t slot = (size_t)h * S + ins_idx;
         *reinterpret_cast<uint4*>(const_cast<T*>(kb) + (size_t)ins_idx * D + kcol) = kn.raw;
         *reinterpret_cast<uint4*>(const_cast<T*>(vh) + (size_t)ins_idx * D) = vn.raw;
@@ -1130,6 +1194,10 @@ struct CombineArgs {
   float* ring_wsum;      // [H, S]
   int Hp;
   int abl;  // measurement-only ablation bits (phases >> 8): 8 = no next-key epilogue, 16 = no y merge, 32 = no per-slot pass
+  // ---- policy 6: KVCacheHybrid — score every head's eviction CANDIDATE for position p + 1 (cache.py:844-894 on the state
+  //      this step leaves behind), commit the counts the streaming pass's inserts produced, bump num_punc (cache.py:1017)
+  HybridStep hyb;
+  int32_t* cache_cts;  // [H]
 };
 
 constexpr int kMaxR = 32;
@@ -1166,6 +1234,19 @@ __global__ __launch_bounds__(kCombThreads) void decode_attn_combine_kernel(Combi
   }
   float rnd_mine = 0.f;
   if (a.next_key && a.policy == 3) rnd_mine = a.rand_next[s_ld];
+  // hybrid (policy 6): the head's policy row, its count after this step's insert and this slot's protection masks are
+  // requested here with everything else (a dependent chain strategies -> table at the tail cost ~3 us of L2 round trips)
+  int hyb_flags = 0, hyb_win = 0, hyb_cts_n = 0;
+  bool hyb_save = false;
+  if (a.next_key && a.policy == 6) {
+    const int pol = (int)a.hyb.strategies[h];
+    hyb_cts_n = a.hyb.cts_next[h];
+    const uint8_t spm = a.hyb.special_mask ? a.hyb.special_mask[(size_t)h * S + s_ld] : 0;
+    const uint8_t pum = a.hyb.punc_mask ? a.hyb.punc_mask[(size_t)h * S + s_ld] : 0;
+    hyb_flags = a.hyb.table[pol * 3];
+    hyb_win = a.hyb.table[pol * 3 + 1];
+    hyb_save = ((hyb_flags & HF_SPECIAL) && spm) || ((hyb_flags & HF_PUNC) && pum);
+  }
   float kn_mine = 0.f, l2_part = -INFINITY;
   bool l2_nan = false;
   if (a.next_key && a.policy == 4) {
@@ -1325,6 +1406,8 @@ __global__ __launch_bounds__(kCombThreads) void decode_attn_combine_kernel(Combi
   if (do_y) sm_y[threadIdx.x] = y_partial(y_lo, true, y_nout, y_G, y_oi, y_g, y_r, y_d);
 
   bool fresh = false;
+  float hyb_ws = 0.f;
+  int32_t hyb_dn = 1;
   // probabilities for this thread's slot
   if (have && !(a.abl & 32)) {
     const int s = s_mine;
@@ -1348,7 +1431,7 @@ __global__ __launch_bounds__(kCombThreads) void decode_attn_combine_kernel(Combi
     const size_t i = (size_t)h * S + s;
     if (a.attn_out) ElemTraits<T>::store(reinterpret_cast<T*>(a.attn_out), i, av);
     if (a.ring_num) {  // fused cache.py:716-723, W > 1: ring[h, s, counter % W] = attn; denom += 1; window sum kept exact
-      if (a.next_key && ps_mine == p_next - 1) {  // two-launch step: this slot was evicted and refilled by the streaming
+      if (a.next_key && a.policy == 5 && ps_mine == p_next - 1) {  // two-launch step: this slot was evicted and refilled by the streaming
         racc = WAcc{0, 0, 0, 0};                  // pass — its history starts from zero (cache.py:754-763); the rest of
         ring_old = 0.f;                           // the ring row and shadow column is cleared below, by the whole wave
         den_old = 0;
@@ -1363,6 +1446,8 @@ __global__ __launch_bounds__(kCombThreads) void decode_attn_combine_kernel(Combi
       *reinterpret_cast<ulonglong2*>(a.ring_acc + i * 4 + 2) = make_ulonglong2(racc.w2, racc.special);
       const float ws_new = wacc_round<T>(racc);
       a.ring_wsum[i] = ws_new;
+      hyb_ws = ws_new;
+      hyb_dn = den_old + 1;
       if (a.next_key && a.policy == 5) {  // next eviction score of the windowed history (cache.py:727-749, W > 1)
         const int32_t dn = den_old + 1;
         float scn = __fdiv_rn(ws_new, (float)(dn < 1 ? 1 : (dn > a.ring_W ? a.ring_W : dn)));
@@ -1424,6 +1509,22 @@ __global__ __launch_bounds__(kCombThreads) void decode_attn_combine_kernel(Combi
     if (ps_mine == -1) scn = -INFINITY;
     my_key = make_key(orderable_f32(scn), ((uint32_t)s_mine << 1) | (uint32_t)(ps_mine == -1));
   }
+  if (a.next_key && a.policy == 6 && have) {  // ref: cache.py:844-894 _eviction_idx_for_head at position p + 1
+    const int flags = hyb_flags, win = hyb_win, cts_n = hyb_cts_n;
+    if ((flags & (HF_HH | HF_WIN)) && !(flags & HF_FULL) && s_mine < (cts_n < S ? cts_n : S)) {
+      float scn;
+      if (flags & HF_HH) {
+        const int32_t d = hyb_dn > a.hyb.W ? a.hyb.W : hyb_dn;  // clamp_max only (:868-870)
+        scn = __fdiv_rn(hyb_ws, (float)d);
+      } else {
+        scn = (float)ps_mine;  // :873
+      }
+      bool save = s_mine < a.g || hyb_save;  // :876 first g SLOTS, :878-883 special / punctuation slots
+      if (flags & HF_WIN) save |= ps_mine > p_next - win;  // :885-889 strict
+      if (save) scn = INFINITY;
+      my_key = make_key(orderable_f32(scn), (uint32_t)s_mine << 1);
+    }
+  }
   if (a.next_key && !(a.abl & 8)) {
     const unsigned long long wk = wave_min_u64_uniform(my_key);
     if (lane == 0) sm_k[wave] = wk;
@@ -1452,6 +1553,15 @@ __global__ __launch_bounds__(kCombThreads) void decode_attn_combine_kernel(Combi
       y_final(y_nout, y_G, y_oi, y_g, y_r, y_d);
     }
   if ((a.hh_num || a.ring_num) && a.hh_counter && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *a.hh_counter += 1;
+  if (a.next_key && a.policy == 6 && blockIdx.x == 0 && threadIdx.x == 0) {
+    a.cache_cts[h] = a.hyb.cts_next[h];  // every block of this head has read cts_next, not cache_cts
+    if (h == 0 && a.hyb.num_punc && a.hyb.token_id && a.hyb.punc_ids) {  // ref: cache.py:1017, once per step
+      const long long id = *a.hyb.token_id;
+      bool f = false;
+      for (int k2 = 0; k2 < a.hyb.n_punc_ids; k2++) f |= a.hyb.punc_ids[k2] == id;
+      if (f) *a.hyb.num_punc += 1;
+    }
+  }
 }
 
 // ---------------------------------------------------------------- launch plan
@@ -1520,7 +1630,14 @@ static int launch_split(const SplitArgs& a, const Plan& p, int H, int R, int D, 
     if (D == 128 && !(a.abl & 32)) {  // matrix-core streaming pass (abl bit 32 = measurement: force the VALU kernel)
       static_assert(kU == 4, "the MFMA tile is 4 row groups x 4 rows per wave");
       dim3 grid(p.n_split, H, R / p.rt), block(kNW * 64);
-      if (a.key_norm != nullptr) {
+      if (a.hyb.strategies != nullptr) {
+        switch (p.rt) {
+          case 8: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 8, kNW, false, false, true>), grid, block, 0, st, a); break;
+          case 4: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 4, kNW, false, false, true>), grid, block, 0, st, a); break;
+          case 2: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 2, kNW, false, false, true>), grid, block, 0, st, a); break;
+          default: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 1, kNW, false, false, true>), grid, block, 0, st, a); break;
+        }
+      } else if (a.key_norm != nullptr) {
         switch (p.rt) {
           case 8: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 8, kNW, true>), grid, block, 0, st, a); break;
           case 4: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 4, kNW, true>), grid, block, 0, st, a); break;
@@ -1540,6 +1657,7 @@ static int launch_split(const SplitArgs& a, const Plan& p, int H, int R, int D, 
     }
   }
   if (p.rt > 4) return CC_ERR_UNSUPPORTED;  // 8 heads per pass exist on the matrix-core path only (reached here only by the measurement switch)
+  if (a.hyb.strategies != nullptr) return CC_ERR_UNSUPPORTED;  // the hybrid decision exists in the matrix-core streaming pass only
   switch (D) {
     case 16: return launch_split_rt<T, 16>(a, p, H, R, st);
     case 32: return launch_split_rt<T, 32>(a, p, H, R, st);
@@ -1651,6 +1769,7 @@ struct FusedStep {
   int policy;  // 1 = heavy hitter, 2 = recent_global / full, 3 = random, 4 = l2
   const float* rand_next;
   void* key_norm;  // policy 4
+  const HybridStep* hyb;  // policy 6
 };
 // The W > 1 history ring folded into the combine pass (denom / counter travel as hh_denom / hh_counter).
 struct RingHistory {
@@ -1700,6 +1819,15 @@ static int attn_impl(const void* q, const void* k, const void* v, const uint8_t*
     sa.key_norm = fs->key_norm;
     sa.l2_pmax = reinterpret_cast<float*>(ws + 256);
     sa.l2_new = sa.l2_pmax + (size_t)H * p.n_split * kNW;
+  }
+  if (fs && fs->policy == 6) {
+    if (!fs->hyb || !fs->hyb->strategies || !fs->hyb->table || cc_dt_size(dtype) != 2 || D != 128 || fs->c->Hp != H || fs->c->Hc != H)
+      return CC_ERR_UNSUPPORTED;
+    sa.hyb = *fs->hyb;
+    // the counts after this step's inserts, [H] int32 behind the ring column word of the workspace
+    sa.hyb.cts_next = reinterpret_cast<int32_t*>(ws + 64);
+    if ((size_t)H * sizeof(int32_t) > 192) return CC_ERR_UNSUPPORTED;  // 48 kv heads per rank at most (256-byte slot)
+    sa.g = fs->g;
   }
   if (fs) {
     sa.next_key = fs->next_key; sa.nk = cc_next_key_slots(S); sa.input_pos = fs->input_pos; sa.k_new = fs->k_new; sa.v_new = fs->v_new;
@@ -1752,6 +1880,10 @@ static int attn_impl(const void* q, const void* k, const void* v, const uint8_t*
     ca.next_key = fs->next_key; ca.input_pos = fs->input_pos; ca.pos = fs->c->pos; ca.H = H; ca.g = fs->g; ca.w = fs->w;
     ca.policy = fs->policy; ca.Hp = fs->c->Hp; ca.rand_next = fs->rand_next;
     ca.key_norm = sa.key_norm; ca.l2_pmax = sa.l2_pmax; ca.l2_new = sa.l2_new; ca.l2_np = H * p.n_split * kNW;
+    if (fs->policy == 6) {
+      ca.hyb = sa.hyb;
+      ca.cache_cts = fs->c->cache_cts;
+    }
   }
   ca.abl = (phases >> 8) & 0xff;
   dim3 grid(p.n_chunks, H), block(kCombThreads);
@@ -1841,6 +1973,27 @@ int cc_decode_step_heavy_hitter_ring(const cc_kv_view* c, const void* q, const v
   RingHistory rh{ring_num, W, wsum_acc, wsum};
   return attn_impl(q, c->k_cache, c->v_cache, c->mask, HQ, c->H, c->S, c->D, c->dtype, scale, y, attn_out, nullptr, nullptr, denom, counter,
                    workspace, workspace_bytes, stream, 3, &fs, &rh);
+}
+
+int cc_decode_step_hybrid(const cc_kv_view* c, const void* q, const void* k_new, const void* v_new, const int32_t* input_pos,
+                          const int64_t* strategies, const int32_t* policy_table, int32_t n_policies, void* ring_num, int32_t* denom,
+                          int64_t* counter, int32_t W, uint64_t* wsum_acc, float* wsum, const uint8_t* special_mask,
+                          uint8_t* punc_mask, const int64_t* token_id, const int64_t* punc_ids, int32_t n_punc_ids,
+                          const int32_t* num_special, int32_t* num_punc, uint64_t* next_key, int32_t global_tokens, int32_t HQ,
+                          float scale, void* y, void* attn_out, void* workspace, size_t workspace_bytes, cc_stream_t stream) {
+  if (!cc_view_ok(c) || !q || !k_new || !v_new || !input_pos || !strategies || !policy_table || n_policies <= 0 || !next_key || !y ||
+      c->Hp != c->H || c->Hc != c->H || HQ <= 0 || HQ % c->H || W <= 0 || (punc_ids && n_punc_ids < 0) ||
+      (ring_num && (!denom || !counter || !wsum_acc || !wsum)))
+    return CC_ERR_BAD_ARG;
+  HybridStep hs{};
+  hs.strategies = strategies; hs.table = policy_table; hs.special_mask = special_mask; hs.punc_mask = punc_mask;
+  hs.token_id = token_id; hs.punc_ids = punc_ids; hs.n_punc_ids = n_punc_ids; hs.num_special = num_special; hs.num_punc = num_punc;
+  hs.W = W;
+  FusedStep fs{c, k_new, v_new, input_pos, reinterpret_cast<unsigned long long*>(next_key), global_tokens, 0, 6, nullptr, nullptr, &hs};
+  RingHistory rh{ring_num, W, wsum_acc, wsum};
+  return attn_impl(q, c->k_cache, c->v_cache, c->mask, HQ, c->H, c->S, c->D, c->dtype, scale, y, attn_out, nullptr, nullptr,
+                   ring_num ? denom : nullptr, ring_num ? counter : nullptr, workspace, workspace_bytes, stream, 3, &fs,
+                   ring_num ? &rh : nullptr);
 }
 
 int cc_decode_attn_gqa_ring(const void* q, const void* k, const void* v, const uint8_t* mask, int32_t HQ, int32_t H, int32_t S,

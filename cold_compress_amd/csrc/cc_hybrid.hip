@@ -41,6 +41,8 @@ struct HybArgs {
   int64_t* fill_out;  // [H]
   float* wsum;        // [H,S] window sums: from the pre-pass, or the tracked state kept by cc_hh_ring_update
   u64* wacc;          // [H,S,4] tracked exact accumulators or null (stateless: pre-pass every call)
+  unsigned long long* key_out;  // seed of the two-launch pipeline (cc_hybrid_next_key_init): [H][nk] candidate keys; no side effects
+  int nk;
 };
 
 // exact sum of one ring row, one wave per row: 16-byte chunks strided over the lanes, integer butterfly
@@ -154,13 +156,42 @@ __global__ __launch_bounds__(kHybThreads) void hybrid_decode_kernel(HybArgs a) {
   __syncthreads();
   const bool is_punc = sm_punc[0] != 0;
   const int num_punc_old = sm_punc[1];
-  if (threadIdx.x == 0 && a.punc_ticket && a.num_punc)
+  if (threadIdx.x == 0 && a.punc_ticket && a.num_punc && !a.key_out)
     ptk = __hip_atomic_fetch_add(a.punc_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const int end_idx = cts < S - 1 ? cts : S - 1;  // ref: _end_idx() :897-899
 
   int fill = -1;       // -1 = token not kept by this head (ref: :948-950 -> dummy slot S-1)
   bool evict = false;
   unsigned long long best = ~0ull;
+  if (a.key_out != nullptr) {
+    // Seed of the fused two-launch step: the head's eviction CANDIDATE for this position (arg-min over its live slots with
+    // the protections of :876-889), whatever the budget says — whether the head appends, evicts it or drops the token is
+    // decided by the streaming pass of the step that consumes it.  Key = (score, slot << 1); nothing else is touched.
+    if ((flags & (F_HH | F_WIN)) && !(flags & F_FULL)) {
+      const int lim = cts < S ? cts : S;
+      for (int s = threadIdx.x; s < lim; s += blockDim.x) {
+        const size_t i = hoff + s;
+        const int32_t psv = a.pos[i];
+        float sc;
+        if (flags & F_HH) {
+          const int32_t d0 = a.denom[i];
+          sc = __fdiv_rn(a.wsum[i], (float)(d0 > W ? W : d0));
+        } else {
+          sc = (float)psv;
+        }
+        bool save = s < a.g;
+        if ((flags & F_SPECIAL) && a.special_mask) save |= a.special_mask[i] != 0;
+        if ((flags & F_PUNC) && a.punc_mask) save |= a.punc_mask[i] != 0;
+        if (flags & F_WIN) save |= psv > p - win;
+        if (save) sc = INFINITY;
+        const unsigned long long key = make_key(orderable_f32(sc), (uint32_t)s << 1);
+        best = key < best ? key : best;
+      }
+    }
+    best = block_min_u64(best, sm_key);
+    for (int i = threadIdx.x; i < a.nk; i += blockDim.x) a.key_out[(size_t)h * a.nk + i] = (i == 0) ? best : ~0ull;
+    return;
+  }
   if ((flags & F_PUNC) && is_punc) {  // :905-906
     fill = end_idx;
   } else if (flags & F_FULL) {  // :908-909
@@ -488,6 +519,32 @@ int cc_hybrid_decode_update(const cc_kv_view* c, const void* k_new, const void* 
     hipLaunchKernelGGL(hybrid_bump_punc_kernel, dim3(1), dim3(64), 0, st, is_punc, token_id, punc_ids, n_punc_ids, num_punc);
     CC_LAUNCH_CHECK();
   }
+  return CC_OK;
+}
+
+int cc_hybrid_next_key_init(const cc_kv_view* c, const int32_t* input_pos, const int64_t* strategies, const int32_t* policy_table,
+                            int32_t n_policies, const int32_t* denom, int32_t W, const float* wsum, const uint8_t* special_mask,
+                            const uint8_t* punc_mask, int32_t global_tokens, uint64_t* next_key, cc_stream_t stream) {
+  CC_ENTRY();
+  if (!cc_view_ok(c) || !input_pos || !strategies || !policy_table || n_policies <= 0 || W <= 0 || !next_key || c->Hp != c->H ||
+      c->Hc != c->H)
+    return CC_ERR_BAD_ARG;
+  HybArgs a{};
+  a.pos = c->pos; a.mask = c->mask; a.cache_cts = c->cache_cts;
+  a.H = c->H; a.S = c->S; a.D = c->D; a.W = W; a.g = global_tokens;
+  a.input_pos = input_pos; a.strategies = strategies; a.table = policy_table;
+  a.denom = const_cast<int32_t*>(denom); a.wsum = const_cast<float*>(wsum);
+  a.special_mask = special_mask; a.punc_mask = const_cast<uint8_t*>(punc_mask);
+  a.key_out = reinterpret_cast<unsigned long long*>(next_key);
+  a.nk = cc_next_key_slots(c->S);
+  dim3 grid(c->H, 1), block(kHybThreads);
+  hipStream_t st = (hipStream_t)stream;
+  switch (c->dtype) {
+    case CC_DT_F32: hipLaunchKernelGGL(hybrid_decode_kernel<float>, grid, block, 0, st, a); break;
+    case CC_DT_BF16: hipLaunchKernelGGL(hybrid_decode_kernel<bf16_t>, grid, block, 0, st, a); break;
+    default: hipLaunchKernelGGL(hybrid_decode_kernel<f16_t>, grid, block, 0, st, a); break;
+  }
+  CC_LAUNCH_CHECK();
   return CC_OK;
 }
 

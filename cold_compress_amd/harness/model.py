@@ -160,11 +160,12 @@ class Attention(nn.Module):
             q, k, v = glue.qkv_rope(self.wqkv(x), freqs_cis, self.n_head, self.n_local_heads, self.head_dim)
         cache = self.kv_cache
         ck = {"input_ids": input_ids}
-        if (not is_prefill and self.fuse_decode_step and type(cache) in (KVCacheHeavyHitter, KVCacheRecentGlobal, KVCacheFull, KVCacheRandom, KVCacheL2)
+        if (not is_prefill and self.fuse_decode_step and type(cache) in (KVCacheHeavyHitter, KVCacheRecentGlobal, KVCacheFull, KVCacheRandom, KVCacheL2,
+                                                                          KVCacheHybrid)
                 and cache.supports_fused_step() and attn_top_k == 1.0):
-            # two launches per layer: insert folded into the K/V streaming pass, history update + next eviction
+            # one or two launches per layer: insert folded into the K/V streaming pass, history update + next eviction
             # scoring folded into the combine pass (bit-identical to the three-call sequence below)
-            y = cache.decode_step(q, k, v, input_pos)
+            y = cache.decode_step(q, k, v, input_pos, input_ids=input_ids) if type(cache) is KVCacheHybrid else cache.decode_step(q, k, v, input_pos)
         elif not is_prefill:
             kc, vc, kv_mask = cache.update_kv(input_pos, k, v, False, **ck)  # insert first, then attend
             hist = cache.fused_history() if (self.fuse_state_update and type(cache) in (KVCacheHeavyHitter, KVCacheHybrid)

@@ -264,6 +264,28 @@ void cc_decode_step_set_single_launch(int32_t enabled);
  * workgroup of a single-launch step records [0..5] s_memtime stamps (start, streaming done, published, sentinel seen,
  * gathered, end), [6..8] s_memrealtime at start / streaming done / end, [9] HW_ID, [10] XCC_ID. */
 void cc_decode_step_trace(void* buf);
+/* The two-launch step for KVCacheHybrid (FastGen per-head policies; cache.py:896-1019 + the fused ring update of
+ * cc_decode_attn_gqa_ring): three launches -> two.  What a head does with the incoming token — append at the end of its
+ * live slots, evict its candidate, or drop the token (slot S - 1, mask untouched) — depends on its policy, its count, the
+ * budget terms and whether the token is punctuation (cache.py:905-950): decided at the top of the K/V streaming pass, from
+ * device scalars.  The CANDIDATE (arg-min over the head's live slots of window-sum / min(denom, W) or of pos, with the
+ * protections of cache.py:876-889 applied) depends only on the state the previous step left behind: the combine pass
+ * scores it for position *input_pos + 1 from the freshly updated window sums, commits the counts the inserts produced
+ * and bumps num_punc (cache.py:1017).  cc_hybrid_next_key_init seeds the candidates.  Arguments as for
+ * cc_hybrid_decode_update / cc_decode_attn_gqa_ring; ring_num may be NULL when no head scores by accumulated attention
+ * (then denom / counter / wsum_acc / wsum are unused).  reset-history-on-evict is not part of this step (the reference's
+ * effective behaviour, see cache.py of this package); 16-bit caches with head_dim 128 only (CC_ERR_UNSUPPORTED otherwise:
+ * use cc_hybrid_decode_update + cc_decode_attn_gqa[_ring]).  next_key: uint64 [H, NK].  Bit-identical to the three-launch
+ * sequence (tests/test_gpu_hybrid.py). */
+int cc_hybrid_next_key_init(const cc_kv_view* c, const int32_t* input_pos, const int64_t* strategies, const int32_t* policy_table,
+                            int32_t n_policies, const int32_t* denom, int32_t W, const float* wsum, const uint8_t* special_mask,
+                            const uint8_t* punc_mask, int32_t global_tokens, uint64_t* next_key, cc_stream_t stream);
+int cc_decode_step_hybrid(const cc_kv_view* c, const void* q, const void* k_new, const void* v_new, const int32_t* input_pos,
+                          const int64_t* strategies, const int32_t* policy_table, int32_t n_policies, void* ring_num, int32_t* denom,
+                          int64_t* counter, int32_t W, uint64_t* wsum_acc, float* wsum, const uint8_t* special_mask,
+                          uint8_t* punc_mask, const int64_t* token_id, const int64_t* punc_ids, int32_t n_punc_ids,
+                          const int32_t* num_special, int32_t* num_punc, uint64_t* next_key, int32_t global_tokens, int32_t HQ,
+                          float scale, void* y, void* attn_out, void* workspace, size_t workspace_bytes, cc_stream_t stream);
 /* Measurement hook (cf. cc_decode_attn_gqa_phases): the same step with its launches selectable. */
 int cc_decode_step_heavy_hitter_phases(const cc_kv_view* c, const void* q, const void* k_new, const void* v_new,
                                 const int32_t* input_pos, double* num, int32_t* denom, int64_t* counter,

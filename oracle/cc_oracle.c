@@ -1082,6 +1082,35 @@ int cc_decode_attn_gqa_ring_cpu(const void* q, const void* k, const void* v, con
   return rc;
 }
 
+/* Oracle twins of the hybrid two-launch step: the oracle keeps no pipeline state — the step IS the reference's sequence
+ * (cache.py:965-1019 decision + insert, then attention, then the ring update cache.py:1283-1286), so the seed is a no-op
+ * and next_key is ignored. */
+int cc_hybrid_next_key_init_cpu(const cc_kv_view* c, const int32_t* input_pos, const int64_t* strategies, const int32_t* policy_table,
+                                int32_t n_policies, const int32_t* denom, int32_t W, const float* wsum, const uint8_t* special_mask,
+                                const uint8_t* punc_mask, int32_t global_tokens, uint64_t* next_key, cc_stream_t stream) {
+  (void)input_pos; (void)denom; (void)W; (void)wsum; (void)special_mask; (void)punc_mask; (void)global_tokens; (void)next_key; (void)stream;
+  if (!view_ok(c) || !strategies || !policy_table || n_policies <= 0) return CC_ERR_BAD_ARG;
+  return CC_OK;
+}
+
+int cc_decode_step_hybrid_cpu(const cc_kv_view* c, const void* q, const void* k_new, const void* v_new, const int32_t* input_pos,
+                              const int64_t* strategies, const int32_t* policy_table, int32_t n_policies, void* ring_num, int32_t* denom,
+                              int64_t* counter, int32_t W, uint64_t* wsum_acc, float* wsum, const uint8_t* special_mask,
+                              uint8_t* punc_mask, const int64_t* token_id, const int64_t* punc_ids, int32_t n_punc_ids,
+                              const int32_t* num_special, int32_t* num_punc, uint64_t* next_key, int32_t global_tokens, int32_t HQ,
+                              float scale, void* y, void* attn_out, void* workspace, size_t workspace_bytes, cc_stream_t stream) {
+  (void)next_key;
+  if (!view_ok(c) || !ring_num || !denom || !wsum) return CC_ERR_BAD_ARG; /* the oracle twin covers the ring-backed form */
+  int64_t* fill = (int64_t*)malloc(sizeof(int64_t) * (size_t)c->H);
+  int rc = cc_hybrid_decode_update_cpu(c, k_new, v_new, input_pos, strategies, policy_table, n_policies, ring_num, denom, W, special_mask,
+                                       punc_mask, NULL, token_id, punc_ids, n_punc_ids, num_special, num_punc, global_tokens, 0, fill,
+                                       wsum, wsum_acc, stream);
+  free(fill);
+  if (rc != CC_OK) return rc;
+  return cc_decode_attn_gqa_ring_cpu(q, c->k_cache, c->v_cache, c->mask, HQ, c->H, c->S, c->D, c->dtype, scale, y, attn_out, ring_num, denom,
+                                     counter, W, wsum_acc, wsum, workspace, workspace_bytes, stream);
+}
+
 int cc_attn_bandsum_cpu(const void* attn, int32_t H, int32_t Lq, int32_t Lk, int32_t dtype, int32_t band, float* out,
                         cc_stream_t stream) {
   (void)stream;

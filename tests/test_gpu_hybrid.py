@@ -265,3 +265,81 @@ def test_hybrid_end_to_end_through_the_harness():
             assert bool(kv.mask.cpu()[0, h, 0, : int(cts[h])].all()) and not bool(kv.mask.cpu()[0, h, 0, int(cts[h]):].any())
         st = kv.compute_statistics(torch.tensor(64))
         assert 0 <= st["compression_ratio"] <= 1 and "avg_strategy_idx" in st
+
+
+HYB5 = [{"strategy": "special"}, {"strategy": "special_punc"}, {"strategy": "special_punc_heavy_hitter", "heavy_hitter_frac": 0.3},
+        {"strategy": "special_punc_window", "recent_window": 0.3}, {"strategy": "full"}]
+HYB_YAML = [{"strategy": "window", "recent_window": 0.1},
+            {"strategy": "window_heavy_hitter", "heavy_hitter_frac": 0.25, "recent_window": 0.1},
+            {"strategy": "window_heavy_hitter", "heavy_hitter_frac": 0.5, "recent_window": 0.1}, {"strategy": "full"}]
+
+
+@pytest.mark.parametrize("strategies,H,HQ,S,T,steps,seed", [(HYB5, 5, 20, 300, 280, 40, 1), (HYB_YAML, 8, 32, 4100, 4000, 30, 2),
+                                                            (HYB5, 3, 6, 130, 20, 140, 3), (HYB_YAML, 4, 32, 18432, 18000, 12, 4),
+                                                            (HYB5, 10, 10, 700, 700, 25, 5)])
+def test_hybrid_two_launch_step_equals_three_launches(strategies, H, HQ, S, T, steps, seed):
+    """KVCacheHybrid.decode_step (cc_decode_step_hybrid: decision + insert in the K/V streaming pass; ring update, the next
+    candidates, the counts and num_punc in the combine pass) against update_kv -> attention (ring update fused) ->
+    update_state, on twin caches: every buffer — pos, mask, counts, K/V, ring, denominators, punctuation / special masks,
+    num_punc, the tracked window sums — and y, bit for bit, through appends, evictions, dropped tokens and punctuation
+    tokens; heads cycle through the policies, partly filled and full.  (The three-launch sequence is the one the reference's
+    own traces pin bit for bit above; its attention inputs are given there, so a trace cannot be replayed through a step
+    that computes the attention itself.)"""
+    import cold_compress_amd.cache as cache
+    from cold_compress_amd.attention_utils import scaled_dot_product_attention as sdpa
+
+    D, dtype = 128, torch.bfloat16
+    cls, rk = cache.get_cache_constructor("hybrid")
+    kw = dict(max_cache_length=S, max_seq_length=S, cache_bits=None, global_tokens=4, token_ids=TOKEN_IDS, min_recovery_frac=0.9,
+              hybrid_strategies=strategies)
+
+    def mk():
+        with torch.device(DEV):
+            return cls(1, H, D, dtype, **{k: kw[k] for k in rk})
+
+    a, b = mk(), mk()
+    gen = torch.Generator().manual_seed(seed)
+    k0 = torch.randn(1, H, T, D, generator=gen).to(dtype).to(DEV)
+    v0 = torch.randn(1, H, T, D, generator=gen).to(dtype).to(DEV)
+    fill = torch.tensor([T if h % 2 == 0 else max(4, T // 2) for h in range(H)], dtype=torch.int32)  # full-ish and half-empty heads
+    ring0 = (torch.rand(H, S, a.history_window_size, generator=gen) * 1e-2).to(dtype)
+    den0 = torch.randint(1, 500, (H, S), generator=gen, dtype=torch.int32)
+    sp0 = torch.rand(H, S, generator=gen) < 0.02
+    pu0 = torch.rand(H, S, generator=gen) < 0.02
+    for kv in (a, b):
+        kv.update_kv(torch.arange(T, device=DEV), k0, v0, True, input_ids=torch.zeros(T, dtype=torch.int64, device=DEV))
+        # a decode-ready state without the profiling pass: head h runs policy h % n
+        kv.cache_strategies = (torch.arange(H, device=DEV) % len(strategies)).to(torch.int64).contiguous()
+        kv.requires_heavy_hitter = any("heavy_hitter" in s["strategy"] for s in strategies)
+        kv.cache_cts.copy_(fill.to(DEV))
+        live = torch.arange(S, device=DEV).view(1, S) < fill.to(DEV).view(H, 1)
+        kv.mask[0, :, 0, :] = live
+        kv.pos[0] = torch.where(live, torch.arange(S, device=DEV, dtype=kv.pos.dtype).view(1, S).expand(H, S), torch.full_like(kv.pos[0], -1))
+        kv.attn_history_num.copy_(ring0.to(DEV).unsqueeze(0))
+        kv.attn_history_denom.copy_(den0.to(DEV).unsqueeze(0))
+        if hasattr(kv, "special_mask"):
+            kv.special_mask[0] = sp0.to(DEV) & live
+            kv.num_special.fill_(int(sp0[0, : int(fill[0])].sum()))
+        if hasattr(kv, "punc_mask"):
+            kv.punc_mask[0] = pu0.to(DEV) & live
+            kv.num_punc.fill_(3)
+    assert b.supports_fused_step()
+    for t in range(steps):
+        p = torch.tensor([T + t], dtype=torch.int32, device=DEV)
+        ids = torch.tensor([[6 if t % 5 == 2 else 11]], dtype=torch.int64, device=DEV)  # every fifth token is punctuation
+        k1 = torch.randn(1, H, 1, D, generator=gen).to(dtype).to(DEV)
+        v1 = torch.randn(1, H, 1, D, generator=gen).to(dtype).to(DEV)
+        q = torch.randn(1, HQ, 1, D, generator=gen).to(dtype).to(DEV)
+        ka, va, ma = a.update_kv(p, k1, v1, False, input_ids=ids)
+        hist = a.fused_history()
+        ya, attn = sdpa(q, ka, va, attn_mask=ma, return_attn=a.return_attn() and hist is None, group_mean=True, history=hist)
+        if hist is not None:
+            a._state_fused = True
+        a.update_state(p, k1, v1, False, attn, input_ids=ids)
+        yb = b.decode_step(q, k1, v1, p, input_ids=ids)
+        torch.cuda.synchronize()
+        assert torch.equal(ya, yb), f"step {t}: attention output"
+        for (na, ta), (nb, tb) in zip(a.named_buffers(), b.named_buffers()):
+            if na != "next_key":
+                assert torch.equal(ta, tb), f"step {t}: {na}"
+    assert b._next_valid

@@ -102,6 +102,10 @@ def main():
                 for kv in caches:
                     kv.prepare_decode(pos)
                 res["fused_step_us"] = round(timed(lambda i: caches[i % n_buf].decode_step(q, k1, k1, pos), n_buf), 2)
+            if strategy == "hybrid" and caches[0].supports_fused_step():
+                for kv in caches:
+                    kv.prepare_decode(pos)
+                res["fused_step_us"] = round(timed(lambda i: caches[i % n_buf].decode_step(q, k1, k1, pos, input_ids=ids), n_buf), 2)
             b = 2 * H * S * D * 2
             res["kv_MB"] = round(b / 1e6, 1)
             best = res.get("fused_step_us", res["three_call_us"])
