@@ -1023,6 +1023,90 @@ class KVCacheKeepItOdd(KVCacheHeadConstant):
         return scores
 
 
+class KVCacheAnalysis(KVCacheFull):
+    """`debug_<strategy>` (ref: cache.py:1291-1420): the model attends over a FULL cache while a shadow cache of the
+    analysed strategy is kept beside it, fed with the attention restricted to the slots it still holds; the attention
+    mass it lost — 1 - sum of the probabilities of its surviving tokens, averaged over heads — is recorded per decode step
+    (`attention_losses`) and reported by compute_statistics (`attention_loss`, `attention_loss@500`, ...).
+
+    At the reference commit this class cannot be constructed: its `full_kwargs` (cache.py:1319-1324) omit `cache_bits`,
+    which KVCache.__init__ reads (cache.py:181 -> AttributeError).  What is implemented — and pinned by
+    tests/golden/f10_analysis_* — is the INTENDED behaviour: the reference's own code with that one keyword supplied
+    (cache_bits=None for the full cache; oracle/gen_golden.py injects exactly that and nothing else).
+
+    As in the reference: the analysed cache must return attention (heavy_hitter, hybrid with a heavy-hitter policy) —
+    for the others model.py hands update_state `attn=None` at decode time and the reference fails on `attn.shape`
+    (raised here as a ColdCompressError); for a head-constant shadow cache the loss would be taken from kv head 0 only
+    (gather with a [1, 1, S] index, cache.py:1393)."""
+    relevant_kwargs = ["max_cache_length", "max_seq_length", "cache_bits", "history_window_size", "recent_window",
+                       "attn_thresholding", "global_tokens", "prompt_compression_strategy"]
+
+    def __init__(self, max_batch_size, n_heads, head_dim, dtype=torch.bfloat16, cache_strategy="heavy_hitter", **kwargs):
+        full_kwargs = {"global_tokens": 0, "max_cache_length": kwargs["max_seq_length"],
+                       "prompt_compression_strategy": kwargs["prompt_compression_strategy"],
+                       "cache_bits": None}  # <- the keyword the reference forgot
+        super().__init__(max_batch_size, n_heads, head_dim, dtype, **full_kwargs)
+        self.compressed = get_cache_constructor(cache_strategy)[0](max_batch_size, n_heads, head_dim, dtype, **kwargs)
+        self.register_buffer("attention_losses", torch.full((self.max_cache_length,), -1, dtype=dtype))
+        self.register_buffer("attention_loss_ctr", torch.zeros((1,), dtype=torch.int32))
+        self.prompt_compressor = get_prompt_compressor_constructor(self.prompt_compression_strategy)(
+            head_specific=self.compressed.head_specific, **kwargs)
+        self.head_specific = self.compressed.head_specific  # compatibility check of the prompt compressor (model.py:225)
+
+    def supports_fused_step(self):
+        return False  # the full cache must hand the attention row to update_state
+
+    def return_attn(self):
+        return self.compressed.return_attn()
+
+    def update_kv(self, input_pos, k_val, v_val, is_prefill, **kwargs):
+        k, v, mask = super().update_kv(input_pos, k_val, v_val, is_prefill, **kwargs)
+        # a prompt longer than the shadow cache is compressed in update_state (it may need the attention)
+        if input_pos.shape[-1] < self.compressed.max_cache_length:
+            self.compressed.update_kv(input_pos, k_val, v_val, is_prefill, **kwargs)
+        return k, v, mask
+
+    def reset(self):
+        super().reset()
+        self.compressed.reset()
+        self.attention_losses.fill_(-1)
+        self.attention_loss_ctr.zero_()
+
+    def update_state(self, input_pos, k_val, v_val, is_prefill, attn, **kwargs):
+        if is_prefill and input_pos.shape[-1] > self.compressed.max_cache_length:
+            input_pos, k_val, v_val, attn = self.prompt_compressor(input_pos, k_val, v_val, attn=attn)
+            self.compressed.update_kv(input_pos, k_val, v_val, is_prefill)
+            self.compressed.update_state(input_pos, k_val, v_val, is_prefill, attn)
+        elif is_prefill:  # no loss at prefill: compressed and uncompressed attention are the same
+            self.compressed.update_state(input_pos, k_val, v_val, is_prefill, attn)
+        else:
+            if attn is None:
+                raise ColdCompressError(f"debug_{type(self.compressed).__name__}: the analysed cache returns no attention, so there "
+                                        "is nothing to measure (the reference fails here on `attn.shape`, cache.py:1395)")
+            _need_device(attn, "attn")
+            S_full = attn.shape[-1]
+            Hp, S = self.compressed.pos.shape[1], self.compressed.max_cache_length
+            idx = self.compressed.pos.reshape(Hp, S).to(torch.int64)
+            idx = torch.where(idx == -1, torch.full_like(idx, S_full - 1), idx).contiguous()  # unfilled -> the last (zero) column
+            src = attn.reshape(-1, S_full)[:Hp].contiguous()  # a [1, 1, S] index gathers kv head 0 only (cache.py:1393)
+            sub = torch.empty((1, Hp, S), dtype=attn.dtype, device=attn.device)
+            _abi.call("cc_gather_vec", _ptr(src), _ptr(idx), Hp, S_full, S, _DT[attn.dtype], _ptr(sub), _stream())
+            self.compressed.update_state(input_pos, k_val, v_val, is_prefill, sub)
+            # the attention mass of the evicted tokens = 1 - the mass of the tokens the shadow cache still holds
+            loss = (1 - sub.sum(dim=-1)).mean()
+            self.attention_losses[self.attention_loss_ctr.to(torch.int64)] = loss
+            self.attention_loss_ctr += 1
+
+    def compute_statistics(self, seq_len):
+        stats = super().compute_statistics(seq_len)
+        losses = self.attention_losses[: int(self.attention_loss_ctr)]
+        assert not torch.any(losses == -1)
+        for k in range(500, len(losses), 500):
+            stats[f"attention_loss@{k}"] = losses[:k].mean().item()
+        stats["attention_loss"] = losses.mean().item()
+        return stats
+
+
 def get_cache_constructor(cache_strategy):
     """ref: cache.py:1444-1478 -> (constructor, relevant_kwargs)."""
     table = {
@@ -1037,11 +1121,12 @@ def get_cache_constructor(cache_strategy):
     if cache_strategy in table:
         cls = table[cache_strategy]
         return cls, cls.relevant_kwargs
-    if cache_strategy.startswith("debug"):
+    if cache_strategy.startswith("debug"):  # ref: cache.py:1460-1474
         name = re.sub(r"debug_+", "", cache_strategy).strip()
-        if name in table:
-            raise NotImplementedError(
-                f"cache strategy '{cache_strategy}': the reference's KVCacheAnalysis cannot be constructed at this commit "
-                "(cache.py:1319-1324 passes the full cache no cache_bits -> AttributeError in KVCache.__init__, cache.py:181), "
-                "so there is no behaviour to reproduce or pin")
+        rk = get_cache_constructor(name)[1] + ["prompt_compression_strategy"]
+
+        def ctor(max_batch_size, n_heads, head_dim, dtype, **kwargs):
+            return KVCacheAnalysis(max_batch_size, n_heads, head_dim, dtype, cache_strategy=name, **kwargs)
+
+        return ctor, rk
     raise ValueError(f"Invalid cache strategy: {cache_strategy}")

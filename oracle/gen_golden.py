@@ -530,6 +530,63 @@ def hybrid_case(C, dtype, strategies, min_recovery, seed, H=4, L=48, S=96, D=16,
     return pack(rec)
 
 
+# ------------------------------------------------------------------------------------------------ F10
+
+
+def analysis_case(C, dtype, seed, H=2, D=16, S=24, S_full=96, L=40, steps=24, g=2, w=3):
+    """KVCacheAnalysis (`debug_heavy_hitter`, cache.py:1291-1420): a full cache with a shadow compressed cache and the
+    attention-loss metric, driven as model.py:389-427 does (the shadow cache is larger than the SnapKV observation window
+    plus the sinks, so that real priorities — not a 16-way tie at 1.0 — decide part of the keep set).  At this commit the class cannot be constructed — its
+    `full_kwargs` (cache.py:1319-1324) omits `cache_bits`, which KVCache.__init__ reads (cache.py:181) — so the fixture pins
+    the INTENDED behaviour: the one missing keyword is injected (cache_bits=None for the full cache) by wrapping
+    KVCacheFull.__init__ for the duration of the capture; nothing else of the reference is altered."""
+    gen = torch.Generator().manual_seed(seed)
+    orig_init = C.KVCacheFull.__init__
+
+    def patched(self, *a, **k):
+        k.setdefault("cache_bits", None)
+        return orig_init(self, *a, **k)
+
+    C.KVCacheFull.__init__ = patched
+    try:
+        cls, rk = C.get_cache_constructor("debug_heavy_hitter")
+        kw = dict(max_cache_length=S, global_tokens=g, max_seq_length=S_full, cache_bits=None, recent_window=w,
+                  history_window_size=1, attn_thresholding=False, prompt_compression_strategy="heavy_hitter")
+        kv = cls(1, H, D, dtype, **{k: kw[k] for k in rk})
+    finally:
+        C.KVCacheFull.__init__ = orig_init
+    rec = {"H": H, "D": D, "S": S, "S_full": S_full, "L": L, "steps": steps, "g": g, "w": w,
+           "dtype": np.array(str(dtype).split(".")[-1]), "relevant_kwargs_json": json.dumps(rk)}
+    k0 = torch.randn(1, H, L, D, generator=gen).to(dtype)
+    v0 = torch.randn(1, H, L, D, generator=gen).to(dtype)
+    pos0 = torch.arange(L)
+    causal = torch.tril(torch.ones(L, L, dtype=torch.bool)).view(1, 1, L, L)
+    attn0 = softmax_rows((1, H, L, L), dtype, gen, causal.expand(1, H, L, L))
+    kv.update_kv(pos0, k0, v0, True)
+    kv.update_state(pos0, k0, v0, True, attn0)
+    rec.update({"k0": k0, "v0": v0, "attn0": attn0, "comp_pos_after_prefill": kv.compressed.pos.clone(),
+                "comp_num_after_prefill": kv.compressed.attn_history_num.clone(), "full_pos_after_prefill": kv.pos.clone()})
+    ks, vs, attns, comp_pos, losses = [], [], [], [], []
+    for t in range(steps):
+        p = torch.tensor([L + t], dtype=torch.int32)
+        k1 = torch.randn(1, H, 1, D, generator=gen).to(dtype)
+        v1 = torch.randn(1, H, 1, D, generator=gen).to(dtype)
+        kc, vc, m = kv.update_kv(p, k1, v1, False)
+        a = softmax_rows((1, H, 1, S_full), dtype, gen, m.clone())  # attention over the FULL cache (group mean already taken)
+        kv.update_state(p, k1, v1, False, a)
+        ks.append(k1)
+        vs.append(v1)
+        attns.append(a)
+        comp_pos.append(kv.compressed.pos.clone())
+        losses.append(kv.attention_losses[t].clone())
+    st = kv.compute_statistics(torch.tensor(L + steps))
+    rec.update({"k_new": torch.stack(ks), "v_new": torch.stack(vs), "attn": torch.stack(attns), "comp_pos_steps": torch.stack(comp_pos),
+                "loss_steps": torch.stack(losses), "final_full_pos": kv.pos.clone(), "final_comp_num": kv.compressed.attn_history_num.clone(),
+                "final_comp_denom": kv.compressed.attn_history_denom.clone(), "final_comp_k": kv.compressed.k_cache.clone(),
+                "loss_ctr": kv.attention_loss_ctr.clone(), "stats_json": json.dumps({k: float(v) for k, v in st.items()})})
+    return pack(rec)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
@@ -542,6 +599,13 @@ def main():
     def save(name, d):
         np.savez_compressed(os.path.join(a.out, name), **d)
         print("wrote", name, sum(v.nbytes for v in d.values()) // 1024, "KiB")
+
+    # F10: debug_* (KVCacheAnalysis): shadow compressed cache + attention-loss metric, intended behaviour
+    if a.only in (None, "f10"):
+        save("f10_analysis_hh_f32.npz", analysis_case(C, torch.float32, seed=71))
+        save("f10_analysis_hh_bf16.npz", analysis_case(C, torch.bfloat16, seed=72, steps=40))
+        if a.only == "f10":
+            return
 
     # F6: hybrid (FastGen) prefill profiling + decode traces
     if a.only in (None, "f6"):

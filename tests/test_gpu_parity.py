@@ -478,3 +478,54 @@ def test_topk_decode_attention_matches_reference():
         assert (p.cpu() - f[f"p_{pct}"]).abs().max() < 1e-5
     with pytest.raises(AssertionError, match="Top-k attention not supported with masks"):
         sdpa(q, k, v, attn_mask=torch.ones(1, 4, 1, 64, dtype=torch.bool, device=DEV), return_attn=True, attn_top_k=0.5)
+
+
+@pytest.mark.parametrize("name", ["f10_analysis_hh_f32.npz", "f10_analysis_hh_bf16.npz"])
+def test_debug_analysis_cache_vs_reference(name):
+    """`debug_heavy_hitter` (KVCacheAnalysis, cache.py:1291-1420) replayed on the reference's own trace — captured with the
+    one keyword its constructor forgets injected (oracle/gen_golden.py: analysis_case): prompt longer than the shadow cache
+    (SnapKV compaction inside update_state), then decode steps with the attention over the FULL cache given; the shadow
+    cache's positions after every step exactly, its history and the recorded attention losses to the dtype's rounding."""
+    import json
+
+    import cold_compress_amd.cache as cache
+
+    f = load_golden(name)
+    dtype = DT_FROM_NAME[f["dtype"]]
+    H, D, S, SF, L, steps, g, w = f["H"], f["D"], f["S"], f["S_full"], f["L"], f["steps"], f["g"], f["w"]
+    ctor, rk = cache.get_cache_constructor("debug_heavy_hitter")
+    kw = dict(max_cache_length=S, global_tokens=g, max_seq_length=SF, cache_bits=None, recent_window=w, history_window_size=1,
+              attn_thresholding=False, prompt_compression_strategy="heavy_hitter")
+    with torch.device(DEV):
+        kv = ctor(1, H, D, dtype, **{k: kw[k] for k in rk})
+    pos0 = torch.arange(L, device=DEV)
+    k0, v0 = f["k0"].to(DEV), f["v0"].to(DEV)
+    kv.update_kv(pos0, k0, v0, True)
+    kv.update_state(pos0, k0, v0, True, f["attn0"].to(DEV))
+    torch.cuda.synchronize()
+    assert torch.equal(kv.pos.cpu(), f["full_pos_after_prefill"])
+    tie_ok = dtype != torch.float32  # 16-bit SnapKV priorities can tie at the boundary (SURVEY 8(c)(2)): then only the set size is pinned
+    same_keep = torch.equal(kv.compressed.pos.cpu(), f["comp_pos_after_prefill"])
+    assert same_keep or tie_ok
+    if not same_keep:
+        pytest.skip("boundary tie in the 16-bit prompt-compaction priorities: the traces diverge legitimately")
+    tol = dict(rtol=2 ** -7, atol=1e-6) if dtype != torch.float32 else dict(rtol=1e-5, atol=1e-7)
+    assert torch.allclose(kv.compressed.attn_history_num.cpu().float(), f["comp_num_after_prefill"].float(), **tol)
+    kv.compressed.attn_history_num.copy_(f["comp_num_after_prefill"].to(DEV))  # column-sum order is unspecified: continue on equal state
+    for t in range(steps):
+        p = torch.tensor([L + t], dtype=torch.int32, device=DEV)
+        k1, v1 = f["k_new"][t].to(DEV), f["v_new"][t].to(DEV)
+        kv.update_kv(p, k1, v1, False)
+        kv.update_state(p, k1, v1, False, f["attn"][t].to(DEV))
+        torch.cuda.synchronize()
+        assert torch.equal(kv.compressed.pos.cpu(), f["comp_pos_steps"][t]), f"step {t}: shadow cache positions"
+        ulp = 2 ** -7 if dtype != torch.float32 else 1e-6
+        assert abs(float(kv.attention_losses[t]) - float(f["loss_steps"][t])) <= ulp * max(1.0, abs(float(f["loss_steps"][t]))), f"step {t}: loss"
+    assert int(kv.attention_loss_ctr) == int(f["loss_ctr"]) == steps
+    assert torch.equal(kv.pos.cpu(), f["final_full_pos"])
+    assert torch.equal(kv.compressed.attn_history_denom.cpu(), f["final_comp_denom"])
+    assert torch.allclose(kv.compressed.attn_history_num.cpu().float(), f["final_comp_num"].float(), **tol)
+    assert (kv.compressed.k_cache.cpu().float() - f["final_comp_k"].float()).abs().max() == 0
+    st, ref = kv.compute_statistics(torch.tensor(L + steps)), json.loads(f["stats_json"])
+    assert abs(st["attention_loss"] - ref["attention_loss"]) <= (2 ** -7 if dtype != torch.float32 else 1e-6)
+    assert abs(st["compression_ratio"] - ref["compression_ratio"]) < 1e-6

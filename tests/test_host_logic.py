@@ -7,6 +7,7 @@ import json
 import os
 import re
 
+import numpy as np
 import pytest
 import torch
 
@@ -115,8 +116,16 @@ def test_buffers_and_statistics_on_cpu():
     for cls, extra in ((cache.KVCacheL2, dict(recent_window=3)), ):
         with pytest.raises(NotImplementedError):  # reference crashes: norm of the int8 image
             cls(1, 2, 8, torch.bfloat16, max_cache_length=16, global_tokens=2, max_seq_length=64, cache_bits=8, **extra)
-    with pytest.raises(NotImplementedError):  # KVCacheAnalysis cannot be constructed in the reference either
-        cache.get_cache_constructor("debug_heavy_hitter")
+    # debug_<strategy> (cache.py:1460-1474): a constructor + the analysed strategy's kwargs + prompt_compression_strategy
+    ctor, rk = cache.get_cache_constructor("debug_heavy_hitter")
+    assert rk == cache.KVCacheHeavyHitter.relevant_kwargs + ["prompt_compression_strategy"]
+    f10 = json.loads(str(np.load(os.path.join(GOLDEN, "f10_analysis_hh_f32.npz"))["relevant_kwargs_json"]))
+    assert rk == f10  # the reference's list (captured with its missing cache_bits keyword injected)
+    an = ctor(1, 2, 8, torch.bfloat16, **{**kw, "prompt_compression_strategy": "heavy_hitter"})
+    assert isinstance(an, cache.KVCacheAnalysis) and an.max_cache_length == 64 and an.compressed.max_cache_length == 16
+    assert an.attention_losses.shape == (64,) and bool((an.attention_losses == -1).all()) and an.return_attn() and an.head_specific
+    with pytest.raises(ValueError):
+        cache.get_cache_constructor("debug_nonsense")
     ring = cache.KVCacheHeavyHitter(1, 2, 8, torch.bfloat16, **{**kw, "history_window_size": 4})
     assert ring.attn_history_num.shape == (1, 2, 16, 4) and ring.attn_history_num.dtype == torch.bfloat16  # cache.py:661-667
     hist = ring.fused_history()  # W > 1: ring, denom, counter, W, tracked accumulators, window sums (no launch: state is current)
