@@ -115,11 +115,21 @@ SIGNATURES = {
     "cc_add_rmsnorm": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _f32, _i32, _vp, _vp, _vp]),
     "cc_qkv_rope": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "cc_silu_mul": (C.c_int, [_vp, _vp, C.c_int64, _i32, _vp, _vp]),
+    "cc_allreduce_handle_bytes": (_sz, []),
+    "cc_allreduce_create": (C.c_int, [_i32, _i32, _sz, C.POINTER(_vp)]),
+    "cc_allreduce_export": (C.c_int, [_vp, _vp]),
+    "cc_allreduce_connect": (C.c_int, [_vp, _vp]),
+    "cc_allreduce_sum": (C.c_int, [_vp, _vp, C.c_int64, _i32, _vp]),
+    "cc_allreduce_status": (_i32, [_vp]),
+    "cc_allreduce_destroy": (C.c_int, [_vp]),
 }
 
 # entry points that only the device library has (no `_cpu` twin)
 DEVICE_ONLY = {"cc_error_string", "cc_device_info", "cc_decode_step_single_launch", "cc_decode_step_status_offset",
-               "cc_decode_step_trace", "cc_decode_step_set_single_launch"}
+               "cc_decode_step_trace", "cc_decode_step_set_single_launch",
+               # inter-GPU transport: no CPU twin (the oracle of the all-reduce is torch.distributed's)
+               "cc_allreduce_handle_bytes", "cc_allreduce_create", "cc_allreduce_export", "cc_allreduce_connect", "cc_allreduce_sum",
+               "cc_allreduce_status", "cc_allreduce_destroy"}
 CC_PHASE_TWO_LAUNCH, CC_PHASE_ONE_LAUNCH = 0x10000, 0x20000
 
 

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(CSRC, "libcoldcompress_hip.so")
 SOURCES = ["cc_api.hip", "cc_evict.hip", "cc_attn_decode.hip", "cc_compact.hip", "cc_attn_prefill.hip", "cc_glue.hip",
-           "cc_hybrid.hip", "cc_attn_prefill_mfma.hip", "cc_quant.hip", "cc_gemv.hip"]
+           "cc_hybrid.hip", "cc_attn_prefill_mfma.hip", "cc_quant.hip", "cc_gemv.hip", "cc_allreduce.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 
 

@@ -41,6 +41,8 @@ def maybe_init_dist() -> Optional[int]:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend=backend, rank=int(os.environ.get("RANK", rank)),
                                 world_size=int(os.environ.get("WORLD_SIZE", world)))
+    if os.environ.get("CC_ONESHOT_ALLREDUCE") == "1" and torch.cuda.is_available():
+        enable_oneshot_allreduce()
     return rank
 
 
@@ -72,8 +74,75 @@ def _apply_tp_linear(linear: nn.Linear, style: str, weight_splits: List[int] = (
     setattr(linear, attr, getattr(linear, attr) // world)
 
 
+class OneShotAllReduce:
+    """The hand-written one-shot xGMI all-reduce of include/coldcompress.h (`cc_allreduce_*`) for the decode-size
+    messages: every rank stores its vector into every peer's IPC-mapped buffer, flags, waits, and sums in rank order — one
+    launch, capturable, bitwise-identical on all ranks.  Handles travel through torch.distributed (any backend).  Larger
+    messages (prefill) stay on RCCL."""
+
+    def __init__(self, max_bytes=64 * 1024, group=None):
+        import ctypes as C
+
+        from . import _abi
+
+        self._abi, self._C = _abi, C
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.max_bytes = int(max_bytes)
+        fns = _abi.lib()
+        comm = C.c_void_p()
+        _abi.check(fns["cc_allreduce_create"](self.rank, self.world, self.max_bytes, C.byref(comm)), "cc_allreduce_create")
+        self._comm = comm
+        nb = int(fns["cc_allreduce_handle_bytes"]())
+        mine = (C.c_uint8 * nb)()
+        _abi.check(fns["cc_allreduce_export"](comm, mine), "cc_allreduce_export")
+        on_dev = dist.get_backend(group) == "nccl"
+        dev = torch.device("cuda", torch.cuda.current_device()) if on_dev else torch.device("cpu")
+        h = torch.tensor(list(mine), dtype=torch.uint8, device=dev)
+        allh = [torch.empty_like(h) for _ in range(self.world)]
+        dist.all_gather(allh, h, group=group)
+        flat = torch.cat([t.cpu() for t in allh]).contiguous()
+        buf = (C.c_uint8 * flat.numel()).from_buffer_copy(flat.numpy().tobytes())
+        _abi.check(fns["cc_allreduce_connect"](comm, buf), "cc_allreduce_connect")
+        dist.barrier(group=group)  # every rank has mapped every buffer before the first store into one
+
+    def fits(self, t):
+        return t.is_cuda and t.is_contiguous() and t.numel() * t.element_size() <= self.max_bytes and t.data_ptr() % 16 == 0 \
+            and t.dtype in (torch.float32, torch.bfloat16, torch.float16)
+
+    def all_reduce(self, t):
+        """In place, on the current stream."""
+        code = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}[t.dtype]
+        st = self._C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        self._abi.check(self._abi.lib()["cc_allreduce_sum"](self._comm, self._C.c_void_p(t.data_ptr()), t.numel(), code, st),
+                        "cc_allreduce_sum")
+        return t
+
+    def status(self):
+        return int(self._abi.lib()["cc_allreduce_status"](self._comm))
+
+    def close(self):
+        if self._comm is not None:
+            self._abi.lib()["cc_allreduce_destroy"](self._comm)
+            self._comm = None
+
+
+_ONESHOT = None
+
+
+def enable_oneshot_allreduce(max_bytes=64 * 1024):
+    """Route the two per-layer all-reduces of apply_tp through `OneShotAllReduce` when the message fits (decode), RCCL
+    otherwise.  Opt-in (also CC_ONESHOT_ALLREDUCE=1 at maybe_init_dist time): RCCL is the default transport."""
+    global _ONESHOT
+    if _ONESHOT is None:
+        _ONESHOT = OneShotAllReduce(max_bytes)
+    return _ONESHOT
+
+
 def _all_reduce_hook(_module, _input, output):
-    dist.all_reduce(output, op=dist.ReduceOp.SUM)
+    if _ONESHOT is not None and _ONESHOT.fits(output):
+        _ONESHOT.all_reduce(output)
+    else:
+        dist.all_reduce(output, op=dist.ReduceOp.SUM)
     return output
 
 

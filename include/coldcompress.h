@@ -516,6 +516,31 @@ size_t cc_softmax_argmax_workspace_bytes(void);
 int cc_softmax_argmax(const void* logits, int32_t V, int32_t dtype, void* probs, int32_t* idx_out, void* workspace,
                       size_t workspace_bytes, cc_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * One-shot sum all-reduce over the GPUs of ONE node, for the decode-size messages of tensor parallelism.
+ * ref: tp.py:134-138, 156-160 (`all_reduce(sum)` of the wo and FFN outputs: 2 * dim bytes, 8-16 KiB, twice per layer).
+ * Every rank stores its vector straight into a slot of every peer's buffer over the xGMI mesh, raises a flag, waits for the
+ * flags raised for it, and adds the `world` slots in RANK ORDER (fp32 accumulate, one rounding): one launch of one workgroup,
+ * no ring hops, capturable in a hipGraph, bitwise-identical results on every rank.  RCCL (torch.distributed "nccl") remains
+ * the general collective and the oracle this is tested against (tests/test_gpu_tp.py).
+ *   cc_allreduce_create   allocates this rank's symmetric buffer (uncached fine-grained device memory; the ONE allocating,
+ *                         synchronising entry point of this ABI: call it at start-up, not on the decode path);
+ *   cc_allreduce_export   copies the buffer's hipIpcMemHandle_t (cc_allreduce_handle_bytes() bytes) into HOST memory;
+ *   cc_allreduce_connect  takes the world's handles in rank order (HOST memory; the host exchanges them, e.g. with
+ *                         torch.distributed.all_gather) and maps the peers' buffers;
+ *   cc_allreduce_sum      in place on `data` (device, 16-byte aligned, n elements of `dtype`, n * size <= max_bytes); every
+ *                         rank must call it in the same order on its stream; never synchronises;
+ *   cc_allreduce_status   0, or 1 if an all-reduce gave up waiting for a peer (bounded polling) — synchronising read.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct cc_comm cc_comm;
+size_t cc_allreduce_handle_bytes(void);
+int cc_allreduce_create(int32_t rank, int32_t world, size_t max_bytes, cc_comm** out);
+int cc_allreduce_export(cc_comm* comm, void* handle_out);
+int cc_allreduce_connect(cc_comm* comm, const void* handles);
+int cc_allreduce_sum(cc_comm* comm, void* data, int64_t n, int32_t dtype, cc_stream_t stream);
+int32_t cc_allreduce_status(cc_comm* comm);
+int cc_allreduce_destroy(cc_comm* comm);
+
 #ifdef __cplusplus
 }
 #endif

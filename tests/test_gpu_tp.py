@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _launch(extra, world=2, timeout=600):
+def _launch(extra, world=2, timeout=600, script="tp2_check.py", marker=None):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -26,10 +26,10 @@ def _launch(extra, world=2, timeout=600):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_PORT"):
         env.pop(k, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "tools", "tp2_check.py")] + extra
+           "--master-port", str(port), os.path.join(ROOT, "tools", script)] + extra
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
     assert r.returncode == 0, f"{' '.join(cmd)}\n{r.stdout[-3000:]}\n{r.stderr[-3000:]}"
-    assert f"TP{world} CHECK OK" in r.stdout, r.stdout[-3000:]
+    assert (marker or f"TP{world} CHECK OK") in r.stdout, r.stdout[-3000:]
     return r.stdout
 
 
@@ -43,3 +43,14 @@ def test_tp2_rccl_matches_unsharded(graph):
 def test_tp2_one_gpu_staged_collectives_matches_unsharded():
     out = _launch(["--backend", "gloo"])
     assert "backend gloo world 2" in out
+
+
+def test_oneshot_allreduce_two_ranks_on_one_gpu():
+    """cc_allreduce_* with two ranks sharing cuda:0: IPC-mapped peer buffers, remote stores, flags, epochs, the two alternating
+    slot sets and hipGraph replays run for real, against the rank-ordered fp32 sum computed on the host (bit-exact)."""
+    _launch(["--one_gpu"], script="allreduce_check.py", marker="ONESHOT ALLREDUCE CHECK OK")
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: the stores cross xGMI")
+def test_oneshot_allreduce_over_xgmi():
+    _launch([], script="allreduce_check.py", marker="ONESHOT ALLREDUCE CHECK OK")
