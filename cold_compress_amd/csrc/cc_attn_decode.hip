@@ -576,7 +576,7 @@ __global__ __launch_bounds__(NW * 64, ONE ? 2 : 1) void decode_attn_split_mfma_k
     }
   }
   // ONE: this lane's slot of the per-slot pass (lane c = t * LPR of row group g finishes row 4g + t of the wave's tile): its
-  // history and position are requested behind the first K/V tile and consumed after the hand-off
+  // history and position are requested here, with everything else, and consumed after the hand-off
   unsigned long long tr0 = 0, tr1 = 0, tr2 = 0, tr3 = 0, tr4 = 0, rt0 = 0, rt1 = 0;
   if constexpr (ONE) {
     if (a.trace) {
@@ -591,9 +591,20 @@ __global__ __launch_bounds__(NW * 64, ONE ? 2 : 1) void decode_attn_split_mfma_k
   constexpr int KH = RT / LPR;
   const int one_slot = row_begin + wave * (RPW * U) + g * U + c / LPR;
   const bool one_have = ONE && c < U * LPR && (c % LPR) == 0 && one_slot < row_end;
+  float one_rnd = 0.f;
   if constexpr (ONE) {
     one_tag = a.one_hdr[h] + 1u;
     one_pin = *a.input_pos;
+    // requested AHEAD of the K/V tile (measured: behind it the step is 0.3 us slower — the tile's in-order waits then end on
+    // these stragglers, and the workgroup leaves the streaming part later)
+    if (one_have) {
+      if (a.num) {
+        one_num = a.num[(size_t)h * S + one_slot];
+        one_den = a.denom[(size_t)h * S + one_slot];
+      }
+      one_ps = a.pos[(a.Hp == 1 ? 0 : (size_t)h * S) + one_slot];
+      if (a.policy == 3) one_rnd = a.rand_next[one_slot];
+    }
   }
   float s_keep[U] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};  // ONE: the wave's (single) tile of scores, kept for the per-slot pass
   // B operand: lane (n = c, kb = g) of step j holds q[head n][8 * (4j + g) .. + 8]; columns n >= RT are zero
@@ -634,17 +645,6 @@ __global__ __launch_bounds__(NW * 64, ONE ? 2 : 1) void decode_attn_split_mfma_k
   if (more) {
     issue_k(base);
     issue_v(base);
-  }
-  float one_rnd = 0.f;
-  if constexpr (ONE) {  // behind the K/V requests: nothing on the streaming path waits for these
-    if (one_have) {
-      if (a.num) {
-        one_num = a.num[(size_t)h * S + one_slot];
-        one_den = a.denom[(size_t)h * S + one_slot];
-      }
-      one_ps = a.pos[(a.Hp == 1 ? 0 : (size_t)h * S) + one_slot];
-      if (a.policy == 3) one_rnd = a.rand_next[one_slot];
-    }
   }
 
   while (more) {
@@ -882,8 +882,8 @@ __global__ __launch_bounds__(NW * 64, ONE ? 2 : 1) void decode_attn_split_mfma_k
     //   publish   the workgroup's (m, l, O[RT][128]) partial as 16-byte granules {tag, x, tag, y}: write-through
     //             (sc0 sc1) stores; each 8-byte half validates itself, so no flag, no fence and no store ordering;
     //   gather    wave r collects the n_split (m, l) pairs of query head r (lane = split) and every thread its share
-    //             of the O granules of the output columns this workgroup finishes — coherent loads, re-read until every
-    //             tag is this launch's.  Tags only ever grow (the epoch words live in the workspace and are bumped once
+    //             of the O granules of the output columns this workgroup finishes — coherent loads, re-read (s_sleep
+    //             between rounds) until every tag is this launch's.  Tags only ever grow (the epoch words live in the workspace and are bumped once
     //             per launch and head), so a granule left by any earlier launch, layer or shape can never match;
     //   finish    the final (M, L) per head in the combine kernel's exact order; then this workgroup's 64 slots —
     //             probabilities from the scores still in registers, group mean, history update, next-eviction key —
@@ -954,17 +954,40 @@ __global__ __launch_bounds__(NW * 64, ONE ? 2 : 1) void decode_attn_split_mfma_k
       o_lds[k] = (i * ppw + qq) * 2;
     }
     bool timed_out = false;
-    if (!(a.abl & 1)) {  // one wave watches query head 0's (m, l) granules; the others sleep at the barrier instead of polling
+    if (a.abl & 1) {  // measurement variant: one wave watches query head 0's (m, l) granules first while the others sleep at the
+                      // barrier (1 KiB instead of 8 KiB per workgroup and round, at the price of a second fabric round trip:
+                      // 10.99 vs 10.63 us at S = 4096 once every round really re-reads memory)
       if (wave == 0) {
         const int off0 = ((h * ns + (lane < ns ? lane : 0)) * RT) * 16;
-        for (unsigned spins = 0;; spins++) {
-          const u32x4_t x = __builtin_amdgcn_raw_buffer_load_b128(ml_rsrc, off0, 0, kOneAuxCoherent);
-          if (__all(x[0] == tag && x[2] == tag)) break;
-          if (spins > kOneSpinMax) {
-            timed_out = true;
-            break;
+        if (a.abl & 4) {
+          // measurement variant: two polls in flight, alternating registers (each check waits for ITS load only)
+          u32x4_t x0 = __builtin_amdgcn_raw_buffer_load_b128(ml_rsrc, off0, 0, kOneAuxCoherent);
+          __builtin_amdgcn_s_sleep(4);
+          asm volatile("" ::: "memory");
+          u32x4_t x1 = __builtin_amdgcn_raw_buffer_load_b128(ml_rsrc, off0, 0, kOneAuxCoherent);
+          for (unsigned spins = 0;; spins++) {
+            if (__all(x0[0] == tag && x0[2] == tag)) break;
+            asm volatile("" ::: "memory");
+            x0 = __builtin_amdgcn_raw_buffer_load_b128(ml_rsrc, off0, 0, kOneAuxCoherent);
+            if (__all(x1[0] == tag && x1[2] == tag)) break;
+            asm volatile("" ::: "memory");
+            x1 = __builtin_amdgcn_raw_buffer_load_b128(ml_rsrc, off0, 0, kOneAuxCoherent);
+            if (spins > kOneSpinMax) {
+              timed_out = true;
+              break;
+            }
           }
-          __builtin_amdgcn_s_sleep(1);
+        } else {
+          for (unsigned spins = 0;; spins++) {
+            asm volatile("" ::: "memory");  // every poll is a load of its own
+            const u32x4_t x = __builtin_amdgcn_raw_buffer_load_b128(ml_rsrc, off0, 0, kOneAuxCoherent);
+            if (__all(x[0] == tag && x[2] == tag)) break;
+            if (spins > kOneSpinMax) {
+              timed_out = true;
+              break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+          }
         }
       }
       __syncthreads();
@@ -972,6 +995,7 @@ __global__ __launch_bounds__(NW * 64, ONE ? 2 : 1) void decode_attn_split_mfma_k
     if (a.trace) tr3 = __builtin_amdgcn_s_memtime();
     u32x4_t mlq[MLN], oq[NOG];
     for (unsigned spins = 0;; spins++) {
+      asm volatile("" ::: "memory");  // every round re-reads memory
 #pragma unroll
       for (int k = 0; k < MLN; k++) mlq[k] = __builtin_amdgcn_raw_buffer_load_b128(ml_rsrc, ml_off[k], 0, kOneAuxCoherent);
 #pragma unroll
@@ -1040,12 +1064,21 @@ __global__ __launch_bounds__(NW * 64, ONE ? 2 : 1) void decode_attn_split_mfma_k
 #pragma unroll
         for (int kk = 0; kk < KH; kk++) {
           const int r_me = j_me * KH + kk;
-          const int src = (lane & ~15) | r_me;
-          float x = -INFINITY;
+          float x;
+          if constexpr (RT == 4) {
+            // lane c = 4t + r of the 16-lane row takes s_keep[t] of lane r: row shifts by 4t (DPP, no LDS crossbar round trips)
+            const float x1 = dpp_mov<0x114>(s_keep[1]);  // row_shr:4
+            const float x2 = dpp_mov<0x118>(s_keep[2]);  // row_shr:8
+            const float x3 = dpp_mov<0x11C>(s_keep[3]);  // row_shr:12
+            x = t_me == 0 ? s_keep[0] : (t_me == 1 ? x1 : (t_me == 2 ? x2 : x3));
+          } else {
+            const int src = (lane & ~15) | r_me;
+            x = -INFINITY;
 #pragma unroll
-          for (int t = 0; t < U; t++) {
-            const float v = __shfl(s_keep[t], src, CC_WAVE);
-            x = (t == t_me) ? v : x;
+            for (int t = 0; t < U; t++) {
+              const float v = __shfl(s_keep[t], src, CC_WAVE);
+              x = (t == t_me) ? v : x;
+            }
           }
           pr[kk] = ElemTraits<T>::rnd(__fdiv_rn(exp_nonpos(x - sm_M1[r_me]), sm_L1[r_me]));
         }

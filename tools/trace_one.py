@@ -24,7 +24,7 @@ def main():
     ap.add_argument("--S", type=int, nargs="+", default=[4096])
     ap.add_argument("--H", type=int, default=8)
     ap.add_argument("--HQ", type=int, default=32)
-    ap.add_argument("--abl", type=int, nargs="+", default=[0, 1])
+    ap.add_argument("--abl", type=int, nargs="+", default=[0, 1], help="0 = default (every thread polls), 1 = sentinel wave first")
     a = ap.parse_args()
     dev, D, H, HQ = "cuda", 128, a.H, a.HQ
     fns = _abi.lib()
