@@ -9,6 +9,8 @@
 //   P3  column-sum reduction over the NWG partials + observation-window mean (last obs_len queries)
 // Rounding points follow the reference: score -> dtype, * scale -> dtype, softmax -> dtype, group mean ->
 // dtype (model.py:416-418).  Results are deterministic run to run.
+#include <stdlib.h>
+
 #include "cc_common.h"
 
 namespace {
@@ -287,7 +289,7 @@ static int run_prefill(PfArgs a, hipStream_t st) {
   return CC_OK;
 }
 
-constexpr int kNWGMfma = 64;  // persistent workgroups per kv head on the MFMA path
+constexpr int kNWGMfma = 64;  // persistent workgroups per kv head on the MFMA path: 512 = two per CU, all co-resident
 
 // MFMA path (cc_attn_prefill_mfma.hip): 16-bit dtype, D == 128, HQ == 4*H.
 static bool mfma_eligible(int HQ, int H, int D, int dtype) {
@@ -357,7 +359,9 @@ int cc_prefill_attn_bands(const void* q, const void* k, const void* v, int32_t H
   hipStream_t st = (hipStream_t)stream;
   if (mfma_eligible(HQ, H, D, dtype) && L >= 64) {
     const int nqt = (L + 31) / 32;
-    const int nwg = nqt < kNWGMfma ? nqt : kNWGMfma;
+    int nwg = nqt < kNWGMfma ? nqt : kNWGMfma;
+    static const char* e_nwg = getenv("CC_PREFILL_NWG");  // measurement only
+    if (e_nwg && atoi(e_nwg) > 0 && atoi(e_nwg) < nwg) nwg = atoi(e_nwg);
     char* vt = reinterpret_cast<char*>(a.cpart) + align256((size_t)(2 + kMaxBands) * kNWGMfma * H * L * sizeof(float));
     const int obs_len = a.obs ? a.obs_len : 0;
     const int rc = cc_prefill_attn_mfma_impl(q, k, v, HQ, H, L, D, dtype, scale, y, a.stats, a.cpart, nwg, vt, a.band, a.nb, obs_len, st);

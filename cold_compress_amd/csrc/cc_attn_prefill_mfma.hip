@@ -17,6 +17,7 @@
 //   from V^T stored with the matching key permutation inside each 32-key block (vt_perm), one 16-byte load per
 //   operand — no LDS transpose, no cross-lane shuffles on the MFMA path.
 // MFMA-bound contraction; HBM traffic is negligible (K/V tiles are re-read from L2 by the 4 waves).
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "cc_common.h"
@@ -86,6 +87,7 @@ struct MArgs {
   int obs_len;     // > 0: plane 1 + nb accumulates the group-mean probabilities of the last obs_len query rows
   int band[kMaxBandsM];
   float scale;
+  unsigned long long* trace;  // measurement only (CC_PREFILL_TRACE): per (kv head, wave) cycle sums of the tile phases, workgroup 0
 };
 
 
@@ -101,6 +103,12 @@ __device__ __forceinline__ void wg_coords(const MArgs& a, int& bx, int& h) {
     bx = b % a.nwg;
   }
 }
+
+// Round i of a persistent workgroup's loop over query tiles: serpentine over the workgroups (0 .. nwg-1, nwg-1 .. 0, ...), so
+// that every workgroup gets the same share of the causal triangle (tile qt costs qt + 1 key tiles; with the plain stride
+// w, w + nwg, ... the last workgroup of a head had 25 % more work than the average at L = 8192 and the launch ended on it).
+// The assignment is static: the partial planes still accumulate in a fixed order.
+__device__ __forceinline__ int q_tile(int i, int bx, int nwg) { return i * nwg + ((i & 1) ? nwg - 1 - bx : bx); }
 
 // key offset inside a 32-key tile held by accumulator register `reg` of a lane in half `hi`
 __device__ __forceinline__ int c_row(int reg, int hi) { return (reg & 3) + 8 * (reg >> 2) + 4 * hi; }
@@ -145,7 +153,9 @@ __global__ __launch_bounds__(256) void prefill_stats_lds_kernel(MArgs a) {
   // cooperative tile load: thread t -> key row t / 8, chunks 2 * (t % 8) and + 1 (32 contiguous bytes)
   const int ld_row = threadIdx.x >> 3, ld_c0 = (threadIdx.x & 7) * 2;
 
-  for (int qt = bx; qt < nqt; qt += a.nwg) {
+  for (int i = 0; i * a.nwg < nqt; i++) {
+    const int qt = q_tile(i, bx, a.nwg);
+    if (qt >= nqt) continue;  // ragged last round (uniform over the workgroup)
     const int q0 = qt * kTQ;
     const int query = q0 + lq;
     const int qc = query < L ? query : L - 1;
@@ -239,8 +249,8 @@ __global__ __launch_bounds__(256, 2) void prefill_pv_lds_kernel(MArgs a) {
   __shared__ __attribute__((aligned(16))) uint4 sm_kt[2][kTK][16];   // [buf][key][chunk ^ (key & 15)]
   __shared__ __attribute__((aligned(16))) uint4 sm_vt[2][kD][4];     // [buf][d][chunk ^ ((d >> 2) & 3)]  (V^T, permuted keys)
   __shared__ float sm_p[4][kTK][kTQ + 1];                            // per-wave probability tiles: [r][key][query]
-  __shared__ float sm_red[2][2 + kMaxBandsM][8][kTK];
   constexpr int NBC = NB >= 0 ? NB : kMaxBandsM;  // band planes the compiled code iterates over
+  __shared__ float sm_red[2][2 + NBC][8][kTK];     // 52.5 KiB of LDS in all without band planes: three workgroups per CU
   const int nb = NB >= 0 ? NB : a.nb;
   const int lane = threadIdx.x & 63, r = threadIdx.x >> 6;
   const int hi = lane >> 5, lq = lane & 31;
@@ -261,8 +271,21 @@ __global__ __launch_bounds__(256, 2) void prefill_pv_lds_kernel(MArgs a) {
   const int kl_row = threadIdx.x >> 3, kl_c0 = (threadIdx.x & 7) * 2;   // K tile: row t/8, chunks 2(t%8), +1
   const int vl_row = threadIdx.x >> 1, vl_c0 = (threadIdx.x & 1) * 2;   // V^T tile: d row t/2, chunks 2(t%2), +1
   const int rd_key = threadIdx.x & 31, rd_qs = threadIdx.x >> 5;        // side sums: key, slice of 4 queries
+  // phase clock of workgroup 0 (measurement only): acc[k] += cycles since the previous stamp
+  const bool tracing = a.trace != nullptr && bx == 0;
+  unsigned long long tr_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tr_last = 0;
+  auto stamp = [&](int k) {
+    if (tracing) {
+      const unsigned long long now = __builtin_amdgcn_s_memtime();
+      tr_acc[k] += now - tr_last;
+      tr_last = now;
+    }
+  };
+  if (tracing) tr_last = __builtin_amdgcn_s_memtime();
 
-  for (int qt = bx; qt < nqt; qt += a.nwg) {
+  for (int i = 0; i * a.nwg < nqt; i++) {
+    const int qt = q_tile(i, bx, a.nwg);
+    if (qt >= nqt) continue;  // ragged last round (uniform over the workgroup)
     const int q0 = qt * kTQ;
     const bool obs_tile = a.obs_len > 0 && q0 + kTQ > L - a.obs_len;
     const int query = q0 + lq;
@@ -335,6 +358,7 @@ __global__ __launch_bounds__(256, 2) void prefill_pv_lds_kernel(MArgs a) {
       constexpr bool FULL = decltype(full_c)::value;
       constexpr bool OBS = decltype(obs_c)::value;
       const int k0 = t * kTK, buf = t & 1;
+      stamp(6);
       if (t + 1 < ntile) fetch(t + 1);
       if (t > 0) fold_fetch(t - 1, obs_c);
       // S^T tile = K . Q^T from the LDS image
@@ -361,7 +385,9 @@ __global__ __launch_bounds__(256, 2) void prefill_pv_lds_kernel(MArgs a) {
         sm_p[r][c_row(e, hi)][lq] = p0;
         sm_p[r][c_row(e + 1, hi)][lq] = p1;
       }
+      stamp(0);
       __syncthreads();  // B1: the four heads' probability tiles are in LDS
+      stamp(1);
       {
         float cs = 0.f, os = 0.f, bs[kMaxBandsM] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -385,6 +411,7 @@ __global__ __launch_bounds__(256, 2) void prefill_pv_lds_kernel(MArgs a) {
         if (OBS) sm_red[buf][obs_pl][rd_qs][rd_key] = os;
       }
       if (t > 0) fold(t - 1, obs_c);  // the previous tile's sums became visible at the last barrier
+      stamp(2);
       // O += P . V : A = P (C layout -> 16-bit), B = V^T fragments from the LDS image
 #pragma unroll
       for (int kb = 0; kb < 2; kb++) {
@@ -395,8 +422,11 @@ __global__ __launch_bounds__(256, 2) void prefill_pv_lds_kernel(MArgs a) {
           o[db] = MfmaOps<T>::mma(pa, sm_vt[buf][d][((kb * 2 + hi) ^ ((d >> 2) & 3)) & 3], o[db]);
         }
       }
+      stamp(3);
       if (t + 1 < ntile) stash((t + 1) & 1);
+      stamp(4);
       __syncthreads();  // B2: tile t + 1 is in LDS, tile t's side sums are in sm_red[buf], sm_p may be rewritten
+      stamp(5);
     };
     __syncthreads();
     fetch(0);
@@ -423,7 +453,10 @@ __global__ __launch_bounds__(256, 2) void prefill_pv_lds_kernel(MArgs a) {
         const int qrow = q0 + c_row(e, hi);
         if (qrow < L) ElemTraits<T>::store(yh, (size_t)qrow * kD + db * 32 + lq, o[db][e]);
       }
+    stamp(7);
   }
+  if (tracing && lane == 0)
+    for (int k = 0; k < 8; k++) a.trace[(h * 4 + r) * 8 + k] = tr_acc[k];
 }
 
 template <typename T>
@@ -454,11 +487,33 @@ extern "C" int cc_prefill_attn_mfma_impl(const void* q, const void* k, const voi
   dim3 block(256);
   static const bool no_remap = getenv("CC_PREFILL_NO_XCD_REMAP") != nullptr;  // measurement only
   a.xcd_remap = (H % 8 == 0 && !no_remap) ? 1 : 0;
-  // pass 1 keeps no per-workgroup partial planes: it can use as many workgroups as fit (5 per CU at ~100 VGPRs)
+  // pass 1 keeps no per-workgroup partial planes; 128 persistent workgroups per head (four per CU) measured best at L = 8192
+  // (64: 0.545 ms, 128: 0.472, 256: 0.512) — with the serpentine assignment every one of them gets the same share of the triangle
   const int nqt = (L + kTQ - 1) / kTQ;
   MArgs a1 = a;
-  a1.nwg = nqt < 256 ? nqt : 256;
+  a1.nwg = nqt < 128 ? nqt : 128;
   a.nwg = nwg;
+  static unsigned long long* trace_buf = nullptr;  // measurement only: phase clocks of the LAST pass-2 launch, printed at exit
+  static const bool want_trace = getenv("CC_PREFILL_TRACE") != nullptr;
+  if (want_trace && !trace_buf) {
+    if (hipMalloc(&trace_buf, 64 * 4 * 8 * sizeof(unsigned long long)) != hipSuccess) trace_buf = nullptr;
+    static unsigned long long* tb = trace_buf;
+    atexit([] {
+      unsigned long long hbuf[64 * 4 * 8];
+      if (hipMemcpy(hbuf, tb, sizeof(hbuf), hipMemcpyDeviceToHost) != hipSuccess) return;
+      const char* names[8] = {"qk+softmax+p->lds", "wait B1", "side sums+fold", "pv issue", "stash (vmcnt)", "wait B2", "prefetch issue", "q-tile epilogue"};
+      for (int hw = 0; hw < 8; hw++) {  // head 0 and 1, four waves each
+        unsigned long long tot = 0;
+        for (int k = 0; k < 8; k++) tot += hbuf[hw * 8 + k];
+        fprintf(stderr, "[prefill trace] head %d wave %d total %llu cycles:", hw / 4, hw % 4, tot);
+        for (int k = 0; k < 8; k++) fprintf(stderr, " %s %.1f%%", names[k], tot ? 100.0 * hbuf[hw * 8 + k] / tot : 0.0);
+        fprintf(stderr, "\n");
+      }
+    });
+  }
+  a.trace = trace_buf;
+  static const char* e_nwg1 = getenv("CC_PREFILL_NWG1");  // measurement only
+  if (e_nwg1 && atoi(e_nwg1) > 0) a1.nwg = nqt < atoi(e_nwg1) ? nqt : atoi(e_nwg1);
   dim3 grid1((unsigned)(a1.nwg * H)), grid((unsigned)(nwg * H));
   if (dtype == CC_DT_BF16) {
     hipLaunchKernelGGL(vt_perm_kernel<bf16_t>, dim3((unsigned)nbk), dim3(256), 0, st, (const bf16_t*)v, (bf16_t*)vt, H, L, Lp);
