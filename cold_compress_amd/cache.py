@@ -26,6 +26,13 @@ _DT = {torch.float32: _abi.CC_DT_F32, torch.bfloat16: _abi.CC_DT_BF16, torch.flo
 STRATEGIES = ["full", "random", "recent_global", "heavy_hitter", "l2", "hybrid", "keep_it_odd"]
 
 
+def add_extension_arguments(parser: argparse.ArgumentParser):
+    """Flags the reference does not have (kept out of add_cache_arguments so that its flag set stays the reference's).
+    --cache_quant_mode fused: with --cache_bits 8, uint8 images on a per-(head, slot) grid, dequantised inside the decode
+    kernels — a different numerical contract (include/coldcompress.h); "reference" = cache.py:283-338 bit for bit."""
+    parser.add_argument("--cache_quant_mode", default="reference", choices=["reference", "fused"])
+
+
 def add_cache_arguments(parser: argparse.ArgumentParser):
     """Same flags, defaults and choices as ref: cache.py:13-118 (the CLI is the compatibility surface)."""
     g = parser.add_argument_group("cache_args")
@@ -73,6 +80,9 @@ def _need_device(t, what):
             f"{what} is on {t.device}: the cold-compress HIP path needs ROCm device tensors (there is no CPU fallback).")
 
 
+_FUSED_SCRATCH = {}  # (H, S, D, dtype, device) -> staging pair of the fused quantised cache's prefill
+
+
 class _Scratch:
     """Per-cache device scratch kept OUT of the module's buffers so `cache_memory_gb` matches the reference."""
 
@@ -108,14 +118,34 @@ class KVCache(nn.Module):
         self.quantize = self.cache_bits is not None
         self.n_bit = self.cache_bits
         self.quantization_axis = 2
+        # opt-in fused quantised cache (our extension, include/coldcompress.h): the decode kernels stream uint8 images
+        mode = getattr(self, "cache_quant_mode", None) or "reference"
+        if mode not in ("reference", "fused"):
+            raise ColdCompressError(f"cache_quant_mode={mode!r}: 'reference' or 'fused'")
+        self.fused_quant = self.quantize and mode == "fused"
+        if self.fused_quant:
+            if self.n_bit != 8 or dtype not in (torch.bfloat16, torch.float16) or head_dim != 128:
+                raise ColdCompressError("cache_quant_mode='fused' serves cache_bits=8, 16-bit models, head_dim 128")
+            if not self._fused_quant_policy():
+                raise ColdCompressError(f"cache_quant_mode='fused' is not available for {type(self).__name__}: it serves "
+                                        "heavy_hitter (history_window_size 1), recent_global, full and random")
+            self.quantize = False  # none of the reference mode's round-trip machinery runs
         self.n_heads = n_heads
         self.head_dim = head_dim
         self.head_specific = head_specific
         self.variable_length = variable_length
         self.cache_shape = (1, n_heads, self.max_cache_length, head_dim)
         S = self.max_cache_length
-        self.register_buffer("k_cache", torch.zeros(self.cache_shape, dtype=dtype))
-        self.register_buffer("v_cache", torch.zeros(self.cache_shape, dtype=dtype))
+        if self.fused_quant:
+            # the images ARE the cache; k_cache / v_cache stay as empty tensors that carry the model dtype
+            self.register_buffer("k_cache", torch.zeros((1, n_heads, 0, head_dim), dtype=dtype))
+            self.register_buffer("v_cache", torch.zeros((1, n_heads, 0, head_dim), dtype=dtype))
+            self.register_buffer("k_cache_q", torch.zeros(self.cache_shape, dtype=torch.uint8))
+            self.register_buffer("v_cache_q", torch.zeros(self.cache_shape, dtype=torch.uint8))
+            self.register_buffer("kv_qparams", torch.zeros((1, n_heads, S, 4), dtype=torch.float32))  # k_scale, k_min, v_scale, v_min
+        else:
+            self.register_buffer("k_cache", torch.zeros(self.cache_shape, dtype=dtype))
+            self.register_buffer("v_cache", torch.zeros(self.cache_shape, dtype=dtype))
         self.register_buffer("pos", torch.full((1, n_heads if head_specific else 1, S), -1, dtype=torch.int32))
         self.register_buffer("cache_cts", torch.zeros((n_heads if variable_length else 1,), dtype=torch.int32))
         self.register_buffer("mask", torch.zeros((1, n_heads, 1, S), dtype=torch.bool))
@@ -144,10 +174,43 @@ class KVCache(nn.Module):
     def reset(self):
         self.k_cache.zero_()
         self.v_cache.zero_()
+        if self.fused_quant:
+            self.k_cache_q.zero_()
+            self.v_cache_q.zero_()
+            self.kv_qparams.zero_()
         self.mask.zero_()
         self.cache_cts.zero_()
         self.pos.fill_(-1)
         self._quant_pending = self.quantize
+
+    # ------------------------------------------------------------------ fused quantised cache (our extension)
+    def _fused_quant_policy(self):
+        """Policy code of cc_decode_step_quant this class runs under cache_quant_mode='fused' (0: not available)."""
+        return 0
+
+    def _fused_scratch(self):
+        """Model-dtype [H, S, D] staging pair shared by every layer of the same shape (prefill fill -> row quantisation)."""
+        key = (self.n_heads, self.max_cache_length, self.head_dim, self.k_cache.dtype, str(self.k_cache_q.device))
+        pair = _FUSED_SCRATCH.get(key)
+        if pair is None:
+            shape = (self.n_heads, self.max_cache_length, self.head_dim)
+            pair = _FUSED_SCRATCH[key] = (torch.empty(shape, dtype=key[3], device=self.k_cache_q.device),
+                                          torch.empty(shape, dtype=key[3], device=self.k_cache_q.device))
+        return pair
+
+    def dequantized_kv(self):
+        """Fused mode: the values the decode kernels see, [1, H, S, D] model dtype (fresh tensors; debugging / tests)."""
+        H, S, D = self.n_heads, self.max_cache_length, self.head_dim
+        k = torch.empty(self.cache_shape, dtype=self.k_cache.dtype, device=self.k_cache_q.device)
+        v = torch.empty_like(k)
+        _abi.call("cc_kv_dequant_rows", _ptr(self.k_cache_q), _ptr(self.v_cache_q), _ptr(self.kv_qparams), H, S, D,
+                  _DT[self.k_cache.dtype], 8, _ptr(k), _ptr(v), _stream())
+        return k, v
+
+    def _quant_step(self, q, k, v, p32, HQ, scale, y, ws, num=None, denom=None, counter=None, rand=None, g=0, w=0, phases=3):
+        _abi.call("cc_decode_step_quant", self._view(), _ptr(self.kv_qparams), 8, self._fused_quant_policy(), _ptr(q), _ptr(k),
+                  _ptr(v), _ptr(p32), _ptr(num), _ptr(denom), _ptr(counter), _ptr(rand), _ptr(self.next_key), int(g), int(w), HQ,
+                  scale, _ptr(y), None, _ptr(ws), ws.numel(), _stream(), phases)
 
     # ------------------------------------------------------------------ quantised KV (ref: cache.py:283-309, 323-338)
     def quantize_cache(self):
@@ -206,14 +269,17 @@ class KVCache(nn.Module):
         return stats
 
     def return_kv_cache(self):
+        if self.fused_quant:  # nobody on the decode path reads these: the kernels stream the images (decode_step)
+            k, v = self.dequantized_kv()
+            return k, v, self.mask
         return self.k_cache, self.v_cache, self.mask
 
     # ------------------------------------------------------------------ ABI plumbing
     def _view(self):
-        key = (self.k_cache.data_ptr(), self.v_cache.data_ptr(), self.pos.data_ptr(), self.mask.data_ptr(),
-               self.cache_cts.data_ptr())
+        kc, vc = (self.k_cache_q, self.v_cache_q) if self.fused_quant else (self.k_cache, self.v_cache)
+        key = (kc.data_ptr(), vc.data_ptr(), self.pos.data_ptr(), self.mask.data_ptr(), self.cache_cts.data_ptr())
         if self._view_cache is None or self._view_cache[0] != key:
-            _need_device(self.k_cache, "k_cache")
+            _need_device(kc, "k_cache")
             H, S, D = self.n_heads, self.max_cache_length, self.head_dim
             v = KVView(key[0], key[1], key[2], key[3], key[4], H, self.pos.shape[1], self.cache_cts.shape[0], S, D,
                        _DT[self.k_cache.dtype])
@@ -258,12 +324,26 @@ class KVCache(nn.Module):
         k = k_val.reshape(H, T, D).contiguous() if k_val.is_contiguous() else k_val.contiguous().view(H, T, D)
         v = v_val.reshape(H, T, D).contiguous() if v_val.is_contiguous() else v_val.contiguous().view(H, T, D)
         p = input_pos.to(torch.int64).reshape(-1, T).contiguous()
+        if self.fused_quant:  # rows land in a model-dtype staging pair, then every row is quantised on its own grid, once
+            ks, vs = self._fused_scratch()
+            ks.zero_()
+            vs.zero_()
+            S = self.max_cache_length
+            tmp = KVView(ks.data_ptr(), vs.data_ptr(), self.pos.data_ptr(), self.mask.data_ptr(), self.cache_cts.data_ptr(), H,
+                         self.pos.shape[1], self.cache_cts.shape[0], S, D, _DT[self.k_cache.dtype])
+            _abi.call("cc_prefill_fill", C.byref(tmp), _ptr(k), _ptr(v), _ptr(p), p.shape[0], T, _stream())
+            _abi.call("cc_kv_quant_rows", _ptr(ks), _ptr(vs), H, S, D, _DT[self.k_cache.dtype], 8, _ptr(self.k_cache_q),
+                      _ptr(self.v_cache_q), _ptr(self.kv_qparams), _stream())
+            return
         _abi.call("cc_prefill_fill", self._view(), _ptr(k), _ptr(v), _ptr(p), p.shape[0], T, _stream())
         if self.quantize:  # a raw-pointer bulk write: the tensors' version counters did not move, the stable marks are void
             self._quant_tag = None
 
     def _decoding_update(self, input_pos, k_val, v_val, **kwargs):
         """ref: cache.py:348-364: generic path = `_token_importances` -> base rules -> arg-min -> insert."""
+        if self.fused_quant:
+            raise ColdCompressError("cache_quant_mode='fused': decode through decode_step() — the three-call path would have to "
+                                    "materialise the dequantised cache every step, which is what this mode exists to avoid")
         k, v = self._new_rows(k_val, v_val)
         self._run_select(input_pos, k, v)
 
@@ -325,6 +405,8 @@ class _RingFusedStep:
         _abi.call("cc_rg_next_key_init", self._view(), _ptr(p32), self._ring_sinks(), _ptr(self.next_key), _stream())
 
     def _pipeline_step(self, q, k, v, p32, HQ, scale, y, ws):
+        if self.fused_quant:
+            return self._quant_step(q, k, v, p32, HQ, scale, y, ws, g=self._ring_sinks())
         _abi.call("cc_decode_step_recent_global", self._view(), _ptr(q), _ptr(k), _ptr(v), _ptr(p32), _ptr(self.next_key),
                   self._ring_sinks(), HQ, scale, _ptr(y), _ptr(ws), ws.numel(), _stream())
 
@@ -359,6 +441,9 @@ class KVCacheFull(_RingFusedStep, KVCacheHeadConstant):
         super().__init__(max_batch_size, n_heads, head_dim, dtype, **kwargs)
         self._init_ring_pipeline()
 
+    def _fused_quant_policy(self):
+        return 2
+
     def _ring_sinks(self):
         return 0  # cache.py:502 is a plain pos.argmin(): a `global_tokens` kwarg (it overrides the 0 above, as in the reference) is ignored
 
@@ -385,8 +470,13 @@ class KVCacheRandom(_RingFusedStep, KVCacheHeadConstant):
         _abi.call("cc_random_next_key_init", self._view(), _ptr(p32), _ptr(r), int(self.global_tokens), int(self.recent_window),
                   _ptr(self.next_key), _stream())
 
+    def _fused_quant_policy(self):
+        return 3
+
     def _pipeline_step(self, q, k, v, p32, HQ, scale, y, ws):
         r = self._rand().to(torch.float32).contiguous()
+        if self.fused_quant:
+            return self._quant_step(q, k, v, p32, HQ, scale, y, ws, rand=r, g=self.global_tokens, w=self.recent_window)
         _abi.call("cc_decode_step_random", self._view(), _ptr(q), _ptr(k), _ptr(v), _ptr(p32), _ptr(r), _ptr(self.next_key),
                   int(self.global_tokens), int(self.recent_window), HQ, scale, _ptr(y), _ptr(ws), ws.numel(), _stream())
 
@@ -403,6 +493,9 @@ class KVCacheRecentGlobal(_RingFusedStep, KVCacheHeadConstant):
     def __init__(self, max_batch_size, n_heads, head_dim, dtype=torch.bfloat16, **kwargs):
         super().__init__(max_batch_size, n_heads, head_dim, dtype, **kwargs)
         self._init_ring_pipeline()
+
+    def _fused_quant_policy(self):
+        return 2
 
     def _run_select(self, input_pos, k, v):
         _abi.call("cc_decode_update_recent_global", self._view(), _ptr(k), _ptr(v), _ptr(self._pos32(input_pos)),
@@ -525,6 +618,9 @@ class KVCacheHeavyHitter(_TrackedWindowSums, KVCacheHeadSpecific):
     def supports_fused_step(self):
         return True
 
+    def _fused_quant_policy(self):
+        return 1 if int(getattr(self, "history_window_size", 1)) == 1 else 0
+
     def update_kv(self, input_pos, k_val, v_val, is_prefill, **kwargs):
         self._next_valid = False  # the three-call path mutates pos / history outside the pipeline
         return super().update_kv(input_pos, k_val, v_val, is_prefill, **kwargs)
@@ -571,6 +667,11 @@ class KVCacheHeavyHitter(_TrackedWindowSums, KVCacheHeadSpecific):
             return y
         # one launch per layer step where the shape and the device allow it (include/coldcompress.h), else two
         phases = 3 if self.single_launch else 3 | _abi.CC_PHASE_TWO_LAUNCH
+        if self.fused_quant:  # the same step over the uint8 images (cc_decode_step_quant)
+            self._quant_step(q, k, v, p32, HQ, 1.0 / math.sqrt(D) if scale is None else scale, y, ws, num=self.attn_history_num,
+                             denom=self.attn_history_denom, counter=self.attn_counter, g=self.global_tokens, w=self.recent_window,
+                             phases=phases)
+            return y
         _abi.call("cc_decode_step_heavy_hitter_phases", self._view(), _ptr(q), _ptr(k), _ptr(v), _ptr(p32), _ptr(self.attn_history_num),
                   _ptr(self.attn_history_denom), _ptr(self.attn_counter), _ptr(self.next_key), int(self.global_tokens),
                   int(self.recent_window), HQ, 1.0 / math.sqrt(D) if scale is None else scale, _ptr(y), None, _ptr(ws),
@@ -580,6 +681,9 @@ class KVCacheHeavyHitter(_TrackedWindowSums, KVCacheHeadSpecific):
 
     def single_launch_active(self, HQ):
         """True when decode_step runs as ONE launch for `HQ` query heads on this device."""
+        if self.fused_quant:
+            return bool(self.single_launch and _abi.lib()["cc_decode_step_quant_single_launch"](
+                HQ, self.n_heads, self.max_cache_length, self.head_dim, _DT[self.k_cache.dtype], 8))
         return bool(self.single_launch and self.history_window_size == 1 and _abi.lib()["cc_decode_step_single_launch"](
             HQ, self.n_heads, self.max_cache_length, self.head_dim, _DT[self.k_cache.dtype]))
 

@@ -194,6 +194,9 @@ struct SplitArgs {
   int yc_chunks;      // grid.x of the two-launch combine pass (unused)
   unsigned long long* trace;  // measurement only (cc_decode_step_trace): [workgroup][16] time stamps and hardware ids
   HybridStep hyb;     // HYB instantiation only
+  // ---- fused quantised cache (QB instantiation): k / v point at the uint8 images [H, S, D]; one (scale, minimum) pair per
+  //      (head, slot) row for K and one for V — dequantised in registers on the way to the LDS slabs
+  float* qparams;     // [H, S, 4]: k_scale, k_min, v_scale, v_min
 };
 
 template <typename T, int D, int RT, int NW, int U>
@@ -518,11 +521,70 @@ constexpr unsigned kOneSpinMax = 1u << 18;  // bounded spin: a launch that is no
 constexpr int kOneStatusWordDev = 1023;     // hdr[0 .. H): per-head epochs; hdr[1023]: timeout word (== kOneStatusWord)
 constexpr int kOneAuxCoherent = 17;         // sc0 sc1: write-through stores / loads that bypass the non-coherent L1 (and stale L2 lines)
 
+// ---- fused quantised cache: value = T(fma(q, scale, min)), one rounding; q in [0, 255]
+template <typename T>
+__device__ __forceinline__ uint32_t pack16x2(float lo, float hi) {
+  if constexpr (ElemTraits<T>::code == CC_DT_BF16) {
+    float ra, rb;
+    return bf16_round_pair(lo, hi, ra, rb);
+  } else {
+    return (uint32_t)f32_to_f16_bits(lo) | ((uint32_t)f32_to_f16_bits(hi) << 16);
+  }
+}
+template <typename T>
+__device__ __forceinline__ uint4 dequant8(uint2 raw, float2 par) {
+  const uint32_t w[2] = {raw.x, raw.y};
+  uint32_t o[4];
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    float f0 = __builtin_fmaf((float)(w[i] & 0xffu), par.x, par.y);
+    float f1 = __builtin_fmaf((float)((w[i] >> 8) & 0xffu), par.x, par.y);
+    float f2 = __builtin_fmaf((float)((w[i] >> 16) & 0xffu), par.x, par.y);
+    float f3 = __builtin_fmaf((float)(w[i] >> 24), par.x, par.y);
+    if constexpr (ElemTraits<T>::code == CC_DT_F16) {  // fp32 first, then f16 (see cc_opaque_f32)
+      f0 = cc_opaque_f32(f0); f1 = cc_opaque_f32(f1); f2 = cc_opaque_f32(f2); f3 = cc_opaque_f32(f3);
+    }
+    o[2 * i] = pack16x2<T>(f0, f1);
+    o[2 * i + 1] = pack16x2<T>(f2, f3);
+  }
+  return make_uint4(o[0], o[1], o[2], o[3]);
+}
+// Quantise the 8 values of this lane on the grid of its 16-lane row group (one cache row of 128 values):
+// min / max over the row, range = max(max - min, 1e-6), scale = range / 255, q = clamp(rint((x - min) * (255 / range)), 0, 255)
+// (IEEE fp32 ops, no contraction)
+template <typename T>
+__device__ __forceinline__ uint2 quant8_row16(uint4 raw, float2& par) {
+  Vec16<T> v;
+  v.raw = raw;
+  float x[8];
+  v.unpack(x);
+  float mn = x[0], mx = x[0];
+#pragma unroll
+  for (int i = 1; i < 8; i++) {
+    mn = fminf(mn, x[i]);
+    mx = fmaxf(mx, x[i]);
+  }
+#pragma unroll
+  for (int off = 8; off > 0; off >>= 1) {
+    mn = fminf(mn, __shfl_xor(mn, off, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, off, 16));
+  }
+  const float range = fmaxf(__fsub_rn(mx, mn), 1e-6f);
+  const float sc = __fdiv_rn(range, 255.f), inv = __fdiv_rn(255.f, range);  // two divides per ROW, none per element
+  uint32_t b[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) b[i] = (uint32_t)fminf(fmaxf(rintf(__fmul_rn(__fsub_rn(x[i], mn), inv)), 0.f), 255.f);
+  par = make_float2(sc, mn);
+  return make_uint2(b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24), b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24));
+}
+
 // L2: the l2 policy's norm bookkeeping (its own instantiation: the others pay nothing).  ONE: the single-launch layer
 // step of the heavy-hitter policy (needs R == RT, one tile per wave, every workgroup of the grid co-resident).
-template <typename T, int RT, int NW, bool L2, bool ONE = false, bool HYB = false>
-__global__ __launch_bounds__(NW * 64, ONE ? 2 : 1) void decode_attn_split_mfma_kernel(SplitArgs a) {
+// QB = 8: the fused quantised cache (uint8 images + per-row (scale, minimum)), dequantised on the way to the LDS slabs.
+template <typename T, int RT, int NW, bool L2, bool ONE = false, bool HYB = false, int QB = 0>
+__global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_split_mfma_kernel(SplitArgs a) {
   static_assert(!(HYB && (L2 || ONE)), "the hybrid decision rides the plain two-launch streaming pass");
+  static_assert(QB == 0 || (QB == 8 && !L2 && !HYB), "fused quantised cache: 8 bits, heavy hitter / recent_global / random");
   static_assert(sizeof(T) == 2 && (RT == 1 || RT == 2 || RT == 4 || RT == 8), "16-bit caches, up to 8 query heads per pass (the MFMA has 16 columns)");
   static_assert(!(ONE && L2) && (!ONE || NW == 4), "the single-launch step runs on 4-wave workgroups; l2 needs a cross-head maximum");
   constexpr int D = 128, VEC = 8, RPW = 4, U = 4;
@@ -539,6 +601,10 @@ __global__ __launch_bounds__(NW * 64, ONE ? 2 : 1) void decode_attn_split_mfma_k
   const int row_end = min(S, row_begin + a.rows_per_split);
   const T* kb = reinterpret_cast<const T*>(a.k) + (size_t)h * S * D;
   const T* vh = reinterpret_cast<const T*>(a.v) + (size_t)h * S * D + c * VEC;
+  // QB: byte images (element offsets are byte offsets) and the head's row parameters
+  const uint8_t* kqb = reinterpret_cast<const uint8_t*>(a.k) + (size_t)h * S * D;
+  const uint8_t* vqh = reinterpret_cast<const uint8_t*>(a.v) + (size_t)h * S * D + c * VEC;
+  const float2* qpar = reinterpret_cast<const float2*>(a.qparams) + (size_t)h * S * 2;  // [slot][0] = K pair, [1] = V pair
   const bool has_mask = a.mask != nullptr && !(a.abl & 4);
   const uint8_t* mh = has_mask ? a.mask + (size_t)h * S : reinterpret_cast<const uint8_t*>(a.k);
   T* sc_out = reinterpret_cast<T*>(a.scores);
@@ -577,7 +643,7 @@ __global__ __launch_bounds__(NW * 64, ONE ? 2 : 1) void decode_attn_split_mfma_k
   }
   // ONE: this lane's slot of the per-slot pass (lane c = t * LPR of row group g finishes row 4g + t of the wave's tile): its
   // history and position are requested here, with everything else, and consumed after the hand-off
-  unsigned long long tr0 = 0, tr1 = 0, tr2 = 0, tr3 = 0, tr4 = 0, rt0 = 0, rt1 = 0;
+  unsigned long long tr0 = 0, tr1 = 0, tr2 = 0, tr3 = 0, tr4 = 0, rt0 = 0, rt1 = 0, trA = 0, trB = 0, trC = 0;
   if constexpr (ONE) {
     if (a.trace) {
       tr0 = __builtin_amdgcn_s_memtime();
@@ -607,6 +673,18 @@ __global__ __launch_bounds__(NW * 64, ONE ? 2 : 1) void decode_attn_split_mfma_k
     }
   }
   float s_keep[U] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};  // ONE: the wave's (single) tile of scores, kept for the per-slot pass
+  // QB: the incoming token's rows are requested AHEAD of the tile (chunk c of K and of V per lane, every row group alike), so that
+  // the inserting row group can quantise them while the tile is in flight — requested behind the tile, the in-order load counter
+  // would hold the ~150 instructions of min / max shuffles and roundings back until the K/V rows have arrived, and the whole kv
+  // head waits for its slowest workgroup.  (Quantising in EVERY wave ahead of the tile was tried: 512 workgroups of redundant
+  // work cost more than the one critical path saves — 12.2 vs 11.7 us at S = 4096.)
+  Vec16<T> qb_kn, qb_vn;
+  if constexpr (QB) {
+    if (a.k_new) {
+      qb_kn.load(reinterpret_cast<const T*>(a.k_new) + (size_t)h * D + c * VEC);
+      qb_vn.load(reinterpret_cast<const T*>(a.v_new) + (size_t)h * D + c * VEC);
+    }
+  }
   // B operand: lane (n = c, kb = g) of step j holds q[head n][8 * (4j + g) .. + 8]; columns n >= RT are zero
   Vec16<T> qB[4];
 #pragma unroll
@@ -616,6 +694,13 @@ __global__ __launch_bounds__(NW * 64, ONE ? 2 : 1) void decode_attn_split_mfma_k
   }
   uint32_t mword = 0x01010101u;
   Vec16<T> kk[U], vv[U];
+  uint2 kq8[U], vq8[U];      // QB: the rows' bytes ...
+  float2 kpar[U], vpar[U];   // ... and their (scale, minimum)
+  auto load_nt_u2 = [](const uint8_t* p) {
+    typedef unsigned int u32x2_nt __attribute__((ext_vector_type(2)));
+    const u32x2_nt v = __builtin_nontemporal_load(reinterpret_cast<const u32x2_nt*>(p));
+    return make_uint2(v.x, v.y);
+  };
   auto issue_k = [&](int base) {  // mask word + the four K rows of this lane's row group (tile row i = 4g + u takes chunk c ^ i)
     const int row0 = base + g * U;
     mword = 0x01010101u;
@@ -632,20 +717,37 @@ __global__ __launch_bounds__(NW * 64, ONE ? 2 : 1) void decode_attn_split_mfma_k
 #pragma unroll
     for (int u = 0; u < U; u++) {
       const int rr = row0 + u < row_end ? row0 + u : row_end - 1;
-      kk[u].load_nt(kb + (size_t)rr * D + ((c ^ (4 * g + u)) & 15) * VEC);
+      if constexpr (QB) {
+        kq8[u] = load_nt_u2(kqb + (size_t)rr * D + ((c ^ (4 * g + u)) & 15) * VEC);
+        kpar[u] = qpar[(size_t)rr * 2];
+      } else {
+        kk[u].load_nt(kb + (size_t)rr * D + ((c ^ (4 * g + u)) & 15) * VEC);
+      }
     }
   };
   auto issue_v = [&](int base) {
     const int row0 = base + g * U;
 #pragma unroll
-    for (int u = 0; u < U; u++) vv[u].load_nt(vh + (size_t)(row0 + u < row_end ? row0 + u : row_end - 1) * D);
+    for (int u = 0; u < U; u++) {
+      const int rr = row0 + u < row_end ? row0 + u : row_end - 1;
+      if constexpr (QB) {
+        vq8[u] = load_nt_u2(vqh + (size_t)rr * D);
+        vpar[u] = qpar[(size_t)rr * 2 + 1];
+      } else {
+        vv[u].load_nt(vh + (size_t)rr * D);
+      }
+    }
   };
   int base = row_begin + wave * (RPW * U);
   bool more = base < row_end;
-  if (more) {
-    issue_k(base);
-    issue_v(base);
-  }
+  // UNCONDITIONAL (rows past the split's end are clamped to its last row, a valid address): behind a branch, the compiler's
+  // wait-count bookkeeping merges "tile loads issued" with "none issued" and every later use of an EARLIER load (the partial
+  // keys, the incoming token's rows) becomes a wait for all loads — the tile included
+  issue_k(base);
+  if constexpr (QB) __builtin_amdgcn_sched_barrier(0);  // K's bytes and parameters go out BEFORE V's: the K stash waits for them only
+  issue_v(base);
+  if constexpr (QB) __builtin_amdgcn_sched_barrier(0);
+  int qb_ins_u = -1;  // QB: tile row (of this lane's row group) that holds the inserted token — its K chunk is UNswizzled (chunk c)
 
   while (more) {
     const int row0 = base + g * U;
@@ -694,19 +796,35 @@ __global__ __launch_bounds__(NW * 64, ONE ? 2 : 1) void decode_attn_split_mfma_k
       const int um = ins_idx - row0;
       const int kcol = ((c ^ (4 * g + um)) & 15) * VEC;
       Vec16<T> kn, vn;
-      kn.load(reinterpret_cast<const T*>(a.k_new) + (size_t)h * D + kcol);
-      vn.load(reinterpret_cast<const T*>(a.v_new) + (size_t)h * D + c * VEC);
+      if constexpr (!QB) {
+        kn.load(reinterpret_cast<const T*>(a.k_new) + (size_t)h * D + kcol);
+        vn.load(reinterpret_cast<const T*>(a.v_new) + (size_t)h * D + c * VEC);
+      }
       float xq[D / 16];  // l2: the new key again, in the canonical norm's element order (same latency window as kn / vn)
       if (L2) {
 #pragma unroll
         for (int i = 0; i < D / 16; i++) xq[i] = ElemTraits<T>::load(reinterpret_cast<const T*>(a.k_new) + (size_t)h * D, c + 16 * i);
       }
       const int32_t p_now = *a.input_pos;
+      // QB: the new row was quantised ahead of the tile (once per step and row), and is attended to through its image like
+      // every other row; this lane holds chunk c of K, not the swizzled chunk: the LDS stash below puts it where it belongs
+      uint2 knq = make_uint2(0, 0), vnq = make_uint2(0, 0);
+      float2 knp = make_float2(0.f, 0.f), vnp = make_float2(0.f, 0.f);
+      if constexpr (QB) {  // by the inserting row group only; its operands were requested ahead of the tile, so this runs while the tile is in flight
+        knq = quant8_row16<T>(qb_kn.raw, knp);
+        vnq = quant8_row16<T>(qb_vn.raw, vnp);
+        qb_ins_u = um;
+      }
 #pragma unroll
       for (int u = 0; u < U; u++)
         if (u == um) {
-          kk[u].raw = kn.raw;
-          vv[u].raw = vn.raw;
+          if constexpr (QB) {
+            kq8[u] = knq; kpar[u] = knp;
+            vq8[u] = vnq; vpar[u] = vnp;
+          } else {
+            kk[u].raw = kn.raw;
+            vv[u].raw = vn.raw;
+          }
           if (!HYB || hyb_kind != 2) mword |= 1u << (8 * u);
         }
       if (HYB && blockIdx.z == 0) {  // ref: cache.py:997-1016 — bookkeeping of the hybrid decision
@@ -721,8 +839,14 @@ __global__ __launch_bounds__(NW * 64, ONE ? 2 : 1) void decode_attn_split_mfma_k
         }
       } else if (blockIdx.z == 0) {
         const size_t slot = (size_t)h * S + ins_idx;
-        *reinterpret_cast<uint4*>(const_cast<T*>(kb) + (size_t)ins_idx * D + kcol) = kn.raw;
-        *reinterpret_cast<uint4*>(const_cast<T*>(vh) + (size_t)ins_idx * D) = vn.raw;
+        if constexpr (QB) {
+          *reinterpret_cast<uint2*>(const_cast<uint8_t*>(kqb) + (size_t)ins_idx * D + c * VEC) = knq;
+          *reinterpret_cast<uint2*>(const_cast<uint8_t*>(vqh) + (size_t)ins_idx * D) = vnq;
+          if (c == 0) *reinterpret_cast<float4*>(a.qparams + slot * 4) = make_float4(knp.x, knp.y, vnp.x, vnp.y);
+        } else {
+          *reinterpret_cast<uint4*>(const_cast<T*>(kb) + (size_t)ins_idx * D + kcol) = kn.raw;
+          *reinterpret_cast<uint4*>(const_cast<T*>(vh) + (size_t)ins_idx * D) = vn.raw;
+        }
         if (c == 0) {
           if (a.Hp != 1 || h == 0) a.pos[(a.Hp == 1 ? 0 : (size_t)h * S) + ins_idx] = p_now;
           a.mask_w[slot] = 1;
@@ -749,7 +873,18 @@ __global__ __launch_bounds__(NW * 64, ONE ? 2 : 1) void decode_attn_split_mfma_k
 
     // ---- K tile -> wave-private LDS slab -> A operand; S^T = K q^T on the matrix core
 #pragma unroll
-    for (int u = 0; u < U; u++) sm_k[wave][4 * g + u][c] = kk[u].raw;
+    for (int u = 0; u < U; u++) {
+      if constexpr (QB) {  // slot c of tile row i holds chunk c ^ i; the inserted row's lane holds chunk c -> slot c ^ i
+        const int i = 4 * g + u;
+        sm_k[wave][i][u == qb_ins_u ? ((c ^ i) & 15) : c] = dequant8<T>(kq8[u], kpar[u]);
+      } else {
+        sm_k[wave][4 * g + u][c] = kk[u].raw;
+      }
+    }
+    qb_ins_u = -1;  // later tiles of this wave hold no inserted row
+    if constexpr (ONE) {
+      if (a.trace && trA == 0) trA = __builtin_amdgcn_s_memtime();  // this wave's K rows have arrived and sit in its LDS slab
+    }
     const uint32_t mcur = mword;
     if (more_next) issue_k(base_next);  // K registers are free again: the next tile streams in behind this tile's math
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -772,6 +907,7 @@ __global__ __launch_bounds__(NW * 64, ONE ? 2 : 1) void decode_attn_split_mfma_k
     if constexpr (ONE) {
 #pragma unroll
       for (int t = 0; t < U; t++) s_keep[t] = s[t];
+      if (a.trace && trB == 0) trB = __builtin_amdgcn_s_memtime();  // scores of the tile are in registers
     }
     if (!ONE && c < RT && !(a.abl & 1)) {
       const size_t o = (size_t)(q0 + c) * S + row0;
@@ -812,7 +948,8 @@ __global__ __launch_bounds__(NW * 64, ONE ? 2 : 1) void decode_attn_split_mfma_k
     // ---- O^T += V^T . P^T on the matrix cores: V tile -> wave-private LDS slab (row major, coalesced), A fragments
     //      back through the transpose read, B = this lane's four probabilities in 16 bit
 #pragma unroll
-    for (int u = 0; u < U; u++) sm_v[wave][4 * g + u][(c ^ (2 * ((4 * g + u) & 7))) & 15] = vv[u].raw;
+    for (int u = 0; u < U; u++)
+      sm_v[wave][4 * g + u][(c ^ (2 * ((4 * g + u) & 7))) & 15] = QB ? dequant8<T>(vq8[u], vpar[u]) : vv[u].raw;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -828,6 +965,9 @@ __global__ __launch_bounds__(NW * 64, ONE ? 2 : 1) void decode_attn_split_mfma_k
       }
     }
     __builtin_amdgcn_wave_barrier();  // the next tile's V stores must stay behind these reads
+    if constexpr (ONE) {
+      if (a.trace && trC == 0) trC = __builtin_amdgcn_s_memtime();  // P.V of the tile issued
+    }
     if (more_next) issue_v(base_next);
     base = base_next;
     more = more_next;
@@ -1167,6 +1307,7 @@ __global__ __launch_bounds__(NW * 64, ONE ? 2 : 1) void decode_attn_split_mfma_k
         tr[8] = __builtin_amdgcn_s_memrealtime();
         tr[9] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID
         tr[10] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));  // HW_REG_XCC_ID[3:0]
+        tr[11] = trA; tr[12] = trB; tr[13] = trC;  // wave 0: K arrived / scores ready / P.V issued
       }
     }
     return;
@@ -1663,7 +1804,13 @@ static int launch_split(const SplitArgs& a, const Plan& p, int H, int R, int D, 
     if (D == 128 && !(a.abl & 32)) {  // matrix-core streaming pass (abl bit 32 = measurement: force the VALU kernel)
       static_assert(kU == 4, "the MFMA tile is 4 row groups x 4 rows per wave");
       dim3 grid(p.n_split, H, R / p.rt), block(kNW * 64);
-      if (a.hyb.strategies != nullptr) {
+      if (a.qparams != nullptr) {  // fused quantised cache: 4 or 8 query heads per kv head
+        switch (p.rt) {
+          case 8: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 8, kNW, false, false, false, 8>), grid, block, 0, st, a); break;
+          case 4: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 4, kNW, false, false, false, 8>), grid, block, 0, st, a); break;
+          default: return CC_ERR_UNSUPPORTED;
+        }
+      } else if (a.hyb.strategies != nullptr) {
         switch (p.rt) {
           case 8: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 8, kNW, false, false, true>), grid, block, 0, st, a); break;
           case 4: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 4, kNW, false, false, true>), grid, block, 0, st, a); break;
@@ -1689,6 +1836,7 @@ static int launch_split(const SplitArgs& a, const Plan& p, int H, int R, int D, 
       return CC_OK;
     }
   }
+  if (a.qparams != nullptr) return CC_ERR_UNSUPPORTED;  // the fused quantised cache exists in the matrix-core streaming pass only
   if (p.rt > 4) return CC_ERR_UNSUPPORTED;  // 8 heads per pass exist on the matrix-core path only (reached here only by the measurement switch)
   if (a.hyb.strategies != nullptr) return CC_ERR_UNSUPPORTED;  // the hybrid decision exists in the matrix-core streaming pass only
   switch (D) {
@@ -1742,7 +1890,14 @@ static int one_capacity(KernelT kernel) {
   return cap;
 }
 template <typename T>
-static int one_capacity_rt(int rt) {
+static int one_capacity_rt(int rt, int qb = 0) {
+  if (qb) {
+    switch (rt) {
+      case 8: return one_capacity(decode_attn_split_mfma_kernel<T, 8, kNW, false, true, false, 8>);
+      case 4: return one_capacity(decode_attn_split_mfma_kernel<T, 4, kNW, false, true, false, 8>);
+      default: return 0;
+    }
+  }
   switch (rt) {
     case 8: return one_capacity(decode_attn_split_mfma_kernel<T, 8, kNW, false, true>);
     case 4: return one_capacity(decode_attn_split_mfma_kernel<T, 4, kNW, false, true>);
@@ -1753,6 +1908,15 @@ static int one_capacity_rt(int rt) {
 template <typename T>
 static int launch_one(const SplitArgs& a, const Plan& p, int H, hipStream_t st) {
   dim3 grid(p.n_split, H, 1), block(kNW * 64);
+  if (a.qparams != nullptr) {
+    switch (p.rt) {
+      case 8: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 8, kNW, false, true, false, 8>), grid, block, 0, st, a); break;
+      case 4: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 4, kNW, false, true, false, 8>), grid, block, 0, st, a); break;
+      default: return CC_ERR_UNSUPPORTED;
+    }
+    CC_LAUNCH_CHECK();
+    return CC_OK;
+  }
   switch (p.rt) {
     case 8: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 8, kNW, false, true>), grid, block, 0, st, a); break;
     case 4: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 4, kNW, false, true>), grid, block, 0, st, a); break;
@@ -1772,12 +1936,18 @@ size_t cc_decode_attn_workspace_bytes(int32_t HQ, int32_t H, int32_t S, int32_t 
   return kOneBytes + base_workspace_bytes(p, HQ, H, S, D, dtype);
 }
 
-int32_t cc_decode_step_single_launch(int32_t HQ, int32_t H, int32_t S, int32_t D, int32_t dtype) {
+static int32_t one_available(int32_t HQ, int32_t H, int32_t S, int32_t D, int32_t dtype, int qb) {
   if (HQ <= 0 || H <= 0 || HQ % H || S <= 0 || D <= 0 || !cc_dt_ok(dtype)) return 0;
   const Plan p = make_plan(HQ, H, S, D, dtype);
   if (!one_shape_ok(p, HQ, H, D, dtype)) return 0;
-  const int cap = dtype == CC_DT_BF16 ? one_capacity_rt<bf16_t>(p.rt) : one_capacity_rt<f16_t>(p.rt);
+  const int cap = dtype == CC_DT_BF16 ? one_capacity_rt<bf16_t>(p.rt, qb) : one_capacity_rt<f16_t>(p.rt, qb);
   return p.n_split * H <= cap ? 1 : 0;
+}
+int32_t cc_decode_step_single_launch(int32_t HQ, int32_t H, int32_t S, int32_t D, int32_t dtype) {
+  return one_available(HQ, H, S, D, dtype, 0);
+}
+int32_t cc_decode_step_quant_single_launch(int32_t HQ, int32_t H, int32_t S, int32_t D, int32_t dtype, int32_t n_bit) {
+  return n_bit == 8 ? one_available(HQ, H, S, D, dtype, 8) : 0;
 }
 
 int32_t cc_decode_step_status_offset(void) { return kOneStatusWord * (int32_t)sizeof(unsigned); }
@@ -1803,6 +1973,7 @@ struct FusedStep {
   const float* rand_next;
   void* key_norm;  // policy 4
   const HybridStep* hyb;  // policy 6
+  float* qparams;  // fused quantised cache: c->k_cache / v_cache are the uint8 images, c->dtype the model dtype
 };
 // The W > 1 history ring folded into the combine pass (denom / counter travel as hh_denom / hh_counter).
 struct RingHistory {
@@ -1862,6 +2033,12 @@ static int attn_impl(const void* q, const void* k, const void* v, const uint8_t*
     if ((size_t)H * sizeof(int32_t) > 192) return CC_ERR_UNSUPPORTED;  // 48 kv heads per rank at most (256-byte slot)
     sa.g = fs->g;
   }
+  if (fs && fs->qparams) {
+    if (cc_dt_size(dtype) != 2 || D != 128 || (fs->policy != 1 && fs->policy != 2 && fs->policy != 3) || rh || probs_out ||
+        ((phases >> 8) & 32) || (p.rt != 4 && p.rt != 8))
+      return CC_ERR_UNSUPPORTED;
+    sa.qparams = fs->qparams;
+  }
   if (fs) {
     sa.next_key = fs->next_key; sa.nk = cc_next_key_slots(S); sa.input_pos = fs->input_pos; sa.k_new = fs->k_new; sa.v_new = fs->v_new;
     sa.pos = fs->c->pos; sa.mask_w = fs->c->mask; sa.cache_cts = fs->c->cache_cts; sa.num = hh_num; sa.denom = hh_denom;
@@ -1876,7 +2053,7 @@ static int attn_impl(const void* q, const void* k, const void* v, const uint8_t*
     const bool policy_ok = fs && ((fs->policy == 1 && hh_num && hh_denom && fs->c->Hp == H) ||
                                   ((fs->policy == 2 || (fs->policy == 3 && fs->rand_next)) && !hh_num && fs->c->Hp == 1));
     const bool one_ok = policy_ok && !rh && !probs_out && !attn_out_needs_probs(fs, attn_out) &&
-                        cc_decode_step_single_launch(HQ, H, S, D, dtype) == 1;
+                        one_available(HQ, H, S, D, dtype, fs->qparams ? 8 : 0) == 1;
     if (one_asked && !one_ok) return CC_ERR_UNSUPPORTED;
     if (one_ok) {
       char* ob = reinterpret_cast<char*>(workspace);
@@ -1981,6 +2158,27 @@ int cc_decode_step_random(const cc_kv_view* c, const void* q, const void* k_new,
   FusedStep fs{c, k_new, v_new, input_pos, reinterpret_cast<unsigned long long*>(next_key), global_tokens, recent_window, 3, rand_next, nullptr};
   return attn_impl(q, c->k_cache, c->v_cache, c->mask, HQ, c->H, c->S, c->D, c->dtype, scale, y, nullptr, nullptr, nullptr, nullptr,
                    nullptr, workspace, workspace_bytes, stream, 3, &fs);
+}
+
+int cc_decode_step_quant(const cc_kv_view* c, float* qparams, int32_t n_bit, int32_t policy, const void* q, const void* k_new,
+                         const void* v_new, const int32_t* input_pos, double* num, int32_t* denom, int64_t* counter,
+                         const float* rand_next, uint64_t* next_key, int32_t global_tokens, int32_t recent_window, int32_t HQ,
+                         float scale, void* y, void* attn_out, void* workspace, size_t workspace_bytes, cc_stream_t stream,
+                         int32_t phases) {
+  if (!cc_view_ok(c) || !qparams || !q || !k_new || !v_new || !input_pos || !next_key || !y || HQ <= 0 || HQ % c->H ||
+      global_tokens < 0)
+    return CC_ERR_BAD_ARG;
+  if (n_bit != 8) return CC_ERR_UNSUPPORTED;
+  switch (policy) {
+    case 1: if (!num || !denom || c->Hp != c->H) return CC_ERR_BAD_ARG; break;
+    case 2: if (num || denom || c->Hp != 1 || global_tokens >= c->S) return CC_ERR_BAD_ARG; break;
+    case 3: if (num || denom || c->Hp != 1 || !rand_next) return CC_ERR_BAD_ARG; break;
+    default: return CC_ERR_UNSUPPORTED;
+  }
+  FusedStep fs{c, k_new, v_new, input_pos, reinterpret_cast<unsigned long long*>(next_key), global_tokens,
+               policy == 2 ? 0 : recent_window, policy, policy == 3 ? rand_next : nullptr, nullptr, nullptr, qparams};
+  return attn_impl(q, c->k_cache, c->v_cache, c->mask, HQ, c->H, c->S, c->D, c->dtype, scale, y, policy == 1 ? attn_out : nullptr,
+                   nullptr, num, denom, policy == 1 ? counter : nullptr, workspace, workspace_bytes, stream, phases, &fs);
 }
 
 int cc_decode_step_l2(const cc_kv_view* c, const void* q, const void* k_new, const void* v_new, const int32_t* input_pos,

@@ -38,6 +38,14 @@ __device__ __forceinline__ uint16_t f32_to_f16_bits(float f) {
   return h;
 }
 
+// An fp32 value the optimiser must treat as opaque: keeps `T(fmaf(a, b, c))` a TWO-step rounding (fp32, then T).  Without it the
+// f16 instantiations fuse the pair into v_fma_mixlo_f16 (ONE rounding of the exact result) wherever the pattern is visible, and
+// two kernels computing the same formula disagree by an ulp in the rare double-rounding cases.
+__device__ __forceinline__ float cc_opaque_f32(float x) {
+  asm("" : "+v"(x));
+  return x;
+}
+
 template <typename T>
 struct ElemTraits;
 template <>

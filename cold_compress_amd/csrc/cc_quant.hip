@@ -307,9 +307,97 @@ static int requant_launch(const RequantSet& rs, int n, int32_t H, int32_t S, int
   return CC_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// The FUSED quantised cache (opt-in; NOT the reference's contract — include/coldcompress.h): one
+// (scale, minimum) pair per (head, slot) ROW of K and of V, fp32, fixed when the row is written; the decode kernels read
+// the uint8 images and dequantise in registers.  These two kernels convert whole caches (prefill, debugging): one wave
+// per row, two passes over the row (the second one hits L1).
+template <typename T>
+__global__ __launch_bounds__(256) void kv_quant_rows_kernel(const T* k, const T* v, uint8_t* kq, uint8_t* vq, float* qparams,
+                                                           size_t rows, int D) {
+  const int lane = threadIdx.x & 63;
+  const size_t wid = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wid >= 2 * rows) return;
+  const int which = wid >= rows ? 1 : 0;
+  const size_t row = which ? wid - rows : wid;
+  const T* src = (which ? v : k) + row * D;
+  uint8_t* dst = (which ? vq : kq) + row * D;
+  float mn = INFINITY, mx = -INFINITY;
+  for (int e = lane; e < D; e += 64) {
+    const float x = ElemTraits<T>::load(src, e);
+    mn = fminf(mn, x);
+    mx = fmaxf(mx, x);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    mn = fminf(mn, __shfl_xor(mn, off, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+  }
+  const float range = fmaxf(__fsub_rn(mx, mn), 1e-6f);
+  const float sc = __fdiv_rn(range, 255.f), inv = __fdiv_rn(255.f, range);
+  for (int e = lane; e < D; e += 64) {
+    const float x = ElemTraits<T>::load(src, e);
+    dst[e] = (uint8_t)fminf(fmaxf(rintf(__fmul_rn(__fsub_rn(x, mn), inv)), 0.f), 255.f);
+  }
+  if (lane == 0) {
+    qparams[row * 4 + 2 * which] = sc;
+    qparams[row * 4 + 2 * which + 1] = mn;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void kv_dequant_rows_kernel(const uint8_t* kq, const uint8_t* vq, const float* qparams, T* k, T* v,
+                                                             size_t rows, int D) {
+  const size_t total = 2 * rows * (size_t)D;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int which = i >= rows * D ? 1 : 0;
+    const size_t j = which ? i - rows * D : i;
+    const size_t row = j / D;
+    const float sc = qparams[row * 4 + 2 * which], mn = qparams[row * 4 + 2 * which + 1];
+    const float x = cc_opaque_f32(__builtin_fmaf((float)(which ? vq : kq)[j], sc, mn));  // fp32 first, then T
+    ElemTraits<T>::store(which ? v : k, j, x);
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int cc_kv_quant_rows(const void* k, const void* v, int32_t H, int32_t S, int32_t D, int32_t dtype, int32_t n_bit, uint8_t* k_q,
+                     uint8_t* v_q, float* qparams, cc_stream_t stream) {
+  CC_ENTRY();
+  if (!k || !v || !k_q || !v_q || !qparams || H <= 0 || S <= 0 || D <= 0 || !cc_dt_ok(dtype)) return CC_ERR_BAD_ARG;
+  if (n_bit != 8) return CC_ERR_UNSUPPORTED;
+  const size_t rows = (size_t)H * S;
+  const unsigned blocks = (unsigned)((2 * rows + 3) / 4);
+  hipStream_t st = (hipStream_t)stream;
+  switch (dtype) {
+    case CC_DT_F32: hipLaunchKernelGGL(kv_quant_rows_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)k, (const float*)v, k_q, v_q, qparams, rows, D); break;
+    case CC_DT_BF16: hipLaunchKernelGGL(kv_quant_rows_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)k, (const bf16_t*)v, k_q, v_q, qparams, rows, D); break;
+    default: hipLaunchKernelGGL(kv_quant_rows_kernel<f16_t>, dim3(blocks), dim3(256), 0, st, (const f16_t*)k, (const f16_t*)v, k_q, v_q, qparams, rows, D); break;
+  }
+  CC_LAUNCH_CHECK();
+  return CC_OK;
+}
+
+int cc_kv_dequant_rows(const uint8_t* k_q, const uint8_t* v_q, const float* qparams, int32_t H, int32_t S, int32_t D, int32_t dtype,
+                       int32_t n_bit, void* k_out, void* v_out, cc_stream_t stream) {
+  CC_ENTRY();
+  if (!k_q || !v_q || !qparams || !k_out || !v_out || H <= 0 || S <= 0 || D <= 0 || !cc_dt_ok(dtype)) return CC_ERR_BAD_ARG;
+  if (n_bit != 8) return CC_ERR_UNSUPPORTED;
+  const size_t rows = (size_t)H * S;
+  size_t nb = (2 * rows * D + 255) / 256;
+  if (nb > 8192) nb = 8192;
+  hipStream_t st = (hipStream_t)stream;
+  switch (dtype) {
+    case CC_DT_F32: hipLaunchKernelGGL(kv_dequant_rows_kernel<float>, dim3((unsigned)nb), dim3(256), 0, st, k_q, v_q, qparams, (float*)k_out, (float*)v_out, rows, D); break;
+    case CC_DT_BF16: hipLaunchKernelGGL(kv_dequant_rows_kernel<bf16_t>, dim3((unsigned)nb), dim3(256), 0, st, k_q, v_q, qparams, (bf16_t*)k_out, (bf16_t*)v_out, rows, D); break;
+    default: hipLaunchKernelGGL(kv_dequant_rows_kernel<f16_t>, dim3((unsigned)nb), dim3(256), 0, st, k_q, v_q, qparams, (f16_t*)k_out, (f16_t*)v_out, rows, D); break;
+  }
+  CC_LAUNCH_CHECK();
+  return CC_OK;
+}
 
 int cc_kv_requant(void* work, void* q_out, void* scales, void* zeros, int32_t H, int32_t S, int32_t D, int32_t dtype,
                   int32_t n_bit, cc_stream_t stream) {

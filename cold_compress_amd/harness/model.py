@@ -241,6 +241,8 @@ class Transformer(nn.Module):
         for i, b in enumerate(self.layers):
             ctor, relevant = get_cache_constructor(cache_strategy=cache_strategy[i])
             lk = {k: kwargs[k][i] if k in layerwise else kwargs[k] for k in relevant}
+            if kwargs.get("cache_quant_mode") and "cache_bits" in relevant:  # our extension: the fused quantised cache
+                lk["cache_quant_mode"] = kwargs["cache_quant_mode"]
             b.attention.kv_cache = ctor(self.max_batch_size, self.config.n_local_heads, head_dim, dtype, **lk)
             b.attention.prompt_compressor = get_prompt_compressor_constructor(
                 kwargs["prompt_compression_strategy"][i])(head_specific=b.attention.kv_cache.head_specific, **lk)

@@ -262,7 +262,8 @@ int32_t cc_decode_step_status_offset(void);
 void cc_decode_step_set_single_launch(int32_t enabled);
 /* Measurement hook: buf = device buffer of [workgroups][16] uint64, or NULL (default).  While set, thread 0 of every
  * workgroup of a single-launch step records [0..5] s_memtime stamps (start, streaming done, published, sentinel seen,
- * gathered, end), [6..8] s_memrealtime at start / streaming done / end, [9] HW_ID, [10] XCC_ID. */
+ * gathered, end), [6..8] s_memrealtime at start / streaming done / end, [9] HW_ID, [10] XCC_ID, [11..13] s_memtime of wave 0
+ * when its K rows have arrived / its scores are in registers / its P.V products are issued. */
 void cc_decode_step_trace(void* buf);
 /* The two-launch step for KVCacheHybrid (FastGen per-head policies; cache.py:896-1019 + the fused ring update of
  * cc_decode_attn_gqa_ring): three launches -> two.  What a head does with the incoming token — append at the end of its
@@ -328,6 +329,42 @@ int cc_kv_requant_pair(void* k_work, void* k_q, void* k_scales, void* k_zeros, v
                        int32_t Hp, uint8_t* stable, int32_t* pos_seen, cc_stream_t stream);
 int cc_kv_dequant(const void* q, const void* scales, const void* zeros, void* work_out, int32_t H, int32_t S,
                   int32_t D, int32_t dtype, int32_t n_bit, cc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * FUSED quantised KV cache — opt-in (`cache_quant_mode="fused"`), a DIFFERENT numerical contract from the reference's
+ * ("fuse dequant into the attention read instead of whole-cache round trips").
+ * The reference (cache.py:283-338, quantization_utils.py:4-45) keeps ONE (scale, zero) per slot shared by all heads and
+ * re-quantises the whole cache every step; its numbers are reproduced by cc_kv_requant above.  Here instead:
+ *   - one (scale, minimum) pair per (head, slot) ROW of K and one per row of V, float32, fixed when the row is written:
+ *       mn, mx = min / max over the row's D values;  range = max(mx - mn, 1e-6f);  scale = range / 255.f;
+ *       q[d]   = (uint8) clamp(rintf((x[d] - mn) * (255.f / range)), 0, 255)          (IEEE fp32 ops, round-half-even)
+ *       value  = T(fmaf((float)q[d], scale, mn))                                      (one rounding to the model dtype)
+ *   - a row is quantised exactly once (at prefill or when the decode step inserts it) and never re-quantised: no drift;
+ *     the inserted token is attended to through its image in the step that inserts it (the reference attends to the
+ *     unquantised new token once and to its round trip afterwards);
+ *   - the decode kernels stream the uint8 images (half the bytes of a 16-bit cache) and dequantise in registers on the way
+ *     to the matrix cores; everything else of the step (scores -> dtype, softmax, P.V, history, next-eviction key) is the
+ *     fused step of cc_decode_step_heavy_hitter / _recent_global / _random applied to the dequantised values.
+ * qparams: float32 [H, S, 4] = (k_scale, k_min, v_scale, v_min) per (head, slot).  n_bit: 8 (others: CC_ERR_UNSUPPORTED).
+ * cc_kv_quant_rows / cc_kv_dequant_rows convert whole caches ([H, S, D] model dtype <-> uint8 images + qparams).
+ * cc_decode_step_quant: c->k_cache / c->v_cache are the uint8 IMAGES [H, S, D], c->dtype the MODEL dtype (of q, k_new,
+ *   v_new, y, attn_out); 16-bit dtype, D == 128, HQ / H in {4, 8} (CC_ERR_UNSUPPORTED otherwise).
+ *   policy: 1 = heavy hitter (num / denom / counter as in cc_decode_step_heavy_hitter, c->Hp == H),
+ *           2 = recent_global / full (num = denom = NULL, c->Hp == 1), 3 = random (rand_next as in cc_decode_step_random).
+ *   next_key comes from the policy's own *_next_key_init (it reads positions and history only, never K / V).
+ *   phases: as cc_decode_step_heavy_hitter_phases (3 = the whole step; CC_PHASE_* select the launch form);
+ *   cc_decode_step_quant_single_launch: 1 when the single-launch form is available for the shape on this device.
+ * ---------------------------------------------------------------------------------------------- */
+int cc_kv_quant_rows(const void* k, const void* v, int32_t H, int32_t S, int32_t D, int32_t dtype, int32_t n_bit,
+                     uint8_t* k_q, uint8_t* v_q, float* qparams, cc_stream_t stream);
+int cc_kv_dequant_rows(const uint8_t* k_q, const uint8_t* v_q, const float* qparams, int32_t H, int32_t S, int32_t D,
+                       int32_t dtype, int32_t n_bit, void* k_out, void* v_out, cc_stream_t stream);
+int cc_decode_step_quant(const cc_kv_view* c, float* qparams, int32_t n_bit, int32_t policy, const void* q,
+                         const void* k_new, const void* v_new, const int32_t* input_pos, double* num, int32_t* denom,
+                         int64_t* counter, const float* rand_next, uint64_t* next_key, int32_t global_tokens,
+                         int32_t recent_window, int32_t HQ, float scale, void* y, void* attn_out, void* workspace,
+                         size_t workspace_bytes, cc_stream_t stream, int32_t phases);
+int32_t cc_decode_step_quant_single_launch(int32_t HQ, int32_t H, int32_t S, int32_t D, int32_t dtype, int32_t n_bit);
 
 /* ------------------------------------------------------------------------------------------------
  * Prefill-time cache fill.  ref: KVCache._prefill_update / _fill_contiguous cache.py:381-401.

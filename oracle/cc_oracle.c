@@ -1552,6 +1552,124 @@ int cc_kv_dequant_cpu(const void* q, const void* scales, const void* zeros, void
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * FUSED quantised cache (opt-in; the build's own contract, NOT the reference's — include/coldcompress.h): one
+ * (scale, minimum) pair per (head, slot) row, fp32; range = max(mx - mn, 1e-6f), scale = range / 255,
+ * q = clamp(rint((x - mn) * (255 / range)), 0, 255); value = T(fmaf(q, scale, mn)).
+ * The step twin dequantises the whole cache, runs the policy's fused step on it with the new token replaced by the
+ * round trip of its own image, and records the image — the arithmetic the device performs in registers.
+ * ---------------------------------------------------------------------------------------------- */
+int cc_decode_step_recent_global_cpu(const cc_kv_view* c, const void* q, const void* k_new, const void* v_new,
+                                     const int32_t* input_pos, uint64_t* next_key, int32_t g, int32_t HQ, float scale, void* y,
+                                     void* workspace, size_t workspace_bytes, cc_stream_t stream);
+
+static void quant_row8(const void* src, int dt, size_t off, int D, uint8_t* dst, float* sc_out, float* mn_out) {
+  float mn = INFINITY, mx = -INFINITY;
+  for (int d = 0; d < D; d++) {
+    const float x = ld(src, dt, off + d);
+    if (x < mn) mn = x;
+    if (x > mx) mx = x;
+  }
+  float range = mx - mn;
+  if (!(range > 1e-6f)) range = 1e-6f;
+  const float sc = range / 255.f, inv = 255.f / range;
+  for (int d = 0; d < D; d++) {
+    float t = nearbyintf((ld(src, dt, off + d) - mn) * inv);
+    if (t < 0.f) t = 0.f;
+    if (t > 255.f) t = 255.f;
+    dst[d] = (uint8_t)t;
+  }
+  *sc_out = sc;
+  *mn_out = mn;
+}
+
+int cc_kv_quant_rows_cpu(const void* k, const void* v, int32_t H, int32_t S, int32_t D, int32_t dt, int32_t n_bit, uint8_t* k_q,
+                         uint8_t* v_q, float* qparams, cc_stream_t stream) {
+  (void)stream;
+  if (!k || !v || !k_q || !v_q || !qparams || H <= 0 || S <= 0 || D <= 0 || !dt_ok(dt)) return CC_ERR_BAD_ARG;
+  if (n_bit != 8) return CC_ERR_UNSUPPORTED;
+  for (size_t r = 0; r < (size_t)H * S; r++) {
+    quant_row8(k, dt, r * D, D, k_q + r * D, &qparams[r * 4], &qparams[r * 4 + 1]);
+    quant_row8(v, dt, r * D, D, v_q + r * D, &qparams[r * 4 + 2], &qparams[r * 4 + 3]);
+  }
+  return CC_OK;
+}
+
+int cc_kv_dequant_rows_cpu(const uint8_t* k_q, const uint8_t* v_q, const float* qparams, int32_t H, int32_t S, int32_t D, int32_t dt,
+                           int32_t n_bit, void* k_out, void* v_out, cc_stream_t stream) {
+  (void)stream;
+  if (!k_q || !v_q || !qparams || !k_out || !v_out || H <= 0 || S <= 0 || D <= 0 || !dt_ok(dt)) return CC_ERR_BAD_ARG;
+  if (n_bit != 8) return CC_ERR_UNSUPPORTED;
+  for (size_t r = 0; r < (size_t)H * S; r++)
+    for (int d = 0; d < D; d++) {
+      st(k_out, dt, r * D + d, fmaf((float)k_q[r * D + d], qparams[r * 4], qparams[r * 4 + 1]));
+      st(v_out, dt, r * D + d, fmaf((float)v_q[r * D + d], qparams[r * 4 + 2], qparams[r * 4 + 3]));
+    }
+  return CC_OK;
+}
+
+int cc_decode_step_quant_cpu(const cc_kv_view* c, float* qparams, int32_t n_bit, int32_t policy, const void* q, const void* k_new,
+                             const void* v_new, const int32_t* input_pos, double* num, int32_t* denom, int64_t* counter,
+                             const float* rand_next, uint64_t* next_key, int32_t g, int32_t w, int32_t HQ, float scale, void* y,
+                             void* attn_out, void* workspace, size_t workspace_bytes, cc_stream_t stream, int32_t phases) {
+  if (!view_ok(c) || !qparams || !q || !k_new || !v_new || !input_pos || !next_key || !y) return CC_ERR_BAD_ARG;
+  if (n_bit != 8 || (phases & 3) != 3 || (policy != 1 && policy != 2 && policy != 3)) return CC_ERR_UNSUPPORTED;
+  const int H = c->H, S = c->S, D = c->D, dt = c->dtype;
+  const size_t es = dt_size(dt), n = (size_t)H * S * D;
+  void* kw = malloc(n * es);
+  void* vw = malloc(n * es);
+  void* kn = malloc((size_t)H * D * es);
+  void* vn = malloc((size_t)H * D * es);
+  uint8_t* img = (uint8_t*)malloc((size_t)2 * H * D);
+  float* par = (float*)malloc((size_t)H * 4 * sizeof(float));
+  int64_t* idx = (int64_t*)malloc((size_t)H * sizeof(int64_t));
+  int rc = CC_ERR_BAD_ARG;
+  if (kw && vw && kn && vn && img && par && idx) {
+    rc = cc_kv_dequant_rows_cpu((const uint8_t*)c->k_cache, (const uint8_t*)c->v_cache, qparams, H, S, D, dt, 8, kw, vw, stream);
+    /* the slot every head writes this step: the minimum of its partial keys (what the step itself will take) */
+    const int nk = cc_hh_next_key_slots_cpu(S);
+    for (int h = 0; h < H && rc == CC_OK; h++) {
+      const uint64_t* row = next_key + (size_t)(c->Hp == 1 ? 0 : h) * nk;
+      uint64_t key = ~(uint64_t)0;
+      for (int i = 0; i < nk; i++)
+        if (row[i] < key) key = row[i];
+      if (key == ~(uint64_t)0) rc = CC_ERR_BAD_ARG;
+      idx[h] = (int64_t)((key & 0xffffffffu) >> 1);
+    }
+    if (rc == CC_OK) {
+      /* the new token's image, and the values every later read (this step's attention included) sees */
+      for (int h = 0; h < H; h++) {
+        quant_row8(k_new, dt, (size_t)h * D, D, img + (size_t)h * D, &par[h * 4], &par[h * 4 + 1]);
+        quant_row8(v_new, dt, (size_t)h * D, D, img + (size_t)(H + h) * D, &par[h * 4 + 2], &par[h * 4 + 3]);
+        for (int d = 0; d < D; d++) {
+          st(kn, dt, (size_t)h * D + d, fmaf((float)img[(size_t)h * D + d], par[h * 4], par[h * 4 + 1]));
+          st(vn, dt, (size_t)h * D + d, fmaf((float)img[(size_t)(H + h) * D + d], par[h * 4 + 2], par[h * 4 + 3]));
+        }
+      }
+      cc_kv_view t = *c;
+      t.k_cache = kw;
+      t.v_cache = vw;
+      if (policy == 1)
+        rc = cc_decode_step_heavy_hitter_cpu(&t, q, kn, vn, input_pos, num, denom, counter, next_key, g, w, HQ, scale, y, attn_out,
+                                             workspace, workspace_bytes, stream);
+      else if (policy == 2)
+        rc = cc_decode_step_recent_global_cpu(&t, q, kn, vn, input_pos, next_key, g, HQ, scale, y, workspace, workspace_bytes, stream);
+      else
+        rc = cc_decode_step_random_cpu(&t, q, kn, vn, input_pos, rand_next, next_key, g, w, HQ, scale, y, workspace, workspace_bytes,
+                                       stream);
+    }
+    if (rc == CC_OK)
+      for (int h = 0; h < H; h++) {
+        const size_t row = (size_t)h * S + (size_t)idx[h];
+        memcpy((uint8_t*)c->k_cache + row * D, img + (size_t)h * D, (size_t)D);
+        memcpy((uint8_t*)c->v_cache + row * D, img + (size_t)(H + h) * D, (size_t)D);
+        memcpy(qparams + row * 4, par + h * 4, 4 * sizeof(float));
+      }
+  }
+  free(kw); free(vw); free(kn); free(vn); free(img); free(par); free(idx);
+  return rc;
+}
+
+/* ------------------------------------------------------------------------------------------------
  * Decode-time dense layers with the caller glue fused (see include/coldcompress.h: cc_gemv_fused).
  * Plain restatement of the eager chain (model.py:317-327, 375-387, 442-443, 452-457, 507-519): every tensor op
  * rounds to the model dtype; dot products accumulate in fp32 (summation order is unspecified -> tolerance class).

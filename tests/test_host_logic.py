@@ -58,6 +58,8 @@ def test_registry_and_relevant_kwargs(f8):
     ap = argparse.ArgumentParser()
     cache.add_cache_arguments(ap)
     assert vars(ap.parse_args([])) == f8["arg_defaults"]
+    cache.add_extension_arguments(ap)  # our own flags live apart from the reference's set
+    assert set(vars(ap.parse_args([]))) - set(f8["arg_defaults"]) == {"cache_quant_mode"}
     ns = ap.parse_args(["--cache_strategy", "heavy_hitter", "--prompt_compression_strategy", "heavy_hitter",
                         "--max_cache_length", "0.25"])
     cache.cache_compatibility(ns)

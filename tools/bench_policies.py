@@ -47,11 +47,20 @@ def make(strategy, H, S, D, extra=None):
               attn_thresholding=False, token_ids={"special": [[1], [2, 3]], "punctuation": [5, 6, 7]}, min_recovery_frac=0.9,
               hybrid_strategies=HYBRID)
     kw.update(extra or {})
+    lk = {k: kw[k] for k in rk}
+    if kw.get("cache_quant_mode"):
+        lk["cache_quant_mode"] = kw["cache_quant_mode"]
     with torch.device(dev):
-        kv = cls(1, H, D, torch.bfloat16, **{k: kw[k] for k in rk})
+        kv = cls(1, H, D, torch.bfloat16, **lk)
     T = S
-    kv.k_cache.normal_()
-    kv.v_cache.normal_()
+    if getattr(kv, "fused_quant", False):  # uint8 images of N(0, 1) rows: 255 steps over [-3.2, 3.2]
+        kv.k_cache_q.copy_((torch.randn(kv.cache_shape, device=dev) * 40 + 128).clamp_(0, 255).to(torch.uint8))
+        kv.v_cache_q.copy_((torch.randn(kv.cache_shape, device=dev) * 40 + 128).clamp_(0, 255).to(torch.uint8))
+        kv.kv_qparams[..., 0::2] = 6.4 / 255
+        kv.kv_qparams[..., 1::2] = -3.2
+    else:
+        kv.k_cache.normal_()
+        kv.v_cache.normal_()
     kv.pos[0] = torch.stack([torch.randperm(S + 64, device=dev)[:S] for _ in range(kv.pos.shape[1])]).int()
     kv.mask.fill_(True)
     kv.cache_cts.fill_(S)
@@ -102,6 +111,16 @@ def main():
                 for kv in caches:
                     kv.prepare_decode(pos)
                 res["fused_step_us"] = round(timed(lambda i: caches[i % n_buf].decode_step(q, k1, k1, pos), n_buf), 2)
+            if strategy in ("heavy_hitter", "recent_global", "full", "random"):
+                # the opt-in fused quantised cache (cache_bits=8, cache_quant_mode="fused"): uint8 images streamed, dequantised in registers
+                del caches
+                torch.cuda.empty_cache()
+                caches = [make(strategy, H, S, D, {"cache_bits": 8, "cache_quant_mode": "fused"}) for _ in range(n_buf)]
+                for kv in caches:
+                    kv.prepare_decode(pos)
+                for i in range(n_buf):
+                    caches[i].decode_step(q, k1, k1, pos)
+                res["fused_quant8_step_us"] = round(timed(lambda i: caches[i % n_buf].decode_step(q, k1, k1, pos), n_buf), 2)
             if strategy == "hybrid" and caches[0].supports_fused_step():
                 for kv in caches:
                     kv.prepare_decode(pos)

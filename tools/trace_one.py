@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--H", type=int, default=8)
     ap.add_argument("--HQ", type=int, default=32)
     ap.add_argument("--abl", type=int, nargs="+", default=[0, 1], help="0 = default (every thread polls), 1 = sentinel wave first")
+    ap.add_argument("--quant", action="store_true", help="the fused quantised cache (cache_bits=8, cache_quant_mode='fused')")
     a = ap.parse_args()
     dev, D, H, HQ = "cuda", 128, a.H, a.HQ
     fns = _abi.lib()
@@ -36,10 +37,19 @@ def main():
                   history_window_size=1, attn_thresholding=False)
         caches = []
         for _ in range(n_buf):
+            lk = {k: kw[k] for k in rk}
+            if a.quant:
+                lk.update(cache_bits=8, cache_quant_mode="fused")
             with torch.device(dev):
-                kv = cls(1, H, D, torch.bfloat16, **{k: kw[k] for k in rk})
-            kv.k_cache.normal_()
-            kv.v_cache.normal_()
+                kv = cls(1, H, D, torch.bfloat16, **lk)
+            if a.quant:
+                kv.k_cache_q.copy_((torch.randn(kv.cache_shape, device=dev) * 40 + 128).clamp_(0, 255).to(torch.uint8))
+                kv.v_cache_q.copy_((torch.randn(kv.cache_shape, device=dev) * 40 + 128).clamp_(0, 255).to(torch.uint8))
+                kv.kv_qparams[..., 0::2] = 6.4 / 255
+                kv.kv_qparams[..., 1::2] = -3.2
+            else:
+                kv.k_cache.normal_()
+                kv.v_cache.normal_()
             kv.pos[0] = torch.stack([torch.randperm(S + 64, device=dev)[:S] for _ in range(H)]).int()
             kv.mask.fill_(True)
             kv.cache_cts.fill_(S)
@@ -60,6 +70,12 @@ def main():
         def fstep(i, phases):
             kv = caches[i % n_buf]
             st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            if a.quant:
+                rc = fns["cc_decode_step_quant"](
+                    kv._view(), p(kv.kv_qparams), 8, 1, p(q), p(k1), p(k1), p(pos), p(kv.attn_history_num), p(kv.attn_history_denom),
+                    p(kv.attn_counter), None, p(kv.next_key), 4, 10, HQ, 1.0 / math.sqrt(D), p(y), None, p(ws), nbytes, st, phases)
+                assert rc == 0, rc
+                return
             rc = fns["cc_decode_step_heavy_hitter_phases"](
                 kv._view(), p(q), p(k1), p(k1), p(pos), p(kv.attn_history_num), p(kv.attn_history_denom),
                 p(kv.attn_counter), p(kv.next_key), 4, 10, HQ, 1.0 / math.sqrt(D), p(y), None, p(ws), nbytes, st, phases)
@@ -94,7 +110,7 @@ def main():
             rel = (t[:, :6] - t0).astype(np.float64)
             span = rel[:, 5].max()
             names = ["start", "stream_done", "published", "sentinel_seen", "gathered", "end"]
-            out = {"S": S, "abl": abl, "us_per_launch_events": round(us_per, 2), "workgroups": int(used.sum()),
+            out = {"S": S, "quant": bool(a.quant), "abl": abl, "us_per_launch_events": round(us_per, 2), "workgroups": int(used.sum()),
                    "ticks_total": float(span)}
             base = t[:, 6].min()
             r0, r1, r2 = t[:, 6] - base, t[:, 7] - base, t[:, 8] - base
@@ -130,6 +146,12 @@ def main():
             out["end_minus_head_last_stream_done_10ns"] = round(float((r2.reshape(H, nsplit).max(axis=1) - hr1.max(axis=1)).mean()), 1)
             out["gather_rtt_mean"] = round(float((ph_[:, :, 4] - ph_[:, :, 3]).mean()), 1)
             out["finish_mean"] = round(float((ph_[:, :, 5] - ph_[:, :, 4]).mean()), 1)
+            if t.shape[1] > 13 and (t[:, 11] != 0).all():  # wave 0 of every workgroup, ticks since its start
+                for nm, col in (("k_arrived", 11), ("scores_ready", 12), ("pv_issued", 13)):
+                    d_ = (t[:, col] - t[:, 0]).astype(np.float64)
+                    out[nm + "_min_mean_max"] = [float(d_.min()), round(float(d_.mean()), 1), float(d_.max())]
+                d_ = (t[:, 1] - t[:, 0]).astype(np.float64)
+                out["stream_done_min_mean_max"] = [float(d_.min()), round(float(d_.mean()), 1), float(d_.max())]
             print(json.dumps(out), flush=True)
 
 
