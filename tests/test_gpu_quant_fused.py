@@ -218,3 +218,51 @@ def test_fused_quant_mode_is_opt_in_and_loud():
                      torch.zeros(1, 2, 1, 128, dtype=torch.bfloat16, device=DEV), False)
     stats = kv.compute_statistics(torch.tensor(10))
     assert "working_cache_gb" not in stats and stats["cache_memory_gb"] > 0
+
+
+def test_fused_quant_end_to_end_in_the_harness():
+    """The whole loop (prefill through the HIP path, row quantisation of the compacted prompt, hipGraph decode over the uint8
+    images) on a small Llama-shaped model: next-token distributions stay close to the unquantised run's (8-bit rows), the
+    cache statistics report half the bytes, and the single-launch hand-off never times out."""
+    from cold_compress_amd.harness import GraphedDecoder, ModelArgs, Transformer, decode_one_token, prefill, setup_caches
+
+    dev = torch.device(DEV)
+    cfg = dict(block_size=1024, vocab_size=512, n_layer=2, n_head=8, n_local_heads=2, dim=1024, intermediate_size=2048)
+    torch.manual_seed(5)
+    model = Transformer(ModelArgs(**cfg)).to(torch.bfloat16).eval()
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(5)
+        for n, p in model.named_parameters():
+            p.fill_(1.0) if "norm" in n else p.normal_(0.0, 0.05, generator=g)
+    model = model.to(dev)
+    prompt = torch.randint(0, cfg["vocab_size"], (300,), generator=torch.Generator().manual_seed(3), dtype=torch.int32).to(dev)
+    runs = {}
+    for name, extra in (("bf16", {}), ("fused", {"cache_bits": 8, "cache_quant_mode": "fused"})):
+        kw = dict(max_cache_length=[128.0], cache_bits=None, cache_length_pattern="tile", cache_strategy=["heavy_hitter"],
+                  cache_strategy_pattern="tile", feed_long_prompts=False, prompt_compression_strategy=["heavy_hitter"], global_tokens=4,
+                  recent_window=10, history_window_size=1, attn_thresholding=False, min_recovery_frac=0.9)
+        kw.update(extra)
+        setup_caches(model, None, dev, 400, kw)
+        with torch.no_grad():
+            tok, probs = prefill(model, prompt.view(1, -1), torch.arange(300, device=dev))
+            pos = torch.tensor([300], dtype=torch.int32, device=dev)
+            plist, toks = [probs.float().clone()], [int(tok)]
+            cur = tok.view(1, 1).to(torch.int32)
+            step = GraphedDecoder(model) if name == "fused" else decode_one_token
+            for i in range(16):
+                nt, pr = step(model, cur, pos)
+                plist.append(pr.float().clone())
+                toks.append(int(nt))
+                # teacher-force the unquantised run's tokens: both runs see the same inputs
+                cur = (nt if name == "bf16" else torch.tensor(runs["bf16"][0][len(toks) - 1], device=dev)).view(1, 1).to(torch.int32)
+                pos += 1
+        torch.cuda.synchronize()
+        kv = model.layers[0].attention.kv_cache
+        runs[name] = (toks, plist, kv.memory_usage(), kv)
+    assert torch.equal(runs["bf16"][1][0], runs["fused"][1][0])  # prefill attends to the prompt's own k / v: identical
+    worst = max(float((a - b).abs().max() / a.abs().max()) for a, b in zip(runs["bf16"][1], runs["fused"][1]))
+    agree = sum(int(a == b) for a, b in zip(runs["bf16"][0], runs["fused"][0]))
+    assert worst < 0.2 and agree >= len(runs["bf16"][0]) - 2, (worst, agree)
+    assert runs["fused"][2] < 0.6 * runs["bf16"][2]
+    kv = runs["fused"][3]
+    assert kv.fused_quant and kv.k_cache.numel() == 0 and kv.step_status(cfg["n_head"]) == 0

@@ -91,6 +91,7 @@ def main():
         ("C4 hybrid 1.0", dict(cache_strategy=["hybrid"], prompt_compression_strategy=["full"], max_cache_length=[1.0]), 16384),
         ("C4 heavy_hitter pyramid 1024", dict(max_cache_length=[1024.0], cache_length_pattern="pyramid"), 16384),
         ("heavy_hitter 4096 cache_bits=8", dict(cache_bits=8), 8192),
+        ("heavy_hitter 4096 cache_bits=8 fused", dict(cache_bits=8, cache_quant_mode="fused"), 8192),
     ]
     for name, cache, pl in cases:
         if a.only and a.only not in name:
