@@ -106,6 +106,17 @@ __device__ __forceinline__ float xor_combine(float v) {
   }
   return IS_MAX ? fmaxf(a, b) : a + b;
 }
+// sum over an aligned group of G lanes, G a WAVE-UNIFORM power of two <= 64: every lane of the group gets the total (xor
+// butterflies: DPP inside a row of 16, permlane swaps across rows — no LDS crossbar).  Fixed order -> deterministic.
+__device__ __forceinline__ float seg_sum(float v, int G) {
+  if (G >= 2) v += dpp_mov<0xB1>(v);
+  if (G >= 4) v += dpp_mov<0x4E>(v);
+  if (G >= 8) v += dpp_mov<0x141>(v);
+  if (G >= 16) v += dpp_mov<0x140>(v);
+  if (G >= 32) v = xor_combine<16, false>(v);
+  if (G >= 64) v = xor_combine<32, false>(v);
+  return v;
+}
 __device__ __forceinline__ float fast_exp(float x) {  // e^x via v_exp_f32 (2^x); exp(-inf) = 0
   return __builtin_amdgcn_exp2f(x * 1.4426950408889634f);
 }
@@ -156,7 +167,9 @@ struct SplitArgs {
   //      from the partial arg-min keys the PREVIOUS step's combine pass (or cc_hh_next_key_init) left in
   //      next_key[h][0..nk): their minimum is torch's arg-min.
   const unsigned long long* next_key;  // [H][nk]
-  int nk;
+  int nk;       // entries per key row (the row stride)
+  int nk_read;  // entries any writer may have left non-~0: all of them where the single-launch step can serve the shape,
+                // the first n_chunks otherwise (only the two-launch combine pass writes such rows)
   const int32_t* input_pos;
   const void* k_new;  // [H, D]
   const void* v_new;
@@ -241,7 +254,7 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_split_kernel(SplitArgs a)
   int ins_idx = -1, ins_was_empty = 0;
   bool key_pending = a.next_key != nullptr && !(a.abl & 128);
   unsigned long long key_part = ~0ull;
-  if (key_pending && lane < a.nk) key_part = a.next_key[(size_t)(a.Hp == 1 ? 0 : h) * a.nk + lane];
+  if (key_pending && lane < a.nk_read) key_part = a.next_key[(size_t)(a.Hp == 1 ? 0 : h) * a.nk + lane];
   // q: [RT][D] of this query group, this lane's VEC-wide column slice (L2-resident after the first workgroups)
   Vec16<T> qraw[RT];
 #pragma unroll
@@ -286,7 +299,7 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_split_kernel(SplitArgs a)
     // rows (and the position) are fetched inside this rare branch — one row group per kv head takes it — so
     // they cost nothing on the streaming path; their latency hides behind the K/V loads already in flight.
     if (key_pending) {  // wave-uniform; first iteration only
-      for (int i = lane + 64; i < a.nk; i += 64) {  // caches beyond 64 chunks (S > 8192)
+      for (int i = lane + 64; i < a.nk_read; i += 64) {  // caches beyond 64 chunks (S > 8192)
         const unsigned long long x = a.next_key[(size_t)(a.Hp == 1 ? 0 : h) * a.nk + i];
         key_part = x < key_part ? x : key_part;
       }
@@ -633,10 +646,15 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
   bool hyb_punc = false;
   bool key_pending = a.next_key != nullptr && !(a.abl & 128);
   unsigned long long key_part = ~0ull;
+  unsigned long long key_more[3] = {~0ull, ~0ull, ~0ull};  // up to 256 entries are requested at once and folded when first used
   if (key_pending) {
-    if (lane < a.nk) key_part = a.next_key[(size_t)(a.Hp == 1 ? 0 : h) * a.nk + lane];
-    // caches beyond 64 chunks (S > 8192) — kept OUT of the streaming loop so that the waits there stay exact
-    for (int i = lane + 64; i < a.nk; i += 64) {
+    const unsigned long long* krow = a.next_key + (size_t)(a.Hp == 1 ? 0 : h) * a.nk;
+    if (lane < a.nk_read) key_part = krow[lane];
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+      if (lane + 64 * (j + 1) < a.nk_read) key_more[j] = krow[lane + 64 * (j + 1)];
+    // rows beyond 256 live entries (two-launch step at S > 32768) — kept OUT of the streaming loop so that the waits there stay exact
+    for (int i = lane + 256; i < a.nk_read; i += 64) {
       const unsigned long long x = a.next_key[(size_t)(a.Hp == 1 ? 0 : h) * a.nk + i];
       key_part = x < key_part ? x : key_part;
     }
@@ -752,8 +770,12 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
   while (more) {
     const int row0 = base + g * U;
     const int base_next = base + NW * RPW * U;
-    const bool more_next = base_next < row_end;
+    // ONE: a wave owns exactly one tile (one_shape_ok: rows_per_split == one iteration's rows) — a compile-time fact, so that the
+    // next tile's address arithmetic, its loads, the loop's second body and the running-maximum rescale disappear from the code
+    const bool more_next = ONE ? false : base_next < row_end;
     if (key_pending) {  // wave-uniform; first iteration only
+#pragma unroll
+      for (int j = 0; j < 3; j++) key_part = key_more[j] < key_part ? key_more[j] : key_part;
       const unsigned long long key = wave_min_u64_uniform(key_part);
       ins_idx = (key == ~0ull) ? -1 : (int)((key & 0xffffffffull) >> 1);
       if (a.abl & 64) ins_idx = -1;
@@ -934,16 +956,18 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
       mx = xor_combine<32, true>(xor_combine<16, true>(mx));
       const float m_new = fmaxf(m, mx);
       const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-      const float alpha = fast_exp(m - m_use);
+      const float alpha = ONE ? 0.f : fast_exp(m - m_use);  // ONE: first and only tile — m = -inf, l = 0, acc = 0: nothing to rescale
       m = m_new;
-      l *= alpha;
+      if constexpr (!ONE) l *= alpha;
 #pragma unroll
       for (int t = 0; t < U; t++) {
         p[t] = fast_exp(s[t] - m_use);
         l += p[t];
       }
+      if constexpr (!ONE) {
 #pragma unroll
-      for (int b = 0; b < D / 16; b++) acc[b] *= alpha;  // every accumulator of this lane belongs to head c
+        for (int b = 0; b < D / 16; b++) acc[b] *= alpha;  // every accumulator of this lane belongs to head c
+      }
     }
     // ---- O^T += V^T . P^T on the matrix cores: V tile -> wave-private LDS slab (row major, coalesced), A fragments
     //      back through the transpose read, B = this lane's four probabilities in 16 bit
@@ -974,6 +998,8 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
   }
   if (L2 && l2_here) {  // publish this wave's maximum over the norms that survive this step
     if (key_pending) {  // a wave without rows never entered the loop
+#pragma unroll
+      for (int j = 0; j < 3; j++) key_part = key_more[j] < key_part ? key_more[j] : key_part;
       const unsigned long long key = wave_min_u64_uniform(key_part);
       ins_idx = (key == ~0ull) ? -1 : (int)((key & 0xffffffffull) >> 1);
     }
@@ -1041,8 +1067,6 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
     __shared__ float sm_w1[RT][64];  // exp(m_i - M_r)
     __shared__ float sm_M1[RT], sm_L1[RT];
     __shared__ __attribute__((aligned(16))) float sm_o1[2 * (RT * 64 + 64)];  // [split][pair of this workgroup][2]: raw partial O
-    __shared__ float sm_yp[2 * (RT * 64 + 64)];                                // [output][chain]: partial sums of y
-    __shared__ unsigned long long sm_key1[NW];
     const auto ml_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.one_ml, 0, (int)a.one_ml_bytes, 0x00020000);
     const auto o_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.one_o, 0, (int)a.one_o_bytes, 0x00020000);
     // ---- publish: thread t merges output columns 2t, 2t + 1 of the workgroup's partial (the arithmetic of the
@@ -1179,16 +1203,20 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
     for (int k = 0; k < NOG; k++)
       if (o_use[k]) *reinterpret_cast<float2*>(&sm_o1[o_lds[k]]) = make_float2(__uint_as_float(oq[k][1]), __uint_as_float(oq[k][3]));
     __syncthreads();
+    unsigned long long trD = 0, trE = 0;
+    if (a.trace) trD = __builtin_amdgcn_s_memtime();
     // ---- y: per output column, G1 strided chains over the splits ...
     const int n_out = 2 * n_pairs;
     const int sh = ns >= 8 ? 3 : (ns >= 4 ? 2 : (ns >= 2 ? 1 : 0)), G1 = 1 << sh;
-    // (tasks go to the LAST threads first: wave 0 keeps the workgroup's serial duties after the next barrier)
+    // The G1 chains of an output sit in G1 adjacent lanes: folded by DPP butterflies and stored at once — no partial sums
+    // through LDS, no second barrier, nothing of y left for the end of the launch (tasks go to the LAST threads first).
     for (int task = NW * 64 - 1 - (int)threadIdx.x; task < (n_out << sh); task += NW * 64) {
       const int ol = task >> sh, gg = task & (G1 - 1);
-      const int r = (2 * pair0 + ol) / D;
+      const int to = 2 * pair0 + ol, r = to / D;
       float part = 0.f;
       for (int i = gg; i < ns; i += G1) part = fmaf(sm_o1[i * ppw * 2 + ol], sm_w1[r][i], part);
-      sm_yp[task] = part;
+      part = seg_sum(part, G1);  // whole groups of G1 lanes are in or out of this loop together
+      if (gg == 0) ElemTraits<T>::store(reinterpret_cast<T*>(a.y), (size_t)(h * RT + r) * D + (to - r * D), part / sm_L1[r]);
     }
     // ---- this workgroup's slots.  ref: attention_utils.py:52 softmax -> model dtype; model.py:416-418 group mean -> model
     //      dtype; cache.py:716-722 history; cache.py:727-749 the next position's eviction score
@@ -1238,7 +1266,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
         } else {
           sum += pr[0];
         }
-        av = ElemTraits<T>::rnd(__fdiv_rn(sum, (float)RT));
+        av = ElemTraits<T>::rnd(sum * (1.0f / (float)RT));  // RT is a power of two: bit-identical to the IEEE divide of the combine pass
       }
       if (one_have) {
         const size_t i = (size_t)h * S + one_slot;
@@ -1276,25 +1304,19 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
       }
     }
     {
+      // one key per WAVE (a head's key row has room for NW per 64-slot workgroup): nothing crosses the waves after the one
+      // barrier of the finish, so no wave's stores wait for another wave (the launch ends a store round trip after the LAST
+      // store is issued: every store that can go out early shortens it)
       const unsigned long long wk = wave_min_u64_uniform(my_key);
-      if (lane == 0) sm_key1[wave] = wk;
-    }
-    __syncthreads();
-    for (int ol = (int)threadIdx.x; ol < n_out; ol += NW * 64) {
-      const int to = 2 * pair0 + ol, r = to / D, d = to - r * D;
-      float O = 0.f;
-      for (int gg = 0; gg < G1; gg++) O += sm_yp[(ol << sh) + gg];
-      ElemTraits<T>::store(reinterpret_cast<T*>(a.y), (size_t)(h * RT + r) * D + d, O / sm_L1[r]);
-    }
-    if (threadIdx.x == 0) {
-      unsigned long long bk = sm_key1[0];
-#pragma unroll
-      for (int w2 = 1; w2 < NW; w2++) bk = sm_key1[w2] < bk ? sm_key1[w2] : bk;
-      if (a.Hp != 1 || h == 0) {
+      if (lane == 0 && (a.Hp != 1 || h == 0)) {
         unsigned long long* nk_row = const_cast<unsigned long long*>(a.next_key) + (a.Hp == 1 ? 0 : (size_t)h * a.nk);
-        nk_row[split] = bk;  // every key of this row was consumed before its readers published: no reader is left
-        for (int s2 = split + ns; s2 < a.nk; s2 += ns) nk_row[s2] = ~0ull;
+        const int e0 = split * NW + wave;
+        nk_row[e0] = wk;  // every key of this row was consumed before its readers published: no reader is left
+        for (int s2 = e0 + ns * NW; s2 < a.nk; s2 += ns * NW) nk_row[s2] = ~0ull;
       }
+    }
+    if (a.trace) trE = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0) {
       if (split == 0) {
         a.one_hdr[h] = tag;  // all n_split workgroups of this head have published, hence read the old epoch
         if (h == 0 && a.hh_counter) *a.hh_counter += 1;
@@ -1308,6 +1330,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
         tr[9] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID
         tr[10] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));  // HW_REG_XCC_ID[3:0]
         tr[11] = trA; tr[12] = trB; tr[13] = trC;  // wave 0: K arrived / scores ready / P.V issued
+        tr[14] = trD; tr[15] = trE;                // finish: final (M, L) + weights in LDS / slots, y chains and keys done
       }
     }
     return;
@@ -1387,6 +1410,11 @@ __global__ __launch_bounds__(kCombThreads) void decode_attn_combine_kernel(Combi
   const int h = blockIdx.y, c = blockIdx.x, nchunks = gridDim.x;
   const int R = a.R, S = a.S, D = a.D, ns = a.n_split;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // a head's key row has kNextKeyPerChunk entries per block of this launch: this pass publishes the first, the others are kept
+  // at ~0 — written HERE, at the start (their readers, the streaming pass, are done), so that these stores drain during the
+  // launch instead of adding a store round trip behind its last instruction
+  if (a.next_key && !(a.abl & 8) && threadIdx.x >= 1 && threadIdx.x < kNextKeyPerChunk && (a.Hp != 1 || h == 0))
+    a.next_key[(size_t)(a.Hp == 1 ? 0 : h) * (kNextKeyPerChunk * nchunks) + threadIdx.x * nchunks + c] = ~0ull;
   // ---- issue this thread's per-slot loads first: their latency overlaps the (M, L) reduction below
   const T* sc = reinterpret_cast<const T*>(a.scores);
   const int s_mine = c * a.chunk + threadIdx.x;
@@ -1711,12 +1739,11 @@ __global__ __launch_bounds__(kCombThreads) void decode_attn_combine_kernel(Combi
     for (int w2 = 1; w2 < kWaves; w2++) bk = sm_k[w2] < bk ? sm_k[w2] : bk;
     // the minimum over all blocks of this head IS torch's arg-min; the next step's streaming pass takes it
     // (plain store: same-address atomics from 8 XCDs measured +4.5 us on this 5 us kernel)
-    // (a head's key row has 2 * nchunks entries — one per 64 slots, the single-launch step's granularity — the upper half
-    //  stays ~0 here)
+    // (a head's key row has kNextKeyPerChunk * nchunks entries — one per wave of the single-launch step's 64-slot workgroups;
+    //  all but the first nchunks stay ~0 here)
     if (a.Hp != 1 || h == 0) {
-      unsigned long long* row = a.next_key + (size_t)(a.Hp == 1 ? 0 : h) * (2 * nchunks);
+      unsigned long long* row = a.next_key + (size_t)(a.Hp == 1 ? 0 : h) * (kNextKeyPerChunk * nchunks);
       row[c] = bk;
-      row[nchunks + c] = ~0ull;
     }
   }
   if (do_y)  // further output groups (only when R*D / n_chunks > 128, i.e. very short caches)
@@ -2040,7 +2067,8 @@ static int attn_impl(const void* q, const void* k, const void* v, const uint8_t*
     sa.qparams = fs->qparams;
   }
   if (fs) {
-    sa.next_key = fs->next_key; sa.nk = cc_next_key_slots(S); sa.input_pos = fs->input_pos; sa.k_new = fs->k_new; sa.v_new = fs->v_new;
+    sa.next_key = fs->next_key; sa.nk = cc_next_key_slots(S);
+    sa.nk_read = one_shape_ok(p, HQ, H, D, dtype) ? sa.nk : p.n_chunks; sa.input_pos = fs->input_pos; sa.k_new = fs->k_new; sa.v_new = fs->v_new;
     sa.pos = fs->c->pos; sa.mask_w = fs->c->mask; sa.cache_cts = fs->c->cache_cts; sa.num = hh_num; sa.denom = hh_denom;
     sa.H = H; sa.Hc = fs->c->Hc; sa.Hp = fs->c->Hp;
   }

@@ -142,10 +142,12 @@ __device__ __forceinline__ unsigned long long make_key(uint32_t ord, uint32_t sl
 // Fused heavy-hitter decode step: the arg-min key of the next eviction is published as one partial minimum
 // per 128-slot chunk of the cache (no atomics: same-address atomics from 8 XCDs serialise in the fabric and
 // cost more than the whole pass); consumers take the minimum over a head's cc_next_key_slots(S) entries.
-// A head's key row holds TWO entries per 128-slot chunk: the two-launch combine pass fills the lower half (one key per
-// block) and keeps the upper half at ~0; the single-launch step publishes one key per 64-slot workgroup.
+// A head's key row holds kNextKeyPerChunk entries per 128-slot chunk: the two-launch combine pass fills the first n_chunks (one
+// key per block) and keeps the others at ~0; the single-launch step publishes one key per WAVE of its 64-slot workgroups
+// (2 workgroups x 4 waves per chunk), so that its waves never wait for each other at the end of the launch.
 constexpr int kNextKeyChunk = 128;
-static inline int cc_next_key_slots(int S) { return 2 * ((S + kNextKeyChunk - 1) / kNextKeyChunk); }
+constexpr int kNextKeyPerChunk = 8;
+static inline int cc_next_key_slots(int S) { return kNextKeyPerChunk * ((S + kNextKeyChunk - 1) / kNextKeyChunk); }
 
 __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
 #pragma unroll

@@ -179,8 +179,9 @@ int cc_decode_attn_gqa_ring(const void* q, const void* k, const void* v, const u
  *   launch 2 (combine): y, group-averaged probabilities, history update, and the arg-min for position
  *     *input_pos + 1 evaluated on the freshly updated history: one partial minimum per 128-slot chunk
  *     -> next_key[h][chunk] (plain stores; no atomics, no reset pass).
- * next_key: uint64 [H, NK], NK = cc_hh_next_key_slots(S) (two entries per 128-slot chunk: the combine pass fills the
- * lower half of a row and keeps the upper half at ~0; the single-launch step below publishes one key per 64 slots);
+ * next_key: uint64 [H, NK], NK = cc_hh_next_key_slots(S) (eight entries per 128-slot chunk: the combine pass fills the
+ * first NK / 8 of a row and keeps the others at ~0; the single-launch step below publishes one key per WAVE of its 64-slot
+ * workgroups, so that no wave waits for another at the end of the launch);
  * entry = (orderable(score) << 32) | slot << 1 | was_empty, ~0 = "no candidate".  Valid as long as positions advance by one and nothing else mutates pos / history in
  * between; re-seed with cc_hh_next_key_init otherwise.
  * Results are bit-identical to the three-call sequence (tests/test_gpu_fused_step.py).
@@ -263,7 +264,8 @@ void cc_decode_step_set_single_launch(int32_t enabled);
 /* Measurement hook: buf = device buffer of [workgroups][16] uint64, or NULL (default).  While set, thread 0 of every
  * workgroup of a single-launch step records [0..5] s_memtime stamps (start, streaming done, published, sentinel seen,
  * gathered, end), [6..8] s_memrealtime at start / streaming done / end, [9] HW_ID, [10] XCC_ID, [11..13] s_memtime of wave 0
- * when its K rows have arrived / its scores are in registers / its P.V products are issued. */
+ * when its K rows have arrived / its scores are in registers / its P.V products are issued, [14..15] s_memtime of thread 0 behind the
+ * two barriers of the finish. */
 void cc_decode_step_trace(void* buf);
 /* The two-launch step for KVCacheHybrid (FastGen per-head policies; cache.py:896-1019 + the fused ring update of
  * cc_decode_attn_gqa_ring): three launches -> two.  What a head does with the incoming token — append at the end of its

@@ -166,7 +166,7 @@ def test_fused_quant_step_vs_oracle(oracle):
     st = dict(kq=kv.k_cache_q.cpu()[0].numpy().copy(), vq=kv.v_cache_q.cpu()[0].numpy().copy(), par=kv.kv_qparams.cpu()[0].numpy().copy(),
               pos=kv.pos.cpu()[0].numpy().copy(), mask=kv.mask.cpu()[0, :, 0].numpy().astype(np.uint8), cts=kv.cache_cts.cpu().numpy().copy(),
               num=kv.attn_history_num.cpu()[0, :, :, 0].numpy().copy(), denom=kv.attn_history_denom.cpu()[0].numpy().copy(),
-              ctr=np.zeros(1, np.int64), key=np.zeros((H, 2 * ((S + 127) // 128)), np.uint64))
+              ctr=np.zeros(1, np.int64))
     # the oracle's prefill images equal the device's
     kq_o, vq_o, par_o = np.zeros_like(st["kq"]), np.zeros_like(st["vq"]), np.zeros_like(st["par"])
     kfull, vfull = np.zeros((H, S, D), np.uint16), np.zeros((H, S, D), np.uint16)

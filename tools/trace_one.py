@@ -24,7 +24,7 @@ def main():
     ap.add_argument("--S", type=int, nargs="+", default=[4096])
     ap.add_argument("--H", type=int, default=8)
     ap.add_argument("--HQ", type=int, default=32)
-    ap.add_argument("--abl", type=int, nargs="+", default=[0, 1], help="0 = default (every thread polls), 1 = sentinel wave first")
+    ap.add_argument("--abl", type=int, nargs="+", default=[0], help="measurement bits of the phases word (0 = the product path)")
     ap.add_argument("--quant", action="store_true", help="the fused quantised cache (cache_bits=8, cache_quant_mode='fused')")
     a = ap.parse_args()
     dev, D, H, HQ = "cuda", 128, a.H, a.HQ
@@ -150,6 +150,9 @@ def main():
                 for nm, col in (("k_arrived", 11), ("scores_ready", 12), ("pv_issued", 13)):
                     d_ = (t[:, col] - t[:, 0]).astype(np.float64)
                     out[nm + "_min_mean_max"] = [float(d_.min()), round(float(d_.mean()), 1), float(d_.max())]
+                if t.shape[1] > 15 and (t[:, 14] != 0).all():
+                    out["finish_ML_weights_mean"] = round(float((t[:, 14] - t[:, 4]).mean()), 1)
+                    out["finish_slots_y_keys_mean"] = round(float((t[:, 15] - t[:, 14]).mean()), 1)
                 d_ = (t[:, 1] - t[:, 0]).astype(np.float64)
                 out["stream_done_min_mean_max"] = [float(d_.min()), round(float(d_.mean()), 1), float(d_.max())]
             print(json.dumps(out), flush=True)
