@@ -1118,44 +1118,11 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
       o_lds[k] = (i * ppw + qq) * 2;
     }
     bool timed_out = false;
-    if (a.abl & 1) {  // measurement variant: one wave watches query head 0's (m, l) granules first while the others sleep at the
-                      // barrier (1 KiB instead of 8 KiB per workgroup and round, at the price of a second fabric round trip:
-                      // 10.99 vs 10.63 us at S = 4096 once every round really re-reads memory)
-      if (wave == 0) {
-        const int off0 = ((h * ns + (lane < ns ? lane : 0)) * RT) * 16;
-        if (a.abl & 4) {
-          // measurement variant: two polls in flight, alternating registers (each check waits for ITS load only)
-          u32x4_t x0 = __builtin_amdgcn_raw_buffer_load_b128(ml_rsrc, off0, 0, kOneAuxCoherent);
-          __builtin_amdgcn_s_sleep(4);
-          asm volatile("" ::: "memory");
-          u32x4_t x1 = __builtin_amdgcn_raw_buffer_load_b128(ml_rsrc, off0, 0, kOneAuxCoherent);
-          for (unsigned spins = 0;; spins++) {
-            if (__all(x0[0] == tag && x0[2] == tag)) break;
-            asm volatile("" ::: "memory");
-            x0 = __builtin_amdgcn_raw_buffer_load_b128(ml_rsrc, off0, 0, kOneAuxCoherent);
-            if (__all(x1[0] == tag && x1[2] == tag)) break;
-            asm volatile("" ::: "memory");
-            x1 = __builtin_amdgcn_raw_buffer_load_b128(ml_rsrc, off0, 0, kOneAuxCoherent);
-            if (spins > kOneSpinMax) {
-              timed_out = true;
-              break;
-            }
-          }
-        } else {
-          for (unsigned spins = 0;; spins++) {
-            asm volatile("" ::: "memory");  // every poll is a load of its own
-            const u32x4_t x = __builtin_amdgcn_raw_buffer_load_b128(ml_rsrc, off0, 0, kOneAuxCoherent);
-            if (__all(x[0] == tag && x[2] == tag)) break;
-            if (spins > kOneSpinMax) {
-              timed_out = true;
-              break;
-            }
-            __builtin_amdgcn_s_sleep(1);
-          }
-        }
-      }
-      __syncthreads();
-    }
+    // The first poll waits until this wave's OWN publish stores are acknowledged (vmcnt counts stores on this chip).  Polls issued
+    // right behind the write-through stores cost 0.8 us at S = 4096 (11.1 vs 10.3 us; found by accident: a never-taken measurement
+    // branch with loads of its own made the compiler put this wait at the join): the stragglers' K/V rows and everybody's granules
+    // then queue behind 6 MB of polls per round that cannot succeed yet.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (a.trace) tr3 = __builtin_amdgcn_s_memtime();
     u32x4_t mlq[MLN], oq[NOG];
     for (unsigned spins = 0;; spins++) {
@@ -1795,7 +1762,7 @@ static Plan make_plan(int HQ, int H, int S, int D, int dtype) {
   // current one, the per-workgroup merge and the number of partials the combine pass has to fold stay constant.
   // (512 splits at S = 65536 made every combine block re-reduce 2048 (m, l) pairs: 27 us of a 33 us launch.)
   const int zb = R / p.rt;
-  int ns_cap = (512 + H * zb - 1) / (H * zb);
+  int ns_cap = (512 + H * zb - 1) / (H * zb);  // (768 / 1024 workgroups at S = 18432: 30.4 instead of 26.1 us per step — measured)
   if (ns_cap < 16) ns_cap = 16;
   if (ns_cap > kMaxSplit) ns_cap = kMaxSplit;
   int ns = (S + rpi - 1) / rpi;

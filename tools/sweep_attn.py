@@ -118,9 +118,8 @@ def main():
             res = {"S": S}
             one = fns["cc_decode_step_single_launch"](HQ, H, S, D, 1) == 1
             res["single_launch_supported"] = bool(one)
-            if one:  # the single-launch step (0x20000 demands it; abl bit 1 << 8: a sentinel wave polls first; 4 << 8: with two polls in flight)
-                for name, ph in (("step_one", 3 | 0x20000), ("step_one_sentinel", 3 | 0x20000 | (1 << 8)), ("step_one_sentinel_2polls", 3 | 0x20000 | (5 << 8)),
-                                 ("step_one_noepi", 3 | 0x20000 | (2 << 8))):
+            if one:  # the single-launch step (0x20000 demands it; abl bit 2 << 8: the streaming part only, no hand-off / finish)
+                for name, ph in (("step_one", 3 | 0x20000), ("step_one_noepi", 3 | 0x20000 | (2 << 8))):
                     t, tmin = timed_graph(lambda i, ph=ph: fstep(i, ph), n)
                     res[name + "_us"] = round(t, 2)
                     res[name + "_min_us"] = round(tmin, 2)
