@@ -765,6 +765,27 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
   if constexpr (QB) __builtin_amdgcn_sched_barrier(0);  // K's bytes and parameters go out BEFORE V's: the K stash waits for them only
   issue_v(base);
   if constexpr (QB) __builtin_amdgcn_sched_barrier(0);
+  // HYB: everything the per-head decision needs besides the candidate key — the head's policy row, its count, the budget terms,
+  // the incoming token's punctuation flag — is fetched HERE, behind the tile's loads (uniform addresses: scalar loads, two
+  // dependent levels), in the shadow of the tile's latency.  Fetched where it is used, behind the key, it cost two to three serial round trips per
+  // workgroup AFTER the first tile had arrived (19.0 vs 16.7 us for the plain streaming pass at S = 18432).
+  int hy_flags = 0, hy_cts = 0, hy_budget = 0;
+  bool hy_punc = false;
+  if constexpr (HYB) {
+    const int pol = (int)a.hyb.strategies[h];
+    hy_flags = a.hyb.table[pol * 3];
+    const int win = a.hyb.table[pol * 3 + 1], hhs = a.hyb.table[pol * 3 + 2];
+    hy_cts = a.cache_cts[h];
+    if (a.hyb.token_id && a.hyb.punc_ids) {  // ref: cache.py:975 torch.isin(input_ids, punc_ids)
+      const long long id = *a.hyb.token_id;
+      for (int k2 = 0; k2 < a.hyb.n_punc_ids; k2++) hy_punc |= a.hyb.punc_ids[k2] == id;
+    }
+    hy_budget = a.g;  // ref: cache.py:912-925
+    if (hy_flags & HF_SPECIAL) hy_budget += a.hyb.num_special ? *a.hyb.num_special : 0;
+    if (hy_flags & HF_PUNC) hy_budget += a.hyb.num_punc ? *a.hyb.num_punc : 0;
+    if (hy_flags & HF_WIN) hy_budget += win;
+    if (hy_flags & HF_HH) hy_budget += hhs;
+  }
   int qb_ins_u = -1;  // QB: tile row (of this lane's row group) that holds the inserted token — its K chunk is UNswizzled (chunk c)
 
   while (more) {
@@ -781,25 +802,16 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
       if (a.abl & 64) ins_idx = -1;
       ins_was_empty = (int)(key & 1ull);
       key_pending = false;
-      if constexpr (HYB) {  // ref: cache.py:896-950 _select_fill_idx, per head
-        const int pol = (int)a.hyb.strategies[h];
-        const int flags = a.hyb.table[pol * 3], win = a.hyb.table[pol * 3 + 1], hhs = a.hyb.table[pol * 3 + 2];
-        const int cts = a.cache_cts[h];
-        if (a.hyb.token_id && a.hyb.punc_ids) {  // ref: cache.py:975 torch.isin(input_ids, punc_ids)
-          const long long id = *a.hyb.token_id;
-          for (int k2 = 0; k2 < a.hyb.n_punc_ids; k2++) hyb_punc |= a.hyb.punc_ids[k2] == id;
-        }
+      if constexpr (HYB) {  // ref: cache.py:896-950 _select_fill_idx, per head — operands fetched in the prologue (hy_*)
+        const int flags = hy_flags, cts = hy_cts;
+        hyb_punc = hy_punc;
         const int end_idx = cts < S - 1 ? cts : S - 1;  // :897-899
         hyb_cts = cts;
         if (((flags & HF_PUNC) && hyb_punc) || (flags & HF_FULL)) {  // :905-909
           ins_idx = end_idx;
           hyb_kind = 0;
         } else {
-          int budget = a.g;  // :912-925
-          if (flags & HF_SPECIAL) budget += a.hyb.num_special ? *a.hyb.num_special : 0;
-          if (flags & HF_PUNC) budget += a.hyb.num_punc ? *a.hyb.num_punc : 0;
-          if (flags & HF_WIN) budget += win;
-          if (flags & HF_HH) budget += hhs;
+          const int budget = hy_budget;  // :912-925
           if (cts < budget) {  // :927-930 append
             ins_idx = end_idx;
             hyb_kind = 0;
