@@ -17,6 +17,10 @@ OUT = os.path.join(CSRC, "libcoldcompress_hip.so")
 SOURCES = ["cc_api.hip", "cc_evict.hip", "cc_attn_decode.hip", "cc_compact.hip", "cc_attn_prefill.hip", "cc_glue.hip",
            "cc_hybrid.hip", "cc_attn_prefill_mfma.hip", "cc_quant.hip", "cc_gemv.hip", "cc_allreduce.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+# Per-file extras.  cc_attn_decode: keep the matrix-core accumulators in architectural VGPRs (gfx950 has one unified register
+# file) — the streaming pass rescales its 32 accumulators with VALU multiplies whenever the running maximum moves, and with the
+# accumulators parked in AGPRs that costs 68 v_accvgpr_read / _write per tile, a sixth of the loop's instructions.
+EXTRA_FLAGS = {"cc_attn_decode.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def _hipcc():
@@ -42,7 +46,7 @@ def build(force=False, verbose=False):
         obj = os.path.join(CSRC, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _stale(obj, src):
-            jobs.append([hipcc, *FLAGS, "-c", src, "-o", obj])
+            jobs.append([hipcc, *FLAGS, *EXTRA_FLAGS.get(s, []), "-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:

@@ -594,10 +594,13 @@ __device__ __forceinline__ uint2 quant8_row16(uint4 raw, float2& par) {
 // L2: the l2 policy's norm bookkeeping (its own instantiation: the others pay nothing).  ONE: the single-launch layer
 // step of the heavy-hitter policy (needs R == RT, one tile per wave, every workgroup of the grid co-resident).
 // QB = 8: the fused quantised cache (uint8 images + per-row (scale, minimum)), dequantised on the way to the LDS slabs.
-template <typename T, int RT, int NW, bool L2, bool ONE = false, bool HYB = false, int QB = 0>
+// NSUB = 2 (multi-tile splits only): two tiles per wave and iteration, each with its own staging registers — the loads of a
+// tile go out two half-iterations ahead of their use instead of one (twice the bytes in flight per wave).
+template <typename T, int RT, int NW, bool L2, bool ONE = false, bool HYB = false, int QB = 0, int NSUB = 1>
 __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_split_mfma_kernel(SplitArgs a) {
   static_assert(!(HYB && (L2 || ONE)), "the hybrid decision rides the plain two-launch streaming pass");
   static_assert(QB == 0 || (QB == 8 && !L2 && !HYB), "fused quantised cache: 8 bits, heavy hitter / recent_global / random");
+  static_assert(NSUB == 1 || (NSUB == 2 && !ONE), "the single-launch step owns exactly one tile per wave");
   static_assert(sizeof(T) == 2 && (RT == 1 || RT == 2 || RT == 4 || RT == 8), "16-bit caches, up to 8 query heads per pass (the MFMA has 16 columns)");
   static_assert(!(ONE && L2) && (!ONE || NW == 4), "the single-launch step runs on 4-wave workgroups; l2 needs a cross-head maximum");
   constexpr int D = 128, VEC = 8, RPW = 4, U = 4;
@@ -710,49 +713,52 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
     qB[j].raw = make_uint4(0, 0, 0, 0);
     if (c < RT) qB[j].load(reinterpret_cast<const T*>(a.q) + (size_t)(q0 + c) * D + (4 * j + g) * VEC);
   }
-  uint32_t mword = 0x01010101u;
-  Vec16<T> kk[U], vv[U];
-  uint2 kq8[U], vq8[U];      // QB: the rows' bytes ...
-  float2 kpar[U], vpar[U];   // ... and their (scale, minimum)
+  struct TileRegs {            // the staging registers of one tile in flight
+    uint32_t mword;
+    Vec16<T> kk[U], vv[U];
+    uint2 kq8[U], vq8[U];      // QB: the rows' bytes ...
+    float2 kpar[U], vpar[U];   // ... and their (scale, minimum)
+  };
+  TileRegs tregs[NSUB];
   auto load_nt_u2 = [](const uint8_t* p) {
     typedef unsigned int u32x2_nt __attribute__((ext_vector_type(2)));
     const u32x2_nt v = __builtin_nontemporal_load(reinterpret_cast<const u32x2_nt*>(p));
     return make_uint2(v.x, v.y);
   };
-  auto issue_k = [&](int base) {  // mask word + the four K rows of this lane's row group (tile row i = 4g + u takes chunk c ^ i)
+  auto issue_k = [&](TileRegs& R, int base) {  // mask word + the four K rows of this lane's row group (tile row i = 4g + u takes chunk c ^ i)
     const int row0 = base + g * U;
-    mword = 0x01010101u;
+    R.mword = 0x01010101u;
     if (has_mask) {
       if (row0 + 3 < S && ((reinterpret_cast<uintptr_t>(mh) + (size_t)row0) & 3) == 0) {
-        mword = *reinterpret_cast<const uint32_t*>(mh + row0);
+        R.mword = *reinterpret_cast<const uint32_t*>(mh + row0);
       } else {
-        mword = 0;
+        R.mword = 0;
 #pragma unroll
         for (int u = 0; u < U; u++)
-          if (row0 + u < S) mword |= (uint32_t)mh[row0 + u] << (8 * u);
+          if (row0 + u < S) R.mword |= (uint32_t)mh[row0 + u] << (8 * u);
       }
     }
 #pragma unroll
     for (int u = 0; u < U; u++) {
       const int rr = row0 + u < row_end ? row0 + u : row_end - 1;
       if constexpr (QB) {
-        kq8[u] = load_nt_u2(kqb + (size_t)rr * D + ((c ^ (4 * g + u)) & 15) * VEC);
-        kpar[u] = qpar[(size_t)rr * 2];
+        R.kq8[u] = load_nt_u2(kqb + (size_t)rr * D + ((c ^ (4 * g + u)) & 15) * VEC);
+        R.kpar[u] = qpar[(size_t)rr * 2];
       } else {
-        kk[u].load_nt(kb + (size_t)rr * D + ((c ^ (4 * g + u)) & 15) * VEC);
+        R.kk[u].load_nt(kb + (size_t)rr * D + ((c ^ (4 * g + u)) & 15) * VEC);
       }
     }
   };
-  auto issue_v = [&](int base) {
+  auto issue_v = [&](TileRegs& R, int base) {
     const int row0 = base + g * U;
 #pragma unroll
     for (int u = 0; u < U; u++) {
       const int rr = row0 + u < row_end ? row0 + u : row_end - 1;
       if constexpr (QB) {
-        vq8[u] = load_nt_u2(vqh + (size_t)rr * D);
-        vpar[u] = qpar[(size_t)rr * 2 + 1];
+        R.vq8[u] = load_nt_u2(vqh + (size_t)rr * D);
+        R.vpar[u] = qpar[(size_t)rr * 2 + 1];
       } else {
-        vv[u].load_nt(vh + (size_t)rr * D);
+        R.vv[u].load_nt(vh + (size_t)rr * D);
       }
     }
   };
@@ -761,10 +767,13 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
   // UNCONDITIONAL (rows past the split's end are clamped to its last row, a valid address): behind a branch, the compiler's
   // wait-count bookkeeping merges "tile loads issued" with "none issued" and every later use of an EARLIER load (the partial
   // keys, the incoming token's rows) becomes a wait for all loads — the tile included
-  issue_k(base);
-  if constexpr (QB) __builtin_amdgcn_sched_barrier(0);  // K's bytes and parameters go out BEFORE V's: the K stash waits for them only
-  issue_v(base);
-  if constexpr (QB) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int sub = 0; sub < NSUB; sub++) {
+    issue_k(tregs[sub], base + sub * NW * RPW * U);
+    if constexpr (QB) __builtin_amdgcn_sched_barrier(0);  // K's bytes and parameters go out BEFORE V's: the K stash waits for them only
+    issue_v(tregs[sub], base + sub * NW * RPW * U);
+    if constexpr (QB) __builtin_amdgcn_sched_barrier(0);
+  }
   // HYB: everything the per-head decision needs besides the candidate key — the head's policy row, its count, the budget terms,
   // the incoming token's punctuation flag — is fetched HERE, behind the tile's loads (uniform addresses: scalar loads, two
   // dependent levels), in the shadow of the tile's latency.  Fetched where it is used, behind the key, it cost two to three serial round trips per
@@ -788,13 +797,11 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
   }
   int qb_ins_u = -1;  // QB: tile row (of this lane's row group) that holds the inserted token — its K chunk is UNswizzled (chunk c)
 
-  while (more) {
-    const int row0 = base + g * U;
-    const int base_next = base + NW * RPW * U;
+  auto tile = [&](TileRegs& R, const int tbase, const int tbase_next, const bool more_next) {
+    const int row0 = tbase + g * U;
     // ONE: a wave owns exactly one tile (one_shape_ok: rows_per_split == one iteration's rows) — a compile-time fact, so that the
     // next tile's address arithmetic, its loads, the loop's second body and the running-maximum rescale disappear from the code
-    const bool more_next = ONE ? false : base_next < row_end;
-    if (key_pending) {  // wave-uniform; first iteration only
+    if (key_pending) {  // wave-uniform; first tile only
 #pragma unroll
       for (int j = 0; j < 3; j++) key_part = key_more[j] < key_part ? key_more[j] : key_part;
       const unsigned long long key = wave_min_u64_uniform(key_part);
@@ -853,13 +860,13 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
       for (int u = 0; u < U; u++)
         if (u == um) {
           if constexpr (QB) {
-            kq8[u] = knq; kpar[u] = knp;
-            vq8[u] = vnq; vpar[u] = vnp;
+            R.kq8[u] = knq; R.kpar[u] = knp;
+            R.vq8[u] = vnq; R.vpar[u] = vnp;
           } else {
-            kk[u].raw = kn.raw;
-            vv[u].raw = vn.raw;
+            R.kk[u].raw = kn.raw;
+            R.vv[u].raw = vn.raw;
           }
-          if (!HYB || hyb_kind != 2) mword |= 1u << (8 * u);
+          if (!HYB || hyb_kind != 2) R.mword |= 1u << (8 * u);
         }
       if (HYB && blockIdx.z == 0) {  // ref: cache.py:997-1016 — bookkeeping of the hybrid decision
         const size_t slot = (size_t)h * S + ins_idx;
@@ -910,17 +917,17 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
     for (int u = 0; u < U; u++) {
       if constexpr (QB) {  // slot c of tile row i holds chunk c ^ i; the inserted row's lane holds chunk c -> slot c ^ i
         const int i = 4 * g + u;
-        sm_k[wave][i][u == qb_ins_u ? ((c ^ i) & 15) : c] = dequant8<T>(kq8[u], kpar[u]);
+        sm_k[wave][i][u == qb_ins_u ? ((c ^ i) & 15) : c] = dequant8<T>(R.kq8[u], R.kpar[u]);
       } else {
-        sm_k[wave][4 * g + u][c] = kk[u].raw;
+        sm_k[wave][4 * g + u][c] = R.kk[u].raw;
       }
     }
     qb_ins_u = -1;  // later tiles of this wave hold no inserted row
     if constexpr (ONE) {
       if (a.trace && trA == 0) trA = __builtin_amdgcn_s_memtime();  // this wave's K rows have arrived and sit in its LDS slab
     }
-    const uint32_t mcur = mword;
-    if (more_next) issue_k(base_next);  // K registers are free again: the next tile streams in behind this tile's math
+    const uint32_t mcur = R.mword;
+    if (more_next) issue_k(R, tbase_next);  // K registers are free again: the next tile streams in behind this tile's math
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -977,18 +984,24 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
         l += p[t];
       }
       if constexpr (!ONE) {
+        // every accumulator of this lane belongs to head c.  The running maximum settles after the first tiles: while no
+        // head of the wave moved it, alpha is exactly 1 and the 32 multiplies — with the accumulators parked in AGPRs, 68 register
+        // moves around them: a fifth of the loop's instructions — are skipped (x * 1 == x: bit-identical)
+        if (__any(alpha != 1.0f)) {
 #pragma unroll
-        for (int b = 0; b < D / 16; b++) acc[b] *= alpha;  // every accumulator of this lane belongs to head c
+          for (int b = 0; b < D / 16; b++) acc[b] *= alpha;
+        }
       }
     }
     // ---- O^T += V^T . P^T on the matrix cores: V tile -> wave-private LDS slab (row major, coalesced), A fragments
     //      back through the transpose read, B = this lane's four probabilities in 16 bit
 #pragma unroll
     for (int u = 0; u < U; u++)
-      sm_v[wave][4 * g + u][(c ^ (2 * ((4 * g + u) & 7))) & 15] = QB ? dequant8<T>(vq8[u], vpar[u]) : vv[u].raw;
+      sm_v[wave][4 * g + u][(c ^ (2 * ((4 * g + u) & 7))) & 15] = QB ? dequant8<T>(R.vq8[u], R.vpar[u]) : R.vv[u].raw;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (more_next) issue_v(R, tbase_next);  // the V registers are free once the tile sits in LDS: the next tile's rows go out before the P.V products
     {
       const s16x4_t pb = Mfma16x16x16<T>::pack(p);
       const char* vrow = reinterpret_cast<const char*>(&sm_v[wave][tr_row][0]) + tr_half * 8;
@@ -1004,7 +1017,12 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
     if constexpr (ONE) {
       if (a.trace && trC == 0) trC = __builtin_amdgcn_s_memtime();  // P.V of the tile issued
     }
-    if (more_next) issue_v(base_next);
+  };
+  while (more) {
+    const int base_next = base + NSUB * NW * RPW * U;
+    const bool more_next = ONE ? false : base_next < row_end;
+#pragma unroll
+    for (int sub = 0; sub < NSUB; sub++) tile(tregs[sub], base + sub * NW * RPW * U, base_next + sub * NW * RPW * U, more_next);
     base = base_next;
     more = more_next;
   }
@@ -1804,40 +1822,48 @@ static int launch_split_rt(const SplitArgs& a, const Plan& p, int H, int R, hipS
   return CC_OK;
 }
 
+template <typename T, bool L2, bool HYB, int QB, int NSUB>
+static int launch_mfma_rt(const SplitArgs& a, int rt, dim3 grid, dim3 block, hipStream_t st) {
+  if constexpr (sizeof(T) == 2) {
+    switch (rt) {
+      case 8: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 8, kNW, L2, false, HYB, QB, NSUB>), grid, block, 0, st, a); break;
+      case 4: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 4, kNW, L2, false, HYB, QB, NSUB>), grid, block, 0, st, a); break;
+      case 2:
+        if constexpr (QB != 0) return CC_ERR_UNSUPPORTED;
+        else hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 2, kNW, L2, false, HYB, QB, NSUB>), grid, block, 0, st, a);
+        break;
+      default:
+        if constexpr (QB != 0) return CC_ERR_UNSUPPORTED;
+        else hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 1, kNW, L2, false, HYB, QB, NSUB>), grid, block, 0, st, a);
+        break;
+    }
+    return CC_OK;
+  } else {
+    return CC_ERR_UNSUPPORTED;
+  }
+}
+
 template <typename T>
 static int launch_split(const SplitArgs& a, const Plan& p, int H, int R, int D, hipStream_t st) {
   if constexpr (sizeof(T) == 2) {
     if (D == 128 && !(a.abl & 32)) {  // matrix-core streaming pass (abl bit 32 = measurement: force the VALU kernel)
       static_assert(kU == 4, "the MFMA tile is 4 row groups x 4 rows per wave");
       dim3 grid(p.n_split, H, R / p.rt), block(kNW * 64);
+      // (NSUB = 2 — two tiles per wave and iteration, each with its own staging registers, the loads two half-iterations ahead of
+      //  their use — was measured at S = 18432: 27.3 instead of 25.4 us per step, the uint8 instantiation 31.5 instead of 25.4; like
+      //  768 / 1024 workgroups, more bytes in flight per CU make this access pattern slower, not faster.  Not instantiated.)
+      int rc;
       if (a.qparams != nullptr) {  // fused quantised cache: 4 or 8 query heads per kv head
-        switch (p.rt) {
-          case 8: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 8, kNW, false, false, false, 8>), grid, block, 0, st, a); break;
-          case 4: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 4, kNW, false, false, false, 8>), grid, block, 0, st, a); break;
-          default: return CC_ERR_UNSUPPORTED;
-        }
+        if (p.rt != 4 && p.rt != 8) return CC_ERR_UNSUPPORTED;
+        rc = launch_mfma_rt<T, false, false, 8, 1>(a, p.rt, grid, block, st);
       } else if (a.hyb.strategies != nullptr) {
-        switch (p.rt) {
-          case 8: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 8, kNW, false, false, true>), grid, block, 0, st, a); break;
-          case 4: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 4, kNW, false, false, true>), grid, block, 0, st, a); break;
-          case 2: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 2, kNW, false, false, true>), grid, block, 0, st, a); break;
-          default: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 1, kNW, false, false, true>), grid, block, 0, st, a); break;
-        }
+        rc = launch_mfma_rt<T, false, true, 0, 1>(a, p.rt, grid, block, st);
       } else if (a.key_norm != nullptr) {
-        switch (p.rt) {
-          case 8: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 8, kNW, true>), grid, block, 0, st, a); break;
-          case 4: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 4, kNW, true>), grid, block, 0, st, a); break;
-          case 2: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 2, kNW, true>), grid, block, 0, st, a); break;
-          default: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 1, kNW, true>), grid, block, 0, st, a); break;
-        }
+        rc = launch_mfma_rt<T, true, false, 0, 1>(a, p.rt, grid, block, st);
       } else {
-        switch (p.rt) {
-          case 8: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 8, kNW, false>), grid, block, 0, st, a); break;
-          case 4: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 4, kNW, false>), grid, block, 0, st, a); break;
-          case 2: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 2, kNW, false>), grid, block, 0, st, a); break;
-          default: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 1, kNW, false>), grid, block, 0, st, a); break;
-        }
+        rc = launch_mfma_rt<T, false, false, 0, 1>(a, p.rt, grid, block, st);
       }
+      if (rc != CC_OK) return rc;
       CC_LAUNCH_CHECK();
       return CC_OK;
     }
