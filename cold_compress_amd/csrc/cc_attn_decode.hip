@@ -532,6 +532,14 @@ struct Mfma16x16x16<f16_t> {
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 constexpr unsigned kOneSpinMax = 1u << 18;  // bounded spin: a launch that is not fully resident gives up instead of hanging
 constexpr int kOneStatusWordDev = 1023;     // hdr[0 .. H): per-head epochs; hdr[1023]: timeout word (== kOneStatusWord)
+// Granule regions are PER KV HEAD at fixed strides, whatever the shape: a location is only ever written by launches of its own
+// head, with tags from that head's epoch word — strictly growing per location even when caches of different head counts and
+// lengths share the workspace (shape-dependent offsets let a stale granule of head 4 sit where head 1 of another shape expects
+// its own, and the two heads' epochs need not be equal once launches with fewer heads have run).
+constexpr int kOneMlHead = 64 * 8 * 16;        // (m, l): 64 splits x up to 8 query heads x 16 B
+constexpr int kOneOHead = 8 * 64 * 64 * 16;    // O: up to 8 query heads x 64 splits x 64 pairs x 16 B
+constexpr int kOneNmHead = 64 * 16;            // l2: one norm-maximum granule per split
+constexpr int kOneMaxHeads = 32;
 constexpr int kOneAuxCoherent = 17;         // sc0 sc1: write-through stores / loads that bypass the non-coherent L1 (and stale L2 lines)
 
 // ---- fused quantised cache: value = T(fma(q, scale, min)), one rounding; q in [0, 255]
@@ -602,7 +610,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
   static_assert(QB == 0 || (QB == 8 && !L2 && !HYB), "fused quantised cache: 8 bits, heavy hitter / recent_global / random");
   static_assert(NSUB == 1 || (NSUB == 2 && !ONE), "the single-launch step owns exactly one tile per wave");
   static_assert(sizeof(T) == 2 && (RT == 1 || RT == 2 || RT == 4 || RT == 8), "16-bit caches, up to 8 query heads per pass (the MFMA has 16 columns)");
-  static_assert(!(ONE && L2) && (!ONE || NW == 4), "the single-launch step runs on 4-wave workgroups; l2 needs a cross-head maximum");
+  static_assert(!ONE || NW == 4, "the single-launch step runs on 4-wave workgroups");
   constexpr int D = 128, VEC = 8, RPW = 4, U = 4;
   if (a.ring_col && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0)
     *a.ring_col = (int)(*a.ring_counter % a.ring_W);
@@ -642,7 +650,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
   const bool l2_here = L2 && blockIdx.z == 0;
   const int kn_row0 = row_begin + (int)threadIdx.x;
   float kn_first = -INFINITY;
-  if (L2 && l2_here && kn_row0 < row_end) kn_first = ElemTraits<T>::load(reinterpret_cast<const T*>(a.key_norm) + (size_t)h * S, kn_row0);
+  if (L2 && !ONE && l2_here && kn_row0 < row_end) kn_first = ElemTraits<T>::load(reinterpret_cast<const T*>(a.key_norm) + (size_t)h * S, kn_row0);
   // ---- every load of the first tile is issued before anything waits (partial keys, q, mask, K, V: use order)
   int ins_idx = -1, ins_was_empty = 0;
   int hyb_kind = 0, hyb_cts = 0;  // HYB: 0 = append at the end, 1 = evict the candidate, 2 = drop (slot S - 1, mask untouched)
@@ -679,6 +687,19 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
   const int one_slot = row_begin + wave * (RPW * U) + g * U + c / LPR;
   const bool one_have = ONE && c < U * LPR && (c % LPR) == 0 && one_slot < row_end;
   float one_rnd = 0.f;
+  float one_kn = 0.f;       // ONE + L2: the key norm of this lane's slot (model dtype) ...
+  float l2_nv_lane = 0.f;   // ... and the inserted key's norm, in the lanes of the row group that inserted it
+  // ONE + L2: the epoch words of the kv heads whose norm granules this thread will gather.  Read HERE: every workgroup has read
+  // them before it publishes anything, and no head's epoch is bumped before its split-0 workgroup has gathered the granules of
+  // ALL workgroups of all heads — so none of these reads can see a bumped word.
+  unsigned l2_ep[3] = {0u, 0u, 0u};
+  if constexpr (ONE && L2) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const int e = (int)threadIdx.x + k * NW * 64;
+      if (e < a.H * a.n_split) l2_ep[k] = a.one_hdr[e / a.n_split];
+    }
+  }
   if constexpr (ONE) {
     one_tag = a.one_hdr[h] + 1u;
     one_pin = *a.input_pos;
@@ -691,6 +712,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
       }
       one_ps = a.pos[(a.Hp == 1 ? 0 : (size_t)h * S) + one_slot];
       if (a.policy == 3) one_rnd = a.rand_next[one_slot];
+      if constexpr (L2) one_kn = ElemTraits<T>::load(reinterpret_cast<const T*>(a.key_norm) + (size_t)h * S, one_slot);
     }
   }
   float s_keep[U] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};  // ONE: the wave's (single) tile of scores, kept for the per-slot pass
@@ -903,10 +925,11 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
           for (int i = 0; i < D / 16; i++) ss = __fadd_rn(ss, __fmul_rn(xq[i], xq[i]));
 #pragma unroll
           for (int off = 8; off > 0; off >>= 1) ss = __fadd_rn(ss, __shfl_xor(ss, off, 16));
+          const float nv = ElemTraits<T>::rnd(cc_sqrt_rn(ss));  // every lane of the row group holds the full sum
+          l2_nv_lane = nv;
           if (c == 0) {
-            const float nv = ElemTraits<T>::rnd(cc_sqrt_rn(ss));
             ElemTraits<T>::store(reinterpret_cast<T*>(a.key_norm), slot, nv);
-            a.l2_new[h] = nv;
+            if constexpr (!ONE) a.l2_new[h] = nv;
           }
         }
       }
@@ -1026,7 +1049,15 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
     base = base_next;
     more = more_next;
   }
-  if (L2 && l2_here) {  // publish this wave's maximum over the norms that survive this step
+  __shared__ float sm_l2w[NW];  // ONE + L2: per-wave maxima of the norms this workgroup's slots hold AFTER the step's insert
+  if constexpr (L2 && ONE) {
+    float kv = -INFINITY;
+    if (one_have) kv = (one_slot == ins_idx) ? l2_nv_lane : one_kn;
+    const bool nn = __any(kv != kv) != 0;
+    const float wm = wave_max_f32(kv);
+    if (lane == 0) sm_l2w[wave] = nn ? NAN : wm;
+  }
+  if (L2 && !ONE && l2_here) {  // publish this wave's maximum over the norms that survive this step
     if (key_pending) {  // a wave without rows never entered the loop
 #pragma unroll
       for (int j = 0; j < 3; j++) key_part = key_more[j] < key_part ? key_more[j] : key_part;
@@ -1117,11 +1148,27 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
           O1 = fmaf(sm_wacc[w][r][d + 1], f, O1);
         }
         const u32x4_t og = {tag, __float_as_uint(O0), tag, __float_as_uint(O1)};
-        __builtin_amdgcn_raw_buffer_store_b128(og, o_rsrc, (((h * RT + r) * ns + split) * 64 + (d >> 1)) * 16, 0, kOneAuxCoherent);
+        __builtin_amdgcn_raw_buffer_store_b128(og, o_rsrc, h * kOneOHead + ((r * ns + split) * 64 + (d >> 1)) * 16, 0, kOneAuxCoherent);
         if (d == 0) {
           const u32x4_t mg = {tag, __float_as_uint(M), tag, __float_as_uint(L)};
-          __builtin_amdgcn_raw_buffer_store_b128(mg, ml_rsrc, ((h * ns + split) * RT + r) * 16, 0, kOneAuxCoherent);
+          __builtin_amdgcn_raw_buffer_store_b128(mg, ml_rsrc, h * kOneMlHead + (split * RT + r) * 16, 0, kOneAuxCoherent);
         }
+      }
+    }
+    // l2: the workgroup's norm maximum travels the same way — one granule {tag, max, tag, nan} per workgroup in the upper half
+    // of the (m, l) region; every workgroup of EVERY kv head gathers all of them (cache.py:602 takes the maximum over all heads)
+    const int nm_base = kOneMaxHeads * kOneMlHead;  // behind the (m, l) regions of all heads
+    if constexpr (L2) {
+      if (threadIdx.x == NW * 64 - 1) {
+        float wm = sm_l2w[0];
+        bool nn = wm != wm;
+#pragma unroll
+        for (int w = 1; w < NW; w++) {
+          nn |= sm_l2w[w] != sm_l2w[w];
+          wm = fmaxf(wm, sm_l2w[w]);
+        }
+        const u32x4_t ng = {tag, __float_as_uint(wm), tag, nn ? 1u : 0u};
+        __builtin_amdgcn_raw_buffer_store_b128(ng, ml_rsrc, nm_base + h * kOneNmHead + split * 16, 0, kOneAuxCoherent);
       }
     }
     if (a.trace) tr2 = __builtin_amdgcn_s_memtime();
@@ -1135,7 +1182,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
     constexpr int NOG = (RT * 64 + 64 + NW * 64 - 1) / (NW * 64);  // O granules per thread
     int ml_off[MLN];
 #pragma unroll
-    for (int k = 0; k < MLN; k++) ml_off[k] = ((h * ns + (lane < ns ? lane : 0)) * RT + (wave + k * NW < RT ? wave + k * NW : 0)) * 16;
+    for (int k = 0; k < MLN; k++) ml_off[k] = h * kOneMlHead + ((lane < ns ? lane : 0) * RT + (wave + k * NW < RT ? wave + k * NW : 0)) * 16;
     int o_off[NOG], o_lds[NOG];
     bool o_use[NOG];
 #pragma unroll
@@ -1144,8 +1191,20 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
       const int i = item / ppw, qq = item - i * ppw;
       o_use[k] = item < n_items && qq < n_pairs;
       const int P = o_use[k] ? pair0 + qq : 0;
-      o_off[k] = (((h * RT + (P >> 6)) * ns + (o_use[k] ? i : 0)) * 64 + (P & 63)) * 16;
+      o_off[k] = h * kOneOHead + (((P >> 6) * ns + (o_use[k] ? i : 0)) * 64 + (P & 63)) * 16;
       o_lds[k] = (i * ppw + qq) * 2;
+    }
+    constexpr int NLG = L2 ? 3 : 0;  // l2: norm-maximum granules per thread (H * n_split <= 768 workgroups are ever co-resident)
+    int nm_off[NLG > 0 ? NLG : 1];
+    bool nm_use[NLG > 0 ? NLG : 1];
+    unsigned nm_tag[NLG > 0 ? NLG : 1];  // a granule of kv head h' carries h''s tag (its epoch word was read in the prologue: l2_ep)
+#pragma unroll
+    for (int k = 0; k < NLG; k++) {
+      const int e = (int)threadIdx.x + k * NW * 64;
+      nm_use[k] = e < a.H * ns;
+      const int hh = nm_use[k] ? e / ns : 0, ss = nm_use[k] ? e - hh * ns : 0;
+      nm_off[k] = nm_base + hh * kOneNmHead + ss * 16;
+      nm_tag[k] = l2_ep[k] + 1u;
     }
     bool timed_out = false;
     // The first poll waits until this wave's OWN publish stores are acknowledged (vmcnt counts stores on this chip).  Polls issued
@@ -1154,14 +1213,18 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
     // then queue behind 6 MB of polls per round that cannot succeed yet.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (a.trace) tr3 = __builtin_amdgcn_s_memtime();
-    u32x4_t mlq[MLN], oq[NOG];
+    u32x4_t mlq[MLN], oq[NOG], nq[NLG > 0 ? NLG : 1];
     for (unsigned spins = 0;; spins++) {
       asm volatile("" ::: "memory");  // every round re-reads memory
 #pragma unroll
       for (int k = 0; k < MLN; k++) mlq[k] = __builtin_amdgcn_raw_buffer_load_b128(ml_rsrc, ml_off[k], 0, kOneAuxCoherent);
 #pragma unroll
       for (int k = 0; k < NOG; k++) oq[k] = __builtin_amdgcn_raw_buffer_load_b128(o_rsrc, o_off[k], 0, kOneAuxCoherent);
+#pragma unroll
+      for (int k = 0; k < NLG; k++) nq[k] = __builtin_amdgcn_raw_buffer_load_b128(ml_rsrc, nm_off[k], 0, kOneAuxCoherent);
       bool ok = true;
+#pragma unroll
+      for (int k = 0; k < NLG; k++) ok = ok && (!nm_use[k] || (nq[k][0] == nm_tag[k] && nq[k][2] == nm_tag[k]));
 #pragma unroll
       for (int k = 0; k < MLN; k++) ok = ok && mlq[k][0] == tag && mlq[k][2] == tag;
 #pragma unroll
@@ -1199,6 +1262,21 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
 #pragma unroll
     for (int k = 0; k < NOG; k++)
       if (o_use[k]) *reinterpret_cast<float2*>(&sm_o1[o_lds[k]]) = make_float2(__uint_as_float(oq[k][1]), __uint_as_float(oq[k][3]));
+    __shared__ float sm_l2g[NW];  // l2: per-wave fold of the gathered norm maxima (NaN propagates: torch.max)
+    if constexpr (L2) {
+      float gm = -INFINITY;
+      bool gn = false;
+#pragma unroll
+      for (int k = 0; k < NLG; k++)
+        if (nm_use[k]) {
+          const float v = __uint_as_float(nq[k][1]);
+          gn |= nq[k][3] != 0u || v != v;
+          gm = fmaxf(gm, v);
+        }
+      const bool nn = __any(gn) != 0;
+      const float wm = wave_max_f32(gm);
+      if (lane == 0) sm_l2g[wave] = nn ? NAN : wm;
+    }
     __syncthreads();
     unsigned long long trD = 0, trE = 0;
     if (a.trace) trD = __builtin_amdgcn_s_memtime();
@@ -1277,7 +1355,22 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
         }
         const int32_t p_next = one_pin + 1;
         const uint32_t low = ((uint32_t)one_slot << 1) | (uint32_t)(ps == -1);
-        if (a.num) {
+        if constexpr (L2) {  // ref: cache.py:597-605: dtype(max over ALL heads and slots - norm), recent window -> +inf, base rules
+          float gm = -INFINITY;
+          bool gn = false;
+#pragma unroll
+          for (int w2 = 0; w2 < NW; w2++) {
+            const float v = sm_l2g[w2];
+            gn |= (v != v);
+            gm = fmaxf(gm, v);
+          }
+          const float kn_eff = (one_slot == ins_idx) ? l2_nv_lane : one_kn;
+          float scn = ElemTraits<T>::rnd((gn ? NAN : gm) - kn_eff);
+          if (ps >= p_next - a.w) scn = INFINITY;
+          if (one_slot < a.g) scn = INFINITY;
+          if (ps == -1) scn = -INFINITY;
+          my_key = make_key(orderable_f32(scn), low);
+        } else if (a.num) {
           if (a.attn_out) ElemTraits<T>::store(reinterpret_cast<T*>(a.attn_out), i, av);
           const double num_new = num_old + (double)av;
           const int32_t den_new = den_old + 1;
@@ -1889,17 +1982,17 @@ extern "C" {
 
 namespace {
 // ---- single-launch layer step: shape eligibility, workspace regions, residency
-// Workspace layout: [epoch words + timeout word: 4 KiB][(m, l) granules: 128 KiB][O granules: 8 MiB][two-launch scratch].
+// Workspace layout: [epoch words + timeout word: 4 KiB][(m, l) + l2 norm granules: 32 heads x 9 KiB][O granules: 32 heads x 512 KiB][two-launch scratch].
 // The single-launch regions sit at FIXED offsets and fixed capacities, whatever the shape: caches of different lengths
 // (pyramid budgets) share one workspace and one set of epoch words, tags grow monotonically across all of them, and
 // nothing but the single-launch kernel ever writes a word that could be mistaken for a tag.
-constexpr size_t kOneHdrBytes = 4096, kOneMlCap = 128 << 10, kOneOCap = 8 << 20;
+constexpr size_t kOneHdrBytes = 4096, kOneMlCap = (size_t)kOneMaxHeads * (kOneMlHead + kOneNmHead), kOneOCap = (size_t)kOneMaxHeads * kOneOHead;
 constexpr size_t kOneBytes = kOneHdrBytes + kOneMlCap + kOneOCap;
 constexpr int kOneStatusWord = 1023;  // hdr[0 .. H): epochs; hdr[1023]: timeout word
 static bool one_shape_ok(const Plan& p, int HQ, int H, int D, int dtype) {
   const int R = HQ / H;
   return cc_dt_size(dtype) == 2 && D == 128 && R == p.rt && p.rows_per_split == rows_per_iter(D, dtype) && p.n_split <= 64 &&
-         H < kOneStatusWord && (size_t)HQ * p.n_split * 16 <= kOneMlCap && (size_t)HQ * p.n_split * 64 * 16 <= kOneOCap;
+         H <= kOneMaxHeads && p.rt <= 8;
 }
 static size_t base_workspace_bytes(const Plan& p, int HQ, int H, int S, int D, int dtype) {
   return align256((size_t)HQ * S * cc_dt_size(dtype)) + align256((size_t)HQ * p.n_split * 2 * sizeof(float)) +
@@ -1922,7 +2015,15 @@ static int one_capacity(KernelT kernel) {
   return cap;
 }
 template <typename T>
-static int one_capacity_rt(int rt, int qb = 0) {
+static int one_capacity_rt(int rt, int qb = 0) {  // qb: 0 = 16-bit cache, 8 = fused quantised cache, -1 = the l2 policy's instantiation
+  if (qb < 0) {
+    switch (rt) {
+      case 8: return one_capacity(decode_attn_split_mfma_kernel<T, 8, kNW, true, true>);
+      case 4: return one_capacity(decode_attn_split_mfma_kernel<T, 4, kNW, true, true>);
+      case 2: return one_capacity(decode_attn_split_mfma_kernel<T, 2, kNW, true, true>);
+      default: return one_capacity(decode_attn_split_mfma_kernel<T, 1, kNW, true, true>);
+    }
+  }
   if (qb) {
     switch (rt) {
       case 8: return one_capacity(decode_attn_split_mfma_kernel<T, 8, kNW, false, true, false, 8>);
@@ -1945,6 +2046,16 @@ static int launch_one(const SplitArgs& a, const Plan& p, int H, hipStream_t st) 
       case 8: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 8, kNW, false, true, false, 8>), grid, block, 0, st, a); break;
       case 4: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 4, kNW, false, true, false, 8>), grid, block, 0, st, a); break;
       default: return CC_ERR_UNSUPPORTED;
+    }
+    CC_LAUNCH_CHECK();
+    return CC_OK;
+  }
+  if (a.key_norm != nullptr) {  // l2
+    switch (p.rt) {
+      case 8: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 8, kNW, true, true>), grid, block, 0, st, a); break;
+      case 4: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 4, kNW, true, true>), grid, block, 0, st, a); break;
+      case 2: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 2, kNW, true, true>), grid, block, 0, st, a); break;
+      default: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 1, kNW, true, true>), grid, block, 0, st, a); break;
     }
     CC_LAUNCH_CHECK();
     return CC_OK;
@@ -1972,6 +2083,8 @@ static int32_t one_available(int32_t HQ, int32_t H, int32_t S, int32_t D, int32_
   if (HQ <= 0 || H <= 0 || HQ % H || S <= 0 || D <= 0 || !cc_dt_ok(dtype)) return 0;
   const Plan p = make_plan(HQ, H, S, D, dtype);
   if (!one_shape_ok(p, HQ, H, D, dtype)) return 0;
+  // l2: every thread gathers at most three workgroups' norm maxima
+  if (qb < 0 && H * p.n_split > 3 * kNW * 64) return 0;
   const int cap = dtype == CC_DT_BF16 ? one_capacity_rt<bf16_t>(p.rt, qb) : one_capacity_rt<f16_t>(p.rt, qb);
   return p.n_split * H <= cap ? 1 : 0;
 }
@@ -2084,9 +2197,10 @@ static int attn_impl(const void* q, const void* k, const void* v, const uint8_t*
   const bool one_asked = (phases & CC_PHASE_ONE_LAUNCH) != 0;
   if (one_asked || (g_one_enabled && (phases & 3) == 3 && !(phases & CC_PHASE_TWO_LAUNCH))) {
     const bool policy_ok = fs && ((fs->policy == 1 && hh_num && hh_denom && fs->c->Hp == H) ||
-                                  ((fs->policy == 2 || (fs->policy == 3 && fs->rand_next)) && !hh_num && fs->c->Hp == 1));
+                                  ((fs->policy == 2 || (fs->policy == 3 && fs->rand_next)) && !hh_num && fs->c->Hp == 1) ||
+                                  (fs->policy == 4 && fs->key_norm && !hh_num && fs->c->Hp == H));
     const bool one_ok = policy_ok && !rh && !probs_out && !attn_out_needs_probs(fs, attn_out) &&
-                        one_available(HQ, H, S, D, dtype, fs->qparams ? 8 : 0) == 1;
+                        one_available(HQ, H, S, D, dtype, fs->qparams ? 8 : (fs->policy == 4 ? -1 : 0)) == 1;
     if (one_asked && !one_ok) return CC_ERR_UNSUPPORTED;
     if (one_ok) {
       char* ob = reinterpret_cast<char*>(workspace);

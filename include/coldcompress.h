@@ -257,9 +257,10 @@ int cc_decode_step_heavy_hitter_ring(const cc_kv_view* c, const void* q, const v
 #define CC_PHASE_ONE_LAUNCH 0x20000
 int32_t cc_decode_step_single_launch(int32_t HQ, int32_t H, int32_t S, int32_t D, int32_t dtype);
 int32_t cc_decode_step_status_offset(void);
-/* Process-wide switch (default 1): 0 makes every fused decode step (heavy hitter, recent_global / full, random) use the
+/* Process-wide switch (default 1): 0 makes every fused decode step (heavy hitter, recent_global / full, random, l2) use the
  * two-launch form — what tests compare the single launch against.  The head-constant policies (recent_global, full,
- * random: cc_decode_step_recent_global / cc_decode_step_random) take the single launch under the same conditions. */
+ * random: cc_decode_step_recent_global / cc_decode_step_random) and l2 (cc_decode_step_l2: every workgroup also gathers every
+ * workgroup's norm maximum) take the single launch under the same conditions (l2: at most 768 workgroups, 32 kv heads). */
 void cc_decode_step_set_single_launch(int32_t enabled);
 /* Measurement hook: buf = device buffer of [workgroups][16] uint64, or NULL (default).  While set, thread 0 of every
  * workgroup of a single-launch step records [0..5] s_memtime stamps (start, streaming done, published, sentinel seen,

@@ -388,12 +388,16 @@ def test_ring_history_folded_into_combine(strategy, dtype, H, HQ, S, D, T, W):
 
 @pytest.mark.parametrize("dtype,H,HQ,S,D,T,g,w", [(torch.bfloat16, 8, 32, 4096, 128, 4090, 4, 10), (torch.float16, 1, 8, 600, 128, 600, 2, 3),
                                                   (torch.bfloat16, 4, 16, 333, 128, 300, 0, 1), (torch.bfloat16, 8, 32, 18432, 128, 18432, 4, 10)])
-def test_l2_fused_step_equals_three_calls(dtype, H, HQ, S, D, T, g, w):
-    """KVCacheL2: the two-launch step (cc_decode_step_l2: global norm maximum folded across the step boundary) against
+@pytest.mark.parametrize("single", [False, True])
+def test_l2_fused_step_equals_three_calls(dtype, H, HQ, S, D, T, g, w, single, single_launch_switch):
+    """KVCacheL2: the fused step (cc_decode_step_l2: global norm maximum folded across the step boundary by the two launches,
+    or — `single` — handed over inside ONE launch, every workgroup gathering every workgroup's norm maximum) against
     update_kv -> attention; every buffer (key_norm included) bit for bit.  The evicted slot is usually the one holding
     the global maximum, so the exclusion of its old norm from the running maximum is exercised on every step."""
     import cold_compress_amd.cache as cache
     from cold_compress_amd.attention_utils import scaled_dot_product_attention as sdpa
+
+    single_launch_switch(single)
 
     cls, rk = cache.get_cache_constructor("l2")
     kw = dict(max_cache_length=S, global_tokens=g, recent_window=w, max_seq_length=4 * S, cache_bits=None)
@@ -420,7 +424,7 @@ def test_l2_fused_step_equals_three_calls(dtype, H, HQ, S, D, T, g, w):
         ya, _ = sdpa(q, ka, va, attn_mask=ma)
         yb = b.decode_step(q, k1, v1, p)
         torch.cuda.synchronize()
-        assert torch.equal(ya, yb), f"step {t}: attention output"
+        _y_check(ya, yb, single, t)
         for (na, ta), (nb, tb) in zip(a.named_buffers(), b.named_buffers()):
             if na != "next_key":
                 assert torch.equal(ta, tb), f"step {t}: {na}"
@@ -473,3 +477,59 @@ def test_l2_fused_step_vs_oracle():
         from helpers import from_np
         assert torch.allclose(y.cpu().float().reshape(HQ, D), from_np(yo, dtype).float(), atol=2e-2, rtol=2e-2), f"step {t}: y"
     assert np.array_equal(to_np(kv.k_cache.cpu()[0]), st["k"]) and np.array_equal(kv.cache_cts.cpu().numpy(), st["cts"])
+
+
+def test_single_launch_caches_of_different_head_counts_share_the_workspace(single_launch_switch):
+    """Caches with different numbers of kv heads and different lengths take turns on ONE workspace (one set of epoch words):
+    launches with fewer heads advance only the first heads' epochs, so tags of different heads drift apart.  The granule regions
+    are per kv head at fixed strides — a location only ever sees its own head's growing tags — and the l2 step compares every
+    gathered norm granule with ITS head's tag: nothing stale may match, no hand-off may time out, and every single-launch step
+    stays bit-identical to its two-launch twin."""
+    import cold_compress_amd.cache as cache
+
+    D, dtype = 128, torch.bfloat16
+
+    def mk(strategy, H, S):
+        cls, rk = cache.get_cache_constructor(strategy)
+        kw = dict(max_cache_length=S, global_tokens=4, max_seq_length=4 * S, cache_bits=None, recent_window=10, history_window_size=1,
+                  attn_thresholding=False)
+        with torch.device(DEV):
+            return cls(1, H, D, dtype, **{k: kw[k] for k in rk})
+
+    shapes = [("heavy_hitter", 1, 8, 3488), ("heavy_hitter", 8, 32, 4096), ("l2", 8, 32, 1024), ("l2", 2, 8, 600), ("heavy_hitter", 4, 16, 333),
+              ("l2", 8, 32, 4096), ("recent_global", 1, 4, 2048)]
+    gen = torch.Generator().manual_seed(77)
+    pairs = []
+    for strategy, H, HQ, S in shapes:
+        a, b = mk(strategy, H, S), mk(strategy, H, S)
+        T = S - 5
+        k0 = (torch.randn(1, H, T, D, generator=gen) * torch.rand(1, H, T, 1, generator=gen)).to(dtype).to(DEV)
+        v0 = torch.randn(1, H, T, D, generator=gen).to(dtype).to(DEV)
+        for kv in (a, b):
+            kv.update_kv(torch.arange(T, device=DEV), k0, v0, True)
+            kv.update_state(torch.arange(T, device=DEV), k0, v0, True, None) if strategy == "l2" else None
+        pairs.append((strategy, H, HQ, S, T, a, b))
+    for t in range(9):  # round-robin over the shapes: uneven epoch advance (the one-head caches step three times as often)
+        for strategy, H, HQ, S, T, a, b in pairs:
+            for rep in range(3 if H == 1 else 1):
+                p = torch.tensor([T + 3 * t + rep], dtype=torch.int32, device=DEV)
+                k1 = torch.randn(1, H, 1, D, generator=gen).to(dtype).to(DEV)
+                v1 = torch.randn(1, H, 1, D, generator=gen).to(dtype).to(DEV)
+                q = torch.randn(1, HQ, 1, D, generator=gen).to(dtype).to(DEV)
+                single_launch_switch(False)
+                if hasattr(a, "single_launch"):
+                    a.single_launch = False
+                ya = a.decode_step(q, k1, v1, p)
+                single_launch_switch(True)
+                yb = b.decode_step(q, k1, v1, p)
+                torch.cuda.synchronize()
+                assert torch.allclose(ya.float(), yb.float(), rtol=2.0 ** -7, atol=1e-6), (strategy, H, S, t)
+                for (na, ta), (nb, tb) in zip(a.named_buffers(), b.named_buffers()):
+                    if na != "next_key":
+                        assert torch.equal(ta, tb), (strategy, H, S, t, na)
+    from cold_compress_amd.attention_utils import _WS
+    from cold_compress_amd import _abi
+
+    off = _abi.lib()["cc_decode_step_status_offset"]()
+    ws = _WS.get((str(pairs[0][5].k_cache.device), "decode"))
+    assert ws is not None and int(ws[off:off + 4].view(torch.int32).item()) == 0
