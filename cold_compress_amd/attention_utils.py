@@ -49,10 +49,31 @@ def _workspace(nbytes, device, kind="decode"):
             raise ColdCompressError("attention scratch must be allocated before hipGraph capture (run one eager step first): "
                                     "a captured allocation would re-zero the single-launch step's epoch words on every replay")
         if ws is not None:
-            _RETIRED.append(ws)
+            _RETIRED.append((kind, ws))
         ws = torch.zeros(max(nbytes, 1), dtype=torch.uint8, device=device)
         _WS[key] = ws
     return ws
+
+
+def single_launch_status(device=None):
+    """0, or 1 if a single-launch layer step ever failed to complete its in-launch hand-off (a launch whose workgroups were not
+    all resident: its results are invalid) on `device` (default: every device) — read from the decode workspaces, the retired
+    ones included (captured hipGraphs may still run on them).  Synchronises."""
+    off = int(_abi.lib()["cc_decode_step_status_offset"]())
+    bad = 0
+    for (dev, kind), ws in list(_WS.items()) + [((str(w.device), k), w) for k, w in _RETIRED]:
+        if kind == "decode" and (device is None or dev == str(device)) and off + 4 <= ws.numel():
+            bad |= int(ws[off:off + 4].view(torch.int32).item())
+    return bad
+
+
+def check_single_launch_status(device=None):
+    """Raise loudly if a single-launch step timed out (see single_launch_status)."""
+    if single_launch_status(device):
+        raise ColdCompressError(
+            "a single-launch layer step did not complete its in-launch hand-off (its workgroups were not all resident, e.g. the "
+            "GPU was shared with another kernel): the tokens produced since are invalid.  Disable the single-launch form with "
+            "cc_decode_step_set_single_launch(0) (or KVCacheHeavyHitter.single_launch = False) when the device is shared.")
 
 
 def decode_attention(query, key, value, attn_mask=None, scale=None, return_attn=False, group_mean=False,

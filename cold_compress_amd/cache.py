@@ -687,15 +687,11 @@ class KVCacheHeavyHitter(_TrackedWindowSums, KVCacheHeadSpecific):
         return bool(self.single_launch and self.history_window_size == 1 and _abi.lib()["cc_decode_step_single_launch"](
             HQ, self.n_heads, self.max_cache_length, self.head_dim, _DT[self.k_cache.dtype]))
 
-    def step_status(self, HQ):
+    def step_status(self, HQ=None):
         """0, or 1 if a single-launch step ever failed to complete its in-launch hand-off on this device (synchronises)."""
-        from .attention_utils import _WS
+        from .attention_utils import single_launch_status
 
-        off = _abi.lib()["cc_decode_step_status_offset"]()
-        ws = _WS.get((str(self.k_cache.device), "decode"))
-        if ws is None or off + 4 > ws.numel():
-            return 0
-        return int(ws[off:off + 4].view(torch.int32).item())
+        return single_launch_status(self.pos.device)
 
     def _run_select(self, input_pos, k, v):
         if self.history_window_size == 1:

@@ -237,6 +237,10 @@ def generate(model, prompt, prefill, decode_one_token, max_new_tokens, next_toke
                                       terminator_ids=terminator_ids, prefix=prefix, attn_top_k=attn_top_k, **kw)
     sync()
     t2 = time.perf_counter()
+    if device.type == "cuda":  # fail loudly: a single-launch step that timed out leaves a word in the decode workspace
+        from ..attention_utils import check_single_launch_status
+
+        check_single_launch_status(device)
     decode_tokens = len(toks) + 1
     stats = {
         "prefill_tokens": prompt_length, "decode_tokens": decode_tokens,

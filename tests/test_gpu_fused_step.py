@@ -527,9 +527,31 @@ def test_single_launch_caches_of_different_head_counts_share_the_workspace(singl
                 for (na, ta), (nb, tb) in zip(a.named_buffers(), b.named_buffers()):
                     if na != "next_key":
                         assert torch.equal(ta, tb), (strategy, H, S, t, na)
-    from cold_compress_amd.attention_utils import _WS
-    from cold_compress_amd import _abi
+    from cold_compress_amd.attention_utils import single_launch_status
 
-    off = _abi.lib()["cc_decode_step_status_offset"]()
-    ws = _WS.get((str(pairs[0][5].k_cache.device), "decode"))
-    assert ws is not None and int(ws[off:off + 4].view(torch.int32).item()) == 0
+    assert single_launch_status() == 0
+
+
+def test_hand_off_timeout_is_reported_loudly():
+    """A single-launch step whose workgroups were not all resident gives up after a bounded spin and leaves a word in the decode
+    workspace; the harness's generate() (and bench.py) check it and raise — simulated here by setting the word."""
+    from cold_compress_amd import _abi
+    from cold_compress_amd.attention_utils import _WS, check_single_launch_status, single_launch_status
+
+    kv = _mk(2, 256, 128, torch.bfloat16)
+    _seed(kv, torch.Generator().manual_seed(1), 250)
+    q = torch.randn(1, 8, 1, 128).to(torch.bfloat16).to(DEV)
+    k1 = torch.randn(1, 2, 1, 128).to(torch.bfloat16).to(DEV)
+    kv.decode_step(q, k1, k1, torch.tensor([300], dtype=torch.int32, device=DEV))
+    assert single_launch_status() == 0
+    check_single_launch_status()
+    ws = _WS[(str(kv.pos.device), "decode")]
+    off = int(_abi.lib()["cc_decode_step_status_offset"]())
+    try:
+        ws[off:off + 4].view(torch.int32).fill_(1)
+        assert kv.step_status() == 1
+        with pytest.raises(_abi.ColdCompressError):
+            check_single_launch_status(kv.pos.device)
+    finally:
+        ws[off:off + 4].view(torch.int32).fill_(0)
+    assert single_launch_status() == 0
