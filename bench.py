@@ -166,8 +166,7 @@ def roofline(model, args, dev):
         with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
             ks = json.load(f)["kernels"]
         # the single-launch instantiation (RT = 4, 4 waves, not l2, ONE, not hybrid), whatever trailing defaults the name carries
-        keys = [n for n in ks if n.startswith("decode_attn_split_mfma_kernel<bf16_t, 4, 4, false, true")
-                and not n.endswith("true, true>")] if one else []
+        keys = [n for n in ks if n.startswith("decode_attn_split_mfma_kernel<bf16_t, 4, 4, false, true, false, 0")] if one else []
         k = ks[keys[0]] if keys else None
         if k and (H, S, D, HQ) == (8, 4096, 128, 32):
             traffic = k["traffic_bytes"]
