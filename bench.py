@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--graph", action="store_true", help="force hipGraph replay (default: time both on a few untimed tokens, keep the faster)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--roofline_iters", type=int, default=20)
+    ap.add_argument("--no_live_pmc", action="store_true", help="take roofline.traffic from profiles/ instead of two rocprofv3 --pmc child runs")
+    ap.add_argument("--pmc_child", action="store_true", help=argparse.SUPPRESS)  # the workload rocprofv3 is wrapped around
     return ap.parse_args()
 
 
@@ -78,6 +80,79 @@ def cache_kwargs(args):
                 cache_strategy=["heavy_hitter"], cache_strategy_pattern="tile", feed_long_prompts=False,
                 prompt_compression_strategy=["heavy_hitter"], global_tokens=4, recent_window=10, history_window_size=1,
                 attn_thresholding=False, min_recovery_frac=0.9)
+
+
+def pmc_child():
+    """What the PMC passes run under rocprofv3: 64 single-launch heavy-hitter layer steps at the benchmark's shape over eight
+    rotating caches (no model around them: the counters are read per kernel).  Prints nothing the parent parses."""
+    from cold_compress_amd.cache import get_cache_constructor
+
+    dev, H, HQ, S, D = torch.device("cuda", 0), 8, 32, 4096, 128
+    cls, rk = get_cache_constructor("heavy_hitter")
+    kw = dict(max_cache_length=S, global_tokens=4, max_seq_length=4 * S, cache_bits=None, recent_window=10, history_window_size=1,
+              attn_thresholding=False)
+    caches = []
+    for _ in range(8):
+        with torch.device(dev):
+            kv = cls(1, H, D, torch.bfloat16, **{k: kw[k] for k in rk})
+        kv.k_cache.normal_()
+        kv.v_cache.normal_()
+        kv.pos[0] = torch.stack([torch.randperm(S + 64, device=dev)[:S] for _ in range(H)]).int()
+        kv.mask.fill_(True)
+        kv.cache_cts.fill_(S)
+        kv.attn_history_num.uniform_()
+        kv.attn_history_denom.fill_(3)
+        caches.append(kv)
+    q = torch.randn(1, HQ, 1, D, device=dev).to(torch.bfloat16)
+    k1 = torch.randn(1, H, 1, D, device=dev).to(torch.bfloat16)
+    for t in range(8):
+        pos = torch.tensor([S + 100 + t], dtype=torch.int32, device=dev)
+        for kv in caches:
+            kv.decode_step(q, k1, k1, pos)
+    torch.cuda.synchronize()
+    assert caches[0].single_launch_active(HQ) and caches[0].step_status() == 0
+
+
+def live_traffic(kernel_prefix, timeout=240):
+    """HBM bytes per launch of the dominant kernel, measured in THIS run: two rocprofv3 passes (FETCH_SIZE and WRITE_SIZE exceed
+    the TCC counter slots together; --pmc only ever with --kernel-trace) around `bench.py --pmc_child`, corrected as
+    MI355X_MICROARCH.md prescribes (FETCH_SIZE x2 on gfx950: wide reads are tallied at 64 B).  None if rocprofv3 is unavailable."""
+    import csv
+    import shutil
+    import subprocess
+    import tempfile
+
+    rp = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if rp is None:
+        return None
+    med = {}
+    with tempfile.TemporaryDirectory(prefix="cc_pmc_", dir="/tmp") as tmp:
+        env = dict(os.environ, TMPDIR="/tmp")
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, ctr)
+            cmd = [rp, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", out, "--", sys.executable,
+                   os.path.abspath(__file__), "--pmc_child"]
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout)
+            except (subprocess.TimeoutExpired, OSError) as e:
+                print(f"[bench] live PMC pass {ctr} failed: {e}", file=sys.stderr)
+                return None
+            vals = []
+            for root, _, files in os.walk(out):
+                for fn in files:
+                    if fn.endswith("counter_collection.csv"):
+                        for row in csv.DictReader(open(os.path.join(root, fn))):
+                            k = row.get("Kernel_Name", "")
+                            if row.get("Counter_Name") == ctr and "(anonymous namespace)::" in k and \
+                                    k.split("(anonymous namespace)::")[1].startswith(kernel_prefix):
+                                vals.append(float(row["Counter_Value"]))
+            if r.returncode != 0 or not vals:
+                print(f"[bench] live PMC pass {ctr}: rc {r.returncode}, {len(vals)} samples: {r.stderr[-300:]}", file=sys.stderr)
+                return None
+            vals.sort()
+            med[ctr] = (vals[len(vals) // 2] * 1024.0, len(vals))
+    fetch, write = 2.0 * med["FETCH_SIZE"][0], med["WRITE_SIZE"][0]
+    return {"traffic": round(fetch + write), "fetch": round(fetch), "write": round(write), "launches": med["FETCH_SIZE"][1]}
 
 
 def roofline(model, args, dev):
@@ -162,7 +237,17 @@ def roofline(model, args, dev):
     # HBM bytes per launch from the PMC counters: they need rocprofv3 around the process (two separate --pmc passes),
     # so they come from the committed summary of that run (tools/pmc_traffic.py), not from inside this process
     traffic, traffic_src = None, None
+    live = None
+    if one and not args.no_live_pmc and (H, S, D, HQ) == (8, 4096, 128, 32):
+        live = live_traffic("decode_attn_split_mfma_kernel<bf16_t, 4, 4, false, true, false, 0")
+    if live:
+        traffic = live["traffic"]
+        traffic_src = ("measured in this run: rocprofv3 --pmc FETCH_SIZE (x2, gfx950 wide-read correction) and --pmc WRITE_SIZE, separate "
+                       "passes with --kernel-trace around `bench.py --pmc_child` (64 single-launch steps at this shape), median over %d "
+                       "launches; fetch %d + write %d B" % (live["launches"], live["fetch"], live["write"]))
     try:
+        if live:
+            raise OSError("measured live")
         with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
             ks = json.load(f)["kernels"]
         # the single-launch instantiation (RT = 4, 4 waves, not l2, ONE, not hybrid), whatever trailing defaults the name carries
@@ -406,6 +491,8 @@ def _self_launch(args):
 
 def main():
     args = parse()
+    if args.pmc_child:
+        return pmc_child()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         _self_launch(args)  # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
