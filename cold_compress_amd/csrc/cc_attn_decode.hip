@@ -599,16 +599,26 @@ __device__ __forceinline__ uint2 quant8_row16(uint4 raw, float2& par) {
   return make_uint2(b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24), b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24));
 }
 
+template <int V>
+struct IntC {
+  static constexpr int value = V;
+};
+
 // L2: the l2 policy's norm bookkeeping (its own instantiation: the others pay nothing).  ONE: the single-launch layer
 // step of the heavy-hitter policy (needs R == RT, one tile per wave, every workgroup of the grid co-resident).
 // QB = 8: the fused quantised cache (uint8 images + per-row (scale, minimum)), dequantised on the way to the LDS slabs.
 // NSUB = 2 (multi-tile splits only): two tiles per wave and iteration, each with its own staging registers — the loads of a
 // tile go out two half-iterations ahead of their use instead of one (twice the bytes in flight per wave).
-template <typename T, int RT, int NW, bool L2, bool ONE = false, bool HYB = false, int QB = 0, int NSUB = 1>
+// NT (ONE only): tiles per wave the single-launch step keeps scores for — 1 for caches up to 64 x 64 slots per kv head (the
+// specialised form), 4 or 8 for longer ones (the wave loops over its tiles like the two-launch streaming pass, and its finish
+// loops over them for the per-slot pass).
+template <typename T, int RT, int NW, bool L2, bool ONE = false, bool HYB = false, int QB = 0, int NSUB = 1, int NT = 1>
 __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_split_mfma_kernel(SplitArgs a) {
   static_assert(!(HYB && (L2 || ONE)), "the hybrid decision rides the plain two-launch streaming pass");
   static_assert(QB == 0 || (QB == 8 && !L2 && !HYB), "fused quantised cache: 8 bits, heavy hitter / recent_global / random");
-  static_assert(NSUB == 1 || (NSUB == 2 && !ONE), "the single-launch step owns exactly one tile per wave");
+  static_assert(NSUB == 1 || (NSUB == 2 && !ONE), "two tiles per iteration: the two-launch streaming pass only");
+  static_assert(NT == 1 || (ONE && !L2 && QB == 0 && NSUB == 1), "several tiles per wave in the single-launch step: 16-bit caches, heavy hitter / head-constant policies");
+  constexpr bool ONE1 = ONE && NT == 1;  // the single-tile form: no loop tail, no rescale, per-slot state requested ahead of the tile
   static_assert(sizeof(T) == 2 && (RT == 1 || RT == 2 || RT == 4 || RT == 8), "16-bit caches, up to 8 query heads per pass (the MFMA has 16 columns)");
   static_assert(!ONE || NW == 4, "the single-launch step runs on 4-wave workgroups");
   constexpr int D = 128, VEC = 8, RPW = 4, U = 4;
@@ -680,13 +690,37 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
     }
   }
   unsigned one_tag = 0;
-  double one_num = 0.0;
-  int32_t one_den = 0, one_ps = 0, one_pin = 0;
+  double one_numv[NT];
+  int32_t one_denv[NT], one_psv[NT], one_pin = 0;
+  float one_rndv[NT];
+#pragma unroll
+  for (int ti = 0; ti < NT; ti++) {
+    one_numv[ti] = 0.0;
+    one_denv[ti] = 0;
+    one_psv[ti] = 0;
+    one_rndv[ti] = 0.f;
+  }
   constexpr int LPR = RT < 4 ? RT : 4;  // lanes per tile row in the per-slot pass; each computes KH = RT / LPR probabilities
   constexpr int KH = RT / LPR;
+  // this lane's slot in tile ti of the wave: one_slot + ti * (NW * RPW * U)
   const int one_slot = row_begin + wave * (RPW * U) + g * U + c / LPR;
-  const bool one_have = ONE && c < U * LPR && (c % LPR) == 0 && one_slot < row_end;
-  float one_rnd = 0.f;
+  const bool one_lane = ONE && c < U * LPR && (c % LPR) == 0;
+  const bool one_have = one_lane && one_slot < row_end;
+  // the history / position (/ uniform draw) of this lane's slot in every tile of the wave
+  auto load_slot_state = [&]() {
+#pragma unroll
+    for (int ti = 0; ti < NT; ti++) {
+      const int sl = one_slot + ti * (NW * RPW * U);
+      if (one_lane && sl < row_end) {
+        if (a.num) {
+          one_numv[ti] = a.num[(size_t)h * S + sl];
+          one_denv[ti] = a.denom[(size_t)h * S + sl];
+        }
+        one_psv[ti] = a.pos[(a.Hp == 1 ? 0 : (size_t)h * S) + sl];
+        if (a.policy == 3) one_rndv[ti] = a.rand_next[sl];
+      }
+    }
+  };
   float one_kn = 0.f;       // ONE + L2: the key norm of this lane's slot (model dtype) ...
   float l2_nv_lane = 0.f;   // ... and the inserted key's norm, in the lanes of the row group that inserted it
   // ONE + L2: the epoch words of the kv heads whose norm granules this thread will gather.  Read HERE: every workgroup has read
@@ -703,19 +737,20 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
   if constexpr (ONE) {
     one_tag = a.one_hdr[h] + 1u;
     one_pin = *a.input_pos;
-    // requested AHEAD of the K/V tile (measured: behind it the step is 0.3 us slower — the tile's in-order waits then end on
-    // these stragglers, and the workgroup leaves the streaming part later)
-    if (one_have) {
-      if (a.num) {
-        one_num = a.num[(size_t)h * S + one_slot];
-        one_den = a.denom[(size_t)h * S + one_slot];
-      }
-      one_ps = a.pos[(a.Hp == 1 ? 0 : (size_t)h * S) + one_slot];
-      if (a.policy == 3) one_rnd = a.rand_next[one_slot];
-      if constexpr (L2) one_kn = ElemTraits<T>::load(reinterpret_cast<const T*>(a.key_norm) + (size_t)h * S, one_slot);
+    // single tile: requested AHEAD of the K/V tile (measured: behind it the step is 0.3 us slower — the tile's in-order waits
+    // then end on these stragglers, and the workgroup leaves the streaming part later); several tiles: requested after the
+    // publish, in the shadow of the hand-off
+    if constexpr (NT == 1) {
+      load_slot_state();
+      if constexpr (L2)
+        if (one_have) one_kn = ElemTraits<T>::load(reinterpret_cast<const T*>(a.key_norm) + (size_t)h * S, one_slot);
     }
   }
-  float s_keep[U] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};  // ONE: the wave's (single) tile of scores, kept for the per-slot pass
+  float s_keep[NT][U];  // ONE: the wave's tiles of scores, kept for the per-slot pass
+#pragma unroll
+  for (int ti = 0; ti < NT; ti++)
+#pragma unroll
+    for (int t = 0; t < U; t++) s_keep[ti][t] = -INFINITY;
   // QB: the incoming token's rows are requested AHEAD of the tile (chunk c of K and of V per lane, every row group alike), so that
   // the inserting row group can quantise them while the tile is in flight — requested behind the tile, the in-order load counter
   // would hold the ~150 instructions of min / max shuffles and roundings back until the K/V rows have arrived, and the whole kv
@@ -819,7 +854,8 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
   }
   int qb_ins_u = -1;  // QB: tile row (of this lane's row group) that holds the inserted token — its K chunk is UNswizzled (chunk c)
 
-  auto tile = [&](TileRegs& R, const int tbase, const int tbase_next, const bool more_next) {
+  auto tile = [&](TileRegs& R, const int tbase, const int tbase_next, const bool more_next, auto ti_c) {
+    constexpr int TI = decltype(ti_c)::value;  // ONE: which of the wave's tiles (compile time: the scores stay in registers)
     const int row0 = tbase + g * U;
     // ONE: a wave owns exactly one tile (one_shape_ok: rows_per_split == one iteration's rows) — a compile-time fact, so that the
     // next tile's address arithmetic, its loads, the loop's second body and the running-maximum rescale disappear from the code
@@ -970,7 +1006,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
     }
     if constexpr (ONE) {
 #pragma unroll
-      for (int t = 0; t < U; t++) s_keep[t] = s[t];
+      for (int t = 0; t < U; t++) s_keep[TI][t] = s[t];
       if (a.trace && trB == 0) trB = __builtin_amdgcn_s_memtime();  // scores of the tile are in registers
     }
     if (!ONE && c < RT && !(a.abl & 1)) {
@@ -998,15 +1034,15 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
       mx = xor_combine<32, true>(xor_combine<16, true>(mx));
       const float m_new = fmaxf(m, mx);
       const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-      const float alpha = ONE ? 0.f : fast_exp(m - m_use);  // ONE: first and only tile — m = -inf, l = 0, acc = 0: nothing to rescale
+      const float alpha = ONE1 ? 0.f : fast_exp(m - m_use);  // single tile: m = -inf, l = 0, acc = 0 — nothing to rescale
       m = m_new;
-      if constexpr (!ONE) l *= alpha;
+      if constexpr (!ONE1) l *= alpha;
 #pragma unroll
       for (int t = 0; t < U; t++) {
         p[t] = fast_exp(s[t] - m_use);
         l += p[t];
       }
-      if constexpr (!ONE) {
+      if constexpr (!ONE1) {
         // every accumulator of this lane belongs to head c.  The running maximum settles after the first tiles: while no
         // head of the wave moved it, alpha is exactly 1 and the 32 multiplies — with the accumulators parked in AGPRs, 68 register
         // moves around them: a fifth of the loop's instructions — are skipped (x * 1 == x: bit-identical)
@@ -1041,13 +1077,29 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
       if (a.trace && trC == 0) trC = __builtin_amdgcn_s_memtime();  // P.V of the tile issued
     }
   };
-  while (more) {
-    const int base_next = base + NSUB * NW * RPW * U;
-    const bool more_next = ONE ? false : base_next < row_end;
+  if constexpr (ONE && NT > 1) {
+    // the wave's tiles, unrolled: tile TI keeps its scores in s_keep[TI] for the finish (at most NT tiles: one_shape_ok)
+    auto run_tiles = [&](auto self, auto ti_c) -> void {
+      constexpr int TI = decltype(ti_c)::value;
+      if constexpr (TI < NT) {
+        const int tb = base + TI * (NW * RPW * U);
+        if (tb < row_end) {
+          tile(tregs[0], tb, tb + NW * RPW * U, TI + 1 < NT && tb + NW * RPW * U < row_end, ti_c);
+          self(self, IntC<TI + 1>{});
+        }
+      }
+    };
+    if (more) run_tiles(run_tiles, IntC<0>{});
+  } else {
+    while (more) {
+      const int base_next = base + NSUB * NW * RPW * U;
+      const bool more_next = ONE ? false : base_next < row_end;
 #pragma unroll
-    for (int sub = 0; sub < NSUB; sub++) tile(tregs[sub], base + sub * NW * RPW * U, base_next + sub * NW * RPW * U, more_next);
-    base = base_next;
-    more = more_next;
+      for (int sub = 0; sub < NSUB; sub++)
+        tile(tregs[sub], base + sub * NW * RPW * U, base_next + sub * NW * RPW * U, more_next, IntC<0>{});
+      base = base_next;
+      more = more_next;
+    }
   }
   __shared__ float sm_l2w[NW];  // ONE + L2: per-wave maxima of the norms this workgroup's slots hold AFTER the step's insert
   if constexpr (L2 && ONE) {
@@ -1171,6 +1223,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
         __builtin_amdgcn_raw_buffer_store_b128(ng, ml_rsrc, nm_base + h * kOneNmHead + split * 16, 0, kOneAuxCoherent);
       }
     }
+    if constexpr (NT > 1) load_slot_state();  // several tiles per wave: the slots' history / positions arrive during the hand-off
     if (a.trace) tr2 = __builtin_amdgcn_s_memtime();
     // ---- what this thread gathers: the (m, l) granule of (head = wave, split = lane) and up to two O granules
     const int ppw = (RT * 64 + ns - 1) / ns;  // output pairs finished per workgroup (pair P = r * 64 + d / 2)
@@ -1296,12 +1349,16 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
     // ---- this workgroup's slots.  ref: attention_utils.py:52 softmax -> model dtype; model.py:416-418 group mean -> model
     //      dtype; cache.py:716-722 history; cache.py:727-749 the next position's eviction score
     unsigned long long my_key = ~0ull;
-    {
+    auto slot_pass = [&](auto ti_c) {
+      constexpr int TI = decltype(ti_c)::value;
+      const int slot_ti = one_slot + TI * (NW * RPW * U);
+      const bool have_ti = one_lane && slot_ti < row_end;
+      unsigned long long key_ti = ~0ull;
       float av = 0.f;
       if (a.num) {  // heavy hitter: the group-mean probability of this lane's row (the head-constant policies keep no history)
         // lane c of a row group computes the probabilities of row t = c / LPR for heads (c % LPR) * KH + [0, KH) — one exp and one
         // IEEE divide per (row, head), spread over the 16 lanes; the score of (row t, head r) sits in lane r of the group as
-        // s_keep[t].  The group mean adds the heads in order r = 0 .. RT - 1, like the combine pass.
+        // s_keep[TI][t].  The group mean adds the heads in order r = 0 .. RT - 1, like the combine pass.
         const int t_me = c / LPR, j_me = c % LPR;
         float pr[KH];
 #pragma unroll
@@ -1309,17 +1366,17 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
           const int r_me = j_me * KH + kk;
           float x;
           if constexpr (RT == 4) {
-            // lane c = 4t + r of the 16-lane row takes s_keep[t] of lane r: row shifts by 4t (DPP, no LDS crossbar round trips)
-            const float x1 = dpp_mov<0x114>(s_keep[1]);  // row_shr:4
-            const float x2 = dpp_mov<0x118>(s_keep[2]);  // row_shr:8
-            const float x3 = dpp_mov<0x11C>(s_keep[3]);  // row_shr:12
-            x = t_me == 0 ? s_keep[0] : (t_me == 1 ? x1 : (t_me == 2 ? x2 : x3));
+            // lane c = 4t + r of the 16-lane row takes s_keep[TI][t] of lane r: row shifts by 4t (DPP, no LDS crossbar round trips)
+            const float x1 = dpp_mov<0x114>(s_keep[TI][1]);  // row_shr:4
+            const float x2 = dpp_mov<0x118>(s_keep[TI][2]);  // row_shr:8
+            const float x3 = dpp_mov<0x11C>(s_keep[TI][3]);  // row_shr:12
+            x = t_me == 0 ? s_keep[TI][0] : (t_me == 1 ? x1 : (t_me == 2 ? x2 : x3));
           } else {
             const int src = (lane & ~15) | r_me;
             x = -INFINITY;
 #pragma unroll
             for (int t = 0; t < U; t++) {
-              const float v = __shfl(s_keep[t], src, CC_WAVE);
+              const float v = __shfl(s_keep[TI][t], src, CC_WAVE);
               x = (t == t_me) ? v : x;
             }
           }
@@ -1343,18 +1400,18 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
         }
         av = ElemTraits<T>::rnd(sum * (1.0f / (float)RT));  // RT is a power of two: bit-identical to the IEEE divide of the combine pass
       }
-      if (one_have) {
-        const size_t i = (size_t)h * S + one_slot;
-        int32_t ps = one_ps;
-        double num_old = one_num;
-        int32_t den_old = one_den;
-        if (one_slot == ins_idx) {  // refilled by this launch's insert: position p, history from zero (cache.py:754-763)
+      if (have_ti) {
+        const size_t i = (size_t)h * S + slot_ti;
+        int32_t ps = one_psv[TI];
+        double num_old = one_numv[TI];
+        int32_t den_old = one_denv[TI];
+        if (slot_ti == ins_idx) {  // refilled by this launch's insert: position p, history from zero (cache.py:754-763)
           ps = one_pin;
           num_old = 0.0;
           den_old = 0;
         }
         const int32_t p_next = one_pin + 1;
-        const uint32_t low = ((uint32_t)one_slot << 1) | (uint32_t)(ps == -1);
+        const uint32_t low = ((uint32_t)slot_ti << 1) | (uint32_t)(ps == -1);
         if constexpr (L2) {  // ref: cache.py:597-605: dtype(max over ALL heads and slots - norm), recent window -> +inf, base rules
           float gm = -INFINITY;
           bool gn = false;
@@ -1364,12 +1421,12 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
             gn |= (v != v);
             gm = fmaxf(gm, v);
           }
-          const float kn_eff = (one_slot == ins_idx) ? l2_nv_lane : one_kn;
+          const float kn_eff = (slot_ti == ins_idx) ? l2_nv_lane : one_kn;
           float scn = ElemTraits<T>::rnd((gn ? NAN : gm) - kn_eff);
           if (ps >= p_next - a.w) scn = INFINITY;
-          if (one_slot < a.g) scn = INFINITY;
+          if (slot_ti < a.g) scn = INFINITY;
           if (ps == -1) scn = -INFINITY;
-          my_key = make_key(orderable_f32(scn), low);
+          key_ti = make_key(orderable_f32(scn), low);
         } else if (a.num) {
           if (a.attn_out) ElemTraits<T>::store(reinterpret_cast<T*>(a.attn_out), i, av);
           const double num_new = num_old + (double)av;
@@ -1379,19 +1436,33 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
           float scn = __fdiv_rn((float)num_new, (float)(den_new < 1 ? 1 : den_new));
           if (ps < a.g || ps >= p_next - a.w) scn = 1.0f;
           if (ps == -1) scn = 0.0f;
-          my_key = make_key(orderable_f32(scn), low);
+          key_ti = make_key(orderable_f32(scn), low);
         } else if (h == 0) {  // head-constant policies: one key row, scored by the workgroups of kv head 0
           if (a.policy == 2) {  // ref: cache.py:500-502, 552-556 — arg-min of pos behind the sinks; -1 = empty first
-            if (one_slot >= a.g) my_key = make_key(orderable_i32(ps), low);
+            if (slot_ti >= a.g) key_ti = make_key(orderable_i32(ps), low);
           } else {  // random, ref: cache.py:523 recent window -> +inf, then the base rules :373-376
-            float scn = one_rnd;
+            float scn = one_rndv[TI];
             if (ps >= p_next - a.w) scn = INFINITY;
-            if (one_slot < a.g) scn = INFINITY;
+            if (slot_ti < a.g) scn = INFINITY;
             if (ps == -1) scn = -INFINITY;
-            my_key = make_key(orderable_f32(scn), low);
+            key_ti = make_key(orderable_f32(scn), low);
           }
         }
       }
+      my_key = key_ti < my_key ? key_ti : my_key;
+    };
+    {
+      // every tile of the wave (compile-time unrolled; tiles past the split's end hold no slot)
+      auto all_tiles = [&](auto self, auto ti_c) -> void {
+        constexpr int TI = decltype(ti_c)::value;
+        if constexpr (TI < NT) {
+          if (row_begin + wave * (RPW * U) + TI * (NW * RPW * U) < row_end) {  // wave-uniform: the wave has a tile TI
+            slot_pass(ti_c);
+            self(self, IntC<TI + 1>{});
+          }
+        }
+      };
+      all_tiles(all_tiles, IntC<0>{});
     }
     {
       // one key per WAVE (a head's key row has room for NW per 64-slot workgroup): nothing crosses the waves after the one
@@ -1402,7 +1473,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
         unsigned long long* nk_row = const_cast<unsigned long long*>(a.next_key) + (a.Hp == 1 ? 0 : (size_t)h * a.nk);
         const int e0 = split * NW + wave;
         nk_row[e0] = wk;  // every key of this row was consumed before its readers published: no reader is left
-        for (int s2 = e0 + ns * NW; s2 < a.nk; s2 += ns * NW) nk_row[s2] = ~0ull;
+        for (int s2 = e0 + ns * NW; s2 < a.nk_read; s2 += ns * NW) nk_row[s2] = ~0ull;  // entries beyond nk_read are never read
       }
     }
     if (a.trace) trE = __builtin_amdgcn_s_memtime();
@@ -1989,11 +2060,17 @@ namespace {
 constexpr size_t kOneHdrBytes = 4096, kOneMlCap = (size_t)kOneMaxHeads * (kOneMlHead + kOneNmHead), kOneOCap = (size_t)kOneMaxHeads * kOneOHead;
 constexpr size_t kOneBytes = kOneHdrBytes + kOneMlCap + kOneOCap;
 constexpr int kOneStatusWord = 1023;  // hdr[0 .. H): epochs; hdr[1023]: timeout word
-static bool one_shape_ok(const Plan& p, int HQ, int H, int D, int dtype) {
-  const int R = HQ / H;
-  return cc_dt_size(dtype) == 2 && D == 128 && R == p.rt && p.rows_per_split == rows_per_iter(D, dtype) && p.n_split <= 64 &&
-         H <= kOneMaxHeads && p.rt <= 8;
+constexpr int kOneMaxTiles = 8;  // tiles per wave the single-launch step keeps scores for (NT = 4 or 8 instantiations)
+// tiles per wave of the single-launch step for this shape: 1 = the specialised single-tile form, 2 .. 8 = the multi-tile form
+// (16-bit caches, 4 or 8 query heads per kv head), 0 = not eligible
+static int one_tiles(const Plan& p, int HQ, int H, int D, int dtype) {
+  const int R = HQ / H, rpi = rows_per_iter(D, dtype);
+  if (cc_dt_size(dtype) != 2 || D != 128 || R != p.rt || p.n_split > 64 || H > kOneMaxHeads || p.rt > 8 || p.rows_per_split % rpi) return 0;
+  const int nt = p.rows_per_split / rpi;
+  if (nt == 1) return 1;
+  return (nt <= kOneMaxTiles && (p.rt == 4 || p.rt == 8)) ? nt : 0;
 }
+static bool one_shape_ok(const Plan& p, int HQ, int H, int D, int dtype) { return one_tiles(p, HQ, H, D, dtype) > 0; }
 static size_t base_workspace_bytes(const Plan& p, int HQ, int H, int S, int D, int dtype) {
   return align256((size_t)HQ * S * cc_dt_size(dtype)) + align256((size_t)HQ * p.n_split * 2 * sizeof(float)) +
          align256((size_t)HQ * p.n_split * D * sizeof(float)) + 256 +  // + the ring column word of the fused W > 1 history
@@ -2015,7 +2092,11 @@ static int one_capacity(KernelT kernel) {
   return cap;
 }
 template <typename T>
-static int one_capacity_rt(int rt, int qb = 0) {  // qb: 0 = 16-bit cache, 8 = fused quantised cache, -1 = the l2 policy's instantiation
+static int one_capacity_rt(int rt, int qb = 0) {  // qb: 0 = 16-bit cache, 8 = fused quantised cache, -1 = the l2 policy's instantiation, 104 / 108 = NT tiles
+  if (qb == 104) return rt == 8 ? one_capacity(decode_attn_split_mfma_kernel<T, 8, kNW, false, true, false, 0, 1, 4>)
+                                : one_capacity(decode_attn_split_mfma_kernel<T, 4, kNW, false, true, false, 0, 1, 4>);
+  if (qb == 108) return rt == 8 ? one_capacity(decode_attn_split_mfma_kernel<T, 8, kNW, false, true, false, 0, 1, 8>)
+                                : one_capacity(decode_attn_split_mfma_kernel<T, 4, kNW, false, true, false, 0, 1, 8>);
   if (qb < 0) {
     switch (rt) {
       case 8: return one_capacity(decode_attn_split_mfma_kernel<T, 8, kNW, true, true>);
@@ -2041,6 +2122,19 @@ static int one_capacity_rt(int rt, int qb = 0) {  // qb: 0 = 16-bit cache, 8 = f
 template <typename T>
 static int launch_one(const SplitArgs& a, const Plan& p, int H, hipStream_t st) {
   dim3 grid(p.n_split, H, 1), block(kNW * 64);
+  const int nt = p.rows_per_split / rows_per_iter(128, ElemTraits<T>::code);
+  if (nt > 1) {  // several tiles per wave (long caches): 16-bit caches, heavy hitter / head-constant policies, RT 4 or 8
+    if (a.qparams != nullptr || a.key_norm != nullptr || (p.rt != 4 && p.rt != 8) || nt > kOneMaxTiles) return CC_ERR_UNSUPPORTED;
+    if (nt <= 4) {
+      if (p.rt == 8) hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 8, kNW, false, true, false, 0, 1, 4>), grid, block, 0, st, a);
+      else hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 4, kNW, false, true, false, 0, 1, 4>), grid, block, 0, st, a);
+    } else {
+      if (p.rt == 8) hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 8, kNW, false, true, false, 0, 1, 8>), grid, block, 0, st, a);
+      else hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 4, kNW, false, true, false, 0, 1, 8>), grid, block, 0, st, a);
+    }
+    CC_LAUNCH_CHECK();
+    return CC_OK;
+  }
   if (a.qparams != nullptr) {
     switch (p.rt) {
       case 8: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 8, kNW, false, true, false, 8>), grid, block, 0, st, a); break;
@@ -2082,7 +2176,12 @@ size_t cc_decode_attn_workspace_bytes(int32_t HQ, int32_t H, int32_t S, int32_t 
 static int32_t one_available(int32_t HQ, int32_t H, int32_t S, int32_t D, int32_t dtype, int qb) {
   if (HQ <= 0 || H <= 0 || HQ % H || S <= 0 || D <= 0 || !cc_dt_ok(dtype)) return 0;
   const Plan p = make_plan(HQ, H, S, D, dtype);
-  if (!one_shape_ok(p, HQ, H, D, dtype)) return 0;
+  const int nt = one_tiles(p, HQ, H, D, dtype);
+  if (nt == 0) return 0;
+  if (nt > 1) {  // the multi-tile form serves the plain 16-bit policies only
+    if (qb != 0) return 0;
+    qb = nt <= 4 ? 104 : 108;
+  }
   // l2: every thread gathers at most three workgroups' norm maxima
   if (qb < 0 && H * p.n_split > 3 * kNW * 64) return 0;
   const int cap = dtype == CC_DT_BF16 ? one_capacity_rt<bf16_t>(p.rt, qb) : one_capacity_rt<f16_t>(p.rt, qb);
@@ -2186,7 +2285,9 @@ static int attn_impl(const void* q, const void* k, const void* v, const uint8_t*
   }
   if (fs) {
     sa.next_key = fs->next_key; sa.nk = cc_next_key_slots(S);
-    sa.nk_read = one_shape_ok(p, HQ, H, D, dtype) ? sa.nk : p.n_chunks; sa.input_pos = fs->input_pos; sa.k_new = fs->k_new; sa.v_new = fs->v_new;
+    // entries any writer may have left non-~0: one per combine block (two-launch step), one per wave of the single-launch workgroups
+    sa.nk_read = one_shape_ok(p, HQ, H, D, dtype) ? (p.n_split * kNW > p.n_chunks ? p.n_split * kNW : p.n_chunks) : p.n_chunks;
+    if (sa.nk_read > sa.nk) sa.nk_read = sa.nk; sa.input_pos = fs->input_pos; sa.k_new = fs->k_new; sa.v_new = fs->v_new;
     sa.pos = fs->c->pos; sa.mask_w = fs->c->mask; sa.cache_cts = fs->c->cache_cts; sa.num = hh_num; sa.denom = hh_denom;
     sa.H = H; sa.Hc = fs->c->Hc; sa.Hp = fs->c->Hp;
   }

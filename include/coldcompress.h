@@ -239,12 +239,14 @@ int cc_decode_step_heavy_hitter_ring(const cc_kv_view* c, const void* q, const v
  * Single-launch layer step.  cc_decode_step_heavy_hitter runs the whole step — insert, K/V streaming pass, softmax
  * normalisation, group mean, history update (cache.py:716-722), the arg-min for position *input_pos + 1 (cache.py:725-749)
  * and y — in ONE launch whenever cc_decode_step_single_launch(...) returns 1: 16-bit caches, head_dim 128, HQ / H in
- * {1, 2, 4}, at most 64 slots per workgroup tile and 64 tiles per kv head (S <= 4096), and the n_split * H workgroups all
+ * {1, 2, 4, 8}, at most 64 workgroups per kv head (the launch plan's split count: n_split <= 64), each with one 64-slot tile per
+ * workgroup (S <= 4096) or — HQ / H in {4, 8}, heavy hitter / recent_global / full / random — up to eight of them (S <= 32768
+ * where the plan keeps 64 splits, i.e. 8 kv heads and more per rank), at most 32 kv heads, and the n_split * H workgroups all
  * resident on the device at once.  Every workgroup publishes its partial (m, l, O) through the workspace as
  * self-validating tagged granules (write-through stores), waits — bounded — for the other workgroups of its kv head,
  * and finishes its own 64 slots from the scores still in its registers.  pos, mask, cache_cts, K/V, num, denom, counter,
  * attn_out and the next keys are bit-identical to the two-launch step; y agrees up to fp32 summation order.
- * Workspace contract for this mode: the first 4 KiB + 128 KiB + 8 MiB of every decode workspace (sized in by
+ * Workspace contract for this mode: the first 4 KiB + 288 KiB + 16 MiB of every decode workspace (sized in by
  * cc_decode_attn_workspace_bytes, at fixed offsets whatever the shape, so that caches of different lengths may share one
  * workspace) hold per-head epoch words and the granules; they must be ZERO before first use and written by nobody
  * else; a launch that could not complete its hand-off (a device that did not keep the grid resident) sets the 32-bit

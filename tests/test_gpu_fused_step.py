@@ -55,7 +55,10 @@ def _seed(kv, gen, T):
 @pytest.mark.parametrize("dtype,H,HQ,S,D,T", [(torch.bfloat16, 8, 32, 4096, 128, 4090), (torch.float32, 2, 4, 333, 16, 300),
                                               (torch.bfloat16, 1, 8, 3488, 128, 3488), (torch.float16, 4, 8, 1000, 64, 1000),
                                               (torch.bfloat16, 3, 12, 1001, 128, 990), (torch.float16, 2, 2, 67, 128, 60),
-                                              (torch.bfloat16, 5, 10, 8200, 128, 8200)])
+                                              (torch.bfloat16, 5, 10, 8200, 128, 8200),
+                                              # caches beyond 64 x 64 slots per head: several tiles per wave in the single launch
+                                              (torch.bfloat16, 8, 32, 8192, 128, 8190), (torch.float16, 4, 16, 5000, 128, 4990),
+                                              (torch.bfloat16, 2, 16, 18432, 128, 18400), (torch.bfloat16, 1, 8, 32768, 128, 32768)])
 @pytest.mark.parametrize("single", [False, True])
 def test_fused_step_equals_three_calls(dtype, H, HQ, S, D, T, single):
     """`single`: decode_step may run as ONE launch where the shape allows it (include/coldcompress.h); every buffer must
@@ -94,7 +97,7 @@ def test_fused_step_equals_three_calls(dtype, H, HQ, S, D, T, single):
 
 @pytest.mark.parametrize("dtype,H,HQ,S,D,T,steps", [(torch.bfloat16, 8, 32, 4096, 128, 4000, 400), (torch.bfloat16, 8, 32, 2560, 128, 2560, 150),
                                                     (torch.float16, 3, 6, 1001, 128, 900, 150), (torch.bfloat16, 2, 2, 130, 128, 100, 60),
-                                                    (torch.bfloat16, 16, 64, 2048, 128, 2048, 100)])
+                                                    (torch.bfloat16, 16, 64, 2048, 128, 2048, 100), (torch.bfloat16, 8, 32, 18432, 128, 18432, 60)])
 def test_single_launch_equals_two_launch_long(dtype, H, HQ, S, D, T, steps):
     """The single-launch layer step against the two-launch step over hundreds of steps on twin caches, interleaved with an
     unrelated bandwidth-heavy kernel so the workgroups of a launch do not arrive evenly: history (float64), denominators,
@@ -216,7 +219,8 @@ def test_fused_step_vs_oracle_pipeline(oracle):
 
 
 @pytest.mark.parametrize("strategy,dtype,H,HQ,S,D,T", [("recent_global", torch.bfloat16, 8, 32, 4096, 128, 4090), ("recent_global", torch.float32, 2, 4, 77, 16, 77),
-                                                       ("full", torch.bfloat16, 4, 16, 600, 128, 500), ("recent_global", torch.float16, 1, 8, 3488, 128, 3488)])
+                                                       ("full", torch.bfloat16, 4, 16, 600, 128, 500), ("recent_global", torch.float16, 1, 8, 3488, 128, 3488),
+                                                       ("recent_global", torch.bfloat16, 8, 32, 8192, 128, 8100), ("full", torch.bfloat16, 2, 8, 20000, 128, 19990)])
 @pytest.mark.parametrize("single", [False, True])
 def test_ring_fused_step_equals_three_calls(strategy, dtype, H, HQ, S, D, T, single, single_launch_switch):
     """Head-constant ring policies (recent_global, full): the fused step (cc_decode_step_recent_global; `single`: as ONE
