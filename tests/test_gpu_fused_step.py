@@ -559,3 +559,17 @@ def test_hand_off_timeout_is_reported_loudly():
     finally:
         ws[off:off + 4].view(torch.int32).fill_(0)
     assert single_launch_status() == 0
+
+
+def test_fused_step_differential_fuzz():
+    """tools/fuzz_step.py on a fixed seed: ~110 random (policy, dtype, heads, length, fill level, sinks, window, cache_bits)
+    cases, every one on the same workspace — the fused step (single launch where the shape allows) vs the three-call path, the
+    history rings, and the fused quantised cache vs the 16-bit step on its dequantised values."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_step.py"), "--n", "120", "--seed", "3"], cwd=root,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "0 mismatches, single-launch hand-off timeouts: 0" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
