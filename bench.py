@@ -82,6 +82,35 @@ def cache_kwargs(args):
                 attn_thresholding=False, min_recovery_frac=0.9)
 
 
+def device_state():
+    """Clocks / power cap / performance level of device 0 as rocm-smi reports them right after the timed region (SURVEY 8(d):
+    state clocks and power cap).  Best effort: {} when rocm-smi is not there."""
+    import shutil
+    import subprocess
+
+    smi = shutil.which("rocm-smi") or ("/opt/rocm/bin/rocm-smi" if os.path.exists("/opt/rocm/bin/rocm-smi") else None)
+    if smi is None:
+        return {}
+    out = {}
+    try:
+        for flags in (["--showclocks", "--showmaxpower", "--showpower"], ["--showperflevel"]):
+            r = subprocess.run([smi, "-d", "0", *flags, "--json"], capture_output=True, text=True, timeout=20)
+            card = next(iter(json.loads(r.stdout).values()))
+            for k, v in card.items():
+                k2 = k.strip().rstrip(":").lower()
+                if "clock speed" in k2:
+                    out[k2.split()[0] + "_mhz"] = int("".join(ch for ch in str(v) if ch.isdigit()) or 0)
+                elif k2.startswith("max graphics package power"):
+                    out["power_cap_w"] = float(v)
+                elif k2.startswith("current socket graphics package power"):
+                    out["power_w"] = float(v)
+                elif k2 == "performance level":
+                    out["perf_level"] = str(v)
+    except Exception as e:  # pragma: no cover
+        out["error"] = f"{type(e).__name__}: {e}"[:120]
+    return out
+
+
 def pmc_child():
     """What the PMC passes run under rocprofv3: 64 single-launch heavy-hitter layer steps at the benchmark's shape over eight
     rotating caches (no model around them: the counters are read per kernel).  Prints nothing the parent parses."""
@@ -597,6 +626,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        dev_state = device_state() if rank == 0 else {}
         if world > 1:
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -626,7 +656,7 @@ def main():
                                    f"{args.prompt_len}-token random prompt -> decode, batch 1, greedy",
                        "parallelism": f"tp{world}", "rccl_ranks": (dist.get_world_size() if world > 1 else 1),
                        "collective_backend": ("none" if world == 1 else dist.get_backend()), "decode_mode": mode, "n_layer": args.n_layer,
-                       "prefill_seconds": round(prefill_s, 2)},
+                       "prefill_seconds": round(prefill_s, 2), "device_state_after_timed_region": dev_state},
             "roofline": roof, "cpu_baseline": cpu,
         }
         if step_us is not None and roof is not None:
