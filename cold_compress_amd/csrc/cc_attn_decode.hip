@@ -838,6 +838,9 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
   int hy_flags = 0, hy_cts = 0, hy_budget = 0;
   bool hy_punc = false;
   if constexpr (HYB) {
+    // (a scheduling barrier: the dependent scalar loads below each end in an s_waitcnt — interleaved with the tile's loads they
+    //  stalled the wave twice with half of the tile not yet requested)
+    __builtin_amdgcn_sched_barrier(0);
     const int pol = (int)a.hyb.strategies[h];
     hy_flags = a.hyb.table[pol * 3];
     const int win = a.hyb.table[pol * 3 + 1], hhs = a.hyb.table[pol * 3 + 2];
@@ -2077,18 +2080,26 @@ static size_t base_workspace_bytes(const Plan& p, int HQ, int H, int S, int D, i
          align256(((size_t)H * p.n_split * kNW + H) * sizeof(float));   // + the l2 policy's partial maxima and new norms
 }
 // workgroups of the single-launch kernel the device keeps resident at once (0: unknown -> never use it)
-template <typename KernelT>
-static int one_capacity(KernelT kernel) {
-  static int cap = -1;  // per instantiation
-  if (cap < 0) {
-    int dev = 0, cus = 0, nb = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, kNW * 64, 0) != hipSuccess) {
-      (void)hipGetLastError();
-      return 0;
-    }
-    cap = cus * (nb > 8 ? 8 : nb);
+// The answer is cached PER KERNEL: every instantiation has the same function type, so a cache keyed by the argument's type
+// (a `static` inside a template over the type) would be ONE cache for all of them — the first kernel asked would answer for
+// the fused-quant and multi-tile instantiations too, which keep fewer workgroups resident.
+static int one_capacity(void (*kernel)(SplitArgs)) {
+  struct Entry {
+    void (*k)(SplitArgs);
+    int cap;
+  };
+  static Entry cache[64];
+  static int n_cached = 0;
+  for (int i = 0; i < n_cached; i++)
+    if (cache[i].k == kernel) return cache[i].cap;
+  int dev = 0, cus = 0, nb = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, kNW * 64, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
   }
+  const int cap = cus * (nb > 8 ? 8 : nb);
+  if (n_cached < 64) cache[n_cached++] = Entry{kernel, cap};
   return cap;
 }
 template <typename T>
