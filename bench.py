@@ -539,6 +539,7 @@ def main():
                          "(one process per GPU; ranks never share a device)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    oneshot = False
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if dry:
@@ -546,6 +547,12 @@ def main():
             _stage_collectives_through_host()
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if os.environ.get("CC_ONESHOT_ALLREDUCE", "1") != "0":
+            # the decode-size all-reduces (2 per layer, 8 KiB) over the one-shot xGMI transport once it has verified itself
+            # against RCCL on this node (all ranks or none); RCCL stays the transport of everything else
+            from cold_compress_amd import tp as _tp
+
+            oneshot = _tp.enable_oneshot_allreduce() is not None
         assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
 
     from cold_compress_amd import _abi
@@ -655,7 +662,10 @@ def main():
                                    f"cache_strategy=heavy_hitter, max_cache_length={kv0.max_cache_length}, "
                                    f"{args.prompt_len}-token random prompt -> decode, batch 1, greedy",
                        "parallelism": f"tp{world}", "rccl_ranks": (dist.get_world_size() if world > 1 else 1),
-                       "collective_backend": ("none" if world == 1 else dist.get_backend()), "decode_mode": mode, "n_layer": args.n_layer,
+                       "collective_backend": ("none" if world == 1 else dist.get_backend()),
+                       "decode_allreduce": ("none" if world == 1 else ("one-shot xGMI (cc_allreduce_sum), verified against RCCL at start-up"
+                                                                       if oneshot else dist.get_backend())),
+                       "decode_mode": mode, "n_layer": args.n_layer,
                        "prefill_seconds": round(prefill_s, 2), "device_state_after_timed_region": dev_state},
             "roofline": roof, "cpu_baseline": cpu,
         }

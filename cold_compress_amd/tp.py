@@ -41,7 +41,9 @@ def maybe_init_dist() -> Optional[int]:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend=backend, rank=int(os.environ.get("RANK", rank)),
                                 world_size=int(os.environ.get("WORLD_SIZE", world)))
-    if os.environ.get("CC_ONESHOT_ALLREDUCE") == "1" and torch.cuda.is_available():
+    # decode-size all-reduces over the one-shot xGMI transport once it has verified itself against RCCL on this
+    # node; CC_ONESHOT_ALLREDUCE=0 keeps RCCL for everything
+    if torch.cuda.is_available() and os.environ.get("CC_ONESHOT_ALLREDUCE", "1") != "0":
         enable_oneshot_allreduce()
     return rank
 
@@ -121,7 +123,7 @@ class OneShotAllReduce:
         return int(self._abi.lib()["cc_allreduce_status"](self._comm))
 
     def close(self):
-        if self._comm is not None:
+        if getattr(self, "_comm", None) is not None:
             self._abi.lib()["cc_allreduce_destroy"](self._comm)
             self._comm = None
 
@@ -129,12 +131,49 @@ class OneShotAllReduce:
 _ONESHOT = None
 
 
-def enable_oneshot_allreduce(max_bytes=64 * 1024):
+def enable_oneshot_allreduce(max_bytes=64 * 1024, verify=True):
     """Route the two per-layer all-reduces of apply_tp through `OneShotAllReduce` when the message fits (decode), RCCL
-    otherwise.  Opt-in (also CC_ONESHOT_ALLREDUCE=1 at maybe_init_dist time): RCCL is the default transport."""
+    otherwise.  With `verify` (default) the transport first proves itself on this node: three all-reduces of a random vector
+    (both slot sets) must match RCCL's result and leave the status word clear, ON EVERY RANK (the verdicts are combined with
+    a MIN all-reduce over RCCL, so either all ranks switch or none does); any failure — IPC handles that cannot be opened,
+    a timed-out flag wait, a wrong sum — leaves RCCL in place and returns None."""
     global _ONESHOT
-    if _ONESHOT is None:
-        _ONESHOT = OneShotAllReduce(max_bytes)
+    if _ONESHOT is not None:
+        return _ONESHOT
+    dev = torch.device("cuda", torch.cuda.current_device())
+    ok, comm, why = 1, None, ""
+    try:
+        comm = OneShotAllReduce(max_bytes)
+    except Exception as e:  # creation / handle exchange failed on this rank
+        ok, why = 0, f"{type(e).__name__}: {e}"
+    if verify:
+        # every rank takes part in the same collectives whatever its own verdict: no rank may wait alone
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            g = torch.Generator(device=dev).manual_seed(4321 + dist.get_rank())
+            for it in range(3):
+                x = torch.randn(4096, device=dev, generator=g).to(torch.bfloat16)
+                ref = x.clone()
+                dist.all_reduce(ref, op=dist.ReduceOp.SUM)
+                got = x.clone()
+                try:
+                    comm.all_reduce(got)
+                    torch.cuda.synchronize()
+                    good = comm.status() == 0 and bool(torch.allclose(got.float(), ref.float(), rtol=2.0 ** -6, atol=2.0 ** -6))
+                except Exception as e:
+                    good, why = False, f"{type(e).__name__}: {e}"
+                if not good:
+                    ok, why = 0, why or f"self-test {it}: status {comm.status()} or sums differ from RCCL's"
+                    break
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok = int(flag.item())
+    if not ok:
+        if why:
+            print(f"[cold_compress_amd.tp] one-shot all-reduce not enabled on rank {dist.get_rank()}: {why}", flush=True)
+        return None
+    _ONESHOT = comm
     return _ONESHOT
 
 

@@ -45,6 +45,13 @@ def test_tp2_one_gpu_staged_collectives_matches_unsharded():
     assert "backend gloo world 2" in out
 
 
+def test_tp2_one_gpu_oneshot_allreduce_in_hipgraph():
+    """The sharded decode step with its two all-reduces per layer on the one-shot transport (self-test against the staged
+    collectives first), replayed from a hipGraph: tokens equal the unsharded model's, layer-0 evictions identical."""
+    out = _launch(["--backend", "gloo", "--oneshot", "--graph"])
+    assert "oneshot True" in out and "graph True" in out
+
+
 def test_oneshot_allreduce_two_ranks_on_one_gpu():
     """cc_allreduce_* with two ranks sharing cuda:0: IPC-mapped peer buffers, remote stores, flags, epochs, the two alternating
     slot sets and hipGraph replays run for real, against the rank-ordered fp32 sum computed on the host (bit-exact)."""

@@ -5,7 +5,9 @@ model on the same weights: tokens equal, layer-0 evictions identical.
   --backend nccl  : one GPU per rank, RCCL all-reduces over xGMI (what tp.py:41-56, 124-176 does with NCCL); with --graph
                     the sharded decode step, collectives included, is replayed from a hipGraph
   --backend gloo  : every rank drives cuda:0 and the collectives are staged over the host — no RCCL, but every kernel of
-                    the sharded decode path runs for real (what a 1-GPU box can check)
+                    the sharded decode path runs for real (what a 1-GPU box can check); with --oneshot the decode-size
+                    all-reduces go through cc_allreduce_sum (IPC-mapped buffers of the two ranks on the one GPU) and --graph
+                    replays the sharded decode step, those collectives included, from a hipGraph
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29541 \
         tools/tp2_check.py [--backend nccl --graph]"""
 import argparse
@@ -25,6 +27,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--backend", choices=["gloo", "nccl"], default="gloo")
     ap.add_argument("--graph", action="store_true", help="replay the sharded decode step from a hipGraph (collectives captured)")
+    ap.add_argument("--oneshot", action="store_true", help="decode-size all-reduces over the one-shot transport (cc_allreduce_sum), after its self-test")
     args = ap.parse_args()
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -49,6 +52,8 @@ def main():
             return orig(t, op=op, **kw)
 
         dist.all_reduce = staged
+    if args.oneshot:
+        assert tp.enable_oneshot_allreduce() is not None, "the one-shot all-reduce did not pass its self-test"
     cfg = dict(CONFIGS["Meta-Llama-3.1-8B-Instruct"])
     cfg["n_layer"] = 2
     cfg["block_size"] = 1024
@@ -106,7 +111,7 @@ def main():
     # rounded differently by the all-reduce, and heavy-hitter scores of random data sit in near-ties
     ok = ok and agree[0] == 1.0 and same_tokens >= len(outs[0][0]) - 1
     if rank == 0:
-        print(f"backend {dist.get_backend()} world {world} graph {bool(args.graph)}: tokens equal: {same_tokens}/{len(outs[0][0])}; "
+        print(f"backend {dist.get_backend()} world {world} graph {bool(args.graph)} oneshot {bool(args.oneshot)}: tokens equal: {same_tokens}/{len(outs[0][0])}; "
               f"TP{world} CHECK {'OK' if ok else 'FAIL'}", flush=True)
     dist.destroy_process_group()
     sys.exit(0 if ok else 1)
