@@ -113,6 +113,46 @@ def test_l2_replay_vs_reference(cc, name):
     assert torch.allclose(kv.key_norm.cpu().float(), f["final_keynorm"].float(), **tol)
 
 
+@pytest.mark.parametrize("name", ["f3_l2_h1_bf16.npz", "f3_l2_long_bf16.npz"])
+@pytest.mark.parametrize("single", [False, True])
+def test_l2_replay_vs_reference_through_the_fused_step(cc, name, single):
+    """The reference's own l2 traces at head_dim 128 (120 / 300 steps) replayed through decode_step — two launches, and the
+    single launch in which every workgroup gathers every workgroup's norm maximum: the slot every step writes is the slot the
+    reference evicted, and the final positions, masks, counts, K, V and norms are the reference's.  (The queries are ours: the
+    l2 policy does not look at attention.)"""
+    from cold_compress_amd import _abi
+
+    f = load_golden(name)
+    dtype = DT_FROM_NAME[f["dtype"]]
+    H, S, D, T, g, w = f["H"], f["S"], f["D"], f["T_prefill"], f["g"], f["w"]
+    assert D == 128
+    _abi.lib()["cc_decode_step_set_single_launch"](1 if single else 0)
+    try:
+        kv = _make(cc, "l2", dtype, H, S, D, g, w)
+        pos0 = torch.arange(T, device=DEV)
+        kv.update_kv(pos0, f["k0"].to(DEV), f["v0"].to(DEV), True)
+        kv.update_state(pos0, f["k0"].to(DEV), f["v0"].to(DEV), True, None)
+        kv.key_norm.copy_(f["keynorm_after_prefill"].to(DEV))  # vector_norm's summation order is unspecified: start from the reference's norms
+        gen = torch.Generator().manual_seed(2)
+        for t in range(f["steps"]):
+            p = torch.tensor([T + t], dtype=torch.int32, device=DEV)
+            q = torch.randn(1, 4 * H, 1, D, generator=gen).to(dtype).to(DEV)
+            kv.decode_step(q, f["k_new"][t].to(DEV), f["v_new"][t].to(DEV), p)
+            if t % 10 == 0 or t == f["steps"] - 1:
+                pos = kv.pos.cpu()[0]
+                for h in range(H):
+                    assert int(pos[h, int(f["idx"][t][h])]) == T + t, f"step {t} head {h}: not the slot the reference evicted"
+                assert torch.equal(kv.cache_cts.cpu(), f["cache_cts_steps"][t])
+        _final_equal(kv, f)
+        tol = dict(rtol=2 ** -7, atol=0)
+        assert torch.allclose(kv.key_norm.cpu().float(), f["final_keynorm"].float(), **tol)
+        from cold_compress_amd.attention_utils import single_launch_status
+
+        assert single_launch_status() == 0
+    finally:
+        _abi.lib()["cc_decode_step_set_single_launch"](1)
+
+
 def test_random_replay_vs_reference(cc):
     f = load_golden("f4_random.npz")
     dtype = DT_FROM_NAME[f["dtype"]]
