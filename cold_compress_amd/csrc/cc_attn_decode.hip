@@ -150,6 +150,7 @@ struct HybridStep {
   int32_t* num_punc;            // device int[1] or null
   int32_t* cts_next;            // [H] workspace: the head's count after this step's insert (committed by the combine pass)
   int W;                        // history window of the ring (clamp of the denominator)
+  int n_pol;                    // rows of `table` (<= 21: the streaming pass fetches the whole table with one vector load)
 };
 
 struct SplitArgs {
@@ -184,6 +185,11 @@ struct SplitArgs {
   const int64_t* ring_counter;
   int* ring_col;
   int ring_W;
+  // ---- single-launch hybrid step (ONE + HYB): the tracked ring state the combine pass would have updated (null: no head
+  //      runs a heavy-hitter policy); ring_col stays null, every workgroup derives the column from the counter itself
+  void* ring_num;     // [H, S, W] T
+  unsigned long long* ring_acc;  // tracked state (include/coldcompress.h): accumulators, tickets, column-major shadow
+  float* ring_wsum;   // [H, S]
   // ---- l2 policy in the fused step (matrix-core kernel only): the inserted key's norm is recorded here, and every
   //      wave publishes the maximum of key_norm over its slots (the evicted slot's old norm excluded), so that the
   //      combine launch can form the global maximum of cache.py:602 without re-reading [H, S] norms per workgroup
@@ -532,6 +538,7 @@ struct Mfma16x16x16<f16_t> {
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 constexpr unsigned kOneSpinMax = 1u << 18;  // bounded spin: a launch that is not fully resident gives up instead of hanging
 constexpr int kOneStatusWordDev = 1023;     // hdr[0 .. H): per-head epochs; hdr[1023]: timeout word (== kOneStatusWord)
+constexpr int kOneTicketWord = 1022;        // hybrid: heads whose workgroups have all published (the last one commits the per-step scalars)
 // Granule regions are PER KV HEAD at fixed strides, whatever the shape: a location is only ever written by launches of its own
 // head, with tags from that head's epoch word — strictly growing per location even when caches of different head counts and
 // lengths share the workspace (shape-dependent offsets let a stale granule of head 4 sit where head 1 of another shape expects
@@ -614,7 +621,7 @@ struct IntC {
 // loops over them for the per-slot pass).
 template <typename T, int RT, int NW, bool L2, bool ONE = false, bool HYB = false, int QB = 0, int NSUB = 1, int NT = 1>
 __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_split_mfma_kernel(SplitArgs a) {
-  static_assert(!(HYB && (L2 || ONE)), "the hybrid decision rides the plain two-launch streaming pass");
+  static_assert(!(HYB && L2), "the hybrid decision rides the plain streaming pass or the single-launch step");
   static_assert(QB == 0 || (QB == 8 && !L2 && !HYB), "fused quantised cache: 8 bits, heavy hitter / recent_global / random");
   static_assert(NSUB == 1 || (NSUB == 2 && !ONE), "two tiles per iteration: the two-launch streaming pass only");
   static_assert(NT == 1 || (ONE && !L2 && QB == 0 && NSUB == 1), "several tiles per wave in the single-launch step: 16-bit caches, heavy hitter / head-constant policies");
@@ -680,6 +687,32 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
       key_part = x < key_part ? x : key_part;
     }
   }
+  // HYB: everything the per-head decision needs besides the candidate key — the policy table (ALL rows: one vector load, the
+  // head's row is picked by a lane read once its policy index has arrived), the punctuation ids (one id per lane), the head's
+  // policy index and count, the budget terms, the incoming token — as FIRST-LEVEL loads issued here, ahead of q and the tile.
+  // (They used to be fetched behind the tile as a dependent chain strategies[h] -> table[pol]: two serial misses to HBM — every
+  // layer has its own few bytes of these, long evicted when its turn comes again — which the first tile's latency did not cover:
+  // the first K rows of EVERY workgroup arrived 2 us later than in the heavy-hitter step.)
+  int hy_tabv = 0, hy_pol = 0, hy_nsp = 0, hy_npu = 0;
+  long long hy_pidv = 0, hy_tok = 0, hy_ctr = 0;
+  int hy_flags = 0, hy_cts = 0, hy_budget = 0, hy_win = 0;
+  bool hy_punc = false;
+  if constexpr (HYB) {
+    if (lane < a.hyb.n_pol * 3) hy_tabv = a.hyb.table[lane];
+    const bool punc_on = a.hyb.token_id != nullptr && a.hyb.punc_ids != nullptr;
+    if (punc_on && lane < a.hyb.n_punc_ids) hy_pidv = a.hyb.punc_ids[lane];
+    hy_pol = (int)a.hyb.strategies[h];
+    hy_cts = a.cache_cts[h];
+    if (punc_on) hy_tok = *a.hyb.token_id;
+    if (a.hyb.num_special) hy_nsp = *a.hyb.num_special;
+    if (a.hyb.num_punc) hy_npu = *a.hyb.num_punc;
+    if (ONE && a.ring_num) hy_ctr = *a.ring_counter;
+    // more than 64 punctuation ids: the rest is compared here (a wait on the token id at the top of the kernel, on this path
+    // only) — kept out of the decision so that the in-order wait counts around the tile stay exact
+    if (punc_on)
+      for (int k2 = lane + 64; k2 < a.hyb.n_punc_ids; k2 += 64) hy_punc |= a.hyb.punc_ids[k2] == hy_tok;
+    __builtin_amdgcn_sched_barrier(0);
+  }
   // ONE: this lane's slot of the per-slot pass (lane c = t * LPR of row group g finishes row 4g + t of the wave's tile): its
   // history and position are requested here, with everything else, and consumed after the hand-off
   unsigned long long tr0 = 0, tr1 = 0, tr2 = 0, tr3 = 0, tr4 = 0, rt0 = 0, rt1 = 0, trA = 0, trB = 0, trC = 0;
@@ -721,6 +754,47 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
       }
     }
   };
+  // ONE + HYB: the ring pass of the finish runs on ALL lanes (the 192-bit window accumulators make it ~150 instructions per slot:
+  // on the 16 score-holding lanes of a tile it would be four times as long) — lane L takes the wave's slots j = L + 64 k, slot j =
+  // row (j & 15) of the wave's tile (j >> 4); the group-mean probabilities reach it through a wave-private LDS row
+  constexpr int HSL = (HYB && ONE) ? (NT * RPW * U + 63) / 64 : 1;
+  float hy_old[HSL];
+  WAcc hy_acc[HSL];
+  int32_t hy_den[HSL], hy_ps[HSL];
+  uint32_t hy_msk[HSL];  // bit 0: special slot, bit 1: punctuation slot
+#pragma unroll
+  for (int k = 0; k < HSL; k++) {
+    hy_old[k] = 0.f;
+    hy_acc[k] = WAcc{0, 0, 0, 0};
+    hy_den[k] = 0;
+    hy_ps[k] = 0;
+    hy_msk[k] = 0;
+  }
+  int one_rcol = 0;  // ONE + HYB: the ring column of this step (every workgroup derives it from the counter: no launch ahead of this one)
+  auto hyb_slot = [&](int k) {
+    const int j = lane + 64 * k;
+    return row_begin + wave * (RPW * U) + (j & (RPW * U - 1)) + (j / (RPW * U)) * (NW * RPW * U);
+  };
+  auto hyb_valid = [&](int k) { return lane + 64 * k < NT * RPW * U && hyb_slot(k) < row_end; };
+  auto hyb_load_state = [&]() {
+    const size_t hs = (size_t)a.H * S;
+#pragma unroll
+    for (int k = 0; k < HSL; k++)
+      if (hyb_valid(k)) {
+        const size_t i = (size_t)h * S + hyb_slot(k);
+        if (a.ring_num) {
+          const T* shadow = reinterpret_cast<const T*>(a.ring_acc + hs * 4 + 2) + (size_t)one_rcol * hs;
+          hy_old[k] = ElemTraits<T>::load(shadow, i);
+          const ulonglong2 a01 = *reinterpret_cast<const ulonglong2*>(a.ring_acc + i * 4);
+          const ulonglong2 a23 = *reinterpret_cast<const ulonglong2*>(a.ring_acc + i * 4 + 2);
+          hy_acc[k] = WAcc{a01.x, a01.y, a23.x, a23.y};
+          hy_den[k] = a.denom[i];
+        }
+        hy_ps[k] = a.pos[i];
+        hy_msk[k] = (a.hyb.special_mask ? (uint32_t)(a.hyb.special_mask[i] != 0) : 0u) |
+                    (a.hyb.punc_mask ? (uint32_t)(a.hyb.punc_mask[i] != 0) << 1 : 0u);
+      }
+  };
   float one_kn = 0.f;       // ONE + L2: the key norm of this lane's slot (model dtype) ...
   float l2_nv_lane = 0.f;   // ... and the inserted key's norm, in the lanes of the row group that inserted it
   // ONE + L2: the epoch words of the kv heads whose norm granules this thread will gather.  Read HERE: every workgroup has read
@@ -740,7 +814,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
     // single tile: requested AHEAD of the K/V tile (measured: behind it the step is 0.3 us slower — the tile's in-order waits
     // then end on these stragglers, and the workgroup leaves the streaming part later); several tiles: requested after the
     // publish, in the shadow of the hand-off
-    if constexpr (NT == 1) {
+    if constexpr (NT == 1 && !HYB) {
       load_slot_state();
       if constexpr (L2)
         if (one_have) one_kn = ElemTraits<T>::load(reinterpret_cast<const T*>(a.key_norm) + (size_t)h * S, one_slot);
@@ -831,30 +905,6 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
     issue_v(tregs[sub], base + sub * NW * RPW * U);
     if constexpr (QB) __builtin_amdgcn_sched_barrier(0);
   }
-  // HYB: everything the per-head decision needs besides the candidate key — the head's policy row, its count, the budget terms,
-  // the incoming token's punctuation flag — is fetched HERE, behind the tile's loads (uniform addresses: scalar loads, two
-  // dependent levels), in the shadow of the tile's latency.  Fetched where it is used, behind the key, it cost two to three serial round trips per
-  // workgroup AFTER the first tile had arrived (19.0 vs 16.7 us for the plain streaming pass at S = 18432).
-  int hy_flags = 0, hy_cts = 0, hy_budget = 0;
-  bool hy_punc = false;
-  if constexpr (HYB) {
-    // (a scheduling barrier: the dependent scalar loads below each end in an s_waitcnt — interleaved with the tile's loads they
-    //  stalled the wave twice with half of the tile not yet requested)
-    __builtin_amdgcn_sched_barrier(0);
-    const int pol = (int)a.hyb.strategies[h];
-    hy_flags = a.hyb.table[pol * 3];
-    const int win = a.hyb.table[pol * 3 + 1], hhs = a.hyb.table[pol * 3 + 2];
-    hy_cts = a.cache_cts[h];
-    if (a.hyb.token_id && a.hyb.punc_ids) {  // ref: cache.py:975 torch.isin(input_ids, punc_ids)
-      const long long id = *a.hyb.token_id;
-      for (int k2 = 0; k2 < a.hyb.n_punc_ids; k2++) hy_punc |= a.hyb.punc_ids[k2] == id;
-    }
-    hy_budget = a.g;  // ref: cache.py:912-925
-    if (hy_flags & HF_SPECIAL) hy_budget += a.hyb.num_special ? *a.hyb.num_special : 0;
-    if (hy_flags & HF_PUNC) hy_budget += a.hyb.num_punc ? *a.hyb.num_punc : 0;
-    if (hy_flags & HF_WIN) hy_budget += win;
-    if (hy_flags & HF_HH) hy_budget += hhs;
-  }
   int qb_ins_u = -1;  // QB: tile row (of this lane's row group) that holds the inserted token — its K chunk is UNswizzled (chunk c)
 
   auto tile = [&](TileRegs& R, const int tbase, const int tbase_next, const bool more_next, auto ti_c) {
@@ -870,7 +920,25 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
       if (a.abl & 64) ins_idx = -1;
       ins_was_empty = (int)(key & 1ull);
       key_pending = false;
-      if constexpr (HYB) {  // ref: cache.py:896-950 _select_fill_idx, per head — operands fetched in the prologue (hy_*)
+      if constexpr (HYB) {  // ref: cache.py:896-950 _select_fill_idx, per head — operands requested at the top of the kernel (hy_*)
+        hy_flags = __shfl(hy_tabv, hy_pol * 3, CC_WAVE);
+        hy_win = __shfl(hy_tabv, hy_pol * 3 + 1, CC_WAVE);
+        const int hhs = __shfl(hy_tabv, hy_pol * 3 + 2, CC_WAVE);
+        if (a.hyb.token_id && a.hyb.punc_ids) {  // ref: cache.py:975 torch.isin(input_ids, punc_ids)
+          const bool f = hy_punc || (lane < a.hyb.n_punc_ids && hy_pidv == hy_tok);
+          hy_punc = __any(f) != 0;
+        }
+        hy_budget = a.g;  // ref: cache.py:912-925
+        if (hy_flags & HF_SPECIAL) hy_budget += hy_nsp;
+        if (hy_flags & HF_PUNC) hy_budget += hy_npu;
+        if (hy_flags & HF_WIN) hy_budget += hy_win;
+        if (hy_flags & HF_HH) hy_budget += hhs;
+        if constexpr (ONE) {
+          if (a.ring_num) {
+            const unsigned long long ctr = (unsigned long long)hy_ctr;
+            one_rcol = (ctr >> 32) == 0 ? (int)((unsigned)ctr % (unsigned)a.ring_W) : (int)(ctr % (unsigned long long)a.ring_W);
+          }
+        }
         const int flags = hy_flags, cts = hy_cts;
         hyb_punc = hy_punc;
         const int end_idx = cts < S - 1 ? cts : S - 1;  // :897-899
@@ -936,7 +1004,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
         if (c == 0) {
           a.pos[slot] = p_now;  // :1006-1007 every head, dropped tokens included
           if (hyb_kind == 0) a.mask_w[slot] = 1;  // :997-1001 appends only (an evicted slot is live already)
-          a.hyb.cts_next[h] = hyb_cts + (hyb_kind == 0 ? 1 : 0);  // committed to cache_cts by the combine pass
+          if constexpr (!ONE) a.hyb.cts_next[h] = hyb_cts + (hyb_kind == 0 ? 1 : 0);  // committed to cache_cts by the combine pass (ONE: by the head's split-0 workgroup, at the end)
           if (hyb_punc && a.hyb.punc_mask) a.hyb.punc_mask[slot] = 1;  // :1011-1016
         }
       } else if (blockIdx.z == 0) {
@@ -1176,6 +1244,12 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
     // timeout word should that ever not hold.
     const int ns = a.n_split;
     const unsigned tag = one_tag;
+    if constexpr (HYB) {
+      // the step counter, num_punc / num_special and the head's count are overwritten at the END of this launch by whoever sees
+      // that every workgroup has published: their prologue loads must have COMPLETED (not merely been issued) before this
+      // workgroup publishes — the values are pinned into registers here
+      asm volatile("" ::"s"(one_rcol), "s"(hy_budget), "s"(hy_cts), "s"((int)hy_punc), "s"(hy_nsp), "s"(hy_npu) : "memory");
+    }
     if (a.trace) {
       tr1 = __builtin_amdgcn_s_memtime();
       rt1 = __builtin_amdgcn_s_memrealtime();
@@ -1226,7 +1300,8 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
         __builtin_amdgcn_raw_buffer_store_b128(ng, ml_rsrc, nm_base + h * kOneNmHead + split * 16, 0, kOneAuxCoherent);
       }
     }
-    if constexpr (NT > 1) load_slot_state();  // several tiles per wave: the slots' history / positions arrive during the hand-off
+    if constexpr (HYB) hyb_load_state();  // hybrid: the slots' ring state / positions / protection masks arrive during the hand-off
+    else if constexpr (NT > 1) load_slot_state();  // several tiles per wave: the slots' history / positions arrive during the hand-off
     if (a.trace) tr2 = __builtin_amdgcn_s_memtime();
     // ---- what this thread gathers: the (m, l) granule of (head = wave, split = lane) and up to two O granules
     const int ppw = (RT * 64 + ns - 1) / ns;  // output pairs finished per workgroup (pair P = r * 64 + d / 2)
@@ -1352,13 +1427,15 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
     // ---- this workgroup's slots.  ref: attention_utils.py:52 softmax -> model dtype; model.py:416-418 group mean -> model
     //      dtype; cache.py:716-722 history; cache.py:727-749 the next position's eviction score
     unsigned long long my_key = ~0ull;
+    __shared__ float sm_hav[HYB ? NW : 1][HYB ? NT * RPW * U : 1];  // hybrid: group-mean probabilities, [wave][tile * 16 + row]
     auto slot_pass = [&](auto ti_c) {
       constexpr int TI = decltype(ti_c)::value;
       const int slot_ti = one_slot + TI * (NW * RPW * U);
       const bool have_ti = one_lane && slot_ti < row_end;
       unsigned long long key_ti = ~0ull;
       float av = 0.f;
-      if (a.num) {  // heavy hitter: the group-mean probability of this lane's row (the head-constant policies keep no history)
+      const bool want_probs = HYB ? (a.ring_num != nullptr || a.attn_out != nullptr) : (a.num != nullptr);
+      if (want_probs) {  // heavy hitter: the group-mean probability of this lane's row (the head-constant policies keep no history)
         // lane c of a row group computes the probabilities of row t = c / LPR for heads (c % LPR) * KH + [0, KH) — one exp and one
         // IEEE divide per (row, head), spread over the 16 lanes; the score of (row t, head r) sits in lane r of the group as
         // s_keep[TI][t].  The group mean adds the heads in order r = 0 .. RT - 1, like the combine pass.
@@ -1403,7 +1480,9 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
         }
         av = ElemTraits<T>::rnd(sum * (1.0f / (float)RT));  // RT is a power of two: bit-identical to the IEEE divide of the combine pass
       }
-      if (have_ti) {
+      if constexpr (HYB) {  // hybrid: the ring pass below consumes the probabilities on all lanes
+        if (have_ti) sm_hav[wave][TI * (RPW * U) + g * U + c / LPR] = av;
+      } else if (have_ti) {
         const size_t i = (size_t)h * S + slot_ti;
         int32_t ps = one_psv[TI];
         double num_old = one_numv[TI];
@@ -1467,6 +1546,61 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
       };
       all_tiles(all_tiles, IntC<0>{});
     }
+    const int hyb_cts_n = hyb_cts + (hyb_kind == 0 ? 1 : 0);  // hybrid: the head's count after this step's insert
+    if constexpr (HYB) {
+      // ---- hybrid: ring column / exact window sum / denominator of every slot (cache.py:716-723 with W = 400), then the head's
+      //      candidate for position p + 1 (cache.py:844-894) — decode_attn_combine_kernel's operations in its order, on all lanes
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const int32_t p_next = one_pin + 1;
+      const size_t hs = (size_t)a.H * S;
+#pragma unroll
+      for (int k = 0; k < HSL; k++)
+        if (hyb_valid(k)) {
+          const int sl = hyb_slot(k);
+          const size_t i = (size_t)h * S + sl;
+          int32_t ps = hy_ps[k];
+          uint32_t msk = hy_msk[k];
+          if (sl == ins_idx) {  // this launch's insert: position p (dropped tokens too, :1006-1007), punctuation flag :1011-1016
+            ps = one_pin;
+            if (hyb_punc && a.hyb.punc_mask) msk |= 2u;
+          }
+          const float av = sm_hav[wave][lane + 64 * k];
+          if (a.attn_out) ElemTraits<T>::store(reinterpret_cast<T*>(a.attn_out), i, av);
+          float ws = 0.f;
+          int32_t dn = 1;
+          if (a.ring_num) {
+            WAcc racc = hy_acc[k];
+            T* shadow = reinterpret_cast<T*>(a.ring_acc + hs * 4 + 2) + (size_t)one_rcol * hs;
+            ElemTraits<T>::store(reinterpret_cast<T*>(a.ring_num), i * (size_t)a.ring_W + one_rcol, av);
+            ElemTraits<T>::store(shadow, i, av);
+            dn = hy_den[k] + 1;
+            a.denom[i] = dn;
+            wacc_add_value(racc, av, false);
+            wacc_add_value(racc, hy_old[k], true);
+            *reinterpret_cast<ulonglong2*>(a.ring_acc + i * 4) = make_ulonglong2(racc.w0, racc.w1);
+            *reinterpret_cast<ulonglong2*>(a.ring_acc + i * 4 + 2) = make_ulonglong2(racc.w2, racc.special);
+            ws = wacc_round<T>(racc);
+            a.ring_wsum[i] = ws;
+          }
+          const int flags = hy_flags;
+          if ((flags & (HF_HH | HF_WIN)) && !(flags & HF_FULL) && sl < (hyb_cts_n < S ? hyb_cts_n : S)) {
+            float scn;
+            if (flags & HF_HH) {
+              const int32_t d = dn > a.hyb.W ? a.hyb.W : dn;  // clamp_max only (:868-870)
+              scn = __fdiv_rn(ws, (float)d);
+            } else {
+              scn = (float)ps;  // :873
+            }
+            bool save = sl < a.g || ((flags & HF_SPECIAL) && (msk & 1u)) || ((flags & HF_PUNC) && (msk & 2u));  // :876-883
+            if (flags & HF_WIN) save |= ps > p_next - hy_win;  // :885-889 strict
+            if (save) scn = INFINITY;
+            const unsigned long long key = make_key(orderable_f32(scn), (uint32_t)sl << 1);
+            my_key = key < my_key ? key : my_key;
+          }
+        }
+    }
     {
       // one key per WAVE (a head's key row has room for NW per 64-slot workgroup): nothing crosses the waves after the one
       // barrier of the finish, so no wave's stores wait for another wave (the launch ends a store round trip after the LAST
@@ -1483,7 +1617,18 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
     if (threadIdx.x == 0) {
       if (split == 0) {
         a.one_hdr[h] = tag;  // all n_split workgroups of this head have published, hence read the old epoch
-        if (h == 0 && a.hh_counter) *a.hh_counter += 1;
+        if constexpr (HYB) {
+          a.cache_cts[h] = hyb_cts_n;  // every workgroup of this head has read the old count (it decided before it published)
+          // the step counter and num_punc are read by the workgroups of EVERY head: the head that completes the set commits them
+          const unsigned t = atomicAdd(&a.one_hdr[kOneTicketWord], 1u);
+          if (t == (unsigned)a.H - 1u) {
+            a.one_hdr[kOneTicketWord] = 0u;
+            if (a.ring_num && a.hh_counter) *a.hh_counter += 1;               // cache.py:723
+            if (hy_punc && a.hyb.num_punc) *a.hyb.num_punc += 1;              // cache.py:1017, once per step
+          }
+        } else if (h == 0 && a.hh_counter) {
+          *a.hh_counter += 1;
+        }
       }
       if (a.trace) {
         unsigned long long* tr = a.trace + (size_t)(h * ns + split) * 16;
@@ -2103,7 +2248,11 @@ static int one_capacity(void (*kernel)(SplitArgs)) {
   return cap;
 }
 template <typename T>
-static int one_capacity_rt(int rt, int qb = 0) {  // qb: 0 = 16-bit cache, 8 = fused quantised cache, -1 = the l2 policy's instantiation, 104 / 108 = NT tiles
+static int one_capacity_rt(int rt, int qb = 0) {  // qb: 0 = 16-bit cache, 8 = fused quantised cache, -1 = the l2 policy's instantiation, 104 / 108 = NT tiles, 201 / 208 = hybrid with 1 / up to 8 tiles
+  if (qb == 201) return rt == 8 ? one_capacity(decode_attn_split_mfma_kernel<T, 8, kNW, false, true, true, 0, 1, 1>)
+                                : one_capacity(decode_attn_split_mfma_kernel<T, 4, kNW, false, true, true, 0, 1, 1>);
+  if (qb == 208) return rt == 8 ? one_capacity(decode_attn_split_mfma_kernel<T, 8, kNW, false, true, true, 0, 1, 8>)
+                                : one_capacity(decode_attn_split_mfma_kernel<T, 4, kNW, false, true, true, 0, 1, 8>);
   if (qb == 104) return rt == 8 ? one_capacity(decode_attn_split_mfma_kernel<T, 8, kNW, false, true, false, 0, 1, 4>)
                                 : one_capacity(decode_attn_split_mfma_kernel<T, 4, kNW, false, true, false, 0, 1, 4>);
   if (qb == 108) return rt == 8 ? one_capacity(decode_attn_split_mfma_kernel<T, 8, kNW, false, true, false, 0, 1, 8>)
@@ -2134,6 +2283,18 @@ template <typename T>
 static int launch_one(const SplitArgs& a, const Plan& p, int H, hipStream_t st) {
   dim3 grid(p.n_split, H, 1), block(kNW * 64);
   const int nt = p.rows_per_split / rows_per_iter(128, ElemTraits<T>::code);
+  if (a.hyb.strategies != nullptr) {  // hybrid: 4 or 8 query heads per kv head; one tile per wave or up to eight
+    if (a.qparams != nullptr || a.key_norm != nullptr || (p.rt != 4 && p.rt != 8) || nt > kOneMaxTiles) return CC_ERR_UNSUPPORTED;
+    if (nt == 1) {
+      if (p.rt == 8) hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 8, kNW, false, true, true, 0, 1, 1>), grid, block, 0, st, a);
+      else hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 4, kNW, false, true, true, 0, 1, 1>), grid, block, 0, st, a);
+    } else {
+      if (p.rt == 8) hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 8, kNW, false, true, true, 0, 1, 8>), grid, block, 0, st, a);
+      else hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 4, kNW, false, true, true, 0, 1, 8>), grid, block, 0, st, a);
+    }
+    CC_LAUNCH_CHECK();
+    return CC_OK;
+  }
   if (nt > 1) {  // several tiles per wave (long caches): 16-bit caches, heavy hitter / head-constant policies, RT 4 or 8
     if (a.qparams != nullptr || a.key_norm != nullptr || (p.rt != 4 && p.rt != 8) || nt > kOneMaxTiles) return CC_ERR_UNSUPPORTED;
     if (nt <= 4) {
@@ -2189,7 +2350,10 @@ static int32_t one_available(int32_t HQ, int32_t H, int32_t S, int32_t D, int32_
   const Plan p = make_plan(HQ, H, S, D, dtype);
   const int nt = one_tiles(p, HQ, H, D, dtype);
   if (nt == 0) return 0;
-  if (nt > 1) {  // the multi-tile form serves the plain 16-bit policies only
+  if (qb == 200) {  // hybrid: its own instantiations, 4 or 8 query heads per kv head
+    if (p.rt != 4 && p.rt != 8) return 0;
+    qb = nt == 1 ? 201 : 208;
+  } else if (nt > 1) {  // the multi-tile form serves the plain 16-bit policies only
     if (qb != 0) return 0;
     qb = nt <= 4 ? 104 : 108;
   }
@@ -2203,6 +2367,9 @@ int32_t cc_decode_step_single_launch(int32_t HQ, int32_t H, int32_t S, int32_t D
 }
 int32_t cc_decode_step_quant_single_launch(int32_t HQ, int32_t H, int32_t S, int32_t D, int32_t dtype, int32_t n_bit) {
   return n_bit == 8 ? one_available(HQ, H, S, D, dtype, 8) : 0;
+}
+int32_t cc_decode_step_hybrid_single_launch(int32_t HQ, int32_t H, int32_t S, int32_t D, int32_t dtype) {
+  return one_available(HQ, H, S, D, dtype, 200);
 }
 
 int32_t cc_decode_step_status_offset(void) { return kOneStatusWord * (int32_t)sizeof(unsigned); }
@@ -2241,7 +2408,9 @@ struct RingHistory {
 
 // the single-launch tail computes probabilities only where a history consumes them: a group-mean output without one
 // needs the two-launch step
-static bool attn_out_needs_probs(const FusedStep* fs, const void* attn_out) { return attn_out != nullptr && fs && fs->policy != 1; }
+static bool attn_out_needs_probs(const FusedStep* fs, const void* attn_out) {
+  return attn_out != nullptr && fs && fs->policy != 1 && fs->policy != 6;
+}
 
 static int attn_impl(const void* q, const void* k, const void* v, const uint8_t* mask, int32_t HQ, int32_t H,
                      int32_t S, int32_t D, int32_t dtype, float scale, void* y, void* attn_out,
@@ -2310,9 +2479,10 @@ static int attn_impl(const void* q, const void* k, const void* v, const uint8_t*
   if (one_asked || (g_one_enabled && (phases & 3) == 3 && !(phases & CC_PHASE_TWO_LAUNCH))) {
     const bool policy_ok = fs && ((fs->policy == 1 && hh_num && hh_denom && fs->c->Hp == H) ||
                                   ((fs->policy == 2 || (fs->policy == 3 && fs->rand_next)) && !hh_num && fs->c->Hp == 1) ||
-                                  (fs->policy == 4 && fs->key_norm && !hh_num && fs->c->Hp == H));
-    const bool one_ok = policy_ok && !rh && !probs_out && !attn_out_needs_probs(fs, attn_out) &&
-                        one_available(HQ, H, S, D, dtype, fs->qparams ? 8 : (fs->policy == 4 ? -1 : 0)) == 1;
+                                  (fs->policy == 4 && fs->key_norm && !hh_num && fs->c->Hp == H) ||
+                                  (fs->policy == 6 && !hh_num && fs->c->Hp == H && fs->c->Hc == H));
+    const bool one_ok = policy_ok && (!rh || fs->policy == 6) && !probs_out && !attn_out_needs_probs(fs, attn_out) &&
+                        one_available(HQ, H, S, D, dtype, fs->qparams ? 8 : (fs->policy == 4 ? -1 : (fs->policy == 6 ? 200 : 0))) == 1;
     if (one_asked && !one_ok) return CC_ERR_UNSUPPORTED;
     if (one_ok) {
       char* ob = reinterpret_cast<char*>(workspace);
@@ -2324,6 +2494,12 @@ static int attn_impl(const void* q, const void* k, const void* v, const uint8_t*
       sa.trace = reinterpret_cast<unsigned long long*>(g_one_trace);
       sa.y = y; sa.attn_out = attn_out; sa.hh_counter = hh_counter; sa.g = fs->g; sa.w = fs->w; sa.yc_chunks = p.n_chunks;
       sa.policy = fs->policy; sa.rand_next = fs->rand_next;
+      if (fs->policy == 6) {  // hybrid: the ring state travels with the launch; every workgroup derives the ring column itself
+        sa.ring_col = nullptr;
+        if (rh) {
+          sa.ring_num = rh->num; sa.ring_acc = reinterpret_cast<unsigned long long*>(rh->acc); sa.ring_wsum = rh->wsum;
+        }
+      }
       return dtype == CC_DT_BF16 ? launch_one<bf16_t>(sa, p, H, st) : launch_one<f16_t>(sa, p, H, st);
     }
   }
@@ -2478,7 +2654,8 @@ int cc_decode_step_hybrid(const cc_kv_view* c, const void* q, const void* k_new,
   HybridStep hs{};
   hs.strategies = strategies; hs.table = policy_table; hs.special_mask = special_mask; hs.punc_mask = punc_mask;
   hs.token_id = token_id; hs.punc_ids = punc_ids; hs.n_punc_ids = n_punc_ids; hs.num_special = num_special; hs.num_punc = num_punc;
-  hs.W = W;
+  hs.W = W; hs.n_pol = n_policies;
+  if (n_policies * 3 > 64) return CC_ERR_UNSUPPORTED;  // the streaming pass fetches the whole policy table with one vector load
   FusedStep fs{c, k_new, v_new, input_pos, reinterpret_cast<unsigned long long*>(next_key), global_tokens, 0, 6, nullptr, nullptr, &hs};
   RingHistory rh{ring_num, W, wsum_acc, wsum};
   return attn_impl(q, c->k_cache, c->v_cache, c->mask, HQ, c->H, c->S, c->D, c->dtype, scale, y, attn_out, nullptr, nullptr,

@@ -292,6 +292,15 @@ int cc_decode_step_hybrid(const cc_kv_view* c, const void* q, const void* k_new,
                           uint8_t* punc_mask, const int64_t* token_id, const int64_t* punc_ids, int32_t n_punc_ids,
                           const int32_t* num_special, int32_t* num_punc, uint64_t* next_key, int32_t global_tokens, int32_t HQ,
                           float scale, void* y, void* attn_out, void* workspace, size_t workspace_bytes, cc_stream_t stream);
+/* cc_decode_step_hybrid runs as ONE launch (the single-launch form above: in-launch hand-off, every workgroup resident) when
+ * this returns 1: 16-bit caches, head_dim 128, HQ / H in {4, 8}, up to eight 64-slot tiles per workgroup (S <= 32768 at 64
+ * workgroups per kv head).  The tail then also does what the combine pass did for this policy: ring column, exact window sum and
+ * denominator of every slot (on all lanes), the head's candidate for the next position, the head's count (committed by the
+ * head's first workgroup once all of them have published), and the step counter / num_punc (committed by the LAST head to
+ * complete, through a ticket word in the workspace header: the workgroups of every head read them in their prologue).
+ * Bit-identical to the two-launch step in every buffer but y (one rounding, as for the other policies).
+ * cc_decode_step_set_single_launch(0) switches it off; the status word is shared with the other single-launch steps. */
+int32_t cc_decode_step_hybrid_single_launch(int32_t HQ, int32_t H, int32_t S, int32_t D, int32_t dtype);
 /* Measurement hook (cf. cc_decode_attn_gqa_phases): the same step with its launches selectable. */
 int cc_decode_step_heavy_hitter_phases(const cc_kv_view* c, const void* q, const void* k_new, const void* v_new,
                                 const int32_t* input_pos, double* num, int32_t* denom, int64_t* counter,

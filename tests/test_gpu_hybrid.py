@@ -274,21 +274,44 @@ HYB_YAML = [{"strategy": "window", "recent_window": 0.1},
             {"strategy": "window_heavy_hitter", "heavy_hitter_frac": 0.5, "recent_window": 0.1}, {"strategy": "full"}]
 
 
-@pytest.mark.parametrize("strategies,H,HQ,S,T,steps,seed", [(HYB5, 5, 20, 300, 280, 40, 1), (HYB_YAML, 8, 32, 4100, 4000, 30, 2),
-                                                            (HYB5, 3, 6, 130, 20, 140, 3), (HYB_YAML, 4, 32, 18432, 18000, 12, 4),
-                                                            (HYB5, 10, 10, 700, 700, 25, 5)])
-def test_hybrid_two_launch_step_equals_three_launches(strategies, H, HQ, S, T, steps, seed):
+@pytest.fixture
+def single_launch():
+    """Process-wide single-launch switch of the fused decode steps (include/coldcompress.h); restored to its default."""
+    from cold_compress_amd import _abi
+
+    fn = _abi.lib()["cc_decode_step_set_single_launch"]
+    yield lambda on: fn(1 if on else 0)
+    fn(1)
+
+
+# (strategies, H, HQ, S, T, steps, seed, single): single = the step runs as ONE launch (cc_decode_step_hybrid_single_launch says
+# so for the shape: HQ / H in {4, 8}, at most 64 workgroups per kv head with up to eight tiles each)
+HYB_STEP_CASES = [(HYB5, 5, 20, 300, 280, 40, 1, False), (HYB_YAML, 8, 32, 4100, 4000, 30, 2, False),
+                  (HYB5, 3, 6, 130, 20, 140, 3, False), (HYB_YAML, 4, 32, 18432, 18000, 12, 4, False),
+                  (HYB5, 10, 10, 700, 700, 25, 5, False),
+                  (HYB5, 5, 20, 300, 280, 40, 1, True), (HYB_YAML, 8, 32, 4100, 4000, 30, 2, True),
+                  (HYB_YAML, 8, 32, 18432, 18400, 40, 6, True), (HYB5, 1, 8, 3488, 3400, 100, 7, True),
+                  (HYB5, 5, 20, 1000, 20, 60, 8, True)]
+
+
+@pytest.mark.parametrize("strategies,H,HQ,S,T,steps,seed,single", HYB_STEP_CASES)
+def test_hybrid_two_launch_step_equals_three_launches(strategies, H, HQ, S, T, steps, seed, single, single_launch):
     """KVCacheHybrid.decode_step (cc_decode_step_hybrid: decision + insert in the K/V streaming pass; ring update, the next
     candidates, the counts and num_punc in the combine pass) against update_kv -> attention (ring update fused) ->
     update_state, on twin caches: every buffer — pos, mask, counts, K/V, ring, denominators, punctuation / special masks,
     num_punc, the tracked window sums — and y, bit for bit, through appends, evictions, dropped tokens and punctuation
     tokens; heads cycle through the policies, partly filled and full.  (The three-launch sequence is the one the reference's
     own traces pin bit for bit above; its attention inputs are given there, so a trace cannot be replayed through a step
-    that computes the attention itself.)"""
+    that computes the attention itself.)  single: the same step as ONE launch (the combine pass folded into the tail of the
+    streaming kernel behind the in-launch hand-off) — every buffer still bit for bit, y within one rounding of the model dtype."""
     import cold_compress_amd.cache as cache
-    from cold_compress_amd.attention_utils import scaled_dot_product_attention as sdpa
+    from cold_compress_amd import _abi
+    from cold_compress_amd.attention_utils import scaled_dot_product_attention as sdpa, single_launch_status
 
     D, dtype = 128, torch.bfloat16
+    single_launch(single)
+    if single:
+        assert _abi.lib()["cc_decode_step_hybrid_single_launch"](HQ, H, S, D, 1) == 1
     cls, rk = cache.get_cache_constructor("hybrid")
     kw = dict(max_cache_length=S, max_seq_length=S, cache_bits=None, global_tokens=4, token_ids=TOKEN_IDS, min_recovery_frac=0.9,
               hybrid_strategies=strategies)
@@ -338,8 +361,12 @@ def test_hybrid_two_launch_step_equals_three_launches(strategies, H, HQ, S, T, s
         a.update_state(p, k1, v1, False, attn, input_ids=ids)
         yb = b.decode_step(q, k1, v1, p, input_ids=ids)
         torch.cuda.synchronize()
-        assert torch.equal(ya, yb), f"step {t}: attention output"
+        if single:
+            assert torch.allclose(ya.float(), yb.float(), rtol=2.0 ** -7, atol=1e-6), f"step {t}: attention output"
+        else:
+            assert torch.equal(ya, yb), f"step {t}: attention output"
         for (na, ta), (nb, tb) in zip(a.named_buffers(), b.named_buffers()):
             if na != "next_key":
                 assert torch.equal(ta, tb), f"step {t}: {na}"
     assert b._next_valid
+    assert single_launch_status() == 0

@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--HQ", type=int, default=32)
     ap.add_argument("--abl", type=int, nargs="+", default=[0], help="measurement bits of the phases word (0 = the product path)")
     ap.add_argument("--quant", action="store_true", help="the fused quantised cache (cache_bits=8, cache_quant_mode='fused')")
+    ap.add_argument("--hybrid", action="store_true", help="KVCacheHybrid (the decode-ready state of tools/bench_policies.py)")
     a = ap.parse_args()
     dev, D, H, HQ = "cuda", 128, a.H, a.HQ
     fns = _abi.lib()
@@ -36,7 +37,11 @@ def main():
         kw = dict(max_cache_length=S, global_tokens=4, max_seq_length=4 * S, cache_bits=None, recent_window=10,
                   history_window_size=1, attn_thresholding=False)
         caches = []
-        for _ in range(n_buf):
+        if a.hybrid:
+            from bench_policies import make
+
+            caches = [make("hybrid", H, S, D) for _ in range(n_buf)]
+        for _ in range(0 if a.hybrid else n_buf):
             lk = {k: kw[k] for k in rk}
             if a.quant:
                 lk.update(cache_bits=8, cache_quant_mode="fused")
@@ -66,9 +71,13 @@ def main():
         trace = torch.zeros((n_wg, 16), dtype=torch.int64, device=dev)
         for kv in caches:
             kv.prepare_decode(pos)
+        q4, k4, ids = q.view(1, HQ, 1, D), k1.view(1, H, 1, D), torch.tensor([[11]], device=dev)
 
         def fstep(i, phases):
             kv = caches[i % n_buf]
+            if a.hybrid:  # the class's own step (its workspace, the library's choice of launch form)
+                kv.decode_step(q4, k4, k4, pos, input_ids=ids)
+                return
             st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
             if a.quant:
                 rc = fns["cc_decode_step_quant"](
@@ -110,7 +119,7 @@ def main():
             rel = (t[:, :6] - t0).astype(np.float64)
             span = rel[:, 5].max()
             names = ["start", "stream_done", "published", "sentinel_seen", "gathered", "end"]
-            out = {"S": S, "quant": bool(a.quant), "abl": abl, "us_per_launch_events": round(us_per, 2), "workgroups": int(used.sum()),
+            out = {"S": S, "quant": bool(a.quant), "hybrid": bool(a.hybrid), "abl": abl, "us_per_launch_events": round(us_per, 2), "workgroups": int(used.sum()),
                    "ticks_total": float(span)}
             base = t[:, 6].min()
             r0, r1, r2 = t[:, 6] - base, t[:, 7] - base, t[:, 8] - base
