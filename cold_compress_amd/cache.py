@@ -873,7 +873,7 @@ class KVCacheHybrid(_TrackedWindowSums, KVCacheHeadSpecific):
         """cc_decode_step_hybrid: 16-bit caches with head_dim 128, profiled heads, and the reference's effective
         no-reset-on-evict behaviour (see the class docstring)."""
         return (self.cache_strategies is not None and self.k_cache.dtype in (torch.bfloat16, torch.float16) and self.head_dim == 128
-                and not self.reset_history_on_evict and self.n_heads <= 48)
+                and not self.reset_history_on_evict and self.n_heads <= 48 and len(self.hybrid_strategies) <= 21)
 
     def _punc_operands(self, input_ids):
         if not hasattr(self, "punc_ids"):

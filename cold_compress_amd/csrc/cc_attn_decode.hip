@@ -758,17 +758,22 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
   // on the 16 score-holding lanes of a tile it would be four times as long) — lane L takes the wave's slots j = L + 64 k, slot j =
   // row (j & 15) of the wave's tile (j >> 4); the group-mean probabilities reach it through a wave-private LDS row
   constexpr int HSL = (HYB && ONE) ? (NT * RPW * U + 63) / 64 : 1;
-  float hy_old[HSL];
-  WAcc hy_acc[HSL];
+  // (RAW load results: nothing is converted, tested or combined where the loads are issued — a conversion or a `!= 0` next to
+  //  its load makes the compiler wait for that load on the spot, and the state loads of a slot then go out one miss after the
+  //  other: 2.6 us to ISSUE them, measured, instead of 0.1)
+  uint16_t hy_old[HSL];
+  ulonglong2 hy_a01[HSL], hy_a23[HSL];
   int32_t hy_den[HSL], hy_ps[HSL];
-  uint32_t hy_msk[HSL];  // bit 0: special slot, bit 1: punctuation slot
+  uint8_t hy_sp[HSL], hy_pu[HSL];  // special / punctuation slot
 #pragma unroll
   for (int k = 0; k < HSL; k++) {
-    hy_old[k] = 0.f;
-    hy_acc[k] = WAcc{0, 0, 0, 0};
+    hy_old[k] = 0;
+    hy_a01[k] = make_ulonglong2(0, 0);
+    hy_a23[k] = make_ulonglong2(0, 0);
     hy_den[k] = 0;
     hy_ps[k] = 0;
-    hy_msk[k] = 0;
+    hy_sp[k] = 0;
+    hy_pu[k] = 0;
   }
   int one_rcol = 0;  // ONE + HYB: the ring column of this step (every workgroup derives it from the counter: no launch ahead of this one)
   auto hyb_slot = [&](int k) {
@@ -778,21 +783,25 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
   auto hyb_valid = [&](int k) { return lane + 64 * k < NT * RPW * U && hyb_slot(k) < row_end; };
   auto hyb_load_state = [&]() {
     const size_t hs = (size_t)a.H * S;
+    // absent operands read a valid dummy (the cache mask / the positions) and are ignored where they would be used: no branch
+    // around any of these loads
+    const uint8_t* spm = a.hyb.special_mask ? a.hyb.special_mask : a.mask_w;
+    const uint8_t* pum = a.hyb.punc_mask ? a.hyb.punc_mask : a.mask_w;
+    const int32_t* dnp = a.ring_num ? a.denom : a.pos;
+    const uint16_t* shadow = a.ring_num ? reinterpret_cast<const uint16_t*>(a.ring_acc + hs * 4 + 2) + (size_t)one_rcol * hs
+                                        : reinterpret_cast<const uint16_t*>(a.pos);
+    const unsigned long long* accp = a.ring_num ? a.ring_acc : reinterpret_cast<const unsigned long long*>(a.k);
 #pragma unroll
     for (int k = 0; k < HSL; k++)
       if (hyb_valid(k)) {
         const size_t i = (size_t)h * S + hyb_slot(k);
-        if (a.ring_num) {
-          const T* shadow = reinterpret_cast<const T*>(a.ring_acc + hs * 4 + 2) + (size_t)one_rcol * hs;
-          hy_old[k] = ElemTraits<T>::load(shadow, i);
-          const ulonglong2 a01 = *reinterpret_cast<const ulonglong2*>(a.ring_acc + i * 4);
-          const ulonglong2 a23 = *reinterpret_cast<const ulonglong2*>(a.ring_acc + i * 4 + 2);
-          hy_acc[k] = WAcc{a01.x, a01.y, a23.x, a23.y};
-          hy_den[k] = a.denom[i];
-        }
+        hy_old[k] = shadow[i];
+        hy_a01[k] = *reinterpret_cast<const ulonglong2*>(accp + i * 4);
+        hy_a23[k] = *reinterpret_cast<const ulonglong2*>(accp + i * 4 + 2);
+        hy_den[k] = dnp[i];
         hy_ps[k] = a.pos[i];
-        hy_msk[k] = (a.hyb.special_mask ? (uint32_t)(a.hyb.special_mask[i] != 0) : 0u) |
-                    (a.hyb.punc_mask ? (uint32_t)(a.hyb.punc_mask[i] != 0) << 1 : 0u);
+        hy_sp[k] = spm[i];
+        hy_pu[k] = pum[i];
       }
   };
   float one_kn = 0.f;       // ONE + L2: the key norm of this lane's slot (model dtype) ...
@@ -1555,13 +1564,17 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       const int32_t p_next = one_pin + 1;
       const size_t hs = (size_t)a.H * S;
+      // opaque constants born HERE: the compiler otherwise hoists `denom + 1` and the mask tests up into the block that issues the
+      // state loads (same condition, operands defined there) — with a wait for each load right behind its issue
+      int late_one = 1, late_ff = 0xff;
+      asm volatile("" : "+s"(late_one), "+s"(late_ff));
 #pragma unroll
       for (int k = 0; k < HSL; k++)
         if (hyb_valid(k)) {
           const int sl = hyb_slot(k);
           const size_t i = (size_t)h * S + sl;
           int32_t ps = hy_ps[k];
-          uint32_t msk = hy_msk[k];
+          uint32_t msk = (a.hyb.special_mask && (hy_sp[k] & late_ff) ? 1u : 0u) | (a.hyb.punc_mask && (hy_pu[k] & late_ff) ? 2u : 0u);
           if (sl == ins_idx) {  // this launch's insert: position p (dropped tokens too, :1006-1007), punctuation flag :1011-1016
             ps = one_pin;
             if (hyb_punc && a.hyb.punc_mask) msk |= 2u;
@@ -1571,14 +1584,17 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
           float ws = 0.f;
           int32_t dn = 1;
           if (a.ring_num) {
-            WAcc racc = hy_acc[k];
+            WAcc racc{hy_a01[k].x, hy_a01[k].y, hy_a23[k].x, hy_a23[k].y};
+            T old_e;
+            old_e.x = hy_old[k];
+            const float old_v = ElemTraits<T>::load(&old_e, 0);
             T* shadow = reinterpret_cast<T*>(a.ring_acc + hs * 4 + 2) + (size_t)one_rcol * hs;
             ElemTraits<T>::store(reinterpret_cast<T*>(a.ring_num), i * (size_t)a.ring_W + one_rcol, av);
             ElemTraits<T>::store(shadow, i, av);
-            dn = hy_den[k] + 1;
+            dn = hy_den[k] + late_one;
             a.denom[i] = dn;
             wacc_add_value(racc, av, false);
-            wacc_add_value(racc, hy_old[k], true);
+            wacc_add_value(racc, old_v, true);
             *reinterpret_cast<ulonglong2*>(a.ring_acc + i * 4) = make_ulonglong2(racc.w0, racc.w1);
             *reinterpret_cast<ulonglong2*>(a.ring_acc + i * 4 + 2) = make_ulonglong2(racc.w2, racc.special);
             ws = wacc_round<T>(racc);

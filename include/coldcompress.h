@@ -280,9 +280,9 @@ void cc_decode_step_trace(void* buf);
  * and bumps num_punc (cache.py:1017).  cc_hybrid_next_key_init seeds the candidates.  Arguments as for
  * cc_hybrid_decode_update / cc_decode_attn_gqa_ring; ring_num may be NULL when no head scores by accumulated attention
  * (then denom / counter / wsum_acc / wsum are unused).  reset-history-on-evict is not part of this step (the reference's
- * effective behaviour, see cache.py of this package); 16-bit caches with head_dim 128 only (CC_ERR_UNSUPPORTED otherwise:
- * use cc_hybrid_decode_update + cc_decode_attn_gqa[_ring]).  next_key: uint64 [H, NK].  Bit-identical to the three-launch
- * sequence (tests/test_gpu_hybrid.py). */
+ * effective behaviour, see cache.py of this package); 16-bit caches with head_dim 128 and at most 21 policy rows only
+ * (CC_ERR_UNSUPPORTED otherwise: use cc_hybrid_decode_update + cc_decode_attn_gqa[_ring]).  next_key: uint64 [H, NK].
+ * Bit-identical to the three-launch sequence (tests/test_gpu_hybrid.py). */
 int cc_hybrid_next_key_init(const cc_kv_view* c, const int32_t* input_pos, const int64_t* strategies, const int32_t* policy_table,
                             int32_t n_policies, const int32_t* denom, int32_t W, const float* wsum, const uint8_t* special_mask,
                             const uint8_t* punc_mask, int32_t global_tokens, uint64_t* next_key, cc_stream_t stream);

@@ -291,7 +291,11 @@ HYB_STEP_CASES = [(HYB5, 5, 20, 300, 280, 40, 1, False), (HYB_YAML, 8, 32, 4100,
                   (HYB5, 10, 10, 700, 700, 25, 5, False),
                   (HYB5, 5, 20, 300, 280, 40, 1, True), (HYB_YAML, 8, 32, 4100, 4000, 30, 2, True),
                   (HYB_YAML, 8, 32, 18432, 18400, 40, 6, True), (HYB5, 1, 8, 3488, 3400, 100, 7, True),
-                  (HYB5, 5, 20, 1000, 20, 60, 8, True)]
+                  (HYB5, 5, 20, 1000, 20, 60, 8, True),
+                  # seeds >= 100: 100 punctuation ids with the one the test feeds (6) at index 80 — past the 64 ids the streaming
+                  # pass compares with one vector load
+                  (HYB5, 5, 20, 300, 280, 30, 101, False), (HYB5, 5, 20, 300, 280, 30, 102, True)]
+LONG_PUNC_IDS = {"special": [[1], [2, 3]], "punctuation": [200 + i for i in range(80)] + [6] + [400 + i for i in range(19)]}
 
 
 @pytest.mark.parametrize("strategies,H,HQ,S,T,steps,seed,single", HYB_STEP_CASES)
@@ -313,8 +317,8 @@ def test_hybrid_two_launch_step_equals_three_launches(strategies, H, HQ, S, T, s
     if single:
         assert _abi.lib()["cc_decode_step_hybrid_single_launch"](HQ, H, S, D, 1) == 1
     cls, rk = cache.get_cache_constructor("hybrid")
-    kw = dict(max_cache_length=S, max_seq_length=S, cache_bits=None, global_tokens=4, token_ids=TOKEN_IDS, min_recovery_frac=0.9,
-              hybrid_strategies=strategies)
+    kw = dict(max_cache_length=S, max_seq_length=S, cache_bits=None, global_tokens=4, token_ids=LONG_PUNC_IDS if seed >= 100 else TOKEN_IDS,
+              min_recovery_frac=0.9, hybrid_strategies=strategies)
 
     def mk():
         with torch.device(DEV):
