@@ -144,6 +144,86 @@ def one_ring(rng, idx):
     return ""
 
 
+HYB_YAML = [{"strategy": "window", "recent_window": 0.1},
+            {"strategy": "window_heavy_hitter", "heavy_hitter_frac": 0.25, "recent_window": 0.1},
+            {"strategy": "window_heavy_hitter", "heavy_hitter_frac": 0.5, "recent_window": 0.1}, {"strategy": "full"}]
+
+
+def one_hybrid_step(rng, idx):
+    """KVCacheHybrid.decode_step (ONE launch where the shape allows it, two otherwise) against update_kv -> attention (ring update
+    fused) -> update_state: every buffer bit for bit, y within one rounding; random per-head fill levels, policies, protection
+    masks, punctuation tokens (3 ids or 100)."""
+    dtype = rng.choice([torch.bfloat16, torch.float16])
+    D = 128
+    H = rng.choice([1, 2, 5, 8])
+    R = rng.choice([2, 4, 4, 8])
+    S = rng.choice([rng.randint(8, 200), rng.randint(201, 3000), rng.randint(3001, 4096), rng.choice([4100, 6000, 9000]),
+                    18432 if H * R <= 32 else rng.randint(300, 2000)])
+    strategies = rng.choice([HYB, HYB_YAML])
+    long_punc = rng.random() < 0.3
+    tids = {"special": [[1], [2, 3]], "punctuation": ([200 + i for i in range(80)] + [6] + [400 + i for i in range(19)]) if long_punc else [5, 6, 7]}
+    g = rng.randint(0, min(4, S // 3))
+    cfg = dict(strategy="hybrid_step", dtype=str(dtype), H=H, R=R, S=S, g=g, yaml=strategies is HYB_YAML, long_punc=long_punc)
+    cls, rk = cache.get_cache_constructor("hybrid")
+    kw = dict(max_cache_length=S, max_seq_length=S, cache_bits=None, global_tokens=g, token_ids=tids, min_recovery_frac=0.9,
+              hybrid_strategies=strategies)
+
+    def mk():
+        with torch.device(DEV):
+            return cls(1, H, D, dtype, **{k: kw[k] for k in rk})
+
+    a, b = mk(), mk()
+    gen = torch.Generator().manual_seed(20_000 + idx)
+    T = rng.choice([S, max(1, S - 3), rng.randint(1, S)])
+    fill = torch.tensor([rng.choice([T, max(1, T // 2), rng.randint(1, T)]) for _ in range(H)], dtype=torch.int32)
+    k0 = torch.randn(1, H, T, D, generator=gen).to(dtype).to(DEV)
+    v0 = torch.randn(1, H, T, D, generator=gen).to(dtype).to(DEV)
+    ring0 = (torch.rand(H, S, 1, generator=gen) * torch.rand(1, 1, a.history_window_size, generator=gen) * 1e-2).to(dtype)
+    den0 = torch.randint(1, 500, (H, S), generator=gen, dtype=torch.int32)
+    sp0 = torch.rand(H, S, generator=gen) < 0.02
+    pu0 = torch.rand(H, S, generator=gen) < 0.02
+    off = rng.randint(0, len(strategies) - 1)
+    npu0 = rng.randint(0, 5)
+    for kv in (a, b):
+        kv.update_kv(torch.arange(T, device=DEV), k0, v0, True, input_ids=torch.zeros(T, dtype=torch.int64, device=DEV))
+        kv.cache_strategies = ((torch.arange(H, device=DEV) + off) % len(strategies)).to(torch.int64).contiguous()
+        kv.requires_heavy_hitter = any("heavy_hitter" in s_["strategy"] for s_ in strategies)
+        kv.cache_cts.copy_(fill.to(DEV))
+        live = torch.arange(S, device=DEV).view(1, S) < fill.to(DEV).view(H, 1)
+        kv.mask[0, :, 0, :] = live
+        kv.pos[0] = torch.where(live, torch.arange(S, device=DEV, dtype=kv.pos.dtype).view(1, S).expand(H, S), torch.full_like(kv.pos[0], -1))
+        kv.attn_history_num.copy_(ring0.to(DEV).unsqueeze(0))
+        kv.attn_history_denom.copy_(den0.to(DEV).unsqueeze(0))
+        if hasattr(kv, "special_mask"):
+            kv.special_mask[0] = sp0.to(DEV) & live
+            kv.num_special.fill_(int(sp0[0, : int(fill[0])].sum()))
+        if hasattr(kv, "punc_mask"):
+            kv.punc_mask[0] = pu0.to(DEV) & live
+            kv.num_punc.fill_(npu0)
+    if not b.supports_fused_step():
+        return None
+    for t in range(8):
+        p = torch.tensor([T + t], dtype=torch.int32, device=DEV)
+        ids = torch.tensor([[6 if rng.random() < 0.3 else 11]], dtype=torch.int64, device=DEV)
+        k1 = torch.randn(1, H, 1, D, generator=gen).to(dtype).to(DEV)
+        v1 = torch.randn(1, H, 1, D, generator=gen).to(dtype).to(DEV)
+        q = torch.randn(1, H * R, 1, D, generator=gen).to(dtype).to(DEV)
+        ka, va, ma = a.update_kv(p, k1, v1, False, input_ids=ids)
+        hist = a.fused_history()
+        ya, attn = sdpa(q, ka, va, attn_mask=ma, return_attn=a.return_attn() and hist is None, group_mean=True, history=hist)
+        if hist is not None:
+            a._state_fused = True
+        a.update_state(p, k1, v1, False, attn, input_ids=ids)
+        yb = b.decode_step(q, k1, v1, p, input_ids=ids)
+        torch.cuda.synchronize()
+        if not torch.allclose(ya.float(), yb.float(), rtol=2.0 ** -7, atol=1e-6):
+            return f"{cfg} step {t}: y differs"
+        for (na, ta), (nb, tb) in zip(a.named_buffers(), b.named_buffers()):
+            if na != "next_key" and not torch.equal(ta, tb):
+                return f"{cfg} step {t}: buffer {na} differs"
+    return ""
+
+
 def one_quant(rng, idx):
     """the fused quantised cache against the same policy's 16-bit cache holding its dequantised values (bit for bit)."""
     import ctypes as C
@@ -221,12 +301,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=300)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--only", choices=["hybrid_step"], default=None, help="run one family of cases only")
     a = ap.parse_args()
     rng = random.Random(a.seed)
     ran = bad = 0
     for i in range(a.n):
         try:
-            r = one_ring(rng, i) if i % 4 == 0 else (one_quant(rng, i) if i % 4 == 1 else one(rng, i))
+            r = one_hybrid_step(rng, i) if a.only == "hybrid_step" else (one_hybrid_step(rng, i) if i % 8 == 4 else one_ring(rng, i)) if i % 4 == 0 else (one_quant(rng, i) if i % 4 == 1 else one(rng, i))
         except Exception as e:  # a crash is a finding too
             r = f"case {i}: {type(e).__name__}: {e}"
         if r is None:
