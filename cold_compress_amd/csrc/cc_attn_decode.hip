@@ -806,17 +806,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
   };
   float one_kn = 0.f;       // ONE + L2: the key norm of this lane's slot (model dtype) ...
   float l2_nv_lane = 0.f;   // ... and the inserted key's norm, in the lanes of the row group that inserted it
-  // ONE + L2: the epoch words of the kv heads whose norm granules this thread will gather.  Read HERE: every workgroup has read
-  // them before it publishes anything, and no head's epoch is bumped before its split-0 workgroup has gathered the granules of
-  // ALL workgroups of all heads — so none of these reads can see a bumped word.
-  unsigned l2_ep[3] = {0u, 0u, 0u};
-  if constexpr (ONE && L2) {
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-      const int e = (int)threadIdx.x + k * NW * 64;
-      if (e < a.H * a.n_split) l2_ep[k] = a.one_hdr[e / a.n_split];
-    }
-  }
+  unsigned l2_ep[3] = {0u, 0u, 0u};  // ONE + L2: epoch words of the kv heads whose norm granules this thread gathers (read behind the tile's loads, below)
   if constexpr (ONE) {
     one_tag = a.one_hdr[h] + 1u;
     one_pin = *a.input_pos;
@@ -839,12 +829,21 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
   // would hold the ~150 instructions of min / max shuffles and roundings back until the K/V rows have arrived, and the whole kv
   // head waits for its slowest workgroup.  (Quantising in EVERY wave ahead of the tile was tried: 512 workgroups of redundant
   // work cost more than the one critical path saves — 12.2 vs 11.7 us at S = 4096.)
+  // The l2 policy does the same (late r2): its norm of the new key (eight more loads, a float64 square root) ran behind the tile's
+  // in-order wait, and the inserting workgroup of every head left the streaming part 2.7 us after the others — with every workgroup
+  // of the launch waiting for it (l2 step 13.5 -> 12.8 us).  The plain 16-bit caches keep the two loads behind the tile: requested
+  // ahead of it by all 2048 waves they cost MORE than the inserting wave gains (A/B on one box: heavy hitter 10.68 -> 10.83 us,
+  // recent_global 10.14 -> 10.60 — every wave of a kv head asks for the same four cache lines, one memory channel serves them one
+  // by one, and the tile's rows queue behind them in the in-order return).
+  constexpr bool AHEAD = QB != 0 || L2;  // the incoming token's rows are requested ahead of the tile
   Vec16<T> qb_kn, qb_vn;
-  if constexpr (QB) {
-    if (a.k_new) {
-      qb_kn.load(reinterpret_cast<const T*>(a.k_new) + (size_t)h * D + c * VEC);
-      qb_vn.load(reinterpret_cast<const T*>(a.v_new) + (size_t)h * D + c * VEC);
-    }
+  int32_t p_ins = 0;
+  qb_kn.raw = make_uint4(0, 0, 0, 0);
+  qb_vn.raw = make_uint4(0, 0, 0, 0);
+  if (AHEAD && a.k_new) {
+    qb_kn.load(reinterpret_cast<const T*>(a.k_new) + (size_t)h * D + c * VEC);
+    qb_vn.load(reinterpret_cast<const T*>(a.v_new) + (size_t)h * D + c * VEC);
+    p_ins = *a.input_pos;
   }
   // B operand: lane (n = c, kb = g) of step j holds q[head n][8 * (4j + g) .. + 8]; columns n >= RT are zero
   Vec16<T> qB[4];
@@ -914,6 +913,16 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
     issue_v(tregs[sub], base + sub * NW * RPW * U);
     if constexpr (QB) __builtin_amdgcn_sched_barrier(0);
   }
+  // ONE + L2: the epoch words of the kv heads whose norm granules this thread will gather.  Read HERE (behind the tile's loads: three integer divisions kept out of the way of the first K rows): every workgroup has read
+  // them before it publishes anything, and no head's epoch is bumped before its split-0 workgroup has gathered the granules of
+  // ALL workgroups of all heads — so none of these reads can see a bumped word.
+  if constexpr (ONE && L2) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const int e = (int)threadIdx.x + k * NW * 64;
+      if (e < a.H * a.n_split) l2_ep[k] = a.one_hdr[e / a.n_split];
+    }
+  }
   int qb_ins_u = -1;  // QB: tile row (of this lane's row group) that holds the inserted token — its K chunk is UNswizzled (chunk c)
 
   auto tile = [&](TileRegs& R, const int tbase, const int tbase_next, const bool more_next, auto ti_c) {
@@ -975,16 +984,16 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
       const int um = ins_idx - row0;
       const int kcol = ((c ^ (4 * g + um)) & 15) * VEC;
       Vec16<T> kn, vn;
-      if constexpr (!QB) {
+      if constexpr (!QB && AHEAD) {  // lane c holds chunk c of the new key (requested ahead of the tile); tile row i = 4g + um wants chunk c ^ i
+        const int xm = (4 * g + um) & 15;
+        kn.raw = make_uint4((uint32_t)__shfl_xor((int)qb_kn.raw.x, xm, 16), (uint32_t)__shfl_xor((int)qb_kn.raw.y, xm, 16),
+                            (uint32_t)__shfl_xor((int)qb_kn.raw.z, xm, 16), (uint32_t)__shfl_xor((int)qb_kn.raw.w, xm, 16));
+        vn.raw = qb_vn.raw;
+      } else if constexpr (!QB) {
         kn.load(reinterpret_cast<const T*>(a.k_new) + (size_t)h * D + kcol);
         vn.load(reinterpret_cast<const T*>(a.v_new) + (size_t)h * D + c * VEC);
       }
-      float xq[D / 16];  // l2: the new key again, in the canonical norm's element order (same latency window as kn / vn)
-      if (L2) {
-#pragma unroll
-        for (int i = 0; i < D / 16; i++) xq[i] = ElemTraits<T>::load(reinterpret_cast<const T*>(a.k_new) + (size_t)h * D, c + 16 * i);
-      }
-      const int32_t p_now = *a.input_pos;
+      const int32_t p_now = AHEAD ? p_ins : *a.input_pos;
       // QB: the new row was quantised ahead of the tile (once per step and row), and is attended to through its image like
       // every other row; this lane holds chunk c of K, not the swizzled chunk: the LDS stash below puts it where it belongs
       uint2 knq = make_uint2(0, 0), vnq = make_uint2(0, 0);
@@ -1036,9 +1045,21 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
           if (ins_was_empty && (a.Hc == a.H || h == 0)) atomicAdd(&a.cache_cts[a.Hc == a.H ? h : 0], 1);
         }
         if (L2) {  // l2: cache.py:592-593 — the new key's norm (sumsq_canonical_16's order), model dtype
+          // the canonical order wants elements c, c + 16, ... of the key in lane c; the lanes of this row group hold chunk c (elements
+          // 8c .. 8c + 7): transposed through the wave's V slab (not yet in use: the V tile is stashed after the scores) — eight more
+          // loads per wave of the whole launch, ahead of the tile, cost every workgroup's first K rows ~0.4 us
+          T* scratch = reinterpret_cast<T*>(&sm_v[wave][0][0]);
+          *reinterpret_cast<uint4*>(scratch + c * VEC) = qb_kn.raw;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
           float ss = 0.f;
 #pragma unroll
-          for (int i = 0; i < D / 16; i++) ss = __fadd_rn(ss, __fmul_rn(xq[i], xq[i]));
+          for (int i = 0; i < D / 16; i++) {
+            const float e = ElemTraits<T>::load(scratch, c + 16 * i);
+            ss = __fadd_rn(ss, __fmul_rn(e, e));
+          }
+          __builtin_amdgcn_wave_barrier();  // the V stash must stay behind these reads
 #pragma unroll
           for (int off = 8; off > 0; off >>= 1) ss = __fadd_rn(ss, __shfl_xor(ss, off, 16));
           const float nv = ElemTraits<T>::rnd(cc_sqrt_rn(ss));  // every lane of the row group holds the full sum
@@ -1253,6 +1274,11 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
     // timeout word should that ever not hold.
     const int ns = a.n_split;
     const unsigned tag = one_tag;
+    if constexpr (L2) {
+      // the epoch words of the other heads (requested behind the tile's loads) must have ARRIVED before this workgroup publishes:
+      // whoever bumps a word does so only after every workgroup of the launch has published
+      asm volatile("" ::"v"(l2_ep[0]), "v"(l2_ep[1]), "v"(l2_ep[2]) : "memory");
+    }
     if constexpr (HYB) {
       // the step counter, num_punc / num_special and the head's count are overwritten at the END of this launch by whoever sees
       // that every workgroup has published: their prologue loads must have COMPLETED (not merely been issued) before this

@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--abl", type=int, nargs="+", default=[0], help="measurement bits of the phases word (0 = the product path)")
     ap.add_argument("--quant", action="store_true", help="the fused quantised cache (cache_bits=8, cache_quant_mode='fused')")
     ap.add_argument("--hybrid", action="store_true", help="KVCacheHybrid (the decode-ready state of tools/bench_policies.py)")
+    ap.add_argument("--policy", default=None, choices=["l2", "recent_global", "random", "full"],
+                    help="another policy's step through its class (the state of tools/bench_policies.py)")
     a = ap.parse_args()
     dev, D, H, HQ = "cuda", 128, a.H, a.HQ
     fns = _abi.lib()
@@ -37,11 +39,12 @@ def main():
         kw = dict(max_cache_length=S, global_tokens=4, max_seq_length=4 * S, cache_bits=None, recent_window=10,
                   history_window_size=1, attn_thresholding=False)
         caches = []
-        if a.hybrid:
+        via_class = a.hybrid or a.policy is not None
+        if via_class:
             from bench_policies import make
 
-            caches = [make("hybrid", H, S, D) for _ in range(n_buf)]
-        for _ in range(0 if a.hybrid else n_buf):
+            caches = [make("hybrid" if a.hybrid else a.policy, H, S, D) for _ in range(n_buf)]
+        for _ in range(0 if via_class else n_buf):
             lk = {k: kw[k] for k in rk}
             if a.quant:
                 lk.update(cache_bits=8, cache_quant_mode="fused")
@@ -77,6 +80,9 @@ def main():
             kv = caches[i % n_buf]
             if a.hybrid:  # the class's own step (its workspace, the library's choice of launch form)
                 kv.decode_step(q4, k4, k4, pos, input_ids=ids)
+                return
+            if via_class:
+                kv.decode_step(q4, k4, k4, pos)
                 return
             st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
             if a.quant:
@@ -119,7 +125,7 @@ def main():
             rel = (t[:, :6] - t0).astype(np.float64)
             span = rel[:, 5].max()
             names = ["start", "stream_done", "published", "sentinel_seen", "gathered", "end"]
-            out = {"S": S, "quant": bool(a.quant), "hybrid": bool(a.hybrid), "abl": abl, "us_per_launch_events": round(us_per, 2), "workgroups": int(used.sum()),
+            out = {"S": S, "quant": bool(a.quant), "hybrid": bool(a.hybrid), "policy": a.policy or ("hybrid" if a.hybrid else "heavy_hitter"), "abl": abl, "us_per_launch_events": round(us_per, 2), "workgroups": int(used.sum()),
                    "ticks_total": float(span)}
             base = t[:, 6].min()
             r0, r1, r2 = t[:, 6] - base, t[:, 7] - base, t[:, 8] - base
