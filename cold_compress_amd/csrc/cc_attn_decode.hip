@@ -619,7 +619,12 @@ struct IntC {
 // NT (ONE only): tiles per wave the single-launch step keeps scores for — 1 for caches up to 64 x 64 slots per kv head (the
 // specialised form), 4 or 8 for longer ones (the wave loops over its tiles like the two-launch streaming pass, and its finish
 // loops over them for the per-slot pass).
-template <typename T, int RT, int NW, bool L2, bool ONE = false, bool HYB = false, int QB = 0, int NSUB = 1, int NT = 1>
+// FULL (ONE only; the two-launch pass always has them): the measurement hooks — time stamps (cc_decode_step_trace), ablation
+// bits of the phases word — and the optional group-mean output attn_out are in the code.  The LEAN instantiations (FULL = false)
+// are what the product runs: ~30 never-taken branches and their live ranges less is 0.25-0.5 us of the step (A/B on one box:
+// heavy hitter 10.65 -> 10.38 us, the fused uint8 step 10.35 -> 9.85); a call that wants a stamp, an ablation bit or attn_out is
+// routed to a FULL instantiation (bf16, four query heads per kv head) or to the two-launch step.
+template <typename T, int RT, int NW, bool L2, bool ONE = false, bool HYB = false, int QB = 0, int NSUB = 1, int NT = 1, bool FULL = !ONE>
 __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_split_mfma_kernel(SplitArgs a) {
   static_assert(!(HYB && L2), "the hybrid decision rides the plain streaming pass or the single-launch step");
   static_assert(QB == 0 || (QB == 8 && !L2 && !HYB), "fused quantised cache: 8 bits, heavy hitter / recent_global / random");
@@ -629,6 +634,13 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
   static_assert(sizeof(T) == 2 && (RT == 1 || RT == 2 || RT == 4 || RT == 8), "16-bit caches, up to 8 query heads per pass (the MFMA has 16 columns)");
   static_assert(!ONE || NW == 4, "the single-launch step runs on 4-wave workgroups");
   constexpr int D = 128, VEC = 8, RPW = 4, U = 4;
+  static_assert(FULL || ONE, "the lean form exists for the single-launch step only");
+  if constexpr (!FULL) {  // constants for the optimiser: every `if (a.trace)`, `a.abl & ...`, `if (a.attn_out)` below folds away
+    a.trace = nullptr;
+    a.abl = 0;
+    a.attn_out = nullptr;
+  }
+  if constexpr (ONE) a.ring_col = nullptr;  // (the single-launch steps derive the ring column themselves)
   if (a.ring_col && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0)
     *a.ring_col = (int)(*a.ring_counter % a.ring_W);
   __shared__ __attribute__((aligned(16))) uint4 sm_k[NW][16][16];  // [wave][tile row i][slot]: 4 KiB per wave
@@ -2292,93 +2304,64 @@ static int one_capacity(void (*kernel)(SplitArgs)) {
   if (n_cached < 64) cache[n_cached++] = Entry{kernel, cap};
   return cap;
 }
+typedef void (*OneKernel)(SplitArgs);
+// The single-launch kernel that serves (query heads per kv head rt, tiles per wave nt, kind), or null.  kind: 0 = 16-bit cache
+// (heavy hitter / head-constant policies), 8 = fused quantised cache, -1 = l2, 200 = hybrid.  full: the instantiation with the
+// measurement hooks and attn_out (bf16, rt = 4 only).  ONE table for the residency check and the launch.
 template <typename T>
-static int one_capacity_rt(int rt, int qb = 0) {  // qb: 0 = 16-bit cache, 8 = fused quantised cache, -1 = the l2 policy's instantiation, 104 / 108 = NT tiles, 201 / 208 = hybrid with 1 / up to 8 tiles
-  if (qb == 201) return rt == 8 ? one_capacity(decode_attn_split_mfma_kernel<T, 8, kNW, false, true, true, 0, 1, 1>)
-                                : one_capacity(decode_attn_split_mfma_kernel<T, 4, kNW, false, true, true, 0, 1, 1>);
-  if (qb == 208) return rt == 8 ? one_capacity(decode_attn_split_mfma_kernel<T, 8, kNW, false, true, true, 0, 1, 8>)
-                                : one_capacity(decode_attn_split_mfma_kernel<T, 4, kNW, false, true, true, 0, 1, 8>);
-  if (qb == 104) return rt == 8 ? one_capacity(decode_attn_split_mfma_kernel<T, 8, kNW, false, true, false, 0, 1, 4>)
-                                : one_capacity(decode_attn_split_mfma_kernel<T, 4, kNW, false, true, false, 0, 1, 4>);
-  if (qb == 108) return rt == 8 ? one_capacity(decode_attn_split_mfma_kernel<T, 8, kNW, false, true, false, 0, 1, 8>)
-                                : one_capacity(decode_attn_split_mfma_kernel<T, 4, kNW, false, true, false, 0, 1, 8>);
-  if (qb < 0) {
-    switch (rt) {
-      case 8: return one_capacity(decode_attn_split_mfma_kernel<T, 8, kNW, true, true>);
-      case 4: return one_capacity(decode_attn_split_mfma_kernel<T, 4, kNW, true, true>);
-      case 2: return one_capacity(decode_attn_split_mfma_kernel<T, 2, kNW, true, true>);
-      default: return one_capacity(decode_attn_split_mfma_kernel<T, 1, kNW, true, true>);
+static OneKernel one_kernel(int rt, int nt, int kind, bool full) {
+#define CC_ONE_K(RT_, L2_, HYB_, QB_, NT_, FULL_) decode_attn_split_mfma_kernel<T, RT_, kNW, L2_, true, HYB_, QB_, 1, NT_, FULL_>
+  if (nt < 1 || nt > kOneMaxTiles) return nullptr;
+  if (full) {
+    if constexpr (ElemTraits<T>::code != CC_DT_BF16) {
+      return nullptr;
+    } else {
+      if (rt != 4) return nullptr;
+      if (kind == 200) return nt == 1 ? CC_ONE_K(4, false, true, 0, 1, true) : CC_ONE_K(4, false, true, 0, 8, true);
+      if (kind == -1) return nt == 1 ? CC_ONE_K(4, true, false, 0, 1, true) : nullptr;
+      if (kind == 8) return nt == 1 ? CC_ONE_K(4, false, false, 8, 1, true) : nullptr;
+      if (kind == 0) return nt == 1 ? CC_ONE_K(4, false, false, 0, 1, true) : (nt <= 4 ? CC_ONE_K(4, false, false, 0, 4, true) : CC_ONE_K(4, false, false, 0, 8, true));
+      return nullptr;
     }
   }
-  if (qb) {
+  if (kind == 200) {  // hybrid: 4 or 8 query heads per kv head; one tile per wave or up to eight
+    if (rt == 8) return nt == 1 ? CC_ONE_K(8, false, true, 0, 1, false) : CC_ONE_K(8, false, true, 0, 8, false);
+    if (rt == 4) return nt == 1 ? CC_ONE_K(4, false, true, 0, 1, false) : CC_ONE_K(4, false, true, 0, 8, false);
+    return nullptr;
+  }
+  if (kind == -1) {  // l2: one tile per wave
+    if (nt != 1) return nullptr;
     switch (rt) {
-      case 8: return one_capacity(decode_attn_split_mfma_kernel<T, 8, kNW, false, true, false, 8>);
-      case 4: return one_capacity(decode_attn_split_mfma_kernel<T, 4, kNW, false, true, false, 8>);
-      default: return 0;
+      case 8: return CC_ONE_K(8, true, false, 0, 1, false);
+      case 4: return CC_ONE_K(4, true, false, 0, 1, false);
+      case 2: return CC_ONE_K(2, true, false, 0, 1, false);
+      case 1: return CC_ONE_K(1, true, false, 0, 1, false);
+      default: return nullptr;
     }
+  }
+  if (kind == 8) {  // fused quantised cache: 4 or 8 query heads per kv head, one tile per wave
+    if (nt != 1) return nullptr;
+    if (rt == 8) return CC_ONE_K(8, false, false, 8, 1, false);
+    if (rt == 4) return CC_ONE_K(4, false, false, 8, 1, false);
+    return nullptr;
+  }
+  if (kind != 0) return nullptr;
+  if (nt > 1) {  // several tiles per wave (long caches): 4 or 8 query heads per kv head
+    if (rt == 8) return nt <= 4 ? CC_ONE_K(8, false, false, 0, 4, false) : CC_ONE_K(8, false, false, 0, 8, false);
+    if (rt == 4) return nt <= 4 ? CC_ONE_K(4, false, false, 0, 4, false) : CC_ONE_K(4, false, false, 0, 8, false);
+    return nullptr;
   }
   switch (rt) {
-    case 8: return one_capacity(decode_attn_split_mfma_kernel<T, 8, kNW, false, true>);
-    case 4: return one_capacity(decode_attn_split_mfma_kernel<T, 4, kNW, false, true>);
-    case 2: return one_capacity(decode_attn_split_mfma_kernel<T, 2, kNW, false, true>);
-    default: return one_capacity(decode_attn_split_mfma_kernel<T, 1, kNW, false, true>);
+    case 8: return CC_ONE_K(8, false, false, 0, 1, false);
+    case 4: return CC_ONE_K(4, false, false, 0, 1, false);
+    case 2: return CC_ONE_K(2, false, false, 0, 1, false);
+    case 1: return CC_ONE_K(1, false, false, 0, 1, false);
+    default: return nullptr;
   }
+#undef CC_ONE_K
 }
-template <typename T>
-static int launch_one(const SplitArgs& a, const Plan& p, int H, hipStream_t st) {
-  dim3 grid(p.n_split, H, 1), block(kNW * 64);
-  const int nt = p.rows_per_split / rows_per_iter(128, ElemTraits<T>::code);
-  if (a.hyb.strategies != nullptr) {  // hybrid: 4 or 8 query heads per kv head; one tile per wave or up to eight
-    if (a.qparams != nullptr || a.key_norm != nullptr || (p.rt != 4 && p.rt != 8) || nt > kOneMaxTiles) return CC_ERR_UNSUPPORTED;
-    if (nt == 1) {
-      if (p.rt == 8) hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 8, kNW, false, true, true, 0, 1, 1>), grid, block, 0, st, a);
-      else hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 4, kNW, false, true, true, 0, 1, 1>), grid, block, 0, st, a);
-    } else {
-      if (p.rt == 8) hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 8, kNW, false, true, true, 0, 1, 8>), grid, block, 0, st, a);
-      else hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 4, kNW, false, true, true, 0, 1, 8>), grid, block, 0, st, a);
-    }
-    CC_LAUNCH_CHECK();
-    return CC_OK;
-  }
-  if (nt > 1) {  // several tiles per wave (long caches): 16-bit caches, heavy hitter / head-constant policies, RT 4 or 8
-    if (a.qparams != nullptr || a.key_norm != nullptr || (p.rt != 4 && p.rt != 8) || nt > kOneMaxTiles) return CC_ERR_UNSUPPORTED;
-    if (nt <= 4) {
-      if (p.rt == 8) hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 8, kNW, false, true, false, 0, 1, 4>), grid, block, 0, st, a);
-      else hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 4, kNW, false, true, false, 0, 1, 4>), grid, block, 0, st, a);
-    } else {
-      if (p.rt == 8) hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 8, kNW, false, true, false, 0, 1, 8>), grid, block, 0, st, a);
-      else hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 4, kNW, false, true, false, 0, 1, 8>), grid, block, 0, st, a);
-    }
-    CC_LAUNCH_CHECK();
-    return CC_OK;
-  }
-  if (a.qparams != nullptr) {
-    switch (p.rt) {
-      case 8: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 8, kNW, false, true, false, 8>), grid, block, 0, st, a); break;
-      case 4: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 4, kNW, false, true, false, 8>), grid, block, 0, st, a); break;
-      default: return CC_ERR_UNSUPPORTED;
-    }
-    CC_LAUNCH_CHECK();
-    return CC_OK;
-  }
-  if (a.key_norm != nullptr) {  // l2
-    switch (p.rt) {
-      case 8: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 8, kNW, true, true>), grid, block, 0, st, a); break;
-      case 4: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 4, kNW, true, true>), grid, block, 0, st, a); break;
-      case 2: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 2, kNW, true, true>), grid, block, 0, st, a); break;
-      default: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 1, kNW, true, true>), grid, block, 0, st, a); break;
-    }
-    CC_LAUNCH_CHECK();
-    return CC_OK;
-  }
-  switch (p.rt) {
-    case 8: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 8, kNW, false, true>), grid, block, 0, st, a); break;
-    case 4: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 4, kNW, false, true>), grid, block, 0, st, a); break;
-    case 2: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 2, kNW, false, true>), grid, block, 0, st, a); break;
-    default: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 1, kNW, false, true>), grid, block, 0, st, a); break;
-  }
-  CC_LAUNCH_CHECK();
-  return CC_OK;
+static OneKernel one_kernel_dt(int dtype, int rt, int nt, int kind, bool full) {
+  return dtype == CC_DT_BF16 ? one_kernel<bf16_t>(rt, nt, kind, full) : (dtype == CC_DT_F16 ? one_kernel<f16_t>(rt, nt, kind, full) : nullptr);
 }
 }  // namespace
 
@@ -2390,22 +2373,20 @@ size_t cc_decode_attn_workspace_bytes(int32_t HQ, int32_t H, int32_t S, int32_t 
   return kOneBytes + base_workspace_bytes(p, HQ, H, S, D, dtype);
 }
 
-static int32_t one_available(int32_t HQ, int32_t H, int32_t S, int32_t D, int32_t dtype, int qb) {
-  if (HQ <= 0 || H <= 0 || HQ % H || S <= 0 || D <= 0 || !cc_dt_ok(dtype)) return 0;
+// kind: see one_kernel.  Returns the kernel when the shape is eligible AND all its workgroups stay resident at once, else null.
+static OneKernel one_pick(int32_t HQ, int32_t H, int32_t S, int32_t D, int32_t dtype, int kind, bool full) {
+  if (HQ <= 0 || H <= 0 || HQ % H || S <= 0 || D <= 0 || !cc_dt_ok(dtype)) return nullptr;
   const Plan p = make_plan(HQ, H, S, D, dtype);
   const int nt = one_tiles(p, HQ, H, D, dtype);
-  if (nt == 0) return 0;
-  if (qb == 200) {  // hybrid: its own instantiations, 4 or 8 query heads per kv head
-    if (p.rt != 4 && p.rt != 8) return 0;
-    qb = nt == 1 ? 201 : 208;
-  } else if (nt > 1) {  // the multi-tile form serves the plain 16-bit policies only
-    if (qb != 0) return 0;
-    qb = nt <= 4 ? 104 : 108;
-  }
+  if (nt == 0) return nullptr;
   // l2: every thread gathers at most three workgroups' norm maxima
-  if (qb < 0 && H * p.n_split > 3 * kNW * 64) return 0;
-  const int cap = dtype == CC_DT_BF16 ? one_capacity_rt<bf16_t>(p.rt, qb) : one_capacity_rt<f16_t>(p.rt, qb);
-  return p.n_split * H <= cap ? 1 : 0;
+  if (kind == -1 && H * p.n_split > 3 * kNW * 64) return nullptr;
+  const OneKernel k = one_kernel_dt(dtype, p.rt, nt, kind, full);
+  if (!k) return nullptr;
+  return p.n_split * H <= one_capacity(k) ? k : nullptr;
+}
+static int32_t one_available(int32_t HQ, int32_t H, int32_t S, int32_t D, int32_t dtype, int kind) {
+  return one_pick(HQ, H, S, D, dtype, kind, false) ? 1 : 0;
 }
 int32_t cc_decode_step_single_launch(int32_t HQ, int32_t H, int32_t S, int32_t D, int32_t dtype) {
   return one_available(HQ, H, S, D, dtype, 0);
@@ -2526,8 +2507,16 @@ static int attn_impl(const void* q, const void* k, const void* v, const uint8_t*
                                   ((fs->policy == 2 || (fs->policy == 3 && fs->rand_next)) && !hh_num && fs->c->Hp == 1) ||
                                   (fs->policy == 4 && fs->key_norm && !hh_num && fs->c->Hp == H) ||
                                   (fs->policy == 6 && !hh_num && fs->c->Hp == H && fs->c->Hc == H));
-    const bool one_ok = policy_ok && (!rh || fs->policy == 6) && !probs_out && !attn_out_needs_probs(fs, attn_out) &&
-                        one_available(HQ, H, S, D, dtype, fs->qparams ? 8 : (fs->policy == 4 ? -1 : (fs->policy == 6 ? 200 : 0))) == 1;
+    // the lean kernels carry no measurement hooks and no attn_out: a call that wants one of them runs a FULL instantiation where
+    // there is one (a time stamp alone is not worth leaving the product kernel for)
+    const int kind = !fs ? 0 : (fs->qparams ? 8 : (fs->policy == 4 ? -1 : (fs->policy == 6 ? 200 : 0)));
+    const bool want_full = attn_out != nullptr || sa.abl != 0;
+    OneKernel kern = nullptr;
+    if (policy_ok && (!rh || fs->policy == 6) && !probs_out && !attn_out_needs_probs(fs, attn_out)) {
+      if (want_full || g_one_trace) kern = one_pick(HQ, H, S, D, dtype, kind, true);
+      if (!kern && !want_full) kern = one_pick(HQ, H, S, D, dtype, kind, false);
+    }
+    const bool one_ok = kern != nullptr;
     if (one_asked && !one_ok) return CC_ERR_UNSUPPORTED;
     if (one_ok) {
       char* ob = reinterpret_cast<char*>(workspace);
@@ -2545,7 +2534,9 @@ static int attn_impl(const void* q, const void* k, const void* v, const uint8_t*
           sa.ring_num = rh->num; sa.ring_acc = reinterpret_cast<unsigned long long*>(rh->acc); sa.ring_wsum = rh->wsum;
         }
       }
-      return dtype == CC_DT_BF16 ? launch_one<bf16_t>(sa, p, H, st) : launch_one<f16_t>(sa, p, H, st);
+      hipLaunchKernelGGL(kern, dim3(p.n_split, H, 1), dim3(kNW * 64), 0, st, sa);
+      CC_LAUNCH_CHECK();
+      return CC_OK;
     }
   }
   if (phases & 1) {
