@@ -246,6 +246,10 @@ int cc_decode_step_heavy_hitter_ring(const cc_kv_view* c, const void* q, const v
  * self-validating tagged granules (write-through stores), waits — bounded — for the other workgroups of its kv head,
  * and finishes its own 64 slots from the scores still in its registers.  pos, mask, cache_cts, K/V, num, denom, counter,
  * attn_out and the next keys are bit-identical to the two-launch step; y agrees up to fp32 summation order.
+ * The kernels the single launch normally runs carry no measurement hooks and no attn_out store (0.3-0.5 us of the step): a call
+ * that passes attn_out, sets a measurement bit of `phases` or runs while a trace buffer is installed (cc_decode_step_trace) is
+ * served by a full-featured instantiation where one exists (bf16, HQ / H = 4), by the two-launch step otherwise — with
+ * CC_PHASE_ONE_LAUNCH, CC_ERR_UNSUPPORTED (a trace buffer alone never changes which step runs: no stamps are written then).
  * Workspace contract for this mode: the first 4 KiB + 288 KiB + 16 MiB of every decode workspace (sized in by
  * cc_decode_attn_workspace_bytes, at fixed offsets whatever the shape, so that caches of different lengths may share one
  * workspace) hold per-head epoch words and the granules; they must be ZERO before first use and written by nobody
