@@ -132,6 +132,67 @@ def test_single_launch_equals_two_launch_long(dtype, H, HQ, S, D, T, steps):
     assert b.step_status(HQ) == 0
 
 
+def _raw_hh_step(kv, q, k1, v1, p, HQ, phases, attn_out):
+    """cc_decode_step_heavy_hitter_phases straight through the C ABI (the class never asks for attn_out)."""
+    import math
+    from cold_compress_amd import _abi
+    from cold_compress_amd.attention_utils import _workspace
+    from cold_compress_amd.cache import _DT, _ptr, _stream
+
+    D = kv.head_dim
+    y = torch.empty((1, HQ, 1, D), dtype=q.dtype, device=q.device)
+    nbytes = _abi.lib()["cc_decode_attn_workspace_bytes"](HQ, kv.n_heads, kv.max_cache_length, D, _DT[kv.k_cache.dtype])
+    ws = _workspace(nbytes, q.device)
+    k, v = kv._new_rows(k1, v1)
+    rc = _abi.lib()["cc_decode_step_heavy_hitter_phases"](
+        kv._view(), _ptr(q.reshape(HQ, D).contiguous()), _ptr(k), _ptr(v), _ptr(p), _ptr(kv.attn_history_num), _ptr(kv.attn_history_denom),
+        _ptr(kv.attn_counter), _ptr(kv.next_key), int(kv.global_tokens), int(kv.recent_window), HQ, 1.0 / math.sqrt(D), _ptr(y),
+        _ptr(attn_out), _ptr(ws), ws.numel(), _stream(), phases)
+    return rc, y
+
+
+@pytest.mark.parametrize("dtype,full_exists", [(torch.bfloat16, True), (torch.float16, False)])
+def test_attn_out_is_served_by_the_full_single_launch_kernel_or_by_two_launches(dtype, full_exists):
+    """The kernels the single launch normally runs have no attn_out store (include/coldcompress.h): a call that passes attn_out
+    gets a full-featured instantiation (bf16, four query heads per kv head) or the two-launch step; demanding ONE launch where
+    there is no such instantiation is CC_ERR_UNSUPPORTED.  attn_out and every buffer equal the two-launch step's bit for bit."""
+    from cold_compress_amd import _abi
+
+    H, HQ, S, D, T = 8, 32, 4096, 128, 4090
+    a, b = _mk(H, S, D, dtype), _mk(H, S, D, dtype)
+    for kv in (a, b):
+        _seed(kv, torch.Generator().manual_seed(31), T)
+    if not a.single_launch_active(HQ):
+        pytest.skip("shape not eligible for the single-launch step on this device")
+    gen = torch.Generator().manual_seed(6)
+    oa = torch.zeros(H, S, dtype=dtype, device=DEV)
+    ob = torch.zeros(H, S, dtype=dtype, device=DEV)
+    for t in range(6):
+        p = torch.tensor([T + 1 + t], dtype=torch.int32, device=DEV)
+        k1 = torch.randn(1, H, 1, D, generator=gen).to(dtype).to(DEV)
+        v1 = torch.randn(1, H, 1, D, generator=gen).to(dtype).to(DEV)
+        q = torch.randn(1, HQ, 1, D, generator=gen).to(dtype).to(DEV)
+        for kv in (a, b):
+            if not kv._next_valid:
+                kv.prepare_decode(p)
+        rc, ya = _raw_hh_step(a, q, k1, v1, p, HQ, 3 | _abi.CC_PHASE_TWO_LAUNCH, oa)
+        assert rc == 0
+        rc1, yb = _raw_hh_step(b, q, k1, v1, p, HQ, 3 | _abi.CC_PHASE_ONE_LAUNCH, ob)
+        if full_exists:
+            assert rc1 == 0
+        else:
+            assert rc1 != 0  # no full-featured f16 instantiation: the demand cannot be met ...
+            rc2, yb = _raw_hh_step(b, q, k1, v1, p, HQ, 3, ob)  # ... the library's own choice (two launches) serves the call
+            assert rc2 == 0
+        torch.cuda.synchronize()
+        assert torch.equal(oa, ob) and float(oa.float().abs().sum()) > 0, f"step {t}: attn_out"
+        assert torch.allclose(ya.float(), yb.float(), rtol=2.0 ** -7, atol=1e-6), f"step {t}: y"
+        for (na, ta), (nb, tb) in zip(a.named_buffers(), b.named_buffers()):
+            if na != "next_key":
+                assert torch.equal(ta, tb), f"step {t}: {na}"
+    assert b.step_status(HQ) == 0
+
+
 def test_single_launch_in_hipgraph():
     """Replayed from a hipGraph (the way the harness decodes), with several layers sharing one workspace: the epoch words
     advance on the device, so replays need no reset node; results equal the two-launch twins bit for bit."""
