@@ -625,7 +625,7 @@ class KVCacheHeavyHitter(_TrackedWindowSums, KVCacheHeadSpecific):
         self._next_valid = False  # the three-call path mutates pos / history outside the pipeline
         return super().update_kv(input_pos, k_val, v_val, is_prefill, **kwargs)
 
-    # ------------------------------------------------------------------ fused decode step (2 launches per layer)
+    # ------------------------------------------------------------------ fused decode step (1 or 2 launches per layer)
     def prepare_decode(self, input_pos):
         """Seed the pipeline: arg-min keys for `input_pos` from the current state (one select-only launch)."""
         if self.history_window_size != 1:  # finite history window: scored from the tracked window sums
@@ -640,8 +640,8 @@ class KVCacheHeavyHitter(_TrackedWindowSums, KVCacheHeadSpecific):
         self._next_valid = True
 
     def decode_step(self, query, k_val, v_val, input_pos, scale=None):
-        """update_kv + attention over the pruned cache + update_state for one decode token in two launches
-        (cc_decode_step_heavy_hitter).  Bit-identical to the three-call sequence; positions must advance by one
+        """update_kv + attention over the pruned cache + update_state for one decode token in ONE launch where the shape and the
+        device allow it (include/coldcompress.h: single-launch layer step), two otherwise (cc_decode_step_heavy_hitter).  Bit-identical to the three-call sequence; positions must advance by one
         between calls (any update_kv / update_state / reset in between re-seeds automatically)."""
         from .attention_utils import _workspace
         import math
@@ -804,7 +804,7 @@ class KVCacheHybrid(_TrackedWindowSums, KVCacheHeadSpecific):
         self._table = None
         self._state_fused = False  # set by the attention op when its combine pass already recorded this step's attention
         self._init_window_state()
-        # fused two-launch decode step (decode_step): every head's eviction candidate for the NEXT position, [H, NK]
+        # fused decode step (decode_step): every head's eviction candidate for the NEXT position, [H, NK]
         nk = int(_abi.lib()["cc_hh_next_key_slots"](S)) if _abi.built() else 0
         self.register_buffer("next_key", torch.full((n_heads, max(nk, 1)), -1, dtype=torch.int64), persistent=False)
         self._next_valid = False
@@ -868,7 +868,7 @@ class KVCacheHybrid(_TrackedWindowSums, KVCacheHeadSpecific):
         """Kept tokens first, original order preserved inside each class (stable)."""
         return torch.argsort((~mask_optimal).to(torch.int8), dim=1, stable=True)
 
-    # ------------------------------------------------------------------ fused decode step (2 launches per layer)
+    # ------------------------------------------------------------------ fused decode step (1 or 2 launches per layer)
     def supports_fused_step(self):
         """cc_decode_step_hybrid: 16-bit caches with head_dim 128, profiled heads, and the reference's effective
         no-reset-on-evict behaviour (see the class docstring)."""
@@ -892,9 +892,10 @@ class KVCacheHybrid(_TrackedWindowSums, KVCacheHeadSpecific):
         self._next_valid = True
 
     def decode_step(self, query, k_val, v_val, input_pos, scale=None, input_ids=None):
-        """update_kv + attention + update_state of one decode token in two launches (cc_decode_step_hybrid): the per-head
-        decision and the insert ride the K/V streaming pass, the ring update, the next candidates, the counts and num_punc
-        the combine pass.  Bit-identical to the three-launch sequence; positions must advance by one between calls."""
+        """update_kv + attention + update_state of one decode token (cc_decode_step_hybrid): the per-head decision and the
+        insert ride the K/V streaming pass; the ring update, the next candidates, the counts and num_punc its tail (ONE launch:
+        cc_decode_step_hybrid_single_launch) or the combine pass (two launches).  Every buffer bit-identical to the three-launch
+        sequence (y within one rounding in the single-launch form); positions must advance by one between calls."""
         from .attention_utils import _workspace
         import math
 

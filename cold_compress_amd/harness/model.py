@@ -135,7 +135,7 @@ class Attention(nn.Module):
         self.n_head, self.head_dim = config.n_head, config.head_dim
         self.n_local_heads, self.dim = config.n_local_heads, config.dim
         self.fuse_state_update = True  # fold cache.py:690-723 into the decode attention combine pass
-        self.fuse_decode_step = True   # heavy hitter: whole update_kv + attention + update_state in two launches
+        self.fuse_decode_step = True   # whole update_kv + attention + update_state in one launch (two where the shape does not allow one)
 
     def compress_prompt(self, input_pos, k_val, v_val, attn):
         if self.kv_cache.max_cache_length < input_pos.shape[0]:
