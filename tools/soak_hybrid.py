@@ -67,6 +67,13 @@ def main():
         print(f"layer {li}: counter {int(kv.attn_counter)} requires_hh {bool(kv.requires_heavy_hitter)} strategies "
               f"{kv.cache_strategies.tolist()} tracked == rebuild: {ok}", flush=True)
         bad += not ok
+    from cold_compress_amd.attention_utils import single_launch_status
+
+    kv0 = model.layers[0].attention.kv_cache
+    one = int(_abi.lib()["cc_decode_step_hybrid_single_launch"](cfg["n_head"], kv0.n_heads, kv0.max_cache_length, kv0.head_dim, 1))
+    st = single_launch_status()
+    print(f"single-launch hybrid step for this shape: {bool(one)}; hand-off timeouts: {st}")
+    bad += st
     print("SOAK", "FAIL" if bad else "OK")
     sys.exit(1 if bad else 0)
 
