@@ -132,6 +132,86 @@ def test_hybrid_decode_fuzz_vs_oracle(oracle):
     _hybrid_decode_vs_oracle(oracle, 4, 4700, 128, torch.bfloat16, 399, [1, 2, 0, 3], [4700, 4699, 30, 2500], 9000, steps=5, tag="split")
 
 
+@pytest.mark.parametrize("H,HQ,S,strat_list,cts_list", [(8, 32, 2048, [0, 1, 2, 3, 1, 2, 0, 1], [300, 900, 800, 1500, 716, 1200, 208, 720]),
+                                                         (5, 20, 300, [1, 2, 0, 3, 2], [300, 299, 30, 150, 120]),
+                                                         (3, 6, 200, [2, 1, 0], [200, 100, 60])])
+def test_hybrid_fused_step_vs_oracle_pipeline(oracle, H, HQ, S, strat_list, cts_list):
+    """KVCacheHybrid.decode_step — ONE launch for the first two shapes (HQ / H = 4), two for the third — against the oracle's
+    own composition of the step (cc_decode_step_hybrid_cpu: decision + insert, attention, ring update with tracked window sums):
+    the two sides compute their own attention, so slots, counts, denominators, punctuation state, counters and K/V are compared
+    exactly and y within the bf16 tolerance of SURVEY 8(c) (3)."""
+    import cold_compress_amd.cache as cache
+
+    D, dtype, W, g, pos_hi = 128, torch.bfloat16, 400, 4, 3 * S
+    code = DT_CODE[dtype]
+    strategies = [{"strategy": "window", "recent_window": 0.1},
+                  {"strategy": "window_heavy_hitter", "heavy_hitter_frac": 0.25, "recent_window": 0.1},
+                  {"strategy": "special_punc_heavy_hitter", "heavy_hitter_frac": 0.3}, {"strategy": "full"}]
+    gen = torch.Generator().manual_seed(1000 + S)
+    kw = dict(max_cache_length=S, max_seq_length=S, cache_bits=None, global_tokens=g, token_ids=TOKEN_IDS, min_recovery_frac=0.9,
+              hybrid_strategies=strategies)
+    with torch.device(DEV):
+        kv = cache.KVCacheHybrid(1, H, D, dtype, **kw)
+    strat = torch.tensor(strat_list, dtype=torch.int64)
+    cts = torch.tensor(cts_list, dtype=torch.int32)
+    kv.cache_strategies = strat.to(DEV)
+    kv.cache_cts.copy_(cts)
+    pos = torch.full((H, S), -1, dtype=torch.int32)
+    for h in range(H):
+        pos[h, : cts[h]] = torch.sort(torch.randperm(pos_hi, generator=gen)[: cts[h]]).values.int()
+    kv.pos[0] = pos.to(DEV)
+    kv.mask[0, :, 0] = (torch.arange(S).view(1, S) < cts.view(H, 1)).to(DEV)
+    kv.k_cache.copy_(torch.randn(1, H, S, D, generator=gen).to(dtype))
+    kv.v_cache.copy_(torch.randn(1, H, S, D, generator=gen).to(dtype))
+    kv.attn_history_num.copy_((torch.rand(1, H, S, W, generator=gen) * 0.01).to(dtype))
+    kv.attn_history_denom.copy_(torch.randint(0, 600, (1, H, S), generator=gen, dtype=torch.int32))
+    kv.special_mask[0] = (torch.rand(H, S, generator=gen) < 0.01).to(DEV)
+    kv.punc_mask[0] = (torch.rand(H, S, generator=gen) < 0.02).to(DEV)
+    kv.num_special.fill_(20)
+    kv.num_punc.fill_(40)
+    kv.attn_counter.fill_(777)
+    assert kv.supports_fused_step()
+    o = oracle
+    st = dict(k=to_np(kv.k_cache.cpu()[0]), v=to_np(kv.v_cache.cpu()[0]), pos=kv.pos.cpu()[0].numpy().copy(),
+              mask=kv.mask.cpu()[0, :, 0].numpy().astype(np.uint8), cts=kv.cache_cts.cpu().numpy().copy(),
+              num=to_np(kv.attn_history_num.cpu()[0]), denom=kv.attn_history_denom.cpu()[0].numpy().copy(),
+              special=kv.special_mask.cpu()[0].numpy().astype(np.uint8), punc=kv.punc_mask.cpu()[0].numpy().astype(np.uint8),
+              nsp=np.array([20], np.int32), npc=np.array([40], np.int32), ctr=np.array([777], np.int64),
+              wsum=np.zeros(H * S, np.float32), acc=np.zeros(o.fns()["cc_hh_ring_acc_words"](H, S, W, code), np.uint64))
+    o.call("cc_hh_ring_window_sums", o.ptr(st["num"]), H, S, W, code, o.ptr(st["wsum"]), o.ptr(st["acc"]), None)
+    tab = policy_table(strategies, S)
+    pids = np.array(TOKEN_IDS["punctuation"], np.int64)
+    key = np.zeros(8 * H * ((S + 127) // 128), np.uint64)
+    for t in range(8):
+        p = torch.tensor([pos_hi + 100 + t], dtype=torch.int32)
+        tok = torch.tensor([[6 if t in (3, 4) else 30]])
+        k1 = torch.randn(1, H, 1, D, generator=gen).to(dtype)
+        v1 = torch.randn(1, H, 1, D, generator=gen).to(dtype)
+        q = torch.randn(1, HQ, 1, D, generator=gen).to(dtype)
+        y = kv.decode_step(q.to(DEV), k1.to(DEV), v1.to(DEV), p.to(DEV), input_ids=tok.to(DEV))
+        torch.cuda.synchronize()
+        view = o.view(st["k"], st["v"], st["pos"], st["mask"], st["cts"], code)
+        yo = np.zeros((HQ, D), np.uint16)
+        stn = strat.numpy().copy()
+        o.call("cc_decode_step_hybrid", C.byref(view), o.ptr(to_np(q.reshape(HQ, D))), o.ptr(to_np(k1.reshape(H, D))),
+               o.ptr(to_np(v1.reshape(H, D))), o.ptr(p.numpy().copy()), o.ptr(stn), o.ptr(tab), len(tab), o.ptr(st["num"]), o.ptr(st["denom"]),
+               o.ptr(st["ctr"]), W, o.ptr(st["acc"]), o.ptr(st["wsum"]), o.ptr(st["special"]), o.ptr(st["punc"]),
+               o.ptr(tok.numpy().astype(np.int64).reshape(-1).copy()), o.ptr(pids), len(pids), o.ptr(st["nsp"]), o.ptr(st["npc"]), o.ptr(key), g, HQ,
+               1.0 / math.sqrt(D), o.ptr(yo), None, None, 0, None)
+        assert np.array_equal(kv.pos.cpu()[0].numpy(), st["pos"]), f"step {t}: pos"
+        assert np.array_equal(kv.cache_cts.cpu().numpy(), st["cts"]), f"step {t}: counts"
+        yr = torch.from_numpy(yo.view(np.int16).copy()).view(torch.bfloat16).float()
+        assert (y.cpu().float()[0, :, 0] - yr).abs().max() < 1e-2, f"step {t}: y"
+    assert np.array_equal(kv.attn_history_denom.cpu()[0].numpy(), st["denom"])
+    assert np.array_equal(kv.punc_mask.cpu()[0].numpy().astype(np.uint8), st["punc"]) and int(kv.num_punc) == int(st["npc"][0])
+    assert np.array_equal(kv.mask.cpu()[0, :, 0].numpy().astype(np.uint8), st["mask"])
+    assert np.array_equal(to_np(kv.k_cache.cpu()[0]), st["k"]) and int(kv.attn_counter) == int(st["ctr"][0])
+    # the rings hold each side's own probabilities: one rounding of the model dtype apart at most
+    ring_g = kv.attn_history_num.cpu()[0].float()
+    ring_o = torch.from_numpy(st["num"].view(np.int16).copy()).view(torch.bfloat16).float().reshape(H, S, W)
+    assert (ring_g - ring_o).abs().max() <= 2.0 ** -8 * max(float(ring_o.abs().max()), 1e-6) + 1e-6
+
+
 def _hybrid_decode_vs_oracle(oracle, H, S, D, dtype, seed, strat_list, cts_list, pos_hi, steps=10, tag=""):
     import cold_compress_amd.cache as cache
 
