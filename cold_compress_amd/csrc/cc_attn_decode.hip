@@ -612,7 +612,9 @@ struct IntC {
 };
 
 // L2: the l2 policy's norm bookkeeping (its own instantiation: the others pay nothing).  ONE: the single-launch layer
-// step of the heavy-hitter policy (needs R == RT, one tile per wave, every workgroup of the grid co-resident).
+// step (heavy hitter, recent_global / full, random; with L2: l2; with HYB: the FastGen hybrid cache) — needs R == RT, at most
+// 64 workgroups per kv head, every workgroup of the grid co-resident.  HYB: the per-head decision of KVCacheHybrid at the top of
+// the pass (two-launch form: candidates, ring and counts follow in the combine pass; with ONE: in the tail, on all lanes).
 // QB = 8: the fused quantised cache (uint8 images + per-row (scale, minimum)), dequantised on the way to the LDS slabs.
 // NSUB = 2 (multi-tile splits only): two tiles per wave and iteration, each with its own staging registers — the loads of a
 // tile go out two half-iterations ahead of their use instead of one (twice the bytes in flight per wave).
