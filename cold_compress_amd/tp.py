@@ -91,21 +91,41 @@ class OneShotAllReduce:
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         self.max_bytes = int(max_bytes)
         fns = _abi.lib()
-        comm = C.c_void_p()
-        _abi.check(fns["cc_allreduce_create"](self.rank, self.world, self.max_bytes, C.byref(comm)), "cc_allreduce_create")
-        self._comm = comm
-        nb = int(fns["cc_allreduce_handle_bytes"]())
-        mine = (C.c_uint8 * nb)()
-        _abi.check(fns["cc_allreduce_export"](comm, mine), "cc_allreduce_export")
         on_dev = dist.get_backend(group) == "nccl"
         dev = torch.device("cuda", torch.cuda.current_device()) if on_dev else torch.device("cpu")
+        nb = int(fns["cc_allreduce_handle_bytes"]())
+
+        def agree(ok):
+            """MIN over the ranks of a local verdict: every rank runs the SAME sequence of collectives whatever fails locally
+            (a rank that raised before a collective its peers entered would leave them waiting for ever)."""
+            f = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(f, op=dist.ReduceOp.MIN, group=group)
+            return int(f.item()) == 1
+
+        comm, mine, err = C.c_void_p(), (C.c_uint8 * nb)(), ""
+        self._comm = None
+        try:
+            _abi.check(fns["cc_allreduce_create"](self.rank, self.world, self.max_bytes, C.byref(comm)), "cc_allreduce_create")
+            self._comm = comm
+            _abi.check(fns["cc_allreduce_export"](comm, mine), "cc_allreduce_export")
+        except Exception as e:
+            err = f"{type(e).__name__}: {e}"
         h = torch.tensor(list(mine), dtype=torch.uint8, device=dev)
         allh = [torch.empty_like(h) for _ in range(self.world)]
         dist.all_gather(allh, h, group=group)
-        flat = torch.cat([t.cpu() for t in allh]).contiguous()
-        buf = (C.c_uint8 * flat.numel()).from_buffer_copy(flat.numpy().tobytes())
-        _abi.check(fns["cc_allreduce_connect"](comm, buf), "cc_allreduce_connect")
-        dist.barrier(group=group)  # every rank has mapped every buffer before the first store into one
+        if not agree(not err):
+            self.close()
+            raise RuntimeError(f"one-shot all-reduce: buffer creation / export failed on some rank ({err or 'another rank'})")
+        try:
+            flat = torch.cat([t.cpu() for t in allh]).contiguous()
+            buf = (C.c_uint8 * flat.numel()).from_buffer_copy(flat.numpy().tobytes())
+            _abi.check(fns["cc_allreduce_connect"](comm, buf), "cc_allreduce_connect")
+        except Exception as e:
+            err = f"{type(e).__name__}: {e}"
+        # (also the barrier: every rank has mapped every buffer before the first store into one)
+        if not agree(not err):
+            self.close()
+            raise RuntimeError(f"one-shot all-reduce: peer buffers could not be mapped on some rank ({err or 'another rank'})")
 
     def fits(self, t):
         return t.is_cuda and t.is_contiguous() and t.numel() * t.element_size() <= self.max_bytes and t.data_ptr() % 16 == 0 \
@@ -152,10 +172,12 @@ def enable_oneshot_allreduce(max_bytes=64 * 1024, verify=True):
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 1:
             g = torch.Generator(device=dev).manual_seed(4321 + dist.get_rank())
-            for it in range(3):
+            for it in range(3):  # (no early exit: a rank that left the loop would leave its peers alone in the next RCCL call)
                 x = torch.randn(4096, device=dev, generator=g).to(torch.bfloat16)
                 ref = x.clone()
                 dist.all_reduce(ref, op=dist.ReduceOp.SUM)
+                if not ok:
+                    continue
                 got = x.clone()
                 try:
                     comm.all_reduce(got)
@@ -165,7 +187,6 @@ def enable_oneshot_allreduce(max_bytes=64 * 1024, verify=True):
                     good, why = False, f"{type(e).__name__}: {e}"
                 if not good:
                     ok, why = 0, why or f"self-test {it}: status {comm.status()} or sums differ from RCCL's"
-                    break
             flag = torch.tensor([ok], dtype=torch.int32, device=dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         ok = int(flag.item())
