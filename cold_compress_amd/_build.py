@@ -55,7 +55,7 @@ def build(force=False, verbose=False):
 
     with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as ex:
         list(ex.map(run, jobs))
-    if jobs or not os.path.exists(OUT):
+    if jobs or not os.path.exists(OUT) or any(os.path.getmtime(o) > os.path.getmtime(OUT) for o in objs):  # (an object compiled by hand)
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT, *objs])
     return OUT
 

@@ -633,8 +633,15 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
   static_assert(NSUB == 1 || (NSUB == 2 && !ONE), "two tiles per iteration: the two-launch streaming pass only");
   static_assert(NT == 1 || (ONE && !L2 && QB == 0 && NSUB == 1), "several tiles per wave in the single-launch step: 16-bit caches, heavy hitter / head-constant policies");
   constexpr bool ONE1 = ONE && NT == 1;  // the single-tile form: no loop tail, no rescale, per-slot state requested ahead of the tile
+  // EML (r3): the workgroup's (m, l) pairs leave EARLY — right behind the scores, while the V rows are still in flight — so that
+  // the final (M, L) of the head, the probabilities, the history update and the next-eviction keys run in the shadow of the
+  // partial-O exchange; what is left behind the last O granule is the y fold alone
+#ifndef CC_AB_EML
+#define CC_AB_EML 1
+#endif
+  constexpr bool EML = CC_AB_EML && ONE1 && !L2 && !HYB;
   static_assert(sizeof(T) == 2 && (RT == 1 || RT == 2 || RT == 4 || RT == 8), "16-bit caches, up to 8 query heads per pass (the MFMA has 16 columns)");
-  static_assert(!ONE || NW == 4, "the single-launch step runs on 4-wave workgroups");
+  static_assert(!ONE || NW == 4 || (NW == 8 && NT == 1 && !HYB), "the single-launch step runs on 4-wave workgroups, or on ONE 8-wave workgroup per CU (single tile; not the hybrid cache)");
   constexpr int D = 128, VEC = 8, RPW = 4, U = 4;
   static_assert(FULL || ONE, "the lean form exists for the single-launch step only");
   if constexpr (!FULL) {  // constants for the optimiser: every `if (a.trace)`, `a.abl & ...`, `if (a.attn_out)` below folds away
@@ -647,6 +654,8 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
     *a.ring_col = (int)(*a.ring_counter % a.ring_W);
   __shared__ __attribute__((aligned(16))) uint4 sm_k[NW][16][16];  // [wave][tile row i][slot]: 4 KiB per wave
   __shared__ __attribute__((aligned(16))) uint4 sm_v[NW][16][16];  // [wave][tile row][chunk ^ 2*(row & 7)]: V tile, row major
+  __shared__ float sm_wm[NW][RT], sm_wl[NW][RT];  // the waves' softmax state per query head (merged across the workgroup)
+  __shared__ unsigned sm_mlcnt;                    // EML: waves whose (m, l) rows are in LDS — the LAST one to arrive publishes
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, c = lane & 15;  // row group of the wave / 16-byte column chunk (and MFMA column n)
@@ -941,8 +950,15 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
     }
   }
   int qb_ins_u = -1;  // QB: tile row (of this lane's row group) that holds the inserted token — its K chunk is UNswizzled (chunk c)
+  if constexpr (EML) {
+    // the arrival counter of the early (m, l) hand-off starts at zero: one barrier HERE, behind the issue of every load of the
+    // tile (the waves of a workgroup reach it together; nothing waits for memory)
+    if (threadIdx.x == 0) sm_mlcnt = 0u;
+    __syncthreads();
+  }
 
-  auto tile = [&](TileRegs& R, const int tbase, const int tbase_next, const bool more_next, auto ti_c) {
+  float pv_p[U];  // the tile's probabilities (unnormalised), between its two halves
+  auto tile_qk = [&](TileRegs& R, const int tbase, const int tbase_next, const bool more_next, auto ti_c) {
     constexpr int TI = decltype(ti_c)::value;  // ONE: which of the wave's tiles (compile time: the scores stay in registers)
     const int row0 = tbase + g * U;
     // ONE: a wave owns exactly one tile (one_shape_ok: rows_per_split == one iteration's rows) — a compile-time fact, so that the
@@ -1144,7 +1160,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
       }
     }
     // ---- online softmax: ONE (m, l) per lane
-    float p[U];
+    float (&p)[U] = pv_p;
     {
       float mx = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
       // ONE running maximum per (wave, head): the four row groups share it (two v_permlane swaps), so their
@@ -1170,6 +1186,9 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
         }
       }
     }
+  };
+  auto tile_pv = [&](TileRegs& R, const int tbase_next, const bool more_next) {
+    const float (&p)[U] = pv_p;
     // ---- O^T += V^T . P^T on the matrix cores: V tile -> wave-private LDS slab (row major, coalesced), A fragments
     //      back through the transpose read, B = this lane's four probabilities in 16 bit
 #pragma unroll
@@ -1195,6 +1214,10 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
       if (a.trace && trC == 0) trC = __builtin_amdgcn_s_memtime();  // P.V of the tile issued
     }
   };
+  auto tile = [&](TileRegs& R, const int tbase, const int tbase_next, const bool more_next, auto ti_c) {
+    tile_qk(R, tbase, tbase_next, more_next, ti_c);
+    tile_pv(R, tbase_next, more_next);
+  };
   if constexpr (ONE && NT > 1) {
     // the wave's tiles, unrolled: tile TI keeps its scores in s_keep[TI] for the finish (at most NT tiles: one_shape_ok)
     auto run_tiles = [&](auto self, auto ti_c) -> void {
@@ -1208,6 +1231,37 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
       }
     };
     if (more) run_tiles(run_tiles, IntC<0>{});
+  } else if constexpr (EML) {
+    // single tile, early (m, l): scores -> [the workgroup's (m, l) pairs leave] -> P.V.  A wave without rows (ragged last split)
+    // skips the tile halves but not the arrival counter: its pair is (-inf, 0).
+    if (more) tile_qk(tregs[0], base, base, false, IntC<0>{});
+    {
+      l = xor_combine<32, false>(xor_combine<16, false>(l));  // the wave's l of head c, in every row group
+      if (lane < RT) {                                          // row group 0, column c = head
+        sm_wm[wave][lane] = m;
+        sm_wl[wave][lane] = l;
+      }
+      // No barrier: the waves' K tiles land up to 2 us apart, and a barrier here held every wave's P.V back until the workgroup's
+      // LAST K tile had arrived (measured, r3: +0.8 us on the streaming part).  Each wave bumps an LDS counter behind its two
+      // stores (release / acquire at workgroup scope); whoever brings it to NW has every wave's row in front of it and publishes.
+      unsigned arrived = 0;
+      if (lane == 0) arrived = __hip_atomic_fetch_add(&sm_mlcnt, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+      arrived = (unsigned)__builtin_amdgcn_readfirstlane((int)arrived);
+      if (arrived == (unsigned)(NW - 1) && lane < RT) {  // the merge of the publish loop below, once per query head
+        const int r = lane;
+        float M = sm_wm[0][r];
+#pragma unroll
+        for (int w = 1; w < NW; w++) M = fmaxf(M, sm_wm[w][r]);
+        const float Mu = (M == -INFINITY) ? 0.f : M;
+        float L = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; w++) L = fmaf(sm_wl[w][r], fast_exp(sm_wm[w][r] - Mu), L);
+        const u32x4_t mg = {one_tag, __float_as_uint(M), one_tag, __float_as_uint(L)};
+        const auto ml_rsrc_e = __builtin_amdgcn_make_buffer_rsrc(a.one_ml, 0, (int)a.one_ml_bytes, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b128(mg, ml_rsrc_e, h * kOneMlHead + (split * RT + r) * 16, 0, kOneAuxCoherent);
+      }
+    }
+    if (more) tile_pv(tregs[0], base, false);
   } else {
     while (more) {
       const int base_next = base + NSUB * NW * RPW * U;
@@ -1258,13 +1312,14 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
   // ---- Epilogue.  The P.V accumulators already cover all 16 rows of the wave's tiles (one running maximum per
   //      (wave, head)), so there is nothing to merge inside a wave: lanes n < RT drop their [128] partial into LDS
   //      (8 x ds_write_b128) and the four waves of the workgroup meet there.
-  __shared__ float sm_wm[NW][RT], sm_wl[NW][RT];
   __shared__ __attribute__((aligned(16))) float sm_wacc[NW][RT][D];
   {
-    l = xor_combine<32, false>(xor_combine<16, false>(l));  // the wave's l of head c, in every row group
-    if (lane < RT) {                                          // row group 0, column c = head
-      sm_wm[wave][lane] = m;
-      sm_wl[wave][lane] = l;
+    if constexpr (!EML) {  // (EML: done between the tile's halves)
+      l = xor_combine<32, false>(xor_combine<16, false>(l));  // the wave's l of head c, in every row group
+      if (lane < RT) {                                          // row group 0, column c = head
+        sm_wm[wave][lane] = m;
+        sm_wl[wave][lane] = l;
+      }
     }
     if (c < RT) {
 #pragma unroll
@@ -1311,6 +1366,20 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
     __shared__ __attribute__((aligned(16))) float sm_o1[2 * (RT * 64 + 64)];  // [split][pair of this workgroup][2]: raw partial O
     const auto ml_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.one_ml, 0, (int)a.one_ml_bytes, 0x00020000);
     const auto o_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.one_o, 0, (int)a.one_o_bytes, 0x00020000);
+    constexpr int MLN = (RT + NW - 1) / NW;            // (m, l) granules per thread: wave w collects heads w, w + NW, ...
+    int ml_off[MLN];
+#pragma unroll
+    for (int k = 0; k < MLN; k++) ml_off[k] = h * kOneMlHead + ((lane < ns ? lane : 0) * RT + (wave + k * NW < RT ? wave + k * NW : 0)) * 16;
+    u32x4_t mlq[MLN];
+    if constexpr (EML) {
+      // the (m, l) pairs left behind the scores, long ago: their first round of loads goes out AHEAD of this workgroup's partial-O
+      // stores (loads return in order: behind the stores they would also wait for the stores' acknowledgements, a round trip)
+      if (wave < RT) {
+#pragma unroll
+        for (int k = 0; k < MLN; k++) mlq[k] = __builtin_amdgcn_raw_buffer_load_b128(ml_rsrc, ml_off[k], 0, kOneAuxCoherent);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
     // ---- publish: thread t merges output columns 2t, 2t + 1 of the workgroup's partial (the arithmetic of the
     //      two-launch epilogue below) and stores them as one granule
     for (int o2 = (int)threadIdx.x * 2; o2 < RT * D; o2 += 2 * NW * 64) {
@@ -1330,7 +1399,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
         }
         const u32x4_t og = {tag, __float_as_uint(O0), tag, __float_as_uint(O1)};
         __builtin_amdgcn_raw_buffer_store_b128(og, o_rsrc, h * kOneOHead + ((r * ns + split) * 64 + (d >> 1)) * 16, 0, kOneAuxCoherent);
-        if (d == 0) {
+        if (!EML && d == 0) {
           const u32x4_t mg = {tag, __float_as_uint(M), tag, __float_as_uint(L)};
           __builtin_amdgcn_raw_buffer_store_b128(mg, ml_rsrc, h * kOneMlHead + (split * RT + r) * 16, 0, kOneAuxCoherent);
         }
@@ -1361,11 +1430,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
     const int pair0 = split * ppw;
     int n_pairs = RT * 64 - pair0;
     n_pairs = n_pairs < 0 ? 0 : (n_pairs > ppw ? ppw : n_pairs);
-    constexpr int MLN = (RT + NW - 1) / NW;            // (m, l) granules per thread: wave w collects heads w, w + NW, ...
     constexpr int NOG = (RT * 64 + 64 + NW * 64 - 1) / (NW * 64);  // O granules per thread
-    int ml_off[MLN];
-#pragma unroll
-    for (int k = 0; k < MLN; k++) ml_off[k] = h * kOneMlHead + ((lane < ns ? lane : 0) * RT + (wave + k * NW < RT ? wave + k * NW : 0)) * 16;
     int o_off[NOG], o_lds[NOG];
     bool o_use[NOG];
 #pragma unroll
@@ -1394,87 +1459,138 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
     // right behind the write-through stores cost 0.8 us at S = 4096 (11.1 vs 10.3 us; found by accident: a never-taken measurement
     // branch with loads of its own made the compiler put this wait at the join): the stragglers' K/V rows and everybody's granules
     // then queue behind 6 MB of polls per round that cannot succeed yet.
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (!EML) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (EML: the first rounds of both gathers are not issued behind these stores)
     if (a.trace) tr3 = __builtin_amdgcn_s_memtime();
-    u32x4_t mlq[MLN], oq[NOG], nq[NLG > 0 ? NLG : 1];
-    for (unsigned spins = 0;; spins++) {
-      asm volatile("" ::: "memory");  // every round re-reads memory
+    u32x4_t oq[NOG], nq[NLG > 0 ? NLG : 1];
+    // one round of loads of each kind (coherent: they bypass the L1 and stale L2 lines), and whether every granule of the round
+    // carries this launch's tag
+    auto load_ml = [&]() {
 #pragma unroll
       for (int k = 0; k < MLN; k++) mlq[k] = __builtin_amdgcn_raw_buffer_load_b128(ml_rsrc, ml_off[k], 0, kOneAuxCoherent);
+    };
+    auto load_o = [&]() {
 #pragma unroll
       for (int k = 0; k < NOG; k++) oq[k] = __builtin_amdgcn_raw_buffer_load_b128(o_rsrc, o_off[k], 0, kOneAuxCoherent);
-#pragma unroll
-      for (int k = 0; k < NLG; k++) nq[k] = __builtin_amdgcn_raw_buffer_load_b128(ml_rsrc, nm_off[k], 0, kOneAuxCoherent);
+    };
+    auto ok_ml = [&]() {
       bool ok = true;
 #pragma unroll
-      for (int k = 0; k < NLG; k++) ok = ok && (!nm_use[k] || (nq[k][0] == nm_tag[k] && nq[k][2] == nm_tag[k]));
-#pragma unroll
       for (int k = 0; k < MLN; k++) ok = ok && mlq[k][0] == tag && mlq[k][2] == tag;
+      return ok;
+    };
+    auto ok_o = [&]() {
+      bool ok = true;
 #pragma unroll
       for (int k = 0; k < NOG; k++) ok = ok && (!o_use[k] || (oq[k][0] == tag && oq[k][2] == tag));
-      if (__all(ok)) break;
-      if (spins > kOneSpinMax) {
-        timed_out = true;
-        break;
-      }
-      __builtin_amdgcn_s_sleep(1);
-    }
-    if (a.trace) tr4 = __builtin_amdgcn_s_memtime();
-    if (timed_out && lane == 0) a.one_hdr[kOneStatusWordDev] = 1u;  // this launch's results are invalid; the host reads the word
+      return ok;
+    };
     // ---- final (M, L) of query heads r = wave, wave + NW, ...: decode_attn_combine_kernel's order (lane = split, n_split <= 64)
+    auto final_ml = [&]() {
 #pragma unroll
-    for (int k = 0; k < MLN; k++) {
-      const int rr = wave + k * NW;
-      if (rr < RT) {
-        const float mi = lane < ns ? __uint_as_float(mlq[k][1]) : -INFINITY;
-        const float M = wave_max_uniform(mi);
-        const float Mu = (M == -INFINITY) ? 0.f : M;
-        float L = 0.f;
-        if (lane < ns) {
-          const float wgt = exp_nonpos(mi - Mu);
-          sm_w1[rr][lane] = wgt;
-          L = __uint_as_float(mlq[k][3]) * wgt;
-        }
-        L = wave_sum_uniform(L);
-        if (lane == 0) {
-          sm_M1[rr] = Mu;
-          sm_L1[rr] = L;
+      for (int k = 0; k < MLN; k++) {
+        const int rr = wave + k * NW;
+        if (rr < RT) {
+          const float mi = lane < ns ? __uint_as_float(mlq[k][1]) : -INFINITY;
+          const float M = wave_max_uniform(mi);
+          const float Mu = (M == -INFINITY) ? 0.f : M;
+          float L = 0.f;
+          if (lane < ns) {
+            const float wgt = exp_nonpos(mi - Mu);
+            sm_w1[rr][lane] = wgt;
+            L = __uint_as_float(mlq[k][3]) * wgt;
+          }
+          L = wave_sum_uniform(L);
+          if (lane == 0) {
+            sm_M1[rr] = Mu;
+            sm_L1[rr] = L;
+          }
         }
       }
-    }
+    };
+    auto stash_o = [&]() {
 #pragma unroll
-    for (int k = 0; k < NOG; k++)
-      if (o_use[k]) *reinterpret_cast<float2*>(&sm_o1[o_lds[k]]) = make_float2(__uint_as_float(oq[k][1]), __uint_as_float(oq[k][3]));
+      for (int k = 0; k < NOG; k++)
+        if (o_use[k]) *reinterpret_cast<float2*>(&sm_o1[o_lds[k]]) = make_float2(__uint_as_float(oq[k][1]), __uint_as_float(oq[k][3]));
+    };
+    // ---- y: per output column, G1 strided chains over the splits.  The G1 chains of an output sit in G1 adjacent lanes: folded by
+    //      DPP butterflies and stored at once — no partial sums through LDS, no second barrier (tasks go to the LAST threads first).
+    auto y_fold = [&]() {
+      const int n_out = 2 * n_pairs;
+      const int sh = ns >= 8 ? 3 : (ns >= 4 ? 2 : (ns >= 2 ? 1 : 0)), G1 = 1 << sh;
+      for (int task = NW * 64 - 1 - (int)threadIdx.x; task < (n_out << sh); task += NW * 64) {
+        const int ol = task >> sh, gg = task & (G1 - 1);
+        const int to = 2 * pair0 + ol, r = to / D;
+        float part = 0.f;
+        for (int i = gg; i < ns; i += G1) part = fmaf(sm_o1[i * ppw * 2 + ol], sm_w1[r][i], part);
+        part = seg_sum(part, G1);  // whole groups of G1 lanes are in or out of this loop together
+        if (gg == 0) ElemTraits<T>::store(reinterpret_cast<T*>(a.y), (size_t)(h * RT + r) * D + (to - r * D), part / sm_L1[r]);
+      }
+    };
     __shared__ float sm_l2g[NW];  // l2: per-wave fold of the gathered norm maxima (NaN propagates: torch.max)
-    if constexpr (L2) {
-      float gm = -INFINITY;
-      bool gn = false;
-#pragma unroll
-      for (int k = 0; k < NLG; k++)
-        if (nm_use[k]) {
-          const float v = __uint_as_float(nq[k][1]);
-          gn |= nq[k][3] != 0u || v != v;
-          gm = fmaxf(gm, v);
-        }
-      const bool nn = __any(gn) != 0;
-      const float wm = wave_max_f32(gm);
-      if (lane == 0) sm_l2g[wave] = nn ? NAN : wm;
-    }
-    __syncthreads();
     unsigned long long trD = 0, trE = 0;
-    if (a.trace) trD = __builtin_amdgcn_s_memtime();
-    // ---- y: per output column, G1 strided chains over the splits ...
-    const int n_out = 2 * n_pairs;
-    const int sh = ns >= 8 ? 3 : (ns >= 4 ? 2 : (ns >= 2 ? 1 : 0)), G1 = 1 << sh;
-    // The G1 chains of an output sit in G1 adjacent lanes: folded by DPP butterflies and stored at once — no partial sums
-    // through LDS, no second barrier, nothing of y left for the end of the launch (tasks go to the LAST threads first).
-    for (int task = NW * 64 - 1 - (int)threadIdx.x; task < (n_out << sh); task += NW * 64) {
-      const int ol = task >> sh, gg = task & (G1 - 1);
-      const int to = 2 * pair0 + ol, r = to / D;
-      float part = 0.f;
-      for (int i = gg; i < ns; i += G1) part = fmaf(sm_o1[i * ppw * 2 + ol], sm_w1[r][i], part);
-      part = seg_sum(part, G1);  // whole groups of G1 lanes are in or out of this loop together
-      if (gg == 0) ElemTraits<T>::store(reinterpret_cast<T*>(a.y), (size_t)(h * RT + r) * D + (to - r * D), part / sm_L1[r]);
+    if constexpr (EML) {
+      // ---- the (m, l) pairs left behind the scores: most of them are there by now.  Only the waves that fold a head poll.
+      const bool ml_mine = wave < RT;  // (MLN == 1 whenever RT <= NW; with RT = 8 on four waves every wave folds two heads)
+      for (unsigned spins = 0; ml_mine; spins++) {  // round 0 was issued ahead of the partial-O stores
+        if (__all(ok_ml())) break;
+        if (spins > kOneSpinMax) {
+          timed_out = true;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");  // every round re-reads memory
+        load_ml();
+      }
+      if (a.trace) tr4 = __builtin_amdgcn_s_memtime();
+      if (ml_mine) final_ml();
+      __syncthreads();
+      if (a.trace) trD = __builtin_amdgcn_s_memtime();
+    } else {
+      for (unsigned spins = 0;; spins++) {
+        asm volatile("" ::: "memory");  // every round re-reads memory
+        load_ml();
+        load_o();
+#pragma unroll
+        for (int k = 0; k < NLG; k++) nq[k] = __builtin_amdgcn_raw_buffer_load_b128(ml_rsrc, nm_off[k], 0, kOneAuxCoherent);
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < NLG; k++) ok = ok && (!nm_use[k] || (nq[k][0] == nm_tag[k] && nq[k][2] == nm_tag[k]));
+        ok = ok && ok_ml() && ok_o();
+        if (__all(ok)) break;
+        if (spins > kOneSpinMax) {
+          timed_out = true;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (a.trace) tr4 = __builtin_amdgcn_s_memtime();
+      if (timed_out && lane == 0) a.one_hdr[kOneStatusWordDev] = 1u;  // this launch's results are invalid; the host reads the word
+      final_ml();
+      stash_o();
+      if constexpr (L2) {
+        float gm = -INFINITY;
+        bool gn = false;
+#pragma unroll
+        for (int k = 0; k < NLG; k++)
+          if (nm_use[k]) {
+            const float v = __uint_as_float(nq[k][1]);
+            gn |= nq[k][3] != 0u || v != v;
+            gm = fmaxf(gm, v);
+          }
+        const bool nn = __any(gn) != 0;
+        const float wm = wave_max_f32(gm);
+        if (lane == 0) sm_l2g[wave] = nn ? NAN : wm;
+      }
+      __syncthreads();
+      if (a.trace) trD = __builtin_amdgcn_s_memtime();
+      y_fold();
+    }
+    if constexpr (EML) {
+      // the first round of the partial-O gather goes out HERE and flies while the per-slot pass runs: what is left behind the last O
+      // granule of the head is the y fold
+      asm volatile("" ::: "memory");
+      load_o();
+      __builtin_amdgcn_sched_barrier(0);
     }
     // ---- this workgroup's slots.  ref: attention_utils.py:52 softmax -> model dtype; model.py:416-418 group mean -> model
     //      dtype; cache.py:716-722 history; cache.py:727-749 the next position's eviction score
@@ -1672,7 +1788,26 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
         for (int s2 = e0 + ns * NW; s2 < a.nk_read; s2 += ns * NW) nk_row[s2] = ~0ull;  // entries beyond nk_read are never read
       }
     }
-    if (a.trace) trE = __builtin_amdgcn_s_memtime();
+    if constexpr (EML) {
+      __builtin_amdgcn_sched_barrier(0);
+      for (unsigned spins = 0;; spins++) {
+        if (__all(ok_o())) break;
+        if (spins > kOneSpinMax) {
+          timed_out = true;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");  // every round re-reads memory
+        load_o();
+      }
+      if (a.trace) trE = __builtin_amdgcn_s_memtime();
+      if (timed_out && lane == 0) a.one_hdr[kOneStatusWordDev] = 1u;  // this launch's results are invalid; the host reads the word
+      stash_o();
+      __syncthreads();
+      y_fold();
+    } else {
+      if (a.trace) trE = __builtin_amdgcn_s_memtime();
+    }
     if (threadIdx.x == 0) {
       if (split == 0) {
         a.one_hdr[h] = tag;  // all n_split workgroups of this head have published, hence read the old epoch
@@ -2142,22 +2277,37 @@ constexpr int kU = 4;   // 16-byte K loads (and V loads) in flight per lane
 
 struct Plan {
   int n_split, rows_per_split, rt, chunk, n_chunks;
+  int nw;  // waves per workgroup of the streaming pass / the single-launch step (4, or 8: see make_plan)
 };
 
-static int rows_per_iter(int D, int dtype) {
+static int rows_per_iter(int D, int dtype, int nw = kNW) {
   const int vec = 16 / (int)cc_dt_size(dtype);
   const int lpr = D / vec;
-  return (64 / lpr) * kU * kNW;
+  return (64 / lpr) * kU * nw;
 }
 
-static Plan make_plan(int HQ, int H, int S, int D, int dtype) {
+// kind: what rides the streaming pass (see one_kernel): 0 = a plain 16-bit cache (heavy hitter / head-constant policies / plain
+// attention), anything else = l2, hybrid, the fused quantised cache.  The step of ONE cache must always get the same plan,
+// whichever form (one launch, two, three calls) runs it: its partials — hence the last bits of (M, L) — depend on the geometry.
+static int g_wide_enabled = 1;  // cc_decode_step_set_wide: 8-wave workgroups where the plan allows them
+static Plan make_plan(int HQ, int H, int S, int D, int dtype, int kind = 0) {
   Plan p;
   const int R = HQ / H;
+  p.nw = kNW;
   p.rt = (R % 4 == 0) ? 4 : (R % 2 == 0) ? 2 : 1;
   // the matrix-core streaming pass has 16 score columns: 8 query heads per pass read K and V ONCE for a group of 8 (Llama-3
   // 70B: HQ / H = 8; with 4 per pass every K / V row was streamed twice)
   if (R % 8 == 0 && cc_dt_size(dtype) == 2 && D == 128) p.rt = 8;
-  const int rpi = rows_per_iter(D, dtype);
+  // (r3) ONE 8-wave workgroup per CU instead of two 4-wave ones, where the cache has 16-row tiles for it (>= 8 x 256 over the
+  // kv heads) and every wave still gets exactly one: half the publishers, granules and polls of the in-launch hand-off, half the
+  // splits for every gatherer to fold, one merge per CU — 4 or 8 query heads per kv head; every policy but the hybrid cache
+  // (whose caches are long: several tiles per wave), so that the steps of the policies that share inputs in the tests (l2 and
+  // the fused quantised cache against the plain 16-bit step) fold their partials alike
+  if (g_wide_enabled && kind != 200 && cc_dt_size(dtype) == 2 && D == 128 && (p.rt == 4 || p.rt == 8) && R == p.rt) {
+    const long tiles = (long)H * ((S + 15) / 16);
+    if (tiles >= 2048 && (long)H * ((S + 127) / 128) <= 256) p.nw = 8;
+  }
+  const int rpi = rows_per_iter(D, dtype, p.nw);
   // ~512 workgroups (two per CU, all resident at once): one tile per workgroup up to S = 64 * 64 rows per kv
   // head at 8 kv heads, MORE TILES PER WORKGROUP beyond that — the loop prefetches the next tile behind the
   // current one, the per-workgroup merge and the number of partials the combine pass has to fold stay constant.
@@ -2183,7 +2333,7 @@ static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 template <typename T, int D>
 static int launch_split_rt(const SplitArgs& a, const Plan& p, int H, int R, hipStream_t st) {
-  dim3 grid(p.n_split, H, R / p.rt), block(kNW * 64);
+  dim3 grid(p.n_split, H, R / p.rt), block(kNW * 64);  // (the VALU pass: fp32 caches / other head dims never get the wide plan)
   switch (p.rt) {
     case 4: hipLaunchKernelGGL((decode_attn_split_kernel<T, D, 4, kNW, kU>), grid, block, 0, st, a); break;
     case 2: hipLaunchKernelGGL((decode_attn_split_kernel<T, D, 2, kNW, kU>), grid, block, 0, st, a); break;
@@ -2193,19 +2343,19 @@ static int launch_split_rt(const SplitArgs& a, const Plan& p, int H, int R, hipS
   return CC_OK;
 }
 
-template <typename T, bool L2, bool HYB, int QB, int NSUB>
+template <typename T, bool L2, bool HYB, int QB, int NSUB, int NW = kNW>
 static int launch_mfma_rt(const SplitArgs& a, int rt, dim3 grid, dim3 block, hipStream_t st) {
   if constexpr (sizeof(T) == 2) {
     switch (rt) {
-      case 8: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 8, kNW, L2, false, HYB, QB, NSUB>), grid, block, 0, st, a); break;
-      case 4: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 4, kNW, L2, false, HYB, QB, NSUB>), grid, block, 0, st, a); break;
+      case 8: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 8, NW, L2, false, HYB, QB, NSUB>), grid, block, 0, st, a); break;
+      case 4: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 4, NW, L2, false, HYB, QB, NSUB>), grid, block, 0, st, a); break;
       case 2:
-        if constexpr (QB != 0) return CC_ERR_UNSUPPORTED;
-        else hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 2, kNW, L2, false, HYB, QB, NSUB>), grid, block, 0, st, a);
+        if constexpr (QB != 0 || NW != kNW) return CC_ERR_UNSUPPORTED;
+        else hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 2, NW, L2, false, HYB, QB, NSUB>), grid, block, 0, st, a);
         break;
       default:
-        if constexpr (QB != 0) return CC_ERR_UNSUPPORTED;
-        else hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 1, kNW, L2, false, HYB, QB, NSUB>), grid, block, 0, st, a);
+        if constexpr (QB != 0 || NW != kNW) return CC_ERR_UNSUPPORTED;
+        else hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 1, NW, L2, false, HYB, QB, NSUB>), grid, block, 0, st, a);
         break;
     }
     return CC_OK;
@@ -2219,18 +2369,20 @@ static int launch_split(const SplitArgs& a, const Plan& p, int H, int R, int D, 
   if constexpr (sizeof(T) == 2) {
     if (D == 128 && !(a.abl & 32)) {  // matrix-core streaming pass (abl bit 32 = measurement: force the VALU kernel)
       static_assert(kU == 4, "the MFMA tile is 4 row groups x 4 rows per wave");
-      dim3 grid(p.n_split, H, R / p.rt), block(kNW * 64);
+      dim3 grid(p.n_split, H, R / p.rt), block(p.nw * 64);
       // (NSUB = 2 — two tiles per wave and iteration, each with its own staging registers, the loads two half-iterations ahead of
       //  their use — was measured at S = 18432: 27.3 instead of 25.4 us per step, the uint8 instantiation 31.5 instead of 25.4; like
       //  768 / 1024 workgroups, more bytes in flight per CU make this access pattern slower, not faster.  Not instantiated.)
       int rc;
       if (a.qparams != nullptr) {  // fused quantised cache: 4 or 8 query heads per kv head
         if (p.rt != 4 && p.rt != 8) return CC_ERR_UNSUPPORTED;
-        rc = launch_mfma_rt<T, false, false, 8, 1>(a, p.rt, grid, block, st);
+        rc = p.nw == 8 ? launch_mfma_rt<T, false, false, 8, 1, 8>(a, p.rt, grid, block, st) : launch_mfma_rt<T, false, false, 8, 1>(a, p.rt, grid, block, st);
       } else if (a.hyb.strategies != nullptr) {
         rc = launch_mfma_rt<T, false, true, 0, 1>(a, p.rt, grid, block, st);
       } else if (a.key_norm != nullptr) {
-        rc = launch_mfma_rt<T, true, false, 0, 1>(a, p.rt, grid, block, st);
+        rc = p.nw == 8 ? launch_mfma_rt<T, true, false, 0, 1, 8>(a, p.rt, grid, block, st) : launch_mfma_rt<T, true, false, 0, 1>(a, p.rt, grid, block, st);
+      } else if (p.nw == 8) {
+        rc = launch_mfma_rt<T, false, false, 0, 1, 8>(a, p.rt, grid, block, st);
       } else {
         rc = launch_mfma_rt<T, false, false, 0, 1>(a, p.rt, grid, block, st);
       }
@@ -2271,7 +2423,7 @@ constexpr int kOneMaxTiles = 8;  // tiles per wave the single-launch step keeps 
 // tiles per wave of the single-launch step for this shape: 1 = the specialised single-tile form, 2 .. 8 = the multi-tile form
 // (16-bit caches, 4 or 8 query heads per kv head), 0 = not eligible
 static int one_tiles(const Plan& p, int HQ, int H, int D, int dtype) {
-  const int R = HQ / H, rpi = rows_per_iter(D, dtype);
+  const int R = HQ / H, rpi = rows_per_iter(D, dtype, p.nw);
   if (cc_dt_size(dtype) != 2 || D != 128 || R != p.rt || p.n_split > 64 || H > kOneMaxHeads || p.rt > 8 || p.rows_per_split % rpi) return 0;
   const int nt = p.rows_per_split / rpi;
   if (nt == 1) return 1;
@@ -2287,7 +2439,7 @@ static size_t base_workspace_bytes(const Plan& p, int HQ, int H, int S, int D, i
 // The answer is cached PER KERNEL: every instantiation has the same function type, so a cache keyed by the argument's type
 // (a `static` inside a template over the type) would be ONE cache for all of them — the first kernel asked would answer for
 // the fused-quant and multi-tile instantiations too, which keep fewer workgroups resident.
-static int one_capacity(void (*kernel)(SplitArgs)) {
+static int one_capacity(void (*kernel)(SplitArgs), int threads) {
   struct Entry {
     void (*k)(SplitArgs);
     int cap;
@@ -2298,7 +2450,7 @@ static int one_capacity(void (*kernel)(SplitArgs)) {
     if (cache[i].k == kernel) return cache[i].cap;
   int dev = 0, cus = 0, nb = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-      hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, kNW * 64, 0) != hipSuccess) {
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, threads, 0) != hipSuccess) {
     (void)hipGetLastError();
     return 0;
   }
@@ -2311,9 +2463,26 @@ typedef void (*OneKernel)(SplitArgs);
 // (heavy hitter / head-constant policies), 8 = fused quantised cache, -1 = l2, 200 = hybrid.  full: the instantiation with the
 // measurement hooks and attn_out (bf16, rt = 4 only).  ONE table for the residency check and the launch.
 template <typename T>
-static OneKernel one_kernel(int rt, int nt, int kind, bool full) {
+static OneKernel one_kernel(int rt, int nt, int kind, bool full, int nw = kNW) {
 #define CC_ONE_K(RT_, L2_, HYB_, QB_, NT_, FULL_) decode_attn_split_mfma_kernel<T, RT_, kNW, L2_, true, HYB_, QB_, 1, NT_, FULL_>
   if (nt < 1 || nt > kOneMaxTiles) return nullptr;
+  if (nw == 8) {  // ONE 8-wave workgroup per CU: 4 or 8 query heads per kv head, one tile per wave (make_plan)
+#define CC_ONE_W(RT_, L2_, QB_, FULL_) decode_attn_split_mfma_kernel<T, RT_, 8, L2_, true, false, QB_, 1, 1, FULL_>
+    if ((kind != 0 && kind != 8 && kind != -1) || nt != 1 || (rt != 4 && rt != 8)) return nullptr;
+    if (full) {
+      if constexpr (ElemTraits<T>::code != CC_DT_BF16) {
+        return nullptr;
+      } else {
+        if (rt != 4) return nullptr;
+        return kind == 0 ? CC_ONE_W(4, false, 0, true) : (kind == 8 ? CC_ONE_W(4, false, 8, true) : CC_ONE_W(4, true, 0, true));
+      }
+    }
+    if (kind == 0) return rt == 8 ? CC_ONE_W(8, false, 0, false) : CC_ONE_W(4, false, 0, false);
+    if (kind == 8) return rt == 8 ? CC_ONE_W(8, false, 8, false) : CC_ONE_W(4, false, 8, false);
+    return rt == 8 ? CC_ONE_W(8, true, 0, false) : CC_ONE_W(4, true, 0, false);
+#undef CC_ONE_W
+  }
+  if (nw != kNW) return nullptr;
   if (full) {
     if constexpr (ElemTraits<T>::code != CC_DT_BF16) {
       return nullptr;
@@ -2362,8 +2531,8 @@ static OneKernel one_kernel(int rt, int nt, int kind, bool full) {
   }
 #undef CC_ONE_K
 }
-static OneKernel one_kernel_dt(int dtype, int rt, int nt, int kind, bool full) {
-  return dtype == CC_DT_BF16 ? one_kernel<bf16_t>(rt, nt, kind, full) : (dtype == CC_DT_F16 ? one_kernel<f16_t>(rt, nt, kind, full) : nullptr);
+static OneKernel one_kernel_dt(int dtype, int rt, int nt, int kind, bool full, int nw) {
+  return dtype == CC_DT_BF16 ? one_kernel<bf16_t>(rt, nt, kind, full, nw) : (dtype == CC_DT_F16 ? one_kernel<f16_t>(rt, nt, kind, full, nw) : nullptr);
 }
 }  // namespace
 
@@ -2371,21 +2540,21 @@ extern "C" {
 
 size_t cc_decode_attn_workspace_bytes(int32_t HQ, int32_t H, int32_t S, int32_t D, int32_t dtype) {
   if (HQ <= 0 || H <= 0 || HQ % H || S <= 0 || D <= 0 || !cc_dt_ok(dtype)) return 0;
-  const Plan p = make_plan(HQ, H, S, D, dtype);
+  const Plan p = make_plan(HQ, H, S, D, dtype, -1);  // the 4-wave plan: at least as many splits as the wide one (policy-agnostic size)
   return kOneBytes + base_workspace_bytes(p, HQ, H, S, D, dtype);
 }
 
 // kind: see one_kernel.  Returns the kernel when the shape is eligible AND all its workgroups stay resident at once, else null.
 static OneKernel one_pick(int32_t HQ, int32_t H, int32_t S, int32_t D, int32_t dtype, int kind, bool full) {
   if (HQ <= 0 || H <= 0 || HQ % H || S <= 0 || D <= 0 || !cc_dt_ok(dtype)) return nullptr;
-  const Plan p = make_plan(HQ, H, S, D, dtype);
+  const Plan p = make_plan(HQ, H, S, D, dtype, kind);
   const int nt = one_tiles(p, HQ, H, D, dtype);
   if (nt == 0) return nullptr;
   // l2: every thread gathers at most three workgroups' norm maxima
-  if (kind == -1 && H * p.n_split > 3 * kNW * 64) return nullptr;
-  const OneKernel k = one_kernel_dt(dtype, p.rt, nt, kind, full);
+  if (kind == -1 && H * p.n_split > 3 * p.nw * 64) return nullptr;
+  const OneKernel k = one_kernel_dt(dtype, p.rt, nt, kind, full, p.nw);
   if (!k) return nullptr;
-  return p.n_split * H <= one_capacity(k) ? k : nullptr;
+  return p.n_split * H <= one_capacity(k, p.nw * 64) ? k : nullptr;
 }
 static int32_t one_available(int32_t HQ, int32_t H, int32_t S, int32_t D, int32_t dtype, int kind) {
   return one_pick(HQ, H, S, D, dtype, kind, false) ? 1 : 0;
@@ -2407,6 +2576,10 @@ void cc_decode_step_trace(void* buf) { g_one_trace = buf; }
 
 static int g_one_enabled = 1;
 void cc_decode_step_set_single_launch(int32_t enabled) { g_one_enabled = enabled ? 1 : 0; }
+// 8-wave workgroups (one per CU) for the plain 16-bit caches that have the tiles for them (make_plan); 0 = 4-wave workgroups
+// everywhere.  Process-wide; change it only between steps of a cache whose fused pipeline is re-seeded (prepare_decode): the
+// geometry decides which entries of a head's key row are live.
+void cc_decode_step_set_wide(int32_t enabled) { g_wide_enabled = enabled ? 1 : 0; }
 
 }  // extern "C"
 
@@ -2453,7 +2626,9 @@ static int attn_impl(const void* q, const void* k, const void* v, const uint8_t*
   if (R > kMaxR) return CC_ERR_UNSUPPORTED;
   if (D != 16 && D != 32 && D != 64 && D != 128) return CC_ERR_UNSUPPORTED;
   if (workspace_bytes < cc_decode_attn_workspace_bytes(HQ, H, S, D, dtype)) return CC_ERR_WORKSPACE;
-  const Plan p = make_plan(HQ, H, S, D, dtype);
+  // what rides the streaming pass decides the plan (one_kernel's kinds)
+  const int kind = !fs ? 0 : (fs->qparams ? 8 : (fs->policy == 4 ? -1 : (fs->policy == 6 ? 200 : 0)));
+  const Plan p = make_plan(HQ, H, S, D, dtype, (phases >> 8) & 32 ? -1 : kind);  // (measurement bit 32 forces the VALU pass: 4 waves)
   if ((size_t)R * p.n_split * sizeof(float) > 64 * 1024) return CC_ERR_UNSUPPORTED;  // combine-kernel LDS budget
   char* ws = reinterpret_cast<char*>(workspace) + kOneBytes;  // the single-launch regions come first, at fixed offsets
   SplitArgs sa{};
@@ -2474,7 +2649,7 @@ static int attn_impl(const void* q, const void* k, const void* v, const uint8_t*
     if (!fs->key_norm || cc_dt_size(dtype) != 2 || D != 128 || ((phases >> 8) & 32)) return CC_ERR_UNSUPPORTED;
     sa.key_norm = fs->key_norm;
     sa.l2_pmax = reinterpret_cast<float*>(ws + 256);
-    sa.l2_new = sa.l2_pmax + (size_t)H * p.n_split * kNW;
+    sa.l2_new = sa.l2_pmax + (size_t)H * p.n_split * p.nw;
   }
   if (fs && fs->policy == 6) {
     if (!fs->hyb || !fs->hyb->strategies || !fs->hyb->table || cc_dt_size(dtype) != 2 || D != 128 || fs->c->Hp != H || fs->c->Hc != H)
@@ -2494,7 +2669,7 @@ static int attn_impl(const void* q, const void* k, const void* v, const uint8_t*
   if (fs) {
     sa.next_key = fs->next_key; sa.nk = cc_next_key_slots(S);
     // entries any writer may have left non-~0: one per combine block (two-launch step), one per wave of the single-launch workgroups
-    sa.nk_read = one_shape_ok(p, HQ, H, D, dtype) ? (p.n_split * kNW > p.n_chunks ? p.n_split * kNW : p.n_chunks) : p.n_chunks;
+    sa.nk_read = one_shape_ok(p, HQ, H, D, dtype) ? (p.n_split * p.nw > p.n_chunks ? p.n_split * p.nw : p.n_chunks) : p.n_chunks;
     if (sa.nk_read > sa.nk) sa.nk_read = sa.nk; sa.input_pos = fs->input_pos; sa.k_new = fs->k_new; sa.v_new = fs->v_new;
     sa.pos = fs->c->pos; sa.mask_w = fs->c->mask; sa.cache_cts = fs->c->cache_cts; sa.num = hh_num; sa.denom = hh_denom;
     sa.H = H; sa.Hc = fs->c->Hc; sa.Hp = fs->c->Hp;
@@ -2511,7 +2686,6 @@ static int attn_impl(const void* q, const void* k, const void* v, const uint8_t*
                                   (fs->policy == 6 && !hh_num && fs->c->Hp == H && fs->c->Hc == H));
     // the lean kernels carry no measurement hooks and no attn_out: a call that wants one of them runs a FULL instantiation where
     // there is one (a time stamp alone is not worth leaving the product kernel for)
-    const int kind = !fs ? 0 : (fs->qparams ? 8 : (fs->policy == 4 ? -1 : (fs->policy == 6 ? 200 : 0)));
     const bool want_full = attn_out != nullptr || sa.abl != 0;
     OneKernel kern = nullptr;
     if (policy_ok && (!rh || fs->policy == 6) && !probs_out && !attn_out_needs_probs(fs, attn_out)) {
@@ -2536,7 +2710,7 @@ static int attn_impl(const void* q, const void* k, const void* v, const uint8_t*
           sa.ring_num = rh->num; sa.ring_acc = reinterpret_cast<unsigned long long*>(rh->acc); sa.ring_wsum = rh->wsum;
         }
       }
-      hipLaunchKernelGGL(kern, dim3(p.n_split, H, 1), dim3(kNW * 64), 0, st, sa);
+      hipLaunchKernelGGL(kern, dim3(p.n_split, H, 1), dim3(p.nw * 64), 0, st, sa);
       CC_LAUNCH_CHECK();
       return CC_OK;
     }
@@ -2562,7 +2736,7 @@ static int attn_impl(const void* q, const void* k, const void* v, const uint8_t*
   if (fs) {
     ca.next_key = fs->next_key; ca.input_pos = fs->input_pos; ca.pos = fs->c->pos; ca.H = H; ca.g = fs->g; ca.w = fs->w;
     ca.policy = fs->policy; ca.Hp = fs->c->Hp; ca.rand_next = fs->rand_next;
-    ca.key_norm = sa.key_norm; ca.l2_pmax = sa.l2_pmax; ca.l2_new = sa.l2_new; ca.l2_np = H * p.n_split * kNW;
+    ca.key_norm = sa.key_norm; ca.l2_pmax = sa.l2_pmax; ca.l2_new = sa.l2_new; ca.l2_np = H * p.n_split * p.nw;
     if (fs->policy == 6) {
       ca.hyb = sa.hyb;
       ca.cache_cts = fs->c->cache_cts;

@@ -268,6 +268,13 @@ int32_t cc_decode_step_status_offset(void);
  * random: cc_decode_step_recent_global / cc_decode_step_random) and l2 (cc_decode_step_l2: every workgroup also gathers every
  * workgroup's norm maximum) take the single launch under the same conditions (l2: at most 768 workgroups, 32 kv heads). */
 void cc_decode_step_set_single_launch(int32_t enabled);
+/* Wide geometry (r3): ONE 8-wave workgroup per CU (128 cache rows each) instead of two 4-wave ones, for the plain 16-bit
+ * caches (heavy hitter / recent_global / full / random, 4 or 8 query heads per kv head, head_dim 128) that have 16-row
+ * tiles for it (H * S / 16 >= 2048 and H * ceil(S / 128) <= 256: Llama-3-8B at cache_len 4096).  On by default;
+ * process-wide.  The geometry decides the split partials (hence the last bits of y and of the probabilities) and which
+ * entries of a head's key row are live: all forms of one cache's step (one launch, two, three calls) follow the switch
+ * together; flip it only where the fused pipeline is re-seeded (prepare_decode / cc_hh_next_key_init). */
+void cc_decode_step_set_wide(int32_t enabled);
 /* Measurement hook: buf = device buffer of [workgroups][16] uint64, or NULL (default).  While set, thread 0 of every
  * workgroup of a single-launch step records [0..5] s_memtime stamps (start, streaming done, published, sentinel seen,
  * gathered, end), [6..8] s_memrealtime at start / streaming done / end, [9] HW_ID, [10] XCC_ID, [11..13] s_memtime of wave 0

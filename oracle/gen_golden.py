@@ -10,6 +10,7 @@ under tests/golden/.  The GPU box never sees the reference.
 Fixtures:
   f1_e2e_<strategy>.npz   tiny-Llama end-to-end runs through generation_utils.generate
   f2_hh_<dtype>.npz       KVCacheHeavyHitter replay trace (update_kv / update_state, as model.py:389-427)
+  f2_hh_query_bf16.npz    the same policy driven from q through the reference's scaled_dot_product_attention + group mean
   f3_l2_<case>.npz        KVCacheL2 replay traces (bf16 rounding ties, unfilled slots, H == 1)
   f4_random.npz           KVCacheRandom with captured torch.rand vectors
   f4_headconst.npz        KVCacheFull / KVCacheRecentGlobal / KVCacheKeepItOdd decode traces
@@ -237,6 +238,79 @@ def replay_cache(C, strategy, dtype, H, S, D, T_prefill, steps, g, w, seed, extr
     if getattr(kv, "quantize", False):
         rec.update({"k_scales": kv.k_scales.clone(), "v_scales": kv.v_scales.clone(), "k_zero_points": kv.k_zero_points.clone(),
                     "v_zero_points": kv.v_zero_points.clone(), "cache_bits": kv.n_bit})
+    return pack(rec)
+
+
+def hh_query_case(A, C, dtype, seed, H=2, R=4, S=256, D=128, T_prefill=236, steps=160, g=4, w=10):
+    """Heavy-hitter decode driven from the QUERY, exactly as Attention.forward does (model.py:389-427): update_kv ->
+    repeat_interleave -> attention_utils.scaled_dot_product_attention(return_attn=True) -> mean over the group ->
+    update_state.  Unlike the f2_hh_* traces (which carry ready-made attention rows) this one lets the reference's own attention
+    produce the probabilities the history accumulates: what a fused decode step (insert + attention + history in one pass) must
+    reproduce.  Records q / k / v per step, the evicted slot, the reference's eviction SCORES (the tensor its arg-min saw,
+    cache.py:738-751: for the near-tie rule), its attention output and group-mean probabilities."""
+    gen = torch.Generator().manual_seed(seed)
+    HQ = H * R
+    cls, rk = C.get_cache_constructor("heavy_hitter")
+    kw = dict(max_cache_length=S, global_tokens=g, max_seq_length=4 * S, cache_bits=None, recent_window=w,
+              history_window_size=1, attn_thresholding=False)
+    kv = cls(1, H, D, dtype, **{k: kw[k] for k in rk})
+    T = T_prefill
+    k0 = torch.randn(1, H, T, D, generator=gen).to(dtype)
+    v0 = torch.randn(1, H, T, D, generator=gen).to(dtype)
+    pos0 = torch.arange(T)
+    kv.update_kv(pos0, k0, v0, True)
+    causal = torch.tril(torch.ones(T, T, dtype=torch.bool)).view(1, 1, T, T)
+    attn0 = softmax_rows((1, H, T, T), dtype, gen, causal.expand(1, H, T, T))
+    kv.update_state(pos0, k0, v0, True, attn0)
+    rec = {"H": H, "R": R, "S": S, "D": D, "T_prefill": T, "steps": steps, "g": g, "w": w,
+           "dtype": np.array(str(dtype).split(".")[-1]),
+           "k_after_prefill": kv.k_cache.clone(), "v_after_prefill": kv.v_cache.clone(), "pos_after_prefill": kv.pos.clone(),
+           "mask_after_prefill": kv.mask.clone(), "cts_after_prefill": kv.cache_cts.clone(),
+           "num_after_prefill": kv.attn_history_num.clone(), "denom_after_prefill": kv.attn_history_denom.clone(),
+           "counter_after_prefill": kv.attn_counter.clone()}
+    qs, ks, vs, idxs, scores, ys, attns = [], [], [], [], [], [], []
+    orig_argmin = torch.Tensor.argmin
+    cap = {}
+
+    def spy(self, *a, **k):  # the tensor KVCacheHeavyHitter._eviction_idx takes its arg-min of (cache.py:751)
+        if self.dtype == torch.float32 and self.shape == (1, H, S):
+            cap["scores"] = self.clone()
+        return orig_argmin(self, *a, **k)
+
+    for t in range(steps):
+        p = torch.tensor([T + t], dtype=torch.int32)
+        # a few kv rows are made "sticky" through a shared direction so that real heavy hitters exist
+        q1 = torch.randn(1, HQ, 1, D, generator=gen).to(dtype)
+        k1 = torch.randn(1, H, 1, D, generator=gen).to(dtype)
+        v1 = torch.randn(1, H, 1, D, generator=gen).to(dtype)
+        pos_before = kv.pos.clone()
+        torch.Tensor.argmin = spy
+        try:
+            k, v, kv_mask = kv.update_kv(p, k1, v1, False, input_ids=torch.tensor([[1]]))
+        finally:
+            torch.Tensor.argmin = orig_argmin
+        changed = (kv.pos != pos_before).squeeze(0)
+        assert bool(changed.sum(dim=-1).eq(1).all())
+        idxs.append(changed.int().argmax(dim=-1).long())
+        scores.append(cap.pop("scores")[0])
+        kv_mask = kv_mask.repeat_interleave(R, dim=1)  # model.py:395-400
+        k_rep = k.repeat_interleave(R, dim=1)
+        v_rep = v.repeat_interleave(R, dim=1)
+        y, attn = A.scaled_dot_product_attention(q1, k_rep, v_rep, attn_mask=kv_mask, dropout_p=0.0, attn_top_k=1.0,
+                                                 return_attn=kv.return_attn())
+        attn = attn.view(1, H, R, 1, -1).mean(dim=2)  # model.py:413-418
+        kv.update_state(p, k, v, False, attn, input_ids=torch.tensor([[1]]))
+        qs.append(q1)
+        ks.append(k1)
+        vs.append(v1)
+        ys.append(y.clone())
+        attns.append(attn.clone())
+    rec.update({"q": torch.stack(qs), "k_new": torch.stack(ks), "v_new": torch.stack(vs), "idx": torch.stack(idxs),
+                "scores": torch.stack(scores), "y": torch.stack(ys), "attn": torch.stack(attns),
+                "final_num": kv.attn_history_num.clone(), "final_denom": kv.attn_history_denom.clone(),
+                "final_counter": kv.attn_counter.clone(), "final_pos": kv.pos.clone(), "final_mask": kv.mask.clone(),
+                "final_cts": kv.cache_cts.clone(), "final_k": kv.k_cache.clone(), "final_v": kv.v_cache.clone(),
+                "torch_version": np.array(torch.__version__)})
     return pack(rec)
 
 
@@ -599,6 +673,12 @@ def main():
     def save(name, d):
         np.savez_compressed(os.path.join(a.out, name), **d)
         print("wrote", name, sum(v.nbytes for v in d.values()) // 1024, "KiB")
+
+    # F2q: heavy hitter driven from the query through the reference's own attention (what the fused decode step replays)
+    if a.only in (None, "f2q"):
+        save("f2_hh_query_bf16.npz", hh_query_case(A, C, torch.bfloat16, seed=201))
+        if a.only == "f2q":
+            return
 
     # F10: debug_* (KVCacheAnalysis): shadow compressed cache + attention-loss metric, intended behaviour
     if a.only in (None, "f10"):

@@ -29,7 +29,9 @@ def main():
     ap.add_argument("--hybrid", action="store_true", help="KVCacheHybrid (the decode-ready state of tools/bench_policies.py)")
     ap.add_argument("--policy", default=None, choices=["l2", "recent_global", "random", "full"],
                     help="another policy's step through its class (the state of tools/bench_policies.py)")
+    ap.add_argument("--wide", type=int, default=1, help="cc_decode_step_set_wide")
     a = ap.parse_args()
+    _abi.lib()["cc_decode_step_set_wide"](a.wide)
     dev, D, H, HQ = "cuda", 128, a.H, a.HQ
     fns = _abi.lib()
     p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
@@ -168,6 +170,12 @@ def main():
                 if t.shape[1] > 15 and (t[:, 14] != 0).all():
                     out["finish_ML_weights_mean"] = round(float((t[:, 14] - t[:, 4]).mean()), 1)
                     out["finish_slots_y_keys_mean"] = round(float((t[:, 15] - t[:, 14]).mean()), 1)
+                    # r3, early (m, l): [4] = (m, l) gathered, [14] = final (M, L) visible to every wave, [15] = partial-O gather
+                    # complete (the per-slot pass ran in its shadow), [5] = end -> what is left behind the last O granule
+                    out["tail_behind_o_gather_mean_max"] = [round(float((t[:, 5] - t[:, 15]).mean()), 1), float((t[:, 5] - t[:, 15]).max())]
+                    out["o_gather_done_min_mean_max"] = [float((t[:, 15] - t0).min()), round(float((t[:, 15] - t0).mean()), 1), float((t[:, 15] - t0).max())]
+                    out["ml_gather_done_min_mean_max"] = [float((t[:, 4] - t0).min()), round(float((t[:, 4] - t0).mean()), 1), float((t[:, 4] - t0).max())]
+                    out["end_min_mean_max"] = [float((t[:, 5] - t0).min()), round(float((t[:, 5] - t0).mean()), 1), float((t[:, 5] - t0).max())]
                 d_ = (t[:, 1] - t[:, 0]).astype(np.float64)
                 out["stream_done_min_mean_max"] = [float(d_.min()), round(float(d_.mean()), 1), float(d_.max())]
             print(json.dumps(out), flush=True)
