@@ -1247,7 +1247,9 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
       unsigned arrived = 0;
       if (lane == 0) arrived = __hip_atomic_fetch_add(&sm_mlcnt, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
       arrived = (unsigned)__builtin_amdgcn_readfirstlane((int)arrived);
-      if (arrived == (unsigned)(NW - 1) && lane < RT) {  // the merge of the publish loop below, once per query head
+      const bool ml_last = arrived == (unsigned)(NW - 1) && lane < RT;
+      float ml_M = 0.f, ml_L = 0.f;
+      if (ml_last) {  // the merge of the publish loop below, once per query head (LDS traffic only inside this branch)
         const int r = lane;
         float M = sm_wm[0][r];
 #pragma unroll
@@ -1256,9 +1258,18 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
         float L = 0.f;
 #pragma unroll
         for (int w = 0; w < NW; w++) L = fmaf(sm_wl[w][r], fast_exp(sm_wm[w][r] - Mu), L);
-        const u32x4_t mg = {one_tag, __float_as_uint(M), one_tag, __float_as_uint(L)};
+        ml_M = M;
+        ml_L = L;
+      }
+      {
+        // The store is UNCONDITIONAL — every lane of every wave executes it; all but the publisher's RT lanes aim past the end of
+        // the buffer, where the hardware drops the write.  Inside the branch above it would make the compiler's in-order wait
+        // for the V rows (older loads) a wait for this write-through store's acknowledgement too (its bookkeeping merges "store
+        // issued" with "not issued" at the join): a memory round trip in front of the P.V products of the workgroup's last wave.
+        const u32x4_t mg = {one_tag, __float_as_uint(ml_M), one_tag, __float_as_uint(ml_L)};
         const auto ml_rsrc_e = __builtin_amdgcn_make_buffer_rsrc(a.one_ml, 0, (int)a.one_ml_bytes, 0x00020000);
-        __builtin_amdgcn_raw_buffer_store_b128(mg, ml_rsrc_e, h * kOneMlHead + (split * RT + r) * 16, 0, kOneAuxCoherent);
+        const int off = ml_last ? h * kOneMlHead + (split * RT + lane) * 16 : 0x7ffffff0;
+        __builtin_amdgcn_raw_buffer_store_b128(mg, ml_rsrc_e, off, 0, kOneAuxCoherent);
       }
     }
     if (more) tile_pv(tregs[0], base, false);
@@ -1531,8 +1542,11 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
     if constexpr (EML) {
       // ---- the (m, l) pairs left behind the scores: most of them are there by now.  Only the waves that fold a head poll.
       const bool ml_mine = wave < RT;  // (MLN == 1 whenever RT <= NW; with RT = 8 on four waves every wave folds two heads)
-      for (unsigned spins = 0; ml_mine; spins++) {  // round 0 was issued ahead of the partial-O stores
-        if (__all(ok_ml())) break;
+      // Round 0 (issued ahead of the partial-O stores) is examined in STRAIGHT-LINE code: the compiler then waits for exactly
+      // these loads — the oldest in flight — and not for the acknowledgements of the stores behind them (at a loop header its
+      // in-order wait counts merge with the back edge's and become a wait for everything)
+      bool ml_ok = !ml_mine || __all(ok_ml());
+      for (unsigned spins = 0; !ml_ok; spins++) {
         if (spins > kOneSpinMax) {
           timed_out = true;
           break;
@@ -1540,6 +1554,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
         __builtin_amdgcn_s_sleep(1);
         asm volatile("" ::: "memory");  // every round re-reads memory
         load_ml();
+        ml_ok = __all(ok_ml());
       }
       if (a.trace) tr4 = __builtin_amdgcn_s_memtime();
       if (ml_mine) final_ml();
