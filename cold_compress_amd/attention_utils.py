@@ -42,7 +42,7 @@ def _workspace(nbytes, device, kind="decode"):
     Decode and prefill never share one: the decode buffer carries state across launches (the single-launch step's epoch
     words, include/coldcompress.h) and its address is baked into captured hipGraphs, so it is only ever replaced by a
     larger one — and the old one is kept alive, never handed back to the allocator."""
-    key = (str(device), kind)
+    key = (_norm_device(device), kind)  # ("cuda" and "cuda:<current>" are one device)
     ws = _WS.get(key)
     if ws is None or ws.numel() < nbytes:
         if torch.cuda.is_current_stream_capturing():
@@ -61,15 +61,44 @@ def single_launch_status(device=None):
     ones included (captured hipGraphs may still run on them).  Synchronises."""
     off = int(_abi.lib()["cc_decode_step_status_offset"]())
     bad = 0
-    for (dev, kind), ws in list(_WS.items()) + [((str(w.device), k), w) for k, w in _RETIRED]:
-        if kind == "decode" and (device is None or dev == str(device)) and off + 4 <= ws.numel():
+    for ws in _decode_workspaces(device):
+        if off + 4 <= ws.numel():
             bad |= int(ws[off:off + 4].view(torch.int32).item())
     return bad
+
+
+def _norm_device(device):
+    """torch.device('cuda') and 'cuda' name the CURRENT device: workspaces are keyed by the indexed form."""
+    if device is None:
+        return None
+    d = torch.device(device)
+    if d.type == "cuda" and d.index is None:
+        d = torch.device("cuda", torch.cuda.current_device())
+    return str(d)
+
+
+def _decode_workspaces(device=None):
+    want = _norm_device(device)
+    return [ws for (dev, kind), ws in list(_WS.items()) + [((str(w.device), k), w) for k, w in _RETIRED]
+            if kind == "decode" and (want is None or _norm_device(dev) == want)]
+
+
+def reset_single_launch_status(device=None):
+    """Clear the (sticky) hand-off timeout word of `device`'s decode workspaces (default: every device) — after the failure has
+    been reported (check_single_launch_status) or the single-launch form has been switched off, so that later generations on the
+    device are judged on their own.  Synchronises."""
+    off = int(_abi.lib()["cc_decode_step_status_offset"]())
+    for ws in _decode_workspaces(device):
+        if off + 4 <= ws.numel():
+            ws[off:off + 4].zero_()
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
 
 
 def check_single_launch_status(device=None):
     """Raise loudly if a single-launch step timed out (see single_launch_status)."""
     if single_launch_status(device):
+        reset_single_launch_status(device)  # reported once: the word is sticky on the device, the next generation starts clean
         raise ColdCompressError(
             "a single-launch layer step did not complete its in-launch hand-off (its workgroups were not all resident, e.g. the "
             "GPU was shared with another kernel): the tokens produced since are invalid.  Disable the single-launch form with "

@@ -881,8 +881,17 @@ class KVCacheHybrid(_TrackedWindowSums, KVCacheHeadSpecific):
         tok = input_ids.to(device=self.punc_ids.device, dtype=torch.int64).reshape(-1)[:1].contiguous()
         return tok, self.punc_ids
 
+    def _check_next_key(self):
+        """The key rows are strided by the C side's cc_hh_next_key_slots(S): a cache constructed before the library was built
+        holds a placeholder row — resize it (the kernels would write past its end)."""
+        nk = int(_abi.lib()["cc_hh_next_key_slots"](self.max_cache_length))
+        if self.next_key.shape[1] != nk:
+            self.next_key = torch.full((self.n_heads, nk), -1, dtype=torch.int64, device=self.next_key.device)
+            self._next_valid = False
+
     def prepare_decode(self, input_pos):
         """Seed the pipeline: every head's eviction candidate for `input_pos` from the current state (one launch)."""
+        self._check_next_key()
         tab = self._policy_table()
         wsum, _ = self._window_state()
         _abi.call("cc_hybrid_next_key_init", self._view(), _ptr(self._pos32(input_pos)), _ptr(self.cache_strategies), _ptr(tab),
@@ -899,6 +908,12 @@ class KVCacheHybrid(_TrackedWindowSums, KVCacheHeadSpecific):
         from .attention_utils import _workspace
         import math
 
+        if hasattr(self, "punc_ids") and input_ids is None:
+            # ref: cache.py:975 needs the token to classify it (torch.isin(input_ids, punc_ids)); the three-call path fails on
+            # None too.  Without it the launch would skip the punctuation bookkeeping silently.
+            raise ColdCompressError("KVCacheHybrid.decode_step needs input_ids=<the token being inserted> when a policy uses "
+                                    "punctuation (cache.py:975)")
+        self._check_next_key()
         k, v = self._new_rows(k_val, v_val)
         p32 = self._pos32(input_pos)
         if not self._next_valid:

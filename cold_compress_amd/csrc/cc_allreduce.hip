@@ -101,7 +101,12 @@ __global__ __launch_bounds__(kArThreads) void allreduce_oneshot_kernel(ArArgs a)
     }
   }
   __syncthreads();
-  if (sm_bad) return;
+  if (sm_bad) {
+    // a peer's flag did not arrive in time: the status word is set (above) AND the output is poisoned, so that a caller that
+    // never reads the word cannot mistake this rank's partial sum for the result (NaN propagates into the logits)
+    for (long long i = threadIdx.x; i < a.n; i += kArThreads) ElemTraits<T>::store(reinterpret_cast<T*>(a.data), i, NAN);
+    return;
+  }
   // ---- local reduction, slots in rank order 0 .. world - 1 (fp32 accumulate, one rounding): identical on every rank
   for (long long i = threadIdx.x; i < nvec; i += kArThreads) {
     float acc[VEC];
@@ -140,12 +145,12 @@ int cc_allreduce_create(int32_t rank, int32_t world, size_t max_bytes, cc_comm**
   void* p = nullptr;
   // uncached fine-grained device memory: stores from peers over xGMI and polls by the owner are coherent without fences on
   // the cache hierarchy of either side
+  // (NO fallback to plain hipMalloc: on coarse-grained, L2-cacheable memory the owner's plain loads of a slot may be served a
+  //  stale line after its flag has been seen — wrong sums that a short self-test can miss.  The caller keeps RCCL instead.)
   if (hipExtMallocWithFlags(&p, c->total_bytes, hipDeviceMallocUncached) != hipSuccess) {
     (void)hipGetLastError();
-    if (hipMalloc(&p, c->total_bytes) != hipSuccess) {
-      free(c);
-      return CC_ERR_HIP;
-    }
+    free(c);
+    return CC_ERR_HIP;
   }
   if (hipMemset(p, 0, c->total_bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
     (void)hipFree(p);

@@ -2769,7 +2769,55 @@ static int attn_impl(const void* q, const void* k, const void* v, const uint8_t*
   return CC_OK;
 }
 
+namespace {
+// Measurement hook: the LAUNCH FLOOR of the layer step — a kernel with the step's grid, workgroup size and K/V access pattern
+// (every lane's 16-byte non-temporal loads of its rows, all issued up front) and nothing else: no scores, no hand-off, no
+// finish.  What it takes is what ANY stand-alone launch that streams this cache takes on this device (launch boundary + first
+// byte + transfer); bench.py reports the step against it (roofline.launch_floor_us / frac_of_launch_floor).
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void kv_stream_floor_kernel(const uint4* __restrict__ k, const uint4* __restrict__ v, int S,
+                                                                  int rows_per_split, unsigned* out) {
+  typedef unsigned int u32x4_nt __attribute__((ext_vector_type(4)));
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
+  const int split = blockIdx.x, h = blockIdx.y;
+  const int row_begin = split * rows_per_split, row_end = min(S, row_begin + rows_per_split);
+  const uint4* kh = k + (size_t)h * S * 16;  // 16 x 16 B per 256-byte row (16-bit caches, head_dim 128)
+  const uint4* vh = v + (size_t)h * S * 16;
+  unsigned x = 0;
+  for (int base = row_begin + wave * 16; base < row_end; base += NW * 16) {
+    u32x4_nt r[8];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int row = base + 4 * g + u < row_end ? base + 4 * g + u : row_end - 1;
+      r[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_nt*>(kh + (size_t)row * 16 + c));
+      r[4 + u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_nt*>(vh + (size_t)row * 16 + c));
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) x ^= r[u].x ^ r[u].y ^ r[u].z ^ r[u].w;
+  }
+  if (x == 0x9e3779b9u) out[0] = x;  // (never: keeps the loads alive)
+}
+
+}  // namespace
+
 extern "C" {
+
+int cc_decode_step_stream_floor(const cc_kv_view* c, int32_t HQ, void* scratch, cc_stream_t stream) {
+  CC_ENTRY();
+  if (!cc_view_ok(c) || !scratch || HQ <= 0 || HQ % c->H) return CC_ERR_BAD_ARG;
+  if (cc_dt_size(c->dtype) != 2 || c->D != 128) return CC_ERR_UNSUPPORTED;
+  const Plan p = make_plan(HQ, c->H, c->S, c->D, c->dtype, 0);
+  const dim3 grid(p.n_split, c->H, 1), block(p.nw * 64);
+  hipStream_t st = (hipStream_t)stream;
+  if (p.nw == 8)
+    hipLaunchKernelGGL(kv_stream_floor_kernel<8>, grid, block, 0, st, reinterpret_cast<const uint4*>(c->k_cache),
+                       reinterpret_cast<const uint4*>(c->v_cache), c->S, p.rows_per_split, reinterpret_cast<unsigned*>(scratch));
+  else
+    hipLaunchKernelGGL(kv_stream_floor_kernel<4>, grid, block, 0, st, reinterpret_cast<const uint4*>(c->k_cache),
+                       reinterpret_cast<const uint4*>(c->v_cache), c->S, p.rows_per_split, reinterpret_cast<unsigned*>(scratch));
+  CC_LAUNCH_CHECK();
+  return CC_OK;
+}
 
 int cc_decode_attn_gqa_phases(const void* q, const void* k, const void* v, const uint8_t* mask, int32_t HQ, int32_t H,
                               int32_t S, int32_t D, int32_t dtype, float scale, void* y, void* attn_out,

@@ -241,6 +241,9 @@ def generate(model, prompt, prefill, decode_one_token, max_new_tokens, next_toke
         from ..attention_utils import check_single_launch_status
 
         check_single_launch_status(device)
+        from ..tp import check_oneshot_allreduce_status
+
+        check_oneshot_allreduce_status()  # (a collective under tensor parallelism: every rank passes here)
     decode_tokens = len(toks) + 1
     stats = {
         "prefill_tokens": prompt_length, "decode_tokens": decode_tokens,

@@ -33,6 +33,9 @@ def maybe_init_dist() -> Optional[int]:
     if world < 2:
         return None
     if torch.cuda.is_available():
+        # the host driver only supports dmabuf IPC: RCCL / IPC handles between the ranks need this (exported by the image; set
+        # here as well in case the launcher's environment lost it) — before the first HIP call of this process
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(rank)
         backend = "nccl"  # RCCL
     else:
@@ -41,9 +44,10 @@ def maybe_init_dist() -> Optional[int]:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend=backend, rank=int(os.environ.get("RANK", rank)),
                                 world_size=int(os.environ.get("WORLD_SIZE", world)))
-    # decode-size all-reduces over the one-shot xGMI transport once it has verified itself against RCCL on this
-    # node; CC_ONESHOT_ALLREDUCE=0 keeps RCCL for everything
-    if torch.cuda.is_available() and os.environ.get("CC_ONESHOT_ALLREDUCE", "1") != "0":
+    # decode-size all-reduces over the one-shot xGMI transport: OPT-IN (CC_ONESHOT_ALLREDUCE=1) until it has run
+    # on a real multi-GPU node (so far only two ranks sharing one GPU have exercised it); it still has to verify itself against
+    # RCCL on this node before it takes over.  RCCL carries every all-reduce otherwise.
+    if torch.cuda.is_available() and os.environ.get("CC_ONESHOT_ALLREDUCE", "0") == "1":
         enable_oneshot_allreduce()
     return rank
 
@@ -88,12 +92,19 @@ class OneShotAllReduce:
         from . import _abi
 
         self._abi, self._C = _abi, C
+        self._comm = None
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         self.max_bytes = int(max_bytes)
-        fns = _abi.lib()
         on_dev = dist.get_backend(group) == "nccl"
         dev = torch.device("cuda", torch.cuda.current_device()) if on_dev else torch.device("cpu")
-        nb = int(fns["cc_allreduce_handle_bytes"]())
+        # Everything that can fail LOCALLY (a missing library, a HIP error) is caught and carried into the collectives below:
+        # every rank always runs all_gather, agree, agree — whatever happened to it
+        fns, nb, err = None, 64, ""  # (64 = sizeof(hipIpcMemHandle_t); only used to keep the all_gather's shape when the library is missing)
+        try:
+            fns = _abi.lib()
+            nb = int(fns["cc_allreduce_handle_bytes"]())
+        except Exception as e:
+            err = f"{type(e).__name__}: {e}"
 
         def agree(ok):
             """MIN over the ranks of a local verdict: every rank runs the SAME sequence of collectives whatever fails locally
@@ -102,9 +113,10 @@ class OneShotAllReduce:
             dist.all_reduce(f, op=dist.ReduceOp.MIN, group=group)
             return int(f.item()) == 1
 
-        comm, mine, err = C.c_void_p(), (C.c_uint8 * nb)(), ""
-        self._comm = None
+        comm, mine = C.c_void_p(), (C.c_uint8 * nb)()
         try:
+            if err:
+                raise RuntimeError(err)
             _abi.check(fns["cc_allreduce_create"](self.rank, self.world, self.max_bytes, C.byref(comm)), "cc_allreduce_create")
             self._comm = comm
             _abi.check(fns["cc_allreduce_export"](comm, mine), "cc_allreduce_export")
@@ -193,9 +205,32 @@ def enable_oneshot_allreduce(max_bytes=64 * 1024, verify=True):
     if not ok:
         if why:
             print(f"[cold_compress_amd.tp] one-shot all-reduce not enabled on rank {dist.get_rank()}: {why}", flush=True)
+        if comm is not None:
+            comm.close()  # (the IPC mappings and the uncached buffer are not left behind)
         return None
     _ONESHOT = comm
     return _ONESHOT
+
+
+def oneshot_allreduce_status() -> int:
+    """0, or non-zero if a one-shot all-reduce on ANY rank ever timed out waiting for a peer (its output was poisoned with NaN
+    and the sums of that step are invalid on that rank).  A collective (MAX over the ranks) when torch.distributed is up:
+    call it from every rank, after the decode loop.  0 when the transport is not in use."""
+    if _ONESHOT is None:
+        return 0
+    st = 1 if _ONESHOT.status() != 0 else 0
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        t = torch.tensor([st], dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        st = int(t.item())
+    return st
+
+
+def check_oneshot_allreduce_status():
+    """Raise loudly (on every rank) if a one-shot all-reduce timed out anywhere since the transport was enabled."""
+    if oneshot_allreduce_status():
+        raise RuntimeError("a one-shot xGMI all-reduce timed out waiting for a peer on some rank: the tokens produced since are "
+                           "invalid (its output was poisoned with NaN).  Unset CC_ONESHOT_ALLREDUCE to keep RCCL for every all-reduce.")
 
 
 def _all_reduce_hook(_module, _input, output):

@@ -281,6 +281,12 @@ void cc_decode_step_set_wide(int32_t enabled);
  * when its K rows have arrived / its scores are in registers / its P.V products are issued, [14..15] s_memtime of thread 0 behind the
  * two barriers of the finish. */
 void cc_decode_step_trace(void* buf);
+/* Measurement hook: the launch floor of the layer step over cache `c` — a kernel with the step's grid, workgroup size and
+ * K/V access pattern (every row read once with the step's 16-byte non-temporal loads) and NOTHING else.  Its duration is what
+ * any stand-alone launch streaming this cache costs on the device (launch boundary + first byte + transfer): bench.py times
+ * it beside the step (roofline.launch_floor_us, frac_of_launch_floor).  16-bit caches with head_dim 128; scratch: >= 4 bytes
+ * of device memory (never written in practice). */
+int cc_decode_step_stream_floor(const cc_kv_view* c, int32_t HQ, void* scratch, cc_stream_t stream);
 /* The two-launch step for KVCacheHybrid (FastGen per-head policies; cache.py:896-1019 + the fused ring update of
  * cc_decode_attn_gqa_ring): three launches -> two.  What a head does with the incoming token — append at the end of its
  * live slots, evict its candidate, or drop the token (slot S - 1, mask untouched) — depends on its policy, its count, the
