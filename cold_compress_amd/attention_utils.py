@@ -182,11 +182,29 @@ def prefill_attention(query, key, value, scale=None, return_attn=False, obs_len=
     return y, AttnSummary(colsum, obs, ol, dt, {b: band_out[i] for i, b in enumerate(bands)})
 
 
+_CAUSAL_SEEN = {}  # (data_ptr, shape, version, device) -> verdict of the full comparison
+
+
 def _is_causal_mask(attn_mask, L):
+    """Is `attn_mask` the lower-triangular causal mask?  The caller model passes the SAME mask tensor to every layer
+    (model.py:402-411: a slice of its precomputed causal_mask): the L x L comparison (268 MB of traffic at L = 16k) is made once
+    per distinct tensor — keyed by storage address, shape and version counter — after an O(L) look at the first and last rows
+    has not already ruled it out."""
     if attn_mask is None or attn_mask.shape[-2:] != (L, L) or attn_mask.dtype != torch.bool:
         return False
-    tril = torch.ones(L, L, dtype=torch.bool, device=attn_mask.device).tril_()
-    return bool((attn_mask.reshape(-1, L, L) == tril).all())
+    key = (attn_mask.data_ptr(), tuple(attn_mask.shape), tuple(attn_mask.stride()), attn_mask._version, str(attn_mask.device))
+    hit = _CAUSAL_SEEN.get(key)
+    if hit is not None:
+        return hit
+    m = attn_mask.reshape(-1, L, L)
+    ok = bool(m[:, -1, :].all()) and bool(m[:, 0, 0].all()) and (L == 1 or not bool(m[:, 0, 1:].any()))
+    if ok:
+        tril = torch.ones(L, L, dtype=torch.bool, device=attn_mask.device).tril_()
+        ok = bool((m == tril).all())
+    if len(_CAUSAL_SEEN) > 64:
+        _CAUSAL_SEEN.clear()
+    _CAUSAL_SEEN[key] = ok
+    return ok
 
 
 def _topk_decode_attention(query, key, value, attn_mask, scale, top_k):

@@ -311,6 +311,9 @@ extern "C" int cc_prefill_attn_mfma_impl(const void* q, const void* k, const voi
                                          float scale, void* y, float* stats, float* cpart, int nwg, void* vt, const int* bands,
                                          int nb, int obs_len, hipStream_t st);
 
+extern "C" int cc_prefill_attn_flash_impl(const void* q, const void* k, const void* v, int HQ, int H, int L, int D, int dtype,
+                                          float scale, void* y, int nwg, void* vt, hipStream_t st);
+
 extern "C" {
 
 size_t cc_prefill_attn_workspace_bytes(int32_t HQ, int32_t H, int32_t L, int32_t D, int32_t dtype) {
@@ -363,6 +366,15 @@ int cc_prefill_attn_bands(const void* q, const void* k, const void* v, int32_t H
     static const char* e_nwg = getenv("CC_PREFILL_NWG");  // measurement only
     if (e_nwg && atoi(e_nwg) > 0 && atoi(e_nwg) < nwg) nwg = atoi(e_nwg);
     char* vt = reinterpret_cast<char*>(a.cpart) + align256((size_t)(2 + kMaxBands) * kNWGMfma * H * L * sizeof(float));
+    // nobody wants the probabilities (ref: attention_utils.py:27-35, the fused fast path of recent_global / l2 / random / full):
+    // ONE pass with online softmax instead of statistics + probabilities
+    static const bool two_pass_only = getenv("CC_PREFILL_TWO_PASS") != nullptr;  // measurement only
+    if (!a.colsum && !a.obs && !a.band_out && !two_pass_only) {
+      static const char* e_nwgf = getenv("CC_PREFILL_NWG_FLASH");  // measurement only
+      int nwgf = nqt < 128 ? nqt : 128;
+      if (e_nwgf && atoi(e_nwgf) > 0) nwgf = nqt < atoi(e_nwgf) ? nqt : atoi(e_nwgf);
+      return cc_prefill_attn_flash_impl(q, k, v, HQ, H, L, D, dtype, scale, y, nwgf, vt, st);
+    }
     const int obs_len = a.obs ? a.obs_len : 0;
     const int rc = cc_prefill_attn_mfma_impl(q, k, v, HQ, H, L, D, dtype, scale, y, a.stats, a.cpart, nwg, vt, a.band, a.nb, obs_len, st);
     if (rc != CC_OK) return rc;

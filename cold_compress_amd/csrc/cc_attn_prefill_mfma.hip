@@ -459,6 +459,180 @@ __global__ __launch_bounds__(256, 2) void prefill_pv_lds_kernel(MArgs a) {
     for (int k = 0; k < 8; k++) a.trace[(h * 4 + r) * 8 + k] = tr_acc[k];
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Single pass (r3): causal attention when NOBODY wants the probabilities — the reference's fast path, attention_utils.py:27-35
+// (F.scaled_dot_product_attention for recent_global / l2 / random / full: no cache state is built from the attention).  Same
+// workgroup shape and LDS pipeline as pass 2 (K and V^T tiles fetched once per workgroup, one tile ahead, double-buffered
+// swizzled images), but no stats pass in front, no probability tiles through LDS, no side planes, ONE barrier per tile:
+// online softmax on the swapped S^T tile (every row statistic lane-local + one half-wave exchange), P unnormalised in the
+// model dtype as the A operand, O rescaled only when a row's reference maximum moves.
+// The reference maximum is LAZY: it is raised only when a tile's row maximum exceeds it by more than kLazy (2^kLazy-fold growth
+// of the unnormalised probabilities is harmless in fp32 / bf16: relative rounding is scale-free), so that after the first few
+// tiles whole waves skip the rescale — which needs the rows' factors in the O layout (rows = queries across registers), i.e. a
+// trip through a wave-private LDS row and 64 multiplies.
+// Numerics: scores rounded as the reference's (dtype(dtype(q.k) * scale)); P rounded to the model dtype unnormalised instead of
+// normalised — a different, equally good rounding of the same quantity: y within the contract's 1e-3 + 2 roundings of the oracle.
+constexpr float kLazy = 6.0f;  // in units of the scaled logits (natural log): e^6 = 403
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void prefill_flash_kernel(MArgs a) {
+  __shared__ __attribute__((aligned(16))) uint4 sm_kt[2][kTK][16];   // [buf][key][chunk ^ (key & 15)]
+  __shared__ __attribute__((aligned(16))) uint4 sm_vt[2][kD][4];     // [buf][d][chunk ^ ((d >> 2) & 3)]  (V^T, permuted keys)
+  __shared__ __attribute__((aligned(16))) float sm_row[4][kTQ];      // per wave: a factor per query row, re-read in the O layout
+  const int lane = threadIdx.x & 63, r = threadIdx.x >> 6;
+  const int hi = lane >> 5, lq = lane & 31;
+  int bx, h;
+  wg_coords(a, bx, h);
+  const int L = a.L;
+  const int j = h * 4 + r;
+  const T* qh = reinterpret_cast<const T*>(a.q) + (size_t)j * L * kD;
+  const T* kh = reinterpret_cast<const T*>(a.k) + (size_t)h * L * kD;
+  const T* vth = reinterpret_cast<const T*>(a.vt) + (size_t)h * kD * a.Lp;
+  const int nqt = (L + kTQ - 1) / kTQ;
+  const int kl_row = threadIdx.x >> 3, kl_c0 = (threadIdx.x & 7) * 2;   // K tile: row t/8, chunks 2(t%8), +1
+  const int vl_row = threadIdx.x >> 1, vl_c0 = (threadIdx.x & 1) * 2;   // V^T tile: d row t/2, chunks 2(t%2), +1
+  // (the 16 query rows of this lane's O registers: c_row(e, hi) = (e & 3) + 8 (e >> 2) + 4 hi -> four runs of four floats of sm_row)
+
+  for (int i = 0; i * a.nwg < nqt; i++) {
+    const int qt = q_tile(i, bx, a.nwg);
+    if (qt >= nqt) continue;  // ragged last round (uniform over the workgroup)
+    const int q0 = qt * kTQ;
+    const int query = q0 + lq;
+    const int qc = query < L ? query : L - 1;
+    uint4 qb[8];
+#pragma unroll
+    for (int ds = 0; ds < 8; ds++) qb[ds] = *reinterpret_cast<const uint4*>(qh + (size_t)qc * kD + ds * 16 + 8 * hi);
+    float m_ref = -INFINITY, l_run = 0.f;  // the row's reference maximum (both half-wave lanes agree) / this lane's share of l
+    f32x16 o[4];
+#pragma unroll
+    for (int b = 0; b < 4; b++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) o[b][e] = 0.f;
+    const int last_q = min(L, q0 + kTQ) - 1;
+    const int ntile = last_q / kTK + 1;
+    uint4 sk0, sk1, sv0, sv1;
+    auto fetch = [&](int t) {
+      const int krow = min(t * kTK + kl_row, L - 1);
+      const uint4* ks = reinterpret_cast<const uint4*>(kh + (size_t)krow * kD) + kl_c0;
+      sk0 = ks[0];
+      sk1 = ks[1];
+      const uint4* vs = reinterpret_cast<const uint4*>(vth + (size_t)vl_row * a.Lp + t * kTK) + vl_c0;
+      sv0 = vs[0];
+      sv1 = vs[1];
+    };
+    auto stash = [&](int buf) {
+      sm_kt[buf][kl_row][(kl_c0 ^ (kl_row & 15)) & 15] = sk0;
+      sm_kt[buf][kl_row][((kl_c0 + 1) ^ (kl_row & 15)) & 15] = sk1;
+      sm_vt[buf][vl_row][(vl_c0 ^ ((vl_row >> 2) & 3)) & 3] = sv0;
+      sm_vt[buf][vl_row][((vl_c0 + 1) ^ ((vl_row >> 2) & 3)) & 3] = sv1;
+    };
+    auto tile = [&](int t, auto full_c) {
+      constexpr bool FULL = decltype(full_c)::value;
+      const int k0 = t * kTK, buf = t & 1;
+      if (t + 1 < ntile) fetch(t + 1);
+      f32x16 s;
+#pragma unroll
+      for (int e = 0; e < 16; e++) s[e] = 0.f;
+#pragma unroll
+      for (int ds = 0; ds < 8; ds++) s = MfmaOps<T>::mma(sm_kt[buf][lq][((2 * ds + hi) ^ (lq & 15)) & 15], qb[ds], s);
+      float x[16];
+#pragma unroll
+      for (int e = 0; e < 16; e += 2) {  // ref: attention_utils.py:37 dtype(dtype(q.k) * scale), two elements per conversion
+        float r0, r1;
+        pf_rnd2<T>(s[e], s[e + 1], r0, r1);
+        pf_rnd2<T>(r0 * a.scale, r1 * a.scale, x[e], x[e + 1]);
+      }
+      if (!FULL) {
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+          const int key = k0 + c_row(e, hi);
+          if (key > query || key >= L || query >= L) x[e] = -INFINITY;
+        }
+      }
+      float mx = x[0];
+#pragma unroll
+      for (int e = 1; e < 16; e++) mx = fmaxf(mx, x[e]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, CC_WAVE));  // the row's maximum over the tile's 32 keys (both half-wave lanes hold it)
+      // lazy reference maximum: raised only when the tile's maximum leaves it more than kLazy behind (or at the first live tile)
+      const bool raise = mx > m_ref + kLazy || (m_ref == -INFINITY && mx > -INFINITY);
+      const float m_new = raise ? mx : m_ref;
+      float alpha = 1.f;
+      if (raise) alpha = m_ref == -INFINITY ? 0.f : pf_exp(m_ref - m_new);
+      m_ref = m_new;
+      const float mneg = m_new == -INFINITY ? 0.f : -m_new * kLog2e;
+      uint32_t pp[8];  // the unnormalised probabilities as packed 16-bit pairs: the A operand of the P.V products
+      float psum = 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; e += 2) {
+        float p0, p1;
+        const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(x[e], kLog2e, mneg));
+        const float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(x[e + 1], kLog2e, mneg));
+        pp[e >> 1] = pf_rnd2<T>(e0, e1, p0, p1);
+        psum += p0 + p1;  // l sums what P.V multiplies: the ROUNDED weights (y is a proper weighted mean of the V rows)
+      }
+      l_run = l_run * alpha + psum;
+      if (__any(raise)) {  // wave-uniform: some row's reference moved — its factor travels to the O layout through LDS
+        if (hi == 0) sm_row[r][lq] = alpha;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int g4 = 0; g4 < 4; g4++) {  // four rows at a time: the factors never sit in sixteen registers
+          const float4 f4 = *reinterpret_cast<const float4*>(&sm_row[r][8 * g4 + 4 * hi]);
+#pragma unroll
+          for (int db = 0; db < 4; db++) {
+            o[db][4 * g4] *= f4.x;
+            o[db][4 * g4 + 1] *= f4.y;
+            o[db][4 * g4 + 2] *= f4.z;
+            o[db][4 * g4 + 3] *= f4.w;
+          }
+        }
+        __builtin_amdgcn_wave_barrier();  // (the row is rewritten by the next raise)
+      }
+      // O += P . V : A = P (C layout -> 16-bit), B = V^T fragments from the LDS image
+#pragma unroll
+      for (int kb = 0; kb < 2; kb++) {
+        const uint4 pa = make_uint4(pp[kb * 4 + 0], pp[kb * 4 + 1], pp[kb * 4 + 2], pp[kb * 4 + 3]);
+#pragma unroll
+        for (int db = 0; db < 4; db++) {
+          const int d = db * 32 + lq;
+          o[db] = MfmaOps<T>::mma(pa, sm_vt[buf][d][((kb * 2 + hi) ^ ((d >> 2) & 3)) & 3], o[db]);
+        }
+      }
+      if (t + 1 < ntile) stash((t + 1) & 1);
+      __syncthreads();  // tile t + 1 is in LDS; every wave is done reading tile t's images
+    };
+    __syncthreads();  // the previous query tile's last readers are done with both buffers
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    const int n_full = (q0 + kTQ <= L) ? min(ntile, (q0 + 1) / kTK) : 0;  // tiles strictly below the diagonal of a complete query tile
+    for (int t = 0; t < n_full; t++) tile(t, BoolC<true>{});
+    for (int t = n_full; t < ntile; t++) tile(t, BoolC<false>{});
+    // y = O / l: the rows' 1 / l in the O layout, through the wave's LDS row
+    const float lt = l_run + __shfl_xor(l_run, 32, CC_WAVE);
+    if (hi == 0) sm_row[r][lq] = __frcp_rn(lt);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    T* yh = reinterpret_cast<T*>(a.y) + (size_t)j * L * kD;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; g4++) {
+      const float4 i4 = *reinterpret_cast<const float4*>(&sm_row[r][8 * g4 + 4 * hi]);
+      const float inv[4] = {i4.x, i4.y, i4.z, i4.w};
+#pragma unroll
+      for (int db = 0; db < 4; db++)
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int e = 4 * g4 + u;
+          const int qrow = q0 + c_row(e, hi);
+          if (qrow < L) ElemTraits<T>::store(yh, (size_t)qrow * kD + db * 32 + lq, o[db][e] * inv[u]);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 template <typename T>
 static void launch_pv(const MArgs& a, dim3 grid, hipStream_t st) {
   switch (a.nb) {
@@ -469,6 +643,31 @@ static void launch_pv(const MArgs& a, dim3 grid, hipStream_t st) {
 }
 
 }  // namespace
+
+// Single-pass entry (no side outputs).  workspace: vt_perm only.
+extern "C" int cc_prefill_attn_flash_impl(const void* q, const void* k, const void* v, int HQ, int H, int L, int D, int dtype,
+                                          float scale, void* y, int nwg, void* vt, hipStream_t st) {
+  if (D != kD || HQ != 4 * H || (dtype != CC_DT_BF16 && dtype != CC_DT_F16)) return CC_ERR_UNSUPPORTED;
+  const int Lp = (L + 31) & ~31;
+  MArgs a{};
+  a.q = q; a.k = k; a.vt = vt; a.y = y;
+  a.H = H; a.L = L; a.Lp = Lp; a.scale = scale; a.nwg = nwg;
+  static const bool no_remap = getenv("CC_PREFILL_NO_XCD_REMAP") != nullptr;  // measurement only
+  a.xcd_remap = (H % 8 == 0 && !no_remap) ? 1 : 0;
+  const size_t tot = (size_t)H * kD * Lp;
+  size_t nbk = (tot + 255) / 256;
+  if (nbk > 8192) nbk = 8192;
+  const dim3 grid((unsigned)(nwg * H)), block(256);
+  if (dtype == CC_DT_BF16) {
+    hipLaunchKernelGGL(vt_perm_kernel<bf16_t>, dim3((unsigned)nbk), dim3(256), 0, st, (const bf16_t*)v, (bf16_t*)vt, H, L, Lp);
+    hipLaunchKernelGGL(prefill_flash_kernel<bf16_t>, grid, block, 0, st, a);
+  } else {
+    hipLaunchKernelGGL(vt_perm_kernel<f16_t>, dim3((unsigned)nbk), dim3(256), 0, st, (const f16_t*)v, (f16_t*)vt, H, L, Lp);
+    hipLaunchKernelGGL(prefill_flash_kernel<f16_t>, grid, block, 0, st, a);
+  }
+  if (hipGetLastError() != hipSuccess) return CC_ERR_HIP;
+  return CC_OK;
+}
 
 // Entry used by cc_attn_prefill.hip's dispatcher.  Returns CC_ERR_UNSUPPORTED when the geometry is not the MFMA one.
 // workspace layout is owned by the caller: stats | cpart planes | vt_perm.

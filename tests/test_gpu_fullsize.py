@@ -68,6 +68,35 @@ def test_prefill_bands_full_size(oracle_mt, L):
     assert bool((summ.bands[band] <= summ.colsum + 1e-3).all())
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("L,H", [(8192, 1), (16384, 1), (1000, 2), (97, 1), (4133, 8)])
+def test_prefill_single_pass_full_size(oracle_mt, L, H):
+    """return_attn=False: the ONE-pass causal attention (online softmax; the reference's fused fast path,
+    attention_utils.py:27-35) against the oracle's attention at the BASELINE prompt lengths and at ragged ones, and against
+    the two-pass product path on the same inputs (a different rounding of the probabilities, the same contract)."""
+    from cold_compress_amd.attention_utils import prefill_attention
+
+    o = oracle_mt
+    R, D, dtype = 4, 128, torch.bfloat16
+    HQ = H * R
+    gen = torch.Generator().manual_seed(L + H)
+    q = (1.5 * torch.randn(1, HQ, L, D, generator=gen)).to(dtype)
+    k = (1.5 * torch.randn(1, H, L, D, generator=gen)).to(dtype)
+    v = torch.randn(1, H, L, D, generator=gen).to(dtype)
+    y, summ = prefill_attention(q.to(DEV), k.to(DEV), v.to(DEV), return_attn=False)
+    assert summ is None
+    y2, _ = prefill_attention(q.to(DEV), k.to(DEV), v.to(DEV), return_attn=True)
+    torch.cuda.synchronize()
+    yo, cs, ob = np.zeros((HQ, L, D), np.uint16), np.zeros((H, L), np.float32), np.zeros((H, L), np.float32)
+    o.call("cc_prefill_attn", o.ptr(to_np(q[0])), o.ptr(to_np(k[0])), o.ptr(to_np(v[0])), HQ, H, L, D, 1, 1.0 / math.sqrt(D),
+           o.ptr(yo), o.ptr(cs), o.ptr(ob), 16, None, 0, None)
+    yref = from_np(yo, dtype).float()
+    tol = 1e-3 + 2 * BF16_ULP * float(yref.abs().max())  # the north star's 1e-3 + two roundings of the output dtype
+    assert not bool(torch.isnan(y).any())
+    assert float((y.cpu().float()[0] - yref).abs().max()) <= tol
+    assert float((y.cpu().float() - y2.cpu().float()).abs().max()) <= tol
+
+
 HYBRID = [{"strategy": "window", "recent_window": 0.1},
           {"strategy": "window_heavy_hitter", "heavy_hitter_frac": 0.25, "recent_window": 0.1},
           {"strategy": "window_heavy_hitter", "heavy_hitter_frac": 0.5, "recent_window": 0.1},
