@@ -182,28 +182,28 @@ def prefill_attention(query, key, value, scale=None, return_attn=False, obs_len=
     return y, AttnSummary(colsum, obs, ol, dt, {b: band_out[i] for i, b in enumerate(bands)})
 
 
-_CAUSAL_SEEN = {}  # (data_ptr, shape, version, device) -> verdict of the full comparison
+_CAUSAL_SEEN = {}  # id(tensor) -> (weak reference to it, its version, verdict of the full comparison)
 
 
 def _is_causal_mask(attn_mask, L):
-    """Is `attn_mask` the lower-triangular causal mask?  The caller model passes the SAME mask tensor to every layer
-    (model.py:402-411: a slice of its precomputed causal_mask): the L x L comparison (268 MB of traffic at L = 16k) is made once
-    per distinct tensor — keyed by storage address, shape and version counter — after an O(L) look at the first and last rows
-    has not already ruled it out."""
+    """Is `attn_mask` the lower-triangular causal mask?  The caller model hands the SAME mask tensor to every layer of a forward
+    pass (model.py:402-411: one slice of its precomputed causal_mask): the L x L comparison (268 MB of traffic at L = 16k) is made
+    once per tensor OBJECT (weakly referenced, so a recycled address can never inherit a verdict; its version counter catches
+    in-place edits) — after an O(L) look at the first and last rows has not already ruled it out."""
+    import weakref
+
     if attn_mask is None or attn_mask.shape[-2:] != (L, L) or attn_mask.dtype != torch.bool:
         return False
-    key = (attn_mask.data_ptr(), tuple(attn_mask.shape), tuple(attn_mask.stride()), attn_mask._version, str(attn_mask.device))
-    hit = _CAUSAL_SEEN.get(key)
-    if hit is not None:
-        return hit
+    hit = _CAUSAL_SEEN.get(id(attn_mask))
+    if hit is not None and hit[0]() is attn_mask and hit[1] == attn_mask._version:
+        return hit[2]
     m = attn_mask.reshape(-1, L, L)
     ok = bool(m[:, -1, :].all()) and bool(m[:, 0, 0].all()) and (L == 1 or not bool(m[:, 0, 1:].any()))
     if ok:
         tril = torch.ones(L, L, dtype=torch.bool, device=attn_mask.device).tril_()
         ok = bool((m == tril).all())
-    if len(_CAUSAL_SEEN) > 64:
-        _CAUSAL_SEEN.clear()
-    _CAUSAL_SEEN[key] = ok
+    key = id(attn_mask)
+    _CAUSAL_SEEN[key] = (weakref.ref(attn_mask, lambda _r, key=key: _CAUSAL_SEEN.pop(key, None)), attn_mask._version, ok)
     return ok
 
 
