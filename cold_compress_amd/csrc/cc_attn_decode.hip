@@ -635,7 +635,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
   constexpr bool ONE1 = ONE && NT == 1;  // the single-tile form: no loop tail, no rescale, per-slot state requested ahead of the tile
   // EML (r3): the workgroup's (m, l) pairs leave EARLY — right behind the scores, while the V rows are still in flight — so that
   // the final (M, L) of the head, the probabilities, the history update and the next-eviction keys run in the shadow of the
-  // partial-O exchange; what is left behind the last O granule is the y fold alone (DESIGN §2.4c)
+  // partial-O exchange; what is left behind the last O granule is the y fold alone (DESIGN §2.2)
 #ifndef CC_AB_EML
 #define CC_AB_EML 1
 #endif

@@ -309,7 +309,7 @@ static int requant_launch(const RequantSet& rs, int n, int32_t H, int32_t S, int
 
 
 // ---------------------------------------------------------------------------------------------------------------
-// The FUSED quantised cache (opt-in; NOT the reference's contract — include/coldcompress.h, DESIGN §2.7b): one
+// The FUSED quantised cache (opt-in; NOT the reference's contract — include/coldcompress.h, DESIGN §2.5): one
 // (scale, minimum) pair per (head, slot) ROW of K and of V, fp32, fixed when the row is written; the decode kernels read
 // the uint8 images and dequantise in registers.  These two kernels convert whole caches (prefill, debugging): one wave
 // per row, two passes over the row (the second one hits L1).
