@@ -105,6 +105,7 @@ SIGNATURES = {
     "cc_topk_keep": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _sz, _vp]),
     "cc_gather_rows": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "cc_gather_vec": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "cc_analysis_loss": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp]),
     "cc_snapkv_priority": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "cc_prefill_attn_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32, _i32]),
     "cc_prefill_attn": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _i32, _vp,

@@ -1200,18 +1200,18 @@ class KVCacheAnalysis(KVCacheFull):
                 raise ColdCompressError(f"debug_{type(self.compressed).__name__}: the analysed cache returns no attention, so there "
                                         "is nothing to measure (the reference fails here on `attn.shape`, cache.py:1395)")
             _need_device(attn, "attn")
-            S_full = attn.shape[-1]
-            Hp, S = self.compressed.pos.shape[1], self.compressed.max_cache_length
-            idx = self.compressed.pos.reshape(Hp, S).to(torch.int64)
-            idx = torch.where(idx == -1, torch.full_like(idx, S_full - 1), idx).contiguous()  # unfilled -> the last (zero) column
-            src = attn.reshape(-1, S_full)[:Hp].contiguous()  # a [1, 1, S] index gathers kv head 0 only (cache.py:1393)
+            # ONE launch (cc_analysis_loss): the shadow cache's view of the attention row (unfilled slots read the last, zero,
+            # column; a head-constant shadow cache reads kv head 0, like the reference's [1, 1, S] gather index), the attention
+            # mass it lost — 1 - the mass of the tokens it still holds, averaged over heads — recorded at attention_loss_ctr,
+            # and the counter's increment: no device scalar travels to the host
+            comp = self.compressed
+            Hp, S, S_full = comp.pos.shape[1], comp.max_cache_length, attn.shape[-1]
+            src = attn.reshape(-1, S_full)
+            src = src if src.is_contiguous() else src.contiguous()
             sub = torch.empty((1, Hp, S), dtype=attn.dtype, device=attn.device)
-            _abi.call("cc_gather_vec", _ptr(src), _ptr(idx), Hp, S_full, S, _DT[attn.dtype], _ptr(sub), _stream())
-            self.compressed.update_state(input_pos, k_val, v_val, is_prefill, sub)
-            # the attention mass of the evicted tokens = 1 - the mass of the tokens the shadow cache still holds
-            loss = (1 - sub.sum(dim=-1)).mean()
-            self.attention_losses[self.attention_loss_ctr.to(torch.int64)] = loss
-            self.attention_loss_ctr += 1
+            _abi.call("cc_analysis_loss", _ptr(src), _ptr(comp.pos), Hp, S_full, S, _DT[attn.dtype], _ptr(sub),
+                      _ptr(self.attention_losses), _ptr(self.attention_loss_ctr), self.attention_losses.numel(), _stream())
+            comp.update_state(input_pos, k_val, v_val, is_prefill, sub)
 
     def compute_statistics(self, seq_len):
         stats = super().compute_statistics(seq_len)

@@ -179,6 +179,45 @@ __global__ __launch_bounds__(256) void gather_rows_small_kernel(const T* src, co
   }
 }
 
+// KVCacheAnalysis' decode-time bookkeeping in ONE launch.  ref: cache.py:1391-1404 — the attention row over the FULL cache is
+// restricted to the slots the shadow cache still holds (unfilled slots read the last, zero, column), handed on as the shadow
+// cache's attention, and the mass it lost is recorded: loss = mean_h dtype(1 - dtype(sum_s sub[h, s])), in the model dtype.
+// One workgroup (a debug path: Hp * S <= a few 100 k elements); fp32 sums folded in a fixed order (the reference's own fp32
+// order inside torch.sum is unspecified: compared to one rounding of the dtype).
+template <typename T>
+__global__ __launch_bounds__(1024) void analysis_loss_kernel(const T* attn, const int32_t* pos, int Hp, int S_full, int S, T* sub, T* losses,
+                                                             int32_t* ctr, int cap) {
+  __shared__ float sm_part[16];
+  __shared__ float sm_head[64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int h = 0; h < Hp; h++) {
+    float acc = 0.f;
+    for (int s = threadIdx.x; s < S; s += 1024) {
+      const int p = pos[(size_t)h * S + s];
+      const float v = ElemTraits<T>::load(attn, (size_t)h * S_full + (p == -1 ? S_full - 1 : p));
+      ElemTraits<T>::store(sub, (size_t)h * S + s, v);
+      acc += v;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, CC_WAVE);
+    if (lane == 0) sm_part[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float t = 0.f;
+      for (int w = 0; w < 16; w++) t += sm_part[w];
+      sm_head[h] = ElemTraits<T>::rnd(1.0f - ElemTraits<T>::rnd(t));  // dtype(1 - dtype(sum))
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int h = 0; h < Hp; h++) t += sm_head[h];
+    const int c = *ctr;
+    if (c >= 0 && c < cap) ElemTraits<T>::store(losses, c, t / (float)Hp);  // .mean() -> dtype
+    *ctr = c + 1;
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void gather_vec_kernel(const T* src, const int64_t* keep, int Hs, int L, int K, T* dst) {
   const int total = Hs * K;
@@ -304,6 +343,21 @@ int cc_gather_vec(const void* src, const int64_t* keep, int32_t Hs, int32_t L, i
     case CC_DT_F32: hipLaunchKernelGGL(gather_vec_kernel<float>, grid, block, 0, st, (const float*)src, keep, Hs, L, K, (float*)dst); break;
     case CC_DT_BF16: hipLaunchKernelGGL(gather_vec_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)src, keep, Hs, L, K, (bf16_t*)dst); break;
     default: hipLaunchKernelGGL(gather_vec_kernel<f16_t>, grid, block, 0, st, (const f16_t*)src, keep, Hs, L, K, (f16_t*)dst); break;
+  }
+  CC_LAUNCH_CHECK();
+  return CC_OK;
+}
+
+int cc_analysis_loss(const void* attn, const int32_t* pos, int32_t Hp, int32_t S_full, int32_t S, int32_t dtype, void* sub_out,
+                     void* losses, int32_t* loss_ctr, int32_t cap, cc_stream_t stream) {
+  CC_ENTRY();
+  if (!attn || !pos || !sub_out || !losses || !loss_ctr || Hp <= 0 || Hp > 64 || S_full <= 0 || S <= 0 || cap <= 0 || !cc_dt_ok(dtype))
+    return CC_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  switch (dtype) {
+    case CC_DT_F32: hipLaunchKernelGGL(analysis_loss_kernel<float>, dim3(1), dim3(1024), 0, st, (const float*)attn, pos, Hp, S_full, S, (float*)sub_out, (float*)losses, loss_ctr, cap); break;
+    case CC_DT_BF16: hipLaunchKernelGGL(analysis_loss_kernel<bf16_t>, dim3(1), dim3(1024), 0, st, (const bf16_t*)attn, pos, Hp, S_full, S, (bf16_t*)sub_out, (bf16_t*)losses, loss_ctr, cap); break;
+    default: hipLaunchKernelGGL(analysis_loss_kernel<f16_t>, dim3(1), dim3(1024), 0, st, (const f16_t*)attn, pos, Hp, S_full, S, (f16_t*)sub_out, (f16_t*)losses, loss_ctr, cap); break;
   }
   CC_LAUNCH_CHECK();
   return CC_OK;

@@ -430,6 +430,16 @@ int cc_gather_rows(const void* src, const int64_t* keep, int32_t Hk, int32_t H, 
 int cc_gather_vec(const void* src, const int64_t* keep, int32_t Hs, int32_t L, int32_t K, int32_t dtype,
                   void* dst, cc_stream_t stream);
 
+/* KVCacheAnalysis (`debug_<strategy>`) decode-time bookkeeping in one launch.  ref: cache.py:1391-1404.
+ *   attn: [>= Hp, S_full] dtype — the group-mean attention row over the FULL cache (row h = kv head h; a head-constant shadow
+ *         cache reads row 0 only, like the reference's gather with a [1, 1, S] index);
+ *   pos:  [Hp, S] int32 — the shadow cache's positions, -1 = unfilled (reads the last column, which is zero);
+ *   sub_out: [Hp, S] dtype = attn[h, pos[h, s]] — what the shadow cache's update_state receives;
+ *   losses[*loss_ctr] = dtype(mean_h dtype(1 - dtype(sum_s sub_out[h, s]))), then *loss_ctr += 1 (device scalars; cap = length of
+ *   losses; an index beyond it is counted but not stored).  Hp <= 64. */
+int cc_analysis_loss(const void* attn, const int32_t* pos, int32_t Hp, int32_t S_full, int32_t S, int32_t dtype, void* sub_out,
+                     void* losses, int32_t* loss_ctr, int32_t cap, cc_stream_t stream);
+
 /* SnapKV priority.  ref: PromptCompressorHeavyHitter._token_importances prompt_compression.py:170-187.
  *   obs_mean: [H, L] dtype = mean over the last min(16,L) query rows of the group-averaged probabilities.
  *   out[h,t] = dtype(avgpool5(obs_mean)[h,t]) (pad 2, count_include_pad=False);

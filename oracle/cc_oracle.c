@@ -598,6 +598,30 @@ int cc_gather_vec_cpu(const void* src, const int64_t* keep, int32_t Hs, int32_t 
   return CC_OK;
 }
 
+/* ref: KVCacheAnalysis.update_state cache.py:1391-1404 (decode): indices[indices == -1] = S_full - 1;
+ * attn_compressed = attn.gather(indices); loss = (1 - attn_compressed.sum(-1)).mean() in the model dtype. */
+int cc_analysis_loss_cpu(const void* attn, const int32_t* pos, int32_t Hp, int32_t S_full, int32_t S, int32_t dtype, void* sub_out,
+                         void* losses, int32_t* loss_ctr, int32_t cap, cc_stream_t stream) {
+  (void)stream;
+  if (!attn || !pos || !sub_out || !losses || !loss_ctr || Hp <= 0 || Hp > 64 || S_full <= 0 || S <= 0 || cap <= 0 || !dt_ok(dtype))
+    return CC_ERR_BAD_ARG;
+  float tot = 0.f;
+  for (int h = 0; h < Hp; h++) {
+    float acc = 0.f;
+    for (int s = 0; s < S; s++) {
+      const int p = pos[(size_t)h * S + s];
+      const float v = ld(attn, dtype, (size_t)h * S_full + (p == -1 ? S_full - 1 : p));
+      st(sub_out, dtype, (size_t)h * S + s, v);
+      acc += v;
+    }
+    tot += rnd(1.0f - rnd(acc, dtype), dtype);
+  }
+  const int c = *loss_ctr;
+  if (c >= 0 && c < cap) st(losses, dtype, (size_t)c, tot / (float)Hp);
+  *loss_ctr = c + 1;
+  return CC_OK;
+}
+
 /* ref: PromptCompressorHeavyHitter._token_importances prompt_compression.py:170-187.
  * AvgPool1d(kernel 5, stride 1, padding 2, count_include_pad=False): mean of the in-range neighbours,
  * fp32 accumulate, rounded to the model dtype; then the observation window and the global tokens are

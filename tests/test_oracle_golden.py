@@ -328,3 +328,33 @@ def test_budget_fixture_is_readable():
         rows = json.load(fh)
     assert rows["normalize"][0] == [0.25, 10240, 2560]
     assert rows["normalize"][1] == [0.1, 34816, 3488]
+
+
+@pytest.mark.parametrize("name", ["f10_analysis_hh_f32.npz", "f10_analysis_hh_bf16.npz"])
+def test_analysis_loss_matches_reference_capture(oracle, name):
+    """cc_analysis_loss_cpu (KVCacheAnalysis' decode-time gather + attention-loss record, cache.py:1391-1404) on the reference's
+    own trace: the attention row over the full cache and the shadow cache's positions of every step -> the recorded loss
+    (to one rounding of the dtype: torch.sum's fp32 order is its own) and the counter."""
+    f = load_golden(name)
+    dtype = DT_FROM_NAME[f["dtype"]]
+    code = DT_CODE[dtype]
+    H, S, SF, steps = f["H"], f["S"], f["S_full"], f["steps"]
+    losses = to_np(torch.full((SF,), -1.0).to(dtype))
+    ctr = np.zeros(1, np.int32)
+    for t in range(steps):
+        attn = to_np(f["attn"][t].reshape(-1, SF)[:H])
+        pos = f["comp_pos_steps"][t].numpy().astype(np.int32).reshape(H, S).copy()
+        sub = np.zeros((H, S), attn.dtype)
+        oracle.call("cc_analysis_loss", oracle.ptr(attn), oracle.ptr(pos), H, SF, S, code, oracle.ptr(sub), oracle.ptr(losses), oracle.ptr(ctr),
+                    SF, None)
+        got = float(from_np(losses, dtype)[t])
+        want = float(f["loss_steps"][t])
+        ulp = 2 ** -7 if dtype != torch.float32 else 1e-6
+        assert abs(got - want) <= ulp * max(1.0, abs(want)), f"step {t}: {got} vs {want}"
+        filled = pos != -1
+        a32 = from_np(attn, dtype).float().numpy()
+        s32 = from_np(sub, dtype).float().numpy()
+        for h in range(H):
+            assert np.array_equal(s32[h][filled[h]], a32[h][pos[h][filled[h]]])
+            assert np.array_equal(s32[h][~filled[h]], np.full((~filled[h]).sum(), a32[h][SF - 1]))
+    assert int(ctr[0]) == steps == int(f["loss_ctr"])
