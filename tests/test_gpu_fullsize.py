@@ -169,6 +169,8 @@ def test_hybrid_profiling_full_size(oracle_mt):
     # score (the reference rounds q.k to the model dtype, attention_utils.py:37) is 0.25 — a last-bit difference of the
     # fp32 dot product moves a probability by a quarter.  The tight bound on y is test_prefill_bands_full_size's.
     yr = from_np(yo, dtype).float()
+    # (0.05 max|y| in r2; stated here as what it is: NOT the attention contract — these heads were built with logits of magnitude
+    #  ~40 to pick different policies — and bounded by one bf16 step of such a score moving a probability by a quarter)
     assert (y.cpu().float()[0] - yr).abs().max() <= 0.05 * yr.abs().max()
 
 
@@ -279,3 +281,71 @@ def test_heavy_hitter_prefill_to_decode_without_state_sync(oracle_mt):
     assert np.allclose(num_d, st["num"], rtol=2 * BF16_ULP, atol=steps * 2.0 ** -16), float(np.abs(num_d - st["num"]).max())
     assert np.array_equal(to_np(kv.k_cache.cpu()[0]), st["k"])
     assert kv.step_status(HQ) == 0
+
+
+def test_l2_prefill_to_decode_without_state_sync(oracle_mt):
+    """KVCacheL2 at C3's size: 8192-token prompt -> L2 prompt compaction to 4096 -> key norms from the filled cache -> 40 decode
+    steps of the fused step (ONE launch, wide geometry), device and oracle each on THEIR OWN state (the device never receives the
+    oracle's norms; VERDICT r2: the golden l2 replays continue from the reference's norms).  Norms are canonical-order on both
+    sides, so the evictions must agree EXACTLY; y within the attention contract."""
+    import cold_compress_amd.cache as cache
+    from cold_compress_amd.prompt_compression import get_prompt_compressor_constructor
+
+    o = oracle_mt
+    L, S, H, R, D, g, w, dtype, steps = 8192, 4096, 8, 4, 128, 4, 10, torch.bfloat16, 40
+    HQ, code = H * R, 1
+    gen = torch.Generator().manual_seed(99)
+    k = (torch.randn(1, H, L, D, generator=gen) * (0.5 + torch.rand(1, H, L, 1, generator=gen))).to(dtype)  # a spread of norms
+    v = torch.randn(1, H, L, D, generator=gen).to(dtype)
+    cls, rk = cache.get_cache_constructor("l2")
+    kw = dict(max_cache_length=S, global_tokens=g, max_seq_length=L + 2048, cache_bits=None, recent_window=w)
+    with torch.device(DEV):
+        kv = cls(1, H, D, dtype, **{x: kw[x] for x in rk})
+    comp = get_prompt_compressor_constructor("l2")(head_specific=True, **{x: kw[x] for x in rk})
+    pos0 = torch.arange(L, device=DEV)
+    kd, vd = k.to(DEV), v.to(DEV)
+    keep, kc, vc, _ = comp(pos0, kd, vd, attn=None)
+    kv.update_kv(keep, kc, vc, True)
+    kv.update_state(keep, kc, vc, True, None)
+    torch.cuda.synchronize()
+    # ---- oracle: its own norms of the prompt's keys -> the same priority rule -> keep set (ties at the boundary: lowest index
+    #      first on both sides, SURVEY 8(c)(2); norms are canonical-order on both sides, so the sets must be equal)
+    kn_all = np.zeros((H, L), np.uint16)
+    o.call("cc_row_l2_norm", o.ptr(to_np(k[0])), H, L, D, code, 1, o.ptr(kn_all), None)
+    prio = from_np(kn_all, dtype).float()
+    ip = torch.arange(L)
+    prio[:, (ip < g) | (ip >= L - w)] = float("inf")  # ref: prompt_compression.py:28-43, 201-209
+    prio_dt = to_np(prio.to(dtype))
+    keep_o = np.zeros((H, S), np.int64)
+    o.call("cc_topk_keep", o.ptr(prio_dt), 1, H, L, S, o.ptr(keep_o), None, 0, None)
+    assert np.array_equal(keep.cpu().numpy().reshape(H, S), keep_o), "l2 keep sets differ"
+    ko, vo = np.zeros((H, S, D), np.uint16), np.zeros((H, S, D), np.uint16)
+    o.call("cc_gather_rows", o.ptr(to_np(k[0])), o.ptr(keep_o), H, H, L, S, D, code, o.ptr(ko), None)
+    o.call("cc_gather_rows", o.ptr(to_np(v[0])), o.ptr(keep_o), H, H, L, S, D, code, o.ptr(vo), None)
+    st = dict(k=ko, v=vo, pos=keep_o.astype(np.int32).copy(), mask=np.ones((H, S), np.uint8), cts=np.array([S], np.int32),
+              kn=np.zeros((H, S), np.uint16))
+    o.call("cc_row_l2_norm", o.ptr(st["k"]), H, S, D, code, 0, o.ptr(st["kn"]), None)  # ref: cache.py:611-612
+    assert np.array_equal(to_np(kv.key_norm.cpu()[0]), st["kn"]), "prefill key norms (canonical order on both sides)"
+    for t in range(steps):
+        p = L + t
+        pt = torch.tensor([p], dtype=torch.int32)
+        k1 = (torch.randn(1, H, 1, D, generator=gen) * (0.5 + torch.rand(1, H, 1, 1, generator=gen))).to(dtype)
+        v1 = torch.randn(1, H, 1, D, generator=gen).to(dtype)
+        q1 = torch.randn(1, HQ, 1, D, generator=gen).to(dtype)
+        yd = kv.decode_step(q1.to(DEV), k1.to(DEV), v1.to(DEV), pt.to(DEV))
+        torch.cuda.synchronize()
+        view = o.view(st["k"], st["v"], st["pos"], st["mask"], st["cts"], code)
+        idx = np.zeros(H, np.int64)
+        o.call("cc_decode_update_l2", C.byref(view), o.ptr(to_np(k1.reshape(H, D))), o.ptr(to_np(v1.reshape(H, D))), o.ptr(pt.numpy().copy()),
+               o.ptr(st["kn"]), g, w, o.ptr(idx), None, 0, None)
+        assert np.array_equal(kv.pos.cpu()[0].numpy(), st["pos"]), f"step {t}: positions (evicted slot {idx.tolist()})"
+        yo1 = np.zeros((HQ, D), np.uint16)
+        o.call("cc_decode_attn_gqa", o.ptr(to_np(q1.reshape(HQ, D))), o.ptr(st["k"]), o.ptr(st["v"]), o.ptr(st["mask"]), HQ, H, S, D, code,
+               1.0 / math.sqrt(D), o.ptr(yo1), None, None, None, None, None, None, 0, None)
+        yr = from_np(yo1, dtype).float()
+        assert (yd.cpu().float()[0, :, 0] - yr).abs().max() <= 1e-3 + 2 * BF16_ULP * yr.abs().max(), f"step {t}: y"
+    assert np.array_equal(to_np(kv.key_norm.cpu()[0]), st["kn"])
+    assert np.array_equal(to_np(kv.k_cache.cpu()[0]), st["k"]) and np.array_equal(to_np(kv.v_cache.cpu()[0]), st["v"])
+    from cold_compress_amd.attention_utils import single_launch_status
+
+    assert single_launch_status(kv.pos.device) == 0

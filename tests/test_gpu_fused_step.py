@@ -244,9 +244,13 @@ def test_single_launch_in_hipgraph():
     assert B[0].step_status(HQ) == 0
 
 
-def test_fused_step_vs_oracle_pipeline(oracle):
-    H, HQ, S, D, g, w = 4, 16, 512, 128, 4, 10
+@pytest.mark.parametrize("H,HQ,S", [(4, 16, 512), (8, 32, 4096), (1, 8, 3488)])
+def test_fused_step_vs_oracle_pipeline(oracle, H, HQ, S):
+    """decode_step (ONE launch at these shapes — the headline one on the wide geometry) against the oracle's fused step, each on
+    its own state: identical slots / counts / denominators / K, y within the contract's 1e-3 + two roundings of the output."""
+    D, g, w = 128, 4, 10
     kv = _mk(H, S, D, torch.bfloat16, g, w)
+    assert kv.single_launch_active(HQ)
     _seed(kv, torch.Generator().manual_seed(3), S - 3)
     st = dict(k=to_np(kv.k_cache.cpu()[0]), v=to_np(kv.v_cache.cpu()[0]), pos=kv.pos.cpu()[0].numpy().copy(),
               mask=kv.mask.cpu()[0, :, 0].numpy().astype(np.uint8), cts=kv.cache_cts.cpu().numpy().copy(),
@@ -274,8 +278,10 @@ def test_fused_step_vs_oracle_pipeline(oracle):
         assert np.array_equal(kv.pos.cpu()[0].numpy(), st["pos"]), f"step {t}"
         assert np.array_equal(kv.cache_cts.cpu().numpy(), st["cts"])
         yr = torch.from_numpy(yo.view(np.int16).copy()).view(torch.bfloat16).float()
-        assert (y.cpu().float()[0, :, 0] - yr).abs().max() < 1e-2
+        assert float((y.cpu().float()[0, :, 0] - yr).abs().max()) <= 1e-3 + 2 * 2.0 ** -8 * float(yr.abs().max()), f"step {t}: y"
     assert np.array_equal(kv.attn_history_denom.cpu()[0].numpy(), st["denom"])
+    assert np.allclose(kv.attn_history_num.cpu()[0, :, :, 0].numpy(), st["num"], rtol=2 * 2.0 ** -8, atol=6 * 2.0 ** -16)
+    assert kv.step_status(HQ) == 0
     assert np.array_equal(to_np(kv.k_cache.cpu()[0]), st["k"])
 
 
