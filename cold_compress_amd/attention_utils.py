@@ -88,9 +88,14 @@ def reset_single_launch_status(device=None):
     been reported (check_single_launch_status) or the single-launch form has been switched off, so that later generations on the
     device are judged on their own.  Synchronises."""
     off = int(_abi.lib()["cc_decode_step_status_offset"]())
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()  # the failed launch (and whatever returned at once behind it) has drained
     for ws in _decode_workspaces(device):
         if off + 4 <= ws.numel():
             ws[off:off + 4].zero_()
+            # ... and every kv head's epoch word moves on: no granule the failed attempt left behind — published by a workgroup
+            # that gave up, or by one that only started after that — can carry the tag of a later launch (the tags only grow)
+            ws[0:128].view(torch.int32).add_(4)
     if torch.cuda.is_available():
         torch.cuda.synchronize()
 

@@ -600,6 +600,9 @@ class KVCacheHeavyHitter(_TrackedWindowSums, KVCacheHeadSpecific):
         nk = int(_abi.lib()["cc_hh_next_key_slots"](S))
         self.register_buffer("next_key", torch.full((n_heads, nk), -1, dtype=torch.int64), persistent=False)
         self._next_valid = False
+        # recoverable hand-off of the single-launch step (include/coldcompress.h, cc_decode_step_heavy_hitter_rc): the last
+        # position whose step is fully committed, per kv head; -1 = none
+        self.register_buffer("step_commit", torch.full((n_heads,), -1, dtype=torch.int32), persistent=False)
         if W > 1:
             self._init_window_state()
 
@@ -609,6 +612,7 @@ class KVCacheHeavyHitter(_TrackedWindowSums, KVCacheHeadSpecific):
         self.attn_history_denom.zero_()
         self.attn_counter.zero_()
         self._next_valid = False
+        self.step_commit.fill_(-1)
         if self.history_window_size > 1:
             self._zero_window_state()
 
@@ -623,6 +627,8 @@ class KVCacheHeavyHitter(_TrackedWindowSums, KVCacheHeadSpecific):
 
     def update_kv(self, input_pos, k_val, v_val, is_prefill, **kwargs):
         self._next_valid = False  # the three-call path mutates pos / history outside the pipeline
+        if is_prefill:
+            self.step_commit.fill_(-1)  # positions restart: no decode position is committed
         return super().update_kv(input_pos, k_val, v_val, is_prefill, **kwargs)
 
     # ------------------------------------------------------------------ fused decode step (1 or 2 launches per layer)
@@ -672,10 +678,10 @@ class KVCacheHeavyHitter(_TrackedWindowSums, KVCacheHeadSpecific):
                              denom=self.attn_history_denom, counter=self.attn_counter, g=self.global_tokens, w=self.recent_window,
                              phases=phases)
             return y
-        _abi.call("cc_decode_step_heavy_hitter_phases", self._view(), _ptr(q), _ptr(k), _ptr(v), _ptr(p32), _ptr(self.attn_history_num),
-                  _ptr(self.attn_history_denom), _ptr(self.attn_counter), _ptr(self.next_key), int(self.global_tokens),
-                  int(self.recent_window), HQ, 1.0 / math.sqrt(D) if scale is None else scale, _ptr(y), None, _ptr(ws),
-                  ws.numel(), _stream(), phases)
+        _abi.call("cc_decode_step_heavy_hitter_rc", self._view(), _ptr(q), _ptr(k), _ptr(v), _ptr(p32), _ptr(self.attn_history_num),
+                  _ptr(self.attn_history_denom), _ptr(self.attn_counter), _ptr(self.next_key), _ptr(self.step_commit),
+                  int(self.global_tokens), int(self.recent_window), HQ, 1.0 / math.sqrt(D) if scale is None else scale, _ptr(y),
+                  _ptr(ws), ws.numel(), _stream(), phases)
         self._quant_pending = self.quantize
         return y
 

@@ -212,6 +212,9 @@ struct SplitArgs {
   const float* rand_next;  // policy 3: [S] uniform draws for position p + 1
   int yc_chunks;      // grid.x of the two-launch combine pass (unused)
   unsigned long long* trace;  // measurement only (cc_decode_step_trace): [workgroup][16] time stamps and hardware ids
+  // ---- recoverable hand-off (r3; the early-(m, l) single-launch steps): step_commit[h] = the last position whose step is fully
+  //      committed for kv head h (-1 = none; null = the caller does not retry).  See "Recoverable hand-off" below.
+  int32_t* commit;
   HybridStep hyb;     // HYB instantiation only
   // ---- fused quantised cache (QB instantiation): k / v point at the uint8 images [H, S, D]; one (scale, minimum) pair per
   //      (head, slot) row for K and one for V — dequantised in registers on the way to the LDS slabs
@@ -539,6 +542,21 @@ typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 constexpr unsigned kOneSpinMax = 1u << 18;  // bounded spin: a launch that is not fully resident gives up instead of hanging
 constexpr int kOneStatusWordDev = 1023;     // hdr[0 .. H): per-head epochs; hdr[1023]: timeout word (== kOneStatusWord)
 constexpr int kOneTicketWord = 1022;        // hybrid: heads whose workgroups have all published (the last one commits the per-step scalars)
+// Recoverable hand-off (the early-(m, l) steps).  A launch whose workgroups are not all resident cannot complete its hand-off:
+// the waits are bounded, and what a timed-out workgroup leaves behind must neither corrupt state nor be half a step.
+//   * hdr[kOneFailWord + h]: set to the launch's tag by any workgroup of kv head h that gives up.  Every workgroup reads it
+//     with each round of its LAST gather and commits nothing when it carries its tag: a head's step is committed by all of its
+//     workgroups or by none (the per-slot history, the next-eviction keys and y are stored only behind that check; a workgroup
+//     that arrives late finds the word set because the one that gave up wrote it a whole streaming phase earlier).
+//   * hdr[kOneStatusWordDev] != 0 (set with the fail word; cleared by the host): every later launch returns at once — nothing is
+//     built on the garbage a failed step's y became.  The host clears it AND advances every epoch word (so that no granule of the
+//     failed attempt can carry a later launch's tag), then simply runs the token again:
+//   * step_commit[h] == *input_pos: this head's step for this position is already committed -> REPLAY: no insert, no history, no
+//     keys — attention over the cache as the committed step left it (the same scores, partials and y, bit for bit).
+// Not closed: a workgroup that completes its gather in the same memory round trip in which another one of its head gives up
+// (the late workgroup it waited for became resident at that very moment) may commit its slots alone; the window is one round
+// trip (~1 us) at the end of a >= 0.1 s wait.
+constexpr int kOneFailWord = 64;
 // Granule regions are PER KV HEAD at fixed strides, whatever the shape: a location is only ever written by launches of its own
 // head, with tags from that head's epoch word — strictly growing per location even when caches of different head counts and
 // lengths share the workspace (shape-dependent offsets let a stale granule of head 4 sit where head 1 of another shape expects
@@ -636,10 +654,8 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
   // EML (r3): the workgroup's (m, l) pairs leave EARLY — right behind the scores, while the V rows are still in flight — so that
   // the final (M, L) of the head, the probabilities, the history update and the next-eviction keys run in the shadow of the
   // partial-O exchange; what is left behind the last O granule is the y fold alone
-#ifndef CC_AB_EML
-#define CC_AB_EML 1
-#endif
-  constexpr bool EML = CC_AB_EML && ONE1 && !L2 && !HYB;
+  constexpr bool EML = ONE1 && !L2 && !HYB;
+  constexpr bool RC = EML;  // the recoverable hand-off (status / commit / fail words, state stores behind the last gather) rides the same kinds
   static_assert(sizeof(T) == 2 && (RT == 1 || RT == 2 || RT == 4 || RT == 8), "16-bit caches, up to 8 query heads per pass (the MFMA has 16 columns)");
   static_assert(!ONE || NW == 4 || (NW == 8 && NT == 1 && !HYB), "the single-launch step runs on 4-wave workgroups, or on ONE 8-wave workgroup per CU (single tile; not the hybrid cache)");
   constexpr int D = 128, VEC = 8, RPW = 4, U = 4;
@@ -656,6 +672,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
   __shared__ __attribute__((aligned(16))) uint4 sm_v[NW][16][16];  // [wave][tile row][chunk ^ 2*(row & 7)]: V tile, row major
   __shared__ float sm_wm[NW][RT], sm_wl[NW][RT];  // the waves' softmax state per query head (merged across the workgroup)
   __shared__ unsigned sm_mlcnt;                    // EML: waves whose (m, l) rows are in LDS — the LAST one to arrive publishes
+  __shared__ unsigned sm_fail;                     // EML: some wave of this workgroup gave up waiting (recoverable hand-off)
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, c = lane & 15;  // row group of the wave / 16-byte column chunk (and MFMA column n)
@@ -833,9 +850,15 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
   float one_kn = 0.f;       // ONE + L2: the key norm of this lane's slot (model dtype) ...
   float l2_nv_lane = 0.f;   // ... and the inserted key's norm, in the lanes of the row group that inserted it
   unsigned l2_ep[3] = {0u, 0u, 0u};  // ONE + L2: epoch words of the kv heads whose norm granules this thread gathers (read behind the tile's loads, below)
+  unsigned rc_status = 0;    // EML: the workspace's status word (a step failed since the host last looked: do nothing)
+  int32_t rc_commit = -2;    // EML: step_commit[h]
   if constexpr (ONE) {
     one_tag = a.one_hdr[h] + 1u;
     one_pin = *a.input_pos;
+    if constexpr (RC) {
+      rc_status = a.one_hdr[kOneStatusWordDev];
+      if (a.commit) rc_commit = a.commit[h];
+    }
     // single tile: requested AHEAD of the K/V tile (measured: behind it the step is 0.3 us slower — the tile's in-order waits
     // then end on these stragglers, and the workgroup leaves the streaming part later); several tiles: requested after the
     // publish, in the shadow of the hand-off
@@ -953,9 +976,14 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
   if constexpr (EML) {
     // the arrival counter of the early (m, l) hand-off starts at zero: one barrier HERE, behind the issue of every load of the
     // tile (the waves of a workgroup reach it together; nothing waits for memory)
-    if (threadIdx.x == 0) sm_mlcnt = 0u;
+    if (threadIdx.x == 0) {
+      sm_mlcnt = 0u;
+      sm_fail = 0u;
+    }
     __syncthreads();
+    if (rc_status != 0u) return;  // a step of this token failed before this launch: leave everything as it is (the host retries)
   }
+  const bool rc_replay = EML && rc_commit == one_pin;  // this head's step for this position is committed already: attention only
 
   float pv_p[U];  // the tile's probabilities (unnormalised), between its two halves
   auto tile_qk = [&](TileRegs& R, const int tbase, const int tbase_next, const bool more_next, auto ti_c) {
@@ -969,6 +997,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
       const unsigned long long key = wave_min_u64_uniform(key_part);
       ins_idx = (key == ~0ull) ? -1 : (int)((key & 0xffffffffull) >> 1);
       if (a.abl & 64) ins_idx = -1;
+      if (rc_replay) ins_idx = -1;  // (the row went in when the step was committed; the key row already holds the NEXT position's keys)
       ins_was_empty = (int)(key & 1ull);
       key_pending = false;
       if constexpr (HYB) {  // ref: cache.py:896-950 _select_fill_idx, per head — operands requested at the top of the kernel (hy_*)
@@ -1075,7 +1104,8 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
             a.num[slot] = 0.0;
             a.denom[slot] = 0;
           }
-          if (ins_was_empty && (a.Hc == a.H || h == 0)) atomicAdd(&a.cache_cts[a.Hc == a.H ? h : 0], 1);
+          // (recoverable hand-off: the count is bumped where the step is committed — a retried insert must not count twice)
+          if (ins_was_empty && (a.Hc == a.H || h == 0) && !(EML && a.commit)) atomicAdd(&a.cache_cts[a.Hc == a.H ? h : 0], 1);
         }
         if (L2) {  // l2: cache.py:592-593 — the new key's norm (sumsq_canonical_16's order), model dtype
           // the canonical order wants elements c, c + 16, ... of the key in lane c; the lanes of this row group hold chunk c (elements
@@ -1479,9 +1509,20 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
 #pragma unroll
       for (int k = 0; k < MLN; k++) mlq[k] = __builtin_amdgcn_raw_buffer_load_b128(ml_rsrc, ml_off[k], 0, kOneAuxCoherent);
     };
+    unsigned failq = 0;  // EML: the head's fail word, read with every round of the partial-O gather (recoverable hand-off)
+    const auto hdr_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.one_hdr, 0, 4096, 0x00020000);
     auto load_o = [&]() {
 #pragma unroll
       for (int k = 0; k < NOG; k++) oq[k] = __builtin_amdgcn_raw_buffer_load_b128(o_rsrc, o_off[k], 0, kOneAuxCoherent);
+      if constexpr (RC) failq = __builtin_amdgcn_raw_buffer_load_b32(hdr_rsrc, (kOneFailWord + h) * 4, 0, kOneAuxCoherent);
+    };
+    // a wave that gives up: the head's fail word (this launch's tag) and the workspace's status word, write-through
+    auto give_up = [&]() {
+      if (lane == 0) {
+        __builtin_amdgcn_raw_buffer_store_b32(tag, hdr_rsrc, (kOneFailWord + h) * 4, 0, kOneAuxCoherent);
+        __builtin_amdgcn_raw_buffer_store_b32(1u, hdr_rsrc, kOneStatusWordDev * 4, 0, kOneAuxCoherent);
+        sm_fail = 1u;
+      }
     };
     auto ok_ml = [&]() {
       bool ok = true;
@@ -1556,6 +1597,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
         load_ml();
         ml_ok = __all(ok_ml());
       }
+      if (timed_out) give_up();
       if (a.trace) tr4 = __builtin_amdgcn_s_memtime();
       if (ml_mine) final_ml();
       __syncthreads();
@@ -1610,6 +1652,9 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
     // ---- this workgroup's slots.  ref: attention_utils.py:52 softmax -> model dtype; model.py:416-418 group mean -> model
     //      dtype; cache.py:716-722 history; cache.py:727-749 the next position's eviction score
     unsigned long long my_key = ~0ull;
+    double def_num = 0.0;  // EML: this lane's deferred history store (def_i < 0: none)
+    int32_t def_den = 0;
+    long long def_i = -1;
     __shared__ float sm_hav[HYB ? NW : 1][HYB ? NT * RPW * U : 1];  // hybrid: group-mean probabilities, [wave][tile * 16 + row]
     auto slot_pass = [&](auto ti_c) {
       constexpr int TI = decltype(ti_c)::value;
@@ -1696,8 +1741,14 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
           if (a.attn_out) ElemTraits<T>::store(reinterpret_cast<T*>(a.attn_out), i, av);
           const double num_new = num_old + (double)av;
           const int32_t den_new = den_old + 1;
-          a.num[i] = num_new;
-          a.denom[i] = den_new;
+          if constexpr (RC) {  // stored behind the LAST gather and the head's fail word: a head's step is committed whole or not at all
+            def_num = num_new;
+            def_den = den_new;
+            def_i = (long long)i;
+          } else {
+            a.num[i] = num_new;
+            a.denom[i] = den_new;
+          }
           float scn = __fdiv_rn((float)num_new, (float)(den_new < 1 ? 1 : den_new));
           if (ps < a.g || ps >= p_next - a.w) scn = 1.0f;
           if (ps == -1) scn = 0.0f;
@@ -1791,18 +1842,19 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
           }
         }
     }
-    {
-      // one key per WAVE (a head's key row has room for NW per 64-slot workgroup): nothing crosses the waves after the one
-      // barrier of the finish, so no wave's stores wait for another wave (the launch ends a store round trip after the LAST
-      // store is issued: every store that can go out early shortens it)
-      const unsigned long long wk = wave_min_u64_uniform(my_key);
+    // one key per WAVE (a head's key row has room for NW per 64-slot workgroup): nothing crosses the waves after the last
+    // barrier of the finish, so no wave's stores wait for another wave (the launch ends a store round trip after the LAST
+    // store is issued: every store that can go out early shortens it)
+    const unsigned long long wk = wave_min_u64_uniform(my_key);
+    auto store_key = [&]() {
       if (lane == 0 && (a.Hp != 1 || h == 0)) {
         unsigned long long* nk_row = const_cast<unsigned long long*>(a.next_key) + (a.Hp == 1 ? 0 : (size_t)h * a.nk);
         const int e0 = split * NW + wave;
         nk_row[e0] = wk;  // every key of this row was consumed before its readers published: no reader is left
         for (int s2 = e0 + ns * NW; s2 < a.nk_read; s2 += ns * NW) nk_row[s2] = ~0ull;  // entries beyond nk_read are never read
       }
-    }
+    };
+    bool failed = false;  // EML: the head's step is not committed by this launch (somebody gave up)
     if constexpr (EML) {
       __builtin_amdgcn_sched_barrier(0);
       for (unsigned spins = 0;; spins++) {
@@ -1816,15 +1868,27 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
         load_o();
       }
       if (a.trace) trE = __builtin_amdgcn_s_memtime();
-      if (timed_out && lane == 0) a.one_hdr[kOneStatusWordDev] = 1u;  // this launch's results are invalid; the host reads the word
+      if (timed_out) give_up();
+      else if (failq == tag && lane == 0) sm_fail = 1u;  // another workgroup of this head gave up: nothing of the head's step is committed
       stash_o();
-      __syncthreads();
-      y_fold();
+      __syncthreads();  // (also makes the verdict workgroup-uniform)
+      failed = sm_fail != 0u;
+      if (!failed) {
+        y_fold();
+        if (!rc_replay) {  // the step's state, behind the last gather and the fail word
+          if (RC && def_i >= 0) {
+            a.num[def_i] = def_num;
+            a.denom[def_i] = def_den;
+          }
+          store_key();
+        }
+      }
     } else {
+      store_key();
       if (a.trace) trE = __builtin_amdgcn_s_memtime();
     }
     if (threadIdx.x == 0) {
-      if (split == 0) {
+      if (split == 0 && !failed) {
         a.one_hdr[h] = tag;  // all n_split workgroups of this head have published, hence read the old epoch
         if constexpr (HYB) {
           a.cache_cts[h] = hyb_cts_n;  // every workgroup of this head has read the old count (it decided before it published)
@@ -1835,8 +1899,12 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
             if (a.ring_num && a.hh_counter) *a.hh_counter += 1;               // cache.py:723
             if (hy_punc && a.hyb.num_punc) *a.hyb.num_punc += 1;              // cache.py:1017, once per step
           }
-        } else if (h == 0 && a.hh_counter) {
-          *a.hh_counter += 1;
+        } else if (!rc_replay) {
+          if (h == 0 && a.hh_counter) *a.hh_counter += 1;
+          if (EML && a.commit) {  // recoverable hand-off: this head's step for this position is done
+            if (ins_was_empty && (a.Hc == a.H || h == 0)) a.cache_cts[a.Hc == a.H ? h : 0] += 1;  // (one writer per count)
+            a.commit[h] = one_pin;
+          }
         }
       }
       if (a.trace) {
@@ -2612,6 +2680,7 @@ struct FusedStep {
   void* key_norm;  // policy 4
   const HybridStep* hyb;  // policy 6
   float* qparams;  // fused quantised cache: c->k_cache / v_cache are the uint8 images, c->dtype the model dtype
+  int32_t* commit;  // recoverable hand-off: step_commit [H] or null
 };
 // The W > 1 history ring folded into the combine pass (denom / counter travel as hh_denom / hh_counter).
 struct RingHistory {
@@ -2688,6 +2757,7 @@ static int attn_impl(const void* q, const void* k, const void* v, const uint8_t*
     if (sa.nk_read > sa.nk) sa.nk_read = sa.nk; sa.input_pos = fs->input_pos; sa.k_new = fs->k_new; sa.v_new = fs->v_new;
     sa.pos = fs->c->pos; sa.mask_w = fs->c->mask; sa.cache_cts = fs->c->cache_cts; sa.num = hh_num; sa.denom = hh_denom;
     sa.H = H; sa.Hc = fs->c->Hc; sa.Hp = fs->c->Hp;
+    sa.commit = fs->commit;
   }
   hipStream_t st = (hipStream_t)stream;
   int rc = CC_OK;
@@ -2845,6 +2915,20 @@ int cc_decode_step_heavy_hitter_phases(const cc_kv_view* c, const void* q, const
     return CC_ERR_BAD_ARG;
   FusedStep fs{c, k_new, v_new, input_pos, reinterpret_cast<unsigned long long*>(next_key), global_tokens, recent_window, 1, nullptr, nullptr};
   return attn_impl(q, c->k_cache, c->v_cache, c->mask, HQ, c->H, c->S, c->D, c->dtype, scale, y, attn_out, nullptr, num, denom,
+                   counter, workspace, workspace_bytes, stream, phases, &fs);
+}
+
+int cc_decode_step_heavy_hitter_rc(const cc_kv_view* c, const void* q, const void* k_new, const void* v_new,
+                                   const int32_t* input_pos, double* num, int32_t* denom, int64_t* counter,
+                                   uint64_t* next_key, int32_t* step_commit, int32_t global_tokens, int32_t recent_window,
+                                   int32_t HQ, float scale, void* y, void* workspace, size_t workspace_bytes,
+                                   cc_stream_t stream, int32_t phases) {
+  if (!cc_view_ok(c) || !q || !k_new || !v_new || !input_pos || !num || !denom || !next_key || !y || c->Hp != c->H ||
+      HQ <= 0 || HQ % c->H)
+    return CC_ERR_BAD_ARG;
+  FusedStep fs{c, k_new, v_new, input_pos, reinterpret_cast<unsigned long long*>(next_key), global_tokens, recent_window, 1, nullptr, nullptr};
+  fs.commit = step_commit;
+  return attn_impl(q, c->k_cache, c->v_cache, c->mask, HQ, c->H, c->S, c->D, c->dtype, scale, y, nullptr, nullptr, num, denom,
                    counter, workspace, workspace_bytes, stream, phases, &fs);
 }
 

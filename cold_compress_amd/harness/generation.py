@@ -175,14 +175,42 @@ class GraphedDecoder:
         return self.out_tok, self.out_probs
 
 
+def _recover_token(model, cur_token, input_pos, decode_fn, nt, npb, forced, attn_top_k, kw, max_retries=6):
+    """In-band recovery from a single-launch hand-off that could not complete (a launch whose workgroups were not all resident: a
+    co-tenant kernel on the device).  One 4-byte read of the decode workspace's status word per token; when it is set the failed
+    step committed nothing of its kv head, every later launch of the token returned at once (include/coldcompress.h,
+    cc_decode_step_heavy_hitter_rc) — so the word is cleared, the epoch words are advanced, and the SAME token runs again: heads
+    whose step is committed replay it (attention only), the others step.  Policies without commit words (everything but heavy
+    hitter W = 1) and a failure that persists raise, as before."""
+    from ..attention_utils import check_single_launch_status, reset_single_launch_status, single_launch_status
+    from ..cache import KVCacheHeavyHitter
+
+    dev = cur_token.device
+    tries = 0
+    while single_launch_status(dev):
+        caches = [l.attention.kv_cache for l in model.layers]
+        ok = all(type(c) is KVCacheHeavyHitter and c.history_window_size == 1 and not c.fused_quant for c in caches)
+        if not ok or tries >= max_retries:
+            check_single_launch_status(dev)  # raises (and clears the word)
+        reset_single_launch_status(dev)
+        tries += 1
+        time.sleep(0.05 * tries)  # whatever shared the device gets a moment to leave
+        nt, npb = decode_fn(model, cur_token, input_pos, next_token=forced, attn_top_k=attn_top_k, **kw)
+    return nt, npb
+
+
 def decode_n_tokens(model, cur_token, input_pos, decode_one_token, num_new_tokens, terminator_ids=None, attn_top_k=1.0,
                     prefix=None, **kw):
     """ref: generation_utils.py:181-217."""
     new_tokens, new_probs = [], []
+    recover = bool(kw.pop("recover", True)) and cur_token.is_cuda
     for i in range(num_new_tokens):
         teacher_force = prefix is not None and i < len(prefix)
         nt = prefix[i].view(1) if teacher_force else None
         nt, npb = decode_one_token(model, cur_token, input_pos, next_token=nt, attn_top_k=attn_top_k, **kw)
+        if recover:
+            nt, npb = _recover_token(model, cur_token, input_pos, decode_one_token, nt, npb, prefix[i].view(1) if teacher_force else None,
+                                     attn_top_k, kw)
         new_tokens.append(nt.clone())
         new_probs.append(npb.clone())
         if terminator_ids and nt in terminator_ids and not teacher_force:

@@ -268,6 +268,25 @@ int32_t cc_decode_step_status_offset(void);
  * random: cc_decode_step_recent_global / cc_decode_step_random) and l2 (cc_decode_step_l2: every workgroup also gathers every
  * workgroup's norm maximum) take the single launch under the same conditions (l2: at most 768 workgroups, 32 kv heads). */
 void cc_decode_step_set_single_launch(int32_t enabled);
+/* The heavy-hitter layer step with the RECOVERABLE hand-off (r3): cc_decode_step_heavy_hitter_phases plus `step_commit`, int32 [H]
+ * on the device, -1 = nothing committed (reset it whenever positions restart).  Single-launch form (early (m, l) hand-off):
+ *   - a launch that finds the status word set returns at once (a step of this token failed: nothing is built on its output);
+ *   - a workgroup that gives up waiting sets the status word and its head's fail word; every workgroup of that head then commits
+ *     NOTHING of the step (history, keys, count, y): a head's step is committed whole — step_commit[h] = *input_pos — or not at all;
+ *   - a head with step_commit[h] == *input_pos REPLAYS: attention over the cache as the committed step left it (same y, bit for
+ *     bit), no insert, no state change.
+ * So the caller recovers by clearing the status word, advancing the workspace's epoch words (attention_utils.
+ * reset_single_launch_status does both) and running the SAME token again: committed heads replay, the others step.  Other
+ * launch forms ignore step_commit (nothing in them can time out).  step_commit may be NULL: no replay, counts bumped at the insert. */
+int cc_decode_step_heavy_hitter_rc(const cc_kv_view* c, const void* q, const void* k_new, const void* v_new,
+                                   const int32_t* input_pos, double* num, int32_t* denom, int64_t* counter,
+                                   uint64_t* next_key, int32_t* step_commit, int32_t global_tokens, int32_t recent_window,
+                                   int32_t HQ, float scale, void* y, void* workspace, size_t workspace_bytes,
+                                   cc_stream_t stream, int32_t phases);
+/* Test hook: n_workgroups one-wave workgroups that hold lds_bytes (256 .. 163840) of LDS each and idle for `microseconds`
+ * (<= 5 s) — what a co-tenant kernel does to the residency of a single-launch step (tests/test_gpu_recovery.py).  scratch: >= 4
+ * bytes of device memory. */
+int cc_debug_occupy(int32_t n_workgroups, int32_t lds_bytes, int32_t microseconds, void* scratch, cc_stream_t stream);
 /* Wide geometry (r3): ONE 8-wave workgroup per CU (128 cache rows each) instead of two 4-wave ones, for the plain 16-bit
  * caches (heavy hitter / recent_global / full / random, 4 or 8 query heads per kv head, head_dim 128) that have 16-row
  * tiles for it (H * S / 16 >= 2048 and H * ceil(S / 128) <= 256: Llama-3-8B at cache_len 4096).  On by default;

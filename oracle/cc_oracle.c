@@ -1484,6 +1484,24 @@ int cc_decode_step_heavy_hitter_phases_cpu(const cc_kv_view* c, const void* q, c
                                          attn_out, workspace, workspace_bytes, stream);
 }
 
+/* The device entry point with the recoverable hand-off's commit words: on the CPU nothing can time out — the step runs, then
+ * every head is marked committed for this position (what the device leaves behind after a successful launch); a head that is
+ * ALREADY committed for this position makes the whole call a refusal here (the replay form is a device matter). */
+int cc_decode_step_heavy_hitter_rc_cpu(const cc_kv_view* c, const void* q, const void* k_new, const void* v_new,
+                                       const int32_t* input_pos, double* num, int32_t* denom, int64_t* counter,
+                                       uint64_t* next_key, int32_t* step_commit, int32_t g, int32_t w, int32_t HQ, float scale,
+                                       void* y, void* workspace, size_t workspace_bytes, cc_stream_t stream, int32_t phases) {
+  if ((phases & 3) != 3) return CC_ERR_UNSUPPORTED;
+  if (step_commit && input_pos && c)
+    for (int h = 0; h < c->H; h++)
+      if (step_commit[h] == *input_pos) return CC_ERR_UNSUPPORTED;
+  const int rc = cc_decode_step_heavy_hitter_cpu(c, q, k_new, v_new, input_pos, num, denom, counter, next_key, g, w, HQ, scale, y,
+                                                 NULL, workspace, workspace_bytes, stream);
+  if (rc == CC_OK && step_commit)
+    for (int h = 0; h < c->H; h++) step_commit[h] = *input_pos;
+  return rc;
+}
+
 /* ------------------------------------------------------------------------------------------------
  * Quantised KV cache (--cache_bits {8,4,2}).  ref: quantization_utils.py:4-98 with axis = 2 (cache.py:183):
  * ONE (scale, zero point) per cache slot s, shared by all heads and channels; every op is a torch elementwise op

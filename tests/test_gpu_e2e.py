@@ -219,7 +219,7 @@ def test_harness_two_launch_step_equals_three_call_path(strategy, extra):
         for li, layer in enumerate(model.layers):
             kv = layer.attention.kv_cache
             for n, b in kv.named_buffers():
-                if n != "next_key":
+                if n not in ("next_key", "step_commit"):
                     state[f"{li}.{n}"] = b.clone()
         outs.append((toks, state))
     assert outs[0][0] == outs[1][0], "generated tokens"

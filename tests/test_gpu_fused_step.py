@@ -89,7 +89,7 @@ def test_fused_step_equals_three_calls(dtype, H, HQ, S, D, T, single):
         else:
             assert torch.equal(ya, yb), f"step {t}: attention output"
         for (na, ta), (nb, tb) in zip(a.named_buffers(), b.named_buffers()):
-            if na != "next_key":
+            if na not in ("next_key", "step_commit"):  # (pipeline bookkeeping of the fused step, not reference state)
                 assert torch.equal(ta, tb), f"step {t}: {na}"
     assert b._next_valid and not a._next_valid
     assert b.step_status(HQ) == 0
@@ -126,7 +126,7 @@ def test_single_launch_equals_two_launch_long(dtype, H, HQ, S, D, T, steps):
             torch.cuda.synchronize()
             assert torch.allclose(ya.float(), yb.float(), rtol=2.0 ** -7, atol=1e-6), f"step {t}: y"
             for (na, ta), (nb, tb) in zip(a.named_buffers(), b.named_buffers()):
-                if na != "next_key":
+                if na not in ("next_key", "step_commit"):  # (pipeline bookkeeping of the fused step, not reference state)
                     assert torch.equal(ta, tb), f"step {t}: {na}"
     torch.cuda.synchronize()
     assert b.step_status(HQ) == 0
@@ -188,7 +188,7 @@ def test_attn_out_is_served_by_the_full_single_launch_kernel_or_by_two_launches(
         assert torch.equal(oa, ob) and float(oa.float().abs().sum()) > 0, f"step {t}: attn_out"
         assert torch.allclose(ya.float(), yb.float(), rtol=2.0 ** -7, atol=1e-6), f"step {t}: y"
         for (na, ta), (nb, tb) in zip(a.named_buffers(), b.named_buffers()):
-            if na != "next_key":
+            if na not in ("next_key", "step_commit"):  # (pipeline bookkeeping of the fused step, not reference state)
                 assert torch.equal(ta, tb), f"step {t}: {na}"
     assert b.step_status(HQ) == 0
 
@@ -239,7 +239,7 @@ def test_single_launch_in_hipgraph():
     torch.cuda.synchronize()
     for l in range(L):
         for (na, ta), (nb, tb) in zip(A[l].named_buffers(), B[l].named_buffers()):
-            if na != "next_key":
+            if na not in ("next_key", "step_commit"):  # (pipeline bookkeeping of the fused step, not reference state)
                 assert torch.equal(ta, tb), f"layer {l}: {na}"
     assert B[0].step_status(HQ) == 0
 
@@ -322,7 +322,7 @@ def test_ring_fused_step_equals_three_calls(strategy, dtype, H, HQ, S, D, T, sin
         torch.cuda.synchronize()
         _y_check(ya, yb, single, t)
         for (na, ta), (nb, tb) in zip(a.named_buffers(), b.named_buffers()):
-            if na != "next_key":
+            if na not in ("next_key", "step_commit"):  # (pipeline bookkeeping of the fused step, not reference state)
                 assert torch.equal(ta, tb), f"step {t}: {na}"
 
 
@@ -366,7 +366,7 @@ def test_random_fused_step_equals_three_calls(dtype, H, HQ, S, D, T, g, w, singl
         torch.cuda.synchronize()
         _y_check(ya, yb, single, t)
         for (na, ta), (nb, tb) in zip(a.named_buffers(), b.named_buffers()):
-            if na != "next_key":
+            if na not in ("next_key", "step_commit"):  # (pipeline bookkeeping of the fused step, not reference state)
                 assert torch.equal(ta, tb), f"step {t}: {na}"
 
 
@@ -497,7 +497,7 @@ def test_l2_fused_step_equals_three_calls(dtype, H, HQ, S, D, T, g, w, single, s
         torch.cuda.synchronize()
         _y_check(ya, yb, single, t)
         for (na, ta), (nb, tb) in zip(a.named_buffers(), b.named_buffers()):
-            if na != "next_key":
+            if na not in ("next_key", "step_commit"):  # (pipeline bookkeeping of the fused step, not reference state)
                 assert torch.equal(ta, tb), f"step {t}: {na}"
 
 
@@ -596,7 +596,7 @@ def test_single_launch_caches_of_different_head_counts_share_the_workspace(singl
                 torch.cuda.synchronize()
                 assert torch.allclose(ya.float(), yb.float(), rtol=2.0 ** -7, atol=1e-6), (strategy, H, S, t)
                 for (na, ta), (nb, tb) in zip(a.named_buffers(), b.named_buffers()):
-                    if na != "next_key":
+                    if na not in ("next_key", "step_commit"):  # (pipeline bookkeeping of the fused step, not reference state)
                         assert torch.equal(ta, tb), (strategy, H, S, t, na)
     from cold_compress_amd.attention_utils import single_launch_status
 

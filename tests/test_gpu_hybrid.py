@@ -450,7 +450,7 @@ def test_hybrid_two_launch_step_equals_three_launches(strategies, H, HQ, S, T, s
         else:
             assert torch.equal(ya, yb), f"step {t}: attention output"
         for (na, ta), (nb, tb) in zip(a.named_buffers(), b.named_buffers()):
-            if na != "next_key":
+            if na not in ("next_key", "step_commit"):  # (pipeline bookkeeping of the fused step, not reference state)
                 assert torch.equal(ta, tb), f"step {t}: {na}"
     assert b._next_valid
     assert single_launch_status() == 0
