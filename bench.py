@@ -269,7 +269,8 @@ def roofline(model, args, dev):
     step_bytes = 2 * H * S * D * 2 + H * S * 29
     split_bytes = 2 * H * S * D * 2 + H * S + HQ * D * 2
     ach = step_bytes / (mean_us * 1e-6) / 1e9
-    wide = (H, S, D, HQ) == (8, 4096, 128, 32)  # ONE 8-wave workgroup per CU (cc_decode_step_set_wide, on by default)
+    # ONE 8-wave workgroup per CU (make_plan's rule; cc_decode_step_set_wide, on by default)
+    wide = D == 128 and HQ // H in (4, 8) and H * ((S + 15) // 16) >= 1280 and H * ((S + 127) // 128) <= 256
     nw = 8 if wide else 4
     kname = (f"decode_attn_split_mfma_kernel<bf16_t,4,{nw},false,true> (single-launch layer step)" if one else
              f"decode_attn_split_mfma_kernel<bf16_t,4,{nw},false> + decode_attn_combine_kernel<bf16_t> (two-launch layer step)")

@@ -2381,14 +2381,16 @@ static Plan make_plan(int HQ, int H, int S, int D, int dtype, int kind = 0) {
   // the matrix-core streaming pass has 16 score columns: 8 query heads per pass read K and V ONCE for a group of 8 (Llama-3
   // 70B: HQ / H = 8; with 4 per pass every K / V row was streamed twice)
   if (R % 8 == 0 && cc_dt_size(dtype) == 2 && D == 128) p.rt = 8;
-  // (r3) ONE 8-wave workgroup per CU instead of two 4-wave ones, where the cache has 16-row tiles for it (>= 8 x 256 over the
+  // (r3) ONE 8-wave workgroup per CU instead of two 4-wave ones, where the cache has 16-row tiles for it (>= 5 x 256 over the
   // kv heads) and every wave still gets exactly one: half the publishers, granules and polls of the in-launch hand-off, half the
   // splits for every gatherer to fold, one merge per CU — 4 or 8 query heads per kv head; every policy but the hybrid cache
   // (whose caches are long: several tiles per wave), so that the steps of the policies that share inputs in the tests (l2 and
   // the fused quantised cache against the plain 16-bit step) fold their partials alike
   if (g_wide_enabled && kind != 200 && cc_dt_size(dtype) == 2 && D == 128 && (p.rt == 4 || p.rt == 8) && R == p.rt) {
     const long tiles = (long)H * ((S + 15) / 16);
-    if (tiles >= 2048 && (long)H * ((S + 127) / 128) <= 256) p.nw = 8;
+    // (measured, r3, same box: 1280 tiles (C2: S = 2560) wide 8.18 vs 8.46 us; 1024 tiles (S = 2048, or 4 kv heads at 4096) wide
+    //  7.8-7.9 vs 7.35-7.75: from five tiles per CU on the 8-wave workgroup pays)
+    if (tiles >= 1280 && (long)H * ((S + 127) / 128) <= 256) p.nw = 8;
   }
   const int rpi = rows_per_iter(D, dtype, p.nw);
   // ~512 workgroups (two per CU, all resident at once): one tile per workgroup up to S = 64 * 64 rows per kv

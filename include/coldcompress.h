@@ -289,7 +289,7 @@ int cc_decode_step_heavy_hitter_rc(const cc_kv_view* c, const void* q, const voi
 int cc_debug_occupy(int32_t n_workgroups, int32_t lds_bytes, int32_t microseconds, void* scratch, cc_stream_t stream);
 /* Wide geometry (r3): ONE 8-wave workgroup per CU (128 cache rows each) instead of two 4-wave ones, for the plain 16-bit
  * caches (heavy hitter / recent_global / full / random, 4 or 8 query heads per kv head, head_dim 128) that have 16-row
- * tiles for it (H * S / 16 >= 2048 and H * ceil(S / 128) <= 256: Llama-3-8B at cache_len 4096).  On by default;
+ * tiles for it (H * S / 16 >= 1280 and H * ceil(S / 128) <= 256: Llama-3-8B at cache_len 2560 .. 4096).  On by default;
  * process-wide.  The geometry decides the split partials (hence the last bits of y and of the probabilities) and which
  * entries of a head's key row are live: all forms of one cache's step (one launch, two, three calls) follow the switch
  * together; flip it only where the fused pipeline is re-seeded (prepare_decode / cc_hh_next_key_init). */
