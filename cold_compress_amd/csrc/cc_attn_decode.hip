@@ -654,10 +654,10 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
   // EML (r3): the workgroup's (m, l) pairs leave EARLY — right behind the scores, while the V rows are still in flight — so that
   // the final (M, L) of the head, the probabilities, the history update and the next-eviction keys run in the shadow of the
   // partial-O exchange; what is left behind the last O granule is the y fold alone
-  constexpr bool EML = ONE1 && !L2 && !HYB;
+  constexpr bool EML = ONE1 && !HYB;  // (l2 included since late r3: its norm maxima leave with the (m, l) pairs)
   constexpr bool RC = EML;  // the recoverable hand-off (status / commit / fail words, state stores behind the last gather) rides the same kinds
   static_assert(sizeof(T) == 2 && (RT == 1 || RT == 2 || RT == 4 || RT == 8), "16-bit caches, up to 8 query heads per pass (the MFMA has 16 columns)");
-  static_assert(!ONE || NW == 4 || (NW == 8 && NT == 1 && !HYB), "the single-launch step runs on 4-wave workgroups, or on ONE 8-wave workgroup per CU (single tile; not the hybrid cache)");
+  static_assert(!ONE || NW == 4 || (NW == 8 && NT == 1), "the single-launch step runs on 4-wave workgroups, or on ONE 8-wave workgroup per CU (single tile)");
   constexpr int D = 128, VEC = 8, RPW = 4, U = 4;
   static_assert(FULL || ONE, "the lean form exists for the single-launch step only");
   if constexpr (!FULL) {  // constants for the optimiser: every `if (a.trace)`, `a.abl & ...`, `if (a.attn_out)` below folds away
@@ -673,6 +673,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
   __shared__ float sm_wm[NW][RT], sm_wl[NW][RT];  // the waves' softmax state per query head (merged across the workgroup)
   __shared__ unsigned sm_mlcnt;                    // EML: waves whose (m, l) rows are in LDS — the LAST one to arrive publishes
   __shared__ unsigned sm_fail;                     // EML: some wave of this workgroup gave up waiting (recoverable hand-off)
+  __shared__ float sm_l2w[NW];  // ONE + L2: per-wave maxima of the norms this workgroup's slots hold AFTER the step's insert
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, c = lane & 15;  // row group of the wave / 16-byte column chunk (and MFMA column n)
@@ -894,6 +895,21 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
     qb_vn.load(reinterpret_cast<const T*>(a.v_new) + (size_t)h * D + c * VEC);
     p_ins = *a.input_pos;
   }
+  if constexpr (L2 && EML) {
+    // the epoch words of the kv heads whose norm granules this thread gathers — AHEAD of the tile here: this workgroup's first
+    // publish (its (m, l) pairs and norm maximum, right behind the scores) must not happen before these loads have completed
+    // (no head's word is bumped before every workgroup of the launch has published), and behind the tile they would make that
+    // publish wait for the V rows (loads return in order).  Heads by a reciprocal multiply (exact for e < 2^16: corrected once).
+    const float inv_ns = 1.0f / (float)a.n_split;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const int e = (int)threadIdx.x + k * NW * 64;
+      int hh = (int)((float)e * inv_ns);
+      hh += ((hh + 1) * a.n_split <= e) ? 1 : 0;
+      hh -= (hh * a.n_split > e) ? 1 : 0;
+      if (e < a.H * a.n_split) l2_ep[k] = a.one_hdr[hh];
+    }
+  }
   // B operand: lane (n = c, kb = g) of step j holds q[head n][8 * (4j + g) .. + 8]; columns n >= RT are zero
   Vec16<T> qB[4];
 #pragma unroll
@@ -965,7 +981,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
   // ONE + L2: the epoch words of the kv heads whose norm granules this thread will gather.  Read HERE (behind the tile's loads: three integer divisions kept out of the way of the first K rows): every workgroup has read
   // them before it publishes anything, and no head's epoch is bumped before its split-0 workgroup has gathered the granules of
   // ALL workgroups of all heads — so none of these reads can see a bumped word.
-  if constexpr (ONE && L2) {
+  if constexpr (ONE && L2 && !EML) {
 #pragma unroll
     for (int k = 0; k < 3; k++) {
       const int e = (int)threadIdx.x + k * NW * 64;
@@ -1271,6 +1287,15 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
         sm_wm[wave][lane] = m;
         sm_wl[wave][lane] = l;
       }
+      if constexpr (L2) {  // the wave's maximum over the norms its slots hold AFTER this step's insert (decided above)
+        float kv = -INFINITY;
+        if (one_have) kv = (one_slot == ins_idx) ? l2_nv_lane : one_kn;
+        const bool nn = __any(kv != kv) != 0;
+        const float wm = wave_max_f32(kv);
+        if (lane == 0) sm_l2w[wave] = nn ? NAN : wm;
+        // the other heads' epoch words have ARRIVED (they were requested ahead of the tile): see above
+        asm volatile("" ::"v"(l2_ep[0]), "v"(l2_ep[1]), "v"(l2_ep[2]) : "memory");
+      }
       // No barrier: the waves' K tiles land up to 2 us apart, and a barrier here held every wave's P.V back until the workgroup's
       // LAST K tile had arrived (measured, r3: +0.8 us on the streaming part).  Each wave bumps an LDS counter behind its two
       // stores (release / acquire at workgroup scope); whoever brings it to NW has every wave's row in front of it and publishes.
@@ -1300,6 +1325,22 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
         const auto ml_rsrc_e = __builtin_amdgcn_make_buffer_rsrc(a.one_ml, 0, (int)a.one_ml_bytes, 0x00020000);
         const int off = ml_last ? h * kOneMlHead + (split * RT + lane) * 16 : 0x7ffffff0;
         __builtin_amdgcn_raw_buffer_store_b128(mg, ml_rsrc_e, off, 0, kOneAuxCoherent);
+        if constexpr (L2) {  // l2: the workgroup's norm maximum leaves with the pairs (same unconditional form; lane RT of the publisher)
+          float wm = -INFINITY;
+          bool nn = false;
+          if (arrived == (unsigned)(NW - 1) && lane == RT) {
+            wm = sm_l2w[0];
+            nn = wm != wm;
+#pragma unroll
+            for (int w = 1; w < NW; w++) {
+              nn |= sm_l2w[w] != sm_l2w[w];
+              wm = fmaxf(wm, sm_l2w[w]);
+            }
+          }
+          const u32x4_t ng = {one_tag, __float_as_uint(wm), one_tag, nn ? 1u : 0u};
+          const int noff = (arrived == (unsigned)(NW - 1) && lane == RT) ? kOneMaxHeads * kOneMlHead + h * kOneNmHead + split * 16 : 0x7ffffff0;
+          __builtin_amdgcn_raw_buffer_store_b128(ng, ml_rsrc_e, noff, 0, kOneAuxCoherent);
+        }
       }
     }
     if (more) tile_pv(tregs[0], base, false);
@@ -1314,8 +1355,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
       more = more_next;
     }
   }
-  __shared__ float sm_l2w[NW];  // ONE + L2: per-wave maxima of the norms this workgroup's slots hold AFTER the step's insert
-  if constexpr (L2 && ONE) {
+  if constexpr (L2 && ONE && !EML) {
     float kv = -INFINITY;
     if (one_have) kv = (one_slot == ins_idx) ? l2_nv_lane : one_kn;
     const bool nn = __any(kv != kv) != 0;
@@ -1387,7 +1427,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
     // timeout word should that ever not hold.
     const int ns = a.n_split;
     const unsigned tag = one_tag;
-    if constexpr (L2) {
+    if constexpr (L2 && !EML) {
       // the epoch words of the other heads (requested behind the tile's loads) must have ARRIVED before this workgroup publishes:
       // whoever bumps a word does so only after every workgroup of the launch has published
       asm volatile("" ::"v"(l2_ep[0]), "v"(l2_ep[1]), "v"(l2_ep[2]) : "memory");
@@ -1412,6 +1452,20 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
 #pragma unroll
     for (int k = 0; k < MLN; k++) ml_off[k] = h * kOneMlHead + ((lane < ns ? lane : 0) * RT + (wave + k * NW < RT ? wave + k * NW : 0)) * 16;
     u32x4_t mlq[MLN];
+    const int nm_base = kOneMaxHeads * kOneMlHead;  // l2: the norm-maximum granules sit behind the (m, l) regions of all heads
+    constexpr int NLG = L2 ? 3 : 0;  // l2: norm-maximum granules per thread (H * n_split <= 768 workgroups are ever co-resident)
+    int nm_off[NLG > 0 ? NLG : 1];
+    bool nm_use[NLG > 0 ? NLG : 1];
+    unsigned nm_tag[NLG > 0 ? NLG : 1];  // a granule of kv head h' carries h''s tag (its epoch word was read in the prologue: l2_ep)
+#pragma unroll
+    for (int k = 0; k < NLG; k++) {
+      const int e = (int)threadIdx.x + k * NW * 64;
+      nm_use[k] = e < a.H * ns;
+      const int hh = nm_use[k] ? e / ns : 0, ss = nm_use[k] ? e - hh * ns : 0;
+      nm_off[k] = nm_base + hh * kOneNmHead + ss * 16;
+      nm_tag[k] = l2_ep[k] + 1u;
+    }
+    u32x4_t nq[NLG > 0 ? NLG : 1];
     if constexpr (EML) {
       // the (m, l) pairs left behind the scores, long ago: their first round of loads goes out AHEAD of this workgroup's partial-O
       // stores (loads return in order: behind the stores they would also wait for the stores' acknowledgements, a round trip)
@@ -1419,6 +1473,10 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
 #pragma unroll
         for (int k = 0; k < MLN; k++) mlq[k] = __builtin_amdgcn_raw_buffer_load_b128(ml_rsrc, ml_off[k], 0, kOneAuxCoherent);
       }
+      // l2: every workgroup's norm maximum (they left with the pairs), gathered by every thread of every workgroup; a thread
+      // without a granule aims past the buffer's end (no request, zeros back): no branch around the loads
+#pragma unroll
+      for (int k = 0; k < NLG; k++) nq[k] = __builtin_amdgcn_raw_buffer_load_b128(ml_rsrc, nm_use[k] ? nm_off[k] : 0x7ffffff0, 0, kOneAuxCoherent);
       __builtin_amdgcn_sched_barrier(0);
     }
     // ---- publish: thread t merges output columns 2t, 2t + 1 of the workgroup's partial (the arithmetic of the
@@ -1448,8 +1506,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
     }
     // l2: the workgroup's norm maximum travels the same way — one granule {tag, max, tag, nan} per workgroup in the upper half
     // of the (m, l) region; every workgroup of EVERY kv head gathers all of them (cache.py:602 takes the maximum over all heads)
-    const int nm_base = kOneMaxHeads * kOneMlHead;  // behind the (m, l) regions of all heads
-    if constexpr (L2) {
+    if constexpr (L2 && !EML) {
       if (threadIdx.x == NW * 64 - 1) {
         float wm = sm_l2w[0];
         bool nn = wm != wm;
@@ -1483,18 +1540,6 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
       o_off[k] = h * kOneOHead + (((P >> 6) * ns + (o_use[k] ? i : 0)) * 64 + (P & 63)) * 16;
       o_lds[k] = (i * ppw + qq) * 2;
     }
-    constexpr int NLG = L2 ? 3 : 0;  // l2: norm-maximum granules per thread (H * n_split <= 768 workgroups are ever co-resident)
-    int nm_off[NLG > 0 ? NLG : 1];
-    bool nm_use[NLG > 0 ? NLG : 1];
-    unsigned nm_tag[NLG > 0 ? NLG : 1];  // a granule of kv head h' carries h''s tag (its epoch word was read in the prologue: l2_ep)
-#pragma unroll
-    for (int k = 0; k < NLG; k++) {
-      const int e = (int)threadIdx.x + k * NW * 64;
-      nm_use[k] = e < a.H * ns;
-      const int hh = nm_use[k] ? e / ns : 0, ss = nm_use[k] ? e - hh * ns : 0;
-      nm_off[k] = nm_base + hh * kOneNmHead + ss * 16;
-      nm_tag[k] = l2_ep[k] + 1u;
-    }
     bool timed_out = false;
     // The first poll waits until this wave's OWN publish stores are acknowledged (vmcnt counts stores on this chip).  Polls issued
     // right behind the write-through stores cost 0.8 us at S = 4096 (11.1 vs 10.3 us; found by accident: a never-taken measurement
@@ -1502,7 +1547,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
     // then queue behind 6 MB of polls per round that cannot succeed yet.
     if constexpr (!EML) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (EML: the first rounds of both gathers are not issued behind these stores)
     if (a.trace) tr3 = __builtin_amdgcn_s_memtime();
-    u32x4_t oq[NOG], nq[NLG > 0 ? NLG : 1];
+    u32x4_t oq[NOG];
     // one round of loads of each kind (coherent: they bypass the L1 and stale L2 lines), and whether every granule of the round
     // carries this launch's tag
     auto load_ml = [&]() {
@@ -1586,7 +1631,13 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
       // Round 0 (issued ahead of the partial-O stores) is examined in STRAIGHT-LINE code: the compiler then waits for exactly
       // these loads — the oldest in flight — and not for the acknowledgements of the stores behind them (at a loop header its
       // in-order wait counts merge with the back edge's and become a wait for everything)
-      bool ml_ok = !ml_mine || __all(ok_ml());
+      auto ok_nm = [&]() {
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < NLG; k++) ok = ok && (!nm_use[k] || (nq[k][0] == nm_tag[k] && nq[k][2] == nm_tag[k]));
+        return ok;
+      };
+      bool ml_ok = (!ml_mine || __all(ok_ml())) && (!L2 || __all(ok_nm()));
       for (unsigned spins = 0; !ml_ok; spins++) {
         if (spins > kOneSpinMax) {
           timed_out = true;
@@ -1594,12 +1645,29 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
         }
         __builtin_amdgcn_s_sleep(1);
         asm volatile("" ::: "memory");  // every round re-reads memory
-        load_ml();
-        ml_ok = __all(ok_ml());
+        if (ml_mine) load_ml();
+#pragma unroll
+        for (int k = 0; k < NLG; k++)
+          if (nm_use[k]) nq[k] = __builtin_amdgcn_raw_buffer_load_b128(ml_rsrc, nm_off[k], 0, kOneAuxCoherent);
+        ml_ok = (!ml_mine || __all(ok_ml())) && (!L2 || __all(ok_nm()));
       }
       if (timed_out) give_up();
       if (a.trace) tr4 = __builtin_amdgcn_s_memtime();
       if (ml_mine) final_ml();
+      if constexpr (L2) {  // the wave's fold of the gathered norm maxima (NaN propagates: torch.max)
+        float gm = -INFINITY;
+        bool gn = false;
+#pragma unroll
+        for (int k = 0; k < NLG; k++)
+          if (nm_use[k]) {
+            const float v = __uint_as_float(nq[k][1]);
+            gn |= nq[k][3] != 0u || v != v;
+            gm = fmaxf(gm, v);
+          }
+        const bool nn = __any(gn) != 0;
+        const float wm = wave_max_f32(gm);
+        if (lane == 0) sm_l2g[wave] = nn ? NAN : wm;
+      }
       __syncthreads();
       if (a.trace) trD = __builtin_amdgcn_s_memtime();
     } else {
@@ -2383,10 +2451,11 @@ static Plan make_plan(int HQ, int H, int S, int D, int dtype, int kind = 0) {
   if (R % 8 == 0 && cc_dt_size(dtype) == 2 && D == 128) p.rt = 8;
   // (r3) ONE 8-wave workgroup per CU instead of two 4-wave ones, where the cache has 16-row tiles for it (>= 5 x 256 over the
   // kv heads) and every wave still gets exactly one: half the publishers, granules and polls of the in-launch hand-off, half the
-  // splits for every gatherer to fold, one merge per CU — 4 or 8 query heads per kv head; every policy but the hybrid cache
-  // (whose caches are long: several tiles per wave), so that the steps of the policies that share inputs in the tests (l2 and
-  // the fused quantised cache against the plain 16-bit step) fold their partials alike
-  if (g_wide_enabled && kind != 200 && cc_dt_size(dtype) == 2 && D == 128 && (p.rt == 4 || p.rt == 8) && R == p.rt) {
+  // splits for every gatherer to fold, one merge per CU — 4 or 8 query heads per kv head; EVERY policy (the hybrid cache's real
+  // sizes never qualify — several tiles per wave — but a step and the plain attention of its three-call twin must fold their
+  // partials alike at every size: the geometry decides the last bits of (M, L))
+  (void)kind;
+  if (g_wide_enabled && cc_dt_size(dtype) == 2 && D == 128 && (p.rt == 4 || p.rt == 8) && R == p.rt) {
     const long tiles = (long)H * ((S + 15) / 16);
     // (measured, r3, same box: 1280 tiles (C2: S = 2560) wide 8.18 vs 8.46 us; 1024 tiles (S = 2048, or 4 kv heads at 4096) wide
     //  7.8-7.9 vs 7.35-7.75: from five tiles per CU on the 8-wave workgroup pays)
@@ -2463,7 +2532,7 @@ static int launch_split(const SplitArgs& a, const Plan& p, int H, int R, int D, 
         if (p.rt != 4 && p.rt != 8) return CC_ERR_UNSUPPORTED;
         rc = p.nw == 8 ? launch_mfma_rt<T, false, false, 8, 1, 8>(a, p.rt, grid, block, st) : launch_mfma_rt<T, false, false, 8, 1>(a, p.rt, grid, block, st);
       } else if (a.hyb.strategies != nullptr) {
-        rc = launch_mfma_rt<T, false, true, 0, 1>(a, p.rt, grid, block, st);
+        rc = p.nw == 8 ? launch_mfma_rt<T, false, true, 0, 1, 8>(a, p.rt, grid, block, st) : launch_mfma_rt<T, false, true, 0, 1>(a, p.rt, grid, block, st);
       } else if (a.key_norm != nullptr) {
         rc = p.nw == 8 ? launch_mfma_rt<T, true, false, 0, 1, 8>(a, p.rt, grid, block, st) : launch_mfma_rt<T, true, false, 0, 1>(a, p.rt, grid, block, st);
       } else if (p.nw == 8) {
@@ -2553,19 +2622,23 @@ static OneKernel one_kernel(int rt, int nt, int kind, bool full, int nw = kNW) {
   if (nt < 1 || nt > kOneMaxTiles) return nullptr;
   if (nw == 8) {  // ONE 8-wave workgroup per CU: 4 or 8 query heads per kv head, one tile per wave (make_plan)
 #define CC_ONE_W(RT_, L2_, QB_, FULL_) decode_attn_split_mfma_kernel<T, RT_, 8, L2_, true, false, QB_, 1, 1, FULL_>
-    if ((kind != 0 && kind != 8 && kind != -1) || nt != 1 || (rt != 4 && rt != 8)) return nullptr;
+#define CC_ONE_WH(RT_, FULL_) decode_attn_split_mfma_kernel<T, RT_, 8, false, true, true, 0, 1, 1, FULL_>
+    if ((kind != 0 && kind != 8 && kind != -1 && kind != 200) || nt != 1 || (rt != 4 && rt != 8)) return nullptr;
     if (full) {
       if constexpr (ElemTraits<T>::code != CC_DT_BF16) {
         return nullptr;
       } else {
         if (rt != 4) return nullptr;
+        if (kind == 200) return CC_ONE_WH(4, true);
         return kind == 0 ? CC_ONE_W(4, false, 0, true) : (kind == 8 ? CC_ONE_W(4, false, 8, true) : CC_ONE_W(4, true, 0, true));
       }
     }
+    if (kind == 200) return rt == 8 ? CC_ONE_WH(8, false) : CC_ONE_WH(4, false);
     if (kind == 0) return rt == 8 ? CC_ONE_W(8, false, 0, false) : CC_ONE_W(4, false, 0, false);
     if (kind == 8) return rt == 8 ? CC_ONE_W(8, false, 8, false) : CC_ONE_W(4, false, 8, false);
     return rt == 8 ? CC_ONE_W(8, true, 0, false) : CC_ONE_W(4, true, 0, false);
 #undef CC_ONE_W
+#undef CC_ONE_WH
   }
   if (nw != kNW) return nullptr;
   if (full) {
