@@ -453,19 +453,30 @@ class KVCacheFull(_RingFusedStep, KVCacheHeadConstant):
 
 
 class KVCacheRandom(_RingFusedStep, KVCacheHeadConstant):
-    """ref: cache.py:505-524.  The uniform vector is drawn by torch on the device (RNG streams are
-    backend-specific); `_rand` is the injection point tests use to replay the reference's draws.  In the two-launch
-    pipeline the draw for position p + 1 is made during step p (one draw per step, same order as the reference)."""
+    """ref: cache.py:505-524.  The reference draws torch.rand(S) per eviction — a backend-specific stream; `_rand` is the injection
+    point tests use to replay the reference's draws (parity is defined given the vector).  In the fused pipeline the draw for
+    position p + 1 is made during step p (one draw per step, same order as the reference), and when `_rand` is not overridden it
+    is made IN the kernels (cc_decode_step_random_rng: a stateless hash of (seed, position, slot), seeded from torch's CPU
+    generator when the pipeline starts) — no vector, no extra launch per step."""
     relevant_kwargs = ["max_cache_length", "max_seq_length", "cache_bits", "global_tokens", "recent_window"]
 
     def __init__(self, max_batch_size, n_heads, head_dim, dtype=torch.bfloat16, **kwargs):
         super().__init__(max_batch_size, n_heads, head_dim, dtype, **kwargs)
         self._init_ring_pipeline()
+        self._rng_seed = 0
 
     def _rand(self):
         return torch.rand(self.max_cache_length, device=self.k_cache.device)
 
+    def _in_kernel_rng(self):
+        return "_rand" not in self.__dict__ and type(self)._rand is KVCacheRandom._rand and not self.fused_quant
+
     def _pipeline_init(self, p32):
+        if self._in_kernel_rng():
+            self._rng_seed = int(torch.randint(0, 2 ** 62, (1,)).item())  # CPU generator: follows torch.manual_seed, no device sync
+            _abi.call("cc_random_next_key_init_rng", self._view(), _ptr(p32), self._rng_seed, int(self.global_tokens),
+                      int(self.recent_window), _ptr(self.next_key), _stream())
+            return
         r = self._rand().to(torch.float32).contiguous()
         _abi.call("cc_random_next_key_init", self._view(), _ptr(p32), _ptr(r), int(self.global_tokens), int(self.recent_window),
                   _ptr(self.next_key), _stream())
@@ -474,6 +485,11 @@ class KVCacheRandom(_RingFusedStep, KVCacheHeadConstant):
         return 3
 
     def _pipeline_step(self, q, k, v, p32, HQ, scale, y, ws):
+        if self._in_kernel_rng():
+            _abi.call("cc_decode_step_random_rng", self._view(), _ptr(q), _ptr(k), _ptr(v), _ptr(p32), self._rng_seed,
+                      _ptr(self.next_key), int(self.global_tokens), int(self.recent_window), HQ, scale, _ptr(y), _ptr(ws),
+                      ws.numel(), _stream())
+            return
         r = self._rand().to(torch.float32).contiguous()
         if self.fused_quant:
             return self._quant_step(q, k, v, p32, HQ, scale, y, ws, rand=r, g=self.global_tokens, w=self.recent_window)

@@ -209,7 +209,8 @@ struct SplitArgs {
   int64_t* hh_counter;
   int g, w;           // global_tokens, recent_window of the next-eviction score
   int policy;         // 1 = heavy hitter (history in num / denom), 2 = recent_global / full, 3 = random (head-constant: no history)
-  const float* rand_next;  // policy 3: [S] uniform draws for position p + 1
+  const float* rand_next;  // policy 3: [S] uniform draws for position p + 1, or null: cc_rng_uniform(rng_seed, p + 1, slot)
+  unsigned long long rng_seed;
   int yc_chunks;      // grid.x of the two-launch combine pass (unused)
   unsigned long long* trace;  // measurement only (cc_decode_step_trace): [workgroup][16] time stamps and hardware ids
   // ---- recoverable hand-off (r3; the early-(m, l) single-launch steps): step_commit[h] = the last position whose step is fully
@@ -794,7 +795,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
           one_denv[ti] = a.denom[(size_t)h * S + sl];
         }
         one_psv[ti] = a.pos[(a.Hp == 1 ? 0 : (size_t)h * S) + sl];
-        if (a.policy == 3) one_rndv[ti] = a.rand_next[sl];
+        if (a.policy == 3 && a.rand_next) one_rndv[ti] = a.rand_next[sl];
       }
     }
   };
@@ -1825,7 +1826,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
           if (a.policy == 2) {  // ref: cache.py:500-502, 552-556 — arg-min of pos behind the sinks; -1 = empty first
             if (slot_ti >= a.g) key_ti = make_key(orderable_i32(ps), low);
           } else {  // random, ref: cache.py:523 recent window -> +inf, then the base rules :373-376
-            float scn = one_rndv[TI];
+            float scn = a.rand_next ? one_rndv[TI] : cc_rng_uniform(a.rng_seed, p_next, slot_ti);
             if (ps >= p_next - a.w) scn = INFINITY;
             if (slot_ti < a.g) scn = INFINITY;
             if (ps == -1) scn = -INFINITY;
@@ -2030,7 +2031,8 @@ struct CombineArgs {
   int H, g, w;
   int policy;  // next-eviction scoring: 1 = heavy hitter (cache.py:727-749), 2 = recent_global / full (cache.py:500-502, 552-556),
                // 3 = random (cache.py:519-524 over rand_next), 4 = l2, 5 = heavy hitter over the W > 1 history ring
-  const float* rand_next;  // policy 3: [S] uniform draws for position p + 1
+  const float* rand_next;  // policy 3: [S] uniform draws for position p + 1, or null: cc_rng_uniform(rng_seed, p + 1, slot)
+  unsigned long long rng_seed;
   // ---- l2 (policy 4, cache.py:597-605): score = dtype(max over all norms - norm); the maximum is folded from the
   //      per-wave partials of the streaming pass and the H freshly inserted norms
   const void* key_norm;   // [H, S] T
@@ -2089,7 +2091,7 @@ __global__ __launch_bounds__(kCombThreads) void decode_attn_combine_kernel(Combi
     p_next = *a.input_pos + 1;
   }
   float rnd_mine = 0.f;
-  if (a.next_key && a.policy == 3) rnd_mine = a.rand_next[s_ld];
+  if (a.next_key && a.policy == 3 && a.rand_next) rnd_mine = a.rand_next[s_ld];
   // hybrid (policy 6): the head's policy row, its count after this step's insert and this slot's protection masks are
   // requested here with everything else (a dependent chain strategies -> table at the tail cost ~3 us of L2 round trips)
   int hyb_flags = 0, hyb_win = 0, hyb_cts_n = 0;
@@ -2359,7 +2361,7 @@ __global__ __launch_bounds__(kCombThreads) void decode_attn_combine_kernel(Combi
     my_key = make_key(orderable_f32(scn), ((uint32_t)s_mine << 1) | (uint32_t)(ps_mine == -1));
   }
   if (a.next_key && a.policy == 3 && have && h == 0) {  // ref: cache.py:523 recent window -> +inf, then the base rules :373-376
-    float scn = rnd_mine;
+    float scn = a.rand_next ? rnd_mine : cc_rng_uniform(a.rng_seed, p_next, s_mine);
     if (ps_mine >= p_next - a.w) scn = INFINITY;
     if (s_mine < a.g) scn = INFINITY;
     if (ps_mine == -1) scn = -INFINITY;
@@ -2756,6 +2758,8 @@ struct FusedStep {
   const HybridStep* hyb;  // policy 6
   float* qparams;  // fused quantised cache: c->k_cache / v_cache are the uint8 images, c->dtype the model dtype
   int32_t* commit;  // recoverable hand-off: step_commit [H] or null
+  unsigned long long rng_seed;  // policy 3 with rand_next == null: the in-kernel generator's seed
+  int rng_on;
 };
 // The W > 1 history ring folded into the combine pass (denom / counter travel as hh_denom / hh_counter).
 struct RingHistory {
@@ -2841,7 +2845,7 @@ static int attn_impl(const void* q, const void* k, const void* v, const uint8_t*
   const bool one_asked = (phases & CC_PHASE_ONE_LAUNCH) != 0;
   if (one_asked || (g_one_enabled && (phases & 3) == 3 && !(phases & CC_PHASE_TWO_LAUNCH))) {
     const bool policy_ok = fs && ((fs->policy == 1 && hh_num && hh_denom && fs->c->Hp == H) ||
-                                  ((fs->policy == 2 || (fs->policy == 3 && fs->rand_next)) && !hh_num && fs->c->Hp == 1) ||
+                                  ((fs->policy == 2 || (fs->policy == 3 && (fs->rand_next || fs->rng_on))) && !hh_num && fs->c->Hp == 1) ||
                                   (fs->policy == 4 && fs->key_norm && !hh_num && fs->c->Hp == H) ||
                                   (fs->policy == 6 && !hh_num && fs->c->Hp == H && fs->c->Hc == H));
     // the lean kernels carry no measurement hooks and no attn_out: a call that wants one of them runs a FULL instantiation where
@@ -2863,7 +2867,7 @@ static int attn_impl(const void* q, const void* k, const void* v, const uint8_t*
       sa.one_o_bytes = (unsigned)kOneOCap;
       sa.trace = reinterpret_cast<unsigned long long*>(g_one_trace);
       sa.y = y; sa.attn_out = attn_out; sa.hh_counter = hh_counter; sa.g = fs->g; sa.w = fs->w; sa.yc_chunks = p.n_chunks;
-      sa.policy = fs->policy; sa.rand_next = fs->rand_next;
+      sa.policy = fs->policy; sa.rand_next = fs->rand_next; sa.rng_seed = fs->rng_seed;
       if (fs->policy == 6) {  // hybrid: the ring state travels with the launch; every workgroup derives the ring column itself
         sa.ring_col = nullptr;
         if (rh) {
@@ -2895,7 +2899,7 @@ static int attn_impl(const void* q, const void* k, const void* v, const uint8_t*
   ca.S = S; ca.R = R; ca.D = D; ca.n_split = p.n_split; ca.chunk = p.chunk;
   if (fs) {
     ca.next_key = fs->next_key; ca.input_pos = fs->input_pos; ca.pos = fs->c->pos; ca.H = H; ca.g = fs->g; ca.w = fs->w;
-    ca.policy = fs->policy; ca.Hp = fs->c->Hp; ca.rand_next = fs->rand_next;
+    ca.policy = fs->policy; ca.Hp = fs->c->Hp; ca.rand_next = fs->rand_next; ca.rng_seed = fs->rng_seed;
     ca.key_norm = sa.key_norm; ca.l2_pmax = sa.l2_pmax; ca.l2_new = sa.l2_new; ca.l2_np = H * p.n_split * p.nw;
     if (fs->policy == 6) {
       ca.hyb = sa.hyb;
@@ -3025,6 +3029,19 @@ int cc_decode_step_random(const cc_kv_view* c, const void* q, const void* k_new,
       HQ % c->H || global_tokens < 0)
     return CC_ERR_BAD_ARG;
   FusedStep fs{c, k_new, v_new, input_pos, reinterpret_cast<unsigned long long*>(next_key), global_tokens, recent_window, 3, rand_next, nullptr};
+  return attn_impl(q, c->k_cache, c->v_cache, c->mask, HQ, c->H, c->S, c->D, c->dtype, scale, y, nullptr, nullptr, nullptr, nullptr,
+                   nullptr, workspace, workspace_bytes, stream, 3, &fs);
+}
+
+int cc_decode_step_random_rng(const cc_kv_view* c, const void* q, const void* k_new, const void* v_new, const int32_t* input_pos,
+                              uint64_t seed, uint64_t* next_key, int32_t global_tokens, int32_t recent_window, int32_t HQ,
+                              float scale, void* y, void* workspace, size_t workspace_bytes, cc_stream_t stream) {
+  if (!cc_view_ok(c) || !q || !k_new || !v_new || !input_pos || !next_key || !y || c->Hp != 1 || HQ <= 0 || HQ % c->H ||
+      global_tokens < 0)
+    return CC_ERR_BAD_ARG;
+  FusedStep fs{c, k_new, v_new, input_pos, reinterpret_cast<unsigned long long*>(next_key), global_tokens, recent_window, 3, nullptr, nullptr};
+  fs.rng_seed = seed;
+  fs.rng_on = 1;
   return attn_impl(q, c->k_cache, c->v_cache, c->mask, HQ, c->H, c->S, c->D, c->dtype, scale, y, nullptr, nullptr, nullptr, nullptr,
                    nullptr, workspace, workspace_bytes, stream, 3, &fs);
 }

@@ -139,6 +139,16 @@ __device__ __forceinline__ unsigned long long make_key(uint32_t ord, uint32_t sl
   return ((unsigned long long)ord << 32) | slot;
 }
 
+// Uniform draw of KVCacheRandom's in-kernel generator (include/coldcompress.h, cc_decode_step_random_rng): stateless, 24 bits.
+__host__ __device__ static inline uint64_t cc_mix64(uint64_t x) {
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+  return x;
+}
+__host__ __device__ static inline float cc_rng_uniform(uint64_t seed, int32_t pos, int32_t slot) {
+  const uint64_t x = cc_mix64(cc_mix64(seed + (uint64_t)(uint32_t)pos * 0x9E3779B97F4A7C15ull + (uint64_t)(uint32_t)slot));
+  return (float)(uint32_t)(x >> 40) * 5.9604644775390625e-08f;  // * 2^-24: exact
+}
+
 // Fused heavy-hitter decode step: the arg-min key of the next eviction is published as one partial minimum
 // per 128-slot chunk of the cache (no atomics: same-address atomics from 8 XCDs serialise in the fabric and
 // cost more than the whole pass); consumers take the minimum over a head's cc_next_key_slots(S) entries.

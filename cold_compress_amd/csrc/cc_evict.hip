@@ -33,6 +33,7 @@ struct UpdArgs {
   int32_t* denom;        // P_HH
   unsigned long long* key_out;  // P_HH pipeline seed: [H][nk] partial arg-min keys (entry 0 = the key, rest = ~0); no side effects
   int nk;
+  unsigned long long rng_seed;  // P_RANDOM with scores == null: cc_rng_uniform(rng_seed, *input_pos, slot)
 };
 
 constexpr int kUpdThreads = 1024;
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(kUpdThreads) void decode_update_kernel(UpdArgs a) {
       dv[u] = 0.0;
       iv[u] = 0;
       if (POLICY == P_SCORES) fv[u] = ElemTraits<ST>::load(reinterpret_cast<const ST*>(a.scores), (a.score_heads == 1 ? 0 : hoff) + sc);
-      if (POLICY == P_RANDOM) fv[u] = reinterpret_cast<const float*>(a.scores)[sc];
+      if (POLICY == P_RANDOM && a.scores) fv[u] = reinterpret_cast<const float*>(a.scores)[sc];
       if (POLICY == P_L2) fv[u] = ElemTraits<T>::load(reinterpret_cast<const T*>(a.key_norm), hoff + sc);
       if (POLICY == P_HH) {
         dv[u] = a.num[hoff + sc];
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(kUpdThreads) void decode_update_kernel(UpdArgs a) {
         if (POLICY == P_SCORES) {
           sc = fv[u];
         } else if (POLICY == P_RANDOM) {
-          sc = (ps >= p - a.w) ? INFINITY : fv[u];  // ref: cache.py:523
+          sc = (ps >= p - a.w) ? INFINITY : (a.scores ? fv[u] : cc_rng_uniform(a.rng_seed, p, s < S ? s : S - 1));  // ref: cache.py:523
         } else if (POLICY == P_L2) {
           // ref: cache.py:601-605 — model-dtype subtraction (fp32 op, rounded to T), recent window -> +inf
           sc = ElemTraits<T>::rnd(gmax - fv[u]);
@@ -451,6 +452,18 @@ int cc_random_next_key_init(const cc_kv_view* c, const int32_t* input_pos, const
   UpdArgs a{};
   a.input_pos = input_pos; a.g = g; a.w = w;
   a.scores = rand_u; a.score_heads = 1;
+  a.key_out = reinterpret_cast<unsigned long long*>(next_key);
+  a.nk = cc_next_key_slots(c->S);
+  return launch_update<P_RANDOM>(c, a, (hipStream_t)stream);
+}
+
+int cc_random_next_key_init_rng(const cc_kv_view* c, const int32_t* input_pos, uint64_t seed, int32_t g, int32_t w,
+                                uint64_t* next_key, cc_stream_t stream) {
+  CC_ENTRY();
+  if (!cc_view_ok(c) || !input_pos || !next_key || c->Hp != 1 || g < 0) return CC_ERR_BAD_ARG;
+  UpdArgs a{};
+  a.input_pos = input_pos; a.g = g; a.w = w;
+  a.scores = nullptr; a.score_heads = 1; a.rng_seed = seed;
   a.key_out = reinterpret_cast<unsigned long long*>(next_key);
   a.nk = cc_next_key_slots(c->S);
   return launch_update<P_RANDOM>(c, a, (hipStream_t)stream);

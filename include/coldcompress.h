@@ -212,6 +212,17 @@ int cc_decode_step_random(const cc_kv_view* c, const void* q, const void* k_new,
                           const int32_t* input_pos, const float* rand_next, uint64_t* next_key, int32_t global_tokens,
                           int32_t recent_window, int32_t HQ, float scale, void* y, void* workspace,
                           size_t workspace_bytes, cc_stream_t stream);
+/* KVCacheRandom's fused step with the uniform draws made IN the kernels (r3): ref cache.py:519-524 draws torch.rand(S) per
+ * eviction — a backend-specific stream, so parity is defined given the vector (cc_decode_step_random, the injection point of the
+ * tests); a product run needs no vector and no extra launch: the draw for slot s at position p is
+ *   u(seed, p, s) = (mix64(seed + p * 0x9E3779B97F4A7C15 + s) >> 40) * 2^-24   (24 bits, like torch.rand's float32)
+ * with mix64 = the murmur3 64-bit finaliser applied twice — stateless (a hipGraph replay advances with *input_pos), identical in
+ * the single-launch step, the two-launch step, cc_random_next_key_init_rng and the oracle's twins. */
+int cc_random_next_key_init_rng(const cc_kv_view* c, const int32_t* input_pos, uint64_t seed, int32_t global_tokens,
+                                int32_t recent_window, uint64_t* next_key, cc_stream_t stream);
+int cc_decode_step_random_rng(const cc_kv_view* c, const void* q, const void* k_new, const void* v_new, const int32_t* input_pos,
+                              uint64_t seed, uint64_t* next_key, int32_t global_tokens, int32_t recent_window, int32_t HQ,
+                              float scale, void* y, void* workspace, size_t workspace_bytes, cc_stream_t stream);
 /* The same two-launch step for KVCacheL2 (cache.py:559-612: score = dtype(max over ALL heads' and slots' key norms -
  * norm), recent window -> +inf, base rules; the inserted key's norm recorded, cache.py:592-593).  The global maximum
  * is folded across the step boundary: the streaming pass publishes per-wave maxima of the surviving norms, the

@@ -1473,6 +1473,46 @@ int cc_decode_step_random_cpu(const cc_kv_view* c, const void* q, const void* k_
   return CC_OK;
 }
 
+/* The in-kernel generator's twins (include/coldcompress.h, cc_decode_step_random_rng): the draw for slot s at position p is
+ * the murmur3 64-bit finaliser applied twice to seed + p * golden + s, top 24 bits * 2^-24.  The reference draws torch.rand(S)
+ * (cache.py:521), a backend stream no other implementation reproduces; parity with the reference is pinned with the vector
+ * injected (cc_decode_step_random_cpu above), and these twins pin the device's own generator. */
+static uint64_t rng_mix64(uint64_t x) {
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+  return x;
+}
+float cc_rng_uniform_cpu(uint64_t seed, int32_t pos, int32_t slot) {
+  const uint64_t x = rng_mix64(rng_mix64(seed + (uint64_t)(uint32_t)pos * 0x9E3779B97F4A7C15ull + (uint64_t)(uint32_t)slot));
+  return (float)(uint32_t)(x >> 40) * 5.9604644775390625e-08f;
+}
+static float* rng_vector(uint64_t seed, int32_t p, int S) {
+  float* u = (float*)malloc((size_t)S * sizeof(float));
+  for (int s = 0; u && s < S; s++) u[s] = cc_rng_uniform_cpu(seed, p, s);
+  return u;
+}
+
+int cc_random_next_key_init_rng_cpu(const cc_kv_view* c, const int32_t* input_pos, uint64_t seed, int32_t g, int32_t w,
+                                    uint64_t* next_key, cc_stream_t stream) {
+  if (!view_ok(c) || !input_pos) return CC_ERR_BAD_ARG;
+  float* u = rng_vector(seed, *input_pos, c->S);
+  if (!u) return CC_ERR_BAD_ARG;
+  const int rc = cc_random_next_key_init_cpu(c, input_pos, u, g, w, next_key, stream);
+  free(u);
+  return rc;
+}
+
+int cc_decode_step_random_rng_cpu(const cc_kv_view* c, const void* q, const void* k_new, const void* v_new,
+                                  const int32_t* input_pos, uint64_t seed, uint64_t* next_key, int32_t g, int32_t w, int32_t HQ,
+                                  float scale, void* y, void* workspace, size_t workspace_bytes, cc_stream_t stream) {
+  if (!view_ok(c) || !input_pos) return CC_ERR_BAD_ARG;
+  float* u = rng_vector(seed, *input_pos + 1, c->S);
+  if (!u) return CC_ERR_BAD_ARG;
+  const int rc = cc_decode_step_random_cpu(c, q, k_new, v_new, input_pos, u, next_key, g, w, HQ, scale, y, workspace,
+                                           workspace_bytes, stream);
+  free(u);
+  return rc;
+}
+
 /* Measurement hook twin: the oracle has no launches to select; only phases == 3 (the whole step) is meaningful. */
 int cc_decode_step_heavy_hitter_phases_cpu(const cc_kv_view* c, const void* q, const void* k_new, const void* v_new,
                                            const int32_t* input_pos, double* num, int32_t* denom, int64_t* counter,

@@ -44,6 +44,16 @@ def fns():
     return _FNS
 
 
+def rng_vector(seed, pos, S):
+    """KVCacheRandom's in-kernel generator restated on the host (cc_rng_uniform_cpu): the float32 [S] draw for position `pos`."""
+    import numpy as np
+    fns()
+    lib = C.CDLL(SO)
+    lib.cc_rng_uniform_cpu.restype = C.c_float
+    lib.cc_rng_uniform_cpu.argtypes = [C.c_uint64, C.c_int32, C.c_int32]
+    return np.array([lib.cc_rng_uniform_cpu(int(seed), int(pos), s) for s in range(S)], dtype=np.float32)
+
+
 def set_threads(n):
     """Thread count of the oracle's OpenMP loops (per-head loops of the decode hot path); returns the previous one."""
     fns()

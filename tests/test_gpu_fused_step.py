@@ -370,6 +370,58 @@ def test_random_fused_step_equals_three_calls(dtype, H, HQ, S, D, T, g, w, singl
                 assert torch.equal(ta, tb), f"step {t}: {na}"
 
 
+@pytest.mark.parametrize("single", [False, True])
+@pytest.mark.parametrize("dtype,H,HQ,S,D,T,g,w", [(torch.bfloat16, 8, 32, 4096, 128, 4090, 4, 10), (torch.float32, 2, 4, 77, 16, 70, 2, 3)])
+def test_random_in_kernel_draws(dtype, H, HQ, S, D, T, g, w, single, single_launch_switch):
+    """KVCacheRandom without an injected vector: the fused step draws IN the kernels (cc_decode_step_random_rng).  Against the
+    three-call path fed the oracle's restatement of the generator (oracle_lib.rng_vector, position by position): every buffer
+    bit for bit, so the generator, its (seed, position, slot) indexing and the single / two-launch forms all agree."""
+    import cold_compress_amd.cache as cache
+    from cold_compress_amd.attention_utils import scaled_dot_product_attention as sdpa
+    from oracle import oracle_lib
+
+    single_launch_switch(single)
+    cls, rk = cache.get_cache_constructor("random")
+    kw = dict(max_cache_length=S, global_tokens=g, recent_window=w, max_seq_length=4 * S, cache_bits=None)
+
+    def mk():
+        with torch.device(DEV):
+            return cls(1, H, D, dtype, **{k: kw[k] for k in rk})
+
+    a, b = mk(), mk()
+    assert b._in_kernel_rng()
+    gen = torch.Generator().manual_seed(13)
+    k0 = torch.randn(1, H, T, D, generator=gen).to(dtype).to(DEV)
+    v0 = torch.randn(1, H, T, D, generator=gen).to(dtype).to(DEV)
+    for kv in (a, b):
+        kv.update_kv(torch.arange(T, device=DEV), k0, v0, True)
+    torch.manual_seed(99)
+    b.prepare_decode(torch.tensor([T], dtype=torch.int32, device=DEV))
+    seed = b._rng_seed
+    assert 0 < seed < 2 ** 62
+    steps = 12
+    draws = iter([torch.from_numpy(oracle_lib.rng_vector(seed, T + t, S)).to(DEV) for t in range(steps)])
+    a._rand = lambda: next(draws)
+    assert not a._in_kernel_rng()
+    evicted = 0
+    for t in range(steps):
+        p = torch.tensor([T + t], dtype=torch.int32, device=DEV)
+        k1 = torch.randn(1, H, 1, D, generator=gen).to(dtype).to(DEV)
+        v1 = torch.randn(1, H, 1, D, generator=gen).to(dtype).to(DEV)
+        q = torch.randn(1, HQ, 1, D, generator=gen).to(dtype).to(DEV)
+        before = a.pos.clone()
+        ka, va, ma = a.update_kv(p, k1, v1, False)
+        evicted += int((before != -1).logical_and(a.pos != before).any())
+        ya, _ = sdpa(q, ka, va, attn_mask=ma)
+        yb = b.decode_step(q, k1, v1, p)
+        torch.cuda.synchronize()
+        _y_check(ya, yb, single, t)
+        for (na, ta), (nb, tb) in zip(a.named_buffers(), b.named_buffers()):
+            if na not in ("next_key", "step_commit"):
+                assert torch.equal(ta, tb), f"step {t}: {na}"
+    assert evicted >= steps - (S - T) - 1  # the cache filled up: the draws decided real evictions
+
+
 def test_random_fused_replay_vs_reference():
     """The reference's own random-policy trace (tests/golden/f4_random.npz: its draws, its evicted slots, its final
     buffers) replayed through the two-launch step."""

@@ -548,9 +548,20 @@ def test_debug_analysis_cache_vs_reference(name):
     same_keep = torch.equal(kv.compressed.pos.cpu(), f["comp_pos_after_prefill"])
     assert same_keep or tie_ok
     if not same_keep:
-        pytest.skip("boundary tie in the 16-bit prompt-compaction priorities: the traces diverge legitimately")
+        # boundary tie in the 16-bit prompt-compaction priorities: the two keep sets are equally good.  The replay
+        # FOLLOWS the reference's (the shadow cache is rebuilt from the prompt rows at the reference's positions) instead of
+        # skipping, so that the 16-bit fixture always pins the decode-time bookkeeping too.
+        comp, rp = kv.compressed, f["comp_pos_after_prefill"].to(DEV)
+        a, b = set(kv.compressed.pos.cpu().flatten().tolist()), set(rp.cpu().flatten().tolist())
+        assert len(a ^ b) <= 2 * H * 2, "more than a boundary tie separates the keep sets"
+        idx = rp[0].to(torch.int64)  # [H, S] prompt positions
+        comp.pos.copy_(rp)
+        comp.k_cache.copy_(torch.gather(k0[0], 1, idx.unsqueeze(-1).expand(-1, -1, D)).unsqueeze(0))
+        comp.v_cache.copy_(torch.gather(v0[0], 1, idx.unsqueeze(-1).expand(-1, -1, D)).unsqueeze(0))
+        comp._next_valid = False
     tol = dict(rtol=2 ** -7, atol=1e-6) if dtype != torch.float32 else dict(rtol=1e-5, atol=1e-7)
-    assert torch.allclose(kv.compressed.attn_history_num.cpu().float(), f["comp_num_after_prefill"].float(), **tol)
+    if same_keep:
+        assert torch.allclose(kv.compressed.attn_history_num.cpu().float(), f["comp_num_after_prefill"].float(), **tol)
     kv.compressed.attn_history_num.copy_(f["comp_num_after_prefill"].to(DEV))  # column-sum order is unspecified: continue on equal state
     for t in range(steps):
         p = torch.tensor([L + t], dtype=torch.int32, device=DEV)

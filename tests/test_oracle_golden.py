@@ -358,3 +358,33 @@ def test_analysis_loss_matches_reference_capture(oracle, name):
             assert np.array_equal(s32[h][filled[h]], a32[h][pos[h][filled[h]]])
             assert np.array_equal(s32[h][~filled[h]], np.full((~filled[h]).sum(), a32[h][SF - 1]))
     assert int(ctr[0]) == steps == int(f["loss_ctr"])
+
+
+def test_in_kernel_generator_restatement():
+    """KVCacheRandom's in-kernel generator (cc_rng_uniform, include/coldcompress.h): the oracle's C restatement against a numpy
+    restatement of the published formula, plus the properties the policy needs — values in [0, 1) on the 2^-24 grid, different
+    positions / seeds give different vectors, near-uniform mean."""
+    from oracle import oracle_lib
+
+    def mix(x):
+        x = np.uint64(x)
+        with np.errstate(over="ignore"):
+            x ^= x >> np.uint64(33); x *= np.uint64(0xff51afd7ed558ccd); x ^= x >> np.uint64(33)
+            x *= np.uint64(0xc4ceb9fe1a85ec53); x ^= x >> np.uint64(33)
+        return x
+
+    def ref(seed, pos, S):
+        with np.errstate(over="ignore"):
+            x = np.uint64(seed) + np.uint64(pos) * np.uint64(0x9E3779B97F4A7C15) + np.arange(S, dtype=np.uint64)
+        x = mix(mix(x))
+        return ((x >> np.uint64(40)).astype(np.float32) * np.float32(2.0 ** -24)).astype(np.float32)
+
+    for seed, pos, S in [(0, 0, 64), (1234567890123456789, 4095, 4096), (2 ** 62 - 1, 2 ** 31 - 2, 257)]:
+        u = oracle_lib.rng_vector(seed, pos, S)
+        assert np.array_equal(u, ref(seed, pos, S))
+        assert u.min() >= 0.0 and u.max() < 1.0
+        assert np.array_equal(u * 2 ** 24, np.round(u * 2 ** 24))
+    u = oracle_lib.rng_vector(7, 100, 4096)
+    assert abs(float(u.mean()) - 0.5) < 0.02 and len(np.unique(u)) > 4000
+    assert not np.array_equal(u, oracle_lib.rng_vector(7, 101, 4096))
+    assert not np.array_equal(u, oracle_lib.rng_vector(8, 100, 4096))
