@@ -61,3 +61,26 @@ def test_oneshot_allreduce_two_ranks_on_one_gpu():
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: the stores cross xGMI")
 def test_oneshot_allreduce_over_xgmi():
     _launch([], script="allreduce_check.py", marker="ONESHOT ALLREDUCE CHECK OK")
+
+
+def test_bench_gpus8_control_flow_dry_run():
+    """`bench.py --gpus 8` end to end on ONE GPU (CC_BENCH_DRYRUN_ONE_GPU=1: every rank on cuda:0, collectives staged through the
+    host; NOT a measurement): self-launch of 8 ranks, the KV-head split down to H = 1 per rank (the shape every rank of the 8-GPU
+    point runs), max-over-ranks timing, per-rank report, one JSON line from rank 0.  Two layers and a short prompt keep it cheap;
+    the control flow is the full-size run's."""
+    import json
+
+    env = dict(os.environ, CC_BENCH_DRYRUN_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "6", "--warmup", "2", "--n_layer", "2",
+           "--prompt_len", "1024", "--cache_len", "512", "--no_cpu_baseline", "--no_live_pmc", "--roofline_iters", "2"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, f"{r.stdout[-3000:]}\n{r.stderr[-3000:]}"
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-3000:]  # rank 0 alone reports
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["steps"] == 6 and out["warmup"] == 2 and out["value"] > 0
+    cfg = out["config"]
+    assert cfg["parallelism"] == "tp8" and cfg["rccl_ranks"] == 8
+    assert cfg["per_rank"] is not None and len(cfg["per_rank"]) == 8
