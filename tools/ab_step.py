@@ -43,7 +43,13 @@ def main():
         out[sh] = round(timed(lambda i: caches[i % n_buf].decode_step(q, k1, k1, pos), n_nodes, iters=15), 2)
         del caches
         torch.cuda.empty_cache()
-    print(json.dumps({"wide": wide, "policy": policy, "us": out}), flush=True)
+    from cold_compress_amd.attention_utils import single_launch_status
+
+    st = single_launch_status(torch.device("cuda", torch.cuda.current_device()))
+    rec = {"wide": wide, "policy": policy, "us": out}
+    if st:  # a hand-off timed out: every later launch was a no-op and the times above mean nothing
+        rec["HANDOFF_TIMEOUT_STATUS"] = int(st)
+    print(json.dumps(rec), flush=True)
 
 
 if __name__ == "__main__":
