@@ -629,6 +629,13 @@ def main():
                 print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); falling back to eager launches",
                       file=sys.stderr)
                 gdec = None
+        if world > 1 and not args.no_graph:
+            # every rank replays a graph or none does (a rank that fell back alone would skip the timed comparison below, whose
+            # MAX all-reduces its peers would then wait in)
+            okf = torch.tensor([1 if gdec is not None else 0], device=dev, dtype=torch.int32)
+            dist.all_reduce(okf, op=dist.ReduceOp.MIN)
+            if int(okf.item()) == 0:
+                gdec = None
         if gdec is None:
             dec, mode = decode_one_token, "eager"
         elif args.graph:
