@@ -17,6 +17,9 @@
 //   averages them over the R query heads of the group, and optionally applies the heavy-hitter history
 //   update (cache.py:690-723) in the same pass.
 // HBM-bound: ~1 flop/byte, no MFMA.
+#include <atomic>
+#include <mutex>
+
 #include "cc_common.h"
 #include "cc_wacc.h"
 
@@ -2600,9 +2603,13 @@ static int one_capacity(void (*kernel)(SplitArgs), int threads) {
     void (*k)(SplitArgs);
     int cap;
   };
+  // readers take no lock: an entry is complete before the count that makes it visible is published (release / acquire); two
+  // threads that miss together both ask the runtime and the second append is refused as a duplicate under the lock
   static Entry cache[64];
-  static int n_cached = 0;
-  for (int i = 0; i < n_cached; i++)
+  static std::atomic<int> n_cached{0};
+  static std::mutex mu;
+  const int n = n_cached.load(std::memory_order_acquire);
+  for (int i = 0; i < n; i++)
     if (cache[i].k == kernel) return cache[i].cap;
   int dev = 0, cus = 0, nb = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
@@ -2611,7 +2618,14 @@ static int one_capacity(void (*kernel)(SplitArgs), int threads) {
     return 0;
   }
   const int cap = cus * (nb > 8 ? 8 : nb);
-  if (n_cached < 64) cache[n_cached++] = Entry{kernel, cap};
+  std::lock_guard<std::mutex> lock(mu);
+  const int m = n_cached.load(std::memory_order_relaxed);
+  for (int i = 0; i < m; i++)
+    if (cache[i].k == kernel) return cache[i].cap;
+  if (m < 64) {
+    cache[m] = Entry{kernel, cap};
+    n_cached.store(m + 1, std::memory_order_release);
+  }
   return cap;
 }
 typedef void (*OneKernel)(SplitArgs);

@@ -58,7 +58,10 @@ def _seed(kv, gen, T):
                                               (torch.bfloat16, 5, 10, 8200, 128, 8200),
                                               # caches beyond 64 x 64 slots per head: several tiles per wave in the single launch
                                               (torch.bfloat16, 8, 32, 8192, 128, 8190), (torch.float16, 4, 16, 5000, 128, 4990),
-                                              (torch.bfloat16, 2, 16, 18432, 128, 18400), (torch.bfloat16, 1, 8, 32768, 128, 32768)])
+                                              (torch.bfloat16, 2, 16, 18432, 128, 18400), (torch.bfloat16, 1, 8, 32768, 128, 32768),
+                                              # the 8-wave geometry in its other instantiations: fp16, and 8 query heads per kv head
+                                              (torch.float16, 8, 32, 4096, 128, 4090), (torch.bfloat16, 8, 64, 4096, 128, 4000),
+                                              (torch.float16, 8, 64, 2560, 128, 2560)])
 @pytest.mark.parametrize("single", [False, True])
 def test_fused_step_equals_three_calls(dtype, H, HQ, S, D, T, single):
     """`single`: decode_step may run as ONE launch where the shape allows it (include/coldcompress.h); every buffer must
