@@ -659,7 +659,11 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
   // the final (M, L) of the head, the probabilities, the history update and the next-eviction keys run in the shadow of the
   // partial-O exchange; what is left behind the last O granule is the y fold alone
   constexpr bool EML = ONE1 && !HYB;  // (l2 included since late r3: its norm maxima leave with the (m, l) pairs)
+#ifdef CC_NO_RC  // (A/B builds)
+  constexpr bool RC = false;
+#else
   constexpr bool RC = EML;  // the recoverable hand-off (status / commit / fail words, state stores behind the last gather) rides the same kinds
+#endif
   static_assert(sizeof(T) == 2 && (RT == 1 || RT == 2 || RT == 4 || RT == 8), "16-bit caches, up to 8 query heads per pass (the MFMA has 16 columns)");
   static_assert(!ONE || NW == 4 || (NW == 8 && NT == 1), "the single-launch step runs on 4-wave workgroups, or on ONE 8-wave workgroup per CU (single tile)");
   constexpr int D = 128, VEC = 8, RPW = 4, U = 4;
@@ -723,6 +727,68 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
   // (late r2, measured on one box against the same build without it: these loads and the fold below cost the step 0.35 us — every
   //  wave of a kv head reads the same 2 KB — but leaving both to wave 0 and handing the key to the others through LDS and a
   //  barrier cost 0.2 us MORE: kept as is)
+  struct TileRegs {            // the staging registers of one tile in flight
+    uint32_t mword;
+    Vec16<T> kk[U], vv[U];
+    uint2 kq8[U], vq8[U];      // QB: the rows' bytes ...
+    float2 kpar[U], vpar[U];   // ... and their (scale, minimum)
+  };
+  TileRegs tregs[NSUB];
+  auto load_nt_u2 = [](const uint8_t* p) {
+    typedef unsigned int u32x2_nt __attribute__((ext_vector_type(2)));
+    const u32x2_nt v = __builtin_nontemporal_load(reinterpret_cast<const u32x2_nt*>(p));
+    return make_uint2(v.x, v.y);
+  };
+  auto issue_k = [&](TileRegs& R, int base) {  // mask word + the four K rows of this lane's row group (tile row i = 4g + u takes chunk c ^ i)
+    const int row0 = base + g * U;
+    R.mword = 0x01010101u;
+    if (has_mask) {
+      if (row0 + 3 < S && ((reinterpret_cast<uintptr_t>(mh) + (size_t)row0) & 3) == 0) {
+        R.mword = *reinterpret_cast<const uint32_t*>(mh + row0);
+      } else {
+        R.mword = 0;
+#pragma unroll
+        for (int u = 0; u < U; u++)
+          if (row0 + u < S) R.mword |= (uint32_t)mh[row0 + u] << (8 * u);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int rr = row0 + u < row_end ? row0 + u : row_end - 1;
+      if constexpr (QB) {
+        R.kq8[u] = load_nt_u2(kqb + (size_t)rr * D + ((c ^ (4 * g + u)) & 15) * VEC);
+        R.kpar[u] = qpar[(size_t)rr * 2];
+      } else {
+        R.kk[u].load_nt(kb + (size_t)rr * D + ((c ^ (4 * g + u)) & 15) * VEC);
+      }
+    }
+  };
+  auto issue_v = [&](TileRegs& R, int base) {
+    const int row0 = base + g * U;
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int rr = row0 + u < row_end ? row0 + u : row_end - 1;
+      if constexpr (QB) {
+        R.vq8[u] = load_nt_u2(vqh + (size_t)rr * D);
+        R.vpar[u] = qpar[(size_t)rr * 2 + 1];
+      } else {
+        R.vv[u].load_nt(vh + (size_t)rr * D);
+      }
+    }
+  };
+  int base = row_begin + wave * (RPW * U);
+  bool more = base < row_end;
+  // Single tile, 16-bit cache (late r3): the K rows are requested right BEHIND the key row — ahead of the per-slot state, the
+  // epoch / status words and q, ~150 instructions earlier than with the rest of the tile.  Same-box A/B, three runs each: heavy
+  // hitter 9.13 -> 8.92 us at S = 4096 (l2 10.5 -> 10.3, recent_global 8.98 -> 8.9, random 9.2 -> 9.1; S = 2560 and one kv head
+  // unchanged).  The neighbours of this placement all LOSE: K ahead of the key row +0.1 (every workgroup's first decision then
+  // queues behind 16 MB of rows), K and V both here +0.2, q moved up with K +0.1 (+0.5 at one kv head), the per-slot state moved
+  // behind V +0.45.
+#ifdef CC_NO_KEARLY  // (A/B builds)
+  constexpr bool KEARLY = false;
+#else
+  constexpr bool KEARLY = ONE1 && !HYB && QB == 0;
+#endif
   if (key_pending) {
     const unsigned long long* krow = a.next_key + (size_t)(a.Hp == 1 ? 0 : h) * a.nk;
     if (lane < a.nk_read) key_part = krow[lane];
@@ -734,6 +800,10 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
       const unsigned long long x = a.next_key[(size_t)(a.Hp == 1 ? 0 : h) * a.nk + i];
       key_part = x < key_part ? x : key_part;
     }
+  }
+  if constexpr (KEARLY) {
+    issue_k(tregs[0], base);
+    __builtin_amdgcn_sched_barrier(0);  // (keeps the scheduler from sinking them back to the rest of the tile)
   }
   // HYB: everything the per-head decision needs besides the candidate key — the policy table (ALL rows: one vector load, the
   // head's row is picked by a lane read once its policy index has arrived), the punctuation ids (one id per lane), the head's
@@ -921,63 +991,12 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
     qB[j].raw = make_uint4(0, 0, 0, 0);
     if (c < RT) qB[j].load(reinterpret_cast<const T*>(a.q) + (size_t)(q0 + c) * D + (4 * j + g) * VEC);
   }
-  struct TileRegs {            // the staging registers of one tile in flight
-    uint32_t mword;
-    Vec16<T> kk[U], vv[U];
-    uint2 kq8[U], vq8[U];      // QB: the rows' bytes ...
-    float2 kpar[U], vpar[U];   // ... and their (scale, minimum)
-  };
-  TileRegs tregs[NSUB];
-  auto load_nt_u2 = [](const uint8_t* p) {
-    typedef unsigned int u32x2_nt __attribute__((ext_vector_type(2)));
-    const u32x2_nt v = __builtin_nontemporal_load(reinterpret_cast<const u32x2_nt*>(p));
-    return make_uint2(v.x, v.y);
-  };
-  auto issue_k = [&](TileRegs& R, int base) {  // mask word + the four K rows of this lane's row group (tile row i = 4g + u takes chunk c ^ i)
-    const int row0 = base + g * U;
-    R.mword = 0x01010101u;
-    if (has_mask) {
-      if (row0 + 3 < S && ((reinterpret_cast<uintptr_t>(mh) + (size_t)row0) & 3) == 0) {
-        R.mword = *reinterpret_cast<const uint32_t*>(mh + row0);
-      } else {
-        R.mword = 0;
-#pragma unroll
-        for (int u = 0; u < U; u++)
-          if (row0 + u < S) R.mword |= (uint32_t)mh[row0 + u] << (8 * u);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      const int rr = row0 + u < row_end ? row0 + u : row_end - 1;
-      if constexpr (QB) {
-        R.kq8[u] = load_nt_u2(kqb + (size_t)rr * D + ((c ^ (4 * g + u)) & 15) * VEC);
-        R.kpar[u] = qpar[(size_t)rr * 2];
-      } else {
-        R.kk[u].load_nt(kb + (size_t)rr * D + ((c ^ (4 * g + u)) & 15) * VEC);
-      }
-    }
-  };
-  auto issue_v = [&](TileRegs& R, int base) {
-    const int row0 = base + g * U;
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      const int rr = row0 + u < row_end ? row0 + u : row_end - 1;
-      if constexpr (QB) {
-        R.vq8[u] = load_nt_u2(vqh + (size_t)rr * D);
-        R.vpar[u] = qpar[(size_t)rr * 2 + 1];
-      } else {
-        R.vv[u].load_nt(vh + (size_t)rr * D);
-      }
-    }
-  };
-  int base = row_begin + wave * (RPW * U);
-  bool more = base < row_end;
   // UNCONDITIONAL (rows past the split's end are clamped to its last row, a valid address): behind a branch, the compiler's
   // wait-count bookkeeping merges "tile loads issued" with "none issued" and every later use of an EARLIER load (the partial
   // keys, the incoming token's rows) becomes a wait for all loads — the tile included
 #pragma unroll
   for (int sub = 0; sub < NSUB; sub++) {
-    issue_k(tregs[sub], base + sub * NW * RPW * U);
+    if constexpr (!KEARLY) issue_k(tregs[sub], base + sub * NW * RPW * U);
     if constexpr (QB) __builtin_amdgcn_sched_barrier(0);  // K's bytes and parameters go out BEFORE V's: the K stash waits for them only
     issue_v(tregs[sub], base + sub * NW * RPW * U);
     if constexpr (QB) __builtin_amdgcn_sched_barrier(0);

@@ -40,7 +40,16 @@ def main():
         for kv in caches:
             kv.decode_step(q, k1, k1, pos)
         n_nodes = max(n_buf, int(os.environ.get("CC_AB_NODES", n_buf)))  # graph nodes per replay (cycling over the n_buf caches)
-        out[sh] = round(timed(lambda i: caches[i % n_buf].decode_step(q, k1, k1, pos), n_nodes, iters=15), 2)
+        def step(i):
+            caches[i % n_buf].decode_step(q, k1, k1, pos)
+            # positions ADVANCE, one per replay (a tiny add kernel per n_nodes steps): at a constant position the recoverable
+            # heavy-hitter step finds step_commit[h] == *input_pos from the second replay on and REPLAYS — attention only, no
+            # insert, no history / key stores — which is not the step (r3: every heavy-hitter A/B between the recoverable
+            # hand-off and this fix timed the replay path, ~0.4 us short of the real step)
+            if i == n_nodes - 1 and os.environ.get("CC_AB_CONST_POS") != "1":
+                pos.add_(1)
+
+        out[sh] = round(timed(step, n_nodes, iters=15), 2)
         del caches
         torch.cuda.empty_cache()
     from cold_compress_amd.attention_utils import single_launch_status
