@@ -381,8 +381,11 @@ class _RingFusedStep:
     draw) and consumed by the K/V streaming pass of step p + 1 (cc_decode_step_recent_global / cc_decode_step_random).
     Same contract as KVCacheHeavyHitter.decode_step."""
 
-    def _init_ring_pipeline(self, rows=1):
+    def _init_ring_pipeline(self, rows=None):
+        """next_key: one row of partial arg-min keys per kv head — also for the head-constant policies (identical rows): each head
+        reads and rewrites its own copy (include/coldcompress.h, cc_decode_step_recent_global)."""
         nk = int(_abi.lib()["cc_hh_next_key_slots"](self.max_cache_length))
+        rows = self.n_heads if rows is None else rows
         self.register_buffer("next_key", torch.full((rows, nk), -1, dtype=torch.int64), persistent=False)
         self._next_valid = False
 

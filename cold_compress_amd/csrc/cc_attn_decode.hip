@@ -182,7 +182,7 @@ struct SplitArgs {
   int32_t* cache_cts;  // [Hc]
   double* num;         // [H, S]
   int32_t* denom;      // [H, S]
-  int H, Hc, Hp;  // Hp == 1: head-constant policy (one pos row, one key row shared by every kv head)
+  int H, Hc, Hp;  // Hp == 1: head-constant policy (one pos row shared by every kv head; the key rows are per kv head all the same — see KEY ROWS)
   // ---- ring history folded into the combine pass (history_window_size W > 1): this launch publishes the ring column
   //      of the step, *ring_counter % W, so that the combine launch may bump the counter without a reader racing it
   const int64_t* ring_counter;
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_split_kernel(SplitArgs a)
   int ins_idx = -1, ins_was_empty = 0;
   bool key_pending = a.next_key != nullptr && !(a.abl & 128);
   unsigned long long key_part = ~0ull;
-  if (key_pending && lane < a.nk_read) key_part = a.next_key[(size_t)(a.Hp == 1 ? 0 : h) * a.nk + lane];
+  if (key_pending && lane < a.nk_read) key_part = a.next_key[(size_t)h * a.nk + lane];
   // q: [RT][D] of this query group, this lane's VEC-wide column slice (L2-resident after the first workgroups)
   Vec16<T> qraw[RT];
 #pragma unroll
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_split_kernel(SplitArgs a)
     // they cost nothing on the streaming path; their latency hides behind the K/V loads already in flight.
     if (key_pending) {  // wave-uniform; first iteration only
       for (int i = lane + 64; i < a.nk_read; i += 64) {  // caches beyond 64 chunks (S > 8192)
-        const unsigned long long x = a.next_key[(size_t)(a.Hp == 1 ? 0 : h) * a.nk + i];
+        const unsigned long long x = a.next_key[(size_t)h * a.nk + i];
         key_part = x < key_part ? x : key_part;
       }
       const unsigned long long key = wave_min_u64_uniform(key_part);
@@ -790,14 +790,21 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
   constexpr bool KEARLY = ONE1 && !HYB && QB == 0;
 #endif
   if (key_pending) {
-    const unsigned long long* krow = a.next_key + (size_t)(a.Hp == 1 ? 0 : h) * a.nk;
+    // KEY ROWS (late r3).  Every kv head reads — and at the end of the step rewrites — ITS OWN row, also under the head-constant
+    // policies, whose rows all hold the same keys.  They used to share row 0, rewritten by kv head 0's waves once THEIR head's
+    // workgroups had all published: nothing made a workgroup of another head read the row before that.  Found by the differential
+    // fuzz at 16 workgroups (recent_global, 8 kv heads, S = 101): on 3.6 % of the steps the workgroups of two kv heads — the two
+    // whose block ids fall on the same pair of XCDs, woken late on an otherwise idle chip — read the NEXT position's candidate
+    // and put their row into the wrong slot, silently.  A head's own row is safe by the argument that already covers the
+    // head-specific policies: its writers have gathered every workgroup of the head, i.e. every reader has published, i.e. read.
+    const unsigned long long* krow = a.next_key + (size_t)h * a.nk;
     if (lane < a.nk_read) key_part = krow[lane];
 #pragma unroll
     for (int j = 0; j < 3; j++)
       if (lane + 64 * (j + 1) < a.nk_read) key_more[j] = krow[lane + 64 * (j + 1)];
     // rows beyond 256 live entries (two-launch step at S > 32768) — kept OUT of the streaming loop so that the waits there stay exact
     for (int i = lane + 256; i < a.nk_read; i += 64) {
-      const unsigned long long x = a.next_key[(size_t)(a.Hp == 1 ? 0 : h) * a.nk + i];
+      const unsigned long long x = a.next_key[(size_t)h * a.nk + i];
       key_part = x < key_part ? x : key_part;
     }
   }
@@ -1844,7 +1851,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
           if (ps < a.g || ps >= p_next - a.w) scn = 1.0f;
           if (ps == -1) scn = 0.0f;
           key_ti = make_key(orderable_f32(scn), low);
-        } else if (h == 0) {  // head-constant policies: one key row, scored by the workgroups of kv head 0
+        } else {  // head-constant policies: every kv head scores the shared positions for its own copy of the key row (KEY ROWS)
           if (a.policy == 2) {  // ref: cache.py:500-502, 552-556 — arg-min of pos behind the sinks; -1 = empty first
             if (slot_ti >= a.g) key_ti = make_key(orderable_i32(ps), low);
           } else {  // random, ref: cache.py:523 recent window -> +inf, then the base rules :373-376
@@ -1938,8 +1945,8 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
     // store is issued: every store that can go out early shortens it)
     const unsigned long long wk = wave_min_u64_uniform(my_key);
     auto store_key = [&]() {
-      if (lane == 0 && (a.Hp != 1 || h == 0)) {
-        unsigned long long* nk_row = const_cast<unsigned long long*>(a.next_key) + (a.Hp == 1 ? 0 : (size_t)h * a.nk);
+      if (lane == 0) {
+        unsigned long long* nk_row = const_cast<unsigned long long*>(a.next_key) + (size_t)h * a.nk;
         const int e0 = split * NW + wave;
         nk_row[e0] = wk;  // every key of this row was consumed before its readers published: no reader is left
         for (int s2 = e0 + ns * NW; s2 < a.nk_read; s2 += ns * NW) nk_row[s2] = ~0ull;  // entries beyond nk_read are never read
@@ -2091,8 +2098,8 @@ __global__ __launch_bounds__(kCombThreads) void decode_attn_combine_kernel(Combi
   // a head's key row has kNextKeyPerChunk entries per block of this launch: this pass publishes the first, the others are kept
   // at ~0 — written HERE, at the start (their readers, the streaming pass, are done), so that these stores drain during the
   // launch instead of adding a store round trip behind its last instruction
-  if (a.next_key && !(a.abl & 8) && threadIdx.x >= 1 && threadIdx.x < kNextKeyPerChunk && (a.Hp != 1 || h == 0))
-    a.next_key[(size_t)(a.Hp == 1 ? 0 : h) * (kNextKeyPerChunk * nchunks) + threadIdx.x * nchunks + c] = ~0ull;
+  if (a.next_key && !(a.abl & 8) && threadIdx.x >= 1 && threadIdx.x < kNextKeyPerChunk)
+    a.next_key[(size_t)h * (kNextKeyPerChunk * nchunks) + threadIdx.x * nchunks + c] = ~0ull;
   // ---- issue this thread's per-slot loads first: their latency overlaps the (M, L) reduction below
   const T* sc = reinterpret_cast<const T*>(a.scores);
   const int s_mine = c * a.chunk + threadIdx.x;
@@ -2365,7 +2372,7 @@ __global__ __launch_bounds__(kCombThreads) void decode_attn_combine_kernel(Combi
         }
     }
   }
-  if (a.next_key && a.policy == 2 && have && h == 0 && s_mine >= a.g)  // arg-min of pos over the slots behind the sinks; -1 = empty first
+  if (a.next_key && a.policy == 2 && have && s_mine >= a.g)  // arg-min of pos over the slots behind the sinks; -1 = empty first (every kv head: its own key row)
     my_key = make_key(orderable_i32(ps_mine), ((uint32_t)s_mine << 1) | (uint32_t)(ps_mine == -1));
   if (a.next_key && a.policy == 4 && have) {  // ref: cache.py:597-605: dtype(max - norm), recent window -> +inf, base rules
     float gm = -INFINITY;
@@ -2382,7 +2389,7 @@ __global__ __launch_bounds__(kCombThreads) void decode_attn_combine_kernel(Combi
     if (ps_mine == -1) scn = -INFINITY;
     my_key = make_key(orderable_f32(scn), ((uint32_t)s_mine << 1) | (uint32_t)(ps_mine == -1));
   }
-  if (a.next_key && a.policy == 3 && have && h == 0) {  // ref: cache.py:523 recent window -> +inf, then the base rules :373-376
+  if (a.next_key && a.policy == 3 && have) {  // ref: cache.py:523 recent window -> +inf, then the base rules :373-376
     float scn = a.rand_next ? rnd_mine : cc_rng_uniform(a.rng_seed, p_next, s_mine);
     if (ps_mine >= p_next - a.w) scn = INFINITY;
     if (s_mine < a.g) scn = INFINITY;
@@ -2419,8 +2426,8 @@ __global__ __launch_bounds__(kCombThreads) void decode_attn_combine_kernel(Combi
     // (plain store: same-address atomics from 8 XCDs measured +4.5 us on this 5 us kernel)
     // (a head's key row has kNextKeyPerChunk * nchunks entries — one per wave of the single-launch step's 64-slot workgroups;
     //  all but the first nchunks stay ~0 here)
-    if (a.Hp != 1 || h == 0) {
-      unsigned long long* row = a.next_key + (size_t)(a.Hp == 1 ? 0 : h) * (kNextKeyPerChunk * nchunks);
+    {
+      unsigned long long* row = a.next_key + (size_t)h * (kNextKeyPerChunk * nchunks);
       row[c] = bk;
     }
   }

@@ -31,7 +31,7 @@ struct UpdArgs {
   const float* gmax_in;  // P_L2: the norm maximum from l2_norm_max_kernel, or null = recompute per workgroup (select-only calls)
   double* num;           // P_HH
   int32_t* denom;        // P_HH
-  unsigned long long* key_out;  // P_HH pipeline seed: [H][nk] partial arg-min keys (entry 0 = the key, rest = ~0); no side effects
+  unsigned long long* key_out;  // pipeline seed: [H][nk] partial arg-min keys, one row per kv head (entry 0 = the key, rest = ~0); no side effects
   int nk;
   unsigned long long rng_seed;  // P_RANDOM with scores == null: cc_rng_uniform(rng_seed, *input_pos, slot)
 };
@@ -207,7 +207,10 @@ __global__ __launch_bounds__(kUpdThreads) void decode_update_kernel(UpdArgs a) {
   const int idx = (int)((best & 0xffffffffull) >> 1);
   const int ins = (int)(best & 1ull);  // ref: cache.py:356-360 num_insertions = (old pos == -1)
   if (a.key_out != nullptr) {  // seed of the fused decode-step pipeline: publish the key, touch nothing else
-    for (int i = threadIdx.x; i < a.nk; i += blockDim.x) a.key_out[(size_t)hp * a.nk + i] = (i == 0) ? best : ~0ull;
+    // (head-constant policies — one workgroup — fill every kv head's copy of the row: each head reads and rewrites its own,
+    //  cc_attn_decode.hip KEY ROWS)
+    for (int hh = h0; hh < h0 + nh; hh++)
+      for (int i = threadIdx.x; i < a.nk; i += blockDim.x) a.key_out[(size_t)hh * a.nk + i] = (i == 0) ? best : ~0ull;
     return;
   }
   if (threadIdx.x == 0) a.idx_out[hp] = idx;

@@ -196,7 +196,10 @@ int cc_decode_step_heavy_hitter(const cc_kv_view* c, const void* q, const void* 
                                 cc_stream_t stream);
 /* The same two-launch step for the head-constant ring policies: KVCacheRecentGlobal (cache.py:527-556: arg-min of
  * pos over the slots behind the first `global_tokens` sinks; empty slots, pos == -1, first) and KVCacheFull
- * (cache.py:493-502: global_tokens = 0).  c->Hp must be 1; next_key: uint64 [1, NK].  No history, no group-mean output. */
+ * (cache.py:493-502: global_tokens = 0).  c->Hp must be 1; next_key: uint64 [H, NK] — one row per kv head, all holding the same
+ * keys: every head reads and rewrites its own copy, so that no workgroup of one head can read a row another head's workgroups
+ * have already rewritten for the next position (the single-launch form has no launch boundary between the two).  No history,
+ * no group-mean output. */
 int cc_rg_next_key_init(const cc_kv_view* c, const int32_t* input_pos, int32_t global_tokens, uint64_t* next_key,
                         cc_stream_t stream);
 int cc_decode_step_recent_global(const cc_kv_view* c, const void* q, const void* k_new, const void* v_new,
@@ -205,7 +208,7 @@ int cc_decode_step_recent_global(const cc_kv_view* c, const void* q, const void*
 /* The same two-launch step for KVCacheRandom (cache.py:505-524: uniform scores, the `recent_window` newest positions
  * -> +inf, then the base rules cache.py:373-376).  `rand_u` / `rand_next`: float32 [S] uniform draws — the init call takes
  * the draw for position *input_pos, every step the draw for position *input_pos + 1 (the reference draws one vector
- * per step, cache.py:521; the order of draws is unchanged).  c->Hp must be 1; next_key: uint64 [1, NK]. */
+ * per step, cache.py:521; the order of draws is unchanged).  c->Hp must be 1; next_key: uint64 [H, NK] (as cc_decode_step_recent_global). */
 int cc_random_next_key_init(const cc_kv_view* c, const int32_t* input_pos, const float* rand_u, int32_t global_tokens,
                             int32_t recent_window, uint64_t* next_key, cc_stream_t stream);
 int cc_decode_step_random(const cc_kv_view* c, const void* q, const void* k_new, const void* v_new,

@@ -1429,7 +1429,9 @@ int cc_decode_step_l2_cpu(const cc_kv_view* c, const void* q, const void* k_new,
 }
 
 /* KVCacheRandom in the same pipeline (ref: cache.py:505-524 + :373-376): the key of the slot the reference's arg-min picks
- * for position p, from the uniform draw for that position. */
+ * for position p, from the uniform draw for that position.  (The device keeps one identical key row PER KV HEAD for the
+ * head-constant policies — each head's workgroups read and rewrite their own copy, include/coldcompress.h; the oracle has no
+ * workgroups to keep apart and uses row 0 of whatever array it is handed.) */
 static uint64_t random_key(const cc_kv_view* c, const float* rand_u, int32_t p, int32_t g, int32_t w) {
   uint64_t best = ~(uint64_t)0;
   for (int s = 0; s < c->S; s++) {

@@ -53,6 +53,9 @@ def _log_evictions(model):
                 if not _kv._next_valid:
                     _kv.prepare_decode(input_pos)
                 keys = _kv.next_key.cpu().numpy().view("uint64").min(axis=1)  # partial minima per chunk -> arg-min key
+                if _kv.pos.shape[1] == 1:  # head-constant policy: every kv head keeps its own copy of the (identical) key row
+                    assert (keys == keys[0]).all(), "the kv heads' copies of a head-constant key row differ"
+                    keys = keys[:1]
                 log[_i].append(torch.from_numpy(((keys & 0xffffffff) >> 1).astype("int64")).to(DEV))
                 return _orig(query, k_val, v_val, input_pos, scale)
 

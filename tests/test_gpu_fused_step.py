@@ -329,6 +329,41 @@ def test_ring_fused_step_equals_three_calls(strategy, dtype, H, HQ, S, D, T, sin
                 assert torch.equal(ta, tb), f"step {t}: {na}"
 
 
+def test_head_constant_key_rows_on_a_small_grid():
+    """Regression (late r3, found by tools/fuzz_step.py): the single-launch step of a head-constant policy on a 16-workgroup grid
+    (8 kv heads x 2 splits), where whole XCDs wake up late.  With ONE key row shared by all heads and rewritten by kv head 0's
+    waves, 3.6 % of such steps put two heads' rows into the NEXT position's slot (their workgroups read the row after it had been
+    rewritten).  Every kv head keeps its own copy now; 250 fresh caches x 6 steps, K / V compared exactly."""
+    import cold_compress_amd.cache as cache
+    from cold_compress_amd.attention_utils import scaled_dot_product_attention as sdpa
+
+    dtype, H, R, S, D, g = torch.float16, 8, 2, 101, 128, 1
+    cls, rk = cache.get_cache_constructor("recent_global")
+    kw = dict(max_cache_length=S, global_tokens=g, max_seq_length=4 * S + 64, cache_bits=None)
+    for it in range(250):
+        with torch.device(DEV):
+            a, b = cls(1, H, D, dtype, **{k: kw[k] for k in rk}), cls(1, H, D, dtype, **{k: kw[k] for k in rk})
+        assert tuple(b.next_key.shape)[0] == H
+        gen = torch.Generator().manual_seed(4000 + it)
+        k0 = torch.randn(1, H, S, D, generator=gen).to(dtype).to(DEV)
+        v0 = torch.randn(1, H, S, D, generator=gen).to(dtype).to(DEV)
+        for kv in (a, b):
+            kv.update_kv(torch.arange(S, device=DEV), k0, v0, True)
+        for t in range(6):
+            p = torch.tensor([S + t], dtype=torch.int32, device=DEV)
+            k1 = torch.randn(1, H, 1, D, generator=gen).to(dtype).to(DEV)
+            v1 = torch.randn(1, H, 1, D, generator=gen).to(dtype).to(DEV)
+            q = torch.randn(1, H * R, 1, D, generator=gen).to(dtype).to(DEV)
+            ka, va, ma = a.update_kv(p, k1, v1, False)
+            sdpa(q, ka, va, attn_mask=ma)
+            b.decode_step(q, k1, v1, p)
+        torch.cuda.synchronize()
+        assert torch.equal(a.pos, b.pos), f"cache {it}: positions"
+        assert torch.equal(a.k_cache, b.k_cache) and torch.equal(a.v_cache, b.v_cache), f"cache {it}: a kv head's row went to another slot"
+        rows = b.next_key.cpu().numpy().view(np.uint64).min(axis=1)
+        assert (rows == rows[0]).all(), f"cache {it}: the kv heads' key rows differ"
+
+
 @pytest.mark.parametrize("single", [False, True])
 @pytest.mark.parametrize("dtype,H,HQ,S,D,T,g,w", [(torch.bfloat16, 8, 32, 4096, 128, 4090, 4, 10), (torch.float32, 2, 4, 77, 16, 70, 2, 3),
                                                   (torch.float16, 4, 16, 600, 128, 600, 0, 1)])
