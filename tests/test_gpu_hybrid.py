@@ -201,7 +201,7 @@ def test_hybrid_fused_step_vs_oracle_pipeline(oracle, H, HQ, S, strat_list, cts_
         assert np.array_equal(kv.pos.cpu()[0].numpy(), st["pos"]), f"step {t}: pos"
         assert np.array_equal(kv.cache_cts.cpu().numpy(), st["cts"]), f"step {t}: counts"
         yr = torch.from_numpy(yo.view(np.int16).copy()).view(torch.bfloat16).float()
-        assert (y.cpu().float()[0, :, 0] - yr).abs().max() < 1e-2, f"step {t}: y"
+        assert (y.cpu().float()[0, :, 0] - yr).abs().max() <= 1e-3 + 2 * 2.0 ** -8 * yr.abs().max(), f"step {t}: y"  # the attention contract
     assert np.array_equal(kv.attn_history_denom.cpu()[0].numpy(), st["denom"])
     assert np.array_equal(kv.punc_mask.cpu()[0].numpy().astype(np.uint8), st["punc"]) and int(kv.num_punc) == int(st["npc"][0])
     assert np.array_equal(kv.mask.cpu()[0, :, 0].numpy().astype(np.uint8), st["mask"])
