@@ -88,7 +88,8 @@ def test_probabilities_masked_zero_rows_sum_to_one_and_permutation_invariance():
     perm = torch.stack([torch.randperm(S, generator=g) for _ in range(H)]).to(DEV)
     idx = perm.view(1, H, S, 1).expand(1, H, S, D)
     y2, a2 = sdpa(q, k.gather(2, idx), v.gather(2, idx), attn_mask=m.gather(3, perm.view(1, H, 1, S)), return_attn=True, group_mean=True)
-    assert (y.float() - y2.float()).abs().max() < 2e-2, "attention must not depend on the slot order"
+    tol = 1e-3 + 2 * 2.0 ** -8 * float(y.float().abs().max())  # the attention contract: 1e-3 + two roundings of the output dtype
+    assert (y.float() - y2.float()).abs().max() <= tol, "attention must not depend on the slot order"
     assert (a.gather(3, perm.view(1, H, 1, S)).float() - a2.float()).abs().max() < 1e-5 + 2 ** -9 * float(a.max())
     # the same cache embedded in a longer buffer whose tail is masked out
     pad = 2 * S
@@ -97,7 +98,7 @@ def test_probabilities_masked_zero_rows_sum_to_one_and_permutation_invariance():
     mp = torch.cat([m, torch.zeros(1, H, 1, S, dtype=torch.bool, device=DEV)], 3)
     y3, a3 = sdpa(q, kp, vp, attn_mask=mp, return_attn=True, group_mean=True)
     assert a3.shape[-1] == pad and bool((a3[..., S:] == 0).all())
-    assert (y.float() - y3.float()).abs().max() < 2e-2
+    assert (y.float() - y3.float()).abs().max() <= tol
 
 
 def test_prompt_compaction_properties():
