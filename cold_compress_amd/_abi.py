@@ -96,6 +96,8 @@ SIGNATURES = {
     "cc_random_next_key_init": (C.c_int, [_view, _vp, _vp, _i32, _i32, _vp, _vp]),
     "cc_decode_step_random": (C.c_int, [_view, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _sz, _vp]),
     "cc_random_next_key_init_rng": (C.c_int, [_view, _vp, C.c_uint64, _i32, _i32, _vp, _vp]),
+    "cc_decode_step_head_constant_rc": (C.c_int, [_view, _i32, _vp, _vp, _vp, _vp, _vp, C.c_uint64, _vp, _vp, _i32, _i32, _i32, _f32,
+                                                  _vp, _vp, _sz, _vp]),
     "cc_decode_step_random_rng": (C.c_int, [_view, _vp, _vp, _vp, _vp, C.c_uint64, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _sz, _vp]),
     "cc_hh_next_key_init": (C.c_int, [_view, _vp, _vp, _vp, _i32, _i32, _vp, _vp]),
     "cc_decode_step_heavy_hitter": (C.c_int, [_view, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp,

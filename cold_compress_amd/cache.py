@@ -388,6 +388,15 @@ class _RingFusedStep:
         rows = self.n_heads if rows is None else rows
         self.register_buffer("next_key", torch.full((rows, nk), -1, dtype=torch.int64), persistent=False)
         self._next_valid = False
+        # recoverable hand-off (include/coldcompress.h, cc_decode_step_head_constant_rc): the last position whose step is fully
+        # committed, per kv head; -1 = none.  Used by the head-constant policies; l2 carries it unused.
+        self.register_buffer("step_commit", torch.full((self.n_heads,), -1, dtype=torch.int32), persistent=False)
+
+    def recoverable(self):
+        """True: a timed-out single-launch step of this cache can be retried in band (harness._recover_token): its step
+        carries commit words and a retry scores the same keys.  recent_global / full / random with in-kernel draws; not l2
+        (its norm maximum crosses kv heads), not the fused uint8 mode."""
+        return False
 
     def supports_fused_step(self):
         return True
@@ -395,9 +404,12 @@ class _RingFusedStep:
     def reset(self):
         super().reset()
         self._next_valid = False
+        self.step_commit.fill_(-1)
 
     def update_kv(self, input_pos, k_val, v_val, is_prefill, **kwargs):
         self._next_valid = False  # the three-call path mutates pos outside the pipeline
+        if is_prefill:
+            self.step_commit.fill_(-1)  # positions restart: no decode position is committed
         return super().update_kv(input_pos, k_val, v_val, is_prefill, **kwargs)
 
     def _ring_sinks(self):
@@ -410,8 +422,9 @@ class _RingFusedStep:
     def _pipeline_step(self, q, k, v, p32, HQ, scale, y, ws):
         if self.fused_quant:
             return self._quant_step(q, k, v, p32, HQ, scale, y, ws, g=self._ring_sinks())
-        _abi.call("cc_decode_step_recent_global", self._view(), _ptr(q), _ptr(k), _ptr(v), _ptr(p32), _ptr(self.next_key),
-                  self._ring_sinks(), HQ, scale, _ptr(y), _ptr(ws), ws.numel(), _stream())
+        _abi.call("cc_decode_step_head_constant_rc", self._view(), 2, _ptr(q), _ptr(k), _ptr(v), _ptr(p32), None, 0,
+                  _ptr(self.next_key), _ptr(self.step_commit), self._ring_sinks(), 0, HQ, scale, _ptr(y), _ptr(ws), ws.numel(),
+                  _stream())
 
     def prepare_decode(self, input_pos):
         self._pipeline_init(self._pos32(input_pos))
@@ -438,6 +451,9 @@ class _RingFusedStep:
 
 class KVCacheFull(_RingFusedStep, KVCacheHeadConstant):
     """ref: cache.py:493-502."""
+
+    def recoverable(self):
+        return not self.fused_quant
 
     def __init__(self, max_batch_size, n_heads, head_dim, dtype=torch.bfloat16, **kwargs):
         self.global_tokens = 0
@@ -474,6 +490,9 @@ class KVCacheRandom(_RingFusedStep, KVCacheHeadConstant):
     def _in_kernel_rng(self):
         return "_rand" not in self.__dict__ and type(self)._rand is KVCacheRandom._rand and not self.fused_quant
 
+    def recoverable(self):
+        return self._in_kernel_rng()  # (an injected vector would be drawn again by the retry)
+
     def _pipeline_init(self, p32):
         if self._in_kernel_rng():
             self._rng_seed = int(torch.randint(0, 2 ** 62, (1,)).item())  # CPU generator: follows torch.manual_seed, no device sync
@@ -488,10 +507,10 @@ class KVCacheRandom(_RingFusedStep, KVCacheHeadConstant):
         return 3
 
     def _pipeline_step(self, q, k, v, p32, HQ, scale, y, ws):
-        if self._in_kernel_rng():
-            _abi.call("cc_decode_step_random_rng", self._view(), _ptr(q), _ptr(k), _ptr(v), _ptr(p32), self._rng_seed,
-                      _ptr(self.next_key), int(self.global_tokens), int(self.recent_window), HQ, scale, _ptr(y), _ptr(ws),
-                      ws.numel(), _stream())
+        if self._in_kernel_rng():  # (the recoverable form: a retried step scores the same draws)
+            _abi.call("cc_decode_step_head_constant_rc", self._view(), 3, _ptr(q), _ptr(k), _ptr(v), _ptr(p32), None,
+                      self._rng_seed, _ptr(self.next_key), _ptr(self.step_commit), int(self.global_tokens),
+                      int(self.recent_window), HQ, scale, _ptr(y), _ptr(ws), ws.numel(), _stream())
             return
         r = self._rand().to(torch.float32).contiguous()
         if self.fused_quant:
@@ -512,6 +531,9 @@ class KVCacheRecentGlobal(_RingFusedStep, KVCacheHeadConstant):
     def __init__(self, max_batch_size, n_heads, head_dim, dtype=torch.bfloat16, **kwargs):
         super().__init__(max_batch_size, n_heads, head_dim, dtype, **kwargs)
         self._init_ring_pipeline()
+
+    def recoverable(self):
+        return not self.fused_quant
 
     def _fused_quant_policy(self):
         return 2
@@ -640,6 +662,10 @@ class KVCacheHeavyHitter(_TrackedWindowSums, KVCacheHeadSpecific):
 
     def supports_fused_step(self):
         return True
+
+    def recoverable(self):
+        """A timed-out single-launch step can be retried in band (cc_decode_step_heavy_hitter_rc): W = 1, 16-bit cache."""
+        return self.history_window_size == 1 and not self.fused_quant
 
     def _fused_quant_policy(self):
         return 1 if int(getattr(self, "history_window_size", 1)) == 1 else 0

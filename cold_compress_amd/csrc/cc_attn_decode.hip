@@ -3086,6 +3086,24 @@ int cc_decode_step_random_rng(const cc_kv_view* c, const void* q, const void* k_
                    nullptr, workspace, workspace_bytes, stream, 3, &fs);
 }
 
+int cc_decode_step_head_constant_rc(const cc_kv_view* c, int32_t policy, const void* q, const void* k_new, const void* v_new,
+                                    const int32_t* input_pos, const float* rand_next, uint64_t seed, uint64_t* next_key,
+                                    int32_t* step_commit, int32_t global_tokens, int32_t recent_window, int32_t HQ, float scale,
+                                    void* y, void* workspace, size_t workspace_bytes, cc_stream_t stream) {
+  if (!cc_view_ok(c) || !q || !k_new || !v_new || !input_pos || !next_key || !y || c->Hp != 1 || HQ <= 0 || HQ % c->H ||
+      global_tokens < 0 || (policy != 2 && policy != 3) || (policy == 2 && (global_tokens >= c->S || rand_next)))
+    return CC_ERR_BAD_ARG;
+  FusedStep fs{c, k_new, v_new, input_pos, reinterpret_cast<unsigned long long*>(next_key), global_tokens,
+               policy == 3 ? recent_window : 0, policy, policy == 3 ? rand_next : nullptr, nullptr};
+  if (policy == 3 && !rand_next) {
+    fs.rng_seed = seed;
+    fs.rng_on = 1;
+  }
+  fs.commit = step_commit;
+  return attn_impl(q, c->k_cache, c->v_cache, c->mask, HQ, c->H, c->S, c->D, c->dtype, scale, y, nullptr, nullptr, nullptr, nullptr,
+                   nullptr, workspace, workspace_bytes, stream, 3, &fs);
+}
+
 int cc_decode_step_quant(const cc_kv_view* c, float* qparams, int32_t n_bit, int32_t policy, const void* q, const void* k_new,
                          const void* v_new, const int32_t* input_pos, double* num, int32_t* denom, int64_t* counter,
                          const float* rand_next, uint64_t* next_key, int32_t global_tokens, int32_t recent_window, int32_t HQ,

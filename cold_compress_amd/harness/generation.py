@@ -180,16 +180,15 @@ def _recover_token(model, cur_token, input_pos, decode_fn, nt, npb, forced, attn
     co-tenant kernel on the device).  One 4-byte read of the decode workspace's status word per token; when it is set the failed
     step committed nothing of its kv head, every later launch of the token returned at once (include/coldcompress.h,
     cc_decode_step_heavy_hitter_rc) — so the word is cleared, the epoch words are advanced, and the SAME token runs again: heads
-    whose step is committed replay it (attention only), the others step.  Policies without commit words (everything but heavy
-    hitter W = 1) and a failure that persists raise, as before."""
+    whose step is committed replay it (attention only), the others step.  Caches whose step carries no commit words (`recoverable()`
+    False: l2, hybrid, history windows, the fused uint8 mode, random with an injected vector) and a failure that persists raise."""
     from ..attention_utils import check_single_launch_status, reset_single_launch_status, single_launch_status
-    from ..cache import KVCacheHeavyHitter
 
     dev = cur_token.device
     tries = 0
     while single_launch_status(dev):
         caches = [l.attention.kv_cache for l in model.layers]
-        ok = all(type(c) is KVCacheHeavyHitter and c.history_window_size == 1 and not c.fused_quant for c in caches)
+        ok = all(callable(getattr(c, "recoverable", None)) and c.recoverable() for c in caches)
         if not ok or tries >= max_retries:
             check_single_launch_status(dev)  # raises (and clears the word)
         reset_single_launch_status(dev)

@@ -226,6 +226,17 @@ int cc_random_next_key_init_rng(const cc_kv_view* c, const int32_t* input_pos, u
 int cc_decode_step_random_rng(const cc_kv_view* c, const void* q, const void* k_new, const void* v_new, const int32_t* input_pos,
                               uint64_t seed, uint64_t* next_key, int32_t global_tokens, int32_t recent_window, int32_t HQ,
                               float scale, void* y, void* workspace, size_t workspace_bytes, cc_stream_t stream);
+/* The head-constant steps with the RECOVERABLE hand-off (late r3; semantics as cc_decode_step_heavy_hitter_rc below: commit words,
+ * replay of committed heads, no-op behind a set status word).  policy: 2 = recent_global / full (rand_next must be NULL), 3 = random
+ * (rand_next: the uniform vector for position *input_pos + 1, or NULL: the draws are made in the kernels from `seed`, as
+ * cc_decode_step_random_rng — the only form a retry may use: a retried step must score the same draw).  step_commit: int32 [H],
+ * -1 = nothing committed; may be NULL (no replay).  The rows of next_key [H, NK] stay identical across kv heads through a
+ * recovered fault: every head scores the shared positions and the same draws.  The position row (shared) is written by kv head
+ * 0's inserting workgroup ahead of the hand-off — idempotent on a retry; the count by kv head 0 at its commit. */
+int cc_decode_step_head_constant_rc(const cc_kv_view* c, int32_t policy, const void* q, const void* k_new, const void* v_new,
+                                    const int32_t* input_pos, const float* rand_next, uint64_t seed, uint64_t* next_key,
+                                    int32_t* step_commit, int32_t global_tokens, int32_t recent_window, int32_t HQ, float scale,
+                                    void* y, void* workspace, size_t workspace_bytes, cc_stream_t stream);
 /* The same two-launch step for KVCacheL2 (cache.py:559-612: score = dtype(max over ALL heads' and slots' key norms -
  * norm), recent window -> +inf, base rules; the inserted key's norm recorded, cache.py:592-593).  The global maximum
  * is folded across the step boundary: the streaming pass publishes per-wave maxima of the surviving norms, the

@@ -1873,3 +1873,27 @@ int cc_decode_step_recent_global_cpu(const cc_kv_view* c, const void* q, const v
   next_key[0] = rg_key(c, g);
   return CC_OK;
 }
+
+/* Twin of the recoverable head-constant steps: the oracle has nothing to time out — it runs the step once and records the
+ * commit; asked to REPLAY a committed position it declines (the replay is a property of the device's launch, tested there). */
+int cc_decode_step_head_constant_rc_cpu(const cc_kv_view* c, int32_t policy, const void* q, const void* k_new, const void* v_new,
+                                        const int32_t* input_pos, const float* rand_next, uint64_t seed, uint64_t* next_key,
+                                        int32_t* step_commit, int32_t g, int32_t w, int32_t HQ, float scale, void* y,
+                                        void* workspace, size_t workspace_bytes, cc_stream_t stream) {
+  if (!view_ok(c) || !input_pos || (policy != 2 && policy != 3) || (policy == 2 && rand_next)) return CC_ERR_BAD_ARG;
+  if (step_commit)
+    for (int h = 0; h < c->H; h++)
+      if (step_commit[h] == *input_pos) return CC_ERR_UNSUPPORTED;
+  int rc;
+  if (policy == 2)
+    rc = cc_decode_step_recent_global_cpu(c, q, k_new, v_new, input_pos, next_key, g, HQ, scale, y, workspace, workspace_bytes, stream);
+  else if (rand_next)
+    rc = cc_decode_step_random_cpu(c, q, k_new, v_new, input_pos, rand_next, next_key, g, w, HQ, scale, y, workspace, workspace_bytes,
+                                   stream);
+  else
+    rc = cc_decode_step_random_rng_cpu(c, q, k_new, v_new, input_pos, seed, next_key, g, w, HQ, scale, y, workspace, workspace_bytes,
+                                       stream);
+  if (rc == CC_OK && step_commit)
+    for (int h = 0; h < c->H; h++) step_commit[h] = *input_pos;
+  return rc;
+}

@@ -1,5 +1,6 @@
-"""The recoverable hand-off of the single-launch heavy-hitter step (include/coldcompress.h, cc_decode_step_heavy_hitter_rc;
-VERDICT r2 "next" item 5): replay of a committed step, the no-op behind a set status word, and a REAL fault — a co-tenant
+"""The recoverable hand-off of the single-launch step (include/coldcompress.h, cc_decode_step_heavy_hitter_rc and, for recent_global /
+full / random, cc_decode_step_head_constant_rc; VERDICT r2 "next" item 5): replay of a committed step, the no-op behind a set status
+word, and a REAL fault — a co-tenant
 kernel (cc_debug_occupy) that keeps part of the step's workgroups from becoming resident until the resident ones give up —
 recovered in band by harness.decode_n_tokens: the tokens and every cache buffer equal a fault-free run's."""
 import ctypes as C
@@ -12,10 +13,10 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-def _mk(H, S, D=128, g=4, w=10):
+def _mk(H, S, D=128, g=4, w=10, strategy="heavy_hitter"):
     import cold_compress_amd.cache as cache
 
-    cls, rk = cache.get_cache_constructor("heavy_hitter")
+    cls, rk = cache.get_cache_constructor(strategy)
     kw = dict(max_cache_length=S, global_tokens=g, max_seq_length=4 * S, cache_bits=None, recent_window=w, history_window_size=1,
               attn_thresholding=False)
     with torch.device(DEV):
@@ -24,8 +25,9 @@ def _mk(H, S, D=128, g=4, w=10):
     T = S - 2
     kv.update_kv(torch.arange(T, device=DEV), torch.randn(1, H, T, D, device=DEV, generator=gen).to(torch.bfloat16),
                  torch.randn(1, H, T, D, device=DEV, generator=gen).to(torch.bfloat16), True)
-    kv.attn_history_num[0, :, :T, 0] = torch.rand(H, T, device=DEV, generator=gen, dtype=torch.float64)
-    kv.attn_history_denom[0, :, :T] = torch.randint(1, 5, (H, T), device=DEV, generator=gen, dtype=torch.int32)
+    if strategy == "heavy_hitter":
+        kv.attn_history_num[0, :, :T, 0] = torch.rand(H, T, device=DEV, generator=gen, dtype=torch.float64)
+        kv.attn_history_denom[0, :, :T] = torch.randint(1, 5, (H, T), device=DEV, generator=gen, dtype=torch.int32)
     return kv, T
 
 
@@ -33,10 +35,15 @@ def _state(kv):
     return {n: b.clone() for n, b in kv.named_buffers()}
 
 
+@pytest.mark.parametrize("strategy", ["heavy_hitter", "recent_global", "full", "random"])
 @pytest.mark.parametrize("H,HQ,S", [(8, 32, 4096), (2, 8, 512)])
-def test_replay_of_a_committed_step_changes_nothing(H, HQ, S):
-    kv, T = _mk(H, S)
-    assert kv.single_launch_active(HQ)
+def test_replay_of_a_committed_step_changes_nothing(H, HQ, S, strategy):
+    from cold_compress_amd import _abi
+
+    torch.manual_seed(21)  # (random: the seed of the in-kernel draws comes from torch's CPU generator)
+    kv, T = _mk(H, S, strategy=strategy)
+    assert kv.recoverable()
+    assert _abi.lib()["cc_decode_step_single_launch"](HQ, H, S, 128, 1) == 1
     gen = torch.Generator(device=DEV).manual_seed(6)
     D = 128
     for t in range(4):  # the third step evicts (the cache is full by then)
@@ -47,13 +54,67 @@ def test_replay_of_a_committed_step_changes_nothing(H, HQ, S):
         y1 = kv.decode_step(q, k1, v1, p).clone()
         torch.cuda.synchronize()
         assert bool((kv.step_commit == T + t).all())
+        if kv.pos.shape[1] == 1:  # head-constant policy: the kv heads' copies of the key row agree
+            rows = kv.next_key.cpu().numpy().view("uint64").min(axis=1)
+            assert (rows == rows[0]).all()
         st = _state(kv)
         y2 = kv.decode_step(q, k1, v1, p)  # the same position again: every head is committed -> attention only
         torch.cuda.synchronize()
         assert torch.equal(y1, y2), f"step {t}: replayed y"
         for n, b in kv.named_buffers():
             assert torch.equal(b, st[n]), f"step {t}: replay changed {n}"
-    assert kv.step_status(HQ) == 0
+    from cold_compress_amd.attention_utils import single_launch_status
+
+    assert single_launch_status(kv.pos.device) == 0
+
+
+@pytest.mark.parametrize("committed", [(0, 2, 5), (1, 3), (7,)])
+@pytest.mark.parametrize("strategy", ["heavy_hitter", "recent_global", "random"])
+def test_half_committed_step_completes_to_the_same_state(strategy, committed):
+    """What a retry finds after a fault, built deterministically: the kv heads in `committed` hold the state a completed step
+    left (rows inserted, history / key row rewritten, step_commit[h] = p), the others the state before the step; what only kv head
+    0 commits for everybody (the shared position row and count of the head-constant policies, the step counter) follows head 0.
+    Running the step at p must REPLAY the committed heads and STEP the others: every buffer and y equal the fault-free step's."""
+    H, HQ, S, D = 8, 32, 4096, 128
+    torch.manual_seed(31)
+    kv, T = _mk(H, S, strategy=strategy)
+    gen = torch.Generator(device=DEV).manual_seed(8)
+    for t in range(3):  # fill the cache: the step under test evicts
+        p = torch.tensor([T + t], dtype=torch.int32, device=DEV)
+        q = torch.randn(1, HQ, 1, D, device=DEV, generator=gen).to(torch.bfloat16)
+        k1 = torch.randn(1, H, 1, D, device=DEV, generator=gen).to(torch.bfloat16)
+        v1 = torch.randn(1, H, 1, D, device=DEV, generator=gen).to(torch.bfloat16)
+        kv.decode_step(q, k1, v1, p)
+    torch.cuda.synchronize()
+    before = _state(kv)
+    p = torch.tensor([T + 3], dtype=torch.int32, device=DEV)
+    q = torch.randn(1, HQ, 1, D, device=DEV, generator=gen).to(torch.bfloat16)
+    k1 = torch.randn(1, H, 1, D, device=DEV, generator=gen).to(torch.bfloat16)
+    v1 = torch.randn(1, H, 1, D, device=DEV, generator=gen).to(torch.bfloat16)
+    y_clean = kv.decode_step(q, k1, v1, p).clone()
+    torch.cuda.synchronize()
+    after = _state(kv)
+    assert bool((after["step_commit"] == T + 3).all()) and not torch.equal(before["k_cache"], after["k_cache"])
+    head0 = 0 in committed
+    sel = torch.zeros(H, dtype=torch.bool, device=DEV)
+    sel[list(committed)] = True
+    for n, b in kv.named_buffers():
+        bi, af = before[n], after[n]
+        if n in ("k_cache", "v_cache", "mask", "attn_history_num", "attn_history_denom", "pos", "cache_cts", "next_key", "step_commit") \
+                and H in bi.shape[:2]:  # one row per kv head (dim 0, or dim 1 behind the batch dim)
+            d = 0 if bi.shape[0] == H else 1
+            m = sel.view([H if i == d else 1 for i in range(bi.dim())])
+            b.copy_(torch.where(m, af, bi))
+        else:  # shared by the kv heads: committed by kv head 0
+            b.copy_(af if head0 else bi)
+    y2 = kv.decode_step(q, k1, v1, p)
+    torch.cuda.synchronize()
+    assert torch.equal(y2, y_clean), "y of the completed step"
+    for n, b in kv.named_buffers():
+        assert torch.equal(b, after[n]), f"{n} differs from the fault-free step's"
+    from cold_compress_amd.attention_utils import single_launch_status
+
+    assert single_launch_status(kv.pos.device) == 0
 
 
 def test_launches_behind_a_set_status_word_do_nothing():
@@ -87,8 +148,10 @@ def test_launches_behind_a_set_status_word_do_nothing():
     assert bool((kv.step_commit == T + 1).all()) and kv.step_status(HQ) == 0
 
 
-def test_co_tenant_fault_is_recovered_in_band():
-    """Two layers of the Llama-3-8B shape, heavy hitter at 1024 slots: 128 workgroups per step (16 per kv head, dispatched head by
+@pytest.mark.parametrize("strategy", ["heavy_hitter", "recent_global"])
+def test_co_tenant_fault_is_recovered_in_band(strategy):
+    """Two layers of the Llama-3-8B shape, heavy hitter (or recent_global: the head-constant form of the recoverable step — its kv
+    heads complete one after the other here, each on its own copy of the key row) at 1024 slots: 128 workgroups per step (16 per kv head, dispatched head by
     head).  Before the fourth decode token a co-tenant kernel pins 150 KB of LDS on 232 of the 256 CUs for 2.2 s — longer than the
     hand-off's bounded wait (~1.6 s): some kv head's workgroups do not all fit beside it, the resident ones give up, every later
     launch of the token returns at once.  decode_n_tokens notices (one status read per token), clears, retries (the co-tenant
@@ -109,8 +172,8 @@ def test_co_tenant_fault_is_recovered_in_band():
     with torch.no_grad():
         for n, p in model.named_parameters():
             p.fill_(1.0) if "norm" in n else p.normal_(0.0, 0.02, generator=g)
-    kw = dict(max_cache_length=[1024.0], cache_bits=None, cache_length_pattern="tile", cache_strategy=["heavy_hitter"],
-              cache_strategy_pattern="tile", feed_long_prompts=False, prompt_compression_strategy=["heavy_hitter"], global_tokens=4,
+    kw = dict(max_cache_length=[1024.0], cache_bits=None, cache_length_pattern="tile", cache_strategy=[strategy],
+              cache_strategy_pattern="tile", feed_long_prompts=False, prompt_compression_strategy=[strategy], global_tokens=4,
               recent_window=10, history_window_size=1, attn_thresholding=False, min_recovery_frac=0.9)
     L, n_new = 1200, 8
     prompt = torch.randint(0, cfg["vocab_size"], (L,), generator=torch.Generator().manual_seed(3), dtype=torch.int32).to(DEV)
@@ -140,7 +203,7 @@ def test_co_tenant_fault_is_recovered_in_band():
             toks, _ = decode_n_tokens(model, tok.view(1, 1).to(torch.int32), pos, step, n_new)
         torch.cuda.synchronize()
         caches = [l.attention.kv_cache for l in model.layers]
-        assert all(c.single_launch_active(cfg["n_head"]) for c in caches)
+        assert all(c.recoverable() for c in caches)
         return [int(t) for t in toks], [{n: b.clone() for n, b in c.named_buffers()} for c in caches]
 
     au.reset_single_launch_status = counting_reset
@@ -150,6 +213,10 @@ def test_co_tenant_fault_is_recovered_in_band():
         fault_t, fault_s = run(fault_at=3)
     finally:
         au.reset_single_launch_status = orig_reset
+    if not resets and strategy != "heavy_hitter":
+        # (whether the pinned CUs split a kv head's workgroups depends on where the dispatcher puts them; the heavy-hitter run
+        #  asserts the provocation, and test_half_committed_step_completes_to_the_same_state covers the logic deterministically)
+        pytest.skip("the co-tenant kernel did not provoke a hand-off timeout on this run")
     assert resets, "the co-tenant kernel did not provoke a hand-off timeout: the test did not test anything"
     assert fault_t == clean_t, f"tokens differ: {fault_t} vs {clean_t} after {len(resets)} retries"
     for l, (a, b) in enumerate(zip(clean_s, fault_s)):
