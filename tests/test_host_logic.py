@@ -239,3 +239,29 @@ def test_attn_summary_runs_reference_group_mean_unchanged():
         attn.view(bsz, 3, 2, seqlen, -1)
     with pytest.raises(ColdCompressError):
         attn.view(bsz, n_local_heads, 4, seqlen, -1).mean(dim=1)
+
+
+def test_recoverable_classification_and_key_row_shapes():
+    """Which caches the in-band retry of a timed-out single-launch step may touch (harness._recover_token asks `recoverable()`),
+    and the layout the fused pipelines rely on: one key row per kv head for EVERY policy (the head-constant ones used to share
+    one row across heads — a race, DESIGN round-3 table), commit words per kv head."""
+    import cold_compress_amd.cache as cache
+
+    H, D, S = 4, 16, 64
+    base = dict(max_cache_length=S, max_seq_length=4 * S, cache_bits=None, global_tokens=2, recent_window=3, history_window_size=1,
+                attn_thresholding=False)
+
+    def mk(strategy, **extra):
+        cls, rk = cache.get_cache_constructor(strategy)
+        kw = dict(base, **extra)
+        return cls(1, H, D, torch.float32, **{k: kw[k] for k in rk})
+
+    for strategy in ("heavy_hitter", "recent_global", "full", "random"):
+        kv = mk(strategy)
+        assert kv.recoverable(), strategy
+        assert tuple(kv.next_key.shape)[0] == H and tuple(kv.step_commit.shape) == (H,) and int(kv.step_commit.max()) == -1
+    assert not mk("heavy_hitter", history_window_size=8).recoverable()  # the ring step carries no commit words
+    assert not mk("l2").recoverable()  # its norm maximum crosses kv heads
+    rnd = mk("random")
+    rnd._rand = lambda: torch.zeros(S)  # an injected vector would be drawn again by a retry
+    assert not rnd.recoverable() and not rnd._in_kernel_rng()
