@@ -778,7 +778,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
   };
   int base = row_begin + wave * (RPW * U);
   bool more = base < row_end;
-  // Single tile, 16-bit cache (late r3): the K rows are requested right BEHIND the key row — ahead of the per-slot state, the
+  // 16-bit caches (late r3): the (first) tile's K rows are requested right BEHIND the key row — ahead of the per-slot state, the
   // epoch / status words and q, ~150 instructions earlier than with the rest of the tile.  Same-box A/B, three runs each: heavy
   // hitter 9.13 -> 8.92 us at S = 4096 (l2 10.5 -> 10.3, recent_global 8.98 -> 8.9, random 9.2 -> 9.1; S = 2560 and one kv head
   // unchanged).  The neighbours of this placement all LOSE: K ahead of the key row +0.1 (every workgroup's first decision then
@@ -787,7 +787,10 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
 #ifdef CC_NO_KEARLY  // (A/B builds)
   constexpr bool KEARLY = false;
 #else
-  constexpr bool KEARLY = ONE1 && !HYB && QB == 0;
+  // (several tiles per wave — hybrid included: the first tile's K rows likewise; C4 hybrid at S = 18432 25.8 -> 25.1 us and
+  //  17.15 -> 16.7 at S = 9000 on two boxes, unchanged on a third; heavy hitter unchanged: its stream is bandwidth-bound.  NOT the
+  //  hybrid cache's single-tile step: 11.1 -> 11.6 us at S = 4096 with it — its decision operands want to be ahead of the rows)
+  constexpr bool KEARLY = ONE && QB == 0 && !(HYB && NT == 1);
 #endif
   if (key_pending) {
     // KEY ROWS (late r3).  Every kv head reads — and at the end of the step rewrites — ITS OWN row, also under the head-constant

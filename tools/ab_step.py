@@ -37,11 +37,12 @@ def main():
         pos = torch.tensor([S + 100], dtype=torch.int32, device="cuda")
         for kv in caches:
             kv.prepare_decode(pos)
+        extra = {"input_ids": torch.tensor([[11]], device="cuda")} if policy == "hybrid" else {}
         for kv in caches:
-            kv.decode_step(q, k1, k1, pos)
+            kv.decode_step(q, k1, k1, pos, **extra)
         n_nodes = max(n_buf, int(os.environ.get("CC_AB_NODES", n_buf)))  # graph nodes per replay (cycling over the n_buf caches)
         def step(i):
-            caches[i % n_buf].decode_step(q, k1, k1, pos)
+            caches[i % n_buf].decode_step(q, k1, k1, pos, **extra)
             # positions ADVANCE, one per replay (a tiny add kernel per n_nodes steps): at a constant position the recoverable
             # heavy-hitter step finds step_commit[h] == *input_pos from the second replay on and REPLAYS — attention only, no
             # insert, no history / key stores — which is not the step (r3: every heavy-hitter A/B between the recoverable
