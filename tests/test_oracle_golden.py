@@ -388,3 +388,94 @@ def test_in_kernel_generator_restatement():
     assert abs(float(u.mean()) - 0.5) < 0.02 and len(np.unique(u)) > 4000
     assert not np.array_equal(u, oracle_lib.rng_vector(7, 101, 4096))
     assert not np.array_equal(u, oracle_lib.rng_vector(8, 100, 4096))
+
+
+def _pipeline_replay(oracle, c, f, T, g, w, strategy, entry):
+    """The oracle's FUSED-step twins (what the device's single- and two-launch steps are checked against) driven by a reference
+    capture: seed the key row, then one step per token — the slot each step fills must be the reference's eviction index."""
+    o = oracle
+    H, S, D = c.H, c.S, c.D
+    nk = int(o.fns()["cc_hh_next_key_slots"](S))
+    key = np.full((H, nk), ~np.uint64(0), np.uint64)
+    commit = np.full(H, -1, np.int32)
+    steps = f["steps"]
+    rand = [f["rand_u"][t].numpy().astype(np.float32).copy() for t in range(steps)] if strategy == "random" else None
+    p0 = _i32(T)
+    if strategy == "random":
+        o.call("cc_random_next_key_init", C.byref(c.view()), o.ptr(p0), o.ptr(rand[0]), g, w, o.ptr(key), None)
+    else:
+        o.call("cc_rg_next_key_init", C.byref(c.view()), o.ptr(p0), g, o.ptr(key), None)
+    HQ = H
+    ws = np.zeros(int(o.fns()["cc_decode_attn_workspace_bytes"](HQ, H, S, D, c.code)), np.uint8)
+    q = np.zeros((HQ, D), c.k.dtype)
+    y = np.zeros((HQ, D), c.k.dtype)
+    for t in range(steps):
+        before = c.pos.copy()
+        kn, vn = to_np(f["k_new"][t].reshape(H, D)), to_np(f["v_new"][t].reshape(H, D))
+        nxt = rand[t + 1] if strategy == "random" and t + 1 < steps else (np.zeros(S, np.float32) if strategy == "random" else None)
+        pp = _i32(T + t)
+        if entry == "rc":
+            o.call("cc_decode_step_head_constant_rc", C.byref(c.view()), 3 if strategy == "random" else 2, o.ptr(q), o.ptr(kn), o.ptr(vn),
+                   o.ptr(pp), o.ptr(nxt) if nxt is not None else None, 0, o.ptr(key), o.ptr(commit), g, w, HQ, 0.25, o.ptr(y), o.ptr(ws),
+                   ws.size, None)
+            assert bool((commit == T + t).all())
+        elif strategy == "random":
+            o.call("cc_decode_step_random", C.byref(c.view()), o.ptr(q), o.ptr(kn), o.ptr(vn), o.ptr(pp), o.ptr(nxt), o.ptr(key), g, w, HQ,
+                   0.25, o.ptr(y), o.ptr(ws), ws.size, None)
+        else:
+            o.call("cc_decode_step_recent_global", C.byref(c.view()), o.ptr(q), o.ptr(kn), o.ptr(vn), o.ptr(pp), o.ptr(key), g, HQ, 0.25,
+                   o.ptr(y), o.ptr(ws), ws.size, None)
+        changed = np.nonzero(c.pos.reshape(-1) != before.reshape(-1))[0]
+        assert np.array_equal(changed, f["idx"][t].numpy().reshape(-1)), f"step {t}: filled slot"
+
+
+@pytest.mark.parametrize("entry", ["plain", "rc"])
+@pytest.mark.parametrize("strategy", ["random", "recent_global", "full"])
+def test_fused_pipeline_twins_replay_the_reference(oracle, strategy, entry):
+    """f4 captures (the reference's own draws, evictions and final buffers) through the oracle's fused-step twins — the plain ones
+    and the recoverable head-constant entry (cc_decode_step_head_constant_rc): same slots step by step, same final cache."""
+    if strategy == "random":
+        f = load_golden("f4_random.npz")
+    else:
+        z = load_golden("f4_headconst.npz")
+        f = {k[len(strategy) + 1:]: v for k, v in z.items() if k.startswith(strategy + ".")}
+    dtype = DT_FROM_NAME[f["dtype"]]
+    H, S, D, T, g, w = f["H"], f["S"], f["D"], f["T_prefill"], f["g"], f["w"]
+    if strategy == "full":
+        g = 0
+    c = OracleCache(oracle, H, S, D, dtype, False, strategy)
+    c.prefill(f["k0"], f["v0"], torch.arange(T))
+    _pipeline_replay(oracle, c, f, T, g, w, strategy, entry)
+    _check_final(c, f, dtype)
+
+
+def test_in_kernel_draw_step_twin_equals_the_vector_step(oracle):
+    """cc_decode_step_random_rng_cpu / cc_random_next_key_init_rng_cpu == the vector forms fed oracle_lib.rng_vector(seed, position):
+    the twin the device's in-kernel draws are checked against is the reference-pinned random step with a restated generator."""
+    from oracle import oracle_lib
+
+    f = load_golden("f4_random.npz")
+    dtype = DT_FROM_NAME[f["dtype"]]
+    H, S, D, T, g, w = f["H"], f["S"], f["D"], f["T_prefill"], f["g"], f["w"]
+    o, seed = oracle, 0x1234567812345
+    a = OracleCache(oracle, H, S, D, dtype, False, "random")
+    b = OracleCache(oracle, H, S, D, dtype, False, "random")
+    for c in (a, b):
+        c.prefill(f["k0"], f["v0"], torch.arange(T))
+    nk = int(o.fns()["cc_hh_next_key_slots"](S))
+    ka, kb = np.zeros((H, nk), np.uint64), np.zeros((H, nk), np.uint64)
+    o.call("cc_random_next_key_init_rng", C.byref(a.view()), o.ptr(_i32(T)), seed, g, w, o.ptr(ka), None)
+    o.call("cc_random_next_key_init", C.byref(b.view()), o.ptr(_i32(T)), o.ptr(oracle_lib.rng_vector(seed, T, S)), g, w, o.ptr(kb), None)
+    assert np.array_equal(ka[0], kb[0])
+    ws = np.zeros(int(o.fns()["cc_decode_attn_workspace_bytes"](H, H, S, D, a.code)), np.uint8)
+    q = to_np(torch.randn(H, D, generator=torch.Generator().manual_seed(1)).to(dtype))
+    ya, yb = np.zeros_like(q), np.zeros_like(q)
+    for t in range(min(40, f["steps"])):
+        kn, vn = to_np(f["k_new"][t].reshape(H, D)), to_np(f["v_new"][t].reshape(H, D))
+        pp = _i32(T + t)
+        o.call("cc_decode_step_random_rng", C.byref(a.view()), o.ptr(q), o.ptr(kn), o.ptr(vn), o.ptr(pp), seed, o.ptr(ka), g, w, H, 0.25,
+               o.ptr(ya), o.ptr(ws), ws.size, None)
+        o.call("cc_decode_step_random", C.byref(b.view()), o.ptr(q), o.ptr(kn), o.ptr(vn), o.ptr(pp), o.ptr(oracle_lib.rng_vector(seed, T + t + 1, S)),
+               o.ptr(kb), g, w, H, 0.25, o.ptr(yb), o.ptr(ws), ws.size, None)
+        assert np.array_equal(a.pos, b.pos) and np.array_equal(ya, yb) and np.array_equal(ka[0], kb[0]), f"step {t}"
+    assert np.array_equal(a.k, b.k) and np.array_equal(a.v, b.v) and np.array_equal(a.mask, b.mask)
