@@ -7,6 +7,7 @@ attention outputs/probabilities.
 """
 import ctypes as C
 import json
+import math
 import os
 
 import numpy as np
@@ -479,3 +480,33 @@ def test_in_kernel_draw_step_twin_equals_the_vector_step(oracle):
                o.ptr(kb), g, w, H, 0.25, o.ptr(yb), o.ptr(ws), ws.size, None)
         assert np.array_equal(a.pos, b.pos) and np.array_equal(ya, yb) and np.array_equal(ka[0], kb[0]), f"step {t}"
     assert np.array_equal(a.k, b.k) and np.array_equal(a.v, b.v) and np.array_equal(a.mask, b.mask)
+
+
+@pytest.mark.parametrize("name", ["f3_l2_h1_bf16.npz", "f3_l2_long_bf16.npz"])  # (the fused l2 step serves 16-bit caches with head_dim 128)
+def test_l2_fused_pipeline_twin_replays_the_reference(oracle, name):
+    """The oracle's fused l2 step (cc_l2_next_key_init + cc_decode_step_l2: what the device's l2 layer step is checked against)
+    through the reference's f3 captures, continuing from the reference's prefill norms: the slot every step fills is the
+    reference's eviction index per head, the final cache and norms equal the reference's."""
+    f = load_golden(name)
+    dtype = DT_FROM_NAME[f["dtype"]]
+    H, S, D, T, g, w = f["H"], f["S"], f["D"], f["T_prefill"], f["g"], f["w"]
+    o = oracle
+    c = OracleCache(oracle, H, S, D, dtype, True, "l2")
+    c.prefill(f["k0"], f["v0"], torch.arange(T))
+    c.key_norm = to_np(f["keynorm_after_prefill"][0])
+    nk = int(o.fns()["cc_hh_next_key_slots"](S))
+    key = np.zeros((H, nk), np.uint64)
+    o.call("cc_l2_next_key_init", C.byref(c.view()), o.ptr(_i32(T)), o.ptr(c.key_norm), g, w, o.ptr(key), None)
+    ws = np.zeros(int(o.fns()["cc_decode_attn_workspace_bytes"](H, H, S, D, c.code)), np.uint8)
+    q = to_np(torch.randn(H, D, generator=torch.Generator().manual_seed(2)).to(dtype))
+    y = np.zeros_like(q)
+    for t in range(f["steps"]):
+        before = c.pos.copy()
+        kn, vn = to_np(f["k_new"][t].reshape(H, D)), to_np(f["v_new"][t].reshape(H, D))
+        o.call("cc_decode_step_l2", C.byref(c.view()), o.ptr(q), o.ptr(kn), o.ptr(vn), o.ptr(_i32(T + t)), o.ptr(c.key_norm), o.ptr(key), g, w,
+               H, 1.0 / math.sqrt(D), o.ptr(y), o.ptr(ws), ws.size, None)
+        filled = np.array([int(np.nonzero(c.pos[h] != before[h])[0][0]) for h in range(H)])
+        assert np.array_equal(filled, f["idx"][t].numpy().reshape(-1)), f"step {t}: filled slots"
+    _check_final(c, f, dtype)
+    got = from_np(c.key_norm, dtype).float()
+    assert torch.allclose(got, f["final_keynorm"][0].float(), rtol=2 ** -7 if dtype != torch.float32 else 1e-6, atol=0)
