@@ -27,6 +27,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+HBM_ACHIEVABLE_GBS = 6300.0  # the same guide: "8 TB/s peak (spec); ~6.3 TB/s achievable" (6.29 TB/s measured float4 copy)
 
 
 def parse():
@@ -405,11 +406,16 @@ def _oracle_layer_step_ms(S, threads, iters, warm, H=8, HQ=32, D=128):
     return ts[len(ts) // 2] * 1e3
 
 
-def _torch_cpu_layer_step_ms(S, threads, iters, warm, H=8, HQ=32, D=128, g=4, w=10):
+def _torch_cpu_layer_step_ms(S, threads, iters, warm, H=8, HQ=32, D=128, g=4, w=10, recycle=False):
     """The same layer step as the reference composes it on its CPU path — eager PyTorch ops on device="cpu", bf16:
     heavy-hitter score / protect / arg-min / reset / scatter insert (cache.py:725-765, 460-490), repeat_interleave of K, V
     and mask, q @ k^T * scale, -inf bias, softmax, @ v, group mean (model.py:389-427, attention_utils.py:36-54), history
-    update (cache.py:716-722).  Our own restatement of that op chain, written here for the baseline only."""
+    update (cache.py:716-722).  Our own restatement of that op chain, written here for the baseline only.
+    recycle=True writes the repeat_interleave results of K and V into buffers allocated once (the same copies, no allocator): at
+    S = 4096 each of those temporaries is EXACTLY 32 MiB = glibc's maximum mmap threshold, so the eager chain mmaps, page-faults and
+    unmaps 64 MiB per step there (and recycles heap blocks at S = 2560: 20 MiB) — the 4-11x cliff between the two cache lengths in
+    `per_layer_step_ms` is that, not arithmetic (measured here: repeat_interleave of [1, 8, S, 128] bf16 x4 takes 1.13 ms
+    at S = 4088 and 4.9 ms at S = 4096)."""
     torch.set_num_threads(threads)
     gen = torch.Generator().manual_seed(0)
     R, dt = HQ // H, torch.bfloat16
@@ -423,6 +429,8 @@ def _torch_cpu_layer_step_ms(S, threads, iters, warm, H=8, HQ=32, D=128, g=4, w=
     k1 = torch.randn(1, H, 1, D, generator=gen).to(dt)
     scale = 1.0 / math.sqrt(D)
     ts = []
+    kbuf = torch.empty(1, H, R, S, D, dtype=dt) if recycle else None
+    vbuf = torch.empty(1, H, R, S, D, dtype=dt) if recycle else None
     with torch.no_grad():
         for i in range(warm + iters):
             p = torch.tensor([S + 200 + i])
@@ -436,7 +444,12 @@ def _torch_cpu_layer_step_ms(S, threads, iters, warm, H=8, HQ=32, D=128, g=4, w=
             kc.scatter_(2, idx.unsqueeze(-1).expand(1, H, 1, D), k1)
             vc.scatter_(2, idx.unsqueeze(-1).expand(1, H, 1, D), k1)
             mask.scatter_(3, idx.unsqueeze(-1), True)
-            kk, vv, mm = kc.repeat_interleave(R, dim=1), vc.repeat_interleave(R, dim=1), mask.repeat_interleave(R, dim=1)
+            if recycle:
+                kbuf.copy_(kc.unsqueeze(2).expand(1, H, R, S, D))
+                vbuf.copy_(vc.unsqueeze(2).expand(1, H, R, S, D))
+                kk, vv, mm = kbuf.view(1, HQ, S, D), vbuf.view(1, HQ, S, D), mask.repeat_interleave(R, dim=1)
+            else:
+                kk, vv, mm = kc.repeat_interleave(R, dim=1), vc.repeat_interleave(R, dim=1), mask.repeat_interleave(R, dim=1)
             att = (q @ kk.transpose(-2, -1)) * scale
             att = att + torch.zeros_like(att).masked_fill(~mm, float("-inf"))
             probs = torch.softmax(att, dim=-1)
@@ -462,6 +475,7 @@ def cpu_baseline(args, n_layer=32):
     t_all = time.perf_counter()
     counts = sorted({c for c in (1, 8, 32, nproc) if c <= nproc})
     res = {}
+    extra = {}
 
     def adaptive(fn, S, threads):
         t0 = time.perf_counter()
@@ -482,6 +496,10 @@ def cpu_baseline(args, n_layer=32):
         for c in sorted({c for c in (8, 32, min(nproc, 64)) if c <= nproc} or {1}):
             row[f"torch_cpu_eager_{c}t_ms"] = round(adaptive(_torch_cpu_layer_step_ms, S, c), 3)
         res[S] = row
+        # the same chain with the two K / V temporaries recycled (see _torch_cpu_layer_step_ms: explains the S = 4096 cliff)
+        c8 = min(8, nproc)
+        extra.setdefault(str(S), {})[f"torch_cpu_eager_recycled_temporaries_{c8}t_ms"] = round(
+            adaptive(lambda S_, t_, it_, w_: _torch_cpu_layer_step_ms(S_, t_, it_, w_, recycle=True), S, c8), 3)
     torch.set_num_threads(min(nproc, 32))
     S0 = int(args.cache_len)
     best_key = min(res[S0], key=res[S0].get)
@@ -491,6 +509,10 @@ def cpu_baseline(args, n_layer=32):
     wall = time.perf_counter() - t_all
     return {"value": round(1e3 / (best * n_layer), 3), "unit": "tokens/s", "cores": threads, "host_cores": nproc, "kind": "port",
             "per_layer_step_ms": {str(k): v for k, v in res.items()},
+            "eager_allocator_note": {"per_layer_step_ms_recycled": extra,
+                                     "why": "eager chain at S=4096 vs 2560: its K/V repeat_interleave temporaries are exactly 32 MiB = glibc's "
+                                            "maximum mmap threshold -> mmap + page faults + munmap of 64 MiB per step at 4096, recycled heap "
+                                            "blocks at 2560; with the temporaries allocated once the two lengths scale with S"},
             "sample": f"per-layer heavy-hitter decode step (evict+insert+GQA attention+history; H=8, HQ=32, D=128, bf16) at "
                       f"S in {sorted(res)}, median of up to 20 iterations per thread count {counts}; value = 1 / ({n_layer} layers x "
                       f"{best:.3f} ms) from the {which} at S={S0} on {threads} of {nproc} host threads (the fastest setting); "
@@ -713,6 +735,19 @@ def main():
                        "prefill_seconds": round(prefill_s, 2), "device_state_after_timed_region": dev_state},
             "roofline": roof, "cpu_baseline": cpu,
         }
+        # north star: tokens/s "as absolute numbers and as fraction of HBM roofline" — the WHOLE token (weights streamed
+        # once + n_layer x B_step; the embedding table is a row lookup), per rank, against the spec peak and the achievable rate
+        w_bytes = sum(p_.numel() * p_.element_size() for n_, p_ in model.named_parameters() if not n_.startswith("tok_embeddings"))
+        step_b = 2 * kv0.n_heads * kv0.max_cache_length * kv0.head_dim * 2 + 29 * kv0.n_heads * kv0.max_cache_length
+        tok_bytes = w_bytes + args.n_layer * step_b
+        tok_rate = tok_bytes / (dt / args.steps) / 1e9  # GB/s per rank
+        out["whole_token"] = {"bytes": int(tok_bytes), "weight_bytes": int(w_bytes), "hot_path_bytes": int(args.n_layer * step_b),
+                              "achieved_gbs": round(tok_rate, 1), "frac_of_hbm_peak": round(tok_rate / HBM_PEAK_GBS, 4),
+                              "frac_of_achievable": round(tok_rate / HBM_ACHIEVABLE_GBS, 4),
+                              "roofline_tokens_per_s": round(HBM_PEAK_GBS * 1e9 / tok_bytes * 1.0, 1),
+                              "note": "per rank: bytes every token must stream from HBM (all weights but the embedding table, once; K, V and "
+                                      "29 B of heavy-hitter state per slot, once per layer) / measured time per token; peak 8 TB/s (spec), "
+                                      "achievable 6.3 TB/s (MI355X_MICROARCH.md, measured float4 copy)"}
         if step_us is not None and roof is not None:
             out["layer_step"] = {"us": round(step_us, 3), "bytes": roof["layer_step_bytes"],
                                  "frac_of_hbm_peak": round(roof["layer_step_bytes"] / (step_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),

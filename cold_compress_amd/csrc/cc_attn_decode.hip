@@ -23,6 +23,41 @@
 #include "cc_common.h"
 #include "cc_wacc.h"
 
+// ---- A/B switches of round 4 (tools/ab_variant.sh NAME "-DCC_V_...=1"); the defaults are what the product runs
+#ifndef CC_V_OEARLY
+#define CC_V_OEARLY 0   // 1: round 0 of the partial-O gather goes out ahead of the final (M, L) fold; 2: right behind the publish
+#endif
+#ifndef CC_V_PRO
+#define CC_V_PRO 0      // prologue diet: unconditional key-row loads, K rows requested ahead of the mask word
+#endif
+#ifndef CC_V_KEY1
+#define CC_V_KEY1 0     // one next-eviction key per WORKGROUP (folded across the waves in LDS) instead of one per wave
+#endif
+#ifndef CC_V_LDSDMA
+#define CC_V_LDSDMA 0   // K / V tiles land in the LDS slabs directly (global_load_lds_dwordx4): no staging registers, no ds_write
+#endif
+#ifndef CC_V_MLW
+#define CC_V_MLW 0      // the final (M, L) fold runs on the workgroup's LAST waves (idle during the partial-O publish of the first ones)
+#endif
+#ifndef CC_V_MLE
+#define CC_V_MLE 0      // round 0 of the (m, l) gather goes out AHEAD of the merge barrier (the pairs left behind the scores, long ago)
+#endif
+#ifndef CC_V_MF
+#define CC_V_MF 0       // the waves' merge factors exp(m_w - M) are computed once (by the (m, l) publisher) instead of by every publishing thread
+#endif
+#ifndef CC_V_VEARLY
+#define CC_V_VEARLY 0   // DMA: the V rows are requested right behind the K rows
+#endif
+#ifndef CC_V_KTOP
+#define CC_V_KTOP 0     // DMA: the K rows are requested ahead of the key row
+#endif
+#ifndef CC_V_SLEEP
+#define CC_V_SLEEP 1    // s_sleep argument between rounds of the early-(m, l) step's two gathers (64 cycles each)
+#endif
+#ifndef CC_V_XCD
+#define CC_V_XCD 0      // 1: the workgroups of kv head h sit on XCD h % 8; 2: ... and the gathers poll the XCD's L2 first
+#endif
+
 namespace {
 
 // ---------------------------------------------------------------- cross-lane all-reduce helpers
@@ -679,13 +714,25 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
   __shared__ __attribute__((aligned(16))) uint4 sm_k[NW][16][16];  // [wave][tile row i][slot]: 4 KiB per wave
   __shared__ __attribute__((aligned(16))) uint4 sm_v[NW][16][16];  // [wave][tile row][chunk ^ 2*(row & 7)]: V tile, row major
   __shared__ float sm_wm[NW][RT], sm_wl[NW][RT];  // the waves' softmax state per query head (merged across the workgroup)
+  __shared__ float sm_wf[NW][RT];                  // EML + MF: exp(m_w - M) of the workgroup's merge, written once by the (m, l) publisher
   __shared__ unsigned sm_mlcnt;                    // EML: waves whose (m, l) rows are in LDS — the LAST one to arrive publishes
   __shared__ unsigned sm_fail;                     // EML: some wave of this workgroup gave up waiting (recoverable hand-off)
   __shared__ float sm_l2w[NW];  // ONE + L2: per-wave maxima of the norms this workgroup's slots hold AFTER the step's insert
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, c = lane & 15;  // row group of the wave / 16-byte column chunk (and MFMA column n)
-  const int split = blockIdx.x, h = blockIdx.y, q0 = h * a.R + blockIdx.z * RT;
+  int split_ = blockIdx.x, h_ = blockIdx.y;
+  if constexpr (CC_V_XCD != 0 && ONE1 && !HYB) {
+    // workgroup b of the grid is dispatched to XCD b % 8 (observed; used for speed only): with kv head = b % H every workgroup of a
+    // kv head sits on XCD h % 8 and the hand-off of a head stays inside one XCD (H a multiple of 8; other head counts keep the
+    // dispatch order).  Cost: heads interleave in dispatch order, so EVERY head needs all workgroups of the launch resident.
+    if ((gridDim.y & 7) == 0) {
+      const int b = blockIdx.x + gridDim.x * blockIdx.y;
+      h_ = b % (int)gridDim.y;
+      split_ = b / (int)gridDim.y;
+    }
+  }
+  const int split = split_, h = h_, q0 = h * a.R + blockIdx.z * RT;
   const int S = a.S;
   const int row_begin = split * a.rows_per_split;
   const int row_end = min(S, row_begin + a.rows_per_split);
@@ -739,19 +786,8 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
     const u32x2_nt v = __builtin_nontemporal_load(reinterpret_cast<const u32x2_nt*>(p));
     return make_uint2(v.x, v.y);
   };
-  auto issue_k = [&](TileRegs& R, int base) {  // mask word + the four K rows of this lane's row group (tile row i = 4g + u takes chunk c ^ i)
+  auto issue_k_rows = [&](TileRegs& R, int base) {
     const int row0 = base + g * U;
-    R.mword = 0x01010101u;
-    if (has_mask) {
-      if (row0 + 3 < S && ((reinterpret_cast<uintptr_t>(mh) + (size_t)row0) & 3) == 0) {
-        R.mword = *reinterpret_cast<const uint32_t*>(mh + row0);
-      } else {
-        R.mword = 0;
-#pragma unroll
-        for (int u = 0; u < U; u++)
-          if (row0 + u < S) R.mword |= (uint32_t)mh[row0 + u] << (8 * u);
-      }
-    }
 #pragma unroll
     for (int u = 0; u < U; u++) {
       const int rr = row0 + u < row_end ? row0 + u : row_end - 1;
@@ -763,7 +799,61 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
       }
     }
   };
+  constexpr bool KFIRST = CC_V_PRO != 0 && ONE1 && !HYB;  // the K rows go out ahead of the (branchy) mask word
+  // LDS-DMA (r4 A/B): the tile's rows land in the wave's slabs directly — load u of a wave delivers tile rows 4u .. 4u + 3 (lane
+  // (g, c) asks for row 4u + g, the chunk that belongs in slot c of that row under the slab's swizzle) into one contiguous 1 KiB
+  // block (lane L -> byte 16 L); no staging registers, no ds_write, and the row OWNERSHIP of the scores (row group g: rows 4g .. 4g + 3,
+  // the MFMA's C layout) is untouched
+  constexpr bool DMA = CC_V_LDSDMA != 0 && ONE1 && QB == 0 && !L2 && !HYB;
+  // (buffer_load ... lds, not global_load_lds: the compiler's wait-count pass treats the FLAT-encoded form as an access to both
+  //  memories and turns every later wait into vmcnt(0) lgkmcnt(0) while one is pending; the MUBUF form is counted exactly)
+  auto dma16 = [](__amdgpu_buffer_rsrc_t rs, int voff, void* lp) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lp, 16, voff, 0, 0, 2 /* nt */);
+  };
+  auto issue_k_dma = [&](int base) {
+    const auto krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(kb), 0, S * D * (int)sizeof(T), 0x00020000);
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int i = 4 * u + g, rr = base + i < row_end ? base + i : row_end - 1;
+      dma16(krs, rr * (D * (int)sizeof(T)) + ((c ^ i) & 15) * 16, &sm_k[wave][4 * u][0]);
+    }
+  };
+  auto issue_v_dma = [&](int base) {
+    const auto vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(reinterpret_cast<const T*>(a.v) + (size_t)h * S * D), 0, S * D * (int)sizeof(T), 0x00020000);
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int i = 4 * u + g, rr = base + i < row_end ? base + i : row_end - 1;
+      dma16(vrs, rr * (D * (int)sizeof(T)) + ((c ^ (2 * (i & 7))) & 15) * 16, &sm_v[wave][4 * u][0]);
+    }
+  };
+  auto issue_k = [&](TileRegs& R, int base) {  // mask word + the four K rows of this lane's row group (tile row i = 4g + u takes chunk c ^ i)
+    const int row0 = base + g * U;
+    if constexpr (DMA) {
+      issue_k_dma(base);
+      __builtin_amdgcn_sched_barrier(0);
+    } else
+    if constexpr (KFIRST) {
+      issue_k_rows(R, base);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    R.mword = 0x01010101u;
+    if (has_mask) {
+      if (row0 + 3 < S && ((reinterpret_cast<uintptr_t>(mh) + (size_t)row0) & 3) == 0) {
+        R.mword = *reinterpret_cast<const uint32_t*>(mh + row0);
+      } else {
+        R.mword = 0;
+#pragma unroll
+        for (int u = 0; u < U; u++)
+          if (row0 + u < S) R.mword |= (uint32_t)mh[row0 + u] << (8 * u);
+      }
+    }
+    if constexpr (!KFIRST && !DMA) issue_k_rows(R, base);
+  };
   auto issue_v = [&](TileRegs& R, int base) {
+    if constexpr (DMA) {
+      issue_v_dma(base);
+      return;
+    }
     const int row0 = base + g * U;
 #pragma unroll
     for (int u = 0; u < U; u++) {
@@ -792,6 +882,28 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
   //  hybrid cache's single-tile step: 11.1 -> 11.6 us at S = 4096 with it — its decision operands want to be ahead of the rows)
   constexpr bool KEARLY = ONE && QB == 0 && !(HYB && NT == 1);
 #endif
+  unsigned one_tag = 0;
+  int32_t one_pin = 0;
+  unsigned rc_status = 0;    // EML: the workspace's status word (a step failed since the host last looked: do nothing)
+  int32_t rc_commit = -2;    // EML: step_commit[h]
+  auto load_step_words = [&]() {
+    one_tag = a.one_hdr[h] + 1u;
+    one_pin = *a.input_pos;
+    if constexpr (RC) {
+      rc_status = a.one_hdr[kOneStatusWordDev];
+      if (a.commit) rc_commit = a.commit[h];
+    }
+  };
+  if constexpr (DMA && CC_V_KTOP != 0) {  // (A/B) the K rows ahead of everything else
+    load_step_words();
+    __builtin_amdgcn_sched_barrier(0);
+    issue_k(tregs[0], base);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (CC_V_VEARLY != 0) {
+      issue_v(tregs[0], base);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
   if (key_pending) {
     // KEY ROWS (late r3).  Every kv head reads — and at the end of the step rewrites — ITS OWN row, also under the head-constant
     // policies, whose rows all hold the same keys.  They used to share row 0, rewritten by kv head 0's waves once THEIR head's
@@ -801,19 +913,39 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
     // and put their row into the wrong slot, silently.  A head's own row is safe by the argument that already covers the
     // head-specific policies: its writers have gathered every workgroup of the head, i.e. every reader has published, i.e. read.
     const unsigned long long* krow = a.next_key + (size_t)h * a.nk;
-    if (lane < a.nk_read) key_part = krow[lane];
+    if constexpr (CC_V_PRO != 0 && ONE) {
+      // no branch around the loads: a lane past the row's live entries reads the row's last live entry again (the minimum does not
+      // change); four exec-mask branches less in front of the first K rows
+      const int last = a.nk_read - 1;
+      key_part = krow[lane < last ? lane : last];
 #pragma unroll
-    for (int j = 0; j < 3; j++)
-      if (lane + 64 * (j + 1) < a.nk_read) key_more[j] = krow[lane + 64 * (j + 1)];
+      for (int j = 0; j < 3; j++)
+        if (64 * (j + 1) < a.nk_read) key_more[j] = krow[lane + 64 * (j + 1) < last ? lane + 64 * (j + 1) : last];  // (wave-uniform test)
+    } else {
+      if (lane < a.nk_read) key_part = krow[lane];
+#pragma unroll
+      for (int j = 0; j < 3; j++)
+        if (lane + 64 * (j + 1) < a.nk_read) key_more[j] = krow[lane + 64 * (j + 1)];
+    }
     // rows beyond 256 live entries (two-launch step at S > 32768) — kept OUT of the streaming loop so that the waits there stay exact
     for (int i = lane + 256; i < a.nk_read; i += 64) {
       const unsigned long long x = a.next_key[(size_t)h * a.nk + i];
       key_part = x < key_part ? x : key_part;
     }
   }
-  if constexpr (KEARLY) {
+  if constexpr (DMA && CC_V_KTOP == 0) {
+    // the step's wave-uniform words are requested AHEAD of the first DMA load: behind it they could no longer travel as scalar
+    // loads (the compiler must assume the DMA writes memory they read) and would become vector loads with a wait for the whole tile
+    load_step_words();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if constexpr (KEARLY && !(DMA && CC_V_KTOP != 0)) {
     issue_k(tregs[0], base);
     __builtin_amdgcn_sched_barrier(0);  // (keeps the scheduler from sinking them back to the rest of the tile)
+    if constexpr (DMA && CC_V_VEARLY != 0) {
+      issue_v(tregs[0], base);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
   // HYB: everything the per-head decision needs besides the candidate key — the policy table (ALL rows: one vector load, the
   // head's row is picked by a lane read once its policy index has arrived), the punctuation ids (one id per lane), the head's
@@ -850,9 +982,8 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
       rt0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz, one clock for the whole device (s_memtime is per XCD)
     }
   }
-  unsigned one_tag = 0;
   double one_numv[NT];
-  int32_t one_denv[NT], one_psv[NT], one_pin = 0;
+  int32_t one_denv[NT], one_psv[NT];
   float one_rndv[NT];
 #pragma unroll
   for (int ti = 0; ti < NT; ti++) {
@@ -935,15 +1066,8 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
   float one_kn = 0.f;       // ONE + L2: the key norm of this lane's slot (model dtype) ...
   float l2_nv_lane = 0.f;   // ... and the inserted key's norm, in the lanes of the row group that inserted it
   unsigned l2_ep[3] = {0u, 0u, 0u};  // ONE + L2: epoch words of the kv heads whose norm granules this thread gathers (read behind the tile's loads, below)
-  unsigned rc_status = 0;    // EML: the workspace's status word (a step failed since the host last looked: do nothing)
-  int32_t rc_commit = -2;    // EML: step_commit[h]
   if constexpr (ONE) {
-    one_tag = a.one_hdr[h] + 1u;
-    one_pin = *a.input_pos;
-    if constexpr (RC) {
-      rc_status = a.one_hdr[kOneStatusWordDev];
-      if (a.commit) rc_commit = a.commit[h];
-    }
+    if constexpr (!DMA) load_step_words();
     // single tile: requested AHEAD of the K/V tile (measured: behind it the step is 0.3 us slower — the tile's in-order waits
     // then end on these stragglers, and the workgroup leaves the streaming part later); several tiles: requested after the
     // publish, in the shadow of the hand-off
@@ -1008,7 +1132,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
   for (int sub = 0; sub < NSUB; sub++) {
     if constexpr (!KEARLY) issue_k(tregs[sub], base + sub * NW * RPW * U);
     if constexpr (QB) __builtin_amdgcn_sched_barrier(0);  // K's bytes and parameters go out BEFORE V's: the K stash waits for them only
-    issue_v(tregs[sub], base + sub * NW * RPW * U);
+    if constexpr (!(DMA && CC_V_VEARLY != 0)) issue_v(tregs[sub], base + sub * NW * RPW * U);
     if constexpr (QB) __builtin_amdgcn_sched_barrier(0);
   }
   // ONE + L2: the epoch words of the kv heads whose norm granules this thread will gather.  Read HERE (behind the tile's loads: three integer divisions kept out of the way of the first K rows): every workgroup has read
@@ -1029,7 +1153,13 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
       sm_mlcnt = 0u;
       sm_fail = 0u;
     }
-    __syncthreads();
+    if constexpr (DMA) {
+      // a bare barrier: __syncthreads() is a workgroup-scope release fence, and with LDS-DMA loads in flight (LDS writes that count
+      // in vmcnt) the fence waits for the whole tile — here, right behind its issue
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    } else {
+      __syncthreads();
+    }
     if (rc_status != 0u) return;  // a step of this token failed before this launch: leave everything as it is (the host retries)
   }
   const bool rc_replay = EML && rc_commit == one_pin;  // this head's step for this position is committed already: attention only
@@ -1104,7 +1234,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
         kn.load(reinterpret_cast<const T*>(a.k_new) + (size_t)h * D + kcol);
         vn.load(reinterpret_cast<const T*>(a.v_new) + (size_t)h * D + c * VEC);
       }
-      const int32_t p_now = AHEAD ? p_ins : *a.input_pos;
+      const int32_t p_now = ONE ? one_pin : (AHEAD ? p_ins : *a.input_pos);  // (ONE: read in the prologue already)
       // QB: the new row was quantised ahead of the tile (once per step and row), and is attended to through its image like
       // every other row; this lane holds chunk c of K, not the swizzled chunk: the LDS stash below puts it where it belongs
       uint2 knq = make_uint2(0, 0), vnq = make_uint2(0, 0);
@@ -1114,13 +1244,20 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
         vnq = quant8_row16<T>(qb_vn.raw, vnp);
         qb_ins_u = um;
       }
+      if constexpr (DMA) {
+        // the new rows were requested BEHIND the tile's DMA loads and loads return in order: when kn / vn are here, the stale cache
+        // rows have landed in the slabs and may be overwritten
+        const int i = 4 * g + um;
+        sm_k[wave][i][c] = kn.raw;                           // (kn is chunk c ^ i: slot c of row i)
+        sm_v[wave][i][(c ^ (2 * (i & 7))) & 15] = vn.raw;    // (vn is chunk c)
+      }
 #pragma unroll
       for (int u = 0; u < U; u++)
         if (u == um) {
           if constexpr (QB) {
             R.kq8[u] = knq; R.kpar[u] = knp;
             R.vq8[u] = vnq; R.vpar[u] = vnp;
-          } else {
+          } else if constexpr (!DMA) {
             R.kk[u].raw = kn.raw;
             R.vv[u].raw = vn.raw;
           }
@@ -1187,6 +1324,9 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
     // ---- K tile -> wave-private LDS slab -> A operand; S^T = K q^T on the matrix core
 #pragma unroll
     for (int u = 0; u < U; u++) {
+      if constexpr (DMA) {
+        // (already there: the DMA loads deliver into the slab; the compiler's wait for them sits in front of the fragment reads)
+      } else
       if constexpr (QB) {  // slot c of tile row i holds chunk c ^ i; the inserted row's lane holds chunk c -> slot c ^ i
         const int i = 4 * g + u;
         sm_k[wave][i][u == qb_ins_u ? ((c ^ i) & 15) : c] = dequant8<T>(R.kq8[u], R.kpar[u]);
@@ -1270,9 +1410,11 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
     const float (&p)[U] = pv_p;
     // ---- O^T += V^T . P^T on the matrix cores: V tile -> wave-private LDS slab (row major, coalesced), A fragments
     //      back through the transpose read, B = this lane's four probabilities in 16 bit
+    if constexpr (!DMA) {
 #pragma unroll
-    for (int u = 0; u < U; u++)
-      sm_v[wave][4 * g + u][(c ^ (2 * ((4 * g + u) & 7))) & 15] = QB ? dequant8<T>(R.vq8[u], R.vpar[u]) : R.vv[u].raw;
+      for (int u = 0; u < U; u++)
+        sm_v[wave][4 * g + u][(c ^ (2 * ((4 * g + u) & 7))) & 15] = QB ? dequant8<T>(R.vq8[u], R.vpar[u]) : R.vv[u].raw;
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1333,6 +1475,17 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
       // LAST K tile had arrived (measured, r3: +0.8 us on the streaming part).  Each wave bumps an LDS counter behind its two
       // stores (release / acquire at workgroup scope); whoever brings it to NW has every wave's row in front of it and publishes.
       unsigned arrived = 0;
+      if constexpr (DMA) {
+        // (relaxed: a release at workgroup scope waits for the V rows still landing in the slab through the DMA path — they count
+        //  in vmcnt.  The LDS unit serves one wave's operations in order: the two stores above are done when the add executes, and
+        //  the last arriver's reads below follow its add.)
+        //  The add is spelled in assembly: the compiler, which cannot tell the counter from the slabs the DMA loads write, would put
+        //  a wait for those in front of any LDS atomic it sees.)
+        if (lane == 0) {
+          const unsigned cnt_addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned*)&sm_mlcnt;
+          asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(arrived) : "v"(cnt_addr), "v"(1u) : "memory");
+        }
+      } else
       if (lane == 0) arrived = __hip_atomic_fetch_add(&sm_mlcnt, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
       arrived = (unsigned)__builtin_amdgcn_readfirstlane((int)arrived);
       const bool ml_last = arrived == (unsigned)(NW - 1) && lane < RT;
@@ -1345,7 +1498,11 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
         const float Mu = (M == -INFINITY) ? 0.f : M;
         float L = 0.f;
 #pragma unroll
-        for (int w = 0; w < NW; w++) L = fmaf(sm_wl[w][r], fast_exp(sm_wm[w][r] - Mu), L);
+        for (int w = 0; w < NW; w++) {
+          const float f = fast_exp(sm_wm[w][r] - Mu);
+          if constexpr (CC_V_MF != 0) sm_wf[w][r] = f;  // (the same factor the partial-O merge below would compute)
+          L = fmaf(sm_wl[w][r], f, L);
+        }
         ml_M = M;
         ml_L = L;
       }
@@ -1357,7 +1514,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
         const u32x4_t mg = {one_tag, __float_as_uint(ml_M), one_tag, __float_as_uint(ml_L)};
         const auto ml_rsrc_e = __builtin_amdgcn_make_buffer_rsrc(a.one_ml, 0, (int)a.one_ml_bytes, 0x00020000);
         const int off = ml_last ? h * kOneMlHead + (split * RT + lane) * 16 : 0x7ffffff0;
-        __builtin_amdgcn_raw_buffer_store_b128(mg, ml_rsrc_e, off, 0, kOneAuxCoherent);
+        __builtin_amdgcn_raw_buffer_store_b128(mg, ml_rsrc_e, off, 0, (CC_V_XCD == 3 && !L2) ? 0 : ((CC_V_XCD == 4 && !L2) ? 16 : kOneAuxCoherent));
         if constexpr (L2) {  // l2: the workgroup's norm maximum leaves with the pairs (same unconditional form; lane RT of the publisher)
           float wm = -INFINITY;
           bool nn = false;
@@ -1441,6 +1598,22 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
         *reinterpret_cast<float4*>(&sm_wacc[wave][c][16 * b + 4 * g]) = make_float4(acc[b][0], acc[b][1], acc[b][2], acc[b][3]);
     }
   }
+  // MLE: round 0 of the (m, l) gather ahead of the merge barrier (same addresses as below)
+  constexpr int MLN_PRE = (RT + NW - 1) / NW;
+  u32x4_t mlq_pre[MLN_PRE];
+  if constexpr (EML && CC_V_MLE != 0) {
+    constexpr int ML_W0p = (CC_V_MLW != 0 && NW >= 2 * RT) ? NW - RT : 0;
+    const int ml_wp = wave - ML_W0p;
+    const auto ml_rsrc_p = __builtin_amdgcn_make_buffer_rsrc(a.one_ml, 0, (int)a.one_ml_bytes, 0x00020000);
+    constexpr int kGatherAuxP = (CC_V_XCD >= 2 && !L2) ? 16 : kOneAuxCoherent;
+    if (ml_wp >= 0 && ml_wp < RT) {
+#pragma unroll
+      for (int k = 0; k < MLN_PRE; k++)
+        mlq_pre[k] = __builtin_amdgcn_raw_buffer_load_b128(
+            ml_rsrc_p, h * kOneMlHead + ((lane < a.n_split ? lane : 0) * RT + (ml_wp + k * NW < RT ? ml_wp + k * NW : 0)) * 16, 0, kGatherAuxP);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
   __syncthreads();
   if constexpr (ONE) {
     // ============================================================================================================
@@ -1460,6 +1633,10 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
     // timeout word should that ever not hold.
     const int ns = a.n_split;
     const unsigned tag = one_tag;
+    // (CC_V_XCD == 2, A/B only: the gathers of a kv head's own granules poll the XCD's L2 — sc1 — which sees the head's write-through
+    //  stores only while all of its workgroups sit on that XCD)
+    constexpr int kGatherAux = (CC_V_XCD >= 2 && EML && !L2) ? 16 : kOneAuxCoherent;
+    constexpr int kPublishAux = (CC_V_XCD == 3 && EML && !L2) ? 0 : ((CC_V_XCD == 4 && EML && !L2) ? 16 : kOneAuxCoherent);  // (4: sc1 stores)  // (3: plain stores: the granules stay in the XCD's L2)
     if constexpr (L2 && !EML) {
       // the epoch words of the other heads (requested behind the tile's loads) must have ARRIVED before this workgroup publishes:
       // whoever bumps a word does so only after every workgroup of the launch has published
@@ -1482,8 +1659,12 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
     const auto o_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.one_o, 0, (int)a.one_o_bytes, 0x00020000);
     constexpr int MLN = (RT + NW - 1) / NW;            // (m, l) granules per thread: wave w collects heads w, w + NW, ...
     int ml_off[MLN];
+    // the waves that fold a head's (m, l) pairs: the first RT — or (MLW) the LAST RT of a workgroup with at least 2 RT waves: the first
+    // RT waves merge and publish the partial O meanwhile (thread t: outputs 2t, 2t + 1), the others would idle
+    constexpr int ML_W0 = (CC_V_MLW != 0 && EML && NW >= 2 * RT) ? NW - RT : 0;
+    const int ml_w = wave - ML_W0;  // this wave's first head (negative: none)
 #pragma unroll
-    for (int k = 0; k < MLN; k++) ml_off[k] = h * kOneMlHead + ((lane < ns ? lane : 0) * RT + (wave + k * NW < RT ? wave + k * NW : 0)) * 16;
+    for (int k = 0; k < MLN; k++) ml_off[k] = h * kOneMlHead + ((lane < ns ? lane : 0) * RT + (ml_w >= 0 && ml_w + k * NW < RT ? ml_w + k * NW : 0)) * 16;
     u32x4_t mlq[MLN];
     const int nm_base = kOneMaxHeads * kOneMlHead;  // l2: the norm-maximum granules sit behind the (m, l) regions of all heads
     constexpr int NLG = L2 ? 3 : 0;  // l2: norm-maximum granules per thread (H * n_split <= 768 workgroups are ever co-resident)
@@ -1502,9 +1683,13 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
     if constexpr (EML) {
       // the (m, l) pairs left behind the scores, long ago: their first round of loads goes out AHEAD of this workgroup's partial-O
       // stores (loads return in order: behind the stores they would also wait for the stores' acknowledgements, a round trip)
-      if (wave < RT) {
+      if constexpr (CC_V_MLE != 0) {
 #pragma unroll
-        for (int k = 0; k < MLN; k++) mlq[k] = __builtin_amdgcn_raw_buffer_load_b128(ml_rsrc, ml_off[k], 0, kOneAuxCoherent);
+        for (int k = 0; k < MLN; k++) mlq[k] = mlq_pre[k];
+      } else
+      if (ml_w >= 0 && ml_w < RT) {
+#pragma unroll
+        for (int k = 0; k < MLN; k++) mlq[k] = __builtin_amdgcn_raw_buffer_load_b128(ml_rsrc, ml_off[k], 0, kGatherAux);
       }
       // l2: every workgroup's norm maximum (they left with the pairs), gathered by every thread of every workgroup; a thread
       // without a granule aims past the buffer's end (no request, zeros back): no branch around the loads
@@ -1515,6 +1700,18 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
     // ---- publish: thread t merges output columns 2t, 2t + 1 of the workgroup's partial (the arithmetic of the
     //      two-launch epilogue below) and stores them as one granule
     for (int o2 = (int)threadIdx.x * 2; o2 < RT * D; o2 += 2 * NW * 64) {
+      if constexpr (CC_V_MF != 0 && EML) {
+        const int r = o2 / D, d = o2 - r * D;
+        float O0 = 0.f, O1 = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; w++) {  // fixed order: deterministic; the factors are the ones this loop used to compute per thread
+          const float f = sm_wf[w][r];
+          O0 = fmaf(sm_wacc[w][r][d], f, O0);
+          O1 = fmaf(sm_wacc[w][r][d + 1], f, O1);
+        }
+        const u32x4_t og = {tag, __float_as_uint(O0), tag, __float_as_uint(O1)};
+        __builtin_amdgcn_raw_buffer_store_b128(og, o_rsrc, h * kOneOHead + ((r * ns + split) * 64 + (d >> 1)) * 16, 0, kPublishAux);
+      } else
       {
         const int r = o2 / D, d = o2 - r * D;
         float M = sm_wm[0][r];
@@ -1530,7 +1727,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
           O1 = fmaf(sm_wacc[w][r][d + 1], f, O1);
         }
         const u32x4_t og = {tag, __float_as_uint(O0), tag, __float_as_uint(O1)};
-        __builtin_amdgcn_raw_buffer_store_b128(og, o_rsrc, h * kOneOHead + ((r * ns + split) * 64 + (d >> 1)) * 16, 0, kOneAuxCoherent);
+        __builtin_amdgcn_raw_buffer_store_b128(og, o_rsrc, h * kOneOHead + ((r * ns + split) * 64 + (d >> 1)) * 16, 0, kPublishAux);
         if (!EML && d == 0) {
           const u32x4_t mg = {tag, __float_as_uint(M), tag, __float_as_uint(L)};
           __builtin_amdgcn_raw_buffer_store_b128(mg, ml_rsrc, h * kOneMlHead + (split * RT + r) * 16, 0, kOneAuxCoherent);
@@ -1585,13 +1782,13 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
     // carries this launch's tag
     auto load_ml = [&]() {
 #pragma unroll
-      for (int k = 0; k < MLN; k++) mlq[k] = __builtin_amdgcn_raw_buffer_load_b128(ml_rsrc, ml_off[k], 0, kOneAuxCoherent);
+      for (int k = 0; k < MLN; k++) mlq[k] = __builtin_amdgcn_raw_buffer_load_b128(ml_rsrc, ml_off[k], 0, kGatherAux);
     };
     unsigned failq = 0;  // EML: the head's fail word, read with every round of the partial-O gather (recoverable hand-off)
     const auto hdr_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.one_hdr, 0, 4096, 0x00020000);
     auto load_o = [&]() {
 #pragma unroll
-      for (int k = 0; k < NOG; k++) oq[k] = __builtin_amdgcn_raw_buffer_load_b128(o_rsrc, o_off[k], 0, kOneAuxCoherent);
+      for (int k = 0; k < NOG; k++) oq[k] = __builtin_amdgcn_raw_buffer_load_b128(o_rsrc, o_off[k], 0, kGatherAux);
       if constexpr (RC) failq = __builtin_amdgcn_raw_buffer_load_b32(hdr_rsrc, (kOneFailWord + h) * 4, 0, kOneAuxCoherent);
     };
     // a wave that gives up: the head's fail word (this launch's tag) and the workspace's status word, write-through
@@ -1618,8 +1815,8 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
     auto final_ml = [&]() {
 #pragma unroll
       for (int k = 0; k < MLN; k++) {
-        const int rr = wave + k * NW;
-        if (rr < RT) {
+        const int rr = ml_w + k * NW;
+        if (rr >= 0 && rr < RT) {
           const float mi = lane < ns ? __uint_as_float(mlq[k][1]) : -INFINITY;
           const float M = wave_max_uniform(mi);
           const float Mu = (M == -INFINITY) ? 0.f : M;
@@ -1659,8 +1856,13 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
     __shared__ float sm_l2g[NW];  // l2: per-wave fold of the gathered norm maxima (NaN propagates: torch.max)
     unsigned long long trD = 0, trE = 0;
     if constexpr (EML) {
+      if constexpr (CC_V_OEARLY == 2) {  // round 0 of the partial-O gather right behind this workgroup's own publish
+        asm volatile("" ::: "memory");
+        load_o();
+        __builtin_amdgcn_sched_barrier(0);
+      }
       // ---- the (m, l) pairs left behind the scores: most of them are there by now.  Only the waves that fold a head poll.
-      const bool ml_mine = wave < RT;  // (MLN == 1 whenever RT <= NW; with RT = 8 on four waves every wave folds two heads)
+      const bool ml_mine = ml_w >= 0 && ml_w < RT;  // (MLN == 1 whenever RT <= NW; with RT = 8 on four waves every wave folds two heads)
       // Round 0 (issued ahead of the partial-O stores) is examined in STRAIGHT-LINE code: the compiler then waits for exactly
       // these loads — the oldest in flight — and not for the acknowledgements of the stores behind them (at a loop header its
       // in-order wait counts merge with the back edge's and become a wait for everything)
@@ -1676,7 +1878,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
           timed_out = true;
           break;
         }
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(CC_V_SLEEP);
         asm volatile("" ::: "memory");  // every round re-reads memory
         if (ml_mine) load_ml();
 #pragma unroll
@@ -1686,6 +1888,11 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
       }
       if (timed_out) give_up();
       if (a.trace) tr4 = __builtin_amdgcn_s_memtime();
+      if constexpr (CC_V_OEARLY == 1) {  // round 0 of the partial-O gather flies during the final (M, L) fold and its barrier too
+        asm volatile("" ::: "memory");
+        load_o();
+        __builtin_amdgcn_sched_barrier(0);
+      }
       if (ml_mine) final_ml();
       if constexpr (L2) {  // the wave's fold of the gathered norm maxima (NaN propagates: torch.max)
         float gm = -INFINITY;
@@ -1743,7 +1950,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
       if (a.trace) trD = __builtin_amdgcn_s_memtime();
       y_fold();
     }
-    if constexpr (EML) {
+    if constexpr (EML && CC_V_OEARLY == 0) {
       // the first round of the partial-O gather goes out HERE and flies while the per-slot pass runs: what is left behind the last O
       // granule of the head is the y fold
       asm volatile("" ::: "memory");
@@ -1947,7 +2154,24 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
     // barrier of the finish, so no wave's stores wait for another wave (the launch ends a store round trip after the LAST
     // store is issued: every store that can go out early shortens it)
     const unsigned long long wk = wave_min_u64_uniform(my_key);
+    // KEY1: one key per WORKGROUP — the waves' keys meet in LDS in front of the finish's last barrier (in the shadow of the partial-O
+    // gather) and wave 0 stores their minimum: the next step's prologue reads n_split entries per kv head instead of NW x n_split
+    constexpr bool KEY1 = CC_V_KEY1 != 0 && EML;
+    __shared__ unsigned long long sm_wk[KEY1 ? NW : 1];
+    if constexpr (KEY1) {
+      if (lane == 0) sm_wk[wave] = wk;
+    }
     auto store_key = [&]() {
+      if constexpr (KEY1) {
+        if (wave == 0) {
+          const unsigned long long k8 = wave_min_u64_uniform(lane < NW ? sm_wk[lane] : ~0ull);
+          if (lane == 0) {
+            unsigned long long* nk_row = const_cast<unsigned long long*>(a.next_key) + (size_t)h * a.nk;
+            nk_row[split] = k8;
+            for (int s2 = split + ns; s2 < a.nk_read; s2 += ns) nk_row[s2] = ~0ull;
+          }
+        }
+      } else
       if (lane == 0) {
         unsigned long long* nk_row = const_cast<unsigned long long*>(a.next_key) + (size_t)h * a.nk;
         const int e0 = split * NW + wave;
@@ -1964,7 +2188,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
           timed_out = true;
           break;
         }
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(CC_V_SLEEP);
         asm volatile("" ::: "memory");  // every round re-reads memory
         load_o();
       }
@@ -2875,7 +3099,12 @@ static int attn_impl(const void* q, const void* k, const void* v, const uint8_t*
   if (fs) {
     sa.next_key = fs->next_key; sa.nk = cc_next_key_slots(S);
     // entries any writer may have left non-~0: one per combine block (two-launch step), one per wave of the single-launch workgroups
-    sa.nk_read = one_shape_ok(p, HQ, H, D, dtype) ? (p.n_split * p.nw > p.n_chunks ? p.n_split * p.nw : p.n_chunks) : p.n_chunks;
+    {
+      // (KEY1: the single-tile steps but the hybrid one leave one key per workgroup)
+      const int nt1 = one_tiles(p, HQ, H, D, dtype);
+      const int per_wg = (CC_V_KEY1 != 0 && nt1 == 1 && kind != 200) ? 1 : p.nw;
+      sa.nk_read = nt1 > 0 ? (p.n_split * per_wg > p.n_chunks ? p.n_split * per_wg : p.n_chunks) : p.n_chunks;
+    }
     if (sa.nk_read > sa.nk) sa.nk_read = sa.nk; sa.input_pos = fs->input_pos; sa.k_new = fs->k_new; sa.v_new = fs->v_new;
     sa.pos = fs->c->pos; sa.mask_w = fs->c->mask; sa.cache_cts = fs->c->cache_cts; sa.num = hh_num; sa.denom = hh_denom;
     sa.H = H; sa.Hc = fs->c->Hc; sa.Hp = fs->c->Hp;

@@ -123,61 +123,43 @@ def main():
             t = trace.cpu().numpy().astype(np.int64)
             used = t[:, 0] != 0
             t = t[used]
-            t0 = t[:, 0].min()
-            rel = (t[:, :6] - t0).astype(np.float64)
-            span = rel[:, 5].max()
-            names = ["start", "stream_done", "published", "sentinel_seen", "gathered", "end"]
-            out = {"S": S, "quant": bool(a.quant), "hybrid": bool(a.hybrid), "policy": a.policy or ("hybrid" if a.hybrid else "heavy_hitter"), "abl": abl, "us_per_launch_events": round(us_per, 2), "workgroups": int(used.sum()),
-                   "ticks_total": float(span)}
+            # s_memtime (columns 0-5, 11-15) is a per-XCD clock: only differences INSIDE a workgroup mean anything (r3's summary
+            # subtracted a global minimum across XCDs from some columns: garbage means).  s_memrealtime (columns 6-8,
+            # 100 MHz) is one clock for the device: it places the workgroups' starts and ends against each other.
+            out = {"S": S, "quant": bool(a.quant), "hybrid": bool(a.hybrid), "policy": a.policy or ("hybrid" if a.hybrid else "heavy_hitter"),
+                   "abl": abl, "us_per_launch_events": round(us_per, 2), "workgroups": int(used.sum())}
             base = t[:, 6].min()
-            r0, r1, r2 = t[:, 6] - base, t[:, 7] - base, t[:, 8] - base
+            r0, r1, r2 = (t[:, 6] - base) / 100.0, (t[:, 7] - base) / 100.0, (t[:, 8] - base) / 100.0  # us on the device clock
+            # ticks of s_memtime per microsecond, from each workgroup's own (start, end) pair on both clocks
+            tpu = float(np.median((t[:, 5] - t[:, 0]) / np.maximum(r2 - r0, 1e-3)))
+            out["memtime_ticks_per_us"] = round(tpu, 1)
             hw, xcc = t[:, 9], t[:, 10] & 15
             cu = ((hw >> 8) & 15) | (((hw >> 12) & 1) << 4) | (((hw >> 13) & 7) << 5) | (xcc << 8)  # cu, sh, se, xcc
             out["distinct_cus"] = int(len(np.unique(cu)))
-            out["stream_done_hist_500ns"] = np.bincount((r1 // 50).astype(np.int64)).tolist()
-            out["stream_done_by_xcc_mean"] = [round(float(r1[xcc == x].mean()), 1) for x in range(8)]
-            out["stream_done_by_xcc_max"] = [int(r1[xcc == x].max()) for x in range(8)]
-            # first / second workgroup on the same CU (by start time)
-            first, second = [], []
-            for cid in np.unique(cu):
-                idx = np.where(cu == cid)[0]
-                idx = idx[np.argsort(r0[idx])]
-                if len(idx) >= 2:
-                    first.append(r1[idx[0]]); second.append(r1[idx[1]])
-            if first:
-                out["cu_first_wg_stream_done_mean_max"] = [round(float(np.mean(first)), 1), int(np.max(first))]
-                out["cu_second_wg_stream_done_mean_max"] = [round(float(np.mean(second)), 1), int(np.max(second))]
-            late = np.argsort(-r1)[:12]
-            out["latest"] = [[int(r1[i]), int(i // (len(r1) // H)), int(i % (len(r1) // H)), int(xcc[i]), int(cu[i] & 255)] for i in late]
-            out["realtime_10ns"] = {"start": [int(r0.min()), float(r0.mean()), int(r0.max())],
-                                    "stream_done": [int(r1.min()), float(r1.mean()), int(r1.max())],
-                                    "end": [int(r2.min()), float(r2.mean()), int(r2.max())]}
-            # per-head: when did the LAST workgroup of the head publish, and how long after that did the head's workgroups finish
             nsplit = int(used.sum()) // H
-            ph_ = rel.reshape(H, nsplit, 6)
-            out["stream_mean"] = round(float((ph_[:, :, 1] - ph_[:, :, 0]).mean()), 1)
-            out["publish_mean"] = round(float((ph_[:, :, 2] - ph_[:, :, 1]).mean()), 1)
-            out["sentinel_wait_mean"] = round(float((ph_[:, :, 3] - ph_[:, :, 2]).mean()), 1)
-            hr1 = r1.reshape(H, nsplit)
-            out["head_stream_done_spread_10ns"] = round(float((hr1.max(axis=1) - hr1.min(axis=1)).mean()), 1)
-            out["end_minus_head_last_stream_done_10ns"] = round(float((r2.reshape(H, nsplit).max(axis=1) - hr1.max(axis=1)).mean()), 1)
-            out["gather_rtt_mean"] = round(float((ph_[:, :, 4] - ph_[:, :, 3]).mean()), 1)
-            out["finish_mean"] = round(float((ph_[:, :, 5] - ph_[:, :, 4]).mean()), 1)
-            if t.shape[1] > 13 and (t[:, 11] != 0).all():  # wave 0 of every workgroup, ticks since its start
-                for nm, col in (("k_arrived", 11), ("scores_ready", 12), ("pv_issued", 13)):
-                    d_ = (t[:, col] - t[:, 0]).astype(np.float64)
-                    out[nm + "_min_mean_max"] = [float(d_.min()), round(float(d_.mean()), 1), float(d_.max())]
-                if t.shape[1] > 15 and (t[:, 14] != 0).all():
-                    out["finish_ML_weights_mean"] = round(float((t[:, 14] - t[:, 4]).mean()), 1)
-                    out["finish_slots_y_keys_mean"] = round(float((t[:, 15] - t[:, 14]).mean()), 1)
-                    # r3, early (m, l): [4] = (m, l) gathered, [14] = final (M, L) visible to every wave, [15] = partial-O gather
-                    # complete (the per-slot pass ran in its shadow), [5] = end -> what is left behind the last O granule
-                    out["tail_behind_o_gather_mean_max"] = [round(float((t[:, 5] - t[:, 15]).mean()), 1), float((t[:, 5] - t[:, 15]).max())]
-                    out["o_gather_done_min_mean_max"] = [float((t[:, 15] - t0).min()), round(float((t[:, 15] - t0).mean()), 1), float((t[:, 15] - t0).max())]
-                    out["ml_gather_done_min_mean_max"] = [float((t[:, 4] - t0).min()), round(float((t[:, 4] - t0).mean()), 1), float((t[:, 4] - t0).max())]
-                    out["end_min_mean_max"] = [float((t[:, 5] - t0).min()), round(float((t[:, 5] - t0).mean()), 1), float((t[:, 5] - t0).max())]
-                d_ = (t[:, 1] - t[:, 0]).astype(np.float64)
-                out["stream_done_min_mean_max"] = [float(d_.min()), round(float(d_.mean()), 1), float(d_.max())]
+            xh = xcc.reshape(H, nsplit)
+            out["xcds_per_kv_head"] = [int(len(np.unique(xh[h_]))) for h_ in range(H)]
+
+            def mmm(v):
+                return [round(float(np.min(v)), 2), round(float(np.mean(v)), 2), round(float(np.max(v)), 2)]
+
+            out["start_us_min_mean_max"] = mmm(r0)
+            out["end_us_min_mean_max"] = mmm(r2)
+            out["launch_span_us"] = round(float(r2.max() - r0.min()), 2)
+            out["gap_to_next_launch_us"] = round(us_per - float(r2.max() - r0.min()), 2)
+            # phases of a workgroup (wave 0), microseconds since ITS start
+            cols = [("k_arrived", 11), ("scores_ready", 12), ("pv_issued", 13), ("merge_barrier_passed", 1), ("o_published", 2),
+                    ("ml_gathered", 4), ("ML_visible", 14), ("o_gathered", 15), ("end", 5)]
+            ph = {}
+            for nm, col in cols:
+                if (t[:, col] != 0).all():
+                    ph[nm] = mmm((t[:, col] - t[:, 0]) / tpu)
+            out["since_own_start_us_min_mean_max"] = ph
+            # per kv head: the LAST workgroup's merge barrier on the device clock, and what follows it until the head's last end
+            hr1, hr2 = r1.reshape(H, nsplit), r2.reshape(H, nsplit)
+            out["head_last_merge_barrier_us"] = [round(float(x), 2) for x in hr1.max(axis=1)]
+            out["head_end_minus_last_merge_barrier_us"] = [round(float(x), 2) for x in (hr2.max(axis=1) - hr1.max(axis=1))]
+            out["head_merge_barrier_spread_us"] = round(float((hr1.max(axis=1) - hr1.min(axis=1)).mean()), 2)
             print(json.dumps(out), flush=True)
 
 
