@@ -79,6 +79,9 @@ SIGNATURES = {
     "cc_decode_step_trace": (None, [_vp]),
     "cc_decode_step_set_single_launch": (None, [_i32]),
     "cc_decode_step_set_wide": (None, [_i32]),
+    "cc_decode_step_probe_xcd": (_i32, []),
+    "cc_decode_step_set_l2_handoff": (None, [_i32]),
+    "cc_decode_step_l2_handoff": (_i32, []),
     "cc_decode_step_heavy_hitter_rc": (C.c_int, [_view, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _sz,
                                                  _vp, _i32]),
     "cc_debug_occupy": (C.c_int, [_i32, _i32, _i32, _vp, _vp]),
@@ -142,7 +145,7 @@ SIGNATURES = {
 
 # entry points that only the device library has (no `_cpu` twin)
 DEVICE_ONLY = {"cc_error_string", "cc_device_info", "cc_decode_step_single_launch", "cc_decode_step_status_offset",
-               "cc_decode_step_trace", "cc_decode_step_set_single_launch", "cc_decode_step_set_wide", "cc_decode_step_stream_floor", "cc_debug_occupy", "cc_decode_step_quant_single_launch",
+               "cc_decode_step_trace", "cc_decode_step_set_single_launch", "cc_decode_step_set_wide", "cc_decode_step_probe_xcd", "cc_decode_step_set_l2_handoff", "cc_decode_step_l2_handoff", "cc_decode_step_stream_floor", "cc_debug_occupy", "cc_decode_step_quant_single_launch",
                "cc_decode_step_hybrid_single_launch",
                # inter-GPU transport: no CPU twin (the oracle of the all-reduce is torch.distributed's)
                "cc_allreduce_handle_bytes", "cc_allreduce_create", "cc_allreduce_export", "cc_allreduce_connect", "cc_allreduce_sum",
@@ -185,7 +188,24 @@ def lib():
         v = _FNS["cc_abi_version"]()
         if v != 1:
             raise ColdCompressError(f"ABI version mismatch: library {v}, python 1")
+        probe_device()
     return _FNS
+
+
+def probe_device():
+    """Observe the current device's block -> XCD dispatch order once (cc_decode_step_probe_xcd: synchronous, outside capture): where
+    it is verified, caches with a multiple of 8 kv heads run their single-tile step with the L2-resident hand-off
+    (include/coldcompress.h).  No GPU: nothing happens.  Called when the library is loaded and when a decode workspace is created."""
+    if _FNS is None:
+        return 0
+    try:
+        import torch
+
+        if not torch.cuda.is_available() or torch.cuda.is_current_stream_capturing():
+            return 0
+    except Exception:  # pragma: no cover
+        return 0
+    return int(_FNS["cc_decode_step_probe_xcd"]())
 
 
 def check(code, what):

@@ -52,6 +52,9 @@ def _workspace(nbytes, device, kind="decode"):
             _RETIRED.append((kind, ws))
         ws = torch.zeros(max(nbytes, 1), dtype=torch.uint8, device=device)
         _WS[key] = ws
+        if kind == "decode" and torch.device(device).type == "cuda":  # (per device, cached: the L2-resident hand-off's eligibility)
+            with torch.cuda.device(torch.device(device)):
+                _abi.probe_device()
     return ws
 
 
@@ -100,14 +103,19 @@ def reset_single_launch_status(device=None):
         torch.cuda.synchronize()
 
 
+def raise_single_launch_failure(device=None):
+    """Clear the (sticky) status word — reported once; the next generation starts clean — and raise."""
+    reset_single_launch_status(device)
+    raise ColdCompressError(
+        "a single-launch layer step did not complete its in-launch hand-off (its workgroups were not all resident, e.g. the "
+        "GPU was shared with another kernel): the tokens produced since are invalid.  Disable the single-launch form with "
+        "cc_decode_step_set_single_launch(0) (or KVCacheHeavyHitter.single_launch = False) when the device is shared.")
+
+
 def check_single_launch_status(device=None):
     """Raise loudly if a single-launch step timed out (see single_launch_status)."""
     if single_launch_status(device):
-        reset_single_launch_status(device)  # reported once: the word is sticky on the device, the next generation starts clean
-        raise ColdCompressError(
-            "a single-launch layer step did not complete its in-launch hand-off (its workgroups were not all resident, e.g. the "
-            "GPU was shared with another kernel): the tokens produced since are invalid.  Disable the single-launch form with "
-            "cc_decode_step_set_single_launch(0) (or KVCacheHeavyHitter.single_launch = False) when the device is shared.")
+        raise_single_launch_failure(device)
 
 
 def decode_attention(query, key, value, attn_mask=None, scale=None, return_attn=False, group_mean=False,

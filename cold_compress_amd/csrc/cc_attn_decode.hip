@@ -23,39 +23,17 @@
 #include "cc_common.h"
 #include "cc_wacc.h"
 
-// ---- A/B switches of round 4 (tools/ab_variant.sh NAME "-DCC_V_...=1"); the defaults are what the product runs
-#ifndef CC_V_OEARLY
-#define CC_V_OEARLY 0   // 1: round 0 of the partial-O gather goes out ahead of the final (M, L) fold; 2: right behind the publish
-#endif
+// ---- A/B switches (tools/ab_variant.sh NAME "-DCC_V_...=0"): the defaults are what the product runs.  Round 4 measured each on one
+//      box against its absence (profiles/r04_ab_step_variants.md); the switches that lost (early partial-O polls, one key per
+//      workgroup, precomputed merge factors, bulk requests moved up, longer sleeps) are gone from the source (commit a08483f has them).
 #ifndef CC_V_PRO
-#define CC_V_PRO 0      // prologue diet: unconditional key-row loads, K rows requested ahead of the mask word
-#endif
-#ifndef CC_V_KEY1
-#define CC_V_KEY1 0     // one next-eviction key per WORKGROUP (folded across the waves in LDS) instead of one per wave
+#define CC_V_PRO 1      // prologue diet: unconditional key-row loads, K rows requested ahead of the mask word
 #endif
 #ifndef CC_V_LDSDMA
-#define CC_V_LDSDMA 0   // K / V tiles land in the LDS slabs directly (global_load_lds_dwordx4): no staging registers, no ds_write
+#define CC_V_LDSDMA 1   // K / V tiles land in the wave's LDS slabs directly (buffer_load ... lds): no staging registers, no ds_write
 #endif
 #ifndef CC_V_MLW
-#define CC_V_MLW 0      // the final (M, L) fold runs on the workgroup's LAST waves (idle during the partial-O publish of the first ones)
-#endif
-#ifndef CC_V_MLE
-#define CC_V_MLE 0      // round 0 of the (m, l) gather goes out AHEAD of the merge barrier (the pairs left behind the scores, long ago)
-#endif
-#ifndef CC_V_MF
-#define CC_V_MF 0       // the waves' merge factors exp(m_w - M) are computed once (by the (m, l) publisher) instead of by every publishing thread
-#endif
-#ifndef CC_V_VEARLY
-#define CC_V_VEARLY 0   // DMA: the V rows are requested right behind the K rows
-#endif
-#ifndef CC_V_KTOP
-#define CC_V_KTOP 0     // DMA: the K rows are requested ahead of the key row
-#endif
-#ifndef CC_V_SLEEP
-#define CC_V_SLEEP 1    // s_sleep argument between rounds of the early-(m, l) step's two gathers (64 cycles each)
-#endif
-#ifndef CC_V_XCD
-#define CC_V_XCD 0      // 1: the workgroups of kv head h sit on XCD h % 8; 2: ... and the gathers poll the XCD's L2 first
+#define CC_V_MLW 1      // the final (M, L) fold runs on the workgroup's LAST waves (idle during the partial-O publish of the first ones)
 #endif
 
 namespace {
@@ -683,7 +661,7 @@ struct IntC {
 // are what the product runs: ~30 never-taken branches and their live ranges less is 0.25-0.5 us of the step (A/B on one box:
 // heavy hitter 10.65 -> 10.38 us, the fused uint8 step 10.35 -> 9.85); a call that wants a stamp, an ablation bit or attn_out is
 // routed to a FULL instantiation (bf16, four query heads per kv head) or to the two-launch step.
-template <typename T, int RT, int NW, bool L2, bool ONE = false, bool HYB = false, int QB = 0, int NSUB = 1, int NT = 1, bool FULL = !ONE>
+template <typename T, int RT, int NW, bool L2, bool ONE = false, bool HYB = false, int QB = 0, int NSUB = 1, int NT = 1, bool FULL = !ONE, bool XL2 = false>
 __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_split_mfma_kernel(SplitArgs a) {
   static_assert(!(HYB && L2), "the hybrid decision rides the plain streaming pass or the single-launch step");
   static_assert(QB == 0 || (QB == 8 && !L2 && !HYB), "fused quantised cache: 8 bits, heavy hitter / recent_global / random");
@@ -703,6 +681,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
   static_assert(!ONE || NW == 4 || (NW == 8 && NT == 1), "the single-launch step runs on 4-wave workgroups, or on ONE 8-wave workgroup per CU (single tile)");
   constexpr int D = 128, VEC = 8, RPW = 4, U = 4;
   static_assert(FULL || ONE, "the lean form exists for the single-launch step only");
+  static_assert(!XL2 || EML, "the L2-resident hand-off rides the early-(m, l) single-tile steps");
   if constexpr (!FULL) {  // constants for the optimiser: every `if (a.trace)`, `a.abl & ...`, `if (a.attn_out)` below folds away
     a.trace = nullptr;
     a.abl = 0;
@@ -714,7 +693,6 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
   __shared__ __attribute__((aligned(16))) uint4 sm_k[NW][16][16];  // [wave][tile row i][slot]: 4 KiB per wave
   __shared__ __attribute__((aligned(16))) uint4 sm_v[NW][16][16];  // [wave][tile row][chunk ^ 2*(row & 7)]: V tile, row major
   __shared__ float sm_wm[NW][RT], sm_wl[NW][RT];  // the waves' softmax state per query head (merged across the workgroup)
-  __shared__ float sm_wf[NW][RT];                  // EML + MF: exp(m_w - M) of the workgroup's merge, written once by the (m, l) publisher
   __shared__ unsigned sm_mlcnt;                    // EML: waves whose (m, l) rows are in LDS — the LAST one to arrive publishes
   __shared__ unsigned sm_fail;                     // EML: some wave of this workgroup gave up waiting (recoverable hand-off)
   __shared__ float sm_l2w[NW];  // ONE + L2: per-wave maxima of the norms this workgroup's slots hold AFTER the step's insert
@@ -722,15 +700,19 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, c = lane & 15;  // row group of the wave / 16-byte column chunk (and MFMA column n)
   int split_ = blockIdx.x, h_ = blockIdx.y;
-  if constexpr (CC_V_XCD != 0 && ONE1 && !HYB) {
-    // workgroup b of the grid is dispatched to XCD b % 8 (observed; used for speed only): with kv head = b % H every workgroup of a
-    // kv head sits on XCD h % 8 and the hand-off of a head stays inside one XCD (H a multiple of 8; other head counts keep the
-    // dispatch order).  Cost: heads interleave in dispatch order, so EVERY head needs all workgroups of the launch resident.
-    if ((gridDim.y & 7) == 0) {
-      const int b = blockIdx.x + gridDim.x * blockIdx.y;
-      h_ = b % (int)gridDim.y;
-      split_ = b / (int)gridDim.y;
-    }
+  if constexpr (XL2) {
+    // XL2 — placement.  The dispatcher deals the blocks of a grid to the XCDs round-robin in block order: blocks b and b + 8 of a
+    // launch always share an XCD (cc_decode_step_probe_xcd observes exactly this relation on the device before this instantiation is
+    // ever chosen; WHICH XCD block 0 lands on depends on what was dispatched before — measured, r4: a table of absolute XCC ids
+    // taken by a probe launch does not hold for a later launch — so nothing here depends on it).  With kv head = b % H, H a multiple
+    // of 8, all workgroups of a kv head sit on ONE XCD, and the head's hand-off — its own (m, l) and partial-O granules — goes
+    // through that XCD's L2 (plain stores, sc1 polls) instead of through memory.  Heads interleave in dispatch order: every head
+    // needs ALL workgroups of the launch resident (the launcher checks the capacity).  Should the relation ever not hold for a
+    // launch (grids of two queues dealt alternately, say), a head's workgroups do not see each other's granules: the bounded wait
+    // ends the step as a recoverable failure and the host falls back to the memory hand-off (harness._recover_token).
+    const int b = blockIdx.x + gridDim.x * blockIdx.y;
+    h_ = b % (int)gridDim.y;
+    split_ = b / (int)gridDim.y;
   }
   const int split = split_, h = h_, q0 = h * a.R + blockIdx.z * RT;
   const int S = a.S;
@@ -894,16 +876,6 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
       if (a.commit) rc_commit = a.commit[h];
     }
   };
-  if constexpr (DMA && CC_V_KTOP != 0) {  // (A/B) the K rows ahead of everything else
-    load_step_words();
-    __builtin_amdgcn_sched_barrier(0);
-    issue_k(tregs[0], base);
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (CC_V_VEARLY != 0) {
-      issue_v(tregs[0], base);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
   if (key_pending) {
     // KEY ROWS (late r3).  Every kv head reads — and at the end of the step rewrites — ITS OWN row, also under the head-constant
     // policies, whose rows all hold the same keys.  They used to share row 0, rewritten by kv head 0's waves once THEIR head's
@@ -933,20 +905,18 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
       key_part = x < key_part ? x : key_part;
     }
   }
-  if constexpr (DMA && CC_V_KTOP == 0) {
+  if constexpr (DMA) {
     // the step's wave-uniform words are requested AHEAD of the first DMA load: behind it they could no longer travel as scalar
     // loads (the compiler must assume the DMA writes memory they read) and would become vector loads with a wait for the whole tile
     load_step_words();
     __builtin_amdgcn_sched_barrier(0);
   }
-  if constexpr (KEARLY && !(DMA && CC_V_KTOP != 0)) {
+  if constexpr (KEARLY) {
     issue_k(tregs[0], base);
     __builtin_amdgcn_sched_barrier(0);  // (keeps the scheduler from sinking them back to the rest of the tile)
-    if constexpr (DMA && CC_V_VEARLY != 0) {
-      issue_v(tregs[0], base);
-      __builtin_amdgcn_sched_barrier(0);
-    }
   }
+  // (r4, with the DMA loads: the V rows right behind the K rows +0.4 us, the K rows ahead of the key row +0.35, both +0.8 — whatever
+  //  is requested behind the bulk (q, mask word, per-slot state) is usable only when the bulk has landed: loads return in order)
   // HYB: everything the per-head decision needs besides the candidate key — the policy table (ALL rows: one vector load, the
   // head's row is picked by a lane read once its policy index has arrived), the punctuation ids (one id per lane), the head's
   // policy index and count, the budget terms, the incoming token — as FIRST-LEVEL loads issued here, ahead of q and the tile.
@@ -1132,7 +1102,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
   for (int sub = 0; sub < NSUB; sub++) {
     if constexpr (!KEARLY) issue_k(tregs[sub], base + sub * NW * RPW * U);
     if constexpr (QB) __builtin_amdgcn_sched_barrier(0);  // K's bytes and parameters go out BEFORE V's: the K stash waits for them only
-    if constexpr (!(DMA && CC_V_VEARLY != 0)) issue_v(tregs[sub], base + sub * NW * RPW * U);
+    issue_v(tregs[sub], base + sub * NW * RPW * U);
     if constexpr (QB) __builtin_amdgcn_sched_barrier(0);
   }
   // ONE + L2: the epoch words of the kv heads whose norm granules this thread will gather.  Read HERE (behind the tile's loads: three integer divisions kept out of the way of the first K rows): every workgroup has read
@@ -1498,11 +1468,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
         const float Mu = (M == -INFINITY) ? 0.f : M;
         float L = 0.f;
 #pragma unroll
-        for (int w = 0; w < NW; w++) {
-          const float f = fast_exp(sm_wm[w][r] - Mu);
-          if constexpr (CC_V_MF != 0) sm_wf[w][r] = f;  // (the same factor the partial-O merge below would compute)
-          L = fmaf(sm_wl[w][r], f, L);
-        }
+        for (int w = 0; w < NW; w++) L = fmaf(sm_wl[w][r], fast_exp(sm_wm[w][r] - Mu), L);
         ml_M = M;
         ml_L = L;
       }
@@ -1514,7 +1480,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
         const u32x4_t mg = {one_tag, __float_as_uint(ml_M), one_tag, __float_as_uint(ml_L)};
         const auto ml_rsrc_e = __builtin_amdgcn_make_buffer_rsrc(a.one_ml, 0, (int)a.one_ml_bytes, 0x00020000);
         const int off = ml_last ? h * kOneMlHead + (split * RT + lane) * 16 : 0x7ffffff0;
-        __builtin_amdgcn_raw_buffer_store_b128(mg, ml_rsrc_e, off, 0, (CC_V_XCD == 3 && !L2) ? 0 : ((CC_V_XCD == 4 && !L2) ? 16 : kOneAuxCoherent));
+        __builtin_amdgcn_raw_buffer_store_b128(mg, ml_rsrc_e, off, 0, XL2 ? 0 : kOneAuxCoherent);
         if constexpr (L2) {  // l2: the workgroup's norm maximum leaves with the pairs (same unconditional form; lane RT of the publisher)
           float wm = -INFINITY;
           bool nn = false;
@@ -1598,22 +1564,6 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
         *reinterpret_cast<float4*>(&sm_wacc[wave][c][16 * b + 4 * g]) = make_float4(acc[b][0], acc[b][1], acc[b][2], acc[b][3]);
     }
   }
-  // MLE: round 0 of the (m, l) gather ahead of the merge barrier (same addresses as below)
-  constexpr int MLN_PRE = (RT + NW - 1) / NW;
-  u32x4_t mlq_pre[MLN_PRE];
-  if constexpr (EML && CC_V_MLE != 0) {
-    constexpr int ML_W0p = (CC_V_MLW != 0 && NW >= 2 * RT) ? NW - RT : 0;
-    const int ml_wp = wave - ML_W0p;
-    const auto ml_rsrc_p = __builtin_amdgcn_make_buffer_rsrc(a.one_ml, 0, (int)a.one_ml_bytes, 0x00020000);
-    constexpr int kGatherAuxP = (CC_V_XCD >= 2 && !L2) ? 16 : kOneAuxCoherent;
-    if (ml_wp >= 0 && ml_wp < RT) {
-#pragma unroll
-      for (int k = 0; k < MLN_PRE; k++)
-        mlq_pre[k] = __builtin_amdgcn_raw_buffer_load_b128(
-            ml_rsrc_p, h * kOneMlHead + ((lane < a.n_split ? lane : 0) * RT + (ml_wp + k * NW < RT ? ml_wp + k * NW : 0)) * 16, 0, kGatherAuxP);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  }
   __syncthreads();
   if constexpr (ONE) {
     // ============================================================================================================
@@ -1633,10 +1583,10 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
     // timeout word should that ever not hold.
     const int ns = a.n_split;
     const unsigned tag = one_tag;
-    // (CC_V_XCD == 2, A/B only: the gathers of a kv head's own granules poll the XCD's L2 — sc1 — which sees the head's write-through
-    //  stores only while all of its workgroups sit on that XCD)
-    constexpr int kGatherAux = (CC_V_XCD >= 2 && EML && !L2) ? 16 : kOneAuxCoherent;
-    constexpr int kPublishAux = (CC_V_XCD == 3 && EML && !L2) ? 0 : ((CC_V_XCD == 4 && EML && !L2) ? 16 : kOneAuxCoherent);  // (4: sc1 stores)  // (3: plain stores: the granules stay in the XCD's L2)
+    // XL2: a kv head's own granules never leave its XCD — plain stores (they stay in the L2), sc1 polls (past the L1, served by the
+    // L2).  The l2 policy's norm maxima cross kv heads, hence XCDs: they keep the write-through / memory-scope form.
+    constexpr int kGatherAux = XL2 ? 16 : kOneAuxCoherent;
+    constexpr int kPublishAux = XL2 ? 0 : kOneAuxCoherent;
     if constexpr (L2 && !EML) {
       // the epoch words of the other heads (requested behind the tile's loads) must have ARRIVED before this workgroup publishes:
       // whoever bumps a word does so only after every workgroup of the launch has published
@@ -1683,10 +1633,6 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
     if constexpr (EML) {
       // the (m, l) pairs left behind the scores, long ago: their first round of loads goes out AHEAD of this workgroup's partial-O
       // stores (loads return in order: behind the stores they would also wait for the stores' acknowledgements, a round trip)
-      if constexpr (CC_V_MLE != 0) {
-#pragma unroll
-        for (int k = 0; k < MLN; k++) mlq[k] = mlq_pre[k];
-      } else
       if (ml_w >= 0 && ml_w < RT) {
 #pragma unroll
         for (int k = 0; k < MLN; k++) mlq[k] = __builtin_amdgcn_raw_buffer_load_b128(ml_rsrc, ml_off[k], 0, kGatherAux);
@@ -1700,18 +1646,6 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
     // ---- publish: thread t merges output columns 2t, 2t + 1 of the workgroup's partial (the arithmetic of the
     //      two-launch epilogue below) and stores them as one granule
     for (int o2 = (int)threadIdx.x * 2; o2 < RT * D; o2 += 2 * NW * 64) {
-      if constexpr (CC_V_MF != 0 && EML) {
-        const int r = o2 / D, d = o2 - r * D;
-        float O0 = 0.f, O1 = 0.f;
-#pragma unroll
-        for (int w = 0; w < NW; w++) {  // fixed order: deterministic; the factors are the ones this loop used to compute per thread
-          const float f = sm_wf[w][r];
-          O0 = fmaf(sm_wacc[w][r][d], f, O0);
-          O1 = fmaf(sm_wacc[w][r][d + 1], f, O1);
-        }
-        const u32x4_t og = {tag, __float_as_uint(O0), tag, __float_as_uint(O1)};
-        __builtin_amdgcn_raw_buffer_store_b128(og, o_rsrc, h * kOneOHead + ((r * ns + split) * 64 + (d >> 1)) * 16, 0, kPublishAux);
-      } else
       {
         const int r = o2 / D, d = o2 - r * D;
         float M = sm_wm[0][r];
@@ -1856,11 +1790,6 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
     __shared__ float sm_l2g[NW];  // l2: per-wave fold of the gathered norm maxima (NaN propagates: torch.max)
     unsigned long long trD = 0, trE = 0;
     if constexpr (EML) {
-      if constexpr (CC_V_OEARLY == 2) {  // round 0 of the partial-O gather right behind this workgroup's own publish
-        asm volatile("" ::: "memory");
-        load_o();
-        __builtin_amdgcn_sched_barrier(0);
-      }
       // ---- the (m, l) pairs left behind the scores: most of them are there by now.  Only the waves that fold a head poll.
       const bool ml_mine = ml_w >= 0 && ml_w < RT;  // (MLN == 1 whenever RT <= NW; with RT = 8 on four waves every wave folds two heads)
       // Round 0 (issued ahead of the partial-O stores) is examined in STRAIGHT-LINE code: the compiler then waits for exactly
@@ -1873,13 +1802,21 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
         return ok;
       };
       bool ml_ok = (!ml_mine || __all(ok_ml())) && (!L2 || __all(ok_nm()));
+      bool peer_failed = false;
       for (unsigned spins = 0; !ml_ok; spins++) {
         if (spins > kOneSpinMax) {
           timed_out = true;
           break;
         }
-        __builtin_amdgcn_s_sleep(CC_V_SLEEP);
+        __builtin_amdgcn_s_sleep(1);
         asm volatile("" ::: "memory");  // every round re-reads memory
+        if constexpr (RC) {  // a workgroup of this head gave up (memory scope: it may sit on another XCD): nothing left to wait for
+          failq = __builtin_amdgcn_raw_buffer_load_b32(hdr_rsrc, (kOneFailWord + h) * 4, 0, kOneAuxCoherent);
+          if (failq == tag) {
+            peer_failed = true;
+            break;
+          }
+        }
         if (ml_mine) load_ml();
 #pragma unroll
         for (int k = 0; k < NLG; k++)
@@ -1887,12 +1824,8 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
         ml_ok = (!ml_mine || __all(ok_ml())) && (!L2 || __all(ok_nm()));
       }
       if (timed_out) give_up();
+      else if (peer_failed && lane == 0) sm_fail = 1u;
       if (a.trace) tr4 = __builtin_amdgcn_s_memtime();
-      if constexpr (CC_V_OEARLY == 1) {  // round 0 of the partial-O gather flies during the final (M, L) fold and its barrier too
-        asm volatile("" ::: "memory");
-        load_o();
-        __builtin_amdgcn_sched_barrier(0);
-      }
       if (ml_mine) final_ml();
       if constexpr (L2) {  // the wave's fold of the gathered norm maxima (NaN propagates: torch.max)
         float gm = -INFINITY;
@@ -1950,7 +1883,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
       if (a.trace) trD = __builtin_amdgcn_s_memtime();
       y_fold();
     }
-    if constexpr (EML && CC_V_OEARLY == 0) {
+    if constexpr (EML) {
       // the first round of the partial-O gather goes out HERE and flies while the per-slot pass runs: what is left behind the last O
       // granule of the head is the y fold
       asm volatile("" ::: "memory");
@@ -2154,24 +2087,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
     // barrier of the finish, so no wave's stores wait for another wave (the launch ends a store round trip after the LAST
     // store is issued: every store that can go out early shortens it)
     const unsigned long long wk = wave_min_u64_uniform(my_key);
-    // KEY1: one key per WORKGROUP — the waves' keys meet in LDS in front of the finish's last barrier (in the shadow of the partial-O
-    // gather) and wave 0 stores their minimum: the next step's prologue reads n_split entries per kv head instead of NW x n_split
-    constexpr bool KEY1 = CC_V_KEY1 != 0 && EML;
-    __shared__ unsigned long long sm_wk[KEY1 ? NW : 1];
-    if constexpr (KEY1) {
-      if (lane == 0) sm_wk[wave] = wk;
-    }
     auto store_key = [&]() {
-      if constexpr (KEY1) {
-        if (wave == 0) {
-          const unsigned long long k8 = wave_min_u64_uniform(lane < NW ? sm_wk[lane] : ~0ull);
-          if (lane == 0) {
-            unsigned long long* nk_row = const_cast<unsigned long long*>(a.next_key) + (size_t)h * a.nk;
-            nk_row[split] = k8;
-            for (int s2 = split + ns; s2 < a.nk_read; s2 += ns) nk_row[s2] = ~0ull;
-          }
-        }
-      } else
       if (lane == 0) {
         unsigned long long* nk_row = const_cast<unsigned long long*>(a.next_key) + (size_t)h * a.nk;
         const int e0 = split * NW + wave;
@@ -2184,11 +2100,12 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
       __builtin_amdgcn_sched_barrier(0);
       for (unsigned spins = 0;; spins++) {
         if (__all(ok_o())) break;
+        if (RC && failq == tag) break;  // a workgroup of this head gave up: the head's step is not committed, nothing left to wait for
         if (spins > kOneSpinMax) {
           timed_out = true;
           break;
         }
-        __builtin_amdgcn_s_sleep(CC_V_SLEEP);
+        __builtin_amdgcn_s_sleep(1);
         asm volatile("" ::: "memory");  // every round re-reads memory
         load_o();
       }
@@ -2961,6 +2878,56 @@ static OneKernel one_kernel(int rt, int nt, int kind, bool full, int nw = kNW) {
 static OneKernel one_kernel_dt(int dtype, int rt, int nt, int kind, bool full, int nw) {
   return dtype == CC_DT_BF16 ? one_kernel<bf16_t>(rt, nt, kind, full, nw) : (dtype == CC_DT_F16 ? one_kernel<f16_t>(rt, nt, kind, full, nw) : nullptr);
 }
+// The XL2 instantiations (placement + L2-resident hand-off): single-tile steps of the plain 16-bit cache (kind 0), the fused
+// quantised cache (8) and l2 (-1), 4 or 8 query heads per kv head, 4- or 8-wave workgroups; FULL for bf16 / rt = 4 / kind 0 only.
+template <typename T>
+static OneKernel one_kernel_xl2(int rt, int kind, bool full, int nw) {
+#define CC_ONE_X(RT_, NW_, L2_, QB_, FULL_) decode_attn_split_mfma_kernel<T, RT_, NW_, L2_, true, false, QB_, 1, 1, FULL_, true>
+  if ((rt != 4 && rt != 8) || (nw != 4 && nw != 8) || (kind != 0 && kind != 8 && kind != -1)) return nullptr;
+  if (full) {
+    if constexpr (ElemTraits<T>::code != CC_DT_BF16) {
+      return nullptr;
+    } else {
+      if (rt != 4 || kind != 0) return nullptr;
+      return nw == 8 ? CC_ONE_X(4, 8, false, 0, true) : CC_ONE_X(4, 4, false, 0, true);
+    }
+  }
+  if (kind == 0) {
+    if (nw == 8) return rt == 8 ? CC_ONE_X(8, 8, false, 0, false) : CC_ONE_X(4, 8, false, 0, false);
+    return rt == 8 ? CC_ONE_X(8, 4, false, 0, false) : CC_ONE_X(4, 4, false, 0, false);
+  }
+  if (kind == 8) {
+    if (nw == 8) return rt == 8 ? CC_ONE_X(8, 8, false, 8, false) : CC_ONE_X(4, 8, false, 8, false);
+    return rt == 8 ? CC_ONE_X(8, 4, false, 8, false) : CC_ONE_X(4, 4, false, 8, false);
+  }
+  if (nw == 8) return rt == 8 ? CC_ONE_X(8, 8, true, 0, false) : CC_ONE_X(4, 8, true, 0, false);
+  return rt == 8 ? CC_ONE_X(8, 4, true, 0, false) : CC_ONE_X(4, 4, true, 0, false);
+#undef CC_ONE_X
+}
+static OneKernel one_kernel_xl2_dt(int dtype, int rt, int kind, bool full, int nw) {
+  return dtype == CC_DT_BF16 ? one_kernel_xl2<bf16_t>(rt, kind, full, nw) : (dtype == CC_DT_F16 ? one_kernel_xl2<f16_t>(rt, kind, full, nw) : nullptr);
+}
+
+// ---- XL2 eligibility of the device: does block b of a launch run on XCD (b % 8)'s fixed XCC?  Observed once per device by
+//      cc_decode_step_probe_xcd (a synchronous launch: never under stream capture — the Python layer calls it when it loads the
+//      library and when it creates a decode workspace); unknown = not eligible.
+constexpr int kMaxDevices = 64;
+struct XccProbe {
+  std::atomic<int> state{0};  // 0 unknown, 1 verified, 2 refuted / failed
+};
+static XccProbe g_xcc_probe[kMaxDevices];
+static int g_l2_handoff_enabled = 1;  // cc_decode_step_set_l2_handoff
+
+__global__ void xcc_probe_kernel(unsigned* out) {
+  if (threadIdx.x == 0)
+    out[blockIdx.x + gridDim.x * blockIdx.y] = (unsigned)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 15u;  // HW_REG_XCC_ID[3:0]
+}
+// -> true when the L2-resident hand-off may be used on the current device
+static bool xl2_device_ok() {
+  int dev = 0;
+  if (!g_l2_handoff_enabled || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return false;
+  return g_xcc_probe[dev].state.load(std::memory_order_acquire) == 1;
+}
 }  // namespace
 
 extern "C" {
@@ -2972,13 +2939,18 @@ size_t cc_decode_attn_workspace_bytes(int32_t HQ, int32_t H, int32_t S, int32_t 
 }
 
 // kind: see one_kernel.  Returns the kernel when the shape is eligible AND all its workgroups stay resident at once, else null.
-static OneKernel one_pick(int32_t HQ, int32_t H, int32_t S, int32_t D, int32_t dtype, int kind, bool full) {
+static OneKernel one_pick(int32_t HQ, int32_t H, int32_t S, int32_t D, int32_t dtype, int kind, bool full, bool allow_xl2 = false) {
   if (HQ <= 0 || H <= 0 || HQ % H || S <= 0 || D <= 0 || !cc_dt_ok(dtype)) return nullptr;
   const Plan p = make_plan(HQ, H, S, D, dtype, kind);
   const int nt = one_tiles(p, HQ, H, D, dtype);
   if (nt == 0) return nullptr;
   // l2: every thread gathers at most three workgroups' norm maxima
   if (kind == -1 && H * p.n_split > 3 * p.nw * 64) return nullptr;
+  // XL2 first: a multiple of 8 kv heads (each head's workgroups on one XCD) on a device whose dispatch order was verified
+  if (allow_xl2 && nt == 1 && (H & 7) == 0 && xl2_device_ok()) {
+    const OneKernel kx = one_kernel_xl2_dt(dtype, p.rt, kind, full, p.nw);
+    if (kx && p.n_split * H <= one_capacity(kx, p.nw * 64)) return kx;
+  }
   const OneKernel k = one_kernel_dt(dtype, p.rt, nt, kind, full, p.nw);
   if (!k) return nullptr;
   return p.n_split * H <= one_capacity(k, p.nw * 64) ? k : nullptr;
@@ -3007,6 +2979,46 @@ void cc_decode_step_set_single_launch(int32_t enabled) { g_one_enabled = enabled
 // everywhere.  Process-wide; change it only between steps of a cache whose fused pipeline is re-seeded (prepare_decode): the
 // geometry decides which entries of a head's key row are live.
 void cc_decode_step_set_wide(int32_t enabled) { g_wide_enabled = enabled ? 1 : 0; }
+
+// The L2-resident hand-off (XL2): on by default where cc_decode_step_probe_xcd verified the device; 0 = always the memory hand-off
+// (the fallback of a step that fails with it — a kernel captured into a hipGraph keeps the form it was captured with).
+void cc_decode_step_set_l2_handoff(int32_t enabled) { g_l2_handoff_enabled = enabled ? 1 : 0; }
+int32_t cc_decode_step_l2_handoff(void) { return xl2_device_ok() ? 1 : 0; }
+// Observe where the dispatcher puts the blocks of a 2-D grid on the CURRENT device: synchronous (its own stream, one small
+// allocation) — call it outside stream capture.  1 = block b always ran on the XCC of block b % 8 (two grid shapes, two launches
+// each): the XL2 instantiations may be used; 0 = not so, or the probe could not run: they never are.  Cached per device.
+int32_t cc_decode_step_probe_xcd(void) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return 0;
+  XccProbe& pr = g_xcc_probe[dev];
+  const int st0 = pr.state.load(std::memory_order_acquire);
+  if (st0 != 0) return st0 == 1 ? 1 : 0;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
+  if (pr.state.load(std::memory_order_acquire) != 0) return pr.state.load() == 1 ? 1 : 0;
+  constexpr int kMaxBlocks = 64 * 16;
+  unsigned* dbuf = nullptr;
+  hipStream_t st = nullptr;
+  bool ok = hipMalloc(&dbuf, kMaxBlocks * sizeof(unsigned)) == hipSuccess && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
+  unsigned host[kMaxBlocks];
+  int launches = 0;
+  const int shapes[2][2] = {{32, 8}, {64, 16}};
+  for (int rep = 0; ok && rep < 4; rep++) {
+    const int gx = shapes[rep & 1][0], gy = shapes[rep & 1][1], nb = gx * gy;
+    hipLaunchKernelGGL(xcc_probe_kernel, dim3(gx, gy), dim3(512), 0, st, dbuf);
+    ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(host, dbuf, nb * sizeof(unsigned), hipMemcpyDeviceToHost, st) == hipSuccess &&
+         hipStreamSynchronize(st) == hipSuccess;
+    // the relation the placement needs, and nothing more: blocks b and b % 8 of ONE launch share an XCD (which XCD block 0 gets
+    // differs from launch to launch)
+    for (int b = 8; b < nb && ok; b++) ok = host[b] == host[b & 7];
+    launches += ok ? 1 : 0;
+  }
+  if (st) (void)hipStreamDestroy(st);
+  if (dbuf) (void)hipFree(dbuf);
+  (void)hipGetLastError();
+  pr.state.store(ok && launches == 4 ? 1 : 2, std::memory_order_release);
+  return ok && launches == 4 ? 1 : 0;
+}
 
 }  // extern "C"
 
@@ -3099,12 +3111,7 @@ static int attn_impl(const void* q, const void* k, const void* v, const uint8_t*
   if (fs) {
     sa.next_key = fs->next_key; sa.nk = cc_next_key_slots(S);
     // entries any writer may have left non-~0: one per combine block (two-launch step), one per wave of the single-launch workgroups
-    {
-      // (KEY1: the single-tile steps but the hybrid one leave one key per workgroup)
-      const int nt1 = one_tiles(p, HQ, H, D, dtype);
-      const int per_wg = (CC_V_KEY1 != 0 && nt1 == 1 && kind != 200) ? 1 : p.nw;
-      sa.nk_read = nt1 > 0 ? (p.n_split * per_wg > p.n_chunks ? p.n_split * per_wg : p.n_chunks) : p.n_chunks;
-    }
+    sa.nk_read = one_shape_ok(p, HQ, H, D, dtype) ? (p.n_split * p.nw > p.n_chunks ? p.n_split * p.nw : p.n_chunks) : p.n_chunks;
     if (sa.nk_read > sa.nk) sa.nk_read = sa.nk; sa.input_pos = fs->input_pos; sa.k_new = fs->k_new; sa.v_new = fs->v_new;
     sa.pos = fs->c->pos; sa.mask_w = fs->c->mask; sa.cache_cts = fs->c->cache_cts; sa.num = hh_num; sa.denom = hh_denom;
     sa.H = H; sa.Hc = fs->c->Hc; sa.Hp = fs->c->Hp;
@@ -3125,8 +3132,8 @@ static int attn_impl(const void* q, const void* k, const void* v, const uint8_t*
     const bool want_full = attn_out != nullptr || sa.abl != 0;
     OneKernel kern = nullptr;
     if (policy_ok && (!rh || fs->policy == 6) && !probs_out && !attn_out_needs_probs(fs, attn_out)) {
-      if (want_full || g_one_trace) kern = one_pick(HQ, H, S, D, dtype, kind, true);
-      if (!kern && !want_full) kern = one_pick(HQ, H, S, D, dtype, kind, false);
+      if (want_full || g_one_trace) kern = one_pick(HQ, H, S, D, dtype, kind, true, true);
+      if (!kern && !want_full) kern = one_pick(HQ, H, S, D, dtype, kind, false, true);
     }
     const bool one_ok = kern != nullptr;
     if (one_asked && !one_ok) return CC_ERR_UNSUPPORTED;

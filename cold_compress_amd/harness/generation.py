@@ -175,47 +175,168 @@ class GraphedDecoder:
         return self.out_tok, self.out_probs
 
 
+def _tp_world():
+    import torch.distributed as dist
+
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def _collective_status(dev):
+    """The single-launch status of `dev` — under tensor parallelism the MAXIMUM over the ranks (a collective: every rank calls it
+    at the same point, so every rank retries, raises or moves on TOGETHER; ADVICE r3: a rank-local verdict lets one rank re-run the
+    token's all-reduces while its peers have moved on)."""
+    from ..attention_utils import single_launch_status
+
+    st = int(single_launch_status(dev))
+    if _tp_world() > 1:
+        import torch.distributed as dist
+
+        t = torch.tensor([st], dtype=torch.int32, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        st = int(t.item())
+    return st
+
+
 def _recover_token(model, cur_token, input_pos, decode_fn, nt, npb, forced, attn_top_k, kw, max_retries=6):
     """In-band recovery from a single-launch hand-off that could not complete (a launch whose workgroups were not all resident: a
-    co-tenant kernel on the device).  One 4-byte read of the decode workspace's status word per token; when it is set the failed
-    step committed nothing of its kv head, every later launch of the token returned at once (include/coldcompress.h,
-    cc_decode_step_heavy_hitter_rc) — so the word is cleared, the epoch words are advanced, and the SAME token runs again: heads
-    whose step is committed replay it (attention only), the others step.  Caches whose step carries no commit words (`recoverable()`
-    False: l2, hybrid, history windows, the fused uint8 mode, random with an injected vector) and a failure that persists raise."""
-    from ..attention_utils import check_single_launch_status, reset_single_launch_status, single_launch_status
+    co-tenant kernel on the device; or, with the L2-resident hand-off, a workgroup that found itself on an unexpected XCD).  Called
+    when the status word of the decode workspace is known to be set: the failed step committed nothing of its kv head, every later
+    launch returned at once (include/coldcompress.h, cc_decode_step_heavy_hitter_rc) — so the word is cleared, the epoch words are
+    advanced, and the SAME token runs again: heads whose step is committed replay it (attention only), the others step.  From the
+    third attempt on the L2-resident hand-off is switched off (memory hand-off; a captured graph is dropped and captured again).
+    Caches whose step carries no commit words (`recoverable()` False) and a failure that persists raise.  Under tensor parallelism
+    the status is the maximum over the ranks, so all ranks take every branch here together."""
+    from .. import _abi
+    from ..attention_utils import raise_single_launch_failure, reset_single_launch_status
 
     dev = cur_token.device
     tries = 0
-    while single_launch_status(dev):
+    while _collective_status(dev):
         caches = [l.attention.kv_cache for l in model.layers]
         ok = all(callable(getattr(c, "recoverable", None)) and c.recoverable() for c in caches)
         if not ok or tries >= max_retries:
-            check_single_launch_status(dev)  # raises (and clears the word)
+            raise_single_launch_failure(dev)  # (clears the word; on every rank together)
         reset_single_launch_status(dev)
         tries += 1
+        if tries >= 2:
+            _abi.lib()["cc_decode_step_set_l2_handoff"](0)
+            if hasattr(decode_fn, "graph"):
+                decode_fn.graph = None  # captured with the L2-resident form: capture again
         time.sleep(0.05 * tries)  # whatever shared the device gets a moment to leave
         nt, npb = decode_fn(model, cur_token, input_pos, next_token=forced, attn_top_k=attn_top_k, **kw)
     return nt, npb
 
 
+class _StatusWatch:
+    """One asynchronous 4-byte copy of every decode workspace's status word per token, inspected when its event has completed —
+    no device synchronisation in the decode loop (a blocking read per token serialises the host's launches with the
+    GPU's work).  Late detection is safe: launches behind a set status word do nothing, so the caches stay where the failed token
+    found them; the loop rewinds to that token."""
+
+    def __init__(self, dev, depth=16):
+        from .. import _abi
+        from ..attention_utils import _decode_workspaces
+
+        self.dev = dev
+        self.off = int(_abi.lib()["cc_decode_step_status_offset"]())
+        self.depth = depth
+        self.slots = torch.zeros((depth, 8), dtype=torch.int32).pin_memory()
+        self.events = [None] * depth
+        self.index = [None] * depth
+        self._ws = _decode_workspaces
+        self.pending = []  # slots in posting order
+
+    def post(self, token_index):
+        if len(self.pending) >= self.depth:
+            self.wait_oldest()
+        slot = next(k for k in range(self.depth) if k not in self.pending)
+        wss = [w for w in self._ws(self.dev) if self.off + 4 <= w.numel()][:8]
+        self.slots[slot].zero_()
+        for k, w in enumerate(wss):
+            self.slots[slot, k:k + 1].copy_(w[self.off:self.off + 4].view(torch.int32), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.events[slot], self.index[slot] = ev, token_index
+        self.pending.append(slot)
+
+    def _take(self):
+        slot = self.pending.pop(0)
+        return self.index[slot], int(self.slots[slot].max().item())
+
+    def ready(self):
+        """-> (token_index, status) of the oldest posted token whose copy has completed, or None."""
+        if self.pending and self.events[self.pending[0]].query():
+            return self._take()
+        return None
+
+    def wait_oldest(self):
+        self.events[self.pending[0]].synchronize()
+        return self._take()
+
+
 def decode_n_tokens(model, cur_token, input_pos, decode_one_token, num_new_tokens, terminator_ids=None, attn_top_k=1.0,
                     prefix=None, **kw):
-    """ref: generation_utils.py:181-217."""
-    new_tokens, new_probs = [], []
-    recover = bool(kw.pop("recover", True)) and cur_token.is_cuda
-    for i in range(num_new_tokens):
-        teacher_force = prefix is not None and i < len(prefix)
-        nt = prefix[i].view(1) if teacher_force else None
-        nt, npb = decode_one_token(model, cur_token, input_pos, next_token=nt, attn_top_k=attn_top_k, **kw)
-        if recover:
-            nt, npb = _recover_token(model, cur_token, input_pos, decode_one_token, nt, npb, prefix[i].view(1) if teacher_force else None,
-                                     attn_top_k, kw)
+    """ref: generation_utils.py:181-217.  `recover` (ours; default: on with one GPU, off under tensor parallelism — there every
+    check is a collective plus a device synchronisation per token, so it is opt-in): watch the single-launch status word and run a
+    failed token again in band (_recover_token).  With one GPU the word is read through an asynchronous copy per token and looked
+    at when that copy has completed — possibly a few tokens late: the loop then rewinds to the failed token (everything launched
+    behind it did nothing)."""
+    new_tokens, new_probs, incs = [], [], []
+    recover = kw.pop("recover", None)
+    tp = _tp_world() > 1
+    recover = (cur_token.is_cuda and not tp) if recover is None else bool(recover)
+    watch = _StatusWatch(cur_token.device) if recover and not tp else None
+    tok0, cur, stopped, i = cur_token, cur_token, False, 0
+
+    def forced_at(k):
+        return prefix[k].view(1) if (prefix is not None and k < len(prefix)) else None
+
+    def commit(k, nt, npb):
+        nonlocal cur, stopped
         new_tokens.append(nt.clone())
         new_probs.append(npb.clone())
+        teacher_force = prefix is not None and k < len(prefix)
         if terminator_ids and nt in terminator_ids and not teacher_force:
+            stopped = True
+            incs.append(0)
+            return
+        input_pos.add_(1)  # (in place, like the reference's `input_pos += 1`)
+        incs.append(1)
+        cur = nt.view(1, -1)
+
+    while True:
+        running = i < num_new_tokens and not stopped
+        if running:
+            nt, npb = decode_one_token(model, cur, input_pos, next_token=forced_at(i), attn_top_k=attn_top_k, **kw)
+            if recover and tp:  # collective and synchronous (opt-in): every rank takes the same branch
+                nt, npb = _recover_token(model, cur, input_pos, decode_one_token, nt, npb, forced_at(i), attn_top_k, kw)
+            if watch is not None:
+                watch.post(i)
+            commit(i, nt, npb)
+            i += 1
+            running = i < num_new_tokens and not stopped
+        if watch is None:
+            if not running:
+                break
+            continue
+        while watch.pending:
+            r = watch.ready() if running else watch.wait_oldest()
+            if r is None:
+                break
+            f, st = r
+            if st:  # token f left the status word set: it, and everything launched behind it, did nothing
+                input_pos.sub_(sum(incs[f:]))
+                del new_tokens[f:], new_probs[f:], incs[f:]
+                cur = new_tokens[f - 1].view(1, -1) if f > 0 else tok0
+                stopped = False
+                watch.pending.clear()
+                nt, npb = _recover_token(model, cur, input_pos, decode_one_token, None, None, forced_at(f), attn_top_k, kw)
+                commit(f, nt, npb)
+                i = f + 1
+                running = i < num_new_tokens and not stopped
+                break
+        if not running and not watch.pending:
             break
-        input_pos += 1
-        cur_token = nt.view(1, -1)
     return new_tokens, new_probs
 
 
@@ -265,12 +386,14 @@ def generate(model, prompt, prefill, decode_one_token, max_new_tokens, next_toke
     sync()
     t2 = time.perf_counter()
     if device.type == "cuda":  # fail loudly: a single-launch step that timed out leaves a word in the decode workspace
-        from ..attention_utils import check_single_launch_status
-
-        check_single_launch_status(device)
+        from ..attention_utils import raise_single_launch_failure
         from ..tp import check_oneshot_allreduce_status
 
-        check_oneshot_allreduce_status()  # (a collective under tensor parallelism: every rank passes here)
+        # both verdicts are collectives under tensor parallelism (every rank passes here and raises or not TOGETHER): the transport's
+        # first — a rank that raised on its own single-launch word before it would leave its peers waiting in this one
+        check_oneshot_allreduce_status()
+        if _collective_status(device):
+            raise_single_launch_failure(device)
     decode_tokens = len(toks) + 1
     stats = {
         "prefill_tokens": prompt_length, "decode_tokens": decode_tokens,

@@ -319,6 +319,26 @@ int cc_debug_occupy(int32_t n_workgroups, int32_t lds_bytes, int32_t microsecond
  * entries of a head's key row are live: all forms of one cache's step (one launch, two, three calls) follow the switch
  * together; flip it only where the fused pipeline is re-seeded (prepare_decode / cc_hh_next_key_init). */
 void cc_decode_step_set_wide(int32_t enabled);
+/* The L2-resident hand-off of the single-launch step (r4).  ref: nothing in the reference corresponds — it is HOW the one launch that
+ * replaces cache.py:725-765 + model.py:395-418 + cache.py:716-722 exchanges its partials.  On a device whose dispatcher puts block b
+ * of a launch on XCD b % 8 (MI355X in SPX mode), a cache with a multiple of 8 kv heads runs its single-tile step with kv head =
+ * block % H: the 16 .. 64 workgroups of a kv head share one XCD, and the head's (m, l) and partial-O granules travel through that
+ * XCD's L2 (plain stores, sc1 polls) instead of through memory (write-through stores, sc0 sc1 polls): 9.4 -> 8.5 us per layer step
+ * at the Llama-3-8B / cache_len 4096 shape together with the other r4 changes (profiles/r04_ab_step_variants.md).  Results are
+ * bit-identical to the memory hand-off (same arithmetic, same fixed orders).  Safety: what the placement needs — blocks b and b + 8
+ * of one launch share an XCD; which XCD block 0 lands on varies from launch to launch and is not relied upon — is OBSERVED per device
+ * (cc_decode_step_probe_xcd) before the form is ever chosen.  Should it not hold for some launch, a head's workgroups do not see each
+ * other's granules: the bounded wait ends the step as a hand-off timeout (status word, nothing committed by the recoverable kinds),
+ * a workgroup that gives up sets the head's fail word and its peers stop waiting when they read it, and the harness retries — from
+ * the third attempt on with the memory hand-off.
+ *   cc_decode_step_probe_xcd: synchronous, call OUTSIDE stream capture (the Python layer does so when it loads the library and when
+ *     it creates a decode workspace); 1 = verified for the current device (cached; two grid shapes, four launches), 0 = refuted or
+ *     not probed -> memory hand-off.
+ *   cc_decode_step_set_l2_handoff(0): process-wide off switch (the fallback after a failed step; a step captured into a hipGraph
+ *     keeps the form it was captured with).  cc_decode_step_l2_handoff(): 1 if enabled AND verified on the current device. */
+int32_t cc_decode_step_probe_xcd(void);
+void cc_decode_step_set_l2_handoff(int32_t enabled);
+int32_t cc_decode_step_l2_handoff(void);
 /* Measurement hook: buf = device buffer of [workgroups][16] uint64, or NULL (default).  While set, thread 0 of every
  * workgroup of a single-launch step records [0..5] s_memtime stamps (start, streaming done, published, sentinel seen,
  * gathered, end), [6..8] s_memrealtime at start / streaming done / end, [9] HW_ID, [10] XCC_ID, [11..13] s_memtime of wave 0

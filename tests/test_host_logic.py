@@ -265,3 +265,69 @@ def test_recoverable_classification_and_key_row_shapes():
     rnd = mk("random")
     rnd._rand = lambda: torch.zeros(S)  # an injected vector would be drawn again by a retry
     assert not rnd.recoverable() and not rnd._in_kernel_rng()
+
+
+def test_decode_loop_rewinds_to_a_late_detected_failed_token(monkeypatch):
+    """harness.decode_n_tokens reads the single-launch status word through an asynchronous copy and may see a failure a few
+    tokens late (no device synchronisation per token): it must rewind to the failed token — positions, token list,
+    the token fed next — and end with exactly the fault-free sequence.  Host logic only: the watch and the retry are stand-ins."""
+    import torch
+
+    from cold_compress_amd.harness import generation as G
+
+    calls = []
+
+    def step(model, x, pos, next_token=None, attn_top_k=1.0, **kw):
+        calls.append((int(x.view(-1)[0]), int(pos[0])))
+        t = torch.tensor([(int(x.view(-1)[0]) * 7 + int(pos[0])) % 101], dtype=torch.int32)
+        return (next_token if next_token is not None else t), torch.ones(1)
+
+    def run(fail_at, lag, n=12, terminators=None):
+        """The fake device: token `fail_at` (first attempt only) sets the word; it becomes visible `lag` tokens later."""
+        state = {"set": False, "failed_once": False}
+
+        class Watch:
+            def __init__(self, dev):
+                self.pending, self.posted = [], {}
+
+            def post(self, i):
+                if i == fail_at and not state["failed_once"]:
+                    state["set"], state["failed_once"] = True, True
+                self.pending.append(i)
+                self.posted[i] = state["set"]  # (sticky: every later token sees it too)
+
+            def ready(self):
+                if self.pending and len(self.pending) > lag:
+                    i = self.pending.pop(0)
+                    return i, int(self.posted[i])
+                return None
+
+            def wait_oldest(self):
+                i = self.pending.pop(0)
+                return i, int(self.posted[i])
+
+        def recover(model, cur, pos, fn, nt, npb, forced, top_k, kw, max_retries=6):
+            assert state["set"]
+            state["set"] = False  # reset_single_launch_status
+            return fn(model, cur, pos, next_token=forced, attn_top_k=top_k, **kw)
+
+        monkeypatch.setattr(G, "_StatusWatch", Watch)
+        monkeypatch.setattr(G, "_recover_token", recover)
+        pos = torch.tensor([40], dtype=torch.int32)
+        toks, _ = G.decode_n_tokens(None, torch.tensor([[3]], dtype=torch.int32), pos, step, n, recover=fail_at is not None or None,
+                                    terminator_ids=terminators)
+        return [int(t) for t in toks], int(pos[0])
+
+    clean, end = run(None, 0)
+    assert end == 52 and len(clean) == 12
+    for fail_at in (0, 1, 5, 11):
+        for lag in (0, 1, 3, 20):
+            got, e = run(fail_at, lag)
+            assert got == clean and e == end, (fail_at, lag, got, clean, e)
+    # a terminator behind the failed token: the rewound run stops where the clean one does, without the position bump of the stop
+    stop = clean[6]
+    c2, e2 = run(None, 0, terminators=[stop])
+    assert c2 == clean[:7] and e2 == 46
+    for lag in (0, 2, 9):
+        g2, e3 = run(4, lag, terminators=[stop])
+        assert g2 == c2 and e3 == e2, (lag, g2, e3)
