@@ -681,7 +681,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
   static_assert(!ONE || NW == 4 || (NW == 8 && NT == 1), "the single-launch step runs on 4-wave workgroups, or on ONE 8-wave workgroup per CU (single tile)");
   constexpr int D = 128, VEC = 8, RPW = 4, U = 4;
   static_assert(FULL || ONE, "the lean form exists for the single-launch step only");
-  static_assert(!XL2 || EML, "the L2-resident hand-off rides the early-(m, l) single-tile steps");
+  static_assert(!XL2 || ONE, "the L2-resident hand-off belongs to the single-launch steps");
   if constexpr (!FULL) {  // constants for the optimiser: every `if (a.trace)`, `a.abl & ...`, `if (a.attn_out)` below folds away
     a.trace = nullptr;
     a.abl = 0;
@@ -711,8 +711,14 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
     // launch (grids of two queues dealt alternately, say), a head's workgroups do not see each other's granules: the bounded wait
     // ends the step as a recoverable failure and the host falls back to the memory hand-off (harness._recover_token).
     const int b = blockIdx.x + gridDim.x * blockIdx.y;
-    h_ = b % (int)gridDim.y;
-    split_ = b / (int)gridDim.y;
+    const int Hg = (int)gridDim.y;
+    if ((Hg & (Hg - 1)) == 0) {  // (the usual case: no integer division in front of the first loads)
+      h_ = b & (Hg - 1);
+      split_ = b >> __builtin_ctz(Hg);
+    } else {
+      h_ = b % Hg;
+      split_ = b / Hg;
+    }
   }
   const int split = split_, h = h_, q0 = h * a.R + blockIdx.z * RT;
   const int S = a.S;
@@ -1664,7 +1670,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
         __builtin_amdgcn_raw_buffer_store_b128(og, o_rsrc, h * kOneOHead + ((r * ns + split) * 64 + (d >> 1)) * 16, 0, kPublishAux);
         if (!EML && d == 0) {
           const u32x4_t mg = {tag, __float_as_uint(M), tag, __float_as_uint(L)};
-          __builtin_amdgcn_raw_buffer_store_b128(mg, ml_rsrc, h * kOneMlHead + (split * RT + r) * 16, 0, kOneAuxCoherent);
+          __builtin_amdgcn_raw_buffer_store_b128(mg, ml_rsrc, h * kOneMlHead + (split * RT + r) * 16, 0, kPublishAux);
         }
       }
     }
@@ -2881,9 +2887,23 @@ static OneKernel one_kernel_dt(int dtype, int rt, int nt, int kind, bool full, i
 // The XL2 instantiations (placement + L2-resident hand-off): single-tile steps of the plain 16-bit cache (kind 0), the fused
 // quantised cache (8) and l2 (-1), 4 or 8 query heads per kv head, 4- or 8-wave workgroups; FULL for bf16 / rt = 4 / kind 0 only.
 template <typename T>
-static OneKernel one_kernel_xl2(int rt, int kind, bool full, int nw) {
+static OneKernel one_kernel_xl2(int rt, int nt, int kind, bool full, int nw) {
 #define CC_ONE_X(RT_, NW_, L2_, QB_, FULL_) decode_attn_split_mfma_kernel<T, RT_, NW_, L2_, true, false, QB_, 1, 1, FULL_, true>
-  if ((rt != 4 && rt != 8) || (nw != 4 && nw != 8) || (kind != 0 && kind != 8 && kind != -1)) return nullptr;
+#define CC_ONE_XM(RT_, HYB_, NT_) decode_attn_split_mfma_kernel<T, RT_, kNW, false, true, HYB_, 0, 1, NT_, false, true>
+  if ((rt != 4 && rt != 8) || (nw != 4 && nw != 8)) return nullptr;
+  if (nt > 1 || kind == 200) {  // several tiles per wave (4-wave workgroups) and the hybrid cache's steps: lean instantiations only
+    if (full || nt > kOneMaxTiles) return nullptr;
+    if (kind == 200) {
+      if (nt == 1) return nw == 8 ? (rt == 8 ? decode_attn_split_mfma_kernel<T, 8, 8, false, true, true, 0, 1, 1, false, true>
+                                             : decode_attn_split_mfma_kernel<T, 4, 8, false, true, true, 0, 1, 1, false, true>)
+                                  : (rt == 8 ? CC_ONE_XM(8, true, 1) : CC_ONE_XM(4, true, 1));
+      return nw == 4 ? (rt == 8 ? CC_ONE_XM(8, true, 8) : CC_ONE_XM(4, true, 8)) : nullptr;
+    }
+    if (kind != 0 || nw != 4) return nullptr;
+    if (rt == 8) return nt <= 4 ? CC_ONE_XM(8, false, 4) : CC_ONE_XM(8, false, 8);
+    return nt <= 4 ? CC_ONE_XM(4, false, 4) : CC_ONE_XM(4, false, 8);
+  }
+  if (kind != 0 && kind != 8 && kind != -1) return nullptr;
   if (full) {
     if constexpr (ElemTraits<T>::code != CC_DT_BF16) {
       return nullptr;
@@ -2903,9 +2923,10 @@ static OneKernel one_kernel_xl2(int rt, int kind, bool full, int nw) {
   if (nw == 8) return rt == 8 ? CC_ONE_X(8, 8, true, 0, false) : CC_ONE_X(4, 8, true, 0, false);
   return rt == 8 ? CC_ONE_X(8, 4, true, 0, false) : CC_ONE_X(4, 4, true, 0, false);
 #undef CC_ONE_X
+#undef CC_ONE_XM
 }
-static OneKernel one_kernel_xl2_dt(int dtype, int rt, int kind, bool full, int nw) {
-  return dtype == CC_DT_BF16 ? one_kernel_xl2<bf16_t>(rt, kind, full, nw) : (dtype == CC_DT_F16 ? one_kernel_xl2<f16_t>(rt, kind, full, nw) : nullptr);
+static OneKernel one_kernel_xl2_dt(int dtype, int rt, int nt, int kind, bool full, int nw) {
+  return dtype == CC_DT_BF16 ? one_kernel_xl2<bf16_t>(rt, nt, kind, full, nw) : (dtype == CC_DT_F16 ? one_kernel_xl2<f16_t>(rt, nt, kind, full, nw) : nullptr);
 }
 
 // ---- XL2 eligibility of the device: does block b of a launch run on XCD (b % 8)'s fixed XCC?  Observed once per device by
@@ -2947,8 +2968,8 @@ static OneKernel one_pick(int32_t HQ, int32_t H, int32_t S, int32_t D, int32_t d
   // l2: every thread gathers at most three workgroups' norm maxima
   if (kind == -1 && H * p.n_split > 3 * p.nw * 64) return nullptr;
   // XL2 first: a multiple of 8 kv heads (each head's workgroups on one XCD) on a device whose dispatch order was verified
-  if (allow_xl2 && nt == 1 && (H & 7) == 0 && xl2_device_ok()) {
-    const OneKernel kx = one_kernel_xl2_dt(dtype, p.rt, kind, full, p.nw);
+  if (allow_xl2 && (H & 7) == 0 && xl2_device_ok()) {
+    const OneKernel kx = one_kernel_xl2_dt(dtype, p.rt, nt, kind, full, p.nw);
     if (kx && p.n_split * H <= one_capacity(kx, p.nw * 64)) return kx;
   }
   const OneKernel k = one_kernel_dt(dtype, p.rt, nt, kind, full, p.nw);
