@@ -71,6 +71,8 @@ SIGNATURES = {
     "cc_kv_dequant_rows": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "cc_decode_step_quant": (C.c_int, [_view, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32,
                                        _vp, _vp, _vp, _sz, _vp, _i32]),
+    "cc_decode_step_quant_rc": (C.c_int, [_view, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_uint64, _vp, _vp, _i32, _i32, _i32,
+                                          _f32, _vp, _vp, _sz, _vp, _i32]),
     "cc_decode_step_quant_single_launch": (_i32, [_i32, _i32, _i32, _i32, _i32, _i32]),
     "cc_decode_step_hybrid_single_launch": (_i32, [_i32, _i32, _i32, _i32, _i32]),
     "cc_hh_next_key_slots": (_i32, [_i32]),
@@ -96,6 +98,8 @@ SIGNATURES = {
                                         _i32, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _sz, _vp]),
     "cc_l2_next_key_init": (C.c_int, [_view, _vp, _vp, _i32, _i32, _vp, _vp]),
     "cc_decode_step_l2": (C.c_int, [_view, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _sz, _vp]),
+    "cc_decode_step_l2_rc": (C.c_int, [_view, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _sz, _vp]),
+    "cc_decode_step_commit_stride": (_i32, []),
     "cc_random_next_key_init": (C.c_int, [_view, _vp, _vp, _i32, _i32, _vp, _vp]),
     "cc_decode_step_random": (C.c_int, [_view, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _sz, _vp]),
     "cc_random_next_key_init_rng": (C.c_int, [_view, _vp, C.c_uint64, _i32, _i32, _vp, _vp]),
@@ -145,7 +149,7 @@ SIGNATURES = {
 
 # entry points that only the device library has (no `_cpu` twin)
 DEVICE_ONLY = {"cc_error_string", "cc_device_info", "cc_decode_step_single_launch", "cc_decode_step_status_offset",
-               "cc_decode_step_trace", "cc_decode_step_set_single_launch", "cc_decode_step_set_wide", "cc_decode_step_probe_xcd", "cc_decode_step_set_l2_handoff", "cc_decode_step_l2_handoff", "cc_decode_step_stream_floor", "cc_debug_occupy", "cc_decode_step_quant_single_launch",
+               "cc_decode_step_trace", "cc_decode_step_set_single_launch", "cc_decode_step_set_wide", "cc_decode_step_probe_xcd", "cc_decode_step_commit_stride", "cc_decode_step_l2_rc", "cc_decode_step_quant_rc", "cc_decode_step_set_l2_handoff", "cc_decode_step_l2_handoff", "cc_decode_step_stream_floor", "cc_debug_occupy", "cc_decode_step_quant_single_launch",
                "cc_decode_step_hybrid_single_launch",
                # inter-GPU transport: no CPU twin (the oracle of the all-reduce is torch.distributed's)
                "cc_allreduce_handle_bytes", "cc_allreduce_create", "cc_allreduce_export", "cc_allreduce_connect", "cc_allreduce_sum",

@@ -207,10 +207,12 @@ class KVCache(nn.Module):
                   _DT[self.k_cache.dtype], 8, _ptr(k), _ptr(v), _stream())
         return k, v
 
-    def _quant_step(self, q, k, v, p32, HQ, scale, y, ws, num=None, denom=None, counter=None, rand=None, g=0, w=0, phases=3):
-        _abi.call("cc_decode_step_quant", self._view(), _ptr(self.kv_qparams), 8, self._fused_quant_policy(), _ptr(q), _ptr(k),
-                  _ptr(v), _ptr(p32), _ptr(num), _ptr(denom), _ptr(counter), _ptr(rand), _ptr(self.next_key), int(g), int(w), HQ,
-                  scale, _ptr(y), None, _ptr(ws), ws.numel(), _stream(), phases)
+    def _quant_step(self, q, k, v, p32, HQ, scale, y, ws, num=None, denom=None, counter=None, rand=None, seed=0, g=0, w=0, phases=3):
+        """The fused step over the uint8 images, recoverable form (cc_decode_step_quant_rc: commit words; random: `rand` = the
+        injected vector, or None -> in-kernel draws from `seed`)."""
+        _abi.call("cc_decode_step_quant_rc", self._view(), _ptr(self.kv_qparams), 8, self._fused_quant_policy(), _ptr(q), _ptr(k),
+                  _ptr(v), _ptr(p32), _ptr(num), _ptr(denom), _ptr(counter), _ptr(rand), int(seed), _ptr(self.next_key),
+                  _ptr(self.step_commit), int(g), int(w), HQ, scale, _ptr(y), _ptr(ws), ws.numel(), _stream(), phases)
 
     # ------------------------------------------------------------------ quantised KV (ref: cache.py:283-309, 323-338)
     def quantize_cache(self):
@@ -364,6 +366,20 @@ class KVCache(nn.Module):
         raise NotImplementedError
 
 
+def _new_step_commit(n_heads):
+    """The recoverable hand-off's commit words (include/coldcompress.h, cc_decode_step_heavy_hitter_rc): per kv head the insert
+    word, its position, and one committed position per workgroup of the head; -1 = nothing."""
+    return torch.full((n_heads, int(_abi.lib()["cc_decode_step_commit_stride"]())), -1, dtype=torch.int32)
+
+
+def step_committed(kv, position, HQ=None):
+    """True when every workgroup word of `kv.step_commit` that the last single-launch step wrote holds `position` (words of splits
+    the launch does not have stay -1) and at least one does."""
+    w = kv.step_commit[:, 2:]
+    used = w != -1
+    return bool(used.any()) and bool((w[used] == int(position)).all()) and bool(used.any(dim=1).all())
+
+
 class KVCacheHeadConstant(KVCache):
     def __init__(self, max_batch_size, n_heads, head_dim, dtype=torch.bfloat16, **kwargs):
         super().__init__(max_batch_size, n_heads, head_dim, dtype, head_specific=False, **kwargs)
@@ -390,12 +406,12 @@ class _RingFusedStep:
         self._next_valid = False
         # recoverable hand-off (include/coldcompress.h, cc_decode_step_head_constant_rc): the last position whose step is fully
         # committed, per kv head; -1 = none.  Used by the head-constant policies; l2 carries it unused.
-        self.register_buffer("step_commit", torch.full((self.n_heads,), -1, dtype=torch.int32), persistent=False)
+        self.register_buffer("step_commit", _new_step_commit(self.n_heads), persistent=False)
 
     def recoverable(self):
         """True: a timed-out single-launch step of this cache can be retried in band (harness._recover_token): its step
-        carries commit words and a retry scores the same keys.  recent_global / full / random with in-kernel draws; not l2
-        (its norm maximum crosses kv heads), not the fused uint8 mode."""
+        carries commit words and a retry scores the same keys.  recent_global / full / l2 / random with in-kernel draws, 16-bit
+        caches and (r4) the fused uint8 mode."""
         return False
 
     def supports_fused_step(self):
@@ -453,7 +469,7 @@ class KVCacheFull(_RingFusedStep, KVCacheHeadConstant):
     """ref: cache.py:493-502."""
 
     def recoverable(self):
-        return not self.fused_quant
+        return True
 
     def __init__(self, max_batch_size, n_heads, head_dim, dtype=torch.bfloat16, **kwargs):
         self.global_tokens = 0
@@ -488,14 +504,20 @@ class KVCacheRandom(_RingFusedStep, KVCacheHeadConstant):
         return torch.rand(self.max_cache_length, device=self.k_cache.device)
 
     def _in_kernel_rng(self):
-        return "_rand" not in self.__dict__ and type(self)._rand is KVCacheRandom._rand and not self.fused_quant
+        return "_rand" not in self.__dict__ and type(self)._rand is KVCacheRandom._rand
 
     def recoverable(self):
         return self._in_kernel_rng()  # (an injected vector would be drawn again by the retry)
 
     def _pipeline_init(self, p32):
         if self._in_kernel_rng():
-            self._rng_seed = int(torch.randint(0, 2 ** 62, (1,)).item())  # CPU generator: follows torch.manual_seed, no device sync
+            # ONE seed per cache object, drawn from torch's CPU generator when the pipeline is first seeded (follows torch.manual_seed, not
+            # torch.cuda.manual_seed; no device sync) and kept: the steps carry it by value, so a hipGraph captured once replays the
+            # seed every later re-seed of the pipeline (a new generation on the same cache) also uses (a fresh seed per
+            # generation reached the init kernel only — the replayed steps kept the captured one).  The draws are a stateless hash of
+            # (seed, position, slot): the same cache object draws the same numbers at the same positions in every generation.
+            if not self._rng_seed:
+                self._rng_seed = int(torch.randint(1, 2 ** 62, (1,)).item())
             _abi.call("cc_random_next_key_init_rng", self._view(), _ptr(p32), self._rng_seed, int(self.global_tokens),
                       int(self.recent_window), _ptr(self.next_key), _stream())
             return
@@ -507,6 +529,8 @@ class KVCacheRandom(_RingFusedStep, KVCacheHeadConstant):
         return 3
 
     def _pipeline_step(self, q, k, v, p32, HQ, scale, y, ws):
+        if self._in_kernel_rng() and self.fused_quant:  # (r4: in-kernel draws for the uint8 images too: no vector, no torch.rand launch)
+            return self._quant_step(q, k, v, p32, HQ, scale, y, ws, rand=None, seed=self._rng_seed, g=self.global_tokens, w=self.recent_window)
         if self._in_kernel_rng():  # (the recoverable form: a retried step scores the same draws)
             _abi.call("cc_decode_step_head_constant_rc", self._view(), 3, _ptr(q), _ptr(k), _ptr(v), _ptr(p32), None,
                       self._rng_seed, _ptr(self.next_key), _ptr(self.step_commit), int(self.global_tokens),
@@ -533,7 +557,7 @@ class KVCacheRecentGlobal(_RingFusedStep, KVCacheHeadConstant):
         self._init_ring_pipeline()
 
     def recoverable(self):
-        return not self.fused_quant
+        return True
 
     def _fused_quant_policy(self):
         return 2
@@ -567,8 +591,12 @@ class KVCacheL2(_RingFusedStep, KVCacheHeadSpecific):
                   int(self.recent_window), _ptr(self.next_key), _stream())
 
     def _pipeline_step(self, q, k, v, p32, HQ, scale, y, ws):
-        _abi.call("cc_decode_step_l2", self._view(), _ptr(q), _ptr(k), _ptr(v), _ptr(p32), _ptr(self.key_norm), _ptr(self.next_key),
-                  int(self.global_tokens), int(self.recent_window), HQ, scale, _ptr(y), _ptr(ws), ws.numel(), _stream())
+        _abi.call("cc_decode_step_l2_rc", self._view(), _ptr(q), _ptr(k), _ptr(v), _ptr(p32), _ptr(self.key_norm), _ptr(self.next_key),
+                  _ptr(self.step_commit), int(self.global_tokens), int(self.recent_window), HQ, scale, _ptr(y), _ptr(ws), ws.numel(),
+                  _stream())
+
+    def recoverable(self):
+        return True
 
     def reset(self):
         super().reset()
@@ -643,7 +671,7 @@ class KVCacheHeavyHitter(_TrackedWindowSums, KVCacheHeadSpecific):
         self._next_valid = False
         # recoverable hand-off of the single-launch step (include/coldcompress.h, cc_decode_step_heavy_hitter_rc): the last
         # position whose step is fully committed, per kv head; -1 = none
-        self.register_buffer("step_commit", torch.full((n_heads,), -1, dtype=torch.int32), persistent=False)
+        self.register_buffer("step_commit", _new_step_commit(n_heads), persistent=False)
         if W > 1:
             self._init_window_state()
 
@@ -665,7 +693,7 @@ class KVCacheHeavyHitter(_TrackedWindowSums, KVCacheHeadSpecific):
 
     def recoverable(self):
         """A timed-out single-launch step can be retried in band (cc_decode_step_heavy_hitter_rc): W = 1, 16-bit cache."""
-        return self.history_window_size == 1 and not self.fused_quant
+        return self.history_window_size == 1
 
     def _fused_quant_policy(self):
         return 1 if int(getattr(self, "history_window_size", 1)) == 1 else 0

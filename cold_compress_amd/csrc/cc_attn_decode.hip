@@ -568,12 +568,18 @@ constexpr int kOneTicketWord = 1022;        // hybrid: heads whose workgroups ha
 //   * hdr[kOneStatusWordDev] != 0 (set with the fail word; cleared by the host): every later launch returns at once — nothing is
 //     built on the garbage a failed step's y became.  The host clears it AND advances every epoch word (so that no granule of the
 //     failed attempt can carry a later launch's tag), then simply runs the token again:
-//   * step_commit[h] == *input_pos: this head's step for this position is already committed -> REPLAY: no insert, no history, no
-//     keys — attention over the cache as the committed step left it (the same scores, partials and y, bit for bit).
-// Not closed: a workgroup that completes its gather in the same memory round trip in which another one of its head gives up
-// (the late workgroup it waited for became resident at that very moment) may commit its slots alone; the window is one round
-// trip (~1 us) at the end of a >= 0.1 s wait.
+//   * step_commit (r4: per WORKGROUP, kRcStride int32 per kv head): words [2 + split] = the last position whose step THIS workgroup has
+//     committed (its slots' history, its keys; split 0 also the head's count and the step counter); words [0], [1] = the slot this
+//     position's insert went to ((slot << 1) | was_empty) and that position, written by whoever decides the insert — BEFORE anything
+//     of the step can be committed (a workgroup commits behind the partial-O gather, i.e. after the inserting workgroup published).
+//     A retry of position p: a workgroup whose word says p recomputes (same scores, same partials: the hand-off needs them) and
+//     stores nothing; the others step; all of them take the insert slot from words [0], [1] when they carry p (committed
+//     workgroups have overwritten their part of the key row with the NEXT position's keys: its minimum is no longer this step's).
+//     Whatever the interleaving of give-ups and commits inside the failed launch — r3 left a window: a workgroup that completed its
+//     gather in the round trip in which a sibling gave up committed alone, and the retry added its probabilities twice — every slot's
+//     history is updated exactly once per position: the retry is idempotent per workgroup.
 constexpr int kOneFailWord = 64;
+constexpr int kRcStride = 66;                  // step_commit: int32 per kv head — [0] insert word, [1] its position, [2 + split] committed position
 // Granule regions are PER KV HEAD at fixed strides, whatever the shape: a location is only ever written by launches of its own
 // head, with tags from that head's epoch word — strictly growing per location even when caches of different head counts and
 // lengths share the workspace (shape-dependent offsets let a stale granule of head 4 sit where head 1 of another shape expects
@@ -873,13 +879,18 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
   unsigned one_tag = 0;
   int32_t one_pin = 0;
   unsigned rc_status = 0;    // EML: the workspace's status word (a step failed since the host last looked: do nothing)
-  int32_t rc_commit = -2;    // EML: step_commit[h]
+  int32_t rc_commit = -2;    // EML: step_commit[h][2 + split]: the last position this workgroup committed
+  int32_t rc_insw = 0, rc_insp = -2;  // EML: step_commit[h][0 .. 1]: the insert slot word of position rc_insp
   auto load_step_words = [&]() {
     one_tag = a.one_hdr[h] + 1u;
     one_pin = *a.input_pos;
     if constexpr (RC) {
       rc_status = a.one_hdr[kOneStatusWordDev];
-      if (a.commit) rc_commit = a.commit[h];
+      if (a.commit) {
+        rc_commit = a.commit[(size_t)h * kRcStride + 2 + split];
+        rc_insw = a.commit[(size_t)h * kRcStride];
+        rc_insp = a.commit[(size_t)h * kRcStride + 1];
+      }
     }
   };
   if (key_pending) {
@@ -1138,7 +1149,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
     }
     if (rc_status != 0u) return;  // a step of this token failed before this launch: leave everything as it is (the host retries)
   }
-  const bool rc_replay = EML && rc_commit == one_pin;  // this head's step for this position is committed already: attention only
+  const bool rc_replay = EML && rc_commit == one_pin;  // this WORKGROUP committed its part of this position's step already: it recomputes and stores nothing
 
   float pv_p[U];  // the tile's probabilities (unnormalised), between its two halves
   auto tile_qk = [&](TileRegs& R, const int tbase, const int tbase_next, const bool more_next, auto ti_c) {
@@ -1152,8 +1163,16 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
       const unsigned long long key = wave_min_u64_uniform(key_part);
       ins_idx = (key == ~0ull) ? -1 : (int)((key & 0xffffffffull) >> 1);
       if (a.abl & 64) ins_idx = -1;
-      if (rc_replay) ins_idx = -1;  // (the row went in when the step was committed; the key row already holds the NEXT position's keys)
       ins_was_empty = (int)(key & 1ull);
+      if constexpr (RC) {
+        if (rc_insp == one_pin) {  // a retry: the slot the first attempt's insert went to (the key row may hold the next position's keys by now)
+          ins_idx = rc_insw >> 1;  // (arithmetic shift: -1 stays -1)
+          ins_was_empty = rc_insw & 1;
+        } else if (a.commit && split == 0 && threadIdx.x == 0) {  // recorded before anything of the step can be committed
+          a.commit[(size_t)h * kRcStride] = ins_idx < 0 ? -1 : ((ins_idx << 1) | ins_was_empty);
+          a.commit[(size_t)h * kRcStride + 1] = one_pin;
+        }
+      }
       key_pending = false;
       if constexpr (HYB) {  // ref: cache.py:896-950 _select_fill_idx, per head — operands requested at the top of the kernel (hy_*)
         hy_flags = __shfl(hy_tabv, hy_pol * 3, CC_WAVE);
@@ -2149,11 +2168,13 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
           }
         } else if (!rc_replay) {
           if (h == 0 && a.hh_counter) *a.hh_counter += 1;
-          if (EML && a.commit) {  // recoverable hand-off: this head's step for this position is done
+          if (EML && a.commit) {  // recoverable hand-off: the head's count travels with split 0's commit
             if (ins_was_empty && (a.Hc == a.H || h == 0)) a.cache_cts[a.Hc == a.H ? h : 0] += 1;  // (one writer per count)
-            a.commit[h] = one_pin;
           }
         }
+      }
+      if constexpr (RC) {  // this workgroup's part of the step (its slots' history, its keys) is committed
+        if (!failed && !rc_replay && a.commit) a.commit[(size_t)h * kRcStride + 2 + split] = one_pin;
       }
       if (a.trace) {
         unsigned long long* tr = a.trace + (size_t)(h * ns + split) * 16;
@@ -2990,6 +3011,7 @@ int32_t cc_decode_step_hybrid_single_launch(int32_t HQ, int32_t H, int32_t S, in
 }
 
 int32_t cc_decode_step_status_offset(void) { return kOneStatusWord * (int32_t)sizeof(unsigned); }
+int32_t cc_decode_step_commit_stride(void) { return kRcStride; }
 
 static void* g_one_trace = nullptr;
 void cc_decode_step_trace(void* buf) { g_one_trace = buf; }
@@ -3364,11 +3386,11 @@ int cc_decode_step_head_constant_rc(const cc_kv_view* c, int32_t policy, const v
                    nullptr, workspace, workspace_bytes, stream, 3, &fs);
 }
 
-int cc_decode_step_quant(const cc_kv_view* c, float* qparams, int32_t n_bit, int32_t policy, const void* q, const void* k_new,
-                         const void* v_new, const int32_t* input_pos, double* num, int32_t* denom, int64_t* counter,
-                         const float* rand_next, uint64_t* next_key, int32_t global_tokens, int32_t recent_window, int32_t HQ,
-                         float scale, void* y, void* attn_out, void* workspace, size_t workspace_bytes, cc_stream_t stream,
-                         int32_t phases) {
+static int decode_step_quant_impl(const cc_kv_view* c, float* qparams, int32_t n_bit, int32_t policy, const void* q, const void* k_new,
+                                  const void* v_new, const int32_t* input_pos, double* num, int32_t* denom, int64_t* counter,
+                                  const float* rand_next, bool rng_on, uint64_t seed, uint64_t* next_key, int32_t* step_commit,
+                                  int32_t global_tokens, int32_t recent_window, int32_t HQ, float scale, void* y, void* attn_out,
+                                  void* workspace, size_t workspace_bytes, cc_stream_t stream, int32_t phases) {
   if (!cc_view_ok(c) || !qparams || !q || !k_new || !v_new || !input_pos || !next_key || !y || HQ <= 0 || HQ % c->H ||
       global_tokens < 0)
     return CC_ERR_BAD_ARG;
@@ -3376,27 +3398,54 @@ int cc_decode_step_quant(const cc_kv_view* c, float* qparams, int32_t n_bit, int
   switch (policy) {
     case 1: if (!num || !denom || c->Hp != c->H) return CC_ERR_BAD_ARG; break;
     case 2: if (num || denom || c->Hp != 1 || global_tokens >= c->S) return CC_ERR_BAD_ARG; break;
-    case 3: if (num || denom || c->Hp != 1 || !rand_next) return CC_ERR_BAD_ARG; break;
+    case 3: if (num || denom || c->Hp != 1 || (!rand_next && !rng_on)) return CC_ERR_BAD_ARG; break;
     default: return CC_ERR_UNSUPPORTED;
   }
   FusedStep fs{c, k_new, v_new, input_pos, reinterpret_cast<unsigned long long*>(next_key), global_tokens,
                policy == 2 ? 0 : recent_window, policy, policy == 3 ? rand_next : nullptr, nullptr, nullptr, qparams};
+  if (policy == 3 && !rand_next) {
+    fs.rng_seed = seed;
+    fs.rng_on = 1;
+  }
+  fs.commit = step_commit;
   return attn_impl(q, c->k_cache, c->v_cache, c->mask, HQ, c->H, c->S, c->D, c->dtype, scale, y, policy == 1 ? attn_out : nullptr,
                    nullptr, num, denom, policy == 1 ? counter : nullptr, workspace, workspace_bytes, stream, phases, &fs);
 }
-
-int cc_decode_step_l2(const cc_kv_view* c, const void* q, const void* k_new, const void* v_new, const int32_t* input_pos,
-                      void* key_norm, uint64_t* next_key, int32_t global_tokens, int32_t recent_window, int32_t HQ, float scale,
-                      void* y, void* workspace, size_t workspace_bytes, cc_stream_t stream) {
+int cc_decode_step_quant(const cc_kv_view* c, float* qparams, int32_t n_bit, int32_t policy, const void* q, const void* k_new,
+                         const void* v_new, const int32_t* input_pos, double* num, int32_t* denom, int64_t* counter,
+                         const float* rand_next, uint64_t* next_key, int32_t global_tokens, int32_t recent_window, int32_t HQ,
+                         float scale, void* y, void* attn_out, void* workspace, size_t workspace_bytes, cc_stream_t stream,
+                         int32_t phases) {
+  return decode_step_quant_impl(c, qparams, n_bit, policy, q, k_new, v_new, input_pos, num, denom, counter, rand_next, false, 0, next_key,
+                                nullptr, global_tokens, recent_window, HQ, scale, y, attn_out, workspace, workspace_bytes, stream, phases);
+}
+int cc_decode_step_quant_rc(const cc_kv_view* c, float* qparams, int32_t n_bit, int32_t policy, const void* q, const void* k_new,
+                            const void* v_new, const int32_t* input_pos, double* num, int32_t* denom, int64_t* counter,
+                            const float* rand_next, uint64_t seed, uint64_t* next_key, int32_t* step_commit, int32_t global_tokens,
+                            int32_t recent_window, int32_t HQ, float scale, void* y, void* workspace, size_t workspace_bytes,
+                            cc_stream_t stream, int32_t phases) {
+  return decode_step_quant_impl(c, qparams, n_bit, policy, q, k_new, v_new, input_pos, num, denom, counter, rand_next, rand_next == nullptr,
+                                seed, next_key, step_commit, global_tokens, recent_window, HQ, scale, y, nullptr, workspace, workspace_bytes,
+                                stream, phases);
+}
+int cc_decode_step_l2_rc(const cc_kv_view* c, const void* q, const void* k_new, const void* v_new, const int32_t* input_pos,
+                         void* key_norm, uint64_t* next_key, int32_t* step_commit, int32_t global_tokens, int32_t recent_window, int32_t HQ,
+                         float scale, void* y, void* workspace, size_t workspace_bytes, cc_stream_t stream) {
   if (!cc_view_ok(c) || !q || !k_new || !v_new || !input_pos || !key_norm || !next_key || !y || c->Hp != c->H || HQ <= 0 ||
       HQ % c->H || global_tokens < 0)
     return CC_ERR_BAD_ARG;
   FusedStep fs{c, k_new, v_new, input_pos, reinterpret_cast<unsigned long long*>(next_key), global_tokens, recent_window, 4, nullptr,
                key_norm};
+  fs.commit = step_commit;
   return attn_impl(q, c->k_cache, c->v_cache, c->mask, HQ, c->H, c->S, c->D, c->dtype, scale, y, nullptr, nullptr, nullptr, nullptr,
                    nullptr, workspace, workspace_bytes, stream, 3, &fs);
 }
-
+int cc_decode_step_l2(const cc_kv_view* c, const void* q, const void* k_new, const void* v_new, const int32_t* input_pos,
+                      void* key_norm, uint64_t* next_key, int32_t global_tokens, int32_t recent_window, int32_t HQ, float scale,
+                      void* y, void* workspace, size_t workspace_bytes, cc_stream_t stream) {
+  return cc_decode_step_l2_rc(c, q, k_new, v_new, input_pos, key_norm, next_key, nullptr, global_tokens, recent_window, HQ, scale, y,
+                              workspace, workspace_bytes, stream);
+}
 int cc_decode_step_heavy_hitter_ring(const cc_kv_view* c, const void* q, const void* k_new, const void* v_new, const int32_t* input_pos,
                                      void* ring_num, int32_t* denom, int64_t* counter, int32_t W, uint64_t* wsum_acc, float* wsum,
                                      uint64_t* next_key, int32_t global_tokens, int32_t recent_window, int32_t HQ, float scale, void* y,

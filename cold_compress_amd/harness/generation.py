@@ -202,8 +202,9 @@ def _recover_token(model, cur_token, input_pos, decode_fn, nt, npb, forced, attn
     co-tenant kernel on the device; or, with the L2-resident hand-off, a workgroup that found itself on an unexpected XCD).  Called
     when the status word of the decode workspace is known to be set: the failed step committed nothing of its kv head, every later
     launch returned at once (include/coldcompress.h, cc_decode_step_heavy_hitter_rc) — so the word is cleared, the epoch words are
-    advanced, and the SAME token runs again: heads whose step is committed replay it (attention only), the others step.  From the
-    third attempt on the L2-resident hand-off is switched off (memory hand-off; a captured graph is dropped and captured again).
+    advanced, and the SAME token runs again: workgroups whose part of the step is committed recompute and store nothing, the others
+    step.  From the fourth attempt on the L2-resident hand-off is switched off (memory hand-off; a captured graph is dropped and
+    captured again).
     Caches whose step carries no commit words (`recoverable()` False) and a failure that persists raise.  Under tensor parallelism
     the status is the maximum over the ranks, so all ranks take every branch here together."""
     from .. import _abi
@@ -218,7 +219,7 @@ def _recover_token(model, cur_token, input_pos, decode_fn, nt, npb, forced, attn
             raise_single_launch_failure(dev)  # (clears the word; on every rank together)
         reset_single_launch_status(dev)
         tries += 1
-        if tries >= 2:
+        if tries >= 3 and _abi.lib()["cc_decode_step_l2_handoff"]():  # (two plain retries first: a co-tenant leaves, a misplaced launch does not)
             _abi.lib()["cc_decode_step_set_l2_handoff"](0)
             if hasattr(decode_fn, "graph"):
                 decode_fn.graph = None  # captured with the L2-resident form: capture again

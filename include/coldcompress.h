@@ -229,8 +229,8 @@ int cc_decode_step_random_rng(const cc_kv_view* c, const void* q, const void* k_
 /* The head-constant steps with the RECOVERABLE hand-off (late r3; semantics as cc_decode_step_heavy_hitter_rc below: commit words,
  * replay of committed heads, no-op behind a set status word).  policy: 2 = recent_global / full (rand_next must be NULL), 3 = random
  * (rand_next: the uniform vector for position *input_pos + 1, or NULL: the draws are made in the kernels from `seed`, as
- * cc_decode_step_random_rng — the only form a retry may use: a retried step must score the same draw).  step_commit: int32 [H],
- * -1 = nothing committed; may be NULL (no replay).  The rows of next_key [H, NK] stay identical across kv heads through a
+ * cc_decode_step_random_rng — the only form a retry may use: a retried step must score the same draw).  step_commit: int32
+ * [H, cc_decode_step_commit_stride()], -1 = nothing committed; may be NULL (no replay).  The rows of next_key [H, NK] stay identical across kv heads through a
  * recovered fault: every head scores the shared positions and the same draws.  The position row (shared) is written by kv head
  * 0's inserting workgroup ahead of the hand-off — idempotent on a retry; the count by kv head 0 at its commit. */
 int cc_decode_step_head_constant_rc(const cc_kv_view* c, int32_t policy, const void* q, const void* k_new, const void* v_new,
@@ -248,6 +248,12 @@ int cc_l2_next_key_init(const cc_kv_view* c, const int32_t* input_pos, void* key
 int cc_decode_step_l2(const cc_kv_view* c, const void* q, const void* k_new, const void* v_new, const int32_t* input_pos,
                       void* key_norm, uint64_t* next_key, int32_t global_tokens, int32_t recent_window, int32_t HQ,
                       float scale, void* y, void* workspace, size_t workspace_bytes, cc_stream_t stream);
+/* ... with the recoverable hand-off (r4; step_commit as in cc_decode_step_heavy_hitter_rc).  The norm maximum crosses kv heads, but
+ * every workgroup republishes its own maximum on a retry and the inserted key's norm is stored with the insert (idempotent), so a
+ * retried head scores against the same maximum the committed ones did. */
+int cc_decode_step_l2_rc(const cc_kv_view* c, const void* q, const void* k_new, const void* v_new, const int32_t* input_pos,
+                         void* key_norm, uint64_t* next_key, int32_t* step_commit, int32_t global_tokens, int32_t recent_window,
+                         int32_t HQ, float scale, void* y, void* workspace, size_t workspace_bytes, cc_stream_t stream);
 /* The same two-launch step for KVCacheHeavyHitter with a finite history window (history_window_size W > 1): the score is
  * dtype(sum_W ring) / clamp(denom, 1, W) over the TRACKED window sums (see cc_hh_ring_update); the evicted slot's ring
  * row, shadow column, accumulator and denom restart from zero inside the combine pass (cache.py:754-763), which also
@@ -293,16 +299,23 @@ int32_t cc_decode_step_status_offset(void);
  * random: cc_decode_step_recent_global / cc_decode_step_random) and l2 (cc_decode_step_l2: every workgroup also gathers every
  * workgroup's norm maximum) take the single launch under the same conditions (l2: at most 768 workgroups, 32 kv heads). */
 void cc_decode_step_set_single_launch(int32_t enabled);
-/* The heavy-hitter layer step with the RECOVERABLE hand-off (r3): cc_decode_step_heavy_hitter_phases plus `step_commit`, int32 [H]
- * on the device, -1 = nothing committed (reset it whenever positions restart).  Single-launch form (early (m, l) hand-off):
+/* The heavy-hitter layer step with the RECOVERABLE hand-off (r3; per-workgroup commit words r4): cc_decode_step_heavy_hitter_phases
+ * plus `step_commit`, int32 [H, cc_decode_step_commit_stride()] on the device, all -1 = nothing committed (reset it whenever
+ * positions restart).  ref: the reference has no hand-off to time out (cache.py:725-765, 716-722); this is what makes ours safe.
+ * Words of kv head h: [0] = (slot << 1) | was_empty of the slot position [1]'s insert went to (-1: none), [2 + split] = the last
+ * position whose step workgroup `split` of the head has committed.  Single-launch form (early (m, l) hand-off):
  *   - a launch that finds the status word set returns at once (a step of this token failed: nothing is built on its output);
- *   - a workgroup that gives up waiting sets the status word and its head's fail word; every workgroup of that head then commits
- *     NOTHING of the step (history, keys, count, y): a head's step is committed whole — step_commit[h] = *input_pos — or not at all;
- *   - a head with step_commit[h] == *input_pos REPLAYS: attention over the cache as the committed step left it (same y, bit for
- *     bit), no insert, no state change.
+ *   - a workgroup that gives up waiting sets the status word and its head's fail word; a workgroup that reads the fail word with
+ *     its last gather commits nothing; one that does not commits ITS part — its slots' history, its next-eviction keys, its word
+ *     [2 + split] = *input_pos (split 0: also the head's count and the step counter) — and nothing else;
+ *   - a workgroup whose word equals *input_pos recomputes its scores and partials (the hand-off needs them: same values, bit for
+ *     bit) and stores nothing; every workgroup of a head whose word [1] equals *input_pos takes the insert slot from word [0] (the
+ *     key row may already hold the next position's keys).  Whatever the interleaving of give-ups and commits inside the failed
+ *     launch, every slot's history is updated exactly once per position: a retry is idempotent per workgroup.
  * So the caller recovers by clearing the status word, advancing the workspace's epoch words (attention_utils.
- * reset_single_launch_status does both) and running the SAME token again: committed heads replay, the others step.  Other
- * launch forms ignore step_commit (nothing in them can time out).  step_commit may be NULL: no replay, counts bumped at the insert. */
+ * reset_single_launch_status does both) and running the SAME token again.  Other launch forms ignore step_commit (nothing in them
+ * can time out).  step_commit may be NULL: no replay, counts bumped at the insert. */
+int32_t cc_decode_step_commit_stride(void);
 int cc_decode_step_heavy_hitter_rc(const cc_kv_view* c, const void* q, const void* k_new, const void* v_new,
                                    const int32_t* input_pos, double* num, int32_t* denom, int64_t* counter,
                                    uint64_t* next_key, int32_t* step_commit, int32_t global_tokens, int32_t recent_window,
@@ -459,6 +472,14 @@ int cc_decode_step_quant(const cc_kv_view* c, float* qparams, int32_t n_bit, int
                          int64_t* counter, const float* rand_next, uint64_t* next_key, int32_t global_tokens,
                          int32_t recent_window, int32_t HQ, float scale, void* y, void* attn_out, void* workspace,
                          size_t workspace_bytes, cc_stream_t stream, int32_t phases);
+/* ... with the recoverable hand-off and, for policy 3, the in-kernel uniform draws (r4): rand_next may be NULL — the draws are then
+ * the stateless hash of (seed, position, slot) that cc_decode_step_random_rng uses (the pipeline must have been seeded with
+ * cc_random_next_key_init_rng on the same seed).  step_commit as in cc_decode_step_heavy_hitter_rc (may be NULL). */
+int cc_decode_step_quant_rc(const cc_kv_view* c, float* qparams, int32_t n_bit, int32_t policy, const void* q, const void* k_new,
+                            const void* v_new, const int32_t* input_pos, double* num, int32_t* denom, int64_t* counter,
+                            const float* rand_next, uint64_t seed, uint64_t* next_key, int32_t* step_commit, int32_t global_tokens,
+                            int32_t recent_window, int32_t HQ, float scale, void* y, void* workspace, size_t workspace_bytes,
+                            cc_stream_t stream, int32_t phases);
 int32_t cc_decode_step_quant_single_launch(int32_t HQ, int32_t H, int32_t S, int32_t D, int32_t dtype, int32_t n_bit);
 
 /* ------------------------------------------------------------------------------------------------

@@ -1526,9 +1526,12 @@ int cc_decode_step_heavy_hitter_phases_cpu(const cc_kv_view* c, const void* q, c
                                          attn_out, workspace, workspace_bytes, stream);
 }
 
-/* The device entry point with the recoverable hand-off's commit words: on the CPU nothing can time out — the step runs, then
- * every head is marked committed for this position (what the device leaves behind after a successful launch); a head that is
- * ALREADY committed for this position makes the whole call a refusal here (the replay form is a device matter). */
+/* The device entry point with the recoverable hand-off's commit words (r4 layout: CC_RC_STRIDE int32 per kv head — [0] the insert
+ * word, [1] its position, [2 + split] the position workgroup `split` committed): on the CPU nothing can time out — the step runs,
+ * then every head is marked for this position in word [1] and in word [2] (the one workgroup a CPU has; word [0], the insert slot,
+ * is the device's business and is set to -1 here); a head ALREADY marked for this position makes the whole call a refusal (the
+ * replay form is a device matter). */
+#define CC_RC_STRIDE 66
 int cc_decode_step_heavy_hitter_rc_cpu(const cc_kv_view* c, const void* q, const void* k_new, const void* v_new,
                                        const int32_t* input_pos, double* num, int32_t* denom, int64_t* counter,
                                        uint64_t* next_key, int32_t* step_commit, int32_t g, int32_t w, int32_t HQ, float scale,
@@ -1536,11 +1539,14 @@ int cc_decode_step_heavy_hitter_rc_cpu(const cc_kv_view* c, const void* q, const
   if ((phases & 3) != 3) return CC_ERR_UNSUPPORTED;
   if (step_commit && input_pos && c)
     for (int h = 0; h < c->H; h++)
-      if (step_commit[h] == *input_pos) return CC_ERR_UNSUPPORTED;
+      if (step_commit[h * CC_RC_STRIDE + 2] == *input_pos) return CC_ERR_UNSUPPORTED;
   const int rc = cc_decode_step_heavy_hitter_cpu(c, q, k_new, v_new, input_pos, num, denom, counter, next_key, g, w, HQ, scale, y,
                                                  NULL, workspace, workspace_bytes, stream);
   if (rc == CC_OK && step_commit)
-    for (int h = 0; h < c->H; h++) step_commit[h] = *input_pos;
+    for (int h = 0; h < c->H; h++) {
+      step_commit[h * CC_RC_STRIDE] = -1;
+      step_commit[h * CC_RC_STRIDE + 1] = step_commit[h * CC_RC_STRIDE + 2] = *input_pos;
+    }
   return rc;
 }
 
@@ -1883,7 +1889,7 @@ int cc_decode_step_head_constant_rc_cpu(const cc_kv_view* c, int32_t policy, con
   if (!view_ok(c) || !input_pos || (policy != 2 && policy != 3) || (policy == 2 && rand_next)) return CC_ERR_BAD_ARG;
   if (step_commit)
     for (int h = 0; h < c->H; h++)
-      if (step_commit[h] == *input_pos) return CC_ERR_UNSUPPORTED;
+      if (step_commit[h * CC_RC_STRIDE + 2] == *input_pos) return CC_ERR_UNSUPPORTED;
   int rc;
   if (policy == 2)
     rc = cc_decode_step_recent_global_cpu(c, q, k_new, v_new, input_pos, next_key, g, HQ, scale, y, workspace, workspace_bytes, stream);
@@ -1894,6 +1900,9 @@ int cc_decode_step_head_constant_rc_cpu(const cc_kv_view* c, int32_t policy, con
     rc = cc_decode_step_random_rng_cpu(c, q, k_new, v_new, input_pos, seed, next_key, g, w, HQ, scale, y, workspace, workspace_bytes,
                                        stream);
   if (rc == CC_OK && step_commit)
-    for (int h = 0; h < c->H; h++) step_commit[h] = *input_pos;
+    for (int h = 0; h < c->H; h++) {
+      step_commit[h * CC_RC_STRIDE] = -1;
+      step_commit[h * CC_RC_STRIDE + 1] = step_commit[h * CC_RC_STRIDE + 2] = *input_pos;
+    }
   return rc;
 }

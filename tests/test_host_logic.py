@@ -259,9 +259,9 @@ def test_recoverable_classification_and_key_row_shapes():
     for strategy in ("heavy_hitter", "recent_global", "full", "random"):
         kv = mk(strategy)
         assert kv.recoverable(), strategy
-        assert tuple(kv.next_key.shape)[0] == H and tuple(kv.step_commit.shape) == (H,) and int(kv.step_commit.max()) == -1
+        assert tuple(kv.next_key.shape)[0] == H and tuple(kv.step_commit.shape) == (H, 66) and int(kv.step_commit.max()) == -1
     assert not mk("heavy_hitter", history_window_size=8).recoverable()  # the ring step carries no commit words
-    assert not mk("l2").recoverable()  # its norm maximum crosses kv heads
+    assert mk("l2").recoverable()  # (r4: per-workgroup commit words; the norm maximum is republished by every workgroup on a retry)
     rnd = mk("random")
     rnd._rand = lambda: torch.zeros(S)  # an injected vector would be drawn again by a retry
     assert not rnd.recoverable() and not rnd._in_kernel_rng()

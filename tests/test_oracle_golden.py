@@ -398,7 +398,7 @@ def _pipeline_replay(oracle, c, f, T, g, w, strategy, entry):
     H, S, D = c.H, c.S, c.D
     nk = int(o.fns()["cc_hh_next_key_slots"](S))
     key = np.full((H, nk), ~np.uint64(0), np.uint64)
-    commit = np.full(H, -1, np.int32)
+    commit = np.full((H, 66), -1, np.int32)  # (include/coldcompress.h: insert word, its position, one word per workgroup)
     steps = f["steps"]
     rand = [f["rand_u"][t].numpy().astype(np.float32).copy() for t in range(steps)] if strategy == "random" else None
     p0 = _i32(T)
@@ -419,7 +419,7 @@ def _pipeline_replay(oracle, c, f, T, g, w, strategy, entry):
             o.call("cc_decode_step_head_constant_rc", C.byref(c.view()), 3 if strategy == "random" else 2, o.ptr(q), o.ptr(kn), o.ptr(vn),
                    o.ptr(pp), o.ptr(nxt) if nxt is not None else None, 0, o.ptr(key), o.ptr(commit), g, w, HQ, 0.25, o.ptr(y), o.ptr(ws),
                    ws.size, None)
-            assert bool((commit == T + t).all())
+            assert bool((commit[:, 1:3] == T + t).all()) and bool((commit[:, 3:] == -1).all())
         elif strategy == "random":
             o.call("cc_decode_step_random", C.byref(c.view()), o.ptr(q), o.ptr(kn), o.ptr(vn), o.ptr(pp), o.ptr(nxt), o.ptr(key), g, w, HQ,
                    0.25, o.ptr(y), o.ptr(ws), ws.size, None)

@@ -297,6 +297,51 @@ def one_quant(rng, idx):
     return ""
 
 
+class Forced:
+    """random.Random whose choice() call number i returns plan[i] where given (None: a small cache length, drawn)."""
+
+    def __init__(self, seed, plan):
+        self.r, self.plan, self.n = random.Random(seed), plan, 0
+
+    def choice(self, seq):
+        i, self.n = self.n, self.n + 1
+        if i in self.plan:
+            v = self.plan[i]
+            return self.r.randint(70, 190) if v is None else v
+        return self.r.choice(seq)
+
+    def __getattr__(self, name):
+        return getattr(self.r, name)
+
+
+# family: (function, {index of the choice() call: forced value}, index of the strategy's choice() call or None)
+SMALL_GRID = {
+    "step": (one, {3: 8, 7: None}, 0),            # strategy, dtype, D, H, R, [two nested choices], S
+    "ring": (one_ring, {3: 8, 5: None}, 0),       # strategy, dtype, D, H, R, S
+    "hybrid": (one_hybrid_step, {1: 8, 4: None}, None),  # dtype, H, R, [nested], S
+    "quant": (one_quant, {2: 8, 5: None}, 0),     # strategy, dtype, H, R, [nested], S
+}
+
+
+def small_grid_stress(family, n, strategy=None, seed0=7000, extra=None):
+    """The fuzz families with 8 kv heads and 70 .. 190 slots — one or two splits per kv head: 8-16 workgroups, where late-waking XCDs
+    expose ordering holes between workgroups (how the shared key row of round 3 was found).  -> (cases run, list of mismatches)."""
+    fn, plan, si = SMALL_GRID[family]
+    plan = dict(plan)
+    if strategy is not None:
+        plan[si] = strategy
+    plan.update(extra or {})
+    ran, bad = 0, []
+    for i in range(n):
+        r = fn(Forced(seed0 + i, plan), i)
+        if r is None:
+            continue
+        ran += 1
+        if r:
+            bad.append(r)
+    return ran, bad
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=300)
