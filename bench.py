@@ -280,7 +280,7 @@ def roofline(model, args, dev):
     traffic, traffic_src = None, None
     live = None
     if one and not args.no_live_pmc and (H, S, D, HQ) == (8, 4096, 128, 32):
-        live = live_traffic("decode_attn_split_mfma_kernel<bf16_t, 4, 8, false, true, false, 0")
+        live = live_traffic(f"decode_attn_split_mfma_kernel<bf16_t, 4, {nw}, false, true, false, 0")
     if live:
         traffic = live["traffic"]
         traffic_src = ("measured in this run: rocprofv3 --pmc FETCH_SIZE (x2, gfx950 wide-read correction) and --pmc WRITE_SIZE, separate "
@@ -289,14 +289,14 @@ def roofline(model, args, dev):
     try:
         if live:
             raise OSError("measured live")
-        with open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")) as f:
             ks = json.load(f)["kernels"]
         # the single-launch instantiation (RT = 4, 8 waves, not l2, ONE, not hybrid), whatever trailing defaults the name carries
-        keys = [n for n in ks if n.startswith("decode_attn_split_mfma_kernel<bf16_t, 4, 8, false, true, false, 0")] if one else []
+        keys = [n for n in ks if n.startswith(f"decode_attn_split_mfma_kernel<bf16_t, 4, {nw}, false, true, false, 0")] if one else []
         k = ks[keys[0]] if keys else None
         if k and (H, S, D, HQ) == (8, 4096, 128, 32):
             traffic = k["traffic_bytes"]
-            traffic_src = ("profiles/r03_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950 wide-read correction) "
+            traffic_src = ("profiles/r04_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950 wide-read correction) "
                            "+ --pmc WRITE_SIZE, separate passes, median per launch; fetch %d + write %d B"
                            % (k["fetch_bytes"], k["write_bytes"]))
     except (OSError, KeyError, ValueError):

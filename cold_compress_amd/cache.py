@@ -445,6 +445,9 @@ class _RingFusedStep:
     def prepare_decode(self, input_pos):
         self._pipeline_init(self._pos32(input_pos))
         self._next_valid = True
+        # a re-seeded pipeline starts from no committed position: a caller that rolled the cache back and runs a position AGAIN
+        # gets a step, not the recoverable hand-off's replay of it (a retry after a failed hand-off does not come here)
+        self.step_commit.fill_(-1)
 
     def decode_step(self, query, k_val, v_val, input_pos, scale=None):
         from .attention_utils import _workspace
@@ -717,6 +720,7 @@ class KVCacheHeavyHitter(_TrackedWindowSums, KVCacheHeadSpecific):
                       _ptr(self.attn_history_denom), int(self.global_tokens), int(self.recent_window), _ptr(self.next_key),
                       _stream())
         self._next_valid = True
+        self.step_commit.fill_(-1)  # (a re-seeded pipeline starts from no committed position: see _RingFusedStep.prepare_decode)
 
     def decode_step(self, query, k_val, v_val, input_pos, scale=None):
         """update_kv + attention over the pruned cache + update_state for one decode token in ONE launch where the shape and the

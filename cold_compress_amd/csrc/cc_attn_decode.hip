@@ -32,6 +32,11 @@
 #ifndef CC_V_LDSDMA
 #define CC_V_LDSDMA 1   // K / V tiles land in the wave's LDS slabs directly (buffer_load ... lds): no staging registers, no ds_write
 #endif
+#ifndef CC_V_EMLMT
+#define CC_V_EMLMT 0    // 1: the several-tiles-per-wave steps take the early-(m, l) order too — MEASURED A LOSS (r4, one box: S = 8192 12.3 ->
+                        // 12.8 us, 18432 21.0 -> 21.75, 32768 32.8 -> 33.9): two gathers in series and one more barrier, and per-slot passes
+                        // of 1.5+ us that a 0.4 us partial-O round trip cannot hide; kept compilable for the record
+#endif
 #ifndef CC_V_MLW
 #define CC_V_MLW 1      // the final (M, L) fold runs on the workgroup's LAST waves (idle during the partial-O publish of the first ones)
 #endif
@@ -587,6 +592,7 @@ constexpr int kRcStride = 66;                  // step_commit: int32 per kv head
 constexpr int kOneMlHead = 64 * 8 * 16;        // (m, l): 64 splits x up to 8 query heads x 16 B
 constexpr int kOneOHead = 8 * 64 * 64 * 16;    // O: up to 8 query heads x 64 splits x 64 pairs x 16 B
 constexpr int kOneNmHead = 64 * 16;            // l2: one norm-maximum granule per split
+constexpr int kOneHmBytes = 32 * 16;           // l2 (two-level exchange): one norm-maximum granule per kv HEAD, behind the per-split regions
 constexpr int kOneMaxHeads = 32;
 constexpr int kOneAuxCoherent = 17;         // sc0 sc1: write-through stores / loads that bypass the non-coherent L1 (and stale L2 lines)
 
@@ -677,12 +683,21 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
   // EML (r3): the workgroup's (m, l) pairs leave EARLY — right behind the scores, while the V rows are still in flight — so that
   // the final (M, L) of the head, the probabilities, the history update and the next-eviction keys run in the shadow of the
   // partial-O exchange; what is left behind the last O granule is the y fold alone
-  constexpr bool EML = ONE1 && !HYB;  // (l2 included since late r3: its norm maxima leave with the (m, l) pairs)
+  // (l2 included since late r3: its norm maxima leave with the (m, l) pairs.  r4: the several-tiles-per-wave steps too — their pairs
+  //  leave behind the LAST tile, ahead of the cross-wave merge: the finish's per-slot passes then run in the shadow of the partial-O
+  //  exchange instead of behind it, the state stores sit behind the last gather, and the step is recoverable like the single-tile one.)
+  constexpr bool EML = ONE && !HYB && (NT == 1 || CC_V_EMLMT != 0);
 #ifdef CC_NO_RC  // (A/B builds)
   constexpr bool RC = false;
 #else
   constexpr bool RC = EML;  // the recoverable hand-off (status / commit / fail words, state stores behind the last gather) rides the same kinds
 #endif
+  // L2X (r4): the l2 policy's norm maximum crosses kv heads (cache.py:602).  With the placement of XL2 it travels in two levels:
+  // the workgroups' maxima inside the head's XCD (plain granules, gathered with the (m, l) pairs by one wave), then ONE granule
+  // per kv head through memory (published by the head's split-0 workgroup, gathered by one wave per workgroup in the shadow of the
+  // partial-O exchange) — instead of every thread of every workgroup gathering all H x n_split maxima through memory ahead of the
+  // final (M, L).  max is associative: the same value, hence the same keys, bit for bit.
+  constexpr bool L2X = L2 && XL2 && EML;
   static_assert(sizeof(T) == 2 && (RT == 1 || RT == 2 || RT == 4 || RT == 8), "16-bit caches, up to 8 query heads per pass (the MFMA has 16 columns)");
   static_assert(!ONE || NW == 4 || (NW == 8 && NT == 1), "the single-launch step runs on 4-wave workgroups, or on ONE 8-wave workgroup per CU (single tile)");
   constexpr int D = 128, VEC = 8, RPW = 4, U = 4;
@@ -702,6 +717,8 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
   __shared__ unsigned sm_mlcnt;                    // EML: waves whose (m, l) rows are in LDS — the LAST one to arrive publishes
   __shared__ unsigned sm_fail;                     // EML: some wave of this workgroup gave up waiting (recoverable hand-off)
   __shared__ float sm_l2w[NW];  // ONE + L2: per-wave maxima of the norms this workgroup's slots hold AFTER the step's insert
+  __shared__ __attribute__((aligned(16))) T sm_l2sc[L2 ? NW : 1][L2 ? 128 : 8];  // l2: the new key, transposed for its norm (the slabs belong to the DMA loads)
+  __shared__ float sm_gmax;     // L2X: the norm maximum over all kv heads (NaN propagates)
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, c = lane & 15;  // row group of the wave / 16-byte column chunk (and MFMA column n)
@@ -798,7 +815,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
   // (g, c) asks for row 4u + g, the chunk that belongs in slot c of that row under the slab's swizzle) into one contiguous 1 KiB
   // block (lane L -> byte 16 L); no staging registers, no ds_write, and the row OWNERSHIP of the scores (row group g: rows 4g .. 4g + 3,
   // the MFMA's C layout) is untouched
-  constexpr bool DMA = CC_V_LDSDMA != 0 && ONE1 && QB == 0 && !L2 && !HYB;
+  constexpr bool DMA = CC_V_LDSDMA != 0 && ONE1 && QB == 0 && !HYB;
   // (buffer_load ... lds, not global_load_lds: the compiler's wait-count pass treats the FLAT-encoded form as an access to both
   //  memories and turns every later wait into vmcnt(0) lgkmcnt(0) while one is pending; the MUBUF form is counted exactly)
   auto dma16 = [](__amdgpu_buffer_rsrc_t rs, int voff, void* lp) {
@@ -1090,6 +1107,10 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
     qb_vn.load(reinterpret_cast<const T*>(a.v_new) + (size_t)h * D + c * VEC);
     p_ins = *a.input_pos;
   }
+  unsigned hm_ep = 0;  // L2X: the epoch word of kv head `lane` (its head-maximum granule carries that tag)
+  if constexpr (L2X) {
+    hm_ep = a.one_hdr[lane < a.H ? lane : 0];  // (ahead of the tile and of anything this workgroup publishes, like l2_ep below)
+  } else
   if constexpr (L2 && EML) {
     // the epoch words of the kv heads whose norm granules this thread gathers — AHEAD of the tile here: this workgroup's first
     // publish (its (m, l) pairs and norm maximum, right behind the scores) must not happen before these loads have completed
@@ -1243,6 +1264,8 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
         // the new rows were requested BEHIND the tile's DMA loads and loads return in order: when kn / vn are here, the stale cache
         // rows have landed in the slabs and may be overwritten
         const int i = 4 * g + um;
+        // (l2 requests the new rows AHEAD of the tile — their arrival says nothing about the DMA loads: wait for those explicitly)
+        if constexpr (AHEAD) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         sm_k[wave][i][c] = kn.raw;                           // (kn is chunk c ^ i: slot c of row i)
         sm_v[wave][i][(c ^ (2 * (i & 7))) & 15] = vn.raw;    // (vn is chunk c)
       }
@@ -1292,7 +1315,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
           // the canonical order wants elements c, c + 16, ... of the key in lane c; the lanes of this row group hold chunk c (elements
           // 8c .. 8c + 7): transposed through the wave's V slab (not yet in use: the V tile is stashed after the scores) — eight more
           // loads per wave of the whole launch, ahead of the tile, cost every workgroup's first K rows ~0.4 us
-          T* scratch = reinterpret_cast<T*>(&sm_v[wave][0][0]);
+          T* scratch = &sm_l2sc[wave][0];
           *reinterpret_cast<uint4*>(scratch + c * VEC) = qb_kn.raw;
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
@@ -1434,24 +1457,9 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
     tile_qk(R, tbase, tbase_next, more_next, ti_c);
     tile_pv(R, tbase_next, more_next);
   };
-  if constexpr (ONE && NT > 1) {
-    // the wave's tiles, unrolled: tile TI keeps its scores in s_keep[TI] for the finish (at most NT tiles: one_shape_ok)
-    auto run_tiles = [&](auto self, auto ti_c) -> void {
-      constexpr int TI = decltype(ti_c)::value;
-      if constexpr (TI < NT) {
-        const int tb = base + TI * (NW * RPW * U);
-        if (tb < row_end) {
-          tile(tregs[0], tb, tb + NW * RPW * U, TI + 1 < NT && tb + NW * RPW * U < row_end, ti_c);
-          self(self, IntC<TI + 1>{});
-        }
-      }
-    };
-    if (more) run_tiles(run_tiles, IntC<0>{});
-  } else if constexpr (EML) {
-    // single tile, early (m, l): scores -> [the workgroup's (m, l) pairs leave] -> P.V.  A wave without rows (ragged last split)
-    // skips the tile halves but not the arrival counter: its pair is (-inf, 0).
-    if (more) tile_qk(tregs[0], base, base, false, IntC<0>{});
-    {
+  // EML: the wave's (m, l) row goes to LDS; the LAST wave to arrive merges the workgroup's pairs and publishes them — behind the
+  // scores of the wave's only tile (NT == 1: ahead of its P.V products), or behind the wave's last tile (NT > 1)
+  auto ml_block = [&]() {
       l = xor_combine<32, false>(xor_combine<16, false>(l));  // the wave's l of head c, in every row group
       if (lane < RT) {                                          // row group 0, column c = head
         sm_wm[wave][lane] = m;
@@ -1464,7 +1472,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
         const float wm = wave_max_f32(kv);
         if (lane == 0) sm_l2w[wave] = nn ? NAN : wm;
         // the other heads' epoch words have ARRIVED (they were requested ahead of the tile): see above
-        asm volatile("" ::"v"(l2_ep[0]), "v"(l2_ep[1]), "v"(l2_ep[2]) : "memory");
+        asm volatile("" ::"v"(l2_ep[0]), "v"(l2_ep[1]), "v"(l2_ep[2]), "v"(hm_ep) : "memory");
       }
       // No barrier: the waves' K tiles land up to 2 us apart, and a barrier here held every wave's P.V back until the workgroup's
       // LAST K tile had arrived (measured, r3: +0.8 us on the streaming part).  Each wave bumps an LDS counter behind its two
@@ -1520,10 +1528,29 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
           }
           const u32x4_t ng = {one_tag, __float_as_uint(wm), one_tag, nn ? 1u : 0u};
           const int noff = (arrived == (unsigned)(NW - 1) && lane == RT) ? kOneMaxHeads * kOneMlHead + h * kOneNmHead + split * 16 : 0x7ffffff0;
-          __builtin_amdgcn_raw_buffer_store_b128(ng, ml_rsrc_e, noff, 0, kOneAuxCoherent);
+          __builtin_amdgcn_raw_buffer_store_b128(ng, ml_rsrc_e, noff, 0, L2X ? 0 : kOneAuxCoherent);  // (L2X: gathered inside the XCD)
         }
       }
-    }
+      };
+  if constexpr (ONE && NT > 1) {
+    // the wave's tiles, unrolled: tile TI keeps its scores in s_keep[TI] for the finish (at most NT tiles: one_shape_ok)
+    auto run_tiles = [&](auto self, auto ti_c) -> void {
+      constexpr int TI = decltype(ti_c)::value;
+      if constexpr (TI < NT) {
+        const int tb = base + TI * (NW * RPW * U);
+        if (tb < row_end) {
+          tile(tregs[0], tb, tb + NW * RPW * U, TI + 1 < NT && tb + NW * RPW * U < row_end, ti_c);
+          self(self, IntC<TI + 1>{});
+        }
+      }
+    };
+    if (more) run_tiles(run_tiles, IntC<0>{});
+    if constexpr (EML) ml_block();  // (a wave without rows arrives with (-inf, 0))
+  } else if constexpr (EML) {
+    // single tile, early (m, l): scores -> [the workgroup's (m, l) pairs leave] -> P.V.  A wave without rows (ragged last split)
+    // skips the tile halves but not the arrival counter: its pair is (-inf, 0).
+    if (more) tile_qk(tregs[0], base, base, false, IntC<0>{});
+    ml_block();
     if (more) tile_pv(tregs[0], base, false);
   } else {
     while (more) {
@@ -1589,6 +1616,35 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
         *reinterpret_cast<float4*>(&sm_wacc[wave][c][16 * b + 4 * g]) = make_float4(acc[b][0], acc[b][1], acc[b][2], acc[b][3]);
     }
   }
+  if constexpr (L2X) {
+    // L2X, level one — EARLY: the workgroups' norm maxima left with their (m, l) pairs, behind their scores; the last wave of the
+    // head's split-0 workgroup (the first blocks of the grid: among the first to start) gathers them through the XCD's L2 right here,
+    // ahead of the merge barrier, and publishes the head's maximum through memory for the other kv heads.  (After the merge barrier
+    // and the (m, l) gather it was 1.5 us later, and every workgroup of the launch ended behind it; every workgroup of the head
+    // storing the same granule was far worse: 32 write-through stores per address, 14.4 us per step.)
+    if (split == 0 && wave == NW - 1) {
+      const auto ml_rsrc_p = __builtin_amdgcn_make_buffer_rsrc(a.one_ml, 0, (int)a.one_ml_bytes, 0x00020000);
+      const int off1 = kOneMaxHeads * kOneMlHead + h * kOneNmHead + (lane < a.n_split ? lane : 0) * 16;
+      u32x4_t nmx = {0u, 0u, 0u, 0u};
+      bool got = false;
+      for (unsigned spins = 0; spins <= kOneSpinMax; spins++) {
+        asm volatile("" ::: "memory");  // every round re-reads memory
+        nmx = __builtin_amdgcn_raw_buffer_load_b128(ml_rsrc_p, off1, 0, 16 /* sc1: the XCD's L2 */);
+        if (__all(lane >= a.n_split || (nmx[0] == one_tag && nmx[2] == one_tag))) {
+          got = true;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (got) {  // (not: nothing is published, and every workgroup of the launch times out on level two — reported like any hand-off timeout)
+        const float v = lane < a.n_split ? __uint_as_float(nmx[1]) : -INFINITY;
+        const bool hn = __any(lane < a.n_split && (nmx[3] != 0u || v != v)) != 0;
+        const float hmx = wave_max_f32(v);
+        const u32x4_t hg = {one_tag, __float_as_uint(hmx), one_tag, hn ? 1u : 0u};
+        __builtin_amdgcn_raw_buffer_store_b128(hg, ml_rsrc_p, lane == 0 ? kOneMaxHeads * (kOneMlHead + kOneNmHead) + h * 16 : 0x7ffffff0, 0, kOneAuxCoherent);
+      }
+    }
+  }
   __syncthreads();
   if constexpr (ONE) {
     // ============================================================================================================
@@ -1642,7 +1698,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
     for (int k = 0; k < MLN; k++) ml_off[k] = h * kOneMlHead + ((lane < ns ? lane : 0) * RT + (ml_w >= 0 && ml_w + k * NW < RT ? ml_w + k * NW : 0)) * 16;
     u32x4_t mlq[MLN];
     const int nm_base = kOneMaxHeads * kOneMlHead;  // l2: the norm-maximum granules sit behind the (m, l) regions of all heads
-    constexpr int NLG = L2 ? 3 : 0;  // l2: norm-maximum granules per thread (H * n_split <= 768 workgroups are ever co-resident)
+    constexpr int NLG = (L2 && !L2X) ? 3 : 0;  // l2, one-level exchange: norm-maximum granules per thread (H * n_split <= 768 workgroups are ever co-resident)
     int nm_off[NLG > 0 ? NLG : 1];
     bool nm_use[NLG > 0 ? NLG : 1];
     unsigned nm_tag[NLG > 0 ? NLG : 1];  // a granule of kv head h' carries h''s tag (its epoch word was read in the prologue: l2_ep)
@@ -1655,6 +1711,8 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
       nm_tag[k] = l2_ep[k] + 1u;
     }
     u32x4_t nq[NLG > 0 ? NLG : 1];
+    u32x4_t hmq = {0u, 0u, 0u, 0u};  // L2X: the kv heads' maxima (lane = kv head)
+    const int hm_base = kOneMaxHeads * (kOneMlHead + kOneNmHead);
     if constexpr (EML) {
       // the (m, l) pairs left behind the scores, long ago: their first round of loads goes out AHEAD of this workgroup's partial-O
       // stores (loads return in order: behind the stores they would also wait for the stores' acknowledgements, a round trip)
@@ -1662,6 +1720,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
 #pragma unroll
         for (int k = 0; k < MLN; k++) mlq[k] = __builtin_amdgcn_raw_buffer_load_b128(ml_rsrc, ml_off[k], 0, kGatherAux);
       }
+
       // l2: every workgroup's norm maximum (they left with the pairs), gathered by every thread of every workgroup; a thread
       // without a granule aims past the buffer's end (no request, zeros back): no branch around the loads
 #pragma unroll
@@ -1918,9 +1977,15 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
     // ---- this workgroup's slots.  ref: attention_utils.py:52 softmax -> model dtype; model.py:416-418 group mean -> model
     //      dtype; cache.py:716-722 history; cache.py:727-749 the next position's eviction score
     unsigned long long my_key = ~0ull;
-    double def_num = 0.0;  // EML: this lane's deferred history store (def_i < 0: none)
-    int32_t def_den = 0;
-    long long def_i = -1;
+    double def_num[NT];  // EML: this lane's deferred history stores, one per tile of the wave (def_i < 0: none)
+    int32_t def_den[NT];
+    long long def_i[NT];
+#pragma unroll
+    for (int ti = 0; ti < NT; ti++) {
+      def_num[ti] = 0.0;
+      def_den[ti] = 0;
+      def_i[ti] = -1;
+    }
     __shared__ float sm_hav[HYB ? NW : 1][HYB ? NT * RPW * U : 1];  // hybrid: group-mean probabilities, [wave][tile * 16 + row]
     auto slot_pass = [&](auto ti_c) {
       constexpr int TI = decltype(ti_c)::value;
@@ -1991,11 +2056,16 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
         if constexpr (L2) {  // ref: cache.py:597-605: dtype(max over ALL heads and slots - norm), recent window -> +inf, base rules
           float gm = -INFINITY;
           bool gn = false;
+          if constexpr (L2X) {
+            gm = sm_gmax;
+            gn = gm != gm;
+          } else {
 #pragma unroll
-          for (int w2 = 0; w2 < NW; w2++) {
-            const float v = sm_l2g[w2];
-            gn |= (v != v);
-            gm = fmaxf(gm, v);
+            for (int w2 = 0; w2 < NW; w2++) {
+              const float v = sm_l2g[w2];
+              gn |= (v != v);
+              gm = fmaxf(gm, v);
+            }
           }
           const float kn_eff = (slot_ti == ins_idx) ? l2_nv_lane : one_kn;
           float scn = ElemTraits<T>::rnd((gn ? NAN : gm) - kn_eff);
@@ -2008,9 +2078,9 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
           const double num_new = num_old + (double)av;
           const int32_t den_new = den_old + 1;
           if constexpr (RC) {  // stored behind the LAST gather and the head's fail word: a head's step is committed whole or not at all
-            def_num = num_new;
-            def_den = den_new;
-            def_i = (long long)i;
+            def_num[TI] = num_new;
+            def_den[TI] = den_new;
+            def_i[TI] = (long long)i;
           } else {
             a.num[i] = num_new;
             a.denom[i] = den_new;
@@ -2033,19 +2103,17 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
       }
       my_key = key_ti < my_key ? key_ti : my_key;
     };
-    {
-      // every tile of the wave (compile-time unrolled; tiles past the split's end hold no slot)
-      auto all_tiles = [&](auto self, auto ti_c) -> void {
-        constexpr int TI = decltype(ti_c)::value;
-        if constexpr (TI < NT) {
-          if (row_begin + wave * (RPW * U) + TI * (NW * RPW * U) < row_end) {  // wave-uniform: the wave has a tile TI
-            slot_pass(ti_c);
-            self(self, IntC<TI + 1>{});
-          }
+    // every tile of the wave (compile-time unrolled; tiles past the split's end hold no slot)
+    auto all_tiles = [&](auto self, auto ti_c) -> void {
+      constexpr int TI = decltype(ti_c)::value;
+      if constexpr (TI < NT) {
+        if (row_begin + wave * (RPW * U) + TI * (NW * RPW * U) < row_end) {  // wave-uniform: the wave has a tile TI
+          slot_pass(ti_c);
+          self(self, IntC<TI + 1>{});
         }
-      };
-      all_tiles(all_tiles, IntC<0>{});
-    }
+      }
+    };
+    if constexpr (!L2X) all_tiles(all_tiles, IntC<0>{});  // (L2X: behind the partial-O gather — the heads' maxima arrive with it)
     const int hyb_cts_n = hyb_cts + (hyb_kind == 0 ? 1 : 0);  // hybrid: the head's count after this step's insert
     if constexpr (HYB) {
       // ---- hybrid: ring column / exact window sum / denominator of every slot (cache.py:716-723 with W = 400), then the head's
@@ -2111,7 +2179,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
     // one key per WAVE (a head's key row has room for NW per 64-slot workgroup): nothing crosses the waves after the last
     // barrier of the finish, so no wave's stores wait for another wave (the launch ends a store round trip after the LAST
     // store is issued: every store that can go out early shortens it)
-    const unsigned long long wk = wave_min_u64_uniform(my_key);
+    unsigned long long wk = wave_min_u64_uniform(my_key);
     auto store_key = [&]() {
       if (lane == 0) {
         unsigned long long* nk_row = const_cast<unsigned long long*>(a.next_key) + (size_t)h * a.nk;
@@ -2123,8 +2191,16 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
     bool failed = false;  // EML: the head's step is not committed by this launch (somebody gave up)
     if constexpr (EML) {
       __builtin_amdgcn_sched_barrier(0);
+      // L2X, level two: the kv heads' maxima (lane = kv head), one wave per workgroup, through memory — requested here, behind the
+      // partial-O round (issued above), polled with it
+      const bool hm_mine = L2X && wave == NW - 1;
+      const int hm_off = hm_base + (lane < a.H ? lane : 0) * 16;
+      auto ok_hm = [&]() { return !hm_mine || lane >= a.H || (hmq[0] == hm_ep + 1u && hmq[2] == hm_ep + 1u); };
+      if constexpr (L2X) {
+        if (hm_mine) hmq = __builtin_amdgcn_raw_buffer_load_b128(ml_rsrc, hm_off, 0, kOneAuxCoherent);
+      }
       for (unsigned spins = 0;; spins++) {
-        if (__all(ok_o())) break;
+        if (__all(ok_o()) && __all(ok_hm())) break;
         if (RC && failq == tag) break;  // a workgroup of this head gave up: the head's step is not committed, nothing left to wait for
         if (spins > kOneSpinMax) {
           timed_out = true;
@@ -2133,19 +2209,38 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
         __builtin_amdgcn_s_sleep(1);
         asm volatile("" ::: "memory");  // every round re-reads memory
         load_o();
+        if constexpr (L2X) {
+          if (hm_mine) hmq = __builtin_amdgcn_raw_buffer_load_b128(ml_rsrc, hm_off, 0, kOneAuxCoherent);
+        }
       }
       if (a.trace) trE = __builtin_amdgcn_s_memtime();
       if (timed_out) give_up();
       else if (failq == tag && lane == 0) sm_fail = 1u;  // another workgroup of this head gave up: nothing of the head's step is committed
       stash_o();
+      if constexpr (L2X) {
+        if (hm_mine) {  // the maximum over all kv heads (NaN propagates: torch.max)
+          const float v = lane < a.H ? __uint_as_float(hmq[1]) : -INFINITY;
+          const bool gn = __any(lane < a.H && (hmq[3] != 0u || v != v)) != 0;
+          const float gm = wave_max_f32(v);
+          if (lane == 0) sm_gmax = gn ? NAN : gm;
+        }
+      }
       __syncthreads();  // (also makes the verdict workgroup-uniform)
       failed = sm_fail != 0u;
       if (!failed) {
         y_fold();
+        if constexpr (L2X) {  // the slots' next-eviction keys, now that the maximum is here (no history to update: l2 keeps none)
+          all_tiles(all_tiles, IntC<0>{});
+          wk = wave_min_u64_uniform(my_key);
+        }
         if (!rc_replay) {  // the step's state, behind the last gather and the fail word
-          if (RC && def_i >= 0) {
-            a.num[def_i] = def_num;
-            a.denom[def_i] = def_den;
+          if constexpr (RC) {
+#pragma unroll
+            for (int ti = 0; ti < NT; ti++)
+              if (def_i[ti] >= 0) {
+                a.num[def_i[ti]] = def_num[ti];
+                a.denom[def_i[ti]] = def_den[ti];
+              }
           }
           store_key();
         }
@@ -2639,11 +2734,15 @@ static int rows_per_iter(int D, int dtype, int nw = kNW) {
   return (64 / lpr) * kU * nw;
 }
 
-// kind: what rides the streaming pass (see one_kernel): 0 = a plain 16-bit cache (heavy hitter / head-constant policies / plain
-// attention), anything else = l2, hybrid, the fused quantised cache.  The step of ONE cache must always get the same plan,
-// whichever form (one launch, two, three calls) runs it: its partials — hence the last bits of (M, L) — depend on the geometry.
+// The step of ONE cache must always get the same plan, whichever form (one launch, two, three calls) and whatever rides the
+// streaming pass (plain attention, l2, hybrid, the fused quantised cache): its partials — hence the last bits of (M, L) — depend on
+// the geometry.
 static int g_wide_enabled = 1;  // cc_decode_step_set_wide: 8-wave workgroups where the plan allows them
-static Plan make_plan(int HQ, int H, int S, int D, int dtype, int kind = 0) {
+static Plan make_plan_w(int HQ, int H, int S, int D, int dtype, bool wide_allowed);
+static Plan make_plan(int HQ, int H, int S, int D, int dtype, bool narrow = false) {
+  return make_plan_w(HQ, H, S, D, dtype, !narrow && g_wide_enabled != 0);
+}
+static Plan make_plan_w(int HQ, int H, int S, int D, int dtype, bool wide_allowed) {
   Plan p;
   const int R = HQ / H;
   p.nw = kNW;
@@ -2656,8 +2755,8 @@ static Plan make_plan(int HQ, int H, int S, int D, int dtype, int kind = 0) {
   // splits for every gatherer to fold, one merge per CU — 4 or 8 query heads per kv head; EVERY policy (the hybrid cache's real
   // sizes never qualify — several tiles per wave — but a step and the plain attention of its three-call twin must fold their
   // partials alike at every size: the geometry decides the last bits of (M, L))
-  (void)kind;
-  if (g_wide_enabled && cc_dt_size(dtype) == 2 && D == 128 && (p.rt == 4 || p.rt == 8) && R == p.rt) {
+  // narrow: the 4-wave plan whatever the switch says (the VALU measurement pass has no 8-wave form)
+  if (wide_allowed && cc_dt_size(dtype) == 2 && D == 128 && (p.rt == 4 || p.rt == 8) && R == p.rt) {
     const long tiles = (long)H * ((S + 15) / 16);
     // (measured, r3, same box: 1280 tiles (C2: S = 2560) wide 8.18 vs 8.46 us; 1024 tiles (S = 2048, or 4 kv heads at 4096) wide
     //  7.8-7.9 vs 7.35-7.75: from five tiles per CU on the 8-wave workgroup pays)
@@ -2772,7 +2871,8 @@ namespace {
 // The single-launch regions sit at FIXED offsets and fixed capacities, whatever the shape: caches of different lengths
 // (pyramid budgets) share one workspace and one set of epoch words, tags grow monotonically across all of them, and
 // nothing but the single-launch kernel ever writes a word that could be mistaken for a tag.
-constexpr size_t kOneHdrBytes = 4096, kOneMlCap = (size_t)kOneMaxHeads * (kOneMlHead + kOneNmHead), kOneOCap = (size_t)kOneMaxHeads * kOneOHead;
+constexpr size_t kOneHdrBytes = 4096, kOneMlCap = (size_t)kOneMaxHeads * (kOneMlHead + kOneNmHead) + 4096 /* kOneHmBytes, padded */,
+                 kOneOCap = (size_t)kOneMaxHeads * kOneOHead;
 constexpr size_t kOneBytes = kOneHdrBytes + kOneMlCap + kOneOCap;
 constexpr int kOneStatusWord = 1023;  // hdr[0 .. H): epochs; hdr[1023]: timeout word
 constexpr int kOneMaxTiles = 8;  // tiles per wave the single-launch step keeps scores for (NT = 4 or 8 instantiations)
@@ -2929,7 +3029,8 @@ static OneKernel one_kernel_xl2(int rt, int nt, int kind, bool full, int nw) {
     if constexpr (ElemTraits<T>::code != CC_DT_BF16) {
       return nullptr;
     } else {
-      if (rt != 4 || kind != 0) return nullptr;
+      if (rt != 4 || (kind != 0 && kind != -1)) return nullptr;
+      if (kind == -1) return nw == 8 ? CC_ONE_X(4, 8, true, 0, true) : nullptr;  // (l2: the traces' shape)
       return nw == 8 ? CC_ONE_X(4, 8, false, 0, true) : CC_ONE_X(4, 4, false, 0, true);
     }
   }
@@ -2976,14 +3077,17 @@ extern "C" {
 
 size_t cc_decode_attn_workspace_bytes(int32_t HQ, int32_t H, int32_t S, int32_t D, int32_t dtype) {
   if (HQ <= 0 || H <= 0 || HQ % H || S <= 0 || D <= 0 || !cc_dt_ok(dtype)) return 0;
-  const Plan p = make_plan(HQ, H, S, D, dtype, -1);  // the 4-wave plan: at least as many splits as the wide one (policy-agnostic size)
-  return kOneBytes + base_workspace_bytes(p, HQ, H, S, D, dtype);
+  // the larger of the two geometries' needs: the size must not depend on the process-wide cc_decode_step_set_wide switch (a caller
+  // that cached it — bench.py does — would otherwise get CC_ERR_WORKSPACE when the switch is flipped later)
+  const size_t a = base_workspace_bytes(make_plan_w(HQ, H, S, D, dtype, true), HQ, H, S, D, dtype);
+  const size_t b = base_workspace_bytes(make_plan_w(HQ, H, S, D, dtype, false), HQ, H, S, D, dtype);
+  return kOneBytes + (a > b ? a : b);
 }
 
 // kind: see one_kernel.  Returns the kernel when the shape is eligible AND all its workgroups stay resident at once, else null.
 static OneKernel one_pick(int32_t HQ, int32_t H, int32_t S, int32_t D, int32_t dtype, int kind, bool full, bool allow_xl2 = false) {
   if (HQ <= 0 || H <= 0 || HQ % H || S <= 0 || D <= 0 || !cc_dt_ok(dtype)) return nullptr;
-  const Plan p = make_plan(HQ, H, S, D, dtype, kind);
+  const Plan p = make_plan(HQ, H, S, D, dtype);
   const int nt = one_tiles(p, HQ, H, D, dtype);
   if (nt == 0) return nullptr;
   // l2: every thread gathers at most three workgroups' norm maxima
@@ -3113,7 +3217,7 @@ static int attn_impl(const void* q, const void* k, const void* v, const uint8_t*
   if (workspace_bytes < cc_decode_attn_workspace_bytes(HQ, H, S, D, dtype)) return CC_ERR_WORKSPACE;
   // what rides the streaming pass decides the plan (one_kernel's kinds)
   const int kind = !fs ? 0 : (fs->qparams ? 8 : (fs->policy == 4 ? -1 : (fs->policy == 6 ? 200 : 0)));
-  const Plan p = make_plan(HQ, H, S, D, dtype, (phases >> 8) & 32 ? -1 : kind);  // (measurement bit 32 forces the VALU pass: 4 waves)
+  const Plan p = make_plan(HQ, H, S, D, dtype, ((phases >> 8) & 32) != 0);  // (measurement bit 32 forces the VALU pass: 4 waves)
   if ((size_t)R * p.n_split * sizeof(float) > 64 * 1024) return CC_ERR_UNSUPPORTED;  // combine-kernel LDS budget
   char* ws = reinterpret_cast<char*>(workspace) + kOneBytes;  // the single-launch regions come first, at fixed offsets
   SplitArgs sa{};
@@ -3277,7 +3381,7 @@ int cc_decode_step_stream_floor(const cc_kv_view* c, int32_t HQ, void* scratch, 
   CC_ENTRY();
   if (!cc_view_ok(c) || !scratch || HQ <= 0 || HQ % c->H) return CC_ERR_BAD_ARG;
   if (cc_dt_size(c->dtype) != 2 || c->D != 128) return CC_ERR_UNSUPPORTED;
-  const Plan p = make_plan(HQ, c->H, c->S, c->D, c->dtype, 0);
+  const Plan p = make_plan(HQ, c->H, c->S, c->D, c->dtype);
   const dim3 grid(p.n_split, c->H, 1), block(p.nw * 64);
   hipStream_t st = (hipStream_t)stream;
   if (p.nw == 8)

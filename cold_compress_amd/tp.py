@@ -32,10 +32,11 @@ def maybe_init_dist() -> Optional[int]:
     rank, world = _get_rank(), _get_world_size()
     if world < 2:
         return None
+    # the host driver only supports dmabuf IPC: RCCL / IPC handles between the ranks need this (exported by the image; set here as
+    # well in case the launcher's environment lost it) — BEFORE the first torch.cuda call of this function, which may bring up
+    # HIP / HSA (behind torch.cuda.is_available() the setdefault could be too late)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if torch.cuda.is_available():
-        # the host driver only supports dmabuf IPC: RCCL / IPC handles between the ranks need this (exported by the image; set
-        # here as well in case the launcher's environment lost it) — before the first HIP call of this process
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(rank)
         backend = "nccl"  # RCCL
     else:

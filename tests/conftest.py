@@ -32,3 +32,23 @@ def pytest_collection_modifyitems(config, items):
     if last:
         rest = [it for it in items if it not in last]
         items[:] = rest + last
+
+
+# ---- the near-tie audit: tests that ACCEPT an eviction differing from the reference / the oracle when it is a
+#      rounding-level tie in the reference's own scores report how often they did — printed with the run's summary, also under -q.
+_AUDIT = []
+
+
+@pytest.fixture
+def audit(request):
+    def add(text):
+        _AUDIT.append(f"{request.node.nodeid}: {text}")
+
+    return add
+
+
+def pytest_terminal_summary(terminalreporter):
+    if _AUDIT:
+        terminalreporter.section("near-tie audit (accepted eviction differences: count / evictions compared)")
+        for line in _AUDIT:
+            terminalreporter.write_line(line)

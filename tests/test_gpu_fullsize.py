@@ -174,7 +174,7 @@ def test_hybrid_profiling_full_size(oracle_mt):
     assert (y.cpu().float()[0] - yr).abs().max() <= 0.05 * yr.abs().max()
 
 
-def test_heavy_hitter_prefill_to_decode_without_state_sync(oracle_mt):
+def test_heavy_hitter_prefill_to_decode_without_state_sync(oracle_mt, audit):
     """8192-token prompt -> SnapKV compaction to 4096 -> history from the column means -> 48 decode steps of the fused
     step, device and oracle each continuing from THEIR OWN numeric state (nothing is copied across after the prompt's
     keep set has been checked)."""
@@ -274,6 +274,7 @@ def test_heavy_hitter_prefill_to_decode_without_state_sync(oracle_mt):
         yr = from_np(yo1, dtype).float()
         assert (yd.cpu().float()[0, :, 0] - yr).abs().max() <= 1e-3 + 2 * BF16_ULP * yr.abs().max(), f"step {t}: y"
         assert np.array_equal(pos_after, st["pos"]), f"step {t}: positions"
+    audit(f"n_just = {justified} of {total} evictions (limit 5 %)")
     assert justified <= 0.05 * total, f"{justified} of {total} evictions were near-tie divergences"
     num_d = kv.attn_history_num.cpu()[0, :, :, 0].numpy()
     assert np.array_equal(kv.attn_history_denom.cpu()[0].numpy(), st["denom"])
@@ -351,7 +352,7 @@ def test_l2_prefill_to_decode_without_state_sync(oracle_mt):
     assert single_launch_status(kv.pos.device) == 0
 
 
-def test_hybrid_prefill_to_decode_without_state_sync(oracle_mt):
+def test_hybrid_prefill_to_decode_without_state_sync(oracle_mt, audit):
     """KVCacheHybrid end to end on its OWN numeric state (the f6 replays continue from the reference's ring):
     3000-token prompt -> matrix-core prefill with band sums -> per-head profiling -> ring seeded from the device's column means
     -> 48 fused decode steps.  The oracle runs the same pipeline from the same inputs: profiling by the row-by-row restatement of
@@ -467,6 +468,7 @@ def test_hybrid_prefill_to_decode_without_state_sync(oracle_mt):
             continue
         yr = from_np(yo1, dtype).float()
         assert (yd.cpu().float()[0, :, 0] - yr).abs().max() <= 1e-3 + 2 * BF16_ULP * yr.abs().max(), f"step {t}: y"
+    audit(f"n_just = {reseated} near-tie candidate re-seats in {steps} steps x {H} heads (limit 2)")
     assert reseated <= 2, f"{reseated} near-tie divergences in {steps} steps"
     assert evict_hh >= len(hh_heads) * (steps - 2) and evict_win >= len(win_heads) * (steps - 2)  # the budgets were full: real evictions
     assert np.array_equal(kv.attn_history_denom.cpu()[0].numpy(), st["denom"]) and int(kv.attn_counter) == int(st["ctr"][0])

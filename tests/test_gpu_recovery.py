@@ -284,14 +284,18 @@ def test_co_tenant_fault_is_recovered_in_band(strategy):
     try:
         clean_t, clean_s = run(fault_at=-1)
         assert not resets, "the fault-free run must not have needed a retry"
-        for attempt in range(3):  # (a run that provoked nothing has tested nothing — try again, then FAIL, never skip)
+        for attempt in range(6):  # (a run that provoked nothing has tested nothing — try again, then FAIL, never skip)
             fault_t, fault_s = run(fault_at=3)
             if resets:
                 break
+            # the co-tenant ran BEHIND the step instead of beside it: HIP maps streams onto a few hardware queues, and a side stream
+            # that shares the decode stream's queue is serialised with it (seen after tests that had used other streams).  The next
+            # stream of torch's pool sits on another queue.
+            side = torch.cuda.Stream()
     finally:
         au.reset_single_launch_status = orig_reset
         _abi.lib()["cc_decode_step_set_l2_handoff"](1)  # (a persistent failure switches it off for the process: not for the tests behind this one)
-    assert resets, "the co-tenant kernel did not provoke a hand-off timeout in three runs: the test did not test anything"
+    assert resets, "the co-tenant kernel did not provoke a hand-off timeout in six runs: the test did not test anything"
     assert fault_t == clean_t, f"tokens differ: {fault_t} vs {clean_t} after {len(resets)} retries"
     for l, (a, b) in enumerate(zip(clean_s, fault_s)):
         for n in a:

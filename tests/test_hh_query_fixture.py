@@ -35,7 +35,7 @@ def y_close(y_mine, y_ref):
     return float((y_mine - y_ref).abs().max()) <= 1e-3 + 2 * BF16_ULP * float(y_ref.abs().max())
 
 
-def test_oracle_pipeline_on_reference_query_trace(oracle):
+def test_oracle_pipeline_on_reference_query_trace(oracle, audit):
     """cc_decode_update_heavy_hitter_cpu + cc_decode_attn_gqa_cpu (history fused) against the reference's own pipeline."""
     o = oracle
     f = load_golden(NAME)
@@ -71,6 +71,7 @@ def test_oracle_pipeline_on_reference_query_trace(oracle):
         assert y_close(from_np(yo, dtype).float(), f["y"][t][0, :, 0].float()), f"step {t}: y"
         a_mine, a_ref = from_np(ao, dtype).float(), f["attn"][t][0, :, 0].float()
         assert bool(((a_mine - a_ref).abs() <= 2 * BF16_ULP * a_ref.abs() + 1e-30).all()), f"step {t}: group-mean probabilities"
+    audit(f"n_just = {n_just} of {steps * H} evictions (limit 5 %)")
     assert n_just <= 0.05 * steps * H, n_just
     assert np.array_equal(st["pos"], f["final_pos"][0].numpy())
     assert np.array_equal(st["k"], to_np(f["final_k"][0])) and np.array_equal(st["v"], to_np(f["final_v"][0]))
@@ -81,7 +82,7 @@ def test_oracle_pipeline_on_reference_query_trace(oracle):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("single", [True, False])
-def test_fused_step_on_reference_query_trace(single):
+def test_fused_step_on_reference_query_trace(single, audit):
     """KVCacheHeavyHitter.decode_step — single launch and two launches — replays the reference's query-driven trace."""
     import cold_compress_amd.cache as cache
 
@@ -117,6 +118,7 @@ def test_fused_step_on_reference_query_trace(single):
         y = kv.decode_step(f["q"][t].to(dev), f["k_new"][t].to(dev), f["v_new"][t].to(dev), pt)
         assert y_close(y.cpu().float()[0, :, 0], f["y"][t][0, :, 0].float()), f"step {t}: y"
     assert kv.step_status(HQ) == 0
+    audit(f"n_just = {n_just} of {steps * H} evictions (limit 5 %)")
     assert n_just <= 0.05 * steps * H, n_just
     assert torch.equal(kv.pos.cpu(), f["final_pos"])
     assert torch.equal(kv.k_cache.cpu(), f["final_k"]) and torch.equal(kv.v_cache.cpu(), f["final_v"])
