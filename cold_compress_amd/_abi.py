@@ -88,6 +88,7 @@ SIGNATURES = {
                                                  _vp, _i32]),
     "cc_debug_occupy": (C.c_int, [_i32, _i32, _i32, _vp, _vp]),
     "cc_decode_step_stream_floor": (C.c_int, [_view, _i32, _vp, _vp]),
+    "cc_decode_step_stream_floor_geom": (C.c_int, [_view, _i32, _i32, _vp, _vp]),
     "cc_rg_next_key_init": (C.c_int, [_view, _vp, _i32, _vp, _vp]),
     "cc_decode_step_recent_global": (C.c_int, [_view, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _sz, _vp]),
     "cc_hh_ring_next_key_init": (C.c_int, [_view, _vp, _vp, _i32, _vp, _i32, _i32, _vp, _vp]),
@@ -149,7 +150,7 @@ SIGNATURES = {
 
 # entry points that only the device library has (no `_cpu` twin)
 DEVICE_ONLY = {"cc_error_string", "cc_device_info", "cc_decode_step_single_launch", "cc_decode_step_status_offset",
-               "cc_decode_step_trace", "cc_decode_step_set_single_launch", "cc_decode_step_set_wide", "cc_decode_step_probe_xcd", "cc_decode_step_commit_stride", "cc_decode_step_l2_rc", "cc_decode_step_quant_rc", "cc_decode_step_set_l2_handoff", "cc_decode_step_l2_handoff", "cc_decode_step_stream_floor", "cc_debug_occupy", "cc_decode_step_quant_single_launch",
+               "cc_decode_step_trace", "cc_decode_step_set_single_launch", "cc_decode_step_set_wide", "cc_decode_step_probe_xcd", "cc_decode_step_commit_stride", "cc_decode_step_l2_rc", "cc_decode_step_quant_rc", "cc_decode_step_set_l2_handoff", "cc_decode_step_l2_handoff", "cc_decode_step_stream_floor", "cc_decode_step_stream_floor_geom", "cc_debug_occupy", "cc_decode_step_quant_single_launch",
                "cc_decode_step_hybrid_single_launch",
                # inter-GPU transport: no CPU twin (the oracle of the all-reduce is torch.distributed's)
                "cc_allreduce_handle_bytes", "cc_allreduce_create", "cc_allreduce_export", "cc_allreduce_connect", "cc_allreduce_sum",

@@ -3377,6 +3377,25 @@ __global__ __launch_bounds__(NW * 64) void kv_stream_floor_kernel(const uint4* _
 
 extern "C" {
 
+int cc_decode_step_stream_floor_geom(const cc_kv_view* c, int32_t waves, int32_t rows_per_workgroup, void* scratch, cc_stream_t stream) {
+  CC_ENTRY();
+  if (!cc_view_ok(c) || !scratch || rows_per_workgroup <= 0 || rows_per_workgroup % (16 * waves)) return CC_ERR_BAD_ARG;
+  if (cc_dt_size(c->dtype) != 2 || c->D != 128) return CC_ERR_UNSUPPORTED;
+  const dim3 grid((c->S + rows_per_workgroup - 1) / rows_per_workgroup, c->H, 1), block(waves * 64);
+  hipStream_t st = (hipStream_t)stream;
+  const uint4 *k = reinterpret_cast<const uint4*>(c->k_cache), *v = reinterpret_cast<const uint4*>(c->v_cache);
+  unsigned* out = reinterpret_cast<unsigned*>(scratch);
+  switch (waves) {
+    case 1: hipLaunchKernelGGL(kv_stream_floor_kernel<1>, grid, block, 0, st, k, v, c->S, rows_per_workgroup, out); break;
+    case 2: hipLaunchKernelGGL(kv_stream_floor_kernel<2>, grid, block, 0, st, k, v, c->S, rows_per_workgroup, out); break;
+    case 4: hipLaunchKernelGGL(kv_stream_floor_kernel<4>, grid, block, 0, st, k, v, c->S, rows_per_workgroup, out); break;
+    case 8: hipLaunchKernelGGL(kv_stream_floor_kernel<8>, grid, block, 0, st, k, v, c->S, rows_per_workgroup, out); break;
+    default: return CC_ERR_UNSUPPORTED;
+  }
+  CC_LAUNCH_CHECK();
+  return CC_OK;
+}
+
 int cc_decode_step_stream_floor(const cc_kv_view* c, int32_t HQ, void* scratch, cc_stream_t stream) {
   CC_ENTRY();
   if (!cc_view_ok(c) || !scratch || HQ <= 0 || HQ % c->H) return CC_ERR_BAD_ARG;

@@ -364,6 +364,10 @@ void cc_decode_step_trace(void* buf);
  * it beside the step (roofline.launch_floor_us, frac_of_launch_floor).  16-bit caches with head_dim 128; scratch: >= 4 bytes
  * of device memory (never written in practice). */
 int cc_decode_step_stream_floor(const cc_kv_view* c, int32_t HQ, void* scratch, cc_stream_t stream);
+/* ... with the geometry given (measurement hook, r4: profiles/r04_step_geometry_H1.jsonl): `waves` in {1, 2, 4, 8} waves per workgroup,
+ * `rows_per_workgroup` cache rows each (a multiple of 16 * waves) — what a launch costs that streams the cache in smaller pieces on
+ * more CUs (few kv heads per rank: tp.py:151-154). */
+int cc_decode_step_stream_floor_geom(const cc_kv_view* c, int32_t waves, int32_t rows_per_workgroup, void* scratch, cc_stream_t stream);
 /* The two-launch step for KVCacheHybrid (FastGen per-head policies; cache.py:896-1019 + the fused ring update of
  * cc_decode_attn_gqa_ring): three launches -> two.  What a head does with the incoming token — append at the end of its
  * live slots, evict its candidate, or drop the token (slot S - 1, mask untouched) — depends on its policy, its count, the

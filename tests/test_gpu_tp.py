@@ -63,18 +63,22 @@ def test_oneshot_allreduce_over_xgmi():
     _launch([], script="allreduce_check.py", marker="ONESHOT ALLREDUCE CHECK OK")
 
 
-def test_bench_gpus8_control_flow_dry_run():
+@pytest.mark.parametrize("oneshot", [False, True])
+def test_bench_gpus8_control_flow_dry_run(oneshot):
     """`bench.py --gpus 8` end to end on ONE GPU (CC_BENCH_DRYRUN_ONE_GPU=1: every rank on cuda:0, collectives staged through the
     host; NOT a measurement): self-launch of 8 ranks, the KV-head split down to H = 1 per rank (the shape every rank of the 8-GPU
     point runs), max-over-ranks timing, per-rank report, one JSON line from rank 0.  Two layers and a short prompt keep it cheap;
     the control flow is the full-size run's."""
     import json
 
-    env = dict(os.environ, CC_BENCH_DRYRUN_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    # oneshot (r4): the decode all-reduces on cc_allreduce_sum — IPC-mapped peer buffers of eight processes, verified against the
+    # staged collectives at start-up, all ranks or none — INSIDE the captured decode graph (what the 8-GPU point will run once the
+    # transport has proved itself over xGMI)
+    env = dict(os.environ, CC_BENCH_DRYRUN_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", CC_ONESHOT_ALLREDUCE="1" if oneshot else "0")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "6", "--warmup", "2", "--n_layer", "2",
-           "--prompt_len", "1024", "--cache_len", "512", "--no_cpu_baseline", "--no_live_pmc", "--roofline_iters", "2"]
+           "--prompt_len", "1024", "--cache_len", "512", "--no_cpu_baseline", "--no_live_pmc", "--roofline_iters", "2"] + (["--graph"] if oneshot else [])
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, f"{r.stdout[-3000:]}\n{r.stderr[-3000:]}"
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -84,3 +88,6 @@ def test_bench_gpus8_control_flow_dry_run():
     cfg = out["config"]
     assert cfg["parallelism"] == "tp8" and cfg["rccl_ranks"] == 8
     assert cfg["per_rank"] is not None and len(cfg["per_rank"]) == 8
+    if oneshot:
+        assert cfg["decode_mode"] == "hipgraph" and cfg["decode_allreduce"].startswith("one-shot")
+        assert all(r_["oneshot_selftest"] == "passed" and r_["oneshot_status"] == 0 for r_ in cfg["per_rank"])

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 4, call 1: same-box A/B of the step variants (tools/ab_variant.sh builds), two shapes, three alternating rounds
+# same-box A/B of the step variants (tools/ab_variant.sh builds): variants installed alternately, three rounds: tools/ab_alternate.sh "v1 v2" "H:HQ:S ..."
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 L=cold_compress_amd/csrc/libcoldcompress_hip.so

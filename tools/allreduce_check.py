@@ -71,6 +71,32 @@ def main():
     torch.cuda.synchronize()
     for b, w_ in zip(bufs, wants):
         ok = ok and torch.equal(b.cpu(), w_)
+    # ---- timing (what profiles/r04_scale_projection.json charges per all-reduce): sixteen 8 KiB all-reduces per replay, nothing else
+    tg = torch.cuda.CUDAGraph()
+    tb = torch.zeros(4096, dtype=torch.bfloat16, device=dev)
+    ar.all_reduce(tb)
+    torch.cuda.synchronize()
+    dist.barrier()
+    with torch.cuda.graph(tg):
+        for _ in range(16):
+            ar.all_reduce(tb)
+    tg.replay()
+    torch.cuda.synchronize()
+    dist.barrier()
+    ts = []
+    for _ in range(10):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        tg.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3 / 16)
+    ts.sort()
+    if rank == 0:
+        import json
+        print("ONESHOT_TIMING " + json.dumps({"world": world, "one_gpu": bool(a.one_gpu), "bytes": 8192, "us_per_allreduce_median": round(ts[5], 2),
+                                              "us_min": round(ts[0], 2), "note": "hipGraph replay of 16 back-to-back cc_allreduce_sum of 4096 bf16; "
+                                              "ranks sharing ONE GPU when one_gpu (no xGMI hop: launch + flag round trip through memory only)"}), flush=True)
     ok = ok and ar.status() == 0
     flag = torch.tensor([1 if ok else 0])
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)

@@ -43,9 +43,17 @@ def main():
                 torch.cuda.synchronize()
                 ts.append(e0.elapsed_time(e1))
             ts.sort()
-            flops = 2 * a.HQ * L * L * D * 1.5  # causal QK^T twice (two passes) + P.V
-            print(json.dumps({"L": L, "H": a.H, "HQ": a.HQ, "return_attn": ret, "bands": bands, "ms": round(ts[len(ts) // 2], 3),
-                              "min_ms": round(ts[0], 3), "causal_TFLOPs": round(flops / (ts[len(ts) // 2] * 1e-3) / 1e12, 1)}), flush=True)
+            # causal flops = 2 HQ L^2 D for QK^T + P.V (the useful work); the two-pass path (return_attn: column / band /
+            # window sums need the probabilities) recomputes QK^T in its second pass: x1.5 EXECUTED.  The single pass (return_attn
+            # False, no side planes) executes the useful flops only — r3's file applied the x1.5 to it too and overstated it.
+            useful = 2 * a.HQ * L * L * D
+            two_pass = ret or bool(bands)
+            executed = useful * (1.5 if two_pass else 1.0)
+            t = ts[len(ts) // 2] * 1e-3
+            print(json.dumps({"L": L, "H": a.H, "HQ": a.HQ, "return_attn": ret, "bands": bands, "passes": 2 if two_pass else 1,
+                              "ms": round(ts[len(ts) // 2], 3), "min_ms": round(ts[0], 3),
+                              "useful_causal_TFLOPs": round(useful / t / 1e12, 1), "executed_TFLOPs": round(executed / t / 1e12, 1),
+                              "frac_of_2.5PF_dense_bf16_useful": round(useful / t / 2.5e15, 3)}), flush=True)
 
 
 if __name__ == "__main__":
