@@ -37,6 +37,9 @@
                         // 12.8 us, 18432 21.0 -> 21.75, 32768 32.8 -> 33.9): two gathers in series and one more barrier, and per-slot passes
                         // of 1.5+ us that a 0.4 us partial-O round trip cannot hide; kept compilable for the record
 #endif
+#ifndef CC_V_ALLLANES
+#define CC_V_ALLLANES 1 // the several-tiles-per-wave steps run the per-slot state pass on all 64 lanes (like the hybrid tail), not on 16 per tile
+#endif
 #ifndef CC_V_MLW
 #define CC_V_MLW 1      // the final (M, L) fold runs on the workgroup's LAST waves (idle during the partial-O publish of the first ones)
 #endif
@@ -986,16 +989,27 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
       rt0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz, one clock for the whole device (s_memtime is per XCD)
     }
   }
-  double one_numv[NT];
-  int32_t one_denv[NT], one_psv[NT];
-  float one_rndv[NT];
+  // ALL (r4): with several tiles per wave the second half of the per-slot pass — history update, next-eviction score, key: ~70
+  // dependent instructions — runs on ALL 64 lanes (lane L takes the wave's slots j = L + 64 k, slot j = row (j & 15) of the wave's
+  // tile (j >> 4)) instead of on the 16 score-holding lanes of one tile after the other: ceil(NT / 4) passes instead of NT; the
+  // group-mean probabilities reach it through a wave-private LDS row, the per-slot state is requested per (lane, k) — coalesced
+  constexpr bool ALL = CC_V_ALLLANES != 0 && ONE && NT > 1 && !HYB;
+  constexpr int SN = ALL ? (NT * RPW * U + 63) / 64 : NT;  // per-slot state entries per lane
+  double one_numv[SN];
+  int32_t one_denv[SN], one_psv[SN];
+  float one_rndv[SN];
 #pragma unroll
-  for (int ti = 0; ti < NT; ti++) {
+  for (int ti = 0; ti < SN; ti++) {
     one_numv[ti] = 0.0;
     one_denv[ti] = 0;
     one_psv[ti] = 0;
     one_rndv[ti] = 0.f;
   }
+  auto all_slot = [&](int k) {  // ALL: the slot of entry k of this lane
+    const int j = lane + 64 * k;
+    return row_begin + wave * (RPW * U) + (j & (RPW * U - 1)) + (j / (RPW * U)) * (NW * RPW * U);
+  };
+  auto all_valid = [&](int k) { return lane + 64 * k < NT * RPW * U && all_slot(k) < row_end; };
   constexpr int LPR = RT < 4 ? RT : 4;  // lanes per tile row in the per-slot pass; each computes KH = RT / LPR probabilities
   constexpr int KH = RT / LPR;
   // this lane's slot in tile ti of the wave: one_slot + ti * (NW * RPW * U)
@@ -1005,9 +1019,9 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
   // the history / position (/ uniform draw) of this lane's slot in every tile of the wave
   auto load_slot_state = [&]() {
 #pragma unroll
-    for (int ti = 0; ti < NT; ti++) {
-      const int sl = one_slot + ti * (NW * RPW * U);
-      if (one_lane && sl < row_end) {
+    for (int ti = 0; ti < SN; ti++) {
+      const int sl = ALL ? all_slot(ti) : one_slot + ti * (NW * RPW * U);
+      if (ALL ? all_valid(ti) : (one_lane && sl < row_end)) {
         if (a.num) {
           one_numv[ti] = a.num[(size_t)h * S + sl];
           one_denv[ti] = a.denom[(size_t)h * S + sl];
@@ -1986,7 +2000,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
       def_den[ti] = 0;
       def_i[ti] = -1;
     }
-    __shared__ float sm_hav[HYB ? NW : 1][HYB ? NT * RPW * U : 1];  // hybrid: group-mean probabilities, [wave][tile * 16 + row]
+    __shared__ float sm_hav[(HYB || ALL) ? NW : 1][(HYB || ALL) ? NT * RPW * U : 1];  // hybrid / ALL: group-mean probabilities, [wave][tile * 16 + row]
     auto slot_pass = [&](auto ti_c) {
       constexpr int TI = decltype(ti_c)::value;
       const int slot_ti = one_slot + TI * (NW * RPW * U);
@@ -2039,7 +2053,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
         }
         av = ElemTraits<T>::rnd(sum * (1.0f / (float)RT));  // RT is a power of two: bit-identical to the IEEE divide of the combine pass
       }
-      if constexpr (HYB) {  // hybrid: the ring pass below consumes the probabilities on all lanes
+      if constexpr (HYB || ALL) {  // hybrid / ALL: the pass below consumes the probabilities on all lanes
         if (have_ti) sm_hav[wave][TI * (RPW * U) + g * U + c / LPR] = av;
       } else if (have_ti) {
         const size_t i = (size_t)h * S + slot_ti;
@@ -2114,6 +2128,51 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
       }
     };
     if constexpr (!L2X) all_tiles(all_tiles, IntC<0>{});  // (L2X: behind the partial-O gather — the heads' maxima arrive with it)
+    if constexpr (ALL) {
+      // ---- the second half of the per-slot pass on all lanes: the slot_pass branches above, operation for operation (heavy hitter:
+      //      cache.py:716-722, 727-749; head-constant policies: cache.py:500-502, 519-524, 552-556)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const int32_t p_next = one_pin + 1;
+#pragma unroll
+      for (int k = 0; k < SN; k++)
+        if (all_valid(k)) {
+          const int sl = all_slot(k);
+          const size_t i = (size_t)h * S + sl;
+          const float av = sm_hav[wave][lane + 64 * k];
+          int32_t ps = one_psv[k];
+          double num_old = one_numv[k];
+          int32_t den_old = one_denv[k];
+          if (sl == ins_idx) {  // refilled by this launch's insert: position p, history from zero (cache.py:754-763)
+            ps = one_pin;
+            num_old = 0.0;
+            den_old = 0;
+          }
+          const uint32_t low = ((uint32_t)sl << 1) | (uint32_t)(ps == -1);
+          unsigned long long key_k = ~0ull;
+          if (a.num) {
+            if (a.attn_out) ElemTraits<T>::store(reinterpret_cast<T*>(a.attn_out), i, av);
+            const double num_new = num_old + (double)av;
+            const int32_t den_new = den_old + 1;
+            a.num[i] = num_new;
+            a.denom[i] = den_new;
+            float scn = __fdiv_rn((float)num_new, (float)(den_new < 1 ? 1 : den_new));
+            if (ps < a.g || ps >= p_next - a.w) scn = 1.0f;
+            if (ps == -1) scn = 0.0f;
+            key_k = make_key(orderable_f32(scn), low);
+          } else if (a.policy == 2) {
+            if (sl >= a.g) key_k = make_key(orderable_i32(ps), low);
+          } else {
+            float scn = a.rand_next ? one_rndv[k] : cc_rng_uniform(a.rng_seed, p_next, sl);
+            if (ps >= p_next - a.w) scn = INFINITY;
+            if (sl < a.g) scn = INFINITY;
+            if (ps == -1) scn = -INFINITY;
+            key_k = make_key(orderable_f32(scn), low);
+          }
+          my_key = key_k < my_key ? key_k : my_key;
+        }
+    }
     const int hyb_cts_n = hyb_cts + (hyb_kind == 0 ? 1 : 0);  // hybrid: the head's count after this step's insert
     if constexpr (HYB) {
       // ---- hybrid: ring column / exact window sum / denominator of every slot (cache.py:716-723 with W = 400), then the head's
@@ -2875,7 +2934,7 @@ constexpr size_t kOneHdrBytes = 4096, kOneMlCap = (size_t)kOneMaxHeads * (kOneMl
                  kOneOCap = (size_t)kOneMaxHeads * kOneOHead;
 constexpr size_t kOneBytes = kOneHdrBytes + kOneMlCap + kOneOCap;
 constexpr int kOneStatusWord = 1023;  // hdr[0 .. H): epochs; hdr[1023]: timeout word
-constexpr int kOneMaxTiles = 8;  // tiles per wave the single-launch step keeps scores for (NT = 4 or 8 instantiations)
+constexpr int kOneMaxTiles = 16;  // tiles per wave the single-launch step keeps scores for (NT = 4, 8 or 16 instantiations; hybrid: up to 8)
 // tiles per wave of the single-launch step for this shape: 1 = the specialised single-tile form, 2 .. 8 = the multi-tile form
 // (16-bit caches, 4 or 8 query heads per kv head), 0 = not eligible
 static int one_tiles(const Plan& p, int HQ, int H, int D, int dtype) {
@@ -2959,13 +3018,14 @@ static OneKernel one_kernel(int rt, int nt, int kind, bool full, int nw = kNW) {
       return nullptr;
     } else {
       if (rt != 4) return nullptr;
-      if (kind == 200) return nt == 1 ? CC_ONE_K(4, false, true, 0, 1, true) : CC_ONE_K(4, false, true, 0, 8, true);
+      if (kind == 200) return nt == 1 ? CC_ONE_K(4, false, true, 0, 1, true) : (nt <= 8 ? CC_ONE_K(4, false, true, 0, 8, true) : nullptr);
       if (kind == -1) return nt == 1 ? CC_ONE_K(4, true, false, 0, 1, true) : nullptr;
       if (kind == 8) return nt == 1 ? CC_ONE_K(4, false, false, 8, 1, true) : nullptr;
-      if (kind == 0) return nt == 1 ? CC_ONE_K(4, false, false, 0, 1, true) : (nt <= 4 ? CC_ONE_K(4, false, false, 0, 4, true) : CC_ONE_K(4, false, false, 0, 8, true));
+      if (kind == 0) return nt == 1 ? CC_ONE_K(4, false, false, 0, 1, true) : (nt <= 4 ? CC_ONE_K(4, false, false, 0, 4, true) : (nt <= 8 ? CC_ONE_K(4, false, false, 0, 8, true) : nullptr));
       return nullptr;
     }
   }
+  if (kind == 200 && nt > 8) return nullptr;
   if (kind == 200) {  // hybrid: 4 or 8 query heads per kv head; one tile per wave or up to eight
     if (rt == 8) return nt == 1 ? CC_ONE_K(8, false, true, 0, 1, false) : CC_ONE_K(8, false, true, 0, 8, false);
     if (rt == 4) return nt == 1 ? CC_ONE_K(4, false, true, 0, 1, false) : CC_ONE_K(4, false, true, 0, 8, false);
@@ -2989,8 +3049,8 @@ static OneKernel one_kernel(int rt, int nt, int kind, bool full, int nw = kNW) {
   }
   if (kind != 0) return nullptr;
   if (nt > 1) {  // several tiles per wave (long caches): 4 or 8 query heads per kv head
-    if (rt == 8) return nt <= 4 ? CC_ONE_K(8, false, false, 0, 4, false) : CC_ONE_K(8, false, false, 0, 8, false);
-    if (rt == 4) return nt <= 4 ? CC_ONE_K(4, false, false, 0, 4, false) : CC_ONE_K(4, false, false, 0, 8, false);
+    if (rt == 8) return nt <= 4 ? CC_ONE_K(8, false, false, 0, 4, false) : (nt <= 8 ? CC_ONE_K(8, false, false, 0, 8, false) : CC_ONE_K(8, false, false, 0, 16, false));
+    if (rt == 4) return nt <= 4 ? CC_ONE_K(4, false, false, 0, 4, false) : (nt <= 8 ? CC_ONE_K(4, false, false, 0, 8, false) : CC_ONE_K(4, false, false, 0, 16, false));
     return nullptr;
   }
   switch (rt) {
@@ -3014,6 +3074,7 @@ static OneKernel one_kernel_xl2(int rt, int nt, int kind, bool full, int nw) {
   if ((rt != 4 && rt != 8) || (nw != 4 && nw != 8)) return nullptr;
   if (nt > 1 || kind == 200) {  // several tiles per wave (4-wave workgroups) and the hybrid cache's steps: lean instantiations only
     if (full || nt > kOneMaxTiles) return nullptr;
+    if (kind == 200 && nt > 8) return nullptr;
     if (kind == 200) {
       if (nt == 1) return nw == 8 ? (rt == 8 ? decode_attn_split_mfma_kernel<T, 8, 8, false, true, true, 0, 1, 1, false, true>
                                              : decode_attn_split_mfma_kernel<T, 4, 8, false, true, true, 0, 1, 1, false, true>)
@@ -3021,8 +3082,8 @@ static OneKernel one_kernel_xl2(int rt, int nt, int kind, bool full, int nw) {
       return nw == 4 ? (rt == 8 ? CC_ONE_XM(8, true, 8) : CC_ONE_XM(4, true, 8)) : nullptr;
     }
     if (kind != 0 || nw != 4) return nullptr;
-    if (rt == 8) return nt <= 4 ? CC_ONE_XM(8, false, 4) : CC_ONE_XM(8, false, 8);
-    return nt <= 4 ? CC_ONE_XM(4, false, 4) : CC_ONE_XM(4, false, 8);
+    if (rt == 8) return nt <= 4 ? CC_ONE_XM(8, false, 4) : (nt <= 8 ? CC_ONE_XM(8, false, 8) : CC_ONE_XM(8, false, 16));
+    return nt <= 4 ? CC_ONE_XM(4, false, 4) : (nt <= 8 ? CC_ONE_XM(4, false, 8) : CC_ONE_XM(4, false, 16));
   }
   if (kind != 0 && kind != 8 && kind != -1) return nullptr;
   if (full) {

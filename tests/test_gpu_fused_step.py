@@ -100,7 +100,8 @@ def test_fused_step_equals_three_calls(dtype, H, HQ, S, D, T, single):
 
 @pytest.mark.parametrize("dtype,H,HQ,S,D,T,steps", [(torch.bfloat16, 8, 32, 4096, 128, 4000, 400), (torch.bfloat16, 8, 32, 2560, 128, 2560, 150),
                                                     (torch.float16, 3, 6, 1001, 128, 900, 150), (torch.bfloat16, 2, 2, 130, 128, 100, 60),
-                                                    (torch.bfloat16, 16, 64, 2048, 128, 2048, 100), (torch.bfloat16, 8, 32, 18432, 128, 18432, 60)])
+                                                    (torch.bfloat16, 16, 64, 2048, 128, 2048, 100), (torch.bfloat16, 8, 32, 18432, 128, 18432, 60),
+                                                    (torch.bfloat16, 8, 32, 40000, 128, 39990, 30)])  # (r4: 10 tiles per wave: the 16-tile instantiation)
 def test_single_launch_equals_two_launch_long(dtype, H, HQ, S, D, T, steps):
     """The single-launch layer step against the two-launch step over hundreds of steps on twin caches, interleaved with an
     unrelated bandwidth-heavy kernel so the workgroups of a launch do not arrive evenly: history (float64), denominators,

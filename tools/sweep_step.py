@@ -42,7 +42,7 @@ def main():
         one = int(fns["cc_decode_step_single_launch"](HQ, H, S, D, 1))
         print(json.dumps({"policy": "heavy_hitter", "H": H, "HQ": HQ, "S": S, "D": D, "dtype": "bf16", "B_step_bytes": b_step,
                           "us_per_step": round(us, 2), "GBps": round(b_step / us / 1e3, 1), "frac_of_8TBps": round(b_step / us / 1e3 / 8000.0, 4),
-                          "launches_per_step": 1 if one else 2, "l2_resident_handoff": int(fns["cc_decode_step_l2_handoff"]()) if S <= 4096 else 0,
+                          "launches_per_step": 1 if one else 2, "l2_resident_handoff": int(fns["cc_decode_step_l2_handoff"]()) if one else 0,
                           "rotating_caches": n_buf}), flush=True)
         del caches
         torch.cuda.empty_cache()
