@@ -66,6 +66,7 @@ SIGNATURES = {
     "cc_gemv_fused": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _vp]),
     "cc_kv_requant": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "cc_kv_requant_pair": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp]),
+    "cc_kv_requant_batch": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "cc_kv_dequant": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "cc_kv_quant_rows": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "cc_kv_dequant_rows": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
@@ -152,6 +153,7 @@ SIGNATURES = {
 DEVICE_ONLY = {"cc_error_string", "cc_device_info", "cc_decode_step_single_launch", "cc_decode_step_status_offset",
                "cc_decode_step_trace", "cc_decode_step_set_single_launch", "cc_decode_step_set_wide", "cc_decode_step_probe_xcd", "cc_decode_step_commit_stride", "cc_decode_step_l2_rc", "cc_decode_step_quant_rc", "cc_decode_step_set_l2_handoff", "cc_decode_step_l2_handoff", "cc_decode_step_stream_floor", "cc_decode_step_stream_floor_geom", "cc_debug_occupy", "cc_decode_step_quant_single_launch",
                "cc_decode_step_hybrid_single_launch",
+               "cc_kv_requant_batch",  # (its oracle is the per-cache twin of cc_kv_requant_pair)
                # inter-GPU transport: no CPU twin (the oracle of the all-reduce is torch.distributed's)
                "cc_allreduce_handle_bytes", "cc_allreduce_create", "cc_allreduce_export", "cc_allreduce_connect", "cc_allreduce_sum",
                "cc_allreduce_status", "cc_allreduce_destroy"}

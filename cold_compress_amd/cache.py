@@ -366,6 +366,47 @@ class KVCache(nn.Module):
         raise NotImplementedError
 
 
+_REQUANT_TABLES = {}  # tuple of the caches' buffer addresses -> device table of cc_kv_requant_batch
+
+
+def flush_quantized(caches):
+    """The pending quantise -> dequantise round trips (KVCache.quantize_cache) of SEVERAL caches as one launch
+    (cc_kv_requant_batch): what a model calls behind its last layer, so that a token costs one round-trip launch instead of
+    one per layer.  The reference runs the round trip inside every layer's update (cache.py:323-338); its result is only read
+    by that layer's NEXT update, so running all of them behind the last layer gives the same numbers.  Caches this form does
+    not cover (not quantised in the reference's mode, nothing pending, an odd shape) take their own quantize_cache()."""
+    todo = [c for c in caches if getattr(c, "quantize", False) and c._quant_pending]
+    groups = {}
+    for c in todo:
+        vec = 16 // c.k_cache.element_size()
+        if c.head_dim % vec or c.n_heads * (c.head_dim // vec) > 1024 or c.pos.shape[1] > 64 or not c.k_cache.is_cuda:
+            c.quantize_cache()
+            continue
+        groups.setdefault((c.n_heads, c.head_dim, c.k_cache.dtype, int(c.n_bit), c.k_cache.device), []).append(c)
+    for (H, D, dtype, n_bit, device), cs in groups.items():
+        if len(cs) == 1:
+            cs[0].quantize_cache()
+            continue
+        for c in cs:  # torch-side writes to the working caches void the stable marks (see quantize_cache)
+            tag = (c.k_cache._version, c.v_cache._version, c.k_cache.data_ptr(), c.v_cache.data_ptr())
+            if tag != c._quant_tag:
+                c._quant_stable.zero_()
+                c._quant_pos_seen.zero_()
+                c._quant_tag = tag
+        rows = [[t.data_ptr() for t in (c.k_cache, c.k_cache_q, c.k_scales, c.k_zero_points, c.v_cache, c.v_cache_q, c.v_scales,
+                                        c.v_zero_points, c.pos, c._quant_stable, c._quant_pos_seen)]
+                + [c.max_cache_length, int(c.pos.shape[1]), 0, 0, 0] for c in cs]
+        key = tuple(x for r in rows for x in r)
+        table = _REQUANT_TABLES.get(key)
+        if table is None:
+            if len(_REQUANT_TABLES) > 64:
+                _REQUANT_TABLES.clear()
+            table = _REQUANT_TABLES[key] = torch.tensor(rows, dtype=torch.int64).to(device)
+        _abi.call("cc_kv_requant_batch", _ptr(table), len(cs), H, max(c.max_cache_length for c in cs), D, _DT[dtype], n_bit, _stream())
+        for c in cs:
+            c._quant_pending = False
+
+
 def _new_step_commit(n_heads):
     """The recoverable hand-off's commit words (include/coldcompress.h, cc_decode_step_heavy_hitter_rc): per kv head the insert
     word, its position, and one committed position per workgroup of the head; -1 = nothing."""

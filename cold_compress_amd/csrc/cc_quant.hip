@@ -158,37 +158,11 @@ static bool quant_args_ok(int H, int S, int D, int dtype, int n_bit) {
 // Vectorised round trip: one thread = one 16-byte vector of the slot (H * D / VEC threads per slot, up to 1024), so a
 // slot costs one 16-byte load, one 16-byte store of the round trip and one packed store of the image per thread
 // (the element-wise kernel above issues 2-byte loads: ~1 TB/s).  Same arithmetic, element for element.
+// requant_vec_slot: the whole workgroup takes slot s of one tensor (K or V); returns whether THIS thread's vector changed.
 template <typename T>
-__global__ __launch_bounds__(1024) void kv_requant_vec_kernel(RequantSet rs, int H, int S, int D, int n_bit) {
+__device__ __forceinline__ bool requant_vec_slot(T* work, uint8_t* q_out, T* scales, T* zeros, int H, int S, int D, int n_bit, int s,
+                                                 float* sm_mn, float* sm_mx) {
   constexpr int VEC = 16 / (int)sizeof(T);
-  __shared__ float sm_mn[16], sm_mx[16];
-  T* work = reinterpret_cast<T*>(rs.work[blockIdx.y]);
-  uint8_t* q_out = rs.q[blockIdx.y];
-  T* scales = reinterpret_cast<T*>(rs.scales[blockIdx.y]);
-  T* zeros = reinterpret_cast<T*>(rs.zeros[blockIdx.y]);
-  // kQSlots consecutive slots per workgroup: lane t of the first wave decides whether slot s0 + t needs the round trip
-  // (in steady state ~0.3 % do: the freshly inserted slot and the few whose image oscillates), then the whole
-  // workgroup walks the ones that do
-  __shared__ unsigned long long sm_need;
-  __shared__ int sm_changed;
-  const int s0 = blockIdx.x * kQSlots;
-  if (threadIdx.x < 64) {
-    const int sc = s0 + (int)threadIdx.x;
-    bool need = threadIdx.x < kQSlots && sc < S;
-    if (need && rs.stable != nullptr) {
-      bool same = rs.stable[(size_t)blockIdx.y * S + sc] != 0;
-      for (int hp = 0; hp < rs.Hp; hp++)
-        same &= rs.pos[(size_t)hp * S + sc] == rs.pos_seen[((size_t)blockIdx.y * rs.Hp + hp) * S + sc];
-      need = !same;
-    }
-    const unsigned long long m = __ballot(need);
-    if (threadIdx.x == 0) sm_need = m;
-  }
-  __syncthreads();
-  unsigned long long todo = sm_need;
-  while (todo) {
-  const int s = s0 + __builtin_ctzll(todo);
-  todo &= todo - 1;
   const int vpr = D / VEC;           // vectors per row
   const int nvec = H * vpr;          // == blockDim.x rounded up to a wave
   const int v = threadIdx.x;
@@ -236,51 +210,146 @@ __global__ __launch_bounds__(1024) void kv_requant_vec_kernel(RequantSet rs, int
   }
   bool changed = false;
   if (in) {
-  float o[VEC];
-  unsigned long long packed = 0ull;  // VEC values of n_bit bits, value j shifted left by j * n_bit
+    float o[VEC];
+    unsigned long long packed = 0ull;  // VEC values of n_bit bits, value j shifted left by j * n_bit
 #pragma unroll
-  for (int e = 0; e < VEC; e++) {
-    float t = ElemTraits<T>::rnd(__fdiv_rn(ElemTraits<T>::rnd(__fsub_rn(x[e], mn)), scale));
-    t = fminf(fmaxf(rintf(t), 0.f), (float)max_int);
-    const int q = (int)t;
-    o[e] = q_dequant<T>(q, half, scale, zero);
-    packed |= (unsigned long long)q << (e * n_bit);
+    for (int e = 0; e < VEC; e++) {
+      float t = ElemTraits<T>::rnd(__fdiv_rn(ElemTraits<T>::rnd(__fsub_rn(x[e], mn)), scale));
+      t = fminf(fmaxf(rintf(t), 0.f), (float)max_int);
+      const int q = (int)t;
+      o[e] = q_dequant<T>(q, half, scale, zero);
+      packed |= (unsigned long long)q << (e * n_bit);
+    }
+    if constexpr (sizeof(T) == 4) {
+#pragma unroll
+      for (int e = 0; e < VEC; e++) changed |= __float_as_uint(o[e]) != __float_as_uint(x[e]);
+      *reinterpret_cast<float4*>(work + base) = make_float4(o[0], o[1], o[2], o[3]);
+    } else {
+      T e16[VEC];
+#pragma unroll
+      for (int e = 0; e < VEC; e++) ElemTraits<T>::store(&e16[e], 0, o[e]);
+      uint32_t w32[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) w32[i] = (uint32_t)e16[2 * i].x | ((uint32_t)e16[2 * i + 1].x << 16);
+      T x16[VEC];
+#pragma unroll
+      for (int e = 0; e < VEC; e++) ElemTraits<T>::store(&x16[e], 0, x[e]);  // exact: x came from T
+#pragma unroll
+      for (int i = 0; i < 4; i++) changed |= w32[i] != ((uint32_t)x16[2 * i].x | ((uint32_t)x16[2 * i + 1].x << 16));
+      *reinterpret_cast<uint4*>(work + base) = make_uint4(w32[0], w32[1], w32[2], w32[3]);
+    }
+    const size_t qbyte = base * n_bit / 8;  // VEC * n_bit is a whole number of bytes (VEC >= 4)
+    const int nbytes = VEC * n_bit / 8;
+    if (nbytes == 8) *reinterpret_cast<uint2*>(q_out + qbyte) = make_uint2((uint32_t)packed, (uint32_t)(packed >> 32));
+    else if (nbytes == 4) *reinterpret_cast<uint32_t*>(q_out + qbyte) = (uint32_t)packed;
+    else if (nbytes == 2) *reinterpret_cast<uint16_t*>(q_out + qbyte) = (uint16_t)packed;
+    else q_out[qbyte] = (uint8_t)packed;
   }
-  if constexpr (sizeof(T) == 4) {
-#pragma unroll
-    for (int e = 0; e < VEC; e++) changed |= __float_as_uint(o[e]) != __float_as_uint(x[e]);
-    *reinterpret_cast<float4*>(work + base) = make_float4(o[0], o[1], o[2], o[3]);
-  } else {
-    T e16[VEC];
-#pragma unroll
-    for (int e = 0; e < VEC; e++) ElemTraits<T>::store(&e16[e], 0, o[e]);
-    uint32_t w32[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) w32[i] = (uint32_t)e16[2 * i].x | ((uint32_t)e16[2 * i + 1].x << 16);
-    T x16[VEC];
-#pragma unroll
-    for (int e = 0; e < VEC; e++) ElemTraits<T>::store(&x16[e], 0, x[e]);  // exact: x came from T
-#pragma unroll
-    for (int i = 0; i < 4; i++) changed |= w32[i] != ((uint32_t)x16[2 * i].x | ((uint32_t)x16[2 * i + 1].x << 16));
-    *reinterpret_cast<uint4*>(work + base) = make_uint4(w32[0], w32[1], w32[2], w32[3]);
+  return changed;
+}
+
+template <typename T>
+__global__ __launch_bounds__(1024) void kv_requant_vec_kernel(RequantSet rs, int H, int S, int D, int n_bit) {
+  __shared__ float sm_mn[16], sm_mx[16];
+  T* work = reinterpret_cast<T*>(rs.work[blockIdx.y]);
+  uint8_t* q_out = rs.q[blockIdx.y];
+  T* scales = reinterpret_cast<T*>(rs.scales[blockIdx.y]);
+  T* zeros = reinterpret_cast<T*>(rs.zeros[blockIdx.y]);
+  // kQSlots consecutive slots per workgroup: lane t of the first wave decides whether slot s0 + t needs the round trip
+  // (in steady state ~0.3 % do: the freshly inserted slot and the few whose image oscillates), then the whole
+  // workgroup walks the ones that do
+  __shared__ unsigned long long sm_need;
+  __shared__ int sm_changed;
+  const int s0 = blockIdx.x * kQSlots;
+  if (threadIdx.x < 64) {
+    const int sc = s0 + (int)threadIdx.x;
+    bool need = threadIdx.x < kQSlots && sc < S;
+    if (need && rs.stable != nullptr) {
+      bool same = rs.stable[(size_t)blockIdx.y * S + sc] != 0;
+      for (int hp = 0; hp < rs.Hp; hp++)
+        same &= rs.pos[(size_t)hp * S + sc] == rs.pos_seen[((size_t)blockIdx.y * rs.Hp + hp) * S + sc];
+      need = !same;
+    }
+    const unsigned long long m = __ballot(need);
+    if (threadIdx.x == 0) sm_need = m;
   }
-  const size_t qbyte = base * n_bit / 8;  // VEC * n_bit is a whole number of bytes (VEC >= 4)
-  const int nbytes = VEC * n_bit / 8;
-  if (nbytes == 8) *reinterpret_cast<uint2*>(q_out + qbyte) = make_uint2((uint32_t)packed, (uint32_t)(packed >> 32));
-  else if (nbytes == 4) *reinterpret_cast<uint32_t*>(q_out + qbyte) = (uint32_t)packed;
-  else if (nbytes == 2) *reinterpret_cast<uint16_t*>(q_out + qbyte) = (uint16_t)packed;
-  else q_out[qbyte] = (uint8_t)packed;
+  __syncthreads();
+  unsigned long long todo = sm_need;
+  while (todo) {
+    const int s = s0 + __builtin_ctzll(todo);
+    todo &= todo - 1;
+    const bool changed = requant_vec_slot<T>(work, q_out, scales, zeros, H, S, D, n_bit, s, sm_mn, sm_mx);
+    if (rs.stable != nullptr) {  // did this pass leave the slot's rows bit-identical?
+      if (threadIdx.x == 0) sm_changed = 0;
+      __syncthreads();
+      if (changed) sm_changed = 1;
+      __syncthreads();
+      if (threadIdx.x == 0) rs.stable[(size_t)blockIdx.y * S + s] = sm_changed ? 0 : 1;
+      if ((int)threadIdx.x < rs.Hp)
+        rs.pos_seen[((size_t)blockIdx.y * rs.Hp + threadIdx.x) * S + s] = rs.pos[(size_t)threadIdx.x * S + s];
+    }
+    __syncthreads();  // sm_mn / sm_mx / sm_changed are reused by the next slot
   }
-  if (rs.stable != nullptr) {  // did this pass leave the slot's rows bit-identical?
-    if (threadIdx.x == 0) sm_changed = 0;
-    __syncthreads();
-    if (changed) sm_changed = 1;
-    __syncthreads();
-    if (threadIdx.x == 0) rs.stable[(size_t)blockIdx.y * S + s] = sm_changed ? 0 : 1;
-    if ((int)threadIdx.x < rs.Hp)
-      rs.pos_seen[((size_t)blockIdx.y * rs.Hp + threadIdx.x) * S + s] = rs.pos[(size_t)threadIdx.x * S + s];
+}
+
+// The same round trip for SEVERAL caches in one launch (every layer of a model at the end of a token: cc_kv_requant_batch).
+// One workgroup = 64 consecutive slots of one cache, K then V; lane t of the first wave decides for slot s0 + t (the
+// position rows are read once for both tensors), then the workgroup walks the slots that need it.  `table`: kReqWords
+// 64-bit words per cache — k_work, k_q, k_scales, k_zeros, v_work, v_q, v_scales, v_zeros, pos, stable, pos_seen, S, Hp.
+constexpr int kReqWords = 16;
+constexpr int kReqScan = 64;
+
+template <typename T>
+__global__ __launch_bounds__(1024) void kv_requant_batch_kernel(const long long* __restrict__ table, int H, int D, int n_bit) {
+  __shared__ float sm_mn[16], sm_mx[16];
+  __shared__ unsigned long long sm_need[2];
+  __shared__ int sm_changed;
+  const long long* e = table + (size_t)blockIdx.y * kReqWords;
+  const int S = (int)e[11], Hp = (int)e[12];
+  const int s0 = blockIdx.x * kReqScan;
+  if (s0 >= S) return;
+  const int32_t* pos = reinterpret_cast<const int32_t*>(e[8]);
+  uint8_t* stable = reinterpret_cast<uint8_t*>(e[9]);
+  int32_t* pos_seen = reinterpret_cast<int32_t*>(e[10]);
+  if (threadIdx.x < 64) {
+    const int sc = s0 + (int)threadIdx.x;
+    bool need_k = sc < S, need_v = need_k;
+    if (need_k) {
+      bool same_k = stable[sc] != 0, same_v = stable[(size_t)S + sc] != 0;
+      for (int hp = 0; hp < Hp; hp++) {
+        const int32_t p = pos[(size_t)hp * S + sc];
+        same_k &= p == pos_seen[(size_t)hp * S + sc];
+        same_v &= p == pos_seen[((size_t)Hp + hp) * S + sc];
+      }
+      need_k = !same_k;
+      need_v = !same_v;
+    }
+    const unsigned long long mk = __ballot(need_k), mv = __ballot(need_v);
+    if (threadIdx.x == 0) {
+      sm_need[0] = mk;
+      sm_need[1] = mv;
+    }
   }
-  __syncthreads();  // sm_mn / sm_mx / sm_changed are reused by the next slot
+  __syncthreads();
+  for (int which = 0; which < 2; which++) {
+    unsigned long long todo = sm_need[which];
+    if (!todo) continue;
+    T* work = reinterpret_cast<T*>(e[4 * which + 0]);
+    uint8_t* q_out = reinterpret_cast<uint8_t*>(e[4 * which + 1]);
+    T* scales = reinterpret_cast<T*>(e[4 * which + 2]);
+    T* zeros = reinterpret_cast<T*>(e[4 * which + 3]);
+    while (todo) {
+      const int s = s0 + __builtin_ctzll(todo);
+      todo &= todo - 1;
+      const bool changed = requant_vec_slot<T>(work, q_out, scales, zeros, H, S, D, n_bit, s, sm_mn, sm_mx);
+      if (threadIdx.x == 0) sm_changed = 0;
+      __syncthreads();
+      if (changed) sm_changed = 1;
+      __syncthreads();
+      if (threadIdx.x == 0) stable[(size_t)which * S + s] = sm_changed ? 0 : 1;
+      if ((int)threadIdx.x < Hp) pos_seen[((size_t)which * Hp + threadIdx.x) * S + s] = pos[(size_t)threadIdx.x * S + s];
+      __syncthreads();
+    }
   }
 }
 
@@ -418,6 +487,25 @@ int cc_kv_requant_pair(void* k_work, void* k_q, void* k_scales, void* k_zeros, v
   RequantSet rs{{k_work, v_work}, {reinterpret_cast<uint8_t*>(k_q), reinterpret_cast<uint8_t*>(v_q)}, {k_scales, v_scales},
                 {k_zeros, v_zeros}, pos, Hp, stable, pos_seen};
   return requant_launch(rs, 2, H, S, D, dtype, n_bit, (hipStream_t)stream);
+}
+
+int cc_kv_requant_batch(const int64_t* table, int32_t n_caches, int32_t H, int32_t S_max, int32_t D, int32_t dtype, int32_t n_bit,
+                        cc_stream_t stream) {
+  CC_ENTRY();
+  if (!table || n_caches <= 0 || n_caches > 65535 || !quant_args_ok(H, S_max, D, dtype, n_bit)) return CC_ERR_BAD_ARG;
+  const int vec = 16 / (int)cc_dt_size(dtype);
+  if (D % vec != 0 || H * (D / vec) > 1024) return CC_ERR_UNSUPPORTED;  // (the single-cache call has an element-wise form)
+  const int threads = ((H * (D / vec) + 63) / 64) * 64;
+  dim3 grid((S_max + kReqScan - 1) / kReqScan, n_caches), block(threads);
+  hipStream_t st = (hipStream_t)stream;
+  const long long* tb = reinterpret_cast<const long long*>(table);
+  switch (dtype) {
+    case CC_DT_F32: hipLaunchKernelGGL(kv_requant_batch_kernel<float>, grid, block, 0, st, tb, H, D, n_bit); break;
+    case CC_DT_BF16: hipLaunchKernelGGL(kv_requant_batch_kernel<bf16_t>, grid, block, 0, st, tb, H, D, n_bit); break;
+    default: hipLaunchKernelGGL(kv_requant_batch_kernel<f16_t>, grid, block, 0, st, tb, H, D, n_bit); break;
+  }
+  CC_LAUNCH_CHECK();
+  return CC_OK;
 }
 
 int cc_kv_dequant(const void* q, const void* scales, const void* zeros, void* work_out, int32_t H, int32_t S, int32_t D,

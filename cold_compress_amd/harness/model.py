@@ -18,7 +18,8 @@ from torch import Tensor
 
 from . import glue
 from ..attention_utils import scaled_dot_product_attention
-from ..cache import KVCacheFull, KVCacheHeavyHitter, KVCacheHybrid, KVCacheL2, KVCacheRandom, KVCacheRecentGlobal, get_cache_constructor
+from ..cache import (KVCacheFull, KVCacheHeavyHitter, KVCacheHybrid, KVCacheL2, KVCacheRandom, KVCacheRecentGlobal, flush_quantized,
+                     get_cache_constructor)
 from ..prompt_compression import get_prompt_compressor_constructor
 
 
@@ -227,6 +228,7 @@ class Transformer(nn.Module):
         self.output = nn.Linear(config.dim, config.vocab_size, bias=False)
         self.freqs_cis: Optional[Tensor] = None
         self.max_batch_size = 1
+        self.batch_quant_flush = True  # False: one round-trip launch per layer, at the start of its next update
 
     @classmethod
     def from_name(cls, name: str):
@@ -278,6 +280,8 @@ class Transformer(nn.Module):
         x, delta = self.tok_embeddings(idx), None
         for layer in self.layers:
             x, delta = layer(x, delta, idx, input_pos, is_prefill, freqs_cis, mask, attn_top_k=attn_top_k)
+        if self.batch_quant_flush:  # --cache_bits (reference mode): every layer's round trip as ONE launch behind the last layer
+            flush_quantized([layer.attention.kv_cache for layer in self.layers])
         if (not is_prefill and x.shape[1] == 1 and x.is_cuda and self.layers[0].fuse_gemv and self.output.bias is None
                 and glue.gemv_supported(self.output.weight)):
             # final RMSNorm (with the last pending residual) fused into the streamed LM head

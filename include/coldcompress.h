@@ -439,6 +439,15 @@ int cc_kv_requant(void* work, void* q_out, void* scales, void* zeros, int32_t H,
 int cc_kv_requant_pair(void* k_work, void* k_q, void* k_scales, void* k_zeros, void* v_work, void* v_q, void* v_scales,
                        void* v_zeros, int32_t H, int32_t S, int32_t D, int32_t dtype, int32_t n_bit, const int32_t* pos,
                        int32_t Hp, uint8_t* stable, int32_t* pos_seen, cc_stream_t stream);
+/* The same round trip for SEVERAL caches in ONE launch: what a model runs at the end of a token for all its layers (the
+ * reference does it per layer inside update_kv, cache.py:323-338; the round trip of layer l is only needed before layer l's
+ * NEXT step, so one launch behind the last layer replaces one launch per layer).  table (device): n_caches x 16 int64 —
+ * k_work, k_q, k_scales, k_zeros, v_work, v_q, v_scales, v_zeros, pos, stable, pos_seen (pointers as for the pair call; stable
+ * and pos_seen are required here), S, Hp, 0, 0, 0.  All caches share H, D, dtype, n_bit; S may differ (S_max = the largest).
+ * Slot for slot the arithmetic of the pair call.  CC_ERR_UNSUPPORTED where the pair call would take its element-wise form
+ * (D not a multiple of the 16-byte vector, or H * D / vector > 1024). */
+int cc_kv_requant_batch(const int64_t* table, int32_t n_caches, int32_t H, int32_t S_max, int32_t D, int32_t dtype, int32_t n_bit,
+                        cc_stream_t stream);
 int cc_kv_dequant(const void* q, const void* scales, const void* zeros, void* work_out, int32_t H, int32_t S,
                   int32_t D, int32_t dtype, int32_t n_bit, cc_stream_t stream);
 

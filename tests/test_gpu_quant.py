@@ -160,3 +160,67 @@ def test_requant_fuzz_vs_oracle(oracle):
         assert np.array_equal(to_np(work.cpu()), work_o), what + " (working cache)"
         assert np.array_equal(q.cpu().numpy(), q_o), what + " (image)"
         assert np.array_equal(to_np(sc.cpu()), sc_o) and np.array_equal(to_np(zp.cpu()), zp_o), what + " (scale / zero point)"
+
+
+@pytest.mark.parametrize("nb", [8, 4])
+def test_batched_round_trip_equals_per_cache(nb):
+    """cc_kv_requant_batch (every layer's round trip as one launch behind the last layer: cache.flush_quantized, what the
+    harness model runs) against the per-cache launches at the start of each cache's next update: five caches of three
+    lengths, two policies, 40 decode tokens — working caches, images, scales, zero points and the stable-slot bookkeeping
+    bit for bit after every token."""
+    import cold_compress_amd.cache as cache
+
+    H, D, T = 8, 128, 24
+    specs = [("heavy_hitter", 64), ("recent_global", 96), ("heavy_hitter", 200), ("heavy_hitter", 64), ("recent_global", 130)]
+
+    def build():
+        out = []
+        for strat, S in specs:
+            cls, rk = cache.get_cache_constructor(strat)
+            kw = dict(max_cache_length=S, global_tokens=2, max_seq_length=1024, cache_bits=nb, recent_window=8, history_window_size=1,
+                      attn_thresholding=False)
+            with torch.device(DEV):
+                out.append(cls(1, H, D, torch.bfloat16, **{k: kw[k] for k in rk}))
+        return out
+
+    A, B = build(), build()
+    gen = torch.Generator().manual_seed(77)
+    rows = lambda n: (torch.randn(1, H, n, D, generator=gen) * 2).to(torch.bfloat16).to(DEV)  # noqa: E731
+
+    def attn_for(kv, n):
+        a = torch.rand(1, H, n, kv.max_cache_length if n == 1 else n, generator=gen)
+        return (a / a.sum(-1, keepdim=True)).to(torch.bfloat16).to(DEV)
+
+    names = ("k_cache", "v_cache", "k_cache_q", "v_cache_q", "k_scales", "v_scales", "k_zero_points", "v_zero_points", "pos",
+             "_quant_stable", "_quant_pos_seen")
+    pre = torch.arange(T, device=DEV)
+    for i in range(len(specs)):
+        k0, v0 = rows(T), rows(T)
+        a0 = attn_for(A[i], T)
+        for kv in (A[i], B[i]):
+            kv.update_kv(pre, k0, v0, True)
+            kv.update_state(pre, k0, v0, True, a0 if kv.return_attn() else None)
+    cache.flush_quantized(B)
+    for t in range(40):
+        p = torch.tensor([T + t], dtype=torch.int32, device=DEV)
+        for i in range(len(specs)):
+            k1, v1 = rows(1), rows(1)
+            a1 = attn_for(A[i], 1)
+            seen = []
+            for kv in (A[i], B[i]):
+                kc, vc, _ = kv.update_kv(p, k1, v1, False)
+                seen.append((kc.clone(), vc.clone()))
+                kv.update_state(p, k1, v1, False, a1 if kv.return_attn() else None)
+            assert torch.equal(_bits(seen[0][0]), _bits(seen[1][0])) and torch.equal(_bits(seen[0][1]), _bits(seen[1][1])), \
+                f"token {t}, cache {i}: K/V attention sees"
+        cache.flush_quantized(B)
+        assert not any(kv._quant_pending for kv in B)
+        for kv in A:
+            kv.quantize_cache()
+        for i in range(len(specs)):
+            for n in names:
+                a, b = getattr(A[i], n), getattr(B[i], n)
+                assert torch.equal(_bits(a) if a.is_floating_point() else a.cpu(), _bits(b) if b.is_floating_point() else b.cpu()), \
+                    f"token {t}, cache {i} ({specs[i]}): {n}"
+    # steady state: most slots are skipped
+    assert all(int(kv._quant_stable.sum()) > kv.max_cache_length for kv in B)
