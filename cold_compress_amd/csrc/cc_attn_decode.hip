@@ -1018,14 +1018,19 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
   const bool one_have = one_lane && one_slot < row_end;
   // the history / position (/ uniform draw) of this lane's slot in every tile of the wave
   auto load_slot_state = [&]() {
+    // A policy without a history reads a valid dummy (element 0 of the K cache) and ignores it — NO branch around these loads:
+    // the path that does not load re-zeroes the registers, the compiler's wait-count pass guards that write with a vmcnt(0), and
+    // with the K tile's DMA loads in flight every wave of the recent_global / full / random steps sat out its K rows here before it
+    // requested q and the V tile (found in the ISA, r4: those steps were SLOWER than the heavy hitter's)
+    const double* nump = a.num ? a.num : reinterpret_cast<const double*>(a.k);
+    const int32_t* denp = a.num ? a.denom : reinterpret_cast<const int32_t*>(a.k);
+    const size_t hist = a.num ? 1 : 0;
 #pragma unroll
     for (int ti = 0; ti < SN; ti++) {
       const int sl = ALL ? all_slot(ti) : one_slot + ti * (NW * RPW * U);
       if (ALL ? all_valid(ti) : (one_lane && sl < row_end)) {
-        if (a.num) {
-          one_numv[ti] = a.num[(size_t)h * S + sl];
-          one_denv[ti] = a.denom[(size_t)h * S + sl];
-        }
+        one_numv[ti] = nump[((size_t)h * S + sl) * hist];
+        one_denv[ti] = denp[((size_t)h * S + sl) * hist];
         one_psv[ti] = a.pos[(a.Hp == 1 ? 0 : (size_t)h * S) + sl];
         if (a.policy == 3 && a.rand_next) one_rndv[ti] = a.rand_next[sl];
       }
@@ -1081,7 +1086,15 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
         hy_pu[k] = pum[i];
       }
   };
-  float one_kn = 0.f;       // ONE + L2: the key norm of this lane's slot (model dtype) ...
+  // ONE + L2: the key norm of this lane's slot — its RAW 16 bits (converted where it is used: a conversion next to the load makes
+  // the compiler wait for the load on the spot, and behind the K tile's DMA loads that wait was vmcnt(0): every wave of the l2
+  // step sat out its K rows before it requested q, the new token's rows and the V tile — found in the ISA, r4) ...
+  uint16_t one_kn_raw = 0;
+  auto one_kn_f = [&]() {
+    T e;
+    e.x = one_kn_raw;
+    return ElemTraits<T>::load(&e, 0);
+  };
   float l2_nv_lane = 0.f;   // ... and the inserted key's norm, in the lanes of the row group that inserted it
   unsigned l2_ep[3] = {0u, 0u, 0u};  // ONE + L2: epoch words of the kv heads whose norm granules this thread gathers (read behind the tile's loads, below)
   if constexpr (ONE) {
@@ -1091,8 +1104,8 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
     // publish, in the shadow of the hand-off
     if constexpr (NT == 1 && !HYB) {
       load_slot_state();
-      if constexpr (L2)
-        if (one_have) one_kn = ElemTraits<T>::load(reinterpret_cast<const T*>(a.key_norm) + (size_t)h * S, one_slot);
+      if constexpr (L2)  // (unconditional: lanes without a slot read a valid neighbour and ignore it)
+        one_kn_raw = reinterpret_cast<const uint16_t*>(a.key_norm)[(size_t)h * S + (one_have ? one_slot : row_begin)];
     }
   }
   float s_keep[NT][U];  // ONE: the wave's tiles of scores, kept for the per-slot pass
@@ -1481,7 +1494,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
       }
       if constexpr (L2) {  // the wave's maximum over the norms its slots hold AFTER this step's insert (decided above)
         float kv = -INFINITY;
-        if (one_have) kv = (one_slot == ins_idx) ? l2_nv_lane : one_kn;
+        if (one_have) kv = (one_slot == ins_idx) ? l2_nv_lane : one_kn_f();
         const bool nn = __any(kv != kv) != 0;
         const float wm = wave_max_f32(kv);
         if (lane == 0) sm_l2w[wave] = nn ? NAN : wm;
@@ -1579,7 +1592,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
   }
   if constexpr (L2 && ONE && !EML) {
     float kv = -INFINITY;
-    if (one_have) kv = (one_slot == ins_idx) ? l2_nv_lane : one_kn;
+    if (one_have) kv = (one_slot == ins_idx) ? l2_nv_lane : one_kn_f();
     const bool nn = __any(kv != kv) != 0;
     const float wm = wave_max_f32(kv);
     if (lane == 0) sm_l2w[wave] = nn ? NAN : wm;
@@ -2081,7 +2094,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
               gm = fmaxf(gm, v);
             }
           }
-          const float kn_eff = (slot_ti == ins_idx) ? l2_nv_lane : one_kn;
+          const float kn_eff = (slot_ti == ins_idx) ? l2_nv_lane : one_kn_f();
           float scn = ElemTraits<T>::rnd((gn ? NAN : gm) - kn_eff);
           if (ps >= p_next - a.w) scn = INFINITY;
           if (slot_ti < a.g) scn = INFINITY;
