@@ -90,6 +90,26 @@ __device__ __forceinline__ float wave_sum_uniform(float v) {
   const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(u, 48));
   return (r0 + r1) + (r2 + r3);
 }
+// N (4 or 8) consecutive floats of a 16-byte aligned LDS row, read in assembly with their own wait: the compiler guards any LDS
+// read it sees behind pending LDS-DMA loads with a wait for those (it cannot tell the row from the slabs they write).
+template <int N>
+__device__ __forceinline__ void lds_read_row_nowait(const float* row, float (&out)[N]) {
+  static_assert(N == 4 || N == 8, "one or two 16-byte reads");
+  typedef float f32x4_t __attribute__((ext_vector_type(4)));
+  const unsigned addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const float*)row;
+  f32x4_t a, b = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (N == 8) {
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)" : "=&v"(a), "=&v"(b) : "v"(addr) : "memory");
+  } else {
+    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(a) : "v"(addr) : "memory");
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) out[i] = a[i];
+  if constexpr (N == 8) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) out[4 + i] = b[i];
+  }
+}
 template <int CTRL>
 __device__ __forceinline__ unsigned long long dpp_min_u64(unsigned long long v) {
   const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(v & 0xffffffffull), CTRL, 0xf, 0xf, true);
@@ -719,7 +739,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
   __shared__ float sm_wm[NW][RT], sm_wl[NW][RT];  // the waves' softmax state per query head (merged across the workgroup)
   __shared__ unsigned sm_mlcnt;                    // EML: waves whose (m, l) rows are in LDS — the LAST one to arrive publishes
   __shared__ unsigned sm_fail;                     // EML: some wave of this workgroup gave up waiting (recoverable hand-off)
-  __shared__ float sm_l2w[NW];  // ONE + L2: per-wave maxima of the norms this workgroup's slots hold AFTER the step's insert
+  __shared__ __attribute__((aligned(16))) float sm_l2w[NW];  // ONE + L2: per-wave maxima of the norms this workgroup's slots hold AFTER the step's insert
   __shared__ __attribute__((aligned(16))) T sm_l2sc[L2 ? NW : 1][L2 ? 128 : 8];  // l2: the new key, transposed for its norm (the slabs belong to the DMA loads)
   __shared__ float sm_gmax;     // L2X: the norm maximum over all kv heads (NaN propagates)
 
@@ -1496,7 +1516,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
         float kv = -INFINITY;
         if (one_have) kv = (one_slot == ins_idx) ? l2_nv_lane : one_kn_f();
         const bool nn = __any(kv != kv) != 0;
-        const float wm = wave_max_f32(kv);
+        const float wm = wave_max_uniform(kv);
         if (lane == 0) sm_l2w[wave] = nn ? NAN : wm;
         // the other heads' epoch words have ARRIVED (they were requested ahead of the tile): see above
         asm volatile("" ::"v"(l2_ep[0]), "v"(l2_ep[1]), "v"(l2_ep[2]), "v"(hm_ep) : "memory");
@@ -1545,12 +1565,22 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
           float wm = -INFINITY;
           bool nn = false;
           if (arrived == (unsigned)(NW - 1) && lane == RT) {
-            wm = sm_l2w[0];
+            float lw[NW];
+            if constexpr (DMA && (NW == 4 || NW == 8)) {
+              // (read in assembly: the compiler cannot tell this row from the slabs the DMA loads write and guards a plain read
+              //  with a wait for the V tile — the workgroup's norm maximum, which every workgroup of the launch waits for, then
+              //  left when its publisher's V rows had landed: found in the ISA, r4)
+              lds_read_row_nowait<NW>(sm_l2w, lw);
+            } else {
+#pragma unroll
+              for (int w = 0; w < NW; w++) lw[w] = sm_l2w[w];
+            }
+            wm = lw[0];
             nn = wm != wm;
 #pragma unroll
             for (int w = 1; w < NW; w++) {
-              nn |= sm_l2w[w] != sm_l2w[w];
-              wm = fmaxf(wm, sm_l2w[w]);
+              nn |= lw[w] != lw[w];
+              wm = fmaxf(wm, lw[w]);
             }
           }
           const u32x4_t ng = {one_tag, __float_as_uint(wm), one_tag, nn ? 1u : 0u};
@@ -1594,7 +1624,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
     float kv = -INFINITY;
     if (one_have) kv = (one_slot == ins_idx) ? l2_nv_lane : one_kn_f();
     const bool nn = __any(kv != kv) != 0;
-    const float wm = wave_max_f32(kv);
+    const float wm = wave_max_uniform(kv);
     if (lane == 0) sm_l2w[wave] = nn ? NAN : wm;
   }
   if (L2 && !ONE && l2_here) {  // publish this wave's maximum over the norms that survive this step
@@ -1613,7 +1643,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
         v = fmaxf(v, x);
       }
     }
-    v = wave_max_f32(v);
+    v = wave_max_uniform(v);
     const bool nn = __any(kn_nan) != 0;
     if (lane == 0) a.l2_pmax[((size_t)h * a.n_split + split) * NW + wave] = nn ? NAN : v;
   }
@@ -1666,7 +1696,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
       if (got) {  // (not: nothing is published, and every workgroup of the launch times out on level two — reported like any hand-off timeout)
         const float v = lane < a.n_split ? __uint_as_float(nmx[1]) : -INFINITY;
         const bool hn = __any(lane < a.n_split && (nmx[3] != 0u || v != v)) != 0;
-        const float hmx = wave_max_f32(v);
+        const float hmx = wave_max_uniform(v);
         const u32x4_t hg = {one_tag, __float_as_uint(hmx), one_tag, hn ? 1u : 0u};
         __builtin_amdgcn_raw_buffer_store_b128(hg, ml_rsrc_p, lane == 0 ? kOneMaxHeads * (kOneMlHead + kOneNmHead) + h * 16 : 0x7ffffff0, 0, kOneAuxCoherent);
       }
@@ -1949,7 +1979,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
             gm = fmaxf(gm, v);
           }
         const bool nn = __any(gn) != 0;
-        const float wm = wave_max_f32(gm);
+        const float wm = wave_max_uniform(gm);
         if (lane == 0) sm_l2g[wave] = nn ? NAN : wm;
       }
       __syncthreads();
@@ -1987,7 +2017,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
             gm = fmaxf(gm, v);
           }
         const bool nn = __any(gn) != 0;
-        const float wm = wave_max_f32(gm);
+        const float wm = wave_max_uniform(gm);
         if (lane == 0) sm_l2g[wave] = nn ? NAN : wm;
       }
       __syncthreads();
@@ -2293,7 +2323,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
         if (hm_mine) {  // the maximum over all kv heads (NaN propagates: torch.max)
           const float v = lane < a.H ? __uint_as_float(hmq[1]) : -INFINITY;
           const bool gn = __any(lane < a.H && (hmq[3] != 0u || v != v)) != 0;
-          const float gm = wave_max_f32(v);
+          const float gm = wave_max_uniform(v);
           if (lane == 0) sm_gmax = gn ? NAN : gm;
         }
       }
@@ -2579,7 +2609,7 @@ __global__ __launch_bounds__(kCombThreads) void decode_attn_combine_kernel(Combi
   }
   __shared__ float sm_l2[kCombThreads / 64];
   if (a.next_key && a.policy == 4) {  // l2: global maximum of the norms (torch.max propagates NaN)
-    const float wm = wave_max_f32(l2_part);
+    const float wm = wave_max_uniform(l2_part);
     const bool nn = __any(l2_nan) != 0;
     if (lane == 0) sm_l2[wave] = nn ? NAN : wm;
   }
