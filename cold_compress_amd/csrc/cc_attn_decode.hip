@@ -1218,6 +1218,32 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
     if (rc_status != 0u) return;  // a step of this token failed before this launch: leave everything as it is (the host retries)
   }
   const bool rc_replay = EML && rc_commit == one_pin;  // this WORKGROUP committed its part of this position's step already: it recomputes and stores nothing
+  // ONE: what this thread gathers in the hand-off — up to NOG partial-O granules of the output pairs this workgroup finishes (pair
+  // P = r * 64 + d / 2).  Two integer divisions by run-time values (~100 scalar and vector instructions): worked out HERE, with the
+  // tile in flight, and pinned — left where they are used, they sat between the merge barrier and the first look at the (m, l)
+  // pairs, on the path every workgroup of the head waits for (found in the ISA, r4).
+  constexpr int NOG = (RT * 64 + 64 + NW * 64 - 1) / (NW * 64);  // O granules per thread
+  int o_off[NOG], o_lds[NOG], o_use[NOG];
+  int ppw = 1, pair0 = 0, n_pairs = 0;
+  if constexpr (ONE) {
+    const int ns_ = a.n_split;
+    ppw = (RT * 64 + ns_ - 1) / ns_;      // output pairs finished per workgroup
+    const int n_items = ns_ * ppw;        // (split, pair) granules this workgroup reads
+    pair0 = split * ppw;
+    n_pairs = RT * 64 - pair0;
+    n_pairs = n_pairs < 0 ? 0 : (n_pairs > ppw ? ppw : n_pairs);
+#pragma unroll
+    for (int k = 0; k < NOG; k++) {
+      const int item = (int)threadIdx.x + k * NW * 64;
+      const int i = item / ppw, qq = item - i * ppw;
+      o_use[k] = (item < n_items && qq < n_pairs) ? 1 : 0;
+      const int P = o_use[k] ? pair0 + qq : 0;
+      o_off[k] = h * kOneOHead + (((P >> 6) * ns_ + (o_use[k] ? i : 0)) * 64 + (P & 63)) * 16;
+      o_lds[k] = (i * ppw + qq) * 2;
+      asm volatile("" : "+v"(o_off[k]), "+v"(o_lds[k]), "+v"(o_use[k]));
+    }
+    asm volatile("" : "+s"(ppw), "+s"(pair0), "+s"(n_pairs));
+  }
 
   float pv_p[U];  // the tile's probabilities (unnormalised), between its two halves
   auto tile_qk = [&](TileRegs& R, const int tbase, const int tbase_next, const bool more_next, auto ti_c) {
@@ -1828,23 +1854,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
     else if constexpr (NT > 1) load_slot_state();  // several tiles per wave: the slots' history / positions arrive during the hand-off
     if (a.trace) tr2 = __builtin_amdgcn_s_memtime();
     // ---- what this thread gathers: the (m, l) granule of (head = wave, split = lane) and up to two O granules
-    const int ppw = (RT * 64 + ns - 1) / ns;  // output pairs finished per workgroup (pair P = r * 64 + d / 2)
-    const int n_items = ns * ppw;             // (split, pair) granules this workgroup reads
-    const int pair0 = split * ppw;
-    int n_pairs = RT * 64 - pair0;
-    n_pairs = n_pairs < 0 ? 0 : (n_pairs > ppw ? ppw : n_pairs);
-    constexpr int NOG = (RT * 64 + 64 + NW * 64 - 1) / (NW * 64);  // O granules per thread
-    int o_off[NOG], o_lds[NOG];
-    bool o_use[NOG];
-#pragma unroll
-    for (int k = 0; k < NOG; k++) {
-      const int item = (int)threadIdx.x + k * NW * 64;
-      const int i = item / ppw, qq = item - i * ppw;
-      o_use[k] = item < n_items && qq < n_pairs;
-      const int P = o_use[k] ? pair0 + qq : 0;
-      o_off[k] = h * kOneOHead + (((P >> 6) * ns + (o_use[k] ? i : 0)) * 64 + (P & 63)) * 16;
-      o_lds[k] = (i * ppw + qq) * 2;
-    }
+    // (ppw, pair0, n_pairs, o_off / o_lds / o_use: worked out in the prologue, while the tile was in flight)
     bool timed_out = false;
     // The first poll waits until this wave's OWN publish stores are acknowledged (vmcnt counts stores on this chip).  Polls issued
     // right behind the write-through stores cost 0.8 us at S = 4096 (11.1 vs 10.3 us; found by accident: a never-taken measurement
