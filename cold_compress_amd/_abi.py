@@ -98,6 +98,8 @@ SIGNATURES = {
     "cc_hybrid_next_key_init": (C.c_int, [_view, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp]),
     "cc_decode_step_hybrid": (C.c_int, [_view, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
                                         _i32, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _sz, _vp]),
+    "cc_decode_step_hybrid_rc": (C.c_int, [_view, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
+                                           _i32, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _sz, _vp]),
     "cc_l2_next_key_init": (C.c_int, [_view, _vp, _vp, _i32, _i32, _vp, _vp]),
     "cc_decode_step_l2": (C.c_int, [_view, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _sz, _vp]),
     "cc_decode_step_l2_rc": (C.c_int, [_view, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _sz, _vp]),

@@ -416,7 +416,7 @@ def _new_step_commit(n_heads):
 def step_committed(kv, position, HQ=None):
     """True when every workgroup word of `kv.step_commit` that the last single-launch step wrote holds `position` (words of splits
     the launch does not have stay -1) and at least one does."""
-    w = kv.step_commit[:, 2:]
+    w = kv.step_commit[:, 2:66]  # (words [66], [67]: the hybrid step's count and ring column)
     used = w != -1
     return bool(used.any()) and bool((w[used] == int(position)).all()) and bool(used.any(dim=1).all())
 
@@ -931,6 +931,7 @@ class KVCacheHybrid(_TrackedWindowSums, KVCacheHeadSpecific):
         # fused decode step (decode_step): every head's eviction candidate for the NEXT position, [H, NK]
         nk = int(_abi.lib()["cc_hh_next_key_slots"](S)) if _abi.built() else 0
         self.register_buffer("next_key", torch.full((n_heads, max(nk, 1)), -1, dtype=torch.int64), persistent=False)
+        self.register_buffer("step_commit", _new_step_commit(n_heads), persistent=False)  # recoverable hand-off (cc_decode_step_hybrid_rc)
         self._next_valid = False
 
     # ------------------------------------------------------------------ small helpers
@@ -963,6 +964,7 @@ class KVCacheHybrid(_TrackedWindowSums, KVCacheHeadSpecific):
         self._zero_window_state()
         self.cache_strategies = None
         self._next_valid = False
+        self.step_commit.fill_(-1)
         self.requires_heavy_hitter = self._init_requires_heavy_hitter()
         if hasattr(self, "special_mask"):
             self.special_mask.zero_()
@@ -1023,6 +1025,20 @@ class KVCacheHybrid(_TrackedWindowSums, KVCacheHeadSpecific):
                   _ptr(getattr(self, "special_mask", None)), _ptr(getattr(self, "punc_mask", None)), int(self.global_tokens),
                   _ptr(self.next_key), _stream())
         self._next_valid = True
+        self.step_commit.fill_(-1)  # (a re-seeded pipeline starts from no committed position: see _RingFusedStep.prepare_decode)
+        # ... and from no head counted: a failed step that nobody retried (recover=False) leaves the single-launch step's ticket
+        # word — heads that have committed the current step — short of H (include/coldcompress.h)
+        from .attention_utils import _decode_workspaces
+
+        off = int(_abi.lib()["cc_decode_step_status_offset"]()) - 4
+        for ws in _decode_workspaces(self.pos.device):
+            if off + 4 <= ws.numel():
+                ws[off:off + 4].zero_()
+
+    def recoverable(self):
+        """A timed-out single-launch step can be retried in band (cc_decode_step_hybrid_rc, late r4): the per-head decision is
+        recorded in the commit words, every workgroup commits or repeats its own part."""
+        return self.supports_fused_step()
 
     def decode_step(self, query, k_val, v_val, input_pos, scale=None, input_ids=None):
         """update_kv + attention + update_state of one decode token (cc_decode_step_hybrid): the per-head decision and the
@@ -1053,12 +1069,12 @@ class KVCacheHybrid(_TrackedWindowSums, KVCacheHeadSpecific):
         if self.requires_heavy_hitter:
             wsum, acc = self._window_state()
             ring, denom, counter = self.attn_history_num, self.attn_history_denom, self.attn_counter
-        _abi.call("cc_decode_step_hybrid", self._view(), _ptr(q), _ptr(k), _ptr(v), _ptr(p32), _ptr(self.cache_strategies), _ptr(tab),
+        _abi.call("cc_decode_step_hybrid_rc", self._view(), _ptr(q), _ptr(k), _ptr(v), _ptr(p32), _ptr(self.cache_strategies), _ptr(tab),
                   tab.shape[0], _ptr(ring), _ptr(denom), _ptr(counter), self.history_window_size, _ptr(acc), _ptr(wsum),
                   _ptr(getattr(self, "special_mask", None)), _ptr(getattr(self, "punc_mask", None)), _ptr(tok), _ptr(pids),
                   0 if pids is None else pids.numel(), _ptr(getattr(self, "num_special", None)), _ptr(getattr(self, "num_punc", None)),
-                  _ptr(self.next_key), int(self.global_tokens), HQ, 1.0 / math.sqrt(D) if scale is None else scale, _ptr(y), None,
-                  _ptr(ws), ws.numel(), _stream())
+                  _ptr(self.next_key), _ptr(self.step_commit), int(self.global_tokens), HQ,
+                  1.0 / math.sqrt(D) if scale is None else scale, _ptr(y), None, _ptr(ws), ws.numel(), _stream())
         return y
 
     # ------------------------------------------------------------------ decode (ref: cache.py:965-1019)

@@ -606,8 +606,14 @@ constexpr int kOneTicketWord = 1022;        // hybrid: heads whose workgroups ha
 //     Whatever the interleaving of give-ups and commits inside the failed launch — r3 left a window: a workgroup that completed its
 //     gather in the round trip in which a sibling gave up committed alone, and the retry added its probabilities twice — every slot's
 //     history is updated exactly once per position: the retry is idempotent per workgroup.
+//   * hybrid (late r4; its tail keeps the memory order — (m, l) and O travel together, ONE gather): the same words, the insert word
+//     = (slot << 2) | kind (append / evict / drop), plus [66] the head's count before the step and [67] the step's ring column:
+//     on a retry the whole per-head decision comes from the record (committed workgroups have rewritten their keys, the head's
+//     first workgroup may have committed the count, the LAST head to complete the step counter).  A workgroup that gives up in
+//     its gather, or reads the head's fail word with it, stores nothing of the step — no y, no ring column, no keys.
 constexpr int kOneFailWord = 64;
-constexpr int kRcStride = 66;                  // step_commit: int32 per kv head — [0] insert word, [1] its position, [2 + split] committed position
+constexpr int kRcStride = 68;                  // step_commit: int32 per kv head — [0] insert word, [1] its position, [2 + split] committed position,
+                                               // hybrid: [66] the head's count before the step, [67] the step's ring column
 // Granule regions are PER KV HEAD at fixed strides, whatever the shape: a location is only ever written by launches of its own
 // head, with tags from that head's epoch word — strictly growing per location even when caches of different head counts and
 // lengths share the workspace (shape-dependent offsets let a stale granule of head 4 sit where head 1 of another shape expects
@@ -715,6 +721,16 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
 #else
   constexpr bool RC = EML;  // the recoverable hand-off (status / commit / fail words, state stores behind the last gather) rides the same kinds
 #endif
+  // NRC (late r4): the single-launch steps whose tail keeps the memory order (one gather: (m, l) and O travel together) — the
+  // hybrid step and the several-tiles-per-wave steps — are recoverable too when the caller passes commit words (a.commit): the
+  // whole commit (y, history / ring column / window sums, keys, counts) sits behind that gather.  HRC: the hybrid part of it (the
+  // recorded decision carries the kind, the head's count and the ring column as well).
+#ifdef CC_NO_HRC  // (A/B builds)
+  constexpr bool NRC = false;
+#else
+  constexpr bool NRC = ONE && !EML;
+#endif
+  constexpr bool HRC = NRC && HYB;
   // L2X (r4): the l2 policy's norm maximum crosses kv heads (cache.py:602).  With the placement of XL2 it travels in two levels:
   // the workgroups' maxima inside the head's XCD (plain granules, gathered with the (m, l) pairs by one wave), then ONE granule
   // per kv head through memory (published by the head's split-0 workgroup, gathered by one wave per workgroup in the shadow of the
@@ -921,15 +937,20 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
   unsigned rc_status = 0;    // EML: the workspace's status word (a step failed since the host last looked: do nothing)
   int32_t rc_commit = -2;    // EML: step_commit[h][2 + split]: the last position this workgroup committed
   int32_t rc_insw = 0, rc_insp = -2;  // EML: step_commit[h][0 .. 1]: the insert slot word of position rc_insp
+  int32_t rc_cts = 0, rc_col = 0;     // hybrid: step_commit[h][66 .. 67]: the head's count before that step, its ring column
   auto load_step_words = [&]() {
     one_tag = a.one_hdr[h] + 1u;
     one_pin = *a.input_pos;
-    if constexpr (RC) {
+    if constexpr (RC || NRC) {
       rc_status = a.one_hdr[kOneStatusWordDev];
       if (a.commit) {
         rc_commit = a.commit[(size_t)h * kRcStride + 2 + split];
         rc_insw = a.commit[(size_t)h * kRcStride];
         rc_insp = a.commit[(size_t)h * kRcStride + 1];
+        if constexpr (HRC) {
+          rc_cts = a.commit[(size_t)h * kRcStride + 66];
+          rc_col = a.commit[(size_t)h * kRcStride + 67];
+        }
       }
     }
   };
@@ -1119,6 +1140,9 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
   unsigned l2_ep[3] = {0u, 0u, 0u};  // ONE + L2: epoch words of the kv heads whose norm granules this thread gathers (read behind the tile's loads, below)
   if constexpr (ONE) {
     if constexpr (!DMA) load_step_words();
+    if constexpr (NRC) {
+      if (threadIdx.x == 0) sm_fail = 0u;  // (read behind the barriers of the epilogue and the finish)
+    }
     // single tile: requested AHEAD of the K/V tile (measured: behind it the step is 0.3 us slower — the tile's in-order waits
     // then end on these stragglers, and the workgroup leaves the streaming part later); several tiles: requested after the
     // publish, in the shadow of the hand-off
@@ -1217,7 +1241,12 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
     }
     if (rc_status != 0u) return;  // a step of this token failed before this launch: leave everything as it is (the host retries)
   }
-  const bool rc_replay = EML && rc_commit == one_pin;  // this WORKGROUP committed its part of this position's step already: it recomputes and stores nothing
+  if constexpr (NRC) {
+    // (HERE, behind the issue of the first tile's loads — at the top of the kernel the test waited for the step words, a cold
+    //  scalar round trip in front of every workgroup's first K rows: +1 us on the C4 step.  Nothing has been written yet.)
+    if (a.commit && rc_status != 0u) return;
+  }
+  const bool rc_replay = (EML || (NRC && a.commit != nullptr)) && rc_commit == one_pin;  // this WORKGROUP committed its part of this position's step already: it recomputes and stores nothing
   // ONE: what this thread gathers in the hand-off — up to NOG partial-O granules of the output pairs this workgroup finishes (pair
   // P = r * 64 + d / 2).  Two integer divisions by run-time values (~100 scalar and vector instructions): worked out HERE, with the
   // tile in flight, and pinned — left where they are used, they sat between the merge barrier and the first look at the (m, l)
@@ -1258,7 +1287,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
       ins_idx = (key == ~0ull) ? -1 : (int)((key & 0xffffffffull) >> 1);
       if (a.abl & 64) ins_idx = -1;
       ins_was_empty = (int)(key & 1ull);
-      if constexpr (RC) {
+      if constexpr (RC || (NRC && !HYB)) {
         if (rc_insp == one_pin) {  // a retry: the slot the first attempt's insert went to (the key row may hold the next position's keys by now)
           ins_idx = rc_insw >> 1;  // (arithmetic shift: -1 stays -1)
           ins_was_empty = rc_insw & 1;
@@ -1305,6 +1334,21 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
           } else {  // :948-950 the token is not kept: it lands in slot S - 1 with the mask untouched
             ins_idx = S - 1;
             hyb_kind = 2;
+          }
+        }
+        if constexpr (HRC) {
+          if (a.commit) {
+            if (rc_insp == one_pin) {  // a retry: the first attempt's decision (the key row, the count, the step counter may have moved on)
+              ins_idx = rc_insw >> 2;
+              hyb_kind = rc_insw & 3;
+              hyb_cts = rc_cts;
+              one_rcol = rc_col;
+            } else if (split == 0 && threadIdx.x == 0) {  // recorded before anything of the step can be committed
+              a.commit[(size_t)h * kRcStride] = (ins_idx << 2) | hyb_kind;
+              a.commit[(size_t)h * kRcStride + 66] = hyb_cts;
+              a.commit[(size_t)h * kRcStride + 67] = one_rcol;
+              a.commit[(size_t)h * kRcStride + 1] = one_pin;
+            }
           }
         }
       }
@@ -1382,7 +1426,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
             a.denom[slot] = 0;
           }
           // (recoverable hand-off: the count is bumped where the step is committed — a retried insert must not count twice)
-          if (ins_was_empty && (a.Hc == a.H || h == 0) && !(EML && a.commit)) atomicAdd(&a.cache_cts[a.Hc == a.H ? h : 0], 1);
+          if (ins_was_empty && (a.Hc == a.H || h == 0) && !((EML || NRC) && a.commit)) atomicAdd(&a.cache_cts[a.Hc == a.H ? h : 0], 1);
         }
         if (L2) {  // l2: cache.py:592-593 — the new key's norm (sumsq_canonical_16's order), model dtype
           // the canonical order wants elements c, c + 16, ... of the key in lane c; the lanes of this row group hold chunk c (elements
@@ -1856,6 +1900,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
     // ---- what this thread gathers: the (m, l) granule of (head = wave, split = lane) and up to two O granules
     // (ppw, pair0, n_pairs, o_off / o_lds / o_use: worked out in the prologue, while the tile was in flight)
     bool timed_out = false;
+    bool hrc_peer_failed = false, hrc_failed = false;  // hybrid, recoverable form: a peer gave up / this workgroup commits nothing
     // The first poll waits until this wave's OWN publish stores are acknowledged (vmcnt counts stores on this chip).  Polls issued
     // right behind the write-through stores cost 0.8 us at S = 4096 (11.1 vs 10.3 us; found by accident: a never-taken measurement
     // branch with loads of its own made the compiler put this wait at the join): the stragglers' K/V rows and everybody's granules
@@ -2006,6 +2051,17 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
         for (int k = 0; k < NLG; k++) ok = ok && (!nm_use[k] || (nq[k][0] == nm_tag[k] && nq[k][2] == nm_tag[k]));
         ok = ok && ok_ml() && ok_o();
         if (__all(ok)) break;
+        if constexpr (NRC) {
+          // the head's fail word, with one round in eight (it travels through memory: a round that waits for it lasts longer —
+          // +1 us on the C4 step when it was read with every round) — a workgroup of this head gave up: nothing left to wait for
+          if (a.commit && (spins & 7u) == 7u) {
+            failq = __builtin_amdgcn_raw_buffer_load_b32(hdr_rsrc, (kOneFailWord + h) * 4, 0, kOneAuxCoherent);
+            if (failq == tag) {
+              hrc_peer_failed = true;
+              break;
+            }
+          }
+        }
         if (spins > kOneSpinMax) {
           timed_out = true;
           break;
@@ -2013,7 +2069,12 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
         __builtin_amdgcn_s_sleep(1);
       }
       if (a.trace) tr4 = __builtin_amdgcn_s_memtime();
-      if (timed_out && lane == 0) a.one_hdr[kOneStatusWordDev] = 1u;  // this launch's results are invalid; the host reads the word
+      if (NRC && a.commit) {
+        if (timed_out) give_up();
+        else if (hrc_peer_failed && lane == 0) sm_fail = 1u;  // (every workgroup commits or repeats ITS part: per-workgroup commit words)
+      } else if (timed_out && lane == 0) {
+        a.one_hdr[kOneStatusWordDev] = 1u;  // this launch's results are invalid; the host reads the word
+      }
       final_ml();
       stash_o();
       if constexpr (L2) {
@@ -2032,8 +2093,11 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
       }
       __syncthreads();
       if (a.trace) trD = __builtin_amdgcn_s_memtime();
-      y_fold();
+      if constexpr (NRC) hrc_failed = a.commit != nullptr && sm_fail != 0u;  // (workgroup-uniform behind the barrier)
+      if (!hrc_failed) y_fold();
     }
+    // hybrid, recoverable form: nothing of the step is stored by a workgroup that failed or that committed this position before
+    const bool hrc_skip = NRC && a.commit != nullptr && (hrc_failed || rc_replay);
     if constexpr (EML) {
       // the first round of the partial-O gather goes out HERE and flies while the per-slot pass runs: what is left behind the last O
       // granule of the head is the y fold
@@ -2180,7 +2244,9 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
         }
       }
     };
-    if constexpr (!L2X) all_tiles(all_tiles, IntC<0>{});  // (L2X: behind the partial-O gather — the heads' maxima arrive with it)
+    if constexpr (!L2X) {
+      if (!hrc_skip) all_tiles(all_tiles, IntC<0>{});  // (L2X: behind the partial-O gather — the heads' maxima arrive with it)
+    }
     if constexpr (ALL) {
       // ---- the second half of the per-slot pass on all lanes: the slot_pass branches above, operation for operation (heavy hitter:
       //      cache.py:716-722, 727-749; head-constant policies: cache.py:500-502, 519-524, 552-556)
@@ -2190,7 +2256,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
       const int32_t p_next = one_pin + 1;
 #pragma unroll
       for (int k = 0; k < SN; k++)
-        if (all_valid(k)) {
+        if (all_valid(k) && !hrc_skip) {
           const int sl = all_slot(k);
           const size_t i = (size_t)h * S + sl;
           const float av = sm_hav[wave][lane + 64 * k];
@@ -2241,7 +2307,7 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
       asm volatile("" : "+s"(late_one), "+s"(late_ff));
 #pragma unroll
       for (int k = 0; k < HSL; k++)
-        if (hyb_valid(k)) {
+        if (hyb_valid(k) && !hrc_skip) {
           const int sl = hyb_slot(k);
           const size_t i = (size_t)h * S + sl;
           int32_t ps = hy_ps[k];
@@ -2358,29 +2424,32 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
         }
       }
     } else {
-      store_key();
+      failed = hrc_failed;
+      if (!hrc_skip) store_key();
       if (a.trace) trE = __builtin_amdgcn_s_memtime();
     }
     if (threadIdx.x == 0) {
       if (split == 0 && !failed) {
         a.one_hdr[h] = tag;  // all n_split workgroups of this head have published, hence read the old epoch
         if constexpr (HYB) {
-          a.cache_cts[h] = hyb_cts_n;  // every workgroup of this head has read the old count (it decided before it published)
-          // the step counter and num_punc are read by the workgroups of EVERY head: the head that completes the set commits them
-          const unsigned t = atomicAdd(&a.one_hdr[kOneTicketWord], 1u);
-          if (t == (unsigned)a.H - 1u) {
-            a.one_hdr[kOneTicketWord] = 0u;
-            if (a.ring_num && a.hh_counter) *a.hh_counter += 1;               // cache.py:723
-            if (hy_punc && a.hyb.num_punc) *a.hyb.num_punc += 1;              // cache.py:1017, once per step
+          if (!rc_replay) {  // (recoverable form: a head that committed this position before does not count twice)
+            a.cache_cts[h] = hyb_cts_n;  // every workgroup of this head has read the old count (it decided before it published)
+            // the step counter and num_punc are read by the workgroups of EVERY head: the head that completes the set commits them
+            const unsigned t = atomicAdd(&a.one_hdr[kOneTicketWord], 1u);
+            if (t == (unsigned)a.H - 1u) {
+              a.one_hdr[kOneTicketWord] = 0u;
+              if (a.ring_num && a.hh_counter) *a.hh_counter += 1;               // cache.py:723
+              if (hy_punc && a.hyb.num_punc) *a.hyb.num_punc += 1;              // cache.py:1017, once per step
+            }
           }
         } else if (!rc_replay) {
           if (h == 0 && a.hh_counter) *a.hh_counter += 1;
-          if (EML && a.commit) {  // recoverable hand-off: the head's count travels with split 0's commit
+          if ((EML || NRC) && a.commit) {  // recoverable hand-off: the head's count travels with split 0's commit
             if (ins_was_empty && (a.Hc == a.H || h == 0)) a.cache_cts[a.Hc == a.H ? h : 0] += 1;  // (one writer per count)
           }
         }
       }
-      if constexpr (RC) {  // this workgroup's part of the step (its slots' history, its keys) is committed
+      if constexpr (RC || NRC) {  // this workgroup's part of the step (its slots' history, its keys) is committed
         if (!failed && !rc_replay && a.commit) a.commit[(size_t)h * kRcStride + 2 + split] = one_pin;
       }
       if (a.trace) {
@@ -3696,12 +3765,13 @@ int cc_decode_step_heavy_hitter_ring(const cc_kv_view* c, const void* q, const v
                    workspace, workspace_bytes, stream, 3, &fs, &rh);
 }
 
-int cc_decode_step_hybrid(const cc_kv_view* c, const void* q, const void* k_new, const void* v_new, const int32_t* input_pos,
-                          const int64_t* strategies, const int32_t* policy_table, int32_t n_policies, void* ring_num, int32_t* denom,
-                          int64_t* counter, int32_t W, uint64_t* wsum_acc, float* wsum, const uint8_t* special_mask,
-                          uint8_t* punc_mask, const int64_t* token_id, const int64_t* punc_ids, int32_t n_punc_ids,
-                          const int32_t* num_special, int32_t* num_punc, uint64_t* next_key, int32_t global_tokens, int32_t HQ,
-                          float scale, void* y, void* attn_out, void* workspace, size_t workspace_bytes, cc_stream_t stream) {
+int cc_decode_step_hybrid_rc(const cc_kv_view* c, const void* q, const void* k_new, const void* v_new, const int32_t* input_pos,
+                             const int64_t* strategies, const int32_t* policy_table, int32_t n_policies, void* ring_num,
+                             int32_t* denom, int64_t* counter, int32_t W, uint64_t* wsum_acc, float* wsum, const uint8_t* special_mask,
+                             uint8_t* punc_mask, const int64_t* token_id, const int64_t* punc_ids, int32_t n_punc_ids,
+                             const int32_t* num_special, int32_t* num_punc, uint64_t* next_key, int32_t* step_commit,
+                             int32_t global_tokens, int32_t HQ, float scale, void* y, void* attn_out, void* workspace,
+                             size_t workspace_bytes, cc_stream_t stream) {
   if (!cc_view_ok(c) || !q || !k_new || !v_new || !input_pos || !strategies || !policy_table || n_policies <= 0 || !next_key || !y ||
       c->Hp != c->H || c->Hc != c->H || HQ <= 0 || HQ % c->H || W <= 0 || (punc_ids && n_punc_ids < 0) ||
       (ring_num && (!denom || !counter || !wsum_acc || !wsum)))
@@ -3712,10 +3782,22 @@ int cc_decode_step_hybrid(const cc_kv_view* c, const void* q, const void* k_new,
   hs.W = W; hs.n_pol = n_policies;
   if (n_policies * 3 > 64) return CC_ERR_UNSUPPORTED;  // the streaming pass fetches the whole policy table with one vector load
   FusedStep fs{c, k_new, v_new, input_pos, reinterpret_cast<unsigned long long*>(next_key), global_tokens, 0, 6, nullptr, nullptr, &hs};
+  fs.commit = step_commit;
   RingHistory rh{ring_num, W, wsum_acc, wsum};
   return attn_impl(q, c->k_cache, c->v_cache, c->mask, HQ, c->H, c->S, c->D, c->dtype, scale, y, attn_out, nullptr, nullptr,
                    ring_num ? denom : nullptr, ring_num ? counter : nullptr, workspace, workspace_bytes, stream, 3, &fs,
                    ring_num ? &rh : nullptr);
+}
+
+int cc_decode_step_hybrid(const cc_kv_view* c, const void* q, const void* k_new, const void* v_new, const int32_t* input_pos,
+                          const int64_t* strategies, const int32_t* policy_table, int32_t n_policies, void* ring_num, int32_t* denom,
+                          int64_t* counter, int32_t W, uint64_t* wsum_acc, float* wsum, const uint8_t* special_mask,
+                          uint8_t* punc_mask, const int64_t* token_id, const int64_t* punc_ids, int32_t n_punc_ids,
+                          const int32_t* num_special, int32_t* num_punc, uint64_t* next_key, int32_t global_tokens, int32_t HQ,
+                          float scale, void* y, void* attn_out, void* workspace, size_t workspace_bytes, cc_stream_t stream) {
+  return cc_decode_step_hybrid_rc(c, q, k_new, v_new, input_pos, strategies, policy_table, n_policies, ring_num, denom, counter, W,
+                                  wsum_acc, wsum, special_mask, punc_mask, token_id, punc_ids, n_punc_ids, num_special, num_punc,
+                                  next_key, nullptr, global_tokens, HQ, scale, y, attn_out, workspace, workspace_bytes, stream);
 }
 
 int cc_decode_attn_gqa_ring(const void* q, const void* k, const void* v, const uint8_t* mask, int32_t HQ, int32_t H, int32_t S,

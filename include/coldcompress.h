@@ -390,6 +390,20 @@ int cc_decode_step_hybrid(const cc_kv_view* c, const void* q, const void* k_new,
                           uint8_t* punc_mask, const int64_t* token_id, const int64_t* punc_ids, int32_t n_punc_ids,
                           const int32_t* num_special, int32_t* num_punc, uint64_t* next_key, int32_t global_tokens, int32_t HQ,
                           float scale, void* y, void* attn_out, void* workspace, size_t workspace_bytes, cc_stream_t stream);
+/* The same step with the recoverable hand-off's commit words (step_commit: int32 [H, cc_decode_step_commit_stride()], -1 before
+ * the first step; null: cc_decode_step_hybrid).  Single-launch form: a workgroup that gives up waiting, or finds that a workgroup
+ * of its kv head did, stores NOTHING of the step (no y, no ring column / window sum / denominator, no keys, no counts); the others
+ * commit their part and mark it in their word.  The per-head decision of the position (slot, append / evict / drop, the head's
+ * count before the step, the ring column) is recorded in words [0], [1], [66], [67] before anything can be committed, and a retry
+ * of the position takes it from there: committed workgroups recompute (the hand-off needs their partials, y is written again)
+ * and store nothing else.  The two-launch form ignores step_commit (nothing to time out). */
+int cc_decode_step_hybrid_rc(const cc_kv_view* c, const void* q, const void* k_new, const void* v_new, const int32_t* input_pos,
+                             const int64_t* strategies, const int32_t* policy_table, int32_t n_policies, void* ring_num,
+                             int32_t* denom, int64_t* counter, int32_t W, uint64_t* wsum_acc, float* wsum, const uint8_t* special_mask,
+                             uint8_t* punc_mask, const int64_t* token_id, const int64_t* punc_ids, int32_t n_punc_ids,
+                             const int32_t* num_special, int32_t* num_punc, uint64_t* next_key, int32_t* step_commit,
+                             int32_t global_tokens, int32_t HQ, float scale, void* y, void* attn_out, void* workspace,
+                             size_t workspace_bytes, cc_stream_t stream);
 /* cc_decode_step_hybrid runs as ONE launch (the single-launch form above: in-launch hand-off, every workgroup resident) when
  * this returns 1: 16-bit caches, head_dim 128, HQ / H in {4, 8}, up to eight 64-slot tiles per workgroup (S <= 32768 at 64
  * workgroups per kv head).  The tail then also does what the combine pass did for this policy: ring column, exact window sum and

@@ -1135,6 +1135,30 @@ int cc_decode_step_hybrid_cpu(const cc_kv_view* c, const void* q, const void* k_
                                      counter, W, wsum_acc, wsum, workspace, workspace_bytes, stream);
 }
 
+/* cc_decode_step_hybrid_rc on the CPU: the step, then every head marked for this position (cf. cc_decode_step_heavy_hitter_rc_cpu;
+ * a head already marked for it: refusal — the replay form is a device matter).  CC_RC_STRIDE is defined further down. */
+int cc_decode_step_hybrid_rc_cpu(const cc_kv_view* c, const void* q, const void* k_new, const void* v_new, const int32_t* input_pos,
+                                 const int64_t* strategies, const int32_t* policy_table, int32_t n_policies, void* ring_num,
+                                 int32_t* denom, int64_t* counter, int32_t W, uint64_t* wsum_acc, float* wsum,
+                                 const uint8_t* special_mask, uint8_t* punc_mask, const int64_t* token_id, const int64_t* punc_ids,
+                                 int32_t n_punc_ids, const int32_t* num_special, int32_t* num_punc, uint64_t* next_key,
+                                 int32_t* step_commit, int32_t global_tokens, int32_t HQ, float scale, void* y, void* attn_out,
+                                 void* workspace, size_t workspace_bytes, cc_stream_t stream) {
+  enum { RC_STRIDE = 68 };
+  if (step_commit && input_pos && c)
+    for (int h = 0; h < c->H; h++)
+      if (step_commit[h * RC_STRIDE + 2] == *input_pos) return CC_ERR_UNSUPPORTED;
+  const int rc = cc_decode_step_hybrid_cpu(c, q, k_new, v_new, input_pos, strategies, policy_table, n_policies, ring_num, denom, counter,
+                                           W, wsum_acc, wsum, special_mask, punc_mask, token_id, punc_ids, n_punc_ids, num_special,
+                                           num_punc, next_key, global_tokens, HQ, scale, y, attn_out, workspace, workspace_bytes, stream);
+  if (rc == CC_OK && step_commit)
+    for (int h = 0; h < c->H; h++) {
+      step_commit[h * RC_STRIDE] = -1;
+      step_commit[h * RC_STRIDE + 1] = step_commit[h * RC_STRIDE + 2] = *input_pos;
+    }
+  return rc;
+}
+
 int cc_attn_bandsum_cpu(const void* attn, int32_t H, int32_t Lq, int32_t Lk, int32_t dtype, int32_t band, float* out,
                         cc_stream_t stream) {
   (void)stream;
@@ -1527,11 +1551,11 @@ int cc_decode_step_heavy_hitter_phases_cpu(const cc_kv_view* c, const void* q, c
 }
 
 /* The device entry point with the recoverable hand-off's commit words (r4 layout: CC_RC_STRIDE int32 per kv head — [0] the insert
- * word, [1] its position, [2 + split] the position workgroup `split` committed): on the CPU nothing can time out — the step runs,
+ * word, [1] its position, [2 + split] the position workgroup `split` committed, [66], [67] the hybrid step's count and ring column): on the CPU nothing can time out — the step runs,
  * then every head is marked for this position in word [1] and in word [2] (the one workgroup a CPU has; word [0], the insert slot,
  * is the device's business and is set to -1 here); a head ALREADY marked for this position makes the whole call a refusal (the
  * replay form is a device matter). */
-#define CC_RC_STRIDE 66
+#define CC_RC_STRIDE 68
 int cc_decode_step_heavy_hitter_rc_cpu(const cc_kv_view* c, const void* q, const void* k_new, const void* v_new,
                                        const int32_t* input_pos, double* num, int32_t* denom, int64_t* counter,
                                        uint64_t* next_key, int32_t* step_commit, int32_t g, int32_t w, int32_t HQ, float scale,

@@ -44,7 +44,7 @@ def _state(kv):
 
 
 @pytest.mark.parametrize("strategy", ["heavy_hitter", "recent_global", "full", "random"])
-@pytest.mark.parametrize("H,HQ,S", [(8, 32, 4096), (2, 8, 512)])
+@pytest.mark.parametrize("H,HQ,S", [(8, 32, 4096), (2, 8, 512), (8, 32, 8192)])  # (8192: two tiles per wave — the memory-order tail)
 def test_replay_of_a_committed_step_changes_nothing(H, HQ, S, strategy):
     from cold_compress_amd import _abi
 
@@ -126,16 +126,18 @@ def test_half_committed_step_completes_to_the_same_state(strategy, committed):
 
 
 @pytest.mark.parametrize("splits", [(0, 5, 31), (7,), tuple(range(1, 32)), tuple(range(0, 31))])
-@pytest.mark.parametrize("strategy", ["heavy_hitter", "recent_global", "l2"])
-def test_a_strict_subset_of_a_heads_workgroups_committed(strategy, splits):
+@pytest.mark.parametrize("strategy,S,NW", [("heavy_hitter", 4096, 8), ("recent_global", 4096, 8), ("l2", 4096, 8),
+                                           # two tiles per wave: the memory-order tail's recoverable form (64 workgroups of 4 waves)
+                                           ("heavy_hitter", 8192, 4), ("recent_global", 8192, 4)])
+def test_a_strict_subset_of_a_heads_workgroups_committed(strategy, S, NW, splits):
     """VERDICT r3 item 3a — the window r3 left open, built deterministically: inside the failed launch SOME workgroups of a kv head
     committed their part of the step (their slots' history, their entries of the key row, their commit word) and the others did
     not (they read the head's fail word, or gave up).  The insert itself (rows, position, mask, the l2 norm, the insert word) went
     in early, before the hand-off.  The retry must leave every buffer exactly as a fault-free step does: committed workgroups
     recompute and store nothing, the others step, all of them find the insert slot in the commit words — the key row's minimum is
     no longer this step's.  Wide geometry: 32 workgroups x 128 slots per kv head, 8 key-row entries per workgroup."""
-    H, HQ, S, D = 8, 32, 4096, 128
-    NW, ROWS = 8, 128
+    H, HQ, D = 8, 32, 128
+    ROWS = 128
     torch.manual_seed(41)
     kv, T = _mk(H, S, strategy=strategy)
     assert kv.recoverable()
@@ -157,6 +159,7 @@ def test_a_strict_subset_of_a_heads_workgroups_committed(strategy, splits):
     torch.cuda.synchronize()
     after = _state(kv)
     assert step_committed(kv, T + 3)
+    assert int((after["step_commit"][:, 2:66] != -1).sum(dim=1).min()) == S // ROWS, "geometry: workgroups per kv head"
     heads = (1, 4, 6) if 0 not in splits else (0, 3)  # kv heads left half committed (the others: fully committed)
     sel = torch.zeros(S, dtype=torch.bool, device=DEV)
     for sp in splits:
@@ -300,4 +303,236 @@ def test_co_tenant_fault_is_recovered_in_band(strategy):
     for l, (a, b) in enumerate(zip(clean_s, fault_s)):
         for n in a:
             assert torch.equal(a[n], b[n]), f"layer {l}: {n} differs after the recovered fault"
+    assert au.single_launch_status(torch.device(DEV)) == 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The hybrid (FastGen) single-launch step, recoverable form (cc_decode_step_hybrid_rc, late r4)
+def _mk_hybrid(H, S, T, seed):
+    """A decode-ready hybrid cache without the profiling pass (cf. tests/test_gpu_hybrid.py): head h runs policy h % n, even heads
+    full-ish, odd heads half empty, ring / denominators / protection masks random."""
+    import cold_compress_amd.cache as cache
+    from test_gpu_hybrid import HYB_YAML, TOKEN_IDS
+
+    D, dtype = 128, torch.bfloat16
+    cls, rk = cache.get_cache_constructor("hybrid")
+    kw = dict(max_cache_length=S, max_seq_length=S, cache_bits=None, global_tokens=4, token_ids=TOKEN_IDS, min_recovery_frac=0.9,
+              hybrid_strategies=HYB_YAML)
+    with torch.device(DEV):
+        kv = cls(1, H, D, dtype, **{k: kw[k] for k in rk})
+    gen = torch.Generator().manual_seed(seed)
+    k0 = torch.randn(1, H, T, D, generator=gen).to(dtype).to(DEV)
+    v0 = torch.randn(1, H, T, D, generator=gen).to(dtype).to(DEV)
+    fill = torch.tensor([T if h % 2 == 0 else max(4, T // 2) for h in range(H)], dtype=torch.int32)
+    ring0 = (torch.rand(H, S, kv.history_window_size, generator=gen) * 1e-2).to(dtype)
+    den0 = torch.randint(1, 500, (H, S), generator=gen, dtype=torch.int32)
+    kv.update_kv(torch.arange(T, device=DEV), k0, v0, True, input_ids=torch.zeros(T, dtype=torch.int64, device=DEV))
+    kv.cache_strategies = (torch.arange(H, device=DEV) % len(HYB_YAML)).to(torch.int64).contiguous()
+    kv.requires_heavy_hitter = True
+    kv.cache_cts.copy_(fill.to(DEV))
+    live = torch.arange(S, device=DEV).view(1, S) < fill.to(DEV).view(H, 1)
+    kv.mask[0, :, 0, :] = live
+    kv.pos[0] = torch.where(live, torch.arange(S, device=DEV, dtype=kv.pos.dtype).view(1, S).expand(H, S), torch.full_like(kv.pos[0], -1))
+    kv.attn_history_num.copy_(ring0.to(DEV).unsqueeze(0))
+    kv.attn_history_denom.copy_(den0.to(DEV).unsqueeze(0))
+    return kv, gen
+
+
+def _hyb_tok(gen, H, HQ, t, D=128):
+    dtype = torch.bfloat16
+    ids = torch.tensor([[6 if t % 5 == 2 else 11]], dtype=torch.int64, device=DEV)  # every fifth token is punctuation
+    k1 = torch.randn(1, H, 1, D, generator=gen).to(dtype).to(DEV)
+    v1 = torch.randn(1, H, 1, D, generator=gen).to(dtype).to(DEV)
+    q = torch.randn(1, HQ, 1, D, generator=gen).to(dtype).to(DEV)
+    return q, k1, v1, ids
+
+
+@pytest.mark.parametrize("H,HQ,S,T", [(8, 32, 8192, 8190), (8, 32, 18432, 18400)])
+def test_hybrid_replay_of_a_committed_step_changes_nothing(H, HQ, S, T):
+    from cold_compress_amd import _abi
+    from cold_compress_amd.attention_utils import single_launch_status
+
+    assert _abi.lib()["cc_decode_step_hybrid_single_launch"](HQ, H, S, 128, 1) == 1
+    kv, gen = _mk_hybrid(H, S, T, seed=51)
+    assert kv.recoverable()
+    for t in range(5):
+        q, k1, v1, ids = _hyb_tok(gen, H, HQ, t)
+        p = torch.tensor([T + t], dtype=torch.int32, device=DEV)
+        y1 = kv.decode_step(q, k1, v1, p, input_ids=ids).clone()
+        torch.cuda.synchronize()
+        assert step_committed(kv, T + t)
+        st = _state(kv)
+        y2 = kv.decode_step(q, k1, v1, p, input_ids=ids)  # the same position again: every workgroup is committed
+        torch.cuda.synchronize()
+        assert torch.equal(y1, y2), f"step {t}: replayed y"
+        for n, b in kv.named_buffers():
+            assert torch.equal(b, st[n]), f"step {t}: replay changed {n}"
+    assert single_launch_status(kv.pos.device) == 0
+
+
+@pytest.mark.parametrize("splits", [(0, 5, 31), (7,), tuple(range(1, 64)), tuple(range(0, 63))])
+def test_hybrid_strict_subset_of_a_heads_workgroups_committed(splits):
+    """The state a failed launch of the hybrid single-launch step leaves, built deterministically (cf. the test above for the other
+    policies): the insert (rows, position, masks) and the recorded decision (commit words [0], [1], [66], [67]) are in; SOME
+    workgroups of the kv heads in `heads` committed their part (their slots' ring column / denominator, their keys, their word),
+    the others did not; the head's count follows its first workgroup; the step counter and num_punc are committed by the LAST
+    head to complete (the ticket word in the workspace holds the heads that have).  The retry must complete the step to exactly
+    the fault-free state.  S = 8192: 64 workgroups x 128 slots per kv head, 4 key-row entries per workgroup."""
+    from cold_compress_amd.attention_utils import _workspace, single_launch_status
+    from cold_compress_amd import _abi
+
+    H, HQ, S, T = 8, 32, 8192, 8190
+    NW, ROWS = 4, 128
+    kv, gen = _mk_hybrid(H, S, T, seed=52)
+    for t in range(4):  # full heads evict, half-empty heads append; token 2 is punctuation
+        q, k1, v1, ids = _hyb_tok(gen, H, HQ, t)
+        kv.decode_step(q, k1, v1, torch.tensor([T + t], dtype=torch.int32, device=DEV), input_ids=ids)
+    torch.cuda.synchronize()
+    before = _state(kv)
+    t = 7  # (7 % 5 == 2: a punctuation token — num_punc moves with the step)
+    q, k1, v1, ids = _hyb_tok(gen, H, HQ, t)
+    p = torch.tensor([T + 4], dtype=torch.int32, device=DEV)
+    y_clean = kv.decode_step(q, k1, v1, p, input_ids=ids).clone()
+    torch.cuda.synchronize()
+    after = _state(kv)
+    assert step_committed(kv, T + 4)
+    assert int((after["step_commit"][:, 2:66] != -1).sum(dim=1).min()) == S // ROWS, "geometry: 64 workgroups per kv head"
+    assert not torch.equal(before["attn_counter"], after["attn_counter"])
+    heads = (1, 4, 6) if 0 not in splits else (0, 3)  # kv heads left half committed (the others: fully committed)
+    sel = torch.zeros(S, dtype=torch.bool, device=DEV)
+    selk = torch.zeros(after["next_key"].shape[1], dtype=torch.bool, device=DEV)
+    for sp in splits:
+        sel[sp * ROWS:(sp + 1) * ROWS] = True
+        selk[sp * NW:(sp + 1) * NW] = True
+    all_first = 0 in splits  # every head's first workgroup committed: counts, step counter and num_punc are in
+    for n, b in kv.named_buffers():
+        bi, af = before[n], after[n]
+        b.copy_(af)  # what went in ahead of the hand-off, and everything of the fully committed heads
+        for h in heads:
+            if n == "attn_history_num":  # [1, H, S, W]: the step's ring column of every slot
+                b[0, h] = torch.where(sel.view(S, 1), af[0, h], bi[0, h])
+            elif n == "attn_history_denom":
+                b[0, h] = torch.where(sel, af[0, h], bi[0, h])
+            elif n == "next_key":
+                b[h] = torch.where(selk, af[h], bi[h])
+            elif n == "step_commit":
+                w = bi[h].clone()
+                w[0:2] = af[h, 0:2]
+                w[66:68] = af[h, 66:68]
+                for sp in splits:
+                    w[2 + sp] = af[h, 2 + sp]
+                b[h] = w
+            elif n == "cache_cts" and not all_first:
+                b[h] = bi[h]
+        if n in ("attn_counter", "num_punc") and not all_first:
+            b.copy_(bi)
+    # (attn_window_sum / attn_window_acc: rebuilt from the ring by the cache — the ring was written by torch)
+    off = int(_abi.lib()["cc_decode_step_status_offset"]()) - 4
+    ws = _workspace(1, kv.pos.device)  # the decode workspace in use (the step above sized it)
+    ws[off:off + 4].view(torch.int32).fill_(0 if all_first else H - len(heads))  # heads that have committed the step
+    y2 = kv.decode_step(q, k1, v1, p, input_ids=ids)
+    torch.cuda.synchronize()
+    assert torch.equal(y2, y_clean), "y of the completed step"
+    for n, b in kv.named_buffers():
+        assert torch.equal(b, after[n]), f"{n} differs from the fault-free step's"
+    assert int(ws[off:off + 4].view(torch.int32).item()) == 0, "ticket word"
+    assert single_launch_status(kv.pos.device) == 0
+
+
+def test_hybrid_co_tenant_fault_is_recovered():
+    """A REAL fault for the hybrid step: twin caches at S = 8192 (64 workgroups per kv head); before the fourth token of the second
+    one a co-tenant kernel pins 150 KB of LDS on 232 CUs for 2.2 s — the step's workgroups do not all fit beside it, the resident
+    ones give up (status word), and what harness._recover_token does — clear the word, advance the epochs, run the SAME position
+    again — must leave y and every buffer equal to the fault-free twin's, for this token and the ones behind it."""
+    import cold_compress_amd.attention_utils as au
+    from cold_compress_amd import _abi
+
+    H, HQ, S, T = 8, 32, 8192, 8190
+    scratch = torch.zeros(64, dtype=torch.int32, device=DEV)
+    provoked = 0
+    try:
+        for attempt in range(6):  # (a run that provoked nothing has tested nothing: try again on a fresh side stream, then FAIL)
+            side = torch.cuda.Stream()
+            a, gen_a = _mk_hybrid(H, S, T, seed=61)
+            b, gen_b = _mk_hybrid(H, S, T, seed=61)
+            for t in range(7):
+                qa, ka, va, ids = _hyb_tok(gen_a, H, HQ, t)
+                qb, kb, vb, _ = _hyb_tok(gen_b, H, HQ, t)
+                p = torch.tensor([T + t], dtype=torch.int32, device=DEV)
+                ya = a.decode_step(qa, ka, va, p, input_ids=ids)
+                torch.cuda.synchronize()
+                if t == 3:
+                    rc = _abi.lib()["cc_debug_occupy"](232, 150 * 1024, 2_200_000, C.c_void_p(scratch.data_ptr()), C.c_void_p(side.cuda_stream))
+                    assert rc == 0
+                yb = b.decode_step(qb, kb, vb, p, input_ids=ids)
+                torch.cuda.synchronize()
+                tries = 0
+                while au.single_launch_status(torch.device(DEV)) != 0:
+                    provoked += 1
+                    tries += 1
+                    assert tries <= 5, "the retry kept failing"
+                    assert b.recoverable()
+                    au.reset_single_launch_status(torch.device(DEV))
+                    yb = b.decode_step(qb, kb, vb, p, input_ids=ids)  # the SAME position again
+                    torch.cuda.synchronize()
+                assert torch.equal(ya, yb), f"token {t}: y differs (attempt {attempt}, {provoked} faults)"
+                for (na, ta), (nb, tb) in zip(a.named_buffers(), b.named_buffers()):
+                    assert torch.equal(ta, tb), f"token {t}: {na} differs (attempt {attempt}, {provoked} faults)"
+            side.synchronize()
+            if provoked:
+                break
+    finally:
+        _abi.lib()["cc_decode_step_set_l2_handoff"](1)
+    assert provoked, "the co-tenant kernel did not provoke a hand-off timeout in six runs: the test did not test anything"
+    assert au.single_launch_status(torch.device(DEV)) == 0
+
+
+@pytest.mark.parametrize("strategy", ["heavy_hitter", "recent_global"])
+def test_several_tiles_co_tenant_fault_is_recovered(strategy):
+    """The same REAL fault for the several-tiles-per-wave step (S = 8192: 64 workgroups of 4 waves per kv head, two tiles per wave —
+    the memory-order tail, recoverable since late r4): twin caches, a co-tenant before the fourth token of the second one, the
+    harness's recovery (clear the word, advance the epochs, the SAME position again); y and every buffer equal the twin's."""
+    import cold_compress_amd.attention_utils as au
+    from cold_compress_amd import _abi
+
+    H, HQ, S, D = 8, 32, 8192, 128
+    scratch = torch.zeros(64, dtype=torch.int32, device=DEV)
+    provoked = 0
+    try:
+        for attempt in range(6):
+            side = torch.cuda.Stream()
+            torch.manual_seed(71)
+            a, T = _mk(H, S, strategy=strategy)
+            torch.manual_seed(71)
+            b, _ = _mk(H, S, strategy=strategy)
+            gen = torch.Generator(device=DEV).manual_seed(72)
+            for t in range(7):
+                p = torch.tensor([T + t], dtype=torch.int32, device=DEV)
+                q = torch.randn(1, HQ, 1, D, device=DEV, generator=gen).to(torch.bfloat16)
+                k1 = torch.randn(1, H, 1, D, device=DEV, generator=gen).to(torch.bfloat16)
+                v1 = torch.randn(1, H, 1, D, device=DEV, generator=gen).to(torch.bfloat16)
+                ya = a.decode_step(q, k1, v1, p)
+                torch.cuda.synchronize()
+                if t == 3:
+                    rc = _abi.lib()["cc_debug_occupy"](232, 150 * 1024, 2_200_000, C.c_void_p(scratch.data_ptr()), C.c_void_p(side.cuda_stream))
+                    assert rc == 0
+                yb = b.decode_step(q, k1, v1, p)
+                torch.cuda.synchronize()
+                tries = 0
+                while au.single_launch_status(torch.device(DEV)) != 0:
+                    provoked += 1
+                    tries += 1
+                    assert tries <= 5, "the retry kept failing"
+                    au.reset_single_launch_status(torch.device(DEV))
+                    yb = b.decode_step(q, k1, v1, p)  # the SAME position again
+                    torch.cuda.synchronize()
+                assert torch.equal(ya, yb), f"token {t}: y differs (attempt {attempt}, {provoked} faults)"
+                for (na, ta), (nb, tb) in zip(a.named_buffers(), b.named_buffers()):
+                    assert torch.equal(ta, tb), f"token {t}: {na} differs (attempt {attempt}, {provoked} faults)"
+            side.synchronize()
+            if provoked:
+                break
+    finally:
+        _abi.lib()["cc_decode_step_set_l2_handoff"](1)
+    assert provoked, "the co-tenant kernel did not provoke a hand-off timeout in six runs: the test did not test anything"
     assert au.single_launch_status(torch.device(DEV)) == 0

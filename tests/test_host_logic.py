@@ -259,7 +259,7 @@ def test_recoverable_classification_and_key_row_shapes():
     for strategy in ("heavy_hitter", "recent_global", "full", "random"):
         kv = mk(strategy)
         assert kv.recoverable(), strategy
-        assert tuple(kv.next_key.shape)[0] == H and tuple(kv.step_commit.shape) == (H, 66) and int(kv.step_commit.max()) == -1
+        assert tuple(kv.next_key.shape)[0] == H and tuple(kv.step_commit.shape) == (H, 68) and int(kv.step_commit.max()) == -1
     assert not mk("heavy_hitter", history_window_size=8).recoverable()  # the ring step carries no commit words
     assert mk("l2").recoverable()  # (r4: per-workgroup commit words; the norm maximum is republished by every workgroup on a retry)
     rnd = mk("random")

@@ -398,7 +398,7 @@ def _pipeline_replay(oracle, c, f, T, g, w, strategy, entry):
     H, S, D = c.H, c.S, c.D
     nk = int(o.fns()["cc_hh_next_key_slots"](S))
     key = np.full((H, nk), ~np.uint64(0), np.uint64)
-    commit = np.full((H, 66), -1, np.int32)  # (include/coldcompress.h: insert word, its position, one word per workgroup)
+    commit = np.full((H, 68), -1, np.int32)  # (include/coldcompress.h: insert word, its position, one word per workgroup, the hybrid step's two)
     steps = f["steps"]
     rand = [f["rand_u"][t].numpy().astype(np.float32).copy() for t in range(steps)] if strategy == "random" else None
     p0 = _i32(T)
