@@ -303,7 +303,8 @@ void cc_decode_step_set_single_launch(int32_t enabled);
  * plus `step_commit`, int32 [H, cc_decode_step_commit_stride()] on the device, all -1 = nothing committed (reset it whenever
  * positions restart).  ref: the reference has no hand-off to time out (cache.py:725-765, 716-722); this is what makes ours safe.
  * Words of kv head h: [0] = (slot << 1) | was_empty of the slot position [1]'s insert went to (-1: none), [2 + split] = the last
- * position whose step workgroup `split` of the head has committed.  Single-launch form (early (m, l) hand-off):
+ * position whose step workgroup `split` of the head has committed.  Single-launch form (early (m, l) hand-off; since late r4 also
+ * the several-tiles-per-wave form, whose tail keeps the memory order — one gather — and commits EVERYTHING, y included, behind it):
  *   - a launch that finds the status word set returns at once (a step of this token failed: nothing is built on its output);
  *   - a workgroup that gives up waiting sets the status word and its head's fail word; a workgroup that reads the fail word with
  *     its last gather commits nothing; one that does not commits ITS part — its slots' history, its next-eviction keys, its word
