@@ -552,7 +552,12 @@ __global__ __launch_bounds__(256, 2) void prefill_flash_kernel(MArgs a) {
       float mx = x[0];
 #pragma unroll
       for (int e = 1; e < 16; e++) mx = fmaxf(mx, x[e]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32, CC_WAVE));  // the row's maximum over the tile's 32 keys (both half-wave lanes hold it)
+      {  // the row's maximum over the tile's 32 keys (both half-wave lanes hold it): one v_permlane32_swap — swap(x, x) hands back
+         // {ours, the partner's} in some order, and the maximum is symmetric (a ds_bpermute round trip per tile before: found in the ISA)
+        const unsigned u = __builtin_bit_cast(unsigned, mx);
+        auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+        mx = fmaxf(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1]));
+      }
       // lazy reference maximum: raised only when the tile's maximum leaves it more than kLazy behind (or at the first live tile)
       const bool raise = mx > m_ref + kLazy || (m_ref == -INFINITY && mx > -INFINITY);
       const float m_new = raise ? mx : m_ref;
