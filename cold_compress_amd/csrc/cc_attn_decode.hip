@@ -40,6 +40,9 @@
 #ifndef CC_V_ALLLANES
 #define CC_V_ALLLANES 1 // the several-tiles-per-wave steps run the per-slot state pass on all 64 lanes (like the hybrid tail), not on 16 per tile
 #endif
+#ifndef CC_V_WORDSFIRST
+#define CC_V_WORDSFIRST 1  // the step's words (epoch, position, status, commit words) are requested at the top of the kernel
+#endif
 #ifndef CC_V_MLW
 #define CC_V_MLW 1      // the final (M, L) fold runs on the workgroup's LAST waves (idle during the partial-O publish of the first ones)
 #endif
@@ -704,6 +707,13 @@ struct IntC {
 // routed to a FULL instantiation (bf16, four query heads per kv head) or to the two-launch step.
 template <typename T, int RT, int NW, bool L2, bool ONE = false, bool HYB = false, int QB = 0, int NSUB = 1, int NT = 1, bool FULL = !ONE, bool XL2 = false>
 __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_split_mfma_kernel(SplitArgs a) {
+  // FULL (measurement instantiation): the workgroup's first instruction, on both clocks — the phases of cc_decode_step_trace count
+  // from HERE (late r4; they used to count from behind the issue of the first K rows, ~0.8 us later)
+  unsigned long long tr_entry = 0, rt_entry = 0;
+  if constexpr (FULL) {
+    tr_entry = __builtin_amdgcn_s_memtime();
+    rt_entry = __builtin_amdgcn_s_memrealtime();  // 100 MHz, one clock for the whole device (s_memtime is per XCD)
+  }
   static_assert(!(HYB && L2), "the hybrid decision rides the plain streaming pass or the single-launch step");
   static_assert(QB == 0 || (QB == 8 && !L2 && !HYB), "fused quantised cache: 8 bits, heavy hitter / recent_global / random");
   static_assert(NSUB == 1 || (NSUB == 2 && !ONE), "two tiles per iteration: the two-launch streaming pass only");
@@ -954,6 +964,17 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
       }
     }
   };
+#if CC_V_WORDSFIRST
+  if constexpr (DMA) {
+    // the step's wave-uniform words are requested AHEAD of the first DMA load: behind it they could no longer travel as scalar
+    // loads (the compiler must assume the DMA writes memory they read) and would become vector loads with a wait for the whole tile.
+    // FIRST of all (late r4): scalar loads return out of order, so every wait for kernel arguments further down is a wait for
+    // these words as well — requested here, at the top, they have arrived by then; requested right in front of the first K rows
+    // (r4) they made the K request wait a memory round trip for the commit words (found with a time stamp at the kernel's entry).
+    load_step_words();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#endif
   if (key_pending) {
     // KEY ROWS (late r3).  Every kv head reads — and at the end of the step rewrites — ITS OWN row, also under the head-constant
     // policies, whose rows all hold the same keys.  They used to share row 0, rewritten by kv head 0's waves once THEIR head's
@@ -983,12 +1004,12 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
       key_part = x < key_part ? x : key_part;
     }
   }
+#if !CC_V_WORDSFIRST
   if constexpr (DMA) {
-    // the step's wave-uniform words are requested AHEAD of the first DMA load: behind it they could no longer travel as scalar
-    // loads (the compiler must assume the DMA writes memory they read) and would become vector loads with a wait for the whole tile
     load_step_words();
     __builtin_amdgcn_sched_barrier(0);
   }
+#endif
   if constexpr (KEARLY) {
     issue_k(tregs[0], base);
     __builtin_amdgcn_sched_barrier(0);  // (keeps the scheduler from sinking them back to the rest of the tile)
@@ -1026,8 +1047,9 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
   unsigned long long tr0 = 0, tr1 = 0, tr2 = 0, tr3 = 0, tr4 = 0, rt0 = 0, rt1 = 0, trA = 0, trB = 0, trC = 0;
   if constexpr (ONE) {
     if (a.trace) {
-      tr0 = __builtin_amdgcn_s_memtime();
-      rt0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz, one clock for the whole device (s_memtime is per XCD)
+      tr3 = __builtin_amdgcn_s_memtime();  // the first K rows (and the key row, the step words) are requested
+      tr0 = tr_entry;
+      rt0 = rt_entry;
     }
   }
   // ALL (r4): with several tiles per wave the second half of the per-slot pass — history update, next-eviction score, key: ~70
@@ -1906,7 +1928,6 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
     // branch with loads of its own made the compiler put this wait at the join): the stragglers' K/V rows and everybody's granules
     // then queue behind 6 MB of polls per round that cannot succeed yet.
     if constexpr (!EML) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (EML: the first rounds of both gathers are not issued behind these stores)
-    if (a.trace) tr3 = __builtin_amdgcn_s_memtime();
     u32x4_t oq[NOG];
     // one round of loads of each kind (coherent: they bypass the L1 and stale L2 lines), and whether every granule of the round
     // carries this launch's tag

@@ -148,7 +148,7 @@ def main():
             out["launch_span_us"] = round(float(r2.max() - r0.min()), 2)
             out["gap_to_next_launch_us"] = round(us_per - float(r2.max() - r0.min()), 2)
             # phases of a workgroup (wave 0), microseconds since ITS start
-            cols = [("k_arrived", 11), ("scores_ready", 12), ("pv_issued", 13), ("merge_barrier_passed", 1), ("o_published", 2),
+            cols = [("k_requested", 3), ("k_arrived", 11), ("scores_ready", 12), ("pv_issued", 13), ("merge_barrier_passed", 1), ("o_published", 2),
                     ("ml_gathered", 4), ("ML_visible", 14), ("o_gathered", 15), ("end", 5)]
             ph = {}
             for nm, col in cols:
