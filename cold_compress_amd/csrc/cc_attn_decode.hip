@@ -43,6 +43,9 @@
 #ifndef CC_V_WORDSFIRST
 #define CC_V_WORDSFIRST 1  // the step's words (epoch, position, status, commit words) are requested at the top of the kernel
 #endif
+#ifndef CC_V_KPIN
+#define CC_V_KPIN 1  // the prologue's kernel arguments in one round of scalar loads, BEHIND the request of the step's words (0: left to the compiler, three rounds)
+#endif
 #ifndef CC_V_MLW
 #define CC_V_MLW 1      // the final (M, L) fold runs on the workgroup's LAST waves (idle during the partial-O publish of the first ones)
 #endif
@@ -973,6 +976,13 @@ __global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_spli
     // (r4) they made the K request wait a memory round trip for the commit words (found with a time stamp at the kernel's entry).
     load_step_words();
     __builtin_amdgcn_sched_barrier(0);
+#if CC_V_KPIN
+    // ... and behind them the kernel arguments the key row, the first K / V rows, q, the mask and the per-slot state need, in ONE
+    // round of scalar loads (left to the compiler they arrive in three, each behind the previous one's wait).  Only here: behind a
+    // volatile asm the compiler reads nothing from memory through scalar loads any more — the step's words are already on their way.
+    asm volatile("" ::"s"(a.next_key), "s"(a.nk), "s"(a.nk_read), "s"(a.k), "s"(a.v), "s"(a.q), "s"(a.mask), "s"(a.S), "s"(a.n_split),
+                 "s"(a.rows_per_split), "s"(a.num), "s"(a.denom), "s"(a.pos), "s"(a.Hp));
+#endif
   }
 #endif
   if (key_pending) {
