@@ -1,4 +1,4 @@
-"""ctypes binding of the C ABI declared in include/coldcompress.h.
+"""ctypes binding of the C ABI declared in include/coldcompress.h (+ the hooks of include/coldcompress_debug.h).
 
 The product path has NO CPU fallback: `lib()` raises if `libcoldcompress_hip.so` has not been built
 (`python -c "import __graft_entry__ as g; g.build()"`), and every wrapper raises `ColdCompressError` on a
@@ -76,6 +76,8 @@ SIGNATURES = {
                                           _f32, _vp, _vp, _sz, _vp, _i32]),
     "cc_decode_step_quant_single_launch": (_i32, [_i32, _i32, _i32, _i32, _i32, _i32]),
     "cc_decode_step_hybrid_single_launch": (_i32, [_i32, _i32, _i32, _i32, _i32]),
+    "cc_decode_step_l2_single_launch": (_i32, [_i32, _i32, _i32, _i32, _i32]),
+    "cc_decode_step_single_launch_enabled": (_i32, []),
     "cc_hh_next_key_slots": (_i32, [_i32]),
     "cc_decode_step_single_launch": (_i32, [_i32, _i32, _i32, _i32, _i32]),
     "cc_decode_step_status_offset": (_i32, []),
@@ -87,7 +89,11 @@ SIGNATURES = {
     "cc_decode_step_l2_handoff": (_i32, []),
     "cc_decode_step_heavy_hitter_rc": (C.c_int, [_view, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _sz,
                                                  _vp, _i32]),
+    "cc_decode_step_qkv_available": (_i32, [_i32, _i32, _i32, _i32, _i32, _i32]),
+    "cc_decode_step_qkv_rc": (C.c_int, [_view, _i32, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
+                                        C.c_uint64, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _sz, _vp]),
     "cc_debug_occupy": (C.c_int, [_i32, _i32, _i32, _vp, _vp]),
+    "cc_debug_qkv_trace": (None, [_vp]),
     "cc_decode_step_stream_floor": (C.c_int, [_view, _i32, _vp, _vp]),
     "cc_decode_step_stream_floor_geom": (C.c_int, [_view, _i32, _i32, _vp, _vp]),
     "cc_rg_next_key_init": (C.c_int, [_view, _vp, _i32, _vp, _vp]),
@@ -154,7 +160,8 @@ SIGNATURES = {
 # entry points that only the device library has (no `_cpu` twin)
 DEVICE_ONLY = {"cc_error_string", "cc_device_info", "cc_decode_step_single_launch", "cc_decode_step_status_offset",
                "cc_decode_step_trace", "cc_decode_step_set_single_launch", "cc_decode_step_set_wide", "cc_decode_step_probe_xcd", "cc_decode_step_commit_stride", "cc_decode_step_l2_rc", "cc_decode_step_quant_rc", "cc_decode_step_set_l2_handoff", "cc_decode_step_l2_handoff", "cc_decode_step_stream_floor", "cc_decode_step_stream_floor_geom", "cc_debug_occupy", "cc_decode_step_quant_single_launch",
-               "cc_decode_step_hybrid_single_launch",
+               "cc_decode_step_hybrid_single_launch", "cc_decode_step_l2_single_launch", "cc_decode_step_single_launch_enabled",
+               "cc_decode_step_qkv_available", "cc_debug_qkv_trace",
                "cc_kv_requant_batch",  # (its oracle is the per-cache twin of cc_kv_requant_pair)
                # inter-GPU transport: no CPU twin (the oracle of the all-reduce is torch.distributed's)
                "cc_allreduce_handle_bytes", "cc_allreduce_create", "cc_allreduce_export", "cc_allreduce_connect", "cc_allreduce_sum",
@@ -197,14 +204,15 @@ def lib():
         v = _FNS["cc_abi_version"]()
         if v != 1:
             raise ColdCompressError(f"ABI version mismatch: library {v}, python 1")
-        probe_device()
+        # (no device probe here — ADVICE r4: loading the library must not allocate or launch on whatever device happens to be current,
+        #  possibly before a TP rank has selected its own; the probe runs when a decode workspace is created: attention_utils._workspace)
     return _FNS
 
 
 def probe_device():
     """Observe the current device's block -> XCD dispatch order once (cc_decode_step_probe_xcd: synchronous, outside capture): where
     it is verified, caches with a multiple of 8 kv heads run their single-tile step with the L2-resident hand-off
-    (include/coldcompress.h).  No GPU: nothing happens.  Called when the library is loaded and when a decode workspace is created."""
+    (include/coldcompress.h).  No GPU: nothing happens.  Called when a decode workspace is created on a device (attention_utils._workspace)."""
     if _FNS is None:
         return 0
     try:

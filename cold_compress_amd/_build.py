@@ -14,13 +14,14 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(CSRC, "libcoldcompress_hip.so")
-SOURCES = ["cc_api.hip", "cc_evict.hip", "cc_attn_decode.hip", "cc_compact.hip", "cc_attn_prefill.hip", "cc_glue.hip",
+SOURCES = ["cc_api.hip", "cc_evict.hip", "cc_attn_decode.hip", "cc_attn_decode_qkv.hip", "cc_compact.hip", "cc_attn_prefill.hip", "cc_glue.hip",
            "cc_hybrid.hip", "cc_attn_prefill_mfma.hip", "cc_quant.hip", "cc_gemv.hip", "cc_allreduce.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 # Per-file extras.  cc_attn_decode: keep the matrix-core accumulators in architectural VGPRs (gfx950 has one unified register
 # file) — the streaming pass rescales its 32 accumulators with VALU multiplies whenever the running maximum moves, and with the
 # accumulators parked in AGPRs that costs 68 v_accvgpr_read / _write per tile, a sixth of the loop's instructions.
-EXTRA_FLAGS = {"cc_attn_decode.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+EXTRA_FLAGS = {"cc_attn_decode.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+               "cc_attn_decode_qkv.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def _hipcc():
@@ -34,7 +35,11 @@ def _stale(obj, src):
     if not os.path.exists(obj):
         return True
     t = os.path.getmtime(obj)
-    deps = [src, os.path.join(CSRC, "cc_common.h"), os.path.join(CSRC, "cc_wacc.h"), os.path.join(HERE, "..", "include", "coldcompress.h"), __file__]
+    inc = os.path.join(HERE, "..", "include")
+    deps = [src, os.path.join(CSRC, "cc_common.h"), os.path.join(CSRC, "cc_wacc.h"), os.path.join(CSRC, "cc_gemv_core.h"),
+            os.path.join(inc, "coldcompress.h"), os.path.join(inc, "coldcompress_debug.h"), __file__]
+    if "cc_attn_decode" in os.path.basename(src):  # the two translation units that instantiate the step kernels
+        deps += [os.path.join(CSRC, "cc_attn_decode_kernels.h"), os.path.join(CSRC, "cc_attn_decode_qkv.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

@@ -421,6 +421,29 @@ def step_committed(kv, position, HQ=None):
     return bool(used.any()) and bool((w[used] == int(position)).all()) and bool(used.any(dim=1).all())
 
 
+def step_is_recoverable(cache, HQ):
+    """`cache.recoverable()` AND the decode step of this cache, for `HQ` query heads on this device, actually takes the form that
+    honours the status / commit words of the recoverable hand-off: the single-launch form.  The two-launch and three-call forms
+    ignore both — they would step on garbage behind a failed launch and step AGAIN on the retry: the harness refuses
+    in-band recovery unless every layer answers True here."""
+    rec = getattr(cache, "recoverable", None)
+    if not callable(rec) or not rec():
+        return False
+    if not cache.k_cache.is_cuda or getattr(cache, "single_launch", True) is False or not cache.supports_fused_step():
+        return False
+    lib = _abi.lib()
+    if not lib["cc_decode_step_single_launch_enabled"]():
+        return False
+    args = (int(HQ), cache.n_heads, cache.max_cache_length, cache.head_dim, _DT[cache.k_cache.dtype])
+    if type(cache).__name__ == "KVCacheHybrid":
+        return bool(lib["cc_decode_step_hybrid_single_launch"](*args))
+    if cache.fused_quant:
+        return bool(lib["cc_decode_step_quant_single_launch"](*args, 8))
+    if type(cache).__name__ == "KVCacheL2":
+        return bool(lib["cc_decode_step_l2_single_launch"](*args))
+    return bool(lib["cc_decode_step_single_launch"](*args))
+
+
 class KVCacheHeadConstant(KVCache):
     def __init__(self, max_batch_size, n_heads, head_dim, dtype=torch.bfloat16, **kwargs):
         super().__init__(max_batch_size, n_heads, head_dim, dtype, head_specific=False, **kwargs)
@@ -430,6 +453,45 @@ class KVCacheHeadSpecific(KVCache):
     def __init__(self, max_batch_size, n_heads, head_dim, dtype=torch.bfloat16, variable_length=False, **kwargs):
         super().__init__(max_batch_size, n_heads, head_dim, dtype, head_specific=True, variable_length=variable_length,
                          **kwargs)
+
+
+def _qkv_step_available(cache, HQ, K):
+    """The layer step can take the layer's QKV projection along (include/coldcompress.h, cc_decode_step_qkv_rc) for this cache,
+    `HQ` query heads and model dim `K` on this device."""
+    memo = cache.__dict__.setdefault("_qkv_ok", {})  # (asked once per layer and token by the eager decode loop)
+    key = (int(HQ), int(K), cache.k_cache.device)
+    if key not in memo:
+        memo[key] = bool(cache.k_cache.is_cuda and cache.k_cache.dtype in (torch.bfloat16, torch.float16) and not cache.fused_quant
+                         and not cache.quantize and _abi.lib()["cc_decode_step_qkv_available"](
+                             int(HQ), cache.n_heads, cache.max_cache_length, cache.head_dim, _DT[cache.k_cache.dtype], int(K)))
+    return memo[key]
+
+
+def _qkv_step(cache, policy, wqkv, bias, x, delta, norm_w, eps, h_out, freqs, input_pos, HQ, scale, qkv_out, num=None, denom=None,
+              counter=None, seed=0, g=0, w=0):
+    """One launch: RMSNorm(x + delta) -> wqkv (+ bias) -> RoPE -> update_kv + attention + update_state (ref: model.py:375-427)."""
+    from .attention_utils import _workspace
+    import math
+
+    p32 = cache._pos32(input_pos)
+    if not cache._next_valid:
+        cache.prepare_decode(p32)
+    D = cache.head_dim
+    N, K = wqkv.shape
+    assert N == (HQ + 2 * cache.n_heads) * D and x.numel() == K, "wqkv must be [(HQ + 2H) * D, dim] and x one token"
+    xc = x.contiguous()
+    dc = delta.contiguous() if delta is not None else None
+    fc = freqs.contiguous() if freqs is not None else None
+    y = torch.empty((1, HQ, 1, D), dtype=wqkv.dtype, device=wqkv.device)
+    code = _DT[cache.k_cache.dtype]
+    ws = _workspace(_abi.lib()["cc_decode_attn_workspace_bytes"](HQ, cache.n_heads, cache.max_cache_length, D, code), wqkv.device)
+    _abi.call("cc_decode_step_qkv_rc", cache._view(), policy, _ptr(wqkv), _ptr(bias) if bias is not None else None, _ptr(xc),
+              _ptr(dc) if dc is not None else None, _ptr(norm_w), float(eps), _ptr(h_out) if h_out is not None else None,
+              _ptr(fc) if fc is not None else None, int(K), _ptr(qkv_out) if qkv_out is not None else None, _ptr(p32),
+              _ptr(num) if num is not None else None, _ptr(denom) if denom is not None else None,
+              _ptr(counter) if counter is not None else None, None, int(seed), _ptr(cache.next_key), _ptr(cache.step_commit), int(g), int(w),
+              int(HQ), 1.0 / math.sqrt(D) if scale is None else float(scale), _ptr(y), _ptr(ws), ws.numel(), _stream())
+    return y
 
 
 class _RingFusedStep:
@@ -483,6 +545,16 @@ class _RingFusedStep:
                   _ptr(self.next_key), _ptr(self.step_commit), self._ring_sinks(), 0, HQ, scale, _ptr(y), _ptr(ws), ws.numel(),
                   _stream())
 
+    # ---- the step with the layer's QKV projection folded in (r5): recent_global / full, random with in-kernel draws
+    _qkv_policy = 2
+
+    def qkv_step_available(self, HQ, K):
+        return type(self)._pipeline_step is _RingFusedStep._pipeline_step and _qkv_step_available(self, HQ, K)
+
+    def decode_step_qkv(self, wqkv, bias, x, delta, norm_w, eps, h_out, freqs, input_pos, HQ, scale=None, qkv_out=None):
+        return _qkv_step(self, self._qkv_policy, wqkv, bias, x, delta, norm_w, eps, h_out, freqs, input_pos, HQ, scale, qkv_out,
+                         g=self._ring_sinks())
+
     def prepare_decode(self, input_pos):
         self._pipeline_init(self._pos32(input_pos))
         self._next_valid = True
@@ -535,14 +607,23 @@ class KVCacheRandom(_RingFusedStep, KVCacheHeadConstant):
     """ref: cache.py:505-524.  The reference draws torch.rand(S) per eviction — a backend-specific stream; `_rand` is the injection
     point tests use to replay the reference's draws (parity is defined given the vector).  In the fused pipeline the draw for
     position p + 1 is made during step p (one draw per step, same order as the reference), and when `_rand` is not overridden it
-    is made IN the kernels (cc_decode_step_random_rng: a stateless hash of (seed, position, slot), seeded from torch's CPU
-    generator when the pipeline starts) — no vector, no extra launch per step."""
+    is made IN the kernels (cc_decode_step_random_rng: a stateless hash of (seed, position, slot)) — no vector, no extra launch per
+    step.  The seed is drawn from torch's CPU generator when the pipeline is first seeded after construction or reset(): every
+    generation draws fresh eviction scores, like the reference's torch.rand per step (cache.py:521), and torch.manual_seed is honoured
+    per generation.  The steps carry the seed by value: a caller that captured them in a hipGraph must capture again when
+    `_graph_epoch` has moved (harness.GraphedDecoder does)."""
     relevant_kwargs = ["max_cache_length", "max_seq_length", "cache_bits", "global_tokens", "recent_window"]
 
     def __init__(self, max_batch_size, n_heads, head_dim, dtype=torch.bfloat16, **kwargs):
         super().__init__(max_batch_size, n_heads, head_dim, dtype, **kwargs)
         self._init_ring_pipeline()
         self._rng_seed = 0
+        self._graph_epoch = 0  # bumped whenever a value that captured steps carry BY VALUE (the seed) changes
+
+    def reset(self):
+        super().reset()
+        self._rng_seed = 0  # the next generation draws its own seed (ADVICE r4: one seed for the object's lifetime made every
+        # generation on the same model draw identical eviction scores at the same (position, slot))
 
     def _rand(self):
         return torch.rand(self.max_cache_length, device=self.k_cache.device)
@@ -555,13 +636,13 @@ class KVCacheRandom(_RingFusedStep, KVCacheHeadConstant):
 
     def _pipeline_init(self, p32):
         if self._in_kernel_rng():
-            # ONE seed per cache object, drawn from torch's CPU generator when the pipeline is first seeded (follows torch.manual_seed, not
-            # torch.cuda.manual_seed; no device sync) and kept: the steps carry it by value, so a hipGraph captured once replays the
-            # seed every later re-seed of the pipeline (a new generation on the same cache) also uses (a fresh seed per
-            # generation reached the init kernel only — the replayed steps kept the captured one).  The draws are a stateless hash of
-            # (seed, position, slot): the same cache object draws the same numbers at the same positions in every generation.
+            # one seed per generation: drawn from torch's CPU generator when the pipeline is first seeded after construction / reset()
+            # (follows torch.manual_seed, not torch.cuda.manual_seed; no device sync) and kept until the next reset().  The steps carry
+            # it by value — a hipGraph captured with the previous seed would replay THAT one while this init kernel scored with the new
+            # (ADVICE r3): `_graph_epoch` tells the holder of such a graph to capture again (harness.GraphedDecoder checks it).
             if not self._rng_seed:
                 self._rng_seed = int(torch.randint(1, 2 ** 62, (1,)).item())
+                self._graph_epoch += 1
             _abi.call("cc_random_next_key_init_rng", self._view(), _ptr(p32), self._rng_seed, int(self.global_tokens),
                       int(self.recent_window), _ptr(self.next_key), _stream())
             return
@@ -571,6 +652,15 @@ class KVCacheRandom(_RingFusedStep, KVCacheHeadConstant):
 
     def _fused_quant_policy(self):
         return 3
+
+    def qkv_step_available(self, HQ, K):
+        return self._in_kernel_rng() and _qkv_step_available(self, HQ, K)
+
+    def decode_step_qkv(self, wqkv, bias, x, delta, norm_w, eps, h_out, freqs, input_pos, HQ, scale=None, qkv_out=None):
+        if not self._next_valid:
+            self.prepare_decode(self._pos32(input_pos))  # (draws the seed)
+        return _qkv_step(self, 3, wqkv, bias, x, delta, norm_w, eps, h_out, freqs, input_pos, HQ, scale, qkv_out, seed=self._rng_seed,
+                         g=self.global_tokens, w=self.recent_window)
 
     def _pipeline_step(self, q, k, v, p32, HQ, scale, y, ws):
         if self._in_kernel_rng() and self.fused_quant:  # (r4: in-kernel draws for the uint8 images too: no vector, no torch.rand launch)
@@ -629,6 +719,9 @@ class KVCacheL2(_RingFusedStep, KVCacheHeadSpecific):
 
     def supports_fused_step(self):
         return self.k_cache.dtype in (torch.bfloat16, torch.float16) and self.head_dim == 128
+
+    def qkv_step_available(self, HQ, K):
+        return False  # (the l2 step keeps its own launch: its norm bookkeeping has no QKV instantiation)
 
     def _pipeline_init(self, p32):
         _abi.call("cc_l2_next_key_init", self._view(), _ptr(p32), _ptr(self.key_norm), int(self.global_tokens),
@@ -802,6 +895,16 @@ class KVCacheHeavyHitter(_TrackedWindowSums, KVCacheHeadSpecific):
                   _ptr(ws), ws.numel(), _stream(), phases)
         self._quant_pending = self.quantize
         return y
+
+    def qkv_step_available(self, HQ, K):
+        return self.single_launch and self.history_window_size == 1 and _qkv_step_available(self, HQ, K)
+
+    def decode_step_qkv(self, wqkv, bias, x, delta, norm_w, eps, h_out, freqs, input_pos, HQ, scale=None, qkv_out=None):
+        """decode_step with the layer's QKV projection folded into the launch (cc_decode_step_qkv_rc): same cache state, same y —
+        q / k / v are cc_gemv_fused's, bit for bit."""
+        return _qkv_step(self, 1, wqkv, bias, x, delta, norm_w, eps, h_out, freqs, input_pos, HQ, scale, qkv_out,
+                         num=self.attn_history_num, denom=self.attn_history_denom, counter=self.attn_counter, g=self.global_tokens,
+                         w=self.recent_window)
 
     def single_launch_active(self, HQ):
         """True when decode_step runs as ONE launch for `HQ` query heads on this device."""

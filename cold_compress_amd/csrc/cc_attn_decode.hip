@@ -23,2502 +23,10 @@
 #include "cc_common.h"
 #include "cc_wacc.h"
 
-// ---- A/B switches (tools/ab_variant.sh NAME "-DCC_V_...=0"): the defaults are what the product runs.  Round 4 measured each on one
-//      box against its absence (profiles/r04_ab_step_variants.md); the switches that lost (early partial-O polls, one key per
-//      workgroup, precomputed merge factors, bulk requests moved up, longer sleeps) are gone from the source (commit a08483f has them).
-#ifndef CC_V_PRO
-#define CC_V_PRO 1      // prologue diet: unconditional key-row loads, K rows requested ahead of the mask word
-#endif
-#ifndef CC_V_LDSDMA
-#define CC_V_LDSDMA 1   // K / V tiles land in the wave's LDS slabs directly (buffer_load ... lds): no staging registers, no ds_write
-#endif
-#ifndef CC_V_EMLMT
-#define CC_V_EMLMT 0    // 1: the several-tiles-per-wave steps take the early-(m, l) order too — MEASURED A LOSS (r4, one box: S = 8192 12.3 ->
-                        // 12.8 us, 18432 21.0 -> 21.75, 32768 32.8 -> 33.9): two gathers in series and one more barrier, and per-slot passes
-                        // of 1.5+ us that a 0.4 us partial-O round trip cannot hide; kept compilable for the record
-#endif
-#ifndef CC_V_ALLLANES
-#define CC_V_ALLLANES 1 // the several-tiles-per-wave steps run the per-slot state pass on all 64 lanes (like the hybrid tail), not on 16 per tile
-#endif
-#ifndef CC_V_WORDSFIRST
-#define CC_V_WORDSFIRST 1  // the step's words (epoch, position, status, commit words) are requested at the top of the kernel
-#endif
-#ifndef CC_V_KPIN
-#define CC_V_KPIN 1  // the prologue's kernel arguments in one round of scalar loads, BEHIND the request of the step's words (0: left to the compiler, three rounds)
-#endif
-#ifndef CC_V_MLW
-#define CC_V_MLW 1      // the final (M, L) fold runs on the workgroup's LAST waves (idle during the partial-O publish of the first ones)
-#endif
+#include "cc_attn_decode_kernels.h"
+#include "cc_attn_decode_qkv.h"
 
 namespace {
-
-// ---------------------------------------------------------------- cross-lane all-reduce helpers
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
-}
-
-// sum over an aligned group of W lanes (W power of two <= 64); every lane of the group gets the total
-template <int W>
-__device__ __forceinline__ float group_sum(float v) {
-  if (W >= 2) v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]  : lane ^ 1
-  if (W >= 4) v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]  : lane ^ 2
-  if (W >= 8) v += dpp_mov<0x141>(v);   // row_half_mirror      : pairs the two quads of each 8
-  if (W >= 16) v += dpp_mov<0x140>(v);  // row_mirror           : pairs the two halves of each 16
-  if (W >= 32) v += __shfl_xor(v, 16, CC_WAVE);
-  if (W >= 64) v += __shfl_xor(v, 32, CC_WAVE);
-  return v;
-}
-// Whole-wave reductions with a wave-UNIFORM (scalar) result: four DPP steps fold each row of 16 lanes, four
-// v_readlane pick up the row results.  No LDS crossbar (ds_bpermute) round trips: ~12 VALU ops instead of 6
-// dependent ~100-cycle shuffles.  Fixed combination order -> deterministic.
-__device__ __forceinline__ float wave_max_uniform(float v) {
-  v = fmaxf(v, dpp_mov<0xB1>(v));
-  v = fmaxf(v, dpp_mov<0x4E>(v));
-  v = fmaxf(v, dpp_mov<0x141>(v));
-  v = fmaxf(v, dpp_mov<0x140>(v));
-  const int u = __builtin_bit_cast(int, v);
-  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(u, 0));
-  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(u, 16));
-  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(u, 32));
-  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(u, 48));
-  return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
-}
-__device__ __forceinline__ float wave_sum_uniform(float v) {
-  v += dpp_mov<0xB1>(v);
-  v += dpp_mov<0x4E>(v);
-  v += dpp_mov<0x141>(v);
-  v += dpp_mov<0x140>(v);
-  const int u = __builtin_bit_cast(int, v);
-  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(u, 0));
-  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(u, 16));
-  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(u, 32));
-  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(u, 48));
-  return (r0 + r1) + (r2 + r3);
-}
-// N (4 or 8) consecutive floats of a 16-byte aligned LDS row, read in assembly with their own wait: the compiler guards any LDS
-// read it sees behind pending LDS-DMA loads with a wait for those (it cannot tell the row from the slabs they write).
-template <int N>
-__device__ __forceinline__ void lds_read_row_nowait(const float* row, float (&out)[N]) {
-  static_assert(N == 4 || N == 8, "one or two 16-byte reads");
-  typedef float f32x4_t __attribute__((ext_vector_type(4)));
-  const unsigned addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const float*)row;
-  f32x4_t a, b = {0.f, 0.f, 0.f, 0.f};
-  if constexpr (N == 8) {
-    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)" : "=&v"(a), "=&v"(b) : "v"(addr) : "memory");
-  } else {
-    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(a) : "v"(addr) : "memory");
-  }
-#pragma unroll
-  for (int i = 0; i < 4; i++) out[i] = a[i];
-  if constexpr (N == 8) {
-#pragma unroll
-    for (int i = 0; i < 4; i++) out[4 + i] = b[i];
-  }
-}
-template <int CTRL>
-__device__ __forceinline__ unsigned long long dpp_min_u64(unsigned long long v) {
-  const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(v & 0xffffffffull), CTRL, 0xf, 0xf, true);
-  const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), CTRL, 0xf, 0xf, true);
-  const unsigned long long o = ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
-  return o < v ? o : v;
-}
-__device__ __forceinline__ unsigned long long wave_min_u64_uniform(unsigned long long v) {
-  v = dpp_min_u64<0xB1>(v);
-  v = dpp_min_u64<0x4E>(v);
-  v = dpp_min_u64<0x141>(v);
-  v = dpp_min_u64<0x140>(v);
-  const int lo = (int)(unsigned)(v & 0xffffffffull), hi = (int)(unsigned)(v >> 32);
-  unsigned long long best = ~0ull;
-#pragma unroll
-  for (int row = 0; row < 4; row++) {
-    const unsigned long long x = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(hi, row * 16) << 32) |
-                                 (unsigned)__builtin_amdgcn_readlane(lo, row * 16);
-    best = x < best ? x : best;
-  }
-  return best;
-}
-// value held by lane ^ OFF for OFF in {16, 32}: one v_permlane{16,32}_swap (VALU; no LDS crossbar traffic).
-// swap(x, x) returns {rows a|a, rows b|b}: whichever differs from ours is the partner's value — but we only ever
-// need sum or max with the partner, both symmetric, so combine the two returned halves directly.
-template <int OFF, bool IS_MAX>
-__device__ __forceinline__ float xor_combine(float v) {
-  const unsigned u = __builtin_bit_cast(unsigned, v);
-  float a, b;
-  if (OFF == 16) {
-    auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-    a = __builtin_bit_cast(float, (unsigned)r[0]);
-    b = __builtin_bit_cast(float, (unsigned)r[1]);
-  } else {
-    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    a = __builtin_bit_cast(float, (unsigned)r[0]);
-    b = __builtin_bit_cast(float, (unsigned)r[1]);
-  }
-  return IS_MAX ? fmaxf(a, b) : a + b;
-}
-// sum over an aligned group of G lanes, G a WAVE-UNIFORM power of two <= 64: every lane of the group gets the total (xor
-// butterflies: DPP inside a row of 16, permlane swaps across rows — no LDS crossbar).  Fixed order -> deterministic.
-__device__ __forceinline__ float seg_sum(float v, int G) {
-  if (G >= 2) v += dpp_mov<0xB1>(v);
-  if (G >= 4) v += dpp_mov<0x4E>(v);
-  if (G >= 8) v += dpp_mov<0x141>(v);
-  if (G >= 16) v += dpp_mov<0x140>(v);
-  if (G >= 32) v = xor_combine<16, false>(v);
-  if (G >= 64) v = xor_combine<32, false>(v);
-  return v;
-}
-__device__ __forceinline__ float fast_exp(float x) {  // e^x via v_exp_f32 (2^x); exp(-inf) = 0
-  return __builtin_amdgcn_exp2f(x * 1.4426950408889634f);
-}
-// e^x for x <= 0 to about one ulp in seven instructions (the library expf is ~40 with a branch, and it sat on the
-// latency-critical tail of the step): x * log2(e) = t + r with t = fl(x * C_hi) and the residual r recovered by two fmas
-// (log2(e) = C_hi + C_lo), then 2^(t + r) = 2^t * (1 + r ln 2 + O(r^2)), |r| < 2^-18.  Used for the probabilities that
-// feed the float64 history — by the combine pass and the single-launch tail alike, so the two stay bit-identical.
-__device__ __forceinline__ float exp_nonpos(float x) {
-  x = fmaxf(x, -200.f);  // e^-200 = 0 in fp32; keeps -inf away from the residual (inf - inf)
-  const float t = x * 1.44269502162933349609f;
-  float r = fmaf(x, 1.44269502162933349609f, -t);
-  r = fmaf(x, 1.92596299112661746e-08f, r);
-  const float e = __builtin_amdgcn_exp2f(t);
-  return fmaf(e, r * 0.6931471805599453f, e);
-}
-
-// KVCacheHybrid (FastGen) in the fused two-launch step: what the per-head decision of cache.py:896-950 needs.  The
-// eviction CANDIDATE of a head (arg-min over its live slots, protections applied) is scored by the combine pass of the
-// previous step; whether the head appends, evicts that candidate or drops the token is decided here, at the top of the
-// streaming pass, from the head's policy, its count, the budget terms and the incoming token's punctuation flag.
-enum { HF_HH = 1, HF_WIN = 2, HF_PUNC = 4, HF_SPECIAL = 8, HF_FULL = 16 };
-struct HybridStep {
-  const int64_t* strategies;    // [H] policy index per head
-  const int32_t* table;         // [n_pol, 3]: flags, window slots, heavy-hitter slots
-  const uint8_t* special_mask;  // [H, S] or null
-  uint8_t* punc_mask;           // [H, S] or null
-  const int64_t* token_id;      // device int64[1] or null
-  const int64_t* punc_ids;      // [n_punc_ids] or null
-  int n_punc_ids;
-  const int32_t* num_special;   // device int[1] or null
-  int32_t* num_punc;            // device int[1] or null
-  int32_t* cts_next;            // [H] workspace: the head's count after this step's insert (committed by the combine pass)
-  int W;                        // history window of the ring (clamp of the denominator)
-  int n_pol;                    // rows of `table` (<= 21: the streaming pass fetches the whole table with one vector load)
-};
-
-struct SplitArgs {
-  const void* q;
-  const void* k;
-  const void* v;
-  const uint8_t* mask;
-  void* scores;    // [HQ, S] T
-  float* part_ml;  // [HQ, n_split, 2]
-  float* part_o;   // [HQ, n_split, D]
-  int S, R, n_split, rows_per_split;
-  float scale;
-  int abl;  // measurement-only ablation bits (phases >> 8): 1 = no score store, 2 = no epilogue, 4 = no mask
-  // ---- fused decode step (next_key != null): this step's insert is folded into the prologue.  The slot comes
-  //      from the partial arg-min keys the PREVIOUS step's combine pass (or cc_hh_next_key_init) left in
-  //      next_key[h][0..nk): their minimum is torch's arg-min.
-  const unsigned long long* next_key;  // [H][nk]
-  int nk;       // entries per key row (the row stride)
-  int nk_read;  // entries any writer may have left non-~0: all of them where the single-launch step can serve the shape,
-                // the first n_chunks otherwise (only the two-launch combine pass writes such rows)
-  const int32_t* input_pos;
-  const void* k_new;  // [H, D]
-  const void* v_new;
-  int32_t* pos;        // [H, S]
-  uint8_t* mask_w;     // [H, S]
-  int32_t* cache_cts;  // [Hc]
-  double* num;         // [H, S]
-  int32_t* denom;      // [H, S]
-  int H, Hc, Hp;  // Hp == 1: head-constant policy (one pos row shared by every kv head; the key rows are per kv head all the same — see KEY ROWS)
-  // ---- ring history folded into the combine pass (history_window_size W > 1): this launch publishes the ring column
-  //      of the step, *ring_counter % W, so that the combine launch may bump the counter without a reader racing it
-  const int64_t* ring_counter;
-  int* ring_col;
-  int ring_W;
-  // ---- single-launch hybrid step (ONE + HYB): the tracked ring state the combine pass would have updated (null: no head
-  //      runs a heavy-hitter policy); ring_col stays null, every workgroup derives the column from the counter itself
-  void* ring_num;     // [H, S, W] T
-  unsigned long long* ring_acc;  // tracked state (include/coldcompress.h): accumulators, tickets, column-major shadow
-  float* ring_wsum;   // [H, S]
-  // ---- l2 policy in the fused step (matrix-core kernel only): the inserted key's norm is recorded here, and every
-  //      wave publishes the maximum of key_norm over its slots (the evicted slot's old norm excluded), so that the
-  //      combine launch can form the global maximum of cache.py:602 without re-reading [H, S] norms per workgroup
-  void* key_norm;   // [H, S] T
-  float* l2_pmax;   // [H, n_split, NW]
-  float* l2_new;    // [H]
-  // ---- single-launch layer step (ONE): the combine pass folded into this launch.  Every workgroup publishes its
-  //      partial as self-validating 16-byte granules {tag, x, tag, y} (write-through stores), waits until the
-  //      n_split workgroups of its kv head have published, and then finishes ITS OWN 64 slots (probabilities, group
-  //      mean, history, next-eviction key) from the scores still in its registers, plus its share of y.
-  unsigned* one_hdr;  // [H] epoch words (tag = epoch + 1, bumped once per launch and head), then the spin-timeout word
-  void* one_ml;       // [H][n_split][RT] granules {tag, m, tag, l}
-  void* one_o;        // [H * RT][n_split][64] granules {tag, O[2p], tag, O[2p + 1]}
-  unsigned one_ml_bytes, one_o_bytes;
-  void* y;            // [HQ, D] T
-  void* attn_out;     // [H, S] T or null
-  int64_t* hh_counter;
-  int g, w;           // global_tokens, recent_window of the next-eviction score
-  int policy;         // 1 = heavy hitter (history in num / denom), 2 = recent_global / full, 3 = random (head-constant: no history)
-  const float* rand_next;  // policy 3: [S] uniform draws for position p + 1, or null: cc_rng_uniform(rng_seed, p + 1, slot)
-  unsigned long long rng_seed;
-  int yc_chunks;      // grid.x of the two-launch combine pass (unused)
-  unsigned long long* trace;  // measurement only (cc_decode_step_trace): [workgroup][16] time stamps and hardware ids
-  // ---- recoverable hand-off (r3; the early-(m, l) single-launch steps): step_commit[h] = the last position whose step is fully
-  //      committed for kv head h (-1 = none; null = the caller does not retry).  See "Recoverable hand-off" below.
-  int32_t* commit;
-  HybridStep hyb;     // HYB instantiation only
-  // ---- fused quantised cache (QB instantiation): k / v point at the uint8 images [H, S, D]; one (scale, minimum) pair per
-  //      (head, slot) row for K and one for V — dequantised in registers on the way to the LDS slabs
-  float* qparams;     // [H, S, 4]: k_scale, k_min, v_scale, v_min
-};
-
-template <typename T, int D, int RT, int NW, int U>
-__global__ __launch_bounds__(NW * 64) void decode_attn_split_kernel(SplitArgs a) {
-  if (a.ring_col && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0)
-    *a.ring_col = (int)(*a.ring_counter % a.ring_W);
-  constexpr int VEC = 16 / (int)sizeof(T);
-  constexpr int LPR = D / VEC;
-  static_assert(LPR >= 1 && LPR <= 64 && (LPR & (LPR - 1)) == 0, "head_dim must map to a power-of-two lane count");
-  constexpr int RPW = 64 / LPR;  // rows per wave-wide load
-  constexpr int NG = NW * RPW;  // row groups per workgroup
-  __shared__ float sm_m[NG][RT];
-  __shared__ float sm_l[NG][RT];
-  __shared__ __attribute__((aligned(16))) float sm_acc[NG][RT][D];
-
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int lr = lane / LPR, lc = lane % LPR;
-  const int split = blockIdx.x, h = blockIdx.y, q0 = h * a.R + blockIdx.z * RT;
-  const int S = a.S;
-  const int row_begin = split * a.rows_per_split;
-  const int row_end = min(S, row_begin + a.rows_per_split);
-  const T* kh = reinterpret_cast<const T*>(a.k) + (size_t)h * S * D + lc * VEC;
-  const T* vh = reinterpret_cast<const T*>(a.v) + (size_t)h * S * D + lc * VEC;
-  const bool has_mask = a.mask != nullptr && !(a.abl & 4);
-  const uint8_t* mh = has_mask ? a.mask + (size_t)h * S : reinterpret_cast<const uint8_t*>(a.k);
-  T* sc_out = reinterpret_cast<T*>(a.scores);
-
-  float m[RT], l[RT], acc[RT][VEC];
-#pragma unroll
-  for (int r = 0; r < RT; r++) {
-    m[r] = -INFINITY;
-    l[r] = 0.f;
-#pragma unroll
-    for (int e = 0; e < VEC; e++) acc[r][e] = 0.f;
-  }
-
-  // ---- Issue EVERY load of the first tile before anything waits: the dependent chain of this kernel is
-  //      kernel args -> {partial keys, q, mask, K, V all in flight} -> math, not args -> q -> K/V.  (An earlier
-  //      version converted q to fp32 first, which put a full L2 round trip in front of the K/V loads: -1 us.)
-  //      vmcnt retires in issue order, so the loads are issued in the order their results are consumed.
-  // fused insert: every wave reduces the head's partial arg-min keys itself (no LDS, no barrier)
-  int ins_idx = -1, ins_was_empty = 0;
-  bool key_pending = a.next_key != nullptr && !(a.abl & 128);
-  unsigned long long key_part = ~0ull;
-  if (key_pending && lane < a.nk_read) key_part = a.next_key[(size_t)h * a.nk + lane];
-  // q: [RT][D] of this query group, this lane's VEC-wide column slice (L2-resident after the first workgroups)
-  Vec16<T> qraw[RT];
-#pragma unroll
-  for (int r = 0; r < RT; r++) qraw[r].load(reinterpret_cast<const T*>(a.q) + (size_t)(q0 + r) * D + lc * VEC);
-
-  // Row group lr of wave `wave` owns the U CONSECUTIVE rows base + lr*U + [0, U): its mask bytes are one
-  // aligned 32-bit word, its scores one contiguous run, and its softmax state (m, l, acc) is private to the
-  // 16-lane group — no cross-group shuffles anywhere in the loop.
-  static_assert(U <= 4, "mask bytes of a row group are packed into one 32-bit word");
-  uint32_t mword = 0x01010101u;
-  Vec16<T> kk[U], vv[U];
-  auto issue_tile = [&](int base) {
-    const int row0 = base + lr * U;
-    mword = 0x01010101u;
-    if (has_mask) {
-      if (U == 4 && row0 + 3 < S && ((reinterpret_cast<uintptr_t>(mh) + (size_t)row0) & 3) == 0) {
-        mword = *reinterpret_cast<const uint32_t*>(mh + row0);  // the common case: one aligned word
-      } else {  // ragged tail / unaligned head offset: assemble from bytes
-        mword = 0;
-#pragma unroll
-        for (int u = 0; u < U; u++)
-          if (row0 + u < S) mword |= (uint32_t)mh[row0 + u] << (8 * u);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < U; u++) kk[u].load(kh + (size_t)(row0 + u < row_end ? row0 + u : row_end - 1) * D);
-#pragma unroll
-    for (int u = 0; u < U; u++) vv[u].load(vh + (size_t)(row0 + u < row_end ? row0 + u : row_end - 1) * D);
-  };
-  int base = row_begin + wave * (RPW * U);
-  bool more = base < row_end;
-  if (more) issue_tile(base);
-
-  float qf[RT][VEC];
-#pragma unroll
-  for (int r = 0; r < RT; r++) qraw[r].unpack(qf[r]);
-
-  while (more) {
-    const int row0 = base + lr * U;
-    // fused insert (cache.py:356-362, 460-490, 754-763): the row group that owns the chosen slot uses the new
-    // token's K/V instead of the stale cache row, writes them back, and one lane does the bookkeeping.  The new
-    // rows (and the position) are fetched inside this rare branch — one row group per kv head takes it — so
-    // they cost nothing on the streaming path; their latency hides behind the K/V loads already in flight.
-    if (key_pending) {  // wave-uniform; first iteration only
-      for (int i = lane + 64; i < a.nk_read; i += 64) {  // caches beyond 64 chunks (S > 8192)
-        const unsigned long long x = a.next_key[(size_t)h * a.nk + i];
-        key_part = x < key_part ? x : key_part;
-      }
-      const unsigned long long key = wave_min_u64_uniform(key_part);
-      ins_idx = (key == ~0ull) ? -1 : (int)((key & 0xffffffffull) >> 1);
-      if (a.abl & 64) ins_idx = -1;
-      ins_was_empty = (int)(key & 1ull);  // the winner's "slot was empty" bit travels with the key (cache.py:356-360)
-      key_pending = false;
-    }
-    if ((unsigned)(ins_idx - row0) < (unsigned)U) {
-      Vec16<T> kn, vn;
-      kn.load(reinterpret_cast<const T*>(a.k_new) + (size_t)h * D + lc * VEC);
-      vn.load(reinterpret_cast<const T*>(a.v_new) + (size_t)h * D + lc * VEC);
-      const int32_t p_now = *a.input_pos;
-#pragma unroll
-      for (int u = 0; u < U; u++)
-        if (row0 + u == ins_idx) {
-          kk[u].raw = kn.raw;
-          vv[u].raw = vn.raw;
-          mword |= 1u << (8 * u);
-        }
-      if (blockIdx.z == 0) {
-        const size_t slot = (size_t)h * S + ins_idx;
-        *reinterpret_cast<uint4*>(const_cast<T*>(kh) + (size_t)ins_idx * D) = kn.raw;
-        *reinterpret_cast<uint4*>(const_cast<T*>(vh) + (size_t)ins_idx * D) = vn.raw;
-        if (lc == 0) {  // stores only: nothing here waits on memory
-          if (a.Hp != 1 || h == 0) a.pos[(a.Hp == 1 ? 0 : (size_t)h * S) + ins_idx] = p_now;
-          a.mask_w[slot] = 1;
-          if (a.num != nullptr) {  // heavy hitter: cache.py:754-763
-            a.num[slot] = 0.0;
-            a.denom[slot] = 0;
-          }
-          if (ins_was_empty && (a.Hc == a.H || h == 0)) atomicAdd(&a.cache_cts[a.Hc == a.H ? h : 0], 1);
-        }
-      }
-    }
-
-    float s[RT][U];
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      float kf[VEC];
-      kk[u].unpack(kf);
-      const bool valid = (row0 + u < row_end) && (((mword >> (8 * u)) & 0xffu) != 0);
-#pragma unroll
-      for (int r = 0; r < RT; r++) {
-        float d = 0.f;
-#pragma unroll
-        for (int e = 0; e < VEC; e++) d = fmaf(qf[r][e], kf[e], d);
-        d = group_sum<LPR>(d);
-        // ref: attention_utils.py:37 (q@k^T -> dtype, * scale -> dtype), :42-43 (-inf bias where masked)
-        const float x = ElemTraits<T>::rnd(ElemTraits<T>::rnd(d) * a.scale);
-        s[r][u] = valid ? x : -INFINITY;
-      }
-    }
-    // ---- scores out: lane lc of each row group stores pair t = pass*LPR + lc  (t = r*U + u): one store
-    //      instruction per pass with every lane active, RPW*U contiguous elements per query head
-#pragma unroll
-    for (int pass = 0; pass * LPR < RT * U; pass++) {
-      const int t = pass * LPR + lc;
-      float val = 0.f;
-#pragma unroll
-      for (int r = 0; r < RT; r++)
-#pragma unroll
-        for (int u = 0; u < U; u++) val = (t == r * U + u) ? s[r][u] : val;
-      const int r = t / U, u = t - r * U;
-      const int row = row0 + u;
-      if (t < RT * U && row < row_end && !(a.abl & 1)) ElemTraits<T>::store(sc_out, (size_t)(q0 + r) * S + row, val);
-    }
-    // ---- online softmax, state private to the row group
-#pragma unroll
-    for (int r = 0; r < RT; r++) {
-      float mx = s[r][0];
-#pragma unroll
-      for (int u = 1; u < U; u++) mx = fmaxf(mx, s[r][u]);
-      const float m_new = fmaxf(m[r], mx);
-      const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-      const float alpha = fast_exp(m[r] - m_use);
-      l[r] *= alpha;
-#pragma unroll
-      for (int e = 0; e < VEC; e++) acc[r][e] *= alpha;
-      m[r] = m_new;
-#pragma unroll
-      for (int u = 0; u < U; u++) s[r][u] = fast_exp(s[r][u] - m_use);
-    }
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      float vf[VEC];
-      vv[u].unpack(vf);
-#pragma unroll
-      for (int r = 0; r < RT; r++) {
-        const float p = s[r][u];
-        l[r] += p;
-#pragma unroll
-        for (int e = 0; e < VEC; e++) acc[r][e] = fmaf(p, vf[e], acc[r][e]);
-      }
-    }
-    base += NW * RPW * U;
-    more = base < row_end;
-    if (more) issue_tile(base);
-  }
-
-  if (a.abl & 2) {  // measurement only: keep the accumulators live, skip the merge
-    float x = 0.f;
-#pragma unroll
-    for (int r = 0; r < RT; r++) {
-      x += l[r] + m[r];
-#pragma unroll
-      for (int e = 0; e < VEC; e++) x += acc[r][e];
-    }
-    if (x == 1.2345f) a.part_ml[0] = x;
-    return;
-  }
-  // ---- row-group partials -> LDS.  Every lane writes its own VEC-wide slice as 16-byte pieces; piece e4 of
-  //      lane lc lands at column (e4/4)*(D/ (VEC/4)) ... i.e. [piece][lc][4]: consecutive lanes are 16 B apart,
-  //      so the ds_write_b128 lane groups are bank-conflict free.  (Measured: merging the row groups in
-  //      registers with v_permlane16/32_swap butterflies instead is SLOWER: 8.9 vs 7.75 us at S = 4096.)
-  constexpr int NP = VEC / 4 > 0 ? VEC / 4 : 1;  // 16-byte pieces per lane
-  const int grp = wave * RPW + lr;
-  if (lc == 0) {
-#pragma unroll
-    for (int r = 0; r < RT; r++) {
-      sm_m[grp][r] = m[r];
-      sm_l[grp][r] = l[r];
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < RT; r++)
-#pragma unroll
-    for (int pc = 0; pc < NP; pc++)
-      *reinterpret_cast<float4*>(&sm_acc[grp][r][(pc * LPR + lc) * 4]) =
-          make_float4(acc[r][pc * 4], acc[r][pc * 4 + 1], acc[r][pc * 4 + 2], acc[r][pc * 4 + 3]);
-  __syncthreads();
-  for (int t = threadIdx.x; t < RT * D; t += NW * 64) {
-    const int r = t / D, d = t - r * D;
-    // column d lives in lane d / VEC, piece (d % VEC) / 4, element d % 4
-    const int dl = (((d % VEC) / 4) * LPR + d / VEC) * 4 + (d & 3);
-    float M = -INFINITY;
-#pragma unroll
-    for (int g = 0; g < NG; g++) M = fmaxf(M, sm_m[g][r]);
-    const float Mu = (M == -INFINITY) ? 0.f : M;
-    float L = 0.f, O = 0.f;
-#pragma unroll
-    for (int g = 0; g < NG; g++) {  // fixed order: deterministic
-      const float f = fast_exp(sm_m[g][r] - Mu);
-      L = fmaf(sm_l[g][r], f, L);
-      O = fmaf(sm_acc[g][r][dl], f, O);
-    }
-    const size_t pj = (size_t)(q0 + r) * a.n_split + split;
-    a.part_o[pj * D + d] = O;
-    if (d == 0) {
-      a.part_ml[pj * 2 + 0] = M;
-      a.part_ml[pj * 2 + 1] = L;
-    }
-  }
-}
-
-// ================================================================================================================
-// Matrix-core variant of the streaming pass for 16-bit caches with head_dim 128 (Llama-3 / Qwen-2 class models).
-//
-// The VALU kernel above spends ~560 vector instructions per 16-row tile, ~40% of them on q.k (fma + bf16 unpack +
-// 16-lane DPP reductions) — with two waves per SIMD that is ~1.9 us of issue time at S = 4096, the same order as
-// the 3.3 us it takes HBM to deliver the tile.  Here q.k runs as FOUR v_mfma_f32_16x16x32 per tile:
-//   * global loads stay exactly as coalesced as before (16 lanes x 16 B = one whole 256-byte K row), but lane c of
-//     the row with tile-local index i fetches 16-byte chunk (c ^ i) of that row instead of chunk c;
-//   * every lane drops its chunk into its own wave's 4 KiB LDS slab at [i][c] (ds_write_b128, conflict free);
-//   * the A operand of step j is read back as [i = lane % 16][(4j + lane / 16) ^ i] — the XOR applied at LOAD time
-//     makes the 16 rows read by a quarter-wave land in 16 different bank groups (conflict free, no padding);
-//   * B = q^T (query head n of the group in column n, zero for n >= RT) lives in 16 VGPRs for the whole kernel;
-//   * C[i][n]: lane (g = lane / 16, n = lane % 16) gets the scores of ITS OWN row group's four rows against head n,
-//     so the mask word, the online-softmax state (one m, l per lane instead of RT) and the 8-byte score store all
-//     stay in the lane that already owns them; the four row groups of a wave share ONE running maximum per head
-//     (two v_permlane swaps per tile);
-//   * P.V runs on the matrix cores too, as O^T = V^T . P^T with v_mfma_f32_16x16x16: the QK output layout IS the
-//     B operand (four probabilities per lane, converted to 16 bit), and the A operand comes from the V tile staged
-//     row-major in a second wave-private LDS slab (coalesced ds_write_b128, chunks XOR-swizzled by 2*(row & 7)) and
-//     read back with the gfx950 LDS transpose read ds_read_b64_tr_b16 — lane i of a 16-lane group supplies the
-//     address of 4 columns of row i/4 and receives the 4 rows of column i (layout verified on the device with
-//     tools/probes/tr_read_probe.hip).  The accumulators then cover all 16 rows of the tile: one partial per WAVE,
-//     nothing to merge inside a wave, every accumulator of a lane belongs to one head (lane-local rescale).
-// ~120 vector instructions + 12 MFMAs per tile instead of ~560 vector instructions.  No workgroup barrier in the
-// loop: both LDS slabs are wave-private.
-typedef float f32x4_t __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
-template <typename T>
-struct Mfma16x16x32;
-template <>
-struct Mfma16x16x32<bf16_t> {
-  __device__ static __forceinline__ f32x4_t mma(uint4 a, uint4 b, f32x4_t c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
-  }
-};
-template <>
-struct Mfma16x16x32<f16_t> {
-  __device__ static __forceinline__ f32x4_t mma(uint4 a, uint4 b, f32x4_t c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
-  }
-};
-typedef short s16x4_t __attribute__((ext_vector_type(4)));
-typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
-// P.V step: v_mfma_f32_16x16x16 (K = 16 cache rows); A = V^T fragment from the LDS transpose read, B = P^T (the QK
-// MFMA's own output layout, converted to 16 bit)
-template <typename T>
-struct Mfma16x16x16;
-template <>
-struct Mfma16x16x16<bf16_t> {
-  __device__ static __forceinline__ f32x4_t mma(s16x4_t a, s16x4_t b, f32x4_t c) {
-    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
-  }
-  __device__ static __forceinline__ s16x4_t pack(const float* p) {
-    s16x4_t r;
-#pragma unroll
-    for (int i = 0; i < 4; i++) r[i] = (short)f32_to_bf16_bits(p[i]);
-    return r;
-  }
-};
-template <>
-struct Mfma16x16x16<f16_t> {
-  __device__ static __forceinline__ f32x4_t mma(s16x4_t a, s16x4_t b, f32x4_t c) {
-    return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4_t, a), __builtin_bit_cast(f16x4_t, b), c, 0, 0, 0);
-  }
-  __device__ static __forceinline__ s16x4_t pack(const float* p) {
-    s16x4_t r;
-#pragma unroll
-    for (int i = 0; i < 4; i++) r[i] = (short)f32_to_f16_bits(p[i]);
-    return r;
-  }
-};
-
-typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-constexpr unsigned kOneSpinMax = 1u << 18;  // bounded spin: a launch that is not fully resident gives up instead of hanging
-constexpr int kOneStatusWordDev = 1023;     // hdr[0 .. H): per-head epochs; hdr[1023]: timeout word (== kOneStatusWord)
-constexpr int kOneTicketWord = 1022;        // hybrid: heads whose workgroups have all published (the last one commits the per-step scalars)
-// Recoverable hand-off (the early-(m, l) steps).  A launch whose workgroups are not all resident cannot complete its hand-off:
-// the waits are bounded, and what a timed-out workgroup leaves behind must neither corrupt state nor be half a step.
-//   * hdr[kOneFailWord + h]: set to the launch's tag by any workgroup of kv head h that gives up.  Every workgroup reads it
-//     with each round of its LAST gather and commits nothing when it carries its tag: a head's step is committed by all of its
-//     workgroups or by none (the per-slot history, the next-eviction keys and y are stored only behind that check; a workgroup
-//     that arrives late finds the word set because the one that gave up wrote it a whole streaming phase earlier).
-//   * hdr[kOneStatusWordDev] != 0 (set with the fail word; cleared by the host): every later launch returns at once — nothing is
-//     built on the garbage a failed step's y became.  The host clears it AND advances every epoch word (so that no granule of the
-//     failed attempt can carry a later launch's tag), then simply runs the token again:
-//   * step_commit (r4: per WORKGROUP, kRcStride int32 per kv head): words [2 + split] = the last position whose step THIS workgroup has
-//     committed (its slots' history, its keys; split 0 also the head's count and the step counter); words [0], [1] = the slot this
-//     position's insert went to ((slot << 1) | was_empty) and that position, written by whoever decides the insert — BEFORE anything
-//     of the step can be committed (a workgroup commits behind the partial-O gather, i.e. after the inserting workgroup published).
-//     A retry of position p: a workgroup whose word says p recomputes (same scores, same partials: the hand-off needs them) and
-//     stores nothing; the others step; all of them take the insert slot from words [0], [1] when they carry p (committed
-//     workgroups have overwritten their part of the key row with the NEXT position's keys: its minimum is no longer this step's).
-//     Whatever the interleaving of give-ups and commits inside the failed launch — r3 left a window: a workgroup that completed its
-//     gather in the round trip in which a sibling gave up committed alone, and the retry added its probabilities twice — every slot's
-//     history is updated exactly once per position: the retry is idempotent per workgroup.
-//   * hybrid (late r4; its tail keeps the memory order — (m, l) and O travel together, ONE gather): the same words, the insert word
-//     = (slot << 2) | kind (append / evict / drop), plus [66] the head's count before the step and [67] the step's ring column:
-//     on a retry the whole per-head decision comes from the record (committed workgroups have rewritten their keys, the head's
-//     first workgroup may have committed the count, the LAST head to complete the step counter).  A workgroup that gives up in
-//     its gather, or reads the head's fail word with it, stores nothing of the step — no y, no ring column, no keys.
-constexpr int kOneFailWord = 64;
-constexpr int kRcStride = 68;                  // step_commit: int32 per kv head — [0] insert word, [1] its position, [2 + split] committed position,
-                                               // hybrid: [66] the head's count before the step, [67] the step's ring column
-// Granule regions are PER KV HEAD at fixed strides, whatever the shape: a location is only ever written by launches of its own
-// head, with tags from that head's epoch word — strictly growing per location even when caches of different head counts and
-// lengths share the workspace (shape-dependent offsets let a stale granule of head 4 sit where head 1 of another shape expects
-// its own, and the two heads' epochs need not be equal once launches with fewer heads have run).
-constexpr int kOneMlHead = 64 * 8 * 16;        // (m, l): 64 splits x up to 8 query heads x 16 B
-constexpr int kOneOHead = 8 * 64 * 64 * 16;    // O: up to 8 query heads x 64 splits x 64 pairs x 16 B
-constexpr int kOneNmHead = 64 * 16;            // l2: one norm-maximum granule per split
-constexpr int kOneHmBytes = 32 * 16;           // l2 (two-level exchange): one norm-maximum granule per kv HEAD, behind the per-split regions
-constexpr int kOneMaxHeads = 32;
-constexpr int kOneAuxCoherent = 17;         // sc0 sc1: write-through stores / loads that bypass the non-coherent L1 (and stale L2 lines)
-
-// ---- fused quantised cache: value = T(fma(q, scale, min)), one rounding; q in [0, 255]
-template <typename T>
-__device__ __forceinline__ uint32_t pack16x2(float lo, float hi) {
-  if constexpr (ElemTraits<T>::code == CC_DT_BF16) {
-    float ra, rb;
-    return bf16_round_pair(lo, hi, ra, rb);
-  } else {
-    return (uint32_t)f32_to_f16_bits(lo) | ((uint32_t)f32_to_f16_bits(hi) << 16);
-  }
-}
-template <typename T>
-__device__ __forceinline__ uint4 dequant8(uint2 raw, float2 par) {
-  const uint32_t w[2] = {raw.x, raw.y};
-  uint32_t o[4];
-#pragma unroll
-  for (int i = 0; i < 2; i++) {
-    float f0 = __builtin_fmaf((float)(w[i] & 0xffu), par.x, par.y);
-    float f1 = __builtin_fmaf((float)((w[i] >> 8) & 0xffu), par.x, par.y);
-    float f2 = __builtin_fmaf((float)((w[i] >> 16) & 0xffu), par.x, par.y);
-    float f3 = __builtin_fmaf((float)(w[i] >> 24), par.x, par.y);
-    if constexpr (ElemTraits<T>::code == CC_DT_F16) {  // fp32 first, then f16 (see cc_opaque_f32)
-      f0 = cc_opaque_f32(f0); f1 = cc_opaque_f32(f1); f2 = cc_opaque_f32(f2); f3 = cc_opaque_f32(f3);
-    }
-    o[2 * i] = pack16x2<T>(f0, f1);
-    o[2 * i + 1] = pack16x2<T>(f2, f3);
-  }
-  return make_uint4(o[0], o[1], o[2], o[3]);
-}
-// Quantise the 8 values of this lane on the grid of its 16-lane row group (one cache row of 128 values):
-// min / max over the row, range = max(max - min, 1e-6), scale = range / 255, q = clamp(rint((x - min) * (255 / range)), 0, 255)
-// (IEEE fp32 ops, no contraction)
-template <typename T>
-__device__ __forceinline__ uint2 quant8_row16(uint4 raw, float2& par) {
-  Vec16<T> v;
-  v.raw = raw;
-  float x[8];
-  v.unpack(x);
-  float mn = x[0], mx = x[0];
-#pragma unroll
-  for (int i = 1; i < 8; i++) {
-    mn = fminf(mn, x[i]);
-    mx = fmaxf(mx, x[i]);
-  }
-#pragma unroll
-  for (int off = 8; off > 0; off >>= 1) {
-    mn = fminf(mn, __shfl_xor(mn, off, 16));
-    mx = fmaxf(mx, __shfl_xor(mx, off, 16));
-  }
-  const float range = fmaxf(__fsub_rn(mx, mn), 1e-6f);
-  const float sc = __fdiv_rn(range, 255.f), inv = __fdiv_rn(255.f, range);  // two divides per ROW, none per element
-  uint32_t b[8];
-#pragma unroll
-  for (int i = 0; i < 8; i++) b[i] = (uint32_t)fminf(fmaxf(rintf(__fmul_rn(__fsub_rn(x[i], mn), inv)), 0.f), 255.f);
-  par = make_float2(sc, mn);
-  return make_uint2(b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24), b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24));
-}
-
-template <int V>
-struct IntC {
-  static constexpr int value = V;
-};
-
-// L2: the l2 policy's norm bookkeeping (its own instantiation: the others pay nothing).  ONE: the single-launch layer
-// step (heavy hitter, recent_global / full, random; with L2: l2; with HYB: the FastGen hybrid cache) — needs R == RT, at most
-// 64 workgroups per kv head, every workgroup of the grid co-resident.  HYB: the per-head decision of KVCacheHybrid at the top of
-// the pass (two-launch form: candidates, ring and counts follow in the combine pass; with ONE: in the tail, on all lanes).
-// QB = 8: the fused quantised cache (uint8 images + per-row (scale, minimum)), dequantised on the way to the LDS slabs.
-// NSUB = 2 (multi-tile splits only): two tiles per wave and iteration, each with its own staging registers — the loads of a
-// tile go out two half-iterations ahead of their use instead of one (twice the bytes in flight per wave).
-// NT (ONE only): tiles per wave the single-launch step keeps scores for — 1 for caches up to 64 x 64 slots per kv head (the
-// specialised form), 4 or 8 for longer ones (the wave loops over its tiles like the two-launch streaming pass, and its finish
-// loops over them for the per-slot pass).
-// FULL (ONE only; the two-launch pass always has them): the measurement hooks — time stamps (cc_decode_step_trace), ablation
-// bits of the phases word — and the optional group-mean output attn_out are in the code.  The LEAN instantiations (FULL = false)
-// are what the product runs: ~30 never-taken branches and their live ranges less is 0.25-0.5 us of the step (A/B on one box:
-// heavy hitter 10.65 -> 10.38 us, the fused uint8 step 10.35 -> 9.85); a call that wants a stamp, an ablation bit or attn_out is
-// routed to a FULL instantiation (bf16, four query heads per kv head) or to the two-launch step.
-template <typename T, int RT, int NW, bool L2, bool ONE = false, bool HYB = false, int QB = 0, int NSUB = 1, int NT = 1, bool FULL = !ONE, bool XL2 = false>
-__global__ __launch_bounds__(NW * 64, (ONE || QB) ? 2 : 1) void decode_attn_split_mfma_kernel(SplitArgs a) {
-  // FULL (measurement instantiation): the workgroup's first instruction, on both clocks — the phases of cc_decode_step_trace count
-  // from HERE (late r4; they used to count from behind the issue of the first K rows, ~0.8 us later)
-  unsigned long long tr_entry = 0, rt_entry = 0;
-  if constexpr (FULL) {
-    tr_entry = __builtin_amdgcn_s_memtime();
-    rt_entry = __builtin_amdgcn_s_memrealtime();  // 100 MHz, one clock for the whole device (s_memtime is per XCD)
-  }
-  static_assert(!(HYB && L2), "the hybrid decision rides the plain streaming pass or the single-launch step");
-  static_assert(QB == 0 || (QB == 8 && !L2 && !HYB), "fused quantised cache: 8 bits, heavy hitter / recent_global / random");
-  static_assert(NSUB == 1 || (NSUB == 2 && !ONE), "two tiles per iteration: the two-launch streaming pass only");
-  static_assert(NT == 1 || (ONE && !L2 && QB == 0 && NSUB == 1), "several tiles per wave in the single-launch step: 16-bit caches, heavy hitter / head-constant policies");
-  constexpr bool ONE1 = ONE && NT == 1;  // the single-tile form: no loop tail, no rescale, per-slot state requested ahead of the tile
-  // EML (r3): the workgroup's (m, l) pairs leave EARLY — right behind the scores, while the V rows are still in flight — so that
-  // the final (M, L) of the head, the probabilities, the history update and the next-eviction keys run in the shadow of the
-  // partial-O exchange; what is left behind the last O granule is the y fold alone
-  // (l2 included since late r3: its norm maxima leave with the (m, l) pairs.  r4: the several-tiles-per-wave steps too — their pairs
-  //  leave behind the LAST tile, ahead of the cross-wave merge: the finish's per-slot passes then run in the shadow of the partial-O
-  //  exchange instead of behind it, the state stores sit behind the last gather, and the step is recoverable like the single-tile one.)
-  constexpr bool EML = ONE && !HYB && (NT == 1 || CC_V_EMLMT != 0);
-#ifdef CC_NO_RC  // (A/B builds)
-  constexpr bool RC = false;
-#else
-  constexpr bool RC = EML;  // the recoverable hand-off (status / commit / fail words, state stores behind the last gather) rides the same kinds
-#endif
-  // NRC (late r4): the single-launch steps whose tail keeps the memory order (one gather: (m, l) and O travel together) — the
-  // hybrid step and the several-tiles-per-wave steps — are recoverable too when the caller passes commit words (a.commit): the
-  // whole commit (y, history / ring column / window sums, keys, counts) sits behind that gather.  HRC: the hybrid part of it (the
-  // recorded decision carries the kind, the head's count and the ring column as well).
-#ifdef CC_NO_HRC  // (A/B builds)
-  constexpr bool NRC = false;
-#else
-  constexpr bool NRC = ONE && !EML;
-#endif
-  constexpr bool HRC = NRC && HYB;
-  // L2X (r4): the l2 policy's norm maximum crosses kv heads (cache.py:602).  With the placement of XL2 it travels in two levels:
-  // the workgroups' maxima inside the head's XCD (plain granules, gathered with the (m, l) pairs by one wave), then ONE granule
-  // per kv head through memory (published by the head's split-0 workgroup, gathered by one wave per workgroup in the shadow of the
-  // partial-O exchange) — instead of every thread of every workgroup gathering all H x n_split maxima through memory ahead of the
-  // final (M, L).  max is associative: the same value, hence the same keys, bit for bit.
-  constexpr bool L2X = L2 && XL2 && EML;
-  static_assert(sizeof(T) == 2 && (RT == 1 || RT == 2 || RT == 4 || RT == 8), "16-bit caches, up to 8 query heads per pass (the MFMA has 16 columns)");
-  static_assert(!ONE || NW == 4 || (NW == 8 && NT == 1), "the single-launch step runs on 4-wave workgroups, or on ONE 8-wave workgroup per CU (single tile)");
-  constexpr int D = 128, VEC = 8, RPW = 4, U = 4;
-  static_assert(FULL || ONE, "the lean form exists for the single-launch step only");
-  static_assert(!XL2 || ONE, "the L2-resident hand-off belongs to the single-launch steps");
-  if constexpr (!FULL) {  // constants for the optimiser: every `if (a.trace)`, `a.abl & ...`, `if (a.attn_out)` below folds away
-    a.trace = nullptr;
-    a.abl = 0;
-    a.attn_out = nullptr;
-  }
-  if constexpr (ONE) a.ring_col = nullptr;  // (the single-launch steps derive the ring column themselves)
-  if (a.ring_col && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0)
-    *a.ring_col = (int)(*a.ring_counter % a.ring_W);
-  __shared__ __attribute__((aligned(16))) uint4 sm_k[NW][16][16];  // [wave][tile row i][slot]: 4 KiB per wave
-  __shared__ __attribute__((aligned(16))) uint4 sm_v[NW][16][16];  // [wave][tile row][chunk ^ 2*(row & 7)]: V tile, row major
-  __shared__ float sm_wm[NW][RT], sm_wl[NW][RT];  // the waves' softmax state per query head (merged across the workgroup)
-  __shared__ unsigned sm_mlcnt;                    // EML: waves whose (m, l) rows are in LDS — the LAST one to arrive publishes
-  __shared__ unsigned sm_fail;                     // EML: some wave of this workgroup gave up waiting (recoverable hand-off)
-  __shared__ __attribute__((aligned(16))) float sm_l2w[NW];  // ONE + L2: per-wave maxima of the norms this workgroup's slots hold AFTER the step's insert
-  __shared__ __attribute__((aligned(16))) T sm_l2sc[L2 ? NW : 1][L2 ? 128 : 8];  // l2: the new key, transposed for its norm (the slabs belong to the DMA loads)
-  __shared__ float sm_gmax;     // L2X: the norm maximum over all kv heads (NaN propagates)
-
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int g = lane >> 4, c = lane & 15;  // row group of the wave / 16-byte column chunk (and MFMA column n)
-  int split_ = blockIdx.x, h_ = blockIdx.y;
-  if constexpr (XL2) {
-    // XL2 — placement.  The dispatcher deals the blocks of a grid to the XCDs round-robin in block order: blocks b and b + 8 of a
-    // launch always share an XCD (cc_decode_step_probe_xcd observes exactly this relation on the device before this instantiation is
-    // ever chosen; WHICH XCD block 0 lands on depends on what was dispatched before — measured, r4: a table of absolute XCC ids
-    // taken by a probe launch does not hold for a later launch — so nothing here depends on it).  With kv head = b % H, H a multiple
-    // of 8, all workgroups of a kv head sit on ONE XCD, and the head's hand-off — its own (m, l) and partial-O granules — goes
-    // through that XCD's L2 (plain stores, sc1 polls) instead of through memory.  Heads interleave in dispatch order: every head
-    // needs ALL workgroups of the launch resident (the launcher checks the capacity).  Should the relation ever not hold for a
-    // launch (grids of two queues dealt alternately, say), a head's workgroups do not see each other's granules: the bounded wait
-    // ends the step as a recoverable failure and the host falls back to the memory hand-off (harness._recover_token).
-    const int b = blockIdx.x + gridDim.x * blockIdx.y;
-    const int Hg = (int)gridDim.y;
-    if ((Hg & (Hg - 1)) == 0) {  // (the usual case: no integer division in front of the first loads)
-      h_ = b & (Hg - 1);
-      split_ = b >> __builtin_ctz(Hg);
-    } else {
-      h_ = b % Hg;
-      split_ = b / Hg;
-    }
-  }
-  const int split = split_, h = h_, q0 = h * a.R + blockIdx.z * RT;
-  const int S = a.S;
-  const int row_begin = split * a.rows_per_split;
-  const int row_end = min(S, row_begin + a.rows_per_split);
-  const T* kb = reinterpret_cast<const T*>(a.k) + (size_t)h * S * D;
-  const T* vh = reinterpret_cast<const T*>(a.v) + (size_t)h * S * D + c * VEC;
-  // QB: byte images (element offsets are byte offsets) and the head's row parameters
-  const uint8_t* kqb = reinterpret_cast<const uint8_t*>(a.k) + (size_t)h * S * D;
-  const uint8_t* vqh = reinterpret_cast<const uint8_t*>(a.v) + (size_t)h * S * D + c * VEC;
-  const float2* qpar = reinterpret_cast<const float2*>(a.qparams) + (size_t)h * S * 2;  // [slot][0] = K pair, [1] = V pair
-  const bool has_mask = a.mask != nullptr && !(a.abl & 4);
-  const uint8_t* mh = has_mask ? a.mask + (size_t)h * S : reinterpret_cast<const uint8_t*>(a.k);
-  T* sc_out = reinterpret_cast<T*>(a.scores);
-
-  float m = -INFINITY, l = 0.f;  // softmax state of (wave, query head c) / (row group g, head c); meaningful for c < RT
-  // O^T accumulators of the P.V MFMAs: block b covers output columns 16b .. 16b+15; lane (g, n = c) holds
-  // O[head n][16b + 4g + t] in acc[b][t] — one partial per WAVE (all 16 rows of the tile), not per row group
-  f32x4_t acc[D / 16];
-#pragma unroll
-  for (int b = 0; b < D / 16; b++) acc[b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  // LDS transpose read (ds_read_b64_tr_b16): lane i of a 16-lane group supplies the address of 4 contiguous columns
-  // of row (i / 4); the group receives, lane n, the 4 ROWS of column n — the A fragment of v_mfma_16x16x16 without
-  // any register shuffles.  Row r of the V tile is stored with its 16-byte chunks XOR-swizzled by 2*(r & 7), which
-  // makes both the row-major ds_write_b128 and the transpose reads bank-conflict free.
-  const int tr_row = 4 * g + (c >> 2);
-  const int tr_sw = 2 * (tr_row & 7), tr_qh = (c >> 1) & 1, tr_half = c & 1;
-
-  // l2: this thread's first norm of the block is requested here and examined only after the streaming loop
-  const bool l2_here = L2 && blockIdx.z == 0;
-  const int kn_row0 = row_begin + (int)threadIdx.x;
-  float kn_first = -INFINITY;
-  if (L2 && !ONE && l2_here && kn_row0 < row_end) kn_first = ElemTraits<T>::load(reinterpret_cast<const T*>(a.key_norm) + (size_t)h * S, kn_row0);
-  // ---- every load of the first tile is issued before anything waits (partial keys, q, mask, K, V: use order)
-  int ins_idx = -1, ins_was_empty = 0;
-  int hyb_kind = 0, hyb_cts = 0;  // HYB: 0 = append at the end, 1 = evict the candidate, 2 = drop (slot S - 1, mask untouched)
-  bool hyb_punc = false;
-  bool key_pending = a.next_key != nullptr && !(a.abl & 128);
-  unsigned long long key_part = ~0ull;
-  unsigned long long key_more[3] = {~0ull, ~0ull, ~0ull};  // up to 256 entries are requested at once and folded when first used
-  // (late r2, measured on one box against the same build without it: these loads and the fold below cost the step 0.35 us — every
-  //  wave of a kv head reads the same 2 KB — but leaving both to wave 0 and handing the key to the others through LDS and a
-  //  barrier cost 0.2 us MORE: kept as is)
-  struct TileRegs {            // the staging registers of one tile in flight
-    uint32_t mword;
-    Vec16<T> kk[U], vv[U];
-    uint2 kq8[U], vq8[U];      // QB: the rows' bytes ...
-    float2 kpar[U], vpar[U];   // ... and their (scale, minimum)
-  };
-  TileRegs tregs[NSUB];
-  auto load_nt_u2 = [](const uint8_t* p) {
-    typedef unsigned int u32x2_nt __attribute__((ext_vector_type(2)));
-    const u32x2_nt v = __builtin_nontemporal_load(reinterpret_cast<const u32x2_nt*>(p));
-    return make_uint2(v.x, v.y);
-  };
-  auto issue_k_rows = [&](TileRegs& R, int base) {
-    const int row0 = base + g * U;
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      const int rr = row0 + u < row_end ? row0 + u : row_end - 1;
-      if constexpr (QB) {
-        R.kq8[u] = load_nt_u2(kqb + (size_t)rr * D + ((c ^ (4 * g + u)) & 15) * VEC);
-        R.kpar[u] = qpar[(size_t)rr * 2];
-      } else {
-        R.kk[u].load_nt(kb + (size_t)rr * D + ((c ^ (4 * g + u)) & 15) * VEC);
-      }
-    }
-  };
-  constexpr bool KFIRST = CC_V_PRO != 0 && ONE1 && !HYB;  // the K rows go out ahead of the (branchy) mask word
-  // LDS-DMA (r4 A/B): the tile's rows land in the wave's slabs directly — load u of a wave delivers tile rows 4u .. 4u + 3 (lane
-  // (g, c) asks for row 4u + g, the chunk that belongs in slot c of that row under the slab's swizzle) into one contiguous 1 KiB
-  // block (lane L -> byte 16 L); no staging registers, no ds_write, and the row OWNERSHIP of the scores (row group g: rows 4g .. 4g + 3,
-  // the MFMA's C layout) is untouched
-  constexpr bool DMA = CC_V_LDSDMA != 0 && ONE1 && QB == 0 && !HYB;
-  // (buffer_load ... lds, not global_load_lds: the compiler's wait-count pass treats the FLAT-encoded form as an access to both
-  //  memories and turns every later wait into vmcnt(0) lgkmcnt(0) while one is pending; the MUBUF form is counted exactly)
-  auto dma16 = [](__amdgpu_buffer_rsrc_t rs, int voff, void* lp) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lp, 16, voff, 0, 0, 2 /* nt */);
-  };
-  auto issue_k_dma = [&](int base) {
-    const auto krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(kb), 0, S * D * (int)sizeof(T), 0x00020000);
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      const int i = 4 * u + g, rr = base + i < row_end ? base + i : row_end - 1;
-      dma16(krs, rr * (D * (int)sizeof(T)) + ((c ^ i) & 15) * 16, &sm_k[wave][4 * u][0]);
-    }
-  };
-  auto issue_v_dma = [&](int base) {
-    const auto vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(reinterpret_cast<const T*>(a.v) + (size_t)h * S * D), 0, S * D * (int)sizeof(T), 0x00020000);
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      const int i = 4 * u + g, rr = base + i < row_end ? base + i : row_end - 1;
-      dma16(vrs, rr * (D * (int)sizeof(T)) + ((c ^ (2 * (i & 7))) & 15) * 16, &sm_v[wave][4 * u][0]);
-    }
-  };
-  auto issue_k = [&](TileRegs& R, int base) {  // mask word + the four K rows of this lane's row group (tile row i = 4g + u takes chunk c ^ i)
-    const int row0 = base + g * U;
-    if constexpr (DMA) {
-      issue_k_dma(base);
-      __builtin_amdgcn_sched_barrier(0);
-    } else
-    if constexpr (KFIRST) {
-      issue_k_rows(R, base);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    R.mword = 0x01010101u;
-    if (has_mask) {
-      if (row0 + 3 < S && ((reinterpret_cast<uintptr_t>(mh) + (size_t)row0) & 3) == 0) {
-        R.mword = *reinterpret_cast<const uint32_t*>(mh + row0);
-      } else {
-        R.mword = 0;
-#pragma unroll
-        for (int u = 0; u < U; u++)
-          if (row0 + u < S) R.mword |= (uint32_t)mh[row0 + u] << (8 * u);
-      }
-    }
-    if constexpr (!KFIRST && !DMA) issue_k_rows(R, base);
-  };
-  auto issue_v = [&](TileRegs& R, int base) {
-    if constexpr (DMA) {
-      issue_v_dma(base);
-      return;
-    }
-    const int row0 = base + g * U;
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      const int rr = row0 + u < row_end ? row0 + u : row_end - 1;
-      if constexpr (QB) {
-        R.vq8[u] = load_nt_u2(vqh + (size_t)rr * D);
-        R.vpar[u] = qpar[(size_t)rr * 2 + 1];
-      } else {
-        R.vv[u].load_nt(vh + (size_t)rr * D);
-      }
-    }
-  };
-  int base = row_begin + wave * (RPW * U);
-  bool more = base < row_end;
-  // 16-bit caches (late r3): the (first) tile's K rows are requested right BEHIND the key row — ahead of the per-slot state, the
-  // epoch / status words and q, ~150 instructions earlier than with the rest of the tile.  Same-box A/B, three runs each: heavy
-  // hitter 9.13 -> 8.92 us at S = 4096 (l2 10.5 -> 10.3, recent_global 8.98 -> 8.9, random 9.2 -> 9.1; S = 2560 and one kv head
-  // unchanged).  The neighbours of this placement all LOSE: K ahead of the key row +0.1 (every workgroup's first decision then
-  // queues behind 16 MB of rows), K and V both here +0.2, q moved up with K +0.1 (+0.5 at one kv head), the per-slot state moved
-  // behind V +0.45.
-#ifdef CC_NO_KEARLY  // (A/B builds)
-  constexpr bool KEARLY = false;
-#else
-  // (several tiles per wave — hybrid included: the first tile's K rows likewise; C4 hybrid at S = 18432 25.8 -> 25.1 us and
-  //  17.15 -> 16.7 at S = 9000 on two boxes, unchanged on a third; heavy hitter unchanged: its stream is bandwidth-bound.  NOT the
-  //  hybrid cache's single-tile step: 11.1 -> 11.6 us at S = 4096 with it — its decision operands want to be ahead of the rows)
-  constexpr bool KEARLY = ONE && QB == 0 && !(HYB && NT == 1);
-#endif
-  unsigned one_tag = 0;
-  int32_t one_pin = 0;
-  unsigned rc_status = 0;    // EML: the workspace's status word (a step failed since the host last looked: do nothing)
-  int32_t rc_commit = -2;    // EML: step_commit[h][2 + split]: the last position this workgroup committed
-  int32_t rc_insw = 0, rc_insp = -2;  // EML: step_commit[h][0 .. 1]: the insert slot word of position rc_insp
-  int32_t rc_cts = 0, rc_col = 0;     // hybrid: step_commit[h][66 .. 67]: the head's count before that step, its ring column
-  auto load_step_words = [&]() {
-    one_tag = a.one_hdr[h] + 1u;
-    one_pin = *a.input_pos;
-    if constexpr (RC || NRC) {
-      rc_status = a.one_hdr[kOneStatusWordDev];
-      if (a.commit) {
-        rc_commit = a.commit[(size_t)h * kRcStride + 2 + split];
-        rc_insw = a.commit[(size_t)h * kRcStride];
-        rc_insp = a.commit[(size_t)h * kRcStride + 1];
-        if constexpr (HRC) {
-          rc_cts = a.commit[(size_t)h * kRcStride + 66];
-          rc_col = a.commit[(size_t)h * kRcStride + 67];
-        }
-      }
-    }
-  };
-#if CC_V_WORDSFIRST
-  if constexpr (DMA) {
-    // the step's wave-uniform words are requested AHEAD of the first DMA load: behind it they could no longer travel as scalar
-    // loads (the compiler must assume the DMA writes memory they read) and would become vector loads with a wait for the whole tile.
-    // FIRST of all (late r4): scalar loads return out of order, so every wait for kernel arguments further down is a wait for
-    // these words as well — requested here, at the top, they have arrived by then; requested right in front of the first K rows
-    // (r4) they made the K request wait a memory round trip for the commit words (found with a time stamp at the kernel's entry).
-    load_step_words();
-    __builtin_amdgcn_sched_barrier(0);
-#if CC_V_KPIN
-    // ... and behind them the kernel arguments the key row, the first K / V rows, q, the mask and the per-slot state need, in ONE
-    // round of scalar loads (left to the compiler they arrive in three, each behind the previous one's wait).  Only here: behind a
-    // volatile asm the compiler reads nothing from memory through scalar loads any more — the step's words are already on their way.
-    asm volatile("" ::"s"(a.next_key), "s"(a.nk), "s"(a.nk_read), "s"(a.k), "s"(a.v), "s"(a.q), "s"(a.mask), "s"(a.S), "s"(a.n_split),
-                 "s"(a.rows_per_split), "s"(a.num), "s"(a.denom), "s"(a.pos), "s"(a.Hp));
-#endif
-  }
-#endif
-  if (key_pending) {
-    // KEY ROWS (late r3).  Every kv head reads — and at the end of the step rewrites — ITS OWN row, also under the head-constant
-    // policies, whose rows all hold the same keys.  They used to share row 0, rewritten by kv head 0's waves once THEIR head's
-    // workgroups had all published: nothing made a workgroup of another head read the row before that.  Found by the differential
-    // fuzz at 16 workgroups (recent_global, 8 kv heads, S = 101): on 3.6 % of the steps the workgroups of two kv heads — the two
-    // whose block ids fall on the same pair of XCDs, woken late on an otherwise idle chip — read the NEXT position's candidate
-    // and put their row into the wrong slot, silently.  A head's own row is safe by the argument that already covers the
-    // head-specific policies: its writers have gathered every workgroup of the head, i.e. every reader has published, i.e. read.
-    const unsigned long long* krow = a.next_key + (size_t)h * a.nk;
-    if constexpr (CC_V_PRO != 0 && ONE) {
-      // no branch around the loads: a lane past the row's live entries reads the row's last live entry again (the minimum does not
-      // change); four exec-mask branches less in front of the first K rows
-      const int last = a.nk_read - 1;
-      key_part = krow[lane < last ? lane : last];
-#pragma unroll
-      for (int j = 0; j < 3; j++)
-        if (64 * (j + 1) < a.nk_read) key_more[j] = krow[lane + 64 * (j + 1) < last ? lane + 64 * (j + 1) : last];  // (wave-uniform test)
-    } else {
-      if (lane < a.nk_read) key_part = krow[lane];
-#pragma unroll
-      for (int j = 0; j < 3; j++)
-        if (lane + 64 * (j + 1) < a.nk_read) key_more[j] = krow[lane + 64 * (j + 1)];
-    }
-    // rows beyond 256 live entries (two-launch step at S > 32768) — kept OUT of the streaming loop so that the waits there stay exact
-    for (int i = lane + 256; i < a.nk_read; i += 64) {
-      const unsigned long long x = a.next_key[(size_t)h * a.nk + i];
-      key_part = x < key_part ? x : key_part;
-    }
-  }
-#if !CC_V_WORDSFIRST
-  if constexpr (DMA) {
-    load_step_words();
-    __builtin_amdgcn_sched_barrier(0);
-  }
-#endif
-  if constexpr (KEARLY) {
-    issue_k(tregs[0], base);
-    __builtin_amdgcn_sched_barrier(0);  // (keeps the scheduler from sinking them back to the rest of the tile)
-  }
-  // (r4, with the DMA loads: the V rows right behind the K rows +0.4 us, the K rows ahead of the key row +0.35, both +0.8 — whatever
-  //  is requested behind the bulk (q, mask word, per-slot state) is usable only when the bulk has landed: loads return in order)
-  // HYB: everything the per-head decision needs besides the candidate key — the policy table (ALL rows: one vector load, the
-  // head's row is picked by a lane read once its policy index has arrived), the punctuation ids (one id per lane), the head's
-  // policy index and count, the budget terms, the incoming token — as FIRST-LEVEL loads issued here, ahead of q and the tile.
-  // (They used to be fetched behind the tile as a dependent chain strategies[h] -> table[pol]: two serial misses to HBM — every
-  // layer has its own few bytes of these, long evicted when its turn comes again — which the first tile's latency did not cover:
-  // the first K rows of EVERY workgroup arrived 2 us later than in the heavy-hitter step.)
-  int hy_tabv = 0, hy_pol = 0, hy_nsp = 0, hy_npu = 0;
-  long long hy_pidv = 0, hy_tok = 0, hy_ctr = 0;
-  int hy_flags = 0, hy_cts = 0, hy_budget = 0, hy_win = 0;
-  bool hy_punc = false;
-  if constexpr (HYB) {
-    if (lane < a.hyb.n_pol * 3) hy_tabv = a.hyb.table[lane];
-    const bool punc_on = a.hyb.token_id != nullptr && a.hyb.punc_ids != nullptr;
-    if (punc_on && lane < a.hyb.n_punc_ids) hy_pidv = a.hyb.punc_ids[lane];
-    hy_pol = (int)a.hyb.strategies[h];
-    hy_cts = a.cache_cts[h];
-    if (punc_on) hy_tok = *a.hyb.token_id;
-    if (a.hyb.num_special) hy_nsp = *a.hyb.num_special;
-    if (a.hyb.num_punc) hy_npu = *a.hyb.num_punc;
-    if (ONE && a.ring_num) hy_ctr = *a.ring_counter;
-    // more than 64 punctuation ids: the rest is compared here (a wait on the token id at the top of the kernel, on this path
-    // only) — kept out of the decision so that the in-order wait counts around the tile stay exact
-    if (punc_on)
-      for (int k2 = lane + 64; k2 < a.hyb.n_punc_ids; k2 += 64) hy_punc |= a.hyb.punc_ids[k2] == hy_tok;
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  // ONE: this lane's slot of the per-slot pass (lane c = t * LPR of row group g finishes row 4g + t of the wave's tile): its
-  // history and position are requested here, with everything else, and consumed after the hand-off
-  unsigned long long tr0 = 0, tr1 = 0, tr2 = 0, tr3 = 0, tr4 = 0, rt0 = 0, rt1 = 0, trA = 0, trB = 0, trC = 0;
-  if constexpr (ONE) {
-    if (a.trace) {
-      tr3 = __builtin_amdgcn_s_memtime();  // the first K rows (and the key row, the step words) are requested
-      tr0 = tr_entry;
-      rt0 = rt_entry;
-    }
-  }
-  // ALL (r4): with several tiles per wave the second half of the per-slot pass — history update, next-eviction score, key: ~70
-  // dependent instructions — runs on ALL 64 lanes (lane L takes the wave's slots j = L + 64 k, slot j = row (j & 15) of the wave's
-  // tile (j >> 4)) instead of on the 16 score-holding lanes of one tile after the other: ceil(NT / 4) passes instead of NT; the
-  // group-mean probabilities reach it through a wave-private LDS row, the per-slot state is requested per (lane, k) — coalesced
-  constexpr bool ALL = CC_V_ALLLANES != 0 && ONE && NT > 1 && !HYB;
-  constexpr int SN = ALL ? (NT * RPW * U + 63) / 64 : NT;  // per-slot state entries per lane
-  double one_numv[SN];
-  int32_t one_denv[SN], one_psv[SN];
-  float one_rndv[SN];
-#pragma unroll
-  for (int ti = 0; ti < SN; ti++) {
-    one_numv[ti] = 0.0;
-    one_denv[ti] = 0;
-    one_psv[ti] = 0;
-    one_rndv[ti] = 0.f;
-  }
-  auto all_slot = [&](int k) {  // ALL: the slot of entry k of this lane
-    const int j = lane + 64 * k;
-    return row_begin + wave * (RPW * U) + (j & (RPW * U - 1)) + (j / (RPW * U)) * (NW * RPW * U);
-  };
-  auto all_valid = [&](int k) { return lane + 64 * k < NT * RPW * U && all_slot(k) < row_end; };
-  constexpr int LPR = RT < 4 ? RT : 4;  // lanes per tile row in the per-slot pass; each computes KH = RT / LPR probabilities
-  constexpr int KH = RT / LPR;
-  // this lane's slot in tile ti of the wave: one_slot + ti * (NW * RPW * U)
-  const int one_slot = row_begin + wave * (RPW * U) + g * U + c / LPR;
-  const bool one_lane = ONE && c < U * LPR && (c % LPR) == 0;
-  const bool one_have = one_lane && one_slot < row_end;
-  // the history / position (/ uniform draw) of this lane's slot in every tile of the wave
-  auto load_slot_state = [&]() {
-    // A policy without a history reads a valid dummy (element 0 of the K cache) and ignores it — NO branch around these loads:
-    // the path that does not load re-zeroes the registers, the compiler's wait-count pass guards that write with a vmcnt(0), and
-    // with the K tile's DMA loads in flight every wave of the recent_global / full / random steps sat out its K rows here before it
-    // requested q and the V tile (found in the ISA, r4: those steps were SLOWER than the heavy hitter's)
-    const double* nump = a.num ? a.num : reinterpret_cast<const double*>(a.k);
-    const int32_t* denp = a.num ? a.denom : reinterpret_cast<const int32_t*>(a.k);
-    const size_t hist = a.num ? 1 : 0;
-#pragma unroll
-    for (int ti = 0; ti < SN; ti++) {
-      const int sl = ALL ? all_slot(ti) : one_slot + ti * (NW * RPW * U);
-      if (ALL ? all_valid(ti) : (one_lane && sl < row_end)) {
-        one_numv[ti] = nump[((size_t)h * S + sl) * hist];
-        one_denv[ti] = denp[((size_t)h * S + sl) * hist];
-        one_psv[ti] = a.pos[(a.Hp == 1 ? 0 : (size_t)h * S) + sl];
-        if (a.policy == 3 && a.rand_next) one_rndv[ti] = a.rand_next[sl];
-      }
-    }
-  };
-  // ONE + HYB: the ring pass of the finish runs on ALL lanes (the 192-bit window accumulators make it ~150 instructions per slot:
-  // on the 16 score-holding lanes of a tile it would be four times as long) — lane L takes the wave's slots j = L + 64 k, slot j =
-  // row (j & 15) of the wave's tile (j >> 4); the group-mean probabilities reach it through a wave-private LDS row
-  constexpr int HSL = (HYB && ONE) ? (NT * RPW * U + 63) / 64 : 1;
-  // (RAW load results: nothing is converted, tested or combined where the loads are issued — a conversion or a `!= 0` next to
-  //  its load makes the compiler wait for that load on the spot, and the state loads of a slot then go out one miss after the
-  //  other: 2.6 us to ISSUE them, measured, instead of 0.1)
-  uint16_t hy_old[HSL];
-  ulonglong2 hy_a01[HSL], hy_a23[HSL];
-  int32_t hy_den[HSL], hy_ps[HSL];
-  uint8_t hy_sp[HSL], hy_pu[HSL];  // special / punctuation slot
-#pragma unroll
-  for (int k = 0; k < HSL; k++) {
-    hy_old[k] = 0;
-    hy_a01[k] = make_ulonglong2(0, 0);
-    hy_a23[k] = make_ulonglong2(0, 0);
-    hy_den[k] = 0;
-    hy_ps[k] = 0;
-    hy_sp[k] = 0;
-    hy_pu[k] = 0;
-  }
-  int one_rcol = 0;  // ONE + HYB: the ring column of this step (every workgroup derives it from the counter: no launch ahead of this one)
-  auto hyb_slot = [&](int k) {
-    const int j = lane + 64 * k;
-    return row_begin + wave * (RPW * U) + (j & (RPW * U - 1)) + (j / (RPW * U)) * (NW * RPW * U);
-  };
-  auto hyb_valid = [&](int k) { return lane + 64 * k < NT * RPW * U && hyb_slot(k) < row_end; };
-  auto hyb_load_state = [&]() {
-    const size_t hs = (size_t)a.H * S;
-    // absent operands read a valid dummy (the cache mask / the positions) and are ignored where they would be used: no branch
-    // around any of these loads
-    const uint8_t* spm = a.hyb.special_mask ? a.hyb.special_mask : a.mask_w;
-    const uint8_t* pum = a.hyb.punc_mask ? a.hyb.punc_mask : a.mask_w;
-    const int32_t* dnp = a.ring_num ? a.denom : a.pos;
-    const uint16_t* shadow = a.ring_num ? reinterpret_cast<const uint16_t*>(a.ring_acc + hs * 4 + 2) + (size_t)one_rcol * hs
-                                        : reinterpret_cast<const uint16_t*>(a.pos);
-    const unsigned long long* accp = a.ring_num ? a.ring_acc : reinterpret_cast<const unsigned long long*>(a.k);
-#pragma unroll
-    for (int k = 0; k < HSL; k++)
-      if (hyb_valid(k)) {
-        const size_t i = (size_t)h * S + hyb_slot(k);
-        hy_old[k] = shadow[i];
-        hy_a01[k] = *reinterpret_cast<const ulonglong2*>(accp + i * 4);
-        hy_a23[k] = *reinterpret_cast<const ulonglong2*>(accp + i * 4 + 2);
-        hy_den[k] = dnp[i];
-        hy_ps[k] = a.pos[i];
-        hy_sp[k] = spm[i];
-        hy_pu[k] = pum[i];
-      }
-  };
-  // ONE + L2: the key norm of this lane's slot — its RAW 16 bits (converted where it is used: a conversion next to the load makes
-  // the compiler wait for the load on the spot, and behind the K tile's DMA loads that wait was vmcnt(0): every wave of the l2
-  // step sat out its K rows before it requested q, the new token's rows and the V tile — found in the ISA, r4) ...
-  uint16_t one_kn_raw = 0;
-  auto one_kn_f = [&]() {
-    T e;
-    e.x = one_kn_raw;
-    return ElemTraits<T>::load(&e, 0);
-  };
-  float l2_nv_lane = 0.f;   // ... and the inserted key's norm, in the lanes of the row group that inserted it
-  unsigned l2_ep[3] = {0u, 0u, 0u};  // ONE + L2: epoch words of the kv heads whose norm granules this thread gathers (read behind the tile's loads, below)
-  if constexpr (ONE) {
-    if constexpr (!DMA) load_step_words();
-    if constexpr (NRC) {
-      if (threadIdx.x == 0) sm_fail = 0u;  // (read behind the barriers of the epilogue and the finish)
-    }
-    // single tile: requested AHEAD of the K/V tile (measured: behind it the step is 0.3 us slower — the tile's in-order waits
-    // then end on these stragglers, and the workgroup leaves the streaming part later); several tiles: requested after the
-    // publish, in the shadow of the hand-off
-    if constexpr (NT == 1 && !HYB) {
-      load_slot_state();
-      if constexpr (L2)  // (unconditional: lanes without a slot read a valid neighbour and ignore it)
-        one_kn_raw = reinterpret_cast<const uint16_t*>(a.key_norm)[(size_t)h * S + (one_have ? one_slot : row_begin)];
-    }
-  }
-  float s_keep[NT][U];  // ONE: the wave's tiles of scores, kept for the per-slot pass
-#pragma unroll
-  for (int ti = 0; ti < NT; ti++)
-#pragma unroll
-    for (int t = 0; t < U; t++) s_keep[ti][t] = -INFINITY;
-  // QB: the incoming token's rows are requested AHEAD of the tile (chunk c of K and of V per lane, every row group alike), so that
-  // the inserting row group can quantise them while the tile is in flight — requested behind the tile, the in-order load counter
-  // would hold the ~150 instructions of min / max shuffles and roundings back until the K/V rows have arrived, and the whole kv
-  // head waits for its slowest workgroup.  (Quantising in EVERY wave ahead of the tile was tried: 512 workgroups of redundant
-  // work cost more than the one critical path saves — 12.2 vs 11.7 us at S = 4096.)
-  // The l2 policy does the same (late r2): its norm of the new key (eight more loads, a float64 square root) ran behind the tile's
-  // in-order wait, and the inserting workgroup of every head left the streaming part 2.7 us after the others — with every workgroup
-  // of the launch waiting for it (l2 step 13.5 -> 12.8 us).  The plain 16-bit caches keep the two loads behind the tile: requested
-  // ahead of it by all 2048 waves they cost MORE than the inserting wave gains (A/B on one box: heavy hitter 10.68 -> 10.83 us,
-  // recent_global 10.14 -> 10.60 — every wave of a kv head asks for the same four cache lines, one memory channel serves them one
-  // by one, and the tile's rows queue behind them in the in-order return).
-  constexpr bool AHEAD = QB != 0 || L2;  // the incoming token's rows are requested ahead of the tile
-  Vec16<T> qb_kn, qb_vn;
-  int32_t p_ins = 0;
-  qb_kn.raw = make_uint4(0, 0, 0, 0);
-  qb_vn.raw = make_uint4(0, 0, 0, 0);
-  if (AHEAD && a.k_new) {
-    qb_kn.load(reinterpret_cast<const T*>(a.k_new) + (size_t)h * D + c * VEC);
-    qb_vn.load(reinterpret_cast<const T*>(a.v_new) + (size_t)h * D + c * VEC);
-    p_ins = *a.input_pos;
-  }
-  unsigned hm_ep = 0;  // L2X: the epoch word of kv head `lane` (its head-maximum granule carries that tag)
-  if constexpr (L2X) {
-    hm_ep = a.one_hdr[lane < a.H ? lane : 0];  // (ahead of the tile and of anything this workgroup publishes, like l2_ep below)
-  } else
-  if constexpr (L2 && EML) {
-    // the epoch words of the kv heads whose norm granules this thread gathers — AHEAD of the tile here: this workgroup's first
-    // publish (its (m, l) pairs and norm maximum, right behind the scores) must not happen before these loads have completed
-    // (no head's word is bumped before every workgroup of the launch has published), and behind the tile they would make that
-    // publish wait for the V rows (loads return in order).  Heads by a reciprocal multiply (exact for e < 2^16: corrected once).
-    const float inv_ns = 1.0f / (float)a.n_split;
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-      const int e = (int)threadIdx.x + k * NW * 64;
-      int hh = (int)((float)e * inv_ns);
-      hh += ((hh + 1) * a.n_split <= e) ? 1 : 0;
-      hh -= (hh * a.n_split > e) ? 1 : 0;
-      if (e < a.H * a.n_split) l2_ep[k] = a.one_hdr[hh];
-    }
-  }
-  // B operand: lane (n = c, kb = g) of step j holds q[head n][8 * (4j + g) .. + 8]; columns n >= RT are zero
-  Vec16<T> qB[4];
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    qB[j].raw = make_uint4(0, 0, 0, 0);
-    if (c < RT) qB[j].load(reinterpret_cast<const T*>(a.q) + (size_t)(q0 + c) * D + (4 * j + g) * VEC);
-  }
-  // UNCONDITIONAL (rows past the split's end are clamped to its last row, a valid address): behind a branch, the compiler's
-  // wait-count bookkeeping merges "tile loads issued" with "none issued" and every later use of an EARLIER load (the partial
-  // keys, the incoming token's rows) becomes a wait for all loads — the tile included
-#pragma unroll
-  for (int sub = 0; sub < NSUB; sub++) {
-    if constexpr (!KEARLY) issue_k(tregs[sub], base + sub * NW * RPW * U);
-    if constexpr (QB) __builtin_amdgcn_sched_barrier(0);  // K's bytes and parameters go out BEFORE V's: the K stash waits for them only
-    issue_v(tregs[sub], base + sub * NW * RPW * U);
-    if constexpr (QB) __builtin_amdgcn_sched_barrier(0);
-  }
-  // ONE + L2: the epoch words of the kv heads whose norm granules this thread will gather.  Read HERE (behind the tile's loads: three integer divisions kept out of the way of the first K rows): every workgroup has read
-  // them before it publishes anything, and no head's epoch is bumped before its split-0 workgroup has gathered the granules of
-  // ALL workgroups of all heads — so none of these reads can see a bumped word.
-  if constexpr (ONE && L2 && !EML) {
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-      const int e = (int)threadIdx.x + k * NW * 64;
-      if (e < a.H * a.n_split) l2_ep[k] = a.one_hdr[e / a.n_split];
-    }
-  }
-  int qb_ins_u = -1;  // QB: tile row (of this lane's row group) that holds the inserted token — its K chunk is UNswizzled (chunk c)
-  if constexpr (EML) {
-    // the arrival counter of the early (m, l) hand-off starts at zero: one barrier HERE, behind the issue of every load of the
-    // tile (the waves of a workgroup reach it together; nothing waits for memory)
-    if (threadIdx.x == 0) {
-      sm_mlcnt = 0u;
-      sm_fail = 0u;
-    }
-    if constexpr (DMA) {
-      // a bare barrier: __syncthreads() is a workgroup-scope release fence, and with LDS-DMA loads in flight (LDS writes that count
-      // in vmcnt) the fence waits for the whole tile — here, right behind its issue
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    } else {
-      __syncthreads();
-    }
-    if (rc_status != 0u) return;  // a step of this token failed before this launch: leave everything as it is (the host retries)
-  }
-  if constexpr (NRC) {
-    // (HERE, behind the issue of the first tile's loads — at the top of the kernel the test waited for the step words, a cold
-    //  scalar round trip in front of every workgroup's first K rows: +1 us on the C4 step.  Nothing has been written yet.)
-    if (a.commit && rc_status != 0u) return;
-  }
-  const bool rc_replay = (EML || (NRC && a.commit != nullptr)) && rc_commit == one_pin;  // this WORKGROUP committed its part of this position's step already: it recomputes and stores nothing
-  // ONE: what this thread gathers in the hand-off — up to NOG partial-O granules of the output pairs this workgroup finishes (pair
-  // P = r * 64 + d / 2).  Two integer divisions by run-time values (~100 scalar and vector instructions): worked out HERE, with the
-  // tile in flight, and pinned — left where they are used, they sat between the merge barrier and the first look at the (m, l)
-  // pairs, on the path every workgroup of the head waits for (found in the ISA, r4).
-  constexpr int NOG = (RT * 64 + 64 + NW * 64 - 1) / (NW * 64);  // O granules per thread
-  int o_off[NOG], o_lds[NOG], o_use[NOG];
-  int ppw = 1, pair0 = 0, n_pairs = 0;
-  if constexpr (ONE) {
-    const int ns_ = a.n_split;
-    ppw = (RT * 64 + ns_ - 1) / ns_;      // output pairs finished per workgroup
-    const int n_items = ns_ * ppw;        // (split, pair) granules this workgroup reads
-    pair0 = split * ppw;
-    n_pairs = RT * 64 - pair0;
-    n_pairs = n_pairs < 0 ? 0 : (n_pairs > ppw ? ppw : n_pairs);
-#pragma unroll
-    for (int k = 0; k < NOG; k++) {
-      const int item = (int)threadIdx.x + k * NW * 64;
-      const int i = item / ppw, qq = item - i * ppw;
-      o_use[k] = (item < n_items && qq < n_pairs) ? 1 : 0;
-      const int P = o_use[k] ? pair0 + qq : 0;
-      o_off[k] = h * kOneOHead + (((P >> 6) * ns_ + (o_use[k] ? i : 0)) * 64 + (P & 63)) * 16;
-      o_lds[k] = (i * ppw + qq) * 2;
-      asm volatile("" : "+v"(o_off[k]), "+v"(o_lds[k]), "+v"(o_use[k]));
-    }
-    asm volatile("" : "+s"(ppw), "+s"(pair0), "+s"(n_pairs));
-  }
-
-  float pv_p[U];  // the tile's probabilities (unnormalised), between its two halves
-  auto tile_qk = [&](TileRegs& R, const int tbase, const int tbase_next, const bool more_next, auto ti_c) {
-    constexpr int TI = decltype(ti_c)::value;  // ONE: which of the wave's tiles (compile time: the scores stay in registers)
-    const int row0 = tbase + g * U;
-    // ONE: a wave owns exactly one tile (one_shape_ok: rows_per_split == one iteration's rows) — a compile-time fact, so that the
-    // next tile's address arithmetic, its loads, the loop's second body and the running-maximum rescale disappear from the code
-    if (key_pending) {  // wave-uniform; first tile only
-#pragma unroll
-      for (int j = 0; j < 3; j++) key_part = key_more[j] < key_part ? key_more[j] : key_part;
-      const unsigned long long key = wave_min_u64_uniform(key_part);
-      ins_idx = (key == ~0ull) ? -1 : (int)((key & 0xffffffffull) >> 1);
-      if (a.abl & 64) ins_idx = -1;
-      ins_was_empty = (int)(key & 1ull);
-      if constexpr (RC || (NRC && !HYB)) {
-        if (rc_insp == one_pin) {  // a retry: the slot the first attempt's insert went to (the key row may hold the next position's keys by now)
-          ins_idx = rc_insw >> 1;  // (arithmetic shift: -1 stays -1)
-          ins_was_empty = rc_insw & 1;
-        } else if (a.commit && split == 0 && threadIdx.x == 0) {  // recorded before anything of the step can be committed
-          a.commit[(size_t)h * kRcStride] = ins_idx < 0 ? -1 : ((ins_idx << 1) | ins_was_empty);
-          a.commit[(size_t)h * kRcStride + 1] = one_pin;
-        }
-      }
-      key_pending = false;
-      if constexpr (HYB) {  // ref: cache.py:896-950 _select_fill_idx, per head — operands requested at the top of the kernel (hy_*)
-        hy_flags = __shfl(hy_tabv, hy_pol * 3, CC_WAVE);
-        hy_win = __shfl(hy_tabv, hy_pol * 3 + 1, CC_WAVE);
-        const int hhs = __shfl(hy_tabv, hy_pol * 3 + 2, CC_WAVE);
-        if (a.hyb.token_id && a.hyb.punc_ids) {  // ref: cache.py:975 torch.isin(input_ids, punc_ids)
-          const bool f = hy_punc || (lane < a.hyb.n_punc_ids && hy_pidv == hy_tok);
-          hy_punc = __any(f) != 0;
-        }
-        hy_budget = a.g;  // ref: cache.py:912-925
-        if (hy_flags & HF_SPECIAL) hy_budget += hy_nsp;
-        if (hy_flags & HF_PUNC) hy_budget += hy_npu;
-        if (hy_flags & HF_WIN) hy_budget += hy_win;
-        if (hy_flags & HF_HH) hy_budget += hhs;
-        if constexpr (ONE) {
-          if (a.ring_num) {
-            const unsigned long long ctr = (unsigned long long)hy_ctr;
-            one_rcol = (ctr >> 32) == 0 ? (int)((unsigned)ctr % (unsigned)a.ring_W) : (int)(ctr % (unsigned long long)a.ring_W);
-          }
-        }
-        const int flags = hy_flags, cts = hy_cts;
-        hyb_punc = hy_punc;
-        const int end_idx = cts < S - 1 ? cts : S - 1;  // :897-899
-        hyb_cts = cts;
-        if (((flags & HF_PUNC) && hyb_punc) || (flags & HF_FULL)) {  // :905-909
-          ins_idx = end_idx;
-          hyb_kind = 0;
-        } else {
-          const int budget = hy_budget;  // :912-925
-          if (cts < budget) {  // :927-930 append
-            ins_idx = end_idx;
-            hyb_kind = 0;
-          } else if (flags & (HF_HH | HF_WIN)) {  // :932-946 evict the candidate the previous step scored
-            hyb_kind = 1;
-            if (ins_idx < 0) ins_idx = 0;  // unreachable with a positive budget (a head over budget has live slots)
-          } else {  // :948-950 the token is not kept: it lands in slot S - 1 with the mask untouched
-            ins_idx = S - 1;
-            hyb_kind = 2;
-          }
-        }
-        if constexpr (HRC) {
-          if (a.commit) {
-            if (rc_insp == one_pin) {  // a retry: the first attempt's decision (the key row, the count, the step counter may have moved on)
-              ins_idx = rc_insw >> 2;
-              hyb_kind = rc_insw & 3;
-              hyb_cts = rc_cts;
-              one_rcol = rc_col;
-            } else if (split == 0 && threadIdx.x == 0) {  // recorded before anything of the step can be committed
-              a.commit[(size_t)h * kRcStride] = (ins_idx << 2) | hyb_kind;
-              a.commit[(size_t)h * kRcStride + 66] = hyb_cts;
-              a.commit[(size_t)h * kRcStride + 67] = one_rcol;
-              a.commit[(size_t)h * kRcStride + 1] = one_pin;
-            }
-          }
-        }
-      }
-    }
-    // fused insert (cache.py:356-362, 460-490, 754-763) — see the VALU kernel; the K chunk follows the swizzle
-    if ((unsigned)(ins_idx - row0) < (unsigned)U) {
-      const int um = ins_idx - row0;
-      const int kcol = ((c ^ (4 * g + um)) & 15) * VEC;
-      Vec16<T> kn, vn;
-      if constexpr (!QB && AHEAD) {  // lane c holds chunk c of the new key (requested ahead of the tile); tile row i = 4g + um wants chunk c ^ i
-        const int xm = (4 * g + um) & 15;
-        kn.raw = make_uint4((uint32_t)__shfl_xor((int)qb_kn.raw.x, xm, 16), (uint32_t)__shfl_xor((int)qb_kn.raw.y, xm, 16),
-                            (uint32_t)__shfl_xor((int)qb_kn.raw.z, xm, 16), (uint32_t)__shfl_xor((int)qb_kn.raw.w, xm, 16));
-        vn.raw = qb_vn.raw;
-      } else if constexpr (!QB) {
-        kn.load(reinterpret_cast<const T*>(a.k_new) + (size_t)h * D + kcol);
-        vn.load(reinterpret_cast<const T*>(a.v_new) + (size_t)h * D + c * VEC);
-      }
-      const int32_t p_now = ONE ? one_pin : (AHEAD ? p_ins : *a.input_pos);  // (ONE: read in the prologue already)
-      // QB: the new row was quantised ahead of the tile (once per step and row), and is attended to through its image like
-      // every other row; this lane holds chunk c of K, not the swizzled chunk: the LDS stash below puts it where it belongs
-      uint2 knq = make_uint2(0, 0), vnq = make_uint2(0, 0);
-      float2 knp = make_float2(0.f, 0.f), vnp = make_float2(0.f, 0.f);
-      if constexpr (QB) {  // by the inserting row group only; its operands were requested ahead of the tile, so this runs while the tile is in flight
-        knq = quant8_row16<T>(qb_kn.raw, knp);
-        vnq = quant8_row16<T>(qb_vn.raw, vnp);
-        qb_ins_u = um;
-      }
-      if constexpr (DMA) {
-        // the new rows were requested BEHIND the tile's DMA loads and loads return in order: when kn / vn are here, the stale cache
-        // rows have landed in the slabs and may be overwritten
-        const int i = 4 * g + um;
-        // (l2 requests the new rows AHEAD of the tile — their arrival says nothing about the DMA loads: wait for those explicitly)
-        if constexpr (AHEAD) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        sm_k[wave][i][c] = kn.raw;                           // (kn is chunk c ^ i: slot c of row i)
-        sm_v[wave][i][(c ^ (2 * (i & 7))) & 15] = vn.raw;    // (vn is chunk c)
-      }
-#pragma unroll
-      for (int u = 0; u < U; u++)
-        if (u == um) {
-          if constexpr (QB) {
-            R.kq8[u] = knq; R.kpar[u] = knp;
-            R.vq8[u] = vnq; R.vpar[u] = vnp;
-          } else if constexpr (!DMA) {
-            R.kk[u].raw = kn.raw;
-            R.vv[u].raw = vn.raw;
-          }
-          if (!HYB || hyb_kind != 2) R.mword |= 1u << (8 * u);
-        }
-      if (HYB && blockIdx.z == 0) {  // ref: cache.py:997-1016 — bookkeeping of the hybrid decision
-        const size_t slot = (size_t)h * S + ins_idx;
-        *reinterpret_cast<uint4*>(const_cast<T*>(kb) + (size_t)ins_idx * D + kcol) = kn.raw;
-        *reinterpret_cast<uint4*>(const_cast<T*>(vh) + (size_t)ins_idx * D) = vn.raw;
-        if (c == 0) {
-          a.pos[slot] = p_now;  // :1006-1007 every head, dropped tokens included
-          if (hyb_kind == 0) a.mask_w[slot] = 1;  // :997-1001 appends only (an evicted slot is live already)
-          if constexpr (!ONE) a.hyb.cts_next[h] = hyb_cts + (hyb_kind == 0 ? 1 : 0);  // committed to cache_cts by the combine pass (ONE: by the head's split-0 workgroup, at the end)
-          if (hyb_punc && a.hyb.punc_mask) a.hyb.punc_mask[slot] = 1;  // :1011-1016
-        }
-      } else if (blockIdx.z == 0) {
-        const size_t slot = (size_t)h * S + ins_idx;
-        if constexpr (QB) {
-          *reinterpret_cast<uint2*>(const_cast<uint8_t*>(kqb) + (size_t)ins_idx * D + c * VEC) = knq;
-          *reinterpret_cast<uint2*>(const_cast<uint8_t*>(vqh) + (size_t)ins_idx * D) = vnq;
-          if (c == 0) *reinterpret_cast<float4*>(a.qparams + slot * 4) = make_float4(knp.x, knp.y, vnp.x, vnp.y);
-        } else {
-          *reinterpret_cast<uint4*>(const_cast<T*>(kb) + (size_t)ins_idx * D + kcol) = kn.raw;
-          *reinterpret_cast<uint4*>(const_cast<T*>(vh) + (size_t)ins_idx * D) = vn.raw;
-        }
-        if (c == 0) {
-          if (a.Hp != 1 || h == 0) a.pos[(a.Hp == 1 ? 0 : (size_t)h * S) + ins_idx] = p_now;
-          a.mask_w[slot] = 1;
-          if (!ONE && a.num != nullptr) {  // heavy hitter: cache.py:754-763 (ONE: the per-slot pass restarts the history)
-            a.num[slot] = 0.0;
-            a.denom[slot] = 0;
-          }
-          // (recoverable hand-off: the count is bumped where the step is committed — a retried insert must not count twice)
-          if (ins_was_empty && (a.Hc == a.H || h == 0) && !((EML || NRC) && a.commit)) atomicAdd(&a.cache_cts[a.Hc == a.H ? h : 0], 1);
-        }
-        if (L2) {  // l2: cache.py:592-593 — the new key's norm (sumsq_canonical_16's order), model dtype
-          // the canonical order wants elements c, c + 16, ... of the key in lane c; the lanes of this row group hold chunk c (elements
-          // 8c .. 8c + 7): transposed through the wave's V slab (not yet in use: the V tile is stashed after the scores) — eight more
-          // loads per wave of the whole launch, ahead of the tile, cost every workgroup's first K rows ~0.4 us
-          T* scratch = &sm_l2sc[wave][0];
-          *reinterpret_cast<uint4*>(scratch + c * VEC) = qb_kn.raw;
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-          __builtin_amdgcn_wave_barrier();
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-          float ss = 0.f;
-#pragma unroll
-          for (int i = 0; i < D / 16; i++) {
-            const float e = ElemTraits<T>::load(scratch, c + 16 * i);
-            ss = __fadd_rn(ss, __fmul_rn(e, e));
-          }
-          __builtin_amdgcn_wave_barrier();  // the V stash must stay behind these reads
-#pragma unroll
-          for (int off = 8; off > 0; off >>= 1) ss = __fadd_rn(ss, __shfl_xor(ss, off, 16));
-          const float nv = ElemTraits<T>::rnd(cc_sqrt_rn(ss));  // every lane of the row group holds the full sum
-          l2_nv_lane = nv;
-          if (c == 0) {
-            ElemTraits<T>::store(reinterpret_cast<T*>(a.key_norm), slot, nv);
-            if constexpr (!ONE) a.l2_new[h] = nv;
-          }
-        }
-      }
-    }
-
-    // ---- K tile -> wave-private LDS slab -> A operand; S^T = K q^T on the matrix core
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      if constexpr (DMA) {
-        // (already there: the DMA loads deliver into the slab; the compiler's wait for them sits in front of the fragment reads)
-      } else
-      if constexpr (QB) {  // slot c of tile row i holds chunk c ^ i; the inserted row's lane holds chunk c -> slot c ^ i
-        const int i = 4 * g + u;
-        sm_k[wave][i][u == qb_ins_u ? ((c ^ i) & 15) : c] = dequant8<T>(R.kq8[u], R.kpar[u]);
-      } else {
-        sm_k[wave][4 * g + u][c] = R.kk[u].raw;
-      }
-    }
-    qb_ins_u = -1;  // later tiles of this wave hold no inserted row
-    if constexpr (ONE) {
-      if (a.trace && trA == 0) trA = __builtin_amdgcn_s_memtime();  // this wave's K rows have arrived and sit in its LDS slab
-    }
-    const uint32_t mcur = R.mword;
-    if (more_next) issue_k(R, tbase_next);  // K registers are free again: the next tile streams in behind this tile's math
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    f32x4_t cs = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int j = 0; j < 4; j++) cs = Mfma16x16x32<T>::mma(sm_k[wave][c][((4 * j + g) ^ c) & 15], qB[j].raw, cs);
-    __builtin_amdgcn_wave_barrier();  // the next tile's stores must stay behind these reads
-
-    // ---- lane (g, n = c): scores of rows row0 + 0..3 against query head c
-    // ref: attention_utils.py:37 (q@k^T -> dtype, * scale -> dtype), :42-43 (-inf bias where masked)
-    float s[U];
-#pragma unroll
-    for (int t = 0; t < U; t++) {
-      const bool valid = (row0 + t < row_end) && (((mcur >> (8 * t)) & 0xffu) != 0);
-      const float x = ElemTraits<T>::rnd(ElemTraits<T>::rnd(cs[t]) * a.scale);
-      s[t] = valid ? x : -INFINITY;
-    }
-    if constexpr (ONE) {
-#pragma unroll
-      for (int t = 0; t < U; t++) s_keep[TI][t] = s[t];
-      if (a.trace && trB == 0) trB = __builtin_amdgcn_s_memtime();  // scores of the tile are in registers
-    }
-    if (!ONE && c < RT && !(a.abl & 1)) {
-      const size_t o = (size_t)(q0 + c) * S + row0;
-      if (row0 + 3 < row_end && (o & 3) == 0) {  // four consecutive 16-bit scores: one 8-byte store
-        T e0, e1, e2, e3;  // s[] already holds values rounded to T: the stores below are exact
-        ElemTraits<T>::store(&e0, 0, s[0]);
-        ElemTraits<T>::store(&e1, 0, s[1]);
-        ElemTraits<T>::store(&e2, 0, s[2]);
-        ElemTraits<T>::store(&e3, 0, s[3]);
-        *reinterpret_cast<uint2*>(sc_out + o) =
-            make_uint2((uint32_t)e0.x | ((uint32_t)e1.x << 16), (uint32_t)e2.x | ((uint32_t)e3.x << 16));
-      } else {
-#pragma unroll
-        for (int t = 0; t < U; t++)
-          if (row0 + t < row_end) ElemTraits<T>::store(sc_out, o + t, s[t]);
-      }
-    }
-    // ---- online softmax: ONE (m, l) per lane
-    float (&p)[U] = pv_p;
-    {
-      float mx = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
-      // ONE running maximum per (wave, head): the four row groups share it (two v_permlane swaps), so their
-      // accumulators carry the same scale and merge by plain addition in the epilogue — no exponentials there
-      mx = xor_combine<32, true>(xor_combine<16, true>(mx));
-      const float m_new = fmaxf(m, mx);
-      const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-      const float alpha = ONE1 ? 0.f : fast_exp(m - m_use);  // single tile: m = -inf, l = 0, acc = 0 — nothing to rescale
-      m = m_new;
-      if constexpr (!ONE1) l *= alpha;
-#pragma unroll
-      for (int t = 0; t < U; t++) {
-        p[t] = fast_exp(s[t] - m_use);
-        l += p[t];
-      }
-      if constexpr (!ONE1) {
-        // every accumulator of this lane belongs to head c.  The running maximum settles after the first tiles: while no
-        // head of the wave moved it, alpha is exactly 1 and the 32 multiplies — with the accumulators parked in AGPRs, 68 register
-        // moves around them: a fifth of the loop's instructions — are skipped (x * 1 == x: bit-identical)
-        if (__any(alpha != 1.0f)) {
-#pragma unroll
-          for (int b = 0; b < D / 16; b++) acc[b] *= alpha;
-        }
-      }
-    }
-  };
-  auto tile_pv = [&](TileRegs& R, const int tbase_next, const bool more_next) {
-    const float (&p)[U] = pv_p;
-    // ---- O^T += V^T . P^T on the matrix cores: V tile -> wave-private LDS slab (row major, coalesced), A fragments
-    //      back through the transpose read, B = this lane's four probabilities in 16 bit
-    if constexpr (!DMA) {
-#pragma unroll
-      for (int u = 0; u < U; u++)
-        sm_v[wave][4 * g + u][(c ^ (2 * ((4 * g + u) & 7))) & 15] = QB ? dequant8<T>(R.vq8[u], R.vpar[u]) : R.vv[u].raw;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (more_next) issue_v(R, tbase_next);  // the V registers are free once the tile sits in LDS: the next tile's rows go out before the P.V products
-    {
-      const s16x4_t pb = Mfma16x16x16<T>::pack(p);
-      const char* vrow = reinterpret_cast<const char*>(&sm_v[wave][tr_row][0]) + tr_half * 8;
-#pragma unroll
-      for (int b = 0; b < D / 16; b++) {
-        const int pos = ((2 * b) ^ tr_sw) | tr_qh;  // chunk 2b + q/2 of the row, swizzled
-        const s16x4_t va = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (s16x4_t __attribute__((address_space(3)))*)(vrow + pos * 16));
-        acc[b] = Mfma16x16x16<T>::mma(va, pb, acc[b]);
-      }
-    }
-    __builtin_amdgcn_wave_barrier();  // the next tile's V stores must stay behind these reads
-    if constexpr (ONE) {
-      if (a.trace && trC == 0) trC = __builtin_amdgcn_s_memtime();  // P.V of the tile issued
-    }
-  };
-  auto tile = [&](TileRegs& R, const int tbase, const int tbase_next, const bool more_next, auto ti_c) {
-    tile_qk(R, tbase, tbase_next, more_next, ti_c);
-    tile_pv(R, tbase_next, more_next);
-  };
-  // EML: the wave's (m, l) row goes to LDS; the LAST wave to arrive merges the workgroup's pairs and publishes them — behind the
-  // scores of the wave's only tile (NT == 1: ahead of its P.V products), or behind the wave's last tile (NT > 1)
-  auto ml_block = [&]() {
-      l = xor_combine<32, false>(xor_combine<16, false>(l));  // the wave's l of head c, in every row group
-      if (lane < RT) {                                          // row group 0, column c = head
-        sm_wm[wave][lane] = m;
-        sm_wl[wave][lane] = l;
-      }
-      if constexpr (L2) {  // the wave's maximum over the norms its slots hold AFTER this step's insert (decided above)
-        float kv = -INFINITY;
-        if (one_have) kv = (one_slot == ins_idx) ? l2_nv_lane : one_kn_f();
-        const bool nn = __any(kv != kv) != 0;
-        const float wm = wave_max_uniform(kv);
-        if (lane == 0) sm_l2w[wave] = nn ? NAN : wm;
-        // the other heads' epoch words have ARRIVED (they were requested ahead of the tile): see above
-        asm volatile("" ::"v"(l2_ep[0]), "v"(l2_ep[1]), "v"(l2_ep[2]), "v"(hm_ep) : "memory");
-      }
-      // No barrier: the waves' K tiles land up to 2 us apart, and a barrier here held every wave's P.V back until the workgroup's
-      // LAST K tile had arrived (measured, r3: +0.8 us on the streaming part).  Each wave bumps an LDS counter behind its two
-      // stores (release / acquire at workgroup scope); whoever brings it to NW has every wave's row in front of it and publishes.
-      unsigned arrived = 0;
-      if constexpr (DMA) {
-        // (relaxed: a release at workgroup scope waits for the V rows still landing in the slab through the DMA path — they count
-        //  in vmcnt.  The LDS unit serves one wave's operations in order: the two stores above are done when the add executes, and
-        //  the last arriver's reads below follow its add.)
-        //  The add is spelled in assembly: the compiler, which cannot tell the counter from the slabs the DMA loads write, would put
-        //  a wait for those in front of any LDS atomic it sees.)
-        if (lane == 0) {
-          const unsigned cnt_addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned*)&sm_mlcnt;
-          asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(arrived) : "v"(cnt_addr), "v"(1u) : "memory");
-        }
-      } else
-      if (lane == 0) arrived = __hip_atomic_fetch_add(&sm_mlcnt, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-      arrived = (unsigned)__builtin_amdgcn_readfirstlane((int)arrived);
-      const bool ml_last = arrived == (unsigned)(NW - 1) && lane < RT;
-      float ml_M = 0.f, ml_L = 0.f;
-      if (ml_last) {  // the merge of the publish loop below, once per query head (LDS traffic only inside this branch)
-        const int r = lane;
-        float M = sm_wm[0][r];
-#pragma unroll
-        for (int w = 1; w < NW; w++) M = fmaxf(M, sm_wm[w][r]);
-        const float Mu = (M == -INFINITY) ? 0.f : M;
-        float L = 0.f;
-#pragma unroll
-        for (int w = 0; w < NW; w++) L = fmaf(sm_wl[w][r], fast_exp(sm_wm[w][r] - Mu), L);
-        ml_M = M;
-        ml_L = L;
-      }
-      {
-        // The store is UNCONDITIONAL — every lane of every wave executes it; all but the publisher's RT lanes aim past the end of
-        // the buffer, where the hardware drops the write.  Inside the branch above it would make the compiler's in-order wait
-        // for the V rows (older loads) a wait for this write-through store's acknowledgement too (its bookkeeping merges "store
-        // issued" with "not issued" at the join): a memory round trip in front of the P.V products of the workgroup's last wave.
-        const u32x4_t mg = {one_tag, __float_as_uint(ml_M), one_tag, __float_as_uint(ml_L)};
-        const auto ml_rsrc_e = __builtin_amdgcn_make_buffer_rsrc(a.one_ml, 0, (int)a.one_ml_bytes, 0x00020000);
-        const int off = ml_last ? h * kOneMlHead + (split * RT + lane) * 16 : 0x7ffffff0;
-        __builtin_amdgcn_raw_buffer_store_b128(mg, ml_rsrc_e, off, 0, XL2 ? 0 : kOneAuxCoherent);
-        if constexpr (L2) {  // l2: the workgroup's norm maximum leaves with the pairs (same unconditional form; lane RT of the publisher)
-          float wm = -INFINITY;
-          bool nn = false;
-          if (arrived == (unsigned)(NW - 1) && lane == RT) {
-            float lw[NW];
-            if constexpr (DMA && (NW == 4 || NW == 8)) {
-              // (read in assembly: the compiler cannot tell this row from the slabs the DMA loads write and guards a plain read
-              //  with a wait for the V tile — the workgroup's norm maximum, which every workgroup of the launch waits for, then
-              //  left when its publisher's V rows had landed: found in the ISA, r4)
-              lds_read_row_nowait<NW>(sm_l2w, lw);
-            } else {
-#pragma unroll
-              for (int w = 0; w < NW; w++) lw[w] = sm_l2w[w];
-            }
-            wm = lw[0];
-            nn = wm != wm;
-#pragma unroll
-            for (int w = 1; w < NW; w++) {
-              nn |= lw[w] != lw[w];
-              wm = fmaxf(wm, lw[w]);
-            }
-          }
-          const u32x4_t ng = {one_tag, __float_as_uint(wm), one_tag, nn ? 1u : 0u};
-          const int noff = (arrived == (unsigned)(NW - 1) && lane == RT) ? kOneMaxHeads * kOneMlHead + h * kOneNmHead + split * 16 : 0x7ffffff0;
-          __builtin_amdgcn_raw_buffer_store_b128(ng, ml_rsrc_e, noff, 0, L2X ? 0 : kOneAuxCoherent);  // (L2X: gathered inside the XCD)
-        }
-      }
-      };
-  if constexpr (ONE && NT > 1) {
-    // the wave's tiles, unrolled: tile TI keeps its scores in s_keep[TI] for the finish (at most NT tiles: one_shape_ok)
-    auto run_tiles = [&](auto self, auto ti_c) -> void {
-      constexpr int TI = decltype(ti_c)::value;
-      if constexpr (TI < NT) {
-        const int tb = base + TI * (NW * RPW * U);
-        if (tb < row_end) {
-          tile(tregs[0], tb, tb + NW * RPW * U, TI + 1 < NT && tb + NW * RPW * U < row_end, ti_c);
-          self(self, IntC<TI + 1>{});
-        }
-      }
-    };
-    if (more) run_tiles(run_tiles, IntC<0>{});
-    if constexpr (EML) ml_block();  // (a wave without rows arrives with (-inf, 0))
-  } else if constexpr (EML) {
-    // single tile, early (m, l): scores -> [the workgroup's (m, l) pairs leave] -> P.V.  A wave without rows (ragged last split)
-    // skips the tile halves but not the arrival counter: its pair is (-inf, 0).
-    if (more) tile_qk(tregs[0], base, base, false, IntC<0>{});
-    ml_block();
-    if (more) tile_pv(tregs[0], base, false);
-  } else {
-    while (more) {
-      const int base_next = base + NSUB * NW * RPW * U;
-      const bool more_next = ONE ? false : base_next < row_end;
-#pragma unroll
-      for (int sub = 0; sub < NSUB; sub++)
-        tile(tregs[sub], base + sub * NW * RPW * U, base_next + sub * NW * RPW * U, more_next, IntC<0>{});
-      base = base_next;
-      more = more_next;
-    }
-  }
-  if constexpr (L2 && ONE && !EML) {
-    float kv = -INFINITY;
-    if (one_have) kv = (one_slot == ins_idx) ? l2_nv_lane : one_kn_f();
-    const bool nn = __any(kv != kv) != 0;
-    const float wm = wave_max_uniform(kv);
-    if (lane == 0) sm_l2w[wave] = nn ? NAN : wm;
-  }
-  if (L2 && !ONE && l2_here) {  // publish this wave's maximum over the norms that survive this step
-    if (key_pending) {  // a wave without rows never entered the loop
-#pragma unroll
-      for (int j = 0; j < 3; j++) key_part = key_more[j] < key_part ? key_more[j] : key_part;
-      const unsigned long long key = wave_min_u64_uniform(key_part);
-      ins_idx = (key == ~0ull) ? -1 : (int)((key & 0xffffffffull) >> 1);
-    }
-    float v = (kn_row0 == ins_idx) ? -INFINITY : kn_first;  // the evicted slot's old norm is gone
-    bool kn_nan = v != v;
-    for (int r = kn_row0 + NW * 64; r < row_end; r += NW * 64) {  // only beyond 256 slots per workgroup
-      const float x = ElemTraits<T>::load(reinterpret_cast<const T*>(a.key_norm) + (size_t)h * S, r);
-      if (r != ins_idx) {
-        kn_nan |= (x != x);
-        v = fmaxf(v, x);
-      }
-    }
-    v = wave_max_uniform(v);
-    const bool nn = __any(kn_nan) != 0;
-    if (lane == 0) a.l2_pmax[((size_t)h * a.n_split + split) * NW + wave] = nn ? NAN : v;
-  }
-
-  if (a.abl & 2) {  // measurement only
-    float x = l + m;
-#pragma unroll
-    for (int b = 0; b < D / 16; b++) x += acc[b][0] + acc[b][1] + acc[b][2] + acc[b][3];
-    if (x == 1.2345f) a.part_ml[0] = x;
-    return;
-  }
-  // ---- Epilogue.  The P.V accumulators already cover all 16 rows of the wave's tiles (one running maximum per
-  //      (wave, head)), so there is nothing to merge inside a wave: lanes n < RT drop their [128] partial into LDS
-  //      (8 x ds_write_b128) and the four waves of the workgroup meet there.
-  __shared__ __attribute__((aligned(16))) float sm_wacc[NW][RT][D];
-  {
-    if constexpr (!EML) {  // (EML: done between the tile's halves)
-      l = xor_combine<32, false>(xor_combine<16, false>(l));  // the wave's l of head c, in every row group
-      if (lane < RT) {                                          // row group 0, column c = head
-        sm_wm[wave][lane] = m;
-        sm_wl[wave][lane] = l;
-      }
-    }
-    if (c < RT) {
-#pragma unroll
-      for (int b = 0; b < D / 16; b++)
-        *reinterpret_cast<float4*>(&sm_wacc[wave][c][16 * b + 4 * g]) = make_float4(acc[b][0], acc[b][1], acc[b][2], acc[b][3]);
-    }
-  }
-  if constexpr (L2X) {
-    // L2X, level one — EARLY: the workgroups' norm maxima left with their (m, l) pairs, behind their scores; the last wave of the
-    // head's split-0 workgroup (the first blocks of the grid: among the first to start) gathers them through the XCD's L2 right here,
-    // ahead of the merge barrier, and publishes the head's maximum through memory for the other kv heads.  (After the merge barrier
-    // and the (m, l) gather it was 1.5 us later, and every workgroup of the launch ended behind it; every workgroup of the head
-    // storing the same granule was far worse: 32 write-through stores per address, 14.4 us per step.)
-    if (split == 0 && wave == NW - 1) {
-      const auto ml_rsrc_p = __builtin_amdgcn_make_buffer_rsrc(a.one_ml, 0, (int)a.one_ml_bytes, 0x00020000);
-      const int off1 = kOneMaxHeads * kOneMlHead + h * kOneNmHead + (lane < a.n_split ? lane : 0) * 16;
-      u32x4_t nmx = {0u, 0u, 0u, 0u};
-      bool got = false;
-      for (unsigned spins = 0; spins <= kOneSpinMax; spins++) {
-        asm volatile("" ::: "memory");  // every round re-reads memory
-        nmx = __builtin_amdgcn_raw_buffer_load_b128(ml_rsrc_p, off1, 0, 16 /* sc1: the XCD's L2 */);
-        if (__all(lane >= a.n_split || (nmx[0] == one_tag && nmx[2] == one_tag))) {
-          got = true;
-          break;
-        }
-        __builtin_amdgcn_s_sleep(1);
-      }
-      if (got) {  // (not: nothing is published, and every workgroup of the launch times out on level two — reported like any hand-off timeout)
-        const float v = lane < a.n_split ? __uint_as_float(nmx[1]) : -INFINITY;
-        const bool hn = __any(lane < a.n_split && (nmx[3] != 0u || v != v)) != 0;
-        const float hmx = wave_max_uniform(v);
-        const u32x4_t hg = {one_tag, __float_as_uint(hmx), one_tag, hn ? 1u : 0u};
-        __builtin_amdgcn_raw_buffer_store_b128(hg, ml_rsrc_p, lane == 0 ? kOneMaxHeads * (kOneMlHead + kOneNmHead) + h * 16 : 0x7ffffff0, 0, kOneAuxCoherent);
-      }
-    }
-  }
-  __syncthreads();
-  if constexpr (ONE) {
-    // ============================================================================================================
-    // Single-launch layer step: what the combine launch did, done here behind an in-launch hand-off.
-    //   publish   the workgroup's (m, l, O[RT][128]) partial as 16-byte granules {tag, x, tag, y}: write-through
-    //             (sc0 sc1) stores; each 8-byte half validates itself, so no flag, no fence and no store ordering;
-    //   gather    wave r collects the n_split (m, l) pairs of query head r (lane = split) and every thread its share
-    //             of the O granules of the output columns this workgroup finishes — coherent loads, re-read (s_sleep
-    //             between rounds) until every tag is this launch's.  Tags only ever grow (the epoch words live in the workspace and are bumped once
-    //             per launch and head), so a granule left by any earlier launch, layer or shape can never match;
-    //   finish    the final (M, L) per head in the combine kernel's exact order; then this workgroup's 64 slots —
-    //             probabilities from the scores still in registers, group mean, history update, next-eviction key —
-    //             and its columns of y.
-    // Probabilities, history and keys repeat decode_attn_combine_kernel's operations in its order: bit-identical to the
-    // two-launch step (y sums its partials in a different fixed order: equal up to fp32 rounding).  Needs all
-    // n_split * H workgroups co-resident (the launcher checks); every wait is bounded and reports through the
-    // timeout word should that ever not hold.
-    const int ns = a.n_split;
-    const unsigned tag = one_tag;
-    // XL2: a kv head's own granules never leave its XCD — plain stores (they stay in the L2), sc1 polls (past the L1, served by the
-    // L2).  The l2 policy's norm maxima cross kv heads, hence XCDs: they keep the write-through / memory-scope form.
-    constexpr int kGatherAux = XL2 ? 16 : kOneAuxCoherent;
-    constexpr int kPublishAux = XL2 ? 0 : kOneAuxCoherent;
-    if constexpr (L2 && !EML) {
-      // the epoch words of the other heads (requested behind the tile's loads) must have ARRIVED before this workgroup publishes:
-      // whoever bumps a word does so only after every workgroup of the launch has published
-      asm volatile("" ::"v"(l2_ep[0]), "v"(l2_ep[1]), "v"(l2_ep[2]) : "memory");
-    }
-    if constexpr (HYB) {
-      // the step counter, num_punc / num_special and the head's count are overwritten at the END of this launch by whoever sees
-      // that every workgroup has published: their prologue loads must have COMPLETED (not merely been issued) before this
-      // workgroup publishes — the values are pinned into registers here
-      asm volatile("" ::"s"(one_rcol), "s"(hy_budget), "s"(hy_cts), "s"((int)hy_punc), "s"(hy_nsp), "s"(hy_npu) : "memory");
-    }
-    if (a.trace) {
-      tr1 = __builtin_amdgcn_s_memtime();
-      rt1 = __builtin_amdgcn_s_memrealtime();
-    }
-    __shared__ float sm_w1[RT][64];  // exp(m_i - M_r)
-    __shared__ float sm_M1[RT], sm_L1[RT];
-    __shared__ __attribute__((aligned(16))) float sm_o1[2 * (RT * 64 + 64)];  // [split][pair of this workgroup][2]: raw partial O
-    const auto ml_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.one_ml, 0, (int)a.one_ml_bytes, 0x00020000);
-    const auto o_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.one_o, 0, (int)a.one_o_bytes, 0x00020000);
-    constexpr int MLN = (RT + NW - 1) / NW;            // (m, l) granules per thread: wave w collects heads w, w + NW, ...
-    int ml_off[MLN];
-    // the waves that fold a head's (m, l) pairs: the first RT — or (MLW) the LAST RT of a workgroup with at least 2 RT waves: the first
-    // RT waves merge and publish the partial O meanwhile (thread t: outputs 2t, 2t + 1), the others would idle
-    constexpr int ML_W0 = (CC_V_MLW != 0 && EML && NW >= 2 * RT) ? NW - RT : 0;
-    const int ml_w = wave - ML_W0;  // this wave's first head (negative: none)
-#pragma unroll
-    for (int k = 0; k < MLN; k++) ml_off[k] = h * kOneMlHead + ((lane < ns ? lane : 0) * RT + (ml_w >= 0 && ml_w + k * NW < RT ? ml_w + k * NW : 0)) * 16;
-    u32x4_t mlq[MLN];
-    const int nm_base = kOneMaxHeads * kOneMlHead;  // l2: the norm-maximum granules sit behind the (m, l) regions of all heads
-    constexpr int NLG = (L2 && !L2X) ? 3 : 0;  // l2, one-level exchange: norm-maximum granules per thread (H * n_split <= 768 workgroups are ever co-resident)
-    int nm_off[NLG > 0 ? NLG : 1];
-    bool nm_use[NLG > 0 ? NLG : 1];
-    unsigned nm_tag[NLG > 0 ? NLG : 1];  // a granule of kv head h' carries h''s tag (its epoch word was read in the prologue: l2_ep)
-#pragma unroll
-    for (int k = 0; k < NLG; k++) {
-      const int e = (int)threadIdx.x + k * NW * 64;
-      nm_use[k] = e < a.H * ns;
-      const int hh = nm_use[k] ? e / ns : 0, ss = nm_use[k] ? e - hh * ns : 0;
-      nm_off[k] = nm_base + hh * kOneNmHead + ss * 16;
-      nm_tag[k] = l2_ep[k] + 1u;
-    }
-    u32x4_t nq[NLG > 0 ? NLG : 1];
-    u32x4_t hmq = {0u, 0u, 0u, 0u};  // L2X: the kv heads' maxima (lane = kv head)
-    const int hm_base = kOneMaxHeads * (kOneMlHead + kOneNmHead);
-    if constexpr (EML) {
-      // the (m, l) pairs left behind the scores, long ago: their first round of loads goes out AHEAD of this workgroup's partial-O
-      // stores (loads return in order: behind the stores they would also wait for the stores' acknowledgements, a round trip)
-      if (ml_w >= 0 && ml_w < RT) {
-#pragma unroll
-        for (int k = 0; k < MLN; k++) mlq[k] = __builtin_amdgcn_raw_buffer_load_b128(ml_rsrc, ml_off[k], 0, kGatherAux);
-      }
-
-      // l2: every workgroup's norm maximum (they left with the pairs), gathered by every thread of every workgroup; a thread
-      // without a granule aims past the buffer's end (no request, zeros back): no branch around the loads
-#pragma unroll
-      for (int k = 0; k < NLG; k++) nq[k] = __builtin_amdgcn_raw_buffer_load_b128(ml_rsrc, nm_use[k] ? nm_off[k] : 0x7ffffff0, 0, kOneAuxCoherent);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    // ---- publish: thread t merges output columns 2t, 2t + 1 of the workgroup's partial (the arithmetic of the
-    //      two-launch epilogue below) and stores them as one granule
-    for (int o2 = (int)threadIdx.x * 2; o2 < RT * D; o2 += 2 * NW * 64) {
-      {
-        const int r = o2 / D, d = o2 - r * D;
-        float M = sm_wm[0][r];
-#pragma unroll
-        for (int w = 1; w < NW; w++) M = fmaxf(M, sm_wm[w][r]);
-        const float Mu = (M == -INFINITY) ? 0.f : M;
-        float L = 0.f, O0 = 0.f, O1 = 0.f;
-#pragma unroll
-        for (int w = 0; w < NW; w++) {  // fixed order: deterministic
-          const float f = fast_exp(sm_wm[w][r] - Mu);
-          L = fmaf(sm_wl[w][r], f, L);
-          O0 = fmaf(sm_wacc[w][r][d], f, O0);
-          O1 = fmaf(sm_wacc[w][r][d + 1], f, O1);
-        }
-        const u32x4_t og = {tag, __float_as_uint(O0), tag, __float_as_uint(O1)};
-        __builtin_amdgcn_raw_buffer_store_b128(og, o_rsrc, h * kOneOHead + ((r * ns + split) * 64 + (d >> 1)) * 16, 0, kPublishAux);
-        if (!EML && d == 0) {
-          const u32x4_t mg = {tag, __float_as_uint(M), tag, __float_as_uint(L)};
-          __builtin_amdgcn_raw_buffer_store_b128(mg, ml_rsrc, h * kOneMlHead + (split * RT + r) * 16, 0, kPublishAux);
-        }
-      }
-    }
-    // l2: the workgroup's norm maximum travels the same way — one granule {tag, max, tag, nan} per workgroup in the upper half
-    // of the (m, l) region; every workgroup of EVERY kv head gathers all of them (cache.py:602 takes the maximum over all heads)
-    if constexpr (L2 && !EML) {
-      if (threadIdx.x == NW * 64 - 1) {
-        float wm = sm_l2w[0];
-        bool nn = wm != wm;
-#pragma unroll
-        for (int w = 1; w < NW; w++) {
-          nn |= sm_l2w[w] != sm_l2w[w];
-          wm = fmaxf(wm, sm_l2w[w]);
-        }
-        const u32x4_t ng = {tag, __float_as_uint(wm), tag, nn ? 1u : 0u};
-        __builtin_amdgcn_raw_buffer_store_b128(ng, ml_rsrc, nm_base + h * kOneNmHead + split * 16, 0, kOneAuxCoherent);
-      }
-    }
-    if constexpr (HYB) hyb_load_state();  // hybrid: the slots' ring state / positions / protection masks arrive during the hand-off
-    else if constexpr (NT > 1) load_slot_state();  // several tiles per wave: the slots' history / positions arrive during the hand-off
-    if (a.trace) tr2 = __builtin_amdgcn_s_memtime();
-    // ---- what this thread gathers: the (m, l) granule of (head = wave, split = lane) and up to two O granules
-    // (ppw, pair0, n_pairs, o_off / o_lds / o_use: worked out in the prologue, while the tile was in flight)
-    bool timed_out = false;
-    bool hrc_peer_failed = false, hrc_failed = false;  // hybrid, recoverable form: a peer gave up / this workgroup commits nothing
-    // The first poll waits until this wave's OWN publish stores are acknowledged (vmcnt counts stores on this chip).  Polls issued
-    // right behind the write-through stores cost 0.8 us at S = 4096 (11.1 vs 10.3 us; found by accident: a never-taken measurement
-    // branch with loads of its own made the compiler put this wait at the join): the stragglers' K/V rows and everybody's granules
-    // then queue behind 6 MB of polls per round that cannot succeed yet.
-    if constexpr (!EML) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (EML: the first rounds of both gathers are not issued behind these stores)
-    u32x4_t oq[NOG];
-    // one round of loads of each kind (coherent: they bypass the L1 and stale L2 lines), and whether every granule of the round
-    // carries this launch's tag
-    auto load_ml = [&]() {
-#pragma unroll
-      for (int k = 0; k < MLN; k++) mlq[k] = __builtin_amdgcn_raw_buffer_load_b128(ml_rsrc, ml_off[k], 0, kGatherAux);
-    };
-    unsigned failq = 0;  // EML: the head's fail word, read with every round of the partial-O gather (recoverable hand-off)
-    const auto hdr_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.one_hdr, 0, 4096, 0x00020000);
-    auto load_o = [&]() {
-#pragma unroll
-      for (int k = 0; k < NOG; k++) oq[k] = __builtin_amdgcn_raw_buffer_load_b128(o_rsrc, o_off[k], 0, kGatherAux);
-      if constexpr (RC) failq = __builtin_amdgcn_raw_buffer_load_b32(hdr_rsrc, (kOneFailWord + h) * 4, 0, kOneAuxCoherent);
-    };
-    // a wave that gives up: the head's fail word (this launch's tag) and the workspace's status word, write-through
-    auto give_up = [&]() {
-      if (lane == 0) {
-        __builtin_amdgcn_raw_buffer_store_b32(tag, hdr_rsrc, (kOneFailWord + h) * 4, 0, kOneAuxCoherent);
-        __builtin_amdgcn_raw_buffer_store_b32(1u, hdr_rsrc, kOneStatusWordDev * 4, 0, kOneAuxCoherent);
-        sm_fail = 1u;
-      }
-    };
-    auto ok_ml = [&]() {
-      bool ok = true;
-#pragma unroll
-      for (int k = 0; k < MLN; k++) ok = ok && mlq[k][0] == tag && mlq[k][2] == tag;
-      return ok;
-    };
-    auto ok_o = [&]() {
-      bool ok = true;
-#pragma unroll
-      for (int k = 0; k < NOG; k++) ok = ok && (!o_use[k] || (oq[k][0] == tag && oq[k][2] == tag));
-      return ok;
-    };
-    // ---- final (M, L) of query heads r = wave, wave + NW, ...: decode_attn_combine_kernel's order (lane = split, n_split <= 64)
-    auto final_ml = [&]() {
-#pragma unroll
-      for (int k = 0; k < MLN; k++) {
-        const int rr = ml_w + k * NW;
-        if (rr >= 0 && rr < RT) {
-          const float mi = lane < ns ? __uint_as_float(mlq[k][1]) : -INFINITY;
-          const float M = wave_max_uniform(mi);
-          const float Mu = (M == -INFINITY) ? 0.f : M;
-          float L = 0.f;
-          if (lane < ns) {
-            const float wgt = exp_nonpos(mi - Mu);
-            sm_w1[rr][lane] = wgt;
-            L = __uint_as_float(mlq[k][3]) * wgt;
-          }
-          L = wave_sum_uniform(L);
-          if (lane == 0) {
-            sm_M1[rr] = Mu;
-            sm_L1[rr] = L;
-          }
-        }
-      }
-    };
-    auto stash_o = [&]() {
-#pragma unroll
-      for (int k = 0; k < NOG; k++)
-        if (o_use[k]) *reinterpret_cast<float2*>(&sm_o1[o_lds[k]]) = make_float2(__uint_as_float(oq[k][1]), __uint_as_float(oq[k][3]));
-    };
-    // ---- y: per output column, G1 strided chains over the splits.  The G1 chains of an output sit in G1 adjacent lanes: folded by
-    //      DPP butterflies and stored at once — no partial sums through LDS, no second barrier (tasks go to the LAST threads first).
-    auto y_fold = [&]() {
-      const int n_out = 2 * n_pairs;
-      const int sh = ns >= 8 ? 3 : (ns >= 4 ? 2 : (ns >= 2 ? 1 : 0)), G1 = 1 << sh;
-      for (int task = NW * 64 - 1 - (int)threadIdx.x; task < (n_out << sh); task += NW * 64) {
-        const int ol = task >> sh, gg = task & (G1 - 1);
-        const int to = 2 * pair0 + ol, r = to / D;
-        float part = 0.f;
-        for (int i = gg; i < ns; i += G1) part = fmaf(sm_o1[i * ppw * 2 + ol], sm_w1[r][i], part);
-        part = seg_sum(part, G1);  // whole groups of G1 lanes are in or out of this loop together
-        if (gg == 0) ElemTraits<T>::store(reinterpret_cast<T*>(a.y), (size_t)(h * RT + r) * D + (to - r * D), part / sm_L1[r]);
-      }
-    };
-    __shared__ float sm_l2g[NW];  // l2: per-wave fold of the gathered norm maxima (NaN propagates: torch.max)
-    unsigned long long trD = 0, trE = 0;
-    if constexpr (EML) {
-      // ---- the (m, l) pairs left behind the scores: most of them are there by now.  Only the waves that fold a head poll.
-      const bool ml_mine = ml_w >= 0 && ml_w < RT;  // (MLN == 1 whenever RT <= NW; with RT = 8 on four waves every wave folds two heads)
-      // Round 0 (issued ahead of the partial-O stores) is examined in STRAIGHT-LINE code: the compiler then waits for exactly
-      // these loads — the oldest in flight — and not for the acknowledgements of the stores behind them (at a loop header its
-      // in-order wait counts merge with the back edge's and become a wait for everything)
-      auto ok_nm = [&]() {
-        bool ok = true;
-#pragma unroll
-        for (int k = 0; k < NLG; k++) ok = ok && (!nm_use[k] || (nq[k][0] == nm_tag[k] && nq[k][2] == nm_tag[k]));
-        return ok;
-      };
-      bool ml_ok = (!ml_mine || __all(ok_ml())) && (!L2 || __all(ok_nm()));
-      bool peer_failed = false;
-      for (unsigned spins = 0; !ml_ok; spins++) {
-        if (spins > kOneSpinMax) {
-          timed_out = true;
-          break;
-        }
-        __builtin_amdgcn_s_sleep(1);
-        asm volatile("" ::: "memory");  // every round re-reads memory
-        if constexpr (RC) {  // a workgroup of this head gave up (memory scope: it may sit on another XCD): nothing left to wait for
-          failq = __builtin_amdgcn_raw_buffer_load_b32(hdr_rsrc, (kOneFailWord + h) * 4, 0, kOneAuxCoherent);
-          if (failq == tag) {
-            peer_failed = true;
-            break;
-          }
-        }
-        if (ml_mine) load_ml();
-#pragma unroll
-        for (int k = 0; k < NLG; k++)
-          if (nm_use[k]) nq[k] = __builtin_amdgcn_raw_buffer_load_b128(ml_rsrc, nm_off[k], 0, kOneAuxCoherent);
-        ml_ok = (!ml_mine || __all(ok_ml())) && (!L2 || __all(ok_nm()));
-      }
-      if (timed_out) give_up();
-      else if (peer_failed && lane == 0) sm_fail = 1u;
-      if (a.trace) tr4 = __builtin_amdgcn_s_memtime();
-      if (ml_mine) final_ml();
-      if constexpr (L2) {  // the wave's fold of the gathered norm maxima (NaN propagates: torch.max)
-        float gm = -INFINITY;
-        bool gn = false;
-#pragma unroll
-        for (int k = 0; k < NLG; k++)
-          if (nm_use[k]) {
-            const float v = __uint_as_float(nq[k][1]);
-            gn |= nq[k][3] != 0u || v != v;
-            gm = fmaxf(gm, v);
-          }
-        const bool nn = __any(gn) != 0;
-        const float wm = wave_max_uniform(gm);
-        if (lane == 0) sm_l2g[wave] = nn ? NAN : wm;
-      }
-      __syncthreads();
-      if (a.trace) trD = __builtin_amdgcn_s_memtime();
-    } else {
-      for (unsigned spins = 0;; spins++) {
-        asm volatile("" ::: "memory");  // every round re-reads memory
-        load_ml();
-        load_o();
-#pragma unroll
-        for (int k = 0; k < NLG; k++) nq[k] = __builtin_amdgcn_raw_buffer_load_b128(ml_rsrc, nm_off[k], 0, kOneAuxCoherent);
-        bool ok = true;
-#pragma unroll
-        for (int k = 0; k < NLG; k++) ok = ok && (!nm_use[k] || (nq[k][0] == nm_tag[k] && nq[k][2] == nm_tag[k]));
-        ok = ok && ok_ml() && ok_o();
-        if (__all(ok)) break;
-        if constexpr (NRC) {
-          // the head's fail word, with one round in eight (it travels through memory: a round that waits for it lasts longer —
-          // +1 us on the C4 step when it was read with every round) — a workgroup of this head gave up: nothing left to wait for
-          if (a.commit && (spins & 7u) == 7u) {
-            failq = __builtin_amdgcn_raw_buffer_load_b32(hdr_rsrc, (kOneFailWord + h) * 4, 0, kOneAuxCoherent);
-            if (failq == tag) {
-              hrc_peer_failed = true;
-              break;
-            }
-          }
-        }
-        if (spins > kOneSpinMax) {
-          timed_out = true;
-          break;
-        }
-        __builtin_amdgcn_s_sleep(1);
-      }
-      if (a.trace) tr4 = __builtin_amdgcn_s_memtime();
-      if (NRC && a.commit) {
-        if (timed_out) give_up();
-        else if (hrc_peer_failed && lane == 0) sm_fail = 1u;  // (every workgroup commits or repeats ITS part: per-workgroup commit words)
-      } else if (timed_out && lane == 0) {
-        a.one_hdr[kOneStatusWordDev] = 1u;  // this launch's results are invalid; the host reads the word
-      }
-      final_ml();
-      stash_o();
-      if constexpr (L2) {
-        float gm = -INFINITY;
-        bool gn = false;
-#pragma unroll
-        for (int k = 0; k < NLG; k++)
-          if (nm_use[k]) {
-            const float v = __uint_as_float(nq[k][1]);
-            gn |= nq[k][3] != 0u || v != v;
-            gm = fmaxf(gm, v);
-          }
-        const bool nn = __any(gn) != 0;
-        const float wm = wave_max_uniform(gm);
-        if (lane == 0) sm_l2g[wave] = nn ? NAN : wm;
-      }
-      __syncthreads();
-      if (a.trace) trD = __builtin_amdgcn_s_memtime();
-      if constexpr (NRC) hrc_failed = a.commit != nullptr && sm_fail != 0u;  // (workgroup-uniform behind the barrier)
-      if (!hrc_failed) y_fold();
-    }
-    // hybrid, recoverable form: nothing of the step is stored by a workgroup that failed or that committed this position before
-    const bool hrc_skip = NRC && a.commit != nullptr && (hrc_failed || rc_replay);
-    if constexpr (EML) {
-      // the first round of the partial-O gather goes out HERE and flies while the per-slot pass runs: what is left behind the last O
-      // granule of the head is the y fold
-      asm volatile("" ::: "memory");
-      load_o();
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    // ---- this workgroup's slots.  ref: attention_utils.py:52 softmax -> model dtype; model.py:416-418 group mean -> model
-    //      dtype; cache.py:716-722 history; cache.py:727-749 the next position's eviction score
-    unsigned long long my_key = ~0ull;
-    double def_num[NT];  // EML: this lane's deferred history stores, one per tile of the wave (def_i < 0: none)
-    int32_t def_den[NT];
-    long long def_i[NT];
-#pragma unroll
-    for (int ti = 0; ti < NT; ti++) {
-      def_num[ti] = 0.0;
-      def_den[ti] = 0;
-      def_i[ti] = -1;
-    }
-    __shared__ float sm_hav[(HYB || ALL) ? NW : 1][(HYB || ALL) ? NT * RPW * U : 1];  // hybrid / ALL: group-mean probabilities, [wave][tile * 16 + row]
-    auto slot_pass = [&](auto ti_c) {
-      constexpr int TI = decltype(ti_c)::value;
-      const int slot_ti = one_slot + TI * (NW * RPW * U);
-      const bool have_ti = one_lane && slot_ti < row_end;
-      unsigned long long key_ti = ~0ull;
-      float av = 0.f;
-      const bool want_probs = HYB ? (a.ring_num != nullptr || a.attn_out != nullptr) : (a.num != nullptr);
-      if (want_probs) {  // heavy hitter: the group-mean probability of this lane's row (the head-constant policies keep no history)
-        // lane c of a row group computes the probabilities of row t = c / LPR for heads (c % LPR) * KH + [0, KH) — one exp and one
-        // IEEE divide per (row, head), spread over the 16 lanes; the score of (row t, head r) sits in lane r of the group as
-        // s_keep[TI][t].  The group mean adds the heads in order r = 0 .. RT - 1, like the combine pass.
-        const int t_me = c / LPR, j_me = c % LPR;
-        float pr[KH];
-#pragma unroll
-        for (int kk = 0; kk < KH; kk++) {
-          const int r_me = j_me * KH + kk;
-          float x;
-          if constexpr (RT == 4) {
-            // lane c = 4t + r of the 16-lane row takes s_keep[TI][t] of lane r: row shifts by 4t (DPP, no LDS crossbar round trips)
-            const float x1 = dpp_mov<0x114>(s_keep[TI][1]);  // row_shr:4
-            const float x2 = dpp_mov<0x118>(s_keep[TI][2]);  // row_shr:8
-            const float x3 = dpp_mov<0x11C>(s_keep[TI][3]);  // row_shr:12
-            x = t_me == 0 ? s_keep[TI][0] : (t_me == 1 ? x1 : (t_me == 2 ? x2 : x3));
-          } else {
-            const int src = (lane & ~15) | r_me;
-            x = -INFINITY;
-#pragma unroll
-            for (int t = 0; t < U; t++) {
-              const float v = __shfl(s_keep[TI][t], src, CC_WAVE);
-              x = (t == t_me) ? v : x;
-            }
-          }
-          pr[kk] = ElemTraits<T>::rnd(__fdiv_rn(exp_nonpos(x - sm_M1[r_me]), sm_L1[r_me]));
-        }
-        float sum = 0.f;
-        if constexpr (LPR == 4) {
-#pragma unroll
-          for (int kk = 0; kk < KH; kk++) sum += dpp_mov<0x00>(pr[kk]);
-#pragma unroll
-          for (int kk = 0; kk < KH; kk++) sum += dpp_mov<0x55>(pr[kk]);
-#pragma unroll
-          for (int kk = 0; kk < KH; kk++) sum += dpp_mov<0xAA>(pr[kk]);
-#pragma unroll
-          for (int kk = 0; kk < KH; kk++) sum += dpp_mov<0xFF>(pr[kk]);
-        } else if constexpr (LPR == 2) {
-          sum += dpp_mov<0xA0>(pr[0]);  // quad_perm [0, 0, 2, 2]
-          sum += dpp_mov<0xF5>(pr[0]);  // quad_perm [1, 1, 3, 3]
-        } else {
-          sum += pr[0];
-        }
-        av = ElemTraits<T>::rnd(sum * (1.0f / (float)RT));  // RT is a power of two: bit-identical to the IEEE divide of the combine pass
-      }
-      if constexpr (HYB || ALL) {  // hybrid / ALL: the pass below consumes the probabilities on all lanes
-        if (have_ti) sm_hav[wave][TI * (RPW * U) + g * U + c / LPR] = av;
-      } else if (have_ti) {
-        const size_t i = (size_t)h * S + slot_ti;
-        int32_t ps = one_psv[TI];
-        double num_old = one_numv[TI];
-        int32_t den_old = one_denv[TI];
-        if (slot_ti == ins_idx) {  // refilled by this launch's insert: position p, history from zero (cache.py:754-763)
-          ps = one_pin;
-          num_old = 0.0;
-          den_old = 0;
-        }
-        const int32_t p_next = one_pin + 1;
-        const uint32_t low = ((uint32_t)slot_ti << 1) | (uint32_t)(ps == -1);
-        if constexpr (L2) {  // ref: cache.py:597-605: dtype(max over ALL heads and slots - norm), recent window -> +inf, base rules
-          float gm = -INFINITY;
-          bool gn = false;
-          if constexpr (L2X) {
-            gm = sm_gmax;
-            gn = gm != gm;
-          } else {
-#pragma unroll
-            for (int w2 = 0; w2 < NW; w2++) {
-              const float v = sm_l2g[w2];
-              gn |= (v != v);
-              gm = fmaxf(gm, v);
-            }
-          }
-          const float kn_eff = (slot_ti == ins_idx) ? l2_nv_lane : one_kn_f();
-          float scn = ElemTraits<T>::rnd((gn ? NAN : gm) - kn_eff);
-          if (ps >= p_next - a.w) scn = INFINITY;
-          if (slot_ti < a.g) scn = INFINITY;
-          if (ps == -1) scn = -INFINITY;
-          key_ti = make_key(orderable_f32(scn), low);
-        } else if (a.num) {
-          if (a.attn_out) ElemTraits<T>::store(reinterpret_cast<T*>(a.attn_out), i, av);
-          const double num_new = num_old + (double)av;
-          const int32_t den_new = den_old + 1;
-          if constexpr (RC) {  // stored behind the LAST gather and the head's fail word: a head's step is committed whole or not at all
-            def_num[TI] = num_new;
-            def_den[TI] = den_new;
-            def_i[TI] = (long long)i;
-          } else {
-            a.num[i] = num_new;
-            a.denom[i] = den_new;
-          }
-          float scn = __fdiv_rn((float)num_new, (float)(den_new < 1 ? 1 : den_new));
-          if (ps < a.g || ps >= p_next - a.w) scn = 1.0f;
-          if (ps == -1) scn = 0.0f;
-          key_ti = make_key(orderable_f32(scn), low);
-        } else {  // head-constant policies: every kv head scores the shared positions for its own copy of the key row (KEY ROWS)
-          if (a.policy == 2) {  // ref: cache.py:500-502, 552-556 — arg-min of pos behind the sinks; -1 = empty first
-            if (slot_ti >= a.g) key_ti = make_key(orderable_i32(ps), low);
-          } else {  // random, ref: cache.py:523 recent window -> +inf, then the base rules :373-376
-            float scn = a.rand_next ? one_rndv[TI] : cc_rng_uniform(a.rng_seed, p_next, slot_ti);
-            if (ps >= p_next - a.w) scn = INFINITY;
-            if (slot_ti < a.g) scn = INFINITY;
-            if (ps == -1) scn = -INFINITY;
-            key_ti = make_key(orderable_f32(scn), low);
-          }
-        }
-      }
-      my_key = key_ti < my_key ? key_ti : my_key;
-    };
-    // every tile of the wave (compile-time unrolled; tiles past the split's end hold no slot)
-    auto all_tiles = [&](auto self, auto ti_c) -> void {
-      constexpr int TI = decltype(ti_c)::value;
-      if constexpr (TI < NT) {
-        if (row_begin + wave * (RPW * U) + TI * (NW * RPW * U) < row_end) {  // wave-uniform: the wave has a tile TI
-          slot_pass(ti_c);
-          self(self, IntC<TI + 1>{});
-        }
-      }
-    };
-    if constexpr (!L2X) {
-      if (!hrc_skip) all_tiles(all_tiles, IntC<0>{});  // (L2X: behind the partial-O gather — the heads' maxima arrive with it)
-    }
-    if constexpr (ALL) {
-      // ---- the second half of the per-slot pass on all lanes: the slot_pass branches above, operation for operation (heavy hitter:
-      //      cache.py:716-722, 727-749; head-constant policies: cache.py:500-502, 519-524, 552-556)
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      const int32_t p_next = one_pin + 1;
-#pragma unroll
-      for (int k = 0; k < SN; k++)
-        if (all_valid(k) && !hrc_skip) {
-          const int sl = all_slot(k);
-          const size_t i = (size_t)h * S + sl;
-          const float av = sm_hav[wave][lane + 64 * k];
-          int32_t ps = one_psv[k];
-          double num_old = one_numv[k];
-          int32_t den_old = one_denv[k];
-          if (sl == ins_idx) {  // refilled by this launch's insert: position p, history from zero (cache.py:754-763)
-            ps = one_pin;
-            num_old = 0.0;
-            den_old = 0;
-          }
-          const uint32_t low = ((uint32_t)sl << 1) | (uint32_t)(ps == -1);
-          unsigned long long key_k = ~0ull;
-          if (a.num) {
-            if (a.attn_out) ElemTraits<T>::store(reinterpret_cast<T*>(a.attn_out), i, av);
-            const double num_new = num_old + (double)av;
-            const int32_t den_new = den_old + 1;
-            a.num[i] = num_new;
-            a.denom[i] = den_new;
-            float scn = __fdiv_rn((float)num_new, (float)(den_new < 1 ? 1 : den_new));
-            if (ps < a.g || ps >= p_next - a.w) scn = 1.0f;
-            if (ps == -1) scn = 0.0f;
-            key_k = make_key(orderable_f32(scn), low);
-          } else if (a.policy == 2) {
-            if (sl >= a.g) key_k = make_key(orderable_i32(ps), low);
-          } else {
-            float scn = a.rand_next ? one_rndv[k] : cc_rng_uniform(a.rng_seed, p_next, sl);
-            if (ps >= p_next - a.w) scn = INFINITY;
-            if (sl < a.g) scn = INFINITY;
-            if (ps == -1) scn = -INFINITY;
-            key_k = make_key(orderable_f32(scn), low);
-          }
-          my_key = key_k < my_key ? key_k : my_key;
-        }
-    }
-    const int hyb_cts_n = hyb_cts + (hyb_kind == 0 ? 1 : 0);  // hybrid: the head's count after this step's insert
-    if constexpr (HYB) {
-      // ---- hybrid: ring column / exact window sum / denominator of every slot (cache.py:716-723 with W = 400), then the head's
-      //      candidate for position p + 1 (cache.py:844-894) — decode_attn_combine_kernel's operations in its order, on all lanes
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      const int32_t p_next = one_pin + 1;
-      const size_t hs = (size_t)a.H * S;
-      // opaque constants born HERE: the compiler otherwise hoists `denom + 1` and the mask tests up into the block that issues the
-      // state loads (same condition, operands defined there) — with a wait for each load right behind its issue
-      int late_one = 1, late_ff = 0xff;
-      asm volatile("" : "+s"(late_one), "+s"(late_ff));
-#pragma unroll
-      for (int k = 0; k < HSL; k++)
-        if (hyb_valid(k) && !hrc_skip) {
-          const int sl = hyb_slot(k);
-          const size_t i = (size_t)h * S + sl;
-          int32_t ps = hy_ps[k];
-          uint32_t msk = (a.hyb.special_mask && (hy_sp[k] & late_ff) ? 1u : 0u) | (a.hyb.punc_mask && (hy_pu[k] & late_ff) ? 2u : 0u);
-          if (sl == ins_idx) {  // this launch's insert: position p (dropped tokens too, :1006-1007), punctuation flag :1011-1016
-            ps = one_pin;
-            if (hyb_punc && a.hyb.punc_mask) msk |= 2u;
-          }
-          const float av = sm_hav[wave][lane + 64 * k];
-          if (a.attn_out) ElemTraits<T>::store(reinterpret_cast<T*>(a.attn_out), i, av);
-          float ws = 0.f;
-          int32_t dn = 1;
-          if (a.ring_num) {
-            WAcc racc{hy_a01[k].x, hy_a01[k].y, hy_a23[k].x, hy_a23[k].y};
-            T old_e;
-            old_e.x = hy_old[k];
-            const float old_v = ElemTraits<T>::load(&old_e, 0);
-            T* shadow = reinterpret_cast<T*>(a.ring_acc + hs * 4 + 2) + (size_t)one_rcol * hs;
-            ElemTraits<T>::store(reinterpret_cast<T*>(a.ring_num), i * (size_t)a.ring_W + one_rcol, av);
-            ElemTraits<T>::store(shadow, i, av);
-            dn = hy_den[k] + late_one;
-            a.denom[i] = dn;
-            wacc_add_value(racc, av, false);
-            wacc_add_value(racc, old_v, true);
-            *reinterpret_cast<ulonglong2*>(a.ring_acc + i * 4) = make_ulonglong2(racc.w0, racc.w1);
-            *reinterpret_cast<ulonglong2*>(a.ring_acc + i * 4 + 2) = make_ulonglong2(racc.w2, racc.special);
-            ws = wacc_round<T>(racc);
-            a.ring_wsum[i] = ws;
-          }
-          const int flags = hy_flags;
-          if ((flags & (HF_HH | HF_WIN)) && !(flags & HF_FULL) && sl < (hyb_cts_n < S ? hyb_cts_n : S)) {
-            float scn;
-            if (flags & HF_HH) {
-              const int32_t d = dn > a.hyb.W ? a.hyb.W : dn;  // clamp_max only (:868-870)
-              scn = __fdiv_rn(ws, (float)d);
-            } else {
-              scn = (float)ps;  // :873
-            }
-            bool save = sl < a.g || ((flags & HF_SPECIAL) && (msk & 1u)) || ((flags & HF_PUNC) && (msk & 2u));  // :876-883
-            if (flags & HF_WIN) save |= ps > p_next - hy_win;  // :885-889 strict
-            if (save) scn = INFINITY;
-            const unsigned long long key = make_key(orderable_f32(scn), (uint32_t)sl << 1);
-            my_key = key < my_key ? key : my_key;
-          }
-        }
-    }
-    // one key per WAVE (a head's key row has room for NW per 64-slot workgroup): nothing crosses the waves after the last
-    // barrier of the finish, so no wave's stores wait for another wave (the launch ends a store round trip after the LAST
-    // store is issued: every store that can go out early shortens it)
-    unsigned long long wk = wave_min_u64_uniform(my_key);
-    auto store_key = [&]() {
-      if (lane == 0) {
-        unsigned long long* nk_row = const_cast<unsigned long long*>(a.next_key) + (size_t)h * a.nk;
-        const int e0 = split * NW + wave;
-        nk_row[e0] = wk;  // every key of this row was consumed before its readers published: no reader is left
-        for (int s2 = e0 + ns * NW; s2 < a.nk_read; s2 += ns * NW) nk_row[s2] = ~0ull;  // entries beyond nk_read are never read
-      }
-    };
-    bool failed = false;  // EML: the head's step is not committed by this launch (somebody gave up)
-    if constexpr (EML) {
-      __builtin_amdgcn_sched_barrier(0);
-      // L2X, level two: the kv heads' maxima (lane = kv head), one wave per workgroup, through memory — requested here, behind the
-      // partial-O round (issued above), polled with it
-      const bool hm_mine = L2X && wave == NW - 1;
-      const int hm_off = hm_base + (lane < a.H ? lane : 0) * 16;
-      auto ok_hm = [&]() { return !hm_mine || lane >= a.H || (hmq[0] == hm_ep + 1u && hmq[2] == hm_ep + 1u); };
-      if constexpr (L2X) {
-        if (hm_mine) hmq = __builtin_amdgcn_raw_buffer_load_b128(ml_rsrc, hm_off, 0, kOneAuxCoherent);
-      }
-      for (unsigned spins = 0;; spins++) {
-        if (__all(ok_o()) && __all(ok_hm())) break;
-        if (RC && failq == tag) break;  // a workgroup of this head gave up: the head's step is not committed, nothing left to wait for
-        if (spins > kOneSpinMax) {
-          timed_out = true;
-          break;
-        }
-        __builtin_amdgcn_s_sleep(1);
-        asm volatile("" ::: "memory");  // every round re-reads memory
-        load_o();
-        if constexpr (L2X) {
-          if (hm_mine) hmq = __builtin_amdgcn_raw_buffer_load_b128(ml_rsrc, hm_off, 0, kOneAuxCoherent);
-        }
-      }
-      if (a.trace) trE = __builtin_amdgcn_s_memtime();
-      if (timed_out) give_up();
-      else if (failq == tag && lane == 0) sm_fail = 1u;  // another workgroup of this head gave up: nothing of the head's step is committed
-      stash_o();
-      if constexpr (L2X) {
-        if (hm_mine) {  // the maximum over all kv heads (NaN propagates: torch.max)
-          const float v = lane < a.H ? __uint_as_float(hmq[1]) : -INFINITY;
-          const bool gn = __any(lane < a.H && (hmq[3] != 0u || v != v)) != 0;
-          const float gm = wave_max_uniform(v);
-          if (lane == 0) sm_gmax = gn ? NAN : gm;
-        }
-      }
-      __syncthreads();  // (also makes the verdict workgroup-uniform)
-      failed = sm_fail != 0u;
-      if (!failed) {
-        y_fold();
-        if constexpr (L2X) {  // the slots' next-eviction keys, now that the maximum is here (no history to update: l2 keeps none)
-          all_tiles(all_tiles, IntC<0>{});
-          wk = wave_min_u64_uniform(my_key);
-        }
-        if (!rc_replay) {  // the step's state, behind the last gather and the fail word
-          if constexpr (RC) {
-#pragma unroll
-            for (int ti = 0; ti < NT; ti++)
-              if (def_i[ti] >= 0) {
-                a.num[def_i[ti]] = def_num[ti];
-                a.denom[def_i[ti]] = def_den[ti];
-              }
-          }
-          store_key();
-        }
-      }
-    } else {
-      failed = hrc_failed;
-      if (!hrc_skip) store_key();
-      if (a.trace) trE = __builtin_amdgcn_s_memtime();
-    }
-    if (threadIdx.x == 0) {
-      if (split == 0 && !failed) {
-        a.one_hdr[h] = tag;  // all n_split workgroups of this head have published, hence read the old epoch
-        if constexpr (HYB) {
-          if (!rc_replay) {  // (recoverable form: a head that committed this position before does not count twice)
-            a.cache_cts[h] = hyb_cts_n;  // every workgroup of this head has read the old count (it decided before it published)
-            // the step counter and num_punc are read by the workgroups of EVERY head: the head that completes the set commits them
-            const unsigned t = atomicAdd(&a.one_hdr[kOneTicketWord], 1u);
-            if (t == (unsigned)a.H - 1u) {
-              a.one_hdr[kOneTicketWord] = 0u;
-              if (a.ring_num && a.hh_counter) *a.hh_counter += 1;               // cache.py:723
-              if (hy_punc && a.hyb.num_punc) *a.hyb.num_punc += 1;              // cache.py:1017, once per step
-            }
-          }
-        } else if (!rc_replay) {
-          if (h == 0 && a.hh_counter) *a.hh_counter += 1;
-          if ((EML || NRC) && a.commit) {  // recoverable hand-off: the head's count travels with split 0's commit
-            if (ins_was_empty && (a.Hc == a.H || h == 0)) a.cache_cts[a.Hc == a.H ? h : 0] += 1;  // (one writer per count)
-          }
-        }
-      }
-      if constexpr (RC || NRC) {  // this workgroup's part of the step (its slots' history, its keys) is committed
-        if (!failed && !rc_replay && a.commit) a.commit[(size_t)h * kRcStride + 2 + split] = one_pin;
-      }
-      if (a.trace) {
-        unsigned long long* tr = a.trace + (size_t)(h * ns + split) * 16;
-        tr[0] = tr0; tr[1] = tr1; tr[2] = tr2; tr[3] = tr3; tr[4] = tr4; tr[5] = __builtin_amdgcn_s_memtime();
-        tr[6] = rt0;
-        tr[7] = rt1;
-        tr[8] = __builtin_amdgcn_s_memrealtime();
-        tr[9] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID
-        tr[10] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));  // HW_REG_XCC_ID[3:0]
-        tr[11] = trA; tr[12] = trB; tr[13] = trC;  // wave 0: K arrived / scores ready / P.V issued
-        tr[14] = trD; tr[15] = trE;                // finish: final (M, L) + weights in LDS / slots, y chains and keys done
-      }
-    }
-    return;
-  }
-  for (int t = threadIdx.x; t < RT * D; t += NW * 64) {
-    const int r = t / D, d = t - r * D;
-    float M = sm_wm[0][r];
-#pragma unroll
-    for (int w = 1; w < NW; w++) M = fmaxf(M, sm_wm[w][r]);
-    const float Mu = (M == -INFINITY) ? 0.f : M;
-    float L = 0.f, O = 0.f;
-#pragma unroll
-    for (int w = 0; w < NW; w++) {  // fixed order: deterministic
-      const float f = fast_exp(sm_wm[w][r] - Mu);
-      L = fmaf(sm_wl[w][r], f, L);
-      O = fmaf(sm_wacc[w][r][d], f, O);
-    }
-    if (a.abl & 16) {  // measurement only: merge but do not store the partials
-      if (O + L == 1.2345f) a.part_ml[0] = L;
-      continue;
-    }
-    const size_t pj = (size_t)(q0 + r) * a.n_split + split;
-    a.part_o[pj * D + d] = O;
-    if (d == 0) *reinterpret_cast<float2*>(a.part_ml + pj * 2) = make_float2(M, L);
-  }
-}
 
 struct CombineArgs {
   const void* scores;
@@ -2949,10 +457,10 @@ static int rows_per_iter(int D, int dtype, int nw = kNW) {
 // The step of ONE cache must always get the same plan, whichever form (one launch, two, three calls) and whatever rides the
 // streaming pass (plain attention, l2, hybrid, the fused quantised cache): its partials — hence the last bits of (M, L) — depend on
 // the geometry.
-static int g_wide_enabled = 1;  // cc_decode_step_set_wide: 8-wave workgroups where the plan allows them
+static std::atomic<int> g_wide_enabled{1};  // cc_decode_step_set_wide: 8-wave workgroups where the plan allows them (process-wide A/B switch)
 static Plan make_plan_w(int HQ, int H, int S, int D, int dtype, bool wide_allowed);
 static Plan make_plan(int HQ, int H, int S, int D, int dtype, bool narrow = false) {
-  return make_plan_w(HQ, H, S, D, dtype, !narrow && g_wide_enabled != 0);
+  return make_plan_w(HQ, H, S, D, dtype, !narrow && g_wide_enabled.load(std::memory_order_relaxed) != 0);
 }
 static Plan make_plan_w(int HQ, int H, int S, int D, int dtype, bool wide_allowed) {
   Plan p;
@@ -3079,13 +587,15 @@ extern "C" {
 
 namespace {
 // ---- single-launch layer step: shape eligibility, workspace regions, residency
-// Workspace layout: [epoch words + timeout word: 4 KiB][(m, l) + l2 norm granules: 32 heads x 9 KiB][O granules: 32 heads x 512 KiB][two-launch scratch].
+// Workspace layout: [epoch words + timeout word: 4 KiB][(m, l) + l2 norm granules: 32 heads x 9 KiB][O granules: 32 heads x 512 KiB]
+//                   [QKV granules: 32 heads x 5 KiB][two-launch scratch].
 // The single-launch regions sit at FIXED offsets and fixed capacities, whatever the shape: caches of different lengths
 // (pyramid budgets) share one workspace and one set of epoch words, tags grow monotonically across all of them, and
 // nothing but the single-launch kernel ever writes a word that could be mistaken for a tag.
 constexpr size_t kOneHdrBytes = 4096, kOneMlCap = (size_t)kOneMaxHeads * (kOneMlHead + kOneNmHead) + 4096 /* kOneHmBytes, padded */,
-                 kOneOCap = (size_t)kOneMaxHeads * kOneOHead;
-constexpr size_t kOneBytes = kOneHdrBytes + kOneMlCap + kOneOCap;
+                 kOneOCap = (size_t)kOneMaxHeads * kOneOHead,
+                 kOneQCap = (size_t)kOneMaxHeads * kOneQHead;  // r5: the fused QKV projection's granules (behind the O granules)
+constexpr size_t kOneBytes = kOneHdrBytes + kOneMlCap + kOneOCap + kOneQCap;
 constexpr int kOneStatusWord = 1023;  // hdr[0 .. H): epochs; hdr[1023]: timeout word
 constexpr int kOneMaxTiles = 16;  // tiles per wave the single-launch step keeps scores for (NT = 4, 8 or 16 instantiations; hybrid: up to 8)
 // tiles per wave of the single-launch step for this shape: 1 = the specialised single-tile form, 2 .. 8 = the multi-tile form
@@ -3273,7 +783,7 @@ struct XccProbe {
   std::atomic<int> state{0};  // 0 unknown, 1 verified, 2 refuted / failed
 };
 static XccProbe g_xcc_probe[kMaxDevices];
-static int g_l2_handoff_enabled = 1;  // cc_decode_step_set_l2_handoff
+static std::atomic<int> g_l2_handoff_enabled{1};  // cc_decode_step_set_l2_handoff
 
 __global__ void xcc_probe_kernel(unsigned* out) {
   if (threadIdx.x == 0)
@@ -3282,7 +792,7 @@ __global__ void xcc_probe_kernel(unsigned* out) {
 // -> true when the L2-resident hand-off may be used on the current device
 static bool xl2_device_ok() {
   int dev = 0;
-  if (!g_l2_handoff_enabled || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return false;
+  if (!g_l2_handoff_enabled.load(std::memory_order_relaxed) || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return false;
   return g_xcc_probe[dev].state.load(std::memory_order_acquire) == 1;
 }
 }  // namespace
@@ -3315,6 +825,24 @@ static OneKernel one_pick(int32_t HQ, int32_t H, int32_t S, int32_t D, int32_t d
   if (!k) return nullptr;
   return p.n_split * H <= one_capacity(k, p.nw * 64) ? k : nullptr;
 }
+static std::atomic<int> g_one_enabled{1};  // cc_decode_step_set_single_launch
+// The QKV form of the single-launch step (cc_attn_decode_qkv.hip): the plain 16-bit caches' single-tile step, 4 or 8 query heads per
+// kv head, model dim K <= 4096 (two 1 KiB input segments per wave), at most 64 projection rows per workgroup.  -> 0 = no,
+// 1 = memory hand-off, 2 = the XL2 placement + L2-resident hand-off
+static int qkv_pick(int32_t HQ, int32_t H, int32_t S, int32_t D, int32_t dtype, int32_t K, Plan* plan_out) {
+  if (HQ <= 0 || H <= 0 || HQ % H || S <= 0 || D != 128 || cc_dt_size(dtype) != 2 || !cc_dt_ok(dtype) || K < 8 || K % 8 || K > 4096) return 0;
+  if (!g_one_enabled.load(std::memory_order_relaxed)) return 0;
+  const Plan p = make_plan(HQ, H, S, D, dtype);
+  if (one_tiles(p, HQ, H, D, dtype) != 1 || (p.rt != 4 && p.rt != 8) || (p.nw != 4 && p.nw != 8)) return 0;
+  const int nu = (p.rt + 2) * 32;
+  if ((nu + p.n_split - 1) / p.n_split > 16) return 0;
+  if (plan_out) *plan_out = p;
+  if ((H & 7) == 0 && xl2_device_ok() && p.n_split * H <= cc_qkv_step_capacity(dtype, p.rt, p.nw, 1)) return 2;
+  return p.n_split * H <= cc_qkv_step_capacity(dtype, p.rt, p.nw, 0) ? 1 : 0;
+}
+int32_t cc_decode_step_qkv_available(int32_t HQ, int32_t H, int32_t S, int32_t D, int32_t dtype, int32_t K) {
+  return qkv_pick(HQ, H, S, D, dtype, K, nullptr) ? 1 : 0;
+}
 static int32_t one_available(int32_t HQ, int32_t H, int32_t S, int32_t D, int32_t dtype, int kind) {
   return one_pick(HQ, H, S, D, dtype, kind, false) ? 1 : 0;
 }
@@ -3327,6 +855,11 @@ int32_t cc_decode_step_quant_single_launch(int32_t HQ, int32_t H, int32_t S, int
 int32_t cc_decode_step_hybrid_single_launch(int32_t HQ, int32_t H, int32_t S, int32_t D, int32_t dtype) {
   return one_available(HQ, H, S, D, dtype, 200);
 }
+int32_t cc_decode_step_l2_single_launch(int32_t HQ, int32_t H, int32_t S, int32_t D, int32_t dtype) {
+  return one_available(HQ, H, S, D, dtype, -1);
+}
+// 1 while the fused decode steps may take their single-launch form at all (cc_decode_step_set_single_launch)
+int32_t cc_decode_step_single_launch_enabled(void) { return g_one_enabled.load(std::memory_order_relaxed) ? 1 : 0; }
 
 int32_t cc_decode_step_status_offset(void) { return kOneStatusWord * (int32_t)sizeof(unsigned); }
 int32_t cc_decode_step_commit_stride(void) { return kRcStride; }
@@ -3334,16 +867,15 @@ int32_t cc_decode_step_commit_stride(void) { return kRcStride; }
 static void* g_one_trace = nullptr;
 void cc_decode_step_trace(void* buf) { g_one_trace = buf; }
 
-static int g_one_enabled = 1;
-void cc_decode_step_set_single_launch(int32_t enabled) { g_one_enabled = enabled ? 1 : 0; }
+void cc_decode_step_set_single_launch(int32_t enabled) { g_one_enabled.store(enabled ? 1 : 0, std::memory_order_relaxed); }
 // 8-wave workgroups (one per CU) for the plain 16-bit caches that have the tiles for them (make_plan); 0 = 4-wave workgroups
 // everywhere.  Process-wide; change it only between steps of a cache whose fused pipeline is re-seeded (prepare_decode): the
 // geometry decides which entries of a head's key row are live.
-void cc_decode_step_set_wide(int32_t enabled) { g_wide_enabled = enabled ? 1 : 0; }
+void cc_decode_step_set_wide(int32_t enabled) { g_wide_enabled.store(enabled ? 1 : 0, std::memory_order_relaxed); }
 
 // The L2-resident hand-off (XL2): on by default where cc_decode_step_probe_xcd verified the device; 0 = always the memory hand-off
 // (the fallback of a step that fails with it — a kernel captured into a hipGraph keeps the form it was captured with).
-void cc_decode_step_set_l2_handoff(int32_t enabled) { g_l2_handoff_enabled = enabled ? 1 : 0; }
+void cc_decode_step_set_l2_handoff(int32_t enabled) { g_l2_handoff_enabled.store(enabled ? 1 : 0, std::memory_order_relaxed); }
 int32_t cc_decode_step_l2_handoff(void) { return xl2_device_ok() ? 1 : 0; }
 // Observe where the dispatcher puts the blocks of a 2-D grid on the CURRENT device: synchronous (its own stream, one small
 // allocation) — call it outside stream capture.  1 = block b always ran on the XCC of block b % 8 (two grid shapes, two launches
@@ -3400,6 +932,7 @@ struct FusedStep {
   int32_t* commit;  // recoverable hand-off: step_commit [H] or null
   unsigned long long rng_seed;  // policy 3 with rand_next == null: the in-kernel generator's seed
   int rng_on;
+  const QkvIn* qkv;  // r5: the layer's QKV projection rides the step (q / k_new / v_new are null; single launch or CC_ERR_UNSUPPORTED)
 };
 // The W > 1 history ring folded into the combine pass (denom / counter travel as hh_denom / hh_counter).
 struct RingHistory {
@@ -3422,7 +955,7 @@ static int attn_impl(const void* q, const void* k, const void* v, const uint8_t*
                      void* workspace, size_t workspace_bytes, cc_stream_t stream, int32_t phases, const FusedStep* fs,
                      const RingHistory* rh = nullptr) {
   CC_ENTRY();
-  if (!q || !k || !v || !y || HQ <= 0 || H <= 0 || HQ % H || S <= 0 || D <= 0 || !cc_dt_ok(dtype) || !workspace)
+  if ((!q && !(fs && fs->qkv)) || !k || !v || !y || HQ <= 0 || H <= 0 || HQ % H || S <= 0 || D <= 0 || !cc_dt_ok(dtype) || !workspace)
     return CC_ERR_BAD_ARG;
   if (hh_num && !hh_denom) return CC_ERR_BAD_ARG;
   const int R = HQ / H;
@@ -3480,10 +1013,32 @@ static int attn_impl(const void* q, const void* k, const void* v, const uint8_t*
   }
   hipStream_t st = (hipStream_t)stream;
   int rc = CC_OK;
+  if (fs && fs->qkv) {
+    // ---- the QKV form: the projection rides the single-launch step (cc_attn_decode_qkv.hip), or nothing does
+    Plan pq;
+    const int form = qkv_pick(HQ, H, S, D, dtype, fs->qkv->K, &pq);
+    const bool policy_ok = (fs->policy == 1 && hh_num && hh_denom && fs->c->Hp == H) ||
+                           ((fs->policy == 2 || (fs->policy == 3 && (fs->rand_next || fs->rng_on))) && !hh_num && fs->c->Hp == 1);
+    if (!form || !policy_ok || rh || probs_out || attn_out || sa.abl != 0 || kind != 0 || (phases & CC_PHASE_TWO_LAUNCH)) return CC_ERR_UNSUPPORTED;
+    if (pq.n_split != p.n_split || pq.nw != p.nw) return CC_ERR_UNSUPPORTED;
+    char* ob = reinterpret_cast<char*>(workspace);
+    sa.one_hdr = reinterpret_cast<unsigned*>(ob);
+    sa.one_ml = ob + kOneHdrBytes;
+    sa.one_o = ob + kOneHdrBytes + kOneMlCap;
+    sa.one_ml_bytes = (unsigned)kOneMlCap;
+    sa.one_o_bytes = (unsigned)kOneOCap;
+    sa.y = y; sa.hh_counter = hh_counter; sa.g = fs->g; sa.w = fs->w; sa.yc_chunks = p.n_chunks;
+    sa.policy = fs->policy; sa.rand_next = fs->rand_next; sa.rng_seed = fs->rng_seed;
+    sa.qkv = *fs->qkv;
+    sa.qkv.gran = ob + kOneHdrBytes + kOneMlCap + kOneOCap;
+    sa.qkv.gran_bytes = (unsigned)kOneQCap;
+    sa.qkv.HQ = HQ;
+    return cc_qkv_step_launch(&sa, sizeof(sa), dtype, p.rt, p.nw, form == 2 ? 1 : 0, p.n_split, H, st);
+  }
   // ---- single-launch layer step (heavy hitter, W == 1): phases bit CC_PHASE_ONE_LAUNCH forces it (error if the shape or
   //      the device's residency does not allow it), CC_PHASE_TWO_LAUNCH forbids it; otherwise it is used whenever it can be
   const bool one_asked = (phases & CC_PHASE_ONE_LAUNCH) != 0;
-  if (one_asked || (g_one_enabled && (phases & 3) == 3 && !(phases & CC_PHASE_TWO_LAUNCH))) {
+  if (one_asked || (g_one_enabled.load(std::memory_order_relaxed) && (phases & 3) == 3 && !(phases & CC_PHASE_TWO_LAUNCH))) {
     const bool policy_ok = fs && ((fs->policy == 1 && hh_num && hh_denom && fs->c->Hp == H) ||
                                   ((fs->policy == 2 || (fs->policy == 3 && (fs->rand_next || fs->rng_on))) && !hh_num && fs->c->Hp == 1) ||
                                   (fs->policy == 4 && fs->key_norm && !hh_num && fs->c->Hp == H) ||
@@ -3721,6 +1276,35 @@ int cc_decode_step_head_constant_rc(const cc_kv_view* c, int32_t policy, const v
   fs.commit = step_commit;
   return attn_impl(q, c->k_cache, c->v_cache, c->mask, HQ, c->H, c->S, c->D, c->dtype, scale, y, nullptr, nullptr, nullptr, nullptr,
                    nullptr, workspace, workspace_bytes, stream, 3, &fs);
+}
+
+/* The layer step with the layer's QKV projection folded in (r5): see include/coldcompress.h. */
+int cc_decode_step_qkv_rc(const cc_kv_view* c, int32_t policy, const void* wqkv, const void* bias, const void* x, const void* delta,
+                          const void* norm_w, float eps, void* h_out, const void* freqs, int32_t K, void* qkv_out,
+                          const int32_t* input_pos, double* num, int32_t* denom, int64_t* counter, const float* rand_next,
+                          uint64_t seed, uint64_t* next_key, int32_t* step_commit, int32_t global_tokens, int32_t recent_window,
+                          int32_t HQ, float scale, void* y, void* workspace, size_t workspace_bytes, cc_stream_t stream) {
+  if (!cc_view_ok(c) || !wqkv || !x || !norm_w || !input_pos || !next_key || !y || HQ <= 0 || HQ % c->H || global_tokens < 0 || K <= 0)
+    return CC_ERR_BAD_ARG;
+  switch (policy) {
+    case 1: if (!num || !denom || c->Hp != c->H || rand_next) return CC_ERR_BAD_ARG; break;
+    case 2: if (num || denom || c->Hp != 1 || global_tokens >= c->S || rand_next) return CC_ERR_BAD_ARG; break;
+    case 3: if (num || denom || c->Hp != 1) return CC_ERR_BAD_ARG; break;
+    default: return CC_ERR_BAD_ARG;
+  }
+  QkvIn qi{};
+  qi.W = wqkv; qi.bias = bias; qi.x = x; qi.delta = delta; qi.norm_w = norm_w; qi.freqs = freqs; qi.h_out = h_out; qi.qkv_out = qkv_out;
+  qi.eps = eps; qi.K = K;
+  FusedStep fs{c, nullptr, nullptr, input_pos, reinterpret_cast<unsigned long long*>(next_key), global_tokens,
+               policy == 2 ? 0 : recent_window, policy, policy == 3 ? rand_next : nullptr, nullptr};
+  if (policy == 3 && !rand_next) {
+    fs.rng_seed = seed;
+    fs.rng_on = 1;
+  }
+  fs.commit = step_commit;
+  fs.qkv = &qi;
+  return attn_impl(nullptr, c->k_cache, c->v_cache, c->mask, HQ, c->H, c->S, c->D, c->dtype, scale, y, nullptr, nullptr, num, denom,
+                   policy == 1 ? counter : nullptr, workspace, workspace_bytes, stream, 3, &fs);
 }
 
 static int decode_step_quant_impl(const cc_kv_view* c, float* qparams, int32_t n_bit, int32_t policy, const void* q, const void* k_new,

@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include "../../include/coldcompress.h"
+#include "../../include/coldcompress_debug.h"
 
 #define CC_WAVE 64
 

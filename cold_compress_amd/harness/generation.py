@@ -151,6 +151,7 @@ class GraphedDecoder:
             with torch.cuda.graph(graph):
                 self.out_tok, self.out_probs = decode_one_token(self.model, self.tok, self.pos)
             self.graph = graph
+            self._epoch = self._cache_epoch()
         finally:  # also when capture is refused (e.g. a collective that cannot be captured): the caller falls back to
             self.pos.copy_(pos0)  # eager launches and must find the state it handed in
             for c, sn, fl in zip(caches, snap, flags):
@@ -162,7 +163,19 @@ class GraphedDecoder:
                 if hasattr(c, "_ring_version"):  # ring and tracked window sums were restored together: still in step
                     c._ring_version = c._ring_tag()
 
+    def _cache_epoch(self):
+        """Moves when a cache changed something the captured steps carry by value (KVCacheRandom's per-generation seed)."""
+        return sum(int(getattr(l.attention.kv_cache, "_graph_epoch", 0)) for l in self.model.layers)
+
     def __call__(self, model, x, input_pos, next_token=None, **_):
+        if self.graph is not None:
+            for l in self.model.layers:  # (a reset cache draws its seed when its pipeline is seeded: do that BEFORE deciding)
+                c = l.attention.kv_cache
+                if hasattr(c, "_graph_epoch") and hasattr(c, "prepare_decode") and c.supports_fused_step() and not c._next_valid:
+                    self.pos.copy_(input_pos)
+                    c.prepare_decode(self.pos)
+            if self._cache_epoch() != self._epoch:
+                self.graph = None
         if self.graph is None:
             self.tok.copy_(x)
             self.pos.copy_(input_pos)
@@ -203,8 +216,8 @@ def _recover_token(model, cur_token, input_pos, decode_fn, nt, npb, forced, attn
     when the status word of the decode workspace is known to be set: the failed step committed nothing of its kv head, every later
     launch returned at once (include/coldcompress.h, cc_decode_step_heavy_hitter_rc) — so the word is cleared, the epoch words are
     advanced, and the SAME token runs again: workgroups whose part of the step is committed recompute and store nothing, the others
-    step.  From the fourth attempt on the L2-resident hand-off is switched off (memory hand-off; a captured graph is dropped and
-    captured again).
+    step.  From the FOURTH attempt on (three have failed) the L2-resident hand-off is switched off (memory hand-off; a captured graph
+    is dropped and captured again) — until the next generate() call.
     Caches whose step carries no commit words (`recoverable()` False) and a failure that persists raise.  Under tensor parallelism
     the status is the maximum over the ranks, so all ranks take every branch here together."""
     from .. import _abi
@@ -213,14 +226,23 @@ def _recover_token(model, cur_token, input_pos, decode_fn, nt, npb, forced, attn
     dev = cur_token.device
     tries = 0
     while _collective_status(dev):
-        caches = [l.attention.kv_cache for l in model.layers]
-        ok = all(callable(getattr(c, "recoverable", None)) and c.recoverable() for c in caches)
+        # every layer's step must be of the form that honours the status / commit words (a layer on the two-launch or
+        # three-call form — a per-layer budget whose shape the single launch cannot serve, single_launch = False — has stepped on
+        # garbage behind the failure and would step again on the retry)
+        from ..cache import step_is_recoverable
+
+        ok = all(step_is_recoverable(l.attention.kv_cache, l.attention.n_head) for l in model.layers)
         if not ok or tries >= max_retries:
             raise_single_launch_failure(dev)  # (clears the word; on every rank together)
         reset_single_launch_status(dev)
         tries += 1
-        if tries >= 3 and _abi.lib()["cc_decode_step_l2_handoff"]():  # (two plain retries first: a co-tenant leaves, a misplaced launch does not)
+        if tries >= 3 and _abi.lib()["cc_decode_step_l2_handoff"]():  # (attempts 1-3 as they are: a co-tenant leaves, a misplaced launch does not)
+            import warnings
+
+            warnings.warn("cold_compress_amd: a single-launch decode step failed three times; the L2-resident hand-off is switched off "
+                          "for the rest of this generation (memory hand-off); generate() switches it back on when the next one starts")
             _abi.lib()["cc_decode_step_set_l2_handoff"](0)
+            _L2_HANDOFF_OFF["by_recovery"] = True
             if hasattr(decode_fn, "graph"):
                 decode_fn.graph = None  # captured with the L2-resident form: capture again
         time.sleep(0.05 * tries)  # whatever shared the device gets a moment to leave
@@ -228,51 +250,102 @@ def _recover_token(model, cur_token, input_pos, decode_fn, nt, npb, forced, attn
     return nt, npb
 
 
+_L2_HANDOFF_OFF = {"by_recovery": False}  # the recovery path switched the L2-resident hand-off off: generate() restores it
+
+
+def _restore_l2_handoff():
+    """A transient co-tenant must not cost every later generation of the process the faster hand-off: what
+    _recover_token switched off is switched back on when the next generation starts (steps captured in a hipGraph keep the form they
+    were captured with)."""
+    if _L2_HANDOFF_OFF["by_recovery"]:
+        from .. import _abi
+
+        _abi.lib()["cc_decode_step_set_l2_handoff"](1)
+        _L2_HANDOFF_OFF["by_recovery"] = False
+
+
 class _StatusWatch:
     """One asynchronous 4-byte copy of every decode workspace's status word per token, inspected when its event has completed —
-    no device synchronisation in the decode loop (a blocking read per token serialises the host's launches with the
-    GPU's work).  Late detection is safe: launches behind a set status word do nothing, so the caches stay where the failed token
-    found them; the loop rewinds to that token."""
+    no device synchronisation in the decode loop while fewer than `depth` tokens are in flight (a blocking read per token
+    serialises the host's launches with the GPU's work).  Late detection is safe: launches behind a set status word do nothing, so
+    the caches stay where the failed token found them; the loop rewinds to that token.  The device side sits in four small methods
+    (_open / _start / _is_done / _wait_done / _status) so that the host logic — the ring, its overflow, the order of verdicts — can be
+    tested with a stand-in device (tests/test_host_logic.py)."""
 
     def __init__(self, dev, depth=16):
+        self.dev = dev
+        self.depth = depth
+        self.index = [None] * depth
+        self.pending = []   # slots in posting order
+        self.overflow = []  # verdicts taken early to free a slot (the host ran `depth` tokens ahead): handed out first, in order
+        self._open(dev)
+
+    # ---- device side
+    def _open(self, dev):
         from .. import _abi
         from ..attention_utils import _decode_workspaces
 
-        self.dev = dev
         self.off = int(_abi.lib()["cc_decode_step_status_offset"]())
-        self.depth = depth
-        self.slots = torch.zeros((depth, 8), dtype=torch.int32).pin_memory()
-        self.events = [None] * depth
-        self.index = [None] * depth
+        self.slots = torch.zeros((self.depth, 8), dtype=torch.int32).pin_memory()
+        self.events = [None] * self.depth
         self._ws = _decode_workspaces
-        self.pending = []  # slots in posting order
 
-    def post(self, token_index):
-        if len(self.pending) >= self.depth:
-            self.wait_oldest()
-        slot = next(k for k in range(self.depth) if k not in self.pending)
+    def _start(self, slot):
         wss = [w for w in self._ws(self.dev) if self.off + 4 <= w.numel()][:8]
         self.slots[slot].zero_()
         for k, w in enumerate(wss):
             self.slots[slot, k:k + 1].copy_(w[self.off:self.off + 4].view(torch.int32), non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        self.events[slot], self.index[slot] = ev, token_index
+        self.events[slot] = ev
+
+    def _is_done(self, slot):
+        return self.events[slot].query()
+
+    def _wait_done(self, slot):
+        self.events[slot].synchronize()
+
+    def _status(self, slot):
+        return int(self.slots[slot].max().item())
+
+    # ---- host logic
+    def post(self, token_index):
+        if len(self.pending) >= self.depth:
+            # the ring is full — the normal case under graph replay without terminators: the oldest verdict is WAITED for and KEPT
+            # (ADVICE r4: it used to be dropped here; had it been the failed token's, the rewind would have started one token late and
+            # the failed token's garbage would have been committed)
+            slot = self.pending[0]
+            self._wait_done(slot)
+            self.overflow.append(self._take())
+        slot = next(k for k in range(self.depth) if k not in self.pending)
+        self._start(slot)
+        self.index[slot] = token_index
         self.pending.append(slot)
 
     def _take(self):
         slot = self.pending.pop(0)
-        return self.index[slot], int(self.slots[slot].max().item())
+        return self.index[slot], self._status(slot)
 
     def ready(self):
         """-> (token_index, status) of the oldest posted token whose copy has completed, or None."""
-        if self.pending and self.events[self.pending[0]].query():
+        if self.overflow:
+            return self.overflow.pop(0)
+        if self.pending and self._is_done(self.pending[0]):
             return self._take()
         return None
 
     def wait_oldest(self):
-        self.events[self.pending[0]].synchronize()
+        if self.overflow:
+            return self.overflow.pop(0)
+        self._wait_done(self.pending[0])
         return self._take()
+
+    def outstanding(self):
+        return bool(self.pending or self.overflow)
+
+    def clear(self):
+        self.pending.clear()
+        self.overflow.clear()
 
 
 def decode_n_tokens(model, cur_token, input_pos, decode_one_token, num_new_tokens, terminator_ids=None, attn_top_k=1.0,
@@ -281,7 +354,9 @@ def decode_n_tokens(model, cur_token, input_pos, decode_one_token, num_new_token
     check is a collective plus a device synchronisation per token, so it is opt-in): watch the single-launch status word and run a
     failed token again in band (_recover_token).  With one GPU the word is read through an asynchronous copy per token and looked
     at when that copy has completed — possibly a few tokens late: the loop then rewinds to the failed token (everything launched
-    behind it did nothing)."""
+    behind it did nothing).  The loop itself never synchronises the device ONLY without `terminator_ids`: with them, `nt in
+    terminator_ids` reads the sampled token on the host every step (the reference's loop does the same, generation_utils.py:207-210),
+    and the status copy is then always complete one token later."""
     new_tokens, new_probs, incs = [], [], []
     recover = kw.pop("recover", None)
     tp = _tp_world() > 1
@@ -320,7 +395,7 @@ def decode_n_tokens(model, cur_token, input_pos, decode_one_token, num_new_token
             if not running:
                 break
             continue
-        while watch.pending:
+        while watch.outstanding():
             r = watch.ready() if running else watch.wait_oldest()
             if r is None:
                 break
@@ -330,13 +405,13 @@ def decode_n_tokens(model, cur_token, input_pos, decode_one_token, num_new_token
                 del new_tokens[f:], new_probs[f:], incs[f:]
                 cur = new_tokens[f - 1].view(1, -1) if f > 0 else tok0
                 stopped = False
-                watch.pending.clear()
+                watch.clear()
                 nt, npb = _recover_token(model, cur, input_pos, decode_one_token, None, None, forced_at(f), attn_top_k, kw)
                 commit(f, nt, npb)
                 i = f + 1
                 running = i < num_new_tokens and not stopped
                 break
-        if not running and not watch.pending:
+        if not running and not watch.outstanding():
             break
     return new_tokens, new_probs
 
@@ -348,6 +423,7 @@ def generate(model, prompt, prefill, decode_one_token, max_new_tokens, next_toke
     reference, the prefill timer is closed after a device sync (SURVEY §5 note)."""
     prompt_length = prompt.size(0)
     device, dtype = prompt.device, prompt.dtype
+    _restore_l2_handoff()
     min_cache_length = model.min_cache_length()
     max_prompt_len = min_cache_length - 1
     prefix = None

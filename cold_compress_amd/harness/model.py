@@ -8,6 +8,7 @@ Conventions that fixture F1's logits depend on (ref: model.py
   into the cache BEFORE attending (:391-411), probabilities averaged per query group (:413-418).
 """
 import math
+import os
 from collections import defaultdict
 from dataclasses import dataclass
 from typing import Any, Dict, Optional
@@ -137,6 +138,8 @@ class Attention(nn.Module):
         self.n_local_heads, self.dim = config.n_local_heads, config.dim
         self.fuse_state_update = True  # fold cache.py:690-723 into the decode attention combine pass
         self.fuse_decode_step = True   # whole update_kv + attention + update_state in one launch (two where the shape does not allow one)
+        # ... with RMSNorm + wqkv + RoPE folded into that launch where the shape allows (cc_decode_step_qkv_rc); CC_FUSE_QKV=0: A/B switch
+        self.fuse_qkv_step = os.environ.get("CC_FUSE_QKV", "1") != "0"
 
     def compress_prompt(self, input_pos, k_val, v_val, attn):
         if self.kv_cache.max_cache_length < input_pos.shape[0]:
@@ -151,6 +154,13 @@ class Attention(nn.Module):
         if fused is not None:
             delta, norm, h_out = fused
             HQ, H, D = self.n_head, self.n_local_heads, self.head_dim
+            cache = self.kv_cache
+            if (self.fuse_qkv_step and self.fuse_decode_step and attn_top_k == 1.0 and D == 128 and hasattr(cache, "qkv_step_available")
+                    and cache.supports_fused_step() and cache.qkv_step_available(HQ, x.shape[-1])):
+                # ONE launch for norm + wqkv + RoPE + update_kv + attention + update_state: the cache's K / V rows stream in the
+                # shadow of the projection's weights (q / k / v bit-identical to the two launches below)
+                y = cache.decode_step_qkv(self.wqkv.weight, self.wqkv.bias, x, delta, norm.weight, norm.eps, h_out, freqs_cis, input_pos, HQ)
+                return glue.gemv_fused(self.wo.weight, y).view(1, 1, -1)
             qkv = glue.gemv_fused(self.wqkv.weight, x, delta=delta, norm_weight=norm.weight, eps=norm.eps, h_out=h_out,
                                   bias=self.wqkv.bias, freqs=freqs_cis, rope_rows=(HQ + H) * D, head_dim=D)
             q = qkv[: HQ * D].view(1, HQ, 1, D)

@@ -294,11 +294,6 @@ int cc_decode_step_heavy_hitter_ring(const cc_kv_view* c, const void* q, const v
 #define CC_PHASE_ONE_LAUNCH 0x20000
 int32_t cc_decode_step_single_launch(int32_t HQ, int32_t H, int32_t S, int32_t D, int32_t dtype);
 int32_t cc_decode_step_status_offset(void);
-/* Process-wide switch (default 1): 0 makes every fused decode step (heavy hitter, recent_global / full, random, l2) use the
- * two-launch form — what tests compare the single launch against.  The head-constant policies (recent_global, full,
- * random: cc_decode_step_recent_global / cc_decode_step_random) and l2 (cc_decode_step_l2: every workgroup also gathers every
- * workgroup's norm maximum) take the single launch under the same conditions (l2: at most 768 workgroups, 32 kv heads). */
-void cc_decode_step_set_single_launch(int32_t enabled);
 /* The heavy-hitter layer step with the RECOVERABLE hand-off (r3; per-workgroup commit words r4): cc_decode_step_heavy_hitter_phases
  * plus `step_commit`, int32 [H, cc_decode_step_commit_stride()] on the device, all -1 = nothing committed (reset it whenever
  * positions restart).  ref: the reference has no hand-off to time out (cache.py:725-765, 716-722); this is what makes ours safe.
@@ -322,17 +317,28 @@ int cc_decode_step_heavy_hitter_rc(const cc_kv_view* c, const void* q, const voi
                                    uint64_t* next_key, int32_t* step_commit, int32_t global_tokens, int32_t recent_window,
                                    int32_t HQ, float scale, void* y, void* workspace, size_t workspace_bytes,
                                    cc_stream_t stream, int32_t phases);
-/* Test hook: n_workgroups one-wave workgroups that hold lds_bytes (256 .. 163840) of LDS each and idle for `microseconds`
- * (<= 5 s) — what a co-tenant kernel does to the residency of a single-launch step (tests/test_gpu_recovery.py).  scratch: >= 4
- * bytes of device memory. */
-int cc_debug_occupy(int32_t n_workgroups, int32_t lds_bytes, int32_t microseconds, void* scratch, cc_stream_t stream);
-/* Wide geometry (r3): ONE 8-wave workgroup per CU (128 cache rows each) instead of two 4-wave ones, for the plain 16-bit
- * caches (heavy hitter / recent_global / full / random, 4 or 8 query heads per kv head, head_dim 128) that have 16-row
- * tiles for it (H * S / 16 >= 1280 and H * ceil(S / 128) <= 256: Llama-3-8B at cache_len 2560 .. 4096).  On by default;
- * process-wide.  The geometry decides the split partials (hence the last bits of y and of the probabilities) and which
- * entries of a head's key row are live: all forms of one cache's step (one launch, two, three calls) follow the switch
- * together; flip it only where the fused pipeline is re-seeded (prepare_decode / cc_hh_next_key_init). */
-void cc_decode_step_set_wide(int32_t enabled);
+/* The layer step WITH THE LAYER'S QKV PROJECTION FOLDED IN (r5) — ref: model.py:375-387 (wqkv, split, apply_rotary_emb), :452-457
+ * (RMSNorm), then :389-427 as cc_decode_step_*_rc.  One launch: every workgroup requests the weight rows of its share of its kv
+ * head's projection AHEAD of its K / V tile (the tile does not depend on q), computes them with cc_gemv_fused's arithmetic — the
+ * residual add x + delta in the model dtype (h_out <- it, may be NULL), RMSNorm in fp32 with two roundings, fp32 dot chains in
+ * cc_gemv_fused's order, bias, the Linear's rounding, RoPE on the (even, odd) pairs of the q and k rows: q / k_new / v_new are
+ * bit-identical to cc_gemv_fused(wqkv, ..., rope_rows = (HQ + H) * D) — hands them to the head's workgroups through tagged
+ * granules (the step's own transports) and runs the recoverable single-launch step on them; the cache's 2 * H * S * D * 2 bytes
+ * stream in the shadow of the (HQ + 2H) * D * K * 2 bytes of weights.
+ *   wqkv [(HQ + 2H) * D, K] row major (q heads, k heads, v heads), bias [(HQ + 2H) * D] or NULL, x / delta (may be NULL) /
+ *   norm_w [K], freqs [D / 2, 2] (cos, sin) of *input_pos in the model dtype (NULL: no RoPE), qkv_out [(HQ + 2H) * D] or NULL
+ *   (a plain copy of the projection; nothing in the step reads it).
+ *   policy: 1 = heavy hitter (num, denom, counter; c->Hp == H), 2 = recent_global / full, 3 = random (rand_next or, NULL, the
+ *   in-kernel draws of `seed`) — the arguments of cc_decode_step_heavy_hitter_rc / cc_decode_step_head_constant_rc.
+ * Shapes: cc_decode_step_qkv_available(HQ, H, S, D, dtype, K) != 0 — 16-bit caches, D = 128, HQ / H in {4, 8}, one 16-row tile
+ * per wave, K % 8 == 0 and K <= 4096, all workgroups resident; CC_ERR_UNSUPPORTED otherwise (the caller runs cc_gemv_fused and
+ * the plain step).  A retry of a failed token recomputes the projection (x and delta are not modified: idempotent). */
+int32_t cc_decode_step_qkv_available(int32_t HQ, int32_t H, int32_t S, int32_t D, int32_t dtype, int32_t K);
+int cc_decode_step_qkv_rc(const cc_kv_view* c, int32_t policy, const void* wqkv, const void* bias, const void* x, const void* delta,
+                          const void* norm_w, float eps, void* h_out, const void* freqs, int32_t K, void* qkv_out,
+                          const int32_t* input_pos, double* num, int32_t* denom, int64_t* counter, const float* rand_next,
+                          uint64_t seed, uint64_t* next_key, int32_t* step_commit, int32_t global_tokens, int32_t recent_window,
+                          int32_t HQ, float scale, void* y, void* workspace, size_t workspace_bytes, cc_stream_t stream);
 /* The L2-resident hand-off of the single-launch step (r4).  ref: nothing in the reference corresponds — it is HOW the one launch that
  * replaces cache.py:725-765 + model.py:395-418 + cache.py:716-722 exchanges its partials.  On a device whose dispatcher puts block b
  * of a launch on XCD b % 8 (MI355X in SPX mode), a cache with a multiple of 8 kv heads runs its single-tile step with kv head =
@@ -344,31 +350,14 @@ void cc_decode_step_set_wide(int32_t enabled);
  * (cc_decode_step_probe_xcd) before the form is ever chosen.  Should it not hold for some launch, a head's workgroups do not see each
  * other's granules: the bounded wait ends the step as a hand-off timeout (status word, nothing committed by the recoverable kinds),
  * a workgroup that gives up sets the head's fail word and its peers stop waiting when they read it, and the harness retries — from
- * the third attempt on with the memory hand-off.
- *   cc_decode_step_probe_xcd: synchronous, call OUTSIDE stream capture (the Python layer does so when it loads the library and when
- *     it creates a decode workspace); 1 = verified for the current device (cached; two grid shapes, four launches), 0 = refuted or
+ * the fourth attempt on with the memory hand-off (until the next generation).
+ *   cc_decode_step_probe_xcd: synchronous, call OUTSIDE stream capture (the Python layer does so when it creates a decode
+ *     workspace on a device); 1 = verified for the current device (cached; two grid shapes, four launches), 0 = refuted or
  *     not probed -> memory hand-off.
- *   cc_decode_step_set_l2_handoff(0): process-wide off switch (the fallback after a failed step; a step captured into a hipGraph
- *     keeps the form it was captured with).  cc_decode_step_l2_handoff(): 1 if enabled AND verified on the current device. */
+ *   cc_decode_step_l2_handoff(): 1 if enabled (cc_decode_step_set_l2_handoff, include/coldcompress_debug.h) AND verified on the
+ *     current device. */
 int32_t cc_decode_step_probe_xcd(void);
-void cc_decode_step_set_l2_handoff(int32_t enabled);
 int32_t cc_decode_step_l2_handoff(void);
-/* Measurement hook: buf = device buffer of [workgroups][16] uint64, or NULL (default).  While set, thread 0 of every
- * workgroup of a single-launch step records [0..5] s_memtime stamps (start, streaming done, published, sentinel seen,
- * gathered, end), [6..8] s_memrealtime at start / streaming done / end, [9] HW_ID, [10] XCC_ID, [11..13] s_memtime of wave 0
- * when its K rows have arrived / its scores are in registers / its P.V products are issued, [14..15] s_memtime of thread 0 behind the
- * two barriers of the finish. */
-void cc_decode_step_trace(void* buf);
-/* Measurement hook: the launch floor of the layer step over cache `c` — a kernel with the step's grid, workgroup size and
- * K/V access pattern (every row read once with the step's 16-byte non-temporal loads) and NOTHING else.  Its duration is what
- * any stand-alone launch streaming this cache costs on the device (launch boundary + first byte + transfer): bench.py times
- * it beside the step (roofline.launch_floor_us, frac_of_launch_floor).  16-bit caches with head_dim 128; scratch: >= 4 bytes
- * of device memory (never written in practice). */
-int cc_decode_step_stream_floor(const cc_kv_view* c, int32_t HQ, void* scratch, cc_stream_t stream);
-/* ... with the geometry given (measurement hook, r4: profiles/r04_step_geometry_H1.jsonl): `waves` in {1, 2, 4, 8} waves per workgroup,
- * `rows_per_workgroup` cache rows each (a multiple of 16 * waves) — what a launch costs that streams the cache in smaller pieces on
- * more CUs (few kv heads per rank: tp.py:151-154). */
-int cc_decode_step_stream_floor_geom(const cc_kv_view* c, int32_t waves, int32_t rows_per_workgroup, void* scratch, cc_stream_t stream);
 /* The two-launch step for KVCacheHybrid (FastGen per-head policies; cache.py:896-1019 + the fused ring update of
  * cc_decode_attn_gqa_ring): three launches -> two.  What a head does with the incoming token — append at the end of its
  * live slots, evict its candidate, or drop the token (slot S - 1, mask untouched) — depends on its policy, its count, the
@@ -414,22 +403,6 @@ int cc_decode_step_hybrid_rc(const cc_kv_view* c, const void* q, const void* k_n
  * Bit-identical to the two-launch step in every buffer but y (one rounding, as for the other policies).
  * cc_decode_step_set_single_launch(0) switches it off; the status word is shared with the other single-launch steps. */
 int32_t cc_decode_step_hybrid_single_launch(int32_t HQ, int32_t H, int32_t S, int32_t D, int32_t dtype);
-/* Measurement hook (cf. cc_decode_attn_gqa_phases): the same step with its launches selectable. */
-int cc_decode_step_heavy_hitter_phases(const cc_kv_view* c, const void* q, const void* k_new, const void* v_new,
-                                const int32_t* input_pos, double* num, int32_t* denom, int64_t* counter,
-                                uint64_t* next_key, int32_t global_tokens, int32_t recent_window, int32_t HQ,
-                                float scale, void* y, void* attn_out, void* workspace, size_t workspace_bytes,
-                                cc_stream_t stream, int32_t phases);
-
-/* Measurement hook: the same operation with its two launches selectable, so that bench.py can bracket the
- * dominant kernel alone with HIP events.  phases: 1 = split kernel only (K/V streaming pass),
- * 2 = combine kernel only (needs a prior phase-1 call on the same workspace), 3 = both (== cc_decode_attn_gqa). */
-int cc_decode_attn_gqa_phases(const void* q, const void* k, const void* v, const uint8_t* mask, int32_t HQ,
-                              int32_t H, int32_t S, int32_t D, int32_t dtype, float scale, void* y,
-                              void* attn_out, void* probs_out, double* hh_num, int32_t* hh_denom,
-                              int64_t* hh_counter, void* workspace, size_t workspace_bytes,
-                              cc_stream_t stream, int32_t phases);
-
 /* ------------------------------------------------------------------------------------------------
  * Quantised KV cache, --cache_bits {8, 4, 2}.  ref: quantization_utils.py:4-98 (quantize_tensor /
  * dequantize_tensor with axis = 2), KVCache.quantize_cache / dequantize_cache cache.py:283-309, called around
@@ -509,6 +482,12 @@ int cc_decode_step_quant_rc(const cc_kv_view* c, float* qparams, int32_t n_bit, 
                             int32_t recent_window, int32_t HQ, float scale, void* y, void* workspace, size_t workspace_bytes,
                             cc_stream_t stream, int32_t phases);
 int32_t cc_decode_step_quant_single_launch(int32_t HQ, int32_t H, int32_t S, int32_t D, int32_t dtype, int32_t n_bit);
+/* ... and for the l2 step (cc_decode_step_l2[_rc]); cc_decode_step_single_launch_enabled: 1 while the process-wide switch
+ * (cc_decode_step_set_single_launch, include/coldcompress_debug.h) allows the single-launch forms at all.  Together with the
+ * per-kind queries they tell a caller which FORM a step call will take: only the single-launch forms read the status / commit words
+ * of the recoverable hand-off (the two-launch and three-call forms have nothing that can time out and ignore them). */
+int32_t cc_decode_step_l2_single_launch(int32_t HQ, int32_t H, int32_t S, int32_t D, int32_t dtype);
+int32_t cc_decode_step_single_launch_enabled(void);
 
 /* ------------------------------------------------------------------------------------------------
  * Prefill-time cache fill.  ref: KVCache._prefill_update / _fill_contiguous cache.py:381-401.

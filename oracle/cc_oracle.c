@@ -1930,3 +1930,39 @@ int cc_decode_step_head_constant_rc_cpu(const cc_kv_view* c, int32_t policy, con
     }
   return rc;
 }
+
+/* The layer step with the layer's QKV projection in front of it (include/coldcompress.h: cc_decode_step_qkv_rc) — ref: model.py:375-387
+ * (wqkv -> split -> apply_rotary_emb on q and k), then :389-427.  On the CPU simply the two restatements in sequence: cc_gemv_fused_cpu
+ * (the projection is a tolerance class: fp32 summation order unspecified) and the recoverable step twin.  The device's single launch is
+ * a scheduling matter; "available" here only restates the shape rule. */
+int32_t cc_decode_step_qkv_available_cpu(int32_t HQ, int32_t H, int32_t S, int32_t D, int32_t dt, int32_t K) {
+  return HQ > 0 && H > 0 && HQ % H == 0 && (HQ / H == 4 || HQ / H == 8) && S > 0 && D == 128 && (dt == CC_DT_BF16 || dt == CC_DT_F16) &&
+         K >= 8 && K % 8 == 0 && K <= 4096;
+}
+int cc_decode_step_qkv_rc_cpu(const cc_kv_view* c, int32_t policy, const void* wqkv, const void* bias, const void* x, const void* delta,
+                              const void* norm_w, float eps, void* h_out, const void* freqs, int32_t K, void* qkv_out,
+                              const int32_t* input_pos, double* num, int32_t* denom, int64_t* counter, const float* rand_next,
+                              uint64_t seed, uint64_t* next_key, int32_t* step_commit, int32_t g, int32_t w, int32_t HQ, float scale,
+                              void* y, void* workspace, size_t workspace_bytes, cc_stream_t stream) {
+  if (!view_ok(c) || !wqkv || !x || !norm_w || !input_pos || !next_key || !y || HQ <= 0 || HQ % c->H || K <= 0) return CC_ERR_BAD_ARG;
+  const int N = (HQ + 2 * c->H) * c->D;
+  const size_t es = c->dtype == CC_DT_F32 ? 4 : 2;
+  char* qkv = (char*)malloc((size_t)N * es);
+  if (!qkv) return CC_ERR_BAD_ARG;
+  int rc = cc_gemv_fused_cpu(wqkv, NULL, x, delta, norm_w, eps, h_out, bias, freqs, freqs ? (HQ + c->H) * c->D : 0, c->D, qkv, N, K,
+                             c->dtype, stream);
+  if (rc == CC_OK) {
+    if (qkv_out) memcpy(qkv_out, qkv, (size_t)N * es);
+    const void* q = qkv;
+    const void* kn = qkv + (size_t)HQ * c->D * es;
+    const void* vn = qkv + (size_t)(HQ + c->H) * c->D * es;
+    if (policy == 1)
+      rc = cc_decode_step_heavy_hitter_rc_cpu(c, q, kn, vn, input_pos, num, denom, counter, next_key, step_commit, g, w, HQ, scale, y,
+                                              workspace, workspace_bytes, stream, 3);
+    else
+      rc = cc_decode_step_head_constant_rc_cpu(c, policy, q, kn, vn, input_pos, rand_next, seed, next_key, step_commit, g, w, HQ, scale,
+                                               y, workspace, workspace_bytes, stream);
+  }
+  free(qkv);
+  return rc;
+}

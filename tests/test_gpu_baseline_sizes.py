@@ -1,0 +1,158 @@
+"""Parity AT the BASELINE configurations' sizes, all kv heads, against the oracle (VERDICT r4 "next" #3):
+
+  * C3 / headline: (H, HQ, S) = (8, 32, 4096), 64 decode steps of the single-launch heavy-hitter layer step, device and oracle
+    each on their own numeric state (the 6-step pipeline test of test_gpu_fused_step.py stays as the quick one);
+  * C4(ii): heavy_hitter + pyramid budgets at their REAL per-layer cache lengths — 2036, 1916, ..., 308, 256: 29 distinct
+    lengths, none but the last a multiple of 16 (ragged last tiles, ragged splits) — 16 own-state steps per length, 8 kv heads;
+  * C5, one rank of Llama-3-70B at TP = 8 (H = 1, HQ = 8): the 32768-token prefill with the SnapKV side outputs, the compaction
+    to S = 3488 (max_cache_length 0.1 of 34816) and 16 own-state decode steps.
+  (C2 — 8192 -> 2560 on all 8 kv heads — is the second parameter set of
+   test_gpu_fullsize.py::test_heavy_hitter_prefill_to_decode_without_state_sync.)
+
+Every test prints how many evictions it accepted as rounding-level near-ties (`n_just`, near-tie rule of DESIGN §3).
+ref: generation_utils.py:279-321 (pyramid), prompt_compression.py:148-194 (SnapKV), cache.py:690-765, attention_utils.py:36-54."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import from_np, hh_own_state_steps, to_np
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+BF16_ULP = 2.0 ** -8
+
+
+@pytest.fixture()
+def oracle_mt(oracle):
+    oracle.set_threads(min(16, os.cpu_count() or 1))
+    yield oracle
+    oracle.set_threads(1)
+
+
+def _mk(H, S, D, dtype, g=4, w=10, max_seq=None):
+    import cold_compress_amd.cache as cache
+
+    with torch.device(DEV):
+        return cache.KVCacheHeavyHitter(1, H, D, dtype, max_cache_length=S, max_seq_length=max_seq or 4 * S, cache_bits=None,
+                                        global_tokens=g, history_window_size=1, recent_window=w, attn_thresholding=False)
+
+
+def _seeded(H, S, D, dtype, seed, T, g=4, w=10):
+    """A cache prefilled with T random rows and a random positive history, and the oracle's copy of that state."""
+    kv = _mk(H, S, D, dtype, g, w)
+    gen = torch.Generator().manual_seed(seed)
+    kv.update_kv(torch.arange(T, device=DEV), (1.5 * torch.randn(1, H, T, D, generator=gen)).to(dtype).to(DEV),
+                 torch.randn(1, H, T, D, generator=gen).to(dtype).to(DEV), True)
+    kv.attn_history_num[0, :, :T, 0] = torch.rand(H, T, generator=gen, dtype=torch.float64).to(DEV)
+    kv.attn_history_denom[0, :, :T] = torch.randint(1, 5, (H, T), generator=gen, dtype=torch.int32).to(DEV)
+    st = dict(k=to_np(kv.k_cache.cpu()[0]), v=to_np(kv.v_cache.cpu()[0]), pos=kv.pos.cpu()[0].numpy().copy(),
+              mask=kv.mask.cpu()[0, :, 0].numpy().astype(np.uint8), cts=kv.cache_cts.cpu().numpy().copy(),
+              num=kv.attn_history_num.cpu()[0, :, :, 0].numpy().copy(), denom=kv.attn_history_denom.cpu()[0].numpy().copy(),
+              ctr=np.zeros(1, np.int64))
+    return kv, st, gen
+
+
+def test_headline_shape_64_own_state_steps(oracle_mt, audit):
+    """(8, 32, 4096): the single-launch step on the wide geometry with the L2-resident hand-off, 64 steps = 512 evictions."""
+    H, HQ, S, D, g, w, dtype = 8, 32, 4096, 128, 4, 10, torch.bfloat16
+    kv, st, gen = _seeded(H, S, D, dtype, 41, S - 5, g, w)  # five appends first, then evictions
+    assert kv.single_launch_active(HQ)
+    justified, total = hh_own_state_steps(oracle_mt, kv, st, gen, S + 11, 64, HQ, g, w, dtype)
+    audit(f"n_just = {justified} of {total} evictions (limit 5 %)")
+    assert justified <= 0.05 * total
+    assert kv.step_status(HQ) == 0
+
+
+PYRAMID_C4 = [2036, 1916, 1852, 1796, 1732, 1668, 1604, 1548, 1484, 1420, 1364, 1300, 1236, 1172, 1116, 1052, 988, 932, 868, 804, 740,
+              684, 620, 556, 500, 436, 372, 308, 256]
+
+
+def test_pyramid_budget_is_the_references():
+    """The list above IS what the harness derives for C4(ii) (heavy_hitter_pyramid.yaml: 1024 on average, 16384 + 2048 tokens, 32
+    layers); the budget arithmetic itself is pinned to the reference by tests/golden/f8_budgets.json."""
+    from cold_compress_amd.harness.generation import apply_pyramid_pattern, normalize_cache_length
+
+    lens = apply_pyramid_pattern(normalize_cache_length(1024.0, 16384 + 2048), 16384 + 2048, 32)
+    assert sorted(set(lens), reverse=True) == PYRAMID_C4 and lens[-4:] == [256] * 4 and len(lens) == 32
+
+
+@pytest.mark.parametrize("S", PYRAMID_C4)
+def test_pyramid_lengths_own_state_steps(oracle_mt, audit, S):
+    H, HQ, D, g, w, dtype = 8, 32, 128, 4, max(1, min(10, S)), torch.bfloat16
+    kv, st, gen = _seeded(H, S, D, dtype, 1000 + S, S, g, w)
+    justified, total = hh_own_state_steps(oracle_mt, kv, st, gen, 16384 + 3, 16, HQ, g, w, dtype)
+    audit(f"n_just = {justified} of {total} evictions (limit 5 %)")
+    assert justified <= 0.05 * total + 1
+    assert kv.step_status(HQ) == 0
+
+
+def test_c5_rank_prefill_32k_compaction_and_decode(oracle_mt, audit):
+    """One TP = 8 rank of the 70B shape: H = 1 kv head, 8 query heads, 32768-token prompt, cache 3488."""
+    import cold_compress_amd.cache as cache
+    from cold_compress_amd.attention_utils import prefill_attention
+    from cold_compress_amd.prompt_compression import get_prompt_compressor_constructor
+
+    o = oracle_mt
+    o.set_threads(min(64, os.cpu_count() or 1))  # (one kv head: the row loop is the only parallelism there is)
+    L, S, H, R, D, g, w, dtype, steps = 32768, 3488, 1, 8, 128, 4, 10, torch.bfloat16, 16
+    HQ, code = H * R, 1
+    gen = torch.Generator().manual_seed(321)
+    q = (1.5 * torch.randn(1, HQ, L, D, generator=gen)).to(dtype)
+    k = (1.5 * torch.randn(1, H, L, D, generator=gen)).to(dtype)
+    v = torch.randn(1, H, L, D, generator=gen).to(dtype)
+    cls, rk = cache.get_cache_constructor("heavy_hitter")
+    kw = dict(max_cache_length=S, global_tokens=g, max_seq_length=L + 2048, cache_bits=None, recent_window=w, history_window_size=1,
+              attn_thresholding=False)
+    with torch.device(DEV):
+        kv = cls(1, H, D, dtype, **{x: kw[x] for x in rk})
+    comp = get_prompt_compressor_constructor("heavy_hitter")(head_specific=True, **{x: kw[x] for x in rk})
+    kd, vd = k.to(DEV), v.to(DEV)
+    y, summ = prefill_attention(q.to(DEV), kd, vd, return_attn=True)
+    keep, kc, vc, state = comp(torch.arange(L, device=DEV), kd, vd, attn=summ)
+    kv.update_kv(keep, kc, vc, True)
+    kv.update_state(keep, kc, vc, True, state)
+    torch.cuda.synchronize()
+    yo, cs, ob = np.zeros((HQ, L, D), np.uint16), np.zeros((H, L), np.float32), np.zeros((H, L), np.float32)
+    o.call("cc_prefill_attn", o.ptr(to_np(q[0])), o.ptr(to_np(k[0])), o.ptr(to_np(v[0])), HQ, H, L, D, code, 1.0 / math.sqrt(D),
+           o.ptr(yo), o.ptr(cs), o.ptr(ob), 16, None, 0, None)
+    yref = from_np(yo, dtype).float()
+    assert float((y.cpu().float()[0] - yref).abs().max()) <= 1e-3 + 2 * BF16_ULP * float(yref.abs().max()), "prefill y"
+    err = (summ.colsum.cpu() - torch.from_numpy(cs)).abs()
+    assert bool((err <= 5e-2 + BF16_ULP * torch.from_numpy(cs).abs()).all()), f"column sums: {float(err.max())}"
+    assert float((summ.obs_mean.cpu() - torch.from_numpy(ob)).abs().max()) < 4e-3
+    # ---- the keep set under the tie contract, then the oracle continues with the device's set and its own column means
+    obs_dt = to_np(torch.from_numpy(ob).to(dtype))
+    prio = np.zeros((H, L), np.uint16)
+    o.call("cc_snapkv_priority", o.ptr(obs_dt), H, L, code, 16, g, o.ptr(prio), None)
+    keep_o = np.zeros((H, S), np.int64)
+    o.call("cc_topk_keep", o.ptr(prio), 1, H, L, S, o.ptr(keep_o), None, 0, None)
+    keep_d = keep.cpu().numpy().reshape(H, S)
+    pf = from_np(prio, dtype).float().numpy()
+    for h in range(H):
+        a, b = set(keep_d[h].tolist()), set(keep_o[h].tolist())
+        if a != b:
+            kth = np.sort(pf[h])[-S]
+            d = np.array(sorted(a ^ b))
+            assert bool((np.abs(pf[h][d] - kth) <= 2 * BF16_ULP * abs(kth) + 1e-30).all()), f"head {h}: non-tie keep members differ"
+            assert len(d) <= 0.02 * S
+    keep_use = np.ascontiguousarray(keep_d)
+    ko, vo = np.zeros((H, S, D), np.uint16), np.zeros((H, S, D), np.uint16)
+    o.call("cc_gather_rows", o.ptr(to_np(k[0])), o.ptr(keep_use), H, H, L, S, D, code, o.ptr(ko), None)
+    o.call("cc_gather_rows", o.ptr(to_np(v[0])), o.ptr(keep_use), H, H, L, S, D, code, o.ptr(vo), None)
+    assert np.array_equal(ko, to_np(kv.k_cache.cpu()[0]))
+    mean = np.zeros((H, L), np.uint16)
+    o.call("cc_colsum_to_mean", o.ptr(cs), None, H, L, code, o.ptr(mean), None)
+    st0 = np.zeros((H, S), np.uint16)
+    o.call("cc_gather_vec", o.ptr(mean), o.ptr(keep_use), H, L, S, code, o.ptr(st0), None)
+    st = dict(k=ko, v=vo, pos=keep_use.astype(np.int32).copy(), mask=np.ones((H, S), np.uint8), cts=np.array([S], np.int32),
+              num=np.zeros((H, S), np.float64), denom=np.zeros((H, S), np.int32), ctr=np.zeros(1, np.int64))
+    o.call("cc_hh_update", o.ptr(st["num"]), o.ptr(st["denom"]), o.ptr(st["ctr"]), o.ptr(st0), H, S, S, code, None)
+    assert np.allclose(kv.attn_history_num.cpu()[0, :, :, 0].numpy(), st["num"], rtol=2 * BF16_ULP, atol=1e-6)
+    o.set_threads(1)
+    justified, total = hh_own_state_steps(o, kv, st, gen, L, steps, HQ, g, w, dtype)
+    audit(f"n_just = {justified} of {total} evictions (limit 5 %)")
+    assert justified <= 0.05 * total + 1
+    assert kv.step_status(HQ) == 0

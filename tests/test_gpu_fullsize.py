@@ -18,7 +18,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import from_np, to_np
+from helpers import from_np, hh_own_state_steps, to_np
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -174,8 +174,9 @@ def test_hybrid_profiling_full_size(oracle_mt):
     assert (y.cpu().float()[0] - yr).abs().max() <= 0.05 * yr.abs().max()
 
 
-def test_heavy_hitter_prefill_to_decode_without_state_sync(oracle_mt, audit):
-    """8192-token prompt -> SnapKV compaction to 4096 -> history from the column means -> 48 decode steps of the fused
+@pytest.mark.parametrize("S,H", [(4096, 2), (2560, 8)])  # C3's length on a head subset; C2 (max_cache_length 0.25 -> 2560) on ALL 8 kv heads (r5)
+def test_heavy_hitter_prefill_to_decode_without_state_sync(oracle_mt, audit, S, H):
+    """8192-token prompt -> SnapKV compaction to S -> history from the column means -> 48 decode steps of the fused
     step, device and oracle each continuing from THEIR OWN numeric state (nothing is copied across after the prompt's
     keep set has been checked)."""
     import cold_compress_amd.cache as cache
@@ -183,7 +184,7 @@ def test_heavy_hitter_prefill_to_decode_without_state_sync(oracle_mt, audit):
     from cold_compress_amd.prompt_compression import get_prompt_compressor_constructor
 
     o = oracle_mt
-    L, S, H, R, D, g, w, dtype, steps = 8192, 4096, 2, 4, 128, 4, 10, torch.bfloat16, 48
+    L, R, D, g, w, dtype, steps = 8192, 4, 128, 4, 10, torch.bfloat16, 48
     HQ, code = H * R, 1
     gen = torch.Generator().manual_seed(77)
     q = (1.5 * torch.randn(1, HQ, L, D, generator=gen)).to(dtype)
@@ -237,50 +238,10 @@ def test_heavy_hitter_prefill_to_decode_without_state_sync(oracle_mt, audit):
     assert np.allclose(num_d, st["num"], rtol=2 * BF16_ULP, atol=1e-6), "prefill history beyond one rounding of the column means"
     assert np.array_equal(kv.attn_history_denom.cpu()[0].numpy(), st["denom"])
     # ---- decode: both sides on their own state; a differing eviction must be a near-tie in the ORACLE's scores, and is then
-    #      followed (the oracle is made to evict the device's slot) so that the caches stay comparable
-    justified = total = 0
-    for t in range(steps):
-        p = L + t
-        pt = torch.tensor([p], dtype=torch.int32)
-        k1 = (1.5 * torch.randn(1, H, 1, D, generator=gen)).to(dtype)
-        v1 = torch.randn(1, H, 1, D, generator=gen).to(dtype)
-        q1 = (1.5 * torch.randn(1, HQ, 1, D, generator=gen)).to(dtype)
-        pos_before = kv.pos.cpu()[0].numpy().copy()
-        yd = kv.decode_step(q1.to(DEV), k1.to(DEV), v1.to(DEV), pt.to(DEV))
-        torch.cuda.synchronize()
-        pos_after = kv.pos.cpu()[0].numpy()
-        idx_d = np.array([int(np.nonzero(pos_after[h] != pos_before[h])[0][0]) for h in range(H)])
-        # the oracle's scores for this position (cache.py:727-749)
-        dn = np.maximum(st["denom"], 1).astype(np.float32)
-        sc = (st["num"].astype(np.float32) / dn).astype(np.float32)
-        sc[(st["pos"] < g) | (st["pos"] >= p - w)] = 1.0
-        sc[st["pos"] == -1] = 0.0
-        idx_o = sc.argmin(axis=1)
-        for h in range(H):
-            total += 1
-            if idx_d[h] != idx_o[h]:
-                gap = float(sc[h, idx_d[h]] - sc[h, idx_o[h]])
-                assert 0 <= gap <= 2 * BF16_ULP * float(sc[h, idx_o[h]]) + 1e-12, f"step {t} head {h}: evicted {idx_d[h]} (score gap {gap})"
-                justified += 1
-                st["num"][h, idx_d[h]] = -1.0  # make the oracle follow the device's (equally good) choice
-        view = o.view(st["k"], st["v"], st["pos"], st["mask"], st["cts"], code)
-        idx = np.zeros(H, np.int64)
-        o.call("cc_decode_update_heavy_hitter", C.byref(view), o.ptr(to_np(k1.reshape(H, D))), o.ptr(to_np(v1.reshape(H, D))),
-               o.ptr(pt.numpy().copy()), o.ptr(st["num"]), o.ptr(st["denom"]), g, w, o.ptr(idx), None)
-        assert np.array_equal(idx, idx_d)
-        yo1 = np.zeros((HQ, D), np.uint16)
-        o.call("cc_decode_attn_gqa", o.ptr(to_np(q1.reshape(HQ, D))), o.ptr(st["k"]), o.ptr(st["v"]), o.ptr(st["mask"]), HQ, H, S, D, code,
-               1.0 / math.sqrt(D), o.ptr(yo1), None, None, o.ptr(st["num"]), o.ptr(st["denom"]), o.ptr(st["ctr"]), None, 0, None)
-        yr = from_np(yo1, dtype).float()
-        assert (yd.cpu().float()[0, :, 0] - yr).abs().max() <= 1e-3 + 2 * BF16_ULP * yr.abs().max(), f"step {t}: y"
-        assert np.array_equal(pos_after, st["pos"]), f"step {t}: positions"
+    #      followed (the oracle is made to evict the device's slot) so that the caches stay comparable (tests/helpers.py)
+    justified, total = hh_own_state_steps(o, kv, st, gen, L, steps, HQ, g, w, dtype)
     audit(f"n_just = {justified} of {total} evictions (limit 5 %)")
     assert justified <= 0.05 * total, f"{justified} of {total} evictions were near-tie divergences"
-    num_d = kv.attn_history_num.cpu()[0, :, :, 0].numpy()
-    assert np.array_equal(kv.attn_history_denom.cpu()[0].numpy(), st["denom"])
-    # drift of the float64 history after `steps` unsynchronised steps: each step adds one bf16-rounded probability per slot
-    assert np.allclose(num_d, st["num"], rtol=2 * BF16_ULP, atol=steps * 2.0 ** -16), float(np.abs(num_d - st["num"]).max())
-    assert np.array_equal(to_np(kv.k_cache.cpu()[0]), st["k"])
     assert kv.step_status(HQ) == 0
 
 

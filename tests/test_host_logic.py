@@ -161,8 +161,12 @@ def test_abi_exports_every_declared_symbol():
 
     so = _build.build()
     header = open(os.path.join(ROOT, "include", "coldcompress.h")).read()
-    declared = set(re.findall(r"\b(cc_[a-z0-9_]+)\s*\(", header))
+    debug = open(os.path.join(ROOT, "include", "coldcompress_debug.h")).read()  # measurement / test hooks and the A/B switches (r5)
+    decl = lambda text: set(re.findall(r"^(?:int|int32_t|size_t|void|const char\*)\s+(cc_[a-z0-9_]+)\s*\(", text, re.M))  # noqa: E731
+    declared = decl(header) | decl(debug)
     assert declared == set(_abi.SIGNATURES), declared ^ set(_abi.SIGNATURES)
+    # the boundary header carries no hook and no process-wide setter
+    assert not [n for n in decl(header) if "_set_" in n or "debug" in n or "trace" in n or n.endswith("_phases") or "stream_floor" in n]
     lib = C.CDLL(so)
     fns = _abi.bind(lib)  # raises AttributeError if a symbol is missing
     assert fns["cc_abi_version"]() == 1
@@ -276,35 +280,54 @@ def test_decode_loop_rewinds_to_a_late_detected_failed_token(monkeypatch):
     from cold_compress_amd.harness import generation as G
 
     calls = []
+    real_watch = G._StatusWatch  # (run() patches the module attribute)
+
+    live = {"state": None, "fail_at": None, "n": 0}
 
     def step(model, x, pos, next_token=None, attn_top_k=1.0, **kw):
         calls.append((int(x.view(-1)[0]), int(pos[0])))
         t = torch.tensor([(int(x.view(-1)[0]) * 7 + int(pos[0])) % 101], dtype=torch.int32)
+        st = live["state"]
+        # the fake device: the failing token's launch and every launch behind a set status word produce GARBAGE (they did nothing)
+        k = int(pos[0]) - 40
+        if st is not None and (st["set"] or (k == live["fail_at"] and not st["failed_once"])):
+            t = torch.tensor([977], dtype=torch.int32)
         return (next_token if next_token is not None else t), torch.ones(1)
 
-    def run(fail_at, lag, n=12, terminators=None):
+    def run(fail_at, lag, n=12, terminators=None, depth=64):
         """The fake device: token `fail_at` (first attempt only) sets the word; it becomes visible `lag` tokens later."""
         state = {"set": False, "failed_once": False}
+        live["state"], live["fail_at"] = state, fail_at
 
-        class Watch:
+        class Watch(real_watch):
+            """The REAL ring / overflow / ordering logic over a stand-in device: a verdict is `done` once `lag` later tokens were posted."""
+
             def __init__(self, dev):
-                self.pending, self.posted = [], {}
+                super().__init__(dev, depth=depth)
 
-            def post(self, i):
+            def _open(self, dev):
+                self.values, self.started, self.n_posted = {}, {}, 0
+
+            def _start(self, slot):
+                i = self.n_posted  # (tokens are posted in order; a rewind restarts the count through clear())
                 if i == fail_at and not state["failed_once"]:
                     state["set"], state["failed_once"] = True, True
-                self.pending.append(i)
-                self.posted[i] = state["set"]  # (sticky: every later token sees it too)
+                self.values[slot] = int(state["set"])  # (sticky: every later token sees it too)
+                self.started[slot] = i
+                self.n_posted += 1
 
-            def ready(self):
-                if self.pending and len(self.pending) > lag:
-                    i = self.pending.pop(0)
-                    return i, int(self.posted[i])
-                return None
+            def post(self, token_index):
+                self.n_posted = token_index
+                super().post(token_index)
 
-            def wait_oldest(self):
-                i = self.pending.pop(0)
-                return i, int(self.posted[i])
+            def _is_done(self, slot):
+                return self.n_posted - 1 - self.started[slot] >= lag
+
+            def _wait_done(self, slot):
+                pass
+
+            def _status(self, slot):
+                return self.values[slot]
 
         def recover(model, cur, pos, fn, nt, npb, forced, top_k, kw, max_retries=6):
             assert state["set"]
@@ -324,6 +347,13 @@ def test_decode_loop_rewinds_to_a_late_detected_failed_token(monkeypatch):
         for lag in (0, 1, 3, 20):
             got, e = run(fail_at, lag)
             assert got == clean and e == end, (fail_at, lag, got, clean, e)
+    # the host runs further ahead than the ring is deep (graph replay, no terminators): the verdict taken early to free a slot must
+    # not be lost (it was — a failure seen only on token f + 1 committed token f's garbage)
+    for depth in (1, 2, 4):
+        for fail_at in (0, 3, 7, 11):
+            for lag in (depth, depth + 1, 3 * depth, 40):
+                got, e = run(fail_at, lag, depth=depth)
+                assert got == clean and e == end, (depth, fail_at, lag, got, clean, e)
     # a terminator behind the failed token: the rewound run stops where the clean one does, without the position bump of the stop
     stop = clean[6]
     c2, e2 = run(None, 0, terminators=[stop])
