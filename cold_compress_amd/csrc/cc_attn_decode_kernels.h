@@ -33,6 +33,9 @@
 #define CC_QKV_TILE_AT 2  // QKV step: where the K / V tile is requested — 0: ahead of the weights, 1: behind the first two units' requests,
                           // 2: behind the LAST unit's request (A/B, r5)
 #endif
+#ifndef CC_QKV_DEPTH
+#define CC_QKV_DEPTH 2  // QKV step: 4-row weight units (8 loads per lane each) in flight per wave: 2 or 3 (A/B, r5)
+#endif
 #ifndef CC_QKV_TRACE
 #define CC_QKV_TRACE 0  // 1 (measurement builds of cc_attn_decode_qkv.hip only): thread 0 of every workgroup stamps the phases of the QKV step
 #endif
@@ -1074,7 +1077,9 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
   // load, 4 us later; every wave reading the whole vector instead — 18 loads per lane in front of the weights — delayed the first
   // weight request by 1 us)
   Vec16<T> q_xa[QXS], q_da[QXS], q_nv[QXS];
-  uint4 q_w[2][4][QXS];  // two units (4 rows x QXS segments each) in flight per lane: see the rounds below
+  constexpr int QDEPTH = CC_QKV_DEPTH;
+  static_assert(QDEPTH == 2 || QDEPTH == 3, "two or three weight units in flight");
+  uint4 q_w[QDEPTH][4][QXS];  // QDEPTH units (4 rows x QXS segments each) in flight per lane: see the rounds below
   uint32_t q_fr_raw = 0;  // the finishing lane's (cos, sin) pair and bias, raw (converted where used)
   uint16_t q_bi_raw = 0;
   auto q_unit_row = [&](int unit) {  // first projection row (of W) of the head's granule unit `unit`
@@ -1430,6 +1435,9 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
       }
     }
     if (q_nmine > 1) q_issue_w(IntC<1>{}, 1);  // (the second unit: behind the barrier — in front of it, only 14 requests per lane are out)
+    if constexpr (QDEPTH == 3) {
+      if (q_nmine > 2) q_issue_w(IntC<2>{}, 2);
+    }
     __builtin_amdgcn_sched_barrier(0);
     qstamp(3);
     // rounds: unit ul of this half is consumed from buffer ul & 1 while unit ul + 1 is in flight; unit ul + 2 is requested into the
@@ -1446,15 +1454,19 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
         if (lane == 0) sm_qpart[q_w4][(q_mine0 + ul) * 4 + t] = sres;
       }
     };
-    int q_ul = 0;
-    for (; q_ul + 2 < q_nmine; q_ul++) {
-      if (q_ul & 1) {
-        q_consume(IntC<1>{}, q_ul);
-        q_issue_w(IntC<1>{}, q_ul + 2);
-      } else {
+    int q_ul = 0, q_slot = 0;  // q_slot = q_ul % QDEPTH
+    for (; q_ul + QDEPTH < q_nmine; q_ul++) {
+      if (q_slot == 0) {
         q_consume(IntC<0>{}, q_ul);
-        q_issue_w(IntC<0>{}, q_ul + 2);
+        q_issue_w(IntC<0>{}, q_ul + QDEPTH);
+      } else if (q_slot == 1) {
+        q_consume(IntC<1>{}, q_ul);
+        q_issue_w(IntC<1>{}, q_ul + QDEPTH);
+      } else {
+        q_consume(IntC<QDEPTH - 1>{}, q_ul);
+        q_issue_w(IntC<QDEPTH - 1>{}, q_ul + QDEPTH);
       }
+      q_slot = q_slot + 1 == QDEPTH ? 0 : q_slot + 1;
     }
     if constexpr (CC_QKV_TILE_AT == 2) {
       issue_k(tregs[0], base);
@@ -1462,8 +1474,10 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
       __builtin_amdgcn_sched_barrier(0);
     }
     for (; q_ul < q_nmine; q_ul++) {
-      if (q_ul & 1) q_consume(IntC<1>{}, q_ul);
-      else q_consume(IntC<0>{}, q_ul);
+      if (q_slot == 0) q_consume(IntC<0>{}, q_ul);
+      else if (q_slot == 1) q_consume(IntC<1>{}, q_ul);
+      else q_consume(IntC<QDEPTH - 1>{}, q_ul);
+      q_slot = q_slot + 1 == QDEPTH ? 0 : q_slot + 1;
     }
     qstamp(4);
     // (the counter was zeroed at the top of the kernel, a barrier ago)

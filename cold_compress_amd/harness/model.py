@@ -138,8 +138,10 @@ class Attention(nn.Module):
         self.n_local_heads, self.dim = config.n_local_heads, config.dim
         self.fuse_state_update = True  # fold cache.py:690-723 into the decode attention combine pass
         self.fuse_decode_step = True   # whole update_kv + attention + update_state in one launch (two where the shape does not allow one)
-        # ... with RMSNorm + wqkv + RoPE folded into that launch where the shape allows (cc_decode_step_qkv_rc); CC_FUSE_QKV=0: A/B switch
-        self.fuse_qkv_step = os.environ.get("CC_FUSE_QKV", "1") != "0"
+        # ... with RMSNorm + wqkv + RoPE folded into that launch where the shape allows (cc_decode_step_qkv_rc).  OPT-IN (CC_FUSE_QKV=1 or
+        # this attribute): bit-identical results, and at the benchmark's shape a tie with the two launches it replaces (r5:
+        # profiles/r05_overlap_probe.md — 18.8-19.0 us against 18.8-19.0 us per layer), so the longer-soaked pair stays the default
+        self.fuse_qkv_step = os.environ.get("CC_FUSE_QKV", "0") == "1"
 
     def compress_prompt(self, input_pos, k_val, v_val, attn):
         if self.kv_cache.max_cache_length < input_pos.shape[0]:

@@ -219,3 +219,45 @@ def test_qkv_step_vs_oracle_pipeline(oracle):
         assert err < 1e-3 + 2.0 * 2.0 ** -8 * float(yr.abs().max()), f"step {t}: y differs from the oracle by {err}"
     assert np.allclose(b.attn_history_num.cpu()[0, :, :, 0].numpy(), st["num"], rtol=2 * 2.0 ** -8, atol=6 * 2.0 ** -16)
     assert np.array_equal(to_np(b.k_cache.cpu()[0]), st["k"]) and np.array_equal(to_np(b.v_cache.cpu()[0]), st["v"])
+
+
+@pytest.mark.parametrize("strategy", ["heavy_hitter", "recent_global"])
+def test_decode_loop_with_the_qkv_form_equals_the_default_loop(strategy):
+    """The harness decode loop with Attention.fuse_qkv_step on (ONE launch for norm + wqkv + RoPE + the step) against the default
+    loop on a twin model: 12 greedy tokens after a 4300-token prompt compacted to 4096 slots — tokens, probabilities and every
+    cache buffer bit-identical (Llama-3-8B's attention shape, two layers, a small FFN and vocabulary)."""
+    import argparse
+
+    import cold_compress_amd.cache as cache
+    from cold_compress_amd.harness import ModelArgs, Transformer, decode_one_token, generate, prefill, setup_caches
+
+    cfg = dict(block_size=8192, vocab_size=512, n_layer=2, n_head=32, n_local_heads=8, dim=4096, intermediate_size=1024, rope_base=500000)
+    torch.manual_seed(5)
+    ref = Transformer(ModelArgs(**cfg)).to(torch.bfloat16).eval()
+    for p_ in ref.parameters():
+        p_.data.normal_(0.0, 0.02)
+    models = []
+    for fuse in (False, True):
+        m = Transformer(ModelArgs(**cfg)).to(torch.bfloat16).eval()
+        m.load_state_dict(ref.state_dict())
+        m = m.to(DEV)
+        ap = argparse.ArgumentParser()
+        cache.add_cache_arguments(ap)
+        kw = vars(ap.parse_args([]))
+        kw.update(cache_strategy=[strategy], prompt_compression_strategy=[strategy], max_cache_length=[4096], global_tokens=4, recent_window=10)
+        setup_caches(m, None, DEV, 4300 + 16, dict(kw))
+        for l in m.layers:
+            l.attention.fuse_qkv_step = fuse
+        models.append(m)
+    assert models[1].layers[0].attention.kv_cache.qkv_step_available(32, 4096) or pytest.skip("QKV form not eligible on this device")
+    prompt = torch.randint(0, 512, (4300,), generator=torch.Generator().manual_seed(2), dtype=torch.int32).to(DEV)
+    outs = []
+    for m in models:
+        seq, probs, _ = generate(m, prompt, prefill, decode_one_token, max_new_tokens=12)
+        torch.cuda.synchronize()
+        outs.append((seq, probs))
+    assert torch.equal(outs[0][0], outs[1][0]), "generated tokens"
+    for t, (pa, pb) in enumerate(zip(outs[0][1], outs[1][1])):
+        assert torch.equal(pa, pb), f"token {t}: probabilities"
+    for la, lb in zip(models[0].layers, models[1].layers):
+        _state_equal(la.attention.kv_cache, lb.attention.kv_cache, "end")

@@ -225,8 +225,9 @@ def test_launches_behind_a_set_status_word_do_nothing():
     assert step_committed(kv, T + 1) and kv.step_status(HQ) == 0
 
 
+@pytest.mark.parametrize("fuse_qkv", [False, True])  # (r5) True: the decode loop on the QKV form of the step — the retry recomputes the projection too
 @pytest.mark.parametrize("strategy", ["heavy_hitter", "recent_global"])
-def test_co_tenant_fault_is_recovered_in_band(strategy):
+def test_co_tenant_fault_is_recovered_in_band(strategy, fuse_qkv):
     """Two layers of the Llama-3-8B shape, heavy hitter (or recent_global: the head-constant form of the recoverable step — its kv
     heads complete one after the other here, each on its own copy of the key row) at 1024 slots: 128 workgroups per step (16 per kv head, dispatched head by
     head).  Before the fourth decode token a co-tenant kernel pins 150 KB of LDS on 232 of the 256 CUs for 2.2 s — longer than the
@@ -265,6 +266,10 @@ def test_co_tenant_fault_is_recovered_in_band(strategy):
 
     def run(fault_at):
         setup_caches(model, None, torch.device(DEV), L + 64, dict(kw))
+        for l in model.layers:
+            l.attention.fuse_qkv_step = fuse_qkv
+            if fuse_qkv:
+                assert l.attention.kv_cache.qkv_step_available(l.attention.n_head, cfg["dim"]), "the QKV form must serve this shape"
         calls = [0]
 
         def step(m, x, pos, **k2):
@@ -536,3 +541,57 @@ def test_several_tiles_co_tenant_fault_is_recovered(strategy):
         _abi.lib()["cc_decode_step_set_l2_handoff"](1)
     assert provoked, "the co-tenant kernel did not provoke a hand-off timeout in six runs: the test did not test anything"
     assert au.single_launch_status(torch.device(DEV)) == 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The QKV form of the step (cc_decode_step_qkv_rc, r5): the same recoverable hand-off, one more in-launch wait (the head's q)
+# ---------------------------------------------------------------------------------------------------------------------------
+def _qkv_layer(HQ, H, D, K, seed):
+    gen = torch.Generator(device=DEV).manual_seed(seed)
+    w = (0.02 * torch.randn((HQ + 2 * H) * D, K, device=DEV, generator=gen)).to(torch.bfloat16)
+    nw = torch.ones(K, device=DEV, dtype=torch.bfloat16)
+    fr = torch.stack([torch.ones(D // 2), torch.zeros(D // 2)], dim=-1).to(torch.bfloat16).to(DEV).contiguous()
+    return w, nw, fr, gen
+
+
+@pytest.mark.parametrize("strategy", ["heavy_hitter", "recent_global", "random"])
+def test_qkv_form_replay_and_status_word(strategy):
+    """The QKV form at the headline shape: (i) a replay of a committed position recomputes the projection and the attention and stores
+    nothing; (ii) behind a set status word the launch does nothing at all — no projection output, no insert, no state."""
+    from cold_compress_amd import _abi
+    from cold_compress_amd.attention_utils import _decode_workspaces, reset_single_launch_status, single_launch_status
+
+    H, HQ, S, D, K = 8, 32, 4096, 128, 4096
+    torch.manual_seed(3)
+    kv, T = _mk(H, S, strategy=strategy)
+    if not kv.qkv_step_available(HQ, K):
+        pytest.skip("QKV form not eligible on this device")
+    w, nw, fr, gen = _qkv_layer(HQ, H, D, K, 9)
+    for t in range(3):
+        p = torch.tensor([T + t], dtype=torch.int32, device=DEV)
+        x = torch.randn(1, 1, K, device=DEV, generator=gen).to(torch.bfloat16)
+        y1 = kv.decode_step_qkv(w, None, x, None, nw, 1e-5, None, fr, p, HQ).clone()
+        torch.cuda.synchronize()
+        assert step_committed(kv, T + t)
+        st = _state(kv)
+        y2 = kv.decode_step_qkv(w, None, x, None, nw, 1e-5, None, fr, p, HQ)  # the same position again
+        torch.cuda.synchronize()
+        assert torch.equal(y1, y2), f"step {t}: replayed y"
+        for n, b in kv.named_buffers():
+            assert torch.equal(b, st[n]), f"step {t}: replay changed {n}"
+    assert single_launch_status(kv.pos.device) == 0
+    off = int(_abi.lib()["cc_decode_step_status_offset"]())
+    ws = _decode_workspaces(kv.pos.device)[0]
+    ws[off:off + 4].view(torch.int32).fill_(1)
+    st = _state(kv)
+    p2 = torch.tensor([T + 3], dtype=torch.int32, device=DEV)
+    out = torch.full(((HQ + 2 * H) * D,), 7.0, device=DEV, dtype=torch.bfloat16)
+    kv.decode_step_qkv(w, None, x, None, nw, 1e-5, None, fr, p2, HQ, qkv_out=out)
+    torch.cuda.synchronize()
+    for n, b in kv.named_buffers():
+        assert torch.equal(b, st[n]), f"a QKV launch behind a set status word changed {n}"
+    assert bool((out == 7.0).all()), "a QKV launch behind a set status word wrote its projection"
+    reset_single_launch_status(kv.pos.device)
+    kv.decode_step_qkv(w, None, x, None, nw, 1e-5, None, fr, p2, HQ)
+    torch.cuda.synchronize()
+    assert step_committed(kv, T + 3) and single_launch_status(kv.pos.device) == 0

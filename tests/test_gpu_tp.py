@@ -40,9 +40,13 @@ def test_tp2_rccl_matches_unsharded(graph):
     assert "backend nccl world 2" in out
 
 
-def test_tp2_one_gpu_staged_collectives_matches_unsharded():
-    out = _launch(["--backend", "gloo"])
-    assert "backend gloo world 2" in out
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_tp_one_gpu_staged_collectives_matches_unsharded(world):
+    """The PRODUCT cache + attention kernels under TP = 2 / 4 / 8 of the 8B shape — 4 / 2 / 1 kv heads per rank, the shapes the ranks
+    of the 2 / 4 / 8-GPU points run (H = 1: the few-head form of the single-launch step) — every rank on cuda:0, collectives
+    staged over the host (r5: world 4 and 8; RCCL over xGMI itself still needs a multi-GPU box)."""
+    out = _launch(["--backend", "gloo"], world=world, timeout=1200)
+    assert f"backend gloo world {world}" in out
 
 
 def test_tp2_one_gpu_oneshot_allreduce_in_hipgraph():

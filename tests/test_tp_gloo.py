@@ -1,4 +1,5 @@
-"""Tensor-parallel path on CPU with the gloo backend, world_size = 2 (ref: tp.py:59-176).
+"""Tensor-parallel path on CPU with the gloo backend, world_size 2, 4 and 8 with Llama-3-8B's head counts — 32 query / 8 kv heads:
+4 / 2 / 1 kv heads per rank, the last being the `n_local_heads == 1` case the reference cannot run (ref: tp.py:59-176).
 
 What is checked without a GPU: `apply_tp` slices wqkv per q/k/v block, wo/w2 row-wise, w1/w3 column-wise, shrinks
 the head counts, and the two sum all-reduces per layer reconstruct exactly the single-process block output.
@@ -66,7 +67,9 @@ def _worker(rank, world, port, q):
 
         host_glue.install(hm.glue)  # CPU tensors: model wiring only, with test-local glue and attention doubles
         torch.manual_seed(0)
-        cfg = dict(block_size=64, vocab_size=64, n_layer=2, n_head=8, n_local_heads=4, dim=64, intermediate_size=96)
+        # Llama-3-8B's head counts at a small width: 32 query heads, 8 kv heads (head_dim 8), so that world 2 / 4 / 8 leave 4 / 2 / 1 kv
+        # heads per rank
+        cfg = dict(block_size=64, vocab_size=64, n_layer=2, n_head=32, n_local_heads=8, dim=256, intermediate_size=384)
         full = Transformer(ModelArgs(**cfg)).eval()
         sharded = Transformer(ModelArgs(**cfg)).eval()
         sharded.load_state_dict(full.state_dict())
@@ -76,22 +79,29 @@ def _worker(rank, world, port, q):
             for layer in m.layers:
                 layer.attention.kv_cache = _FullCacheDouble()
         a = sharded.layers[0].attention
-        assert (a.n_head, a.n_local_heads, a.dim, a.head_dim) == (4, 2, 32, 8)
-        assert a.wqkv.weight.shape == (32 + 16 + 16, 64) and a.wo.weight.shape == (64, 32)
+        hq, hk = 32 // world, 8 // world
+        assert (a.n_head, a.n_local_heads, a.dim, a.head_dim) == (hq, hk, hq * 8, 8)
+        assert a.wqkv.weight.shape == ((hq + 2 * hk) * 8, 256) and a.wo.weight.shape == (256, hq * 8)
         ff = sharded.layers[0].feed_forward
-        assert ff.w1.weight.shape == (48, 64) and ff.w2.weight.shape == (64, 48)
-        assert sharded.config.n_local_heads == 2  # caches will be built with H / world heads (tp.py:163-168)
+        assert ff.w1.weight.shape == (384 // world, 256) and ff.w2.weight.shape == (256, 384 // world)
+        assert sharded.config.n_local_heads == hk  # caches will be built with H / world heads (tp.py:163-168); 1 at world 8
         idx = torch.arange(12).view(1, 12) % 64
         pos = torch.arange(12)
         with torch.no_grad():
             y_full = full(idx, pos, is_prefill=True)
             y_tp = sharded(idx, pos, is_prefill=True)
         err = (y_full - y_tp).abs().max().item()
-        # the q heads this rank owns are heads [rank*4, rank*4+4) of the full model, kv heads [rank*2, rank*2+2)
-        wq_full = full.layers[0].attention.wqkv.weight[:64]
-        assert torch.equal(a.wqkv.weight[:32], wq_full[rank * 32:(rank + 1) * 32])
-        wk_full = full.layers[0].attention.wqkv.weight[64:96]
-        assert torch.equal(a.wqkv.weight[32:48], wk_full[rank * 16:(rank + 1) * 16])
+        # the q heads this rank owns are heads [rank*hq, (rank+1)*hq) of the full model, kv heads [rank*hk, (rank+1)*hk)
+        wq_full = full.layers[0].attention.wqkv.weight[:256]
+        assert torch.equal(a.wqkv.weight[: hq * 8], wq_full[rank * hq * 8:(rank + 1) * hq * 8])
+        wk_full = full.layers[0].attention.wqkv.weight[256:320]
+        assert torch.equal(a.wqkv.weight[hq * 8: (hq + hk) * 8], wk_full[rank * hk * 8:(rank + 1) * hk * 8])
+        wv_full = full.layers[0].attention.wqkv.weight[320:384]
+        assert torch.equal(a.wqkv.weight[(hq + hk) * 8:], wv_full[rank * hk * 8:(rank + 1) * hk * 8])
+        # a real collective ran: the world the JSON line of bench.py reports comes from here (dist.get_world_size() after an all-reduce)
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        assert int(t.item()) == world == dist.get_world_size()
         q.put((rank, err))
         dist.barrier()
         dist.destroy_process_group()
@@ -100,14 +110,18 @@ def _worker(rank, world, port, q):
         raise
 
 
-def test_tp2_gloo_matches_single_process():
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_tp_gloo_matches_single_process(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=180) for _ in procs]
+    res = [q.get(timeout=300) for _ in procs]
     for p in procs:
         p.join(timeout=60)
     for rank, err in res:

@@ -107,11 +107,24 @@ def main():
         agree.append(float((mine == pb).float().mean()))
     print(f"rank {rank}: fraction of cache slots holding the same position as the unsharded run, per layer: {agree}", flush=True)
     same_tokens = sum(int(x == y) for x, y in zip(outs[0][0], outs[1][0]))
+    # a differing greedy token must be a near-tie of the UNSHARDED model's own distribution (random weights: near-uniform
+    # probabilities; the all-reduce sums `world` partial residuals in another order — the more ranks, the more often the arg-max of
+    # two almost equal probabilities flips): the sharded run's token must carry, in the unsharded distribution, the maximum minus at
+    # most twice the largest difference between the two distributions at that step.  Inputs are teacher-forced: no drift.
+    near_tie = 0
+    for i, (ta, tb) in enumerate(zip(outs[0][0], outs[1][0])):
+        if ta != tb:
+            a, b = outs[0][1][i].view(-1), outs[1][1][i].view(-1)
+            gap = float(a.max() - a[tb])
+            if gap <= 2.0 * float((a - b).abs().max()):
+                near_tie += 1
+            else:
+                ok = False
     # layer 0 sees identical inputs on both runs: its evictions must agree exactly; deeper layers see a residual stream
     # rounded differently by the all-reduce, and heavy-hitter scores of random data sit in near-ties
-    ok = ok and agree[0] == 1.0 and same_tokens >= len(outs[0][0]) - 1
+    ok = ok and agree[0] == 1.0 and same_tokens + near_tie == len(outs[0][0]) and near_tie <= max(1, world // 2)
     if rank == 0:
-        print(f"backend {dist.get_backend()} world {world} graph {bool(args.graph)} oneshot {bool(args.oneshot)}: tokens equal: {same_tokens}/{len(outs[0][0])}; "
+        print(f"backend {dist.get_backend()} world {world} graph {bool(args.graph)} oneshot {bool(args.oneshot)}: tokens equal: {same_tokens}/{len(outs[0][0])} (+ {near_tie} arg-max near-ties); "
               f"TP{world} CHECK {'OK' if ok else 'FAIL'}", flush=True)
     dist.destroy_process_group()
     sys.exit(0 if ok else 1)
