@@ -30,11 +30,11 @@
 #define CC_V_KPIN 1  // the prologue's kernel arguments in one round of scalar loads, BEHIND the request of the step's words (0: left to the compiler, three rounds)
 #endif
 #ifndef CC_QKV_TILE_AT
-#define CC_QKV_TILE_AT 2  // QKV step: where the K / V tile is requested — 0: ahead of the weights, 1: behind the first two units' requests,
-                          // 2: behind the LAST unit's request (A/B, r5)
+#define CC_QKV_TILE_AT 2  // QKV step: where the K / V tile is requested — 0: ahead of the weights (20.0 us per layer at C3), 1: behind the first
+                          // unit's request (20.5), 2: behind the LAST unit's request (19.1; the product) — A/B, r5, same box
 #endif
 #ifndef CC_QKV_DEPTH
-#define CC_QKV_DEPTH 2  // QKV step: 4-row weight units (8 loads per lane each) in flight per wave: 2 or 3 (A/B, r5)
+#define CC_QKV_DEPTH 2  // QKV step: 4-row weight units (8 loads per lane each) in flight per wave: 2 (18.9 us per layer at C3) or 3 (19.6) — A/B, r5
 #endif
 #ifndef CC_QKV_TRACE
 #define CC_QKV_TRACE 0  // 1 (measurement builds of cc_attn_decode_qkv.hip only): thread 0 of every workgroup stamps the phases of the QKV step
@@ -1534,7 +1534,7 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
     qstamp(5);
   }
   int qb_ins_u = -1;  // QB: tile row (of this lane's row group) that holds the inserted token — its K chunk is UNswizzled (chunk c)
-  if constexpr (EML && !QKV) {  // (QKV: zeroed at the top of the kernel — HERE its waves are minutes apart, throttled by the memory pipe)
+  if constexpr (EML && !QKV) {  // (QKV: zeroed behind a barrier at the top of the kernel — HERE its waves are microseconds apart, each at its own weights)
     // the arrival counter of the early (m, l) hand-off starts at zero: one barrier HERE, behind the issue of every load of the
     // tile (the waves of a workgroup reach it together; nothing waits for memory)
     if (threadIdx.x == 0) {
@@ -1623,10 +1623,12 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
         sm_fail = 1u;  // (reset at the barrier above; read behind the finish's barriers: this head's step commits nothing)
       }
       uint32_t* qw = reinterpret_cast<uint32_t*>(&sm_qkv[0]);
+      const bool q_bad = q_to || q_pf;  // (wave-uniform) the step commits nothing: ZEROS instead of whatever half-arrived granules hold —
+      // y stays finite (garbage bits may be NaN: the logits behind them, the sampled token and its embedding row would follow)
 #pragma unroll
       for (int k = 0; k < QNG; k++) {
         const int G = lane + 64 * k;
-        if (G < QNU) *reinterpret_cast<uint2*>(qw + 2 * G) = make_uint2(gq[k][1], gq[k][3]);
+        if (G < QNU) *reinterpret_cast<uint2*>(qw + 2 * G) = q_bad ? make_uint2(0u, 0u) : make_uint2(gq[k][1], gq[k][3]);
       }
       qstamp(6);
     }

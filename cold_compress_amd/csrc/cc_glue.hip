@@ -300,7 +300,7 @@ __global__ __launch_bounds__(kSmThreads) void softmax_write_kernel(const T* logi
   __syncthreads();
   const float mx = sm_ml[0], sum = sm_ml[1];
   float bp = -1.f;
-  int bi = 0x7fffffff;
+  int bi = 0x7fffffff, nan_i = 0x7fffffff;
   for (int i = lo + threadIdx.x; i < hi; i += kSmThreads) {  // indices increase: the first maximal element wins
     const float p = ElemTraits<T>::rnd(__fdiv_rn(sm_exp<T>(ElemTraits<T>::load(logits, (size_t)i) - mx), sum));
     ElemTraits<T>::store(probs, (size_t)i, p);
@@ -308,15 +308,21 @@ __global__ __launch_bounds__(kSmThreads) void softmax_write_kernel(const T* logi
       bp = p;
       bi = i;
     }
+    // torch.argmax: NaN counts as the maximum, the FIRST one wins (generation_utils.py:140 on a NaN distribution returns its index,
+    // never an index past the vocabulary — r5: garbage logits behind a failed layer step used to yield -1 here, and the next token's
+    // embedding lookup asserted on the device)
+    if (p != p && nan_i == 0x7fffffff) nan_i = i;
   }
   unsigned long long best = bi == 0x7fffffff ? ~0ull : (((unsigned long long)(~orderable_f32(bp)) << 32) | (unsigned)bi);
+  if (nan_i != 0x7fffffff) best = (unsigned long long)(unsigned)nan_i;  // key 0 in the upper half: beats every number; the smallest index among NaNs
   best = block_min_u64(best, sm_k);
   if (threadIdx.x == 0) {
     atomicMin(&ws->key, best);
     __threadfence();
     if (atomicAdd(&ws->ticket, 1u) == (unsigned)gridDim.x - 1) {  // last workgroup: every key is in
       __threadfence();
-      *idx_out = (int32_t)(atomicMin(&ws->key, ~0ull) & 0xffffffffull);
+      const unsigned long long k = atomicMin(&ws->key, ~0ull);
+      *idx_out = k == ~0ull ? 0 : (int32_t)(k & 0xffffffffull);  // (nothing compared greater than -1: cannot happen for V > 0 — a valid index anyway)
     }
   }
 }

@@ -1857,13 +1857,14 @@ int cc_softmax_argmax_cpu(const void* logits, int32_t V, int32_t dt, void* probs
   double sum = 0.0;
   for (int i = 0; i < V; i++) sum += (double)expf(ld(logits, dt, (size_t)i) - mx);
   float best = -INFINITY;
-  int bi = 0;
+  int bi = 0, nan_i = -1;
   for (int i = 0; i < V; i++) {
     const float p = rnd(expf(ld(logits, dt, (size_t)i) - mx) / (float)sum, dt);
     st(probs, dt, (size_t)i, p);
     if (p > best) { best = p; bi = i; }
+    if (p != p && nan_i < 0) nan_i = i;  /* torch.argmax: NaN is the maximum, the first one wins */
   }
-  *idx_out = bi;
+  *idx_out = nan_i >= 0 ? nan_i : bi;
   return CC_OK;
 }
 

@@ -49,6 +49,11 @@ CASES = [
     ("w13_norm", 14336, 4096, dict(norm=True, delta=True, swiglu=True)), ("w2", 4096, 14336, {}),
     ("ragged", 1030, 1000, dict(norm=True)), ("ragged_pair", 77, 264, dict(swiglu=True, norm=True, delta=True)),
     ("tiny_rope_bias", 96, 64, dict(norm=True, rope=(64, 16), bias=True)), ("tp8_wo", 4096, 512, {}),
+    # r5: BASELINE C5 — the Llama-3-70B shape (dim 8192, ffn 28672, 64 / 8 heads) unsharded and as ONE rank of TP = 8 sees it
+    ("70b_wqkv", 10240, 8192, dict(norm=True, delta=True, rope=(9216, 128))), ("70b_wo", 8192, 8192, {}),
+    ("70b_w13", 28672, 8192, dict(norm=True, delta=True, swiglu=True)), ("70b_w2", 8192, 28672, {}),
+    ("c5_rank_wqkv", 1280, 8192, dict(norm=True, delta=True, rope=(1152, 128))), ("c5_rank_wo", 8192, 1024, {}),
+    ("c5_rank_w13", 3584, 8192, dict(norm=True, delta=True, swiglu=True)), ("c5_rank_w2", 8192, 3584, {}),
 ]
 
 

@@ -107,3 +107,22 @@ def test_softmax_argmax_matches_torch(dt, V):
     logits[7] = logits[V - 3] = logits.max() + 1
     probs, idx = glue.softmax_argmax(logits)
     assert int(idx) == 7
+
+
+@pytest.mark.parametrize("dt,V", [(torch.bfloat16, 128256), (torch.float32, 300)])
+def test_softmax_argmax_on_nan_logits_returns_a_valid_index(dt, V):
+    """Garbage logits (behind a failed single-launch step the attention output is whatever its buffer held) must still sample a token
+    INSIDE the vocabulary: torch.argmax treats NaN as the maximum and returns the first one's index — so does cc_softmax_argmax (r5:
+    it used to return -1, and the next token's embedding lookup asserted on the device before the host had seen the status word)."""
+    from cold_compress_amd.harness import glue
+
+    g = torch.Generator().manual_seed(1)
+    logits = (torch.randn(V, generator=g) * 3).to(dt)
+    logits[V // 2] = float("nan")  # every probability becomes NaN (the sum is NaN): the first index wins
+    probs, idx = glue.softmax_argmax(logits.to(DEV))
+    torch.cuda.synchronize()
+    ref = torch.softmax(logits.float(), dim=-1).to(dt)
+    assert 0 <= int(idx) < V and int(idx) == int(torch.argmax(ref)) == 0
+    all_nan = torch.full((V,), float("nan"), dtype=dt, device=DEV)
+    _, idx = glue.softmax_argmax(all_nan)
+    assert int(idx) == 0

@@ -137,15 +137,12 @@ def test_qkv_step_replays_in_a_hipgraph():
     h = torch.zeros_like(x)
     x.copy_(xs)
     b.prepare_decode(p)
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):  # warm-up outside capture (workspace allocation, the XCD probe)
-        pass
     graph = torch.cuda.CUDAGraph()
     yb_buf = None
+    # warm-up outside capture (workspace allocation, the XCD probe) on a third cache whose state is discarded
     twin = _mk(kind, H, S, D, dtype)
     _seed(twin, torch.Generator().manual_seed(3), T)
-    twin.decode_step_qkv(w, None, x, None, nw, 1e-5, h, fr, p, HQ)  # (allocates the workspace; its state is discarded)
+    twin.decode_step_qkv(w, None, x, None, nw, 1e-5, h, fr, p, HQ)
     torch.cuda.synchronize()
     with torch.cuda.graph(graph):
         yb_buf = b.decode_step_qkv(w, None, x, None, nw, 1e-5, h, fr, p, HQ)

@@ -49,6 +49,14 @@ def test_tp_one_gpu_staged_collectives_matches_unsharded(world):
     assert f"backend gloo world {world}" in out
 
 
+def test_tp8_c5_rank_shape_one_gpu():
+    """BASELINE C5's per-rank shapes end to end (one layer of the Llama-3-70B shape, a 4096-entry vocabulary, under TP = 8: one kv head and 8 query heads per
+    rank, model dim 8192, cache 3488 after a 3600-token prompt) — product kernels on every rank, all on cuda:0, collectives staged over
+    the host: layer-0 evictions identical to the unsharded model's on every rank, tokens equal up to counted arg-max near-ties."""
+    out = _launch(["--backend", "gloo", "--model", "Llama-3-70B-shape", "--layers", "1", "--vocab", "4096", "--cache", "3488", "--prompt", "3600"], world=8, timeout=1500)
+    assert "backend gloo world 8" in out
+
+
 def test_tp2_one_gpu_oneshot_allreduce_in_hipgraph():
     """The sharded decode step with its two all-reduces per layer on the one-shot transport (self-test against the staged
     collectives first), replayed from a hipGraph: tokens equal the unsharded model's, layer-0 evictions identical."""

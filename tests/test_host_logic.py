@@ -216,6 +216,10 @@ def test_oracle_glue_twins_match_torch_cpu(oracle):
     probs, idx = np.zeros(1000, np.float32), np.zeros(1, np.int32)
     o.call("cc_softmax_argmax", f(logits), 1000, 0, o.ptr(probs), o.ptr(idx), None, 0, None)
     assert np.allclose(probs, torch.softmax(logits, -1).numpy(), rtol=1e-5, atol=1e-8) and int(idx[0]) == 17
+    # NaN: torch.argmax returns the first NaN's index (r5: never an index outside the vocabulary)
+    logits[400] = float("nan")
+    o.call("cc_softmax_argmax", f(logits), 1000, 0, o.ptr(probs), o.ptr(idx), None, 0, None)
+    assert int(idx[0]) == int(torch.argmax(torch.softmax(logits, -1))) == 0
 
 
 def test_attn_summary_runs_reference_group_mean_unchanged():

@@ -28,6 +28,13 @@ def main():
     ap.add_argument("--backend", choices=["gloo", "nccl"], default="gloo")
     ap.add_argument("--graph", action="store_true", help="replay the sharded decode step from a hipGraph (collectives captured)")
     ap.add_argument("--oneshot", action="store_true", help="decode-size all-reduces over the one-shot transport (cc_allreduce_sum), after its self-test")
+    ap.add_argument("--model", default="Meta-Llama-3.1-8B-Instruct", help="harness.CONFIGS key; Llama-3-70B-shape = BASELINE C5 (two layers of it)")
+    ap.add_argument("--no_fuse_gemv", action="store_true", help="debugging: the sharded model's dense layers through torch (hipBLASLt)")
+    ap.add_argument("--no_fuse_step", action="store_true", help="debugging: the sharded model's caches through the three-call path")
+    ap.add_argument("--layers", type=int, default=2)
+    ap.add_argument("--vocab", type=int, default=0, help="override the vocabulary size (0: the config's) — keeps eight ranks' host copies small")
+    ap.add_argument("--cache", type=int, default=128, help="cache slots per layer (C5: 3488)")
+    ap.add_argument("--prompt", type=int, default=300, help="prompt tokens (> --cache: the prompt is compacted)")
     args = ap.parse_args()
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -52,11 +59,21 @@ def main():
             return orig(t, op=op, **kw)
 
         dist.all_reduce = staged
+    if args.backend == "gloo" and args.cache >= 1024:
+        # every rank shares cuda:0 and runs its kernels CONCURRENTLY with the others': a single-launch step needs all of its workgroups
+        # resident at once, which eight processes streaming full-size caches do not grant each other (measured, r5: hand-off timeouts,
+        # different garbage in every run — this harness drives decode_one_token without the recovery loop).  The documented switch for
+        # shared devices: the two-launch forms (same arithmetic, bit-identical cache state).
+        from cold_compress_amd import _abi
+
+        _abi.lib()["cc_decode_step_set_single_launch"](0)
     if args.oneshot:
         assert tp.enable_oneshot_allreduce() is not None, "the one-shot all-reduce did not pass its self-test"
-    cfg = dict(CONFIGS["Meta-Llama-3.1-8B-Instruct"])
-    cfg["n_layer"] = 2
-    cfg["block_size"] = 1024
+    cfg = dict(CONFIGS[args.model])
+    cfg["n_layer"] = args.layers
+    cfg["block_size"] = max(1024, args.prompt + 128)
+    if args.vocab:
+        cfg["vocab_size"] = args.vocab
     torch.manual_seed(77)
     ref = Transformer(ModelArgs(**cfg)).to(torch.bfloat16).eval()
     with torch.no_grad():
@@ -67,16 +84,20 @@ def main():
     ref = ref.to(dev)
     tp.apply_tp(sharded)
     sharded = sharded.to(dev)
-    kw = dict(max_cache_length=[128.0], cache_bits=None, cache_length_pattern="tile", cache_strategy=["heavy_hitter"],
+    for l in sharded.layers:
+        l.fuse_gemv = not args.no_fuse_gemv
+        l.attention.fuse_decode_step = not args.no_fuse_step
+    kw = dict(max_cache_length=[float(args.cache)], cache_bits=None, cache_length_pattern="tile", cache_strategy=["heavy_hitter"],
               cache_strategy_pattern="tile", feed_long_prompts=False, prompt_compression_strategy=["heavy_hitter"], global_tokens=4,
               recent_window=10, history_window_size=1, attn_thresholding=False, min_recovery_frac=0.9)
     outs = []
-    prompt = torch.randint(0, cfg["vocab_size"], (300,), generator=torch.Generator().manual_seed(3), dtype=torch.int32).to(dev)
+    L = args.prompt
+    prompt = torch.randint(0, cfg["vocab_size"], (L,), generator=torch.Generator().manual_seed(3), dtype=torch.int32).to(dev)
     for name, model in (("tp1", ref), ("tp2", sharded)):
-        setup_caches(model, None, dev, 400, dict(kw))
+        setup_caches(model, None, dev, L + 100, dict(kw))
         with torch.no_grad():
-            tok, probs = prefill(model, prompt.view(1, -1), torch.arange(300, device=dev))
-            pos = torch.tensor([300], dtype=torch.int32, device=dev)
+            tok, probs = prefill(model, prompt.view(1, -1), torch.arange(L, device=dev))
+            pos = torch.tensor([L], dtype=torch.int32, device=dev)
             toks, plist = [int(tok)], [probs.float().clone()]
             cur = tok.view(1, 1).to(torch.int32)
             step = decode_one_token
@@ -101,11 +122,12 @@ def main():
             ok = False
         if rank == 0:
             print(f"step {i}: token tp1 {outs[0][0][i]} tp2 {outs[1][0][i]}  max|dp|/max p = {rel:.4f}", flush=True)
-    agree = []
+    agree, differ = [], []
     for l, (pa, pb) in enumerate(zip(outs[0][2], outs[1][2])):
         mine = pa[:, rank * H:(rank + 1) * H]
-        agree.append(float((mine == pb).float().mean()))
-    print(f"rank {rank}: fraction of cache slots holding the same position as the unsharded run, per layer: {agree}", flush=True)
+        differ.append(int((mine != pb).sum()))
+        agree.append(1.0 if differ[-1] == 0 else 1.0 - differ[-1] / mine.numel())
+    print(f"rank {rank}: cache slots holding a different position than in the unsharded run, per layer: {differ}", flush=True)
     same_tokens = sum(int(x == y) for x, y in zip(outs[0][0], outs[1][0]))
     # a differing greedy token must be a near-tie of the UNSHARDED model's own distribution (random weights: near-uniform
     # probabilities; the all-reduce sums `world` partial residuals in another order — the more ranks, the more often the arg-max of
@@ -122,10 +144,18 @@ def main():
                 ok = False
     # layer 0 sees identical inputs on both runs: its evictions must agree exactly; deeper layers see a residual stream
     # rounded differently by the all-reduce, and heavy-hitter scores of random data sit in near-ties
-    ok = ok and agree[0] == 1.0 and same_tokens + near_tie == len(outs[0][0]) and near_tie <= max(1, world // 2)
+    # (long caches: the unsharded step and a rank's step split the cache differently — 32 x 8 waves against 55 x 4 at C5 — so the last
+    #  bit of (M, L), hence of a bf16 probability, hence a near-tie eviction may differ: at most one slot per 2048 and rank, counted)
+    ok = ok and differ[0] <= args.cache // 2048 and same_tokens + near_tie == len(outs[0][0]) and near_tie <= max(1, world // 2)
     if rank == 0:
         print(f"backend {dist.get_backend()} world {world} graph {bool(args.graph)} oneshot {bool(args.oneshot)}: tokens equal: {same_tokens}/{len(outs[0][0])} (+ {near_tie} arg-max near-ties); "
               f"TP{world} CHECK {'OK' if ok else 'FAIL'}", flush=True)
+    from cold_compress_amd.attention_utils import single_launch_status
+
+    st = int(single_launch_status(dev))
+    if st:
+        print(f"rank {rank}: a single-launch step reported a hand-off timeout (status word {st}): the comparison above is void", flush=True)
+        ok = False
     dist.destroy_process_group()
     sys.exit(0 if ok else 1)
 
