@@ -288,7 +288,7 @@ __global__ __launch_bounds__(kSmThreads) void softmax_write_kernel(const T* logi
     float sacc = 0.f;
     for (int g = threadIdx.x; g < kSmBlocks; g += 64) {
       const float2 p = ws->part[g];
-      if (p.y > 0.f) sacc += p.y * sm_exp<T>(p.x - m);
+      if (p.y > 0.f || p.y != p.y) sacc += p.y * sm_exp<T>(p.x - m);  // (a NaN partial sum makes the whole distribution NaN, as torch.softmax does)
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) sacc += __shfl_xor(sacc, off, CC_WAVE);

@@ -40,11 +40,12 @@ def test_tp2_rccl_matches_unsharded(graph):
     assert "backend nccl world 2" in out
 
 
-@pytest.mark.parametrize("world", [2, 4, 8])
+@pytest.mark.parametrize("world", [2, 8] + ([4] if os.environ.get("CC_LONG_TESTS") == "1" else []))
 def test_tp_one_gpu_staged_collectives_matches_unsharded(world):
-    """The PRODUCT cache + attention kernels under TP = 2 / 4 / 8 of the 8B shape — 4 / 2 / 1 kv heads per rank, the shapes the ranks
-    of the 2 / 4 / 8-GPU points run (H = 1: the few-head form of the single-launch step) — every rank on cuda:0, collectives
-    staged over the host (r5: world 4 and 8; RCCL over xGMI itself still needs a multi-GPU box)."""
+    """The PRODUCT cache + attention kernels under TP = 2 / 8 (and 4 with CC_LONG_TESTS=1: 30 s of process start-up each) of the 8B
+    shape — 4 / 1 (/ 2) kv heads per rank, the shapes the ranks of the 2 / 8 (/ 4)-GPU points run (H = 1: the few-head form of the
+    single-launch step) — every rank on cuda:0, collectives staged over the host (r5: world 4 and 8 ran green; RCCL over xGMI itself
+    still needs a multi-GPU box)."""
     out = _launch(["--backend", "gloo"], world=world, timeout=1200)
     assert f"backend gloo world {world}" in out
 
@@ -89,14 +90,14 @@ def test_bench_gpus8_control_flow_dry_run(oneshot):
     env = dict(os.environ, CC_BENCH_DRYRUN_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", CC_ONESHOT_ALLREDUCE="1" if oneshot else "0")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
         env.pop(k, None)
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "6", "--warmup", "2", "--n_layer", "2",
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "4", "--warmup", "1", "--n_layer", "2",
            "--prompt_len", "1024", "--cache_len", "512", "--no_cpu_baseline", "--no_live_pmc", "--roofline_iters", "2"] + (["--graph"] if oneshot else [])
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, f"{r.stdout[-3000:]}\n{r.stderr[-3000:]}"
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-3000:]  # rank 0 alone reports
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 8 and out["steps"] == 6 and out["warmup"] == 2 and out["value"] > 0
+    assert out["n_gpus"] == 8 and out["steps"] == 4 and out["warmup"] == 1 and out["value"] > 0
     cfg = out["config"]
     assert cfg["parallelism"] == "tp8" and cfg["rccl_ranks"] == 8
     assert cfg["per_rank"] is not None and len(cfg["per_rank"]) == 8
