@@ -219,11 +219,25 @@ static GvCfg pick_cfg(const GemvArgs& a, int vec) {
   }
   if (env_rb > 0 && env_cu > 0) return {env_rb, env_cu, env_cap};
   const int nseg = (a.K / vec + 63) / 64, nstep = (nseg + kGvWaves - 1) / kGvWaves;
-  // measured on MI355X (tools/bench_gemv.py): many small workgroups beat few large ones — 2 rows x 2 segments per
-  // wave for K = 4096 (wo 8.3 us, wqkv 10.5 us, w1 21.9 us = 5.35 TB/s), 4 x 4 for K = 14336 (w2 24.4 us)
+  // measured on MI355X (tools/bench_gemv.py): 2 rows x 2 segments per wave for the SwiGLU pair at K = 4096 (w1 + w3 39.5 us =
+  // 5.95 TB/s), 4 x 4 for K = 14336 (w2 20.9 us)
   GvCfg c;
   c.cap = 2048;
-  if (nstep <= 2) {
+  if (nstep <= 2 && a.W3 == nullptr) {
+    // r5 (same-box sweeps, tools/bench_gemv.py with CC_GEMV_CFG, two repetitions each): 4 rows per workgroup and 1024 workgroups — 8
+    // loads in flight per lane, four workgroups per CU — instead of 2 rows and 2048: wqkv with its norm prologue and RoPE epilogue
+    // 12.25 -> 11.0 us, wo 8.14 -> 7.86 (2048 / 1536 / 1280 / 896 / 768 / 640 / 512 workgroups: 12.4 / 12.4 / 12.1 / 11.5 / 11.6 /
+    // 12.0 / 12.7; 8 rows: 11.8-11.9); the LM head (128256 rows: 125 rounds per workgroup) prefers 2 rows x 1024: 163.4 -> 157.7.
+    // The arithmetic of a row does not depend on either number: bit-identical results.  (Also tried, r5: the SwiGLU pair as one wave
+    // per row pair — 256 workgroups x 8 waves, no LDS, no barrier, the geometry at which a stream-only launch moves the pair's 235 MB
+    // in 37.1 us: 41.1-41.4 us against this kernel's 40.0; removed.)
+    if (a.N >= 32768) {
+      c.rb = 2; c.cu = 2;
+    } else {
+      c.rb = 4; c.cu = 2;
+    }
+    c.cap = 1024;
+  } else if (nstep <= 2) {
     c.rb = 2; c.cu = 2;
   } else if (a.W3 != nullptr) {
     c.rb = 2; c.cu = (nstep <= 4 || nstep > 8) ? 4 : 8;
