@@ -139,8 +139,8 @@ class Attention(nn.Module):
         self.fuse_state_update = True  # fold cache.py:690-723 into the decode attention combine pass
         self.fuse_decode_step = True   # whole update_kv + attention + update_state in one launch (two where the shape does not allow one)
         # ... with RMSNorm + wqkv + RoPE folded into that launch where the shape allows (cc_decode_step_qkv_rc).  OPT-IN (CC_FUSE_QKV=1 or
-        # this attribute): bit-identical results, and at the benchmark's shape a tie with the two launches it replaces (r5:
-        # profiles/r05_overlap_probe.md — 18.8-19.0 us against 18.8-19.0 us per layer), so the longer-soaked pair stays the default
+        # this attribute): bit-identical results, but at the benchmark's shape 0.5-0.8 us per layer SLOWER than the two launches it
+        # replaces (r5: profiles/r05_overlap_probe.md — 19.0 us against 18.3-18.6), so the pair stays the default
         self.fuse_qkv_step = os.environ.get("CC_FUSE_QKV", "0") == "1"
 
     def compress_prompt(self, input_pos, k_val, v_val, attn):
