@@ -503,7 +503,7 @@ def overlap_probe(model, args, dev):
                            "frac_of_hbm_peak": round((w_bytes + step_bytes) / (out["fused_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
     out["decode_loop_uses"] = "fused (CC_FUSE_QKV=1)" if os.environ.get("CC_FUSE_QKV", "0") == "1" else "twin (default)"
     out["note"] = ("per layer, hipGraph replays over the model's 32 weight matrices and caches, medians; the QKV form moves the projection's "
-                   "50 MB and the step's 17.7 MB in one launch — see profiles/r05_overlap_probe.md for why the two forms tie at this size")
+                   "50 MB and the step's 17.7 MB in one launch — see profiles/r05_overlap_probe.md for why the one launch does not beat the two at this size")
     return out
 
 
