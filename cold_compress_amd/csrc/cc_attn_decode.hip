@@ -18,6 +18,7 @@
 //   update (cache.py:690-723) in the same pass.
 // HBM-bound: ~1 flop/byte, no MFMA.
 #include <atomic>
+#include <cstdlib>
 #include <mutex>
 
 #include "cc_common.h"
@@ -480,7 +481,16 @@ static Plan make_plan_w(int HQ, int H, int S, int D, int dtype, bool wide_allowe
     const long tiles = (long)H * ((S + 15) / 16);
     // (measured, r3, same box: 1280 tiles (C2: S = 2560) wide 8.18 vs 8.46 us; 1024 tiles (S = 2048, or 4 kv heads at 4096) wide
     //  7.8-7.9 vs 7.35-7.75: from five tiles per CU on the 8-wave workgroup pays)
-    if (tiles >= 1280 && (long)H * ((S + 127) / 128) <= 256) p.nw = 8;
+    // (r5: with a wave's partial O rows inside its K slab the workgroup holds 69.8 KB of LDS and TWO fit a CU — but up to 512 wide
+    //  workgroups, i.e. caches of up to 64 x 128 rows per kv head on the single-tile form, measured WORSE than the several-tiles form
+    //  they would replace: S = 5120 / 6144 / 8192 at 8 kv heads 11.35 / 11.93 / 13.6 us against 10.21 / 10.81 / 12.07, same box; the
+    //  rule stays at one workgroup per CU.  CC_WIDE_MAX_WG: the A/B override, read once)
+    static long wide_max = -1;
+    if (wide_max < 0) {
+      const char* e = getenv("CC_WIDE_MAX_WG");
+      wide_max = e ? atol(e) : 256;
+    }
+    if (tiles >= 1280 && (long)H * ((S + 127) / 128) <= wide_max) p.nw = 8;
   }
   const int rpi = rows_per_iter(D, dtype, p.nw);
   // ~512 workgroups (two per CU, all resident at once): one tile per workgroup up to S = 64 * 64 rows per kv

@@ -2098,7 +2098,13 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
   // ---- Epilogue.  The P.V accumulators already cover all 16 rows of the wave's tiles (one running maximum per
   //      (wave, head)), so there is nothing to merge inside a wave: lanes n < RT drop their [128] partial into LDS
   //      (8 x ds_write_b128) and the four waves of the workgroup meet there.
-  __shared__ __attribute__((aligned(16))) float sm_wacc[NW][RT][D];
+  // The waves' partial O rows live IN their K slabs (r5): a wave's slab (16 rows x 256 B = 4 KiB) is read by that wave alone, for the
+  // last time by the Q.K products of its last tile — fences and this wave's own program order separate those reads from the stores
+  // below — and RT x 128 floats fit it exactly at RT = 8.  16 KiB of LDS less per 8-wave workgroup: 69.8 instead of 85.8 KB (two wide
+  // workgroups would fit a CU; the plan does not use that — make_plan_w has the measurement — but a co-tenant's LDS has more room).
+  static_assert(RT * D * sizeof(float) <= sizeof(sm_k[0]), "a wave's partial O rows must fit its K slab");
+  typedef float __attribute__((may_alias)) wacc_f32;
+  auto sm_wacc = [&](int w, int r, int d) -> wacc_f32& { return reinterpret_cast<wacc_f32*>(&sm_k[w][0][0])[r * D + d]; };
   {
     if constexpr (!EML) {  // (EML: done between the tile's halves)
       l = xor_combine<32, false>(xor_combine<16, false>(l));  // the wave's l of head c, in every row group
@@ -2110,7 +2116,7 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
     if (c < RT) {
 #pragma unroll
       for (int b = 0; b < D / 16; b++)
-        *reinterpret_cast<float4*>(&sm_wacc[wave][c][16 * b + 4 * g]) = make_float4(acc[b][0], acc[b][1], acc[b][2], acc[b][3]);
+        *reinterpret_cast<float4 __attribute__((may_alias))*>(&sm_wacc(wave, c, 16 * b + 4 * g)) = make_float4(acc[b][0], acc[b][1], acc[b][2], acc[b][3]);
     }
   }
   if constexpr (L2X) {
@@ -2239,8 +2245,8 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
         for (int w = 0; w < NW; w++) {  // fixed order: deterministic
           const float f = fast_exp(sm_wm[w][r] - Mu);
           L = fmaf(sm_wl[w][r], f, L);
-          O0 = fmaf(sm_wacc[w][r][d], f, O0);
-          O1 = fmaf(sm_wacc[w][r][d + 1], f, O1);
+          O0 = fmaf(sm_wacc(w, r, d), f, O0);
+          O1 = fmaf(sm_wacc(w, r, d + 1), f, O1);
         }
         const u32x4_t og = {tag, __float_as_uint(O0), tag, __float_as_uint(O1)};
         __builtin_amdgcn_raw_buffer_store_b128(og, o_rsrc, h * kOneOHead + ((r * ns + split) * 64 + (d >> 1)) * 16, 0, kPublishAux);
@@ -2856,7 +2862,7 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
     for (int w = 0; w < NW; w++) {  // fixed order: deterministic
       const float f = fast_exp(sm_wm[w][r] - Mu);
       L = fmaf(sm_wl[w][r], f, L);
-      O = fmaf(sm_wacc[w][r][d], f, O);
+      O = fmaf(sm_wacc(w, r, d), f, O);
     }
     if (a.abl & 16) {  // measurement only: merge but do not store the partials
       if (O + L == 1.2345f) a.part_ml[0] = L;
