@@ -199,6 +199,7 @@ def roofline(model, args, dev):
     H, S, D = kv0.n_heads, kv0.max_cache_length, kv0.head_dim
     HQ = layers[0].n_head
     fns = _abi.lib()
+    _abi.probe_device()  # (cached per device; the decode loop's workspace has run it already — this workspace is the roofline's own)
     nbytes = fns["cc_decode_attn_workspace_bytes"](HQ, H, S, D, 1)
     ws = torch.zeros(nbytes, dtype=torch.uint8, device=dev)  # zero: the single-launch step's epoch words live here
     q = torch.randn(HQ, D, device=dev).to(torch.bfloat16)

@@ -56,6 +56,7 @@ def main():
     a = ap.parse_args()
     dev = "cuda"
     fns = _abi.lib()
+    _abi.probe_device()  # (r5: loading the library no longer probes the dispatch order: without this the tool measures the memory hand-off)
     H, HQ, D = a.H, a.HQ, a.D
     p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
     for S in a.S:

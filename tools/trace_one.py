@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--wide", type=int, default=1, help="cc_decode_step_set_wide")
     a = ap.parse_args()
     _abi.lib()["cc_decode_step_set_wide"](a.wide)
+    _abi.probe_device()  # (r5: loading the library no longer probes the dispatch order: without this the tool measures the memory hand-off)
     dev, D, H, HQ = "cuda", 128, a.H, a.HQ
     fns = _abi.lib()
     p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
