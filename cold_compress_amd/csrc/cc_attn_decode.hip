@@ -791,6 +791,7 @@ static OneKernel one_kernel_xl2_dt(int dtype, int rt, int nt, int kind, bool ful
 constexpr int kMaxDevices = 64;
 struct XccProbe {
   std::atomic<int> state{0};  // 0 unknown, 1 verified, 2 refuted / failed
+  std::atomic<int> demoted{0};  // cc_decode_step_demote_l2_handoff: the caller saw a step fail with the L2-resident hand-off on THIS device
 };
 static XccProbe g_xcc_probe[kMaxDevices];
 static std::atomic<int> g_l2_handoff_enabled{1};  // cc_decode_step_set_l2_handoff
@@ -803,7 +804,7 @@ __global__ void xcc_probe_kernel(unsigned* out) {
 static bool xl2_device_ok() {
   int dev = 0;
   if (!g_l2_handoff_enabled.load(std::memory_order_relaxed) || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return false;
-  return g_xcc_probe[dev].state.load(std::memory_order_acquire) == 1;
+  return g_xcc_probe[dev].state.load(std::memory_order_acquire) == 1 && g_xcc_probe[dev].demoted.load(std::memory_order_relaxed) == 0;
 }
 }  // namespace
 
@@ -887,6 +888,14 @@ void cc_decode_step_set_wide(int32_t enabled) { g_wide_enabled.store(enabled ? 1
 // (the fallback of a step that fails with it — a kernel captured into a hipGraph keeps the form it was captured with).
 void cc_decode_step_set_l2_handoff(int32_t enabled) { g_l2_handoff_enabled.store(enabled ? 1 : 0, std::memory_order_relaxed); }
 int32_t cc_decode_step_l2_handoff(void) { return xl2_device_ok() ? 1 : 0; }
+// Per DEVICE (the current one), unlike the A/B switch above: what the recovery path of a caller uses.  demoted != 0: steps launched on
+// this device from now on take the memory hand-off whatever the probe said; 0: the probe's verdict counts again.  Other devices of the
+// process are untouched.  -> the previous value.
+int32_t cc_decode_step_demote_l2_handoff(int32_t demoted) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return 0;
+  return g_xcc_probe[dev].demoted.exchange(demoted ? 1 : 0, std::memory_order_relaxed);
+}
 // Observe where the dispatcher puts the blocks of a 2-D grid on the CURRENT device: synchronous (its own stream, one small
 // allocation) — call it outside stream capture.  1 = block b always ran on the XCC of block b % 8 (two grid shapes, two launches
 // each): the XL2 instantiations may be used; 0 = not so, or the probe could not run: they never are.  Cached per device.

@@ -216,8 +216,8 @@ def _recover_token(model, cur_token, input_pos, decode_fn, nt, npb, forced, attn
     when the status word of the decode workspace is known to be set: the failed step committed nothing of its kv head, every later
     launch returned at once (include/coldcompress.h, cc_decode_step_heavy_hitter_rc) — so the word is cleared, the epoch words are
     advanced, and the SAME token runs again: workgroups whose part of the step is committed recompute and store nothing, the others
-    step.  From the FOURTH attempt on (three have failed) the L2-resident hand-off is switched off (memory hand-off; a captured graph
-    is dropped and captured again) — until the next generate() call.
+    step.  From the FOURTH attempt on (three have failed) the L2-resident hand-off is demoted ON THIS DEVICE (memory hand-off; a
+    captured graph is dropped and captured again) — until the next generate() call.
     Caches whose step carries no commit words (`recoverable()` False) and a failure that persists raise.  Under tensor parallelism
     the status is the maximum over the ranks, so all ranks take every branch here together."""
     from .. import _abi
@@ -240,9 +240,10 @@ def _recover_token(model, cur_token, input_pos, decode_fn, nt, npb, forced, attn
             import warnings
 
             warnings.warn("cold_compress_amd: a single-launch decode step failed three times; the L2-resident hand-off is switched off "
-                          "for the rest of this generation (memory hand-off); generate() switches it back on when the next one starts")
-            _abi.lib()["cc_decode_step_set_l2_handoff"](0)
-            _L2_HANDOFF_OFF["by_recovery"] = True
+                          "on this device for the rest of this generation (memory hand-off); generate() restores it when the next one starts")
+            with torch.cuda.device(dev):  # per device (r5): other devices of the process keep the faster hand-off
+                _abi.lib()["cc_decode_step_demote_l2_handoff"](1)
+            _L2_HANDOFF_DEMOTED.add(dev.index if dev.index is not None else torch.cuda.current_device())
             if hasattr(decode_fn, "graph"):
                 decode_fn.graph = None  # captured with the L2-resident form: capture again
         time.sleep(0.05 * tries)  # whatever shared the device gets a moment to leave
@@ -250,18 +251,20 @@ def _recover_token(model, cur_token, input_pos, decode_fn, nt, npb, forced, attn
     return nt, npb
 
 
-_L2_HANDOFF_OFF = {"by_recovery": False}  # the recovery path switched the L2-resident hand-off off: generate() restores it
+_L2_HANDOFF_DEMOTED = set()  # device indices on which the recovery path demoted the L2-resident hand-off: generate() restores them
 
 
 def _restore_l2_handoff():
     """A transient co-tenant must not cost every later generation of the process the faster hand-off: what
-    _recover_token switched off is switched back on when the next generation starts (steps captured in a hipGraph keep the form they
-    were captured with)."""
-    if _L2_HANDOFF_OFF["by_recovery"]:
+    _recover_token demoted (per device) is restored when the next generation starts (steps captured in a hipGraph keep the form
+    they were captured with)."""
+    if _L2_HANDOFF_DEMOTED:
         from .. import _abi
 
-        _abi.lib()["cc_decode_step_set_l2_handoff"](1)
-        _L2_HANDOFF_OFF["by_recovery"] = False
+        for idx in sorted(_L2_HANDOFF_DEMOTED):
+            with torch.cuda.device(idx):
+                _abi.lib()["cc_decode_step_demote_l2_handoff"](0)
+        _L2_HANDOFF_DEMOTED.clear()
 
 
 class _StatusWatch:

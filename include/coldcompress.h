@@ -354,10 +354,15 @@ int cc_decode_step_qkv_rc(const cc_kv_view* c, int32_t policy, const void* wqkv,
  *   cc_decode_step_probe_xcd: synchronous, call OUTSIDE stream capture (the Python layer does so when it creates a decode
  *     workspace on a device); 1 = verified for the current device (cached; two grid shapes, four launches), 0 = refuted or
  *     not probed -> memory hand-off.
- *   cc_decode_step_l2_handoff(): 1 if enabled (cc_decode_step_set_l2_handoff, include/coldcompress_debug.h) AND verified on the
- *     current device. */
+ *   cc_decode_step_l2_handoff(): 1 if verified on the current device AND neither demoted there (below) nor switched off by the A/B
+ *     switch of include/coldcompress_debug.h.
+ *   cc_decode_step_demote_l2_handoff(demoted): state of the CURRENT DEVICE only (r5; the recovery path's lever — the process-wide
+ *     switch is a debug hook): 1 = every step launched on this device from now on takes the memory hand-off whatever the probe said,
+ *     0 = the probe's verdict counts again.  Returns the previous value.  The forms give bit-identical cache state, so a flip never
+ *     changes results; a step captured into a hipGraph keeps the form it was captured with. */
 int32_t cc_decode_step_probe_xcd(void);
 int32_t cc_decode_step_l2_handoff(void);
+int32_t cc_decode_step_demote_l2_handoff(int32_t demoted);
 /* The two-launch step for KVCacheHybrid (FastGen per-head policies; cache.py:896-1019 + the fused ring update of
  * cc_decode_attn_gqa_ring): three launches -> two.  What a head does with the incoming token — append at the end of its
  * live slots, evict its candidate, or drop the token (slot S - 1, mask untouched) — depends on its policy, its count, the

@@ -1,7 +1,7 @@
 /* coldcompress_debug.h — measurement hooks, test hooks and process-wide A/B switches of libcoldcompress_hip.so (r5: split out of
  * coldcompress.h).  NOTHING here is part of the drop-in boundary: a caller that replaces the reference's hot path
- * needs include/coldcompress.h only.  bench.py, tools/ and tests/ use these; the Python product layer uses exactly one of them
- * (cc_decode_step_set_l2_handoff, from the recovery path of harness/generation.py).
+ * needs include/coldcompress.h only.  bench.py, tools/ and tests/ use these; the Python product layer uses NONE of them (its recovery
+ * path demotes the L2-resident hand-off per device: cc_decode_step_demote_l2_handoff, include/coldcompress.h).
  *
  * The three switches are process-wide (std::atomic<int> inside the library: reads and writes are safe from any thread, but a flip is
  * seen by every stream's NEXT call) — they select between forms that give bit-identical cache state, so flipping one never changes
@@ -30,8 +30,8 @@ int cc_debug_occupy(int32_t n_workgroups, int32_t lds_bytes, int32_t microsecond
  * together; flip it only where the fused pipeline is re-seeded (prepare_decode / cc_hh_next_key_init). */
 void cc_decode_step_set_wide(int32_t enabled);
 /* Process-wide off switch of the L2-resident hand-off (include/coldcompress.h, cc_decode_step_probe_xcd): 0 = always the memory
- * hand-off.  The harness flips it after three failed attempts of a token and restores it when the next generation starts; a step
- * captured into a hipGraph keeps the form it was captured with. */
+ * hand-off, on every device (A/B measurements; the harness's recovery path uses the per-device cc_decode_step_demote_l2_handoff
+ * instead).  A step captured into a hipGraph keeps the form it was captured with. */
 void cc_decode_step_set_l2_handoff(int32_t enabled);
 /* Measurement hook: buf = device buffer of [workgroups][16] uint64, or NULL (default).  While set, thread 0 of every
  * workgroup of a single-launch step records [0..5] s_memtime stamps (start, streaming done, published, sentinel seen,

@@ -302,7 +302,7 @@ def test_co_tenant_fault_is_recovered_in_band(strategy, fuse_qkv):
             side = torch.cuda.Stream()
     finally:
         au.reset_single_launch_status = orig_reset
-        _abi.lib()["cc_decode_step_set_l2_handoff"](1)  # (a persistent failure switches it off for the process: not for the tests behind this one)
+        _abi.lib()["cc_decode_step_demote_l2_handoff"](0)  # (a persistent failure demotes it on the device: not for the tests behind this one)
     assert resets, "the co-tenant kernel did not provoke a hand-off timeout in six runs: the test did not test anything"
     assert fault_t == clean_t, f"tokens differ: {fault_t} vs {clean_t} after {len(resets)} retries"
     for l, (a, b) in enumerate(zip(clean_s, fault_s)):
@@ -487,7 +487,7 @@ def test_hybrid_co_tenant_fault_is_recovered():
             if provoked:
                 break
     finally:
-        _abi.lib()["cc_decode_step_set_l2_handoff"](1)
+        _abi.lib()["cc_decode_step_demote_l2_handoff"](0)
     assert provoked, "the co-tenant kernel did not provoke a hand-off timeout in six runs: the test did not test anything"
     assert au.single_launch_status(torch.device(DEV)) == 0
 
@@ -538,7 +538,7 @@ def test_several_tiles_co_tenant_fault_is_recovered(strategy):
             if provoked:
                 break
     finally:
-        _abi.lib()["cc_decode_step_set_l2_handoff"](1)
+        _abi.lib()["cc_decode_step_demote_l2_handoff"](0)
     assert provoked, "the co-tenant kernel did not provoke a hand-off timeout in six runs: the test did not test anything"
     assert au.single_launch_status(torch.device(DEV)) == 0
 
@@ -595,3 +595,45 @@ def test_qkv_form_replay_and_status_word(strategy):
     kv.decode_step_qkv(w, None, x, None, nw, 1e-5, None, fr, p2, HQ)
     torch.cuda.synchronize()
     assert step_committed(kv, T + 3) and single_launch_status(kv.pos.device) == 0
+
+
+@pytest.mark.parametrize("strategy", ["heavy_hitter", "recent_global", "l2"])
+def test_demoted_l2_handoff_gives_identical_steps_and_is_restored(strategy):
+    """What the recovery path falls back to after three failed attempts (r5: per DEVICE, cc_decode_step_demote_l2_handoff): the memory
+    hand-off at the headline shape gives y and cache state bit-identical to the L2-resident one, the query reports the form, and the
+    next generate() restores what was demoted."""
+    from cold_compress_amd import _abi
+    from cold_compress_amd.attention_utils import single_launch_status
+    from cold_compress_amd.harness import generation as G
+
+    fns = _abi.lib()
+    H, HQ, S, D = 8, 32, 4096, 128
+    a, T = _mk(H, S, strategy=strategy)
+    b, _ = _mk(H, S, strategy=strategy)
+    _abi.probe_device()
+    if not fns["cc_decode_step_l2_handoff"]():
+        pytest.skip("the L2-resident hand-off is not verified on this device: there is one form only")
+    gen = torch.Generator(device=DEV).manual_seed(17)
+    try:
+        for t in range(4):  # two appends, then evictions
+            p = torch.tensor([T + t], dtype=torch.int32, device=DEV)
+            q = torch.randn(1, HQ, 1, D, device=DEV, generator=gen).to(torch.bfloat16)
+            k1 = torch.randn(1, H, 1, D, device=DEV, generator=gen).to(torch.bfloat16)
+            v1 = torch.randn(1, H, 1, D, device=DEV, generator=gen).to(torch.bfloat16)
+            assert fns["cc_decode_step_demote_l2_handoff"](0) == 0 and fns["cc_decode_step_l2_handoff"]() == 1
+            ya = a.decode_step(q, k1, v1, p).clone()
+            assert fns["cc_decode_step_demote_l2_handoff"](1) == 0 and fns["cc_decode_step_l2_handoff"]() == 0
+            yb = b.decode_step(q, k1, v1, p).clone()
+            assert fns["cc_decode_step_demote_l2_handoff"](0) == 1
+            torch.cuda.synchronize()
+            assert torch.equal(ya, yb), f"token {t}: y differs between the hand-offs"
+            for (na, ta), (nb, tb) in zip(a.named_buffers(), b.named_buffers()):
+                assert torch.equal(ta, tb), f"token {t}: {na} differs between the hand-offs"
+        assert single_launch_status(torch.device(DEV)) == 0
+        # what _recover_token leaves behind, and what the next generation does with it
+        fns["cc_decode_step_demote_l2_handoff"](1)
+        G._L2_HANDOFF_DEMOTED.add(torch.cuda.current_device())
+        G._restore_l2_handoff()
+        assert fns["cc_decode_step_l2_handoff"]() == 1 and not G._L2_HANDOFF_DEMOTED
+    finally:
+        fns["cc_decode_step_demote_l2_handoff"](0)
