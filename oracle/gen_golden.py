@@ -32,6 +32,17 @@ import torch
 
 REF = "/root/reference"
 
+SEED_OFFSET = 0  # --seed_offset: every seed below is shifted by it (0 = the committed fixtures; tests/test_oracle_fresh_seeds.py uses others)
+
+
+def _gen(seed):
+    return torch.Generator().manual_seed(int(seed) + SEED_OFFSET)
+
+
+def _seed(seed):
+    return torch.manual_seed(int(seed) + SEED_OFFSET)
+
+
 
 def _import_reference():
     sys.dont_write_bytecode = True
@@ -82,7 +93,7 @@ TINY = dict(block_size=256, vocab_size=128, n_layer=2, n_head=4, n_local_heads=2
 
 
 def run_e2e(C, G, M, name, cache_args, prompt_len=40, new_tokens=12, seed=0, n_layer=2):
-    torch.manual_seed(seed)
+    _seed(seed)
     cfg = dict(TINY)
     cfg["n_layer"] = n_layer
     model = M.Transformer(M.ModelArgs(**cfg)).to(torch.float32).eval()
@@ -164,7 +175,7 @@ def softmax_rows(shape, dtype, gen, mask=None):
 
 def replay_cache(C, strategy, dtype, H, S, D, T_prefill, steps, g, w, seed, extra=None, rand_capture=None, capture_kv=False):
     """Drive a reference cache exactly as model.py:389-427 does and record inputs/outputs."""
-    gen = torch.Generator().manual_seed(seed)
+    gen = _gen(seed)
     cls, rk = C.get_cache_constructor(strategy)
     kw = dict(max_cache_length=S, global_tokens=g, max_seq_length=4 * S, cache_bits=None, recent_window=w,
               history_window_size=1, attn_thresholding=False)
@@ -248,7 +259,7 @@ def hh_query_case(A, C, dtype, seed, H=2, R=4, S=256, D=128, T_prefill=236, step
     produce the probabilities the history accumulates: what a fused decode step (insert + attention + history in one pass) must
     reproduce.  Records q / k / v per step, the evicted slot, the reference's eviction SCORES (the tensor its arg-min saw,
     cache.py:738-751: for the near-tie rule), its attention output and group-mean probabilities."""
-    gen = torch.Generator().manual_seed(seed)
+    gen = _gen(seed)
     HQ = H * R
     cls, rk = C.get_cache_constructor("heavy_hitter")
     kw = dict(max_cache_length=S, global_tokens=g, max_seq_length=4 * S, cache_bits=None, recent_window=w,
@@ -321,7 +332,7 @@ def quant_cases():
     """quantization_utils.quantize_tensor / dequantize_tensor with axis = 2 on [1, H, S, D] tensors: known answers."""
     import quantization_utils as Q
 
-    gen = torch.Generator().manual_seed(23)
+    gen = _gen(23)
     out = {}
     H, S, D = 3, 40, 16
     for dt, tag in ((torch.float32, "f32"), (torch.bfloat16, "bf16"), (torch.float16, "f16")):
@@ -345,7 +356,7 @@ def quant_cases():
 
 
 def compress_cases(P):
-    gen = torch.Generator().manual_seed(11)
+    gen = _gen(11)
     out = {}
     cases = []
 
@@ -355,10 +366,10 @@ def compress_cases(P):
         return bool((s[..., K - 1] == s[..., K]).any()) if prio.shape[-1] > K else False
 
     def add(name, comp, input_pos, k, v, **kw):
-        torch.manual_seed(5)  # the random compressor draws randperm per call: same draw for both calls
+        _seed(5)  # the random compressor draws randperm per call: same draw for both calls
         prio = comp._token_importances(input_pos, k, v, **kw)
         # NB: the heavy-hitter compressor mutates nothing we re-use; call the full path too
-        torch.manual_seed(5)
+        _seed(5)
         keep, k2, v2, st = comp(input_pos, k, v, **kw)
         out[name + ".priority"] = prio.clone()
         out[name + ".keep"] = keep.clone()
@@ -384,7 +395,7 @@ def compress_cases(P):
         out[f"heavy_hitter_{tag}.attn"] = attn
         add(f"heavy_hitter_{tag}", P.PromptCompressorHeavyHitter(head_specific=True, **kw), pos, k, v, attn=attn)
         # random: capture the permutation through the priority itself (priority is an input of the check)
-        torch.manual_seed(5)
+        _seed(5)
         add(f"random_{tag}", P.PromptCompressorRandom(head_specific=False, **kw), pos, k, v)
         add(f"keep_it_odd_{tag}", P.PromptCompressorKeepItOdd(head_specific=False, **kw), pos, k, v)
     # a larger bf16 L2 case where boundary ties are near-certain
@@ -401,7 +412,7 @@ def compress_cases(P):
 
 
 def attn_cases(A, dtype):
-    gen = torch.Generator().manual_seed(3)
+    gen = _gen(3)
     out = {}
     # decode: HQ=8, H=2 (R=4), S=96, D=32, with mask; driven as model.py:395-418
     HQ, H, S, D = 8, 2, 96, 32
@@ -446,7 +457,7 @@ def attn_cases(A, dtype):
 
 def attn_topk_case(A):
     """attention_utils.py:24-26, 45-50: top-k decode attention (L == 1, NO mask — with a mask the reference asserts)."""
-    gen = torch.Generator().manual_seed(9)
+    gen = _gen(9)
     H, S, D = 4, 64, 16
     q = torch.randn(1, H, 1, D, generator=gen)
     k = torch.randn(1, H, S, D, generator=gen)
@@ -518,7 +529,7 @@ FASTGEN_YAML = [  # cache_configs/fastgen.yaml of the reference
 def hybrid_case(C, dtype, strategies, min_recovery, seed, H=4, L=48, S=96, D=16, steps=40, peaky=1.5):
     """KVCacheHybrid driven as model.py:389-427 does: prefill (update_kv, then update_state with the [1,H,L,L]
     attention -> profile_and_update) and `steps` decode steps."""
-    gen = torch.Generator().manual_seed(seed)
+    gen = _gen(seed)
     token_ids = {"special": [[1], [2, 3]], "punctuation": [5, 6, 7]}
     kv = C.KVCacheHybrid(1, H, D, dtype, max_cache_length=S, max_seq_length=S, cache_bits=None, global_tokens=4,
                          token_ids=token_ids, min_recovery_frac=min_recovery, hybrid_strategies=strategies)
@@ -614,7 +625,7 @@ def analysis_case(C, dtype, seed, H=2, D=16, S=24, S_full=96, L=40, steps=24, g=
     `full_kwargs` (cache.py:1319-1324) omits `cache_bits`, which KVCache.__init__ reads (cache.py:181) — so the fixture pins
     the INTENDED behaviour: the one missing keyword is injected (cache_bits=None for the full cache) by wrapping
     KVCacheFull.__init__ for the duration of the capture; nothing else of the reference is altered."""
-    gen = torch.Generator().manual_seed(seed)
+    gen = _gen(seed)
     orig_init = C.KVCacheFull.__init__
 
     def patched(self, *a, **k):
@@ -665,7 +676,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
     ap.add_argument("--only", default=None, help="generate only one fixture family (e.g. f6)")
+    ap.add_argument("--seed_offset", type=int, default=0, help="shift every seed (0 = the committed fixtures): fresh reference-made "
+                    "vectors for the same cases, written wherever --out says — never into tests/golden")
     a = ap.parse_args()
+    global SEED_OFFSET
+    SEED_OFFSET = a.seed_offset
     os.makedirs(a.out, exist_ok=True)
     A, C, G, M, P = _import_reference()
     torch.set_num_threads(1)

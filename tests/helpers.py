@@ -4,7 +4,9 @@ import os
 import numpy as np
 import torch
 
-GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+# CC_GOLDEN_DIR: the same fixture families made by the reference from OTHER seeds (oracle/gen_golden.py --seed_offset N --out DIR; only
+# tests/test_oracle_fresh_seeds.py sets it, in the build container where /root/reference exists)
+GOLDEN = os.environ.get("CC_GOLDEN_DIR") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 DT_CODE = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
 DT_FROM_NAME = {"float32": torch.float32, "bfloat16": torch.bfloat16, "float16": torch.float16}
