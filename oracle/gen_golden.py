@@ -35,6 +35,26 @@ REF = "/root/reference"
 SEED_OFFSET = 0  # --seed_offset: every seed below is shifted by it (0 = the committed fixtures; tests/test_oracle_fresh_seeds.py uses others)
 
 
+JITTER = False  # --jitter_shapes: the cache replays (f2 / f3 / f4 / f9) also move their lengths, windows and step counts with the offset
+
+
+def _jitter(S, T_prefill, steps, g, w, seed):
+    """Shapes of a replay case shifted by a draw that depends on (offset, seed): cache length, prefill length (a case that starts
+    from a full cache stays full), protected globals / recent window (kept below the cache length), step count."""
+    if not JITTER:
+        return S, T_prefill, steps, g, w
+    import random
+
+    r = random.Random(1000003 * SEED_OFFSET + int(seed))
+    S2 = max(12, S + r.randint(-4, 12))
+    g2 = max(0, g + r.randint(-1, 2))
+    w2 = max(1, w + r.randint(-2, 3))
+    while g2 + w2 > S2 - 4:
+        w2, g2 = max(1, w2 - 1), max(0, g2 - 1)
+    T2 = S2 if T_prefill >= S else min(S2, max(1, T_prefill + r.randint(-6, 6)))
+    return S2, T2, steps + r.randint(0, 12), g2, w2
+
+
 def _gen(seed):
     return torch.Generator().manual_seed(int(seed) + SEED_OFFSET)
 
@@ -175,6 +195,7 @@ def softmax_rows(shape, dtype, gen, mask=None):
 
 def replay_cache(C, strategy, dtype, H, S, D, T_prefill, steps, g, w, seed, extra=None, rand_capture=None, capture_kv=False):
     """Drive a reference cache exactly as model.py:389-427 does and record inputs/outputs."""
+    S, T_prefill, steps, g, w = _jitter(S, T_prefill, steps, g, w, seed)
     gen = _gen(seed)
     cls, rk = C.get_cache_constructor(strategy)
     kw = dict(max_cache_length=S, global_tokens=g, max_seq_length=4 * S, cache_bits=None, recent_window=w,
@@ -678,9 +699,12 @@ def main():
     ap.add_argument("--only", default=None, help="generate only one fixture family (e.g. f6)")
     ap.add_argument("--seed_offset", type=int, default=0, help="shift every seed (0 = the committed fixtures): fresh reference-made "
                     "vectors for the same cases, written wherever --out says — never into tests/golden")
+    ap.add_argument("--jitter_shapes", action="store_true", help="with --seed_offset: the cache replays also move their cache length, "
+                    "prefill length, protected windows and step counts (a draw per case)")
     a = ap.parse_args()
-    global SEED_OFFSET
+    global SEED_OFFSET, JITTER
     SEED_OFFSET = a.seed_offset
+    JITTER = bool(a.jitter_shapes)
     os.makedirs(a.out, exist_ok=True)
     A, C, G, M, P = _import_reference()
     torch.set_num_threads(1)
