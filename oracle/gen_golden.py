@@ -550,6 +550,14 @@ FASTGEN_YAML = [  # cache_configs/fastgen.yaml of the reference
 def hybrid_case(C, dtype, strategies, min_recovery, seed, H=4, L=48, S=96, D=16, steps=40, peaky=1.5):
     """KVCacheHybrid driven as model.py:389-427 does: prefill (update_kv, then update_state with the [1,H,L,L]
     attention -> profile_and_update) and `steps` decode steps."""
+    if JITTER:  # --jitter_shapes: prompt length (the planted special / punctuation ids need L >= 41), step count, recovery threshold
+        import random  # and the second head's peakiness move with (offset, seed)
+
+        r = random.Random(1000003 * SEED_OFFSET + int(seed) + 7)
+        L = min(S - 8, max(42, L + r.randint(-6, 12)))
+        steps = steps + r.randint(0, 16)
+        min_recovery = round(min(0.97, max(0.15, min_recovery + r.uniform(-0.08, 0.08))), 3)
+        peaky = peaky * r.uniform(0.7, 1.4)
     gen = _gen(seed)
     token_ids = {"special": [[1], [2, 3]], "punctuation": [5, 6, 7]}
     kv = C.KVCacheHybrid(1, H, D, dtype, max_cache_length=S, max_seq_length=S, cache_bits=None, global_tokens=4,

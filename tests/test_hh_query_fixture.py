@@ -31,6 +31,26 @@ def justified(f, t, h, mine, ref):
     return 0 <= gap <= 2 * BF16_ULP * abs(float(sc[ref])) + 1e-12, gap
 
 
+def score_on_rounding_boundary(q, k_img, h, s, R, scale):
+    """Does one of the R query heads of kv head h have its dot product with slot s (exact, from the bf16 operands) within fp32
+    accumulation noise of a bf16 rounding midpoint — before or after the scale factor (attention_utils.py:36-40 rounds twice)?
+    -> (yes / no, the relative change of a probability when that score moves by one bf16 step, plus two roundings)."""
+    kk = torch.from_numpy(k_img[h, s].astype(np.int16)).view(torch.bfloat16).double()
+    hit, bound = False, 0.0
+    for r in range(R):
+        qq = q[h * R + r].double()
+        dot, noise = float((qq * kk).sum()), 2e-7 * float((qq * kk).abs().sum())  # (fp32 accumulation of D = 128 products)
+        for v in (dot, float(torch.tensor(dot).bfloat16()) * scale):
+            if v == 0.0:
+                continue
+            step = 2.0 ** (math.floor(math.log2(abs(v))) - 7)  # spacing of bf16 at |v|
+            frac = (abs(v) / step) % 1.0
+            if abs(frac - 0.5) * step <= noise + 1e-12:
+                hit = True
+                bound = max(bound, math.exp(2.0 ** (math.floor(math.log2(abs(dot * scale) + 1e-30)) - 7 + 1)) - 1.0)
+    return hit, bound + 2 * BF16_ULP
+
+
 def y_close(y_mine, y_ref):
     return float((y_mine - y_ref).abs().max()) <= 1e-3 + 2 * BF16_ULP * float(y_ref.abs().max())
 
@@ -45,7 +65,7 @@ def test_oracle_pipeline_on_reference_query_trace(oracle, audit):
               mask=f["mask_after_prefill"][0, :, 0].numpy().astype(np.uint8), cts=f["cts_after_prefill"].numpy().astype(np.int32).copy(),
               num=f["num_after_prefill"][0, :, :, 0].numpy().astype(np.float64).copy(), denom=f["denom_after_prefill"][0].numpy().astype(np.int32).copy(),
               ctr=f["counter_after_prefill"].numpy().astype(np.int64).copy())
-    n_just = 0
+    n_just = n_flip = 0
     for t in range(steps):
         p = T + t
         pt = np.array([p], np.int32)
@@ -70,9 +90,17 @@ def test_oracle_pipeline_on_reference_query_trace(oracle, audit):
                1.0 / math.sqrt(D), o.ptr(yo), o.ptr(ao), None, o.ptr(st["num"]), o.ptr(st["denom"]), o.ptr(st["ctr"]), None, 0, None)
         assert y_close(from_np(yo, dtype).float(), f["y"][t][0, :, 0].float()), f"step {t}: y"
         a_mine, a_ref = from_np(ao, dtype).float(), f["attn"][t][0, :, 0].float()
-        assert bool(((a_mine - a_ref).abs() <= 2 * BF16_ULP * a_ref.abs() + 1e-30).all()), f"step {t}: group-mean probabilities"
-    audit(f"n_just = {n_just} of {steps * H} evictions (limit 5 %)")
+        for h, s in ((a_mine - a_ref).abs() > 2 * BF16_ULP * a_ref.abs() + 1e-30).nonzero().tolist():
+            # beyond two roundings: accepted only where the reference's bf16 matmul had a dot product ON a rounding boundary (its
+            # blocked fp32 accumulation and the oracle's sequential one land on different sides: the score moves by one bf16 step,
+            # the probability by exp(step) — seen on 2 of 83 reference-made traces from other seeds, r5, never on the committed one)
+            ok, bound = score_on_rounding_boundary(f["q"][t].reshape(HQ, D), st["k"], h, s, R, 1.0 / math.sqrt(D))
+            rel = float((a_mine[h, s] - a_ref[h, s]).abs() / a_ref[h, s].abs())
+            assert ok and rel <= bound, f"step {t} head {h} slot {s}: group-mean probability off by {rel / BF16_ULP:.1f} roundings, no score on a rounding boundary"
+            n_flip += 1
+    audit(f"n_just = {n_just} of {steps * H} evictions (limit 5 %); probabilities behind a score on a bf16 rounding boundary = {n_flip} of {steps * H * S}")
     assert n_just <= 0.05 * steps * H, n_just
+    assert n_flip <= 1e-4 * steps * H * S + 1, n_flip
     assert np.array_equal(st["pos"], f["final_pos"][0].numpy())
     assert np.array_equal(st["k"], to_np(f["final_k"][0])) and np.array_equal(st["v"], to_np(f["final_v"][0]))
     assert np.array_equal(st["denom"], f["final_denom"][0].numpy())
