@@ -554,8 +554,9 @@ def hybrid_case(C, dtype, strategies, min_recovery, seed, H=4, L=48, S=96, D=16,
         import random  # and the second head's peakiness move with (offset, seed)
 
         r = random.Random(1000003 * SEED_OFFSET + int(seed) + 7)
-        L = min(S - 8, max(42, L + r.randint(-6, 12)))
-        steps = steps + r.randint(0, 16)
+        if L + steps <= S:  # (a head on the `full` policy must never outgrow the cache: cache.py:277 asserts; the 450-step case, whose
+            L = min(S - 8, max(42, L + r.randint(-6, 12)))  # recovery threshold selects no `full` head, keeps its lengths)
+            steps = min(steps + r.randint(0, 16), S - 1 - L)
         min_recovery = round(min(0.97, max(0.15, min_recovery + r.uniform(-0.08, 0.08))), 3)
         peaky = peaky * r.uniform(0.7, 1.4)
     gen = _gen(seed)

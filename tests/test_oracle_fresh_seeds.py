@@ -17,11 +17,12 @@ ORACLE_TESTS = ["test_oracle_golden.py", "test_oracle_hybrid.py", "test_oracle_q
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference lives in the build container only")
-@pytest.mark.parametrize("offset", [1009, 77003])
-def test_oracle_matches_reference_on_fresh_seeds(tmp_path, offset):
+@pytest.mark.parametrize("offset,jitter", [(1009, False), (77003, True)])
+def test_oracle_matches_reference_on_fresh_seeds(tmp_path, offset, jitter):
+    """jitter: the cache replays and the hybrid cases also move their lengths, windows, thresholds and step counts (--jitter_shapes)."""
     env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
-    gen = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "gen_golden.py"), "--out", str(tmp_path), "--seed_offset", str(offset)],
-                         capture_output=True, text=True, env=env, timeout=900)
+    gen = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "gen_golden.py"), "--out", str(tmp_path), "--seed_offset", str(offset)]
+                         + (["--jitter_shapes"] if jitter else []), capture_output=True, text=True, env=env, timeout=900)
     assert gen.returncode == 0, gen.stdout[-2000:] + gen.stderr[-2000:]
     committed = sorted(f for f in os.listdir(os.path.join(HERE, "golden")) if f.endswith((".npz", ".json")))
     assert sorted(os.listdir(tmp_path)) == committed, "the generator no longer writes the fixture set that is committed"
