@@ -404,6 +404,11 @@ def compress_cases(P):
         cases.append(name)
 
     H, L, D, S = 4, 96, 16, 40
+    if JITTER:  # --jitter_shapes: prompt length and kept length move (the protected 4 + 10 tokens stay: the tests read them as constants)
+        import random
+
+        r = random.Random(1000003 * SEED_OFFSET + 11)
+        L, S = r.randint(70, 150), r.randint(24, 64)
     pos = torch.arange(L)
     for dt, tag in ((torch.float32, "f32"), (torch.bfloat16, "bf16")):
         k = torch.randn(1, H, L, D, generator=gen).to(dt)
