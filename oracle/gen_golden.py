@@ -442,6 +442,12 @@ def attn_cases(A, dtype):
     out = {}
     # decode: HQ=8, H=2 (R=4), S=96, D=32, with mask; driven as model.py:395-418
     HQ, H, S, D = 8, 2, 96, 32
+    jr = None
+    if JITTER:  # --jitter_shapes: the decode cache lengths and the prefill length move
+        import random
+
+        jr = random.Random(1000003 * SEED_OFFSET + 3 + (0 if dtype == torch.float32 else 1))
+        S = jr.randint(40, 160)
     R = HQ // H
     q = torch.randn(1, HQ, 1, D, generator=gen).to(dtype)
     k = torch.randn(1, H, S, D, generator=gen).to(dtype)
@@ -456,6 +462,8 @@ def attn_cases(A, dtype):
                 "dec.attn_gm": p.view(1, H, R, 1, -1).mean(dim=2)})
     # decode, Llama-3-8B head geometry but short cache: HQ=32,H=8,D=128,S=256
     HQ, H, S, D = 32, 8, 256, 128
+    if jr is not None:
+        S = jr.randint(203, 420)
     R = HQ // H
     q = torch.randn(1, HQ, 1, D, generator=gen).to(dtype)
     k = torch.randn(1, H, S, D, generator=gen).to(dtype)
@@ -468,6 +476,8 @@ def attn_cases(A, dtype):
                 "dec8b.attn_gm": p.view(1, H, R, 1, -1).mean(dim=2)})
     # prefill: HQ=4,H=2,L=48,D=16, causal
     HQ, H, L, D = 4, 2, 48, 16
+    if jr is not None:
+        L = jr.randint(17, 90)
     R = HQ // H
     q = torch.randn(1, HQ, L, D, generator=gen).to(dtype)
     k = torch.randn(1, H, L, D, generator=gen).to(dtype)
