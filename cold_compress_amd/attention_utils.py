@@ -118,11 +118,15 @@ def check_single_launch_status(device=None):
         raise_single_launch_failure(device)
 
 
+def _need_device(t, message):
+    if not t.is_cuda:
+        raise ColdCompressError(message)
+
+
 def decode_attention(query, key, value, attn_mask=None, scale=None, return_attn=False, group_mean=False,
                      history=None):
     """query [1, HQ, 1, D]; key/value [1, H, S, D]; attn_mask bool [1, H or HQ, 1, S] or None."""
-    if not query.is_cuda:
-        raise ColdCompressError("decode attention needs ROCm device tensors (no CPU fallback)")
+    _need_device(query, "decode attention needs ROCm device tensors (no CPU fallback)")
     _, HQ, _, D = query.shape
     _, H, S, _ = key.shape
     if HQ % H:
@@ -168,8 +172,7 @@ def decode_attention(query, key, value, attn_mask=None, scale=None, return_attn=
 def prefill_attention(query, key, value, scale=None, return_attn=False, obs_len=16, bands=()):
     """Causal attention, query [1, HQ, L, D], key/value [1, H, L, D]; side outputs as an AttnSummary.
     `bands`: window widths (<= 4) whose band sums the hybrid cache's profiling score needs."""
-    if not query.is_cuda:
-        raise ColdCompressError("prefill attention needs ROCm device tensors (no CPU fallback)")
+    _need_device(query, "prefill attention needs ROCm device tensors (no CPU fallback)")
     _, HQ, L, D = query.shape
     H = key.shape[1]
     dt = query.dtype

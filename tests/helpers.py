@@ -8,6 +8,10 @@ import torch
 # tests/test_oracle_fresh_seeds.py sets it, in the build container where /root/reference exists)
 GOLDEN = os.environ.get("CC_GOLDEN_DIR") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
+# CC_TEST_DEVICE=cpu (with CC_TEST_CPU_TWIN=1, tests/conftest.py): the fixture-driven `-m gpu` tests run the product's Python layer on CPU
+# tensors over the oracle's twins (tests/cpu_twin.py) — tests/test_host_e2e_cpu.py launches that run inside the CPU suite
+TEST_DEVICE = os.environ.get("CC_TEST_DEVICE", "cuda")
+
 DT_CODE = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
 DT_FROM_NAME = {"float32": torch.float32, "bfloat16": torch.bfloat16, "float16": torch.float16}
 
@@ -70,7 +74,7 @@ def hh_own_state_steps(o, kv, st, gen, p0, steps, HQ, g, w, dtype, scale_q=1.5):
         v1 = torch.randn(1, H, 1, D, generator=gen).to(dtype)
         q1 = (scale_q * torch.randn(1, HQ, 1, D, generator=gen)).to(dtype)
         pos_before = kv.pos.cpu()[0].numpy().copy()
-        yd = kv.decode_step(q1.to("cuda"), k1.to("cuda"), v1.to("cuda"), pt.to("cuda"))
+        yd = kv.decode_step(q1.to(TEST_DEVICE), k1.to(TEST_DEVICE), v1.to(TEST_DEVICE), pt.to(TEST_DEVICE))
         torch.cuda.synchronize()
         pos_after = kv.pos.cpu()[0].numpy()
         idx_d = np.array([int(np.nonzero(pos_after[h] != pos_before[h])[0][0]) for h in range(H)])

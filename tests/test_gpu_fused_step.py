@@ -12,7 +12,7 @@ import torch
 from helpers import to_np
 
 pytestmark = pytest.mark.gpu
-DEV = "cuda"
+DEV = __import__("helpers").TEST_DEVICE  # "cuda"; "cpu" only under tests/cpu_twin.py
 
 
 @pytest.fixture()

@@ -17,7 +17,7 @@ from helpers import DT_CODE, DT_FROM_NAME, from_np, load_golden, to_np
 from test_oracle_hybrid import FIXTURES, policy_table
 
 pytestmark = pytest.mark.gpu
-DEV = "cuda"
+DEV = __import__("helpers").TEST_DEVICE  # "cuda"; "cpu" only under tests/cpu_twin.py
 TOKEN_IDS = {"special": [[1], [2, 3]], "punctuation": [5, 6, 7]}
 
 

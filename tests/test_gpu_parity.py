@@ -17,7 +17,7 @@ from helpers import DT_CODE, DT_FROM_NAME, from_np, load_golden, to_np
 
 pytestmark = pytest.mark.gpu
 
-DEV = "cuda"
+DEV = __import__("helpers").TEST_DEVICE  # "cuda"; "cpu" only under tests/cpu_twin.py
 
 
 @pytest.fixture(scope="module")

@@ -9,7 +9,7 @@ from helpers import DT_FROM_NAME, load_golden
 from test_gpu_e2e import _build, _log_evictions  # noqa: F401
 
 pytestmark = pytest.mark.gpu
-DEV = "cuda"
+DEV = __import__("helpers").TEST_DEVICE  # "cuda"; "cpu" only under tests/cpu_twin.py
 TAGS = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}
 
 

@@ -15,7 +15,7 @@ import torch
 from helpers import DT_CODE, from_np, to_np
 
 pytestmark = pytest.mark.gpu
-DEV = "cuda"
+DEV = __import__("helpers").TEST_DEVICE  # "cuda"; "cpu" only under tests/cpu_twin.py
 
 
 def _abi():

@@ -116,7 +116,7 @@ def test_fused_step_on_reference_query_trace(single, audit):
 
     f = load_golden(NAME)
     H, R, S, D, T, g, w, steps = f["H"], f["R"], f["S"], f["D"], f["T_prefill"], f["g"], f["w"], f["steps"]
-    HQ, dev = H * R, "cuda"
+    HQ, dev = H * R, __import__("helpers").TEST_DEVICE
     cls, rk = cache.get_cache_constructor("heavy_hitter")
     kw = dict(max_cache_length=S, global_tokens=g, max_seq_length=4 * S, cache_bits=None, recent_window=w, history_window_size=1,
               attn_thresholding=False)

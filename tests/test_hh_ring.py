@@ -63,7 +63,7 @@ def test_ring_replay_gpu(name):
     f = load_golden(name)
     dtype = DT_FROM_NAME[f["dtype"]]
     H, S, D, T, g, w = f["H"], f["S"], f["D"], f["T_prefill"], f["g"], f["w"]
-    dev = "cuda"
+    dev = __import__("helpers").TEST_DEVICE
     with torch.device(dev):
         kv = cache.KVCacheHeavyHitter(1, H, D, dtype, max_cache_length=S, max_seq_length=4 * S, cache_bits=None, global_tokens=g,
                                       history_window_size=W, recent_window=w, attn_thresholding=False)
