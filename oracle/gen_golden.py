@@ -113,6 +113,14 @@ TINY = dict(block_size=256, vocab_size=128, n_layer=2, n_head=4, n_local_heads=2
 
 
 def run_e2e(C, G, M, name, cache_args, prompt_len=40, new_tokens=12, seed=0, n_layer=2):
+    shift = 0
+    if JITTER and name != "recent_global":  # --jitter_shapes: prompt length, number of new tokens and the prompt's token pattern move
+        import random  # (the weights move with the seed; BASELINE config C1 — recent_global, 40 -> 12 tokens — keeps its lengths)
+
+        r = random.Random(1000003 * SEED_OFFSET + 31 * prompt_len + new_tokens + n_layer)
+        prompt_len = max(17, prompt_len + r.randint(-6, 10))
+        new_tokens = new_tokens + r.randint(0, 8)
+        shift = r.randint(0, 127)
     _seed(seed)
     cfg = dict(TINY)
     cfg["n_layer"] = n_layer
@@ -146,8 +154,8 @@ def run_e2e(C, G, M, name, cache_args, prompt_len=40, new_tokens=12, seed=0, n_l
         return out
 
     model.forward = fwd
-    prompt = (torch.arange(prompt_len) * 7 % 128).to(torch.int32) if name != "recent_global" else (
-        torch.arange(prompt_len) % 128).to(torch.int32)
+    prompt = ((torch.arange(prompt_len) * 7 + shift) % 128).to(torch.int32) if name != "recent_global" else (
+        (torch.arange(prompt_len) + shift) % 128).to(torch.int32)
     seq, probs, stats = G.generate(model, prompt, G.prefill, G.decode_one_token, max_new_tokens=new_tokens)
     d = {"prompt": prompt, "seq": seq, "logits": torch.stack(logits_log),
          "n_layer": n_layer, "prompt_len": prompt_len, "new_tokens": new_tokens,
