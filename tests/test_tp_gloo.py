@@ -7,6 +7,10 @@ The attention CORE (cache + HIP attention) needs the device, so this test swaps 
 independent double for it (plain causal softmax attention in torch, defined below) — the property under test is
 the sharding/all-reduce wiring, which is independent of what the per-head core computes.  Per-head cache
 state needs no exchange (every buffer is indexed by kv head), which the GPU parity tests cover per head.
+
+Late r5, second test: the same sharding with the REAL product caches, compressors and step code — every C-ABI call served by the
+oracle's twin on CPU tensors (tests/cpu_twin.py, test-only) — at world 2 and 8 (ONE kv head per rank): a compacted prompt and decode
+steps with evictions give the unsharded run's tokens, and every rank's heads hold exactly the unsharded run's positions for them.
 """
 import os
 import socket
@@ -110,7 +114,87 @@ def _worker(rank, world, port, q):
         raise
 
 
+def _worker_real(rank, world, port, q):
+    """The sharded model with the REAL product caches, compressors and attention entry points (every C-ABI call served by the oracle's
+    twin on CPU tensors: tests/cpu_twin.py) against the unsharded model on the same weights: a compacted prompt, then decode steps with
+    evictions — tokens equal, every rank's kv heads hold exactly the positions the unsharded run keeps for those heads."""
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                          LOCAL_RANK=str(rank), LOCAL_WORLD_SIZE=str(world))
+        import copy
+
+        import pytest as _pytest
+
+        from cold_compress_amd import tp
+        from cold_compress_amd.harness import ModelArgs, Transformer, decode_one_token, prefill, setup_caches
+        from cpu_twin import cpu_twin
+        from oracle import oracle_lib
+
+        torch.set_num_threads(1)
+        oracle_lib.fns()
+        mp_ = _pytest.MonkeyPatch()
+        with cpu_twin(mp_, oracle_lib):
+            assert tp.maybe_init_dist() == rank and dist.get_backend() == "gloo"
+            torch.manual_seed(11)
+            cfg = dict(block_size=128, vocab_size=64, n_layer=2, n_head=32, n_local_heads=8, dim=512, intermediate_size=256)
+            full = Transformer(ModelArgs(**cfg)).eval()
+            sharded = copy.deepcopy(full)
+            tp.apply_tp(sharded)
+            kw = dict(max_cache_length=[32.0], cache_bits=None, cache_length_pattern="tile", cache_strategy=["heavy_hitter"],
+                      cache_strategy_pattern="tile", feed_long_prompts=False, prompt_compression_strategy=["heavy_hitter"], global_tokens=4,
+                      recent_window=6, history_window_size=1, attn_thresholding=False, min_recovery_frac=0.9)
+            L, steps = 60, 14
+            prompt = torch.randint(0, 64, (L,), generator=torch.Generator().manual_seed(3), dtype=torch.int32)
+            outs = []
+            for model in (full, sharded):
+                setup_caches(model, None, "cpu", L + 40, dict(kw))
+                with torch.no_grad():
+                    tok, _ = prefill(model, prompt.view(1, -1), torch.arange(L))
+                    pos = torch.tensor([L], dtype=torch.int32)
+                    toks, cur = [int(tok)], tok.view(1, 1).to(torch.int32)
+                    for i in range(steps):
+                        nt, _ = decode_one_token(model, cur, pos)
+                        toks.append(int(nt))
+                        # teacher-force the unsharded run's tokens: both runs see the same inputs
+                        cur = (nt if model is full else torch.tensor(outs[0][0][len(toks) - 1])).view(1, 1).to(torch.int32)
+                        pos += 1
+                outs.append((toks, [l.attention.kv_cache.pos.clone() for l in model.layers], [int(l.attention.kv_cache.n_heads) for l in model.layers]))
+            hk = 8 // world
+            assert outs[1][2] == [hk, hk] and outs[0][2] == [8, 8]
+            differ = [int((pa[:, rank * hk:(rank + 1) * hk] != pb).sum()) for pa, pb in zip(outs[0][1], outs[1][1])]
+            same = sum(int(a == b) for a, b in zip(outs[0][0], outs[1][0]))
+            evicted = int((outs[0][1][0] >= L).sum())  # (decode-time inserts present in the unsharded cache: evictions happened)
+            q.put((rank, {"differ": differ, "same_tokens": same, "n_tokens": len(outs[0][0]), "inserted": evicted}))
+            dist.barrier()
+            dist.destroy_process_group()
+        mp_.undo()
+    except Exception as e:  # pragma: no cover
+        import traceback
+
+        q.put((rank, repr(e) + traceback.format_exc()[-1500:]))
+        raise
+
+
 import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_tp_gloo_real_cache_over_oracle_twins(world):
+    """(world 8: ONE kv head per rank — the `n_local_heads == 1` path — through the real KVCacheHeavyHitter / compressor / step code)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_real, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, r in res:
+        assert isinstance(r, dict), f"rank {rank}: {r}"
+        assert r["inserted"] > 0, "no decode-time insert survived: the run did not evict"
+        assert r["differ"] == [0, 0], f"rank {rank}: cache positions differ from the unsharded run's, per layer: {r['differ']}"
+        assert r["same_tokens"] == r["n_tokens"], f"rank {rank}: {r['same_tokens']} of {r['n_tokens']} tokens equal"
 
 
 @pytest.mark.parametrize("world", [2, 4, 8])
