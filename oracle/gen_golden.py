@@ -191,6 +191,64 @@ def run_e2e(C, G, M, name, cache_args, prompt_len=40, new_tokens=12, seed=0, n_l
     return pack(d)
 
 
+def generate_cases(C, G, M):
+    """generation_utils.generate's own branches (ref: generation_utils.py:399-531), which the F1 runs do not reach: a long prompt
+    fed token by token behind the prefill (feed_long_prompts), a prompt exactly as long as the smallest cache (split by one),
+    decode_first_token, teacher forcing (next_tokens), early stop on a terminator id.  One tiny model; per case the prompt, the
+    generate() keywords, the returned sequence, the token counts of its stats and every layer's final positions."""
+    import random
+
+    r = random.Random(1000003 * SEED_OFFSET + 97)
+    j = (lambda lo, hi: r.randint(lo, hi)) if JITTER else (lambda lo, hi: 0)
+    _seed(7)
+    model = M.Transformer(M.ModelArgs(**dict(TINY))).to(torch.float32).eval()
+    out = {"sd." + k: v.clone() for k, v in model.state_dict().items()}
+    hh = dict(cache_strategy=["heavy_hitter"], prompt_compression_strategy=["heavy_hitter"], max_cache_length=[32], global_tokens=4,
+              recent_window=4)
+    rg = dict(cache_strategy=["recent_global"], prompt_compression_strategy=["recent_global"], max_cache_length=[16], global_tokens=4)
+    l2 = dict(cache_strategy=["l2"], prompt_compression_strategy=["l2"], max_cache_length=[24], global_tokens=4, recent_window=5)
+    cases = [("feed_long", hh, 56 + j(-5, 9), 10 + j(0, 5), dict(feed_long_prompts=True)),
+             ("prompt_equals_cache", rg, 16, 9 + j(0, 5), dict()),
+             ("decode_first", l2, 48 + j(-5, 9), 8 + j(0, 5), dict(decode_first_token=True)),
+             ("teacher_forced", hh, 44 + j(-5, 9), 0, dict(next_tokens=[(11 * i + 3 + j(0, 50)) % 128 for i in range(9 + j(0, 4))])),
+             ("terminator", hh, 40 + j(-5, 9), 14 + j(0, 4), dict(terminator_ids="@step5"))]
+    names = []
+    for name, cache_args, prompt_len, new_tokens, gk in cases:
+        parser = argparse.ArgumentParser()
+        C.add_cache_arguments(parser)
+        G.add_generation_arguments(parser)
+        kw = vars(parser.parse_args([]))
+        kw.update(cache_args)
+        total = prompt_len + max(new_tokens, len(gk.get("next_tokens", []))) + 2
+        prompt = ((torch.arange(prompt_len) * 5 + 2 + j(0, 100)) % 128).to(torch.int32)
+
+        def run(gkw):
+            G.setup_caches(model, FakeTok(), "cpu", total, dict(kw))
+            g2 = dict(gkw)
+            if "next_tokens" in g2:
+                g2["next_tokens"] = torch.tensor(g2["next_tokens"], dtype=torch.int32)
+            return G.generate(model, prompt, G.prefill, G.decode_one_token, max_new_tokens=new_tokens, **g2)
+
+        if gk.get("terminator_ids") == "@step5":  # a token the greedy run really produces: found by a run without terminators
+            seq0, _, _ = run({})
+            gk = dict(terminator_ids=[int(seq0[prompt_len + 5])])
+        seq, probs, stats = run(gk)
+        out[name + ".prompt"] = prompt
+        out[name + ".seq"] = seq.clone()
+        out[name + ".cache_args_json"] = np.array(json.dumps(cache_args))
+        out[name + ".gen_kwargs_json"] = np.array(json.dumps(gk))
+        out[name + ".new_tokens"] = np.array(new_tokens)
+        out[name + ".total"] = np.array(total)
+        out[name + ".prefill_tokens"] = np.array(int(stats["prefill_tokens"]))
+        out[name + ".decode_tokens"] = np.array(int(stats["decode_tokens"]))
+        out[name + ".n_probs"] = np.array(len(probs))
+        for li, layer in enumerate(model.layers):
+            out[f"{name}.final_pos_L{li}"] = layer.attention.kv_cache.pos.clone()
+        names.append(name)
+    out["cases"] = np.array(names)
+    return pack(out)
+
+
 # ------------------------------------------------------------------------------------------------ F2/F3/F4
 
 
@@ -827,6 +885,8 @@ def main():
     save("f1_e2e_hh_pyramid.npz", run_e2e(C, G, M, "heavy_hitter", dict(
         cache_strategy=["heavy_hitter"], prompt_compression_strategy=["heavy_hitter"], max_cache_length=[64],
         cache_length_pattern="pyramid", global_tokens=2, recent_window=3), prompt_len=120, new_tokens=16, n_layer=4))
+
+    save("f1_generate_branches.npz", generate_cases(C, G, M))
 
     # F2: heavy-hitter replay
     for dt, tag in ((torch.float32, "f32"), (torch.bfloat16, "bf16")):

@@ -212,7 +212,7 @@ def test_compressors_vs_reference(cc):
         assert torch.equal(got.float(), f[name + ".k_out"].float()), name
     # full compressor objects (priority computed by the product too)
     for tag, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
-        kw = dict(max_cache_length=40, global_tokens=4, recent_window=10)
+        kw = dict(max_cache_length=int(f[f"l2_{tag}.keep"].shape[-1]), global_tokens=4, recent_window=10)  # (40 in the committed fixture)
         k, v = f[f"l2_{tag}.k_in"].to(DEV), f[f"l2_{tag}.v_in"].to(DEV)
         L = k.shape[2]
         pos = torch.arange(L, device=DEV)

@@ -51,3 +51,44 @@ def test_fixture_driven_gpu_tests_pass_on_the_cpu_twin():
     tail = run.stdout.strip().splitlines()[-1]
     n_passed = int(tail.split(" passed")[0].split()[-1])
     assert n_passed >= 90 and "failed" not in tail, tail
+
+
+def test_generate_branches_match_reference_on_cpu(twin):
+    """harness.generate's own branches (ref: generation_utils.py:399-531) that the F1 runs do not reach — a long prompt fed token by
+    token behind the prefill (feed_long_prompts), a prompt exactly as long as the smallest cache (split by one), decode_first_token,
+    teacher forcing (next_tokens), early stop on a terminator id — against the reference's runs (tests/golden/f1_generate_branches.npz,
+    oracle/gen_golden.py::generate_cases): the returned sequence, the token counts of the stats, the number of probability rows and
+    every layer's final positions."""
+    import argparse
+    import json
+
+    import numpy as np
+
+    import cold_compress_amd.cache as cache
+    from cold_compress_amd.harness import ModelArgs, Transformer, decode_one_token, generate, prefill, setup_caches
+    from helpers import GOLDEN, load_golden
+
+    f = load_golden("f1_generate_branches.npz")
+    names = [str(c) for c in np.load(os.path.join(GOLDEN, "f1_generate_branches.npz"))["cases"]]
+    assert len(names) >= 5
+    cfg = dict(block_size=256, vocab_size=128, n_layer=2, n_head=4, n_local_heads=2, dim=64, intermediate_size=128)
+    model = Transformer(ModelArgs(**cfg)).to(torch.float32).eval()
+    model.load_state_dict({k[3:]: v for k, v in f.items() if k.startswith("sd.")}, strict=True)
+    for name in names:
+        ap = argparse.ArgumentParser()
+        cache.add_cache_arguments(ap)
+        kw = vars(ap.parse_args([]))
+        kw.update(json.loads(f[name + ".cache_args_json"]))
+        gk = json.loads(f[name + ".gen_kwargs_json"])
+        if "next_tokens" in gk:
+            gk["next_tokens"] = torch.tensor(gk["next_tokens"], dtype=torch.int32)
+        setup_caches(model, None, "cpu", int(f[name + ".total"]), dict(kw))
+        seq, probs, stats = generate(model, f[name + ".prompt"], prefill, decode_one_token, max_new_tokens=int(f[name + ".new_tokens"]), **gk)
+        assert torch.equal(seq, f[name + ".seq"]), f"{name}: sequence"
+        assert (stats["prefill_tokens"], stats["decode_tokens"], len(probs)) == (int(f[name + ".prefill_tokens"]), int(f[name + ".decode_tokens"]),
+                                                                               int(f[name + ".n_probs"])), name
+        for li, layer in enumerate(model.layers):
+            # (the SET of positions every head holds: slot order is the F1 tests' business, and l2 may evict two keys of equal norm —
+            #  repeated tokens, vector_norm's unspecified summation order — in either order: seen on a jittered fresh-seed set)
+            mine, ref = layer.attention.kv_cache.pos.sort(dim=-1).values, f[f"{name}.final_pos_L{li}"].sort(dim=-1).values
+            assert torch.equal(mine, ref), f"{name}: layer {li} positions"

@@ -2,8 +2,8 @@
 GPU box), oracle/gen_golden.py makes every fixture family again from shifted seeds (`--seed_offset`, written to a temporary
 directory, never into tests/golden) and every CPU oracle test runs on them (`CC_GOLDEN_DIR`, tests/helpers.py).  The 43 committed
 fixtures pin the oracle on fixed inputs; this pins it on fresh ones each time the suite runs here — a differential fuzz of the
-restatement against the thing it restates ("outputs of the reference itself run here").  CPU-only; skipped without
-the reference."""
+restatement against the thing it restates ("outputs of the reference itself run here") — and of the product's Python layer, which runs
+on the same fresh vectors over the oracle's twins (tests/cpu_twin.py).  CPU-only; skipped without the reference."""
 import os
 import subprocess
 import sys
@@ -31,3 +31,9 @@ def test_oracle_matches_reference_on_fresh_seeds(tmp_path, offset, jitter):
                          + [os.path.join(HERE, t) for t in ORACLE_TESTS], capture_output=True, text=True, env=env, cwd=ROOT, timeout=900)
     assert run.returncode == 0, f"seed offset {offset}:\n" + run.stdout[-4000:] + run.stderr[-2000:]
     assert " passed" in run.stdout and "failed" not in run.stdout
+    # ... and the PRODUCT's host side on the same fresh vectors: the harness end to end and generate()'s branches over the oracle's twins
+    # (tests/test_host_e2e_cpu.py); for the jittered set also its child run of the fixture-driven `-m gpu` files
+    sel = [] if jitter else ["-k", "not fixture_driven"]
+    twin = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "not gpu", "-p", "no:cacheprovider", os.path.join(HERE, "test_host_e2e_cpu.py")] + sel,
+                          capture_output=True, text=True, env=env, cwd=ROOT, timeout=1800)
+    assert twin.returncode == 0, f"seed offset {offset} (CPU twin):\n" + twin.stdout[-4000:] + twin.stderr[-2000:]
