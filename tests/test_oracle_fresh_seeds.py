@@ -1,6 +1,6 @@
 """The oracle against the reference on vectors NOBODY has looked at: where /root/reference exists (the build container; never the
 GPU box), oracle/gen_golden.py makes every fixture family again from shifted seeds (`--seed_offset`, written to a temporary
-directory, never into tests/golden) and every CPU oracle test runs on them (`CC_GOLDEN_DIR`, tests/helpers.py).  The 43 committed
+directory, never into tests/golden) and every CPU oracle test runs on them (`CC_GOLDEN_DIR`, tests/helpers.py).  The committed
 fixtures pin the oracle on fixed inputs; this pins it on fresh ones each time the suite runs here — a differential fuzz of the
 restatement against the thing it restates ("outputs of the reference itself run here") — and of the product's Python layer, which runs
 on the same fresh vectors over the oracle's twins (tests/cpu_twin.py).  CPU-only; skipped without the reference."""
