@@ -212,6 +212,12 @@ def generate_cases(C, G, M):
              ("decode_first", l2, 48 + j(-5, 9), 8 + j(0, 5), dict(decode_first_token=True)),
              ("teacher_forced", hh, 44 + j(-5, 9), 0, dict(next_tokens=[(11 * i + 3 + j(0, 50)) % 128 for i in range(9 + j(0, 4))])),
              ("terminator", hh, 40 + j(-5, 9), 14 + j(0, 4), dict(terminator_ids="@step5"))]
+    # the FastGen hybrid cache THROUGH generate() (cache_configs/hybrid.yaml, fastgen.yaml): prefill profiling from the harness's own
+    # attention, the token ids reaching the cache, per-head policies at decode time (the f6 fixtures drive the class directly)
+    for hname, strategies, frac in (("hybrid", HYBRID_YAML, 0.5), ("fastgen", FASTGEN_YAML, 0.6)):
+        hy = dict(cache_strategy=["hybrid"], prompt_compression_strategy=["full"], max_cache_length=[1.0], global_tokens=4,
+                  hybrid_strategies=strategies, min_recovery_frac=round(frac + (r.uniform(-0.1, 0.1) if JITTER else 0.0), 3))
+        cases.append((hname, hy, 52 + j(-5, 9), 20 + j(0, 6), dict()))
     names = []
     for name, cache_args, prompt_len, new_tokens, gk in cases:
         parser = argparse.ArgumentParser()
@@ -221,13 +227,25 @@ def generate_cases(C, G, M):
         kw.update(cache_args)
         total = prompt_len + max(new_tokens, len(gk.get("next_tokens", []))) + 2
         prompt = ((torch.arange(prompt_len) * 5 + 2 + j(0, 100)) % 128).to(torch.int32)
+        if name in ("hybrid", "fastgen"):  # special ids [1], [2, 3] and punctuation 5, 6, 7 (FakeTok) where the policies look for them
+            prompt = prompt.clamp(min=8)
+            prompt[0], prompt[10], prompt[11], prompt[20], prompt[33], prompt[40] = 1, 2, 3, 5, 6, 7
+
+        after_prefill = []
 
         def run(gkw):
             G.setup_caches(model, FakeTok(), "cpu", total, dict(kw))
             g2 = dict(gkw)
             if "next_tokens" in g2:
                 g2["next_tokens"] = torch.tensor(g2["next_tokens"], dtype=torch.int32)
-            return G.generate(model, prompt, G.prefill, G.decode_one_token, max_new_tokens=new_tokens, **g2)
+            del after_prefill[:]
+
+            def pf(m, x, input_pos, **k2):  # (positions every layer holds when the prefill returns)
+                r_ = G.prefill(m, x, input_pos, **k2)
+                after_prefill.append([l.attention.kv_cache.pos.clone() for l in m.layers])
+                return r_
+
+            return G.generate(model, prompt, pf, G.decode_one_token, max_new_tokens=new_tokens, **g2)
 
         if gk.get("terminator_ids") == "@step5":  # a token the greedy run really produces: found by a run without terminators
             seq0, _, _ = run({})
@@ -244,6 +262,10 @@ def generate_cases(C, G, M):
         out[name + ".n_probs"] = np.array(len(probs))
         for li, layer in enumerate(model.layers):
             out[f"{name}.final_pos_L{li}"] = layer.attention.kv_cache.pos.clone()
+            out[f"{name}.pos_after_prefill_L{li}"] = after_prefill[0][li]
+            if hasattr(layer.attention.kv_cache, "cache_strategies"):
+                out[f"{name}.cache_strategies_L{li}"] = layer.attention.kv_cache.cache_strategies.clone()
+                out[f"{name}.final_cts_L{li}"] = layer.attention.kv_cache.cache_cts.clone()
         names.append(name)
     out["cases"] = np.array(names)
     return pack(out)
