@@ -218,6 +218,12 @@ def generate_cases(C, G, M):
         hy = dict(cache_strategy=["hybrid"], prompt_compression_strategy=["full"], max_cache_length=[1.0], global_tokens=4,
                   hybrid_strategies=strategies, min_recovery_frac=round(frac + (r.uniform(-0.1, 0.1) if JITTER else 0.0), 3))
         cases.append((hname, hy, 52 + j(-5, 9), 20 + j(0, 6), dict()))
+    # per-layer plumbing: different strategies, a fractional and an absolute cache length, a fractional recent window on the two layers
+    # (ref: generation_utils.py:324-388 setup_caches, model.py:191-233), and the toy keep_it_odd policy end to end
+    cases.append(("mixed_layers", dict(cache_strategy=["recent_global", "heavy_hitter"], prompt_compression_strategy=["recent_global", "heavy_hitter"],
+                                       max_cache_length=[0.25, 32], global_tokens=3, recent_window=0.2), 50 + j(-5, 9), 14 + j(0, 5), dict()))
+    cases.append(("keep_it_odd", dict(cache_strategy=["keep_it_odd"], prompt_compression_strategy=["keep_it_odd"], max_cache_length=[24],
+                                      global_tokens=4), 45 + j(-5, 9), 10 + j(0, 5), dict()))
     names = []
     for name, cache_args, prompt_len, new_tokens, gk in cases:
         parser = argparse.ArgumentParser()

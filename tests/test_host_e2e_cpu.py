@@ -58,7 +58,8 @@ def test_generate_branches_match_reference_on_cpu(twin):
     token behind the prefill (feed_long_prompts), a prompt exactly as long as the smallest cache (split by one), decode_first_token,
     teacher forcing (next_tokens), early stop on a terminator id — and the FastGen hybrid cache THROUGH generate() (hybrid.yaml and
     fastgen.yaml: prefill profiling from the harness's own attention, the token ids reaching the cache, per-head policies at decode
-    time) — against the reference's runs (tests/golden/f1_generate_branches.npz,
+    time), two layers with different strategies / a fractional and an absolute cache length / a fractional recent window (setup_caches'
+    per-layer plumbing), the toy keep_it_odd policy — against the reference's runs (tests/golden/f1_generate_branches.npz,
     oracle/gen_golden.py::generate_cases): the returned sequence, the token counts of the stats, the number of probability rows and
     every layer's final positions."""
     import argparse
@@ -79,7 +80,7 @@ def test_generate_branches_match_reference_on_cpu(twin):
 
     f = load_golden("f1_generate_branches.npz")
     names = [str(c) for c in np.load(os.path.join(GOLDEN, "f1_generate_branches.npz"))["cases"]]
-    assert len(names) >= 7
+    assert len(names) >= 9
     cfg = dict(block_size=256, vocab_size=128, n_layer=2, n_head=4, n_local_heads=2, dim=64, intermediate_size=128)
     model = Transformer(ModelArgs(**cfg)).to(torch.float32).eval()
     model.load_state_dict({k[3:]: v for k, v in f.items() if k.startswith("sd.")}, strict=True)
