@@ -123,4 +123,5 @@ def test_generate_branches_match_reference_on_cpu(twin):
             assert hybrid or torch.equal(mine, ref), f"{name}: layer {li} positions"
             if f"{name}.cache_strategies_L{li}" in f:  # the hybrid cache through generate(): the policy every head was profiled into, its counts
                 assert torch.equal(layer.attention.kv_cache.cache_strategies.cpu(), f[f"{name}.cache_strategies_L{li}"]), f"{name}: layer {li} policies"
-                assert torch.equal(layer.attention.kv_cache.cache_cts.cpu(), f[f"{name}.final_cts_L{li}"]), f"{name}: layer {li} counts"
+                if torch.equal(seq, f[name + ".seq"]):  # (a run whose tokens part ways generates other punctuation: other counts)
+                    assert torch.equal(layer.attention.kv_cache.cache_cts.cpu(), f[f"{name}.final_cts_L{li}"]), f"{name}: layer {li} counts"
