@@ -6,9 +6,13 @@ only inputs and the outputs the reference computed for them are written, as smal
 under tests/golden/.  The GPU box never sees the reference.
 
     PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py [--out tests/golden]
+    ... --seed_offset N [--jitter_shapes] --out SOME_OTHER_DIR     (r5) the same families from other seeds (and shapes): fresh vectors
+        for differential runs (tests/test_oracle_fresh_seeds.py; CC_GOLDEN_DIR=DIR pytest ...); offset 0 without jitter = the committed files
 
 Fixtures:
   f1_e2e_<strategy>.npz   tiny-Llama end-to-end runs through generation_utils.generate
+  f1_generate_branches.npz  generate()'s own branches (feed_long_prompts, prompt == cache length, decode_first_token, teacher forcing,
+                          terminator ids), the hybrid cache through generate(), per-layer strategy / length plumbing, keep_it_odd
   f2_hh_<dtype>.npz       KVCacheHeavyHitter replay trace (update_kv / update_state, as model.py:389-427)
   f2_hh_query_bf16.npz    the same policy driven from q through the reference's scaled_dot_product_attention + group mean
   f3_l2_<case>.npz        KVCacheL2 replay traces (bf16 rounding ties, unfilled slots, H == 1)
