@@ -226,6 +226,8 @@ def generate_cases(C, G, M):
     # (ref: generation_utils.py:324-388 setup_caches, model.py:191-233), and the toy keep_it_odd policy end to end
     cases.append(("mixed_layers", dict(cache_strategy=["recent_global", "heavy_hitter"], prompt_compression_strategy=["recent_global", "heavy_hitter"],
                                        max_cache_length=[0.25, 32], global_tokens=3, recent_window=0.2), 50 + j(-5, 9), 14 + j(0, 5), dict()))
+    # (debug_* through setup_caches cannot be captured: the reference raises in KVCacheAnalysis.__init__ — 'no attribute cache_bits',
+    #  cache.py:181 reached before the attribute exists; the f10 fixtures drive the class directly)
     cases.append(("keep_it_odd", dict(cache_strategy=["keep_it_odd"], prompt_compression_strategy=["keep_it_odd"], max_cache_length=[24],
                                       global_tokens=4), 45 + j(-5, 9), 10 + j(0, 5), dict()))
     names = []
@@ -270,6 +272,8 @@ def generate_cases(C, G, M):
         out[name + ".prefill_tokens"] = np.array(int(stats["prefill_tokens"]))
         out[name + ".decode_tokens"] = np.array(int(stats["decode_tokens"]))
         out[name + ".n_probs"] = np.array(len(probs))
+        cs = model.get_cache_stats(prompt_len, new_tokens)  # (ref: model.py get_cache_stats -> KVCache.compute_statistics, cache.py:255-281)
+        out[name + ".cache_stats_json"] = np.array(json.dumps({k: float(v) for k, v in cs.items()}))
         for li, layer in enumerate(model.layers):
             out[f"{name}.final_pos_L{li}"] = layer.attention.kv_cache.pos.clone()
             out[f"{name}.pos_after_prefill_L{li}"] = after_prefill[0][li]

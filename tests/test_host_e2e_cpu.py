@@ -116,6 +116,12 @@ def test_generate_branches_match_reference_on_cpu(twin):
             assert torch.equal(seq, f[name + ".seq"]), f"{name}: sequence"
         assert (stats["prefill_tokens"], stats["decode_tokens"], len(probs)) == (int(f[name + ".prefill_tokens"]), int(f[name + ".decode_tokens"]),
                                                                                int(f[name + ".n_probs"])), name
+        if not hybrid or torch.equal(seq, f[name + ".seq"]):  # compression ratios, per-policy head fractions, cache memory (cache.py:255-281)
+            want = json.loads(f[name + ".cache_stats_json"])
+            got = model.get_cache_stats(len(f[name + ".prompt"]), int(f[name + ".new_tokens"]))
+            assert set(got) == set(want), f"{name}: statistics keys {sorted(set(got) ^ set(want))}"
+            for k_, v_ in want.items():
+                assert abs(float(got[k_]) - v_) <= 1e-6 + 1e-6 * abs(v_), f"{name}: {k_} = {float(got[k_])}, reference {v_}"
         for li, layer in enumerate(model.layers):
             # (the SET of positions every head holds: slot order is the F1 tests' business, and l2 may evict two keys of equal norm —
             #  repeated tokens, vector_norm's unspecified summation order — in either order: seen on a jittered fresh-seed set)
