@@ -120,16 +120,26 @@ def test_e2e_matches_reference(name):
 def check_e2e(name):
     """(also run by tests/test_host_e2e_cpu.py: the same harness on CPU tensors over the oracle's twins)"""
     f, model, seq, log, logits = _run(name)
-    assert torch.equal(seq, f["seq"]), "generated tokens differ from the reference"
     got = torch.stack(logits).cpu()
     assert got.shape == f["logits"].shape
     if "l2" in name:
         div = _l2_tie_divergence(f, log, f["n_layer"])
         if div is not None:  # identical up to the verified norm tie; afterwards the cache contents legitimately differ
-            t = div[1] + 1  # logits row 0 is the prefill; decode step t is row t + 1
+            t, n = div[1] + 1, int(f["prompt_len"])  # logits row 0 is the prefill (token index n); decode step t is row t + 1
+            assert torch.equal(seq[: n + t], f["seq"][: n + t]), "generated tokens differ from the reference before the norm tie"
             assert (got[:t] - f["logits"][:t]).abs().max() < 1e-3
-            assert (got - f["logits"]).abs().max() < 2e-2
+            # behind the tie: the logits stay close while the tokens agree, and a token may differ only where the reference's own two
+            # best logits are closer than twice the deviation there (r5, a fresh-seed run: margin 0.0013 at a deviation of 0.003) —
+            # from then on it is another generation
+            for r in range(t, got.shape[0]):
+                dev = float((got[r] - f["logits"][r]).abs().max())
+                assert dev < 2e-2, f"logits row {r}: {dev}"
+                if int(seq[n + r]) != int(f["seq"][n + r]):
+                    top2 = f["logits"][r].float().topk(2).values
+                    assert float(top2[0] - top2[1]) <= 2 * dev, f"token {n + r} differs where the reference's margin is {float(top2[0] - top2[1])}"
+                    break
             return
+    assert torch.equal(seq, f["seq"]), "generated tokens differ from the reference"
     assert (got - f["logits"]).abs().max() < 1e-3, "fp32 logits differ by more than the north-star 1e-3"
     for li, layer in enumerate(model.layers):
         kv = layer.attention.kv_cache
