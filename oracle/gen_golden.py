@@ -228,6 +228,10 @@ def generate_cases(C, G, M):
                                        max_cache_length=[0.25, 32], global_tokens=3, recent_window=0.2), 50 + j(-5, 9), 14 + j(0, 5), dict()))
     # (debug_* through setup_caches cannot be captured: the reference raises in KVCacheAnalysis.__init__ — 'no attribute cache_bits',
     #  cache.py:181 reached before the attribute exists; the f10 fixtures drive the class directly)
+    # the quantised KV cache through generate() at 4 and 2 bits (8 bits: f9_e2e_heavy_hitter_q8.npz)
+    for nb in (4, 2):
+        cases.append((f"heavy_hitter_q{nb}", dict(cache_strategy=["heavy_hitter"], prompt_compression_strategy=["heavy_hitter"], max_cache_length=[32],
+                                                  global_tokens=4, recent_window=4, cache_bits=nb), 50 + j(-5, 9), 12 + j(0, 5), dict()))
     cases.append(("keep_it_odd", dict(cache_strategy=["keep_it_odd"], prompt_compression_strategy=["keep_it_odd"], max_cache_length=[24],
                                       global_tokens=4), 45 + j(-5, 9), 10 + j(0, 5), dict()))
     names = []

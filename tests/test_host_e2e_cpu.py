@@ -80,7 +80,7 @@ def test_generate_branches_match_reference_on_cpu(twin):
 
     f = load_golden("f1_generate_branches.npz")
     names = [str(c) for c in np.load(os.path.join(GOLDEN, "f1_generate_branches.npz"))["cases"]]
-    assert len(names) >= 9
+    assert len(names) >= 11
     cfg = dict(block_size=256, vocab_size=128, n_layer=2, n_head=4, n_local_heads=2, dim=64, intermediate_size=128)
     model = Transformer(ModelArgs(**cfg)).to(torch.float32).eval()
     model.load_state_dict({k[3:]: v for k, v in f.items() if k.startswith("sd.")}, strict=True)
@@ -119,7 +119,8 @@ def test_generate_branches_match_reference_on_cpu(twin):
         if not hybrid or torch.equal(seq, f[name + ".seq"]):  # compression ratios, per-policy head fractions, cache memory (cache.py:255-281)
             want = json.loads(f[name + ".cache_stats_json"])
             got = model.get_cache_stats(len(f[name + ".prompt"]), int(f[name + ".new_tokens"]))
-            assert set(got) == set(want), f"{name}: statistics keys {sorted(set(got) ^ set(want))}"
+            extra = {k_ for k_ in set(got) - set(want) if not k_.startswith("working_cache_gb")}  # (ours, documented: the working copy of a quantised cache)
+            assert set(want) <= set(got) and not extra, f"{name}: statistics keys {sorted(set(got) ^ set(want))}"
             for k_, v_ in want.items():
                 assert abs(float(got[k_]) - v_) <= 1e-6 + 1e-6 * abs(v_), f"{name}: {k_} = {float(got[k_])}, reference {v_}"
         for li, layer in enumerate(model.layers):
