@@ -24,7 +24,9 @@ class _NoStream:
 
 
 @contextlib.contextmanager
-def cpu_twin(monkeypatch, oracle):
+def cpu_twin(monkeypatch, oracle, single_launch=False):
+    """single_launch: the availability queries answer YES, so that the Python layer takes the call sequence of the single-launch /
+    recoverable forms (the `_rc` entry points with their commit words, the QKV form's query) — served by the same twins."""
     import host_glue
 
     import cold_compress_amd.attention_utils as au
@@ -67,7 +69,9 @@ def cpu_twin(monkeypatch, oracle):
         if real is not None and name in host_only:
             twins[name] = real[name]
         elif name in answers_no:
-            twins[name] = (lambda *a, **k: 0)
+            yes = single_launch and name in ("cc_decode_step_single_launch", "cc_decode_step_quant_single_launch", "cc_decode_step_hybrid_single_launch",
+                                             "cc_decode_step_l2_single_launch", "cc_decode_step_single_launch_enabled")
+            twins[name] = (lambda *a, **k: 1) if yes else (lambda *a, **k: 0)
         else:  # compute entry points without a twin fail LOUDLY (check() raises), never silently do nothing
             twins[name] = (lambda *a, **k: CC_ERR_UNSUPPORTED)
     twins["cc_decode_step_l2_rc"], twins["cc_decode_step_quant_rc"] = l2_rc, quant_rc

@@ -31,6 +31,25 @@ def test_e2e_host_logic_matches_reference_on_cpu(twin, name):
     E.check_e2e(name)
 
 
+@pytest.mark.parametrize("name,entry", [("f1_e2e_recent_global.npz", "cc_decode_step_head_constant_rc"), ("f1_e2e_heavy_hitter.npz", "cc_decode_step_heavy_hitter_rc"),
+                                        ("f1_e2e_hh_pyramid.npz", "cc_decode_step_heavy_hitter_rc")])
+def test_e2e_host_logic_on_the_recoverable_forms(monkeypatch, oracle, name, entry):
+    """The same runs with the availability queries answering YES: the Python layer then takes the call sequence of the single-launch /
+    recoverable forms — the `_rc` entry points with their commit words (what a device with the single launch runs) — and must reach the
+    same tokens, slots, logits and final state; the test also checks that those entry points are what was called."""
+    monkeypatch.setattr(E, "DEV", "cpu")
+    calls = {}
+    with cpu_twin(monkeypatch, oracle, single_launch=True) as fns:
+        for k in [k for k in fns if k.startswith("cc_decode_step") or k.startswith("cc_decode_update")]:
+            def counted(*a, _f=fns[k], _k=k, **kw):
+                calls[_k] = calls.get(_k, 0) + 1
+                return _f(*a, **kw)
+
+            fns[k] = counted
+        E.check_e2e(name)
+    assert calls.get(entry, 0) > 0 and not any(k.startswith("cc_decode_update") for k in calls), calls
+
+
 def test_c1_ring_known_answer_on_cpu(twin):
     """BASELINE config C1 (the reference's CPU-runnable case): recent_global, S = 16, g = 4 -> the slot at decode step t is 4 + (t mod 12)."""
     f, model, seq, log, _ = E._run("f1_e2e_recent_global.npz")
