@@ -1,0 +1,20 @@
+#!/bin/bash
+# Differential fuzz against the reference on the CPU (build container only: needs /root/reference).  For every offset the reference makes
+# every fixture family again (oracle/gen_golden.py --seed_offset N --jitter_shapes), then (i) the CPU oracle tests, (ii) the fixture-driven
+# `-m gpu` test files with the product's Python layer on CPU tensors over the oracle's twins (tests/cpu_twin.py), (iii) the harness end
+# to end and generate()'s branches (tests/test_host_e2e_cpu.py) run on those vectors.  A set with a failure is KEPT (path printed).
+#   tools/fuzz_fresh_seeds.sh [first_offset [count [stride]]]        e.g. tools/fuzz_fresh_seeds.sh 700001 20 97
+cd "$(dirname "$0")/.." || exit 1
+first=${1:-700001}; count=${2:-10}; stride=${3:-97}
+mkdir -p .ab
+for i in $(seq 0 $((count - 1))); do
+  off=$((first + i * stride)); d=$PWD/.ab/fresh_$off; rm -rf "$d"; mkdir -p "$d"
+  PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py --out "$d" --seed_offset $off --jitter_shapes > "$d.log" 2>&1 || { echo "offset $off: generator failed: $(tail -2 "$d.log" | tr '\n' ' ')"; continue; }
+  r1=$(CC_GOLDEN_DIR=$d python -m pytest -q -m "not gpu" -p no:cacheprovider tests/test_oracle_golden.py tests/test_oracle_hybrid.py tests/test_oracle_quant.py \
+        tests/test_hh_ring.py tests/test_window_sums.py tests/test_hh_query_fixture.py tests/test_hybrid_profile_ref.py 2>&1 | tail -1)
+  r2=$(CC_GOLDEN_DIR=$d CC_TEST_CPU_TWIN=1 CC_TEST_DEVICE=cpu python -m pytest -m gpu -q -p no:cacheprovider tests/test_gpu_parity.py tests/test_gpu_e2e.py \
+        tests/test_gpu_hybrid.py tests/test_gpu_quant.py tests/test_hh_ring.py tests/test_hh_query_fixture.py 2>&1 | grep 'passed\|failed' | tail -1)
+  r3=$(CC_GOLDEN_DIR=$d python -m pytest -q -p no:cacheprovider tests/test_host_e2e_cpu.py -k "not fixture_driven" 2>&1 | tail -1)
+  echo "offset $off | oracle: $r1 | twin: $r2 | harness: $r3"
+  case "$r1$r2$r3" in *failed*|*error*) echo "  kept: $d";; *) rm -rf "$d" "$d.log";; esac
+done
