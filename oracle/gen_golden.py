@@ -210,10 +210,11 @@ def generate_cases(C, G, M):
     hh = dict(cache_strategy=["heavy_hitter"], prompt_compression_strategy=["heavy_hitter"], max_cache_length=[32], global_tokens=4,
               recent_window=4)
     rg = dict(cache_strategy=["recent_global"], prompt_compression_strategy=["recent_global"], max_cache_length=[16], global_tokens=4)
-    l2 = dict(cache_strategy=["l2"], prompt_compression_strategy=["l2"], max_cache_length=[24], global_tokens=4, recent_window=5)
     cases = [("feed_long", hh, 56 + j(-5, 9), 10 + j(0, 5), dict(feed_long_prompts=True)),
              ("prompt_equals_cache", rg, 16, 9 + j(0, 5), dict()),
-             ("decode_first", l2, 48 + j(-5, 9), 8 + j(0, 5), dict(decode_first_token=True)),
+             # (heavy_hitter, not l2: l2 evicts keys of EQUAL norm — repeated tokens — in an order that follows vector_norm's unspecified
+             #  summation order, and a jittered set showed the kept sets drifting apart behind such a tie; the branch is the point here)
+             ("decode_first", hh, 48 + j(-5, 9), 8 + j(0, 5), dict(decode_first_token=True)),
              ("teacher_forced", hh, 44 + j(-5, 9), 0, dict(next_tokens=[(11 * i + 3 + j(0, 50)) % 128 for i in range(9 + j(0, 4))])),
              ("terminator", hh, 40 + j(-5, 9), 14 + j(0, 4), dict(terminator_ids="@step5"))]
     # the FastGen hybrid cache THROUGH generate() (cache_configs/hybrid.yaml, fastgen.yaml): prefill profiling from the harness's own

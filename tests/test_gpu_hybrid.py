@@ -94,7 +94,7 @@ def test_hybrid_prefill_and_decode_vs_reference(name):
 
 
 @pytest.mark.parametrize("name", FIXTURES)
-def test_hybrid_stable_partition_keeps_the_same_sets(name):
+def test_hybrid_stable_partition_keeps_the_same_sets(name, audit):
     f = load_golden(name)
     dtype = DT_FROM_NAME[f["dtype"]]
     kv = _make(f, dtype)
@@ -102,10 +102,25 @@ def test_hybrid_stable_partition_keeps_the_same_sets(name):
     assert kv.cache_strategies.cpu().tolist() == f["cache_strategies"].tolist()
     cts = kv.cache_cts.cpu()
     assert torch.equal(cts, f["cts_after_prefill"].to(torch.int32))
+    n_tie = 0
     for h in range(f["H"]):
         mine = kv.pos.cpu()[0, h, : int(cts[h])]
         ref = f["pos_after_prefill"][0, h, : int(cts[h])]
-        assert sorted(mine.tolist()) == sorted(ref.tolist())
+        if sorted(mine.tolist()) != sorted(ref.tolist()):
+            # the heavy-hitter part of a policy keeps the top-k column means: tokens swapped between the two sets must sit ON the
+            # selection boundary — column means within two roundings of the dtype of each other (the reference's bf16 chain and ours
+            # round in different places; r5, a jittered fresh-seed set: 0.00848 against 0.00842, one bf16 step) — never elsewhere
+            L = int(f["L"])
+            cm = f["attn0"][0, h].float().sum(0) / (L - torch.arange(L)).float()
+            swapped = sorted(set(mine.tolist()) ^ set(ref.tolist()))
+            vals = cm[torch.tensor(swapped)]
+            step = 2.0 ** (torch.floor(torch.log2(vals.max())) - (7 if dtype == torch.bfloat16 else 10 if dtype == torch.float16 else 20))
+            assert float(vals.max() - vals.min()) <= 2 * float(step), f"head {h}: kept sets differ away from the selection boundary: {swapped}, {vals.tolist()}"
+            assert len(swapped) <= 4, swapped
+            n_tie += len(swapped) // 2
+    audit(f"kept tokens swapped on a top-k boundary tie = {n_tie} (column means within two roundings)")
+    for h in range(f["H"]):
+        mine = kv.pos.cpu()[0, h, : int(cts[h])]
         assert bool((mine[1:] > mine[:-1]).all()), "stable partition keeps the original order inside the kept class"
         assert bool((kv.pos.cpu()[0, h, int(cts[h]):] == -1).all())
 
