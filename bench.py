@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--no_graph", action="store_true", help="force eager launches")
     ap.add_argument("--graph", action="store_true", help="force hipGraph replay (default: time both on a few untimed tokens, keep the faster)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--no_long_window", action="store_true", help="skip the extra 128-token window behind the timed region (value_128_steps)")
     ap.add_argument("--roofline_iters", type=int, default=20)
     ap.add_argument("--no_live_pmc", action="store_true", help="take roofline.traffic from profiles/ instead of two rocprofv3 --pmc child runs")
     ap.add_argument("--pmc_child", action="store_true", help=argparse.SUPPRESS)  # the workload rocprofv3 is wrapped around
@@ -310,6 +311,9 @@ def roofline(model, args, dev):
             # what ANY stand-alone launch streaming these 16.8 MB costs here: the step's grid and K/V loads and nothing else
             # (cc_decode_step_stream_floor), same graph, same caches, same events — and the step against it
             "launch_floor_us": round(floor_us, 3), "frac_of_launch_floor": round(floor_us / mean_us, 4),
+            # the ceiling of ANY stand-alone launch of this size on this device, as a fraction of HBM peak: B_step over the floor launch
+            # (stated beside `frac` — the 0.60 of the north star lies above it at S = 4096)
+            "ceiling_standalone": round(step_bytes / (floor_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
             "min_us": round(us[0], 3), "launches": len(us) * len(layers), "layer_step_bytes": step_bytes,
             "two_launch_step_us": round(sum(us_two) / len(us_two), 3),
             "streaming_pass_only": {"kernel": "decode_attn_split_mfma_kernel<bf16_t,4,4,false>", "bytes_per_launch": split_bytes,
@@ -447,7 +451,11 @@ def overlap_probe(model, args, dev):
     dt = atts[0].wqkv.weight.dtype
     x = torch.randn(1, 1, K, device=dev).to(dt)
     h = torch.empty_like(x)
-    fr = model.freqs_cis[args.prompt_len + 30_000: args.prompt_len + 30_001].contiguous()
+    # (the row used to be sliced at prompt_len + 30000 — past the table's end for the default 8k prompt: an EMPTY slice, a
+    #  null pointer, and both forms silently skipped the rotation; r5's overlap numbers were measured without the RoPE epilogue)
+    p_rope = (args.prompt_len + 30_000) % model.freqs_cis.shape[0]
+    fr = model.freqs_cis[p_rope: p_rope + 1].contiguous()
+    assert fr.numel() > 0 and fr.data_ptr() != 0, "the RoPE row of the overlap probe must exist"
     pos = torch.tensor([args.prompt_len + 30_000], dtype=torch.int32, device=dev)
     snap = [{k: v.clone() for k, v in a.kv_cache._buffers.items()} for a in atts]
     for a in atts:
@@ -788,20 +796,12 @@ def main():
 
         gdec = None
         if not args.no_graph:
-            try:
-                gdec = GraphedDecoder(model)
-                run_with(gdec, 1)  # captures (on a state snapshot) and runs the first step
-            except Exception as e:  # pragma: no cover - only if capture is refused (e.g. RCCL under capture)
-                print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); falling back to eager launches",
-                      file=sys.stderr)
-                gdec = None
-        if world > 1 and not args.no_graph:
-            # every rank replays a graph or none does (a rank that fell back alone would skip the timed comparison below, whose
-            # MAX all-reduces its peers would then wait in)
-            okf = torch.tensor([1 if gdec is not None else 0], device=dev, dtype=torch.int32)
-            dist.all_reduce(okf, op=dist.ReduceOp.MIN)
-            if int(okf.item()) == 0:
-                gdec = None
+            # every rank replays a graph or none does (harness.negotiate_graphed_decoder: a capture refused on ANY rank — e.g. RCCL
+            # under capture — sends all of them to eager launches; tests/test_tp_gloo.py injects the refusal on one rank)
+            from cold_compress_amd.harness import negotiate_graphed_decoder
+
+            gdec = negotiate_graphed_decoder(lambda: GraphedDecoder(model), lambda d: run_with(d, 1), dev,
+                                             log=lambda m: print(f"[bench] {m}", file=sys.stderr))
         if gdec is None:
             dec, mode = decode_one_token, "eager"
         elif args.graph:
@@ -832,6 +832,23 @@ def main():
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
+        # `value` is the window the caller asked for (--steps); the builder's longer window (128 tokens, what README /
+        # DESIGN quote) rides the same line as value_128_steps, measured right behind it under the same barrier / MAX-over-ranks rule
+        dt128 = None
+        if args.steps != 128 and not args.no_long_window:
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            run(128)
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            dt128 = time.perf_counter() - t1
+            if world > 1:
+                t = torch.tensor([dt128], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt128 = float(t.item())
 
         # a timed-out one-shot all-reduce poisons its output and sets a word: every rank checks (a collective), loudly
         oneshot_status = 0
@@ -885,6 +902,7 @@ def main():
             "metric": "decode tokens/sec, Llama-3-8B heavy_hitter cache=4096 (+ evict/attention layer-step HBM GB/s in roofline)",
             "value": round(args.steps / dt, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+            "value_128_steps": round((128 / dt128) if dt128 else (args.steps / dt), 2),
             "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"Llama-3-8B shape (32 layers, HQ=32, H=8, D=128, bf16, random N(0,0.02) weights), "
                                    f"cache_strategy=heavy_hitter, max_cache_length={kv0.max_cache_length}, "

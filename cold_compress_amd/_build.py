@@ -20,8 +20,10 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 # Per-file extras.  cc_attn_decode: keep the matrix-core accumulators in architectural VGPRs (gfx950 has one unified register
 # file) — the streaming pass rescales its 32 accumulators with VALU multiplies whenever the running maximum moves, and with the
 # accumulators parked in AGPRs that costs 68 v_accvgpr_read / _write per tile, a sixth of the loop's instructions.
-EXTRA_FLAGS = {"cc_attn_decode.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
-               "cc_attn_decode_qkv.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+# -amdgpu-kernarg-preload-count=14 (r6): the step kernels' leading scalar arguments — what their first requests need — arrive in SGPRs
+# with the wave instead of through a round of kernel-argument loads (cc_attn_decode_kernels.h, CC_V_PRELOAD).
+EXTRA_FLAGS = {"cc_attn_decode.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-mllvm", "-amdgpu-kernarg-preload-count=14"],
+               "cc_attn_decode_qkv.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-mllvm", "-amdgpu-kernarg-preload-count=14"]}
 
 
 def _hipcc():

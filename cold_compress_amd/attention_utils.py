@@ -103,13 +103,25 @@ def reset_single_launch_status(device=None):
         torch.cuda.synchronize()
 
 
+def set_device_single_launch(device, enabled):
+    """The knob for a SHARED GPU (include/coldcompress.h, cc_decode_step_device_single_launch): enabled = False makes every decode step
+    launched on `device` from now on take the two-launch forms — nothing in them waits for other workgroups, so a device this process
+    shares with other processes or kernels cannot time them out; True restores the single-launch forms.  Per device: other devices of
+    the process keep theirs.  Drop captured decode graphs (GraphedDecoder.graph = None) after flipping it: a captured step keeps the
+    form it was captured with.  -> the previous setting."""
+    dev = torch.device(device)
+    with torch.cuda.device(dev):
+        return bool(_abi.lib()["cc_decode_step_device_single_launch"](1 if enabled else 0))
+
+
 def raise_single_launch_failure(device=None):
     """Clear the (sticky) status word — reported once; the next generation starts clean — and raise."""
     reset_single_launch_status(device)
     raise ColdCompressError(
         "a single-launch layer step did not complete its in-launch hand-off (its workgroups were not all resident, e.g. the "
-        "GPU was shared with another kernel): the tokens produced since are invalid.  Disable the single-launch form with "
-        "cc_decode_step_set_single_launch(0) (or KVCacheHeavyHitter.single_launch = False) when the device is shared.")
+        "GPU was shared with another kernel): the tokens produced since are invalid.  On a shared device switch the single-launch "
+        "forms off for THAT device: cold_compress_amd.attention_utils.set_device_single_launch(device, False) "
+        "(cc_decode_step_device_single_launch(0) in include/coldcompress.h).")
 
 
 def check_single_launch_status(device=None):

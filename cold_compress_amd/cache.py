@@ -421,11 +421,15 @@ def step_committed(kv, position, HQ=None):
     return bool(used.any()) and bool((w[used] == int(position)).all()) and bool(used.any(dim=1).all())
 
 
-def step_is_recoverable(cache, HQ):
+def step_is_recoverable(cache, HQ, attention=None):
     """`cache.recoverable()` AND the decode step of this cache, for `HQ` query heads on this device, actually takes the form that
     honours the status / commit words of the recoverable hand-off: the single-launch form.  The two-launch and three-call forms
     ignore both — they would step on garbage behind a failed launch and step AGAIN on the retry: the harness refuses
-    in-band recovery unless every layer answers True here."""
+    in-band recovery unless every layer answers True here.  `attention`: the layer's Attention module, when the caller
+    has one — a layer that does not route its decode through the fused step (`fuse_decode_step = False`: the three-call path)
+    answers False whatever its cache could do."""
+    if attention is not None and not getattr(attention, "fuse_decode_step", True):
+        return False
     rec = getattr(cache, "recoverable", None)
     if not callable(rec) or not rec():
         return False
@@ -435,13 +439,14 @@ def step_is_recoverable(cache, HQ):
     if not lib["cc_decode_step_single_launch_enabled"]():
         return False
     args = (int(HQ), cache.n_heads, cache.max_cache_length, cache.head_dim, _DT[cache.k_cache.dtype])
-    if type(cache).__name__ == "KVCacheHybrid":
-        return bool(lib["cc_decode_step_hybrid_single_launch"](*args))
-    if cache.fused_quant:
-        return bool(lib["cc_decode_step_quant_single_launch"](*args, 8))
-    if type(cache).__name__ == "KVCacheL2":
-        return bool(lib["cc_decode_step_l2_single_launch"](*args))
-    return bool(lib["cc_decode_step_single_launch"](*args))
+    with torch.cuda.device(cache.k_cache.device):  # (residency and the dispatch-order verdict are facts of THAT device)
+        if isinstance(cache, KVCacheHybrid):  # (isinstance: a subclass takes its parent's step)
+            return bool(lib["cc_decode_step_hybrid_single_launch"](*args))
+        if cache.fused_quant:
+            return bool(lib["cc_decode_step_quant_single_launch"](*args, 8))
+        if isinstance(cache, KVCacheL2):
+            return bool(lib["cc_decode_step_l2_single_launch"](*args))
+        return bool(lib["cc_decode_step_single_launch"](*args))
 
 
 class KVCacheHeadConstant(KVCache):
@@ -458,13 +463,14 @@ class KVCacheHeadSpecific(KVCache):
 def _qkv_step_available(cache, HQ, K):
     """The layer step can take the layer's QKV projection along (include/coldcompress.h, cc_decode_step_qkv_rc) for this cache,
     `HQ` query heads and model dim `K` on this device."""
-    memo = cache.__dict__.setdefault("_qkv_ok", {})  # (asked once per layer and token by the eager decode loop)
-    key = (int(HQ), int(K), cache.k_cache.device)
-    if key not in memo:
-        memo[key] = bool(cache.k_cache.is_cuda and cache.k_cache.dtype in (torch.bfloat16, torch.float16) and not cache.fused_quant
-                         and not cache.quantize and _abi.lib()["cc_decode_step_qkv_available"](
-                             int(HQ), cache.n_heads, cache.max_cache_length, cache.head_dim, _DT[cache.k_cache.dtype], int(K)))
-    return memo[key]
+    # NOT memoised (ADVICE r5): the answer hangs on state that moves under a running process — the single-launch switch, a demoted
+    # L2 hand-off, the dispatch-order probe (not yet run at the first question) — and a stale "yes" makes cc_decode_step_qkv_rc
+    # return CC_ERR_UNSUPPORTED in the middle of a decode or a recovery.  One ctypes call per layer and token in the eager loop.
+    if not (cache.k_cache.is_cuda and cache.k_cache.dtype in (torch.bfloat16, torch.float16) and not cache.fused_quant and not cache.quantize):
+        return False
+    with torch.cuda.device(cache.k_cache.device):
+        return bool(_abi.lib()["cc_decode_step_qkv_available"](int(HQ), cache.n_heads, cache.max_cache_length, cache.head_dim,
+                                                               _DT[cache.k_cache.dtype], int(K)))
 
 
 def _qkv_step(cache, policy, wqkv, bias, x, delta, norm_w, eps, h_out, freqs, input_pos, HQ, scale, qkv_out, num=None, denom=None,

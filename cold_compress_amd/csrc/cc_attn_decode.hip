@@ -532,15 +532,15 @@ template <typename T, bool L2, bool HYB, int QB, int NSUB, int NW = kNW>
 static int launch_mfma_rt(const SplitArgs& a, int rt, dim3 grid, dim3 block, hipStream_t st) {
   if constexpr (sizeof(T) == 2) {
     switch (rt) {
-      case 8: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 8, NW, L2, false, HYB, QB, NSUB>), grid, block, 0, st, a); break;
-      case 4: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 4, NW, L2, false, HYB, QB, NSUB>), grid, block, 0, st, a); break;
+      case 8: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 8, NW, L2, false, HYB, QB, NSUB>), grid, block, 0, st, CC_LEAD_ARGS(a) a); break;
+      case 4: hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 4, NW, L2, false, HYB, QB, NSUB>), grid, block, 0, st, CC_LEAD_ARGS(a) a); break;
       case 2:
         if constexpr (QB != 0 || NW != kNW) return CC_ERR_UNSUPPORTED;
-        else hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 2, NW, L2, false, HYB, QB, NSUB>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 2, NW, L2, false, HYB, QB, NSUB>), grid, block, 0, st, CC_LEAD_ARGS(a) a);
         break;
       default:
         if constexpr (QB != 0 || NW != kNW) return CC_ERR_UNSUPPORTED;
-        else hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 1, NW, L2, false, HYB, QB, NSUB>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((decode_attn_split_mfma_kernel<T, 1, NW, L2, false, HYB, QB, NSUB>), grid, block, 0, st, CC_LEAD_ARGS(a) a);
         break;
     }
     return CC_OK;
@@ -602,9 +602,8 @@ namespace {
 // The single-launch regions sit at FIXED offsets and fixed capacities, whatever the shape: caches of different lengths
 // (pyramid budgets) share one workspace and one set of epoch words, tags grow monotonically across all of them, and
 // nothing but the single-launch kernel ever writes a word that could be mistaken for a tag.
-constexpr size_t kOneHdrBytes = 4096, kOneMlCap = (size_t)kOneMaxHeads * (kOneMlHead + kOneNmHead) + 4096 /* kOneHmBytes, padded */,
-                 kOneOCap = (size_t)kOneMaxHeads * kOneOHead,
-                 kOneQCap = (size_t)kOneMaxHeads * kOneQHead;  // r5: the fused QKV projection's granules (behind the O granules)
+// (kOneHdrBytes, kOneMlCap, kOneOCap: cc_attn_decode_kernels.h — the LDS-DMA steps derive the granule regions from the header's address)
+constexpr size_t kOneQCap = (size_t)kOneMaxHeads * kOneQHead;  // r5: the fused QKV projection's granules (behind the O granules)
 constexpr size_t kOneBytes = kOneHdrBytes + kOneMlCap + kOneOCap + kOneQCap;
 constexpr int kOneStatusWord = 1023;  // hdr[0 .. H): epochs; hdr[1023]: timeout word
 constexpr int kOneMaxTiles = 16;  // tiles per wave the single-launch step keeps scores for (NT = 4, 8 or 16 instantiations; hybrid: up to 8)
@@ -627,9 +626,9 @@ static size_t base_workspace_bytes(const Plan& p, int HQ, int H, int S, int D, i
 // The answer is cached PER KERNEL: every instantiation has the same function type, so a cache keyed by the argument's type
 // (a `static` inside a template over the type) would be ONE cache for all of them — the first kernel asked would answer for
 // the fused-quant and multi-tile instantiations too, which keep fewer workgroups resident.
-static int one_capacity(void (*kernel)(SplitArgs), int threads) {
+static int one_capacity(void (*kernel)(CC_LEAD_TYPES SplitArgs), int threads) {
   struct Entry {
-    void (*k)(SplitArgs);
+    void (*k)(CC_LEAD_TYPES SplitArgs);
     int cap;
   };
   // readers take no lock: an entry is complete before the count that makes it visible is published (release / acquire); two
@@ -657,7 +656,7 @@ static int one_capacity(void (*kernel)(SplitArgs), int threads) {
   }
   return cap;
 }
-typedef void (*OneKernel)(SplitArgs);
+typedef void (*OneKernel)(CC_LEAD_TYPES SplitArgs);
 // The single-launch kernel that serves (query heads per kv head rt, tiles per wave nt, kind), or null.  kind: 0 = 16-bit cache
 // (heavy hitter / head-constant policies), 8 = fused quantised cache, -1 = l2, 200 = hybrid.  full: the instantiation with the
 // measurement hooks and attn_out (bf16, rt = 4 only).  ONE table for the residency check and the launch.
@@ -792,6 +791,7 @@ constexpr int kMaxDevices = 64;
 struct XccProbe {
   std::atomic<int> state{0};  // 0 unknown, 1 verified, 2 refuted / failed
   std::atomic<int> demoted{0};  // cc_decode_step_demote_l2_handoff: the caller saw a step fail with the L2-resident hand-off on THIS device
+  std::atomic<int> one_off{0};  // cc_decode_step_device_single_launch(0): THIS device is shared — its steps take the two-launch forms
 };
 static XccProbe g_xcc_probe[kMaxDevices];
 static std::atomic<int> g_l2_handoff_enabled{1};  // cc_decode_step_set_l2_handoff
@@ -820,7 +820,9 @@ size_t cc_decode_attn_workspace_bytes(int32_t HQ, int32_t H, int32_t S, int32_t 
 }
 
 // kind: see one_kernel.  Returns the kernel when the shape is eligible AND all its workgroups stay resident at once, else null.
-static OneKernel one_pick(int32_t HQ, int32_t H, int32_t S, int32_t D, int32_t dtype, int kind, bool full, bool allow_xl2 = false) {
+static OneKernel one_pick(int32_t HQ, int32_t H, int32_t S, int32_t D, int32_t dtype, int kind, bool full, bool allow_xl2 = false,
+                          bool* is_xl2 = nullptr) {
+  if (is_xl2) *is_xl2 = false;
   if (HQ <= 0 || H <= 0 || HQ % H || S <= 0 || D <= 0 || !cc_dt_ok(dtype)) return nullptr;
   const Plan p = make_plan(HQ, H, S, D, dtype);
   const int nt = one_tiles(p, HQ, H, D, dtype);
@@ -828,21 +830,34 @@ static OneKernel one_pick(int32_t HQ, int32_t H, int32_t S, int32_t D, int32_t d
   // l2: every thread gathers at most three workgroups' norm maxima
   if (kind == -1 && H * p.n_split > 3 * p.nw * 64) return nullptr;
   // XL2 first: a multiple of 8 kv heads (each head's workgroups on one XCD) on a device whose dispatch order was verified
-  if (allow_xl2 && (H & 7) == 0 && xl2_device_ok()) {
+  // (r6 A/B, CC_V_FEWXCD: 1, 2 or 4 kv heads on a grid of 8 virtual ones — every XCD must hold a head's n_split workgroups)
+  const bool virt8 = CC_V_FEWXCD != 0 && (H == 1 || H == 2 || H == 4);
+  if (allow_xl2 && ((H & 7) == 0 || virt8) && xl2_device_ok()) {
     const OneKernel kx = one_kernel_xl2_dt(dtype, p.rt, nt, kind, full, p.nw);
-    if (kx && p.n_split * H <= one_capacity(kx, p.nw * 64)) return kx;
+    if (kx && p.n_split * (virt8 ? 8 : H) <= one_capacity(kx, p.nw * 64)) {
+      if (is_xl2) *is_xl2 = true;
+      return kx;
+    }
   }
   const OneKernel k = one_kernel_dt(dtype, p.rt, nt, kind, full, p.nw);
   if (!k) return nullptr;
   return p.n_split * H <= one_capacity(k, p.nw * 64) ? k : nullptr;
 }
-static std::atomic<int> g_one_enabled{1};  // cc_decode_step_set_single_launch
+static std::atomic<int> g_one_enabled{1};  // cc_decode_step_set_single_launch (process-wide A/B switch, debug header)
+// the single-launch forms are allowed for a launch on the CURRENT device: the process-wide switch AND the device's own (r6: co-residency
+// of a launch's workgroups is a fact of one device — a rank that shares its GPU switches ITS device off, not the process)
+static bool one_enabled_here() {
+  if (!g_one_enabled.load(std::memory_order_relaxed)) return false;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return true;
+  return g_xcc_probe[dev].one_off.load(std::memory_order_relaxed) == 0;
+}
 // The QKV form of the single-launch step (cc_attn_decode_qkv.hip): the plain 16-bit caches' single-tile step, 4 or 8 query heads per
 // kv head, model dim K <= 4096 (two 1 KiB input segments per wave), at most 64 projection rows per workgroup.  -> 0 = no,
 // 1 = memory hand-off, 2 = the XL2 placement + L2-resident hand-off
 static int qkv_pick(int32_t HQ, int32_t H, int32_t S, int32_t D, int32_t dtype, int32_t K, Plan* plan_out) {
   if (HQ <= 0 || H <= 0 || HQ % H || S <= 0 || D != 128 || cc_dt_size(dtype) != 2 || !cc_dt_ok(dtype) || K < 8 || K % 8 || K > 4096) return 0;
-  if (!g_one_enabled.load(std::memory_order_relaxed)) return 0;
+  if (!one_enabled_here()) return 0;
   const Plan p = make_plan(HQ, H, S, D, dtype);
   if (one_tiles(p, HQ, H, D, dtype) != 1 || (p.rt != 4 && p.rt != 8) || (p.nw != 4 && p.nw != 8)) return 0;
   const int nu = (p.rt + 2) * 32;
@@ -870,9 +885,18 @@ int32_t cc_decode_step_l2_single_launch(int32_t HQ, int32_t H, int32_t S, int32_
   return one_available(HQ, H, S, D, dtype, -1);
 }
 // 1 while the fused decode steps may take their single-launch form at all (cc_decode_step_set_single_launch)
-int32_t cc_decode_step_single_launch_enabled(void) { return g_one_enabled.load(std::memory_order_relaxed) ? 1 : 0; }
+int32_t cc_decode_step_single_launch_enabled(void) { return one_enabled_here() ? 1 : 0; }
+// Per DEVICE (the current one): enabled == 0 -> steps launched on this device take the two-launch forms from now on (a device shared
+// with other processes or kernels: a launch's workgroups are not all resident together there); != 0 -> the single-launch forms
+// again.  Other devices of the process are untouched.  -> the previous value.  (The user-facing knob: include/coldcompress.h.)
+int32_t cc_decode_step_device_single_launch(int32_t enabled) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return 1;
+  return g_xcc_probe[dev].one_off.exchange(enabled ? 0 : 1, std::memory_order_relaxed) ? 0 : 1;
+}
 
 int32_t cc_decode_step_status_offset(void) { return kOneStatusWord * (int32_t)sizeof(unsigned); }
+int32_t cc_decode_step_wait_bound_us(void) { return (int32_t)(kOneWaitTicks / 100ull); }  // (s_memrealtime: 100 ticks per microsecond)
 int32_t cc_decode_step_commit_stride(void) { return kRcStride; }
 
 static void* g_one_trace = nullptr;
@@ -914,9 +938,9 @@ int32_t cc_decode_step_probe_xcd(void) {
   bool ok = hipMalloc(&dbuf, kMaxBlocks * sizeof(unsigned)) == hipSuccess && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
   unsigned host[kMaxBlocks];
   int launches = 0;
-  const int shapes[2][2] = {{32, 8}, {64, 16}};
+  const int shapes[4][2] = {{32, 8}, {64, 16}, {256, 1}, {1024, 1}};  // (r6: the XL2 steps are launched as 1-D grids)
   for (int rep = 0; ok && rep < 4; rep++) {
-    const int gx = shapes[rep & 1][0], gy = shapes[rep & 1][1], nb = gx * gy;
+    const int gx = shapes[rep][0], gy = shapes[rep][1], nb = gx * gy;
     hipLaunchKernelGGL(xcc_probe_kernel, dim3(gx, gy), dim3(512), 0, st, dbuf);
     ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(host, dbuf, nb * sizeof(unsigned), hipMemcpyDeviceToHost, st) == hipSuccess &&
          hipStreamSynchronize(st) == hipSuccess;
@@ -1030,6 +1054,9 @@ static int attn_impl(const void* q, const void* k, const void* v, const uint8_t*
     sa.H = H; sa.Hc = fs->c->Hc; sa.Hp = fs->c->Hp;
     sa.commit = fs->commit;
   }
+#if CC_V_PRELOAD
+  if (sa.nk_read > kLeadNkReadMax || H > kLeadHMax) return CC_ERR_UNSUPPORTED;  // (the packed preloaded word: 2^20 live key entries, 2047 kv heads)
+#endif
   hipStream_t st = (hipStream_t)stream;
   int rc = CC_OK;
   if (fs && fs->qkv) {
@@ -1057,7 +1084,7 @@ static int attn_impl(const void* q, const void* k, const void* v, const uint8_t*
   // ---- single-launch layer step (heavy hitter, W == 1): phases bit CC_PHASE_ONE_LAUNCH forces it (error if the shape or
   //      the device's residency does not allow it), CC_PHASE_TWO_LAUNCH forbids it; otherwise it is used whenever it can be
   const bool one_asked = (phases & CC_PHASE_ONE_LAUNCH) != 0;
-  if (one_asked || (g_one_enabled.load(std::memory_order_relaxed) && (phases & 3) == 3 && !(phases & CC_PHASE_TWO_LAUNCH))) {
+  if (one_asked || (one_enabled_here() && (phases & 3) == 3 && !(phases & CC_PHASE_TWO_LAUNCH))) {
     const bool policy_ok = fs && ((fs->policy == 1 && hh_num && hh_denom && fs->c->Hp == H) ||
                                   ((fs->policy == 2 || (fs->policy == 3 && (fs->rand_next || fs->rng_on))) && !hh_num && fs->c->Hp == 1) ||
                                   (fs->policy == 4 && fs->key_norm && !hh_num && fs->c->Hp == H) ||
@@ -1066,9 +1093,10 @@ static int attn_impl(const void* q, const void* k, const void* v, const uint8_t*
     // there is one (a time stamp alone is not worth leaving the product kernel for)
     const bool want_full = attn_out != nullptr || sa.abl != 0;
     OneKernel kern = nullptr;
+    bool kern_xl2 = false;
     if (policy_ok && (!rh || fs->policy == 6) && !probs_out && !attn_out_needs_probs(fs, attn_out)) {
-      if (want_full || g_one_trace) kern = one_pick(HQ, H, S, D, dtype, kind, true, true);
-      if (!kern && !want_full) kern = one_pick(HQ, H, S, D, dtype, kind, false, true);
+      if (want_full || g_one_trace) kern = one_pick(HQ, H, S, D, dtype, kind, true, true, &kern_xl2);
+      if (!kern && !want_full) kern = one_pick(HQ, H, S, D, dtype, kind, false, true, &kern_xl2);
     }
     const bool one_ok = kern != nullptr;
     if (one_asked && !one_ok) return CC_ERR_UNSUPPORTED;
@@ -1088,7 +1116,15 @@ static int attn_impl(const void* q, const void* k, const void* v, const uint8_t*
           sa.ring_num = rh->num; sa.ring_acc = reinterpret_cast<unsigned long long*>(rh->acc); sa.ring_wsum = rh->wsum;
         }
       }
-      hipLaunchKernelGGL(kern, dim3(p.n_split, H, 1), dim3(p.nw * 64), 0, st, sa);
+#if CC_V_PRELOAD
+      // (the XL2 instantiations take their (kv head, split) from a linear block index: a 1-D grid, the head count preloaded)
+      sa.virt8 = (kern_xl2 && (H & 7) != 0) ? 1 : 0;
+      const dim3 one_grid = kern_xl2 ? dim3(p.n_split * (sa.virt8 ? 8 : H), 1, 1) : dim3(p.n_split, H, 1);
+#else
+      const dim3 one_grid(p.n_split, H, 1);
+      (void)kern_xl2;
+#endif
+      hipLaunchKernelGGL(kern, one_grid, dim3(p.nw * 64), 0, st, CC_LEAD_ARGS(sa) sa);
       CC_LAUNCH_CHECK();
       return CC_OK;
     }

@@ -39,6 +39,36 @@
 #ifndef CC_QKV_TRACE
 #define CC_QKV_TRACE 0  // 1 (measurement builds of cc_attn_decode_qkv.hip only): thread 0 of every workgroup stamps the phases of the QKV step
 #endif
+#ifndef CC_V_PRELOAD
+#define CC_V_PRELOAD 0  // r6 A/B (VERDICT r5 #1b, "the prologue"): 1 = the operands of the step's FIRST requests (its words, the key row, the K
+                        // rows) are leading scalar kernel arguments, preloaded into SGPRs at wave launch (-mllvm
+                        // -amdgpu-kernarg-preload-count=14; tools/probes/preload_probe shows the firmware honours it, also under graph
+                        // replay): no kernel-argument round trip in front of the first K request.  MEASURED (profiles/r06_ab_step_variants.md):
+                        // with LATE + EARLYARGS below the first K request leaves 0.46-0.59 us after a workgroup's first instruction
+                        // instead of 0.85 — and the K rows LAND when they always did (2.9 us at C3, 1.6-1.7 at one kv head): the step is
+                        // 0.05-0.1 us SLOWER at C3 / C2, 0.05 faster at C5's rank.  What bounds the first byte is not when it is asked
+                        // for (tools/probes/first_byte_probe).  Off: the r5 prologue is the product's.
+#endif
+#ifndef CC_V_LATE
+#define CC_V_LATE 1     // r6 A/B: with the preloaded arguments, the LDS-DMA steps read the rest of their argument block BEHIND the first K request
+                        // (0: left to the compiler, which puts scalar waits in front of the K request in 37 of 47 instantiations)
+#endif
+#ifndef CC_V_EARLYARGS
+#define CC_V_EARLYARGS 1  // r6 (LATE steps): the rest of the argument block is REQUESTED at the kernel's first instruction — scalar loads spelled
+                          // in assembly, which the compiler's wait-count pass does not see — and waited for once, behind the K request:
+                          // the round trip runs in the shadow of the prologue instead of behind it (0: requested behind the K request)
+#endif
+#ifndef CC_V_VEARLY
+#define CC_V_VEARLY 0   // r6 A/B: the V rows requested right behind the K rows (1: the steps without the XL2 placement — few-head ranks, whose
+                        // caches are latency-bound, not bandwidth-bound; 2: every LDS-DMA step).  At C3 this order lost 0.4 us (r4).
+#endif
+#ifndef CC_V_FEWXCD
+#define CC_V_FEWXCD 0   // r6 A/B: ranks with 1, 2 or 4 kv heads take the XL2 instantiations on a grid of 8 VIRTUAL heads — block b works for kv head
+                        // b % 8 when that is < H and exits otherwise: a head's workgroups share ONE XCD, its hand-off stays in that L2
+#endif
+#if CC_V_FEWXCD && !CC_V_PRELOAD
+#error "the virtual-head placement takes its head counts from the preloaded arguments"
+#endif
 #ifndef CC_V_MLW
 #define CC_V_MLW 1      // the final (M, L) fold runs on the workgroup's LAST waves (idle during the partial-O publish of the first ones)
 #endif
@@ -283,7 +313,23 @@ struct SplitArgs {
   //      (head, slot) row for K and one for V — dequantised in registers on the way to the LDS slabs
   float* qparams;     // [H, S, 4]: k_scale, k_min, v_scale, v_min
   QkvIn qkv;          // QKV instantiations only: q / k_new / v_new are null, the step computes them itself
+  int virt8;          // XL2 instantiations (r6, CC_V_FEWXCD): the grid has 8 virtual kv heads, blocks of heads >= H exit (travels in the preloaded word)
 };
+
+// PRELOAD (r6): 14 dwords — all the hardware preloads — in front of the argument block: K base, S, rows per split, the key rows, their
+// stride, (live entries | kv heads << 20), the workspace header, the position word, the commit words.  The kernel takes THESE instead of
+// the block's copies (the launcher fills both alike: cc_lead_of).
+#if CC_V_PRELOAD
+#define CC_LEAD_PARAMS const void* pl_k, int pl_S, int pl_rps, const unsigned long long* pl_key, int pl_nk, int pl_misc, unsigned* pl_hdr, const int32_t* pl_pos, int32_t* pl_commit,
+#define CC_LEAD_TYPES const void*, int, int, const unsigned long long*, int, int, unsigned*, const int32_t*, int32_t*,
+#define CC_LEAD_ARGS(sa) (sa).k, (sa).S, (sa).rows_per_split, (sa).next_key, (sa).nk, (int)((unsigned)(sa).nk_read | ((unsigned)(sa).H << 20) | ((sa).virt8 ? 0x80000000u : 0u)), (sa).one_hdr, (sa).input_pos, (sa).commit,
+constexpr int kLeadNkReadMax = (1 << 20) - 1, kLeadHMax = (1 << 11) - 1;
+#else
+#define CC_LEAD_PARAMS
+#define CC_LEAD_TYPES
+#define CC_LEAD_ARGS(sa)
+#endif
+constexpr int kLeadBytes = CC_V_PRELOAD ? 56 : 0;  // 14 dwords (pointers on 8-byte boundaries: see the parameter list)
 
 template <typename T, int D, int RT, int NW, int U>
 __global__ __launch_bounds__(NW * 64) void decode_attn_split_kernel(SplitArgs a) {
@@ -603,7 +649,25 @@ struct Mfma16x16x16<f16_t> {
 };
 
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-constexpr unsigned kOneSpinMax = 1u << 18;  // bounded spin: a launch that is not fully resident gives up instead of hanging
+// Bounded waits: a launch that is not fully resident gives up instead of hanging.  r6: the bound is DEVICE TIME — kOneWaitTicks of
+// s_memrealtime, the 100 MHz clock all XCDs share: 30 ms — instead of 2^18 poll rounds (1.6 s with memory polls, measured; shorter
+// through an L2).  The clock is read once per 256 unsuccessful rounds (a scalar memory instruction with a wait of its own: nothing a
+// wait that succeeds within microseconds ever executes), first to take the start, then to compare; 2^22 rounds stay as a cap.
+constexpr unsigned kOneSpinMax = 1u << 22;
+constexpr unsigned long long kOneWaitTicks = 3000000ull;
+struct WaitBound {
+  unsigned long long t0 = 0;
+  __device__ __forceinline__ bool expired(unsigned spins) {
+    if (spins > kOneSpinMax) return true;
+    if ((spins & 255u) != 255u) return false;
+    const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+    if (t0 == 0) {
+      t0 = now | 1ull;
+      return false;
+    }
+    return now - t0 > kOneWaitTicks;
+  }
+};
 constexpr int kOneStatusWordDev = 1023;     // hdr[0 .. H): per-head epochs; hdr[1023]: timeout word (== kOneStatusWord)
 constexpr int kOneTicketWord = 1022;        // hybrid: heads whose workgroups have all published (the last one commits the per-step scalars)
 // Recoverable hand-off (the early-(m, l) steps).  A launch whose workgroups are not all resident cannot complete its hand-off:
@@ -643,6 +707,9 @@ constexpr int kOneNmHead = 64 * 16;            // l2: one norm-maximum granule p
 constexpr int kOneHmBytes = 32 * 16;           // l2 (two-level exchange): one norm-maximum granule per kv HEAD, behind the per-split regions
 constexpr int kOneMaxHeads = 32;
 constexpr int kOneQHead = (8 + 2) * 128 / 4 * 16;  // QKV: up to 8 query heads + k + v of 128 values, four 16-bit values per 8-byte granule half
+// the workspace's single-launch regions, at fixed offsets behind the 4 KiB header (cc_attn_decode.hip: kOneBytes)
+constexpr size_t kOneHdrBytes = 4096, kOneMlCap = (size_t)kOneMaxHeads * (kOneMlHead + kOneNmHead) + 4096 /* kOneHmBytes, padded */,
+                 kOneOCap = (size_t)kOneMaxHeads * kOneOHead;
 constexpr int kOneAuxCoherent = 17;         // sc0 sc1: write-through stores / loads that bypass the non-coherent L1 (and stale L2 lines)
 
 // ---- fused quantised cache: value = T(fma(q, scale, min)), one rounding; q in [0, 255]
@@ -729,7 +796,7 @@ struct IntC {
 // tile's 16.8 MB stream in the shadow of the 50 MB of weights: one launch boundary, one prologue and one first-byte latency per
 // attention sub-block instead of two.  One workgroup per CU (the LDS decides that anyway): 256 registers per lane.
 template <typename T, int RT, int NW, bool L2, bool ONE = false, bool HYB = false, int QB = 0, int NSUB = 1, int NT = 1, bool FULL = !ONE, bool XL2 = false, bool QKV = false>
-__global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void decode_attn_split_mfma_kernel(SplitArgs a) {
+__global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void decode_attn_split_mfma_kernel(CC_LEAD_PARAMS SplitArgs a_in) {
   // FULL (measurement instantiation): the workgroup's first instruction, on both clocks — the phases of cc_decode_step_trace count
   // from HERE (late r4; they used to count from behind the issue of the first K rows, ~0.8 us later)
   unsigned long long tr_entry = 0, rt_entry = 0;
@@ -737,6 +804,76 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
     tr_entry = __builtin_amdgcn_s_memtime();
     rt_entry = __builtin_amdgcn_s_memrealtime();  // 100 MHz, one clock for the whole device (s_memtime is per XCD)
   }
+  // LATE (r6, with the preloaded arguments; the LDS-DMA steps): the argument block is read in TWO PHASES.  Phase 0 — entry to the
+  // first K request — runs on the 14 preloaded dwords alone: the step's words, the key row and the K rows are requested without one
+  // kernel-argument load having been issued, so nothing the compiler does with scalar registers can put a wait in front of them
+  // (left to the compiler, 37 of 47 LDS-DMA instantiations had an `s_waitcnt lgkmcnt(0)` there: a scalar register reused while an
+  // argument load into it was pending — tools/isa_first_request_audit.py).  Phase 1 — right behind the K request — fetches the rest
+  // of the block in one round of scalar loads through a laundered kernarg pointer (late_phase below): one round trip, in the shadow
+  // of the K rows.
+  constexpr bool LATE = CC_V_PRELOAD != 0 && CC_V_LATE != 0 && CC_V_LDSDMA != 0 && ONE && NT == 1 && QB == 0 && !HYB && !QKV;
+  SplitArgs a{};
+  if constexpr (!LATE) a = a_in;
+#if CC_V_PRELOAD
+  // the preloaded copies REPLACE the argument block's (same values: CC_LEAD_ARGS): every use below reads an SGPR that was there
+  // when the wave started, not a kernel-argument load
+  auto apply_lead = [&]() {
+    a.k = pl_k;
+    a.S = pl_S;
+    a.rows_per_split = pl_rps;
+    a.next_key = pl_key;
+    a.nk = pl_nk;
+    a.nk_read = pl_misc & kLeadNkReadMax;
+    a.one_hdr = pl_hdr;
+    a.input_pos = pl_pos;
+    a.commit = pl_commit;
+  };
+  apply_lead();
+  const int lead_H = (int)(((unsigned)pl_misc >> 20) & (unsigned)kLeadHMax);
+  // EARLY (LATE steps): phase 1's scalar loads go out HERE, as the kernel's first instructions, in assembly — the compiler does not
+  // know that these registers are pending and therefore never waits for them (nor may it read them: nothing touches ea* until the
+  // `s_waitcnt lgkmcnt(0)` of late_phase hands them over; tools/isa_first_request_audit.py checks that in the ISA).  Offsets: the
+  // block starts kLeadBytes into the kernel-argument segment; the static_asserts pin the fields.
+  typedef unsigned ea_x8 __attribute__((ext_vector_type(8)));
+  typedef unsigned ea_x4 __attribute__((ext_vector_type(4)));
+  typedef unsigned ea_x2 __attribute__((ext_vector_type(2)));
+  constexpr bool EARLY = LATE && CC_V_EARLYARGS != 0;
+  if constexpr (EARLY && FULL) asm volatile("" : "+s"(tr_entry), "+s"(rt_entry));  // (the entry stamps are scalar-memory results too: waited for HERE, ahead of the loads below)
+  ea_x8 ea_q = {}, ea_kn = {}, ea_ct = {}, ea_ao = {};
+  ea_x4 ea_r = {}, ea_rn = {};
+  ea_x2 ea_hp = {}, ea_y = {}, ea_nrm = {}, ea_tr = {};
+  unsigned ea_abl = 0;
+  if constexpr (EARLY) {
+    static_assert(offsetof(SplitArgs, q) == 0 && offsetof(SplitArgs, v) == 16 && offsetof(SplitArgs, mask) == 24, "ea_q");
+    static_assert(offsetof(SplitArgs, R) == 60 && offsetof(SplitArgs, n_split) == 64 && offsetof(SplitArgs, scale) == 72 && offsetof(SplitArgs, abl) == 76, "ea_r");
+    static_assert(offsetof(SplitArgs, k_new) == 104 && offsetof(SplitArgs, v_new) == 112 && offsetof(SplitArgs, pos) == 120 && offsetof(SplitArgs, mask_w) == 128, "ea_kn");
+    static_assert(offsetof(SplitArgs, cache_cts) == 136 && offsetof(SplitArgs, num) == 144 && offsetof(SplitArgs, denom) == 152 && offsetof(SplitArgs, H) == 160 &&
+                  offsetof(SplitArgs, Hc) == 164 && offsetof(SplitArgs, Hp) == 168, "ea_ct / ea_hp");
+    static_assert(offsetof(SplitArgs, key_norm) == 224 && offsetof(SplitArgs, y) == 280, "ea_nrm / ea_y");
+    static_assert(offsetof(SplitArgs, attn_out) == 288 && offsetof(SplitArgs, hh_counter) == 296 && offsetof(SplitArgs, g) == 304 && offsetof(SplitArgs, w) == 308 &&
+                  offsetof(SplitArgs, policy) == 312, "ea_ao");
+    static_assert(offsetof(SplitArgs, rand_next) == 320 && offsetof(SplitArgs, rng_seed) == 328 && offsetof(SplitArgs, trace) == 344, "ea_rn / ea_tr");
+    static_assert(kLeadBytes == 56, "the immediates below are 56 + the field's offset");
+    typedef const char __attribute__((address_space(4))) kernarg_b;
+    kernarg_b* kp0 = (kernarg_b*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile(
+        "s_load_dwordx8 %0, %11, 0x38\n\t"    // q, k, v, mask
+        "s_load_dwordx8 %1, %11, 0xa0\n\t"    // k_new, v_new, pos, mask_w
+        "s_load_dwordx8 %2, %11, 0xc0\n\t"    // cache_cts, num, denom, H, Hc
+        "s_load_dwordx2 %6, %11, 0xe0\n\t"    // Hp
+        "s_load_dwordx4 %4, %11, 0x74\n\t"    // R, n_split, rows_per_split, scale
+        "s_load_dwordx2 %7, %11, 0x150\n\t"   // y
+        "s_load_dwordx8 %3, %11, 0x158\n\t"   // attn_out, hh_counter, g, w, policy
+        "s_load_dwordx4 %5, %11, 0x178\n\t"   // rand_next, rng_seed
+        "s_load_dwordx2 %8, %11, 0x118\n\t"   // key_norm
+        "s_load_dwordx2 %9, %11, 0x190\n\t"   // trace
+        "s_load_dword %10, %11, 0x84"           // abl
+        : "=s"(ea_q), "=s"(ea_kn), "=s"(ea_ct), "=s"(ea_ao), "=s"(ea_r), "=s"(ea_rn), "=s"(ea_hp), "=s"(ea_y), "=s"(ea_nrm), "=s"(ea_tr), "=s"(ea_abl)
+        : "s"(kp0));
+  }
+#else
+  auto apply_lead = [&]() {};
+#endif
   static_assert(!(HYB && L2), "the hybrid decision rides the plain streaming pass or the single-launch step");
   static_assert(QB == 0 || (QB == 8 && !L2 && !HYB), "fused quantised cache: 8 bits, heavy hitter / recent_global / random");
   static_assert(NSUB == 1 || (NSUB == 2 && !ONE), "two tiles per iteration: the two-launch streaming pass only");
@@ -777,12 +914,15 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
                 "the fused projection rides the lean single-tile step of the plain 16-bit caches");
   static_assert(FULL || ONE, "the lean form exists for the single-launch step only");
   static_assert(!XL2 || ONE, "the L2-resident hand-off belongs to the single-launch steps");
-  if constexpr (!FULL) {  // constants for the optimiser: every `if (a.trace)`, `a.abl & ...`, `if (a.attn_out)` below folds away
-    a.trace = nullptr;
-    a.abl = 0;
-    a.attn_out = nullptr;
-  }
-  if constexpr (ONE) a.ring_col = nullptr;  // (the single-launch steps derive the ring column themselves)
+  auto apply_consts = [&]() {
+    if constexpr (!FULL) {  // constants for the optimiser: every `if (a.trace)`, `a.abl & ...`, `if (a.attn_out)` below folds away
+      a.trace = nullptr;
+      a.abl = 0;
+      a.attn_out = nullptr;
+    }
+    if constexpr (ONE) a.ring_col = nullptr;  // (the single-launch steps derive the ring column themselves)
+  };
+  apply_consts();
   if (a.ring_col && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0)
     *a.ring_col = (int)(*a.ring_counter % a.ring_W);
   __shared__ __attribute__((aligned(16))) uint4 sm_k[NW][16][16];  // [wave][tile row i][slot]: 4 KiB per wave
@@ -832,8 +972,17 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
     // needs ALL workgroups of the launch resident (the launcher checks the capacity).  Should the relation ever not hold for a
     // launch (grids of two queues dealt alternately, say), a head's workgroups do not see each other's granules: the bounded wait
     // ends the step as a recoverable failure and the host falls back to the memory hand-off (harness._recover_token).
+#if CC_V_PRELOAD
+    const int b = blockIdx.x;  // (a 1-D grid of n_split * H blocks: the head count comes preloaded)
+#if CC_V_FEWXCD
+    const int Hg = pl_misc < 0 ? 8 : lead_H;  // (bit 31: eight virtual heads)
+#else
+    const int Hg = lead_H;
+#endif
+#else
     const int b = blockIdx.x + gridDim.x * blockIdx.y;
     const int Hg = (int)gridDim.y;
+#endif
     if ((Hg & (Hg - 1)) == 0) {  // (the usual case: no integer division in front of the first loads)
       h_ = b & (Hg - 1);
       split_ = b >> __builtin_ctz(Hg);
@@ -841,20 +990,34 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
       h_ = b % Hg;
       split_ = b / Hg;
     }
+#if CC_V_FEWXCD
+    if (h_ >= lead_H) return;  // a virtual head: nothing to do (before any barrier, any load)
+#endif
   }
-  const int split = split_, h = h_, q0 = h * a.R + blockIdx.z * RT;
+  const int split = split_, h = h_;
   const int S = a.S;
   const int row_begin = split * a.rows_per_split;
   const int row_end = min(S, row_begin + a.rows_per_split);
   const T* kb = reinterpret_cast<const T*>(a.k) + (size_t)h * S * D;
-  const T* vh = reinterpret_cast<const T*>(a.v) + (size_t)h * S * D + c * VEC;
-  // QB: byte images (element offsets are byte offsets) and the head's row parameters
-  const uint8_t* kqb = reinterpret_cast<const uint8_t*>(a.k) + (size_t)h * S * D;
-  const uint8_t* vqh = reinterpret_cast<const uint8_t*>(a.v) + (size_t)h * S * D + c * VEC;
-  const float2* qpar = reinterpret_cast<const float2*>(a.qparams) + (size_t)h * S * 2;  // [slot][0] = K pair, [1] = V pair
-  const bool has_mask = a.mask != nullptr && !(a.abl & 4);
-  const uint8_t* mh = has_mask ? a.mask + (size_t)h * S : reinterpret_cast<const uint8_t*>(a.k);
-  T* sc_out = reinterpret_cast<T*>(a.scores);
+  // what hangs on the argument block's later fields (LATE: worked out again behind phase 1)
+  int q0 = 0;
+  const T* vh = nullptr;
+  const uint8_t *kqb = nullptr, *vqh = nullptr;  // QB: byte images (element offsets are byte offsets) ...
+  const float2* qpar = nullptr;                  // ... and the head's row parameters: [slot][0] = K pair, [1] = V pair
+  bool has_mask = false;
+  const uint8_t* mh = nullptr;
+  T* sc_out = nullptr;
+  auto derive = [&]() {
+    q0 = h * a.R + blockIdx.z * RT;
+    vh = reinterpret_cast<const T*>(a.v) + (size_t)h * S * D + c * VEC;
+    kqb = reinterpret_cast<const uint8_t*>(a.k) + (size_t)h * S * D;
+    vqh = reinterpret_cast<const uint8_t*>(a.v) + (size_t)h * S * D + c * VEC;
+    qpar = reinterpret_cast<const float2*>(a.qparams) + (size_t)h * S * 2;
+    has_mask = a.mask != nullptr && !(a.abl & 4);
+    mh = has_mask ? a.mask + (size_t)h * S : reinterpret_cast<const uint8_t*>(a.k);
+    sc_out = reinterpret_cast<T*>(a.scores);
+  };
+  if constexpr (!LATE) derive();
 
   float m = -INFINITY, l = 0.f;  // softmax state of (wave, query head c) / (row group g, head c); meaningful for c < RT
   // O^T accumulators of the P.V MFMAs: block b covers output columns 16b .. 16b+15; lane (g, n = c) holds
@@ -878,7 +1041,7 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
   int ins_idx = -1, ins_was_empty = 0;
   int hyb_kind = 0, hyb_cts = 0;  // HYB: 0 = append at the end, 1 = evict the candidate, 2 = drop (slot S - 1, mask untouched)
   bool hyb_punc = false;
-  bool key_pending = a.next_key != nullptr && !(a.abl & 128);
+  bool key_pending = a.next_key != nullptr && (LATE || !(a.abl & 128));  // (LATE: the measurement bit is looked at behind phase 1)
   unsigned long long key_part = ~0ull;
   unsigned long long key_more[3] = {~0ull, ~0ull, ~0ull};  // up to 256 entries are requested at once and folded when first used
   // (late r2, measured on one box against the same build without it: these loads and the fold below cost the step 0.35 us — every
@@ -936,11 +1099,91 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
       dma16(vrs, rr * (D * (int)sizeof(T)) + ((c ^ (2 * (i & 7))) & 15) * 16, &sm_v[wave][4 * u][0]);
     }
   };
+  unsigned long long tr_kreq = 0;
+  // LATE, phase 1: the rest of the argument block through a laundered pointer — the loads cannot be issued ahead of the asm that
+  // "produces" it, i.e. ahead of the K request in front of it — then the preloaded copies and the constants again
+  auto late_phase = [&]() {
+    if constexpr (LATE) {
+      typedef const char __attribute__((address_space(4))) kernarg_bytes;
+      kernarg_bytes* kp = (kernarg_bytes*)__builtin_amdgcn_kernarg_segment_ptr();
+      asm volatile("" : "+s"(kp));
+      static_assert(kLeadBytes % alignof(SplitArgs) == 0, "the argument block follows the 14 preloaded dwords without padding");
+      // member by member THROUGH the constant address space (a memcpy through a generic pointer becomes vector loads behind the
+      // DMA request — the compiler must assume it wrote what they read — with in-order waits for the K rows in front of them);
+      // the hybrid / QKV sub-blocks and the two-launch scratch are not this instantiation's
+#if CC_V_PRELOAD
+      if constexpr (EARLY) {
+        // the loads of the kernel's first instructions: ONE wait, here — they have been in flight for the whole prologue
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ea_q), "+s"(ea_kn), "+s"(ea_ct), "+s"(ea_ao), "+s"(ea_r), "+s"(ea_rn), "+s"(ea_hp), "+s"(ea_y),
+                     "+s"(ea_nrm), "+s"(ea_tr), "+s"(ea_abl));
+        auto p64 = [](unsigned lo, unsigned hi) { return (unsigned long long)lo | ((unsigned long long)hi << 32); };
+        // (pointers rebuilt from integers must be told that they point to GLOBAL memory — kernel arguments are by the ABI — or every
+        //  access through them becomes a FLAT instruction, counted in vmcnt AND lgkmcnt: the in-order waits all turn into (0, 0))
+        typedef __attribute__((address_space(1))) char gchar;
+#define CC_GPTR(T, lo, hi) reinterpret_cast<T>((char*)(gchar*)p64(lo, hi))
+        a.q = CC_GPTR(const void*, ea_q[0], ea_q[1]);
+        a.v = CC_GPTR(const void*, ea_q[4], ea_q[5]);
+        a.mask = CC_GPTR(const uint8_t*, ea_q[6], ea_q[7]);
+        a.R = (int)ea_r[0];
+        a.n_split = (int)ea_r[1];
+        a.scale = __uint_as_float(ea_r[3]);
+        a.abl = (int)ea_abl;
+        a.k_new = CC_GPTR(const void*, ea_kn[0], ea_kn[1]);
+        a.v_new = CC_GPTR(const void*, ea_kn[2], ea_kn[3]);
+        a.pos = CC_GPTR(int32_t*, ea_kn[4], ea_kn[5]);
+        a.mask_w = CC_GPTR(uint8_t*, ea_kn[6], ea_kn[7]);
+        a.cache_cts = CC_GPTR(int32_t*, ea_ct[0], ea_ct[1]);
+        a.num = CC_GPTR(double*, ea_ct[2], ea_ct[3]);
+        a.denom = CC_GPTR(int32_t*, ea_ct[4], ea_ct[5]);
+        a.H = (int)ea_ct[6];
+        a.Hc = (int)ea_ct[7];
+        a.Hp = (int)ea_hp[0];
+        a.key_norm = CC_GPTR(void*, ea_nrm[0], ea_nrm[1]);
+        // (the granule regions sit at fixed offsets behind the workspace's header: no loads)
+        a.one_ml = reinterpret_cast<char*>(a.one_hdr) + kOneHdrBytes;
+        a.one_o = reinterpret_cast<char*>(a.one_hdr) + kOneHdrBytes + kOneMlCap;
+        a.one_ml_bytes = (unsigned)kOneMlCap;
+        a.one_o_bytes = (unsigned)kOneOCap;
+        a.y = CC_GPTR(void*, ea_y[0], ea_y[1]);
+        a.attn_out = CC_GPTR(void*, ea_ao[0], ea_ao[1]);
+        a.hh_counter = CC_GPTR(int64_t*, ea_ao[2], ea_ao[3]);
+        a.g = (int)ea_ao[4];
+        a.w = (int)ea_ao[5];
+        a.policy = (int)ea_ao[6];
+        a.rand_next = CC_GPTR(const float*, ea_rn[0], ea_rn[1]);
+        a.rng_seed = p64(ea_rn[2], ea_rn[3]);
+        a.trace = CC_GPTR(unsigned long long*, ea_tr[0], ea_tr[1]);
+        apply_lead();
+        apply_consts();
+        derive();
+        if (a.abl & 128) key_pending = false;
+#undef CC_GPTR
+        return;
+      }
+#endif
+      typedef const SplitArgs __attribute__((address_space(4))) args_c;
+      args_c* ap = (args_c*)(kp + kLeadBytes);
+#define CC_LATE_FIELD(f) a.f = ap->f
+      CC_LATE_FIELD(q); CC_LATE_FIELD(v); CC_LATE_FIELD(mask); CC_LATE_FIELD(R); CC_LATE_FIELD(n_split); CC_LATE_FIELD(scale);
+      CC_LATE_FIELD(abl); CC_LATE_FIELD(k_new); CC_LATE_FIELD(v_new); CC_LATE_FIELD(pos); CC_LATE_FIELD(mask_w); CC_LATE_FIELD(cache_cts);
+      CC_LATE_FIELD(num); CC_LATE_FIELD(denom); CC_LATE_FIELD(H); CC_LATE_FIELD(Hc); CC_LATE_FIELD(Hp); CC_LATE_FIELD(key_norm);
+      CC_LATE_FIELD(one_ml); CC_LATE_FIELD(one_o); CC_LATE_FIELD(one_ml_bytes); CC_LATE_FIELD(one_o_bytes); CC_LATE_FIELD(y);
+      CC_LATE_FIELD(attn_out); CC_LATE_FIELD(hh_counter); CC_LATE_FIELD(g); CC_LATE_FIELD(w); CC_LATE_FIELD(policy); CC_LATE_FIELD(rand_next);
+      CC_LATE_FIELD(rng_seed); CC_LATE_FIELD(trace); CC_LATE_FIELD(virt8);
+#undef CC_LATE_FIELD
+      apply_lead();
+      apply_consts();
+      derive();
+      if (a.abl & 128) key_pending = false;  // (measurement: the key row was read, and is ignored)
+    }
+  };
   auto issue_k = [&](TileRegs& R, int base) {  // mask word + the four K rows of this lane's row group (tile row i = 4g + u takes chunk c ^ i)
     const int row0 = base + g * U;
     if constexpr (DMA) {
       issue_k_dma(base);
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (LATE && FULL) tr_kreq = __builtin_amdgcn_s_memtime();  // (the trace's "K requested": the block's trace pointer arrives with phase 1, behind it)
+      if constexpr (LATE) late_phase();  // (single tile: this is the step's one K request)
     } else
     if constexpr (KFIRST) {
       issue_k_rows(R, base);
@@ -998,7 +1241,26 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
   int32_t rc_commit = -2;    // EML: step_commit[h][2 + split]: the last position this workgroup committed
   int32_t rc_insw = 0, rc_insp = -2;  // EML: step_commit[h][0 .. 1]: the insert slot word of position rc_insp
   int32_t rc_cts = 0, rc_col = 0;     // hybrid: step_commit[h][66 .. 67]: the head's count before that step, its ring column
+  // VW (r6, with the preloaded arguments): in the LDS-DMA steps the words travel as VECTOR loads of a wave-uniform address (an
+  // opaque zero in a VGPR keeps the compiler from turning them back into scalar loads), the first loads the wave issues.  As scalar
+  // loads they shared lgkmcnt with the argument block's own loads: one register reused between the two kinds and the compiler put an
+  // `s_waitcnt lgkmcnt(0)` — a cold round trip to memory — in front of the key row and the first K request.  Vector loads return in
+  // order: the wait where the words are first consumed (words_to_sgpr, behind the issue of the whole tile) is an exact vmcnt(N).
+  constexpr bool VW = CC_V_PRELOAD != 0 && DMA;
   auto load_step_words = [&]() {
+    if constexpr (VW) {
+      int vz;
+      asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
+      one_tag = a.one_hdr[h + vz];
+      one_pin = a.input_pos[vz];
+      rc_status = a.one_hdr[kOneStatusWordDev + vz];
+      // (no branch around the loads: without commit words a valid dummy — the header — is read and ignored)
+      const int32_t* cw = a.commit ? a.commit + (size_t)h * kRcStride : reinterpret_cast<const int32_t*>(a.one_hdr);
+      rc_commit = cw[2 + split + vz];
+      rc_insw = cw[vz];
+      rc_insp = cw[1 + vz];
+      return;
+    }
     one_tag = a.one_hdr[h] + 1u;
     one_pin = *a.input_pos;
     if constexpr (RC || NRC) {
@@ -1014,6 +1276,17 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
       }
     }
   };
+  auto words_to_sgpr = [&]() {  // VW: the words are back (the compiler's wait sits right here) — wave-uniform values again
+    if constexpr (VW) {
+      one_tag = (unsigned)__builtin_amdgcn_readfirstlane((int)one_tag) + 1u;
+      one_pin = __builtin_amdgcn_readfirstlane(one_pin);
+      rc_status = (RC || NRC) ? (unsigned)__builtin_amdgcn_readfirstlane((int)rc_status) : 0u;
+      const bool have = (RC || NRC) && a.commit != nullptr;
+      rc_commit = have ? __builtin_amdgcn_readfirstlane(rc_commit) : -2;
+      rc_insw = have ? __builtin_amdgcn_readfirstlane(rc_insw) : 0;
+      rc_insp = have ? __builtin_amdgcn_readfirstlane(rc_insp) : -2;
+    }
+  };
 #if CC_V_WORDSFIRST
   if constexpr (DMA) {
     // the step's wave-uniform words are requested AHEAD of the first DMA load: behind it they could no longer travel as scalar
@@ -1023,7 +1296,7 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
     // (r4) they made the K request wait a memory round trip for the commit words (found with a time stamp at the kernel's entry).
     load_step_words();
     __builtin_amdgcn_sched_barrier(0);
-#if CC_V_KPIN
+#if CC_V_KPIN && !CC_V_PRELOAD
     // ... and behind them the kernel arguments the key row, the first K / V rows, q, the mask and the per-slot state need, in ONE
     // round of scalar loads (left to the compiler they arrive in three, each behind the previous one's wait).  Only here: behind a
     // volatile asm the compiler reads nothing from memory through scalar loads any more — the step's words are already on their way.
@@ -1143,8 +1416,10 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
     }
     qstamp(1);
   }
+  constexpr bool VEARLY = DMA && !QKV && (CC_V_VEARLY == 2 || (CC_V_VEARLY == 1 && !XL2));
   if constexpr (KEARLY && !QKV) {  // (QKV: the tile is requested behind the projection's last weight rows, below)
     issue_k(tregs[0], base);
+    if constexpr (VEARLY) issue_v(tregs[0], base);
     __builtin_amdgcn_sched_barrier(0);  // (keeps the scheduler from sinking them back to the rest of the tile)
   }
   // (r4, with the DMA loads: the V rows right behind the K rows +0.4 us, the K rows ahead of the key row +0.35, both +0.8 — whatever
@@ -1180,7 +1455,7 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
   unsigned long long tr0 = 0, tr1 = 0, tr2 = 0, tr3 = 0, tr4 = 0, rt0 = 0, rt1 = 0, trA = 0, trB = 0, trC = 0;
   if constexpr (ONE) {
     if (a.trace) {
-      tr3 = __builtin_amdgcn_s_memtime();  // the first K rows (and the key row, the step words) are requested
+      tr3 = (LATE && FULL) ? tr_kreq : __builtin_amdgcn_s_memtime();  // the first K rows (and the key row, the step words) are requested
       tr0 = tr_entry;
       rt0 = rt_entry;
     }
@@ -1368,7 +1643,7 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
   for (int sub = 0; sub < NSUB; sub++) {
     if constexpr (!KEARLY) issue_k(tregs[sub], base + sub * NW * RPW * U);
     if constexpr (QB) __builtin_amdgcn_sched_barrier(0);  // K's bytes and parameters go out BEFORE V's: the K stash waits for them only
-    if constexpr (!QKV) issue_v(tregs[sub], base + sub * NW * RPW * U);
+    if constexpr (!QKV && !VEARLY) issue_v(tregs[sub], base + sub * NW * RPW * U);
     if constexpr (QB) __builtin_amdgcn_sched_barrier(0);
   }
   // ONE + L2: the epoch words of the kv heads whose norm granules this thread will gather.  Read HERE (behind the tile's loads: three integer divisions kept out of the way of the first K rows): every workgroup has read
@@ -1382,6 +1657,7 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
     }
   }
   if constexpr (QKV) {
+    words_to_sgpr();
     if (rc_status != 0u) return;  // a step of this token failed before this launch: leave everything as it is (the host retries)
     // ================= the projection (cc_gemv.hip's gemv_kernel<T, false, RB, 2, 2>, operation for operation) =================
     // Four waves split K into quarters exactly like the stand-alone GEMV's workgroup (wave w: the 1 KiB segments w and w + 4 of a row,
@@ -1548,14 +1824,19 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
     } else {
       __syncthreads();
     }
-    if (rc_status != 0u) return;  // a step of this token failed before this launch: leave everything as it is (the host retries)
+    if constexpr (!VW) {
+      if (rc_status != 0u) return;  // a step of this token failed before this launch: leave everything as it is (the host retries)
+    }
+    // (VW: the words are vector loads, the oldest in flight — the test sits in front of the wave's first tile half, below, so that
+    //  the gather arithmetic in between still runs in the shadow of the K rows)
   }
   if constexpr (NRC) {
     // (HERE, behind the issue of the first tile's loads — at the top of the kernel the test waited for the step words, a cold
     //  scalar round trip in front of every workgroup's first K rows: +1 us on the C4 step.  Nothing has been written yet.)
     if (a.commit && rc_status != 0u) return;
   }
-  const bool rc_replay = (EML || (NRC && a.commit != nullptr)) && rc_commit == one_pin;  // this WORKGROUP committed its part of this position's step already: it recomputes and stores nothing
+  bool rc_replay = false;  // this WORKGROUP committed its part of this position's step already: it recomputes and stores nothing
+  if constexpr (!(VW && !QKV)) rc_replay = (EML || (NRC && a.commit != nullptr)) && rc_commit == one_pin;
   // ONE: what this thread gathers in the hand-off — up to NOG partial-O granules of the output pairs this workgroup finishes (pair
   // P = r * 64 + d / 2).  Two integer divisions by run-time values (~100 scalar and vector instructions): worked out HERE, with the
   // tile in flight, and pinned — left where they are used, they sat between the merge barrier and the first look at the (m, l)
@@ -1591,6 +1872,7 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
       const auto hd_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.one_hdr, 0, 4096, 0x00020000);
       u32x4_t gq[QNG];
       bool q_to = false, q_pf = false;
+      WaitBound q_wb;
       for (unsigned spins = 0;; spins++) {
         asm volatile("" ::: "memory");  // every round re-reads memory
 #pragma unroll
@@ -1609,7 +1891,7 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
             break;
           }
         }
-        if (spins > kOneSpinMax) {
+        if (q_wb.expired(spins)) {
           q_to = true;
           break;
         }
@@ -2044,6 +2326,12 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
   } else if constexpr (EML) {
     // single tile, early (m, l): scores -> [the workgroup's (m, l) pairs leave] -> P.V.  A wave without rows (ragged last split)
     // skips the tile halves but not the arrival counter: its pair is (-inf, 0).
+    if constexpr (VW && !QKV) {
+      __builtin_amdgcn_sched_barrier(0);  // (the scheduler otherwise hoists the first of these waits up to the barrier)
+      words_to_sgpr();
+      if (rc_status != 0u) return;  // a step of this token failed before this launch: leave everything as it is (the host retries)
+      rc_replay = rc_commit == one_pin;
+    }
     if (more) tile_qk(tregs[0], base, base, false, IntC<0>{});
     qstamp(8);
     ml_block();
@@ -2130,7 +2418,8 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
       const int off1 = kOneMaxHeads * kOneMlHead + h * kOneNmHead + (lane < a.n_split ? lane : 0) * 16;
       u32x4_t nmx = {0u, 0u, 0u, 0u};
       bool got = false;
-      for (unsigned spins = 0; spins <= kOneSpinMax; spins++) {
+      WaitBound nm_wb;
+      for (unsigned spins = 0; !nm_wb.expired(spins); spins++) {
         asm volatile("" ::: "memory");  // every round re-reads memory
         nmx = __builtin_amdgcn_raw_buffer_load_b128(ml_rsrc_p, off1, 0, 16 /* sc1: the XCD's L2 */);
         if (__all(lane >= a.n_split || (nmx[0] == one_tag && nmx[2] == one_tag))) {
@@ -2375,8 +2664,9 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
       };
       bool ml_ok = (!ml_mine || __all(ok_ml())) && (!L2 || __all(ok_nm()));
       bool peer_failed = false;
+      WaitBound ml_wb;
       for (unsigned spins = 0; !ml_ok; spins++) {
-        if (spins > kOneSpinMax) {
+        if (ml_wb.expired(spins)) {
           timed_out = true;
           break;
         }
@@ -2416,6 +2706,7 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
       __syncthreads();
       if (a.trace) trD = __builtin_amdgcn_s_memtime();
     } else {
+      WaitBound mo_wb;
       for (unsigned spins = 0;; spins++) {
         asm volatile("" ::: "memory");  // every round re-reads memory
         load_ml();
@@ -2438,7 +2729,7 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
             }
           }
         }
-        if (spins > kOneSpinMax) {
+        if (mo_wb.expired(spins)) {
           timed_out = true;
           break;
         }
@@ -2753,10 +3044,11 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
       if constexpr (L2X) {
         if (hm_mine) hmq = __builtin_amdgcn_raw_buffer_load_b128(ml_rsrc, hm_off, 0, kOneAuxCoherent);
       }
+      WaitBound o_wb;
       for (unsigned spins = 0;; spins++) {
         if (__all(ok_o()) && __all(ok_hm())) break;
         if (RC && failq == tag) break;  // a workgroup of this head gave up: the head's step is not committed, nothing left to wait for
-        if (spins > kOneSpinMax) {
+        if (o_wb.expired(spins)) {
           timed_out = true;
           break;
         }

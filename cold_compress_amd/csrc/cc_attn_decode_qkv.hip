@@ -17,7 +17,7 @@
 
 namespace {
 
-typedef void (*QkvKernel)(SplitArgs);
+typedef void (*QkvKernel)(CC_LEAD_TYPES SplitArgs);
 
 template <typename T>
 static QkvKernel qkv_kernel(int rt, int nw, bool xl2) {
@@ -83,7 +83,12 @@ int cc_qkv_step_launch(const void* split_args, size_t split_args_bytes, int dtyp
   SplitArgs a;
   __builtin_memcpy(&a, split_args, sizeof(SplitArgs));
   a.qkv.trace = g_qkv_trace;
-  hipLaunchKernelGGL(k, dim3(grid_x, grid_y, 1), dim3(nw * 64), 0, stream, a);
+#if CC_V_PRELOAD
+  const dim3 grid = xl2 ? dim3(grid_x * grid_y, 1, 1) : dim3(grid_x, grid_y, 1);  // (XL2: a linear block index, the head count preloaded)
+#else
+  const dim3 grid(grid_x, grid_y, 1);
+#endif
+  hipLaunchKernelGGL(k, grid, dim3(nw * 64), 0, stream, CC_LEAD_ARGS(a) a);
   CC_LAUNCH_CHECK();
   return CC_OK;
 }

@@ -169,12 +169,16 @@ class GraphedDecoder:
 
     def __call__(self, model, x, input_pos, next_token=None, **_):
         if self.graph is not None:
-            for l in self.model.layers:  # (a reset cache draws its seed when its pipeline is seeded: do that BEFORE deciding)
+            # A decoder reused across reset() / generations: prepare_decode sits OUTSIDE the captured step, so EVERY cache whose fused
+            # pipeline was invalidated since (reset, a prefill) is re-seeded here, at the position the replay is about to run — the
+            # captured step would otherwise evict or insert at the previous generation's `next_key` / `step_commit` (r5
+            # did this for KVCacheRandom only, whose per-generation seed also moves the epoch below)
+            for l in self.model.layers:
                 c = l.attention.kv_cache
-                if hasattr(c, "_graph_epoch") and hasattr(c, "prepare_decode") and c.supports_fused_step() and not c._next_valid:
+                if hasattr(c, "prepare_decode") and c.supports_fused_step() and not c._next_valid:
                     self.pos.copy_(input_pos)
                     c.prepare_decode(self.pos)
-            if self._cache_epoch() != self._epoch:
+            if self._cache_epoch() != self._epoch:  # (something the captured steps carry BY VALUE moved: capture again)
                 self.graph = None
         if self.graph is None:
             self.tok.copy_(x)
@@ -186,6 +190,35 @@ class GraphedDecoder:
         if next_token is not None:
             return next_token, self.out_probs
         return self.out_tok, self.out_probs
+
+
+def negotiate_graphed_decoder(make, first_step, device, log=None):
+    """Capture the decode step in a hipGraph on EVERY rank or on none (ref: generation_utils.py:581-587 compiles the step once per
+    process; under tp.py's TP every rank must then run the same thing).  `make()` builds the decoder (GraphedDecoder(model));
+    `first_step(dec)` runs its first step, i.e. the capture.  A capture that is refused on ANY rank — the RCCL all-reduce inside the
+    step cannot be captured by this runtime, an allocator that balks under capture — sends ALL ranks to eager launches: the verdicts
+    are combined with a MIN all-reduce that every rank enters whatever happened locally (a rank that fell back alone would replay
+    nothing while its peers wait in the captured collective — or skip a timed comparison whose all-reduces its peers sit in).
+    -> the decoder, or None (eager).  (bench.py's logic since r2, moved here in r6 so that it can be exercised: tests/test_tp_gloo.py
+    injects the refusal on one rank.)"""
+    dec = None
+    try:
+        dec = make()
+        first_step(dec)
+    except Exception as e:  # capture refused: fall back — together (below)
+        if log is not None:
+            log(f"hipGraph capture failed ({type(e).__name__}: {e}); falling back to eager launches")
+        dec = None
+    if _tp_world() > 1:
+        import torch.distributed as dist
+
+        ok = torch.tensor([1 if dec is not None else 0], device=device, dtype=torch.int32)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            if dec is not None and log is not None:
+                log("a peer rank's hipGraph capture was refused: this rank falls back to eager launches with it")
+            dec = None
+    return dec
 
 
 def _tp_world():
@@ -231,12 +264,14 @@ def _recover_token(model, cur_token, input_pos, decode_fn, nt, npb, forced, attn
         # garbage behind the failure and would step again on the retry)
         from ..cache import step_is_recoverable
 
-        ok = all(step_is_recoverable(l.attention.kv_cache, l.attention.n_head) for l in model.layers)
+        ok = all(step_is_recoverable(l.attention.kv_cache, l.attention.n_head, l.attention) for l in model.layers)
         if not ok or tries >= max_retries:
             raise_single_launch_failure(dev)  # (clears the word; on every rank together)
         reset_single_launch_status(dev)
         tries += 1
-        if tries >= 3 and _abi.lib()["cc_decode_step_l2_handoff"]():  # (attempts 1-3 as they are: a co-tenant leaves, a misplaced launch does not)
+        with torch.cuda.device(dev):  # (the hand-off's verdict is per device: ask about `dev`, not the current one — ADVICE r5)
+            l2_on = bool(_abi.lib()["cc_decode_step_l2_handoff"]())
+        if tries >= 3 and l2_on:  # (attempts 1-3 as they are: a co-tenant leaves, a misplaced launch does not)
             import warnings
 
             warnings.warn("cold_compress_amd: a single-launch decode step failed three times; the L2-resident hand-off is switched off "

@@ -294,6 +294,11 @@ int cc_decode_step_heavy_hitter_ring(const cc_kv_view* c, const void* q, const v
 #define CC_PHASE_ONE_LAUNCH 0x20000
 int32_t cc_decode_step_single_launch(int32_t HQ, int32_t H, int32_t S, int32_t D, int32_t dtype);
 int32_t cc_decode_step_status_offset(void);
+/* r6: every wait of the in-launch hand-off is bounded by DEVICE TIME (the 100 MHz clock all XCDs share), not by a number of poll
+ * rounds: a workgroup that has waited this many microseconds for its kv head's other workgroups gives up (status word, fail word:
+ * below).  The failure latency a caller's recovery path sees is this plus the kernel's own few microseconds.  (r2-r5: 2^18 poll
+ * rounds — 1.6 s measured with memory polls.)  ref: the reference has no hand-off (cache.py:725-765 runs in one eager op chain). */
+int32_t cc_decode_step_wait_bound_us(void);
 /* The heavy-hitter layer step with the RECOVERABLE hand-off (r3; per-workgroup commit words r4): cc_decode_step_heavy_hitter_phases
  * plus `step_commit`, int32 [H, cc_decode_step_commit_stride()] on the device, all -1 = nothing committed (reset it whenever
  * positions restart).  ref: the reference has no hand-off to time out (cache.py:725-765, 716-722); this is what makes ours safe.
@@ -488,11 +493,21 @@ int cc_decode_step_quant_rc(const cc_kv_view* c, float* qparams, int32_t n_bit, 
                             cc_stream_t stream, int32_t phases);
 int32_t cc_decode_step_quant_single_launch(int32_t HQ, int32_t H, int32_t S, int32_t D, int32_t dtype, int32_t n_bit);
 /* ... and for the l2 step (cc_decode_step_l2[_rc]); cc_decode_step_single_launch_enabled: 1 while the process-wide switch
- * (cc_decode_step_set_single_launch, include/coldcompress_debug.h) allows the single-launch forms at all.  Together with the
+ * (cc_decode_step_set_single_launch, include/coldcompress_debug.h) AND the current device's own (cc_decode_step_device_single_launch,
+ * below) allow the single-launch forms at all.  Together with the
  * per-kind queries they tell a caller which FORM a step call will take: only the single-launch forms read the status / commit words
  * of the recoverable hand-off (the two-launch and three-call forms have nothing that can time out and ignore them). */
 int32_t cc_decode_step_l2_single_launch(int32_t HQ, int32_t H, int32_t S, int32_t D, int32_t dtype);
 int32_t cc_decode_step_single_launch_enabled(void);
+/* r6 — the knob for SHARED devices (per device, like the co-residency it is about).  The single-launch forms need all
+ * workgroups of a launch resident together: on a GPU that this process shares with other processes or concurrent kernels (several TP
+ * ranks on one GPU, a co-tenant job) that does not hold, and every hand-off would end in the bounded wait.  enabled == 0: steps
+ * launched on the CURRENT device take the two-launch forms from now on (nothing in them can time out; the cache state they leave is
+ * bit-identical, so the switch may be flipped between any two steps); != 0: the single-launch forms again.  Other devices of the
+ * process are untouched; cc_decode_step_single_launch_enabled and the per-kind queries answer for the current device.  -> the previous
+ * value.  (A step captured into a hipGraph keeps the form it was captured with.)  ref: the reference has no such form to switch
+ * (cache.py:314-364 runs as eager ops). */
+int32_t cc_decode_step_device_single_launch(int32_t enabled);
 
 /* ------------------------------------------------------------------------------------------------
  * Prefill-time cache fill.  ref: KVCache._prefill_update / _fill_contiguous cache.py:381-401.

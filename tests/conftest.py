@@ -58,21 +58,46 @@ def pytest_collection_modifyitems(config, items):
         items[:] = rest + last
 
 
-# ---- the near-tie audit: tests that ACCEPT an eviction differing from the reference / the oracle when it is a
-#      rounding-level tie in the reference's own scores report how often they did — printed with the run's summary, also under -q.
+# ---- the acceptance audit (near-tie evictions; VERDICT r5 #3: EVERY rule that accepts a difference, one table).
+#      A test that lets something other than equality pass — an eviction inside a rounding-level tie of the reference's own scores, a
+#      kept token swapped on a top-k boundary tie, an l2 eviction between two equal norms, an 8-bit code on a rounding boundary, a
+#      probability behind a score on a bf16 rounding midpoint — reports how often it did (count), out of how many comparisons
+#      (compared), against which limit.  Printed with the run's summary (also under -q): the per-test lines, then one row per rule.
 _AUDIT = []
+RULES = ("near-tie eviction", "near-tie candidate re-seat", "top-k boundary swap", "l2 norm tie", "q8 boundary code", "boundary probability")
 
 
 @pytest.fixture
 def audit(request):
-    def add(text):
-        _AUDIT.append(f"{request.node.nodeid}: {text}")
+    def add(text, rule=None, count=None, compared=None, limit=None):
+        """text: the per-test line (kept from r3-r5); rule / count / compared / limit: its row of the table — one call per rule."""
+        assert rule is None or rule in RULES, rule
+        _AUDIT.append(dict(node=request.node.nodeid, text=text, rule=rule, count=count, compared=compared, limit=limit))
 
     return add
 
 
 def pytest_terminal_summary(terminalreporter):
-    if _AUDIT:
-        terminalreporter.section("near-tie audit (accepted eviction differences: count / evictions compared)")
-        for line in _AUDIT:
-            terminalreporter.write_line(line)
+    if not _AUDIT:
+        return
+    terminalreporter.section("near-tie audit (accepted eviction differences: count / evictions compared)")
+    for a in _AUDIT:
+        terminalreporter.write_line(f"{a['node']}: {a['text']}")
+    rows = {}
+    for a in _AUDIT:
+        if a["rule"] is None:
+            continue
+        r = rows.setdefault(a["rule"], dict(tests=0, count=0, compared=0, limits=[]))
+        r["tests"] += 1
+        r["count"] += int(a["count"] or 0)
+        r["compared"] += int(a["compared"] or 0)
+        if a["limit"] is not None and str(a["limit"]) not in r["limits"]:
+            r["limits"].append(str(a["limit"]))
+    terminalreporter.section("acceptance rules: every rule that lets a difference pass (accepted / compared, against its limit)")
+    terminalreporter.write_line(f"{'rule':<28} {'tests':>5} {'accepted':>9} {'compared':>12}  limit")
+    for rule in RULES:
+        r = rows.get(rule)
+        if r is None:
+            terminalreporter.write_line(f"{rule:<28} {0:>5} {'-':>9} {'-':>12}  (no test of this selection uses the rule)")
+        else:
+            terminalreporter.write_line(f"{rule:<28} {r['tests']:>5} {r['count']:>9} {r['compared']:>12}  {'; '.join(r['limits'])}")

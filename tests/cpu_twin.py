@@ -16,7 +16,8 @@ TWIN_FILES = ["test_gpu_parity.py", "test_gpu_e2e.py", "test_gpu_hybrid.py", "te
 DEVICE_ONLY_TESTS = [re.compile(x) for x in (
     r"test_library_and_device", r"test_cpu_tensors_are_refused", r"hipgraph", r"test_harness_two_launch_step_equals_three_call_path",
     r"test_requant_known_answers", r"test_batched_round_trip_equals_per_cache", r"test_e2e_cache_bits_8\[True\]",
-    r"test_hybrid_two_launch_step_equals_three_launches\[.*-True\]", r"test_fused_step_on_reference_query_trace\[True\]")]
+    r"test_hybrid_two_launch_step_equals_three_launches\[.*-True\]", r"test_fused_step_on_reference_query_trace\[True\]",
+    r"test_one_graphed_decoder_across_two_generations")]
 
 
 class _NoStream:

@@ -103,7 +103,8 @@ HYBRID = [{"strategy": "window", "recent_window": 0.1},
           {"strategy": "full"}]
 
 
-def test_hybrid_profiling_full_size(oracle_mt):
+@pytest.mark.parametrize("H,R", [(3, 2), (8, 4)])  # (r6, VERDICT r5 #3: the Llama-3-8B head geometry — 8 kv heads, 4 query heads each — as well)
+def test_hybrid_profiling_full_size(oracle_mt, H, R):
     """C4: 16384-token prompt, cache 18432, hybrid.yaml's four policies; three kinds of heads (tests/hybrid_inputs.py)."""
     import cold_compress_amd.cache as cache
     import hybrid_profile_ref as hp
@@ -111,7 +112,7 @@ def test_hybrid_profiling_full_size(oracle_mt):
     from hybrid_inputs import make_inputs
 
     o = oracle_mt
-    L, S, H, R, D, g, frac, dtype = 16384, 18432, 3, 2, 128, 4, 0.97, torch.bfloat16
+    L, S, D, g, frac, dtype = 16384, 18432, 128, 4, 0.97, torch.bfloat16
     HQ = H * R
     q, k, v = make_inputs(L, H, R, D, 0, dtype)
     cls, rk = cache.get_cache_constructor("hybrid")
@@ -164,7 +165,7 @@ def test_hybrid_profiling_full_size(oracle_mt):
             lo, hi = vk * (1 - 2 * BF16_ULP), vk * (1 + 2 * BF16_ULP)
             assert bool(((cum[diff] >= lo) & (cum[diff] <= hi)).all()), f"head {h}: a non-tie member differs"
             assert diff.sum() <= 0.02 * keep_ref.sum() + 8, f"head {h}: {int(diff.sum())} members differ"
-    assert checked >= 2
+    assert checked >= (2 if H == 3 else 6)
     # the attention output of the same pass, loosely: these heads have logits of magnitude ~40, where one bf16 step of a
     # score (the reference rounds q.k to the model dtype, attention_utils.py:37) is 0.25 — a last-bit difference of the
     # fp32 dot product moves a probability by a quarter.  The tight bound on y is test_prefill_bands_full_size's.
@@ -174,7 +175,7 @@ def test_hybrid_profiling_full_size(oracle_mt):
     assert (y.cpu().float()[0] - yr).abs().max() <= 0.05 * yr.abs().max()
 
 
-@pytest.mark.parametrize("S,H", [(4096, 2), (2560, 8)])  # C3's length on a head subset; C2 (max_cache_length 0.25 -> 2560) on ALL 8 kv heads (r5)
+@pytest.mark.parametrize("S,H", [(4096, 2), (2560, 8), (4096, 8)])  # C3's length on a head subset; C2 (max_cache_length 0.25 -> 2560) on ALL 8 kv heads (r5); r6: C3 on all 8
 def test_heavy_hitter_prefill_to_decode_without_state_sync(oracle_mt, audit, S, H):
     """8192-token prompt -> SnapKV compaction to S -> history from the column means -> 48 decode steps of the fused
     step, device and oracle each continuing from THEIR OWN numeric state (nothing is copied across after the prompt's
@@ -240,7 +241,7 @@ def test_heavy_hitter_prefill_to_decode_without_state_sync(oracle_mt, audit, S, 
     # ---- decode: both sides on their own state; a differing eviction must be a near-tie in the ORACLE's scores, and is then
     #      followed (the oracle is made to evict the device's slot) so that the caches stay comparable (tests/helpers.py)
     justified, total = hh_own_state_steps(o, kv, st, gen, L, steps, HQ, g, w, dtype)
-    audit(f"n_just = {justified} of {total} evictions (limit 5 %)")
+    audit(f"n_just = {justified} of {total} evictions (limit 5 %)", rule="near-tie eviction", count=justified, compared=total, limit="5 % of the evictions, each within 2 bf16 roundings of the minimum")
     assert justified <= 0.05 * total, f"{justified} of {total} evictions were near-tie divergences"
     assert kv.step_status(HQ) == 0
 
@@ -429,7 +430,7 @@ def test_hybrid_prefill_to_decode_without_state_sync(oracle_mt, audit):
             continue
         yr = from_np(yo1, dtype).float()
         assert (yd.cpu().float()[0, :, 0] - yr).abs().max() <= 1e-3 + 2 * BF16_ULP * yr.abs().max(), f"step {t}: y"
-    audit(f"n_just = {reseated} near-tie candidate re-seats in {steps} steps x {H} heads (limit 2)")
+    audit(f"n_just = {reseated} near-tie candidate re-seats in {steps} steps x {H} heads (limit 2)", rule="near-tie candidate re-seat", count=reseated, compared=steps * H, limit="2 per run")
     assert reseated <= 2, f"{reseated} near-tie divergences in {steps} steps"
     assert evict_hh >= len(hh_heads) * (steps - 2) and evict_win >= len(win_heads) * (steps - 2)  # the budgets were full: real evictions
     assert np.array_equal(kv.attn_history_denom.cpu()[0].numpy(), st["denom"]) and int(kv.attn_counter) == int(st["ctr"][0])

@@ -696,6 +696,45 @@ def test_single_launch_caches_of_different_head_counts_share_the_workspace(singl
     assert single_launch_status() == 0
 
 
+def test_per_device_single_launch_knob():
+    """the knob for shared devices is a property of ONE device (cc_decode_step_device_single_launch, boundary header;
+    attention_utils.set_device_single_launch) — co-residency is a per-device fact.  Off: the availability queries of this device answer
+    0 and a cache's steps take the two-launch forms, leaving state bit-identical to the single-launch twin's; on again: the single
+    launch is back.  The process-wide A/B switch of the debug header is untouched by it."""
+    from cold_compress_amd import _abi
+    from cold_compress_amd.attention_utils import set_device_single_launch, single_launch_status
+    from cold_compress_amd.cache import step_is_recoverable
+
+    fns = _abi.lib()
+    dev = torch.device(DEV, torch.cuda.current_device())
+    H, HQ, S, D, dtype = 8, 32, 1024, 128, torch.bfloat16
+    a, b = _mk(H, S, D, dtype), _mk(H, S, D, dtype)
+    _seed(a, torch.Generator().manual_seed(5), S - 3)
+    _seed(b, torch.Generator().manual_seed(5), S - 3)
+    gen = torch.Generator().manual_seed(6)
+    assert fns["cc_decode_step_single_launch"](HQ, H, S, D, 1) == 1 and step_is_recoverable(a, HQ)
+    try:
+        assert set_device_single_launch(dev, False) is True  # (the previous setting)
+        assert fns["cc_decode_step_single_launch_enabled"]() == 0 and not step_is_recoverable(a, HQ)
+        for t in range(4):
+            p = torch.tensor([S + 10 + t], dtype=torch.int32, device=DEV)
+            k1 = torch.randn(1, H, 1, D, generator=gen).to(dtype).to(DEV)
+            q = torch.randn(1, HQ, 1, D, generator=gen).to(dtype).to(DEV)
+            set_device_single_launch(dev, False)
+            ya = a.decode_step(q, k1, k1, p)   # two launches: the device is "shared"
+            set_device_single_launch(dev, True)
+            yb = b.decode_step(q, k1, k1, p)   # one launch
+            torch.cuda.synchronize()
+            assert torch.allclose(ya.float(), yb.float(), rtol=2.0 ** -7, atol=1e-6), t
+            for (na, ta), (nb, tb) in zip(a.named_buffers(), b.named_buffers()):
+                if na not in ("next_key", "step_commit"):
+                    assert torch.equal(ta, tb), (t, na)
+            assert (a.step_commit[:, 2:66] == -1).all(), "the two-launch form writes no commit words"
+    finally:
+        set_device_single_launch(dev, True)
+    assert fns["cc_decode_step_single_launch_enabled"]() == 1 and single_launch_status() == 0
+
+
 def test_hand_off_timeout_is_reported_loudly():
     """A single-launch step whose workgroups were not all resident gives up after a bounded spin and leaves a word in the decode
     workspace; the harness's generate() (and bench.py) check it and raise — simulated here by setting the word."""

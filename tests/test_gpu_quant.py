@@ -79,8 +79,10 @@ def test_quantised_cache_replay_bit_exact(name):
 
 @pytest.mark.parametrize("graphed", [False, True])
 def test_e2e_cache_bits_8(graphed, audit):
-    """Tiny-Llama end-to-end with cache_bits=8 (fp32): tokens identical, logits within the north-star 1e-3, final
-    quantised images / scales / zero points bit-exact.  The fused two-launch decode step is in the loop."""
+    """Tiny-Llama end-to-end with cache_bits=8 (fp32): tokens identical, logits within the north-star 1e-3, final scales / zero
+    points to 1e-4, the final quantised images equal up to AT MOST 8 codes per image one rounding step off (a K / V value that sits on
+    a rounding boundary behind this build's own fp32 GEMMs: see below; 0 on the committed fixture — the quantiser itself is pinned
+    bit for bit by the known-answer and replay tests).  The fused two-launch decode step is in the loop."""
     from cold_compress_amd.harness import GraphedDecoder, decode_one_token, generate, prefill
 
     f = load_golden("f9_e2e_heavy_hitter_q8.npz")
@@ -109,18 +111,20 @@ def test_e2e_cache_bits_8(graphed, audit):
         # rounding, and so do the 8-bit images — a code is round(x / scale), and a value that sits ON a rounding boundary flips its
         # code on that 1e-6 (found by running this test on reference-made fixtures from other seeds, r5: one code of 4096 off by
         # one at seed offset 5003, three at offset 11 with jittered shapes, none at 0 / 1000; tools/dbg/q8_fresh_seed_diag.py).
-        # Accepted: single-step differences in at most 0.5 % of an image's codes (counted in the audit; a slot's scale and zero point
+        # Accepted: single-step differences in at most 8 codes of an image (counted in the audit; a slot's scale and zero point
         # move by the same 1e-6, which shifts every code of the slot by a hair); the quantiser itself is pinned bit for bit by the
         # known-answer and replay tests above (same inputs on both sides).
         for nm, mine in (("K", kv.k_cache_q), ("V", kv.v_cache_q)):
             d = (mine.cpu().view(torch.uint8).to(torch.int16) - f[f"final_{nm.lower()}_L{li}"].view(torch.uint8).to(torch.int16)).abs()
             off += int((d > 0).sum())
-            assert int(d.max()) <= 1 and int((d > 0).sum()) <= max(2, d.numel() // 200), f"layer {li} {nm} image: {int((d > 0).sum())} codes differ, by up to {int(d.max())}"
+            # (a small ABSOLUTE count — at most 8 codes of an image, observed 0 .. 3 — not a fraction of it: 0.5 % of an
+            #  image was hundreds of codes, room enough to hide a quantiser regression end to end)
+            assert int(d.max()) <= 1 and int((d > 0).sum()) <= 8, f"layer {li} {nm} image: {int((d > 0).sum())} codes differ, by up to {int(d.max())}"
         assert torch.allclose(kv.k_scales.cpu(), f[f"final_k_scales_L{li}"], rtol=1e-4, atol=1e-7)
         assert torch.allclose(kv.k_zero_points.cpu(), f[f"final_k_zero_points_L{li}"], rtol=1e-4, atol=1e-6)
         assert torch.equal(kv.pos.cpu(), f[f"final_pos_L{li}"])
         assert torch.equal(kv.attn_history_denom.cpu(), f[f"final_denom_L{li}"])
-    audit(f"8-bit codes off by one rounding step = {off} (limit 0.5 % of an image)")
+    audit(f"8-bit codes off by one rounding step = {off} (limit 8 per image)", rule="q8 boundary code", count=off, compared=sum(2 * l.attention.kv_cache.k_cache_q.numel() for l in model.layers), limit="8 per image")
     stats = model.get_cache_stats(f["prompt_len"], f["new_tokens"])
     assert abs(stats["compression_ratio_avg"] - f["compression_ratio_avg"]) < 1e-6
 

@@ -13,6 +13,15 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
+
+def _pin_us():
+    """How long the co-tenant of the fault tests pins its CUs: 2.5 bounded waits of the hand-off — at least one attempt of the step
+    times out beside it, and it is gone well within the harness's six attempts."""
+    from cold_compress_amd import _abi
+
+    return int(2.5 * _abi.lib()["cc_decode_step_wait_bound_us"]())
+
+
 def step_committed(kv, p):
     from cold_compress_amd.cache import step_committed as f
 
@@ -225,13 +234,90 @@ def test_launches_behind_a_set_status_word_do_nothing():
     assert step_committed(kv, T + 1) and kv.step_status(HQ) == 0
 
 
+def test_hand_off_wait_is_bounded_by_device_time():
+    """the failure latency of a single-launch step is a DEVICE-TIME bound (cc_decode_step_wait_bound_us, 30 ms), not
+    2^18 poll rounds (1.6 s).  A co-tenant pins 150 KB of LDS on 232 of the 256 CUs for ten bounds; ONE step of a cache with 128
+    workgroups (8 kv heads x 16) is launched beside it: some head's workgroups are not all resident, the resident ones give up —
+    and say so in the status word.  The host watches that word through a third stream while both kernels are still running (the
+    step's LAUNCH cannot end before the co-tenant has left: its remaining workgroups wait for a CU, whatever the resident ones
+    decided): it must flip within [0.5, 4] bounds of the launch.  Nothing of the failed heads is committed; with the co-tenant gone
+    and the word cleared, the same step completes."""
+    import time
+
+    from cold_compress_amd import _abi
+    from cold_compress_amd.attention_utils import _decode_workspaces, reset_single_launch_status, single_launch_status
+    from cold_compress_amd.cache import step_is_recoverable
+
+    fns = _abi.lib()
+    bound_ms = fns["cc_decode_step_wait_bound_us"]() / 1000.0
+    assert 5.0 <= bound_ms <= 100.0, bound_ms
+    H, HQ, S, D = 8, 32, 1024, 128
+    kv, T = _mk(H, S)
+    gen = torch.Generator(device=DEV).manual_seed(9)
+    q = torch.randn(1, HQ, 1, D, device=DEV, generator=gen).to(torch.bfloat16)
+    k1 = torch.randn(1, H, 1, D, device=DEV, generator=gen).to(torch.bfloat16)
+    p = torch.tensor([T], dtype=torch.int32, device=DEV)
+    kv.decode_step(q, k1, k1, p)  # (workspace, pipeline)
+    torch.cuda.synchronize()
+    assert step_is_recoverable(kv, HQ), "the shape must take the single-launch form"
+    off = int(fns["cc_decode_step_status_offset"]())
+    ws = _decode_workspaces(kv.pos.device)[0]
+    word = ws[off:off + 4].view(torch.int32)
+    # four watch streams, polled without blocking: HIP maps streams onto a few hardware queues, and a watcher that shares the
+    # co-tenant's queue sees nothing until the co-tenant has left (how this test failed inside the full suite and passed alone)
+    n_watch = 4
+    host = torch.zeros(n_watch, dtype=torch.int32).pin_memory()
+    watchers = [torch.cuda.Stream() for _ in range(n_watch)]
+    scratch = torch.zeros(64, dtype=torch.int32, device=DEV)
+    p2 = torch.tensor([T + 1], dtype=torch.int32, device=DEV)
+    flipped_ms = None
+    try:
+        for attempt in range(6):  # (a side stream that shares the decode stream's hardware queue runs BEHIND the step: try the next)
+            side = torch.cuda.Stream()
+            rc = fns["cc_debug_occupy"](232, 150 * 1024, int(10 * bound_ms * 1000), C.c_void_p(scratch.data_ptr()), C.c_void_p(side.cuda_stream))
+            assert rc == 0
+            time.sleep(0.002)  # (the co-tenant is resident before the step is launched)
+            t0 = time.perf_counter()
+            kv.decode_step(q, k1, k1, p2)
+            pending = [None] * n_watch  # per watcher: (event, time the copy was issued)
+            while (time.perf_counter() - t0) * 1e3 < 8 * bound_ms and flipped_ms is None:
+                for wi, ws_ in enumerate(watchers):
+                    if pending[wi] is None:
+                        with torch.cuda.stream(ws_):
+                            host[wi:wi + 1].copy_(word, non_blocking=True)
+                            ev = torch.cuda.Event()
+                            ev.record()
+                        pending[wi] = (ev, time.perf_counter())
+                    elif pending[wi][0].query():
+                        if int(host[wi]) != 0:
+                            flipped_ms = (time.perf_counter() - t0) * 1e3
+                            break
+                        pending[wi] = None
+                time.sleep(0.001)
+            torch.cuda.synchronize()
+            if single_launch_status(kv.pos.device) != 0:
+                break
+        assert single_launch_status(kv.pos.device) != 0, "the co-tenant did not provoke a hand-off timeout in six attempts: nothing was tested"
+        assert flipped_ms is not None, "the status word was not seen set while the co-tenant was still there"
+        assert 0.5 * bound_ms <= flipped_ms <= 4.0 * bound_ms, f"the step gave up after {flipped_ms:.1f} ms against a bound of {bound_ms:.0f} ms"
+        assert not step_committed(kv, T + 1)
+    finally:
+        torch.cuda.synchronize()
+        reset_single_launch_status(kv.pos.device)
+        fns["cc_decode_step_demote_l2_handoff"](0)
+    kv.decode_step(q, k1, k1, p2)  # the retry, alone on the device
+    torch.cuda.synchronize()
+    assert step_committed(kv, T + 1) and single_launch_status(kv.pos.device) == 0
+
+
 @pytest.mark.parametrize("fuse_qkv", [False, True])  # (r5) True: the decode loop on the QKV form of the step — the retry recomputes the projection too
 @pytest.mark.parametrize("strategy", ["heavy_hitter", "recent_global"])
 def test_co_tenant_fault_is_recovered_in_band(strategy, fuse_qkv):
     """Two layers of the Llama-3-8B shape, heavy hitter (or recent_global: the head-constant form of the recoverable step — its kv
     heads complete one after the other here, each on its own copy of the key row) at 1024 slots: 128 workgroups per step (16 per kv head, dispatched head by
-    head).  Before the fourth decode token a co-tenant kernel pins 150 KB of LDS on 232 of the 256 CUs for 2.2 s — longer than the
-    hand-off's bounded wait (~1.6 s): some kv head's workgroups do not all fit beside it, the resident ones give up, every later
+    head).  Before the fourth decode token a co-tenant kernel pins 150 KB of LDS on 232 of the 256 CUs for 2.5 bounded waits (r6: the
+    bound is device time, cc_decode_step_wait_bound_us = 30 ms; r2-r5: 2^18 poll rounds, ~1.6 s, and a 2.2 s pin) — longer than the
+    hand-off's bounded wait: some kv head's workgroups do not all fit beside it, the resident ones give up, every later
     launch of the token returns at once.  decode_n_tokens notices (one status read per token), clears, retries (the co-tenant
     leaves meanwhile) — the generated tokens and every cache buffer equal the fault-free run's.  (What a head needs is ITS
     workgroups resident together — measured with this hook: the step completes beside 224 pinned CUs and fails beside 232.)"""
@@ -274,7 +360,7 @@ def test_co_tenant_fault_is_recovered_in_band(strategy, fuse_qkv):
 
         def step(m, x, pos, **k2):
             if calls[0] == fault_at:
-                rc = _abi.lib()["cc_debug_occupy"](232, 150 * 1024, 2_200_000, C.c_void_p(scratch.data_ptr()), C.c_void_p(side.cuda_stream))
+                rc = _abi.lib()["cc_debug_occupy"](232, 150 * 1024, _pin_us(), C.c_void_p(scratch.data_ptr()), C.c_void_p(side.cuda_stream))
                 assert rc == 0
             calls[0] += 1
             return decode_one_token(m, x, pos, **k2)
@@ -467,7 +553,7 @@ def test_hybrid_co_tenant_fault_is_recovered():
                 ya = a.decode_step(qa, ka, va, p, input_ids=ids)
                 torch.cuda.synchronize()
                 if t == 3:
-                    rc = _abi.lib()["cc_debug_occupy"](232, 150 * 1024, 2_200_000, C.c_void_p(scratch.data_ptr()), C.c_void_p(side.cuda_stream))
+                    rc = _abi.lib()["cc_debug_occupy"](232, 150 * 1024, _pin_us(), C.c_void_p(scratch.data_ptr()), C.c_void_p(side.cuda_stream))
                     assert rc == 0
                 yb = b.decode_step(qb, kb, vb, p, input_ids=ids)
                 torch.cuda.synchronize()
@@ -519,7 +605,7 @@ def test_several_tiles_co_tenant_fault_is_recovered(strategy):
                 ya = a.decode_step(q, k1, v1, p)
                 torch.cuda.synchronize()
                 if t == 3:
-                    rc = _abi.lib()["cc_debug_occupy"](232, 150 * 1024, 2_200_000, C.c_void_p(scratch.data_ptr()), C.c_void_p(side.cuda_stream))
+                    rc = _abi.lib()["cc_debug_occupy"](232, 150 * 1024, _pin_us(), C.c_void_p(scratch.data_ptr()), C.c_void_p(side.cuda_stream))
                     assert rc == 0
                 yb = b.decode_step(q, k1, v1, p)
                 torch.cuda.synchronize()

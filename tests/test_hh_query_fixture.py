@@ -102,7 +102,9 @@ def test_oracle_pipeline_on_reference_query_trace(oracle, audit):
             rel = float((a_mine[h, s] - a_ref[h, s]).abs() / a_ref[h, s].abs())
             assert ok and rel <= bound, f"step {t} head {h} slot {s}: group-mean probability off by {rel / BF16_ULP:.1f} roundings, no score on a rounding boundary"
             n_flip += 1
-    audit(f"n_just = {n_just} of {steps * H} evictions (limit 5 %); probabilities behind a score on a bf16 rounding boundary = {n_flip} of {steps * H * S}")
+    audit(f"n_just = {n_just} of {steps * H} evictions (limit 5 %); probabilities behind a score on a bf16 rounding boundary = {n_flip} of {steps * H * S}",
+          rule="near-tie eviction", count=n_just, compared=steps * H, limit="5 % of the evictions, each within 2 bf16 roundings of the minimum")
+    audit(f"boundary probabilities = {n_flip}", rule="boundary probability", count=n_flip, compared=steps * H * S, limit="1e-4 of the entries, each behind a dot product within 2e-7 of a bf16 midpoint")
     assert n_just <= 0.05 * steps * H, n_just
     assert n_flip <= 1e-4 * steps * H * S + 1, n_flip
     assert np.array_equal(st["pos"], f["final_pos"][0].numpy())
@@ -150,7 +152,7 @@ def test_fused_step_on_reference_query_trace(single, audit):
         y = kv.decode_step(f["q"][t].to(dev), f["k_new"][t].to(dev), f["v_new"][t].to(dev), pt)
         assert y_close(y.cpu().float()[0, :, 0], f["y"][t][0, :, 0].float()), f"step {t}: y"
     assert kv.step_status(HQ) == 0
-    audit(f"n_just = {n_just} of {steps * H} evictions (limit 5 %)")
+    audit(f"n_just = {n_just} of {steps * H} evictions (limit 5 %)", rule="near-tie eviction", count=n_just, compared=steps * H, limit="5 % of the evictions, each within 2 bf16 roundings of the minimum")
     assert n_just <= 0.05 * steps * H, n_just
     assert torch.equal(kv.pos.cpu(), f["final_pos"])
     assert torch.equal(kv.k_cache.cpu(), f["final_k"]) and torch.equal(kv.v_cache.cpu(), f["final_v"])

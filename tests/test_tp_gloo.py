@@ -213,6 +213,60 @@ def test_tp_gloo_matches_single_process(world):
         assert err < 1e-4, f"rank {rank}: TP output differs from the single-process model by {err}"
 
 
+def _worker_capture_refused(rank, world, port, q, refusing_rank):
+    """One rank's capture is refused (fault injection); every rank must end up on eager launches — TOGETHER: the verdicts are combined
+    in a collective that every rank enters whatever happened locally, and none hangs in it."""
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from cold_compress_amd.harness import negotiate_graphed_decoder
+
+        captured, logs = [], []
+
+        class Dec:  # stands in for GraphedDecoder: "capturing" is its first step
+            pass
+
+        def first_step(d):
+            if rank == refusing_rank:
+                raise RuntimeError("hipErrorStreamCaptureUnsupported: operation not permitted when stream is capturing (injected)")
+            captured.append(d)
+
+        dec = negotiate_graphed_decoder(Dec, first_step, torch.device("cpu"), log=logs.append)
+        # a second negotiation in which nobody refuses: all ranks keep their decoder
+        dec2 = negotiate_graphed_decoder(Dec, lambda d: None, torch.device("cpu"), log=logs.append)
+        # ... and the ranks are still in step with each other afterwards (a collective behind the negotiation completes)
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        q.put((rank, dict(dec_is_none=dec is None, dec2_kept=dec2 is not None, captured_locally=len(captured), logs=logs, ranks=int(t.item()))))
+        dist.destroy_process_group()
+    except Exception as e:  # pragma: no cover
+        q.put((rank, repr(e)))
+
+
+@pytest.mark.parametrize("world,refusing_rank", [(2, 1), (4, 0)])
+def test_capture_refused_on_one_rank_sends_every_rank_to_eager(world, refusing_rank):
+    """'hipGraph capture of the RCCL all-reduce refused -> every rank falls back together' (bench.py had the logic since
+    r2, nothing exercised it).  harness.negotiate_graphed_decoder under gloo: the refusing rank raises inside its capture; EVERY rank
+    must come back with no decoder (the ranks whose own capture succeeded drop it), nobody hangs, and a negotiation without a
+    refusal keeps the decoders.  ref: tp.py:134-160 (the all-reduces a captured step would contain)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_capture_refused, args=(r, world, port, q, refusing_rank)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, r in res:
+        assert isinstance(r, dict), f"rank {rank}: {r}"
+        assert r["dec_is_none"], f"rank {rank} kept a captured decoder although rank {refusing_rank}'s capture was refused"
+        assert r["dec2_kept"], f"rank {rank}: a negotiation nobody refused must keep the decoder"
+        assert r["ranks"] == world
+        assert r["captured_locally"] == (0 if rank == refusing_rank else 1)
+        assert any("refused" in m or "failed" in m for m in r["logs"]), f"rank {rank} fell back silently: {r['logs']}"
+
+
 def test_tp_noop_without_torchrun(monkeypatch):
     from cold_compress_amd import tp
 

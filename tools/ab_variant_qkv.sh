@@ -5,7 +5,7 @@ set -e
 root=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p "$root/.ab"
 cd "$root/cold_compress_amd/csrc"
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-function -mllvm -amdgpu-mfma-vgpr-form=1 $2 \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-function -mllvm -amdgpu-mfma-vgpr-form=1 -mllvm -amdgpu-kernarg-preload-count=14 $2 \
   -c cc_attn_decode_qkv.hip -o "/tmp/abq_$1.o"
 objs=$(ls *.o | grep -v '^cc_attn_decode_qkv.o$')
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$root/.ab/lib$1.so" "/tmp/abq_$1.o" $objs

@@ -64,9 +64,9 @@ def main():
         # resident at once, which eight processes streaming full-size caches do not grant each other (measured, r5: hand-off timeouts,
         # different garbage in every run — this harness drives decode_one_token without the recovery loop).  The documented switch for
         # shared devices: the two-launch forms (same arithmetic, bit-identical cache state).
-        from cold_compress_amd import _abi
+        from cold_compress_amd.attention_utils import set_device_single_launch
 
-        _abi.lib()["cc_decode_step_set_single_launch"](0)
+        set_device_single_launch(torch.device("cuda", torch.cuda.current_device()), False)  # (r6: the per-device knob of the boundary header)
     if args.oneshot:
         assert tp.enable_oneshot_allreduce() is not None, "the one-shot all-reduce did not pass its self-test"
     cfg = dict(CONFIGS[args.model])
