@@ -309,7 +309,7 @@ static int run_side(PfArgs a, int nwg, hipStream_t st) {
 
 extern "C" int cc_prefill_attn_mfma_impl(const void* q, const void* k, const void* v, int HQ, int H, int L, int D, int dtype,
                                          float scale, void* y, float* stats, float* cpart, int nwg, void* vt, const int* bands,
-                                         int nb, int obs_len, hipStream_t st);
+                                         int nb, int obs_len, hipStream_t st, int max_partials, int* n_partials);
 
 extern "C" int cc_prefill_attn_flash_impl(const void* q, const void* k, const void* v, int HQ, int H, int L, int D, int dtype,
                                           float scale, void* y, int nwg, void* vt, hipStream_t st);
@@ -376,10 +376,12 @@ int cc_prefill_attn_bands(const void* q, const void* k, const void* v, int32_t H
       return cc_prefill_attn_flash_impl(q, k, v, HQ, H, L, D, dtype, scale, y, nwgf, vt, st);
     }
     const int obs_len = a.obs ? a.obs_len : 0;
-    const int rc = cc_prefill_attn_mfma_impl(q, k, v, HQ, H, L, D, dtype, scale, y, a.stats, a.cpart, nwg, vt, a.band, a.nb, obs_len, st);
+    int n_partials = nwg;  // partial planes the pass left per output plane: its workgroups per head (two-pass form) or its query segments (r6)
+    const int rc = cc_prefill_attn_mfma_impl(q, k, v, HQ, H, L, D, dtype, scale, y, a.stats, a.cpart, nwg, vt, a.band, a.nb, obs_len, st,
+                                             kNWGMfma, &n_partials);
     if (rc != CC_OK) return rc;
     a.obs_plane = obs_len > 0 ? 1 + a.nb : -1;
-    if (a.colsum || a.obs || a.band_out) return dtype == CC_DT_BF16 ? run_side<bf16_t>(a, nwg, st) : run_side<f16_t>(a, nwg, st);
+    if (a.colsum || a.obs || a.band_out) return dtype == CC_DT_BF16 ? run_side<bf16_t>(a, n_partials, st) : run_side<f16_t>(a, n_partials, st);
     return CC_OK;
   }
   switch (dtype) {

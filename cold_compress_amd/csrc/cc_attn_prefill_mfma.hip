@@ -474,7 +474,10 @@ __global__ __launch_bounds__(256, 2) void prefill_pv_lds_kernel(MArgs a) {
 // normalised — a different, equally good rounding of the same quantity: y within the contract's 1e-3 + 2 roundings of the oracle.
 constexpr float kLazy = 6.0f;  // in units of the scaled logits (natural log): e^6 = 403
 
-template <typename T>
+// STATS (r6): the pass also leaves, per (query head, query), the pair (m_ref, l_exact) the K-stationary side-sum pass below
+// normalises with — l_exact sums the UNROUNDED weights exp(x - m_ref) (softmax is shift-invariant: exp(x - m_ref) / l_exact is the
+// reference's fp32 softmax up to fp32 rounding, attention_utils.py:52), next to l_run, which sums what P.V multiplies.
+template <typename T, bool STATS = false>
 __global__ __launch_bounds__(256, 2) void prefill_flash_kernel(MArgs a) {
   __shared__ __attribute__((aligned(16))) uint4 sm_kt[2][kTK][16];   // [buf][key][chunk ^ (key & 15)]
   __shared__ __attribute__((aligned(16))) uint4 sm_vt[2][kD][4];     // [buf][d][chunk ^ ((d >> 2) & 3)]  (V^T, permuted keys)
@@ -503,6 +506,7 @@ __global__ __launch_bounds__(256, 2) void prefill_flash_kernel(MArgs a) {
 #pragma unroll
     for (int ds = 0; ds < 8; ds++) qb[ds] = *reinterpret_cast<const uint4*>(qh + (size_t)qc * kD + ds * 16 + 8 * hi);
     float m_ref = -INFINITY, l_run = 0.f;  // the row's reference maximum (both half-wave lanes agree) / this lane's share of l
+    float l_ex = 0.f;                      // STATS: this lane's share of the sum of the unrounded weights
     f32x16 o[4];
 #pragma unroll
     for (int b = 0; b < 4; b++)
@@ -566,7 +570,7 @@ __global__ __launch_bounds__(256, 2) void prefill_flash_kernel(MArgs a) {
       m_ref = m_new;
       const float mneg = m_new == -INFINITY ? 0.f : -m_new * kLog2e;
       uint32_t pp[8];  // the unnormalised probabilities as packed 16-bit pairs: the A operand of the P.V products
-      float psum = 0.f;
+      float psum = 0.f, esum = 0.f;
 #pragma unroll
       for (int e = 0; e < 16; e += 2) {
         float p0, p1;
@@ -574,8 +578,10 @@ __global__ __launch_bounds__(256, 2) void prefill_flash_kernel(MArgs a) {
         const float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(x[e + 1], kLog2e, mneg));
         pp[e >> 1] = pf_rnd2<T>(e0, e1, p0, p1);
         psum += p0 + p1;  // l sums what P.V multiplies: the ROUNDED weights (y is a proper weighted mean of the V rows)
+        if constexpr (STATS) esum += e0 + e1;
       }
       l_run = l_run * alpha + psum;
+      if constexpr (STATS) l_ex = l_ex * alpha + esum;
       if (__any(raise)) {  // wave-uniform: some row's reference moved — its factor travels to the O layout through LDS
         if (hi == 0) sm_row[r][lq] = alpha;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -614,6 +620,13 @@ __global__ __launch_bounds__(256, 2) void prefill_flash_kernel(MArgs a) {
     const int n_full = (q0 + kTQ <= L) ? min(ntile, (q0 + 1) / kTK) : 0;  // tiles strictly below the diagonal of a complete query tile
     for (int t = 0; t < n_full; t++) tile(t, BoolC<true>{});
     for (int t = n_full; t < ntile; t++) tile(t, BoolC<false>{});
+    if constexpr (STATS) {
+      const float le = l_ex + __shfl_xor(l_ex, 32, CC_WAVE);
+      if (hi == 0 && query < L) {
+        a.stats[((size_t)j * L + query) * 2] = m_ref;
+        a.stats[((size_t)j * L + query) * 2 + 1] = le;
+      }
+    }
     // y = O / l: the rows' 1 / l in the O layout, through the wave's LDS row
     const float lt = l_run + __shfl_xor(l_run, 32, CC_WAVE);
     if (hi == 0) sm_row[r][lq] = __frcp_rn(lt);
@@ -636,6 +649,265 @@ __global__ __launch_bounds__(256, 2) void prefill_flash_kernel(MArgs a) {
     }
     __builtin_amdgcn_wave_barrier();
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Side sums, K-STATIONARY (r6): the column / band / observation-window sums of the group-mean probabilities as a
+// QK-only sweep with the KEYS fixed — the shape of a flash backward's dK loop.  ref: model.py:416-418 (group mean -> dtype),
+// cache.py:704 (column sums), prompt_compression.py:170-194 (observation window), cache.py:1093, 1155 (FastGen bands).
+//
+//   unit       = (kv head, block of 128 keys, segment of qseg queries); a workgroup of 4 waves, wave w owning keys
+//                k0 + 32 w .. + 31 as the A operand of S^T = K . Q^T — eight 16-byte fragments per lane, loaded ONCE per unit;
+//   sweep      = the segment's query tiles (32 queries) at or above the block's first key; the tile's rows of ALL FOUR query
+//                heads of the group are staged once per workgroup in a double-buffered, XOR-swizzled LDS image (32 KiB per tile);
+//                each wave runs the four heads one after the other against its keys: lane = query, registers = keys, so that the
+//                group mean — ((p0 + p1) + p2) + p3, * 0.25, -> dtype: the two-pass kernel's order — is LANE-LOCAL (a running sum
+//                across the four heads): no probability tiles through LDS, no barrier for them, no P.V, no O accumulators;
+//   sums       = per lane, 16 keys x {column, bands, window} accumulators that live in registers for the whole sweep; ONE
+//                cross-lane reduction per unit, one store per key and plane into the unit's own slice of the partial planes
+//                [plane][segment][H][L] (every (segment, key) is written by exactly one unit: no atomics, fixed order) — folded
+//                over the segments by prefill_side_kernel like the two-pass kernel's per-workgroup planes.
+// Probabilities: dtype(exp2(x log2e - m log2e) * (1 / l)) with (m, l) = the flash pass's (m_ref, l_exact) — pass 2's formula.
+// Against the two-pass form: the same QK^T contraction and rounding chain, but 1/4 of the group-mean work (no redundancy across
+// heads, no LDS round trip), no per-tile plane fold (134 MB of writes at L = 8192), and the P.V half lives in the flash pass.
+constexpr int kQSeg = 512;    // queries per unit (a multiple of 32; doubled until the segments fit the workspace's 64 partial planes)
+constexpr int kKBlk = 128;    // keys per unit: 4 waves x 32
+
+#ifndef CC_KSTAT_SGB
+#define CC_KSTAT_SGB 0   // VALU instructions woven in behind each (fragment read, MFMA) pair of the side-sum pass (0: the compiler's own order —
+                         // measured best: 1.514 ms per layer at L = 8192 against 1.540 (10) and 1.547 (18), same box)
+#endif
+template <typename T, int NB, bool OBS>
+__global__ __launch_bounds__(256, 2) void prefill_colsum_kstat_kernel(MArgs a, int nseg, int qseg, int units_per_head) {
+  __shared__ __attribute__((aligned(16))) uint4 sm_q[2][4][kTQ][16];  // [buf][head][query][chunk ^ (query & 15)]: 64 KiB
+  constexpr int NBC = NB >= 0 ? NB : kMaxBandsM;
+  const int nb = NB >= 0 ? NB : a.nb;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int hi = lane >> 5, lq = lane & 31;
+  int bx, h;
+  wg_coords(a, bx, h);
+  const int L = a.L;
+  const T* kh = reinterpret_cast<const T*>(a.k) + (size_t)h * L * kD;
+  const size_t plane = (size_t)nseg * a.H * L;
+  const int obs_pl = 1 + nb;
+  const int nkb = (L + kKBlk - 1) / kKBlk;
+
+  for (int u = bx; u < units_per_head; u += a.nwg) {
+    // the NON-EMPTY units — segment qs holds the key blocks that start below its last query — in (segment, key block) order:
+    // workgroups that run together sweep the same queries (one L2-resident segment); the slices of the empty pairs stay zero
+    // (the launcher clears the planes)
+    int qs = 0, kb = u;
+    for (;; qs++) {
+      const int n_here = min(nkb, (min(L, (qs + 1) * qseg) + kKBlk - 1) / kKBlk);
+      if (kb < n_here) break;
+      kb -= n_here;
+    }
+    const int k0 = kb * kKBlk + 32 * w;                    // this wave's first key
+    const int q_hi = min(L, (qs + 1) * qseg);
+    const int q_lo = max(qs * qseg, (kb * kKBlk) & ~31);   // first query tile that can see the block's first key
+    float* cp = a.cpart + ((size_t)qs * a.H + h) * L;
+    float acc[1 + kMaxBandsM + 1][16];
+#pragma unroll
+    for (int pl = 0; pl < 2 + kMaxBandsM; pl++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc[pl][e] = 0.f;
+    if (q_lo < q_hi) {  // (workgroup-uniform: the loop below holds barriers)
+      // K fragments: lane (key k0 + lq, chunk 2 ds + hi), held for the whole sweep
+      uint4 kf[8];
+      const int kc = min(k0 + lq, L - 1);
+#pragma unroll
+      for (int ds = 0; ds < 8; ds++) kf[ds] = *reinterpret_cast<const uint4*>(kh + (size_t)kc * kD + ds * 16 + 8 * hi);
+      // Q tiles by LDS-DMA (buffer_load ... lds): wave w stages the 32 rows of query head w — eight requests of four rows, lane
+      // (row 4 i + lane / 16, slot lane % 16) asking for the chunk that belongs in that slot under the image's XOR swizzle — straight
+      // into the image: no staging registers (a register-staged tile was SPILLED to scratch right behind its request at 237 VGPRs:
+      // a wait for the prefetch and a round trip through scratch per tile, found in the ISA), no ds_write
+      const auto q_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(reinterpret_cast<const T*>(a.q) + (size_t)(h * 4 + w) * L * kD), 0,
+                                                          L * kD * (int)sizeof(T), 0x00020000);
+      // (the destination through a generic pointer, cast inside a captureless lambda — cc_attn_decode_kernels.h's form: with the cast
+      //  of the __shared__ array's address written at the call, the HOST pass silently dropped the kernel's launch stub)
+      auto dma16 = [](__amdgpu_buffer_rsrc_t rs, int voff, void* lp) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lp, 16, voff, 0, 0, 0);
+      };
+      auto fetch = [&](int q0, int buf) {
+#pragma unroll
+        for (int i4 = 0; i4 < 8; i4++) {
+          const int row = 4 * i4 + (lane >> 4);
+          const int qr = min(q0 + row, L - 1);
+          const int voff = qr * (kD * (int)sizeof(T)) + (((lane & 15) ^ (row & 15)) & 15) * 16;
+          dma16(q_rs, voff, &sm_q[buf][w][4 * i4][0]);
+        }
+      };
+      __syncthreads();  // the previous unit's last readers are done with both buffers
+      fetch(q_lo, 0);
+      // one query tile (32 queries x the group's 4 heads) against this wave's 32 keys.  FULL: the tile lies strictly below the
+      // diagonal of complete tiles — no causal / bounds selects (compiled twice, like the two-pass kernel's tile body)
+      // the rows' statistics travel one tile ahead, like the Q tile, and are requested IN FRONT of it: loads return in order — a
+      // request behind the next tile's rows (r6, first cut) made every step wait out its own prefetch, an L2 round trip per tile
+      float2 st4[4], st4n[4];
+      auto fetch_stats = [&](int q0) {
+        const int qc = min(q0 + lq, L - 1);
+#pragma unroll
+        for (int r = 0; r < 4; r++) st4n[r] = *reinterpret_cast<const float2*>(a.stats + ((size_t)(h * 4 + r) * L + qc) * 2);
+      };
+      // One step = four heads.  The head's eight products (each with its own LDS fragment read) and the PREVIOUS head's rounding
+      // chain are independent instruction streams: they are written side by side and the scheduler is told to weave them — one
+      // fragment read, one MFMA, a slice of the chain, eight times (CC_KSTAT_SGB) — so that the matrix pipe, the LDS and the VALU of
+      // a wave work at the same time.  Left to itself the compiler issues the step's 32 MFMAs first and the 650 VALU instructions
+      // behind them, and the four waves of a workgroup — in lockstep at the tile's barrier — all wait for the LDS together and then
+      // all for the VALU: 5400 cycles per step where either phase alone is ~2000 (profiles/r06_prefill_kstat.md).
+      auto mma_head = [&](int buf, int r, f32x16& sx) {
+#pragma unroll
+        for (int e = 0; e < 16; e++) sx[e] = 0.f;
+#pragma unroll
+        for (int ds = 0; ds < 8; ds++) sx = MfmaOps<T>::mma(kf[ds], sm_q[buf][r][lq][((2 * ds + hi) ^ (lq & 15)) & 15], sx);
+      };
+      auto chain_head = [&](int q0, int r, const f32x16& sx, float (&sum)[16], auto full_c) {
+        constexpr bool FULL = decltype(full_c)::value;
+        const int query = q0 + lq;
+        const float m_l2 = -st4[r].x * kLog2e;
+        const float inv_l = __frcp_rn(st4[r].y);
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) {  // ref: attention_utils.py:37 (dtype(dtype(q.k) * scale)), :52 (softmax -> dtype)
+          float r0, r1, v0, v1, p0, p1;
+          pf_rnd2<T>(sx[e], sx[e + 1], r0, r1);
+          pf_rnd2<T>(r0 * a.scale, r1 * a.scale, v0, v1);
+          if (!FULL) {
+            const int key0 = k0 + c_row(e, hi), key1 = k0 + c_row(e + 1, hi);
+            if (key0 > query || key0 >= L || query >= L) v0 = -INFINITY;
+            if (key1 > query || key1 >= L || query >= L) v1 = -INFINITY;
+          }
+          const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(v0, kLog2e, m_l2)) * inv_l;
+          const float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(v1, kLog2e, m_l2)) * inv_l;
+          pf_rnd2<T>(e0, e1, p0, p1);
+          if (r == 0) {
+            sum[e] = p0;
+            sum[e + 1] = p1;
+          } else {  // ((p0 + p1) + p2) + p3: the group mean's order (model.py:416-418; the two-pass kernel's)
+            sum[e] += p0;
+            sum[e + 1] += p1;
+          }
+        }
+      };
+      auto weave = [&]() {  // (hints for the WHOLE step, one ordered sequence: the fragment reads two ahead of their MFMAs —
+        // a read issued right in front of its product stalls it for the LDS latency —, head 0's eight MFMAs bare, then a slice of
+        // the previous head's chain behind every MFMA)
+#if CC_KSTAT_SGB > 0
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+        for (int i32 = 0; i32 < 32; i32++) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (i32 < 30) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          if (i32 >= 8) __builtin_amdgcn_sched_group_barrier(0x002, CC_KSTAT_SGB, 0);
+        }
+#endif
+      };
+      auto step = [&](int q0, int buf, auto full_c) {
+        constexpr bool FULL = decltype(full_c)::value;
+        const int query = q0 + lq;
+        float sum[16];
+        f32x16 sa, sb;
+        mma_head(buf, 0, sa);
+        mma_head(buf, 1, sb);
+        chain_head(q0, 0, sa, sum, full_c);
+        mma_head(buf, 2, sa);
+        chain_head(q0, 1, sb, sum, full_c);
+        mma_head(buf, 3, sb);
+        chain_head(q0, 2, sa, sum, full_c);
+        chain_head(q0, 3, sb, sum, full_c);
+        float obs_f = 0.f;
+        if constexpr (OBS) obs_f = (query >= L - a.obs_len && query < L) ? 1.f : 0.f;
+        // a band plane takes the tile whole, not at all, or element by element (only the tiles the band's edge crosses)
+        int band_mode[kMaxBandsM];
+#pragma unroll
+        for (int b = 0; b < NBC; b++) {
+          const int bw = a.band[b];
+          band_mode[b] = (NB < 0 && b >= nb) ? 0 : ((q0 + kTQ - 1 - k0 < bw) ? 2 : ((q0 - (k0 + kTK - 1) >= bw) ? 0 : 1));
+        }
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) {
+          float a0, a1;
+          pf_rnd2<T>(sum[e] * 0.25f, sum[e + 1] * 0.25f, a0, a1);  // == / 4 exactly
+          acc[0][e] += a0;
+          acc[0][e + 1] += a1;
+          if constexpr (OBS) {
+            acc[1 + kMaxBandsM][e] = __builtin_fmaf(a0, obs_f, acc[1 + kMaxBandsM][e]);
+            acc[1 + kMaxBandsM][e + 1] = __builtin_fmaf(a1, obs_f, acc[1 + kMaxBandsM][e + 1]);
+          }
+#pragma unroll
+          for (int b = 0; b < NBC; b++) {
+            if (band_mode[b] == 2) {
+              acc[1 + b][e] += a0;
+              acc[1 + b][e + 1] += a1;
+            } else if (band_mode[b] == 1) {
+              if (query - (k0 + c_row(e, hi)) < a.band[b]) acc[1 + b][e] += a0;
+              if (query - (k0 + c_row(e + 1, hi)) < a.band[b]) acc[1 + b][e + 1] += a1;
+            }
+          }
+        }
+        weave();
+        (void)FULL;
+      };
+      int buf = 0;
+      fetch_stats(q_lo);
+#pragma unroll
+      for (int r = 0; r < 4; r++) st4[r] = st4n[r];
+      __syncthreads();
+      for (int q0 = q_lo; q0 < q_hi; q0 += kTQ, buf ^= 1) {
+        const bool more = q0 + kTQ < q_hi;
+        // (unconditional, clamped: a branch around loads makes every later in-order wait conservative)
+        fetch_stats(more ? q0 + kTQ : q0);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(more ? q0 + kTQ : q0, buf ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        // tiles whose last query lies below this wave's first key hold nothing for it (the diagonal block's upper waves)
+        if (q0 + kTQ - 1 >= k0 && k0 < L) {
+          if ((k0 + kTK - 1 <= q0) && (q0 + kTQ <= L) && (k0 + kTK <= L)) step(q0, buf, BoolC<true>{});
+          else step(q0, buf, BoolC<false>{});
+        }
+        // (the next tile's statistics were requested ahead of its rows: their wait leaves the DMA requests in flight)
+#pragma unroll
+        for (int r = 0; r < 4; r++) st4[r] = st4n[r];
+        __syncthreads();  // (a release at workgroup scope: waits for this wave's DMA requests) tile q0 + 32 is in LDS; every wave is done with tile q0's image
+      }
+    }
+    // ---- the unit's sums: over the 32 query lanes of each half-wave (fixed butterfly: deterministic), one store per key and plane
+    auto reduce_store = [&](float (&ac)[16], int dst_pl) {  // (the plane by reference: a run-time plane index would put acc in scratch)
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        float v = ac[e];
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 32);
+        const int key = k0 + c_row(e, hi);
+        if (lq == 0 && key < L) cp[(size_t)dst_pl * plane + key] = v;
+      }
+    };
+    reduce_store(acc[0], 0);
+    if constexpr (NBC > 0) {
+      if (NB >= 0 || 0 < nb) reduce_store(acc[1], 1);
+    }
+    if constexpr (NBC > 1) {
+      if (NB >= 0 || 1 < nb) reduce_store(acc[2], 2);
+    }
+    if constexpr (NBC > 2) {
+      if (NB >= 0 || 2 < nb) reduce_store(acc[3], 3);
+    }
+    if constexpr (NBC > 3) {
+      if (NB >= 0 || 3 < nb) reduce_store(acc[4], 4);
+    }
+    if constexpr (OBS) reduce_store(acc[1 + kMaxBandsM], obs_pl);
+  }
+}
+
+template <typename T>
+static void launch_colsum(const MArgs& a, dim3 grid, int nseg, int qseg, int units_per_head, hipStream_t st) {
+#define CC_COLSUM_LAUNCH(NB_, OBS_) hipLaunchKernelGGL((prefill_colsum_kstat_kernel<T, NB_, OBS_>), grid, dim3(256), 0, st, a, nseg, qseg, units_per_head)
+  const bool obs = a.obs_len > 0;
+  switch (a.nb) {
+    case 0: if (obs) CC_COLSUM_LAUNCH(0, true); else CC_COLSUM_LAUNCH(0, false); break;
+    case 1: if (obs) CC_COLSUM_LAUNCH(1, true); else CC_COLSUM_LAUNCH(1, false); break;
+    default: if (obs) CC_COLSUM_LAUNCH(-1, true); else CC_COLSUM_LAUNCH(-1, false); break;
+  }
+#undef CC_COLSUM_LAUNCH
 }
 
 template <typename T>
@@ -678,7 +950,7 @@ extern "C" int cc_prefill_attn_flash_impl(const void* q, const void* k, const vo
 // workspace layout is owned by the caller: stats | cpart planes | vt_perm.
 extern "C" int cc_prefill_attn_mfma_impl(const void* q, const void* k, const void* v, int HQ, int H, int L, int D, int dtype,
                                          float scale, void* y, float* stats, float* cpart, int nwg, void* vt, const int* bands,
-                                         int nb, int obs_len, hipStream_t st) {
+                                         int nb, int obs_len, hipStream_t st, int max_partials, int* n_partials) {
   if (D != kD || HQ != 4 * H || (dtype != CC_DT_BF16 && dtype != CC_DT_F16) || nb > kMaxBandsM) return CC_ERR_UNSUPPORTED;
   const int Lp = (L + 31) & ~31;
   MArgs a{};
@@ -691,6 +963,44 @@ extern "C" int cc_prefill_attn_mfma_impl(const void* q, const void* k, const voi
   dim3 block(256);
   static const bool no_remap = getenv("CC_PREFILL_NO_XCD_REMAP") != nullptr;  // measurement only
   a.xcd_remap = (H % 8 == 0 && !no_remap) ? 1 : 0;
+  *n_partials = nwg;
+  // r6 (built and MEASURED — profiles/r06_prefill_kstat.md): the flash pass (y, and the row statistics as a by-product)
+  // + the K-stationary side-sum pass, instead of statistics pass + probabilities / P.V pass.  A tie at L = 8192 (1.51-1.55 ms against
+  // 1.55), a loss at 16384 (5.60 against 5.33): the side-sum pass runs its LDS-bound fragment reads and its VALU-bound rounding chains
+  // as two phases in lockstep across the workgroup (0.66 ms where either phase alone is ~0.25), and the statistics cost the flash pass
+  // 12 %.  OPT-IN (CC_PREFILL_KSTAT=1); the two-pass form stays the product.
+  static const char* e_kstat = getenv("CC_PREFILL_KSTAT");
+  if (e_kstat && atoi(e_kstat) == 1) {
+    int qseg = kQSeg;
+    while ((L + qseg - 1) / qseg > max_partials) qseg *= 2;
+    const int nseg = (L + qseg - 1) / qseg, nkb = (L + kKBlk - 1) / kKBlk;
+    int units = 0;
+    for (int qs = 0; qs < nseg; qs++) {
+      const int q_end = L < (qs + 1) * qseg ? L : (qs + 1) * qseg;
+      const int n_here = (q_end + kKBlk - 1) / kKBlk;
+      units += n_here < nkb ? n_here : nkb;
+    }
+    const int nqt = (L + kTQ - 1) / kTQ;
+    MArgs af = a;
+    af.nwg = nqt < 128 ? nqt : 128;
+    MArgs ac = a;
+    ac.nwg = units < 64 ? units : 64;  // two workgroups per CU of the head's XCD
+    const int npl = 1 + nb + (obs_len > 0 ? 1 : 0);
+    if (hipMemsetAsync(cpart, 0, (size_t)npl * nseg * H * L * sizeof(float), st) != hipSuccess) return CC_ERR_HIP;
+    const dim3 gridf((unsigned)(af.nwg * H)), gridc((unsigned)(ac.nwg * H));
+    if (dtype == CC_DT_BF16) {
+      hipLaunchKernelGGL(vt_perm_kernel<bf16_t>, dim3((unsigned)nbk), dim3(256), 0, st, (const bf16_t*)v, (bf16_t*)vt, H, L, Lp);
+      hipLaunchKernelGGL((prefill_flash_kernel<bf16_t, true>), gridf, block, 0, st, af);
+      launch_colsum<bf16_t>(ac, gridc, nseg, qseg, units, st);
+    } else {
+      hipLaunchKernelGGL(vt_perm_kernel<f16_t>, dim3((unsigned)nbk), dim3(256), 0, st, (const f16_t*)v, (f16_t*)vt, H, L, Lp);
+      hipLaunchKernelGGL((prefill_flash_kernel<f16_t, true>), gridf, block, 0, st, af);
+      launch_colsum<f16_t>(ac, gridc, nseg, qseg, units, st);
+    }
+    if (hipGetLastError() != hipSuccess) return CC_ERR_HIP;
+    *n_partials = nseg;
+    return CC_OK;
+  }
   // pass 1 keeps no per-workgroup partial planes; 128 persistent workgroups per head (four per CU) measured best at L = 8192
   // (64: 0.545 ms, 128: 0.472, 256: 0.512) — with the serpentine assignment every one of them gets the same share of the triangle
   const int nqt = (L + kTQ - 1) / kTQ;
