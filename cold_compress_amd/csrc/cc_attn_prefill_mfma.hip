@@ -755,65 +755,79 @@ __global__ __launch_bounds__(256, 2) void prefill_colsum_kstat_kernel(MArgs a, i
       // a wave work at the same time.  Left to itself the compiler issues the step's 32 MFMAs first and the 650 VALU instructions
       // behind them, and the four waves of a workgroup — in lockstep at the tile's barrier — all wait for the LDS together and then
       // all for the VALU: 5400 cycles per step where either phase alone is ~2000 (profiles/r06_prefill_kstat.md).
-      auto mma_head = [&](int buf, int r, f32x16& sx) {
-#pragma unroll
-        for (int e = 0; e < 16; e++) sx[e] = 0.f;
-#pragma unroll
-        for (int ds = 0; ds < 8; ds++) sx = MfmaOps<T>::mma(kf[ds], sm_q[buf][r][lq][((2 * ds + hi) ^ (lq & 15)) & 15], sx);
+      // One step = four heads, written as SLICES: slice i of a stage holds the fragment read of the NEXT product, product i of head
+      // r + 1 and pair i (two of the 16 keys) of head r's rounding chain, and ends at a scheduling fence — the matrix pipe, the LDS and
+      // the VALU of a wave work at the same time, by construction (hints alone — sched_group_barrier — were followed loosely and
+      // bought nothing: profiles/r06_prefill_kstat.md).  Left to itself the compiler issues the step's 32 MFMAs first and the 650
+      // VALU instructions behind them, and the waves of a workgroup, in lockstep at the tile's barrier, all wait for the LDS together
+      // and then all for the VALU.
+      auto frag = [&](int buf, int idx) {  // fragment `idx` = (head idx / 8, k-chunk idx % 8) of the staged tile
+        const int r = (idx >> 3) & 3, ds = idx & 7;
+        return sm_q[buf][r][lq][((2 * ds + hi) ^ (lq & 15)) & 15];
       };
-      auto chain_head = [&](int q0, int r, const f32x16& sx, float (&sum)[16], auto full_c) {
+      auto chain_pair = [&](int q0, int r, int e, const f32x16& sx, float (&sum)[16], auto full_c) {
         constexpr bool FULL = decltype(full_c)::value;
         const int query = q0 + lq;
         const float m_l2 = -st4[r].x * kLog2e;
         const float inv_l = __frcp_rn(st4[r].y);
-#pragma unroll
-        for (int e = 0; e < 16; e += 2) {  // ref: attention_utils.py:37 (dtype(dtype(q.k) * scale)), :52 (softmax -> dtype)
-          float r0, r1, v0, v1, p0, p1;
-          pf_rnd2<T>(sx[e], sx[e + 1], r0, r1);
-          pf_rnd2<T>(r0 * a.scale, r1 * a.scale, v0, v1);
-          if (!FULL) {
-            const int key0 = k0 + c_row(e, hi), key1 = k0 + c_row(e + 1, hi);
-            if (key0 > query || key0 >= L || query >= L) v0 = -INFINITY;
-            if (key1 > query || key1 >= L || query >= L) v1 = -INFINITY;
-          }
-          const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(v0, kLog2e, m_l2)) * inv_l;
-          const float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(v1, kLog2e, m_l2)) * inv_l;
-          pf_rnd2<T>(e0, e1, p0, p1);
-          if (r == 0) {
-            sum[e] = p0;
-            sum[e + 1] = p1;
-          } else {  // ((p0 + p1) + p2) + p3: the group mean's order (model.py:416-418; the two-pass kernel's)
-            sum[e] += p0;
-            sum[e + 1] += p1;
-          }
+        // ref: attention_utils.py:37 (dtype(dtype(q.k) * scale)), :52 (softmax -> dtype)
+        float r0, r1, v0, v1, p0, p1;
+        pf_rnd2<T>(sx[e], sx[e + 1], r0, r1);
+        pf_rnd2<T>(r0 * a.scale, r1 * a.scale, v0, v1);
+        if (!FULL) {
+          const int key0 = k0 + c_row(e, hi), key1 = k0 + c_row(e + 1, hi);
+          if (key0 > query || key0 >= L || query >= L) v0 = -INFINITY;
+          if (key1 > query || key1 >= L || query >= L) v1 = -INFINITY;
         }
-      };
-      auto weave = [&]() {  // (hints for the WHOLE step, one ordered sequence: the fragment reads two ahead of their MFMAs —
-        // a read issued right in front of its product stalls it for the LDS latency —, head 0's eight MFMAs bare, then a slice of
-        // the previous head's chain behind every MFMA)
-#if CC_KSTAT_SGB > 0
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-#pragma unroll
-        for (int i32 = 0; i32 < 32; i32++) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          if (i32 < 30) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-          if (i32 >= 8) __builtin_amdgcn_sched_group_barrier(0x002, CC_KSTAT_SGB, 0);
+        const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(v0, kLog2e, m_l2)) * inv_l;
+        const float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(v1, kLog2e, m_l2)) * inv_l;
+        pf_rnd2<T>(e0, e1, p0, p1);
+        if (r == 0) {
+          sum[e] = p0;
+          sum[e + 1] = p1;
+        } else {  // ((p0 + p1) + p2) + p3: the group mean's order (model.py:416-418; the two-pass kernel's)
+          sum[e] += p0;
+          sum[e + 1] += p1;
         }
-#endif
       };
       auto step = [&](int q0, int buf, auto full_c) {
         constexpr bool FULL = decltype(full_c)::value;
         const int query = q0 + lq;
         float sum[16];
         f32x16 sa, sb;
-        mma_head(buf, 0, sa);
-        mma_head(buf, 1, sb);
-        chain_head(q0, 0, sa, sum, full_c);
-        mma_head(buf, 2, sa);
-        chain_head(q0, 1, sb, sum, full_c);
-        mma_head(buf, 3, sb);
-        chain_head(q0, 2, sa, sum, full_c);
-        chain_head(q0, 3, sb, sum, full_c);
+#pragma unroll
+        for (int e = 0; e < 16; e++) sa[e] = sb[e] = 0.f;
+        uint4 fr = frag(buf, 0);
+        // head 0's products, bare (reads one ahead)
+#pragma unroll
+        for (int ds = 0; ds < 8; ds++) {
+          const uint4 nx = frag(buf, ds + 1);
+          sa = MfmaOps<T>::mma(kf[ds], fr, sa);
+          fr = nx;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // stages: products of head r + 1 woven with the chain of head r
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+#pragma unroll
+          for (int ds = 0; ds < 8; ds++) {
+            const uint4 nx = frag(buf, (r + 1) * 8 + ds + 1);  // (the last one re-reads fragment 0: harmless, keeps the slices alike)
+            if ((r & 1) == 0) {
+              sb = MfmaOps<T>::mma(kf[ds], fr, ds == 0 ? f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f} : sb);
+              chain_pair(q0, r, 2 * ds, sa, sum, full_c);
+            } else {
+              sa = MfmaOps<T>::mma(kf[ds], fr, ds == 0 ? f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f} : sa);
+              chain_pair(q0, r, 2 * ds, sb, sum, full_c);
+            }
+            fr = nx;
+            // (the slice's results are pinned HERE: pure VALU work carries no ordering against the fence and was otherwise sunk
+            //  below all of them — the slices then held a read, a wait and an MFMA each, and the chains ran behind the lot)
+            asm volatile("" : "+v"(sum[2 * ds]), "+v"(sum[2 * ds + 1]));
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+#pragma unroll
+        for (int ds = 0; ds < 8; ds++) chain_pair(q0, 3, 2 * ds, sb, sum, full_c);
         float obs_f = 0.f;
         if constexpr (OBS) obs_f = (query >= L - a.obs_len && query < L) ? 1.f : 0.f;
         // a band plane takes the tile whole, not at all, or element by element (only the tiles the band's edge crosses)
@@ -844,7 +858,6 @@ __global__ __launch_bounds__(256, 2) void prefill_colsum_kstat_kernel(MArgs a, i
             }
           }
         }
-        weave();
         (void)FULL;
       };
       int buf = 0;
