@@ -269,10 +269,13 @@ def test_hand_off_wait_is_bounded_by_device_time():
     host = torch.zeros(n_watch, dtype=torch.int32).pin_memory()
     watchers = [torch.cuda.Stream() for _ in range(n_watch)]
     scratch = torch.zeros(64, dtype=torch.int32, device=DEV)
-    p2 = torch.tensor([T + 1], dtype=torch.int32, device=DEV)
     flipped_ms = None
     try:
         for attempt in range(6):  # (a side stream that shares the decode stream's hardware queue runs BEHIND the step: try the next)
+            # (a NEW position per attempt: an attempt whose co-tenant ran behind the step has committed its position — how this test
+            #  failed inside the suite and passed alone)
+            p_fail = T + 1 + attempt
+            p2 = torch.tensor([p_fail], dtype=torch.int32, device=DEV)
             side = torch.cuda.Stream()
             rc = fns["cc_debug_occupy"](232, 150 * 1024, int(10 * bound_ms * 1000), C.c_void_p(scratch.data_ptr()), C.c_void_p(side.cuda_stream))
             assert rc == 0
@@ -300,14 +303,14 @@ def test_hand_off_wait_is_bounded_by_device_time():
         assert single_launch_status(kv.pos.device) != 0, "the co-tenant did not provoke a hand-off timeout in six attempts: nothing was tested"
         assert flipped_ms is not None, "the status word was not seen set while the co-tenant was still there"
         assert 0.5 * bound_ms <= flipped_ms <= 4.0 * bound_ms, f"the step gave up after {flipped_ms:.1f} ms against a bound of {bound_ms:.0f} ms"
-        assert not step_committed(kv, T + 1)
+        assert not step_committed(kv, p_fail)
     finally:
         torch.cuda.synchronize()
         reset_single_launch_status(kv.pos.device)
         fns["cc_decode_step_demote_l2_handoff"](0)
     kv.decode_step(q, k1, k1, p2)  # the retry, alone on the device
     torch.cuda.synchronize()
-    assert step_committed(kv, T + 1) and single_launch_status(kv.pos.device) == 0
+    assert step_committed(kv, p_fail) and single_launch_status(kv.pos.device) == 0
 
 
 @pytest.mark.parametrize("fuse_qkv", [False, True])  # (r5) True: the decode loop on the QKV form of the step — the retry recomputes the projection too
