@@ -58,6 +58,11 @@
                           // in assembly, which the compiler's wait-count pass does not see — and waited for once, behind the K request:
                           // the round trip runs in the shadow of the prologue instead of behind it (0: requested behind the K request)
 #endif
+#ifndef CC_V_ORDER
+#define CC_V_ORDER 0    // r6 A/B (with PRELOAD + LATE + EARLYARGS, plain 16-bit steps): 1 = the step's SMALL requests first — words, key row, per-slot
+                        // state, q — and the bulk (K rows, mask word, V rows) behind them, all within the first ~150 instructions: nothing
+                        // the scores need queues behind 8 MB of rows, and the V rows leave ~0.4 us earlier than in the product's order
+#endif
 #ifndef CC_V_VEARLY
 #define CC_V_VEARLY 0   // r6 A/B: the V rows requested right behind the K rows (1: the steps without the XL2 placement — few-head ranks, whose
                         // caches are latency-bound, not bandwidth-bound; 2: every LDS-DMA step).  At C3 this order lost 0.4 us (r4).
@@ -812,6 +817,7 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
   // of the block in one round of scalar loads through a laundered kernarg pointer (late_phase below): one round trip, in the shadow
   // of the K rows.
   constexpr bool LATE = CC_V_PRELOAD != 0 && CC_V_LATE != 0 && CC_V_LDSDMA != 0 && ONE && NT == 1 && QB == 0 && !HYB && !QKV;
+  constexpr bool SMALLFIRST = LATE && CC_V_EARLYARGS != 0 && CC_V_ORDER != 0 && !L2;
   SplitArgs a{};
   if constexpr (!LATE) a = a_in;
 #if CC_V_PRELOAD
@@ -1183,7 +1189,7 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
       issue_k_dma(base);
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (LATE && FULL) tr_kreq = __builtin_amdgcn_s_memtime();  // (the trace's "K requested": the block's trace pointer arrives with phase 1, behind it)
-      if constexpr (LATE) late_phase();  // (single tile: this is the step's one K request)
+      if constexpr (LATE && !SMALLFIRST) late_phase();  // (single tile: this is the step's one K request)
     } else
     if constexpr (KFIRST) {
       issue_k_rows(R, base);
@@ -1233,7 +1239,7 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
   // (several tiles per wave — hybrid included: the first tile's K rows likewise; C4 hybrid at S = 18432 25.8 -> 25.1 us and
   //  17.15 -> 16.7 at S = 9000 on two boxes, unchanged on a third; heavy hitter unchanged: its stream is bandwidth-bound.  NOT the
   //  hybrid cache's single-tile step: 11.1 -> 11.6 us at S = 4096 with it — its decision operands want to be ahead of the rows)
-  constexpr bool KEARLY = ONE && QB == 0 && !(HYB && NT == 1);
+  constexpr bool KEARLY = ONE && QB == 0 && !(HYB && NT == 1) && !SMALLFIRST;
 #endif
   unsigned one_tag = 0;
   int32_t one_pin = 0;
@@ -1416,6 +1422,9 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
     }
     qstamp(1);
   }
+  // SMALLFIRST: the rest of the argument block (requested at the kernel's first instruction) is taken HERE, behind the key row's
+  // requests; the per-slot state, q, the K rows, the mask word and the V rows follow in program order below
+  if constexpr (SMALLFIRST) late_phase();
   constexpr bool VEARLY = DMA && !QKV && (CC_V_VEARLY == 2 || (CC_V_VEARLY == 1 && !XL2));
   if constexpr (KEARLY && !QKV) {  // (QKV: the tile is requested behind the projection's last weight rows, below)
     issue_k(tregs[0], base);
