@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--graph", action="store_true", help="force hipGraph replay (default: time both on a few untimed tokens, keep the faster)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_long_window", action="store_true", help="skip the extra 128-token window behind the timed region (value_128_steps)")
+    ap.add_argument("--settle", type=int, default=160,
+                    help="untimed decode tokens AHEAD of the --warmup steps: the device reaches its steady clocks (r6: the first ~200 tokens "
+                         "behind a prefill run 1.5 %% slower than the ones behind them; reported as config.settle_tokens)")
     ap.add_argument("--roofline_iters", type=int, default=20)
     ap.add_argument("--no_live_pmc", action="store_true", help="take roofline.traffic from profiles/ instead of two rocprofv3 --pmc child runs")
     ap.add_argument("--pmc_child", action="store_true", help=argparse.SUPPRESS)  # the workload rocprofv3 is wrapped around
@@ -817,6 +820,10 @@ def main():
         def run(n):
             run_with(dec, n)
 
+        # untimed: clocks settle (see --settle), clamped so the whole run stays inside the 2048 decode positions the caches were
+        # built for; then the W warm-up steps the caller asked for
+        args.settle = max(0, min(args.settle, 2048 - (1 + 60 + args.warmup + args.steps + 128 + 8)))
+        run(args.settle)
         run(args.warmup)
         if world > 1:
             dist.barrier()
@@ -911,7 +918,7 @@ def main():
                        "collective_backend": ("none" if world == 1 else dist.get_backend()),
                        "decode_allreduce": ("none" if world == 1 else ("one-shot xGMI (cc_allreduce_sum), verified against RCCL at start-up"
                                                                        if oneshot else dist.get_backend())),
-                       "per_rank": per_rank, "decode_mode": mode, "n_layer": args.n_layer,
+                       "per_rank": per_rank, "decode_mode": mode, "n_layer": args.n_layer, "settle_tokens": args.settle,
                        "prefill_seconds": round(prefill_s, 2), "device_state_after_timed_region": dev_state},
             "roofline": roof, "cpu_baseline": cpu,
             # the parity contract the numbers above were checked under (tests/, __graft_entry__.smoke): the BUILD's statement of the

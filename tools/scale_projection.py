@@ -51,7 +51,7 @@ def main():
             row["measured_tokens_per_s"] = bench["value"]
         rows.append(row)
     print(json.dumps({"WHAT_THIS_IS": "a PROJECTION from one-GPU measurements and stated assumptions — no multi-GPU run has happened (no 2-GPU or "
-                                      "8-GPU box was available in rounds 1-4); nothing here is a result",
+                                      "8-GPU box was available to the builder in any round; the driver runs the N = 1, 2, 4, 8 bench itself); nothing here is a result",
                       "workload": bench["config"]["workload"], "scaling": "strong (TP = N, the same token stream)",
                       "measured_inputs": {"one_gpu_ms_per_token": bench["ms_per_step"], "one_gpu_tokens_per_s": bench["value"],
                                           "layer_step_us_by_kv_heads_per_rank": step_us, "weight_bytes": w_bytes},
