@@ -86,7 +86,7 @@ __global__ __launch_bounds__(kCombThreads) void decode_attn_combine_kernel(Combi
   // at ~0 — written HERE, at the start (their readers, the streaming pass, are done), so that these stores drain during the
   // launch instead of adding a store round trip behind its last instruction
   if (a.next_key && !(a.abl & 8) && threadIdx.x >= 1 && threadIdx.x < kNextKeyPerChunk)
-    a.next_key[(size_t)h * (kNextKeyPerChunk * nchunks) + threadIdx.x * nchunks + c] = ~0ull;
+    a.next_key[(size_t)h * (kNextKeyPerChunk * nchunks + kNextKeyTail) + threadIdx.x * nchunks + c] = ~0ull;
   // ---- issue this thread's per-slot loads first: their latency overlaps the (M, L) reduction below
   const T* sc = reinterpret_cast<const T*>(a.scores);
   const int s_mine = c * a.chunk + threadIdx.x;
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(kCombThreads) void decode_attn_combine_kernel(Combi
     // (a head's key row has kNextKeyPerChunk * nchunks entries — one per wave of the single-launch step's 64-slot workgroups;
     //  all but the first nchunks stay ~0 here)
     {
-      unsigned long long* row = a.next_key + (size_t)h * (kNextKeyPerChunk * nchunks);
+      unsigned long long* row = a.next_key + (size_t)h * (kNextKeyPerChunk * nchunks + kNextKeyTail);  // (the row stride: cc_next_key_slots)
       row[c] = bk;
     }
   }
@@ -1049,7 +1049,8 @@ static int attn_impl(const void* q, const void* k, const void* v, const uint8_t*
     sa.next_key = fs->next_key; sa.nk = cc_next_key_slots(S);
     // entries any writer may have left non-~0: one per combine block (two-launch step), one per wave of the single-launch workgroups
     sa.nk_read = one_shape_ok(p, HQ, H, D, dtype) ? (p.n_split * p.nw > p.n_chunks ? p.n_split * p.nw : p.n_chunks) : p.n_chunks;
-    if (sa.nk_read > sa.nk) sa.nk_read = sa.nk; sa.input_pos = fs->input_pos; sa.k_new = fs->k_new; sa.v_new = fs->v_new;
+    if (sa.nk_read > cc_next_key_live(S)) sa.nk_read = cc_next_key_live(S);
+    sa.input_pos = fs->input_pos; sa.k_new = fs->k_new; sa.v_new = fs->v_new;
     sa.pos = fs->c->pos; sa.mask_w = fs->c->mask; sa.cache_cts = fs->c->cache_cts; sa.num = hh_num; sa.denom = hh_denom;
     sa.H = H; sa.Hc = fs->c->Hc; sa.Hp = fs->c->Hp;
     sa.commit = fs->commit;
@@ -1165,6 +1166,10 @@ static int attn_impl(const void* q, const void* k, const void* v, const uint8_t*
     default: hipLaunchKernelGGL(decode_attn_combine_kernel<f16_t>, grid, block, lds, st, ca); break;
   }
   CC_LAUNCH_CHECK();
+  // l2: the norm record the NEXT step's single-launch form starts from (cc_common.h, cc_l2_record) — the single-launch step leaves
+  // it itself; behind the two launches a third, small one does (this is the slow route already)
+  if (fs && fs->policy == 4 && fs->next_key)
+    return cc_l2_record_launch(sa.key_norm, H, S, dtype, fs->input_pos, 0, fs->next_key, st);
   return CC_OK;
 }
 

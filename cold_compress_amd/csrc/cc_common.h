@@ -158,7 +158,21 @@ __host__ __device__ static inline float cc_rng_uniform(uint64_t seed, int32_t po
 // (2 workgroups x 4 waves per chunk), so that its waves never wait for each other at the end of the launch.
 constexpr int kNextKeyChunk = 128;
 constexpr int kNextKeyPerChunk = 8;
-static inline int cc_next_key_slots(int S) { return kNextKeyPerChunk * ((S + kNextKeyChunk - 1) / kNextKeyChunk); }
+// r6: behind the live entries every row carries kNextKeyTail more that no arg-min ever reads — per-head state a policy's step hands
+// to the NEXT step of the same cache.  l2: entries [live + 0], [live + 1] = the head's norm record of an even / odd position (below).
+constexpr int kNextKeyTail = 8;
+static inline int cc_next_key_live(int S) { return kNextKeyPerChunk * ((S + kNextKeyChunk - 1) / kNextKeyChunk); }
+static inline int cc_next_key_slots(int S) { return cc_next_key_live(S) + kNextKeyTail; }  // the row stride
+// The l2 policy's carried norm record of kv head h, written by the step of position p into row entry [live + (p & 1)]: the two
+// largest norms of the head AFTER p's insert (T1 >= T2, as multiset: two slots holding the maximum give T1 == T2) and a slot i1
+// that holds T1 — model-dtype bit patterns (norms are >= +0 or NaN: unsigned order == numeric order, NaN above everything, which
+// is torch.max's propagation).  The step of p + 1 evicts ONE slot e of the head: the head's maximum over the slots it keeps is
+// (i1 == e ? T2 : T1), and with the inserted norm that is the head's term of cache.py:602's maximum — no reduction over the head.
+int cc_l2_record_launch(const void* key_norm, int H, int S, int dtype, const int32_t* input_pos, int delta, unsigned long long* next_key,
+                        hipStream_t st);  // cc_evict.hip: the record of position *input_pos + delta from the norms as they stand
+__host__ __device__ static inline unsigned long long cc_l2_record(unsigned t1, unsigned t2, unsigned i1) {
+  return (unsigned long long)(t1 & 0xffffu) | ((unsigned long long)(t2 & 0xffffu) << 16) | ((unsigned long long)i1 << 32);
+}
 
 __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
 #pragma unroll

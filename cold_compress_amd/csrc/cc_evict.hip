@@ -123,6 +123,32 @@ __global__ __launch_bounds__(kUpdThreads) void l2_norm_max_kernel(const void* ke
   if (threadIdx.x == 0) *out = m;
 }
 
+// The l2 step's carried norm record (cc_common.h, cc_l2_record) of every kv head from the norms as they stand — what the seed of the
+// pipeline and the two-launch step leave for the next single-launch step.  One workgroup per kv head; 16-bit norms, read as patterns.
+__global__ __launch_bounds__(kUpdThreads) void l2_record_kernel(const uint16_t* key_norm, int S, const int32_t* input_pos, int delta,
+                                                                unsigned long long* next_key, int nk) {
+  __shared__ unsigned long long sm_key[kUpdThreads / 64 + 2];
+  const int h = blockIdx.x;
+  const uint16_t* kn = key_norm + (size_t)h * S;
+  unsigned long long k1 = 0;  // (pattern << 32 | slot) of this thread's largest norm; t2: the pattern of its second largest
+  unsigned t2 = 0;
+  for (int s = threadIdx.x; s < S; s += kUpdThreads) {
+    const unsigned long long key = ((unsigned long long)kn[s] << 32) | (unsigned)s;
+    if (key > k1) {
+      t2 = (unsigned)(k1 >> 32);
+      k1 = key;
+    } else if ((unsigned)(key >> 32) > t2) {
+      t2 = (unsigned)(key >> 32);
+    }
+  }
+  const unsigned long long K1 = ~block_min_u64(~k1, sm_key);
+  __syncthreads();  // (sm_key is reused)
+  const unsigned long long x = (k1 == K1) ? (unsigned long long)t2 : (k1 >> 32);
+  const unsigned long long T2 = ~block_min_u64(~x, sm_key);
+  if (threadIdx.x == 0)
+    next_key[(size_t)h * nk + (nk - kNextKeyTail) + ((*input_pos + delta) & 1)] = cc_l2_record((unsigned)(K1 >> 32), (unsigned)T2, (unsigned)(K1 & 0xffffffffull));
+}
+
 template <int POLICY, typename T, typename ST>
 __global__ __launch_bounds__(kUpdThreads) void decode_update_kernel(UpdArgs a) {
   __shared__ unsigned long long sm_key[kUpdThreads / 64 + 2];
@@ -210,7 +236,7 @@ __global__ __launch_bounds__(kUpdThreads) void decode_update_kernel(UpdArgs a) {
     // (head-constant policies — one workgroup — fill every kv head's copy of the row: each head reads and rewrites its own,
     //  cc_attn_decode.hip KEY ROWS)
     for (int hh = h0; hh < h0 + nh; hh++)
-      for (int i = threadIdx.x; i < a.nk; i += blockDim.x) a.key_out[(size_t)hh * a.nk + i] = (i == 0) ? best : ~0ull;
+      for (int i = threadIdx.x; i < a.nk - kNextKeyTail; i += blockDim.x) a.key_out[(size_t)hh * a.nk + i] = (i == 0) ? best : ~0ull;  // (the live entries)
     return;
   }
   if (threadIdx.x == 0) a.idx_out[hp] = idx;
@@ -322,6 +348,16 @@ __global__ __launch_bounds__(256) void row_l2_norm_kernel(const T* x, int rows, 
 
 }  // namespace
 
+// (shared with cc_attn_decode.hip: the two-launch l2 step leaves the record of ITS position the same way; declared in cc_common.h)
+int cc_l2_record_launch(const void* key_norm, int H, int S, int dtype, const int32_t* input_pos, int delta, unsigned long long* next_key,
+                        hipStream_t st) {
+  if (cc_dt_size(dtype) != 2) return CC_OK;  // (the single-launch l2 step serves 16-bit caches only: nobody reads a record of another)
+  hipLaunchKernelGGL(l2_record_kernel, dim3(H), dim3(kUpdThreads), 0, st, reinterpret_cast<const uint16_t*>(key_norm), S, input_pos, delta,
+                     next_key, cc_next_key_slots(S));
+  CC_LAUNCH_CHECK();
+  return CC_OK;
+}
+
 extern "C" {
 
 int cc_decode_update_full(const cc_kv_view* c, const void* k_new, const void* v_new, const int32_t* input_pos,
@@ -409,7 +445,10 @@ int cc_l2_next_key_init(const cc_kv_view* c, const int32_t* input_pos, void* key
   a.key_norm = key_norm;
   a.key_out = reinterpret_cast<unsigned long long*>(next_key);
   a.nk = cc_next_key_slots(c->S);
-  return launch_update<P_L2>(c, a, (hipStream_t)stream);
+  const int rc = launch_update<P_L2>(c, a, (hipStream_t)stream);
+  if (rc != CC_OK) return rc;
+  // the norm record the first step (position *input_pos) takes its head's maximum from: the state behind position *input_pos - 1
+  return cc_l2_record_launch(key_norm, c->H, c->S, c->dtype, input_pos, -1, reinterpret_cast<unsigned long long*>(next_key), (hipStream_t)stream);
 }
 
 int cc_decode_update_heavy_hitter(const cc_kv_view* c, const void* k_new, const void* v_new,

@@ -592,6 +592,74 @@ def test_l2_fused_step_equals_three_calls(dtype, H, HQ, S, D, T, g, w, single, s
                 assert torch.equal(ta, tb), f"step {t}: {na}"
 
 
+@pytest.mark.parametrize("H,HQ,S,T", [(8, 32, 4096, 4093), (2, 8, 600, 600), (8, 32, 1024, 1000)])
+def test_l2_carried_norm_record_across_step_forms(H, HQ, S, T, single_launch_switch):
+    """r6: the single-launch l2 step takes its head's norm maximum from the RECORD the previous step left in the key
+    row's tail (the head's two largest norms and a holder) instead of reducing the head's norms inside the launch.  Every writer of that
+    record is exercised against the three-call path (update_kv -> attention), every buffer bit for bit: the pipeline's seed, the
+    single-launch step, the two-launch step (a third small launch), in every alternation; with the cases the record exists for —
+    the holder of the maximum evicted (most steps), the holder PROTECTED by the recent window (a huge key: the maximum stays, another
+    slot goes), two slots holding the same maximum (T1 == T2: the same key inserted twice), the maximum in one head only, a NaN key
+    (torch.max propagates it: every score NaN), and a re-seed in the middle (update_kv invalidates the pipeline)."""
+    import cold_compress_amd.cache as cache
+    from cold_compress_amd.attention_utils import scaled_dot_product_attention as sdpa
+
+    D, dtype, g, w = 128, torch.bfloat16, 4, 6
+    cls, rk = cache.get_cache_constructor("l2")
+    kw = dict(max_cache_length=S, global_tokens=g, recent_window=w, max_seq_length=4 * S, cache_bits=None)
+
+    def mk():
+        with torch.device(DEV):
+            return cls(1, H, D, dtype, **{k: kw[k] for k in rk})
+
+    a, b = mk(), mk()
+    gen = torch.Generator().manual_seed(29)
+    k0 = (torch.randn(1, H, T, D, generator=gen) * torch.rand(1, H, T, 1, generator=gen)).to(dtype).to(DEV)
+    v0 = torch.randn(1, H, T, D, generator=gen).to(dtype).to(DEV)
+    for kv in (a, b):
+        kv.update_kv(torch.arange(T, device=DEV), k0, v0, True)
+        kv.update_state(torch.arange(T, device=DEV), k0, v0, True, None)
+    forms = [True, True, False, True, False, False, True, True, True, False, True, True]  # single launch?
+    n_steps = 40
+    k_dup = None
+    for t in range(n_steps):
+        p = torch.tensor([T + t], dtype=torch.int32, device=DEV)
+        k1 = torch.randn(1, H, 1, D, generator=gen)
+        if t == 4:
+            k1 = k1 * 6.0           # the global maximum, protected by the recent window for the next w steps
+        if t == 9:
+            k1[:, 1:] *= 0.05       # ... a maximum in kv head 0 only
+            k1[:, 0] *= 5.0
+        if t == 14:
+            k_dup = k1.clone() * 4.0
+        if t in (14, 15):
+            k1 = k_dup.clone()      # two slots of every head hold the same (largest) norm
+        if t == 30:
+            k1[0, H - 1, 0, 3] = float("nan")
+        k1 = k1.to(dtype).to(DEV)
+        v1 = torch.randn(1, H, 1, D, generator=gen).to(dtype).to(DEV)
+        q = torch.randn(1, HQ, 1, D, generator=gen).to(dtype).to(DEV)
+        ka, va, ma = a.update_kv(p, k1, v1, False)
+        ya, _ = sdpa(q, ka, va, attn_mask=ma)
+        if t == 22:  # the three-call path on b too: its pipeline is invalid afterwards and must be seeded again (record included)
+            kb, vb, mb = b.update_kv(p, k1, v1, False)
+            yb, _ = sdpa(q, kb, vb, attn_mask=mb)
+            single = False
+        else:
+            single = forms[t % len(forms)]
+            single_launch_switch(single)
+            yb = b.decode_step(q, k1, v1, p)
+        torch.cuda.synchronize()
+        if t < 30:  # (behind the NaN key the outputs of the head that holds it are NaN on both sides)
+            _y_check(ya, yb, single, t)
+        for (na, ta), (nb, tb) in zip(a.named_buffers(), b.named_buffers()):
+            if na not in ("next_key", "step_commit"):  # (pipeline bookkeeping of the fused step, not reference state)
+                assert torch.equal(ta.view(torch.int16) if ta.dtype == dtype else ta, tb.view(torch.int16) if tb.dtype == dtype else tb), f"step {t} ({'one' if single else 'two'} launch): {na}"
+    from cold_compress_amd.attention_utils import single_launch_status
+
+    assert single_launch_status() == 0
+
+
 def test_l2_fused_step_vs_oracle():
     """The same step through the C ABI against the oracle's twin: slots, norms, K/V and the attention output."""
     import ctypes as C

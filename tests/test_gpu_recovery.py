@@ -176,6 +176,7 @@ def test_a_strict_subset_of_a_heads_workgroups_committed(strategy, S, NW, splits
     selk = torch.zeros(after["next_key"].shape[1], dtype=torch.bool, device=DEV)
     for sp in splits:
         selk[sp * NW:(sp + 1) * NW] = True
+    selk[-8:] = 0 in splits  # the row's tail (r6; l2: the head's carried norm record) is committed by the head's first workgroup
     for n, b in kv.named_buffers():
         bi, af = before[n], after[n]
         b.copy_(af)  # what went in ahead of the hand-off, and everything of the fully committed heads
