@@ -75,11 +75,9 @@
 #error "the virtual-head placement takes its head counts from the preloaded arguments"
 #endif
 #ifndef CC_V_L2CARRY
-#define CC_V_L2CARRY 0  // r6: the l2 single-launch step takes its head's norm maximum from a RECORD the previous step left (the
-                        // head's two largest norms and a holder: cc_common.h, cc_l2_record) instead of reducing the head's norms inside the
-                        // launch — the head's term of cache.py:602's maximum leaves one workgroup ~1 us into the launch, the cross-head
-                        // gather rides the (m, l) round, and the next-eviction keys move from the tail into the partial-O shadow.
-                        // 0 = the r4 / r5 exchange (one level through memory, or two levels with the XL2 placement).
+#define CC_V_L2CARRY 0  // r6: the l2 single-launch step carries each head's norm maximum across steps (a resolved RECORD in the
+                        // key row's tail: cc_common.h, cc_l2_record) — no reduction over the head's norms and NO cross-head hand-off inside
+                        // the launch; see L2C in the kernel.  0 = the r4 / r5 exchange (one level through memory, or two with XL2).
 #endif
 #ifndef CC_V_MLW
 #define CC_V_MLW 1      // the final (M, L) fold runs on the workgroup's LAST waves (idle during the partial-O publish of the first ones)
@@ -715,7 +713,7 @@ constexpr int kRcStride = 68;                  // step_commit: int32 per kv head
 // its own, and the two heads' epochs need not be equal once launches with fewer heads have run).
 constexpr int kOneMlHead = 64 * 8 * 16;        // (m, l): 64 splits x up to 8 query heads x 16 B
 constexpr int kOneOHead = 8 * 64 * 64 * 16;    // O: up to 8 query heads x 64 splits x 64 pairs x 16 B
-constexpr int kOneNmHead = 64 * 16;            // l2: one norm-maximum granule per split
+constexpr int kOneNmHead = 64 * 32;            // l2: one norm-maximum granule per split (r4 / r5 exchange), or two record granules per split (r6, L2C)
 constexpr int kOneHmBytes = 32 * 32 * 16;      // l2: norm-maximum granules per kv HEAD, behind the per-split regions.  Two-level exchange (r4): one per
                                                // head, [src]; carried record (r6): [dest head][src head] at a row stride of kOneMaxHeads granules — the
                                                // publisher of head `src` tags the granule of `dest` with DEST's epoch (see L2C in the kernel)
@@ -921,19 +919,24 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
   // per kv head through memory (published by the head's split-0 workgroup, gathered by one wave per workgroup in the shadow of the
   // partial-O exchange) — instead of every thread of every workgroup gathering all H x n_split maxima through memory ahead of the
   // final (M, L).  max is associative: the same value, hence the same keys, bit for bit.
-  // L2C (r6): the carried norm record — see CC_V_L2CARRY.  Every single-launch l2 step (with or without the XL2 placement).
-  //   start   every wave requests the head's two record entries (key row tail) with the key row; once the eviction slot e is known,
-  //           wave 0 of the head's split-0 workgroup computes the new key's norm (the inserting row group's arithmetic, bit for bit; its
-  //           operands were requested ahead of the tile) and publishes  M_h = max(i1 == e ? T2 : T1, norm)  as H granules through
-  //           memory — the granule for kv head `dest` tagged with DEST's epoch (read in the prologue: `dest` cannot complete its step,
-  //           hence bump its epoch, before this granule exists; a gatherer compares against its OWN head's tag, which no late start
-  //           can see bumped — the r4 form, in which gatherers read the OTHER heads' epochs, relied on every head waiting for every
-  //           workgroup of every other head, which no longer holds);
-  //   (m, l)  the workgroups' top-2 norms of their slots AFTER the insert leave with the pairs (one granule per workgroup); the last
-  //           wave of every workgroup gathers the H head maxima with the (m, l) round -> sm_gmax -> the keys are scored in the shadow of
-  //           the partial-O exchange like every other policy's;
-  //   tail    the last wave of the head's split-0 workgroup gathers the workgroups' top-2 with the partial-O round, folds them and
-  //           stores the record of THIS position (entry [live + (p & 1)]: a retry of p still finds p - 1's) with the step's commit.
+  // L2C (r6): the carried norm record — see CC_V_L2CARRY.  cache.py:602 takes the maximum of the norms over ALL kv heads and slots; the
+  // step of position p leaves, per kv head, the maximum over the slots the head KEEPS at p + 1 (everything but the slot p + 1 evicts:
+  // that slot is the arg-min of the keys this very step scores) in the head's key row tail.  The step of p + 1 then needs no reduction
+  // over norms and no hand-off between heads, and — the l2 keys depend on nothing the attention computes — the workgroup's LAST wave
+  // does the policy's whole per-slot pass alone, between its scores and its P.V products (the V rows are still landing):
+  //   loads   (that wave only, between the K and the V rows) the new keys of all kv heads, the heads' records, position and norm of
+  //           every slot of the workgroup;
+  //   fold    the new keys' norms (the inserting row group's arithmetic, bit for bit: four heads per pass, one per row group) ->
+  //           max over heads of max(record, new norm) = the maximum at this position; the keys of the workgroup's slots, their
+  //           minimum, the slots' two largest norms after the insert (with a holder) -> two granules inside the head's XCD; the
+  //           minimum key goes to the wave's entry of the key row with the step's commit (the other waves' entries stay ~0);
+  //   record  the last wave of the head's split-0 workgroup gathers the workgroups' granules with the partial-O round (they left a
+  //           whole streaming phase earlier), finds the slot position p + 2 will evict, resolves the head's maximum without it and
+  //           stores the record of THIS position with the step's commit (entry [live + (p & 1)]: a retry of p still finds p - 1's in
+  //           the other entry).
+  // Nothing of the r4 / r5 exchange is left in the launch: no norm maxima with the (m, l) pairs, no level-one / level-two gathers, no
+  // per-slot pass in the tail, no per-slot state in the other waves.  Seeds and two-launch steps leave the same record through
+  // l2_record_kernel (cc_evict.hip).
   constexpr bool L2C = L2 && EML && CC_V_L2CARRY != 0;
   constexpr bool L2X = L2 && XL2 && EML && !L2C;
   static_assert(sizeof(T) == 2 && (RT == 1 || RT == 2 || RT == 4 || RT == 8), "16-bit caches, up to 8 query heads per pass (the MFMA has 16 columns)");
@@ -962,7 +965,7 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
   __shared__ __attribute__((aligned(16))) float sm_l2w[NW];  // ONE + L2: per-wave maxima of the norms this workgroup's slots hold AFTER the step's insert
   __shared__ __attribute__((aligned(16))) T sm_l2sc[L2 ? NW : 1][L2 ? 128 : 8];  // l2: the new key, transposed for its norm (the slabs belong to the DMA loads)
   __shared__ float sm_gmax;     // L2X / L2C: the norm maximum over all kv heads (NaN propagates)
-  __shared__ __attribute__((aligned(16))) float sm_l2t[3][NW];  // L2C: per-wave top-2 of the norms (bit patterns): [0] T1, [1] its slot, [2] T2
+  __shared__ __attribute__((aligned(16))) T sm_l2c4[L2C ? 4 : 1][L2C ? 128 : 8];  // L2C: four new keys, transposed for their norms (one per row group of the workgroup's last wave)
   // QKV: the projection's partial sums [K quarter][row of this workgroup's share], the RMSNorm partials, and the head's gathered
   // q (RT heads), k_new, v_new
   constexpr int QNU = (RT + 2) * 32;  // granule units (4 projection rows each) per kv head
@@ -1265,7 +1268,6 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
   //  hybrid cache's single-tile step: 11.1 -> 11.6 us at S = 4096 with it — its decision operands want to be ahead of the rows)
   constexpr bool KEARLY = ONE && QB == 0 && !(HYB && NT == 1) && !SMALLFIRST;
 #endif
-  unsigned long long l2_rec[2] = {0ull, 0ull};  // L2C: the head's norm records (cc_l2_record) of the two positions before this one
   unsigned one_tag = 0;
   int32_t one_pin = 0;
   unsigned rc_status = 0;    // EML: the workspace's status word (a step failed since the host last looked: do nothing)
@@ -1336,18 +1338,6 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
 #endif
   }
 #endif
-  // L2C: the head's publisher (wave 0 of its split-0 workgroup) requests what its granules need — the new key's chunk of this lane's
-  // column group, the kv heads' epoch words — as the FIRST vector loads of the wave: loads return in order, and behind the K rows
-  // they would be usable only when the tile has landed (~3 us; the whole point is to publish at ~1 us).  A branch around loads is
-  // harmless HERE only: they are the oldest loads in flight, so no later in-order wait count depends on whether they were issued.
-  uint4 l2_pub_kn = make_uint4(0, 0, 0, 0);
-  unsigned l2_pub_ep = 0;
-  if constexpr (L2C) {
-    if (split == 0 && wave == 0 && a.k_new != nullptr) {
-      l2_pub_kn = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(a.k_new) + (size_t)h * D + c * VEC);
-      l2_pub_ep = a.one_hdr[lane < a.H ? lane : 0];
-    }
-  }
   if (key_pending) {
     // KEY ROWS (late r3).  Every kv head reads — and at the end of the step rewrites — ITS OWN row, also under the head-constant
     // policies, whose rows all hold the same keys.  They used to share row 0, rewritten by kv head 0's waves once THEIR head's
@@ -1375,11 +1365,6 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
     for (int i = lane + 256; i < a.nk_read; i += 64) {
       const unsigned long long x = a.next_key[(size_t)h * a.nk + i];
       key_part = x < key_part ? x : key_part;
-    }
-    if constexpr (L2C) {  // the head's norm records of the even / odd position before this one (the row's tail: never part of the arg-min)
-      const unsigned long long* rt2 = krow + (a.nk - kNextKeyTail);
-      l2_rec[0] = rt2[0];
-      l2_rec[1] = rt2[1];
     }
   }
 #if !CC_V_WORDSFIRST
@@ -1627,7 +1612,7 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
     // single tile: requested AHEAD of the K/V tile (measured: behind it the step is 0.3 us slower — the tile's in-order waits
     // then end on these stragglers, and the workgroup leaves the streaming part later); several tiles: requested after the
     // publish, in the shadow of the hand-off
-    if constexpr (NT == 1 && !HYB) {
+    if constexpr (NT == 1 && !HYB && !L2C) {  // (L2C: the workgroup's last wave reads the state of ALL its slots, between the K and the V rows)
       load_slot_state();
       if constexpr (L2)  // (unconditional: lanes without a slot read a valid neighbour and ignore it)
         one_kn_raw = reinterpret_cast<const uint16_t*>(a.key_norm)[(size_t)h * S + (one_have ? one_slot : row_begin)];
@@ -1685,6 +1670,36 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
     qB[j].raw = make_uint4(0, 0, 0, 0);
     if constexpr (!QKV) {
       if (c < RT) qB[j].load(reinterpret_cast<const T*>(a.q) + (size_t)(q0 + c) * D + (4 * j + g) * VEC);
+    }
+  }
+  // L2C: what the workgroup's last wave needs for the policy's per-slot pass — see L2C above.  A wave-uniform branch around loads:
+  // harmless HERE (between the K and the V rows), where the only older loads anybody waits for are the K tile and the small ones in
+  // front of it — an in-order wait that does not count these loads merely lets a few of the small ones land first.
+  constexpr int L2S = L2C ? NW / 4 : 1;  // slots per lane: the workgroup holds NW * 16
+  uint4 l2c_kn[2];
+  ulonglong2 l2c_rc = make_ulonglong2(0ull, 0ull);
+  int32_t l2c_ps[L2S];
+  uint16_t l2c_nr[L2S];
+  l2c_kn[0] = l2c_kn[1] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+  for (int k = 0; k < L2S; k++) {
+    l2c_ps[k] = 0;
+    l2c_nr[k] = 0;
+  }
+  if constexpr (L2C) {
+    if (wave == NW - 1) {
+#pragma unroll
+      for (int j = 0; j < 2; j++) {  // heads 4 j + row group (heads past the count re-read this head's: valid, ignored)
+        const int hj = 4 * j + g < a.H ? 4 * j + g : h;
+        l2c_kn[j] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(a.k_new) + (size_t)hj * D + c * VEC);
+      }
+      l2c_rc = *reinterpret_cast<const ulonglong2*>(a.next_key + (size_t)(lane < a.H ? lane : h) * a.nk + (a.nk - kNextKeyTail));  // lane = kv head
+#pragma unroll
+      for (int k = 0; k < L2S; k++) {
+        const int sl = row_begin + k * 64 + lane < row_end ? row_begin + k * 64 + lane : row_end - 1;
+        l2c_ps[k] = a.pos[(size_t)h * S + sl];
+        l2c_nr[k] = reinterpret_cast<const uint16_t*>(a.key_norm)[(size_t)h * S + sl];
+      }
     }
   }
   // UNCONDITIONAL (rows past the split's end are clamped to its last row, a valid address): behind a branch, the compiler's
@@ -1978,13 +1993,6 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
     // ONE: a wave owns exactly one tile (one_shape_ok: rows_per_split == one iteration's rows) — a compile-time fact, so that the
     // next tile's address arithmetic, its loads, the loop's second body and the running-maximum rescale disappear from the code
     if (key_pending) {  // wave-uniform; first tile only
-      if constexpr (L2C) {
-        // (pinned HERE: with the record's loads in the key row's block the compiler folded these minima — and the wait for the whole
-        //  key row, a cold round trip — into that block, in FRONT of the first K rows' request: found in the ISA)
-        unsigned klo = (unsigned)(key_part & 0xffffffffull), khi = (unsigned)(key_part >> 32);
-        asm volatile("" : "+v"(klo), "+v"(khi));
-        key_part = ((unsigned long long)khi << 32) | klo;
-      }
 #pragma unroll
       for (int j = 0; j < 3; j++) key_part = key_more[j] < key_part ? key_more[j] : key_part;
       const unsigned long long key = wave_min_u64_uniform(key_part);
@@ -1999,65 +2007,6 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
           a.commit[(size_t)h * kRcStride] = ins_idx < 0 ? -1 : ((ins_idx << 1) | ins_was_empty);
           a.commit[(size_t)h * kRcStride + 1] = one_pin;
         }
-      }
-      if constexpr (L2C) {
-        // L2C, start: the head's term of cache.py:602's maximum, from the record of position p - 1 — published by wave 0 of the head's
-        // split-0 workgroup as soon as the eviction slot is known (the K / V tile is still in flight: nothing here waits for it)
-        u32x4_t hg = {0u, 0u, 0u, 0u};
-        int hg_off = 0x7ffffff0;
-        if (split == 0 && wave == 0) {  // (wave-uniform)
-          const unsigned long long rec = l2_rec[(one_pin + 1) & 1];
-          const unsigned t1 = (unsigned)(rec & 0xffffull), t2 = (unsigned)((rec >> 16) & 0xffffull), i1 = (unsigned)(rec >> 32);
-          // the new key's norm: the inserting row group's arithmetic (below), operation for operation — the transposition through
-          // this wave's scratch row is spelled in assembly with its own wait (a plain LDS access behind pending LDS-DMA loads gets a
-          // wait for THOSE from the compiler, which cannot tell the row from the slabs they write)
-          unsigned eb[8];
-          {
-            const unsigned wa = (unsigned)(uintptr_t)(__attribute__((address_space(3))) T*)&sm_l2sc[wave][0];
-            const u32x4_t kr = {l2_pub_kn.x, l2_pub_kn.y, l2_pub_kn.z, l2_pub_kn.w};
-            asm volatile(
-                "ds_write_b128 %8, %9\n\t"
-                "s_waitcnt lgkmcnt(0)\n\t"
-                "ds_read_u16 %0, %10\n\t"
-                "ds_read_u16 %1, %10 offset:32\n\t"
-                "ds_read_u16 %2, %10 offset:64\n\t"
-                "ds_read_u16 %3, %10 offset:96\n\t"
-                "ds_read_u16 %4, %10 offset:128\n\t"
-                "ds_read_u16 %5, %10 offset:160\n\t"
-                "ds_read_u16 %6, %10 offset:192\n\t"
-                "ds_read_u16 %7, %10 offset:224\n\t"
-                "s_waitcnt lgkmcnt(0)"
-                : "=&v"(eb[0]), "=&v"(eb[1]), "=&v"(eb[2]), "=&v"(eb[3]), "=&v"(eb[4]), "=&v"(eb[5]), "=&v"(eb[6]), "=&v"(eb[7])
-                : "v"(wa + (unsigned)c * 16u), "v"(kr), "v"(wa + (unsigned)c * 2u)
-                : "memory");
-          }
-          float ss = 0.f;
-#pragma unroll
-          for (int i = 0; i < D / 16; i++) {
-            T et;
-            et.x = (uint16_t)eb[i];
-            const float e = ElemTraits<T>::load(&et, 0);
-            ss = __fadd_rn(ss, __fmul_rn(e, e));
-          }
-#pragma unroll
-          for (int off = 8; off > 0; off >>= 1) ss = __fadd_rn(ss, __shfl_xor(ss, off, 16));
-          T nt;
-          ElemTraits<T>::store(&nt, 0, cc_sqrt_rn(ss));
-          unsigned m16 = (ins_idx >= 0 && i1 == (unsigned)ins_idx) ? t2 : t1;  // the head's maximum over the slots it keeps ...
-          if (ins_idx >= 0) m16 = (unsigned)nt.x > m16 ? (unsigned)nt.x : m16;  // ... and the inserted norm (patterns: unsigned order, NaN on top)
-          T mt;
-          mt.x = (uint16_t)m16;
-          const float mf = ElemTraits<T>::load(&mt, 0);
-          unsigned epv = l2_pub_ep;
-          asm volatile("" : "+v"(epv));  // (the + 1 stays HERE: folded into the branch that requests the word it waited a round trip there)
-          const unsigned dtag = epv + 1u;  // lane = destination kv head: ITS epoch's tag
-          hg = u32x4_t{dtag, __float_as_uint(mf), dtag, (mf != mf) ? 1u : 0u};
-          if (lane < a.H) hg_off = kOneMaxHeads * (kOneMlHead + kOneNmHead) + (lane * kOneMaxHeads + h) * 16;
-        }
-        // (unconditional, like every publish of this kernel: a store inside the branch would turn the later in-order waits of ALL waves
-        //  into waits that count it; lanes that publish nothing aim past the buffer's end, where the hardware drops the write)
-        const auto hm_rsrc_p = __builtin_amdgcn_make_buffer_rsrc(a.one_ml, 0, (int)a.one_ml_bytes, 0x00020000);
-        __builtin_amdgcn_raw_buffer_store_b128(hg, hm_rsrc_p, hg_off, 0, kOneAuxCoherent);
       }
       key_pending = false;
       if constexpr (HYB) {  // ref: cache.py:896-950 _select_fill_idx, per head — operands requested at the top of the kernel (hy_*)
@@ -2343,7 +2292,118 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
   };
   // EML: the wave's (m, l) row goes to LDS; the LAST wave to arrive merges the workgroup's pairs and publishes them — behind the
   // scores of the wave's only tile (NT == 1: ahead of its P.V products), or behind the wave's last tile (NT > 1)
-  u32x4_t l2_hmq0 = {0u, 0u, 0u, 0u};  // L2C: round 0 of the gather of the kv heads' maxima (requested in ml_block, examined in the (m, l) round)
+  // L2C: the policy's per-slot pass, by the workgroup's last wave alone (see L2C above).  Results: the workgroup's minimum key (into
+  // l2c_wk, stored with the commit) and its two granules (stored by the caller, unconditionally).
+  unsigned long long l2c_wk = ~0ull;
+  u32x4_t l2c_g1 = {0u, 0u, 0u, 0u}, l2c_g2 = {0u, 0u, 0u, 0u};
+  auto l2c_pass = [&]() {
+    // ---- the norms of the new keys, four kv heads per pass (row group g: head 4 j + g), the inserting row group's arithmetic
+    //      operation for operation.  The transposition through LDS is spelled in assembly with its own waits: a plain LDS access
+    //      behind pending LDS-DMA loads gets a wait for THOSE from the compiler (it cannot tell these rows from the slabs the V rows
+    //      are still landing in).
+    auto norm16 = [&](const uint4& kn) -> unsigned {
+      unsigned eb[8];
+      const unsigned wa = (unsigned)(uintptr_t)(__attribute__((address_space(3))) T*)&sm_l2c4[g][0];
+      const u32x4_t kr = {kn.x, kn.y, kn.z, kn.w};
+      asm volatile(
+          "ds_write_b128 %8, %9\n\t"
+          "s_waitcnt lgkmcnt(0)\n\t"
+          "ds_read_u16 %0, %10\n\t"
+          "ds_read_u16 %1, %10 offset:32\n\t"
+          "ds_read_u16 %2, %10 offset:64\n\t"
+          "ds_read_u16 %3, %10 offset:96\n\t"
+          "ds_read_u16 %4, %10 offset:128\n\t"
+          "ds_read_u16 %5, %10 offset:160\n\t"
+          "ds_read_u16 %6, %10 offset:192\n\t"
+          "ds_read_u16 %7, %10 offset:224\n\t"
+          "s_waitcnt lgkmcnt(0)"
+          : "=&v"(eb[0]), "=&v"(eb[1]), "=&v"(eb[2]), "=&v"(eb[3]), "=&v"(eb[4]), "=&v"(eb[5]), "=&v"(eb[6]), "=&v"(eb[7])
+          : "v"(wa + (unsigned)c * 16u), "v"(kr), "v"(wa + (unsigned)c * 2u)
+          : "memory");
+      float ss = 0.f;
+#pragma unroll
+      for (int i = 0; i < D / 16; i++) {
+        T et;
+        et.x = (uint16_t)eb[i];
+        const float e = ElemTraits<T>::load(&et, 0);
+        ss = __fadd_rn(ss, __fmul_rn(e, e));
+      }
+#pragma unroll
+      for (int off = 8; off > 0; off >>= 1) ss = __fadd_rn(ss, __shfl_xor(ss, off, 16));
+      T nt;
+      ElemTraits<T>::store(&nt, 0, cc_sqrt_rn(ss));
+      return (unsigned)nt.x;  // (every lane of the row group)
+    };
+    if (key_pending) {  // a last wave without rows (ragged last split) never entered its tile: the insert slot, as tile_qk derives it
+#pragma unroll
+      for (int j = 0; j < 3; j++) key_part = key_more[j] < key_part ? key_more[j] : key_part;
+      const unsigned long long key = wave_min_u64_uniform(key_part);
+      ins_idx = (key == ~0ull) ? -1 : (int)((key & 0xffffffffull) >> 1);
+      ins_was_empty = (int)(key & 1ull);
+      if (rc_insp == one_pin) {  // a retry: the slot the first attempt's insert went to
+        ins_idx = rc_insw >> 1;
+        ins_was_empty = rc_insw & 1;
+      }
+      key_pending = false;
+    }
+    // the record of position p - 1 of kv head `lane` (bits 0-15: the head's maximum over the slots it keeps at p)
+    const unsigned rec16 = (unsigned)((((one_pin + 1) & 1) ? l2c_rc.y : l2c_rc.x) & 0xffffull);
+    unsigned gmax16 = 0u, nv_own = 0u;
+    const int npass = (a.H + 3) >> 2;
+    for (int j = 0; j < npass; j++) {  // (wave-uniform trip count; the first two passes' keys were prefetched)
+      const int hj = 4 * j + g;
+      uint4 kn = j == 0 ? l2c_kn[0] : l2c_kn[1];
+      if (j >= 2) kn = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(a.k_new) + (size_t)(hj < a.H ? hj : h) * D + c * VEC);
+      const unsigned nv = norm16(kn);
+      const unsigned rh = (unsigned)__shfl((int)rec16, hj < a.H ? hj : 0, CC_WAVE);
+      unsigned term = hj < a.H ? (nv > rh ? nv : rh) : 0u;  // max(record, new norm): patterns, unsigned order, NaN on top
+      gmax16 = term > gmax16 ? term : gmax16;
+      if (j == (h >> 2)) nv_own = (unsigned)__builtin_amdgcn_readlane((int)nv, (h & 3) << 4);  // this head's new norm (its row group's lanes all hold it)
+    }
+    gmax16 = (unsigned)wave_max_uniform((float)gmax16);  // (small integers: exact as floats)
+    T mt;
+    mt.x = (uint16_t)gmax16;
+    const float gm = ElemTraits<T>::load(&mt, 0);  // NaN propagates (torch.max)
+    T vt;
+    vt.x = (uint16_t)nv_own;
+    const float nv_own_f = ElemTraits<T>::load(&vt, 0);
+    // ---- the workgroup's slots: ref cache.py:597-605 dtype(max - norm), recent window -> +inf, base rules; and the two largest
+    //      norms AFTER this step's insert
+    const int32_t p_next = one_pin + 1;
+    unsigned long long kmin = ~0ull, k1 = 0ull;
+    unsigned t2 = 0u;
+#pragma unroll
+    for (int k = 0; k < L2S; k++) {
+      const int sl = row_begin + k * 64 + lane;
+      if (sl < row_end) {
+        const bool ins = sl == ins_idx;
+        const int32_t ps = ins ? one_pin : l2c_ps[k];
+        T et;
+        et.x = l2c_nr[k];
+        const float kn_eff = ins ? nv_own_f : ElemTraits<T>::load(&et, 0);
+        const unsigned kp = ins ? nv_own : (unsigned)l2c_nr[k];
+        float scn = ElemTraits<T>::rnd(gm - kn_eff);
+        if (ps >= p_next - a.w) scn = INFINITY;
+        if (sl < a.g) scn = INFINITY;
+        if (ps == -1) scn = -INFINITY;
+        const unsigned long long key = make_key(orderable_f32(scn), ((uint32_t)sl << 1) | (uint32_t)(ps == -1));
+        kmin = key < kmin ? key : kmin;
+        const unsigned long long nk64 = ((unsigned long long)kp << 32) | (unsigned)sl;
+        if (nk64 > k1) {
+          t2 = (unsigned)(k1 >> 32);
+          k1 = nk64;
+        } else if (kp > t2) {
+          t2 = kp;
+        }
+      }
+    }
+    l2c_wk = wave_min_u64_uniform(kmin);
+    const unsigned long long K1 = ~wave_min_u64_uniform(~k1);
+    const unsigned long long x2 = (k1 == K1) ? (unsigned long long)t2 : (k1 >> 32);
+    const unsigned T2w = (unsigned)~wave_min_u64_uniform(~x2);
+    l2c_g1 = u32x4_t{one_tag, (unsigned)(l2c_wk >> 32), one_tag, (unsigned)(l2c_wk & 0xffffffffull)};
+    l2c_g2 = u32x4_t{one_tag, (unsigned)(K1 >> 32) | (T2w << 16), one_tag, (unsigned)(K1 & 0xffffffffull)};
+  };
   auto ml_block = [&]() {
       l = xor_combine<32, false>(xor_combine<16, false>(l));  // the wave's l of head c, in every row group
       if (lane < RT) {                                          // row group 0, column c = head
@@ -2351,24 +2411,7 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
         sm_wl[wave][lane] = l;
       }
       if constexpr (L2C) {
-        // the wave's two largest norms (model-dtype patterns; with a slot that holds the largest) over the slots it holds AFTER this
-        // step's insert: what the head's record of this position is folded from (the NEXT step's business — nothing in this launch
-        // waits for it but the record's store in the tail)
-        unsigned kp = 0u;
-        if (one_have) {
-          T nt;
-          ElemTraits<T>::store(&nt, 0, l2_nv_lane);
-          kp = (one_slot == ins_idx) ? (unsigned)nt.x : (unsigned)one_kn_raw;
-        }
-        const unsigned long long k64 = one_have ? (((unsigned long long)kp << 32) | (unsigned)one_slot) : 0ull;
-        const unsigned long long K1 = ~wave_min_u64_uniform(~k64);
-        const unsigned long long x2 = (one_have && k64 == K1) ? 0ull : (unsigned long long)kp;
-        const unsigned T2 = (unsigned)~wave_min_u64_uniform(~x2);
-        if (lane == 0) {
-          sm_l2t[0][wave] = __uint_as_float((unsigned)(K1 >> 32));
-          sm_l2t[1][wave] = __uint_as_float((unsigned)(K1 & 0xffffffffull));
-          sm_l2t[2][wave] = __uint_as_float(T2);
-        }
+        // (nothing leaves with the pairs: the head's maximum comes from the record, see L2C)
       } else
       if constexpr (L2) {  // the wave's maximum over the norms its slots hold AFTER this step's insert (decided above)
         float kv = -INFINITY;
@@ -2419,44 +2462,7 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
         const auto ml_rsrc_e = __builtin_amdgcn_make_buffer_rsrc(a.one_ml, 0, (int)a.one_ml_bytes, 0x00020000);
         const int off = ml_last ? h * kOneMlHead + (split * RT + lane) * 16 : 0x7ffffff0;
         __builtin_amdgcn_raw_buffer_store_b128(mg, ml_rsrc_e, off, 0, XL2 ? 0 : kOneAuxCoherent);
-        if constexpr (L2C) {  // the workgroup's top-2 leaves with the pairs: one granule {tag, T1 | T2 << 16, tag, slot of T1}
-          unsigned g1 = 0u, g2 = 0u, gi = 0u;
-          if (arrived == (unsigned)(NW - 1) && lane == RT) {
-            float r1[NW], ri[NW], r2[NW];
-            if constexpr (DMA && (NW == 4 || NW == 8)) {  // (in assembly, like the norm maximum's row below: no wait for the V tile)
-              lds_read_row_nowait<NW>(sm_l2t[0], r1);
-              lds_read_row_nowait<NW>(sm_l2t[1], ri);
-              lds_read_row_nowait<NW>(sm_l2t[2], r2);
-            } else {
-#pragma unroll
-              for (int w = 0; w < NW; w++) {
-                r1[w] = sm_l2t[0][w];
-                ri[w] = sm_l2t[1][w];
-                r2[w] = sm_l2t[2][w];
-              }
-            }
-            // fold the waves' (T1, slot, T2) in order: the multiset's two largest, a holder of the largest
-#pragma unroll
-            for (int w = 0; w < NW; w++) {
-              const unsigned a1 = __float_as_uint(r1[w]), ai = __float_as_uint(ri[w]), a2 = __float_as_uint(r2[w]);
-              if (w == 0) {
-                g1 = a1; gi = ai; g2 = a2;
-              } else if (a1 > g1) {
-                g2 = g1 > a2 ? g1 : a2;
-                g1 = a1; gi = ai;
-              } else {
-                g2 = a1 > g2 ? a1 : g2;
-              }
-            }
-          }
-          const u32x4_t ng = {one_tag, g1 | (g2 << 16), one_tag, gi};
-          const int noff = (arrived == (unsigned)(NW - 1) && lane == RT) ? kOneMaxHeads * kOneMlHead + h * kOneNmHead + split * 16 : 0x7ffffff0;
-          __builtin_amdgcn_raw_buffer_store_b128(ng, ml_rsrc_e, noff, 0, XL2 ? 0 : kOneAuxCoherent);  // (gathered by the head's own split-0 workgroup)
-          // round 0 of the kv heads' maxima (through memory: ~1 us; the publishers stored them when THEIR first K rows had landed) goes
-          // out HERE, a streaming phase ahead of the (m, l) round that examines it.  Unconditional: every wave but the workgroup's last,
-          // and its lanes beyond the head count, aim past the buffer's end (no request, zeros back).
-          const int hoff = (wave == NW - 1 && lane < a.H) ? kOneMaxHeads * (kOneMlHead + kOneNmHead) + (h * kOneMaxHeads + lane) * 16 : 0x7ffffff0;
-          l2_hmq0 = __builtin_amdgcn_raw_buffer_load_b128(ml_rsrc_e, hoff, 0, kOneAuxCoherent);
+        if constexpr (L2C) {
         } else
         if constexpr (L2) {  // l2: the workgroup's norm maximum leaves with the pairs (same unconditional form; lane RT of the publisher)
           float wm = -INFINITY;
@@ -2512,6 +2518,15 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
     if (more) tile_qk(tregs[0], base, base, false, IntC<0>{});
     qstamp(8);
     ml_block();
+    if constexpr (L2C) {
+      // the policy's whole per-slot pass, by the workgroup's last wave, while its V rows land; its two granules leave HERE (stores
+      // unconditional: the other waves aim past the buffer's end, where the hardware drops the write)
+      if (wave == NW - 1) l2c_pass();
+      const auto nm_rsrc_e = __builtin_amdgcn_make_buffer_rsrc(a.one_ml, 0, (int)a.one_ml_bytes, 0x00020000);
+      const int goff = (wave == NW - 1 && lane == 0) ? kOneMaxHeads * kOneMlHead + h * kOneNmHead + split * 32 : 0x7ffffff0;
+      __builtin_amdgcn_raw_buffer_store_b128(l2c_g1, nm_rsrc_e, goff, 0, XL2 ? 0 : kOneAuxCoherent);
+      __builtin_amdgcn_raw_buffer_store_b128(l2c_g2, nm_rsrc_e, (wave == NW - 1 && lane == 0) ? goff + 16 : 0x7ffffff0, 0, XL2 ? 0 : kOneAuxCoherent);
+    }
     if (more) tile_pv(tregs[0], base, false);
     qstamp(9);
   } else {
@@ -2683,7 +2698,6 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
     u32x4_t nq[NLG > 0 ? NLG : 1];
     u32x4_t hmq = {0u, 0u, 0u, 0u};  // L2X: the kv heads' maxima (lane = kv head)
     const int hm_base = kOneMaxHeads * (kOneMlHead + kOneNmHead);
-    const int hmc_off = hm_base + (h * kOneMaxHeads + (lane < a.H ? lane : 0)) * 16;  // L2C: [dest = this head][src = lane]
     if constexpr (EML) {
       // the (m, l) pairs left behind the scores, long ago: their first round of loads goes out AHEAD of this workgroup's partial-O
       // stores (loads return in order: behind the stores they would also wait for the stores' acknowledgements, a round trip)
@@ -2691,7 +2705,6 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
 #pragma unroll
         for (int k = 0; k < MLN; k++) mlq[k] = __builtin_amdgcn_raw_buffer_load_b128(ml_rsrc, ml_off[k], 0, kGatherAux);
       }
-      if constexpr (L2C) hmq = l2_hmq0;  // the kv heads' maxima addressed to THIS head (lane = source head): round 0 left in ml_block
 
       // l2: every workgroup's norm maximum (they left with the pairs), gathered by every thread of every workgroup; a thread
       // without a granule aims past the buffer's end (no request, zeros back): no branch around the loads
@@ -2841,8 +2854,7 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
         for (int k = 0; k < NLG; k++) ok = ok && (!nm_use[k] || (nq[k][0] == nm_tag[k] && nq[k][2] == nm_tag[k]));
         return ok;
       };
-      auto ok_hmc = [&]() { return !L2C || wave != NW - 1 || lane >= a.H || (hmq[0] == tag && hmq[2] == tag); };
-      bool ml_ok = (!ml_mine || __all(ok_ml())) && (!L2 || __all(ok_nm())) && __all(ok_hmc());
+      bool ml_ok = (!ml_mine || __all(ok_ml())) && (!L2 || __all(ok_nm()));
       bool peer_failed = false;
       WaitBound ml_wb;
       for (unsigned spins = 0; !ml_ok; spins++) {
@@ -2863,22 +2875,14 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
 #pragma unroll
         for (int k = 0; k < NLG; k++)
           if (nm_use[k]) nq[k] = __builtin_amdgcn_raw_buffer_load_b128(ml_rsrc, nm_off[k], 0, kOneAuxCoherent);
-        if constexpr (L2C) {
-          if (wave == NW - 1) hmq = __builtin_amdgcn_raw_buffer_load_b128(ml_rsrc, hmc_off, 0, kOneAuxCoherent);
-        }
-        ml_ok = (!ml_mine || __all(ok_ml())) && (!L2 || __all(ok_nm())) && __all(ok_hmc());
+        ml_ok = (!ml_mine || __all(ok_ml())) && (!L2 || __all(ok_nm()));
       }
       if (timed_out) give_up();
       else if (peer_failed && lane == 0) sm_fail = 1u;
       if (a.trace) tr4 = __builtin_amdgcn_s_memtime();
       if (ml_mine) final_ml();
-      if constexpr (L2C) {  // the maximum over all kv heads (NaN propagates: torch.max), for the keys scored below
-        if (wave == NW - 1) {
-          const float v = lane < a.H ? __uint_as_float(hmq[1]) : -INFINITY;
-          const bool gn = __any(lane < a.H && (hmq[3] != 0u || v != v)) != 0;
-          const float gm = wave_max_uniform(v);
-          if (lane == 0) sm_gmax = gn ? NAN : gm;
-        }
+      if constexpr (L2C) {
+        // (the kv heads' terms sit in sm_l2m since the merge barrier: folded where the keys are scored, below)
       } else
       if constexpr (L2) {  // the wave's fold of the gathered norm maxima (NaN propagates: torch.max)
         float gm = -INFINITY;
@@ -3045,7 +3049,7 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
         if constexpr (L2) {  // ref: cache.py:597-605: dtype(max over ALL heads and slots - norm), recent window -> +inf, base rules
           float gm = -INFINITY;
           bool gn = false;
-          if constexpr (L2X || L2C) {
+          if constexpr (L2X) {
             gm = sm_gmax;
             gn = gm != gm;
           } else {
@@ -3102,8 +3106,8 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
         }
       }
     };
-    if constexpr (!L2X) {
-      if (!hrc_skip) all_tiles(all_tiles, IntC<0>{});  // (L2X: behind the partial-O gather — the heads' maxima arrive with it)
+    if constexpr (!L2X && !L2C) {
+      if (!hrc_skip) all_tiles(all_tiles, IntC<0>{});  // (L2X: behind the partial-O gather — the heads' maxima arrive with it; L2C: done long ago by one wave)
     }
     if constexpr (ALL) {
       // ---- the second half of the per-slot pass on all lanes: the slot_pass branches above, operation for operation (heavy hitter:
@@ -3215,7 +3219,8 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
     // one key per WAVE (a head's key row has room for NW per 64-slot workgroup): nothing crosses the waves after the last
     // barrier of the finish, so no wave's stores wait for another wave (the launch ends a store round trip after the LAST
     // store is issued: every store that can go out early shortens it)
-    unsigned long long wk = wave_min_u64_uniform(my_key);
+    // (L2C: the workgroup's minimum in its last wave's entry, ~0 in the others': the row's minimum is all a reader takes)
+    unsigned long long wk = L2C ? l2c_wk : wave_min_u64_uniform(my_key);
     auto store_key = [&]() {
       if (lane == 0) {
         unsigned long long* nk_row = const_cast<unsigned long long*>(a.next_key) + (size_t)h * a.nk;
@@ -3235,15 +3240,17 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
       if constexpr (L2X) {
         if (hm_mine) hmq = __builtin_amdgcn_raw_buffer_load_b128(ml_rsrc, hm_off, 0, kOneAuxCoherent);
       }
-      // L2C, tail: the workgroups' top-2 granules of this head (lane = split; they left with the (m, l) pairs, long ago), gathered by
-      // the last wave of the head's split-0 workgroup with the partial-O round — the record of this position is folded from them
+      // L2C, tail: the workgroups' two granules of this head (lane = split), gathered by the last wave of the head's split-0 workgroup
+      // with the partial-O round — the record of this position is resolved from them
       const bool rec_mine = L2C && split == 0 && wave == NW - 1;
-      const int rec_off = nm_base + h * kOneNmHead + (lane < ns ? lane : 0) * 16;
-      u32x4_t recq = {0u, 0u, 0u, 0u};
-      auto ok_rec = [&]() { return !rec_mine || lane >= ns || (recq[0] == tag && recq[2] == tag); };
-      if constexpr (L2C) {
-        if (rec_mine) recq = __builtin_amdgcn_raw_buffer_load_b128(ml_rsrc, rec_off, 0, kGatherAux);
-      }
+      const int rec_off = nm_base + h * kOneNmHead + (lane < ns ? lane : 0) * 32;
+      u32x4_t recq = {0u, 0u, 0u, 0u}, recq2 = {0u, 0u, 0u, 0u};
+      auto ok_rec = [&]() { return !rec_mine || lane >= ns || (recq[0] == tag && recq[2] == tag && recq2[0] == tag && recq2[2] == tag); };
+      auto load_rec = [&]() {
+        recq = __builtin_amdgcn_raw_buffer_load_b128(ml_rsrc, rec_mine ? rec_off : 0x7ffffff0, 0, kGatherAux);
+        recq2 = __builtin_amdgcn_raw_buffer_load_b128(ml_rsrc, rec_mine ? rec_off + 16 : 0x7ffffff0, 0, kGatherAux);
+      };
+      if constexpr (L2C) load_rec();  // (unconditional: every other wave aims past the buffer's end — no request, zeros back)
       WaitBound o_wb;
       for (unsigned spins = 0;; spins++) {
         if (__all(ok_o()) && __all(ok_hm()) && __all(ok_rec())) break;
@@ -3258,21 +3265,25 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
         if constexpr (L2X) {
           if (hm_mine) hmq = __builtin_amdgcn_raw_buffer_load_b128(ml_rsrc, hm_off, 0, kOneAuxCoherent);
         }
-        if constexpr (L2C) {
-          if (rec_mine) recq = __builtin_amdgcn_raw_buffer_load_b128(ml_rsrc, rec_off, 0, kGatherAux);
-        }
+        if constexpr (L2C) load_rec();
       }
       unsigned long long rec_new = 0ull;  // L2C: the head's record of this position (wave-uniform; meaningful in rec_mine's wave)
       if constexpr (L2C) {
         if (rec_mine) {
-          const unsigned a1 = lane < ns ? (recq[1] & 0xffffu) : 0u, a2 = lane < ns ? (recq[1] >> 16) : 0u, ai = lane < ns ? recq[3] : 0u;
+          // the slot position p + 2 will evict: the arg-min of the keys this step scored (the minimum over the workgroups' minima)
+          const unsigned long long kq = lane < ns ? (((unsigned long long)recq[1] << 32) | recq[3]) : ~0ull;
+          const unsigned long long kmin = wave_min_u64_uniform(kq);
+          const int e_next = (kmin == ~0ull) ? -1 : (int)((kmin & 0xffffffffull) >> 1);
+          // the head's two largest norms, a holder of the largest — and the head's maximum over the slots it keeps
+          const unsigned a1 = lane < ns ? (recq2[1] & 0xffffu) : 0u, a2 = lane < ns ? (recq2[1] >> 16) : 0u, ai = lane < ns ? recq2[3] : 0u;
           const unsigned long long k64 = ((unsigned long long)a1 << 32) | ai;
           const unsigned long long K1 = ~wave_min_u64_uniform(~k64);
           const unsigned long long win = __ballot(k64 == K1);                         // (slots are distinct across workgroups; lanes
           const int wl = (int)__builtin_ctzll(win ? win : 1ull);                      //  without one tie at 0 only when every norm is +0)
           const unsigned long long x2 = (lane == wl) ? (unsigned long long)a2 : (unsigned long long)a1;
-          const unsigned T2 = (unsigned)~wave_min_u64_uniform(~x2);
-          rec_new = cc_l2_record((unsigned)(K1 >> 32), T2, (unsigned)(K1 & 0xffffffffull));
+          const unsigned T2h = (unsigned)~wave_min_u64_uniform(~x2);
+          const unsigned T1h = (unsigned)(K1 >> 32), i1h = (unsigned)(K1 & 0xffffffffull);
+          rec_new = cc_l2_record((e_next >= 0 && i1h == (unsigned)e_next) ? T2h : T1h, T1h, i1h);
         }
       }
       if (a.trace) trE = __builtin_amdgcn_s_memtime();

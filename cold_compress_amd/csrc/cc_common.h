@@ -163,15 +163,16 @@ constexpr int kNextKeyPerChunk = 8;
 constexpr int kNextKeyTail = 8;
 static inline int cc_next_key_live(int S) { return kNextKeyPerChunk * ((S + kNextKeyChunk - 1) / kNextKeyChunk); }
 static inline int cc_next_key_slots(int S) { return cc_next_key_live(S) + kNextKeyTail; }  // the row stride
-// The l2 policy's carried norm record of kv head h, written by the step of position p into row entry [live + (p & 1)]: the two
-// largest norms of the head AFTER p's insert (T1 >= T2, as multiset: two slots holding the maximum give T1 == T2) and a slot i1
-// that holds T1 — model-dtype bit patterns (norms are >= +0 or NaN: unsigned order == numeric order, NaN above everything, which
-// is torch.max's propagation).  The step of p + 1 evicts ONE slot e of the head: the head's maximum over the slots it keeps is
-// (i1 == e ? T2 : T1), and with the inserted norm that is the head's term of cache.py:602's maximum — no reduction over the head.
+// The l2 policy's carried norm record of kv head h, written by the step of position p into row entry [live + (p & 1)].  Bits 0-15:
+// the head's largest norm over the slots it KEEPS at position p + 1 — every slot AFTER p's insert but the one p + 1 evicts, which is
+// the arg-min of the keys the step of p scores — as a model-dtype bit pattern (norms are >= +0 or NaN: unsigned order == numeric
+// order, NaN above everything, which is torch.max's propagation).  With the norm of p + 1's new key that is the head's term of
+// cache.py:602's maximum at p + 1: no reduction over the head and no exchange between heads inside p + 1's launch.  Bits 16-31 / 32-63:
+// the head's largest norm over ALL slots and a slot that holds it (not consumed: for inspection and the tests).
 int cc_l2_record_launch(const void* key_norm, int H, int S, int dtype, const int32_t* input_pos, int delta, unsigned long long* next_key,
                         hipStream_t st);  // cc_evict.hip: the record of position *input_pos + delta from the norms as they stand
-__host__ __device__ static inline unsigned long long cc_l2_record(unsigned t1, unsigned t2, unsigned i1) {
-  return (unsigned long long)(t1 & 0xffffu) | ((unsigned long long)(t2 & 0xffffu) << 16) | ((unsigned long long)i1 << 32);
+__host__ __device__ static inline unsigned long long cc_l2_record(unsigned kept_max, unsigned all_max, unsigned all_max_slot) {
+  return (unsigned long long)(kept_max & 0xffffu) | ((unsigned long long)(all_max & 0xffffu) << 16) | ((unsigned long long)all_max_slot << 32);
 }
 
 __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {

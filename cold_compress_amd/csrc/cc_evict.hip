@@ -123,30 +123,33 @@ __global__ __launch_bounds__(kUpdThreads) void l2_norm_max_kernel(const void* ke
   if (threadIdx.x == 0) *out = m;
 }
 
-// The l2 step's carried norm record (cc_common.h, cc_l2_record) of every kv head from the norms as they stand — what the seed of the
-// pipeline and the two-launch step leave for the next single-launch step.  One workgroup per kv head; 16-bit norms, read as patterns.
+// The l2 step's carried norm record (cc_common.h, cc_l2_record) of every kv head from the norms and the key row as they stand — what
+// the seed of the pipeline and the two-launch step leave for the next single-launch step: the head's largest norm over the slots it
+// KEEPS at the next position, i.e. all but the arg-min of the keys just scored (the row's live entries).  One workgroup per kv head;
+// 16-bit norms, read as patterns (norms are >= +0 or NaN: unsigned order == numeric order, NaN on top — torch.max's propagation).
 __global__ __launch_bounds__(kUpdThreads) void l2_record_kernel(const uint16_t* key_norm, int S, const int32_t* input_pos, int delta,
                                                                 unsigned long long* next_key, int nk) {
   __shared__ unsigned long long sm_key[kUpdThreads / 64 + 2];
   const int h = blockIdx.x;
+  const unsigned long long* row = next_key + (size_t)h * nk;
+  unsigned long long kb = ~0ull;
+  for (int i = threadIdx.x; i < nk - kNextKeyTail; i += kUpdThreads) kb = row[i] < kb ? row[i] : kb;
+  const unsigned long long kmin = block_min_u64(kb, sm_key);
+  const int e_next = (kmin == ~0ull) ? -1 : (int)((kmin & 0xffffffffull) >> 1);
+  __syncthreads();  // (sm_key is reused)
   const uint16_t* kn = key_norm + (size_t)h * S;
-  unsigned long long k1 = 0;  // (pattern << 32 | slot) of this thread's largest norm; t2: the pattern of its second largest
-  unsigned t2 = 0;
+  unsigned long long k1 = 0;  // (pattern << 32 | slot) of this thread's largest norm among the kept slots
+  unsigned long long ka = 0;  // ... among all slots (kept for inspection: the record's upper fields)
   for (int s = threadIdx.x; s < S; s += kUpdThreads) {
     const unsigned long long key = ((unsigned long long)kn[s] << 32) | (unsigned)s;
-    if (key > k1) {
-      t2 = (unsigned)(k1 >> 32);
-      k1 = key;
-    } else if ((unsigned)(key >> 32) > t2) {
-      t2 = (unsigned)(key >> 32);
-    }
+    ka = key > ka ? key : ka;
+    if (s != e_next) k1 = key > k1 ? key : k1;
   }
   const unsigned long long K1 = ~block_min_u64(~k1, sm_key);
-  __syncthreads();  // (sm_key is reused)
-  const unsigned long long x = (k1 == K1) ? (unsigned long long)t2 : (k1 >> 32);
-  const unsigned long long T2 = ~block_min_u64(~x, sm_key);
+  __syncthreads();
+  const unsigned long long KA = ~block_min_u64(~ka, sm_key);
   if (threadIdx.x == 0)
-    next_key[(size_t)h * nk + (nk - kNextKeyTail) + ((*input_pos + delta) & 1)] = cc_l2_record((unsigned)(K1 >> 32), (unsigned)T2, (unsigned)(K1 & 0xffffffffull));
+    next_key[(size_t)h * nk + (nk - kNextKeyTail) + ((*input_pos + delta) & 1)] = cc_l2_record((unsigned)(K1 >> 32), (unsigned)(KA >> 32), (unsigned)(KA & 0xffffffffull));
 }
 
 template <int POLICY, typename T, typename ST>

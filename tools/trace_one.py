@@ -30,6 +30,10 @@ def main():
     ap.add_argument("--policy", default=None, choices=["l2", "recent_global", "random", "full"],
                     help="another policy's step through its class (the state of tools/bench_policies.py)")
     ap.add_argument("--wide", type=int, default=1, help="cc_decode_step_set_wide")
+    ap.add_argument("--advance", action="store_true",
+                    help="the position moves on behind every replay of the graph (r6): without it the recoverable steps find their position "
+                         "committed after the first replay and only REPLAY it — no insert, no state stores — and the traced launch is lighter "
+                         "than a real step")
     a = ap.parse_args()
     _abi.lib()["cc_decode_step_set_wide"](a.wide)
     _abi.probe_device()  # (r5: loading the library no longer probes the dispatch order: without this the tool measures the memory hand-off)
@@ -111,6 +115,8 @@ def main():
             with torch.cuda.graph(g):
                 for i in range(n_buf):
                     fstep(i, ph)
+                if a.advance:
+                    pos.add_(1)
             fns["cc_decode_step_trace"](None)
             for _ in range(3):
                 g.replay()
