@@ -79,6 +79,17 @@
                         // key row's tail: cc_common.h, cc_l2_record) — no reduction over the head's norms and NO cross-head hand-off inside
                         // the launch; see L2C in the kernel.  0 = the r4 / r5 exchange (one level through memory, or two with XL2).
 #endif
+#ifndef CC_V_FLATLOADS
+#define CC_V_FLATLOADS 0  // r6: in the LDS-DMA steps every small load between the key row and the V rows (mask word, per-slot state, q) is issued
+                          // by ALL lanes, unconditionally (lanes without a row / slot / head aim at a valid dummy or past a buffer's end):
+                          // behind exec-mask branches the compiler's wait-count pass could not count them, its wait for the KEY ROW became
+                          // vmcnt(8) — a wait for the K tile — and the key row's reduction, the insert decision and the commit words
+                          // (~100 instructions) ran on every wave's critical path BEHIND the K rows instead of in the two microseconds the
+                          // wave waits for them (found in the ISA while measuring the l2 cuts).  MEASURED A LOSS (same box, three rounds:
+                          // C3 8.38 -> 8.51, C2 7.53 -> 7.84, C5's rank 7.68 -> 7.87, recent_global 8.05 -> 8.23): the wait becomes exact
+                          // (vmcnt(16)) and the reduction does move up — and the V rows, no longer held back by five branches, leave
+                          // earlier and compete with the K rows, the order r4 measured at +0.1..0.4 us.  0 = the r5 form (the product).
+#endif
 #ifndef CC_V_MLW
 #define CC_V_MLW 1      // the final (M, L) fold runs on the workgroup's LAST waves (idle during the partial-O publish of the first ones)
 #endif
@@ -1222,6 +1233,12 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
       issue_k_rows(R, base);
       __builtin_amdgcn_sched_barrier(0);
     }
+    if constexpr (DMA && CC_V_FLATLOADS != 0) {
+      // one aligned word per lane, no branch: a lane whose four rows are not one aligned word inside the cache (a ragged end, an odd
+      // base) reads the first word of the K cache instead and takes the bytes one by one where the word is consumed (mword_fixup)
+      const bool okw = has_mask && row0 + 3 < S && ((reinterpret_cast<uintptr_t>(mh) + (size_t)row0) & 3) == 0;
+      R.mword = *reinterpret_cast<const uint32_t*>(okw ? mh + row0 : reinterpret_cast<const uint8_t*>(a.k));
+    } else {
     R.mword = 0x01010101u;
     if (has_mask) {
       if (row0 + 3 < S && ((reinterpret_cast<uintptr_t>(mh) + (size_t)row0) & 3) == 0) {
@@ -1232,6 +1249,7 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
         for (int u = 0; u < U; u++)
           if (row0 + u < S) R.mword |= (uint32_t)mh[row0 + u] << (8 * u);
       }
+    }
     }
     if constexpr (!KFIRST && !DMA) issue_k_rows(R, base);
   };
@@ -1535,6 +1553,13 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
 #pragma unroll
     for (int ti = 0; ti < SN; ti++) {
       const int sl = ALL ? all_slot(ti) : one_slot + ti * (NW * RPW * U);
+      if constexpr (DMA && CC_V_FLATLOADS != 0) {  // every lane, no branch: a lane without a slot reads the split's first (valid, ignored)
+        const int slc = (one_lane && sl < row_end) ? sl : row_begin;
+        one_numv[ti] = nump[((size_t)h * S + slc) * hist];
+        one_denv[ti] = denp[((size_t)h * S + slc) * hist];
+        one_psv[ti] = a.pos[(a.Hp == 1 ? 0 : (size_t)h * S) + slc];
+        if (a.policy == 3 && a.rand_next) one_rndv[ti] = a.rand_next[slc];
+      } else
       if (ALL ? all_valid(ti) : (one_lane && sl < row_end)) {
         one_numv[ti] = nump[((size_t)h * S + sl) * hist];
         one_denv[ti] = denp[((size_t)h * S + sl) * hist];
@@ -1639,7 +1664,7 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
   int32_t p_ins = 0;
   qb_kn.raw = make_uint4(0, 0, 0, 0);
   qb_vn.raw = make_uint4(0, 0, 0, 0);
-  if (AHEAD && a.k_new) {
+  if (AHEAD && ((DMA && CC_V_FLATLOADS != 0) || a.k_new)) {  // (the single-launch steps always carry the new rows: no branch around the loads)
     qb_kn.load(reinterpret_cast<const T*>(a.k_new) + (size_t)h * D + c * VEC);
     qb_vn.load(reinterpret_cast<const T*>(a.v_new) + (size_t)h * D + c * VEC);
     p_ins = *a.input_pos;
@@ -1669,6 +1694,11 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
   for (int j = 0; j < 4; j++) {
     qB[j].raw = make_uint4(0, 0, 0, 0);
     if constexpr (!QKV) {
+      if constexpr (DMA && CC_V_FLATLOADS != 0) {  // every lane, no branch: columns n >= RT aim past the buffer's end (no request, zeros back)
+        const auto q_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.q), 0, (q0 + RT) * D * (int)sizeof(T), 0x00020000);
+        const u32x4_t qv = __builtin_amdgcn_raw_buffer_load_b128(q_rsrc, c < RT ? ((q0 + c) * D + (4 * j + g) * VEC) * (int)sizeof(T) : 0x7ffffff0, 0, 0);
+        qB[j].raw = make_uint4(qv[0], qv[1], qv[2], qv[3]);
+      } else
       if (c < RT) qB[j].load(reinterpret_cast<const T*>(a.q) + (size_t)(q0 + c) * D + (4 * j + g) * VEC);
     }
   }
@@ -2063,6 +2093,18 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
             }
           }
         }
+      }
+    }
+    if constexpr (DMA && CC_V_FLATLOADS != 0) {  // mword_fixup: see issue_k
+      const bool okw = has_mask && row0 + 3 < S && ((reinterpret_cast<uintptr_t>(mh) + (size_t)row0) & 3) == 0;
+      if (!has_mask) {
+        R.mword = 0x01010101u;
+      } else if (__any(!okw)) {  // (wave-uniform; rare: the cache's ragged end or an unaligned mask)
+        uint32_t mw = 0;
+#pragma unroll
+        for (int u = 0; u < U; u++)
+          if (!okw && row0 + u < S) mw |= (uint32_t)mh[row0 + u] << (8 * u);
+        if (!okw) R.mword = mw;
       }
     }
     // fused insert (cache.py:356-362, 460-490, 754-763) — see the VALU kernel; the K chunk follows the swizzle
