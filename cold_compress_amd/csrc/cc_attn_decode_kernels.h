@@ -90,6 +90,10 @@
                           // (vmcnt(16)) and the reduction does move up — and the V rows, no longer held back by five branches, leave
                           // earlier and compete with the K rows, the order r4 measured at +0.1..0.4 us.  0 = the r5 form (the product).
 #endif
+#ifndef CC_V_VDELAY
+#define CC_V_VDELAY 0   // r6 A/B: s_sleep CC_V_VDELAY (x 64 cycles) in front of the V rows' request in the LDS-DMA steps — the opposite of
+                        // CC_V_VEARLY / CC_V_FLATLOADS, which both lost by letting the V rows compete with the K rows earlier
+#endif
 #ifndef CC_V_MLW
 #define CC_V_MLW 1      // the final (M, L) fold runs on the workgroup's LAST waves (idle during the partial-O publish of the first ones)
 #endif
@@ -1739,6 +1743,7 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
   for (int sub = 0; sub < NSUB; sub++) {
     if constexpr (!KEARLY) issue_k(tregs[sub], base + sub * NW * RPW * U);
     if constexpr (QB) __builtin_amdgcn_sched_barrier(0);  // K's bytes and parameters go out BEFORE V's: the K stash waits for them only
+    if constexpr (DMA && CC_V_VDELAY != 0) __builtin_amdgcn_s_sleep(CC_V_VDELAY);
     if constexpr (!QKV && !VEARLY) issue_v(tregs[sub], base + sub * NW * RPW * U);
     if constexpr (QB) __builtin_amdgcn_sched_barrier(0);
   }
