@@ -12,9 +12,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python bench.
 T=$(ls $O/prof/*/*kernel_trace.csv | head -1)
 python tools/summarize_prof.py $T > $O/decode_kernel_summary.txt
 cp $(ls $O/prof/*/*kernel_stats.csv | head -1) $O/bench_kernel_stats.csv
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- python bench.py --steps 4 --warmup 2 --no_cpu_baseline --no_long_window > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- python bench.py --steps 4 --warmup 2 --no_cpu_baseline --no_long_window > /dev/null 2>&1
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $O/sq -- python bench.py --steps 4 --warmup 2 --no_cpu_baseline --graph --no_long_window > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- python bench.py --steps 4 --warmup 2 --settle 0 --no_cpu_baseline --no_long_window > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- python bench.py --steps 4 --warmup 2 --settle 0 --no_cpu_baseline --no_long_window > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $O/sq -- python bench.py --steps 4 --warmup 2 --settle 0 --no_cpu_baseline --graph --no_long_window > /dev/null 2>&1
 F=$(ls $O/fetch/*/*counter_collection.csv | head -1); W=$(ls $O/write/*/*counter_collection.csv | head -1)
 python tools/pmc_traffic.py $F $W > $O/pmc_traffic.json
 python tools/pmc_sq.py $(ls $O/sq/*/*counter_collection.csv | head -1) > $O/pmc_sq_counters.json
