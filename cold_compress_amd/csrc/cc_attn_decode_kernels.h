@@ -90,6 +90,13 @@
                           // (vmcnt(16)) and the reduction does move up — and the V rows, no longer held back by five branches, leave
                           // earlier and compete with the K rows, the order r4 measured at +0.1..0.4 us.  0 = the r5 form (the product).
 #endif
+#ifndef CC_V_WFACT
+#define CC_V_WFACT 0    // r6: the early-(m, l) steps keep the waves' merge factors exp(m_w - M) — computed once per (wave, head) by the lane that
+                        // merges the workgroup's (m, l) pair, between the scores and the P.V products — in LDS; the partial-O publish behind
+                        // the merge barrier reads them instead of recomputing NW maxima, subtractions and exponentials per thread (~50 of its
+                        // ~110 instructions, on every workgroup's path between the merge barrier and its partial O).  Same function, same
+                        // operands: the same bits.  0 = recompute (r5)
+#endif
 #ifndef CC_V_VDELAY
 #define CC_V_VDELAY 0   // r6 A/B: s_sleep CC_V_VDELAY (x 64 cycles) in front of the V rows' request in the LDS-DMA steps — the opposite of
                         // CC_V_VEARLY / CC_V_FLATLOADS, which both lost by letting the V rows compete with the K rows earlier
@@ -975,6 +982,7 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
   __shared__ __attribute__((aligned(16))) uint4 sm_k[NW][16][16];  // [wave][tile row i][slot]: 4 KiB per wave
   __shared__ __attribute__((aligned(16))) uint4 sm_v[NW][16][16];  // [wave][tile row][chunk ^ 2*(row & 7)]: V tile, row major
   __shared__ float sm_wm[NW][RT], sm_wl[NW][RT];  // the waves' softmax state per query head (merged across the workgroup)
+  __shared__ float sm_wf[NW][RT];                 // EML: the waves' merge factors exp(m_w - M) per query head (CC_V_WFACT)
   __shared__ unsigned sm_mlcnt;                    // EML: waves whose (m, l) rows are in LDS — the LAST one to arrive publishes
   __shared__ unsigned sm_fail;                     // EML: some wave of this workgroup gave up waiting (recoverable hand-off)
   __shared__ __attribute__((aligned(16))) float sm_l2w[NW];  // ONE + L2: per-wave maxima of the norms this workgroup's slots hold AFTER the step's insert
@@ -2496,7 +2504,11 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
         const float Mu = (M == -INFINITY) ? 0.f : M;
         float L = 0.f;
 #pragma unroll
-        for (int w = 0; w < NW; w++) L = fmaf(sm_wl[w][r], fast_exp(sm_wm[w][r] - Mu), L);
+        for (int w = 0; w < NW; w++) {
+          const float f = fast_exp(sm_wm[w][r] - Mu);
+          if constexpr (CC_V_WFACT != 0) sm_wf[w][r] = f;  // (read by the partial-O publish, behind the merge barrier)
+          L = fmaf(sm_wl[w][r], f, L);
+        }
         ml_M = M;
         ml_L = L;
       }
@@ -2764,17 +2776,26 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
     for (int o2 = (int)threadIdx.x * 2; o2 < RT * D; o2 += 2 * NW * 64) {
       {
         const int r = o2 / D, d = o2 - r * D;
-        float M = sm_wm[0][r];
+        float M = 0.f, L = 0.f, O0 = 0.f, O1 = 0.f;
+        if constexpr (EML && CC_V_WFACT != 0) {
+#pragma unroll
+          for (int w = 0; w < NW; w++) {  // fixed order: deterministic (the factors: ml_block, the (m, l) merge)
+            const float f = sm_wf[w][r];
+            O0 = fmaf(sm_wacc(w, r, d), f, O0);
+            O1 = fmaf(sm_wacc(w, r, d + 1), f, O1);
+          }
+        } else {
+        M = sm_wm[0][r];
 #pragma unroll
         for (int w = 1; w < NW; w++) M = fmaxf(M, sm_wm[w][r]);
         const float Mu = (M == -INFINITY) ? 0.f : M;
-        float L = 0.f, O0 = 0.f, O1 = 0.f;
 #pragma unroll
         for (int w = 0; w < NW; w++) {  // fixed order: deterministic
           const float f = fast_exp(sm_wm[w][r] - Mu);
           L = fmaf(sm_wl[w][r], f, L);
           O0 = fmaf(sm_wacc(w, r, d), f, O0);
           O1 = fmaf(sm_wacc(w, r, d + 1), f, O1);
+        }
         }
         const u32x4_t og = {tag, __float_as_uint(O0), tag, __float_as_uint(O1)};
         __builtin_amdgcn_raw_buffer_store_b128(og, o_rsrc, h * kOneOHead + ((r * ns + split) * 64 + (d >> 1)) * 16, 0, kPublishAux);
