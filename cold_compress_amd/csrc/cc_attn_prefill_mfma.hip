@@ -22,6 +22,13 @@
 
 #include "cc_common.h"
 
+#ifndef CC_PF_WPE_PV
+#define CC_PF_WPE_PV 2     // waves per SIMD the compiler must leave room for (r6 A/B: 3 = 168 VGPRs)
+#endif
+#ifndef CC_PF_WPE_FLASH
+#define CC_PF_WPE_FLASH 2
+#endif
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -245,7 +252,7 @@ struct BoolC {
 };
 
 template <typename T, int NB>
-__global__ __launch_bounds__(256, 2) void prefill_pv_lds_kernel(MArgs a) {
+__global__ __launch_bounds__(256, CC_PF_WPE_PV) void prefill_pv_lds_kernel(MArgs a) {
   __shared__ __attribute__((aligned(16))) uint4 sm_kt[2][kTK][16];   // [buf][key][chunk ^ (key & 15)]
   __shared__ __attribute__((aligned(16))) uint4 sm_vt[2][kD][4];     // [buf][d][chunk ^ ((d >> 2) & 3)]  (V^T, permuted keys)
   __shared__ float sm_p[4][kTK][kTQ + 1];                            // per-wave probability tiles: [r][key][query]
@@ -478,7 +485,7 @@ constexpr float kLazy = 6.0f;  // in units of the scaled logits (natural log): e
 // normalises with — l_exact sums the UNROUNDED weights exp(x - m_ref) (softmax is shift-invariant: exp(x - m_ref) / l_exact is the
 // reference's fp32 softmax up to fp32 rounding, attention_utils.py:52), next to l_run, which sums what P.V multiplies.
 template <typename T, bool STATS = false>
-__global__ __launch_bounds__(256, 2) void prefill_flash_kernel(MArgs a) {
+__global__ __launch_bounds__(256, CC_PF_WPE_FLASH) void prefill_flash_kernel(MArgs a) {
   __shared__ __attribute__((aligned(16))) uint4 sm_kt[2][kTK][16];   // [buf][key][chunk ^ (key & 15)]
   __shared__ __attribute__((aligned(16))) uint4 sm_vt[2][kD][4];     // [buf][d][chunk ^ ((d >> 2) & 3)]  (V^T, permuted keys)
   __shared__ __attribute__((aligned(16))) float sm_row[4][kTQ];      // per wave: a factor per query row, re-read in the O layout
