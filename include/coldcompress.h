@@ -179,9 +179,11 @@ int cc_decode_attn_gqa_ring(const void* q, const void* k, const void* v, const u
  *   launch 2 (combine): y, group-averaged probabilities, history update, and the arg-min for position
  *     *input_pos + 1 evaluated on the freshly updated history: one partial minimum per 128-slot chunk
  *     -> next_key[h][chunk] (plain stores; no atomics, no reset pass).
- * next_key: uint64 [H, NK], NK = cc_hh_next_key_slots(S) (eight entries per 128-slot chunk: the combine pass fills the
- * first NK / 8 of a row and keeps the others at ~0; the single-launch step below publishes one key per WAVE of its 64-slot
- * workgroups, so that no wave waits for another at the end of the launch);
+ * next_key: uint64 [H, NK], NK = cc_hh_next_key_slots(S) = the row stride: eight LIVE entries per 128-slot chunk (the combine pass
+ * fills the first eighth of them and keeps the others at ~0; the single-launch step below publishes one key per WAVE of its
+ * 64-slot workgroups, so that no wave waits for another at the end of the launch) plus, r6, a TAIL of eight entries no arg-min
+ * ever reads — per-head state a policy's step hands to the next step of the same cache (l2: the head's carried norm record,
+ * written by cc_l2_next_key_init and every l2 step; the other policies leave it alone);
  * entry = (orderable(score) << 32) | slot << 1 | was_empty, ~0 = "no candidate".  Valid as long as positions advance by one and nothing else mutates pos / history in
  * between; re-seed with cc_hh_next_key_init otherwise.
  * Results are bit-identical to the three-call sequence (tests/test_gpu_fused_step.py).
