@@ -3256,7 +3256,9 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
             old_e.x = hy_old[k];
             const float old_v = ElemTraits<T>::load(&old_e, 0);
             T* shadow = reinterpret_cast<T*>(a.ring_acc + hs * 4 + 2) + (size_t)one_rcol * hs;
+#ifndef CC_HYB_NO_RING_STORE  // (A/B builds: the price of the reference-layout column — one 2-byte store per slot, W * 2 bytes apart)
             ElemTraits<T>::store(reinterpret_cast<T*>(a.ring_num), i * (size_t)a.ring_W + one_rcol, av);
+#endif
             ElemTraits<T>::store(shadow, i, av);
             dn = hy_den[k] + late_one;
             a.denom[i] = dn;
