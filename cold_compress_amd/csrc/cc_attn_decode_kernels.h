@@ -736,9 +736,9 @@ constexpr int kRcStride = 68;                  // step_commit: int32 per kv head
 constexpr int kOneMlHead = 64 * 8 * 16;        // (m, l): 64 splits x up to 8 query heads x 16 B
 constexpr int kOneOHead = 8 * 64 * 64 * 16;    // O: up to 8 query heads x 64 splits x 64 pairs x 16 B
 constexpr int kOneNmHead = 64 * 32;            // l2: one norm-maximum granule per split (r4 / r5 exchange), or two record granules per split (r6, L2C)
-constexpr int kOneHmBytes = 32 * 32 * 16;      // l2: norm-maximum granules per kv HEAD, behind the per-split regions.  Two-level exchange (r4): one per
-                                               // head, [src]; carried record (r6): [dest head][src head] at a row stride of kOneMaxHeads granules — the
-                                               // publisher of head `src` tags the granule of `dest` with DEST's epoch (see L2C in the kernel)
+constexpr int kOneHmBytes = 32 * 32 * 16;      // l2, two-level exchange (r4): one norm-maximum granule per kv HEAD, behind the per-split regions (the first
+                                               // 32 granules; the rest of the 16 KiB was the [dest head][src head] matrix of r6's first carried-record
+                                               // cut — in the history — and is unused now)
 constexpr int kOneMaxHeads = 32;
 constexpr int kOneQHead = (8 + 2) * 128 / 4 * 16;  // QKV: up to 8 query heads + k + v of 128 values, four 16-bit values per 8-byte granule half
 // the workspace's single-launch regions, at fixed offsets behind the 4 KiB header (cc_attn_decode.hip: kOneBytes)
@@ -987,7 +987,7 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
   __shared__ unsigned sm_fail;                     // EML: some wave of this workgroup gave up waiting (recoverable hand-off)
   __shared__ __attribute__((aligned(16))) float sm_l2w[NW];  // ONE + L2: per-wave maxima of the norms this workgroup's slots hold AFTER the step's insert
   __shared__ __attribute__((aligned(16))) T sm_l2sc[L2 ? NW : 1][L2 ? 128 : 8];  // l2: the new key, transposed for its norm (the slabs belong to the DMA loads)
-  __shared__ float sm_gmax;     // L2X / L2C: the norm maximum over all kv heads (NaN propagates)
+  __shared__ float sm_gmax;     // L2X: the norm maximum over all kv heads (NaN propagates)
   __shared__ __attribute__((aligned(16))) T sm_l2c4[L2C ? 4 : 1][L2C ? 128 : 8];  // L2C: four new keys, transposed for their norms (one per row group of the workgroup's last wave)
   // QKV: the projection's partial sums [K quarter][row of this workgroup's share], the RMSNorm partials, and the head's gathered
   // q (RT heads), k_new, v_new
