@@ -25,9 +25,4 @@ timeout 300 python tools/bench_prefill.py > $O/bench_prefill.jsonl 2>/dev/null
 timeout 300 python tools/sweep_step.py > $O/sweep_step.jsonl 2>/dev/null
 timeout 200 python tools/trace_one.py --S 4096 > $O/single_launch_trace_S4096.json 2>/dev/null
 timeout 200 python tools/trace_one.py --S 4096 --H 1 --HQ 4 > $O/single_launch_trace_S4096_H1.json 2>/dev/null
-# the last step-order A/B of the round: small requests first (ord), preload + late + early args (pre), the product (cur)
-L=cold_compress_amd/csrc/libcoldcompress_hip.so
-cp $L .ab/libcur.so
-for r in 1 2 3; do for v in cur pre ord; do [ -f .ab/lib$v.so ] || continue; cp .ab/lib$v.so $L; echo -n "$v "; timeout 200 python tools/ab_step.py heavy_hitter 8:32:4096 8:32:2560 1:8:3488 2>/dev/null || echo "FAILED/timeout"; done; done > $O/ab_order.txt 2>&1
-cp .ab/libcur.so $L
 cat $O/rc.txt; tail -3 $O/gputest.log; head -c 700 $O/bench.json
