@@ -86,6 +86,7 @@ SIGNATURES = {
     "cc_decode_step_trace": (None, [_vp]),
     "cc_decode_step_set_single_launch": (None, [_i32]),
     "cc_decode_step_set_wide": (None, [_i32]),
+    "cc_decode_step_l2_carry": (_i32, []),
     "cc_decode_step_probe_xcd": (_i32, []),
     "cc_decode_step_set_l2_handoff": (None, [_i32]),
     "cc_decode_step_l2_handoff": (_i32, []),
@@ -162,7 +163,7 @@ SIGNATURES = {
 
 # entry points that only the device library has (no `_cpu` twin)
 DEVICE_ONLY = {"cc_error_string", "cc_device_info", "cc_decode_step_single_launch", "cc_decode_step_status_offset", "cc_decode_step_wait_bound_us",
-               "cc_decode_step_trace", "cc_decode_step_set_single_launch", "cc_decode_step_set_wide", "cc_decode_step_probe_xcd", "cc_decode_step_commit_stride", "cc_decode_step_l2_rc", "cc_decode_step_quant_rc", "cc_decode_step_set_l2_handoff", "cc_decode_step_l2_handoff", "cc_decode_step_demote_l2_handoff", "cc_decode_step_stream_floor", "cc_decode_step_stream_floor_geom", "cc_debug_occupy", "cc_decode_step_quant_single_launch",
+               "cc_decode_step_trace", "cc_decode_step_set_single_launch", "cc_decode_step_set_wide", "cc_decode_step_l2_carry", "cc_decode_step_probe_xcd", "cc_decode_step_commit_stride", "cc_decode_step_l2_rc", "cc_decode_step_quant_rc", "cc_decode_step_set_l2_handoff", "cc_decode_step_l2_handoff", "cc_decode_step_demote_l2_handoff", "cc_decode_step_stream_floor", "cc_decode_step_stream_floor_geom", "cc_debug_occupy", "cc_decode_step_quant_single_launch",
                "cc_decode_step_hybrid_single_launch", "cc_decode_step_l2_single_launch", "cc_decode_step_single_launch_enabled", "cc_decode_step_device_single_launch",
                "cc_decode_step_qkv_available", "cc_debug_qkv_trace",
                "cc_kv_requant_batch",  # (its oracle is the per-cache twin of cc_kv_requant_pair)

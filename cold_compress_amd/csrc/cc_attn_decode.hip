@@ -896,6 +896,7 @@ int32_t cc_decode_step_device_single_launch(int32_t enabled) {
 }
 
 int32_t cc_decode_step_status_offset(void) { return kOneStatusWord * (int32_t)sizeof(unsigned); }
+int32_t cc_decode_step_l2_carry(void) { return CC_V_L2CARRY != 0 ? 1 : 0; }
 int32_t cc_decode_step_wait_bound_us(void) { return (int32_t)(kOneWaitTicks / 100ull); }  // (s_memrealtime: 100 ticks per microsecond)
 int32_t cc_decode_step_commit_stride(void) { return kRcStride; }
 

@@ -592,6 +592,23 @@ def test_l2_fused_step_equals_three_calls(dtype, H, HQ, S, D, T, g, w, single, s
                 assert torch.equal(ta, tb), f"step {t}: {na}"
 
 
+def _check_l2_record(kv, p):
+    """The l2 cache's carried norm record of position p (key row tail, entry [live + (p & 1)], bits 0-15; cc_common.h): the head's
+    largest norm over the slots it keeps at p + 1 — all but the arg-min of the key row's live entries — as a model-dtype pattern
+    (unsigned order; NaN on top)."""
+    nk = kv.next_key.cpu().numpy().view(np.uint64)
+    kn = kv.key_norm.cpu()[0].view(torch.int16).numpy().view(np.uint16).astype(np.uint32)  # [H, S] patterns
+    live = nk.shape[1] - 8
+    for h in range(nk.shape[0]):
+        kmin = int(nk[h, :live].min())
+        keep = np.ones(kn.shape[1], bool)
+        if kmin != 0xFFFFFFFFFFFFFFFF:
+            keep[(kmin & 0xFFFFFFFF) >> 1] = False
+        want = int(kn[h][keep].max()) if keep.any() else 0
+        got = int(nk[h, live + (p & 1)]) & 0xFFFF
+        assert got == want, f"position {p}, kv head {h}: record {got:#06x}, state {want:#06x}"
+
+
 @pytest.mark.parametrize("H,HQ,S,T", [(8, 32, 4096, 4093), (2, 8, 600, 600), (8, 32, 1024, 1000)])
 def test_l2_carried_norm_record_across_step_forms(H, HQ, S, T, single_launch_switch):
     """r6: the single-launch l2 step takes its head's norm maximum from the RECORD the previous step left in the key
@@ -620,6 +637,13 @@ def test_l2_carried_norm_record_across_step_forms(H, HQ, S, T, single_launch_swi
         kv.update_kv(torch.arange(T, device=DEV), k0, v0, True)
         kv.update_state(torch.arange(T, device=DEV), k0, v0, True, None)
     forms = [True, True, False, True, False, False, True, True, True, False, True, True]  # single launch?
+    # (the single-launch step writes the record only in CC_V_L2CARRY builds; the seed and the two-launch step always do)
+    from cold_compress_amd import _abi
+
+    l2_carry = bool(_abi.lib()["cc_decode_step_l2_carry"]())
+    b.prepare_decode(torch.tensor([T], dtype=torch.int32, device=DEV))  # seeds the pipeline: the record of position T - 1
+    torch.cuda.synchronize()
+    _check_l2_record(b, T - 1)
     n_steps = 40
     k_dup = None
     for t in range(n_steps):
@@ -652,6 +676,8 @@ def test_l2_carried_norm_record_across_step_forms(H, HQ, S, T, single_launch_swi
         torch.cuda.synchronize()
         if t < 30:  # (behind the NaN key the outputs of the head that holds it are NaN on both sides)
             _y_check(ya, yb, single, t)
+        if t != 22 and (not single or l2_carry):  # the step left the head's record for position T + t: check it against the state
+            _check_l2_record(b, T + t)
         for (na, ta), (nb, tb) in zip(a.named_buffers(), b.named_buffers()):
             if na not in ("next_key", "step_commit"):  # (pipeline bookkeeping of the fused step, not reference state)
                 assert torch.equal(ta.view(torch.int16) if ta.dtype == dtype else ta, tb.view(torch.int16) if tb.dtype == dtype else tb), f"step {t} ({'one' if single else 'two'} launch): {na}"
