@@ -1169,7 +1169,7 @@ static int attn_impl(const void* q, const void* k, const void* v, const uint8_t*
   CC_LAUNCH_CHECK();
   // l2: the norm record the NEXT step's single-launch form starts from (cc_common.h, cc_l2_record) — the single-launch step leaves
   // it itself; behind the two launches a third, small one does (this is the slow route already)
-  if (fs && fs->policy == 4 && fs->next_key)
+  if (CC_V_L2CARRY != 0 && fs && fs->policy == 4 && fs->next_key)  // (only the r6 A/B build's single-launch step reads it)
     return cc_l2_record_launch(sa.key_norm, H, S, dtype, fs->input_pos, 0, fs->next_key, st);
   return CC_OK;
 }

@@ -351,6 +351,7 @@ __global__ __launch_bounds__(256) void row_l2_norm_kernel(const T* x, int rows, 
 
 }  // namespace
 
+extern "C" int32_t cc_decode_step_l2_carry(void);  // cc_attn_decode.hip: CC_V_L2CARRY of this build
 // (shared with cc_attn_decode.hip: the two-launch l2 step leaves the record of ITS position the same way; declared in cc_common.h)
 int cc_l2_record_launch(const void* key_norm, int H, int S, int dtype, const int32_t* input_pos, int delta, unsigned long long* next_key,
                         hipStream_t st) {
@@ -451,6 +452,8 @@ int cc_l2_next_key_init(const cc_kv_view* c, const int32_t* input_pos, void* key
   const int rc = launch_update<P_L2>(c, a, (hipStream_t)stream);
   if (rc != CC_OK) return rc;
   // the norm record the first step (position *input_pos) takes its head's maximum from: the state behind position *input_pos - 1
+  // (only the r6 A/B build's single-launch step reads it: cc_decode_step_l2_carry())
+  if (!cc_decode_step_l2_carry()) return CC_OK;
   return cc_l2_record_launch(key_norm, c->H, c->S, c->dtype, input_pos, -1, reinterpret_cast<unsigned long long*>(next_key), (hipStream_t)stream);
 }
 

@@ -183,8 +183,7 @@ int cc_decode_attn_gqa_ring(const void* q, const void* k, const void* v, const u
  * fills the first eighth of them and keeps the others at ~0; the single-launch step below publishes one key per WAVE of its
  * 64-slot workgroups, so that no wave waits for another at the end of the launch) plus, r6, a TAIL of eight entries no arg-min
  * ever reads — per-head state a policy's step hands to the next step of the same cache (l2: the head's carried norm record,
- * written by cc_l2_next_key_init and the two-launch l2 step, and read and written by the single-launch l2 step of the r6 A/B
- * build only (-DCC_V_L2CARRY=1); the other policies leave it alone);
+ * written and read by the r6 A/B build only, -DCC_V_L2CARRY=1: nothing touches the tail in the product);
  * entry = (orderable(score) << 32) | slot << 1 | was_empty, ~0 = "no candidate".  Valid as long as positions advance by one and nothing else mutates pos / history in
  * between; re-seed with cc_hh_next_key_init otherwise.
  * Results are bit-identical to the three-call sequence (tests/test_gpu_fused_step.py).

@@ -30,8 +30,8 @@ int cc_debug_occupy(int32_t n_workgroups, int32_t lds_bytes, int32_t microsecond
  * together; flip it only where the fused pipeline is re-seeded (prepare_decode / cc_hh_next_key_init). */
 void cc_decode_step_set_wide(int32_t enabled);
 /* 1 if this build's single-launch l2 step takes its norm maximum from the record carried in the key rows' tail (the r6 A/B build,
- * -DCC_V_L2CARRY=1) and writes that record itself; 0 = the r4 / r5 exchange (the product).  The seed (cc_l2_next_key_init) and the
- * two-launch l2 step write the record either way (tests/test_gpu_fused_step.py checks it against the state). */
+ * -DCC_V_L2CARRY=1) and writes that record itself; 0 = the r4 / r5 exchange (the product).  In that build the seed
+ * (cc_l2_next_key_init) and the two-launch l2 step write the record too (tests/test_gpu_fused_step.py checks it against the state). */
 int32_t cc_decode_step_l2_carry(void);
 /* Process-wide off switch of the L2-resident hand-off (include/coldcompress.h, cc_decode_step_probe_xcd): 0 = always the memory
  * hand-off, on every device (A/B measurements; the harness's recovery path uses the per-device cc_decode_step_demote_l2_handoff
