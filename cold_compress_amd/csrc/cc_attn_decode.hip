@@ -491,6 +491,9 @@ static Plan make_plan_w(int HQ, int H, int S, int D, int dtype, bool wide_allowe
       wide_max = e ? atol(e) : 256;
     }
     if (tiles >= 1280 && (long)H * ((S + 127) / 128) <= wide_max) p.nw = 8;
+#if CC_V_NW16
+    if (p.nw == 8 && p.rt == 4 && tiles >= 2048 && g_wide_enabled.load(std::memory_order_relaxed) == 2) p.nw = 16;  // (A/B: see CC_V_NW16)
+#endif
   }
   const int rpi = rows_per_iter(D, dtype, p.nw);
   // ~512 workgroups (two per CU, all resident at once): one tile per workgroup up to S = 64 * 64 rows per kv
@@ -664,6 +667,9 @@ template <typename T>
 static OneKernel one_kernel(int rt, int nt, int kind, bool full, int nw = kNW) {
 #define CC_ONE_K(RT_, L2_, HYB_, QB_, NT_, FULL_) decode_attn_split_mfma_kernel<T, RT_, kNW, L2_, true, HYB_, QB_, 1, NT_, FULL_>
   if (nt < 1 || nt > kOneMaxTiles) return nullptr;
+#if CC_V_NW16
+  if (nw == 16) return (rt == 4 && nt == 1 && kind == 0 && !full) ? decode_attn_split_mfma_kernel<T, 4, 16, false, true, false, 0, 1, 1, false> : nullptr;
+#endif
   if (nw == 8) {  // ONE 8-wave workgroup per CU: 4 or 8 query heads per kv head, one tile per wave (make_plan)
 #define CC_ONE_W(RT_, L2_, QB_, FULL_) decode_attn_split_mfma_kernel<T, RT_, 8, L2_, true, false, QB_, 1, 1, FULL_>
 #define CC_ONE_WH(RT_, FULL_) decode_attn_split_mfma_kernel<T, RT_, 8, false, true, true, 0, 1, 1, FULL_>
@@ -743,6 +749,9 @@ template <typename T>
 static OneKernel one_kernel_xl2(int rt, int nt, int kind, bool full, int nw) {
 #define CC_ONE_X(RT_, NW_, L2_, QB_, FULL_) decode_attn_split_mfma_kernel<T, RT_, NW_, L2_, true, false, QB_, 1, 1, FULL_, true>
 #define CC_ONE_XM(RT_, HYB_, NT_) decode_attn_split_mfma_kernel<T, RT_, kNW, false, true, HYB_, 0, 1, NT_, false, true>
+#if CC_V_NW16
+  if (nw == 16) return (rt == 4 && nt == 1 && kind == 0 && !full) ? CC_ONE_X(4, 16, false, 0, false) : nullptr;
+#endif
   if ((rt != 4 && rt != 8) || (nw != 4 && nw != 8)) return nullptr;
   if (nt > 1 || kind == 200) {  // several tiles per wave (4-wave workgroups) and the hybrid cache's steps: lean instantiations only
     if (full || nt > kOneMaxTiles) return nullptr;
@@ -907,7 +916,7 @@ void cc_decode_step_set_single_launch(int32_t enabled) { g_one_enabled.store(ena
 // 8-wave workgroups (one per CU) for the plain 16-bit caches that have the tiles for them (make_plan); 0 = 4-wave workgroups
 // everywhere.  Process-wide; change it only between steps of a cache whose fused pipeline is re-seeded (prepare_decode): the
 // geometry decides which entries of a head's key row are live.
-void cc_decode_step_set_wide(int32_t enabled) { g_wide_enabled.store(enabled ? 1 : 0, std::memory_order_relaxed); }
+void cc_decode_step_set_wide(int32_t enabled) { g_wide_enabled.store(enabled == 2 && CC_V_NW16 != 0 ? 2 : (enabled ? 1 : 0), std::memory_order_relaxed); }
 
 // The L2-resident hand-off (XL2): on by default where cc_decode_step_probe_xcd verified the device; 0 = always the memory hand-off
 // (the fallback of a step that fails with it — a kernel captured into a hipGraph keeps the form it was captured with).
@@ -1131,6 +1140,7 @@ static int attn_impl(const void* q, const void* k, const void* v, const uint8_t*
       return CC_OK;
     }
   }
+  if (p.nw == 16) return CC_ERR_UNSUPPORTED;  // (the 16-wave A/B geometry has no two-launch form)
   if (phases & 1) {
     switch (dtype) {
       case CC_DT_F32: rc = launch_split<float>(sa, p, H, R, D, st); break;

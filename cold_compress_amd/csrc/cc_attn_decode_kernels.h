@@ -97,6 +97,11 @@
                         // ~110 instructions, on every workgroup's path between the merge barrier and its partial O).  Same function, same
                         // operands: the same bits.  0 = recompute (r5)
 #endif
+#ifndef CC_V_NW16
+#define CC_V_NW16 0     // r6 A/B: cc_decode_step_set_wide(2) plans ONE 16-wave workgroup per 256 rows (n_split 16 at S = 4096: half the partials of
+                        // the hand-off again — the move from 4 to 8 waves gained 0.4 us at C3 — on half the CUs); heavy hitter / head-constant
+                        // policies, 4 query heads per kv head, single launch only, timing experiments only (no two-launch twin of this geometry)
+#endif
 #ifndef CC_V_VDELAY
 #define CC_V_VDELAY 0   // r6 A/B: s_sleep CC_V_VDELAY (x 64 cycles) in front of the V rows' request in the LDS-DMA steps — the opposite of
                         // CC_V_VEARLY / CC_V_FLATLOADS, which both lost by letting the V rows compete with the K rows earlier
@@ -830,7 +835,7 @@ struct IntC {
 // tile's 16.8 MB stream in the shadow of the 50 MB of weights: one launch boundary, one prologue and one first-byte latency per
 // attention sub-block instead of two.  One workgroup per CU (the LDS decides that anyway): 256 registers per lane.
 template <typename T, int RT, int NW, bool L2, bool ONE = false, bool HYB = false, int QB = 0, int NSUB = 1, int NT = 1, bool FULL = !ONE, bool XL2 = false, bool QKV = false>
-__global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void decode_attn_split_mfma_kernel(CC_LEAD_PARAMS SplitArgs a_in) {
+__global__ __launch_bounds__(NW * 64, NW == 16 ? 4 : (QKV ? 1 : ((ONE || QB) ? 2 : 1))) void decode_attn_split_mfma_kernel(CC_LEAD_PARAMS SplitArgs a_in) {
   // FULL (measurement instantiation): the workgroup's first instruction, on both clocks — the phases of cc_decode_step_trace count
   // from HERE (late r4; they used to count from behind the issue of the first K rows, ~0.8 us later)
   unsigned long long tr_entry = 0, rt_entry = 0;
@@ -962,7 +967,8 @@ __global__ __launch_bounds__(NW * 64, QKV ? 1 : ((ONE || QB) ? 2 : 1)) void deco
   constexpr bool L2C = L2 && EML && CC_V_L2CARRY != 0;
   constexpr bool L2X = L2 && XL2 && EML && !L2C;
   static_assert(sizeof(T) == 2 && (RT == 1 || RT == 2 || RT == 4 || RT == 8), "16-bit caches, up to 8 query heads per pass (the MFMA has 16 columns)");
-  static_assert(!ONE || NW == 4 || (NW == 8 && NT == 1), "the single-launch step runs on 4-wave workgroups, or on ONE 8-wave workgroup per CU (single tile)");
+  static_assert(!ONE || NW == 4 || ((NW == 8 || (NW == 16 && !L2 && !HYB && QB == 0 && !QKV)) && NT == 1),
+                "the single-launch step runs on 4-wave workgroups, or on ONE 8-wave workgroup per CU (single tile); 16 waves: the r6 A/B build (CC_V_NW16)");
   constexpr int D = 128, VEC = 8, RPW = 4, U = 4;
   static_assert(!QKV || (ONE && NT == 1 && !HYB && QB == 0 && !L2 && !FULL && (NW == 4 || NW == 8) && CC_V_LDSDMA != 0 && CC_V_WORDSFIRST != 0),
                 "the fused projection rides the lean single-tile step of the plain 16-bit caches");
